@@ -1,0 +1,548 @@
+//
+// ref_harness.cpp -- drives the *reference's own code* (compiled from /root/reference where it lies)
+// to produce golden fixtures and reference CPU timings.
+//
+// TEST INFRASTRUCTURE ONLY.  Built by oracle/Makefile into oracle/_ref/ref_harness (git-ignored).
+// Nothing in the product path links, imports or executes this file or its binary.
+// No reference source is copied here: the reference headers are #included from /root/reference
+// and only their public functions are called.  The two app-level helpers the reference keeps in
+// synthetic-hand-tracker/synthetic-tracker.cpp (an animation-bank reader and the software depth
+// rasteriser, :39-55 and :69-76) are not reachable through a header, so this file has its own
+// small equivalents built on the reference's PhysModel::HitCheck / DCamera API.
+//
+// The reference hard-codes "../assets/model_hand.json" etc. (handtrack.h:349,831-832).  The two
+// small JSON assets are embedded into this binary at build time (.incbin from /root/reference) and
+// written to a temporary directory at start-up, so the binary also runs on the GPU box where
+// /root/reference does not exist.
+//
+// Modes:
+//   model  <out.htfx>                              baked 17-bone model (what PhysModel/LoadHandModel build)
+//   scan   <animbank.pose> <stride>                workload statistics per animation row
+//   frames <animbank.pose> <first> <stride> <n> <out.htfx>    64x64 frames + cameras + start poses
+//   golden <animbank.pose> <rows,comma> <seed> <fc2gain> <out.htfx>   per-stage goldens
+//   bench  <frames.htfx> <seed> <fc2gain> <reps>   reference CPU time for the unit of work
+//
+#include "/root/reference/include/handtrack.h"
+#include <sys/stat.h>
+#include <unistd.h>
+#include <chrono>
+#include "htfx.h"
+
+// ---- embedded assets (build artefact only; see oracle/Makefile) -------------------------------
+__asm__(
+	".section .rodata\n"
+	".global ht_asset_model\n ht_asset_model:\n .incbin \"/root/reference/assets/model_hand.json\"\n"
+	".global ht_asset_model_end\n ht_asset_model_end:\n .byte 0\n"
+	".global ht_asset_vanity\n ht_asset_vanity:\n .incbin \"/root/reference/assets/vanity_bones.json\"\n"
+	".global ht_asset_vanity_end\n ht_asset_vanity_end:\n .byte 0\n"
+	".text\n");
+extern "C" const char ht_asset_model[], ht_asset_model_end[], ht_asset_vanity[], ht_asset_vanity_end[];
+
+static void stage_assets()
+{
+	char tmpl[] = "/tmp/htref_XXXXXX";
+	char *d = mkdtemp(tmpl);
+	if (!d) { perror("mkdtemp"); exit(2); }
+	std::string root(d);
+	mkdir((root + "/assets").c_str(), 0700);
+	mkdir((root + "/run").c_str(), 0700);
+	{ std::ofstream o(root + "/assets/model_hand.json", std::ios::binary); o.write(ht_asset_model, ht_asset_model_end - ht_asset_model); }
+	{ std::ofstream o(root + "/assets/vanity_bones.json", std::ios::binary); o.write(ht_asset_vanity, ht_asset_vanity_end - ht_asset_vanity); }
+	if (chdir((root + "/run").c_str())) { perror("chdir"); exit(2); }
+}
+
+// ---- seeded synthetic weights (our own generator; mirrored in hand_tracking_samples_amd/weights.py) ----
+static inline uint64_t splitmix64_at(uint64_t seed, uint64_t i)
+{
+	uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+static std::vector<float> make_cnnb(uint64_t seed, double fc2gain)
+{
+	// .cnnb layout (cnn.h:288,454,590): conv1 W[400] B[16]; conv2 W[16384] B[64]; fc1 W[2304*2048] B[2048]; fc2 W[2048*2304] B[2304]
+	struct L { size_t nw, nb; double fan; double gain; } layers[4] = {
+		{ 400, 16, 25.0 * 1 + 25.0 * 16, 1.0 }, { 16384, 64, 16.0 * 16 + 16.0 * 64, 1.0 },
+		{ (size_t)2304 * 2048, 2048, 2304.0 + 2048.0, 1.0 }, { (size_t)2048 * 2304, 2304, 2048.0 + 2304.0, fc2gain } };
+	std::vector<float> out;
+	uint64_t ctr = 0;
+	for (auto &l : layers)
+	{
+		double range = std::sqrt(6.0 / l.fan) * l.gain;
+		for (size_t i = 0; i < l.nw; i++) { double u = (double)(splitmix64_at(seed, ctr++) >> 11) * (1.0 / 9007199254740992.0); out.push_back((float)((2.0 * u - 1.0) * range)); }
+		for (size_t i = 0; i < l.nb; i++) { double u = (double)(splitmix64_at(seed, ctr++) >> 11) * (1.0 / 9007199254740992.0); out.push_back((float)((2.0 * u - 1.0) * 0.05 * l.gain)); }
+	}
+	return out;
+}
+static void load_weights(HandTracker &htk, uint64_t seed, double fc2gain)
+{
+	auto w = make_cnnb(seed, fc2gain);
+	std::string s((const char*)w.data(), w.size() * sizeof(float));
+	std::istringstream is(s, std::ios::binary);
+	htk.cnn.loadb(is);
+}
+
+// ---- helpers ------------------------------------------------------------------------------------
+static std::vector<std::vector<Pose>> read_animbank(const char *fn, size_t nb)
+{
+	std::vector<std::vector<Pose>> bank;
+	FILE *f = fopen(fn, "r");
+	if (!f) { fprintf(stderr, "cannot open %s\n", fn); exit(2); }
+	for (;;)
+	{
+		std::vector<Pose> p(nb);
+		bool ok = true;
+		for (auto &q : p)
+			if (fscanf(f, "%f %f %f %f %f %f %f", &q.position.x, &q.position.y, &q.position.z, &q.orientation.x, &q.orientation.y, &q.orientation.z, &q.orientation.w) != 7) { ok = false; break; }
+		if (!ok) break;
+		bank.push_back(p);
+	}
+	fclose(f);
+	return bank;
+}
+static Image<unsigned short> raycast_depth(PhysModel &model, const DCamera &cam)   // software rasteriser via PhysModel::HitCheck
+{
+	Image<unsigned short> depth(cam);
+	depth.cam.depth_scale = cam.depth_scale;
+	for (int y = 0; y < cam.dim().y; y++) for (int x = 0; x < cam.dim().x; x++)
+	{
+		auto h = model.HitCheck(float3(0, 0, 0), depth.cam.deprojectz(float2((float)x, (float)y), 4.0f));
+		depth.pixel(int2(x, y)) = (unsigned short)(h.impact.z / depth.cam.depth_scale);
+	}
+	return depth;
+}
+struct Frame { Image<unsigned short> seg; std::vector<Pose> start, gt; };
+static Frame make_frame(PhysModel &fake, const std::vector<std::vector<Pose>> &bank, size_t k)
+{
+	DCamera dcam({ 320,240 }, { 305,305 }, { 160,120 }, 0.001f);
+	fake.SetPose(bank[k % bank.size()]);
+	auto depth = raycast_depth(fake, dcam);
+	Frame fr;
+	fr.seg = HandSegmentVR(depth, 0xF, { 0.1f,0.70f });
+	fr.gt = bank[k % bank.size()];
+	fr.start = bank[(k + 1) % bank.size()];
+	Pose inv = fr.seg.cam.pose.inverse();
+	for (auto &p : fr.gt) p = inv * p;
+	for (auto &p : fr.start) p = inv * p;
+	fr.seg.cam.pose = Pose();
+	return fr;
+}
+static std::vector<float> flat(const std::vector<Pose> &p) { std::vector<float> o; for (auto &q : p) { for (int i = 0; i < 3; i++) o.push_back(q.position[i]); for (int i = 0; i < 4; i++) o.push_back(q.orientation[i]); } return o; }
+static std::vector<float> camvec(const DCamera &c) { return { c.focal().x, c.focal().y, c.principal().x, c.principal().y, c.depth_scale, c.pose.position.x, c.pose.position.y, c.pose.position.z, c.pose.orientation.x, c.pose.orientation.y, c.pose.orientation.z, c.pose.orientation.w }; }
+static int rbidx(PhysModel &m, const RigidBody *rb) { return rb ? (int)(rb - m.rigidbodies.data()) : -1; }
+
+struct Out
+{
+	htfx_writer w;
+	void f32(const std::string &n, const std::vector<float> &v, std::vector<uint32_t> dims = {}) { if (dims.empty()) dims = { (uint32_t)v.size() }; htfx_put(&w, n.c_str(), HTFX_F32, (uint32_t)dims.size(), dims.data(), v.data()); }
+	void i32(const std::string &n, const std::vector<int> &v, std::vector<uint32_t> dims = {}) { if (dims.empty()) dims = { (uint32_t)v.size() }; htfx_put(&w, n.c_str(), HTFX_I32, (uint32_t)dims.size(), dims.data(), v.data()); }
+	void u16(const std::string &n, const std::vector<unsigned short> &v, std::vector<uint32_t> dims = {}) { if (dims.empty()) dims = { (uint32_t)v.size() }; htfx_put(&w, n.c_str(), HTFX_U16, (uint32_t)dims.size(), dims.data(), v.data()); }
+	void v3(const std::string &n, const std::vector<float3> &v) { std::vector<float> o; for (auto &a : v) { o.push_back(a.x); o.push_back(a.y); o.push_back(a.z); } f32(n, o, { (uint32_t)v.size(), 3 }); }
+	void state(const std::string &n, PhysModel &m)   // [nb,13] pos3 quat4 linmom3 angmom3
+	{
+		std::vector<float> o;
+		for (auto &rb : m.rigidbodies) { for (int i = 0; i < 3; i++) o.push_back(rb.position[i]); for (int i = 0; i < 4; i++) o.push_back(rb.orientation[i]); for (int i = 0; i < 3; i++) o.push_back(rb.linear_momentum[i]); for (int i = 0; i < 3; i++) o.push_back(rb.angular_momentum[i]); }
+		f32(n, o, { (uint32_t)m.rigidbodies.size(), 13 });
+	}
+	void linears(const std::string &n, PhysModel &m, const std::vector<LimitLinear> &L)   // [n,16]
+	{
+		std::vector<float> o;
+		for (auto &c : L)
+		{
+			o.push_back((float)rbidx(m, c.rb0)); o.push_back((float)rbidx(m, c.rb1));
+			for (int i = 0; i < 3; i++) o.push_back(c.position0[i]); for (int i = 0; i < 3; i++) o.push_back(c.position1[i]); for (int i = 0; i < 3; i++) o.push_back(c.normal[i]);
+			o.push_back(c.targetdist); o.push_back(c.targetspeednobias); o.push_back(c.forcelimit.x); o.push_back(c.forcelimit.y); o.push_back((float)c.friction_master);
+		}
+		f32(n, o, { (uint32_t)L.size(), 16 });
+	}
+	void angulars(const std::string &n, PhysModel &m, const std::vector<LimitAngular> &A)   // [n,8]
+	{
+		std::vector<float> o;
+		for (auto &a : A) { o.push_back((float)rbidx(m, a.rb0)); o.push_back((float)rbidx(m, a.rb1)); for (int i = 0; i < 3; i++) o.push_back(a.axis[i]); o.push_back(a.targetspin); o.push_back(a.mintorque); o.push_back(a.maxtorque); }
+		f32(n, o, { (uint32_t)A.size(), 8 });
+	}
+};
+static void zero_momenta(PhysModel &m) { for (auto &rb : m.rigidbodies) rb.linear_momentum = rb.angular_momentum = float3(0, 0, 0); }
+static void reset_tracker(HandTracker &htk, const std::vector<Pose> &start)
+{
+	htk.handmodel.SetPose(start); htk.othermodel.SetPose(start);
+	zero_momenta(htk.handmodel); zero_momenta(htk.othermodel);
+	htk.prev_frame_error = 0.0f; htk.initializing = 0;
+}
+
+// the deterministic unit of work: update_cnn_model + mainthreadpasses passes as HandTracker::update runs them (handtrack.h:748-785)
+static std::vector<Pose> unit_of_work(HandTracker &htk, const Image<unsigned short> &seg, Out *out = NULL, const std::string &pre = "")
+{
+	auto points = takesubsample(PointCloud(seg, { 0.1f,htk.drangey }), htk.subsample_fraction, htk.subsample_voxel, htk.subsample_size);
+	htk.othermodel.SetPose(htk.handmodel.GetPose());
+	auto pose = htk.update_cnn_model(seg);
+	if (out)
+	{
+		out->state(pre + "uw_other_after_cnn", htk.othermodel);
+		out->f32(pre + "uw_accept", { (float)pose.size(), htk.prev_frame_error, (float)htk.initializing });
+	}
+	htk.handmodel.SetPose(pose);
+	for (int i = 0; !htk.angles_only && i < htk.mainthreadpasses; i++)
+	{
+		std::vector<LimitLinear> linears; std::vector<LimitAngular> angulars;
+		HandModelEnhancements(htk.handmodel, angulars, false, float3(0, 0, 0), float3(0, 0, 0), 0);
+		if (points.size() > htk.min_point_num && htk.boundary_planes)
+		{
+			std::vector<float3> outdirs = { float3(-1, -0.25f, 0), float3(-1, -1, 0), float3(0, -1, 0), float3(1, -1, 0), float3(1, -0.25f, 0) };
+			Append(linears, cloud_chamber(htk.handmodel, points, outdirs, { 0,0,0 }, { 0,0,1 }, 10.0f));
+		}
+		htk.handmodel.FitPointCloud(points, linears, angulars, htk.microforce);
+		if (out) out->state(pre + "uw_hand_pass" + std::to_string(i), htk.handmodel);
+	}
+	if (points.size() < htk.min_point_num) htk.initializing = 50;
+	return htk.handmodel.GetPoseUser();
+}
+
+// ---- modes ---------------------------------------------------------------------------------------
+static int mode_model(const char *outfn)
+{
+	HandTracker htk;
+	PhysModel &m = htk.handmodel;
+	Out o; if (htfx_open(&o.w, outfn)) return 2;
+	int nb = (int)m.rigidbodies.size(), nj = (int)m.joints.size();
+	o.i32("nb", { nb }); o.i32("nj", { nj });
+	std::vector<float> bf; std::vector<int> bi, ign(nb * nb, 0), nverts, nplanes;
+	for (int b = 0; b < nb; b++)
+	{
+		auto &rb = m.rigidbodies[b];
+		o.v3("b" + std::to_string(b) + "/verts", rb.shapes[0].verts);
+		std::vector<float> pl; for (auto &p : rb.shapes[0].planes) for (int i = 0; i < 4; i++) pl.push_back(p[i]);
+		o.f32("b" + std::to_string(b) + "/planes", pl, { (uint32_t)rb.shapes[0].planes.size(), 4 });
+		std::vector<int> tr; for (auto &t : rb.shapes[0].tris) for (int i = 0; i < 3; i++) tr.push_back(t[i]);
+		o.i32("b" + std::to_string(b) + "/tris", tr, { (uint32_t)rb.shapes[0].tris.size(), 3 });
+		nverts.push_back((int)rb.shapes[0].verts.size()); nplanes.push_back((int)rb.shapes[0].planes.size());
+		// body_f row: mass massinv radius radius_inner damping friction gravscale com3 pos_start3 quat_start4 tensorinv9(column major)
+		bf.push_back(rb.mass); bf.push_back(rb.massinv); bf.push_back(rb.radius); bf.push_back(rb.radius_inner); bf.push_back(rb.damping); bf.push_back(rb.friction); bf.push_back(rb.gravscale);
+		for (int i = 0; i < 3; i++) bf.push_back(rb.com[i]); for (int i = 0; i < 3; i++) bf.push_back(rb.position_start[i]); for (int i = 0; i < 4; i++) bf.push_back(rb.orientation_start[i]);
+		for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) bf.push_back(rb.tensorinv_massless[c][r]);
+		bi.push_back(rb.collide);
+		for (auto *x : rb.ignore) ign[b * nb + rbidx(m, x)] = 1;
+	}
+	o.f32("body_f", bf, { (uint32_t)nb, 26 }); o.i32("body_collide", bi); o.i32("ignore", ign, { (uint32_t)nb, (uint32_t)nb });
+	o.i32("nverts", nverts); o.i32("nplanes", nplanes);
+	std::vector<int> ji; std::vector<float> jf;
+	for (auto &j : m.joints)
+	{
+		ji.push_back(j.rbi0); ji.push_back(j.rbi1);
+		for (int i = 0; i < 3; i++) jf.push_back(j.p0[i]); for (int i = 0; i < 3; i++) jf.push_back(j.p1[i]);
+		for (int i = 0; i < 3; i++) jf.push_back(j.rangemin[i]); for (int i = 0; i < 3; i++) jf.push_back(j.rangemax[i]); for (int i = 0; i < 4; i++) jf.push_back(j.jointframe[i]);
+	}
+	o.i32("joint_i", ji, { (uint32_t)nj, 2 }); o.f32("joint_f", jf, { (uint32_t)nj, 16 });
+	o.f32("physics", { physics_deltaT, physics_restitution, physics_gravity.x, physics_gravity.y, physics_gravity.z, physics_coloumb, physics_biasfactorjoint, physics_biasfactorpositive, physics_biasfactornegative,
+		physics_falltime_to_ballistic, physics_driftmax, physics_damping, (float)physics_iterations, (float)physics_iterations_post, (float)physics_use_collision, physics_weak_force, bone_sum_error_scale, unibody_force });
+	o.state("rest_state", m);
+	{   // the 0.1 m cube proxy of UnibodyFit (handtrack.h:454-455)
+		WingMesh box = WingMeshCube(0.1f);
+		RigidBody ub({ Shape(box.verts, box.GenerateTris()) }, float3(0, 0, 0));
+		o.v3("unibody/verts", ub.shapes[0].verts);
+		std::vector<float> u = { ub.mass, ub.massinv, ub.radius, ub.damping, ub.friction, ub.gravscale, ub.com.x, ub.com.y, ub.com.z };
+		for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) u.push_back(ub.tensorinv_massless[c][r]);
+		o.f32("unibody/f", u);
+	}
+	htfx_close(&o.w);
+	printf("model: %d bodies %d joints -> %s\n", nb, nj, outfn);
+	return 0;
+}
+
+static int mode_scan(const char *bankfn, int stride)
+{
+	HandTracker htk;
+	PhysModel fake = LoadHandModel();
+	auto bank = read_animbank(bankfn, fake.rigidbodies.size());
+	printf("# animbank rows=%d\n# row inrange P pairs contacts fiterr focal\n", (int)bank.size());
+	for (size_t k = 0; k < bank.size(); k += stride)
+	{
+		Frame fr = make_frame(fake, bank, k);
+		auto pc = PointCloud(fr.seg, { 0.1f,0.7f });
+		auto vp = takesubsample(pc, 4);
+		htk.handmodel.SetPose(fr.start); zero_momenta(htk.handmodel);
+		float err = FitError(htk.handmodel, vp, fr.seg);
+		auto rbs = Addresses(htk.handmodel.rigidbodies);
+		int pairs = 0;
+		for (auto rb0 : rbs) for (auto rb1 : rbs) if (rb0 < rb1)
+		{
+			if (length(rb1->position - rb0->position) > rb0->radius + rb1->radius) continue;
+			if (std::find(rb0->ignore.begin(), rb0->ignore.end(), rb1) != rb0->ignore.end()) continue;
+			pairs++;
+		}
+		std::vector<PhysContact> contacts; FindShapeShapeContacts(contacts, rbs);
+		printf("%d %d %d %d %d %.4f %.2f\n", (int)k, (int)pc.size(), (int)vp.size(), pairs, (int)contacts.size(), err, fr.seg.cam.focal().x);
+	}
+	return 0;
+}
+
+static int mode_frames(const char *bankfn, int first, int stride, int n, const char *outfn)
+{
+	PhysModel fake = LoadHandModel();
+	auto bank = read_animbank(bankfn, fake.rigidbodies.size());
+	std::vector<unsigned short> depth; std::vector<float> cams, start, gt; std::vector<int> rows;
+	for (int i = 0; i < n; i++)
+	{
+		size_t k = (size_t)(first + (long)i * stride) % bank.size();
+		Frame fr = make_frame(fake, bank, k);
+		depth.insert(depth.end(), fr.seg.raster.begin(), fr.seg.raster.end());
+		auto c = camvec(fr.seg.cam); cams.insert(cams.end(), c.begin(), c.end());
+		auto s = flat(fr.start); start.insert(start.end(), s.begin(), s.end());
+		auto g = flat(fr.gt); gt.insert(gt.end(), g.begin(), g.end());
+		rows.push_back((int)k);
+		if (i % 32 == 0) { printf("frame %d/%d row %d\n", i, n, (int)k); fflush(stdout); }
+	}
+	Out o; if (htfx_open(&o.w, outfn)) return 2;
+	o.u16("depth", depth, { (uint32_t)n, 64, 64 }); o.f32("cam", cams, { (uint32_t)n, 12 });
+	o.f32("startpose", start, { (uint32_t)n, 17, 7 }); o.f32("gtpose", gt, { (uint32_t)n, 17, 7 }); o.i32("rows", rows);
+	htfx_close(&o.w);
+	return 0;
+}
+
+static void dump_contacts(Out &o, const std::string &n, PhysModel &m, const std::vector<PhysContact> &C)
+{
+	std::vector<float> v;
+	for (auto &c : C)
+	{
+		v.push_back((float)rbidx(m, c.rb0)); v.push_back((float)rbidx(m, c.rb1));
+		for (int i = 0; i < 3; i++) v.push_back(c.normal[i]); for (int i = 0; i < 3; i++) v.push_back(c.p0w[i]); for (int i = 0; i < 3; i++) v.push_back(c.p1w[i]);
+		v.push_back(c.separation); for (int i = 0; i < 3; i++) v.push_back(c.p0[i]); for (int i = 0; i < 3; i++) v.push_back(c.p1[i]);
+	}
+	o.f32(n, v, { (uint32_t)C.size(), 18 });
+}
+
+static int mode_golden(const char *bankfn, const char *rowscsv, uint64_t seed, double gain, const char *outfn)
+{
+	HandTracker htk;
+	htk.microforce = 3.0f; htk.mainthreadpasses = 3; htk.always_take_cnn = 0;     // synthetic-tracker.cpp:91-93
+	load_weights(htk, seed, gain);
+	PhysModel fake = LoadHandModel();
+	auto bank = read_animbank(bankfn, fake.rigidbodies.size());
+	std::vector<int> rows; { std::stringstream ss(rowscsv); std::string t; while (std::getline(ss, t, ',')) rows.push_back(atoi(t.c_str())); }
+	Out o; if (htfx_open(&o.w, outfn)) return 2;
+	o.i32("rows", rows); o.f32("weights_seed_gain", { (float)seed, (float)gain });
+	for (size_t fi = 0; fi < rows.size(); fi++)
+	{
+		std::string pre = "f" + std::to_string(fi) + "/";
+		Frame fr = make_frame(fake, bank, rows[fi]);
+		auto &seg = fr.seg;
+		o.u16(pre + "depth", seg.raster, { 64,64 }); o.f32(pre + "cam", camvec(seg.cam)); o.f32(pre + "startpose", flat(fr.start), { 17,7 }); o.f32(pre + "gtpose", flat(fr.gt), { 17,7 });
+		float2 drange = { 0.1f, htk.drangey };
+		// S1: CNN input / layers / output (handtrack.h:700-701)
+		auto cnn_input = Transform(seg, [drange, &seg](unsigned short d) {return (float)clamp(1.0f - (d*seg.cam.depth_scale - drange.x) / (drange.y - drange.x), 0.0f, 1.0f); });
+		const bool full = fi < 2;   // bulky per-stage arrays only for the first two frames (fixture size)
+		if (full) o.f32(pre + "cnn_input", cnn_input.raster);
+		{
+			std::vector<float> x = cnn_input.raster;
+			for (size_t li = 0; li < htk.cnn.layers.size(); li++)
+			{
+				x = htk.cnn.layers[li]->forward(x);
+				if (fi == 0 && (li == 3 || li >= 6)) o.f32(pre + "cnn_layer" + std::to_string(li), x);   // pooled / FC stages (the 60x60 planes are too bulky)
+			}
+			o.f32(pre + "cnn_output", x);
+			auto y = htk.cnn.Eval(cnn_input.raster);
+			if (y != x) { fprintf(stderr, "Eval != layerwise?\n"); return 3; }
+		}
+		auto cnn_output = htk.cnn.Eval(cnn_input.raster);
+		// S2: decode (handtrack.h:218-241)
+		DCamera hcam = camsub(seg.cam, 4);
+		CNNOutputAnalysis an(cnn_output, hcam);
+		{
+			std::vector<float> cr, ip; for (auto &c : an.crays) for (int i = 0; i < 4; i++) cr.push_back(c[i]); for (auto &p : an.image_points) { ip.push_back(p.x); ip.push_back(p.y); }
+			o.f32(pre + "an_crays", cr, { 8,4 }); o.f32(pre + "an_image_points", ip, { 8,2 }); o.f32(pre + "an_confidence", an.confidence); o.f32(pre + "an_vals", an.vals);
+			o.f32(pre + "an_angles", { an.wristroll, an.pitch, an.tilt, an.palmq.x, an.palmq.y, an.palmq.z, an.palmq.w }); o.f32(pre + "an_clenched", an.finger_clenched);
+			std::vector<float> top2;   // margin information for tolerance decisions: best and second best value per map
+			for (int mi = 0; mi < 8; mi++) { std::vector<float> mm(cnn_output.begin() + 256 * mi, cnn_output.begin() + 256 * (mi + 1)); std::sort(mm.begin(), mm.end()); top2.push_back(mm[255]); top2.push_back(mm[254]); }
+			o.f32(pre + "an_top2", top2, { 8,2 });
+		}
+		// S3: point clouds (misc_image.h:409-417, physmodel.h:58-64)
+		auto pc = PointCloud(seg, drange);
+		auto vpts = takesubsample(pc, htk.subsample_fraction);
+		o.i32(pre + "pc_count", { (int)pc.size(), (int)vpts.size() }); o.v3(pre + "vpts", vpts);
+		// S4: FitError at the start pose (handtrack.h:371-399)
+		reset_tracker(htk, fr.start);
+		o.f32(pre + "fiterror_start", { FitError(htk.handmodel, vpts, seg) });
+		// S5: closest + cloud constraints at the start pose (physmodel.h:137-181)
+		{
+			auto rbs = Addresses(htk.handmodel.rigidbodies);
+			std::vector<float> cl;
+			for (auto &v : vpts) { auto r = closest(rbs, v); cl.push_back((float)rbidx(htk.handmodel, r.first)); for (int i = 0; i < 4; i++) cl.push_back(r.second[i]); }
+			o.f32(pre + "closest_vpts", cl, { (uint32_t)vpts.size(), 5 });
+			if (full) o.linears(pre + "cloud_rows_vpts", htk.handmodel, CloudConstraints(rbs, vpts, seg.cam.pose.position));
+			o.linears(pre + "cloud_rows_sub", htk.handmodel, CloudConstraints(rbs, takesubsample(vpts), seg.cam.pose.position));
+		}
+		// S6: joint rows after HandModelEnhancements (handtrack.h:406-441, physmodel.h:321-334)
+		{
+			std::vector<LimitAngular> extra;
+			HandModelEnhancements(htk.handmodel, extra, false, float3(0, 0, 0), float3(0, 0, 0), 0);
+			std::vector<float> jr; for (auto &j : htk.handmodel.joints) { for (int i = 0; i < 3; i++) jr.push_back(j.rangemin[i]); for (int i = 0; i < 3; i++) jr.push_back(j.rangemax[i]); }
+			o.f32(pre + "joint_ranges", jr, { 16,6 });
+			o.linears(pre + "joint_linears", htk.handmodel, htk.handmodel.GetLinearConstraints());
+			o.angulars(pre + "joint_angulars", htk.handmodel, htk.handmodel.GetAngularConstraints());
+			std::vector<LimitAngular> extra2;
+			HandModelEnhancements(htk.handmodel, extra2, false, qrot(seg.cam.pose.orientation, float3(-1, 0, 0)), qrot(seg.cam.pose.orientation, float3(0, -1, 0)));
+			o.angulars(pre + "enh_angulars", htk.handmodel, extra2);
+			o.angulars(pre + "apply_angles", htk.handmodel, an.ApplyAngles(htk.handmodel, seg.cam.pose, 10000.0f));
+			std::vector<float3> outdirs = { float3(-1, -0.25f, 0), float3(-1, -1, 0), float3(0, -1, 0), float3(1, -1, 0), float3(1, -0.25f, 0) };
+			o.linears(pre + "chamber_rows", htk.handmodel, cloud_chamber(htk.handmodel, vpts, outdirs, { 0,0,0 }, { 0,0,1 }, 10.0f));
+		}
+		// S7: body-body contacts at the start pose (physics.h:451-462, gjk.h:607-643)
+		{
+			std::vector<PhysContact> contacts; FindShapeShapeContacts(contacts, Addresses(htk.handmodel.rigidbodies));
+			dump_contacts(o, pre + "contacts_start", htk.handmodel, contacts);
+		}
+		// S8: two consecutive FitPointCloud passes from the start pose with zero momenta (physmodel.h:345-356)
+		reset_tracker(htk, fr.start);
+		for (int p = 0; p < 2; p++)
+		{
+			std::vector<LimitAngular> angulars;
+			HandModelEnhancements(htk.handmodel, angulars, false, float3(0, 0, 0), float3(0, 0, 0), 0);
+			htk.handmodel.FitPointCloud(vpts, {}, angulars, htk.microforce);
+			o.state(pre + "fit_pass" + std::to_string(p), htk.handmodel);
+		}
+		// S9: MultiStepSim after s=1..5 steps from the start pose (handtrack.h:642-690)
+		for (int s = 1; s <= 5; s++)
+		{
+			reset_tracker(htk, fr.start);
+			htk.steps = s;
+			htk.MultiStepSim(htk.othermodel, an, vpts, seg.cam.pose);
+			o.state(pre + "multistep" + std::to_string(s), htk.othermodel);
+		}
+		htk.steps = 5;
+		// S10: the whole unit of work
+		reset_tracker(htk, fr.start);
+		auto user = unit_of_work(htk, seg, &o, pre);
+		o.f32(pre + "uw_pose_user", flat(user), { 17,7 });
+		o.f32(pre + "uw_final", { htk.prev_frame_error, (float)htk.initializing });
+		// S10b: a second frame of streaming use (state carried: momenta, prev_frame_error, initializing); same image again
+		auto user2 = unit_of_work(htk, seg, NULL, "");
+		o.f32(pre + "uw2_pose_user", flat(user2), { 17,7 }); o.state(pre + "uw2_hand", htk.handmodel);
+		o.f32(pre + "uw2_final", { htk.prev_frame_error, (float)htk.initializing });
+		// S12: forced reset path (handtrack.h:480-506, 451-470)
+		if (fi < 3)
+		{
+			reset_tracker(htk, fr.start);
+			PoseFromScratch(htk.othermodel, vpts, an, seg.cam.pose);
+			o.state(pre + "scratch", htk.othermodel);
+			for (int i = 0; i < 3; i++) { UnibodyFit(htk.othermodel, vpts, seg.cam.pose.position); o.state(pre + "unibody" + std::to_string(i), htk.othermodel); }
+			o.f32(pre + "fiterror_scratch", { FitError(htk.othermodel, vpts, seg) });
+		}
+		printf("golden frame %d row %d P=%d\n", (int)fi, rows[fi], (int)vpts.size()); fflush(stdout);
+	}
+	// S13: GJK / EPA unit cases on pairs of bodies in hand-made poses (gjk.h:367-437, hull.h:233-310)
+	{
+		PhysModel &m = htk.handmodel;
+		m.Reset();
+		struct Case { int a, b; float3 pa; float4 qa; float3 pb; float4 qb; };
+		std::vector<Case> cases;
+		uint64_t c = 0;
+		auto rnd = [&]() { return (float)((double)(splitmix64_at(0xC0FFEEull, c++) >> 11) * (1.0 / 9007199254740992.0)); };
+		for (int i = 0; i < 48; i++)
+		{
+			int a = (int)(rnd() * 17) % 17, b = (int)(rnd() * 17) % 17; if (a == b) b = (b + 1) % 17;
+			float4 qa = normalize(float4(rnd() - 0.5f, rnd() - 0.5f, rnd() - 0.5f, rnd() - 0.5f)), qb = normalize(float4(rnd() - 0.5f, rnd() - 0.5f, rnd() - 0.5f, rnd() - 0.5f));
+			float sep = (i < 16) ? 0.08f : (i < 32) ? 0.03f : 0.008f;     // far, near/touching, penetrating
+			float3 dir = normalize(float3(rnd() - 0.5f, rnd() - 0.5f, rnd() - 0.5f));
+			cases.push_back({ a, b, float3(0,0,0.4f), qa, float3(0,0,0.4f) + dir * sep, qb });
+		}
+		std::vector<float> in, outv;
+		for (auto &cs : cases)
+		{
+			auto &A = m.rigidbodies[cs.a]; auto &B = m.rigidbodies[cs.b];
+			A.position = cs.pa; A.orientation = cs.qa; B.position = cs.pb; B.orientation = cs.qb;
+			auto h = Separated(SupportFunc(&A, A.shapes[0]), SupportFunc(&B, B.shapes[0]), 1);
+			in.push_back((float)cs.a); in.push_back((float)cs.b);
+			for (int i = 0; i < 3; i++) in.push_back(cs.pa[i]); for (int i = 0; i < 4; i++) in.push_back(cs.qa[i]); for (int i = 0; i < 3; i++) in.push_back(cs.pb[i]); for (int i = 0; i < 4; i++) in.push_back(cs.qb[i]);
+			for (int i = 0; i < 3; i++) outv.push_back(h.normal[i]); for (int i = 0; i < 3; i++) outv.push_back(h.p0w[i]); for (int i = 0; i < 3; i++) outv.push_back(h.p1w[i]); outv.push_back(h.separation);
+			auto patch = ContactPatch(SupportFunc(&A, A.shapes[0]), SupportFunc(&B, B.shapes[0]), physics_driftmax);
+			outv.push_back((float)patch.count);
+			for (int k = 0; k < 5; k++) { for (int i = 0; i < 3; i++) outv.push_back(k < patch.count ? patch[k].p0w[i] : 0); for (int i = 0; i < 3; i++) outv.push_back(k < patch.count ? patch[k].p1w[i] : 0); outv.push_back(k < patch.count ? patch[k].separation : 0); }
+		}
+		o.f32("gjk_cases_in", in, { (uint32_t)cases.size(), 16 }); o.f32("gjk_cases_out", outv, { (uint32_t)cases.size(), 46 });
+		m.Reset();
+	}
+	htfx_close(&o.w);
+	return 0;
+}
+
+// minimal HTFX reader for bench mode
+struct Arr { std::string name; uint32_t dtype, ndim, dims[4]; std::vector<char> data; };
+static std::vector<Arr> htfx_read(const char *fn)
+{
+	std::vector<Arr> v; FILE *f = fopen(fn, "rb"); if (!f) { fprintf(stderr, "cannot open %s\n", fn); exit(2); }
+	char magic[8]; uint32_t count; if (fread(magic, 1, 8, f) != 8 || fread(&count, 4, 1, f) != 1) exit(2);
+	for (uint32_t i = 0; i < count; i++)
+	{
+		Arr a; char nm[48]; uint64_t n;
+		if (fread(nm, 1, 48, f) != 48) exit(2); a.name = nm;
+		if (fread(&a.dtype, 4, 1, f) != 1 || fread(&a.ndim, 4, 1, f) != 1 || fread(a.dims, 4, 4, f) != 4 || fread(&n, 8, 1, f) != 1) exit(2);
+		a.data.resize(n); if (n && fread(a.data.data(), 1, n, f) != n) exit(2);
+		fseek(f, (long)((8 - (n & 7)) & 7), SEEK_CUR);
+		v.push_back(std::move(a));
+	}
+	fclose(f); return v;
+}
+static int mode_bench(const char *framesfn, uint64_t seed, double gain, int reps, int maxframes)
+{
+	HandTracker htk;
+	htk.microforce = 3.0f; htk.mainthreadpasses = 3; htk.always_take_cnn = 0;
+	load_weights(htk, seed, gain);
+	auto arrs = htfx_read(framesfn);
+	const Arr *ad = NULL, *ac = NULL, *as = NULL;
+	for (auto &a : arrs) { if (a.name == "depth") ad = &a; if (a.name == "cam") ac = &a; if (a.name == "startpose") as = &a; }
+	if (!ad || !ac || !as) { fprintf(stderr, "frames file lacks depth/cam/startpose\n"); return 2; }
+	int n = (int)ad->dims[0]; if (maxframes > 0 && n > maxframes) n = maxframes;
+	std::vector<Image<unsigned short>> segs; std::vector<std::vector<Pose>> starts;
+	for (int i = 0; i < n; i++)
+	{
+		const float *c = (const float*)ac->data.data() + 12 * i;
+		DCamera cam({ 64,64 }, { c[0],c[1] }, { c[2],c[3] }, c[4], Pose({ c[5],c[6],c[7] }, { c[8],c[9],c[10],c[11] }));
+		const unsigned short *d = (const unsigned short*)ad->data.data() + 4096 * i;
+		segs.push_back(Image<unsigned short>(cam, std::vector<unsigned short>(d, d + 4096)));
+		std::vector<Pose> sp(17); const float *s = (const float*)as->data.data() + 119 * i;
+		for (int b = 0; b < 17; b++) sp[b] = Pose({ s[7 * b],s[7 * b + 1],s[7 * b + 2] }, { s[7 * b + 3],s[7 * b + 4],s[7 * b + 5],s[7 * b + 6] });
+		starts.push_back(sp);
+	}
+	double best_cnn = 1e30, best_uw = 1e30; double checksum = 0;
+	for (int r = 0; r < reps; r++)
+	{
+		auto t0 = std::chrono::steady_clock::now();
+		for (int i = 0; i < n; i++)
+		{
+			float2 drange = { 0.1f, htk.drangey }; auto &seg = segs[i];
+			auto in = Transform(seg, [drange, &seg](unsigned short d) {return (float)clamp(1.0f - (d*seg.cam.depth_scale - drange.x) / (drange.y - drange.x), 0.0f, 1.0f); });
+			auto y = htk.cnn.Eval(in.raster); checksum += y[0];
+		}
+		auto t1 = std::chrono::steady_clock::now();
+		for (int i = 0; i < n; i++)
+		{
+			reset_tracker(htk, starts[i]);
+			auto p = unit_of_work(htk, segs[i]); checksum += p[1].position.x;
+		}
+		auto t2 = std::chrono::steady_clock::now();
+		double c = std::chrono::duration<double>(t1 - t0).count() / n, u = std::chrono::duration<double>(t2 - t1).count() / n;
+		best_cnn = std::min(best_cnn, c); best_uw = std::min(best_uw, u);
+	}
+	printf("{\"frames\": %d, \"reps\": %d, \"cnn_ms\": %.4f, \"cnn_fps\": %.2f, \"frame_ms\": %.4f, \"frame_fps\": %.2f, \"checksum\": %.6f}\n", n, reps, best_cnn * 1e3, 1.0 / best_cnn, best_uw * 1e3, 1.0 / best_uw, checksum);
+	return 0;
+}
+
+int main(int argc, char **argv) try
+{
+	if (argc < 2) { fprintf(stderr, "usage: see header of ref_harness.cpp\n"); return 1; }
+	std::string mode = argv[1];
+	// resolve file arguments to absolute paths before we chdir into the staged asset tree
+	std::vector<std::string> a;
+	for (int i = 2; i < argc; i++) { std::string s = argv[i]; if (s.find('/') != std::string::npos || s.find(".htfx") != std::string::npos || s.find(".pose") != std::string::npos) { char buf[4096]; if (s[0] != '/' && getcwd(buf, sizeof buf)) s = std::string(buf) + "/" + s; } a.push_back(s); }
+	stage_assets();
+	if (mode == "model" && a.size() == 1) return mode_model(a[0].c_str());
+	if (mode == "scan" && a.size() == 2) return mode_scan(a[0].c_str(), atoi(a[1].c_str()));
+	if (mode == "frames" && a.size() == 5) return mode_frames(a[0].c_str(), atoi(a[1].c_str()), atoi(a[2].c_str()), atoi(a[3].c_str()), a[4].c_str());
+	if (mode == "golden" && a.size() == 5) return mode_golden(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());
+	if (mode == "bench" && a.size() >= 4) return mode_bench(a[0].c_str(), strtoull(a[1].c_str(), 0, 0), atof(a[2].c_str()), atoi(a[3].c_str()), a.size() > 4 ? atoi(a[4].c_str()) : 0);
+	fprintf(stderr, "bad arguments\n");
+	return 1;
+}
+catch (const char *c) { fprintf(stderr, "reference threw: %s\n", c); return 4; }
+catch (const std::exception &e) { fprintf(stderr, "reference threw: %s\n", e.what()); return 4; }
