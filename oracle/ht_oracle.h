@@ -1,0 +1,138 @@
+/*
+ * ht_oracle.h -- public interface of the CPU oracle (plain C restatement of the reference hot path).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * libht_oracle.so, and only as the checker / reported CPU baseline.  The product (hand_tracking_samples_amd/)
+ * never includes, links or calls anything in oracle/.
+ *
+ * Parity status: PINNED.  Every stage is compared bit for bit (transcendental-free stages) or to <=1e-6
+ * against tests/golden/golden8.htfx, which oracle/_ref/ref_harness produced by running the reference's own
+ * code (see tests/test_oracle_vs_golden.py).
+ */
+#ifndef HT_ORACLE_H
+#define HT_ORACLE_H
+#include <stdint.h>
+#include "ho_math.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HO_MAXB 32          /* bodies */
+#define HO_MAXJ 32          /* joints */
+#define HO_NCNN_OUT 2304
+#define HO_NLANDMARK 8
+#define HO_NKEYANGLE 16
+
+typedef struct ho_shape { int nverts; f3 *verts; int nplanes; f4 *planes; } ho_shape;
+
+/* RigidBody, physics.h:118-173 (fields the path touches) */
+typedef struct ho_body
+{
+	f3 position; f4 orientation; f3 linmom, angmom;
+	float mass, massinv; m33 tensorinv_massless; m33 Iinv;
+	float radius, radius_inner;
+	f3 position_next; f4 orientation_next;
+	f3 position_start; f4 orientation_start;
+	float damping, gravscale, friction; int collide; f3 com;
+	ho_shape shape;
+} ho_body;
+
+typedef struct ho_joint { int rbi0, rbi1; f3 p0, p1, rangemin, rangemax; f4 jointframe; } ho_joint;   /* physmodel.h:238-245 */
+
+typedef struct ho_model
+{
+	int nb, nj;
+	ho_body bodies[HO_MAXB];
+	ho_joint joints[HO_MAXJ];
+	unsigned char ignore[HO_MAXB][HO_MAXB];
+} ho_model;
+
+/* LimitLinear physics.h:270-308, LimitAngular physics.h:239-266; bodies by index, -1 = NULL.
+ * ub: the row acts on the transient single "unibody" of UnibodyFit instead of model bodies. */
+typedef struct ho_linear { int rb0, rb1; f3 position0, position1, normal; float targetdist, targetspeednobias; f2 forcelimit; int friction_master; float targetspeed, impulsesum; } ho_linear;
+typedef struct ho_angular { int rb0, rb1; f3 axis; float torque, targetspin, mintorque, maxtorque; } ho_angular;
+
+typedef struct ho_contact { int rb0, rb1; f3 normal, p0w, p1w; float separation; f3 p0, p1; } ho_contact;   /* PhysContact physics.h:425-434 */
+
+typedef struct ho_physics   /* physics.h:34-47 with the HandTracker ctor overrides handtrack.h:837-838 */
+{
+	float deltaT, restitution; f3 gravity; float coloumb, biasfactorjoint, biasfactorpositive, biasfactornegative, falltime_to_ballistic, driftmax, damping;
+	int iterations, iterations_post, use_collision; float weak_force, bone_sum_error_scale, unibody_force;
+} ho_physics;
+
+typedef struct ho_camera { int w, h; f2 focal, principal; float depth_scale; pose_t pose; } ho_camera;   /* DCamera misc_image.h:30-55 */
+
+typedef struct ho_analysis   /* CNNOutputAnalysis handtrack.h:182-242 */
+{
+	f4 crays[HO_NLANDMARK]; f2 image_points[HO_NLANDMARK]; float confidence[HO_NLANDMARK];
+	float vals[HO_NKEYANGLE]; float wristroll, pitch, tilt; f4 palmq; float finger_clenched[5];
+} ho_analysis;
+
+typedef struct ho_params   /* HandTracker fields handtrack.h:523-547 */
+{
+	float segment_scale, full_reset_on_error; int angles_only, always_take_cnn; float drangey; int boundary_planes; float microforce, cloudforce_max_point, cloudforce_max_sum;
+	int mainthreadpasses, subsample_fraction; int min_point_num; float accum_error_threshold, min_cray_prob;
+	int steps, steps_keypoints, steps_keyangles, steps_palmangle, steps_cloudstart, steps_unibody;
+} ho_params;
+
+typedef struct ho_tracker
+{
+	ho_physics phys; ho_params par;
+	ho_model handmodel, othermodel;
+	ho_body unibody_proto;              /* the 0.1 m cube of UnibodyFit handtrack.h:454-455 */
+	float *weights; size_t nweights;
+	float prev_frame_error; int initializing;
+	float cnn_input[4096], cnn_output[HO_NCNN_OUT]; ho_analysis analysis;
+	/* statistics of the last update (for benches/tests) */
+	int last_npoints, last_ncontacts, last_accept;
+} ho_tracker;
+
+/* ---- lifecycle ---- */
+ho_tracker *ho_create(const char *model_htfx_path);
+void ho_destroy(ho_tracker *t);
+int ho_load_weights(ho_tracker *t, const float *w, size_t n);          /* .cnnb order, cnn.h:590 */
+void ho_default_params(ho_params *p);
+void ho_set_state(ho_tracker *t, int which, const float *state13);      /* which: 0 handmodel 1 othermodel; [nb][13] pos quat linmom angmom */
+void ho_get_state(ho_tracker *t, int which, float *state13);
+void ho_set_pose(ho_tracker *t, int which, const float *pose7);         /* PhysModel::SetPose: momenta untouched */
+void ho_reset_tracker(ho_tracker *t, const float *pose7);               /* both models to pose, zero momenta, prev_frame_error=0, initializing=0 */
+
+/* ---- stages ---- */
+void ho_cnn_eval(const float *weights, const float *input, float *output, float *const *layers);
+void ho_cnn_input(const uint16_t *depth, int n, float depth_scale, float drange_x, float drange_y, float *out);
+void ho_decode(const float *cnn_output, const ho_camera *hcam, ho_analysis *out);
+int ho_pointcloud(const uint16_t *depth, const ho_camera *cam, float rmin, float rmax, int fraction, f3 *out, int cap, int *n_full);
+float ho_fit_error(ho_tracker *t, ho_model *m, const f3 *pts, int n, const uint16_t *depth, const ho_camera *cam);
+int ho_closest(ho_model *m, f3 v, f4 *plane);
+ho_linear ho_cloud_constraint(ho_model *m, f3 v, f3 origin);
+void ho_enhancements(ho_tracker *t, ho_model *m, ho_angular *ang, int *nang, int tiepinkyringmid, f3 palmxdir, f3 armdir, int fingerhold);
+int ho_joint_linears(ho_model *m, ho_linear *out);
+int ho_joint_angulars(ho_tracker *t, ho_model *m, ho_angular *out);
+int ho_apply_angles(ho_tracker *t, ho_model *m, const ho_analysis *an, pose_t camera_pose, float drive_force, float coneangle, ho_angular *out);
+int ho_cloud_chamber(ho_model *m, const f3 *pts, int n, ho_linear *out, float maxforce);
+int ho_find_contacts(ho_tracker *t, ho_model *m, ho_contact *out, int cap);
+void ho_physics_update(ho_tracker *t, ho_body **bodies, int nb, ho_model *model_for_collision, ho_linear *lin, int nlin, int lincap, ho_angular *ang, int nang);
+void ho_fit_pointcloud(ho_tracker *t, ho_model *m, const f3 *pts, int n, const ho_linear *lin_in, int nlin_in, const ho_angular *ang_in, int nang_in, float microforce);
+void ho_multistep(ho_tracker *t, ho_model *m, const ho_analysis *an, const f3 *vpts, int n, pose_t camera_pose);
+void ho_pose_from_scratch(ho_tracker *t, ho_model *m, const f3 *pts, int n, const ho_analysis *an, pose_t camera_pose);
+void ho_unibody_fit(ho_tracker *t, ho_model *m, const f3 *pts, int n, f3 camera_position);
+
+/* GJK (gjk.h) on two posed bodies of a model */
+typedef struct ho_gjk_contact { f3 normal, p0w, p1w, impact; float separation, dist; int type; } ho_gjk_contact;
+ho_gjk_contact ho_separated_bodies(const ho_body *a, const ho_body *b);
+int ho_contact_patch_bodies(const ho_body *a, const ho_body *b, float max_separation, ho_gjk_contact *out5);
+
+/* ---- the unit of work: update_cnn_model + mainthreadpasses passes (handtrack.h:693-785, synchronous) ---- */
+int ho_update_cnn_model(ho_tracker *t, const uint16_t *depth, const ho_camera *cam, float *pose_out7);   /* returns number of poses (0 or nb) */
+void ho_update(ho_tracker *t, const uint16_t *depth, const ho_camera *cam, float *pose_user_out7);
+
+/* flat helpers for ctypes */
+void ho_camera_from12(const float *c12, int w, int h, ho_camera *cam);
+int ho_sizeof_tracker(void);
+ho_model *ho_model_ptr(ho_tracker *t, int which);
+ho_body *ho_body_ptr(ho_model *m, int b);
+#ifdef __cplusplus
+}
+#endif
+#endif
