@@ -1,0 +1,338 @@
+// ht_api.hip -- the C-ABI layer (include/ht_mi355x.h): context, device memory, launch sequencing.
+// Host code stays C++ and only sequences hand-written HIP kernels; there is no CPU fallback: every entry point fails with
+// HT_ERR_HIP when no gfx950 device is usable.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <map>
+#include "ht_device.hpp"
+#include "ht_host.hpp"
+
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return HT_ERR_HIP; } } while (0)
+
+// ------------------------------------------------------------------------------------------------- HTFX container (baked model)
+struct fx_arr { uint32_t dtype, ndim, dims[4]; std::vector<unsigned char> data; const float *f() const { return (const float *)data.data(); } const int *i() const { return (const int *)data.data(); } };
+static bool fx_load(const char *path, std::map<std::string, fx_arr> &out)
+{
+	FILE *fp = fopen(path, "rb");
+	if (!fp) return false;
+	char magic[8]; uint32_t count;
+	if (fread(magic, 1, 8, fp) != 8 || memcmp(magic, "HTFX0001", 8) || fread(&count, 4, 1, fp) != 1) { fclose(fp); return false; }
+	for (uint32_t i = 0; i < count; i++)
+	{
+		char nm[48]; fx_arr a; uint64_t n;
+		if (fread(nm, 1, 48, fp) != 48 || fread(&a.dtype, 4, 1, fp) != 1 || fread(&a.ndim, 4, 1, fp) != 1 || fread(a.dims, 4, 4, fp) != 4 || fread(&n, 8, 1, fp) != 1) { fclose(fp); return false; }
+		a.data.resize(n);
+		if (n && fread(a.data.data(), 1, n, fp) != n) { fclose(fp); return false; }
+		fseek(fp, (long)((8 - (n & 7)) & 7), SEEK_CUR);
+		nm[47] = 0;
+		out[nm] = std::move(a);
+	}
+	fclose(fp);
+	return true;
+}
+
+// ------------------------------------------------------------------------------------------------- context
+static void default_params(ht_params &p)     // handtrack.h:523-547, physics.h:45-47, physmodel.h:234, handtrack.h:369,450
+{
+	p.full_reset_on_error = 0.6f; p.angles_only = 0; p.always_take_cnn = 0; p.drangey = 0.7f; p.boundary_planes = 1; p.microforce = 1.0f;
+	p.cloudforce_max_point = 15.0f; p.cloudforce_max_sum = 3000.0f; p.mainthreadpasses = 1; p.subsample_fraction = 4; p.min_point_num = 400;
+	p.accum_error_threshold = 0.0f; p.min_cray_prob = 0.0f; p.steps = 5; p.steps_keypoints = 3; p.steps_keyangles = 2; p.steps_palmangle = 2; p.steps_cloudstart = 1; p.steps_unibody = 3;
+	p.physics_iterations = 16; p.physics_iterations_post = 4; p.physics_use_collision = 1; p.physics_weak_force = 0.4f; p.bone_sum_error_scale = 4.0f; p.unibody_force = 0.1f;
+}
+
+template <class T> static int dev_alloc(ht_ctx *ctx, T **p, size_t n)
+{
+	void *q = nullptr;
+	HIPCHK(ctx, hipMalloc(&q, n * sizeof(T)));
+	ctx->allocs.push_back(q);
+	*p = (T *)q;
+	return HT_OK;
+}
+template <class T> static int dev_upload(ht_ctx *ctx, T **p, const std::vector<T> &h)
+{
+	int r = dev_alloc(ctx, p, h.size() ? h.size() : 1);
+	if (r) return r;
+	if (h.size()) HIPCHK(ctx, hipMemcpy(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+	return HT_OK;
+}
+
+static int load_model(ht_ctx *ctx, const char *path)
+{
+	std::map<std::string, fx_arr> fx;
+	if (!fx_load(path, fx)) { ctx->err = std::string("cannot read baked model ") + path; return HT_ERR_IO; }
+	auto need = [&](const char *n) -> const fx_arr * { auto it = fx.find(n); if (it == fx.end()) { ctx->err = std::string("model entry missing: ") + n; return nullptr; } return &it->second; };
+	const fx_arr *a;
+	if (!(a = need("nb"))) return HT_ERR_IO; int nb = a->i()[0];
+	if (!(a = need("nj"))) return HT_ERR_IO; int nj = a->i()[0];
+	if (nb < 1 || nb > HT_MAXNB || nj > HT_MAXNJ) { ctx->err = "model too large"; return HT_ERR_IO; }
+	ht_model_dev &m = ctx->model;
+	memset(&m, 0, sizeof m);
+	m.nb = nb; m.nj = nj;
+	const fx_arr *bf = need("body_f"), *bc = need("body_collide"), *ig = need("ignore"), *ji = need("joint_i"), *jf = need("joint_f"), *ph = need("physics"), *ubv = need("unibody/verts"), *ubf = need("unibody/f");
+	if (!bf || !bc || !ig || !ji || !jf || !ph || !ubv || !ubf) return HT_ERR_IO;
+	const float *P = ph->f();
+	ht_physics_dev &phys = ctx->phys;
+	phys.deltaT = P[0]; phys.restitution = P[1]; phys.gravity_len = sqrtf((P[2] * P[2] + P[3] * P[3]) + P[4] * P[4]); phys.coloumb = P[5]; phys.biasfactorjoint = P[6]; phys.biasfactorpositive = P[7];
+	phys.falltime_to_ballistic = P[9]; phys.driftmax = P[10];
+	const float physics_damping = P[11];
+	std::vector<float4> verts, planes; std::vector<float> bodyc((size_t)nb * HT_BC, 0.0f), jointc((size_t)nj * HT_JC, 0.0f);
+	ctx->h_bodyc.clear();
+	for (int b = 0; b < nb; b++)
+	{
+		char nm[64];
+		snprintf(nm, sizeof nm, "b%d/verts", b); const fx_arr *v = need(nm); if (!v) return HT_ERR_IO;
+		snprintf(nm, sizeof nm, "b%d/planes", b); const fx_arr *pl = need(nm); if (!pl) return HT_ERR_IO;
+		m.vert_off[b] = (int)verts.size(); m.plane_off[b] = (int)planes.size();
+		float diam2 = 0.0f;
+		for (uint32_t i = 0; i < v->dims[0]; i++) verts.push_back(make_float4(v->f()[3 * i], v->f()[3 * i + 1], v->f()[3 * i + 2], 0.0f));
+		for (uint32_t i = 0; i < v->dims[0]; i++) for (uint32_t j = i + 1; j < v->dims[0]; j++)
+		{
+			float dx = v->f()[3 * i] - v->f()[3 * j], dy = v->f()[3 * i + 1] - v->f()[3 * j + 1], dz = v->f()[3 * i + 2] - v->f()[3 * j + 2];
+			float d2 = dx * dx + dy * dy + dz * dz; if (d2 > diam2) diam2 = d2;
+		}
+		for (uint32_t i = 0; i < pl->dims[0]; i++) planes.push_back(make_float4(pl->f()[4 * i], pl->f()[4 * i + 1], pl->f()[4 * i + 2], pl->f()[4 * i + 3]));
+		const float *r = bf->f() + 26 * b;     // mass massinv radius radius_inner damping friction gravscale com3 pos_start3 quat_start4 tensorinv9
+		float *c = &bodyc[(size_t)b * HT_BC];
+		c[HT_BC_MASS] = r[0]; c[HT_BC_MASSINV] = r[1]; c[HT_BC_RADIUS] = r[2]; c[HT_BC_RINNER] = r[3];
+		c[HT_BC_DAMPLEFT] = powf((1.0f - (r[4] < physics_damping ? physics_damping : r[4])), phys.deltaT);      // physics.h:506
+		c[HT_BC_FRICTION] = r[5]; c[HT_BC_DIAM] = sqrtf(diam2);
+		for (int i = 0; i < 3; i++) c[HT_BC_COM + i] = r[7 + i];
+		for (int i = 0; i < 3; i++) c[HT_BC_POS0 + i] = r[10 + i];
+		for (int i = 0; i < 4; i++) c[HT_BC_Q0 + i] = r[13 + i];
+		for (int i = 0; i < 9; i++) c[HT_BC_TINV + i] = r[17 + i];
+		m.collide[b] = bc->i()[b];
+		unsigned mask = 0; for (int j = 0; j < nb; j++) if (ig->i()[b * nb + j]) mask |= 1u << j;
+		m.ignore[b] = mask;
+	}
+	m.vert_off[nb] = (int)verts.size(); m.plane_off[nb] = (int)planes.size();
+	for (int j = 0; j < nj; j++)
+	{
+		float *c = &jointc[(size_t)j * HT_JC]; const float *r = jf->f() + 16 * j;
+		c[HT_JC_RB0] = (float)ji->i()[2 * j]; c[HT_JC_RB1] = (float)ji->i()[2 * j + 1];
+		for (int i = 0; i < 3; i++) { c[HT_JC_P0 + i] = r[i]; c[HT_JC_P1 + i] = r[3 + i]; c[HT_JC_RMIN + i] = r[6 + i]; c[HT_JC_RMAX + i] = r[9 + i]; }
+		for (int i = 0; i < 4; i++) c[HT_JC_FRAME + i] = r[12 + i];
+	}
+	{   // unibody cube: f = mass massinv radius damping friction gravscale com3 tensorinv9
+		const float *u = ubf->f();
+		m.ub_massinv = u[1];
+		m.ub_dampleft = powf((1.0f - (u[3] < physics_damping ? physics_damping : u[3])), phys.deltaT);
+		for (int i = 0; i < 3; i++) m.ub_com[i] = u[6 + i];
+		for (int i = 0; i < 9; i++) m.ub_tinv[i] = u[9 + i];
+	}
+	ctx->h_bodyc = bodyc; ctx->h_jointc = jointc;
+	float4 *dv, *dp; float *dbc, *djc;
+	int r;
+	if ((r = dev_upload(ctx, &dv, verts)) || (r = dev_upload(ctx, &dp, planes)) || (r = dev_upload(ctx, &dbc, bodyc)) || (r = dev_upload(ctx, &djc, jointc))) return r;
+	m.verts = dv; m.planes = dp; m.bodyc = dbc; m.jointc = djc;
+	return HT_OK;
+}
+
+static void sync_params(ht_ctx *ctx)
+{
+	ctx->phys.iterations = ctx->par.physics_iterations; ctx->phys.iterations_post = ctx->par.physics_iterations_post; ctx->phys.use_collision = ctx->par.physics_use_collision;
+	ctx->phys.weak_force = ctx->par.physics_weak_force; ctx->phys.bone_sum_error_scale = ctx->par.bone_sum_error_scale; ctx->phys.unibody_force = ctx->par.unibody_force;
+}
+
+extern "C" int ht_create(const char *model_path, int max_batch, int device, ht_ctx **out)
+{
+	if (!out || !model_path || max_batch < 1) return HT_ERR_ARG;
+	ht_ctx *ctx = new ht_ctx();
+	*out = ctx;      // returned even on failure so that ht_last_error can be read; caller destroys it
+	ctx->B = max_batch; ctx->device = device;
+	default_params(ctx->par);
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { ctx->err = "no HIP device: the MI355X hot path has no CPU fallback"; return HT_ERR_HIP; }
+	HIPCHK(ctx, hipSetDevice(device));
+	hipDeviceProp_t prop;
+	HIPCHK(ctx, hipGetDeviceProperties(&prop, device));
+	if (!strstr(prop.gcnArchName, "gfx950")) { ctx->err = std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only"; return HT_ERR_HIP; }
+	HIPCHK(ctx, hipStreamCreate(&ctx->stream));
+	int r = load_model(ctx, model_path);
+	if (r) return r;
+	sync_params(ctx);
+	r = ht_alloc_buffers(ctx);
+	if (r) return r;
+	ctx->ready = true;
+	return HT_OK;
+}
+extern "C" int ht_destroy(ht_ctx *ctx)
+{
+	if (!ctx) return HT_ERR_ARG;
+	for (void *p : ctx->allocs) (void)hipFree(p);
+	for (auto &kv : ctx->prof) for (hipEvent_t e : kv.second.ev) (void)hipEventDestroy(e);
+	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+	return HT_OK;
+}
+extern "C" const char *ht_last_error(const ht_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+extern "C" int ht_get_params(const ht_ctx *ctx, ht_params *p) { if (!ctx || !p) return HT_ERR_ARG; *p = ctx->par; return HT_OK; }
+extern "C" int ht_set_params(ht_ctx *ctx, const ht_params *p) { if (!ctx || !p) return HT_ERR_ARG; ctx->par = *p; sync_params(ctx); return HT_OK; }
+extern "C" int ht_model_info(const ht_ctx *ctx, int *nb, int *nj, int *mb) { if (!ctx) return HT_ERR_ARG; if (nb) *nb = ctx->model.nb; if (nj) *nj = ctx->model.nj; if (mb) *mb = ctx->B; return HT_OK; }
+
+#define CHECK_READY(ctx) do { if (!(ctx)) return HT_ERR_ARG; if (!(ctx)->ready) { (ctx)->err = "context not initialised (ht_create failed)"; return HT_ERR_STATE; } } while (0)
+#define CHECK_BATCH(ctx, B) do { if ((B) < 1 || (B) > (ctx)->B) { (ctx)->err = "batch exceeds the capacity given to ht_create"; return HT_ERR_ARG; } } while (0)
+
+// ------------------------------------------------------------------------------------------------- CNN
+extern "C" int ht_cnn_load_weights(ht_ctx *ctx, const float *w, size_t n)
+{
+	CHECK_READY(ctx);
+	if (!w || n != HT_CNNB_COUNT) { ctx->err = "weights: expected HT_CNNB_COUNT fp32 values in .cnnb order"; return HT_ERR_ARG; }
+	if (!ctx->d_weights) { int r = dev_alloc(ctx, &ctx->d_weights, (size_t)HT_CNNB_COUNT + 16384); if (r) return r; }
+	HIPCHK(ctx, hipMemcpy(ctx->d_weights, w, n * sizeof(float), hipMemcpyHostToDevice));
+	// conv2 weights repacked to [k][oc], k = (ky*4+kx)*16 + ic  (reference index: kx + 4*(ky + 4*(ic + 16*oc)), cnn.h:45-47)
+	const float *W2 = w + 416;
+	std::vector<float> w2p(16384);
+	for (int oc = 0; oc < 64; oc++) for (int ic = 0; ic < 16; ic++) for (int ky = 0; ky < 4; ky++) for (int kx = 0; kx < 4; kx++)
+		w2p[(size_t)((ky * 4 + kx) * 16 + ic) * 64 + oc] = W2[kx + 4 * (ky + 4 * (ic + 16 * oc))];
+	float *d = ctx->d_weights;
+	HIPCHK(ctx, hipMemcpy(d + HT_CNNB_COUNT, w2p.data(), 16384 * sizeof(float), hipMemcpyHostToDevice));
+	ht_cnn_weights &cw = ctx->cnnw;
+	cw.W1 = d; cw.B1 = d + 400; cw.W2p = d + HT_CNNB_COUNT; cw.B2 = d + 416 + 16384; cw.W3 = d + 416 + 16448; cw.B3 = cw.W3 + (size_t)2304 * 2048; cw.W4 = cw.B3 + 2048; cw.B4 = cw.W4 + (size_t)2048 * 2304;
+	ctx->have_weights = true;
+	return HT_OK;
+}
+static int cnn_forward(ht_ctx *ctx, const float *d_in, float *d_out, int B, hipStream_t s)
+{
+	if (!ctx->have_weights) { ctx->err = "CNN weights not loaded (ht_cnn_load_weights)"; return HT_ERR_STATE; }
+	ht_prof_scope p0(ctx, "cnn", s);
+	ht_launch_cnn(ctx->cnnw, d_in, ctx->d_act1, ctx->d_act2, ctx->d_act3, ctx->d_logits, B, s);
+	ht_launch_softmax_decode(ctx->d_logits, d_out, nullptr, nullptr, 1, B, s);
+	return HT_OK;
+}
+extern "C" int ht_cnn_eval_dev(ht_ctx *ctx, const float *d_in, float *d_out, int B, void *stream)
+{
+	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	if (!d_in || !d_out) return HT_ERR_ARG;
+	int r = cnn_forward(ctx, d_in, d_out, B, (hipStream_t)stream);
+	if (r) return r;
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
+extern "C" int ht_cnn_eval(ht_ctx *ctx, const float *in, float *out, int B)
+{
+	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	if (!in || !out) return HT_ERR_ARG;
+	HIPCHK(ctx, hipMemcpyAsync(ctx->d_cnn_in, in, (size_t)B * HT_CNN_IN * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+	int r = cnn_forward(ctx, ctx->d_cnn_in, ctx->d_cnn_out, B, ctx->stream);
+	if (r) return r;
+	HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_cnn_out, (size_t)B * HT_CNN_OUT * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- stage: prepare / decode
+extern "C" int ht_stage_prepare(ht_ctx *ctx, const uint16_t *depth, const float *cams, int B, float *cnn_in, float *points, int *npoints)
+{
+	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	if (!depth || !cams) return HT_ERR_ARG;
+	hipStream_t s = ctx->stream;
+	HIPCHK(ctx, hipMemcpyAsync(ctx->d_depth, depth, (size_t)B * 4096 * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+	HIPCHK(ctx, hipMemcpyAsync(ctx->d_cams, cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyHostToDevice, s));
+	ht_launch_prepare(ctx->d_depth, ctx->d_cams, ctx->par.drangey, ctx->par.subsample_fraction, ctx->d_cnn_in, ctx->d_pts, ctx->d_npts, B, s);
+	if (cnn_in) HIPCHK(ctx, hipMemcpyAsync(cnn_in, ctx->d_cnn_in, (size_t)B * HT_CNN_IN * sizeof(float), hipMemcpyDeviceToHost, s));
+	if (points) HIPCHK(ctx, hipMemcpyAsync(points, ctx->d_pts, (size_t)B * HT_MAXPTS * sizeof(float4), hipMemcpyDeviceToHost, s));
+	if (npoints) HIPCHK(ctx, hipMemcpyAsync(npoints, ctx->d_npts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
+extern "C" int ht_stage_decode(ht_ctx *ctx, const float *cnn_out, const float *cams, int B, float *analysis)
+{
+	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	if (!cnn_out || !cams || !analysis) return HT_ERR_ARG;
+	hipStream_t s = ctx->stream;
+	HIPCHK(ctx, hipMemcpyAsync(ctx->d_cnn_out, cnn_out, (size_t)B * HT_CNN_OUT * sizeof(float), hipMemcpyHostToDevice, s));
+	HIPCHK(ctx, hipMemcpyAsync(ctx->d_cams, cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyHostToDevice, s));
+	ht_launch_softmax_decode(nullptr, ctx->d_cnn_out, ctx->d_cams, ctx->d_analysis, 0, B, s);
+	HIPCHK(ctx, hipMemcpyAsync(analysis, ctx->d_analysis, (size_t)B * HT_ANALYSIS * sizeof(float), hipMemcpyDeviceToHost, s));
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- profiling hooks
+// Each named phase records a pair of HIP events on the stream the kernels run on; pairs are pooled and only resolved in
+// ht_profile_read, so enabling the profile adds no host synchronisation to the launch sequence.
+ht_prof_scope::ht_prof_scope(ht_ctx *c, const char *name, hipStream_t s) : ctx(c), ent(nullptr), stream(s), slot(0)
+{
+	if (!c->profile) return;
+	auto it = c->prof.find(name);
+	if (it == c->prof.end()) { ht_prof_entry e; e.used = 0; e.total_ms = 0; e.launches = 0; it = c->prof.emplace(name, e).first; }
+	ht_prof_entry *e = &it->second;
+	if (e->used + 2 > e->ev.size())
+	{
+		hipEvent_t a, b;
+		if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+		e->ev.push_back(a); e->ev.push_back(b);
+	}
+	ent = e; slot = e->used; e->used += 2;
+	(void)hipEventRecord(e->ev[slot], s);
+}
+ht_prof_scope::~ht_prof_scope()
+{
+	if (!ent) return;
+	(void)hipEventRecord(ent->ev[slot + 1], stream);
+	ent->launches++;
+}
+static void prof_resolve(ht_prof_entry &e)
+{
+	for (size_t i = 0; i + 1 < e.used; i += 2)
+	{
+		float ms = 0;
+		if (hipEventSynchronize(e.ev[i + 1]) == hipSuccess && hipEventElapsedTime(&ms, e.ev[i], e.ev[i + 1]) == hipSuccess) e.total_ms += ms;
+	}
+	e.used = 0;
+}
+extern "C" int ht_profile_enable(ht_ctx *ctx, int on) { if (!ctx) return HT_ERR_ARG; ctx->profile = on != 0; return HT_OK; }
+extern "C" int ht_profile_read(ht_ctx *ctx, int reset, int max_entries, char *names, int name_stride, float *total_ms, int *launches, int *n_entries)
+{
+	if (!ctx || !n_entries) return HT_ERR_ARG;
+	int k = 0;
+	for (auto &kv : ctx->prof)
+	{
+		ht_prof_entry &e = kv.second;
+		prof_resolve(e);
+		if (k < max_entries)
+		{
+			if (names && name_stride > 0) { strncpy(names + (size_t)k * name_stride, kv.first.c_str(), name_stride - 1); names[(size_t)k * name_stride + name_stride - 1] = 0; }
+			if (total_ms) total_ms[k] = e.total_ms;
+			if (launches) launches[k] = e.launches;
+			k++;
+		}
+		if (reset) { e.total_ms = 0; e.launches = 0; }
+	}
+	*n_entries = k;
+	return HT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- buffers
+int ht_alloc_buffers(ht_ctx *ctx)
+{
+	const size_t B = (size_t)ctx->B, nb = (size_t)ctx->model.nb;
+	int r;
+#define A(ptr, n) if ((r = dev_alloc(ctx, &ctx->ptr, (n)))) return r
+	A(d_depth, B * 4096); A(d_cams, B * HT_CAM); A(d_cnn_in, B * HT_CNN_IN); A(d_act1, B * 3600); A(d_act2, B * 2304); A(d_act3, B * 2048);
+	A(d_logits, B * HT_CNN_OUT); A(d_cnn_out, B * HT_CNN_OUT); A(d_analysis, B * HT_ANALYSIS);
+	A(d_pts, B * HT_MAXPTS); A(d_npts, B);
+	A(d_state[0], B * nb * HT_STATE_STRIDE); A(d_state[1], B * nb * HT_STATE_STRIDE);
+	A(d_prev_err, B); A(d_initializing, B); A(d_err_old, B); A(d_err_new, B); A(d_flags, B);
+	A(d_rows, B * HT_MAXPTS * HT_ROW); A(d_nrows, B);
+	A(d_chamber, B * 5 * nb * HT_ROW);
+	A(d_contacts, B * HT_MAXCONTACT * HT_CONTACT); A(d_ncontacts, B);
+	A(d_scratch, B * (HT_MAXPTS + 5 * nb + 32) * 12);
+	A(d_poses_out, B * nb * HT_POSE); A(d_start, B * nb * HT_POSE);
+	A(d_stage, B * nb * HT_STATE_STRIDE);
+#undef A
+	HIPCHK(ctx, hipMemset(ctx->d_state[0], 0, B * nb * HT_STATE_STRIDE * sizeof(float)));
+	HIPCHK(ctx, hipMemset(ctx->d_state[1], 0, B * nb * HT_STATE_STRIDE * sizeof(float)));
+	HIPCHK(ctx, hipMemset(ctx->d_prev_err, 0, B * sizeof(float)));
+	HIPCHK(ctx, hipMemset(ctx->d_initializing, 0, B * sizeof(int)));
+	HIPCHK(ctx, hipMemset(ctx->d_npts, 0, B * sizeof(int)));
+	HIPCHK(ctx, hipMemset(ctx->d_nrows, 0, B * sizeof(int)));
+	HIPCHK(ctx, hipMemset(ctx->d_ncontacts, 0, B * sizeof(int)));
+	return HT_OK;
+}

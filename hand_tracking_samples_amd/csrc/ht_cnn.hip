@@ -1,0 +1,352 @@
+// ht_cnn.hip -- CDNA4 (gfx950) kernels for the depth-tile CNN of the hand tracker.
+//
+// Reference computation: CNN::Eval (third_party/cnn.h:550-556) over the topology of PoseInitializerCNN
+// (include/handtrack.h:108-118), preceded by the depth normalisation of handtrack.h:700 and the point-cloud
+// extraction of misc_image.h:409-417 / physmodel.h:58-64 (both read the same depth tile, so one kernel does both).
+//
+//   k_prepare   u16 depth tile -> fp32 CNN input + order-preserving compacted point cloud  (HBM-bound, 8 KB in / 16 KB out per frame)
+//   k_conv1     5x5x1->16 valid conv + 4x4 max-pool + tanh, input tile staged in LDS, fp32 VALU in the reference's tap order
+//   k_conv2     4x4x16->64 valid conv as an implicit GEMM on v_mfma_f32_16x16x4_f32, + 2x2 max-pool + tanh
+//   k_fc        [B,K]x[K,N]+bias (+tanh) on v_mfma_f32_32x32x2_f32, 128x64 block tile, LDS-staged, register prefetch
+//   k_softmax_decode   chunked softmax (cnn.h:497-511) fused with the heat-map decode (handtrack.h:218-241)
+//
+// Numerics: the MFMA accumulator starts at the bias and sums k in ascending order, which is the reference's own order
+// (cnn.h:219-226, 407-426); the only difference is one rounding per multiply-add instead of two.  max-pool commutes
+// with the monotone tanh, so tanh is applied after pooling (16x fewer exponentials in conv1).
+#include "ht_device.hpp"
+
+// ------------------------------------------------------------------------------------------------- k_prepare
+// one block per frame; thread t owns pixels [16t, 16t+16) so that a block-wide prefix sum keeps the row-major order
+__global__ __launch_bounds__(256) void k_prepare(const uint16_t *__restrict__ depth, const float *__restrict__ cams, float drangey, int fraction,
+                                                  float *__restrict__ cnn_in, float4 *__restrict__ pts, int *__restrict__ npts)
+{
+	const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const float *cam = cams + (size_t)b * HT_CAM;
+	const float fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3], dscale = cam[4];
+	const uint4 *src = reinterpret_cast<const uint4 *>(depth + (size_t)b * 4096 + 16 * t);
+	uint4 r0 = src[0], r1 = src[1];
+	unsigned w[8] = { r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w };
+	float d[16], cin[16];
+	int cnt = 0;
+	unsigned mask = 0;
+#pragma unroll
+	for (int i = 0; i < 16; i++)
+	{
+		unsigned px = (w[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
+		d[i] = (float)(int)px * dscale;
+		cin[i] = clamp_std(1.0f - (d[i] - 0.1f) / (drangey - 0.1f), 0.0f, 1.0f);     // handtrack.h:700
+		bool in = d[i] >= 0.1f && d[i] < drangey;                                     // FallsWithinRange misc_image.h:24
+		mask |= in ? (1u << i) : 0u;
+		cnt += in;
+	}
+	if (cnn_in)
+	{
+		float4 *dst = reinterpret_cast<float4 *>(cnn_in + (size_t)b * 4096 + 16 * t);
+#pragma unroll
+		for (int i = 0; i < 4; i++) dst[i] = make_float4(cin[4 * i], cin[4 * i + 1], cin[4 * i + 2], cin[4 * i + 3]);
+	}
+	// exclusive prefix of cnt over the 256 threads
+	int incl = cnt;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+	__shared__ int wsum[4];
+	if (lane == 63) wsum[wave] = incl;
+	__syncthreads();
+	int base = incl - cnt;
+	for (int i = 0; i < wave; i++) base += wsum[i];
+	if (pts)
+	{
+		int rank = base;
+#pragma unroll
+		for (int i = 0; i < 16; i++) if (mask & (1u << i))
+		{
+			if (rank % fraction == 0 && rank / fraction < HT_MAXPTS)
+			{
+				int p = 16 * t + i;
+				float x = (float)(p & 63), y = (float)(p >> 6);
+				pts[(size_t)b * HT_MAXPTS + rank / fraction] = make_float4(((x - cx) / fx) * d[i], ((y - cy) / fy) * d[i], 1.0f * d[i], 0.0f);   // deprojectz misc_image.h:48
+			}
+			rank++;
+		}
+	}
+	if (npts && t == 255)
+	{
+		int total = base + cnt;
+		int n = (total + fraction - 1) / fraction;
+		npts[b] = n < HT_MAXPTS ? n : HT_MAXPTS;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------- k_conv1
+__device__ __forceinline__ float tanh_ref(float t) { float e = (float)exp((double)(2 * t)); return (e - 1) / (e + 1); }   // cnn.h:31
+
+// block per frame; thread <-> pooled pixel (15x15), loops the 16 output channels over an 8x8 register patch
+__global__ __launch_bounds__(256) void k_conv1(const float *__restrict__ cnn_in, const float *__restrict__ W1, const float *__restrict__ B1, float *__restrict__ act1)
+{
+	__shared__ __attribute__((aligned(16))) float tile[64 * 64];
+	const int b = blockIdx.x, t = threadIdx.x;
+	const float4 *src = reinterpret_cast<const float4 *>(cnn_in + (size_t)b * 4096);
+	float4 *tl = reinterpret_cast<float4 *>(tile);
+#pragma unroll
+	for (int i = 0; i < 4; i++) tl[t + 256 * i] = src[t + 256 * i];
+	__syncthreads();
+	if (t >= 225) return;
+	const int px = t % 15, py = t / 15;
+	float patch[8][8];
+#pragma unroll
+	for (int r = 0; r < 8; r++)
+	{
+		float4 a = tl[((4 * py + r) * 64 + 4 * px) / 4], c = tl[((4 * py + r) * 64 + 4 * px) / 4 + 1];
+		patch[r][0] = a.x; patch[r][1] = a.y; patch[r][2] = a.z; patch[r][3] = a.w; patch[r][4] = c.x; patch[r][5] = c.y; patch[r][6] = c.z; patch[r][7] = c.w;
+	}
+	for (int c = 0; c < 16; c++)
+	{
+		float acc[4][4];
+		const float bias = B1[c];
+#pragma unroll
+		for (int oy = 0; oy < 4; oy++)
+#pragma unroll
+			for (int ox = 0; ox < 4; ox++) acc[oy][ox] = bias;
+#pragma unroll
+		for (int ky = 0; ky < 5; ky++)
+#pragma unroll
+			for (int kx = 0; kx < 5; kx++)
+			{
+				const float w = W1[c * 25 + ky * 5 + kx];           // W index = kx + 5*(ky + 5*(ic + 1*oc)), cnn.h:45-47,227
+#pragma unroll
+				for (int oy = 0; oy < 4; oy++)
+#pragma unroll
+					for (int ox = 0; ox < 4; ox++) acc[oy][ox] += patch[oy + ky][ox + kx] * w;
+			}
+		// two 2x2 max-pools (cnn.h:141-148) = max over the 4x4 block; std::max(a,b) = (a<b)?b:a
+		float m[2][2];
+#pragma unroll
+		for (int qy = 0; qy < 2; qy++)
+#pragma unroll
+			for (int qx = 0; qx < 2; qx++)
+				m[qy][qx] = fmax_std(fmax_std(fmax_std(acc[2 * qy][2 * qx], acc[2 * qy][2 * qx + 1]), acc[2 * qy + 1][2 * qx]), acc[2 * qy + 1][2 * qx + 1]);
+		float mm = fmax_std(fmax_std(fmax_std(m[0][0], m[0][1]), m[1][0]), m[1][1]);
+		act1[(size_t)b * 3600 + c * 225 + py * 15 + px] = tanh_ref(mm);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------- k_conv2
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// W2p: weights repacked to [k][oc] with k = (ky*4+kx)*16 + ic, i.e. the reference's accumulation order (cnn.h:223-225)
+__global__ __launch_bounds__(256) void k_conv2(const float *__restrict__ act1, const float *__restrict__ W2p, const float *__restrict__ B2, float *__restrict__ act2)
+{
+	__shared__ float in[3600];
+	__shared__ float out[64 * 144];
+	const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	for (int i = t; i < 3600; i += 256) in[i] = act1[(size_t)b * 3600 + i];
+	const int n = 16 * wave + (lane & 15);
+	float breg[64];
+#pragma unroll
+	for (int ks = 0; ks < 64; ks++) breg[ks] = W2p[(4 * ks + (lane >> 4)) * 64 + n];
+	const float bias = B2[n];
+	__syncthreads();
+	// per lane k decomposition is fixed per k-step: k = 4*ks + (lane>>4): tap p = k>>4 = ks>>2, ic = 4*(ks&3) + (lane>>4)
+	const int icl = lane >> 4;
+	for (int mt = 0; mt < 9; mt++)
+	{
+		const int m = mt * 16 + (lane & 15);
+		const int oy = m / 12, ox = m % 12;
+		f32x4 acc = { bias, bias, bias, bias };
+		const float *base = in + oy * 15 + ox;
+#pragma unroll
+		for (int ks = 0; ks < 64; ks++)
+		{
+			const int p = ks >> 2, ky = p >> 2, kx = p & 3, ic = 4 * (ks & 3) + icl;
+			float a = base[ic * 225 + ky * 15 + kx];
+			acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[ks], acc, 0, 0, 0);
+		}
+		// C/D map 16x16: col = lane&15 (oc), row = (lane>>4)*4 + r (pixel within the tile)
+#pragma unroll
+		for (int r = 0; r < 4; r++) out[n * 144 + mt * 16 + (lane >> 4) * 4 + r] = acc[r];
+	}
+	__syncthreads();
+	for (int i = t; i < 2304; i += 256)
+	{
+		const int c = i / 36, py = (i % 36) / 6, pxx = i % 6;
+		const float *o = out + c * 144 + (2 * py) * 12 + 2 * pxx;
+		float mm = fmax_std(fmax_std(fmax_std(o[0], o[1]), o[12]), o[13]);
+		act2[(size_t)b * 2304 + i] = tanh_ref(mm);        // index = x + 6y + 36c, the layout LFull consumes
+	}
+}
+
+// ------------------------------------------------------------------------------------------------- k_fc
+// C[M][N] = bias[N] + A[M][K] * W[K][N]  (W row-major as stored in the .cnnb, cnn.h:417)  [+ tanh]
+// block tile 128(M) x 64(N) x 32(K); 4 waves as 2(M) x 2(N); wave tile 64x32 = two 32x32x2 MFMA tiles.
+#define FC_BM 128
+#define FC_BN 64
+#define FC_BK 32
+#define FC_LDA (FC_BM + 1)
+template <bool TANH>
+__global__ __launch_bounds__(256) void k_fc(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K)
+{
+	__shared__ float As[FC_BK * FC_LDA];
+	__shared__ __attribute__((aligned(16))) float Bs[FC_BK * FC_BN];
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+	const int m0 = blockIdx.y * FC_BM, n0 = blockIdx.x * FC_BN;
+	// staging assignments
+	const int ar = t >> 3, akc = (t & 7) * 4;          // A: rows ar + 32*i, 4 consecutive k
+	const int bk = t >> 4, bnc = (t & 15) * 4;         // B: rows bk + 16*i, 4 consecutive n
+	float4 ra[4], rb[2];
+	auto gload = [&](int k0) {
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+		{
+			int row = m0 + ar + 32 * i;
+			ra[i] = row < M ? *reinterpret_cast<const float4 *>(A + (size_t)row * K + k0 + akc) : make_float4(0, 0, 0, 0);
+		}
+#pragma unroll
+		for (int i = 0; i < 2; i++) rb[i] = *reinterpret_cast<const float4 *>(W + (size_t)(k0 + bk + 16 * i) * N + n0 + bnc);
+	};
+	auto lstore = [&]() {
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+		{
+			int row = ar + 32 * i;
+			As[(akc + 0) * FC_LDA + row] = ra[i].x; As[(akc + 1) * FC_LDA + row] = ra[i].y; As[(akc + 2) * FC_LDA + row] = ra[i].z; As[(akc + 3) * FC_LDA + row] = ra[i].w;
+		}
+#pragma unroll
+		for (int i = 0; i < 2; i++) *reinterpret_cast<float4 *>(Bs + (bk + 16 * i) * FC_BN + bnc) = rb[i];
+	};
+	const float bv = bias[n0 + wn * 32 + (lane & 31)];
+	f32x16 acc0, acc1;
+#pragma unroll
+	for (int r = 0; r < 16; r++) { acc0[r] = bv; acc1[r] = bv; }
+	gload(0);
+	for (int k0 = 0; k0 < K; k0 += FC_BK)
+	{
+		__syncthreads();
+		lstore();
+		__syncthreads();
+		if (k0 + FC_BK < K) gload(k0 + FC_BK);
+		const float *ap = As + (lane >> 5) * FC_LDA + wm * 64 + (lane & 31);
+		const float *bp = Bs + (lane >> 5) * FC_BN + wn * 32 + (lane & 31);
+#pragma unroll
+		for (int kk = 0; kk < FC_BK / 2; kk++)
+		{
+			float a0 = ap[2 * kk * FC_LDA], a1 = ap[2 * kk * FC_LDA + 32], bb = bp[2 * kk * FC_BN];
+			acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bb, acc0, 0, 0, 0);
+			acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bb, acc1, 0, 0, 0);
+		}
+	}
+	// C/D map 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+	const int col = n0 + wn * 32 + (lane & 31);
+#pragma unroll
+	for (int r = 0; r < 16; r++)
+	{
+		int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+		int g0 = m0 + wm * 64 + row, g1 = g0 + 32;
+		float v0 = acc0[r], v1 = acc1[r];
+		if (TANH) { v0 = tanh_ref(v0); v1 = tanh_ref(v1); }
+		if (g0 < M) C[(size_t)g0 * N + col] = v0;
+		if (g1 < M) C[(size_t)g1 * N + col] = v1;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------- k_softmax_decode
+// one wave per frame.  softmax chunks: 8 x 256 then 16 x 16 (handtrack.h:118); sums run in ascending order like cnn.h:503-505.
+// analysis layout (HT_ANALYSIS floats): crays 8x4 | image_points 8x2 | confidence 8 | vals 16 | wristroll pitch tilt | palmq 4 | clenched 5
+__device__ void decode_frame(const float *__restrict__ y, const float *__restrict__ cam, float *__restrict__ an, int lane)
+{
+	// hcam = camsub(cam,4) misc_image.h:60
+	const float fx = cam[0] / 4.0f, fy = cam[1] / 4.0f, cx = cam[2] / 4.0f, cy = cam[3] / 4.0f;
+	if (lane < 8)
+	{
+		const float *base = y + 256 * lane;
+		int mxx = 0, mxy = 0; float best = base[0];
+		for (int i = 1; i < 256; i++) { float v = base[i]; if (v > best) { best = v; mxx = i & 15; mxy = i >> 4; } }      // ImageFindMax misc_image.h:298-305
+		float wsum = 0.0f, vx = 0.0f, vy = 0.0f;
+		for (int sy = max(0, mxy - 1); sy < min(16, mxy + 2); sy++) for (int sx = max(0, mxx - 1); sx < min(16, mxx + 2); sx++)
+		{
+			float w = base[sy * 16 + sx];
+			vx = vx + (float)sx * w; vy = vy + (float)sy * w; wsum += w;                                                   // PeakSubPixel misc_image.h:312-325
+		}
+		float px, py;
+		if (wsum == 0) { px = (float)mxx; py = (float)mxy; } else { px = vx / wsum; py = vy / wsum; }
+		int ix = (int)(px + 0.5f), iy = (int)(py + 0.5f);
+		float vol = 0.0f;
+		for (int sy = max(0, iy - 1); sy < min(16, iy + 2); sy++) for (int sx = max(0, ix - 1); sx < min(16, ix + 2); sx++) vol += base[sy * 16 + sx];   // PeakVolume :328-336
+		xf cp = XF(V3(cam[5], cam[6], cam[7]), V4(cam[8], cam[9], cam[10], cam[11]));
+		v3 nrm = normalize(apply(cp, V3((px - cx) / fx, (py - cy) / fy, 1.0f) * 1.0f));
+		an[4 * lane + 0] = nrm.x; an[4 * lane + 1] = nrm.y; an[4 * lane + 2] = nrm.z; an[4 * lane + 3] = base[16 * mxy + mxx];
+		an[HT_AN_IMGPT + 2 * lane] = px; an[HT_AN_IMGPT + 2 * lane + 1] = py;
+		an[HT_AN_CONF + lane] = vol;
+	}
+	else if (lane < 24)
+	{
+		const int row = lane - 8;
+		const float *r = y + 2048 + 16 * row;
+		int p = 0;
+		for (int x = 1; x < 16; x++) if (r[p] < r[x]) p = x;                                                              // Peaks1D misc_image.h:389-399
+		float v = 0.0f, wsum = 0.0f;
+		for (int i = max(0, p - 1); i < min(16, p + 2); i++) { float w = r[i]; v += (float)i * w; wsum += w; }
+		an[HT_AN_VALS + row] = ((wsum == 0) ? (float)p : v / wsum) / (float)(16 - 1);
+	}
+}
+__device__ void calc_angles(float *an)      // handtrack.h:194-202
+{
+	const float *vals = an + HT_AN_VALS;
+	float wristroll = vals[0] * 3.1415f * 2.0f + 3.1415f / 2.0f;
+	float pitch = (vals[1] - 0.5f) * 3.1415f;
+	float tilt = (vals[2] - 0.5f) * 3.1415f;
+	v4 palmq = qmul(normalize(V4(1.0f, 0, 0, 1.0f)), qmul(quat_axis_angle(V3(-1, 0, 0), pitch), quat_axis_angle(V3(0, 0, 1), wristroll)));
+	an[HT_AN_ANGLES + 0] = wristroll; an[HT_AN_ANGLES + 1] = pitch; an[HT_AN_ANGLES + 2] = tilt;
+	an[HT_AN_PALMQ + 0] = palmq.x; an[HT_AN_PALMQ + 1] = palmq.y; an[HT_AN_PALMQ + 2] = palmq.z; an[HT_AN_PALMQ + 3] = palmq.w;
+	for (int i = 0; i < 5; i++) an[HT_AN_CLENCH + i] = vals[3 + i] * 3.1415f;
+}
+// softmax=1: logits -> probabilities (written to cnn_out) then decode; softmax=0: decode an existing cnn_out
+__global__ __launch_bounds__(64) void k_softmax_decode(const float *__restrict__ logits, float *__restrict__ cnn_out, const float *__restrict__ cams, float *__restrict__ analysis, int softmax)
+{
+	__shared__ float y[HT_CNN_OUT];
+	__shared__ float an[HT_ANALYSIS];
+	const int b = blockIdx.x, lane = threadIdx.x;
+	if (softmax)
+	{
+		for (int i = lane; i < HT_CNN_OUT; i += 64) y[i] = (float)exp((double)logits[(size_t)b * HT_CNN_OUT + i]);
+		__syncthreads();
+		if (lane < 24)
+		{
+			const int s = lane < 8 ? 256 : 16, base = lane < 8 ? 256 * lane : 2048 + 16 * (lane - 8);
+			float sum = 0.0f;
+			for (int i = base; i < base + s; i++) sum += y[i];
+			for (int i = base; i < base + s; i++) y[i] /= sum;
+		}
+		__syncthreads();
+		for (int i = lane; i < HT_CNN_OUT; i += 64) cnn_out[(size_t)b * HT_CNN_OUT + i] = y[i];
+	}
+	else
+	{
+		for (int i = lane; i < HT_CNN_OUT; i += 64) y[i] = cnn_out[(size_t)b * HT_CNN_OUT + i];
+		__syncthreads();
+	}
+	if (!analysis) return;
+	decode_frame(y, cams + (size_t)b * HT_CAM, an, lane);
+	__syncthreads();
+	if (lane == 0) calc_angles(an);
+	__syncthreads();
+	for (int i = lane; i < HT_ANALYSIS; i += 64) analysis[(size_t)b * HT_ANALYSIS + i] = an[i];
+}
+
+// ------------------------------------------------------------------------------------------------- host launchers
+void ht_launch_prepare(const uint16_t *depth, const float *cams, float drangey, int fraction, float *cnn_in, float4 *pts, int *npts, int B, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_prepare, dim3(B), dim3(256), 0, s, depth, cams, drangey, fraction, cnn_in, pts, npts);
+}
+void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, float *act2, float *act3, float *logits, int B, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_conv1, dim3(B), dim3(256), 0, s, cnn_in, w.W1, w.B1, act1);
+	hipLaunchKernelGGL(k_conv2, dim3(B), dim3(256), 0, s, act1, w.W2p, w.B2, act2);
+	dim3 g1(2048 / FC_BN, (B + FC_BM - 1) / FC_BM), g2(2304 / FC_BN, (B + FC_BM - 1) / FC_BM);
+	hipLaunchKernelGGL(k_fc<true>, g1, dim3(256), 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
+	hipLaunchKernelGGL(k_fc<false>, g2, dim3(256), 0, s, act3, w.W4, w.B4, logits, B, 2304, 2048);
+}
+void ht_launch_softmax_decode(const float *logits, float *cnn_out, const float *cams, float *analysis, int softmax, int B, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_softmax_decode, dim3(B), dim3(64), 0, s, logits, cnn_out, cams, analysis, softmax);
+}

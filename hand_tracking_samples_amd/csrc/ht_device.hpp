@@ -1,0 +1,84 @@
+// ht_device.hpp -- device-side data model shared by the kernels and the C-ABI layer (product code).
+//
+// HBM layout (per context, capacity = max_batch tracker slots; everything resident for the life of the context):
+//   constants  : model (vertices, planes, per-body and per-joint constants), CNN weights (37.8 MB, conv2 repacked k-major)
+//   per slot   : handmodel / othermodel state [nb][16] floats (pos3 quat4 linmom3 angmom3 pad3), prev_frame_error, initializing
+//   per frame  : depth u16[4096] (only for host-buffer calls), cam[12], cnn_in[4096], act1[3600], act2[2304], act3[2048],
+//                logits/cnn_out[2304], analysis[84], points float4[1024] + count, cloud rows [1024][16], chamber rows [5*nb][16],
+//                contacts, solver scratch (pre-computed row stream)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ht_mi355x.h"
+#include "ht_math.hpp"
+
+#define HT_MAXPTS 1024          // sub-sampled points per 64x64 frame (4096 / 4)
+#define HT_MAXNB 32             // bodies
+#define HT_MAXNJ 32             // joints
+#define HT_STATE_STRIDE 16      // floats per body in device state arrays
+#define HT_ROW 16               // floats per linear row: rb0 rb1 position0[3] position1[3] normal[3] targetdist targetspeednobias fmin fmax friction_master
+#define HT_AROW 8               // floats per angular row: rb0 rb1 axis[3] targetspin mintorque maxtorque
+#define HT_MAXCONTACT 96        // contacts kept per frame (3 rows each)
+#define HT_CONTACT 12           // floats per contact: rb0 rb1 normal[3] p0w[3] p1w[3] separation
+#define HT_MAXPAIRS 160         // candidate pair slots per frame
+
+// analysis layout (HT_ANALYSIS = 84 floats)
+#define HT_AN_CRAYS 0
+#define HT_AN_IMGPT 32
+#define HT_AN_CONF 48
+#define HT_AN_VALS 56
+#define HT_AN_ANGLES 72
+#define HT_AN_PALMQ 75
+#define HT_AN_CLENCH 79
+
+// per-body constants, 32 floats each
+#define HT_BC 32
+#define HT_BC_MASS 0
+#define HT_BC_MASSINV 1
+#define HT_BC_RADIUS 2
+#define HT_BC_RINNER 3
+#define HT_BC_DAMPLEFT 4        // powf(1 - max(damping, physics_damping), dt), physics.h:506 (constant per body)
+#define HT_BC_FRICTION 5
+#define HT_BC_DIAM 6            // max vertex-vertex distance (lets the contact patch skip provably rejected jiggle runs)
+#define HT_BC_COM 8             // 3
+#define HT_BC_POS0 12           // 3  position_start
+#define HT_BC_Q0 16             // 4  orientation_start
+#define HT_BC_TINV 20           // 9  tensorinv_massless, column major
+// per-joint constants, 24 floats each: rbi0 rbi1 p0[3] p1[3] rangemin[3] rangemax[3] jointframe[4]
+#define HT_JC 24
+#define HT_JC_RB0 0
+#define HT_JC_RB1 1
+#define HT_JC_P0 2
+#define HT_JC_P1 5
+#define HT_JC_RMIN 8
+#define HT_JC_RMAX 11
+#define HT_JC_FRAME 14
+
+struct ht_model_dev
+{
+	int nb, nj;
+	const float4 *verts;      // all bodies back to back (com-centred collision vertices)
+	const float4 *planes;     // all bodies back to back (local half-space planes)
+	const float *bodyc;       // [nb][HT_BC]
+	const float *jointc;      // [nj][HT_JC]
+	int vert_off[HT_MAXNB + 1];
+	int plane_off[HT_MAXNB + 1];
+	unsigned ignore[HT_MAXNB];          // bit j of ignore[i]: body i ignores body j (physmodel.h:260-277, handtrack.h:354-358)
+	int collide[HT_MAXNB];
+	// UnibodyFit's cube proxy (handtrack.h:454-455)
+	float ub_massinv, ub_dampleft; float ub_com[3]; float ub_tinv[9];
+};
+
+struct ht_physics_dev      // physics.h:34-47 after handtrack.h:837-838
+{
+	float deltaT, restitution, gravity_len, coloumb, biasfactorjoint, biasfactorpositive, falltime_to_ballistic, driftmax;
+	int iterations, iterations_post, use_collision;
+	float weak_force, bone_sum_error_scale, unibody_force;
+};
+
+struct ht_cnn_weights { const float *W1, *B1, *W2p, *B2, *W3, *B3, *W4, *B4; };
+
+// ---- kernel launchers (defined in the .hip files) ----
+void ht_launch_prepare(const uint16_t *depth, const float *cams, float drangey, int fraction, float *cnn_in, float4 *pts, int *npts, int B, hipStream_t s);
+void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, float *act2, float *act3, float *logits, int B, hipStream_t s);
+void ht_launch_softmax_decode(const float *logits, float *cnn_out, const float *cams, float *analysis, int softmax, int B, hipStream_t s);

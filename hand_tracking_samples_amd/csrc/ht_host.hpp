@@ -1,0 +1,47 @@
+// ht_host.hpp -- host-side context behind the C-ABI (product code).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+#include "ht_device.hpp"
+
+struct ht_prof_entry { std::vector<hipEvent_t> ev; size_t used; float total_ms; int launches; };
+
+struct ht_ctx
+{
+	bool ready = false, have_weights = false, profile = false;
+	int B = 0, device = 0;
+	std::string err;
+	hipStream_t stream = nullptr;
+	ht_params par;
+	ht_physics_dev phys;
+	ht_model_dev model;
+	ht_cnn_weights cnnw;
+	std::vector<float> h_bodyc, h_jointc;
+	std::vector<void *> allocs;
+	std::map<std::string, ht_prof_entry> prof;
+
+	// device buffers (capacity B frames / tracker slots)
+	float *d_weights = nullptr;
+	uint16_t *d_depth = nullptr;
+	float *d_cams = nullptr, *d_cnn_in = nullptr, *d_act1 = nullptr, *d_act2 = nullptr, *d_act3 = nullptr, *d_logits = nullptr, *d_cnn_out = nullptr, *d_analysis = nullptr;
+	float4 *d_pts = nullptr; int *d_npts = nullptr;
+	float *d_state[2] = { nullptr, nullptr };      // [B][nb][HT_STATE_STRIDE]: 0 handmodel, 1 othermodel
+	float *d_prev_err = nullptr; int *d_initializing = nullptr;
+	float *d_err_old = nullptr, *d_err_new = nullptr; int *d_flags = nullptr;
+	float *d_rows = nullptr; int *d_nrows = nullptr;            // cloud rows [B][HT_MAXPTS][HT_ROW]
+	float *d_chamber = nullptr;                                  // [B][5*nb][HT_ROW]
+	float *d_contacts = nullptr; int *d_ncontacts = nullptr;    // [B][HT_MAXCONTACT][HT_CONTACT]
+	float *d_scratch = nullptr;                                  // solver row stream [B][HT_MAXPTS + 5*nb + 32][12]
+	float *d_poses_out = nullptr, *d_start = nullptr;
+	float *d_stage = nullptr;                                    // staging for host<->device state copies
+};
+
+struct ht_prof_scope
+{
+	ht_ctx *ctx; ht_prof_entry *ent; hipStream_t stream; size_t slot;
+	ht_prof_scope(ht_ctx *c, const char *name, hipStream_t s);
+	~ht_prof_scope();
+};
+
+int ht_alloc_buffers(ht_ctx *ctx);

@@ -1,0 +1,247 @@
+"""ctypes binding of libht_mi355x.so (the C-ABI declared in include/ht_mi355x.h).
+
+There is no CPU fallback: if the library is missing it is built with hipcc; if it cannot be loaded, or a context cannot be
+created on a gfx950 device, an exception is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HT_OK = 0
+CNN_IN, CNN_OUT, CNNB_COUNT, POSE, STATE, CAM, ANALYSIS = 4096, 2304, 9458400, 7, 13, 12, 84
+MAXPTS, ROW, CONTACT = 1024, 16, 12
+
+# every symbol include/ht_mi355x.h declares (checked by tests/test_abi.py)
+SYMBOLS = (
+    "ht_create", "ht_destroy", "ht_last_error", "ht_get_params", "ht_set_params", "ht_model_info",
+    "ht_cnn_load_weights", "ht_cnn_eval", "ht_cnn_eval_dev",
+    "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_update_sync", "ht_update_dev",
+    "ht_stage_prepare", "ht_stage_decode", "ht_stage_fit_error", "ht_stage_cloud_rows", "ht_stage_contacts", "ht_stage_fit",
+    "ht_stage_multistep", "ht_stage_scratch_unibody", "ht_profile_enable", "ht_profile_read",
+)
+
+
+class Params(C.Structure):
+    _fields_ = [("full_reset_on_error", C.c_float), ("angles_only", C.c_int), ("always_take_cnn", C.c_int), ("drangey", C.c_float), ("boundary_planes", C.c_int),
+                ("microforce", C.c_float), ("cloudforce_max_point", C.c_float), ("cloudforce_max_sum", C.c_float), ("mainthreadpasses", C.c_int),
+                ("subsample_fraction", C.c_int), ("min_point_num", C.c_int), ("accum_error_threshold", C.c_float), ("min_cray_prob", C.c_float),
+                ("steps", C.c_int), ("steps_keypoints", C.c_int), ("steps_keyangles", C.c_int), ("steps_palmangle", C.c_int), ("steps_cloudstart", C.c_int), ("steps_unibody", C.c_int),
+                ("physics_iterations", C.c_int), ("physics_iterations_post", C.c_int), ("physics_use_collision", C.c_int),
+                ("physics_weak_force", C.c_float), ("bone_sum_error_scale", C.c_float), ("unibody_force", C.c_float)]
+
+
+class HTError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load(build_if_missing=True):
+    """Load (building first if needed) the shared library; raises if that is impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing and _build.stale():
+        _build.build(verbose=False)
+    if not os.path.exists(_build.LIB):
+        raise HTError("libht_mi355x.so is missing and could not be built; the MI355X path has no fallback")
+    L = C.CDLL(_build.LIB)
+    fp, ip, vp = C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p
+    u16p = C.POINTER(C.c_uint16)
+    L.ht_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
+    L.ht_destroy.argtypes = [vp]
+    L.ht_last_error.argtypes = [vp]; L.ht_last_error.restype = C.c_char_p
+    L.ht_get_params.argtypes = [vp, C.POINTER(Params)]; L.ht_set_params.argtypes = [vp, C.POINTER(Params)]
+    L.ht_model_info.argtypes = [vp, ip, ip, ip]
+    L.ht_cnn_load_weights.argtypes = [vp, fp, C.c_size_t]
+    L.ht_cnn_eval.argtypes = [vp, fp, fp, C.c_int]
+    L.ht_cnn_eval_dev.argtypes = [vp, vp, vp, C.c_int, vp]
+    L.ht_tracker_reset.argtypes = [vp, C.c_int, C.c_int, fp]
+    L.ht_get_state.argtypes = [vp, C.c_int, C.c_int, C.c_int, fp]; L.ht_set_state.argtypes = [vp, C.c_int, C.c_int, C.c_int, fp]
+    L.ht_get_tracker_flags.argtypes = [vp, C.c_int, C.c_int, fp, ip]
+    L.ht_update_sync.argtypes = [vp, u16p, fp, C.c_int, fp, fp]
+    L.ht_update_dev.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp]
+    L.ht_stage_prepare.argtypes = [vp, u16p, fp, C.c_int, fp, fp, ip]
+    L.ht_stage_decode.argtypes = [vp, fp, fp, C.c_int, fp]
+    L.ht_stage_fit_error.argtypes = [vp, C.c_int, C.c_int, fp]
+    L.ht_stage_cloud_rows.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, fp, ip]
+    L.ht_stage_contacts.argtypes = [vp, C.c_int, C.c_int, C.c_int, fp, ip]
+    L.ht_stage_fit.argtypes = [vp, C.c_int]
+    L.ht_stage_multistep.argtypes = [vp, fp, C.c_int]
+    L.ht_stage_scratch_unibody.argtypes = [vp, fp, C.c_int, C.c_int]
+    L.ht_profile_enable.argtypes = [vp, C.c_int]
+    L.ht_profile_read.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_int, fp, ip, ip]
+    for name in SYMBOLS:
+        if name != "ht_last_error":
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def _f(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _i(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _c(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+class Context:
+    """One (GPU, stream) context = the batched counterpart of a HandTracker object (handtrack.h:513-846)."""
+
+    def __init__(self, model_path, max_batch, device=0):
+        self.L = load()
+        self.h = C.c_void_p()
+        rc = self.L.ht_create(os.fsencode(model_path), int(max_batch), int(device), C.byref(self.h))
+        if rc != HT_OK:
+            msg = self.L.ht_last_error(self.h).decode() if self.h else "ht_create failed"
+            if self.h:
+                self.L.ht_destroy(self.h)
+                self.h = C.c_void_p()
+            raise HTError("ht_create: %s (status %d)" % (msg, rc))
+        nb, nj, mb = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.L.ht_model_info(self.h, C.byref(nb), C.byref(nj), C.byref(mb)))
+        self.nb, self.nj, self.max_batch = nb.value, nj.value, mb.value
+
+    def close(self):
+        if self.h:
+            self.L.ht_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != HT_OK:
+            raise HTError("%s (status %d)" % (self.L.ht_last_error(self.h).decode(), rc))
+
+    # -- parameters
+    @property
+    def params(self):
+        p = Params()
+        self._chk(self.L.ht_get_params(self.h, C.byref(p)))
+        return p
+
+    def set_params(self, **kw):
+        p = self.params
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+        self._chk(self.L.ht_set_params(self.h, C.byref(p)))
+
+    # -- CNN
+    def load_weights(self, w):
+        w = _c(w, np.float32)
+        self._chk(self.L.ht_cnn_load_weights(self.h, _f(w), w.size))
+
+    def cnn_eval(self, x):
+        x = _c(x, np.float32).reshape(-1, CNN_IN)
+        out = np.empty((x.shape[0], CNN_OUT), np.float32)
+        self._chk(self.L.ht_cnn_eval(self.h, _f(x), _f(out), x.shape[0]))
+        return out
+
+    def cnn_eval_dev(self, d_in, d_out, B, stream):
+        self._chk(self.L.ht_cnn_eval_dev(self.h, d_in, d_out, B, stream))
+
+    # -- tracker
+    def tracker_reset(self, poses, first=0):
+        poses = _c(poses, np.float32).reshape(-1, self.nb, POSE)
+        self._chk(self.L.ht_tracker_reset(self.h, first, poses.shape[0], _f(poses)))
+
+    def get_state(self, which, n, first=0):
+        s = np.empty((n, self.nb, STATE), np.float32)
+        self._chk(self.L.ht_get_state(self.h, which, first, n, _f(s)))
+        return s
+
+    def set_state(self, which, state, first=0):
+        state = _c(state, np.float32).reshape(-1, self.nb, STATE)
+        self._chk(self.L.ht_set_state(self.h, which, first, state.shape[0], _f(state)))
+
+    def tracker_flags(self, n, first=0):
+        e = np.empty(n, np.float32); i = np.empty(n, np.int32)
+        self._chk(self.L.ht_get_tracker_flags(self.h, first, n, _f(e), _i(i)))
+        return e, i
+
+    def update_sync(self, depth, cams, want_cnn=False):
+        depth = _c(depth, np.uint16).reshape(-1, 4096)
+        cams = _c(cams, np.float32).reshape(-1, CAM)
+        B = depth.shape[0]
+        poses = np.empty((B, self.nb, POSE), np.float32)
+        cnn = np.empty((B, CNN_OUT), np.float32) if want_cnn else None
+        self._chk(self.L.ht_update_sync(self.h, depth.ctypes.data_as(C.POINTER(C.c_uint16)), _f(cams), B, _f(poses), _f(cnn) if want_cnn else None))
+        return (poses, cnn) if want_cnn else poses
+
+    def update_dev(self, d_depth, d_cams, d_start, B, d_poses_out, stream):
+        self._chk(self.L.ht_update_dev(self.h, d_depth, d_cams, d_start, B, d_poses_out, stream))
+
+    # -- stages
+    def stage_prepare(self, depth, cams):
+        depth = _c(depth, np.uint16).reshape(-1, 4096)
+        cams = _c(cams, np.float32).reshape(-1, CAM)
+        B = depth.shape[0]
+        cnn_in = np.empty((B, CNN_IN), np.float32); pts = np.empty((B, MAXPTS, 4), np.float32); n = np.empty(B, np.int32)
+        self._chk(self.L.ht_stage_prepare(self.h, depth.ctypes.data_as(C.POINTER(C.c_uint16)), _f(cams), B, _f(cnn_in), _f(pts), _i(n)))
+        return cnn_in, pts, n
+
+    def stage_decode(self, cnn_out, cams):
+        cnn_out = _c(cnn_out, np.float32).reshape(-1, CNN_OUT)
+        cams = _c(cams, np.float32).reshape(-1, CAM)
+        an = np.empty((cnn_out.shape[0], ANALYSIS), np.float32)
+        self._chk(self.L.ht_stage_decode(self.h, _f(cnn_out), _f(cams), cnn_out.shape[0], _f(an)))
+        return an
+
+    def stage_fit_error(self, which, B):
+        e = np.empty(B, np.float32)
+        self._chk(self.L.ht_stage_fit_error(self.h, which, B, _f(e)))
+        return e
+
+    def stage_cloud_rows(self, which, stride, use_cam_origin, B):
+        rows = np.empty((B, MAXPTS, ROW), np.float32); n = np.empty(B, np.int32)
+        self._chk(self.L.ht_stage_cloud_rows(self.h, which, stride, int(use_cam_origin), B, _f(rows), _i(n)))
+        return rows, n
+
+    def stage_contacts(self, which, B, cap=96):
+        c = np.empty((B, cap, CONTACT), np.float32); n = np.empty(B, np.int32)
+        self._chk(self.L.ht_stage_contacts(self.h, which, B, cap, _f(c), _i(n)))
+        return c, n
+
+    def stage_fit(self, B):
+        self._chk(self.L.ht_stage_fit(self.h, B))
+
+    def stage_multistep(self, analysis, B):
+        analysis = _c(analysis, np.float32).reshape(B, ANALYSIS)
+        self._chk(self.L.ht_stage_multistep(self.h, _f(analysis), B))
+
+    def stage_scratch_unibody(self, analysis, B, n_unibody):
+        analysis = _c(analysis, np.float32).reshape(B, ANALYSIS)
+        self._chk(self.L.ht_stage_scratch_unibody(self.h, _f(analysis), B, n_unibody))
+
+    # -- profiling
+    def profile_enable(self, on=True):
+        self._chk(self.L.ht_profile_enable(self.h, int(on)))
+
+    def profile_read(self, reset=True):
+        names = C.create_string_buffer(64 * 48); ms = np.zeros(64, np.float32); n = np.zeros(64, np.int32); k = C.c_int()
+        self._chk(self.L.ht_profile_read(self.h, int(reset), 64, names, 48, _f(ms), _i(n), C.byref(k)))
+        out = {}
+        for j in range(k.value):
+            out[names.raw[48 * j:48 * (j + 1)].split(b"\0", 1)[0].decode()] = (float(ms[j]), int(n[j]))
+        return out

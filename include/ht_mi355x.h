@@ -1,0 +1,137 @@
+/*
+ * ht_mi355x.h -- C-ABI of the MI355X-native hand-tracking hot path (libht_mi355x.so).
+ *
+ * This is the drop-in boundary for the per-frame path of IntelRealSense/hand_tracking_samples:
+ *   depth tile -> CNN forward (third_party/cnn.h) -> heat-map decode -> dynamics-based pose solver
+ *   (include/physmodel.h, third_party/physics.h, third_party/gjk.h) as driven by include/handtrack.h.
+ * The reference has no FFI (it is header-only C++), so each entry point cites the reference interface it replaces.
+ * C++ wrappers that keep the reference's own names (HandTracker::update, CNN::Eval ...) live in include/ht_handtrack.hpp;
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions: plain pointers and sizes, no exceptions across the ABI, every function returns an int status
+ * (HT_OK == 0); the caller owns all buffers it passes, the library owns its device memory; one context per
+ * (GPU, stream); a context is not thread safe.  *_dev entry points take DEVICE pointers and a hipStream_t
+ * (passed as void*) and are asynchronous; the others take HOST pointers and are synchronous.
+ *
+ * Layouts: a pose is 7 floats (position xyz, orientation quaternion xyzw) like Pose (third_party/geometric.h:111-125);
+ * a body state is 13 floats (pose, linear momentum, angular momentum, physics.h:103-116);
+ * a camera is 12 floats (focal xy, principal xy, depth_scale, pose) like DCamera (include/misc_image.h:30-55).
+ */
+#ifndef HT_MI355X_H
+#define HT_MI355X_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HT_OK 0
+#define HT_ERR_ARG 1          /* bad argument (NULL, size, batch > capacity) */
+#define HT_ERR_IO 2           /* file missing / malformed */
+#define HT_ERR_HIP 3          /* a HIP call failed (no device, out of memory, launch failure) */
+#define HT_ERR_STATE 4        /* call sequence error (e.g. weights not loaded) */
+
+#define HT_CNN_IN 4096        /* 64x64x1 input, handtrack.h:108 */
+#define HT_CNN_OUT 2304       /* 8 heat-maps 16x16 + 16 rows x 16 bins, handtrack.h:117-118 */
+#define HT_CNNB_COUNT 9458400 /* fp32 values in a .cnnb file, cnn.h:288,454,590 */
+#define HT_POSE 7
+#define HT_STATE 13
+#define HT_CAM 12
+#define HT_ANALYSIS 84        /* floats per frame, see ht_stage_decode */
+
+typedef struct ht_ctx ht_ctx;
+
+/* Tunables of HandTracker (handtrack.h:523-547) and the physics globals it sets (physics.h:34-47, handtrack.h:837-838). */
+typedef struct ht_params
+{
+	float full_reset_on_error;      /* 0.6   */
+	int   angles_only;              /* 0     */
+	int   always_take_cnn;          /* 0     */
+	float drangey;                  /* 0.7   */
+	int   boundary_planes;          /* 1     */
+	float microforce;               /* 1 (synthetic-tracker.cpp:92 sets 3) */
+	float cloudforce_max_point;     /* 15    */
+	float cloudforce_max_sum;       /* 3000  */
+	int   mainthreadpasses;         /* 1 (synthetic-tracker.cpp:93 sets 3) */
+	int   subsample_fraction;       /* 4     */
+	int   min_point_num;            /* 400   */
+	float accum_error_threshold;    /* 0     */
+	float min_cray_prob;            /* 0     */
+	int   steps, steps_keypoints, steps_keyangles, steps_palmangle, steps_cloudstart, steps_unibody;   /* 5 3 2 2 1 3 */
+	int   physics_iterations, physics_iterations_post, physics_use_collision;                          /* 16 4 1 */
+	float physics_weak_force;       /* 0.4 (physmodel.h:234) */
+	float bone_sum_error_scale;     /* 4   (handtrack.h:369) */
+	float unibody_force;            /* 0.1 (handtrack.h:450) */
+} ht_params;
+
+/* ---- lifecycle --------------------------------------------------------------------------------------------------
+ * ht_create      replaces  HandTracker::HandTracker() (handtrack.h:830-839): builds both hand models and the CNN topology.
+ *                model_path: a baked model (.htfx, see hand_tracking_samples_amd/model.py) holding what
+ *                PhysModel::PhysModel + LoadHandModel compute (physmodel.h:444-475, handtrack.h:347-366).
+ *                max_batch: number of independent tracker slots (frames processed per call).
+ * ht_destroy     replaces  HandTracker::~HandTracker() (handtrack.h:841-844). */
+int ht_create(const char *model_path, int max_batch, int device, ht_ctx **out);
+int ht_destroy(ht_ctx *ctx);
+const char *ht_last_error(const ht_ctx *ctx);
+int ht_get_params(const ht_ctx *ctx, ht_params *p);
+int ht_set_params(ht_ctx *ctx, const ht_params *p);                    /* replaces HandTracker::load_config / visit_fields (handtrack.h:549-581, 822-828) */
+int ht_model_info(const ht_ctx *ctx, int *n_bodies, int *n_joints, int *max_batch);
+
+/* ---- CNN ---------------------------------------------------------------------------------------------------------
+ * ht_cnn_load_weights  replaces  CNN::loadb(std::istream&) (cnn.h:590) / PoseInitializerCNN (handtrack.h:103-130): n must be HT_CNNB_COUNT.
+ * ht_cnn_eval          replaces  std::vector<float> CNN::Eval(const std::vector<float>&) (cnn.h:550-556) for B inputs at once:
+ *                      in [B][4096] -> out [B][2304]. */
+int ht_cnn_load_weights(ht_ctx *ctx, const float *weights, size_t n);
+int ht_cnn_eval(ht_ctx *ctx, const float *in, float *out, int B);
+int ht_cnn_eval_dev(ht_ctx *ctx, const float *d_in, float *d_out, int B, void *stream);
+
+/* ---- tracker -----------------------------------------------------------------------------------------------------
+ * ht_tracker_reset    replaces  handmodel.SetPose(p) + othermodel.SetPose(p) with momenta, prev_frame_error and initializing
+ *                     cleared (physmodel.h:435; what synthetic-tracker does implicitly at start).  poses [n][nb][7].
+ * ht_get_state / ht_set_state   read / write PhysModel rigid-body state (which: 0 handmodel, 1 othermodel), [n][nb][13].
+ * ht_update_sync      replaces  std::vector<Pose> HandTracker::update(Image<unsigned short>) (handtrack.h:748-785) for B independent
+ *                     trackers, with the background CNN job of :755-768 run synchronously every frame (= update_cnn_model, :734-741,
+ *                     then mainthreadpasses passes of :769-780).  depth [B][64*64] (64x64 tiles: HandSegmentVR is the identity,
+ *                     :283-284), cams [B][12], poses_out [B][nb][7] = GetPoseUser() (physmodel.h:434).
+ *                     cnn_out (optional, [B][2304]) receives HandTracker::cnn_output.
+ * ht_update_dev       the same on device buffers, asynchronous on `stream`; d_start_poses (optional, [B][nb][7]) re-seeds every
+ *                     tracker slot before the update (independent-frame batches, BASELINE config 3). */
+int ht_tracker_reset(ht_ctx *ctx, int first, int n, const float *poses);
+int ht_get_state(ht_ctx *ctx, int which, int first, int n, float *state);
+int ht_set_state(ht_ctx *ctx, int which, int first, int n, const float *state);
+int ht_get_tracker_flags(ht_ctx *ctx, int first, int n, float *prev_frame_error, int *initializing);
+int ht_update_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int B, float *poses_out, float *cnn_out);
+int ht_update_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, const float *d_start_poses, int B, float *d_poses_out, void *stream);
+
+/* ---- stage entry points (same kernels, exposed one reference function at a time so parity tests can pin each) -----
+ * All take HOST buffers and are synchronous.  `which` selects the model (0 handmodel, 1 othermodel) of slots [0,B).
+ * ht_stage_prepare    depth -> CNN input (handtrack.h:700) and sub-sampled point cloud (misc_image.h:409-417, physmodel.h:58-64):
+ *                     cnn_in [B][4096] (optional), points [B][1024][4] (optional), npoints [B] (optional).
+ * ht_stage_decode     CNNOutputAnalysis (handtrack.h:218-241): cnn_out [B][2304] -> analysis [B][HT_ANALYSIS]:
+ *                     crays 8x4 | image_points 8x2 | confidence 8 | vals 16 | wristroll pitch tilt | palmq 4 | finger_clenched 5.
+ * ht_stage_fit_error  FitError (handtrack.h:371-399) of model `which` against the prepared points / depth: err [B].
+ * ht_stage_cloud_rows CloudConstraints (physmodel.h:164-181) of model `which`, every `stride`-th prepared point, ray origin =
+ *                     camera position if use_cam_origin else 0: rows [B][1024][16] (layout: rb0 rb1 position0 position1 normal
+ *                     targetdist targetspeednobias forcelimit.xy friction_master), nrows [B].
+ * ht_stage_contacts   FindShapeShapeContacts (physics.h:451-462): contacts [B][cap][12] (rb0 rb1 normal p0w p1w separation), n [B].
+ * ht_stage_fit        one PhysModel::FitPointCloud(points, chamber-rows-if-enabled, HandModelEnhancements) pass on handmodel
+ *                     exactly as HandTracker::update runs it (handtrack.h:769-780).
+ * ht_stage_multistep  HandTracker::MultiStepSim on othermodel with the given analysis (handtrack.h:642-690). */
+int ht_stage_prepare(ht_ctx *ctx, const uint16_t *depth, const float *cams, int B, float *cnn_in, float *points, int *npoints);
+int ht_stage_decode(ht_ctx *ctx, const float *cnn_out, const float *cams, int B, float *analysis);
+int ht_stage_fit_error(ht_ctx *ctx, int which, int B, float *err);
+int ht_stage_cloud_rows(ht_ctx *ctx, int which, int stride, int use_cam_origin, int B, float *rows, int *nrows);
+int ht_stage_contacts(ht_ctx *ctx, int which, int B, int cap, float *contacts, int *ncontacts);
+int ht_stage_fit(ht_ctx *ctx, int B);
+int ht_stage_multistep(ht_ctx *ctx, const float *analysis, int B);
+int ht_stage_scratch_unibody(ht_ctx *ctx, const float *analysis, int B, int n_unibody);
+
+/* ---- timing hooks for bench.py: HIP-event time (ms) of the dominant kernels accumulated since the last reset ----- */
+int ht_profile_enable(ht_ctx *ctx, int on);
+int ht_profile_read(ht_ctx *ctx, int reset, int max_entries, char *names, int name_stride, float *total_ms, int *launches, int *n_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
