@@ -77,6 +77,9 @@ static int load_model(ht_ctx *ctx, const char *path)
 	ht_physics_dev &phys = ctx->phys;
 	phys.deltaT = P[0]; phys.restitution = P[1]; phys.gravity_len = sqrtf((P[2] * P[2] + P[3] * P[3]) + P[4] * P[4]); phys.coloumb = P[5]; phys.biasfactorjoint = P[6]; phys.biasfactorpositive = P[7];
 	phys.falltime_to_ballistic = P[9]; phys.driftmax = P[10];
+	phys.cos40d = cos((double)(40.0f * 3.14f / 180.0f));      // handtrack.h:437 (cos resolves to the double overload there)
+	phys.cos40 = (float)phys.cos40d;
+	phys.jiggle_sin = sinf(3.14f / 180.0f * (4.0f) / 2.0f);    // gjk.h:626-628
 	const float physics_damping = P[11];
 	std::vector<float4> verts, planes; std::vector<float> bodyc((size_t)nb * HT_BC, 0.0f), jointc((size_t)nj * HT_JC, 0.0f);
 	ctx->h_bodyc.clear();
@@ -321,7 +324,7 @@ int ht_alloc_buffers(ht_ctx *ctx)
 	A(d_state[0], B * nb * HT_STATE_STRIDE); A(d_state[1], B * nb * HT_STATE_STRIDE);
 	A(d_prev_err, B); A(d_initializing, B); A(d_err_old, B); A(d_err_new, B); A(d_flags, B);
 	A(d_rows, B * HT_MAXPTS * HT_ROW); A(d_nrows, B);
-	A(d_chamber, B * 5 * nb * HT_ROW);
+	A(d_chamber, B * 5 * nb * HT_ROW); A(d_nchamber, B); A(d_accepted, B);
 	A(d_contacts, B * HT_MAXCONTACT * HT_CONTACT); A(d_ncontacts, B);
 	A(d_scratch, B * (HT_MAXPTS + 5 * nb + 32) * 12);
 	A(d_poses_out, B * nb * HT_POSE); A(d_start, B * nb * HT_POSE);

@@ -1,0 +1,271 @@
+// ht_cloud.hip -- point-cloud side of the pose solver on CDNA4: closest-feature search, cloud constraint rows,
+// boundary ("chamber") planes and the fit-error metric.
+//
+// Reference computations:
+//   closest / mostabove                include/physmodel.h:127-162
+//   CloudConstraint(s), ConvexHitCheck include/physmodel.h:164-181, third_party/geometric.h:275-302, physics.h:328-331
+//   containing_plane / cloud_chamber   include/physmodel.h:183-193, 486-496, physics.h:347-350
+//   FitError                           include/handtrack.h:371-399
+//
+// Mapping: one lane per point (64 points per wave).  The per-body loop and the per-plane loops are wave-uniform, so plane
+// coefficients arrive through scalar loads and every active lane does the same 6 flops per plane; the sphere cull of
+// physmodel.h:153 is a per-lane predicate.  Body poses are expanded once per block into an LDS table (lane b <-> body b).
+// All arithmetic keeps the reference's evaluation order (-ffp-contract=off), so rows are bit-identical to the CPU path.
+#include "ht_device.hpp"
+#include "ht_launch.hpp"
+
+#define BT 32       // floats per body-table entry
+// pos 0..2 | q 3..6 | radius 7 | rinner 8 | invp 9..11 (= qrot(qconj(q), -pos)) | RI columns 12..20 (qmat(qconj(q))) | RF columns 21..29 (qmat(q))
+__device__ __forceinline__ void body_table_build(const ht_model_dev &M, const float *__restrict__ st, float *tab, int lane)
+{
+	if (lane < M.nb)
+	{
+		const float *s = st + lane * HT_STATE_STRIDE;
+		v3 pos = V3(s[0], s[1], s[2]); v4 q = V4(s[3], s[4], s[5], s[6]);
+		v4 qc = qconj(q);
+		v3 invp = qrot(qc, -pos);
+		m3 ri = qmat(qc), rf = qmat(q);
+		float *t = tab + lane * BT;
+		t[0] = pos.x; t[1] = pos.y; t[2] = pos.z; t[3] = q.x; t[4] = q.y; t[5] = q.z; t[6] = q.w;
+		t[7] = M.bodyc[lane * HT_BC + HT_BC_RADIUS]; t[8] = M.bodyc[lane * HT_BC + HT_BC_RINNER];
+		t[9] = invp.x; t[10] = invp.y; t[11] = invp.z;
+		t[12] = ri.x.x; t[13] = ri.x.y; t[14] = ri.x.z; t[15] = ri.y.x; t[16] = ri.y.y; t[17] = ri.y.z; t[18] = ri.z.x; t[19] = ri.z.y; t[20] = ri.z.z;
+		t[21] = rf.x.x; t[22] = rf.x.y; t[23] = rf.x.z; t[24] = rf.y.x; t[25] = rf.y.y; t[26] = rf.y.z; t[27] = rf.z.x; t[28] = rf.z.y; t[29] = rf.z.z;
+	}
+}
+__device__ __forceinline__ v3 tab_pos(const float *t) { return V3(t[0], t[1], t[2]); }
+__device__ __forceinline__ v3 tab_to_local(const float *t, v3 w)      // pose.inverse() * w  (geometric.h:119,122)
+{
+	v3 X = V3(t[12], t[13], t[14]), Y = V3(t[15], t[16], t[17]), Z = V3(t[18], t[19], t[20]);
+	return V3(t[9], t[10], t[11]) + ((X * w.x + Y * w.y) + Z * w.z);
+}
+__device__ __forceinline__ v3 tab_rot(const float *t, v3 v)           // qrot(q, v)
+{
+	v3 X = V3(t[21], t[22], t[23]), Y = V3(t[24], t[25], t[26]), Z = V3(t[27], t[28], t[29]);
+	return (X * v.x + Y * v.y) + Z * v.z;
+}
+__device__ __forceinline__ v3 tab_to_world(const float *t, v3 v) { return tab_pos(t) + tab_rot(t, v); }     // pose * v
+
+// closest(rigidbodies, v): physmodel.h:137-162.  `active` lanes carry a point; loops are wave-uniform.
+__device__ __forceinline__ void closest_feature(const ht_model_dev &M, const float *tab, bool active, v3 v, int &rbmin, v4 &pmin, float &dmin)
+{
+	pmin = V4(0, 0, 0, FLT_MAX);
+	dmin = dot_plane(pmin, v);
+	rbmin = -1;
+	for (int b = 0; b < M.nb; b++)
+	{
+		const float *t = tab + b * BT;
+		v3 n = safenormalize(v - tab_pos(t));
+		v4 p = V4(n, -dot(tab_pos(t), n) - t[8]);
+		float d = dot_plane(p, v);
+		if (d < dmin) { pmin = p; dmin = d; rbmin = b; }
+	}
+	for (int b = 0; b < M.nb; b++)
+	{
+		const float *t = tab + b * BT;
+		bool consider = active && !(length(v - tab_pos(t)) - t[7] > dmin);
+		if (!__any(consider)) continue;
+		v3 vl = tab_to_local(t, v);
+		const float4 *pl = M.planes + M.plane_off[b];
+		const int np = M.plane_off[b + 1] - M.plane_off[b];
+		float best = 0.0f; int bi = 0;
+		for (int i = 0; i < np; i++)
+		{
+			float4 q = pl[i];                                   // uniform address -> scalar load
+			float d = dot_plane(V4(q.x, q.y, q.z, q.w), vl);
+			if (i == 0 || best < d) { best = d; bi = i; }       // std::max_element: first maximum
+		}
+		if (consider)
+		{
+			float4 q = pl[bi];
+			v3 n = tab_rot(t, V3(q.x, q.y, q.z));               // Pose::TransformPlane geometric.h:124
+			v4 p = V4(n, q.w - dot(tab_pos(t), n));
+			float d = dot_plane(p, v);
+			if (d < dmin) { pmin = p; dmin = d; rbmin = b; }
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------- k_cloud_rows
+// mode 0: forcelimit (-1,1) (CloudConstraints as is)     1: FitPointCloud scaling (physmodel.h:347)
+//      2: MultiStepSim scaling (handtrack.h:656,681)     3: UnibodyFit scaling (handtrack.h:461)
+__global__ __launch_bounds__(64) void k_cloud_rows(ht_model_dev M, const float *__restrict__ state, const float4 *__restrict__ pts, const int *__restrict__ npts,
+                                                   const float *__restrict__ cams, const int *__restrict__ active_flag, int stride, int use_cam_origin, int mode,
+                                                   float microforce, float weak_force, float cf_max_point, float cf_max_sum, float unibody_force,
+                                                   float *__restrict__ rows, int *__restrict__ nrows)
+{
+	__shared__ float tab[HT_MAXNB * BT];
+	const int b = blockIdx.y, lane = threadIdx.x;
+	const int n = npts[b];
+	const int nsub = (n + stride - 1) / stride;
+	if (blockIdx.x == 0 && lane == 0) nrows[b] = (active_flag && !active_flag[b]) ? 0 : nsub;
+	if (active_flag && !active_flag[b]) return;
+	const int i = blockIdx.x * 64 + lane;
+	if (blockIdx.x * 64 >= nsub) return;
+	body_table_build(M, state + (size_t)b * M.nb * HT_STATE_STRIDE, tab, lane);
+	__syncthreads();
+	const bool active = i < nsub;
+	float4 pv = pts[(size_t)b * HT_MAXPTS + (active ? i * stride : 0)];
+	const v3 v = V3(pv.x, pv.y, pv.z);
+	const float *cam = cams + (size_t)b * HT_CAM;
+	const v3 origin = use_cam_origin ? V3(cam[5], cam[6], cam[7]) : V3(0, 0, 0);
+	int rb; v4 p; float dmin;
+	closest_feature(M, tab, active, v, rb, p, dmin);
+	if (rb < 0) rb = 0;
+	// ConvexHitCheck from the ray origin, only when the point faces away (physmodel.h:170)
+	const bool want = active && dot(v - origin, xyz(p)) > 0;
+	bool hit = false; v3 impact = V3(0, 0, 0);
+	for (int bb = 0; bb < M.nb; bb++)
+	{
+		bool mine = want && rb == bb;
+		if (!__any(mine)) continue;
+		const float *t = tab + bb * BT;
+		v3 v0 = tab_to_local(t, origin), v1 = tab_to_local(t, v);
+		const float4 *pl = M.planes + M.plane_off[bb];
+		const int np = M.plane_off[bb + 1] - M.plane_off[bb];
+		bool done = !mine, ok = true;
+		for (int k = 0; k < np; k++)
+		{
+			float4 q = pl[k];
+			v4 plane = V4(q.x, q.y, q.z, q.w);
+			float d0 = dot_plane(plane, v0), d1 = dot_plane(plane, v1);
+			if (!done)
+			{
+				if (d0 >= 0 && d1 >= 0) { ok = false; done = true; }
+				else if (!(d0 <= 0 && d1 <= 0))
+				{
+					v3 c = v0 + ((v1 - v0) * d0) / (d0 - d1);
+					if (d0 >= 0) v0 = c; else v1 = c;
+				}
+			}
+		}
+		if (mine && ok) { hit = true; impact = tab_to_world(t, v0); }
+	}
+	if (!active) return;
+	const float *t = tab + rb * BT;
+	v3 position1, normal;
+	if (hit) { position1 = tab_to_local(t, impact); normal = normalize(v - origin); }
+	else { position1 = tab_to_local(t, v - xyz(p) * dot_plane(p, v)); normal = xyz(p); }
+	const float targetdist = dot(tab_to_world(t, position1) - v, normal);                  // ConstrainAlongDirection physics.h:328-331
+	float fmin = -1.0f, fmax = 1.0f;
+	if (mode == 1) { float k = (rb == 0 || rb == 1 || rb == 2) ? weak_force : 1.0f; fmin = -1.0f * k * microforce; fmax = 1.0f * k * microforce; }
+	else if (mode == 2) { float cloudforce = fmin_std(cf_max_point, cf_max_sum / (float)n); float k = (rb == 0) ? 0.1f : 1.0f; fmin = -cloudforce * k; fmax = cloudforce * k; }
+	else if (mode == 3) { fmin = -1.0f * unibody_force; fmax = 1.0f * unibody_force; }
+	float4 *out = reinterpret_cast<float4 *>(rows + ((size_t)b * HT_MAXPTS + i) * HT_ROW);
+	out[0] = make_float4(-1.0f, (float)rb, v.x, v.y);
+	out[1] = make_float4(v.z, position1.x, position1.y, position1.z);
+	out[2] = make_float4(normal.x, normal.y, normal.z, targetdist);
+	out[3] = make_float4(0.0f, fmin_std(fmin, fmax), fmax_std(fmin, fmax), 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------- k_fit_error
+__global__ __launch_bounds__(256) void k_fit_error(ht_model_dev M, const float *__restrict__ state, const float4 *__restrict__ pts, const int *__restrict__ npts,
+                                                  const uint16_t *__restrict__ depth, const float *__restrict__ cams, float bone_sum_error_scale, float *__restrict__ err)
+{
+	__shared__ float tab[HT_MAXNB * BT];
+	__shared__ int perr[HT_MAXNB];
+	const int b = blockIdx.x, t = threadIdx.x;
+	if (t < 64) body_table_build(M, state + (size_t)b * M.nb * HT_STATE_STRIDE, tab, t);
+	if (t < HT_MAXNB) perr[t] = 0;
+	__syncthreads();
+	const int n = npts[b];
+	for (int base = 0; base < n; base += 256)
+	{
+		const int i = base + t;
+		const bool active = i < n;
+		float4 pv = pts[(size_t)b * HT_MAXPTS + (active ? i : 0)];
+		int rb; v4 p; float dmin;
+		closest_feature(M, tab, active, V3(pv.x, pv.y, pv.z), rb, p, dmin);
+		// pointerror[bone] = max(pointerror[bone], d) with pointerror starting at 0 (handtrack.h:376-383): only d > 0 matters,
+		// and for non-negative floats the integer order of the bit patterns is the float order
+		if (active && rb >= 0 && dmin > 0.0f) atomicMax(&perr[rb], __float_as_int(dmin));
+	}
+	__syncthreads();
+	if (t == 0)
+	{
+		float point_error_sum = 0.0f;
+		for (int k = 0; k < M.nb; k++) point_error_sum += __int_as_float(perr[k]);
+		const float *cam = cams + (size_t)b * HT_CAM;
+		xf ci = inverse(XF(V3(cam[5], cam[6], cam[7]), V4(cam[8], cam[9], cam[10], cam[11])));
+		float bone_error_sum = 0;
+		for (int k = 0; k < M.nb; k++)
+		{
+			v3 position = apply(ci, tab_pos(tab + k * BT));
+			int px = (int)(position.x / position.z * cam[0] + cam[2]), py = (int)(position.y / position.z * cam[1] + cam[3]);     // projectz misc_image.h:50
+			if (!(px >= 0 && px <= 63 && py >= 0 && py <= 63)) continue;
+			float bone_error = (float)(int)depth[(size_t)b * 4096 + py * 64 + px] * cam[4] - position.z;
+			bone_error_sum += clamp_std(bone_error, 0.0f, 0.01f);
+		}
+		err[b] = point_error_sum + bone_error_sum * bone_sum_error_scale;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------- k_chamber
+// 5 silhouette planes through the camera origin + one ConstrainUnderPlane row per (plane, body); rows [B][5*nb][HT_ROW], nch[b] = 0 or 5*nb
+__global__ __launch_bounds__(64) void k_chamber(ht_model_dev M, const float *__restrict__ state, const float4 *__restrict__ pts, const int *__restrict__ npts,
+                                                int min_point_num, int enabled, float maxforce, float *__restrict__ rows, int *__restrict__ nch)
+{
+	__shared__ float tab[HT_MAXNB * BT];
+	__shared__ float planes[5][4];
+	const int b = blockIdx.x, lane = threadIdx.x;
+	const int n = npts[b];
+	const bool on = enabled && n > min_point_num;        // handtrack.h:774
+	if (lane == 0) nch[b] = on ? 5 * M.nb : 0;
+	if (!on) return;
+	body_table_build(M, state + (size_t)b * M.nb * HT_STATE_STRIDE, tab, lane);
+	if (lane < 5)
+	{
+		const float od[5][3] = { { -1, -0.25f, 0 }, { -1, -1, 0 }, { 0, -1, 0 }, { 1, -1, 0 }, { 1, -0.25f, 0 } };    // handtrack.h:776
+		const v3 outdir = V3(od[lane][0], od[lane][1], od[lane][2]), origin = V3(0, 0, 0), viewdir = V3(0, 0, 1);
+		v3 best = viewdir - outdir;
+		best = best + origin;
+		v3 tangent = cross(best, outdir);
+		for (int i = 0; i < n; i++)
+		{
+			float4 pv = pts[(size_t)b * HT_MAXPTS + i];
+			v3 p = V3(pv.x, pv.y, pv.z);
+			if (dot(cross(best - origin, p - origin), tangent) > 0) best = p;
+		}
+		v3 nn = normalize(cross(tangent, best));
+		planes[lane][0] = nn.x; planes[lane][1] = nn.y; planes[lane][2] = nn.z; planes[lane][3] = -dot(nn, origin);
+	}
+	__syncthreads();
+	for (int item = lane; item < 5 * M.nb; item += 64)
+	{
+		const int d = item / M.nb, rb = item % M.nb;
+		const float *t = tab + rb * BT;
+		v4 plane = V4(planes[d][0], planes[d][1], planes[d][2], planes[d][3]);
+		// ConstrainUnderPlane physics.h:347-350: support vertex of the body against the plane normal (maxdir geometric.h:218-224)
+		v3 dirl = qrot(qconj(V4(t[3], t[4], t[5], t[6])), xyz(plane));
+		const float4 *vs = M.verts + M.vert_off[rb];
+		const int nv = M.vert_off[rb + 1] - M.vert_off[rb];
+		int bi = 0; float bd = 0.0f;
+		for (int k = 0; k < nv; k++) { float4 q = vs[k]; float dd = dot(V3(q.x, q.y, q.z), dirl); if (k == 0 || bd < dd) { bd = dd; bi = k; } }
+		float4 q = vs[bi];
+		v3 sv = V3(q.x, q.y, q.z);
+		v3 p0 = xyz(plane) * -plane.w, axis = -xyz(plane);
+		float targetdist = dot(tab_to_world(t, sv) - p0, axis);
+		float4 *out = reinterpret_cast<float4 *>(rows + ((size_t)b * 5 * M.nb + item) * HT_ROW);
+		out[0] = make_float4(-1.0f, (float)rb, p0.x, p0.y);
+		out[1] = make_float4(p0.z, sv.x, sv.y, sv.z);
+		out[2] = make_float4(axis.x, axis.y, axis.z, targetdist);
+		out[3] = make_float4(0.0f, fmin_std(0.0f, maxforce), fmax_std(0.0f, maxforce), 0.0f);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------- launchers
+void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const float *cams, const int *active_flag, int stride, int use_cam_origin, int mode,
+                          const ht_params &par, float *rows, int *nrows, int B, hipStream_t s)
+{
+	dim3 grid((HT_MAXPTS / stride + 63) / 64, B);
+	hipLaunchKernelGGL(k_cloud_rows, grid, dim3(64), 0, s, M, state, pts, npts, cams, active_flag, stride, use_cam_origin, mode, par.microforce, par.physics_weak_force,
+	                   par.cloudforce_max_point, par.cloudforce_max_sum, par.unibody_force, rows, nrows);
+}
+void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, float scale, float *err, int B, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_fit_error, dim3(B), dim3(256), 0, s, M, state, pts, npts, depth, cams, scale, err);
+}
+void ht_launch_chamber(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, int min_point_num, int enabled, float maxforce, float *rows, int *nch, int B, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_chamber, dim3(B), dim3(64), 0, s, M, state, pts, npts, min_point_num, enabled, maxforce, rows, nch);
+}

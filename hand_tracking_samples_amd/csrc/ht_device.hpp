@@ -74,6 +74,9 @@ struct ht_physics_dev      // physics.h:34-47 after handtrack.h:837-838
 	float deltaT, restitution, gravity_len, coloumb, biasfactorjoint, biasfactorpositive, falltime_to_ballistic, driftmax;
 	int iterations, iterations_post, use_collision;
 	float weak_force, bone_sum_error_scale, unibody_force;
+	float cos40;          // cos(40*3.14/180) evaluated in double like handtrack.h:437, rounded to float for transport and widened again on use
+	double cos40d;        // the double itself
+	float jiggle_sin;     // sinf(3.14f/180.0f*4.0f/2.0f), gjk.h:628
 };
 
 struct ht_cnn_weights { const float *W1, *B1, *W2p, *B2, *W3, *B3, *W4, *B4; };

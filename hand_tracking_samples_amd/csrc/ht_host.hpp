@@ -30,7 +30,8 @@ struct ht_ctx
 	float *d_prev_err = nullptr; int *d_initializing = nullptr;
 	float *d_err_old = nullptr, *d_err_new = nullptr; int *d_flags = nullptr;
 	float *d_rows = nullptr; int *d_nrows = nullptr;            // cloud rows [B][HT_MAXPTS][HT_ROW]
-	float *d_chamber = nullptr;                                  // [B][5*nb][HT_ROW]
+	float *d_chamber = nullptr; int *d_nchamber = nullptr;      // [B][5*nb][HT_ROW]
+	int *d_accepted = nullptr;
 	float *d_contacts = nullptr; int *d_ncontacts = nullptr;    // [B][HT_MAXCONTACT][HT_CONTACT]
 	float *d_scratch = nullptr;                                  // solver row stream [B][HT_MAXPTS + 5*nb + 32][12]
 	float *d_poses_out = nullptr, *d_start = nullptr;

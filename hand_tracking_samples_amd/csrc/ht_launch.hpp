@@ -1,0 +1,30 @@
+// ht_launch.hpp -- host-callable launchers of the solver-side kernels (product code).
+#pragma once
+#include "ht_device.hpp"
+
+struct solve_args
+{
+	const float *rows_pre; const int *n_pre; int pre_stride;      // chamber rows [B][pre_stride][HT_ROW] (may be null)
+	const float *rows_cloud; const int *n_cloud;                    // cloud rows [B][HT_MAXPTS][HT_ROW] (may be null)
+	const float *contacts; const int *ncontacts;                    // [B][HT_MAXCONTACT][HT_CONTACT] (may be null)
+	const float *analysis; const float *cams;                       // for ApplyAngles / landmark-ray rows / arm cone
+	const int *active_flag;                                         // optional per-frame enable
+	float *state;                                                   // [B][nb][HT_STATE_STRIDE] of the model being solved
+	float *scratch; int scratch_stride;                             // [B][scratch_stride][12] pre-computed single-body row stream
+	int apply_angles; float drive_force; int ray_rows; int arm_cone; int zero_momenta; int steps_keyangles; float min_cray_prob;
+};
+
+void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const float *cams, const int *active_flag, int stride, int use_cam_origin, int mode,
+                          const ht_params &par, float *rows, int *nrows, int B, hipStream_t s);
+void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, float scale, float *err, int B, hipStream_t s);
+void ht_launch_chamber(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, int min_point_num, int enabled, float maxforce, float *rows, int *nch, int B, hipStream_t s);
+void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, float *contacts, int *ncontacts, int B, hipStream_t s);
+void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solve_args &a, int B, hipStream_t s);
+void ht_launch_set_pose(float *state, const float *src, int nb, int n, int mode, hipStream_t s);
+void ht_launch_get_state(const float *state, float *dst, int nb, int n, hipStream_t s);
+void ht_launch_clear_flags(float *prev_err, int *initializing, int n, hipStream_t s);
+void ht_launch_decide_reset(const float *err_old, float thr, int angles_only, int *flags, int n, hipStream_t s);
+void ht_launch_scratch(const ht_model_dev &M, float *state, const float4 *pts, const int *npts, const float *analysis, const float *cams, const int *flags, int B, hipStream_t s);
+void ht_launch_unibody(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float *rows, const int *nrows, const int *flags, float *scratch, int scratch_stride, int B, hipStream_t s);
+void ht_launch_accept(float *hand, const float *other, const float *err_old, const float *err_new, const int *npts, float *prev_err, int *initializing, int *accepted, int nb, int n, const ht_params &p, hipStream_t s);
+void ht_launch_output(const ht_model_dev &M, const float *hand, const int *npts, int *initializing, int min_point_num, float *poses, int n, hipStream_t s);

@@ -1,16 +1,238 @@
-// ht_solver_api.hip -- tracker / solver entry points of the C-ABI (work in progress: filled in stage by stage).
+// ht_solver_api.hip -- tracker / solver entry points of the C-ABI: launch sequencing of the per-frame path
+// (HandTracker::update / update_cnn_model / MultiStepSim / FitPointCloud, include/handtrack.h:642-785).
+#include <string.h>
 #include "ht_device.hpp"
 #include "ht_host.hpp"
-#define NOTYET(ctx) do { if (!(ctx)) return HT_ERR_ARG; (ctx)->err = "entry point not implemented yet"; return HT_ERR_STATE; } while (0)
-extern "C" int ht_tracker_reset(ht_ctx *ctx, int, int, const float *) { NOTYET(ctx); }
-extern "C" int ht_get_state(ht_ctx *ctx, int, int, int, float *) { NOTYET(ctx); }
-extern "C" int ht_set_state(ht_ctx *ctx, int, int, int, const float *) { NOTYET(ctx); }
-extern "C" int ht_get_tracker_flags(ht_ctx *ctx, int, int, float *, int *) { NOTYET(ctx); }
-extern "C" int ht_update_sync(ht_ctx *ctx, const uint16_t *, const float *, int, float *, float *) { NOTYET(ctx); }
-extern "C" int ht_update_dev(ht_ctx *ctx, const uint16_t *, const float *, const float *, int, float *, void *) { NOTYET(ctx); }
-extern "C" int ht_stage_fit_error(ht_ctx *ctx, int, int, float *) { NOTYET(ctx); }
-extern "C" int ht_stage_cloud_rows(ht_ctx *ctx, int, int, int, int, float *, int *) { NOTYET(ctx); }
-extern "C" int ht_stage_contacts(ht_ctx *ctx, int, int, int, float *, int *) { NOTYET(ctx); }
-extern "C" int ht_stage_fit(ht_ctx *ctx, int) { NOTYET(ctx); }
-extern "C" int ht_stage_multistep(ht_ctx *ctx, const float *, int) { NOTYET(ctx); }
-extern "C" int ht_stage_scratch_unibody(ht_ctx *ctx, const float *, int, int) { NOTYET(ctx); }
+#include "ht_launch.hpp"
+
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return HT_ERR_HIP; } } while (0)
+#define CHECK_READY(ctx) do { if (!(ctx)) return HT_ERR_ARG; if (!(ctx)->ready) { (ctx)->err = "context not initialised (ht_create failed)"; return HT_ERR_STATE; } } while (0)
+#define CHECK_BATCH(ctx, B) do { if ((B) < 1 || (B) > (ctx)->B) { (ctx)->err = "batch exceeds the capacity given to ht_create"; return HT_ERR_ARG; } } while (0)
+#define CHECK_RANGE(ctx, first, n) do { if ((first) < 0 || (n) < 1 || (first) + (n) > (ctx)->B) { (ctx)->err = "slot range exceeds the capacity given to ht_create"; return HT_ERR_ARG; } } while (0)
+
+static int scratch_stride(const ht_ctx *ctx) { return HT_MAXPTS + 5 * ctx->model.nb + 32; }
+
+// ---- building blocks ------------------------------------------------------------------------------------------------
+static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int *n_pre, bool cloud, bool contacts, const int *active,
+                       int apply_angles, float drive_force, int ray_rows, int arm_cone, int zero_momenta, int B, hipStream_t s)
+{
+	solve_args a;
+	memset(&a, 0, sizeof a);
+	a.rows_pre = rows_pre; a.n_pre = n_pre; a.pre_stride = 5 * ctx->model.nb;
+	a.rows_cloud = cloud ? ctx->d_rows : nullptr; a.n_cloud = ctx->d_nrows;
+	a.contacts = contacts ? ctx->d_contacts : nullptr; a.ncontacts = ctx->d_ncontacts;
+	a.analysis = ctx->d_analysis; a.cams = ctx->d_cams; a.active_flag = active;
+	a.state = ctx->d_state[which]; a.scratch = ctx->d_scratch; a.scratch_stride = scratch_stride(ctx);
+	a.apply_angles = apply_angles; a.drive_force = drive_force; a.ray_rows = ray_rows; a.arm_cone = arm_cone; a.zero_momenta = zero_momenta;
+	a.steps_keyangles = ctx->par.steps_keyangles; a.min_cray_prob = ctx->par.min_cray_prob;
+	ht_launch_solve(ctx->model, ctx->phys, a, B, s);
+}
+// HandTracker::MultiStepSim on othermodel (handtrack.h:642-690)
+static void multistep(ht_ctx *ctx, int B, hipStream_t s)
+{
+	const ht_params &p = ctx->par;
+	for (int st = 0; st < p.steps; st++)
+	{
+		const bool angles = (st < p.steps_keyangles) || p.angles_only;
+		const bool rays = (st < p.steps_keypoints) && !p.angles_only;
+		const bool cloud = (st >= p.steps_cloudstart) && !p.angles_only;
+		if (cloud) { ht_prof_scope ps(ctx, "cloud_rows", s); ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, nullptr, 4, 1, 2, p, ctx->d_rows, ctx->d_nrows, B, s); }
+		if (ctx->phys.use_collision) { ht_prof_scope ps(ctx, "contacts", s); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_contacts, ctx->d_ncontacts, B, s); }
+		ht_prof_scope ps(ctx, "solve", s);
+		solve_step(ctx, 1, nullptr, nullptr, cloud, ctx->phys.use_collision != 0, nullptr, angles, st < p.steps_palmangle ? 10000.0f : 0.0f, rays, 1, 1, B, s);
+	}
+}
+// one main-thread pass of HandTracker::update (handtrack.h:769-780)
+static void main_pass(ht_ctx *ctx, int B, hipStream_t s)
+{
+	const ht_params &p = ctx->par;
+	{ ht_prof_scope ps(ctx, "chamber", s); ht_launch_chamber(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, p.min_point_num, p.boundary_planes, 10.0f, ctx->d_chamber, ctx->d_nchamber, B, s); }
+	{ ht_prof_scope ps(ctx, "cloud_rows", s); ht_launch_cloud_rows(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, ctx->d_cams, nullptr, 1, 0, 1, p, ctx->d_rows, ctx->d_nrows, B, s); }
+	if (ctx->phys.use_collision) { ht_prof_scope ps(ctx, "contacts", s); ht_launch_contacts(ctx->model, ctx->d_state[0], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_contacts, ctx->d_ncontacts, B, s); }
+	ht_prof_scope ps(ctx, "solve", s);
+	solve_step(ctx, 0, ctx->d_chamber, ctx->d_nchamber, true, ctx->phys.use_collision != 0, nullptr, 0, 0.0f, 0, 0, 0, B, s);
+}
+static void reset_path(ht_ctx *ctx, const int *flags, int n_unibody, int B, hipStream_t s)
+{
+	ht_prof_scope ps(ctx, "reset_path", s);
+	ht_launch_scratch(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_analysis, ctx->d_cams, flags, B, s);
+	for (int i = 0; i < n_unibody; i++)
+	{
+		ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, flags, 4, 1, 3, ctx->par, ctx->d_rows, ctx->d_nrows, B, s);
+		ht_launch_unibody(ctx->model, ctx->phys, ctx->d_state[1], ctx->d_rows, ctx->d_nrows, flags, ctx->d_scratch, scratch_stride(ctx), B, s);
+	}
+}
+
+// the whole unit of work on device buffers
+static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, const float *d_start, int B, float *d_poses_out, float *d_cnn_out, hipStream_t s)
+{
+	if (!ctx->have_weights) { ctx->err = "CNN weights not loaded (ht_cnn_load_weights)"; return HT_ERR_STATE; }
+	const ht_params &p = ctx->par;
+	const int nb = ctx->model.nb;
+	if (d_cams != ctx->d_cams) HIPCHK(ctx, hipMemcpyAsync(ctx->d_cams, d_cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyDeviceToDevice, s));
+	if (d_start)
+	{
+		ht_launch_set_pose(ctx->d_state[0], d_start, nb, B, 1, s);
+		ht_launch_set_pose(ctx->d_state[1], d_start, nb, B, 1, s);
+		ht_launch_clear_flags(ctx->d_prev_err, ctx->d_initializing, B, s);
+	}
+	{ ht_prof_scope ps(ctx, "prepare", s); ht_launch_prepare(d_depth, ctx->d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, ctx->d_pts, ctx->d_npts, B, s); }
+	float *cnn_out = d_cnn_out ? d_cnn_out : ctx->d_cnn_out;
+	{
+		ht_prof_scope ps(ctx, "cnn", s);
+		ht_launch_cnn(ctx->cnnw, ctx->d_cnn_in, ctx->d_act1, ctx->d_act2, ctx->d_act3, ctx->d_logits, B, s);
+		ht_launch_softmax_decode(ctx->d_logits, cnn_out, ctx->d_cams, ctx->d_analysis, 1, B, s);
+	}
+	ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, s);                       // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757
+	{ ht_prof_scope ps(ctx, "fit_error", s); ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, ctx->d_cams, p.bone_sum_error_scale, ctx->d_err_old, B, s); }
+	ht_launch_decide_reset(ctx->d_err_old, p.full_reset_on_error, p.angles_only, ctx->d_flags, B, s);
+	reset_path(ctx, ctx->d_flags, p.steps_unibody, B, s);
+	multistep(ctx, B, s);
+	{ ht_prof_scope ps(ctx, "fit_error", s); ht_launch_fit_error(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, d_depth, ctx->d_cams, p.bone_sum_error_scale, ctx->d_err_new, B, s); }
+	ht_launch_accept(ctx->d_state[0], ctx->d_state[1], ctx->d_err_old, ctx->d_err_new, ctx->d_npts, ctx->d_prev_err, ctx->d_initializing, ctx->d_accepted, nb, B, p, s);
+	for (int i = 0; !p.angles_only && i < p.mainthreadpasses; i++) main_pass(ctx, B, s);
+	ht_launch_output(ctx->model, ctx->d_state[0], ctx->d_npts, ctx->d_initializing, p.min_point_num, d_poses_out, B, s);
+	return HT_OK;
+}
+
+// ---- public entry points ----------------------------------------------------------------------------------------------
+extern "C" int ht_tracker_reset(ht_ctx *ctx, int first, int n, const float *poses)
+{
+	CHECK_READY(ctx); CHECK_RANGE(ctx, first, n);
+	if (!poses) return HT_ERR_ARG;
+	hipStream_t s = ctx->stream;
+	const int nb = ctx->model.nb;
+	HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage, poses, (size_t)n * nb * HT_POSE * sizeof(float), hipMemcpyHostToDevice, s));
+	for (int w = 0; w < 2; w++) ht_launch_set_pose(ctx->d_state[w] + (size_t)first * nb * HT_STATE_STRIDE, ctx->d_stage, nb, n, 1, s);
+	ht_launch_clear_flags(ctx->d_prev_err + first, ctx->d_initializing + first, n, s);
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
+extern "C" int ht_get_state(ht_ctx *ctx, int which, int first, int n, float *state)
+{
+	CHECK_READY(ctx); CHECK_RANGE(ctx, first, n);
+	if (!state || which < 0 || which > 1) return HT_ERR_ARG;
+	hipStream_t s = ctx->stream;
+	const int nb = ctx->model.nb;
+	ht_launch_get_state(ctx->d_state[which] + (size_t)first * nb * HT_STATE_STRIDE, ctx->d_stage, nb, n, s);
+	HIPCHK(ctx, hipMemcpyAsync(state, ctx->d_stage, (size_t)n * nb * HT_STATE * sizeof(float), hipMemcpyDeviceToHost, s));
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
+extern "C" int ht_set_state(ht_ctx *ctx, int which, int first, int n, const float *state)
+{
+	CHECK_READY(ctx); CHECK_RANGE(ctx, first, n);
+	if (!state || which < 0 || which > 1) return HT_ERR_ARG;
+	hipStream_t s = ctx->stream;
+	const int nb = ctx->model.nb;
+	HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage, state, (size_t)n * nb * HT_STATE * sizeof(float), hipMemcpyHostToDevice, s));
+	ht_launch_set_pose(ctx->d_state[which] + (size_t)first * nb * HT_STATE_STRIDE, ctx->d_stage, nb, n, 3, s);
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
+extern "C" int ht_get_tracker_flags(ht_ctx *ctx, int first, int n, float *prev_frame_error, int *initializing)
+{
+	CHECK_READY(ctx); CHECK_RANGE(ctx, first, n);
+	if (prev_frame_error) HIPCHK(ctx, hipMemcpy(prev_frame_error, ctx->d_prev_err + first, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+	if (initializing) HIPCHK(ctx, hipMemcpy(initializing, ctx->d_initializing + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+	return HT_OK;
+}
+extern "C" int ht_update_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, const float *d_start_poses, int B, float *d_poses_out, void *stream)
+{
+	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	if (!d_depth || !d_cams || !d_poses_out) return HT_ERR_ARG;
+	int r = run_update(ctx, d_depth, d_cams, d_start_poses, B, d_poses_out, nullptr, (hipStream_t)stream);
+	if (r) return r;
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
+extern "C" int ht_update_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int B, float *poses_out, float *cnn_out)
+{
+	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	if (!depth || !cams || !poses_out) return HT_ERR_ARG;
+	hipStream_t s = ctx->stream;
+	const int nb = ctx->model.nb;
+	HIPCHK(ctx, hipMemcpyAsync(ctx->d_depth, depth, (size_t)B * 4096 * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+	HIPCHK(ctx, hipMemcpyAsync(ctx->d_cams, cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyHostToDevice, s));
+	int r = run_update(ctx, ctx->d_depth, ctx->d_cams, nullptr, B, ctx->d_poses_out, nullptr, s);
+	if (r) return r;
+	HIPCHK(ctx, hipMemcpyAsync(poses_out, ctx->d_poses_out, (size_t)B * nb * HT_POSE * sizeof(float), hipMemcpyDeviceToHost, s));
+	if (cnn_out) HIPCHK(ctx, hipMemcpyAsync(cnn_out, ctx->d_cnn_out, (size_t)B * HT_CNN_OUT * sizeof(float), hipMemcpyDeviceToHost, s));
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
+
+// ---- stage entry points (operate on the buffers ht_stage_prepare filled and on the tracker state of slots [0,B)) -------------
+extern "C" int ht_stage_fit_error(ht_ctx *ctx, int which, int B, float *err)
+{
+	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	if (!err || which < 0 || which > 1) return HT_ERR_ARG;
+	hipStream_t s = ctx->stream;
+	ht_launch_fit_error(ctx->model, ctx->d_state[which], ctx->d_pts, ctx->d_npts, ctx->d_depth, ctx->d_cams, ctx->par.bone_sum_error_scale, ctx->d_err_old, B, s);
+	HIPCHK(ctx, hipMemcpyAsync(err, ctx->d_err_old, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, s));
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
+extern "C" int ht_stage_cloud_rows(ht_ctx *ctx, int which, int stride, int use_cam_origin, int B, float *rows, int *nrows)
+{
+	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	if (!rows || !nrows || which < 0 || which > 1 || stride < 1) return HT_ERR_ARG;
+	hipStream_t s = ctx->stream;
+	HIPCHK(ctx, hipMemsetAsync(ctx->d_rows, 0, (size_t)B * HT_MAXPTS * HT_ROW * sizeof(float), s));
+	ht_launch_cloud_rows(ctx->model, ctx->d_state[which], ctx->d_pts, ctx->d_npts, ctx->d_cams, nullptr, stride, use_cam_origin, 0, ctx->par, ctx->d_rows, ctx->d_nrows, B, s);
+	HIPCHK(ctx, hipMemcpyAsync(rows, ctx->d_rows, (size_t)B * HT_MAXPTS * HT_ROW * sizeof(float), hipMemcpyDeviceToHost, s));
+	HIPCHK(ctx, hipMemcpyAsync(nrows, ctx->d_nrows, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
+extern "C" int ht_stage_contacts(ht_ctx *ctx, int which, int B, int cap, float *contacts, int *ncontacts)
+{
+	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	if (!contacts || !ncontacts || which < 0 || which > 1 || cap < 1) return HT_ERR_ARG;
+	hipStream_t s = ctx->stream;
+	ht_launch_contacts(ctx->model, ctx->d_state[which], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_contacts, ctx->d_ncontacts, B, s);
+	std::vector<float> tmp((size_t)B * HT_MAXCONTACT * HT_CONTACT);
+	HIPCHK(ctx, hipMemcpyAsync(tmp.data(), ctx->d_contacts, tmp.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+	HIPCHK(ctx, hipMemcpyAsync(ncontacts, ctx->d_ncontacts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	HIPCHK(ctx, hipGetLastError());
+	const int ncopy = cap < HT_MAXCONTACT ? cap : HT_MAXCONTACT;
+	for (int b = 0; b < B; b++) memcpy(contacts + (size_t)b * cap * HT_CONTACT, tmp.data() + (size_t)b * HT_MAXCONTACT * HT_CONTACT, (size_t)ncopy * HT_CONTACT * sizeof(float));
+	return HT_OK;
+}
+extern "C" int ht_stage_fit(ht_ctx *ctx, int B)
+{
+	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	main_pass(ctx, B, ctx->stream);
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
+extern "C" int ht_stage_multistep(ht_ctx *ctx, const float *analysis, int B)
+{
+	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	if (!analysis) return HT_ERR_ARG;
+	hipStream_t s = ctx->stream;
+	HIPCHK(ctx, hipMemcpyAsync(ctx->d_analysis, analysis, (size_t)B * HT_ANALYSIS * sizeof(float), hipMemcpyHostToDevice, s));
+	multistep(ctx, B, s);
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
+extern "C" int ht_stage_scratch_unibody(ht_ctx *ctx, const float *analysis, int B, int n_unibody)
+{
+	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	if (!analysis) return HT_ERR_ARG;
+	hipStream_t s = ctx->stream;
+	HIPCHK(ctx, hipMemcpyAsync(ctx->d_analysis, analysis, (size_t)B * HT_ANALYSIS * sizeof(float), hipMemcpyHostToDevice, s));
+	reset_path(ctx, nullptr, n_unibody, B, s);
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}

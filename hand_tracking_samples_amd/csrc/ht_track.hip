@@ -1,0 +1,278 @@
+// ht_track.hip -- tracker-level kernels: state plumbing, the full-reset path (PoseFromScratch + UnibodyFit), accept/reject of the
+// CNN-driven pose and the user-space pose output.
+//
+// Reference computations:
+//   PoseFromScratch / FixPositions / Reset    include/handtrack.h:480-506, include/physmodel.h:404-408, 221-226
+//   UnibodyFit                                 include/handtrack.h:451-470
+//   update_cnn_model accept logic              include/handtrack.h:704-726
+//   PhysModel::GetPoseUser / SetPose           include/physmodel.h:433-435, third_party/physics.h:142
+#include "ht_device.hpp"
+#include "ht_launch.hpp"
+
+__device__ __forceinline__ v3 G3(const float *p) { return V3(p[0], p[1], p[2]); }
+__device__ __forceinline__ v4 G4(const float *p) { return V4(p[0], p[1], p[2], p[3]); }
+__device__ __forceinline__ m3 GM(const float *p) { m3 m; m.x = V3(p[0], p[1], p[2]); m.y = V3(p[3], p[4], p[5]); m.z = V3(p[6], p[7], p[8]); return m; }
+
+// ---- state plumbing ---------------------------------------------------------------------------------------------
+// mode 0: SetPose from poses[B][nb][7] (momenta untouched); 1: SetPose + zero momenta; 2: copy pose from another state array; 3: full 13-float state in
+__global__ void k_set_pose(float *__restrict__ state, const float *__restrict__ src, int nb, int n, int mode)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n * nb) return;
+	float *s = state + (size_t)i * HT_STATE_STRIDE;
+	if (mode == 2) { const float *o = src + (size_t)i * HT_STATE_STRIDE; for (int k = 0; k < 7; k++) s[k] = o[k]; return; }
+	if (mode == 3) { const float *o = src + (size_t)i * HT_STATE; for (int k = 0; k < 13; k++) s[k] = o[k]; return; }
+	const float *o = src + (size_t)i * HT_POSE;
+	for (int k = 0; k < 7; k++) s[k] = o[k];
+	if (mode == 1) for (int k = 7; k < 13; k++) s[k] = 0.0f;
+}
+__global__ void k_get_state(const float *__restrict__ state, float *__restrict__ dst, int nb, int n)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n * nb) return;
+	const float *s = state + (size_t)i * HT_STATE_STRIDE;
+	for (int k = 0; k < 13; k++) dst[(size_t)i * HT_STATE + k] = s[k];
+}
+__global__ void k_clear_flags(float *prev_err, int *initializing, int n)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) { prev_err[i] = 0.0f; initializing[i] = 0; }
+}
+// flags[b] = angles_only || olderror > full_reset_on_error (handtrack.h:706)
+__global__ void k_decide_reset(const float *__restrict__ err_old, float thr, int angles_only, int *__restrict__ flags, int n)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) flags[i] = (angles_only || err_old[i] > thr) ? 1 : 0;
+}
+
+// ---- PoseFromScratch: one wave per flagged frame -----------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_scratch(ht_model_dev M, float *__restrict__ state, const float4 *__restrict__ pts, const int *__restrict__ npts,
+                                               const float *__restrict__ analysis, const float *__restrict__ cams, const int *__restrict__ flags)
+{
+	__shared__ float pos[HT_MAXNB][3], q[HT_MAXNB][4];
+	__shared__ float pc[3];
+	const int b = blockIdx.x, lane = threadIdx.x;
+	if (flags && !flags[b]) return;
+	const float *an = analysis + (size_t)b * HT_ANALYSIS;
+	const float *cam = cams + (size_t)b * HT_CAM;
+	if (lane == 0)
+	{
+		// palm ray from the first three landmark rays, inverse-distance weighted centroid of the cloud (sequential sums, handtrack.h:483-490)
+		v4 cs = (G4(an + HT_AN_CRAYS) + G4(an + HT_AN_CRAYS + 4)) + G4(an + HT_AN_CRAYS + 8);
+		v3 palmray = normalize(xyz(cs));
+		v3 pcom = V3(0, 0, 0); float wsum = 0.00000000001f;
+		const int n = npts[b];
+		for (int i = 0; i < n; i++)
+		{
+			float4 pv = pts[(size_t)b * HT_MAXPTS + i];
+			v3 p = V3(pv.x, pv.y, pv.z);
+			v3 c = cross(p, palmray);
+			float w = 1.0f / (0.000001f + dot(c, c));
+			pcom = pcom + p * w; wsum += w;
+		}
+		pcom = pcom / wsum;
+		pc[0] = pcom.x; pc[1] = pcom.y; pc[2] = pcom.z;
+	}
+	if (lane < M.nb)
+	{
+		const float *bc = M.bodyc + lane * HT_BC;     // Reset(rb) physmodel.h:221-226
+		for (int i = 0; i < 3; i++) pos[lane][i] = bc[HT_BC_POS0 + i];
+		for (int i = 0; i < 4; i++) q[lane][i] = bc[HT_BC_Q0 + i];
+	}
+	__syncthreads();
+	const v4 camq = V4(cam[8], cam[9], cam[10], cam[11]);
+	const v4 palmq = G4(an + HT_AN_PALMQ);
+	xf p1 = XF(V3(pc[0], pc[1], pc[2]), qmul(camq, palmq));
+	xf dp = mul(p1, inverse(XF(G3(pos[1]), G4(q[1]))));
+	__syncthreads();
+	if (lane < M.nb)
+	{
+		xf np = mul(dp, XF(G3(pos[lane]), G4(q[lane])));
+		pos[lane][0] = np.p.x; pos[lane][1] = np.p.y; pos[lane][2] = np.p.z; q[lane][0] = np.q.x; q[lane][1] = np.q.y; q[lane][2] = np.q.z; q[lane][3] = np.q.w;
+	}
+	__syncthreads();
+	if (lane >= 1 && lane <= 4 && M.nb >= 17)     // curl the four fingers by the decoded clench angles (handtrack.h:498-504)
+	{
+		const int finger = lane;
+		const float a = an[HT_AN_CLENCH + finger];
+		const v4 jf = G4(M.jointc + (1 + finger * 3) * HT_JC + HT_JC_FRAME);
+		const float ang[3] = { a / 2.0f, a, a * 1.25f };
+		for (int k = 0; k < 3; k++)
+		{
+			const int bb = 2 + k + finger * 3;
+			v4 o = qmul(jf, qmul(G4(q[bb]), quat_axis_angle(V3(1, 0, 0), ang[k])));
+			q[bb][0] = o.x; q[bb][1] = o.y; q[bb][2] = o.z; q[bb][3] = o.w;
+		}
+	}
+	__syncthreads();
+	if (lane == 0)      // FixPositions: ordered top-down (physmodel.h:404-408)
+	{
+		for (int j = 0; j < M.nj; j++)
+		{
+			const float *jc = M.jointc + j * HT_JC;
+			const int r0 = (int)jc[HT_JC_RB0], r1 = (int)jc[HT_JC_RB1];
+			xf u0 = XF(apply(XF(G3(pos[r0]), G4(q[r0])), -G3(M.bodyc + r0 * HT_BC + HT_BC_COM)), G4(q[r0]));
+			xf u1 = XF(apply(XF(G3(pos[r1]), G4(q[r1])), -G3(M.bodyc + r1 * HT_BC + HT_BC_COM)), G4(q[r1]));
+			v3 np = G3(pos[r1]) + (apply(u0, G3(jc + HT_JC_P0)) - apply(u1, G3(jc + HT_JC_P1)));
+			pos[r1][0] = np.x; pos[r1][1] = np.y; pos[r1][2] = np.z;
+		}
+	}
+	__syncthreads();
+	if (lane < M.nb)
+	{
+		float *s = state + ((size_t)b * M.nb + lane) * HT_STATE_STRIDE;
+		for (int i = 0; i < 3; i++) s[i] = pos[lane][i];
+		for (int i = 0; i < 4; i++) s[3 + i] = q[lane][i];
+		for (int i = 7; i < 13; i++) s[i] = 0.0f;
+	}
+}
+
+// ---- UnibodyFit: one wave per flagged frame; the rows all act on one proxy body, so the Gauss-Seidel chain is sequential -----------
+__global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev ph, float *__restrict__ state, const float *__restrict__ rows, const int *__restrict__ nrows,
+                                                const int *__restrict__ flags, float *__restrict__ scratch, int scratch_stride)
+{
+	__shared__ float pos[HT_MAXNB][3], q[HT_MAXNB][4];
+	__shared__ float res[8];
+	const int b = blockIdx.x, lane = threadIdx.x;
+	if (flags && !flags[b]) return;
+	const int nb = M.nb;
+	float *st = state + (size_t)b * nb * HT_STATE_STRIDE;
+	if (lane < nb) { for (int i = 0; i < 3; i++) pos[lane][i] = st[lane * HT_STATE_STRIDE + i]; for (int i = 0; i < 4; i++) q[lane][i] = st[lane * HT_STATE_STRIDE + 3 + i]; }
+	__syncthreads();
+	// SanityCheck before the solve (handtrack.h:463) is a no-op unless the pose already holds NaNs; those bodies are reset
+	if (lane < nb)
+	{
+		bool bad = false;
+		for (int i = 0; i < 13; i++) bad = bad || isnan(st[lane * HT_STATE_STRIDE + i]);
+		if (bad) { for (int i = 0; i < 3; i++) pos[lane][i] = M.bodyc[lane * HT_BC + HT_BC_POS0 + i]; for (int i = 0; i < 4; i++) q[lane][i] = M.bodyc[lane * HT_BC + HT_BC_Q0 + i]; }
+	}
+	__syncthreads();
+	const int n = nrows[b];
+	const float dt = ph.deltaT;
+	const v3 ubpos = G3(pos[1]) + V3(M.ub_com[0], M.ub_com[1], M.ub_com[2]);        // RigidBody ctor: position += com (physics.h:157)
+	const v4 ubq = G4(q[1]);
+	const xf ubi = inverse(XF(ubpos, ubq));
+	const float minv = M.ub_massinv;
+	const m3 tinv = GM(M.ub_tinv);
+	const m3 Iinv = world_inertia(ubq, tinv, minv);
+	float *scr = scratch + (size_t)b * scratch_stride * 12;
+	for (int i = lane; i < n; i += 64)     // re-express every cloud row on the proxy body and pre-compute (handtrack.h:457-462)
+	{
+		const float *r = rows + ((size_t)b * HT_MAXPTS + i) * HT_ROW;
+		const int rb1 = (int)r[1];
+		const v3 p1 = apply(ubi, apply(XF(G3(pos[rb1]), G4(q[rb1])), G3(r + 5)));
+		const v3 nrm = G3(r + 8);
+		const v3 r1 = qrot(ubq, p1);
+		const float impulsed = minv + dot(cross(mul(Iinv, cross(r1, nrm)), r1), nrm);
+		float4 *o = reinterpret_cast<float4 *>(scr + (size_t)i * 12);
+		o[0] = make_float4(r1.x, r1.y, r1.z, nrm.x);
+		o[1] = make_float4(nrm.y, nrm.z, r[11] / dt, r[12]);
+		o[2] = make_float4(r[13] * dt, r[14] * dt, impulsed, 0.0f);
+	}
+	__syncthreads();
+	if (lane == 0)
+	{
+		v3 lin = V3(0, 0, 0), ang = V3(0, 0, 0);
+		lin = lin * M.ub_dampleft; ang = ang * M.ub_dampleft;            // rbinitvelocity on a body at rest
+		lin = lin + V3(0, 0, 0); ang = ang + V3(0, 0, 0);
+		v3 pn = ubpos; v4 qn = ubq;
+		const int total = ph.iterations + ph.iterations_post;
+		for (int sweep = 0; sweep < total; sweep++)
+		{
+			const bool post = sweep >= ph.iterations;
+			for (int k = 0; k < n; k++)
+			{
+				const float4 *c = reinterpret_cast<const float4 *>(scr + (size_t)k * 12);
+				const float4 c0 = c[0], c1 = c[1], c2 = c[2];
+				const v3 r1 = V3(c0.x, c0.y, c0.z), nrm = V3(c0.w, c1.x, c1.y);
+				const float ts = post ? fmin_std(c1.z, c1.w) : c1.z;
+				const v3 v1 = cross(mul(Iinv, ang), r1) + lin * minv;
+				const float vn = dot(v1, nrm);
+				float impulse = (-ts - vn) / c2.z;
+				impulse = fmin_std(c2.y - c2.w, impulse);
+				impulse = fmax_std(c2.x - c2.w, impulse);
+				const v3 imp = nrm * impulse;
+				lin = lin + imp; ang = ang + cross(r1, imp);
+				scr[(size_t)k * 12 + 11] = c2.w + impulse;
+			}
+			if (sweep + 1 == ph.iterations)
+			{
+				pn = ubpos + (lin * minv) * dt;
+				const m3 tm = tinv * minv;
+				auto diffq = [&](v4 o) -> v4 { v4 sn = normalize(o); m3 Mx = qmat(sn); m3 Ii = mul(Mx, mul(tm, transpose(Mx))); v3 hs = mul(Ii, ang) * 0.5f; return qmul(V4(hs.x, hs.y, hs.z, 0), sn); };
+				v4 d1 = diffq(ubq), d2 = diffq(ubq + d1 * (dt / 2)), d3 = diffq(ubq + d2 * (dt / 2)), d4 = diffq(ubq + d3 * dt);
+				v4 o = normalize((((ubq + d1 * (dt / 6)) + d2 * (dt / 3)) + d3 * (dt / 3)) + d4 * (dt / 6));
+				if (o.x < FLT_EPSILON / 4.0f && o.x > -FLT_EPSILON / 4.0f) o.x = 0.0f;
+				if (o.y < FLT_EPSILON / 4.0f && o.y > -FLT_EPSILON / 4.0f) o.y = 0.0f;
+				if (o.z < FLT_EPSILON / 4.0f && o.z > -FLT_EPSILON / 4.0f) o.z = 0.0f;
+				qn = o;
+			}
+		}
+		res[0] = pn.x; res[1] = pn.y; res[2] = pn.z; res[3] = qn.x; res[4] = qn.y; res[5] = qn.z; res[6] = qn.w;
+	}
+	__syncthreads();
+	const xf dp = mul(XF(V3(res[0], res[1], res[2]), V4(res[3], res[4], res[5], res[6])), inverse(XF(G3(pos[1]), G4(q[1]))));
+	if (lane < nb)
+	{
+		xf np = mul(dp, XF(G3(pos[lane]), G4(q[lane])));
+		float *s = st + lane * HT_STATE_STRIDE;
+		bool bad = isnan(np.p.x) || isnan(np.p.y) || isnan(np.p.z) || isnan(np.q.x) || isnan(np.q.y) || isnan(np.q.z) || isnan(np.q.w);
+		for (int i = 7; i < 13; i++) bad = bad || isnan(s[i]);
+		if (bad) { const float *bc = M.bodyc + lane * HT_BC; np = XF(G3(bc + HT_BC_POS0), G4(bc + HT_BC_Q0)); for (int i = 7; i < 13; i++) s[i] = 0.0f; }
+		s[0] = np.p.x; s[1] = np.p.y; s[2] = np.p.z; s[3] = np.q.x; s[4] = np.q.y; s[5] = np.q.z; s[6] = np.q.w;
+	}
+}
+
+// ---- accept / reject the CNN-driven pose (handtrack.h:714-726), one thread per frame ---------------------------------------------
+__global__ void k_accept(float *__restrict__ hand, const float *__restrict__ other, const float *__restrict__ err_old, const float *__restrict__ err_new,
+                         const int *__restrict__ npts, float *__restrict__ prev_err, int *__restrict__ initializing, int *__restrict__ accepted,
+                         int nb, int n, int min_point_num, int always_take_cnn, int angles_only, float accum_error_threshold)
+{
+	const int b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= n) return;
+	float pfe = prev_err[b];
+	const float olderror = err_old[b], newerror = err_new[b];
+	if (newerror > olderror) pfe = 0.0f; else pfe += olderror - newerror;
+	const bool take = (npts[b] > min_point_num && initializing[b]) || always_take_cnn || angles_only || pfe > accum_error_threshold;
+	if (take)
+		for (int i = 0; i < nb; i++) for (int k = 0; k < 7; k++) hand[((size_t)b * nb + i) * HT_STATE_STRIDE + k] = other[((size_t)b * nb + i) * HT_STATE_STRIDE + k];      // handmodel.SetPose (momenta kept)
+	if (pfe > accum_error_threshold) pfe = 0.0f;
+	prev_err[b] = pfe;
+	const int ini = initializing[b] - 1;
+	initializing[b] = ini < 0 ? 0 : ini;
+	if (accepted) accepted[b] = take ? nb : 0;
+}
+// GetPoseUser (physmodel.h:434) + the "initializing = 50" rule of handtrack.h:781-782
+__global__ void k_output(ht_model_dev M, const float *__restrict__ hand, const int *__restrict__ npts, int *__restrict__ initializing, int min_point_num, float *__restrict__ poses, int n)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n * M.nb) return;
+	const int b = i / M.nb, rb = i % M.nb;
+	const float *s = hand + (size_t)i * HT_STATE_STRIDE;
+	v3 pu = apply(XF(G3(s), G4(s + 3)), -G3(M.bodyc + rb * HT_BC + HT_BC_COM));
+	float *o = poses + (size_t)i * HT_POSE;
+	o[0] = pu.x; o[1] = pu.y; o[2] = pu.z; o[3] = s[3]; o[4] = s[4]; o[5] = s[5]; o[6] = s[6];
+	if (rb == 0 && npts[b] < min_point_num) initializing[b] = 50;
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------------------
+void ht_launch_set_pose(float *state, const float *src, int nb, int n, int mode, hipStream_t s) { hipLaunchKernelGGL(k_set_pose, dim3((n * nb + 255) / 256), dim3(256), 0, s, state, src, nb, n, mode); }
+void ht_launch_get_state(const float *state, float *dst, int nb, int n, hipStream_t s) { hipLaunchKernelGGL(k_get_state, dim3((n * nb + 255) / 256), dim3(256), 0, s, state, dst, nb, n); }
+void ht_launch_clear_flags(float *prev_err, int *initializing, int n, hipStream_t s) { hipLaunchKernelGGL(k_clear_flags, dim3((n + 255) / 256), dim3(256), 0, s, prev_err, initializing, n); }
+void ht_launch_decide_reset(const float *err_old, float thr, int angles_only, int *flags, int n, hipStream_t s) { hipLaunchKernelGGL(k_decide_reset, dim3((n + 255) / 256), dim3(256), 0, s, err_old, thr, angles_only, flags, n); }
+void ht_launch_scratch(const ht_model_dev &M, float *state, const float4 *pts, const int *npts, const float *analysis, const float *cams, const int *flags, int B, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_scratch, dim3(B), dim3(64), 0, s, M, state, pts, npts, analysis, cams, flags);
+}
+void ht_launch_unibody(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float *rows, const int *nrows, const int *flags, float *scratch, int scratch_stride, int B, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_unibody, dim3(B), dim3(64), 0, s, M, ph, state, rows, nrows, flags, scratch, scratch_stride);
+}
+void ht_launch_accept(float *hand, const float *other, const float *err_old, const float *err_new, const int *npts, float *prev_err, int *initializing, int *accepted, int nb, int n, const ht_params &p, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_accept, dim3((n + 63) / 64), dim3(64), 0, s, hand, other, err_old, err_new, npts, prev_err, initializing, accepted, nb, n, p.min_point_num, p.always_take_cnn, p.angles_only, p.accum_error_threshold);
+}
+void ht_launch_output(const ht_model_dev &M, const float *hand, const int *npts, int *initializing, int min_point_num, float *poses, int n, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_output, dim3((n * M.nb + 255) / 256), dim3(256), 0, s, M, hand, npts, initializing, min_point_num, poses, n);
+}
