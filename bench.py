@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- synthetic depth frames/s of the MI355X hand-tracking hot path (CNN + pose solver), 1..8 GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one pass of the whole per-frame path (BASELINE.json configs[2]: depth normalise -> CNN -> decode -> FitError ->
+[reset path] -> 5-step MultiStepSim -> accept -> 3 FitPointCloud passes -> poses) over one batch of independent 64x64
+synthetic frames per GPU, inputs resident in HBM, every tracker re-seeded from its start pose (independent frames).
+Frames are sharded contiguous per rank with no data-path collective; with N>1 the poses are all-gathered over RCCL once
+per step (inside the timed region).  Scaling is weak: --frames-per-gpu (default 1024) is fixed as N grows.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP-event timed on the
+stream it runs on) and `cpu_baseline` (the reference's own code from oracle/_ref when present, else the C oracle port).
+"""
+import argparse
+import json
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_MFMA_PEAK_TF = 157.3      # dense fp32 MFMA (= fp32 vector) peak
+
+
+def _load_frames(n):
+    z = np.load(os.path.join(ROOT, "tests", "golden", "frames256.npz"))
+    reps = (n + len(z["depth"]) - 1) // len(z["depth"])
+    tile = lambda a: np.concatenate([a] * reps)[:n]
+    return (tile(z["depth"].reshape(-1, 4096)).astype(np.uint16), tile(z["cam"]).astype(np.float32), tile(z["startpose"]).astype(np.float32))
+
+
+def _write_htfx(path, arrays):
+    code = {np.dtype(np.float32): 0, np.dtype(np.int32): 1, np.dtype(np.uint16): 2, np.dtype(np.uint8): 3}
+    with open(path, "wb") as f:
+        f.write(b"HTFX0001" + struct.pack("<I", len(arrays)))
+        for name, a in arrays.items():
+            a = np.ascontiguousarray(a)
+            raw = a.tobytes()
+            f.write(name.encode()[:47].ljust(48, b"\0"))
+            f.write(struct.pack("<IIIIIIQ", code[a.dtype], a.ndim, *(list(a.shape) + [1] * (4 - a.ndim)), len(raw)))
+            f.write(raw + b"\0" * ((8 - (len(raw) & 7)) & 7))
+
+
+def cpu_baseline(depth, cams, start, seed, gain):
+    """Reference CPU path on a bounded sample of the same workload (single thread)."""
+    nsample = min(192, len(depth))
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    if os.path.exists(ref_bin):
+        try:
+            with tempfile.TemporaryDirectory() as td:
+                fn = os.path.join(td, "frames.htfx")
+                _write_htfx(fn, {"depth": depth[:nsample].reshape(-1, 64, 64), "cam": cams[:nsample], "startpose": start[:nsample]})
+                out = subprocess.run([ref_bin, "bench", fn, hex(seed), str(gain), "3"], capture_output=True, text=True, timeout=600)
+                r = json.loads(out.stdout.strip().splitlines()[-1])
+                return {"value": r["frame_fps"], "unit": "frames/s", "cores": 1, "kind": "reference",
+                        "sample": "%d frames x 3 reps (best), reference headers built -O2 -ffp-contract=off, update_cnn_model + 3 passes" % nsample,
+                        "cnn_only_fps": r["cnn_fps"]}
+        except Exception as e:      # fall through to the port
+            sys.stderr.write("reference baseline unavailable (%s); timing the C oracle port\n" % e)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import oracle_lib as ol
+    from hand_tracking_samples_amd import weights as W
+    o = ol.Oracle(W.make_cnnb(seed, gain))
+    o.head.par.microforce = 3.0
+    o.head.par.mainthreadpasses = 3
+    nsample = min(128, len(depth))
+    user = np.zeros((17, 7), np.float32)
+    best = 1e30
+    for rep in range(2):
+        t0 = time.perf_counter()
+        for i in range(nsample):
+            o.reset(start[i])
+            cam = ol.camera(cams[i])
+            o.L.ho_update(o.h, ol.u16ptr(np.ascontiguousarray(depth[i])), C.byref(cam), ol.fptr(user))
+        best = min(best, (time.perf_counter() - t0) / nsample)
+    o.close()
+    return {"value": 1.0 / best, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames x 2 reps (best), C oracle -O2 -ffp-contract=off, update_cnn_model + 3 passes" % nsample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames-per-gpu", type=int, default=1024)
+    ap.add_argument("--workload", default="cnn+solver", choices=["cnn+solver", "cnn"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from hand_tracking_samples_amd import native, weights as W
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE\n" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    B = args.frames_per_gpu
+    seed, gain = W.DEFAULT_SEED, W.DEFAULT_FC2_GAIN
+
+    # contiguous shard of the global frame list for this rank (frames differ across ranks through the tiling offset)
+    depth_all, cams_all, start_all = _load_frames(B * world)
+    sl = slice(rank * B, (rank + 1) * B)
+    depth, cams, start = depth_all[sl], cams_all[sl], start_all[sl]
+
+    ctx = native.Context(os.path.join(ROOT, "tests", "golden", "model_hand17.htfx"), B, device=local)
+    ctx.load_weights(W.make_cnnb(seed, gain))
+    ctx.set_params(microforce=3.0, mainthreadpasses=3)        # synthetic-tracker.cpp:91-93
+    d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
+    d_cams = torch.from_numpy(cams).to(dev)
+    d_start = torch.from_numpy(start).to(dev)
+    d_poses = torch.empty((B, ctx.nb, 7), dtype=torch.float32, device=dev)
+    d_cnn_in = torch.empty((B, 4096), dtype=torch.float32, device=dev)
+    d_cnn_out = torch.empty((B, 2304), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world * B, ctx.nb, 7), dtype=torch.float32, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream(dev)
+
+    if args.workload == "cnn":
+        cnn_in, _, _ = ctx.stage_prepare(depth, cams)
+        d_cnn_in.copy_(torch.from_numpy(cnn_in))
+
+    def step():
+        if args.workload == "cnn":
+            ctx.cnn_eval_dev(d_cnn_in.data_ptr(), d_cnn_out.data_ptr(), B, stream.cuda_stream)
+        else:
+            ctx.update_dev(d_depth.data_ptr(), d_cams.data_ptr(), d_start.data_ptr(), B, d_poses.data_ptr(), stream.cuda_stream)
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, d_poses)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ctx.profile_enable(True)
+    ctx.profile_read(reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    prof = ctx.profile_read(reset=True)
+    ctx.profile_enable(False)
+
+    if rank == 0:
+        total_frames = B * world * args.steps
+        value = total_frames / elapsed
+        # dominant kernel of the workload by HIP-event time
+        phases = {k: v for k, v in prof.items() if v[1] > 0}
+        dom = max(phases, key=lambda k: phases[k][0]) if phases else None
+        roof = None
+        if dom == "solve":
+            # algorithmic HBM bytes of one k_solve launch: per frame the body state in and out
+            # (2 x 17 x 52 B) plus the constraint rows it consumes (64 B each); mean rows per frame measured from the data
+            npts = np.array([int(((d.astype(np.float32) * c[4] >= 0.1) & (d.astype(np.float32) * c[4] < 0.7)).sum() + 3) // 4 for d, c in zip(depth, cams)])
+            main_rows = float(np.mean(npts + np.where(npts > 400, 85, 0))); sim_rows = float(np.mean((npts + 3) // 4))
+            rows_mean = (3 * main_rows + 4 * sim_rows) / 8.0
+            per_frame = 2 * ctx.nb * 52 + 64.0 * rows_mean
+            avg_ms = phases[dom][0] / phases[dom][1]
+            achieved = per_frame * B / (avg_ms * 1e-3) / 1e9
+            roof = {"kernel": "k_solve", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                    "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": phases[dom][1], "algorithmic_bytes_per_launch": int(per_frame * B),
+                    "note": "sequential Gauss-Seidel: latency/VALU-bound, not a streaming kernel (SURVEY 8d)"}
+        elif dom == "cnn":
+            avg_ms = phases[dom][0] / phases[dom][1]
+            achieved = 26.47e6 * B / (avg_ms * 1e-3) / 1e12
+            roof = {"kernel": "cnn (k_conv1+k_conv2+k_fc x2+k_softmax_decode)", "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": round(achieved / FP32_MFMA_PEAK_TF, 5), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": phases[dom][1]}
+        cnn_roof = None
+        if "cnn" in phases and dom != "cnn":
+            avg_ms = phases["cnn"][0] / phases["cnn"][1]
+            ach = 26.47e6 * B / (avg_ms * 1e-3) / 1e12
+            cnn_roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 5), "avg_ms": round(avg_ms, 4)}
+        out = {
+            "metric": "synthetic depth frames/sec (CNN+solver), 64x64x1 input, 17-bone hand" if args.workload == "cnn+solver" else "synthetic depth frames/sec (CNN forward only), 64x64x1 input",
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (256 software-rendered animbank frames tiled; seeded weights 0x5EED0001)",
+            "config": {"workload": "BASELINE configs[2]: %d independent 64x64 frames per GPU, CNN + decode + 5-step MultiStepSim + 3 FitPointCloud passes (GJK + PGS), 17 bones" % B
+                       if args.workload == "cnn+solver" else "BASELINE configs[1]: %d frames per GPU, CNN forward only" % B,
+                       "frames_per_gpu": B, "global_frames_per_step": B * world, "parallelism": "frames sharded per GPU, RCCL all-gather of poses" if world > 1 else "single GPU"},
+            "roofline": roof,
+            "phase_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(phases.items())},
+        }
+        if cnn_roof:
+            out["roofline_cnn"] = cnn_roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(depth, cams, start, seed, gain)
+            out["speedup_vs_cpu_1thread"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
