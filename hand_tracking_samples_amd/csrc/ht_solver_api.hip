@@ -140,6 +140,13 @@ extern "C" int ht_get_tracker_flags(ht_ctx *ctx, int first, int n, float *prev_f
 	if (initializing) HIPCHK(ctx, hipMemcpy(initializing, ctx->d_initializing + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
 	return HT_OK;
 }
+extern "C" int ht_set_tracker_flags(ht_ctx *ctx, int first, int n, const float *prev_frame_error, const int *initializing)
+{
+	CHECK_READY(ctx); CHECK_RANGE(ctx, first, n);
+	if (prev_frame_error) HIPCHK(ctx, hipMemcpy(ctx->d_prev_err + first, prev_frame_error, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+	if (initializing) HIPCHK(ctx, hipMemcpy(ctx->d_initializing + first, initializing, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+	return HT_OK;
+}
 extern "C" int ht_update_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, const float *d_start_poses, int B, float *d_poses_out, void *stream)
 {
 	CHECK_READY(ctx); CHECK_BATCH(ctx, B);

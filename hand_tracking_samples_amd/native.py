@@ -19,7 +19,7 @@ MAXPTS, ROW, CONTACT = 1024, 16, 12
 SYMBOLS = (
     "ht_create", "ht_destroy", "ht_last_error", "ht_get_params", "ht_set_params", "ht_model_info",
     "ht_cnn_load_weights", "ht_cnn_eval", "ht_cnn_eval_dev",
-    "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_update_sync", "ht_update_dev",
+    "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev",
     "ht_stage_prepare", "ht_stage_decode", "ht_stage_fit_error", "ht_stage_cloud_rows", "ht_stage_contacts", "ht_stage_fit",
     "ht_stage_multistep", "ht_stage_scratch_unibody", "ht_profile_enable", "ht_profile_read",
 )
@@ -68,6 +68,7 @@ def load(build_if_missing=True):
     L.ht_tracker_reset.argtypes = [vp, C.c_int, C.c_int, fp]
     L.ht_get_state.argtypes = [vp, C.c_int, C.c_int, C.c_int, fp]; L.ht_set_state.argtypes = [vp, C.c_int, C.c_int, C.c_int, fp]
     L.ht_get_tracker_flags.argtypes = [vp, C.c_int, C.c_int, fp, ip]
+    L.ht_set_tracker_flags.argtypes = [vp, C.c_int, C.c_int, fp, ip]
     L.ht_update_sync.argtypes = [vp, u16p, fp, C.c_int, fp, fp]
     L.ht_update_dev.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp]
     L.ht_stage_prepare.argtypes = [vp, u16p, fp, C.c_int, fp, fp, ip]
@@ -179,6 +180,10 @@ class Context:
         e = np.empty(n, np.float32); i = np.empty(n, np.int32)
         self._chk(self.L.ht_get_tracker_flags(self.h, first, n, _f(e), _i(i)))
         return e, i
+
+    def set_tracker_flags(self, prev_frame_error, initializing, first=0):
+        e = _c(prev_frame_error, np.float32); i = _c(initializing, np.int32)
+        self._chk(self.L.ht_set_tracker_flags(self.h, first, e.size, _f(e), _i(i)))
 
     def update_sync(self, depth, cams, want_cnn=False):
         depth = _c(depth, np.uint16).reshape(-1, 4096)

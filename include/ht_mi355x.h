@@ -100,7 +100,8 @@ int ht_cnn_eval_dev(ht_ctx *ctx, const float *d_in, float *d_out, int B, void *s
 int ht_tracker_reset(ht_ctx *ctx, int first, int n, const float *poses);
 int ht_get_state(ht_ctx *ctx, int which, int first, int n, float *state);
 int ht_set_state(ht_ctx *ctx, int which, int first, int n, const float *state);
-int ht_get_tracker_flags(ht_ctx *ctx, int first, int n, float *prev_frame_error, int *initializing);
+int ht_get_tracker_flags(ht_ctx *ctx, int first, int n, float *prev_frame_error, int *initializing);     /* HandTracker::prev_frame_error / initializing (handtrack.h:546-547) */
+int ht_set_tracker_flags(ht_ctx *ctx, int first, int n, const float *prev_frame_error, const int *initializing);
 int ht_update_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int B, float *poses_out, float *cnn_out);
 int ht_update_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, const float *d_start_poses, int B, float *d_poses_out, void *stream);
 

@@ -203,9 +203,15 @@ def test_unit_of_work_two_frames(ctx, golden):
     for f in range(NF):
         assert ini[f] == int(golden["f%d/uw_final" % f][1])
         assert abs(pfe[f] - golden["f%d/uw_final" % f][0]) <= 1e-4
+    # second frame of streaming use, teacher-forced from the reference's state after the first frame (free-running
+    # sequences diverge through discrete closest-bone / GJK branch flips, SURVEY section 7 "discrete sensitivity")
+    ctx.set_state(0, np.stack([golden["f%d/uw_hand_pass2" % f] for f in range(NF)]))
+    ctx.set_tracker_flags([golden["f%d/uw_final" % f][0] for f in range(NF)], [int(golden["f%d/uw_final" % f][1]) for f in range(NF)])
     poses2 = ctx.update_sync(depth, cams)
+    pfe, ini = ctx.tracker_flags(NF)
     for f in range(NF):
         ref = golden["f%d/uw2_pose_user" % f]
         dp = np.abs(poses2[f, :, :3] - ref[:, :3]).max(); dq = np.abs(poses2[f, :, 3:] - ref[:, 3:]).max()
         print("second frame %d: |dpos| %.2e |dquat| %.2e" % (f, dp, dq))
         assert dp <= FULL_POS_TOL and dq <= FULL_QUAT_TOL
+        assert ini[f] == int(golden["f%d/uw2_final" % f][1])
