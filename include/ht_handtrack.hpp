@@ -1,0 +1,131 @@
+// ht_handtrack.hpp -- C++ wrappers over the C-ABI (ht_mi355x.h) that keep the reference's own names and signatures, so that
+// code written against include/handtrack.h / third_party/cnn.h of IntelRealSense/hand_tracking_samples keeps compiling:
+//
+//     HandTracker htk;                                   // handtrack.h:830 (paths are constructor arguments here)
+//     htk.microforce = 3.0f; htk.mainthreadpasses = 3;   // synthetic-tracker.cpp:91-93
+//     std::vector<Pose> pose = htk.update(std::move(dimage));      // handtrack.h:748
+//     std::vector<float> y = htk.cnn.Eval(x);                        // cnn.h:550
+//
+// Only the members the per-frame path and synthetic-tracker.cpp touch are provided.  Documented deviation: update()
+// runs the CNN job synchronously every frame (the reference polls a background std::async job for 1 ms, which makes its output
+// timing dependent, handtrack.h:755-768); this is HandTracker::update_cnn_model followed by the main-thread passes.
+// Errors are reported the way the reference's apps expect them: by throwing std::runtime_error (synthetic-tracker.cpp:255-264).
+#pragma once
+#include <cstdint>
+#include <fstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "ht_mi355x.h"
+
+namespace ht_mi355x
+{
+struct float2 { float x, y; };
+struct int2 { int x, y; };
+struct float3 { float x, y, z; };
+struct float4 { float x, y, z, w; };
+struct Pose { float3 position{ 0, 0, 0 }; float4 orientation{ 0, 0, 0, 1 }; };            // geometric.h:111-125
+
+class DCamera                                                                                // misc_image.h:30-55
+{
+	int2 dim_{ 64, 64 }; float2 focal_{ 164.f, 164.f }; float2 principal_{ 32.f, 32.f };
+public:
+	float depth_scale = 0.001f; Pose pose;
+	DCamera() {}
+	DCamera(int2 dim, float2 focal, float2 principal, float depth_scale, Pose pose = Pose()) : dim_(dim), focal_(focal), principal_(principal), depth_scale(depth_scale), pose(pose) {}
+	int2 &dim() { return dim_; } const int2 &dim() const { return dim_; }
+	float2 &focal() { return focal_; } const float2 &focal() const { return focal_; }
+	float2 &principal() { return principal_; } const float2 &principal() const { return principal_; }
+};
+template <class T> struct Image                                                              // misc_image.h:109-129
+{
+	DCamera cam; std::vector<T> raster;
+	Image() {}
+	Image(DCamera cam) : cam(cam), raster((size_t)cam.dim().x * cam.dim().y, T(0)) {}
+	Image(DCamera cam, std::vector<T> data) : cam(cam), raster(std::move(data)) {}
+	const int2 dim() const { return cam.dim(); }
+	T &pixel(int2 p) { return raster[(size_t)p.y * dim().x + p.x]; }
+};
+
+inline void check(ht_ctx *ctx, int rc) { if (rc != HT_OK) throw std::runtime_error(std::string("ht_mi355x: ") + (ctx ? ht_last_error(ctx) : "no context")); }
+
+class CNN                                                                                    // third_party/cnn.h:100-605 (forward surface)
+{
+	ht_ctx *ctx_ = nullptr;
+	friend struct HandTracker;
+public:
+	std::vector<float> Eval(const std::vector<float> &x)                                     // cnn.h:550
+	{
+		if (x.size() != HT_CNN_IN) throw std::runtime_error("CNN::Eval expects 64*64 inputs");
+		std::vector<float> y(HT_CNN_OUT);
+		check(ctx_, ht_cnn_eval(ctx_, x.data(), y.data(), 1));
+		return y;
+	}
+	void loadb(std::istream &s)                                                              // cnn.h:590
+	{
+		std::vector<float> w(HT_CNNB_COUNT);
+		s.read((char *)w.data(), (std::streamsize)(w.size() * sizeof(float)));
+		if ((size_t)s.gcount() != w.size() * sizeof(float)) throw std::runtime_error("CNN::loadb: short .cnnb stream");
+		check(ctx_, ht_cnn_load_weights(ctx_, w.data(), w.size()));
+	}
+	void loadb(std::string fname) { std::ifstream is(fname, std::ios_base::binary | std::ios_base::in); if (!is.is_open()) throw std::runtime_error("cannot open " + fname); loadb(is); }   // cnn.h:592
+};
+
+struct HandTracker                                                                            // include/handtrack.h:513-846
+{
+	// tunables with the reference's names and defaults (handtrack.h:523-547); pushed to the device context before every update
+	float full_reset_on_error = 0.6f; bool angles_only = false; bool always_take_cnn = false; float drangey = 0.7f; int boundary_planes = 1;
+	float microforce = 1.0f; float cloudforce_max_point = 15.0f; float cloudforce_max_sum = 3000.0f; int mainthreadpasses = 1; int subsample_fraction = 4;
+	size_t min_point_num = 400; float accum_error_threshold = 0.0f; float min_cray_prob = 0.0f;
+	int steps = 5, steps_keypoints = 3, steps_keyangles = 2, steps_palmangle = 2, steps_cloudstart = 1, steps_unibody = 3;
+	CNN cnn;
+	Image<float> cnn_input; std::vector<float> cnn_output;
+
+	// model_path: baked model; cnnb_path may be empty: like the reference (handtrack.h:123-126) a missing
+	// weight file is not an error at construction, but update() then fails loudly instead of running on random weights.
+	explicit HandTracker(const std::string &model_path, const std::string &cnnb_path = "", int device = 0)
+	{
+		int rc = ht_create(model_path.c_str(), 1, device, &ctx_);
+		if (rc != HT_OK) { std::string msg = ctx_ ? ht_last_error(ctx_) : "ht_create failed"; if (ctx_) ht_destroy(ctx_); ctx_ = nullptr; throw std::runtime_error("HandTracker: " + msg); }
+		cnn.ctx_ = ctx_;
+		ht_model_info(ctx_, &nb_, nullptr, nullptr);
+		if (!cnnb_path.empty()) { std::ifstream is(cnnb_path, std::ios_base::in | std::ios_base::binary); if (is.is_open()) cnn.loadb(is); }
+		cnn_output.assign(HT_CNN_OUT, 0.01f);
+	}
+	~HandTracker() { if (ctx_) ht_destroy(ctx_); }
+	HandTracker(const HandTracker &) = delete; HandTracker &operator=(const HandTracker &) = delete;
+
+	void SetPose(const std::vector<Pose> &pose) { check(ctx_, ht_tracker_reset(ctx_, 0, 1, flat(pose).data())); }          // handmodel/othermodel.SetPose
+
+	std::vector<Pose> update(Image<unsigned short> dimage)                                   // handtrack.h:748
+	{
+		if (dimage.dim().x != 64 || dimage.dim().y != 64) throw std::runtime_error("HandTracker::update: 64x64 tiles only (run HandSegmentVR first)");
+		push_params();
+		const DCamera &c = dimage.cam;
+		float cam[HT_CAM] = { c.focal().x, c.focal().y, c.principal().x, c.principal().y, c.depth_scale, c.pose.position.x, c.pose.position.y, c.pose.position.z,
+		                      c.pose.orientation.x, c.pose.orientation.y, c.pose.orientation.z, c.pose.orientation.w };
+		std::vector<float> out((size_t)nb_ * HT_POSE);
+		check(ctx_, ht_update_sync(ctx_, dimage.raster.data(), cam, 1, out.data(), cnn_output.data()));
+		std::vector<Pose> pose(nb_);
+		for (int b = 0; b < nb_; b++) { const float *p = &out[(size_t)b * HT_POSE]; pose[b].position = { p[0], p[1], p[2] }; pose[b].orientation = { p[3], p[4], p[5], p[6] }; }
+		return pose;
+	}
+private:
+	ht_ctx *ctx_ = nullptr; int nb_ = 0;
+	std::vector<float> flat(const std::vector<Pose> &pose) const
+	{
+		std::vector<float> f((size_t)nb_ * HT_POSE, 0.f);
+		for (int b = 0; b < nb_ && b < (int)pose.size(); b++) { float *p = &f[(size_t)b * HT_POSE]; p[0] = pose[b].position.x; p[1] = pose[b].position.y; p[2] = pose[b].position.z; p[3] = pose[b].orientation.x; p[4] = pose[b].orientation.y; p[5] = pose[b].orientation.z; p[6] = pose[b].orientation.w; }
+		return f;
+	}
+	void push_params()
+	{
+		ht_params p; check(ctx_, ht_get_params(ctx_, &p));
+		p.full_reset_on_error = full_reset_on_error; p.angles_only = angles_only; p.always_take_cnn = always_take_cnn; p.drangey = drangey; p.boundary_planes = boundary_planes;
+		p.microforce = microforce; p.cloudforce_max_point = cloudforce_max_point; p.cloudforce_max_sum = cloudforce_max_sum; p.mainthreadpasses = mainthreadpasses;
+		p.subsample_fraction = subsample_fraction; p.min_point_num = (int)min_point_num; p.accum_error_threshold = accum_error_threshold; p.min_cray_prob = min_cray_prob;
+		p.steps = steps; p.steps_keypoints = steps_keypoints; p.steps_keyangles = steps_keyangles; p.steps_palmangle = steps_palmangle; p.steps_cloudstart = steps_cloudstart; p.steps_unibody = steps_unibody;
+		check(ctx_, ht_set_params(ctx_, &p));
+	}
+};
+}  // namespace ht_mi355x

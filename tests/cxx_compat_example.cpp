@@ -1,0 +1,19 @@
+// Compile-and-link check of the C++ compatibility header (and, on a GPU box, a one-frame run).
+#include <cstdio>
+#include "../include/ht_handtrack.hpp"
+using namespace ht_mi355x;
+int main(int argc, char **argv)
+{
+	if (argc < 2) { printf("usage: %s model.htfx [weights.cnnb]\n", argv[0]); return 2; }
+	try
+	{
+		HandTracker htk(argv[1], argc > 2 ? argv[2] : "");
+		htk.microforce = 3.0f; htk.mainthreadpasses = 3;
+		Image<unsigned short> dimage(DCamera({ 64, 64 }, { 164.f, 164.f }, { 32.f, 32.f }, 0.001f));
+		for (auto &d : dimage.raster) d = 4000;
+		std::vector<float> x(HT_CNN_IN, 0.5f);
+		if (argc > 2) { auto y = htk.cnn.Eval(x); printf("cnn out[0]=%g\n", y[0]); auto pose = htk.update(std::move(dimage)); printf("bones=%zu\n", pose.size()); }
+	}
+	catch (const std::exception &e) { printf("error: %s\n", e.what()); return 1; }
+	return 0;
+}
