@@ -12,6 +12,7 @@ struct solve_args
 	float *state;                                                   // [B][nb][HT_STATE_STRIDE] of the model being solved
 	float *scratch; int scratch_stride;                             // [B][scratch_stride][12] pre-computed single-body row stream
 	int apply_angles; float drive_force; int ray_rows; int arm_cone; int zero_momenta; int steps_keyangles; float min_cray_prob;
+	int dbg;                                                        // timing experiments only (HT_DEBUG_SKIP): 1 skip chains, 2 skip two-body linear, 4 skip angular
 };
 
 void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const float *cams, const int *active_flag, int stride, int use_cam_origin, int mode,

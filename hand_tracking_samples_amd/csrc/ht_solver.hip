@@ -10,33 +10,36 @@
 //   HandModelEnhancements, CNNOutputAnalysis::ApplyAngles, the landmark-ray rows of MultiStepSim   include/handtrack.h:406-441, 203-216, 666-676
 //   SanityCheck                         include/physmodel.h:437-442
 //
-// Exact-order parallelism.  The reference applies rows strictly in vector order.  Rows with rb0 == NULL touch one body only, and
-// such rows on different bodies commute exactly; they form a prefix of the row vector (chamber / landmark-ray rows, then cloud rows).
-// That prefix is stably partitioned by body, pre-computed (lever arm r1 = R*position1, effective mass, limits*dt: all invariant during
-// one PhysicsUpdate) and streamed from HBM/L2; lane b then walks the chain of body b with the body's momenta in registers.  The
-// two-body tail (joint rows, contact triples, all angular rows) runs in reference order, wave-uniform, on LDS-resident body state.
+// Exact-order parallelism.  The reference applies rows strictly in vector order; two rows commute exactly when they touch disjoint
+// bodies.  (1) Rows with rb0 == NULL touch one body only and form a prefix of the row vector (chamber / landmark-ray rows, then
+// cloud rows): the prefix is stably partitioned by body, pre-computed (lever arm r1 = R*position1, effective mass, limits*dt: all
+// invariant during one PhysicsUpdate) into LDS, and lane b walks the chain of body b with the body's momenta in registers.
+// (2) The two-body tail (joint rows, contact triples; then all angular rows) is list-scheduled: level(row) = 1 + the highest level
+// of an earlier row sharing a body, so conflicting rows keep their order and rows of one level touch disjoint bodies.  Row r lives in
+// the registers of lane r%64; levels run one after the other, the rows of a level in parallel lanes, on LDS-resident body momenta.
+// For the 17-bone hand that is ~24 levels for the 48 joint rows and ~35-45 for the ~70-85 angular rows.
 // Everything is compiled -ffp-contract=off, so the result is the reference's bit for bit except for acos/sin/cos in a few row builders.
 #include "ht_device.hpp"
 #include "ht_launch.hpp"
 
 #define SROW 12            // floats per pre-computed single-body row: r1[3] n[3] targetspeed tsnobias fmin*dt fmax*dt impulsed impulsesum
-#define MAX2 (3 * HT_MAXNJ + 3 * 48)     // two-body linear rows kept in LDS (joints + 48 contacts)
-#define L2W 20             // words per two-body linear row in LDS
-#define MAXA 160           // angular rows kept in LDS
-#define AW 12              // words per angular row in LDS
-
+#define CH_CAP 640         // single-body rows kept in LDS (30 KB); the rest of a frame's chain rows stream from the HBM scratch
+#define LSLOTS 3           // two-body linear rows live in registers: row r in lane r%64, slot r/64  (<= 192 rows: 3*nj + 3*contacts)
+#define ASLOTS 2           // angular rows likewise (<= 128 rows)
+#define MAXL2 (64 * LSLOTS)
+#define MAXA2 (64 * ASLOTS)
 
 struct lds_t
 {
 	float pos[HT_MAXNB][3], q[HT_MAXNB][4], lin[HT_MAXNB][3], ang[HT_MAXNB][3], Iinv[HT_MAXNB][9], massinv[HT_MAXNB], friction[HT_MAXNB];
-	float pos_next[HT_MAXNB][3], q_next[HT_MAXNB][4];
 	float jr[HT_MAXNJ][6];                 // joint ranges after HandModelEnhancements
-	float l2[MAX2][L2W];                   // rb0 rb1 r0[3] r1[3] n[3] ts tsnb fmin fmax impulsed impulsesum fm | pad
-	float an[MAXA][AW];                    // rb0 rb1 axis[3] targetspin min*dt max*dt spintotorque torque mintorque | pad
-	int cnt[HT_MAXNB], start[HT_MAXNB];
-	int acount[HT_MAXNJ + 1];
-	float ray[20][HT_ROW];
-	int nray;
+	float ray[20][HT_ROW]; int nray;
+	int acount[HT_MAXNJ], aprefix[HT_MAXNJ + 1];
+	unsigned char lrb[MAXL2][2], arb[MAXA2][2];     // body pair of every two-body row (255 = none), for the level schedule
+	unsigned char llev[MAXL2], alev[MAXA2];
+	int nlev_lin, nlev_ang;
+	float cisum[64];                       // impulse sum of each contact's normal row, read by its two friction rows (physics.h:292)
+	float chain[CH_CAP][SROW];
 };
 
 __device__ __forceinline__ v3 L3(const float *p) { return V3(p[0], p[1], p[2]); }
@@ -135,6 +138,25 @@ __device__ __forceinline__ void linear_precompute(const ht_physics_dev &ph, cons
 }
 
 // ------------------------------------------------------------------------------------------------- k_solve
+struct lrow { int rb0, rb1; v3 r0, r1, n; float ts, tsnb, fmn, fmx, impulsed, isum; int fm, lev, cidx; };
+struct arow { int rb0, rb1; v3 axis; float targetspin, mn, mx, s2t, torque, mintorque; int lev; };
+
+// row counts of ConstrainAngularRangeW (physics.h:351-393) for given limits, without building the rows
+__device__ __forceinline__ int angular_range_count(v3 lmin, v3 lmax)
+{
+	v3 jmin = (lmin * 3.14f) / 180.0f, jmax = (lmax * 3.14f) / 180.0f;
+	if (jmin.x == 0 && jmax.x == 0 && jmin.z < jmax.z)
+	{
+		v3 nmin = V3(lmin.z, lmin.y, 0), nmax = V3(lmax.z, lmax.y, 0);
+		jmin = (nmin * 3.14f) / 180.0f; jmax = (nmax * 3.14f) / 180.0f;
+	}
+	int n = 0;
+	if (jmax.x == jmin.x) n += 1; else if (jmax.x - jmin.x < 360.0f * 3.14f / 180.0f) n += 2;
+	n += (jmax.y == jmin.y) ? 1 : 2;
+	n += (jmin.z == jmax.z) ? 1 : 2;
+	return n;
+}
+
 __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph, solve_args a)
 {
 	__shared__ lds_t S;
@@ -177,117 +199,16 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		}
 		else if (lane < 8)
 		{
-			const int kb[4] = { 14, 11, 8, 5 }; const float r0[4] = { -30.0f, -10.0f, -10.0f, -10.0f }, r1[4] = { 10.0f, 10.0f, 10.0f, 20.0f };
 			const int k = lane - 4;
-			bool up = (double)dot(qydir(L4(S.q[1])), qydir(L4(S.q[kb[k]]))) > ph.cos40d;
-			S.jr[kb[k] - 1][1] = up ? r0[k] : -0.0f;
-			S.jr[kb[k] - 1][4] = up ? r1[k] : 0.0f;
+			const int kb = k == 0 ? 14 : k == 1 ? 11 : k == 2 ? 8 : 5;
+			const float r0 = k == 0 ? -30.0f : -10.0f, r1 = k == 3 ? 20.0f : 10.0f;          // handtrack.h:434
+			bool up = (double)dot(qydir(L4(S.q[1])), qydir(L4(S.q[kb]))) > ph.cos40d;
+			S.jr[kb - 1][1] = up ? r0 : -0.0f;
+			S.jr[kb - 1][4] = up ? r1 : 0.0f;
 		}
 	}
-	__syncthreads();
-
-	// ---- angular rows: [ApplyAngles 12] [arm cone 1] [joint ranges] ----
-	int na_pre = 0;
-	if (a.apply_angles || a.arm_cone)
-	{
-		if (lane == 0)
-		{
-			float tmp[13][8];
-			int k = 0;
-			const float *cam = a.cams + (size_t)b * HT_CAM;
-			const v4 camq = V4(cam[8], cam[9], cam[10], cam[11]);
-			if (a.apply_angles)
-			{
-				const float *an = a.analysis + (size_t)b * HT_ANALYSIS;
-				const v4 palmq = V4(an[HT_AN_PALMQ], an[HT_AN_PALMQ + 1], an[HT_AN_PALMQ + 2], an[HT_AN_PALMQ + 3]);
-				const float *fc = an + HT_AN_CLENCH;
-				angular_drive(ph, S, -1, 1, qmul(camq, palmq), a.drive_force, tmp); k = 3;                              // handtrack.h:206
-				float th = fc[0];
-				cone_angle(ph, S, 1, V3((float)cos((double)th), 0, (float)sin((double)th)), 4, V3(0, 0, 1), 10.0f, tmp[k++]);
-				for (int finger = 1; finger <= 4; finger++)
-				{
-					float aa = fc[finger];
-					cone_angle(ph, S, 1, V3(0, (float)(-sin((double)aa)), (float)cos((double)aa)), 3 + finger * 3, V3(0, 0, 1), 10.0f, tmp[k++]);
-					v4 jf = L4(M.jointc + (1 + finger * 3) * HT_JC + HT_JC_FRAME);
-					v3 inner = V3(0, (float)(-sin((double)(aa / 2.0f))), (float)cos((double)(aa / 2.0f)));
-					cone_angle(ph, S, 1, qrot(jf, qrot(jf, inner)), 2 + finger * 3, V3(0, 0, 1), 10.0f, tmp[k++]);
-				}
-			}
-			if (a.arm_cone) cone_angle(ph, S, -1, qrot(camq, V3(0, -1, 0)), 0, V3(0, 0, 1), 70.0f, tmp[k++]);             // handtrack.h:426, 684
-			for (int i = 0; i < k; i++) for (int j = 0; j < 8; j++) S.an[i][j] = tmp[i][j];
-			S.acount[HT_MAXNJ] = k;
-		}
-		__syncthreads();
-		na_pre = S.acount[HT_MAXNJ];
-	}
-	{
-		float jrows[6][8];
-		int n = 0;
-		if (lane < nj)
-		{
-			const float *jc = M.jointc + lane * HT_JC;
-			const int rb0 = (int)jc[HT_JC_RB0], rb1 = (int)jc[HT_JC_RB1];
-			const v4 jf = L4(jc + HT_JC_FRAME);
-			n = angular_range_w(ph, rb0, rb0 >= 0 ? qmul(L4(S.q[rb0]), jf) : jf, rb1, rb1 >= 0 ? L4(S.q[rb1]) : V4(0, 0, 0, 1), L3(S.jr[lane]), L3(S.jr[lane] + 3), jrows);
-			S.acount[lane] = n;
-		}
-		__syncthreads();
-		int off = na_pre;
-		for (int j = 0; j < lane && j < nj; j++) off += S.acount[j];
-		if (lane < nj) for (int i = 0; i < n && off + i < MAXA; i++) for (int k = 0; k < 8; k++) S.an[off + i][k] = jrows[i][k];
-	}
-	__syncthreads();
-	int na = na_pre;
-	for (int j = 0; j < nj; j++) na += S.acount[j];
-	if (na > MAXA) na = MAXA;
-	// pre-compute per angular row: min*dt, max*dt, spintotorque (physics.h:256-259); Iinv is invariant during the update
-	for (int i = lane; i < na; i += 64)
-	{
-		float *w = S.an[i];
-		const int rb0 = __float_as_int(w[0]), rb1 = __float_as_int(w[1]);
-		const v3 axis = L3(w + 2);
-		const float mintorque = w[6], maxtorque = w[7];
-		float spintotorque = 1.0f / (((rb0 >= 0) ? dot(axis, mul(LM(S.Iinv[rb0]), axis)) : 0.0f) + ((rb1 >= 0) ? dot(axis, mul(LM(S.Iinv[rb1]), axis)) : 0.0f));
-		w[6] = mintorque * dt; w[7] = maxtorque * dt; w[8] = spintotorque; w[9] = 0.0f; w[10] = mintorque;
-	}
-
-	// ---- two-body linear rows: joints (physmodel.h:328-334) then contacts (physics.h:463-489) ----
-	if (lane < nj)
-	{
-		const float *jc = M.jointc + lane * HT_JC;
-		const int rb0 = (int)jc[HT_JC_RB0], rb1 = (int)jc[HT_JC_RB1];
-		const v3 p0 = L3(jc + HT_JC_P0) - L3(M.bodyc + rb0 * HT_BC + HT_BC_COM), p1 = L3(jc + HT_JC_P1) - L3(M.bodyc + rb1 * HT_BC + HT_BC_COM);
-		const v3 d = anchor_world(S, rb1, p1) - anchor_world(S, rb0, p0);
-		linear_precompute(ph, S, S.l2[3 * lane + 0], rb0, rb1, p0, p1, V3(1, 0, 0), d.x, 0.0f, -FLT_MAX, FLT_MAX, 0);
-		linear_precompute(ph, S, S.l2[3 * lane + 1], rb0, rb1, p0, p1, V3(0, 1, 0), d.y, 0.0f, -FLT_MAX, FLT_MAX, 0);
-		linear_precompute(ph, S, S.l2[3 * lane + 2], rb0, rb1, p0, p1, V3(0, 0, 1), d.z, 0.0f, -FLT_MAX, FLT_MAX, 0);
-	}
-	int nc = (a.contacts && ph.use_collision) ? a.ncontacts[b] : 0;
-	if (nc > 48) nc = 48;
-	if (lane < nc)
-	{
-		const float *c = a.contacts + ((size_t)b * HT_MAXCONTACT + lane) * HT_CONTACT;
-		const int rb0 = (int)c[0], rb1 = (int)c[1];
-		const v3 normal = L3(c + 2), p0w = L3(c + 5), p1w = L3(c + 8);
-		const float separation = c[11];
-		const v3 p0 = apply(inverse(body_xf(S, rb0)), p0w), p1 = apply(inverse(body_xf(S, rb1)), p1w);        // PhysContact physics.h:431-432
-		const v3 r0 = p0w - L3(S.pos[rb0]), r1 = p1w - L3(S.pos[rb1]);
-		const v3 v0 = cross(spin_of(S, rb0), r0) + L3(S.lin[rb0]) * S.massinv[rb0];
-		const v3 v1 = cross(spin_of(S, rb1), r1) + L3(S.lin[rb1]) * S.massinv[rb1];
-		const v3 v = v0 - v1;
-		const float minsep = ph.driftmax * 0.25f;
-		const float bouncevel = fmax_std(0.0f, (-dot(normal, v) - ph.gravity_len * ph.falltime_to_ballistic) * ph.restitution);
-		float *w = S.l2[3 * nj + 3 * lane];
-		linear_precompute(ph, S, w, rb0, rb1, p0, p1, -normal, fmin_std((separation - minsep) * ph.biasfactorpositive, separation), -bouncevel, 0, FLT_MAX, 0);
-		v4 q = quat_from_to(V3(0, 0, 1), -normal);
-		v3 tangent = qxdir(q), binormal = qydir(q);
-		linear_precompute(ph, S, w + L2W, rb0, rb1, p0, p1, binormal, 0, 0, 0, 0, -1);
-		linear_precompute(ph, S, w + 2 * L2W, rb0, rb1, p0, p1, tangent, 0, 0, 0, 0, -2);
-	}
-	const int n2 = 3 * nj + 3 * nc;
-
 	// ---- landmark-ray rows of MultiStepSim (handtrack.h:666-676): 2 dead-zone pairs per open finger ----
-	if (a.ray_rows && lane == 0)
+	if (a.ray_rows && lane == 8)
 	{
 		const float *an = a.analysis + (size_t)b * HT_ANALYSIS;
 		const float *cam = a.cams + (size_t)b * HT_CAM;
@@ -316,7 +237,167 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	}
 	__syncthreads();
 
-	// ---- single-body prefix: [ray rows | chamber rows] then cloud rows; stable partition by body + pre-compute -> scratch ----
+	// ---- angular rows: [ApplyAngles 12] [arm cone 1] [joint ranges], generated by the lane that owns them ----
+	const int na_pre = (a.apply_angles ? 12 : 0) + (a.arm_cone ? 1 : 0);
+	if (lane < nj) S.acount[lane] = angular_range_count(L3(S.jr[lane]), L3(S.jr[lane] + 3));
+	__syncthreads();
+	if (lane == 0) { int acc = na_pre; for (int j = 0; j < nj; j++) { S.aprefix[j] = acc; acc += S.acount[j]; } S.aprefix[nj] = acc; }
+	__syncthreads();
+	int na = S.aprefix[nj];
+	if (na > MAXA2) na = MAXA2;
+	arow AR[ASLOTS];
+#pragma unroll
+	for (int s = 0; s < ASLOTS; s++)
+	{
+		const int r = lane + 64 * s;
+		arow &R = AR[s];
+		R.rb0 = -1; R.rb1 = -1; R.axis = V3(0, 0, 1); R.targetspin = -FLT_MAX; R.mn = 0; R.mx = 0; R.s2t = 0; R.torque = 0; R.mintorque = 0; R.lev = 0;
+		if (r < na)
+		{
+			float row[8];
+			if (r < na_pre)
+			{
+				const float *cam = a.cams + (size_t)b * HT_CAM;
+				const v4 camq = V4(cam[8], cam[9], cam[10], cam[11]);
+				const int ra = a.apply_angles ? r : 12;          // index into the ApplyAngles list, 12 = the arm cone
+				if (ra == 12) cone_angle(ph, S, -1, qrot(camq, V3(0, -1, 0)), 0, V3(0, 0, 1), 70.0f, row);             // handtrack.h:426, 684
+				else
+				{
+					const float *an = a.analysis + (size_t)b * HT_ANALYSIS;
+					const float *fc = an + HT_AN_CLENCH;
+					if (ra < 3)
+					{
+						float tmp[3][8];
+						angular_drive(ph, S, -1, 1, qmul(camq, V4(an[HT_AN_PALMQ], an[HT_AN_PALMQ + 1], an[HT_AN_PALMQ + 2], an[HT_AN_PALMQ + 3])), a.drive_force, tmp);      // handtrack.h:206
+						for (int k = 0; k < 8; k++) row[k] = ra == 0 ? tmp[0][k] : ra == 1 ? tmp[1][k] : tmp[2][k];
+					}
+					else if (ra == 3) { float th = fc[0]; cone_angle(ph, S, 1, V3((float)cos((double)th), 0, (float)sin((double)th)), 4, V3(0, 0, 1), 10.0f, row); }
+					else
+					{
+						const int finger = 1 + (ra - 4) / 2;
+						const float aa = fc[finger];
+						if (((ra - 4) & 1) == 0) cone_angle(ph, S, 1, V3(0, (float)(-sin((double)aa)), (float)cos((double)aa)), 3 + finger * 3, V3(0, 0, 1), 10.0f, row);
+						else
+						{
+							v4 jf = L4(M.jointc + (1 + finger * 3) * HT_JC + HT_JC_FRAME);
+							v3 inner = V3(0, (float)(-sin((double)(aa / 2.0f))), (float)cos((double)(aa / 2.0f)));
+							cone_angle(ph, S, 1, qrot(jf, qrot(jf, inner)), 2 + finger * 3, V3(0, 0, 1), 10.0f, row);
+						}
+					}
+				}
+			}
+			else
+			{
+				int j = 0;
+				while (j + 1 < nj && S.aprefix[j + 1] <= r) j++;
+				const int sub = r - S.aprefix[j];
+				const float *jc = M.jointc + j * HT_JC;
+				const int rb0 = (int)jc[HT_JC_RB0], rb1 = (int)jc[HT_JC_RB1];
+				const v4 jf = L4(jc + HT_JC_FRAME);
+				float jrows[6][8];
+				angular_range_w(ph, rb0, rb0 >= 0 ? qmul(L4(S.q[rb0]), jf) : jf, rb1, rb1 >= 0 ? L4(S.q[rb1]) : V4(0, 0, 0, 1), L3(S.jr[j]), L3(S.jr[j] + 3), jrows);
+				for (int k = 0; k < 8; k++) row[k] = sub == 0 ? jrows[0][k] : sub == 1 ? jrows[1][k] : sub == 2 ? jrows[2][k] : sub == 3 ? jrows[3][k] : sub == 4 ? jrows[4][k] : jrows[5][k];
+			}
+			R.rb0 = __float_as_int(row[0]); R.rb1 = __float_as_int(row[1]); R.axis = V3(row[2], row[3], row[4]); R.targetspin = row[5];
+			const float mintorque = row[6], maxtorque = row[7];
+			// physics.h:256-259: Iinv is invariant during the update, so 1/(axis.Iinv0.axis + axis.Iinv1.axis) is computed once
+			R.s2t = 1.0f / (((R.rb0 >= 0) ? dot(R.axis, mul(LM(S.Iinv[R.rb0]), R.axis)) : 0.0f) + ((R.rb1 >= 0) ? dot(R.axis, mul(LM(S.Iinv[R.rb1]), R.axis)) : 0.0f));
+			R.mn = mintorque * dt; R.mx = maxtorque * dt; R.mintorque = mintorque; R.torque = 0.0f;
+			S.arb[r][0] = (unsigned char)(R.rb0 >= 0 ? R.rb0 : 255); S.arb[r][1] = (unsigned char)(R.rb1 >= 0 ? R.rb1 : 255);
+		}
+	}
+
+	// ---- two-body linear rows: joints (physmodel.h:328-334) then contacts (physics.h:463-489), each built by its owner lane ----
+	int nc = (a.contacts && ph.use_collision) ? a.ncontacts[b] : 0;
+	if (3 * nj + 3 * nc > MAXL2) nc = (MAXL2 - 3 * nj) / 3;
+	const int n2 = 3 * nj + 3 * nc;
+	lrow LR[LSLOTS];
+#pragma unroll
+	for (int s = 0; s < LSLOTS; s++)
+	{
+		const int r = lane + 64 * s;
+		lrow &R = LR[s];
+		R.rb0 = -1; R.rb1 = -1; R.r0 = R.r1 = R.n = V3(0, 0, 0); R.ts = R.tsnb = R.fmn = R.fmx = R.isum = 0; R.impulsed = 1; R.fm = 0; R.lev = 0; R.cidx = 0;
+		if (r < n2)
+		{
+			v3 p0, p1, n; float targetdist, tsnb, fmn, fmx;
+			if (r < 3 * nj)
+			{
+				const int j = r / 3, ax = r % 3;
+				const float *jc = M.jointc + j * HT_JC;
+				R.rb0 = (int)jc[HT_JC_RB0]; R.rb1 = (int)jc[HT_JC_RB1];
+				p0 = L3(jc + HT_JC_P0) - L3(M.bodyc + R.rb0 * HT_BC + HT_BC_COM); p1 = L3(jc + HT_JC_P1) - L3(M.bodyc + R.rb1 * HT_BC + HT_BC_COM);
+				const v3 d = anchor_world(S, R.rb1, p1) - anchor_world(S, R.rb0, p0);                       // ConstrainPositionNailed physics.h:342-346
+				n = V3(ax == 0 ? 1.0f : 0.0f, ax == 1 ? 1.0f : 0.0f, ax == 2 ? 1.0f : 0.0f);
+				targetdist = ax == 0 ? d.x : ax == 1 ? d.y : d.z; tsnb = 0.0f; fmn = -FLT_MAX; fmx = FLT_MAX;
+			}
+			else
+			{
+				const int ci = (r - 3 * nj) / 3, k = (r - 3 * nj) % 3;
+				const float *c = a.contacts + ((size_t)b * HT_MAXCONTACT + ci) * HT_CONTACT;
+				R.rb0 = (int)c[0]; R.rb1 = (int)c[1]; R.cidx = ci;
+				const v3 normal = L3(c + 2), p0w = L3(c + 5), p1w = L3(c + 8);
+				const float separation = c[11];
+				p0 = apply(inverse(body_xf(S, R.rb0)), p0w); p1 = apply(inverse(body_xf(S, R.rb1)), p1w);          // PhysContact physics.h:431-432
+				if (k == 0)
+				{
+					const v3 r0w = p0w - L3(S.pos[R.rb0]), r1w = p1w - L3(S.pos[R.rb1]);
+					const v3 v0 = cross(spin_of(S, R.rb0), r0w) + L3(S.lin[R.rb0]) * S.massinv[R.rb0];
+					const v3 v1 = cross(spin_of(S, R.rb1), r1w) + L3(S.lin[R.rb1]) * S.massinv[R.rb1];
+					const v3 v = v0 - v1;
+					const float minsep = ph.driftmax * 0.25f;
+					const float bouncevel = fmax_std(0.0f, (-dot(normal, v) - ph.gravity_len * ph.falltime_to_ballistic) * ph.restitution);
+					n = -normal; targetdist = fmin_std((separation - minsep) * ph.biasfactorpositive, separation); tsnb = -bouncevel; fmn = 0; fmx = FLT_MAX;
+				}
+				else
+				{
+					v4 q = quat_from_to(V3(0, 0, 1), -normal);
+					n = k == 1 ? qydir(q) : qxdir(q);           // row order: normal, binormal (friction_master -1), tangent (-2)
+					targetdist = 0; tsnb = 0; fmn = 0; fmx = 0; R.fm = -k;
+				}
+			}
+			R.r0 = qrot(L4(S.q[R.rb0]), p0); R.r1 = qrot(L4(S.q[R.rb1]), p1); R.n = n;
+			R.impulsed = (S.massinv[R.rb0] + dot(cross(mul(LM(S.Iinv[R.rb0]), cross(R.r0, n)), R.r0), n)) + (S.massinv[R.rb1] + dot(cross(mul(LM(S.Iinv[R.rb1]), cross(R.r1, n)), R.r1), n));
+			R.ts = targetdist / dt; R.tsnb = tsnb; R.fmn = fmin_std(fmn, fmx) * dt; R.fmx = fmax_std(fmn, fmx) * dt; R.isum = 0.0f;
+			S.lrb[r][0] = (unsigned char)R.rb0; S.lrb[r][1] = (unsigned char)R.rb1;
+		}
+	}
+	if (lane < 64) S.cisum[lane] = 0.0f;
+	__syncthreads();
+	// ---- level schedule (one lane, once per solve): level(row) = 1 + max level of an earlier row sharing a body ----
+	if (lane == 0)
+	{
+		unsigned char last[HT_MAXNB];
+		for (int k = 0; k < nb; k++) last[k] = 0;
+		int mx = 0;
+		for (int r = 0; r < n2; r++)
+		{
+			const int b0 = S.lrb[r][0], b1 = S.lrb[r][1];
+			int l = (last[b0] > last[b1] ? last[b0] : last[b1]) + 1;
+			last[b0] = last[b1] = (unsigned char)l; S.llev[r] = (unsigned char)l; if (l > mx) mx = l;
+		}
+		S.nlev_lin = mx;
+		for (int k = 0; k < nb; k++) last[k] = 0;
+		mx = 0;
+		for (int r = 0; r < na; r++)
+		{
+			const int b0 = S.arb[r][0], b1 = S.arb[r][1];
+			int l0 = b0 != 255 ? last[b0] : 0, l1 = b1 != 255 ? last[b1] : 0;
+			int l = (l0 > l1 ? l0 : l1) + 1;
+			if (b0 != 255) last[b0] = (unsigned char)l;
+			if (b1 != 255) last[b1] = (unsigned char)l;
+			S.alev[r] = (unsigned char)l; if (l > mx) mx = l;
+		}
+		S.nlev_ang = mx;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int s = 0; s < LSLOTS; s++) if (lane + 64 * s < n2) LR[s].lev = S.llev[lane + 64 * s];
+#pragma unroll
+	for (int s = 0; s < ASLOTS; s++) if (lane + 64 * s < na) AR[s].lev = S.alev[lane + 64 * s];
+	const int nlev_lin = S.nlev_lin, nlev_ang = S.nlev_ang;
+
+	// ---- single-body prefix: [ray rows | chamber rows] then cloud rows; stable partition by body + pre-compute -> LDS (overflow: HBM) ----
 	const int npre_g = a.rows_pre ? a.n_pre[b] : 0;
 	const int npre = a.ray_rows ? S.nray : npre_g;
 	const int ncl = a.rows_cloud ? a.n_cloud[b] : 0;
@@ -345,7 +426,6 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 #pragma unroll
 	for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(mystart, o); if (lane >= o) mystart += v; }
 	mystart -= mycnt;
-	if (lane < nb) { S.cnt[lane] = mycnt; S.start[lane] = mystart; }
 	int myrun = 0;
 	for (int base = 0; base < n1; base += 64)          // pass B: placement in stable order + pre-compute
 	{
@@ -369,7 +449,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			const v3 p1 = L3(r + 5), n = L3(r + 8);
 			const v3 r1 = qrot(L4(S.q[body]), p1);
 			const float impulsed = S.massinv[body] + dot(cross(mul(LM(S.Iinv[body]), cross(r1, n)), r1), n);       // 0 + (...) for the NULL side
-			float4 *o = reinterpret_cast<float4 *>(scr + (size_t)dst * SROW);
+			float4 *o = reinterpret_cast<float4 *>(dst < CH_CAP ? &S.chain[dst][0] : scr + (size_t)dst * SROW);
 			o[0] = make_float4(r1.x, r1.y, r1.z, n.x);
 			o[1] = make_float4(n.y, n.z, r[11] / dt, r[12]);
 			o[2] = make_float4(r[13] * dt, r[14] * dt, impulsed, 0.0f);
@@ -378,23 +458,25 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	__syncthreads();
 
 	// ---- Gauss-Seidel sweeps ----
+	v3 pos_next = V3(0, 0, 0); v4 q_next = V4(0, 0, 0, 1);
 	const int total_sweeps = ph.iterations + ph.iterations_post;
 	for (int sweep = 0; sweep < total_sweeps; sweep++)
 	{
 		const bool post = sweep >= ph.iterations;
-		// chains: lane b applies the rows of body b in order
-		if (lane < nb && mycnt > 0)
+		// (1) chains: lane b applies the single-body rows of body b in order, momenta in registers
+		if (lane < nb && mycnt > 0 && !(a.dbg & 1))
 		{
 			v3 lin = L3(S.lin[lane]), ang = L3(S.ang[lane]);
 			const m3 I = LM(S.Iinv[lane]);
 			const float minv = S.massinv[lane];
-			float *rp = scr + (size_t)mystart * SROW;
-			const int cnt = mycnt;
+			auto rowp = [&](int idx) -> float * { return idx < CH_CAP ? &S.chain[idx][0] : scr + (size_t)idx * SROW; };
+			float *rp = rowp(mystart);
 			float4 c0 = reinterpret_cast<float4 *>(rp)[0], c1 = reinterpret_cast<float4 *>(rp)[1], c2 = reinterpret_cast<float4 *>(rp)[2];
-			for (int k = 0; k < cnt; k++)
+			for (int k = 0; k < mycnt; k++)
 			{
 				float4 n0 = c0, n1 = c1, n2 = c2;
-				if (k + 1 < cnt) { const float4 *nx = reinterpret_cast<const float4 *>(rp + (size_t)(k + 1) * SROW); n0 = nx[0]; n1 = nx[1]; n2 = nx[2]; }      // prefetch
+				float *np = rp;
+				if (k + 1 < mycnt) { np = rowp(mystart + k + 1); const float4 *nx = reinterpret_cast<const float4 *>(np); n0 = nx[0]; n1 = nx[1]; n2 = nx[2]; }      // prefetch
 				const v3 r1 = V3(c0.x, c0.y, c0.z), n = V3(c0.w, c1.x, c1.y);
 				const float ts = post ? fmin_std(c1.z, c1.w) : c1.z;                      // RemoveBias physics.h:288
 				const v3 v1 = cross(mul(I, ang), r1) + lin * minv;
@@ -405,62 +487,78 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				impulse = fmax_std(c2.x - c2.w, impulse);
 				const v3 imp = n * impulse;
 				lin = lin + imp; ang = ang + cross(r1, imp);
-				rp[(size_t)k * SROW + 11] = c2.w + impulse;
-				c0 = n0; c1 = n1; c2 = n2;
+				rp[11] = c2.w + impulse;
+				c0 = n0; c1 = n1; c2 = n2; rp = np;
 			}
 			S3(S.lin[lane], lin); S3(S.ang[lane], ang);
 		}
 		__syncthreads();
-		// two-body linear rows, reference order, wave-uniform
-		for (int i = 0; i < n2; i++)
+		// (2) two-body linear rows, level by level (LimitLinear::Iter physics.h:289-307)
+		for (int L = 1; L <= ((a.dbg & 2) ? 0 : nlev_lin); L++)
 		{
-			float *w = S.l2[i];
-			const int rb0 = __float_as_int(w[0]), rb1 = __float_as_int(w[1]), fm = __float_as_int(w[17]);
-			float fmn = w[13], fmx = w[14];
-			if (fm)
+#pragma unroll
+			for (int s = 0; s < LSLOTS; s++)
 			{
-				const float master = S.l2[i + fm][16];
-				const float lim = fmax_std(((rb0 >= 0) ? S.friction[rb0] : 0), ((rb1 >= 0) ? S.friction[rb1] : 0)) * master / dt;       // physics.h:292
-				fmx = lim * dt; fmn = (-lim) * dt;
+				lrow &R = LR[s];
+				if (R.lev == L)
+				{
+					float fmn = R.fmn, fmx = R.fmx;
+					if (R.fm)
+					{
+						const float master = S.cisum[R.cidx];
+						const float lim = fmax_std(S.friction[R.rb0], S.friction[R.rb1]) * master / dt;       // physics.h:292
+						fmx = lim * dt; fmn = (-lim) * dt;
+					}
+					const float ts = post ? fmin_std(R.ts, R.tsnb) : R.ts;
+					const v3 l0 = L3(S.lin[R.rb0]), a0 = L3(S.ang[R.rb0]), l1 = L3(S.lin[R.rb1]), a1 = L3(S.ang[R.rb1]);
+					const v3 v0 = cross(mul(LM(S.Iinv[R.rb0]), a0), R.r0) + l0 * S.massinv[R.rb0];
+					const v3 v1 = cross(mul(LM(S.Iinv[R.rb1]), a1), R.r1) + l1 * S.massinv[R.rb1];
+					const float vn = dot(v1 - v0, R.n);
+					const float impulsen = -ts - vn;
+					float impulse = impulsen / R.impulsed;
+					impulse = fmin_std(fmx - R.isum, impulse);
+					impulse = fmax_std(fmn - R.isum, impulse);
+					{ const v3 imp = R.n * -impulse; S3(S.lin[R.rb0], l0 + imp); S3(S.ang[R.rb0], a0 + cross(R.r0, imp)); }
+					{ const v3 imp = R.n * impulse; S3(S.lin[R.rb1], l1 + imp); S3(S.ang[R.rb1], a1 + cross(R.r1, imp)); }
+					R.isum = R.isum + impulse;
+					if (lane + 64 * s >= 3 * nj && R.fm == 0) S.cisum[R.cidx] = R.isum;
+				}
 			}
-			const v3 r0 = L3(w + 2), r1 = L3(w + 5), n = L3(w + 8);
-			const float ts = post ? fmin_std(w[11], w[12]) : w[11];
-			const v3 v0 = (rb0 >= 0) ? cross(spin_of(S, rb0), r0) + L3(S.lin[rb0]) * S.massinv[rb0] : V3(0, 0, 0);
-			const v3 v1 = (rb1 >= 0) ? cross(spin_of(S, rb1), r1) + L3(S.lin[rb1]) * S.massinv[rb1] : V3(0, 0, 0);
-			const float vn = dot(v1 - v0, n);
-			const float impulsen = -ts - vn;
-			float impulse = impulsen / w[15];
-			impulse = fmin_std(fmx - w[16], impulse);
-			impulse = fmax_std(fmn - w[16], impulse);
-			if (rb0 >= 0) { const v3 imp = n * -impulse; S3(S.lin[rb0], L3(S.lin[rb0]) + imp); S3(S.ang[rb0], L3(S.ang[rb0]) + cross(r0, imp)); }
-			if (rb1 >= 0) { const v3 imp = n * impulse; S3(S.lin[rb1], L3(S.lin[rb1]) + imp); S3(S.ang[rb1], L3(S.ang[rb1]) + cross(r1, imp)); }
-			w[16] = w[16] + impulse;
+			__syncthreads();
 		}
-		// angular rows
-		for (int i = 0; i < na; i++)
+		// (3) angular rows, level by level (LimitAngular::Iter physics.h:251-265)
+		for (int L = 1; L <= ((a.dbg & 4) ? 0 : nlev_ang); L++)
 		{
-			float *w = S.an[i];
-			float targetspin = w[5];
-			if (post) targetspin = (w[10] < 0) ? 0 : fmin_std(targetspin, 0.0f);            // RemoveBias physics.h:250
-			if (targetspin == -FLT_MAX) continue;
-			const int rb0 = __float_as_int(w[0]), rb1 = __float_as_int(w[1]);
-			const v3 axis = L3(w + 2);
-			const float currentspin = ((rb1 >= 0) ? dot(spin_of(S, rb1), axis) : 0.0f) - ((rb0 >= 0) ? dot(spin_of(S, rb0), axis) : 0.0f);
-			const float dspin = targetspin - currentspin;
-			float dtorque = dspin * w[8];
-			dtorque = fmin_std(dtorque, w[7] - w[9]);
-			dtorque = fmax_std(dtorque, w[6] - w[9]);
-			if (rb0 >= 0) S3(S.ang[rb0], L3(S.ang[rb0]) - axis * dtorque);
-			if (rb1 >= 0) S3(S.ang[rb1], L3(S.ang[rb1]) + axis * dtorque);
-			w[9] = w[9] + dtorque;
+#pragma unroll
+			for (int s = 0; s < ASLOTS; s++)
+			{
+				arow &R = AR[s];
+				if (R.lev == L)
+				{
+					float targetspin = R.targetspin;
+					if (post) targetspin = (R.mintorque < 0) ? 0 : fmin_std(targetspin, 0.0f);            // RemoveBias physics.h:250
+					if (!(targetspin == -FLT_MAX))
+					{
+						const v3 a0 = R.rb0 >= 0 ? L3(S.ang[R.rb0]) : V3(0, 0, 0), a1 = R.rb1 >= 0 ? L3(S.ang[R.rb1]) : V3(0, 0, 0);
+						const float currentspin = ((R.rb1 >= 0) ? dot(mul(LM(S.Iinv[R.rb1]), a1), R.axis) : 0.0f) - ((R.rb0 >= 0) ? dot(mul(LM(S.Iinv[R.rb0]), a0), R.axis) : 0.0f);
+						const float dspin = targetspin - currentspin;
+						float dtorque = dspin * R.s2t;
+						dtorque = fmin_std(dtorque, R.mx - R.torque);
+						dtorque = fmax_std(dtorque, R.mn - R.torque);
+						if (R.rb0 >= 0) S3(S.ang[R.rb0], a0 - R.axis * dtorque);
+						if (R.rb1 >= 0) S3(S.ang[R.rb1], a1 + R.axis * dtorque);
+						R.torque = R.torque + dtorque;
+					}
+				}
+			}
+			__syncthreads();
 		}
-		__syncthreads();
 		if (sweep + 1 == ph.iterations && lane < nb)
 		{
 			// rbcalcnextpose physics.h:522-531 with rkupdateq :211-218 (momentum-preserving RK4 on the quaternion)
 			const float *bc = M.bodyc + lane * HT_BC;
 			const float minv = S.massinv[lane];
-			const v3 pn = L3(S.pos[lane]) + (L3(S.lin[lane]) * minv) * dt;
+			pos_next = L3(S.pos[lane]) + (L3(S.lin[lane]) * minv) * dt;
 			const m3 tinv = LM(bc + HT_BC_TINV) * minv;
 			const v3 angm = L3(S.ang[lane]);
 			const v4 s = L4(S.q[lane]);
@@ -476,10 +574,8 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			if (o.x < FLT_EPSILON / 4.0f && o.x > -FLT_EPSILON / 4.0f) o.x = 0.0f;
 			if (o.y < FLT_EPSILON / 4.0f && o.y > -FLT_EPSILON / 4.0f) o.y = 0.0f;
 			if (o.z < FLT_EPSILON / 4.0f && o.z > -FLT_EPSILON / 4.0f) o.z = 0.0f;
-			S3(S.pos_next[lane], pn);
-			S.q_next[lane][0] = o.x; S.q_next[lane][1] = o.y; S.q_next[lane][2] = o.z; S.q_next[lane][3] = o.w;
+			q_next = o;
 		}
-		__syncthreads();
 	}
 
 	// ---- rbupdatepose (physics.h:533-541), SanityCheck (physmodel.h:437-442), optional momentum reset (handtrack.h:686-687) ----
@@ -487,7 +583,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	{
 		float *s = st + lane * HT_STATE_STRIDE;
 		const float *bc = M.bodyc + lane * HT_BC;
-		v3 pos = L3(S.pos_next[lane]); v4 q = L4(S.q_next[lane]);
+		v3 pos = pos_next; v4 q = q_next;
 		v3 lin = L3(S.lin[lane]), ang = L3(S.ang[lane]);
 		const bool bad = isnan(lin.x) || isnan(lin.y) || isnan(lin.z) || isnan(pos.x) || isnan(pos.y) || isnan(pos.z) || isnan(ang.x) || isnan(ang.y) || isnan(ang.z)
 		              || isnan(q.x) || isnan(q.y) || isnan(q.z) || isnan(q.w);

@@ -1,6 +1,7 @@
 // ht_solver_api.hip -- tracker / solver entry points of the C-ABI: launch sequencing of the per-frame path
 // (HandTracker::update / update_cnn_model / MultiStepSim / FitPointCloud, include/handtrack.h:642-785).
 #include <string.h>
+#include <stdlib.h>
 #include "ht_device.hpp"
 #include "ht_host.hpp"
 #include "ht_launch.hpp"
@@ -25,6 +26,7 @@ static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int 
 	a.state = ctx->d_state[which]; a.scratch = ctx->d_scratch; a.scratch_stride = scratch_stride(ctx);
 	a.apply_angles = apply_angles; a.drive_force = drive_force; a.ray_rows = ray_rows; a.arm_cone = arm_cone; a.zero_momenta = zero_momenta;
 	a.steps_keyangles = ctx->par.steps_keyangles; a.min_cray_prob = ctx->par.min_cray_prob;
+	{ static int dbg = -1; if (dbg < 0) { const char *e = getenv("HT_DEBUG_SKIP"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
 	ht_launch_solve(ctx->model, ctx->phys, a, B, s);
 }
 // HandTracker::MultiStepSim on othermodel (handtrack.h:642-690)
