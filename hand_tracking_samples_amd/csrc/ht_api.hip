@@ -9,6 +9,7 @@
 #include <map>
 #include "ht_device.hpp"
 #include "ht_host.hpp"
+#include "ht_launch.hpp"
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return HT_ERR_HIP; } } while (0)
 
@@ -325,7 +326,7 @@ int ht_alloc_buffers(ht_ctx *ctx)
 	A(d_prev_err, B); A(d_initializing, B); A(d_err_old, B); A(d_err_new, B); A(d_flags, B);
 	A(d_rows, B * HT_MAXPTS * HT_ROW); A(d_nrows, B);
 	A(d_chamber, B * 5 * nb * HT_ROW); A(d_nchamber, B); A(d_accepted, B);
-	A(d_contacts, B * HT_MAXCONTACT * HT_CONTACT); A(d_ncontacts, B);
+	A(d_contacts, B * HT_MAXCONTACT * HT_CONTACT); A(d_ncontacts, B); A(d_epa_ws, ht_contacts_workspace_bytes((int)B));
 	A(d_scratch, B * (HT_MAXPTS + 5 * nb + 32) * 12);
 	A(d_poses_out, B * nb * HT_POSE); A(d_start, B * nb * HT_POSE);
 	A(d_stage, B * nb * HT_STATE_STRIDE);

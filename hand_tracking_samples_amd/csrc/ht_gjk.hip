@@ -15,6 +15,7 @@
 // The 4 extra "jiggle" GJK runs of the contact patch are skipped when they provably cannot add a contact: an extra
 // sample is rejected if it lies within 0.05 m of an accepted one on either shape (gjk.h:637) and every sample lies in the
 // convex hull of its shape, so a shape whose diameter is below 0.05 m can never contribute a second sample.
+#include <stdlib.h>
 #include "ht_device.hpp"
 #include "ht_launch.hpp"
 
@@ -112,8 +113,11 @@ __device__ gjk_hit calcpoints(simplex &src)
 		v3 b = barycentric(src.W[0].p, src.W[1].p, src.W[2].p, src.v);
 		src.W[0].t = b.x; src.W[1].t = b.y; src.W[2].t = b.z;
 	}
+	// pa = sum t_i a_i in index order, starting from zero (gjk.h:348-353); static indices keep the simplex in registers
 	v3 pa = V3(0, 0, 0), pb = V3(0, 0, 0);
-	for (int i = 0; i < src.count; i++) { pa = pa + src.W[i].a * src.W[i].t; pb = pb + src.W[i].b * src.W[i].t; }
+	if (src.count > 0) { pa = pa + src.W[0].a * src.W[0].t; pb = pb + src.W[0].b * src.W[0].t; }
+	if (src.count > 1) { pa = pa + src.W[1].a * src.W[1].t; pb = pb + src.W[1].b * src.W[1].t; }
+	if (src.count > 2) { pa = pa + src.W[2].a * src.W[2].t; pb = pb + src.W[2].b * src.W[2].t; }
 	gjk_hit h;
 	h.p0w = pa; h.p1w = pb;
 	h.separation = length(pa - pb) + FLT_MIN;
@@ -121,11 +125,11 @@ __device__ gjk_hit calcpoints(simplex &src)
 	return h;
 }
 
-// ---- expanding polytope on per-wave LDS arrays -------------------------------------------------
+// ---- expanding polytope; its triangle / vertex arrays live in a per-(frame, wave) HBM workspace (cold path) ------
 #define EPA_MAXT 192
 #define EPA_MAXV 96
 struct epa_mem { int tv[EPA_MAXT][3]; int tn[EPA_MAXT][3]; int tid[EPA_MAXT]; float vx[EPA_MAXV], vy[EPA_MAXV], vz[EPA_MAXV]; };
-// every lane executes the same statements on the same values, so each lane's own program order keeps the LDS arrays coherent
+// every lane executes the same statements on the same values, so each lane's own program order keeps the arrays coherent
 __device__ __forceinline__ v3 ev(const epa_mem &m, int i) { return V3(m.vx[i], m.vy[i], m.vz[i]); }
 __device__ __forceinline__ bool tri_dead(const epa_mem &m, int t) { return m.tn[t][0] == -1; }
 __device__ __forceinline__ bool hasvert(const epa_mem &m, int t, int x) { return m.tv[t][0] == x || m.tv[t][1] == x || m.tv[t][2] == x; }
@@ -269,7 +273,9 @@ __device__ v4 inverse_w(v3 c0, v3 c1, v3 c2, v3 c3)
 }
 
 // Separated(A, B, findclosest = 1), gjk.h:367-437
-__device__ gjk_hit separated(const support_t &A, const support_t &B, epa_mem &em, int lane)
+// `cutoff` > 0 enables an exact early-out: dot(w,v)/|v| is a lower bound of the distance between the shapes, and the separation the
+// reference finally reports is never below it; once the bound exceeds the contact cut-off the pair cannot produce a contact.
+__device__ gjk_hit separated(const support_t &A, const support_t &B, epa_mem &em, int lane, float cutoff, bool &far_apart)
 {
 	simplex last, next;
 	last.count = 0; next.count = 0;
@@ -288,12 +294,13 @@ __device__ gjk_hit separated(const support_t &A, const support_t &B, epa_mem &em
 		last = next;
 		v = last.v;
 		w = point_on_minkowski(A, B, -v, lane);
+		if (cutoff > 0.0f) { const float wv = dot(w.p, v); if (wv > 0.0f && wv > (cutoff * 1.01f + 1e-6f) * length(v)) { far_apart = true; break; } }
 		if (dot(w.p, v) >= dot(v, v) - 0.00001f - 0.00001f * dot(v, v)) break;
 		if (last.count == 1) next1(next, last, w); else if (last.count == 2) next2(next, last, w); else next3(next, last, w);
 		if (is_zero(next.v))
 		{
-			if (next.count == 2) { last = next; v3 n = orth(next.W[0].p - next.W[1].p); next.W[next.count++] = point_on_minkowski(A, B, n, lane); }
-			if (next.count == 3) { last = next; v3 n = tri_normal(next.W[0].p, next.W[1].p, next.W[2].p); next.W[next.count++] = point_on_minkowski(A, B, n, lane); }
+			if (next.count == 2) { last = next; v3 n = orth(next.W[0].p - next.W[1].p); next.W[2] = point_on_minkowski(A, B, n, lane); next.count = 3; }
+			if (next.count == 3) { last = next; v3 n = tri_normal(next.W[0].p, next.W[1].p, next.W[2].p); next.W[3] = point_on_minkowski(A, B, n, lane); next.count = 4; }
 			v3 start[4] = { next.W[0].p, next.W[1].p, next.W[2].p, next.W[3].p };
 			v4 mpp = expanding_polytope(em, start, A, B, lane);
 			gjk_hit h;
@@ -313,7 +320,7 @@ __device__ gjk_hit separated(const support_t &A, const support_t &B, epa_mem &em
 #define GJK_WAVES 4
 #define GJK_WCAP 48         // contacts staged per wave
 __global__ __launch_bounds__(64 * GJK_WAVES) void k_contacts(ht_model_dev M, const float *__restrict__ state, float driftmax, float jiggle_sin, const int *__restrict__ active_flag,
-                                                             float *__restrict__ contacts, int *__restrict__ ncontacts)
+                                                             epa_mem *__restrict__ epa_ws, float *__restrict__ contacts, int *__restrict__ ncontacts, int dbg)
 {
 	__shared__ float spos[HT_MAXNB][8];             // pos3 q4 radius
 	__shared__ unsigned char cand[HT_MAXNB * HT_MAXNB / 2][2];
@@ -322,32 +329,45 @@ __global__ __launch_bounds__(64 * GJK_WAVES) void k_contacts(ht_model_dev M, con
 	__shared__ int cprefix[HT_MAXNB * HT_MAXNB / 2 + 1];
 	__shared__ float wlist[GJK_WAVES][GJK_WCAP][HT_CONTACT];
 	__shared__ unsigned short wcand[GJK_WAVES][GJK_WCAP];
-	__shared__ epa_mem epa[GJK_WAVES];
 	const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	if (active_flag && !active_flag[b]) { if (t == 0) ncontacts[b] = 0; return; }
+	epa_mem &em = epa_ws[(size_t)b * GJK_WAVES + wave];
 	if (t < M.nb)
 	{
 		const float *s = state + ((size_t)b * M.nb + t) * HT_STATE_STRIDE;
 		for (int i = 0; i < 7; i++) spos[t][i] = s[i];
 		spos[t][7] = M.bodyc[t * HT_BC + HT_BC_RADIUS];
 	}
+	if (t == 0) ncand = 0;
 	__syncthreads();
-	if (t == 0)
+	// broad phase in the reference's pair order (physics.h:453-457): wave 0 tests 64 pairs at a time and compacts with a ballot
+	if (wave == 0)
 	{
-		// broad phase in the reference's pair order (physics.h:453-457)
+		const int npairs = M.nb * (M.nb - 1) / 2;
 		int k = 0;
-		for (int i = 0; i < M.nb; i++) for (int j = i + 1; j < M.nb; j++)
+		for (int base = 0; base < npairs; base += 64)
 		{
-			if (!(M.collide[i] & M.collide[j] & 2)) continue;
-			v3 d = V3(spos[j][0], spos[j][1], spos[j][2]) - V3(spos[i][0], spos[i][1], spos[i][2]);
-			if (length(d) > spos[i][7] + spos[j][7]) continue;
-			if (M.ignore[i] & (1u << j)) continue;
-			cand[k][0] = (unsigned char)i; cand[k][1] = (unsigned char)j; k++;
+			const int pidx = base + lane;
+			// pair index -> (i, j), i < j, row-major over the upper triangle
+			int i = 0, rem = pidx;
+			while (i < M.nb - 1 && rem >= M.nb - 1 - i) { rem -= M.nb - 1 - i; i++; }
+			const int j = i + 1 + rem;
+			bool keep = false;
+			if (pidx < npairs)
+			{
+				keep = (M.collide[i] & M.collide[j] & 2) != 0;
+				v3 d = V3(spos[j][0], spos[j][1], spos[j][2]) - V3(spos[i][0], spos[i][1], spos[i][2]);
+				if (length(d) > spos[i][7] + spos[j][7]) keep = false;
+				if (M.ignore[i] & (1u << j)) keep = false;
+			}
+			const unsigned long long m = __ballot(keep);
+			if (keep) { const int dst = k + __popcll(m & ((1ull << lane) - 1ull)); cand[dst][0] = (unsigned char)i; cand[dst][1] = (unsigned char)j; }
+			k += __popcll(m);
 		}
-		ncand = k;
+		if (lane == 0) ncand = k;
 	}
 	__syncthreads();
-	const int nc = ncand;
+	const int nc = (dbg & 8) ? 0 : ncand;
 	for (int c = t; c < nc; c += 64 * GJK_WAVES) ccount[c] = 0;
 	__syncthreads();
 	int wn = 0;
@@ -357,46 +377,54 @@ __global__ __launch_bounds__(64 * GJK_WAVES) void k_contacts(ht_model_dev M, con
 		support_t A, Bs;
 		A.verts = M.verts + M.vert_off[i]; A.n = M.vert_off[i + 1] - M.vert_off[i]; A.pos = V3(spos[i][0], spos[i][1], spos[i][2]); A.q = V4(spos[i][3], spos[i][4], spos[i][5], spos[i][6]); A.outer = 0; A.opos = V3(0, 0, 0); A.oq = V4(0, 0, 0, 1);
 		Bs.verts = M.verts + M.vert_off[j]; Bs.n = M.vert_off[j + 1] - M.vert_off[j]; Bs.pos = V3(spos[j][0], spos[j][1], spos[j][2]); Bs.q = V4(spos[j][3], spos[j][4], spos[j][5], spos[j][6]); Bs.outer = 0; Bs.opos = V3(0, 0, 0); Bs.oq = V4(0, 0, 0, 1);
-		gjk_hit hit[5];
-		hit[0] = separated(A, Bs, epa[wave], lane);
-		int hc = 0;
-		if (!(hit[0].separation > driftmax))
+		bool far_apart = false;
+		const gjk_hit h0 = separated(A, Bs, em, lane, (dbg & 16) ? 0.0f : driftmax, far_apart);
+		int kept = 0;
+		auto stage = [&](const gjk_hit &h) {
+			if (wn < GJK_WCAP)
+			{
+				if (lane == 0)
+				{
+					float *o = wlist[wave][wn];
+					o[0] = (float)i; o[1] = (float)j; o[2] = h.normal.x; o[3] = h.normal.y; o[4] = h.normal.z;
+					o[5] = h.p0w.x; o[6] = h.p0w.y; o[7] = h.p0w.z; o[8] = h.p1w.x; o[9] = h.p1w.y; o[10] = h.p1w.z; o[11] = h.separation;
+					wcand[wave][wn] = (unsigned short)c;
+				}
+				wn++; kept++;
+			}
+		};
+		if (!far_apart && !(h0.separation > driftmax))
 		{
-			hc = 1;
+			const int first = wn;
+			stage(h0);
 			const float dmin = fminf(M.bodyc[i * HT_BC + HT_BC_DIAM], M.bodyc[j * HT_BC + HT_BC_DIAM]);
 			if (!(dmin < 0.049f))         // otherwise every jiggle sample is rejected by the 0.05 m proximity test (see header)
 			{
-				const v3 n = hit[0].normal;
+				const v3 n = h0.normal;
 				v4 qs = quat_from_to(n, V3(0, 0, 1));
 				v3 tangent = qxdir(qs), bitangent = qydir(qs);
-				v3 rollaxes[4] = { tangent, bitangent, -tangent, -bitangent };
 				for (int r = 0; r < 4; r++)
 				{
-					v4 jiggle = normalize(V4(rollaxes[r] * jiggle_sin, 1));
-					v3 pivot = hit[0].p0w;
+					const v3 raxis = r == 0 ? tangent : r == 1 ? bitangent : r == 2 ? -tangent : -bitangent;
+					v4 jiggle = normalize(V4(raxis * jiggle_sin, 1));
+					v3 pivot = h0.p0w;
 					v4 id = V4(0, 0, 0, 1);
 					xf ar = mul(mul(mul(XF(n * 0.2f, id), XF(-pivot, id)), XF(V3(0, 0, 0), jiggle)), XF(pivot, id));
 					support_t AJ = A; AJ.outer = 1; AJ.opos = ar.p; AJ.oq = ar.q;
-					hit[hc] = separated(AJ, Bs, epa[wave], lane);
-					hit[hc].normal = n;
-					hit[hc].p0w = apply(inverse(ar), hit[hc].p0w);
-					hit[hc].separation = dot(n, hit[hc].p0w - hit[hc].p1w);
+					bool dummy = false;
+					gjk_hit hj = separated(AJ, Bs, em, lane, 0.0f, dummy);
+					hj.normal = n;
+					hj.p0w = apply(inverse(ar), hj.p0w);
+					hj.separation = dot(n, hj.p0w - hj.p1w);
 					bool match = false;
-					for (int q = 0; !match && q < hc; q++) match = length(hit[hc].p0w - hit[q].p0w) < 0.05f || length(hit[hc].p1w - hit[q].p1w) < 0.05f;
+					for (int q = first; !match && q < wn; q++)
+					{
+						const float *o = wlist[wave][q];
+						match = length(hj.p0w - V3(o[5], o[6], o[7])) < 0.05f || length(hj.p1w - V3(o[8], o[9], o[10])) < 0.05f;
+					}
 					if (match) continue;
-					hc++;
+					stage(hj);
 				}
-			}
-		}
-		int kept = 0;
-		for (int k = 0; k < hc && wn < GJK_WCAP; k++, wn++, kept++)
-		{
-			if (lane == 0)
-			{
-				float *o = wlist[wave][wn];
-				o[0] = (float)i; o[1] = (float)j; o[2] = hit[k].normal.x; o[3] = hit[k].normal.y; o[4] = hit[k].normal.z;
-				o[5] = hit[k].p0w.x; o[6] = hit[k].p0w.y; o[7] = hit[k].p0w.z; o[8] = hit[k].p1w.x; o[9] = hit[k].p1w.y; o[10] = hit[k].p1w.z; o[11] = hit[k].separation;
-				wcand[wave][wn] = (unsigned short)c;
 			}
 		}
 		if (lane == 0) ccount[c] = (unsigned char)kept;
@@ -411,7 +439,6 @@ __global__ __launch_bounds__(64 * GJK_WAVES) void k_contacts(ht_model_dev M, con
 	}
 	__syncthreads();
 	// each wave writes its staged contacts at their rank in pair order
-	if (lane == 0)
 	{
 		int prevc = -1, k = 0;
 		for (int e = 0; e < wn; e++)
@@ -419,12 +446,13 @@ __global__ __launch_bounds__(64 * GJK_WAVES) void k_contacts(ht_model_dev M, con
 			int c = wcand[wave][e];
 			k = (c == prevc) ? k + 1 : 0; prevc = c;
 			int dst = cprefix[c] + k;
-			if (dst < HT_MAXCONTACT) for (int q = 0; q < HT_CONTACT; q++) contacts[((size_t)b * HT_MAXCONTACT + dst) * HT_CONTACT + q] = wlist[wave][e][q];
+			if (dst < HT_MAXCONTACT && lane < HT_CONTACT) contacts[((size_t)b * HT_MAXCONTACT + dst) * HT_CONTACT + lane] = wlist[wave][e][lane];
 		}
 	}
 }
 
-void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, float *contacts, int *ncontacts, int B, hipStream_t s)
+size_t ht_contacts_workspace_bytes(int B) { return (size_t)B * GJK_WAVES * sizeof(epa_mem); }
+void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_contacts, dim3(B), dim3(64 * GJK_WAVES), 0, s, M, state, driftmax, jiggle_sin, active_flag, contacts, ncontacts);
+	hipLaunchKernelGGL(k_contacts, dim3(B), dim3(64 * GJK_WAVES), 0, s, M, state, driftmax, jiggle_sin, active_flag, (epa_mem *)epa_ws, contacts, ncontacts, []{ const char *e = getenv("HT_DEBUG_SKIP"); return e ? atoi(e) : 0; }());
 }

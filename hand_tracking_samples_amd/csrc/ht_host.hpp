@@ -33,6 +33,7 @@ struct ht_ctx
 	float *d_chamber = nullptr; int *d_nchamber = nullptr;      // [B][5*nb][HT_ROW]
 	int *d_accepted = nullptr;
 	float *d_contacts = nullptr; int *d_ncontacts = nullptr;    // [B][HT_MAXCONTACT][HT_CONTACT]
+	unsigned char *d_epa_ws = nullptr;                           // expanding-polytope workspace, one per (frame, wave)
 	float *d_scratch = nullptr;                                  // solver row stream [B][HT_MAXPTS + 5*nb + 32][12]
 	float *d_poses_out = nullptr, *d_start = nullptr;
 	float *d_stage = nullptr;                                    // staging for host<->device state copies

@@ -449,10 +449,9 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			const v3 p1 = L3(r + 5), n = L3(r + 8);
 			const v3 r1 = qrot(L4(S.q[body]), p1);
 			const float impulsed = S.massinv[body] + dot(cross(mul(LM(S.Iinv[body]), cross(r1, n)), r1), n);       // 0 + (...) for the NULL side
-			float4 *o = reinterpret_cast<float4 *>(dst < CH_CAP ? &S.chain[dst][0] : scr + (size_t)dst * SROW);
-			o[0] = make_float4(r1.x, r1.y, r1.z, n.x);
-			o[1] = make_float4(n.y, n.z, r[11] / dt, r[12]);
-			o[2] = make_float4(r[13] * dt, r[14] * dt, impulsed, 0.0f);
+			const float4 o0 = make_float4(r1.x, r1.y, r1.z, n.x), o1 = make_float4(n.y, n.z, r[11] / dt, r[12]), o2 = make_float4(r[13] * dt, r[14] * dt, impulsed, 0.0f);
+			if (dst < CH_CAP) { float4 *o = reinterpret_cast<float4 *>(&S.chain[dst][0]); o[0] = o0; o[1] = o1; o[2] = o2; }
+			else { float4 *o = reinterpret_cast<float4 *>(scr + (size_t)dst * SROW); o[0] = o0; o[1] = o1; o[2] = o2; }
 		}
 	}
 	__syncthreads();
@@ -463,20 +462,14 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	for (int sweep = 0; sweep < total_sweeps; sweep++)
 	{
 		const bool post = sweep >= ph.iterations;
-		// (1) chains: lane b applies the single-body rows of body b in order, momenta in registers
+		// (1) chains: lane b applies the single-body rows of body b in order, momenta in registers.
+		//     Rows [mystart, mystart+mycnt) are contiguous: the part below CH_CAP is read with LDS instructions, the rest from HBM scratch.
 		if (lane < nb && mycnt > 0 && !(a.dbg & 1))
 		{
 			v3 lin = L3(S.lin[lane]), ang = L3(S.ang[lane]);
 			const m3 I = LM(S.Iinv[lane]);
 			const float minv = S.massinv[lane];
-			auto rowp = [&](int idx) -> float * { return idx < CH_CAP ? &S.chain[idx][0] : scr + (size_t)idx * SROW; };
-			float *rp = rowp(mystart);
-			float4 c0 = reinterpret_cast<float4 *>(rp)[0], c1 = reinterpret_cast<float4 *>(rp)[1], c2 = reinterpret_cast<float4 *>(rp)[2];
-			for (int k = 0; k < mycnt; k++)
-			{
-				float4 n0 = c0, n1 = c1, n2 = c2;
-				float *np = rp;
-				if (k + 1 < mycnt) { np = rowp(mystart + k + 1); const float4 *nx = reinterpret_cast<const float4 *>(np); n0 = nx[0]; n1 = nx[1]; n2 = nx[2]; }      // prefetch
+			auto apply_row = [&](const float4 c0, const float4 c1, const float4 c2) -> float {
 				const v3 r1 = V3(c0.x, c0.y, c0.z), n = V3(c0.w, c1.x, c1.y);
 				const float ts = post ? fmin_std(c1.z, c1.w) : c1.z;                      // RemoveBias physics.h:288
 				const v3 v1 = cross(mul(I, ang), r1) + lin * minv;
@@ -487,8 +480,27 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				impulse = fmax_std(c2.x - c2.w, impulse);
 				const v3 imp = n * impulse;
 				lin = lin + imp; ang = ang + cross(r1, imp);
-				rp[11] = c2.w + impulse;
-				c0 = n0; c1 = n1; c2 = n2; rp = np;
+				return c2.w + impulse;
+			};
+			const int nl = (mystart + mycnt <= CH_CAP) ? mycnt : (mystart >= CH_CAP ? 0 : CH_CAP - mystart);
+			if (nl > 0)
+			{
+				float4 *rp = reinterpret_cast<float4 *>(&S.chain[mystart][0]);
+				float4 c0 = rp[0], c1 = rp[1], c2 = rp[2];
+				for (int k = 0; k < nl; k++)
+				{
+					float4 n0 = c0, n1 = c1, n2 = c2;
+					if (k + 1 < nl) { n0 = rp[3 * (k + 1)]; n1 = rp[3 * (k + 1) + 1]; n2 = rp[3 * (k + 1) + 2]; }      // prefetch the next row
+					const float isum = apply_row(c0, c1, c2);
+					S.chain[mystart + k][11] = isum;
+					c0 = n0; c1 = n1; c2 = n2;
+				}
+			}
+			for (int k = nl; k < mycnt; k++)
+			{
+				float4 *rp = reinterpret_cast<float4 *>(scr + (size_t)(mystart + k) * SROW);
+				const float isum = apply_row(rp[0], rp[1], rp[2]);
+				scr[(size_t)(mystart + k) * SROW + 11] = isum;
 			}
 			S3(S.lin[lane], lin); S3(S.ang[lane], ang);
 		}

@@ -39,7 +39,7 @@ static void multistep(ht_ctx *ctx, int B, hipStream_t s)
 		const bool rays = (st < p.steps_keypoints) && !p.angles_only;
 		const bool cloud = (st >= p.steps_cloudstart) && !p.angles_only;
 		if (cloud) { ht_prof_scope ps(ctx, "cloud_rows", s); ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, nullptr, 4, 1, 2, p, ctx->d_rows, ctx->d_nrows, B, s); }
-		if (ctx->phys.use_collision) { ht_prof_scope ps(ctx, "contacts", s); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_contacts, ctx->d_ncontacts, B, s); }
+		if (ctx->phys.use_collision) { ht_prof_scope ps(ctx, "contacts", s); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s); }
 		ht_prof_scope ps(ctx, "solve", s);
 		solve_step(ctx, 1, nullptr, nullptr, cloud, ctx->phys.use_collision != 0, nullptr, angles, st < p.steps_palmangle ? 10000.0f : 0.0f, rays, 1, 1, B, s);
 	}
@@ -50,7 +50,7 @@ static void main_pass(ht_ctx *ctx, int B, hipStream_t s)
 	const ht_params &p = ctx->par;
 	{ ht_prof_scope ps(ctx, "chamber", s); ht_launch_chamber(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, p.min_point_num, p.boundary_planes, 10.0f, ctx->d_chamber, ctx->d_nchamber, B, s); }
 	{ ht_prof_scope ps(ctx, "cloud_rows", s); ht_launch_cloud_rows(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, ctx->d_cams, nullptr, 1, 0, 1, p, ctx->d_rows, ctx->d_nrows, B, s); }
-	if (ctx->phys.use_collision) { ht_prof_scope ps(ctx, "contacts", s); ht_launch_contacts(ctx->model, ctx->d_state[0], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_contacts, ctx->d_ncontacts, B, s); }
+	if (ctx->phys.use_collision) { ht_prof_scope ps(ctx, "contacts", s); ht_launch_contacts(ctx->model, ctx->d_state[0], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s); }
 	ht_prof_scope ps(ctx, "solve", s);
 	solve_step(ctx, 0, ctx->d_chamber, ctx->d_nchamber, true, ctx->phys.use_collision != 0, nullptr, 0, 0.0f, 0, 0, 0, B, s);
 }
@@ -205,7 +205,7 @@ extern "C" int ht_stage_contacts(ht_ctx *ctx, int which, int B, int cap, float *
 	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
 	if (!contacts || !ncontacts || which < 0 || which > 1 || cap < 1) return HT_ERR_ARG;
 	hipStream_t s = ctx->stream;
-	ht_launch_contacts(ctx->model, ctx->d_state[which], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_contacts, ctx->d_ncontacts, B, s);
+	ht_launch_contacts(ctx->model, ctx->d_state[which], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s);
 	std::vector<float> tmp((size_t)B * HT_MAXCONTACT * HT_CONTACT);
 	HIPCHK(ctx, hipMemcpyAsync(tmp.data(), ctx->d_contacts, tmp.size() * sizeof(float), hipMemcpyDeviceToHost, s));
 	HIPCHK(ctx, hipMemcpyAsync(ncontacts, ctx->d_ncontacts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
