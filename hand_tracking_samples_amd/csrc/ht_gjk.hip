@@ -7,30 +7,62 @@
 //   ExpandingPolytopeAlgorithm        third_party/hull.h:233-310 (Tri bookkeeping :79-186)
 //   SupportFunc / SupportFuncTrans    third_party/gjk.h:568-582, maxdir third_party/geometric.h:218-224
 //
-// Mapping: one 256-thread block per frame; each of its 4 waves takes candidate pairs c = wave, wave+4, ... and runs GJK
-// wave-cooperatively: the support map (arg-max of a dot product over all 162/258 collision vertices of a bone, first
-// maximum wins) is a strided scan + butterfly reduction over the 64 lanes; the simplex logic is wave-uniform.
-// Contacts are staged per wave in LDS and written out in pair order, so the solver sees the reference's row order.
+// Mapping.  A 128-thread block serves two frames (one wave each) and stages all collision vertices (3042 x float4 = 48 KB) in
+// LDS once.  GJK runs one lane per candidate pair (measured on the animation bank: 3.5 iterations per pair on average, 10 at
+// most, ~28 pairs per frame): the support map is a plain scan over the 162/258 vertices of the lane's bone (first maximum wins,
+// as std::max_element does) and the simplex logic is the reference's branchy code executed per lane.  A pair whose simplex
+// encloses the origin needs the expanding polytope; that part is rare but long, so it is run wave-cooperatively, one pair at a
+// time: triangles are scored one per lane, support scans are strided over the 64 lanes with a butterfly arg-max, and only the
+// mesh surgery (extrude / back-to-back fix / compaction, hull.h:136-186) stays sequential on a per-wave LDS mesh.
+// Contacts are compacted in pair order with a prefix sum, so the solver sees the reference's row order.
 //
 // The 4 extra "jiggle" GJK runs of the contact patch are skipped when they provably cannot add a contact: an extra
 // sample is rejected if it lies within 0.05 m of an accepted one on either shape (gjk.h:637) and every sample lies in the
 // convex hull of its shape, so a shape whose diameter is below 0.05 m can never contribute a second sample.
+// A second exact shortcut: dot(w,v)/|v| is a lower bound of the distance between the shapes and the separation the reference
+// finally reports is never below it, so once the bound exceeds the contact cut-off the pair cannot produce a contact.
 #include <stdlib.h>
 #include "ht_device.hpp"
 #include "ht_launch.hpp"
 
-struct support_t { const float4 *verts; int n; v3 pos; v4 q; int outer; v3 opos; v4 oq; };
+extern __shared__ __attribute__((aligned(16))) float4 g_sm[];      // [0, nvert): collision vertices of all bodies; then per-wave areas
+
+struct support_t { int voff, n; v3 pos; v4 q; int outer; v3 opos; v4 oq; };
 struct mkpoint { v3 a, b, p; float t; };
 struct simplex { v3 v; mkpoint W[4]; int count; };
 struct gjk_hit { v3 normal, p0w, p1w; float separation; };
 
-__device__ __forceinline__ v3 support_inner(const support_t &s, v3 dir, int lane)
+// ---- support maps ----------------------------------------------------------------------------------------------------
+// per-lane scan (every lane its own shape)
+__device__ __forceinline__ v3 support_inner(const support_t &s, v3 dir)
 {
 	const v3 dl = qrot(qconj(s.q), dir);
-	float best = -INFINITY; int bi = 0x7fffffff;
+	const float4 *vs = g_sm + s.voff;
+	float4 q0 = vs[0];
+	float best = dot(V3(q0.x, q0.y, q0.z), dl); int bi = 0;
+	for (int i = 1; i < s.n; i++)
+	{
+		float4 q = vs[i];
+		float d = dot(V3(q.x, q.y, q.z), dl);
+		if (best < d) { best = d; bi = i; }
+	}
+	float4 q = vs[bi];
+	return s.pos + qrot(s.q, V3(q.x, q.y, q.z));
+}
+__device__ __forceinline__ v3 support(const support_t &s, v3 dir)
+{
+	if (s.outer) return s.opos + qrot(s.oq, support_inner(s, qrot(qconj(s.oq), dir)));
+	return support_inner(s, dir);
+}
+// wave-cooperative scan (all lanes the same shape and direction): strided partial arg-max + butterfly; ties go to the lower index
+__device__ __forceinline__ v3 support_inner_wave(const support_t &s, v3 dir, int lane)
+{
+	const v3 dl = qrot(qconj(s.q), dir);
+	const float4 *vs = g_sm + s.voff;
+	float best = 0.0f; int bi = 0x7fffffff;
 	for (int i = lane; i < s.n; i += 64)
 	{
-		float4 q = s.verts[i];
+		float4 q = vs[i];
 		float d = dot(V3(q.x, q.y, q.z), dl);
 		if (bi == 0x7fffffff || best < d) { best = d; bi = i; }
 	}
@@ -40,19 +72,20 @@ __device__ __forceinline__ v3 support_inner(const support_t &s, v3 dir, int lane
 		float ob = __shfl_xor(best, o); int oi = __shfl_xor(bi, o);
 		if (oi != 0x7fffffff && (bi == 0x7fffffff || best < ob || (ob == best && oi < bi))) { best = ob; bi = oi; }
 	}
-	float4 q = s.verts[bi];
+	float4 q = vs[bi];
 	return s.pos + qrot(s.q, V3(q.x, q.y, q.z));
 }
-__device__ __forceinline__ v3 support(const support_t &s, v3 dir, int lane)
+__device__ __forceinline__ v3 support_wave(const support_t &s, v3 dir, int lane)
 {
-	if (s.outer) return s.opos + qrot(s.oq, support_inner(s, qrot(qconj(s.oq), dir), lane));
-	return support_inner(s, dir, lane);
+	if (s.outer) return s.opos + qrot(s.oq, support_inner_wave(s, qrot(qconj(s.oq), dir), lane));
+	return support_inner_wave(s, dir, lane);
 }
-__device__ __forceinline__ mkpoint point_on_minkowski(const support_t &A, const support_t &B, v3 n, int lane)
+__device__ __forceinline__ mkpoint point_on_minkowski(const support_t &A, const support_t &B, v3 n)      // gjk.h:68-73
 {
-	mkpoint m; m.a = support(A, n, lane); m.b = support(B, -n, lane); m.p = m.a - m.b; m.t = 0; return m;
+	mkpoint m; m.a = support(A, n); m.b = support(B, -n); m.p = m.a - m.b; m.t = 0; return m;
 }
 
+// ---- simplex updates (NextMinkSimplex1..3, gjk.h:93-275) -------------------------------------------------------------
 __device__ void next1(simplex &dst, const simplex &src, const mkpoint &w)
 {
 	const v3 O = V3(0, 0, 0);
@@ -105,8 +138,7 @@ __device__ void next3(simplex &dst, const simplex &src, const mkpoint &w)
 	if (!inp0e2 && !inp1e2 && t2 > 0.0f) { keep_edge(dst, s2, w, t2, v2); return; }
 	dst.W[0] = w; dst.W[0].t = 1.0f; dst.v = w.p; dst.count = 1;
 }
-
-__device__ gjk_hit calcpoints(simplex &src)
+__device__ gjk_hit calcpoints(simplex &src)      // gjk.h:337-363
 {
 	if (src.count == 3)
 	{
@@ -125,15 +157,52 @@ __device__ gjk_hit calcpoints(simplex &src)
 	return h;
 }
 
-// ---- expanding polytope; its triangle / vertex arrays live in a per-(frame, wave) HBM workspace (cold path) ------
+// Separated(A, B, findclosest = 1), gjk.h:367-437, per lane.  Returns 0: separated (hit valid), 1: far apart (no contact possible),
+// 2: the simplex `tet` encloses the origin and the expanding polytope has to run (gjk.h:400-428).
+__device__ int gjk_run(const support_t &A, const support_t &B, float cutoff, gjk_hit &hit, simplex &tet)
+{
+	simplex last, next;
+	last.count = 0; next.count = 0;
+	for (int i = 0; i < 4; i++) { last.W[i].a = last.W[i].b = last.W[i].p = V3(0, 0, 0); last.W[i].t = 0; next.W[i] = last.W[i]; }
+	int iter = 0;
+	v3 v = point_on_minkowski(A, B, V3(0, 0, 1)).p;
+	last.v = v;
+	mkpoint w = point_on_minkowski(A, B, -v);
+	next.W[0] = w; next.W[0].t = 1.0f; next.v = w.p; next.count = 1;                        // NextMinkSimplex0
+	for (;;)
+	{
+		bool go;
+		if (iter == 0) { iter++; go = true; }
+		else { iter++; go = (dot(w.p, v) < dot(v, v) - 0.00001f); if (go) { go = (iter < 100); iter++; } }      // while(!iter++ || (... && iter++<100))
+		if (!go) break;
+		last = next;
+		v = last.v;
+		w = point_on_minkowski(A, B, -v);
+		if (cutoff > 0.0f) { const float wv = dot(w.p, v); if (wv > 0.0f && wv > (cutoff * 1.01f + 1e-6f) * length(v)) return 1; }
+		if (dot(w.p, v) >= dot(v, v) - 0.00001f - 0.00001f * dot(v, v)) break;
+		if (last.count == 1) next1(next, last, w); else if (last.count == 2) next2(next, last, w); else next3(next, last, w);
+		if (is_zero(next.v))
+		{
+			if (next.count == 2) { v3 n = orth(next.W[0].p - next.W[1].p); next.W[2] = point_on_minkowski(A, B, n); next.count = 3; }
+			if (next.count == 3) { v3 n = tri_normal(next.W[0].p, next.W[1].p, next.W[2].p); next.W[3] = point_on_minkowski(A, B, n); next.count = 4; }
+			tet = next;
+			return 2;
+		}
+		if (dot(next.v, next.v) >= dot(last.v, last.v)) break;
+	}
+	hit = calcpoints(last);
+	return 0;
+}
+
+// ---- expanding polytope, wave-cooperative on a per-wave LDS mesh (hull.h:233-310) ---------------------------------------
 #define EPA_MAXT 192
 #define EPA_MAXV 96
-struct epa_mem { int tv[EPA_MAXT][3]; int tn[EPA_MAXT][3]; int tid[EPA_MAXT]; float vx[EPA_MAXV], vy[EPA_MAXV], vz[EPA_MAXV]; };
-// every lane executes the same statements on the same values, so each lane's own program order keeps the arrays coherent
+struct epa_mem { int tv[EPA_MAXT][3]; int tn[EPA_MAXT][3]; float vx[EPA_MAXV], vy[EPA_MAXV], vz[EPA_MAXV]; unsigned char ab[EPA_MAXT]; };
+// the mesh surgery is executed by every lane on the same values (same stores from all lanes), so each lane's own program order keeps it coherent
 __device__ __forceinline__ v3 ev(const epa_mem &m, int i) { return V3(m.vx[i], m.vy[i], m.vz[i]); }
 __device__ __forceinline__ bool tri_dead(const epa_mem &m, int t) { return m.tn[t][0] == -1; }
 __device__ __forceinline__ bool hasvert(const epa_mem &m, int t, int x) { return m.tv[t][0] == x || m.tv[t][1] == x || m.tv[t][2] == x; }
-__device__ int *neib(epa_mem &m, int t, int va, int vb)
+__device__ int *neib(epa_mem &m, int t, int va, int vb)      // hull.h:97-109
 {
 	for (int i = 0; i < 3; i++)
 	{
@@ -143,26 +212,24 @@ __device__ int *neib(epa_mem &m, int t, int va, int vb)
 	}
 	return &m.tn[t][0];      // unreachable for a consistent mesh (the reference asserts)
 }
-__device__ void tri_set(epa_mem &m, int t, int a, int b, int c, int id, int n0, int n1, int n2)
+__device__ void tri_set(epa_mem &m, int t, int a, int b, int c, int n0, int n1, int n2)
 {
-	m.tv[t][0] = a; m.tv[t][1] = b; m.tv[t][2] = c; m.tid[t] = id; m.tn[t][0] = n0; m.tn[t][1] = n1; m.tn[t][2] = n2;
+	m.tv[t][0] = a; m.tv[t][1] = b; m.tv[t][2] = c; m.tn[t][0] = n0; m.tn[t][1] = n1; m.tn[t][2] = n2;
 }
-__device__ void nnfix(epa_mem &m, int k)
+__device__ void nnfix(epa_mem &m, int k)      // hull.h:112-127
 {
-	if (m.tid[k] == -1) return;
 	for (int i = 0; i < 3; i++)
 	{
 		int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
 		if (m.tn[k][i] != -1) *neib(m, m.tn[k][i], m.tv[k][i2], m.tv[k][i1]) = k;
 	}
 }
-__device__ void swapn(epa_mem &m, int a, int b)
+__device__ void swapn(epa_mem &m, int a, int b)      // hull.h:128-134 (the ids are swapped back by the reference's second std::swap)
 {
 	for (int i = 0; i < 3; i++) { int t = m.tv[a][i]; m.tv[a][i] = m.tv[b][i]; m.tv[b][i] = t; t = m.tn[a][i]; m.tn[a][i] = m.tn[b][i]; m.tn[b][i] = t; }
-	// ids are swapped twice by the reference (std::swap of the Tri, then of the ids) => they stay in place
 	nnfix(m, a); nnfix(m, b);
 }
-__device__ void b2bfix(epa_mem &m, int s, int t)
+__device__ void b2bfix(epa_mem &m, int s, int t)      // hull.h:136-150
 {
 	for (int i = 0; i < 3; i++)
 	{
@@ -173,64 +240,78 @@ __device__ void b2bfix(epa_mem &m, int s, int t)
 	}
 	for (int i = 0; i < 3; i++) { m.tn[s][i] = -1; m.tn[t][i] = -1; }
 }
-__device__ bool extrude(epa_mem &m, int &nt, int t0, int v)
+__device__ bool extrude(epa_mem &m, int &nt, int t0, int v)      // hull.h:167-186
 {
 	if (nt + 3 > EPA_MAXT) return false;
 	int t[3] = { m.tv[t0][0], m.tv[t0][1], m.tv[t0][2] };
 	int b = nt;
 	int n[3] = { m.tn[t0][0], m.tn[t0][1], m.tn[t0][2] };
-	tri_set(m, nt++, v, t[1], t[2], b + 0, n[0], b + 1, b + 2); *neib(m, n[0], t[1], t[2]) = b + 0;
-	tri_set(m, nt++, v, t[2], t[0], b + 1, n[1], b + 2, b + 0); *neib(m, n[1], t[2], t[0]) = b + 1;
-	tri_set(m, nt++, v, t[0], t[1], b + 2, n[2], b + 0, b + 1); *neib(m, n[2], t[0], t[1]) = b + 2;
+	tri_set(m, nt++, v, t[1], t[2], n[0], b + 1, b + 2); *neib(m, n[0], t[1], t[2]) = b + 0;
+	tri_set(m, nt++, v, t[2], t[0], n[1], b + 2, b + 0); *neib(m, n[1], t[2], t[0]) = b + 1;
+	tri_set(m, nt++, v, t[0], t[1], n[2], b + 0, b + 1); *neib(m, n[2], t[0], t[1]) = b + 2;
 	m.tn[t0][0] = m.tn[t0][1] = m.tn[t0][2] = -1;
 	if (hasvert(m, n[0], v)) b2bfix(m, b + 0, n[0]);
 	if (hasvert(m, n[1], v)) b2bfix(m, b + 1, n[1]);
 	if (hasvert(m, n[2], v)) b2bfix(m, b + 2, n[2]);
 	return true;
 }
-__device__ __forceinline__ bool above(const epa_mem &m, int t, v3 p, float epsilon)
+__device__ __forceinline__ bool above(const epa_mem &m, int t, v3 p, float epsilon)      // hull.h:50-54
 {
 	v3 n = tri_normal(ev(m, m.tv[t][0]), ev(m, m.tv[t][1]), ev(m, m.tv[t][2]));
 	return dot(n, p - ev(m, m.tv[t][0])) > epsilon;
 }
-__device__ v4 expanding_polytope(epa_mem &m, const v3 start[4], const support_t &A, const support_t &B, int lane)
+// all 64 lanes call this with identical arguments
+__device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 s2, v3 s3, const support_t &A, const support_t &B, int lane)
 {
 	v4 plane = V4(0, 0, 0, -FLT_MAX);
 	const float epsilon = 0.001f;
 	int nv = 4, nt = 0;
-	for (int i = 0; i < 4; i++) { m.vx[i] = start[i].x; m.vy[i] = start[i].y; m.vz[i] = start[i].z; }
-	v3 center = (((ev(m, 0) + ev(m, 1)) + ev(m, 2)) + ev(m, 3)) / 4.0f;
-	if (dot(cross(ev(m, 2) - ev(m, 0), ev(m, 1) - ev(m, 0)), ev(m, 3) - ev(m, 0)) > 0.0f)
+	m.vx[0] = s0.x; m.vy[0] = s0.y; m.vz[0] = s0.z; m.vx[1] = s1.x; m.vy[1] = s1.y; m.vz[1] = s1.z;
+	m.vx[2] = s2.x; m.vy[2] = s2.y; m.vz[2] = s2.z; m.vx[3] = s3.x; m.vy[3] = s3.y; m.vz[3] = s3.z;
+	v3 center = (((s0 + s1) + s2) + s3) / 4.0f;
+	if (dot(cross(s2 - s0, s1 - s0), s3 - s0) > 0.0f)
 	{
-		v3 a = ev(m, 2), b = ev(m, 3);
-		m.vx[2] = b.x; m.vy[2] = b.y; m.vz[2] = b.z; m.vx[3] = a.x; m.vy[3] = a.y; m.vz[3] = a.z;
+		m.vx[2] = s3.x; m.vy[2] = s3.y; m.vz[2] = s3.z; m.vx[3] = s2.x; m.vy[3] = s2.y; m.vz[3] = s2.z;
 	}
-	tri_set(m, nt++, 2, 3, 1, 0, 2, 3, 1); tri_set(m, nt++, 3, 2, 0, 1, 3, 2, 0); tri_set(m, nt++, 0, 1, 3, 2, 0, 1, 3); tri_set(m, nt++, 1, 0, 2, 3, 1, 0, 2);
+	tri_set(m, nt++, 2, 3, 1, 2, 3, 1); tri_set(m, nt++, 3, 2, 0, 3, 2, 0); tri_set(m, nt++, 0, 1, 3, 0, 1, 3); tri_set(m, nt++, 1, 0, 2, 1, 0, 2);
 	for (int guard = 0; guard < 128; guard++)
 	{
-		v4 face = V4(0, 0, 0, -FLT_MAX);
-		for (int i = 0; i < nt; i++)
+		// face with the largest plane offset; the sequential scan keeps the first maximum (strict >), hull.h:248-261
+		float bd = 0.0f; int bi = 0x7fffffff; v3 bn = V3(0, 0, 0);
+		for (int i = lane; i < nt; i += 64)
 		{
 			v3 n = tri_normal(ev(m, m.tv[i][0]), ev(m, m.tv[i][1]), ev(m, m.tv[i][2]));
 			float d = -dot(n, ev(m, m.tv[i][0]));
-			if (d > face.w) face = V4(n, d);
+			if (d > -FLT_MAX && (bi == 0x7fffffff || d > bd)) { bd = d; bi = i; bn = n; }
 		}
-		v3 v = support(A, xyz(face), lane) - support(B, -xyz(face), lane);
+#pragma unroll
+		for (int o = 32; o >= 1; o >>= 1)
+		{
+			float ob = __shfl_xor(bd, o); int oi = __shfl_xor(bi, o);
+			float ox = __shfl_xor(bn.x, o), oy = __shfl_xor(bn.y, o), oz = __shfl_xor(bn.z, o);
+			if (oi != 0x7fffffff && (bi == 0x7fffffff || ob > bd || (ob == bd && oi < bi))) { bd = ob; bi = oi; bn = V3(ox, oy, oz); }
+		}
+		v4 face = (bi == 0x7fffffff) ? V4(0, 0, 0, -FLT_MAX) : V4(bn, bd);
+		v3 v = support_wave(A, xyz(face), lane) - support_wave(B, -xyz(face), lane);
 		v4 p = V4(xyz(face), -dot(xyz(face), v));
 		if (p.w > plane.w) plane = p;
 		bool dup = false;
-		for (int i = 0; i < nv; i++) if (same(v, ev(m, i))) { dup = true; break; }
-		if (dup) break;
+		for (int i = lane; i < nv; i += 64) dup = dup || same(v, ev(m, i));
+		if (__any(dup)) break;
 		if (plane.w >= face.w - epsilon) break;
 		if (nv >= EPA_MAXV) break;
 		const int vid = nv;
 		m.vx[nv] = v.x; m.vy[nv] = v.y; m.vz[nv] = v.z; nv++;
+		// which triangles see the new vertex (independent of the surgery order: vertices of existing triangles never change)
+		for (int i = lane; i < nt; i += 64) m.ab[i] = (!tri_dead(m, i) && above(m, i, v, 0.01f * epsilon)) ? 1 : 0;
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+		__builtin_amdgcn_wave_barrier();
 		bool okk = true;
 		int j = nt;
 		while (j--)
 		{
 			if (tri_dead(m, j)) continue;
-			if (above(m, j, ev(m, vid), 0.01f * epsilon)) okk = okk && extrude(m, nt, j, vid);
+			if (m.ab[j]) okk = okk && extrude(m, nt, j, vid);
 		}
 		j = nt;
 		while (okk && j--)
@@ -253,6 +334,8 @@ __device__ v4 expanding_polytope(epa_mem &m, const v3 start[4], const support_t 
 			swapn(m, j, nt - 1);
 			nt--;
 		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+		__builtin_amdgcn_wave_barrier();
 	}
 	return plane;
 }
@@ -271,188 +354,173 @@ __device__ v4 inverse_w(v3 c0, v3 c1, v3 c2, v3 c3)
 	          + a.x.w * (a.y.x * a.w.y * a.z.z + a.z.x * a.y.y * a.w.z + a.w.x * a.z.y * a.y.z - a.y.x * a.z.y * a.w.z - a.w.x * a.y.y * a.z.z - a.z.x * a.w.y * a.y.z);
 	return adjw / det;
 }
-
-// Separated(A, B, findclosest = 1), gjk.h:367-437
-// `cutoff` > 0 enables an exact early-out: dot(w,v)/|v| is a lower bound of the distance between the shapes, and the separation the
-// reference finally reports is never below it; once the bound exceeds the contact cut-off the pair cannot produce a contact.
-__device__ gjk_hit separated(const support_t &A, const support_t &B, epa_mem &em, int lane, float cutoff, bool &far_apart)
+__device__ __forceinline__ support_t bcast(const support_t &s, int src)
 {
-	simplex last, next;
-	last.count = 0; next.count = 0;
-	for (int i = 0; i < 4; i++) { last.W[i].a = last.W[i].b = last.W[i].p = V3(0, 0, 0); last.W[i].t = 0; next.W[i] = last.W[i]; }
-	int iter = 0;
-	v3 v = point_on_minkowski(A, B, V3(0, 0, 1), lane).p;
-	last.v = v;
-	mkpoint w = point_on_minkowski(A, B, -v, lane);
-	next.W[0] = w; next.W[0].t = 1.0f; next.v = w.p; next.count = 1;                        // NextMinkSimplex0
-	for (;;)
+	support_t r;
+	r.voff = __shfl(s.voff, src); r.n = __shfl(s.n, src); r.outer = __shfl(s.outer, src);
+	r.pos = V3(__shfl(s.pos.x, src), __shfl(s.pos.y, src), __shfl(s.pos.z, src));
+	r.q = V4(__shfl(s.q.x, src), __shfl(s.q.y, src), __shfl(s.q.z, src), __shfl(s.q.w, src));
+	r.opos = V3(__shfl(s.opos.x, src), __shfl(s.opos.y, src), __shfl(s.opos.z, src));
+	r.oq = V4(__shfl(s.oq.x, src), __shfl(s.oq.y, src), __shfl(s.oq.z, src), __shfl(s.oq.w, src));
+	return r;
+}
+// One GJK run per lane (lanes with run == false idle), then the expanding polytope for the lanes that need it, one pair at a time on the
+// whole wave.  On return status is 0 (hit valid) or 1 (far apart).
+__device__ void separated_wave(bool run, const support_t &A, const support_t &B, float cutoff, epa_mem &em, int lane, int &status, gjk_hit &hit, int dbg)
+{
+	simplex tet;
+	tet.count = 0;
+	for (int i = 0; i < 4; i++) { tet.W[i].a = tet.W[i].b = tet.W[i].p = V3(0, 0, 0); tet.W[i].t = 0; }
+	tet.v = V3(0, 0, 0);
+	status = 1;
+	if (run) status = gjk_run(A, B, cutoff, hit, tet);
+	unsigned long long need = __ballot(run && status == 2);
+	while (need)
 	{
-		bool go;
-		if (iter == 0) { iter++; go = true; }
-		else { iter++; go = (dot(w.p, v) < dot(v, v) - 0.00001f); if (go) { go = (iter < 100); iter++; } }      // while(!iter++ || (... && iter++<100))
-		if (!go) break;
-		last = next;
-		v = last.v;
-		w = point_on_minkowski(A, B, -v, lane);
-		if (cutoff > 0.0f) { const float wv = dot(w.p, v); if (wv > 0.0f && wv > (cutoff * 1.01f + 1e-6f) * length(v)) { far_apart = true; break; } }
-		if (dot(w.p, v) >= dot(v, v) - 0.00001f - 0.00001f * dot(v, v)) break;
-		if (last.count == 1) next1(next, last, w); else if (last.count == 2) next2(next, last, w); else next3(next, last, w);
-		if (is_zero(next.v))
+		const int src = __ffsll((long long)need) - 1;
+		need &= need - 1;
+		const support_t Ab = bcast(A, src), Bb = bcast(B, src);
+		v3 s[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++) s[k] = V3(__shfl(tet.W[k].p.x, src), __shfl(tet.W[k].p.y, src), __shfl(tet.W[k].p.z, src));
+		v4 mpp = (dbg & 32) ? V4(0, 0, 1, -0.001f) : expanding_polytope_wave(em, s[0], s[1], s[2], s[3], Ab, Bb, lane);
+		if (lane == src)
 		{
-			if (next.count == 2) { last = next; v3 n = orth(next.W[0].p - next.W[1].p); next.W[2] = point_on_minkowski(A, B, n, lane); next.count = 3; }
-			if (next.count == 3) { last = next; v3 n = tri_normal(next.W[0].p, next.W[1].p, next.W[2].p); next.W[3] = point_on_minkowski(A, B, n, lane); next.count = 4; }
-			v3 start[4] = { next.W[0].p, next.W[1].p, next.W[2].p, next.W[3].p };
-			v4 mpp = expanding_polytope(em, start, A, B, lane);
-			gjk_hit h;
-			h.normal = -xyz(mpp);
-			h.separation = fmin_std(0.0f, mpp.w);
-			v4 bw = inverse_w(next.W[0].p, next.W[1].p, next.W[2].p, next.W[3].p);
-			h.p0w = ((next.W[0].a * bw.x + next.W[1].a * bw.y) + next.W[2].a * bw.z) + next.W[3].a * bw.w;
-			h.p1w = ((next.W[0].b * bw.x + next.W[1].b * bw.y) + next.W[2].b * bw.z) + next.W[3].b * bw.w;
-			return h;
+			hit.normal = -xyz(mpp);                                  // gjk.h:417-423
+			hit.separation = fmin_std(0.0f, mpp.w);
+			v4 bw = inverse_w(tet.W[0].p, tet.W[1].p, tet.W[2].p, tet.W[3].p);
+			hit.p0w = ((tet.W[0].a * bw.x + tet.W[1].a * bw.y) + tet.W[2].a * bw.z) + tet.W[3].a * bw.w;
+			hit.p1w = ((tet.W[0].b * bw.x + tet.W[1].b * bw.y) + tet.W[2].b * bw.z) + tet.W[3].b * bw.w;
+			status = 0;
 		}
-		if (dot(next.v, next.v) >= dot(last.v, last.v)) break;
 	}
-	return calcpoints(last);
 }
 
 // ------------------------------------------------------------------------------------------------- k_contacts
-#define GJK_WAVES 4
-#define GJK_WCAP 48         // contacts staged per wave
-__global__ __launch_bounds__(64 * GJK_WAVES) void k_contacts(ht_model_dev M, const float *__restrict__ state, float driftmax, float jiggle_sin, const int *__restrict__ active_flag,
-                                                             epa_mem *__restrict__ epa_ws, float *__restrict__ contacts, int *__restrict__ ncontacts, int dbg)
+#define GJK_FRAMES 2        // frames (waves) per block sharing the LDS vertex copy
+__global__ __launch_bounds__(64 * GJK_FRAMES) void k_contacts(ht_model_dev M, const float *__restrict__ state, float driftmax, float jiggle_sin, const int *__restrict__ active_flag,
+                                                              float *__restrict__ contacts, int *__restrict__ ncontacts, int B, int dbg)
 {
-	__shared__ float spos[HT_MAXNB][8];             // pos3 q4 radius
-	__shared__ unsigned char cand[HT_MAXNB * HT_MAXNB / 2][2];
-	__shared__ int ncand;
-	__shared__ unsigned char ccount[HT_MAXNB * HT_MAXNB / 2];
-	__shared__ int cprefix[HT_MAXNB * HT_MAXNB / 2 + 1];
-	__shared__ float wlist[GJK_WAVES][GJK_WCAP][HT_CONTACT];
-	__shared__ unsigned short wcand[GJK_WAVES][GJK_WCAP];
-	const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-	if (active_flag && !active_flag[b]) { if (t == 0) ncontacts[b] = 0; return; }
-	epa_mem &em = epa_ws[(size_t)b * GJK_WAVES + wave];
-	if (t < M.nb)
+	const int nvert = M.vert_off[M.nb];
+	float4 *sverts = g_sm;
+	// per-wave LDS areas after the vertices: body poses, candidate list, polytope mesh
+	unsigned char *wbase = reinterpret_cast<unsigned char *>(g_sm + nvert);
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const size_t wstride = (sizeof(float) * HT_MAXNB * 8 + HT_MAXNB * HT_MAXNB + sizeof(epa_mem) + 15) & ~(size_t)15;
+	float (*P)[8] = reinterpret_cast<float (*)[8]>(wbase + wave * wstride);                       // [nb][pos3 q4 radius]
+	unsigned char (*cand)[2] = reinterpret_cast<unsigned char (*)[2]>(wbase + wave * wstride + sizeof(float) * HT_MAXNB * 8);
+	epa_mem &em = *reinterpret_cast<epa_mem *>(wbase + wave * wstride + sizeof(float) * HT_MAXNB * 8 + HT_MAXNB * HT_MAXNB);
+	const int b = blockIdx.x * GJK_FRAMES + wave;
+	for (int i = t; i < nvert; i += 64 * GJK_FRAMES) sverts[i] = M.verts[i];
+	const bool live = b < B && !(active_flag && !active_flag[b]);
+	if (live && lane < M.nb)
 	{
-		const float *s = state + ((size_t)b * M.nb + t) * HT_STATE_STRIDE;
-		for (int i = 0; i < 7; i++) spos[t][i] = s[i];
-		spos[t][7] = M.bodyc[t * HT_BC + HT_BC_RADIUS];
+		const float *s = state + ((size_t)b * M.nb + lane) * HT_STATE_STRIDE;
+		for (int i = 0; i < 7; i++) P[lane][i] = s[i];
+		P[lane][7] = M.bodyc[lane * HT_BC + HT_BC_RADIUS];
 	}
-	if (t == 0) ncand = 0;
 	__syncthreads();
-	// broad phase in the reference's pair order (physics.h:453-457): wave 0 tests 64 pairs at a time and compacts with a ballot
-	if (wave == 0)
+	if (!live) { if (b < B && lane == 0) ncontacts[b] = 0; return; }
+	const int npairs = M.nb * (M.nb - 1) / 2;
+	// broad phase in the reference's pair order (physics.h:453-457), compacted with a ballot; pair index -> (i, j), i < j, row-major
+	int ncand = 0;
+	for (int base = 0; base < npairs; base += 64)
 	{
-		const int npairs = M.nb * (M.nb - 1) / 2;
-		int k = 0;
-		for (int base = 0; base < npairs; base += 64)
+		const int pidx = base + lane;
+		int i = 0, rem = pidx;
+		while (i < M.nb - 1 && rem >= M.nb - 1 - i) { rem -= M.nb - 1 - i; i++; }
+		const int j = i + 1 + rem;
+		bool keep = false;
+		if (pidx < npairs)
 		{
-			const int pidx = base + lane;
-			// pair index -> (i, j), i < j, row-major over the upper triangle
-			int i = 0, rem = pidx;
-			while (i < M.nb - 1 && rem >= M.nb - 1 - i) { rem -= M.nb - 1 - i; i++; }
-			const int j = i + 1 + rem;
-			bool keep = false;
-			if (pidx < npairs)
-			{
-				keep = (M.collide[i] & M.collide[j] & 2) != 0;
-				v3 d = V3(spos[j][0], spos[j][1], spos[j][2]) - V3(spos[i][0], spos[i][1], spos[i][2]);
-				if (length(d) > spos[i][7] + spos[j][7]) keep = false;
-				if (M.ignore[i] & (1u << j)) keep = false;
-			}
-			const unsigned long long m = __ballot(keep);
-			if (keep) { const int dst = k + __popcll(m & ((1ull << lane) - 1ull)); cand[dst][0] = (unsigned char)i; cand[dst][1] = (unsigned char)j; }
-			k += __popcll(m);
+			keep = (M.collide[i] & M.collide[j] & 2) != 0;
+			v3 d = V3(P[j][0], P[j][1], P[j][2]) - V3(P[i][0], P[i][1], P[i][2]);
+			if (length(d) > P[i][7] + P[j][7]) keep = false;
+			if (M.ignore[i] & (1u << j)) keep = false;
 		}
-		if (lane == 0) ncand = k;
+		if (dbg & 8) keep = false;
+		const unsigned long long m = __ballot(keep);
+		if (keep) { const int dst = ncand + __popcll(m & ((1ull << lane) - 1ull)); cand[dst][0] = (unsigned char)i; cand[dst][1] = (unsigned char)j; }
+		ncand += __popcll(m);
 	}
-	__syncthreads();
-	const int nc = (dbg & 8) ? 0 : ncand;
-	for (int c = t; c < nc; c += 64 * GJK_WAVES) ccount[c] = 0;
-	__syncthreads();
-	int wn = 0;
-	for (int c = wave; c < nc; c += GJK_WAVES)
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the candidate list is read back by other lanes of this wave
+	__builtin_amdgcn_wave_barrier();
+	int nout = 0;                       // contacts written so far for this frame (wave-uniform)
+	for (int base = 0; base < ncand; base += 64)
 	{
-		const int i = cand[c][0], j = cand[c][1];
+		const int cidx = base + lane;
+		const bool keep = cidx < ncand;
+		const int i = keep ? cand[cidx][0] : 0, j = keep ? cand[cidx][1] : 1;
+		// narrow phase, one lane per surviving pair (ContactPatch gjk.h:607-643)
 		support_t A, Bs;
-		A.verts = M.verts + M.vert_off[i]; A.n = M.vert_off[i + 1] - M.vert_off[i]; A.pos = V3(spos[i][0], spos[i][1], spos[i][2]); A.q = V4(spos[i][3], spos[i][4], spos[i][5], spos[i][6]); A.outer = 0; A.opos = V3(0, 0, 0); A.oq = V4(0, 0, 0, 1);
-		Bs.verts = M.verts + M.vert_off[j]; Bs.n = M.vert_off[j + 1] - M.vert_off[j]; Bs.pos = V3(spos[j][0], spos[j][1], spos[j][2]); Bs.q = V4(spos[j][3], spos[j][4], spos[j][5], spos[j][6]); Bs.outer = 0; Bs.opos = V3(0, 0, 0); Bs.oq = V4(0, 0, 0, 1);
-		bool far_apart = false;
-		const gjk_hit h0 = separated(A, Bs, em, lane, (dbg & 16) ? 0.0f : driftmax, far_apart);
-		int kept = 0;
-		auto stage = [&](const gjk_hit &h) {
-			if (wn < GJK_WCAP)
-			{
-				if (lane == 0)
-				{
-					float *o = wlist[wave][wn];
-					o[0] = (float)i; o[1] = (float)j; o[2] = h.normal.x; o[3] = h.normal.y; o[4] = h.normal.z;
-					o[5] = h.p0w.x; o[6] = h.p0w.y; o[7] = h.p0w.z; o[8] = h.p1w.x; o[9] = h.p1w.y; o[10] = h.p1w.z; o[11] = h.separation;
-					wcand[wave][wn] = (unsigned short)c;
-				}
-				wn++; kept++;
-			}
-		};
-		if (!far_apart && !(h0.separation > driftmax))
+		A.voff = M.vert_off[i]; A.n = M.vert_off[i + 1] - M.vert_off[i]; A.pos = V3(P[i][0], P[i][1], P[i][2]); A.q = V4(P[i][3], P[i][4], P[i][5], P[i][6]); A.outer = 0; A.opos = V3(0, 0, 0); A.oq = V4(0, 0, 0, 1);
+		Bs.voff = M.vert_off[j]; Bs.n = M.vert_off[j + 1] - M.vert_off[j]; Bs.pos = V3(P[j][0], P[j][1], P[j][2]); Bs.q = V4(P[j][3], P[j][4], P[j][5], P[j][6]); Bs.outer = 0; Bs.opos = V3(0, 0, 0); Bs.oq = V4(0, 0, 0, 1);
+		gjk_hit hits[5];
+		int hc = 0, status;
+		separated_wave(keep, A, Bs, (dbg & 16) ? 0.0f : driftmax, em, lane, status, hits[0], dbg);
+		const bool touching = keep && status == 0 && !(hits[0].separation > driftmax);
+		if (touching) hc = 1;
+		const float dmin = fminf(M.bodyc[i * HT_BC + HT_BC_DIAM], M.bodyc[j * HT_BC + HT_BC_DIAM]);
+		const bool jig = touching && !(dmin < 0.049f);      // otherwise every jiggle sample is rejected by the 0.05 m proximity test (see header)
+		if (__any(jig))
 		{
-			const int first = wn;
-			stage(h0);
-			const float dmin = fminf(M.bodyc[i * HT_BC + HT_BC_DIAM], M.bodyc[j * HT_BC + HT_BC_DIAM]);
-			if (!(dmin < 0.049f))         // otherwise every jiggle sample is rejected by the 0.05 m proximity test (see header)
+			const v3 n = jig ? hits[0].normal : V3(0, 0, 1);
+			v4 qs = quat_from_to(n, V3(0, 0, 1));
+			v3 tangent = qxdir(qs), bitangent = qydir(qs);
+			for (int r = 0; r < 4; r++)
 			{
-				const v3 n = h0.normal;
-				v4 qs = quat_from_to(n, V3(0, 0, 1));
-				v3 tangent = qxdir(qs), bitangent = qydir(qs);
-				for (int r = 0; r < 4; r++)
+				const v3 raxis = r == 0 ? tangent : r == 1 ? bitangent : r == 2 ? -tangent : -bitangent;
+				v4 jiggle = normalize(V4(raxis * jiggle_sin, 1));
+				v3 pivot = jig ? hits[0].p0w : V3(0, 0, 0);
+				v4 id = V4(0, 0, 0, 1);
+				xf ar = mul(mul(mul(XF(n * 0.2f, id), XF(-pivot, id)), XF(V3(0, 0, 0), jiggle)), XF(pivot, id));
+				support_t AJ = A; AJ.outer = 1; AJ.opos = ar.p; AJ.oq = ar.q;
+				gjk_hit hj; int st;
+				separated_wave(jig, AJ, Bs, 0.0f, em, lane, st, hj, dbg);
+				if (jig)
 				{
-					const v3 raxis = r == 0 ? tangent : r == 1 ? bitangent : r == 2 ? -tangent : -bitangent;
-					v4 jiggle = normalize(V4(raxis * jiggle_sin, 1));
-					v3 pivot = h0.p0w;
-					v4 id = V4(0, 0, 0, 1);
-					xf ar = mul(mul(mul(XF(n * 0.2f, id), XF(-pivot, id)), XF(V3(0, 0, 0), jiggle)), XF(pivot, id));
-					support_t AJ = A; AJ.outer = 1; AJ.opos = ar.p; AJ.oq = ar.q;
-					bool dummy = false;
-					gjk_hit hj = separated(AJ, Bs, em, lane, 0.0f, dummy);
 					hj.normal = n;
 					hj.p0w = apply(inverse(ar), hj.p0w);
 					hj.separation = dot(n, hj.p0w - hj.p1w);
 					bool match = false;
-					for (int q = first; !match && q < wn; q++)
+					for (int q = 0; q < 4; q++) if (q < hc && !match) match = length(hj.p0w - hits[q].p0w) < 0.05f || length(hj.p1w - hits[q].p1w) < 0.05f;
+					if (!match)
 					{
-						const float *o = wlist[wave][q];
-						match = length(hj.p0w - V3(o[5], o[6], o[7])) < 0.05f || length(hj.p1w - V3(o[8], o[9], o[10])) < 0.05f;
+						if (hc == 1) hits[1] = hj; else if (hc == 2) hits[2] = hj; else if (hc == 3) hits[3] = hj; else hits[4] = hj;
+						hc++;
 					}
-					if (match) continue;
-					stage(hj);
 				}
 			}
 		}
-		if (lane == 0) ccount[c] = (unsigned char)kept;
-	}
-	__syncthreads();
-	if (t == 0)
-	{
-		int acc = 0;
-		for (int c = 0; c < nc; c++) { cprefix[c] = acc; acc += ccount[c]; }
-		cprefix[nc] = acc;
-		ncontacts[b] = acc < HT_MAXCONTACT ? acc : HT_MAXCONTACT;
-	}
-	__syncthreads();
-	// each wave writes its staged contacts at their rank in pair order
-	{
-		int prevc = -1, k = 0;
-		for (int e = 0; e < wn; e++)
+		// compaction in pair order: exclusive prefix of the per-lane contact counts across the wave
+		int incl = hc;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+		const int total = __shfl(incl, 63);
+		int dst = nout + incl - hc;
+		for (int k = 0; k < 5; k++) if (k < hc && dst + k < HT_MAXCONTACT)
 		{
-			int c = wcand[wave][e];
-			k = (c == prevc) ? k + 1 : 0; prevc = c;
-			int dst = cprefix[c] + k;
-			if (dst < HT_MAXCONTACT && lane < HT_CONTACT) contacts[((size_t)b * HT_MAXCONTACT + dst) * HT_CONTACT + lane] = wlist[wave][e][lane];
+			const gjk_hit &h = k == 0 ? hits[0] : k == 1 ? hits[1] : k == 2 ? hits[2] : k == 3 ? hits[3] : hits[4];
+			float4 *o = reinterpret_cast<float4 *>(contacts + ((size_t)b * HT_MAXCONTACT + dst + k) * HT_CONTACT);
+			o[0] = make_float4((float)i, (float)j, h.normal.x, h.normal.y);
+			o[1] = make_float4(h.normal.z, h.p0w.x, h.p0w.y, h.p0w.z);
+			o[2] = make_float4(h.p1w.x, h.p1w.y, h.p1w.z, h.separation);
 		}
+		nout += total;
 	}
+	if (lane == 0) ncontacts[b] = nout < HT_MAXCONTACT ? nout : HT_MAXCONTACT;
 }
 
-size_t ht_contacts_workspace_bytes(int B) { return (size_t)B * GJK_WAVES * sizeof(epa_mem); }
+size_t ht_contacts_workspace_bytes(int B) { (void)B; return 16; }      // the polytope mesh lives in LDS now
+
 void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_contacts, dim3(B), dim3(64 * GJK_WAVES), 0, s, M, state, driftmax, jiggle_sin, active_flag, (epa_mem *)epa_ws, contacts, ncontacts, []{ const char *e = getenv("HT_DEBUG_SKIP"); return e ? atoi(e) : 0; }());
+	(void)epa_ws;
+	static int dbg = -1;
+	static bool attr_set = false;
+	if (dbg < 0) { const char *e = getenv("HT_DEBUG_SKIP"); dbg = e ? atoi(e) : 0; }
+	const size_t wstride = (sizeof(float) * HT_MAXNB * 8 + HT_MAXNB * HT_MAXNB + sizeof(epa_mem) + 15) & ~(size_t)15;
+	const size_t smem = (size_t)M.vert_off[M.nb] * sizeof(float4) + GJK_FRAMES * wstride;
+	if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_contacts), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+	hipLaunchKernelGGL(k_contacts, dim3((B + GJK_FRAMES - 1) / GJK_FRAMES), dim3(64 * GJK_FRAMES), smem, s, M, state, driftmax, jiggle_sin, active_flag, contacts, ncontacts, B, dbg);
 }

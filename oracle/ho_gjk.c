@@ -276,6 +276,7 @@ static f3 m44_mulv_xyz(f3 c0, f3 c1, f3 c2, f3 c3, f4 b)   /* mul(float4x4({c0,1
 	return add3(add3(add3(scale3(c0, b.x), scale3(c1, b.y)), scale3(c2, b.z)), scale3(c3, b.w));
 }
 
+int ho_dbg_calls, ho_dbg_iters, ho_dbg_maxiter;      /* iteration statistics for sizing the device kernels */
 /* Separated(A,B,findclosest=1), gjk.h:367-437 */
 static ho_gjk_contact separated(const support_t *A, const support_t *B)
 {
@@ -286,9 +287,12 @@ static ho_gjk_contact separated(const support_t *A, const support_t *B)
 	last.count = 0; last.v = v;
 	mkpoint w = point_on_minkowski(A, B, neg3(v));
 	next0(&next, &last, &w);
+	int loops = 0;
+	ho_dbg_calls++;
 	for (;;)
 	{
 		int go;
+		loops++; ho_dbg_iters++; if (loops > ho_dbg_maxiter) ho_dbg_maxiter = loops;
 		if (iter == 0) { iter++; go = 1; }
 		else
 		{
