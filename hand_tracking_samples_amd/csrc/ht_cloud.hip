@@ -69,11 +69,19 @@ __device__ __forceinline__ void closest_feature(const ht_model_dev &M, const flo
 		const float4 *pl = M.planes + M.plane_off[b];
 		const int np = M.plane_off[b + 1] - M.plane_off[b];
 		float best = 0.0f; int bi = 0;
-		for (int i = 0; i < np; i++)
+		// planes arrive through scalar loads (uniform address); 8 are requested per group so that one wait covers 8 planes
+		for (int i0 = 0; i0 < np; i0 += 8)
 		{
-			float4 q = pl[i];                                   // uniform address -> scalar load
-			float d = dot_plane(V4(q.x, q.y, q.z, q.w), vl);
-			if (i == 0 || best < d) { best = d; bi = i; }       // std::max_element: first maximum
+			float4 q[8];
+#pragma unroll
+			for (int k = 0; k < 8; k++) q[k] = pl[min(i0 + k, np - 1)];
+#pragma unroll
+			for (int k = 0; k < 8; k++)
+			{
+				const int i = i0 + k;
+				float d = dot_plane(V4(q[k].x, q[k].y, q[k].z, q[k].w), vl);
+				if (i < np && (i == 0 || best < d)) { best = d; bi = i; }       // std::max_element: first maximum
+			}
 		}
 		if (consider)
 		{
@@ -124,18 +132,23 @@ __global__ __launch_bounds__(64) void k_cloud_rows(ht_model_dev M, const float *
 		const float4 *pl = M.planes + M.plane_off[bb];
 		const int np = M.plane_off[bb + 1] - M.plane_off[bb];
 		bool done = !mine, ok = true;
-		for (int k = 0; k < np; k++)
+		for (int k0 = 0; k0 < np; k0 += 8)
 		{
-			float4 q = pl[k];
-			v4 plane = V4(q.x, q.y, q.z, q.w);
-			float d0 = dot_plane(plane, v0), d1 = dot_plane(plane, v1);
-			if (!done)
+			float4 qq[8];
+#pragma unroll
+			for (int k = 0; k < 8; k++) qq[k] = pl[min(k0 + k, np - 1)];
+#pragma unroll
+			for (int k = 0; k < 8; k++)
 			{
-				if (d0 >= 0 && d1 >= 0) { ok = false; done = true; }
-				else if (!(d0 <= 0 && d1 <= 0))
+				v4 plane = V4(qq[k].x, qq[k].y, qq[k].z, qq[k].w);
+				float d0 = dot_plane(plane, v0), d1 = dot_plane(plane, v1);
+				const bool live = !done && k0 + k < np;
+				if (live && d0 >= 0 && d1 >= 0) { ok = false; done = true; }
+				const bool clip = live && !done && !(d0 <= 0 && d1 <= 0);
+				if (__any(clip))      // the three divisions are only issued when some lane's segment really straddles this plane
 				{
 					v3 c = v0 + ((v1 - v0) * d0) / (d0 - d1);
-					if (d0 >= 0) v0 = c; else v1 = c;
+					if (clip) { if (d0 >= 0) v0 = c; else v1 = c; }
 				}
 			}
 		}

@@ -31,13 +31,18 @@
 
 struct lds_t
 {
-	float pos[HT_MAXNB][3], q[HT_MAXNB][4], lin[HT_MAXNB][3], ang[HT_MAXNB][3], Iinv[HT_MAXNB][9], massinv[HT_MAXNB], friction[HT_MAXNB];
+	// body state in 16-byte records so that a row update moves it with a few ds_read_b128 / ds_write_b128
+	float4 lin4[HT_MAXNB];                 // xyz linear momentum, w = massinv
+	float4 ang4[HT_MAXNB];                 // xyz angular momentum, w = friction
+	float4 I4[HT_MAXNB][3];                // columns of the world inverse inertia (w unused)
+	float pos[HT_MAXNB][3], q[HT_MAXNB][4];
 	float jr[HT_MAXNJ][6];                 // joint ranges after HandModelEnhancements
 	float ray[20][HT_ROW]; int nray;
 	int acount[HT_MAXNJ], aprefix[HT_MAXNJ + 1];
 	unsigned char lrb[MAXL2][2], arb[MAXA2][2];     // body pair of every two-body row (255 = none), for the level schedule
 	unsigned char llev[MAXL2], alev[MAXA2];
 	int nlev_lin, nlev_ang;
+	int lastlev[HT_MAXNB];                 // scratch of the level scheduler
 	float cisum[64];                       // impulse sum of each contact's normal row, read by its two friction rows (physics.h:292)
 	float chain[CH_CAP][SROW];
 };
@@ -47,6 +52,8 @@ __device__ __forceinline__ v4 L4(const float *p) { return V4(p[0], p[1], p[2], p
 __device__ __forceinline__ void S3(float *p, v3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
 __device__ __forceinline__ m3 LM(const float *p) { m3 m; m.x = V3(p[0], p[1], p[2]); m.y = V3(p[3], p[4], p[5]); m.z = V3(p[6], p[7], p[8]); return m; }
 __device__ __forceinline__ xf body_xf(const lds_t &S, int b) { return XF(L3(S.pos[b]), L4(S.q[b])); }
+__device__ __forceinline__ v3 F3(float4 f) { return V3(f.x, f.y, f.z); }
+__device__ __forceinline__ m3 body_I(const lds_t &S, int b) { m3 m; m.x = F3(S.I4[b][0]); m.y = F3(S.I4[b][1]); m.z = F3(S.I4[b][2]); return m; }
 __device__ __forceinline__ v3 anchor_world(const lds_t &S, int rb, v3 p) { return rb >= 0 ? apply(body_xf(S, rb), p) : p; }
 
 // ---- angular row builders ----------------------------------------------------------------------
@@ -126,17 +133,7 @@ __constant__ int FEATURE_BONE[8] = { 1, 1, 1, 4, 7, 10, 13, 16 };
 __constant__ float FEATURE_OFF[8][3] = { { 0, 0, 0 }, { -0.03f, 0, -0.03f }, { 0.03f, 0, -0.03f }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
 
 // ---- two-body row maths ------------------------------------------------------------------------
-__device__ __forceinline__ v3 spin_of(const lds_t &S, int b) { return mul(LM(S.Iinv[b]), L3(S.ang[b])); }       // physics.h:126
-__device__ __forceinline__ void linear_precompute(const ht_physics_dev &ph, const lds_t &S, float *w, int rb0, int rb1, v3 p0, v3 p1, v3 n, float targetdist, float tsnb, float fmin, float fmax, int fm)
-{
-	v3 r0 = rb0 >= 0 ? qrot(L4(S.q[rb0]), p0) : p0;
-	v3 r1 = rb1 >= 0 ? qrot(L4(S.q[rb1]), p1) : p1;
-	float impulsed = ((rb0 >= 0) ? S.massinv[rb0] + dot(cross(mul(LM(S.Iinv[rb0]), cross(r0, n)), r0), n) : 0)
-	               + ((rb1 >= 0) ? S.massinv[rb1] + dot(cross(mul(LM(S.Iinv[rb1]), cross(r1, n)), r1), n) : 0);
-	w[0] = __int_as_float(rb0); w[1] = __int_as_float(rb1); S3(w + 2, r0); S3(w + 5, r1); S3(w + 8, n);
-	w[11] = targetdist / ph.deltaT; w[12] = tsnb; w[13] = fmin * ph.deltaT; w[14] = fmax * ph.deltaT; w[15] = impulsed; w[16] = 0.0f; w[17] = __int_as_float(fm);
-}
-
+__device__ __forceinline__ v3 spin_of(const lds_t &S, int b) { return mul(body_I(S, b), F3(S.ang4[b])); }       // physics.h:126
 // ------------------------------------------------------------------------------------------------- k_solve
 struct lrow { int rb0, rb1; v3 r0, r1, n; float ts, tsnb, fmn, fmx, impulsed, isum; int fm, lev, cidx; };
 struct arow { int rb0, rb1; v3 axis; float targetspin, mn, mx, s2t, torque, mintorque; int lev; };
@@ -178,10 +175,10 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		lin = lin + V3(0, 0, 0); ang = ang + V3(0, 0, 0);
 		for (int i = 0; i < 3; i++) S.pos[lane][i] = s[i];
 		for (int i = 0; i < 4; i++) S.q[lane][i] = s[3 + i];
-		S3(S.lin[lane], lin); S3(S.ang[lane], ang);
-		S.massinv[lane] = bc[HT_BC_MASSINV]; S.friction[lane] = bc[HT_BC_FRICTION];
+		S.lin4[lane] = make_float4(lin.x, lin.y, lin.z, bc[HT_BC_MASSINV]);
+		S.ang4[lane] = make_float4(ang.x, ang.y, ang.z, bc[HT_BC_FRICTION]);
 		m3 I = world_inertia(V4(s[3], s[4], s[5], s[6]), LM(bc + HT_BC_TINV), bc[HT_BC_MASSINV]);
-		S.Iinv[lane][0] = I.x.x; S.Iinv[lane][1] = I.x.y; S.Iinv[lane][2] = I.x.z; S.Iinv[lane][3] = I.y.x; S.Iinv[lane][4] = I.y.y; S.Iinv[lane][5] = I.y.z; S.Iinv[lane][6] = I.z.x; S.Iinv[lane][7] = I.z.y; S.Iinv[lane][8] = I.z.z;
+		S.I4[lane][0] = make_float4(I.x.x, I.x.y, I.x.z, 0.0f); S.I4[lane][1] = make_float4(I.y.x, I.y.y, I.y.z, 0.0f); S.I4[lane][2] = make_float4(I.z.x, I.z.y, I.z.z, 0.0f);
 	}
 	if (lane < nj) for (int i = 0; i < 6; i++) S.jr[lane][i] = M.jointc[lane * HT_JC + HT_JC_RMIN + i];
 	if (lane == 0) S.nray = 0;
@@ -237,6 +234,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	}
 	__syncthreads();
 
+	if (a.dbg & 256) return;
 	// ---- angular rows: [ApplyAngles 12] [arm cone 1] [joint ranges], generated by the lane that owns them ----
 	const int na_pre = (a.apply_angles ? 12 : 0) + (a.arm_cone ? 1 : 0);
 	if (lane < nj) S.acount[lane] = angular_range_count(L3(S.jr[lane]), L3(S.jr[lane] + 3));
@@ -301,12 +299,13 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			R.rb0 = __float_as_int(row[0]); R.rb1 = __float_as_int(row[1]); R.axis = V3(row[2], row[3], row[4]); R.targetspin = row[5];
 			const float mintorque = row[6], maxtorque = row[7];
 			// physics.h:256-259: Iinv is invariant during the update, so 1/(axis.Iinv0.axis + axis.Iinv1.axis) is computed once
-			R.s2t = 1.0f / (((R.rb0 >= 0) ? dot(R.axis, mul(LM(S.Iinv[R.rb0]), R.axis)) : 0.0f) + ((R.rb1 >= 0) ? dot(R.axis, mul(LM(S.Iinv[R.rb1]), R.axis)) : 0.0f));
+			R.s2t = 1.0f / (((R.rb0 >= 0) ? dot(R.axis, mul(body_I(S, R.rb0), R.axis)) : 0.0f) + ((R.rb1 >= 0) ? dot(R.axis, mul(body_I(S, R.rb1), R.axis)) : 0.0f));
 			R.mn = mintorque * dt; R.mx = maxtorque * dt; R.mintorque = mintorque; R.torque = 0.0f;
 			S.arb[r][0] = (unsigned char)(R.rb0 >= 0 ? R.rb0 : 255); S.arb[r][1] = (unsigned char)(R.rb1 >= 0 ? R.rb1 : 255);
 		}
 	}
 
+	if (a.dbg & 512) return;
 	// ---- two-body linear rows: joints (physmodel.h:328-334) then contacts (physics.h:463-489), each built by its owner lane ----
 	int nc = (a.contacts && ph.use_collision) ? a.ncontacts[b] : 0;
 	if (3 * nj + 3 * nc > MAXL2) nc = (MAXL2 - 3 * nj) / 3;
@@ -342,8 +341,8 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				if (k == 0)
 				{
 					const v3 r0w = p0w - L3(S.pos[R.rb0]), r1w = p1w - L3(S.pos[R.rb1]);
-					const v3 v0 = cross(spin_of(S, R.rb0), r0w) + L3(S.lin[R.rb0]) * S.massinv[R.rb0];
-					const v3 v1 = cross(spin_of(S, R.rb1), r1w) + L3(S.lin[R.rb1]) * S.massinv[R.rb1];
+					const v3 v0 = cross(spin_of(S, R.rb0), r0w) + F3(S.lin4[R.rb0]) * S.lin4[R.rb0].w;
+					const v3 v1 = cross(spin_of(S, R.rb1), r1w) + F3(S.lin4[R.rb1]) * S.lin4[R.rb1].w;
 					const v3 v = v0 - v1;
 					const float minsep = ph.driftmax * 0.25f;
 					const float bouncevel = fmax_std(0.0f, (-dot(normal, v) - ph.gravity_len * ph.falltime_to_ballistic) * ph.restitution);
@@ -357,7 +356,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				}
 			}
 			R.r0 = qrot(L4(S.q[R.rb0]), p0); R.r1 = qrot(L4(S.q[R.rb1]), p1); R.n = n;
-			R.impulsed = (S.massinv[R.rb0] + dot(cross(mul(LM(S.Iinv[R.rb0]), cross(R.r0, n)), R.r0), n)) + (S.massinv[R.rb1] + dot(cross(mul(LM(S.Iinv[R.rb1]), cross(R.r1, n)), R.r1), n));
+			R.impulsed = (S.lin4[R.rb0].w + dot(cross(mul(body_I(S, R.rb0), cross(R.r0, n)), R.r0), n)) + (S.lin4[R.rb1].w + dot(cross(mul(body_I(S, R.rb1), cross(R.r1, n)), R.r1), n));
 			R.ts = targetdist / dt; R.tsnb = tsnb; R.fmn = fmin_std(fmn, fmx) * dt; R.fmx = fmax_std(fmn, fmx) * dt; R.isum = 0.0f;
 			S.lrb[r][0] = (unsigned char)R.rb0; S.lrb[r][1] = (unsigned char)R.rb1;
 		}
@@ -367,14 +366,14 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	// ---- level schedule (one lane, once per solve): level(row) = 1 + max level of an earlier row sharing a body ----
 	if (lane == 0)
 	{
-		unsigned char last[HT_MAXNB];
+		int *last = S.lastlev;               // LDS, not a private array: dynamic indexing of a private array goes to scratch memory
 		for (int k = 0; k < nb; k++) last[k] = 0;
 		int mx = 0;
 		for (int r = 0; r < n2; r++)
 		{
 			const int b0 = S.lrb[r][0], b1 = S.lrb[r][1];
 			int l = (last[b0] > last[b1] ? last[b0] : last[b1]) + 1;
-			last[b0] = last[b1] = (unsigned char)l; S.llev[r] = (unsigned char)l; if (l > mx) mx = l;
+			last[b0] = l; last[b1] = l; S.llev[r] = (unsigned char)l; if (l > mx) mx = l;
 		}
 		S.nlev_lin = mx;
 		for (int k = 0; k < nb; k++) last[k] = 0;
@@ -384,8 +383,8 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			const int b0 = S.arb[r][0], b1 = S.arb[r][1];
 			int l0 = b0 != 255 ? last[b0] : 0, l1 = b1 != 255 ? last[b1] : 0;
 			int l = (l0 > l1 ? l0 : l1) + 1;
-			if (b0 != 255) last[b0] = (unsigned char)l;
-			if (b1 != 255) last[b1] = (unsigned char)l;
+			if (b0 != 255) last[b0] = l;
+			if (b1 != 255) last[b1] = l;
 			S.alev[r] = (unsigned char)l; if (l > mx) mx = l;
 		}
 		S.nlev_ang = mx;
@@ -396,6 +395,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 #pragma unroll
 	for (int s = 0; s < ASLOTS; s++) if (lane + 64 * s < na) AR[s].lev = S.alev[lane + 64 * s];
 	const int nlev_lin = S.nlev_lin, nlev_ang = S.nlev_ang;
+	if (a.dbg & 64) return;
 
 	// ---- single-body prefix: [ray rows | chamber rows] then cloud rows; stable partition by body + pre-compute -> LDS (overflow: HBM) ----
 	const int npre_g = a.rows_pre ? a.n_pre[b] : 0;
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		{
 			const v3 p1 = L3(r + 5), n = L3(r + 8);
 			const v3 r1 = qrot(L4(S.q[body]), p1);
-			const float impulsed = S.massinv[body] + dot(cross(mul(LM(S.Iinv[body]), cross(r1, n)), r1), n);       // 0 + (...) for the NULL side
+			const float impulsed = S.lin4[body].w + dot(cross(mul(body_I(S, body), cross(r1, n)), r1), n);       // 0 + (...) for the NULL side
 			const float4 o0 = make_float4(r1.x, r1.y, r1.z, n.x), o1 = make_float4(n.y, n.z, r[11] / dt, r[12]), o2 = make_float4(r[13] * dt, r[14] * dt, impulsed, 0.0f);
 			if (dst < CH_CAP) { float4 *o = reinterpret_cast<float4 *>(&S.chain[dst][0]); o[0] = o0; o[1] = o1; o[2] = o2; }
 			else { float4 *o = reinterpret_cast<float4 *>(scr + (size_t)dst * SROW); o[0] = o0; o[1] = o1; o[2] = o2; }
@@ -456,6 +456,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	}
 	__syncthreads();
 
+	if (a.dbg & 128) return;
 	// ---- Gauss-Seidel sweeps ----
 	v3 pos_next = V3(0, 0, 0); v4 q_next = V4(0, 0, 0, 1);
 	const int total_sweeps = ph.iterations + ph.iterations_post;
@@ -466,9 +467,10 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		//     Rows [mystart, mystart+mycnt) are contiguous: the part below CH_CAP is read with LDS instructions, the rest from HBM scratch.
 		if (lane < nb && mycnt > 0 && !(a.dbg & 1))
 		{
-			v3 lin = L3(S.lin[lane]), ang = L3(S.ang[lane]);
-			const m3 I = LM(S.Iinv[lane]);
-			const float minv = S.massinv[lane];
+			const float4 lin0 = S.lin4[lane], ang0 = S.ang4[lane];
+			v3 lin = F3(lin0), ang = F3(ang0);
+			const m3 I = body_I(S, lane);
+			const float minv = lin0.w;
 			auto apply_row = [&](const float4 c0, const float4 c1, const float4 c2) -> float {
 				const v3 r1 = V3(c0.x, c0.y, c0.z), n = V3(c0.w, c1.x, c1.y);
 				const float ts = post ? fmin_std(c1.z, c1.w) : c1.z;                      // RemoveBias physics.h:288
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				const float isum = apply_row(rp[0], rp[1], rp[2]);
 				scr[(size_t)(mystart + k) * SROW + 11] = isum;
 			}
-			S3(S.lin[lane], lin); S3(S.ang[lane], ang);
+			S.lin4[lane] = make_float4(lin.x, lin.y, lin.z, lin0.w); S.ang4[lane] = make_float4(ang.x, ang.y, ang.z, ang0.w);
 		}
 		__syncthreads();
 		// (2) two-body linear rows, level by level (LimitLinear::Iter physics.h:289-307)
@@ -514,24 +516,25 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				lrow &R = LR[s];
 				if (R.lev == L)
 				{
+					const float4 L0 = S.lin4[R.rb0], A0 = S.ang4[R.rb0], L1 = S.lin4[R.rb1], A1 = S.ang4[R.rb1];
 					float fmn = R.fmn, fmx = R.fmx;
 					if (R.fm)
 					{
 						const float master = S.cisum[R.cidx];
-						const float lim = fmax_std(S.friction[R.rb0], S.friction[R.rb1]) * master / dt;       // physics.h:292
+						const float lim = fmax_std(A0.w, A1.w) * master / dt;       // physics.h:292
 						fmx = lim * dt; fmn = (-lim) * dt;
 					}
 					const float ts = post ? fmin_std(R.ts, R.tsnb) : R.ts;
-					const v3 l0 = L3(S.lin[R.rb0]), a0 = L3(S.ang[R.rb0]), l1 = L3(S.lin[R.rb1]), a1 = L3(S.ang[R.rb1]);
-					const v3 v0 = cross(mul(LM(S.Iinv[R.rb0]), a0), R.r0) + l0 * S.massinv[R.rb0];
-					const v3 v1 = cross(mul(LM(S.Iinv[R.rb1]), a1), R.r1) + l1 * S.massinv[R.rb1];
+					const v3 l0 = F3(L0), a0 = F3(A0), l1 = F3(L1), a1 = F3(A1);
+					const v3 v0 = cross(mul(body_I(S, R.rb0), a0), R.r0) + l0 * L0.w;
+					const v3 v1 = cross(mul(body_I(S, R.rb1), a1), R.r1) + l1 * L1.w;
 					const float vn = dot(v1 - v0, R.n);
 					const float impulsen = -ts - vn;
 					float impulse = impulsen / R.impulsed;
 					impulse = fmin_std(fmx - R.isum, impulse);
 					impulse = fmax_std(fmn - R.isum, impulse);
-					{ const v3 imp = R.n * -impulse; S3(S.lin[R.rb0], l0 + imp); S3(S.ang[R.rb0], a0 + cross(R.r0, imp)); }
-					{ const v3 imp = R.n * impulse; S3(S.lin[R.rb1], l1 + imp); S3(S.ang[R.rb1], a1 + cross(R.r1, imp)); }
+					{ const v3 imp = R.n * -impulse; const v3 nl = l0 + imp, na = a0 + cross(R.r0, imp); S.lin4[R.rb0] = make_float4(nl.x, nl.y, nl.z, L0.w); S.ang4[R.rb0] = make_float4(na.x, na.y, na.z, A0.w); }
+					{ const v3 imp = R.n * impulse; const v3 nl = l1 + imp, na = a1 + cross(R.r1, imp); S.lin4[R.rb1] = make_float4(nl.x, nl.y, nl.z, L1.w); S.ang4[R.rb1] = make_float4(na.x, na.y, na.z, A1.w); }
 					R.isum = R.isum + impulse;
 					if (lane + 64 * s >= 3 * nj && R.fm == 0) S.cisum[R.cidx] = R.isum;
 				}
@@ -551,14 +554,15 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 					if (post) targetspin = (R.mintorque < 0) ? 0 : fmin_std(targetspin, 0.0f);            // RemoveBias physics.h:250
 					if (!(targetspin == -FLT_MAX))
 					{
-						const v3 a0 = R.rb0 >= 0 ? L3(S.ang[R.rb0]) : V3(0, 0, 0), a1 = R.rb1 >= 0 ? L3(S.ang[R.rb1]) : V3(0, 0, 0);
-						const float currentspin = ((R.rb1 >= 0) ? dot(mul(LM(S.Iinv[R.rb1]), a1), R.axis) : 0.0f) - ((R.rb0 >= 0) ? dot(mul(LM(S.Iinv[R.rb0]), a0), R.axis) : 0.0f);
+						const float4 A0 = R.rb0 >= 0 ? S.ang4[R.rb0] : make_float4(0, 0, 0, 0), A1 = R.rb1 >= 0 ? S.ang4[R.rb1] : make_float4(0, 0, 0, 0);
+						const v3 a0 = F3(A0), a1 = F3(A1);
+						const float currentspin = ((R.rb1 >= 0) ? dot(mul(body_I(S, R.rb1), a1), R.axis) : 0.0f) - ((R.rb0 >= 0) ? dot(mul(body_I(S, R.rb0), a0), R.axis) : 0.0f);
 						const float dspin = targetspin - currentspin;
 						float dtorque = dspin * R.s2t;
 						dtorque = fmin_std(dtorque, R.mx - R.torque);
 						dtorque = fmax_std(dtorque, R.mn - R.torque);
-						if (R.rb0 >= 0) S3(S.ang[R.rb0], a0 - R.axis * dtorque);
-						if (R.rb1 >= 0) S3(S.ang[R.rb1], a1 + R.axis * dtorque);
+						if (R.rb0 >= 0) { const v3 na = a0 - R.axis * dtorque; S.ang4[R.rb0] = make_float4(na.x, na.y, na.z, A0.w); }
+						if (R.rb1 >= 0) { const v3 na = a1 + R.axis * dtorque; S.ang4[R.rb1] = make_float4(na.x, na.y, na.z, A1.w); }
 						R.torque = R.torque + dtorque;
 					}
 				}
@@ -569,10 +573,10 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		{
 			// rbcalcnextpose physics.h:522-531 with rkupdateq :211-218 (momentum-preserving RK4 on the quaternion)
 			const float *bc = M.bodyc + lane * HT_BC;
-			const float minv = S.massinv[lane];
-			pos_next = L3(S.pos[lane]) + (L3(S.lin[lane]) * minv) * dt;
+			const float minv = S.lin4[lane].w;
+			pos_next = L3(S.pos[lane]) + (F3(S.lin4[lane]) * minv) * dt;
 			const m3 tinv = LM(bc + HT_BC_TINV) * minv;
-			const v3 angm = L3(S.ang[lane]);
+			const v3 angm = F3(S.ang4[lane]);
 			const v4 s = L4(S.q[lane]);
 			auto diffq = [&](v4 o) -> v4 {
 				v4 sn = normalize(o);
@@ -596,7 +600,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		float *s = st + lane * HT_STATE_STRIDE;
 		const float *bc = M.bodyc + lane * HT_BC;
 		v3 pos = pos_next; v4 q = q_next;
-		v3 lin = L3(S.lin[lane]), ang = L3(S.ang[lane]);
+		v3 lin = F3(S.lin4[lane]), ang = F3(S.ang4[lane]);
 		const bool bad = isnan(lin.x) || isnan(lin.y) || isnan(lin.z) || isnan(pos.x) || isnan(pos.y) || isnan(pos.z) || isnan(ang.x) || isnan(ang.y) || isnan(ang.z)
 		              || isnan(q.x) || isnan(q.y) || isnan(q.z) || isnan(q.w);
 		if (bad) { pos = L3(bc + HT_BC_POS0); q = L4(bc + HT_BC_Q0); lin = V3(0, 0, 0); ang = V3(0, 0, 0); }
