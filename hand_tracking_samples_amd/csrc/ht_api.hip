@@ -154,6 +154,8 @@ extern "C" int ht_create(const char *model_path, int max_batch, int device, ht_c
 	HIPCHK(ctx, hipGetDeviceProperties(&prop, device));
 	if (!strstr(prop.gcnArchName, "gfx950")) { ctx->err = std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only"; return HT_ERR_HIP; }
 	HIPCHK(ctx, hipStreamCreate(&ctx->stream));
+	for (int i = 0; i < 2; i++) { HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking)); HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming)); }
+	HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
 	int r = load_model(ctx, model_path);
 	if (r) return r;
 	sync_params(ctx);
@@ -167,6 +169,8 @@ extern "C" int ht_destroy(ht_ctx *ctx)
 	if (!ctx) return HT_ERR_ARG;
 	for (void *p : ctx->allocs) (void)hipFree(p);
 	for (auto &kv : ctx->prof) for (hipEvent_t e : kv.second.ev) (void)hipEventDestroy(e);
+	for (int i = 0; i < 2; i++) { if (ctx->side[i]) (void)hipStreamDestroy(ctx->side[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
+	if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 	return HT_OK;
@@ -201,7 +205,7 @@ extern "C" int ht_cnn_load_weights(ht_ctx *ctx, const float *w, size_t n)
 static int cnn_forward(ht_ctx *ctx, const float *d_in, float *d_out, int B, hipStream_t s)
 {
 	if (!ctx->have_weights) { ctx->err = "CNN weights not loaded (ht_cnn_load_weights)"; return HT_ERR_STATE; }
-	ht_prof_scope p0(ctx, "cnn", s);
+	ht_prof_scope p0(ctx, "cnn", s, true);
 	ht_launch_cnn(ctx->cnnw, d_in, ctx->d_act1, ctx->d_act2, ctx->d_act3, ctx->d_logits, B, s);
 	ht_launch_softmax_decode(ctx->d_logits, d_out, nullptr, nullptr, 1, B, s);
 	return HT_OK;
@@ -261,9 +265,9 @@ extern "C" int ht_stage_decode(ht_ctx *ctx, const float *cnn_out, const float *c
 // ------------------------------------------------------------------------------------------------- profiling hooks
 // Each named phase records a pair of HIP events on the stream the kernels run on; pairs are pooled and only resolved in
 // ht_profile_read, so enabling the profile adds no host synchronisation to the launch sequence.
-ht_prof_scope::ht_prof_scope(ht_ctx *c, const char *name, hipStream_t s) : ctx(c), ent(nullptr), stream(s), slot(0)
+ht_prof_scope::ht_prof_scope(ht_ctx *c, const char *name, hipStream_t s, bool minor_phase) : ctx(c), ent(nullptr), stream(s), slot(0)
 {
-	if (!c->profile) return;
+	if (!c->profile || (minor_phase && !c->profile_phases)) return;
 	auto it = c->prof.find(name);
 	if (it == c->prof.end()) { ht_prof_entry e; e.used = 0; e.total_ms = 0; e.launches = 0; it = c->prof.emplace(name, e).first; }
 	ht_prof_entry *e = &it->second;
@@ -291,7 +295,7 @@ static void prof_resolve(ht_prof_entry &e)
 	}
 	e.used = 0;
 }
-extern "C" int ht_profile_enable(ht_ctx *ctx, int on) { if (!ctx) return HT_ERR_ARG; ctx->profile = on != 0; return HT_OK; }
+extern "C" int ht_profile_enable(ht_ctx *ctx, int on) { if (!ctx) return HT_ERR_ARG; ctx->profile = on != 0; ctx->profile_phases = on > 1; return HT_OK; }
 extern "C" int ht_profile_read(ht_ctx *ctx, int reset, int max_entries, char *names, int name_stride, float *total_ms, int *launches, int *n_entries)
 {
 	if (!ctx || !n_entries) return HT_ERR_ARG;

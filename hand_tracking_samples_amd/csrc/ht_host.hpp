@@ -10,9 +10,12 @@ struct ht_prof_entry { std::vector<hipEvent_t> ev; size_t used; float total_ms; 
 struct ht_ctx
 {
 	bool ready = false, have_weights = false, profile = false;
+	bool profile_phases = false;     // also time the minor phases (serialises the side streams; used for the phase table, not for the timed region)
 	int B = 0, device = 0;
 	std::string err;
 	hipStream_t stream = nullptr;
+	hipStream_t side[2] = { nullptr, nullptr };     // independent kernels of one fit step (cloud rows, contacts, chamber) run side by side
+	hipEvent_t ev_fork = nullptr, ev_join[2] = { nullptr, nullptr };
 	ht_params par;
 	ht_physics_dev phys;
 	ht_model_dev model;
@@ -42,7 +45,7 @@ struct ht_ctx
 struct ht_prof_scope
 {
 	ht_ctx *ctx; ht_prof_entry *ent; hipStream_t stream; size_t slot;
-	ht_prof_scope(ht_ctx *c, const char *name, hipStream_t s);
+	ht_prof_scope(ht_ctx *c, const char *name, hipStream_t s, bool minor_phase = false);
 	~ht_prof_scope();
 };
 

@@ -29,6 +29,11 @@ static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int 
 	{ static int dbg = -1; if (dbg < 0) { const char *e = getenv("HT_DEBUG_SKIP"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
 	ht_launch_solve(ctx->model, ctx->phys, a, B, s);
 }
+// Fork/join helpers: the row-producing kernels of one fit step only read the pose, so they run side by side on two extra streams
+// and the solve waits for all of them (each of them is latency-bound on its slowest frame and leaves most of the chip idle).
+static void fork(ht_ctx *ctx, hipStream_t s) { (void)hipEventRecord(ctx->ev_fork, s); for (int i = 0; i < 2; i++) (void)hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0); }
+static void join(ht_ctx *ctx, hipStream_t s, int n) { for (int i = 0; i < n; i++) { (void)hipEventRecord(ctx->ev_join[i], ctx->side[i]); (void)hipStreamWaitEvent(s, ctx->ev_join[i], 0); } }
+
 // HandTracker::MultiStepSim on othermodel (handtrack.h:642-690)
 static void multistep(ht_ctx *ctx, int B, hipStream_t s)
 {
@@ -38,25 +43,33 @@ static void multistep(ht_ctx *ctx, int B, hipStream_t s)
 		const bool angles = (st < p.steps_keyangles) || p.angles_only;
 		const bool rays = (st < p.steps_keypoints) && !p.angles_only;
 		const bool cloud = (st >= p.steps_cloudstart) && !p.angles_only;
-		if (cloud) { ht_prof_scope ps(ctx, "cloud_rows", s); ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, nullptr, 4, 1, 2, p, ctx->d_rows, ctx->d_nrows, B, s); }
-		if (ctx->phys.use_collision) { ht_prof_scope ps(ctx, "contacts", s); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s); }
+		const bool coll = ctx->phys.use_collision != 0;
+		const bool par = cloud && coll && !ctx->profile_phases;
+		if (par) fork(ctx, s);
+		if (cloud) { ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, nullptr, 4, 1, 2, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[0] : s); }
+		if (coll) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s); }
+		if (par) join(ctx, s, 1);
 		ht_prof_scope ps(ctx, "solve", s);
-		solve_step(ctx, 1, nullptr, nullptr, cloud, ctx->phys.use_collision != 0, nullptr, angles, st < p.steps_palmangle ? 10000.0f : 0.0f, rays, 1, 1, B, s);
+		solve_step(ctx, 1, nullptr, nullptr, cloud, coll, nullptr, angles, st < p.steps_palmangle ? 10000.0f : 0.0f, rays, 1, 1, B, s);
 	}
 }
 // one main-thread pass of HandTracker::update (handtrack.h:769-780)
 static void main_pass(ht_ctx *ctx, int B, hipStream_t s)
 {
 	const ht_params &p = ctx->par;
-	{ ht_prof_scope ps(ctx, "chamber", s); ht_launch_chamber(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, p.min_point_num, p.boundary_planes, 10.0f, ctx->d_chamber, ctx->d_nchamber, B, s); }
-	{ ht_prof_scope ps(ctx, "cloud_rows", s); ht_launch_cloud_rows(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, ctx->d_cams, nullptr, 1, 0, 1, p, ctx->d_rows, ctx->d_nrows, B, s); }
-	if (ctx->phys.use_collision) { ht_prof_scope ps(ctx, "contacts", s); ht_launch_contacts(ctx->model, ctx->d_state[0], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s); }
+	const bool coll = ctx->phys.use_collision != 0;
+	const bool par = !ctx->profile_phases;
+	if (par) fork(ctx, s);
+	{ ht_prof_scope ps(ctx, "chamber", s, true); ht_launch_chamber(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, p.min_point_num, p.boundary_planes, 10.0f, ctx->d_chamber, ctx->d_nchamber, B, par ? ctx->side[1] : s); }
+	{ ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, ctx->d_cams, nullptr, 1, 0, 1, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[0] : s); }
+	if (coll) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[0], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s); }
+	if (par) join(ctx, s, 2);
 	ht_prof_scope ps(ctx, "solve", s);
-	solve_step(ctx, 0, ctx->d_chamber, ctx->d_nchamber, true, ctx->phys.use_collision != 0, nullptr, 0, 0.0f, 0, 0, 0, B, s);
+	solve_step(ctx, 0, ctx->d_chamber, ctx->d_nchamber, true, coll, nullptr, 0, 0.0f, 0, 0, 0, B, s);
 }
 static void reset_path(ht_ctx *ctx, const int *flags, int n_unibody, int B, hipStream_t s)
 {
-	ht_prof_scope ps(ctx, "reset_path", s);
+	ht_prof_scope ps(ctx, "reset_path", s, true);
 	ht_launch_scratch(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_analysis, ctx->d_cams, flags, B, s);
 	for (int i = 0; i < n_unibody; i++)
 	{
@@ -78,19 +91,19 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		ht_launch_set_pose(ctx->d_state[1], d_start, nb, B, 1, s);
 		ht_launch_clear_flags(ctx->d_prev_err, ctx->d_initializing, B, s);
 	}
-	{ ht_prof_scope ps(ctx, "prepare", s); ht_launch_prepare(d_depth, ctx->d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, ctx->d_pts, ctx->d_npts, B, s); }
+	{ ht_prof_scope ps(ctx, "prepare", s, true); ht_launch_prepare(d_depth, ctx->d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, ctx->d_pts, ctx->d_npts, B, s); }
 	float *cnn_out = d_cnn_out ? d_cnn_out : ctx->d_cnn_out;
 	{
-		ht_prof_scope ps(ctx, "cnn", s);
+		ht_prof_scope ps(ctx, "cnn", s, true);
 		ht_launch_cnn(ctx->cnnw, ctx->d_cnn_in, ctx->d_act1, ctx->d_act2, ctx->d_act3, ctx->d_logits, B, s);
 		ht_launch_softmax_decode(ctx->d_logits, cnn_out, ctx->d_cams, ctx->d_analysis, 1, B, s);
 	}
 	ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, s);                       // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757
-	{ ht_prof_scope ps(ctx, "fit_error", s); ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, ctx->d_cams, p.bone_sum_error_scale, ctx->d_err_old, B, s); }
+	{ ht_prof_scope ps(ctx, "fit_error", s, true); ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, ctx->d_cams, p.bone_sum_error_scale, ctx->d_err_old, B, s); }
 	ht_launch_decide_reset(ctx->d_err_old, p.full_reset_on_error, p.angles_only, ctx->d_flags, B, s);
 	reset_path(ctx, ctx->d_flags, p.steps_unibody, B, s);
 	multistep(ctx, B, s);
-	{ ht_prof_scope ps(ctx, "fit_error", s); ht_launch_fit_error(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, d_depth, ctx->d_cams, p.bone_sum_error_scale, ctx->d_err_new, B, s); }
+	{ ht_prof_scope ps(ctx, "fit_error", s, true); ht_launch_fit_error(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, d_depth, ctx->d_cams, p.bone_sum_error_scale, ctx->d_err_new, B, s); }
 	ht_launch_accept(ctx->d_state[0], ctx->d_state[1], ctx->d_err_old, ctx->d_err_new, ctx->d_npts, ctx->d_prev_err, ctx->d_initializing, ctx->d_accepted, nb, B, p, s);
 	for (int i = 0; !p.angles_only && i < p.mainthreadpasses; i++) main_pass(ctx, B, s);
 	ht_launch_output(ctx->model, ctx->d_state[0], ctx->d_npts, ctx->d_initializing, p.min_point_num, d_poses_out, B, s);

@@ -155,8 +155,10 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 	const float minv = M.ub_massinv;
 	const m3 tinv = GM(M.ub_tinv);
 	const m3 Iinv = world_inertia(ubq, tinv, minv);
-	float *scr = scratch + (size_t)b * scratch_stride * 12;
-	for (int i = lane; i < n; i += 64)     // re-express every cloud row on the proxy body and pre-compute (handtrack.h:457-462)
+	(void)scratch; (void)scratch_stride;
+	__shared__ __attribute__((aligned(16))) float urow[HT_MAXPTS / 4][12];      // rows of this solve (<= 256: every 4th of <= 1024 points)
+	const int nr = n < HT_MAXPTS / 4 ? n : HT_MAXPTS / 4;
+	for (int i = lane; i < nr; i += 64)     // re-express every cloud row on the proxy body and pre-compute (handtrack.h:457-462)
 	{
 		const float *r = rows + ((size_t)b * HT_MAXPTS + i) * HT_ROW;
 		const int rb1 = (int)r[1];
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 		const v3 nrm = G3(r + 8);
 		const v3 r1 = qrot(ubq, p1);
 		const float impulsed = minv + dot(cross(mul(Iinv, cross(r1, nrm)), r1), nrm);
-		float4 *o = reinterpret_cast<float4 *>(scr + (size_t)i * 12);
+		float4 *o = reinterpret_cast<float4 *>(&urow[i][0]);
 		o[0] = make_float4(r1.x, r1.y, r1.z, nrm.x);
 		o[1] = make_float4(nrm.y, nrm.z, r[11] / dt, r[12]);
 		o[2] = make_float4(r[13] * dt, r[14] * dt, impulsed, 0.0f);
@@ -180,10 +182,12 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 		for (int sweep = 0; sweep < total; sweep++)
 		{
 			const bool post = sweep >= ph.iterations;
-			for (int k = 0; k < n; k++)
+			const float4 *c = reinterpret_cast<const float4 *>(&urow[0][0]);
+			float4 c0 = c[0], c1 = c[1], c2 = c[2];
+			for (int k = 0; k < nr; k++)
 			{
-				const float4 *c = reinterpret_cast<const float4 *>(scr + (size_t)k * 12);
-				const float4 c0 = c[0], c1 = c[1], c2 = c[2];
+				float4 n0 = c0, n1 = c1, n2 = c2;
+				if (k + 1 < nr) { n0 = c[3 * (k + 1)]; n1 = c[3 * (k + 1) + 1]; n2 = c[3 * (k + 1) + 2]; }      // prefetch the next row
 				const v3 r1 = V3(c0.x, c0.y, c0.z), nrm = V3(c0.w, c1.x, c1.y);
 				const float ts = post ? fmin_std(c1.z, c1.w) : c1.z;
 				const v3 v1 = cross(mul(Iinv, ang), r1) + lin * minv;
@@ -193,7 +197,8 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 				impulse = fmax_std(c2.x - c2.w, impulse);
 				const v3 imp = nrm * impulse;
 				lin = lin + imp; ang = ang + cross(r1, imp);
-				scr[(size_t)k * 12 + 11] = c2.w + impulse;
+				urow[k][11] = c2.w + impulse;
+				c0 = n0; c1 = n1; c2 = n2;
 			}
 			if (sweep + 1 == ph.iterations)
 			{

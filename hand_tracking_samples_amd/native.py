@@ -240,8 +240,9 @@ class Context:
         self._chk(self.L.ht_stage_scratch_unibody(self.h, _f(analysis), B, n_unibody))
 
     # -- profiling
-    def profile_enable(self, on=True):
-        self._chk(self.L.ht_profile_enable(self.h, int(on)))
+    def profile_enable(self, level=1):
+        """0 off; 1 bracket only the dominant kernel (k_solve) with HIP events; 2 bracket every phase (serialises the side streams)."""
+        self._chk(self.L.ht_profile_enable(self.h, int(level)))
 
     def profile_read(self, reset=True):
         names = C.create_string_buffer(64 * 48); ms = np.zeros(64, np.float32); n = np.zeros(64, np.int32); k = C.c_int()

@@ -128,7 +128,9 @@ int ht_stage_fit(ht_ctx *ctx, int B);
 int ht_stage_multistep(ht_ctx *ctx, const float *analysis, int B);
 int ht_stage_scratch_unibody(ht_ctx *ctx, const float *analysis, int B, int n_unibody);
 
-/* ---- timing hooks for bench.py: HIP-event time (ms) of the dominant kernels accumulated since the last reset ----- */
+/* ---- timing hooks for bench.py: HIP-event time (ms) per named phase accumulated since the last reset.
+ * on = 1: only the dominant kernel ("solve") is bracketed (negligible perturbation, used inside the timed region);
+ * on = 2: every phase is bracketed and the side streams are serialised (phase table). ----- */
 int ht_profile_enable(ht_ctx *ctx, int on);
 int ht_profile_read(ht_ctx *ctx, int reset, int max_entries, char *names, int name_stride, float *total_ms, int *launches, int *n_entries);
 
