@@ -327,7 +327,7 @@ int ht_alloc_buffers(ht_ctx *ctx)
 	A(d_logits, B * HT_CNN_OUT); A(d_cnn_out, B * HT_CNN_OUT); A(d_analysis, B * HT_ANALYSIS);
 	A(d_pts, B * HT_MAXPTS); A(d_npts, B);
 	A(d_state[0], B * nb * HT_STATE_STRIDE); A(d_state[1], B * nb * HT_STATE_STRIDE);
-	A(d_prev_err, B); A(d_initializing, B); A(d_err_old, B); A(d_err_new, B); A(d_flags, B);
+	A(d_prev_err, B); A(d_initializing, B); A(d_err_old, B); A(d_err_new, B); A(d_flags, B); A(d_nflags, B);
 	A(d_rows, B * HT_MAXPTS * HT_ROW); A(d_nrows, B);
 	A(d_chamber, B * 5 * nb * HT_ROW); A(d_nchamber, B); A(d_accepted, B);
 	A(d_contacts, B * HT_MAXCONTACT * HT_CONTACT); A(d_ncontacts, B); A(d_epa_ws, ht_contacts_workspace_bytes((int)B));

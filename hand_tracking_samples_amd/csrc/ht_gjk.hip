@@ -420,7 +420,7 @@ __global__ __launch_bounds__(64 * GJK_FRAMES) void k_contacts(ht_model_dev M, co
 		P[lane][7] = M.bodyc[lane * HT_BC + HT_BC_RADIUS];
 	}
 	__syncthreads();
-	if (!live) { if (b < B && lane == 0) ncontacts[b] = 0; return; }
+	if (!live) return;      // frames outside the active set keep whatever another launch produced for them
 	const int npairs = M.nb * (M.nb - 1) / 2;
 	// broad phase in the reference's pair order (physics.h:453-457), compacted with a ballot; pair index -> (i, j), i < j, row-major
 	int ncand = 0;

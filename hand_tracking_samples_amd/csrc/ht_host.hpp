@@ -31,7 +31,7 @@ struct ht_ctx
 	float4 *d_pts = nullptr; int *d_npts = nullptr;
 	float *d_state[2] = { nullptr, nullptr };      // [B][nb][HT_STATE_STRIDE]: 0 handmodel, 1 othermodel
 	float *d_prev_err = nullptr; int *d_initializing = nullptr;
-	float *d_err_old = nullptr, *d_err_new = nullptr; int *d_flags = nullptr;
+	float *d_err_old = nullptr, *d_err_new = nullptr; int *d_flags = nullptr, *d_nflags = nullptr;
 	float *d_rows = nullptr; int *d_nrows = nullptr;            // cloud rows [B][HT_MAXPTS][HT_ROW]
 	float *d_chamber = nullptr; int *d_nchamber = nullptr;      // [B][5*nb][HT_ROW]
 	int *d_accepted = nullptr;

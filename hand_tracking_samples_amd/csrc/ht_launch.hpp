@@ -25,7 +25,7 @@ void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solv
 void ht_launch_set_pose(float *state, const float *src, int nb, int n, int mode, hipStream_t s);
 void ht_launch_get_state(const float *state, float *dst, int nb, int n, hipStream_t s);
 void ht_launch_clear_flags(float *prev_err, int *initializing, int n, hipStream_t s);
-void ht_launch_decide_reset(const float *err_old, float thr, int angles_only, int *flags, int n, hipStream_t s);
+void ht_launch_decide_reset(const float *err_old, float thr, int angles_only, int *flags, int *nflags, int n, hipStream_t s);
 void ht_launch_scratch(const ht_model_dev &M, float *state, const float4 *pts, const int *npts, const float *analysis, const float *cams, const int *flags, int B, hipStream_t s);
 void ht_launch_unibody(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float *rows, const int *nrows, const int *flags, float *scratch, int scratch_stride, int B, hipStream_t s);
 void ht_launch_accept(float *hand, const float *other, const float *err_old, const float *err_new, const int *npts, float *prev_err, int *initializing, int *accepted, int nb, int n, const ht_params &p, hipStream_t s);

@@ -35,10 +35,11 @@ static void fork(ht_ctx *ctx, hipStream_t s) { (void)hipEventRecord(ctx->ev_fork
 static void join(ht_ctx *ctx, hipStream_t s, int n) { for (int i = 0; i < n; i++) { (void)hipEventRecord(ctx->ev_join[i], ctx->side[i]); (void)hipStreamWaitEvent(s, ctx->ev_join[i], 0); } }
 
 // HandTracker::MultiStepSim on othermodel (handtrack.h:642-690)
-static void multistep(ht_ctx *ctx, int B, hipStream_t s)
+// `first_active`: when given, step 0 only touches the frames whose flag is set (the others did it already, see run_update)
+static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int to_step = 1 << 30, const int *active = nullptr)
 {
 	const ht_params &p = ctx->par;
-	for (int st = 0; st < p.steps; st++)
+	for (int st = from_step; st < p.steps && st < to_step; st++)
 	{
 		const bool angles = (st < p.steps_keyangles) || p.angles_only;
 		const bool rays = (st < p.steps_keypoints) && !p.angles_only;
@@ -46,11 +47,11 @@ static void multistep(ht_ctx *ctx, int B, hipStream_t s)
 		const bool coll = ctx->phys.use_collision != 0;
 		const bool par = cloud && coll && !ctx->profile_phases;
 		if (par) fork(ctx, s);
-		if (cloud) { ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, nullptr, 4, 1, 2, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[0] : s); }
-		if (coll) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s); }
+		if (cloud) { ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, active, 4, 1, 2, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[0] : s); }
+		if (coll) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, active, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s); }
 		if (par) join(ctx, s, 1);
 		ht_prof_scope ps(ctx, "solve", s);
-		solve_step(ctx, 1, nullptr, nullptr, cloud, coll, nullptr, angles, st < p.steps_palmangle ? 10000.0f : 0.0f, rays, 1, 1, B, s);
+		solve_step(ctx, 1, nullptr, nullptr, cloud, coll, active, angles, st < p.steps_palmangle ? 10000.0f : 0.0f, rays, 1, 1, B, s);
 	}
 }
 // one main-thread pass of HandTracker::update (handtrack.h:769-780)
@@ -67,9 +68,9 @@ static void main_pass(ht_ctx *ctx, int B, hipStream_t s)
 	ht_prof_scope ps(ctx, "solve", s);
 	solve_step(ctx, 0, ctx->d_chamber, ctx->d_nchamber, true, coll, nullptr, 0, 0.0f, 0, 0, 0, B, s);
 }
-static void reset_path(ht_ctx *ctx, const int *flags, int n_unibody, int B, hipStream_t s)
+static void reset_path(ht_ctx *ctx, const int *flags, int n_unibody, int B, hipStream_t s, hipStream_t prof_stream)
 {
-	ht_prof_scope ps(ctx, "reset_path", s, true);
+	ht_prof_scope ps(ctx, "reset_path", prof_stream, true);
 	ht_launch_scratch(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_analysis, ctx->d_cams, flags, B, s);
 	for (int i = 0; i < n_unibody; i++)
 	{
@@ -100,9 +101,23 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 	}
 	ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, s);                       // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757
 	{ ht_prof_scope ps(ctx, "fit_error", s, true); ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, ctx->d_cams, p.bone_sum_error_scale, ctx->d_err_old, B, s); }
-	ht_launch_decide_reset(ctx->d_err_old, p.full_reset_on_error, p.angles_only, ctx->d_flags, B, s);
-	reset_path(ctx, ctx->d_flags, p.steps_unibody, B, s);
-	multistep(ctx, B, s);
+	ht_launch_decide_reset(ctx->d_err_old, p.full_reset_on_error, p.angles_only, ctx->d_flags, ctx->d_nflags, B, s);
+	if (!ctx->profile_phases && p.steps >= 1 && p.steps_cloudstart >= 1 && !p.angles_only)
+	{
+		// the full-reset path touches few frames but is long (3 sequential single-body solves): it runs on a side stream while step 0 of
+		// MultiStepSim (which uses no cloud rows) proceeds for all other frames; the reset frames then do their step 0 on their own
+		fork(ctx, s);
+		reset_path(ctx, ctx->d_flags, p.steps_unibody, B, ctx->side[0], s);
+		multistep(ctx, B, s, 0, 1, ctx->d_nflags);
+		join(ctx, s, 1);
+		multistep(ctx, B, s, 0, 1, ctx->d_flags);
+		multistep(ctx, B, s, 1);
+	}
+	else
+	{
+		reset_path(ctx, ctx->d_flags, p.steps_unibody, B, s, s);
+		multistep(ctx, B, s);
+	}
 	{ ht_prof_scope ps(ctx, "fit_error", s, true); ht_launch_fit_error(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, d_depth, ctx->d_cams, p.bone_sum_error_scale, ctx->d_err_new, B, s); }
 	ht_launch_accept(ctx->d_state[0], ctx->d_state[1], ctx->d_err_old, ctx->d_err_new, ctx->d_npts, ctx->d_prev_err, ctx->d_initializing, ctx->d_accepted, nb, B, p, s);
 	for (int i = 0; !p.angles_only && i < p.mainthreadpasses; i++) main_pass(ctx, B, s);
@@ -253,7 +268,7 @@ extern "C" int ht_stage_scratch_unibody(ht_ctx *ctx, const float *analysis, int 
 	if (!analysis) return HT_ERR_ARG;
 	hipStream_t s = ctx->stream;
 	HIPCHK(ctx, hipMemcpyAsync(ctx->d_analysis, analysis, (size_t)B * HT_ANALYSIS * sizeof(float), hipMemcpyHostToDevice, s));
-	reset_path(ctx, nullptr, n_unibody, B, s);
+	reset_path(ctx, nullptr, n_unibody, B, s, s);
 	HIPCHK(ctx, hipStreamSynchronize(s));
 	HIPCHK(ctx, hipGetLastError());
 	return HT_OK;

@@ -39,10 +39,10 @@ __global__ void k_clear_flags(float *prev_err, int *initializing, int n)
 	if (i < n) { prev_err[i] = 0.0f; initializing[i] = 0; }
 }
 // flags[b] = angles_only || olderror > full_reset_on_error (handtrack.h:706)
-__global__ void k_decide_reset(const float *__restrict__ err_old, float thr, int angles_only, int *__restrict__ flags, int n)
+__global__ void k_decide_reset(const float *__restrict__ err_old, float thr, int angles_only, int *__restrict__ flags, int *__restrict__ nflags, int n)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) flags[i] = (angles_only || err_old[i] > thr) ? 1 : 0;
+	if (i < n) { const int f = (angles_only || err_old[i] > thr) ? 1 : 0; flags[i] = f; nflags[i] = !f; }
 }
 
 // ---- PoseFromScratch: one wave per flagged frame -----------------------------------------------------------------
@@ -264,7 +264,7 @@ __global__ void k_output(ht_model_dev M, const float *__restrict__ hand, const i
 void ht_launch_set_pose(float *state, const float *src, int nb, int n, int mode, hipStream_t s) { hipLaunchKernelGGL(k_set_pose, dim3((n * nb + 255) / 256), dim3(256), 0, s, state, src, nb, n, mode); }
 void ht_launch_get_state(const float *state, float *dst, int nb, int n, hipStream_t s) { hipLaunchKernelGGL(k_get_state, dim3((n * nb + 255) / 256), dim3(256), 0, s, state, dst, nb, n); }
 void ht_launch_clear_flags(float *prev_err, int *initializing, int n, hipStream_t s) { hipLaunchKernelGGL(k_clear_flags, dim3((n + 255) / 256), dim3(256), 0, s, prev_err, initializing, n); }
-void ht_launch_decide_reset(const float *err_old, float thr, int angles_only, int *flags, int n, hipStream_t s) { hipLaunchKernelGGL(k_decide_reset, dim3((n + 255) / 256), dim3(256), 0, s, err_old, thr, angles_only, flags, n); }
+void ht_launch_decide_reset(const float *err_old, float thr, int angles_only, int *flags, int *nflags, int n, hipStream_t s) { hipLaunchKernelGGL(k_decide_reset, dim3((n + 255) / 256), dim3(256), 0, s, err_old, thr, angles_only, flags, nflags, n); }
 void ht_launch_scratch(const ht_model_dev &M, float *state, const float4 *pts, const int *npts, const float *analysis, const float *cams, const int *flags, int B, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_scratch, dim3(B), dim3(64), 0, s, M, state, pts, npts, analysis, cams, flags);
