@@ -197,8 +197,13 @@ def main():
             per_frame = 2 * ctx.nb * 52 + 64.0 * rows_mean
             avg_ms = phases[dom][0] / phases[dom][1]
             achieved = per_frame * B / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            try:      # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), if present
+                traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["k_solve"]["hbm_bytes_per_launch"]
+            except Exception:
+                pass
             roof = {"kernel": "k_solve", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                    "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": phases[dom][1], "algorithmic_bytes_per_launch": int(per_frame * B),
+                    "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches": phases[dom][1], "algorithmic_bytes_per_launch": int(per_frame * B),
                     "note": "sequential Gauss-Seidel: latency/VALU-bound, not a streaming kernel (SURVEY 8d)"}
         elif dom == "cnn":
             avg_ms = phases[dom][0] / phases[dom][1]
