@@ -80,6 +80,8 @@ struct HandTracker                                                              
 	int steps = 5, steps_keypoints = 3, steps_keyangles = 2, steps_palmangle = 2, steps_cloudstart = 1, steps_unibody = 3;
 	CNN cnn;
 	Image<float> cnn_input; std::vector<float> cnn_output;
+	// the parts of CNNOutputAnalysis that synthetic-tracker.cpp draws (handtrack.h:186,188; synthetic-tracker.cpp:221-222)
+	struct { std::vector<Image<unsigned char>> hmaps; Image<float> vmap; } cnn_output_analysis;
 
 	// model_path: baked model; cnnb_path may be empty: like the reference (handtrack.h:123-126) a missing
 	// weight file is not an error at construction, but update() then fails loudly instead of running on random weights.
@@ -106,6 +108,19 @@ struct HandTracker                                                              
 		                      c.pose.orientation.x, c.pose.orientation.y, c.pose.orientation.z, c.pose.orientation.w };
 		std::vector<float> out((size_t)nb_ * HT_POSE);
 		check(ctx_, ht_update_sync(ctx_, dimage.raster.data(), cam, 1, out.data(), cnn_output.data()));
+		// visualisation members, filled on the host from what the device returned (handtrack.h:700, 225, 236-238)
+		const float dr = drangey - 0.1f;
+		cnn_input = Image<float>(c);
+		for (size_t i = 0; i < dimage.raster.size(); i++) { float v = 1.0f - (dimage.raster[i] * c.depth_scale - 0.1f) / dr; cnn_input.raster[i] = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+		DCamera hcam({ 16, 16 }, { c.focal().x / 4.0f, c.focal().y / 4.0f }, { c.principal().x / 4.0f, c.principal().y / 4.0f }, c.depth_scale, c.pose);
+		cnn_output_analysis.hmaps.clear();
+		for (int m = 0; m < 8; m++)
+		{
+			Image<unsigned char> h(hcam);
+			for (int i = 0; i < 256; i++) { float y = cnn_output[(size_t)256 * m + i] * 255.0f; h.raster[i] = (unsigned char)(y < 0.0f ? 0.0f : (y > 255.0f ? 255.0f : y)); }      // ToGrayScale misc_image.h:169
+			cnn_output_analysis.hmaps.push_back(h);
+		}
+		cnn_output_analysis.vmap = Image<float>(DCamera({ 16, 16 }, { 16.f, 16.f }, { 8.f, 8.f }, c.depth_scale), std::vector<float>(cnn_output.begin() + 2048, cnn_output.end()));
 		std::vector<Pose> pose(nb_);
 		for (int b = 0; b < nb_; b++) { const float *p = &out[(size_t)b * HT_POSE]; pose[b].position = { p[0], p[1], p[2] }; pose[b].orientation = { p[3], p[4], p[5], p[6] }; }
 		return pose;
