@@ -10,30 +10,9 @@
 #include "ht_device.hpp"
 #include "ht_host.hpp"
 #include "ht_launch.hpp"
+#include "ht_model_build.hpp"
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return HT_ERR_HIP; } } while (0)
-
-// ------------------------------------------------------------------------------------------------- HTFX container (baked model)
-struct fx_arr { uint32_t dtype, ndim, dims[4]; std::vector<unsigned char> data; const float *f() const { return (const float *)data.data(); } const int *i() const { return (const int *)data.data(); } };
-static bool fx_load(const char *path, std::map<std::string, fx_arr> &out)
-{
-	FILE *fp = fopen(path, "rb");
-	if (!fp) return false;
-	char magic[8]; uint32_t count;
-	if (fread(magic, 1, 8, fp) != 8 || memcmp(magic, "HTFX0001", 8) || fread(&count, 4, 1, fp) != 1) { fclose(fp); return false; }
-	for (uint32_t i = 0; i < count; i++)
-	{
-		char nm[48]; fx_arr a; uint64_t n;
-		if (fread(nm, 1, 48, fp) != 48 || fread(&a.dtype, 4, 1, fp) != 1 || fread(&a.ndim, 4, 1, fp) != 1 || fread(a.dims, 4, 4, fp) != 4 || fread(&n, 8, 1, fp) != 1) { fclose(fp); return false; }
-		a.data.resize(n);
-		if (n && fread(a.data.data(), 1, n, fp) != n) { fclose(fp); return false; }
-		fseek(fp, (long)((8 - (n & 7)) & 7), SEEK_CUR);
-		nm[47] = 0;
-		out[nm] = std::move(a);
-	}
-	fclose(fp);
-	return true;
-}
 
 // ------------------------------------------------------------------------------------------------- context
 static void default_params(ht_params &p)     // handtrack.h:523-547, physics.h:45-47, physmodel.h:234, handtrack.h:369,450
@@ -62,8 +41,12 @@ template <class T> static int dev_upload(ht_ctx *ctx, T **p, const std::vector<T
 
 static int load_model(ht_ctx *ctx, const char *path)
 {
-	std::map<std::string, fx_arr> fx;
-	if (!fx_load(path, fx)) { ctx->err = std::string("cannot read baked model ") + path; return HT_ERR_IO; }
+	// `path` is either the reference's model JSON (built here, a33) or a model baked earlier with ht_model_bake
+	fx_map fx;
+	char magic[8] = { 0 };
+	{ FILE *fp = fopen(path, "rb"); if (!fp) { ctx->err = std::string("cannot open model ") + path; return HT_ERR_IO; } size_t n = fread(magic, 1, 8, fp); (void)n; fclose(fp); }
+	if (!memcmp(magic, "HTFX0001", 8)) { if (!fx_load(path, fx)) { ctx->err = std::string("cannot read baked model ") + path; return HT_ERR_IO; } }
+	else if (!ht_build_model(path, HT_BUILD_HAND_TWEAKS, fx, ctx->err)) return HT_ERR_IO;
 	auto need = [&](const char *n) -> const fx_arr * { auto it = fx.find(n); if (it == fx.end()) { ctx->err = std::string("model entry missing: ") + n; return nullptr; } return &it->second; };
 	const fx_arr *a;
 	if (!(a = need("nb"))) return HT_ERR_IO; int nb = a->i()[0];
@@ -163,6 +146,13 @@ extern "C" int ht_create(const char *model_path, int max_batch, int device, ht_c
 	if (r) return r;
 	ctx->ready = true;
 	return HT_OK;
+}
+extern "C" int ht_model_bake(const char *json_path, const char *out_path, int flags)
+{
+	if (!json_path || !out_path) return HT_ERR_ARG;
+	fx_map fx; std::string err;
+	if (!ht_build_model(json_path, flags, fx, err)) { fprintf(stderr, "ht_model_bake: %s\n", err.c_str()); return HT_ERR_IO; }
+	return fx_save(out_path, fx) ? HT_OK : HT_ERR_IO;
 }
 extern "C" int ht_destroy(ht_ctx *ctx)
 {

@@ -83,9 +83,11 @@ struct HandTracker                                                              
 	// the parts of CNNOutputAnalysis that synthetic-tracker.cpp draws (handtrack.h:186,188; synthetic-tracker.cpp:221-222)
 	struct { std::vector<Image<unsigned char>> hmaps; Image<float> vmap; } cnn_output_analysis;
 
-	// model_path: baked model; cnnb_path may be empty: like the reference (handtrack.h:123-126) a missing
-	// weight file is not an error at construction, but update() then fails loudly instead of running on random weights.
-	explicit HandTracker(const std::string &model_path, const std::string &cnnb_path = "", int device = 0)
+	// Defaults are the reference's hard-coded asset paths (handtrack.h:349,831): the model JSON is built on the host at
+	// construction like PhysModel + LoadHandModel do; a model baked with ht_model_bake is accepted too.  Like the reference
+	// (handtrack.h:123-126) a missing weight file is not an error at construction, but update() then fails loudly instead
+	// of running on random weights.
+	explicit HandTracker(const std::string &model_path = "../assets/model_hand.json", const std::string &cnnb_path = "../assets/handposedd.cnnb", int device = 0)
 	{
 		int rc = ht_create(model_path.c_str(), 1, device, &ctx_);
 		if (rc != HT_OK) { std::string msg = ctx_ ? ht_last_error(ctx_) : "ht_create failed"; if (ctx_) ht_destroy(ctx_); ctx_ = nullptr; throw std::runtime_error("HandTracker: " + msg); }

@@ -67,12 +67,18 @@ typedef struct ht_params
 
 /* ---- lifecycle --------------------------------------------------------------------------------------------------
  * ht_create      replaces  HandTracker::HandTracker() (handtrack.h:830-839): builds both hand models and the CNN topology.
- *                model_path: a baked model (.htfx, see hand_tracking_samples_amd/model.py) holding what
- *                PhysModel::PhysModel + LoadHandModel compute (physmodel.h:444-475, handtrack.h:347-366).
+ *                model_path: the reference's own model file (assets/model_hand.json: "controlcages" + "joints"), which is
+ *                built on the host exactly as PhysModel::PhysModel + LoadHandModel build it (physmodel.h:444-475,
+ *                handtrack.h:347-366: 2x subdivision, 48-vertex hull, mass properties, planes, ignore lists), or a model
+ *                baked earlier by ht_model_bake (recognised by its "HTFX0001" magic).
  *                max_batch: number of independent tracker slots (frames processed per call).
  * ht_destroy     replaces  HandTracker::~HandTracker() (handtrack.h:841-844). */
 int ht_create(const char *model_path, int max_batch, int device, ht_ctx **out);
 int ht_destroy(ht_ctx *ctx);
+/* ht_model_bake  replaces  PhysModel::PhysModel(const char *jsonfile) (physmodel.h:444-475) and, with flags & 1,
+ *                LoadHandModel()'s post-processing (handtrack.h:350-358).  Host only (no device needed): writes the built
+ *                model as a named-array container that ht_create also accepts. */
+int ht_model_bake(const char *json_path, const char *out_path, int flags);
 const char *ht_last_error(const ht_ctx *ctx);
 int ht_get_params(const ht_ctx *ctx, ht_params *p);
 int ht_set_params(ht_ctx *ctx, const ht_params *p);                    /* replaces HandTracker::load_config / visit_fields (handtrack.h:549-581, 822-828) */

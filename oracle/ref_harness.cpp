@@ -17,6 +17,7 @@
 //
 // Modes:
 //   model  <out.htfx>                              baked 17-bone model (what PhysModel/LoadHandModel build)
+//   modelfile <model.json> <out.htfx>              any PhysModel JSON (absolute path) as PhysModel(const char*) builds it
 //   scan   <animbank.pose> <stride>                workload statistics per animation row
 //   frames <animbank.pose> <first> <stride> <n> <out.htfx>    64x64 frames + cameras + start poses
 //   golden <animbank.pose> <rows,comma> <seed> <fc2gain> <out.htfx>   per-stage goldens
@@ -200,10 +201,8 @@ static std::vector<Pose> unit_of_work(HandTracker &htk, const Image<unsigned sho
 }
 
 // ---- modes ---------------------------------------------------------------------------------------
-static int mode_model(const char *outfn)
+static int dump_model(PhysModel &m, const char *outfn)
 {
-	HandTracker htk;
-	PhysModel &m = htk.handmodel;
 	Out o; if (htfx_open(&o.w, outfn)) return 2;
 	int nb = (int)m.rigidbodies.size(), nj = (int)m.joints.size();
 	o.i32("nb", { nb }); o.i32("nj", { nj });
@@ -248,6 +247,17 @@ static int mode_model(const char *outfn)
 	htfx_close(&o.w);
 	printf("model: %d bodies %d joints -> %s\n", nb, nj, outfn);
 	return 0;
+}
+static int mode_model(const char *outfn)
+{
+	HandTracker htk;
+	return dump_model(htk.handmodel, outfn);
+}
+static int mode_modelfile(const char *jsonfn, const char *outfn)     // any PhysModel JSON, without LoadHandModel's post-processing
+{
+	HandTracker htk;     // sets the physics globals the dump records (handtrack.h:837-838)
+	PhysModel m(jsonfn);
+	return dump_model(m, outfn);
 }
 
 static int mode_scan(const char *bankfn, int stride)
@@ -537,6 +547,7 @@ int main(int argc, char **argv) try
 	for (int i = 2; i < argc; i++) { std::string s = argv[i]; if (s.find('/') != std::string::npos || s.find(".htfx") != std::string::npos || s.find(".pose") != std::string::npos) { char buf[4096]; if (s[0] != '/' && getcwd(buf, sizeof buf)) s = std::string(buf) + "/" + s; } a.push_back(s); }
 	stage_assets();
 	if (mode == "model" && a.size() == 1) return mode_model(a[0].c_str());
+	if (mode == "modelfile" && a.size() == 2) return mode_modelfile(a[0].c_str(), a[1].c_str());
 	if (mode == "scan" && a.size() == 2) return mode_scan(a[0].c_str(), atoi(a[1].c_str()));
 	if (mode == "frames" && a.size() == 5) return mode_frames(a[0].c_str(), atoi(a[1].c_str()), atoi(a[2].c_str()), atoi(a[3].c_str()), a[4].c_str());
 	if (mode == "golden" && a.size() == 5) return mode_golden(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());
