@@ -12,40 +12,83 @@
 //
 // Exact-order parallelism.  The reference applies rows strictly in vector order; two rows commute exactly when they touch disjoint
 // bodies.  (1) Rows with rb0 == NULL touch one body only and form a prefix of the row vector (chamber / landmark-ray rows, then
-// cloud rows): the prefix is stably partitioned by body, pre-computed (lever arm r1 = R*position1, effective mass, limits*dt: all
-// invariant during one PhysicsUpdate) into LDS, and lane b walks the chain of body b with the body's momenta in registers.
+// cloud rows): the prefix is stably partitioned by body and pre-computed (lever arm r1 = R*position1, effective mass, limits*dt: all
+// invariant during one PhysicsUpdate) into LDS; the chains of different bodies run side by side.
 // (2) The two-body tail (joint rows, contact triples; then all angular rows) is list-scheduled: level(row) = 1 + the highest level
-// of an earlier row sharing a body, so conflicting rows keep their order and rows of one level touch disjoint bodies.  Row r lives in
-// the registers of lane r%64; levels run one after the other, the rows of a level in parallel lanes, on LDS-resident body momenta.
-// For the 17-bone hand that is ~24 levels for the 48 joint rows and ~35-45 for the ~70-85 angular rows.
-// Everything is compiled -ffp-contract=off, so the result is the reference's bit for bit except for acos/sin/cos in a few row builders.
+// of an earlier row sharing a body, so conflicting rows keep their order and rows of one level touch disjoint bodies.
+//
+// Lane mapping of a sweep ("quad layout").  A body's momenta live one component per lane in a quad of 4 lanes (x, y, z, spare):
+// every 3-vector operation of the reference is one scalar instruction per lane, cross products and dot products fetch the other
+// components through DPP quad permutes (no LDS, no extra instruction when the permute folds into the consumer), and the scalar part
+// of a row (impulse, clamps) is computed redundantly by the 4 lanes.  Chains: quad q walks body q, then body q+16.  Two-body linear
+// rows: lanes 8p..8p+7 (two quads = the two bodies) take the p-th row of the current level; the sides meet through DPP row shifts.
+// Angular rows stay one row per lane in registers.  The operations per component and their order are those of the reference, so
+// the result is the reference's bit for bit (compiled -ffp-contract=off) except for acos/sin/cos in a few row builders.
+// The division by the (sweep-invariant) effective mass uses the same reciprocal-refinement + residual-correction FMA sequence the
+// compiler emits for an IEEE fp32 division, without the range scaling (operands are far from the exponent limits).
 #include "ht_device.hpp"
 #include "ht_launch.hpp"
 
-#define SROW 12            // floats per pre-computed single-body row: r1[3] n[3] targetspeed tsnobias fmin*dt fmax*dt impulsed impulsesum
-#define CH_CAP 640         // single-body rows kept in LDS (30 KB); the rest of a frame's chain rows stream from the HBM scratch
-#define LSLOTS 3           // two-body linear rows live in registers: row r in lane r%64, slot r/64  (<= 192 rows: 3*nj + 3*contacts)
-#define ASLOTS 2           // angular rows likewise (<= 128 rows)
-#define MAXL2 (64 * LSLOTS)
+#define CROW 12            // floats per single-body row: r1[3] n[3] ts ts_post fmin*dt fmax*dt effmass impulsesum
+#define LROW 16            // floats per two-body linear row: ts ts_post fmin*dt fmax*dt(|mu) effmass impulsesum meta r0[3] r1[3] n[3]
+#define MAXL2 (3 * HT_MAXNJ + 3 * HT_MAXCONTACT)      // two-body linear rows (all live in LDS)
+#define ASLOTS 2           // angular rows live in registers: row r in lane r%64, slot r/64  (<= 128 rows)
 #define MAXA2 (64 * ASLOTS)
+#define POOL_FLOATS 7424   // LDS pool shared by the two-body linear rows (front) and the single-body chain rows (rest; overflow: HBM scratch)
+#define LM_FRIC 0x10000    // meta bits of a two-body linear row: friction row (limits from its contact's normal row, physics.h:292)
+#define LM_NORMAL 0x20000  //                                     normal row of a contact (publishes its impulse sum)
 
 struct lds_t
 {
-	// body state in 16-byte records so that a row update moves it with a few ds_read_b128 / ds_write_b128
+	// body state in 16-byte records: component c of body b is word 4*b + c
 	float4 lin4[HT_MAXNB];                 // xyz linear momentum, w = massinv
 	float4 ang4[HT_MAXNB];                 // xyz angular momentum, w = friction
 	float4 I4[HT_MAXNB][3];                // columns of the world inverse inertia (w unused)
 	float pos[HT_MAXNB][3], q[HT_MAXNB][4];
+	int ccnt[HT_MAXNB], cstart[HT_MAXNB];  // chain of body b: rows [cstart, cstart+ccnt) of the partitioned single-body stream
+	unsigned short lorder[MAXL2];          // two-body linear rows sorted by level
+	unsigned short lstart[MAXL2 + 2];      // level L = lorder[lstart[L] .. lstart[L+1])
+	float cisum[HT_MAXCONTACT];            // impulse sum of each contact's normal row, read by its two friction rows (physics.h:292)
+	int nlev_lin, nlev_ang, nray;
+	// prologue only
 	float jr[HT_MAXNJ][6];                 // joint ranges after HandModelEnhancements
-	float ray[20][HT_ROW]; int nray;
+	float ray[20][HT_ROW];
 	int acount[HT_MAXNJ], aprefix[HT_MAXNJ + 1];
 	unsigned char lrb[MAXL2][2], arb[MAXA2][2];     // body pair of every two-body row (255 = none), for the level schedule
-	unsigned char llev[MAXL2], alev[MAXA2];
-	int nlev_lin, nlev_ang;
+	unsigned short llev[MAXL2]; unsigned char alev[MAXA2];
+	unsigned short lfill[MAXL2 + 2];
 	int lastlev[HT_MAXNB];                 // scratch of the level scheduler
-	float cisum[64];                       // impulse sum of each contact's normal row, read by its two friction rows (physics.h:292)
-	float chain[CH_CAP][SROW];
+	float pool[POOL_FLOATS] __attribute__((aligned(16)));
 };
+
+// ---- DPP helpers (quad layout) -------------------------------------------------------------------
+#define QP_BC0 0x00        // quad_perm:[0,0,0,0]
+#define QP_BC1 0x55        // quad_perm:[1,1,1,1]
+#define QP_BC2 0xAA        // quad_perm:[2,2,2,2]
+#define QP_ROT1 0xC9       // quad_perm:[1,2,0,3]: lane c reads component (c+1)%3
+#define QP_ROT2 0xD2       // quad_perm:[2,0,1,3]: lane c reads component (c+2)%3
+#define DPP_ROW_SHL4 0x104 // lane i reads lane i+4 of its 16-lane row
+#define DPP_ROW_SHR4 0x114 // lane i reads lane i-4
+template <int CTRL> __device__ __forceinline__ float dpp(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true)); }
+// value of the same component held by the other quad of a lane pair (quads 2p and 2p+1)
+__device__ __forceinline__ float pair_swap(float v)
+{
+	int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_SHL4, 0xF, 0x5, false);       // quads 0 and 2 of a row read lane+4
+	t = __builtin_amdgcn_update_dpp(t, __float_as_int(v), DPP_ROW_SHR4, 0xF, 0xA, false);           // quads 1 and 3 read lane-4
+	return __int_as_float(t);
+}
+// x / y as the IEEE fp32 division expands (reciprocal estimate, one Newton step, quotient with two residual corrections)
+__device__ __forceinline__ float div_ieee(float x, float y)
+{
+	float r = __builtin_amdgcn_rcpf(y);
+	const float e = __fmaf_rn(-y, r, 1.0f);
+	r = __fmaf_rn(e, r, r);
+	float q = x * r;
+	float rem = __fmaf_rn(-y, q, x);
+	q = __fmaf_rn(rem, r, q);
+	rem = __fmaf_rn(-y, q, x);
+	return __fmaf_rn(rem, r, q);
+}
 
 __device__ __forceinline__ v3 L3(const float *p) { return V3(p[0], p[1], p[2]); }
 __device__ __forceinline__ v4 L4(const float *p) { return V4(p[0], p[1], p[2], p[3]); }
@@ -135,7 +178,6 @@ __constant__ float FEATURE_OFF[8][3] = { { 0, 0, 0 }, { -0.03f, 0, -0.03f }, { 0
 // ---- two-body row maths ------------------------------------------------------------------------
 __device__ __forceinline__ v3 spin_of(const lds_t &S, int b) { return mul(body_I(S, b), F3(S.ang4[b])); }       // physics.h:126
 // ------------------------------------------------------------------------------------------------- k_solve
-struct lrow { int rb0, rb1; v3 r0, r1, n; float ts, tsnb, fmn, fmx, impulsed, isum; int fm, lev, cidx; };
 struct arow { int rb0, rb1; v3 axis; float targetspin, mn, mx, s2t, torque, mintorque; int lev; };
 
 // row counts of ConstrainAngularRangeW (physics.h:351-393) for given limits, without building the rows
@@ -306,64 +348,66 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	}
 
 	if (a.dbg & 512) return;
-	// ---- two-body linear rows: joints (physmodel.h:328-334) then contacts (physics.h:463-489), each built by its owner lane ----
+	// ---- two-body linear rows: joints (physmodel.h:328-334) then contacts (physics.h:463-489), each built by one lane into its LDS record ----
 	int nc = (a.contacts && ph.use_collision) ? a.ncontacts[b] : 0;
-	if (3 * nj + 3 * nc > MAXL2) nc = (MAXL2 - 3 * nj) / 3;
+	if (nc > HT_MAXCONTACT) nc = HT_MAXCONTACT;
 	const int n2 = 3 * nj + 3 * nc;
-	lrow LR[LSLOTS];
-#pragma unroll
-	for (int s = 0; s < LSLOTS; s++)
+	for (int r = lane; r < n2; r += 64)
 	{
-		const int r = lane + 64 * s;
-		lrow &R = LR[s];
-		R.rb0 = -1; R.rb1 = -1; R.r0 = R.r1 = R.n = V3(0, 0, 0); R.ts = R.tsnb = R.fmn = R.fmx = R.isum = 0; R.impulsed = 1; R.fm = 0; R.lev = 0; R.cidx = 0;
-		if (r < n2)
+		int rb0, rb1, meta = 0;
+		v3 p0, p1, n; float targetdist, tsnb, fmn, fmx;
+		if (r < 3 * nj)
 		{
-			v3 p0, p1, n; float targetdist, tsnb, fmn, fmx;
-			if (r < 3 * nj)
+			const int j = r / 3, ax = r % 3;
+			const float *jc = M.jointc + j * HT_JC;
+			rb0 = (int)jc[HT_JC_RB0]; rb1 = (int)jc[HT_JC_RB1];
+			p0 = L3(jc + HT_JC_P0) - L3(M.bodyc + rb0 * HT_BC + HT_BC_COM); p1 = L3(jc + HT_JC_P1) - L3(M.bodyc + rb1 * HT_BC + HT_BC_COM);
+			const v3 d = anchor_world(S, rb1, p1) - anchor_world(S, rb0, p0);                       // ConstrainPositionNailed physics.h:342-346
+			n = V3(ax == 0 ? 1.0f : 0.0f, ax == 1 ? 1.0f : 0.0f, ax == 2 ? 1.0f : 0.0f);
+			targetdist = ax == 0 ? d.x : ax == 1 ? d.y : d.z; tsnb = 0.0f; fmn = -FLT_MAX; fmx = FLT_MAX;
+		}
+		else
+		{
+			const int ci = (r - 3 * nj) / 3, k = (r - 3 * nj) % 3;
+			const float *c = a.contacts + ((size_t)b * HT_MAXCONTACT + ci) * HT_CONTACT;
+			rb0 = (int)c[0]; rb1 = (int)c[1]; meta = ci << 24;
+			const v3 normal = L3(c + 2), p0w = L3(c + 5), p1w = L3(c + 8);
+			const float separation = c[11];
+			p0 = apply(inverse(body_xf(S, rb0)), p0w); p1 = apply(inverse(body_xf(S, rb1)), p1w);          // PhysContact physics.h:431-432
+			if (k == 0)
 			{
-				const int j = r / 3, ax = r % 3;
-				const float *jc = M.jointc + j * HT_JC;
-				R.rb0 = (int)jc[HT_JC_RB0]; R.rb1 = (int)jc[HT_JC_RB1];
-				p0 = L3(jc + HT_JC_P0) - L3(M.bodyc + R.rb0 * HT_BC + HT_BC_COM); p1 = L3(jc + HT_JC_P1) - L3(M.bodyc + R.rb1 * HT_BC + HT_BC_COM);
-				const v3 d = anchor_world(S, R.rb1, p1) - anchor_world(S, R.rb0, p0);                       // ConstrainPositionNailed physics.h:342-346
-				n = V3(ax == 0 ? 1.0f : 0.0f, ax == 1 ? 1.0f : 0.0f, ax == 2 ? 1.0f : 0.0f);
-				targetdist = ax == 0 ? d.x : ax == 1 ? d.y : d.z; tsnb = 0.0f; fmn = -FLT_MAX; fmx = FLT_MAX;
+				const v3 r0w = p0w - L3(S.pos[rb0]), r1w = p1w - L3(S.pos[rb1]);
+				const v3 v0 = cross(spin_of(S, rb0), r0w) + F3(S.lin4[rb0]) * S.lin4[rb0].w;
+				const v3 v1 = cross(spin_of(S, rb1), r1w) + F3(S.lin4[rb1]) * S.lin4[rb1].w;
+				const v3 v = v0 - v1;
+				const float minsep = ph.driftmax * 0.25f;
+				const float bouncevel = fmax_std(0.0f, (-dot(normal, v) - ph.gravity_len * ph.falltime_to_ballistic) * ph.restitution);
+				n = -normal; targetdist = fmin_std((separation - minsep) * ph.biasfactorpositive, separation); tsnb = -bouncevel; fmn = 0; fmx = FLT_MAX;
+				meta |= LM_NORMAL;
 			}
 			else
 			{
-				const int ci = (r - 3 * nj) / 3, k = (r - 3 * nj) % 3;
-				const float *c = a.contacts + ((size_t)b * HT_MAXCONTACT + ci) * HT_CONTACT;
-				R.rb0 = (int)c[0]; R.rb1 = (int)c[1]; R.cidx = ci;
-				const v3 normal = L3(c + 2), p0w = L3(c + 5), p1w = L3(c + 8);
-				const float separation = c[11];
-				p0 = apply(inverse(body_xf(S, R.rb0)), p0w); p1 = apply(inverse(body_xf(S, R.rb1)), p1w);          // PhysContact physics.h:431-432
-				if (k == 0)
-				{
-					const v3 r0w = p0w - L3(S.pos[R.rb0]), r1w = p1w - L3(S.pos[R.rb1]);
-					const v3 v0 = cross(spin_of(S, R.rb0), r0w) + F3(S.lin4[R.rb0]) * S.lin4[R.rb0].w;
-					const v3 v1 = cross(spin_of(S, R.rb1), r1w) + F3(S.lin4[R.rb1]) * S.lin4[R.rb1].w;
-					const v3 v = v0 - v1;
-					const float minsep = ph.driftmax * 0.25f;
-					const float bouncevel = fmax_std(0.0f, (-dot(normal, v) - ph.gravity_len * ph.falltime_to_ballistic) * ph.restitution);
-					n = -normal; targetdist = fmin_std((separation - minsep) * ph.biasfactorpositive, separation); tsnb = -bouncevel; fmn = 0; fmx = FLT_MAX;
-				}
-				else
-				{
-					v4 q = quat_from_to(V3(0, 0, 1), -normal);
-					n = k == 1 ? qydir(q) : qxdir(q);           // row order: normal, binormal (friction_master -1), tangent (-2)
-					targetdist = 0; tsnb = 0; fmn = 0; fmx = 0; R.fm = -k;
-				}
+				v4 q = quat_from_to(V3(0, 0, 1), -normal);
+				n = k == 1 ? qydir(q) : qxdir(q);           // row order: normal, binormal (friction_master -1), tangent (-2)
+				targetdist = 0; tsnb = 0; fmn = 0;
+				fmx = 0;
+				meta |= LM_FRIC;
 			}
-			R.r0 = qrot(L4(S.q[R.rb0]), p0); R.r1 = qrot(L4(S.q[R.rb1]), p1); R.n = n;
-			R.impulsed = (S.lin4[R.rb0].w + dot(cross(mul(body_I(S, R.rb0), cross(R.r0, n)), R.r0), n)) + (S.lin4[R.rb1].w + dot(cross(mul(body_I(S, R.rb1), cross(R.r1, n)), R.r1), n));
-			R.ts = targetdist / dt; R.tsnb = tsnb; R.fmn = fmin_std(fmn, fmx) * dt; R.fmx = fmax_std(fmn, fmx) * dt; R.isum = 0.0f;
-			S.lrb[r][0] = (unsigned char)R.rb0; S.lrb[r][1] = (unsigned char)R.rb1;
 		}
+		const v3 r0 = qrot(L4(S.q[rb0]), p0), r1 = qrot(L4(S.q[rb1]), p1);
+		const float impulsed = (S.lin4[rb0].w + dot(cross(mul(body_I(S, rb0), cross(r0, n)), r0), n)) + (S.lin4[rb1].w + dot(cross(mul(body_I(S, rb1), cross(r1, n)), r1), n));
+		const float ts = targetdist / dt;
+		float *o = S.pool + r * LROW;
+		o[0] = ts; o[1] = fmin_std(ts, tsnb); o[2] = fmin_std(fmn, fmx) * dt; o[3] = fmax_std(fmn, fmx) * dt; o[4] = impulsed; o[5] = 0.0f;
+		if (meta & LM_FRIC) o[3] = fmax_std(S.ang4[rb0].w, S.ang4[rb1].w);       // mu of physics.h:292; the limits are formed from the master row's impulse every sweep
+		o[6] = __int_as_float(meta | rb0 | (rb1 << 8));
+		o[7] = r0.x; o[8] = r0.y; o[9] = r0.z; o[10] = r1.x; o[11] = r1.y; o[12] = r1.z; o[13] = n.x; o[14] = n.y; o[15] = n.z;
+		S.lrb[r][0] = (unsigned char)rb0; S.lrb[r][1] = (unsigned char)rb1;
 	}
-	if (lane < 64) S.cisum[lane] = 0.0f;
+	for (int i = lane; i < HT_MAXCONTACT; i += 64) S.cisum[i] = 0.0f;
 	__syncthreads();
-	// ---- level schedule (one lane, once per solve): level(row) = 1 + max level of an earlier row sharing a body ----
+	// ---- level schedule (one lane, once per solve): level(row) = 1 + max level of an earlier row sharing a body; linear rows are then
+	//      counting-sorted by level so that the p-th lane pair picks the p-th row of a level ----
 	if (lane == 0)
 	{
 		int *last = S.lastlev;               // LDS, not a private array: dynamic indexing of a private array goes to scratch memory
@@ -373,9 +417,15 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		{
 			const int b0 = S.lrb[r][0], b1 = S.lrb[r][1];
 			int l = (last[b0] > last[b1] ? last[b0] : last[b1]) + 1;
-			last[b0] = l; last[b1] = l; S.llev[r] = (unsigned char)l; if (l > mx) mx = l;
+			last[b0] = l; last[b1] = l; S.llev[r] = (unsigned short)l; if (l > mx) mx = l;
 		}
 		S.nlev_lin = mx;
+		for (int l = 0; l <= mx + 1; l++) S.lfill[l] = 0;
+		for (int r = 0; r < n2; r++) S.lfill[S.llev[r]]++;
+		int acc = 0;
+		for (int l = 1; l <= mx; l++) { S.lstart[l] = (unsigned short)acc; acc += S.lfill[l]; S.lfill[l] = 0; }
+		S.lstart[mx + 1] = (unsigned short)acc;
+		for (int r = 0; r < n2; r++) { const int l = S.llev[r]; S.lorder[S.lstart[l] + S.lfill[l]] = (unsigned short)r; S.lfill[l]++; }
 		for (int k = 0; k < nb; k++) last[k] = 0;
 		mx = 0;
 		for (int r = 0; r < na; r++)
@@ -391,18 +441,19 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	}
 	__syncthreads();
 #pragma unroll
-	for (int s = 0; s < LSLOTS; s++) if (lane + 64 * s < n2) LR[s].lev = S.llev[lane + 64 * s];
-#pragma unroll
 	for (int s = 0; s < ASLOTS; s++) if (lane + 64 * s < na) AR[s].lev = S.alev[lane + 64 * s];
 	const int nlev_lin = S.nlev_lin, nlev_ang = S.nlev_ang;
 	if (a.dbg & 64) return;
 
-	// ---- single-body prefix: [ray rows | chamber rows] then cloud rows; stable partition by body + pre-compute -> LDS (overflow: HBM) ----
+	// ---- single-body prefix: [ray rows | chamber rows] then cloud rows; stable partition by body + pre-compute -> LDS pool (overflow: HBM) ----
 	const int npre_g = a.rows_pre ? a.n_pre[b] : 0;
 	const int npre = a.ray_rows ? S.nray : npre_g;
 	const int ncl = a.rows_cloud ? a.n_cloud[b] : 0;
 	const int n1 = npre + ncl;
-	float *scr = a.scratch + (size_t)b * a.scratch_stride * SROW;
+	float *const chain = S.pool + n2 * LROW;                      // chain rows follow the two-body rows in the pool
+	int chcap = (POOL_FLOATS - n2 * LROW) / CROW;                 // rows that fit in LDS; the rest stream from the HBM scratch
+	if (chcap < 0) chcap = 0;
+	float *scr = a.scratch + (size_t)b * a.scratch_stride * CROW;
 	auto row_ptr = [&](int i) -> const float * {
 		if (i < npre) return a.ray_rows ? S.ray[i] : a.rows_pre + ((size_t)b * a.pre_stride + i) * HT_ROW;
 		return a.rows_cloud + ((size_t)b * HT_MAXPTS + (i - npre)) * HT_ROW;
@@ -426,6 +477,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 #pragma unroll
 	for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(mystart, o); if (lane >= o) mystart += v; }
 	mystart -= mycnt;
+	if (lane < HT_MAXNB) { S.ccnt[lane] = (a.dbg & 1) ? 0 : mycnt; S.cstart[lane] = mystart; }
 	int myrun = 0;
 	for (int base = 0; base < n1; base += 64)          // pass B: placement in stable order + pre-compute
 	{
@@ -449,9 +501,10 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			const v3 p1 = L3(r + 5), n = L3(r + 8);
 			const v3 r1 = qrot(L4(S.q[body]), p1);
 			const float impulsed = S.lin4[body].w + dot(cross(mul(body_I(S, body), cross(r1, n)), r1), n);       // 0 + (...) for the NULL side
-			const float4 o0 = make_float4(r1.x, r1.y, r1.z, n.x), o1 = make_float4(n.y, n.z, r[11] / dt, r[12]), o2 = make_float4(r[13] * dt, r[14] * dt, impulsed, 0.0f);
-			if (dst < CH_CAP) { float4 *o = reinterpret_cast<float4 *>(&S.chain[dst][0]); o[0] = o0; o[1] = o1; o[2] = o2; }
-			else { float4 *o = reinterpret_cast<float4 *>(scr + (size_t)dst * SROW); o[0] = o0; o[1] = o1; o[2] = o2; }
+			const float ts = r[11] / dt;
+			const float4 o0 = make_float4(r1.x, r1.y, r1.z, n.x), o1 = make_float4(n.y, n.z, ts, fmin_std(ts, r[12])), o2 = make_float4(r[13] * dt, r[14] * dt, impulsed, 0.0f);
+			if (dst < chcap) { float4 *ol = reinterpret_cast<float4 *>(chain + dst * CROW); ol[0] = o0; ol[1] = o1; ol[2] = o2; }
+			else { float4 *og = reinterpret_cast<float4 *>(scr + (size_t)dst * CROW); og[0] = o0; og[1] = o1; og[2] = o2; }
 		}
 	}
 	__syncthreads();
@@ -460,87 +513,112 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	// ---- Gauss-Seidel sweeps ----
 	v3 pos_next = V3(0, 0, 0); v4 q_next = V4(0, 0, 0, 1);
 	const int total_sweeps = ph.iterations + ph.iterations_post;
+	const int quad = lane >> 2, c = lane & 3, cc = c < 3 ? c : 2;         // lane 3 of a quad shadows component z; its vector results are never stored
+	const int c1 = (cc + 1) % 3, c2 = (cc + 2) % 3;
+	const int side = quad & 1;                                            // two-body rows: even quad = rb0, odd quad = rb1
+	const int sidesign = side ? 0 : (int)0x80000000;                      // rb0 receives -impulse, and contributes -v0 to v1 - v0
+	float *const lin_w = reinterpret_cast<float *>(S.lin4), *const ang_w = reinterpret_cast<float *>(S.ang4), *const I_w = reinterpret_cast<float *>(S.I4);
 	for (int sweep = 0; sweep < total_sweeps; sweep++)
 	{
 		const bool post = sweep >= ph.iterations;
-		// (1) chains: lane b applies the single-body rows of body b in order, momenta in registers.
-		//     Rows [mystart, mystart+mycnt) are contiguous: the part below CH_CAP is read with LDS instructions, the rest from HBM scratch.
-		if (lane < nb && mycnt > 0 && !(a.dbg & 1))
+		const int tsoff = post ? 1 : 0;                                   // RemoveBias (physics.h:288): ts_post = min(ts, ts_nobias) was stored next to ts
+		// (1) chains: quad q applies the single-body rows of body q (then q+16) in order; momenta, inertia row and mass stay in registers
+		for (int half = 0; half * 16 < nb; half++)
 		{
-			const float4 lin0 = S.lin4[lane], ang0 = S.ang4[lane];
-			v3 lin = F3(lin0), ang = F3(ang0);
-			const m3 I = body_I(S, lane);
-			const float minv = lin0.w;
-			auto apply_row = [&](const float4 c0, const float4 c1, const float4 c2) -> float {
-				const v3 r1 = V3(c0.x, c0.y, c0.z), n = V3(c0.w, c1.x, c1.y);
-				const float ts = post ? fmin_std(c1.z, c1.w) : c1.z;                      // RemoveBias physics.h:288
-				const v3 v1 = cross(mul(I, ang), r1) + lin * minv;
-				const float vn = dot(v1, n);
-				const float impulsen = -ts - vn;
-				float impulse = impulsen / c2.z;
-				impulse = fmin_std(c2.y - c2.w, impulse);
-				impulse = fmax_std(c2.x - c2.w, impulse);
-				const v3 imp = n * impulse;
-				lin = lin + imp; ang = ang + cross(r1, imp);
-				return c2.w + impulse;
-			};
-			const int nl = (mystart + mycnt <= CH_CAP) ? mycnt : (mystart >= CH_CAP ? 0 : CH_CAP - mystart);
-			if (nl > 0)
+			const int body = quad + 16 * half;
+			const bool has = body < nb;
+			const int cnt = has ? S.ccnt[body] : 0, start = has ? S.cstart[body] : 0;
+			if (cnt > 0)
 			{
-				float4 *rp = reinterpret_cast<float4 *>(&S.chain[mystart][0]);
-				float4 c0 = rp[0], c1 = rp[1], c2 = rp[2];
-				for (int k = 0; k < nl; k++)
+				float l = lin_w[4 * body + cc], av = ang_w[4 * body + cc];
+				const float minv = lin_w[4 * body + 3];
+				const float Ix = I_w[12 * body + cc], Iy = I_w[12 * body + 4 + cc], Iz = I_w[12 * body + 8 + cc];
+				// one LimitLinear::Iter (physics.h:289-307) on this body; ra = r1[c+1], rb = r1[c+2], n = normal[c]
+				auto row_step = [&](float ra, float rb, float n, float ts, float fmn, float fmx, float effmass, float isum) -> float {
+					const float w = (Ix * dpp<QP_BC0>(av) + Iy * dpp<QP_BC1>(av)) + Iz * dpp<QP_BC2>(av);      // (Iinv * angular_momentum)[c]
+					const float v1 = (dpp<QP_ROT1>(w) * rb - dpp<QP_ROT2>(w) * ra) + l * minv;                 // (cross(spin, r1) + lin*massinv)[c]
+					const float p = v1 * n;
+					const float vn = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);
+					const float impulsen = -ts - vn;
+					float impulse = div_ieee(impulsen, effmass);
+					impulse = fmin_std(fmx - isum, impulse);
+					impulse = fmax_std(fmn - isum, impulse);
+					const float imp = n * impulse;
+					l = l + imp;
+					av = av + (ra * dpp<QP_ROT2>(imp) - rb * dpp<QP_ROT1>(imp));                                 // cross(r1, imp)[c]
+					return isum + impulse;
+				};
+				const int nl = (start + cnt <= chcap) ? cnt : (start >= chcap ? 0 : chcap - start);
+				if (nl > 0)
 				{
-					float4 n0 = c0, n1 = c1, n2 = c2;
-					if (k + 1 < nl) { n0 = rp[3 * (k + 1)]; n1 = rp[3 * (k + 1) + 1]; n2 = rp[3 * (k + 1) + 2]; }      // prefetch the next row
-					const float isum = apply_row(c0, c1, c2);
-					S.chain[mystart + k][11] = isum;
-					c0 = n0; c1 = n1; c2 = n2;
+					float *rp = chain + start * CROW;
+					float ra = rp[c1], rb = rp[c2], n = rp[3 + cc], ts = rp[6 + tsoff];
+					float4 t = *reinterpret_cast<const float4 *>(rp + 8);
+					for (int k = 0; k < nl; k++)
+					{
+						float *np = rp + ((k + 1 < nl) ? CROW : 0);                                      // prefetch the next row
+						const float nra = np[c1], nrb = np[c2], nn = np[3 + cc], nts = np[6 + tsoff];
+						const float4 nt = *reinterpret_cast<const float4 *>(np + 8);
+						const float isum = row_step(ra, rb, n, ts, t.x, t.y, t.z, t.w);
+						if (c == 3) rp[11] = isum;
+						rp = np; ra = nra; rb = nrb; n = nn; ts = nts; t = nt;
+					}
 				}
+				for (int k = nl; k < cnt; k++)
+				{
+					float *rp = scr + (size_t)(start + k) * CROW;
+					const float4 t = *reinterpret_cast<const float4 *>(rp + 8);
+					const float isum = row_step(rp[c1], rp[c2], rp[3 + cc], rp[6 + tsoff], t.x, t.y, t.z, t.w);
+					if (c == 3) rp[11] = isum;
+				}
+				if (c < 3) { lin_w[4 * body + c] = l; ang_w[4 * body + c] = av; }
 			}
-			for (int k = nl; k < mycnt; k++)
-			{
-				float4 *rp = reinterpret_cast<float4 *>(scr + (size_t)(mystart + k) * SROW);
-				const float isum = apply_row(rp[0], rp[1], rp[2]);
-				scr[(size_t)(mystart + k) * SROW + 11] = isum;
-			}
-			S.lin4[lane] = make_float4(lin.x, lin.y, lin.z, lin0.w); S.ang4[lane] = make_float4(ang.x, ang.y, ang.z, ang0.w);
 		}
-		__syncthreads();
-		// (2) two-body linear rows, level by level (LimitLinear::Iter physics.h:289-307)
+		__builtin_amdgcn_wave_barrier();
+		// (2) two-body linear rows, level by level (LimitLinear::Iter physics.h:289-307): lane pair p takes the p-th row of the level
 		for (int L = 1; L <= ((a.dbg & 2) ? 0 : nlev_lin); L++)
 		{
-#pragma unroll
-			for (int s = 0; s < LSLOTS; s++)
+			for (int idx = S.lstart[L] + (lane >> 3); idx < S.lstart[L + 1]; idx += 8)
 			{
-				lrow &R = LR[s];
-				if (R.lev == L)
+				float *R = S.pool + (int)S.lorder[idx] * LROW;
+				const int meta = __float_as_int(R[6]);
+				const int body = side ? ((meta >> 8) & 255) : (meta & 255);
+				const float *rv = R + 7 + 3 * side;
+				const float ra = rv[c1], rb = rv[c2], n = R[13 + cc];
+				const float ts = R[tsoff], effmass = R[4], isum = R[5];
+				float fmn = R[2], fmx = R[3];
+				const float l = lin_w[4 * body + cc], av = ang_w[4 * body + cc], minv = lin_w[4 * body + 3];
+				const float Ix = I_w[12 * body + cc], Iy = I_w[12 * body + 4 + cc], Iz = I_w[12 * body + 8 + cc];
+				if (meta & LM_FRIC)
 				{
-					const float4 L0 = S.lin4[R.rb0], A0 = S.ang4[R.rb0], L1 = S.lin4[R.rb1], A1 = S.ang4[R.rb1];
-					float fmn = R.fmn, fmx = R.fmx;
-					if (R.fm)
-					{
-						const float master = S.cisum[R.cidx];
-						const float lim = fmax_std(A0.w, A1.w) * master / dt;       // physics.h:292
-						fmx = lim * dt; fmn = (-lim) * dt;
-					}
-					const float ts = post ? fmin_std(R.ts, R.tsnb) : R.ts;
-					const v3 l0 = F3(L0), a0 = F3(A0), l1 = F3(L1), a1 = F3(A1);
-					const v3 v0 = cross(mul(body_I(S, R.rb0), a0), R.r0) + l0 * L0.w;
-					const v3 v1 = cross(mul(body_I(S, R.rb1), a1), R.r1) + l1 * L1.w;
-					const float vn = dot(v1 - v0, R.n);
-					const float impulsen = -ts - vn;
-					float impulse = impulsen / R.impulsed;
-					impulse = fmin_std(fmx - R.isum, impulse);
-					impulse = fmax_std(fmn - R.isum, impulse);
-					{ const v3 imp = R.n * -impulse; const v3 nl = l0 + imp, na = a0 + cross(R.r0, imp); S.lin4[R.rb0] = make_float4(nl.x, nl.y, nl.z, L0.w); S.ang4[R.rb0] = make_float4(na.x, na.y, na.z, A0.w); }
-					{ const v3 imp = R.n * impulse; const v3 nl = l1 + imp, na = a1 + cross(R.r1, imp); S.lin4[R.rb1] = make_float4(nl.x, nl.y, nl.z, L1.w); S.ang4[R.rb1] = make_float4(na.x, na.y, na.z, A1.w); }
-					R.isum = R.isum + impulse;
-					if (lane + 64 * s >= 3 * nj && R.fm == 0) S.cisum[R.cidx] = R.isum;
+					const float master = S.cisum[(meta >> 24) & 255];
+					const float lim = fmx * master / dt;       // physics.h:292 (fmx slot holds max(friction0, friction1))
+					fmx = lim * dt; fmn = (-lim) * dt;
+				}
+				const float w = (Ix * dpp<QP_BC0>(av) + Iy * dpp<QP_BC1>(av)) + Iz * dpp<QP_BC2>(av);
+				const float v = (dpp<QP_ROT1>(w) * rb - dpp<QP_ROT2>(w) * ra) + l * minv;                     // velocity of this side's anchor
+				const float u = __int_as_float(__float_as_int(v) ^ sidesign);                                 // rb1 side: v1, rb0 side: -v0
+				const float d = u + pair_swap(u);                                                              // (v1 - v0)[c] on both sides (v1 + -v0)
+				const float p = d * n;
+				const float vn = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);
+				const float impulsen = -ts - vn;
+				float impulse = div_ieee(impulsen, effmass);
+				impulse = fmin_std(fmx - isum, impulse);
+				impulse = fmax_std(fmn - isum, impulse);
+				const float imp = n * __int_as_float(__float_as_int(impulse) ^ sidesign);                      // rb0: n * -impulse, rb1: n * impulse
+				const float ln = l + imp;
+				const float an = av + (ra * dpp<QP_ROT2>(imp) - rb * dpp<QP_ROT1>(imp));
+				if (c < 3) { lin_w[4 * body + c] = ln; ang_w[4 * body + c] = an; }
+				else if (side == 0)
+				{
+					const float ns = isum + impulse;
+					R[5] = ns;
+					if (meta & LM_NORMAL) S.cisum[(meta >> 24) & 255] = ns;
 				}
 			}
-			__syncthreads();
+			__builtin_amdgcn_wave_barrier();
 		}
+		__syncthreads();
 		// (3) angular rows, level by level (LimitAngular::Iter physics.h:251-265)
 		for (int L = 1; L <= ((a.dbg & 4) ? 0 : nlev_ang); L++)
 		{

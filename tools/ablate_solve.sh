@@ -1,0 +1,10 @@
+# Times bench.py with parts of k_solve skipped (HT_DEBUG_SKIP bits, see csrc/ht_solver.hip); results are NOT valid poses.
+mkdir -p gpurun_out; rm -f gpurun_out/abl.log
+for d in 0 256 512 64 128 1 2 4 7; do
+  HT_DEBUG_SKIP=$d python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+import sys,json
+j=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('dbg',$d,'ms/step',j['ms_per_step'],'solve ms/step',j['phase_ms_per_step'].get('solve'))
+" >> gpurun_out/abl.log || exit 1
+done
+cat gpurun_out/abl.log
