@@ -29,7 +29,7 @@
 #include "ht_device.hpp"
 #include "ht_launch.hpp"
 
-#define CROW 12            // floats per single-body row: r1[3] n[3] ts ts_post fmin*dt fmax*dt effmass impulsesum
+#define CROW 12            // floats per single-body row: r1[3] ts | n[3] ts_post | fmin*dt fmax*dt effmass impulsesum
 #define LROW 16            // floats per two-body linear row: ts ts_post fmin*dt fmax*dt(|mu) effmass impulsesum meta r0[3] r1[3] n[3]
 #define MAXL2 (3 * HT_MAXNJ + 3 * HT_MAXCONTACT)      // two-body linear rows (all live in LDS)
 #define ASLOTS 2           // angular rows live in registers: row r in lane r%64, slot r/64  (<= 128 rows)
@@ -65,6 +65,7 @@ struct lds_t
 #define QP_BC0 0x00        // quad_perm:[0,0,0,0]
 #define QP_BC1 0x55        // quad_perm:[1,1,1,1]
 #define QP_BC2 0xAA        // quad_perm:[2,2,2,2]
+#define QP_BC3 0xFF        // quad_perm:[3,3,3,3]
 #define QP_ROT1 0xC9       // quad_perm:[1,2,0,3]: lane c reads component (c+1)%3
 #define QP_ROT2 0xD2       // quad_perm:[2,0,1,3]: lane c reads component (c+2)%3
 #define DPP_ROW_SHL4 0x104 // lane i reads lane i+4 of its 16-lane row
@@ -77,6 +78,9 @@ __device__ __forceinline__ float pair_swap(float v)
 	t = __builtin_amdgcn_update_dpp(t, __float_as_int(v), DPP_ROW_SHR4, 0xF, 0xA, false);           // quads 1 and 3 read lane-4
 	return __int_as_float(t);
 }
+// max(lo, min(hi, x)) for lo <= hi in one instruction; equals the reference's std::min/std::max pair except for the sign of a zero
+// result and NaN operands (a NaN impulse ends in the SanityCheck reset either way)
+__device__ __forceinline__ float clamp_med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 // x / y as the IEEE fp32 division expands (reciprocal estimate, one Newton step, quotient with two residual corrections)
 __device__ __forceinline__ float div_ieee(float x, float y)
 {
@@ -451,7 +455,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	const int ncl = a.rows_cloud ? a.n_cloud[b] : 0;
 	const int n1 = npre + ncl;
 	float *const chain = S.pool + n2 * LROW;                      // chain rows follow the two-body rows in the pool
-	int chcap = (POOL_FLOATS - n2 * LROW) / CROW;                 // rows that fit in LDS; the rest stream from the HBM scratch
+	int chcap = (POOL_FLOATS - n2 * LROW) / CROW - 2;             // rows that fit in LDS (the sweep reads up to 2 records ahead); the rest stream from the HBM scratch
 	if (chcap < 0) chcap = 0;
 	float *scr = a.scratch + (size_t)b * a.scratch_stride * CROW;
 	auto row_ptr = [&](int i) -> const float * {
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			const v3 r1 = qrot(L4(S.q[body]), p1);
 			const float impulsed = S.lin4[body].w + dot(cross(mul(body_I(S, body), cross(r1, n)), r1), n);       // 0 + (...) for the NULL side
 			const float ts = r[11] / dt;
-			const float4 o0 = make_float4(r1.x, r1.y, r1.z, n.x), o1 = make_float4(n.y, n.z, ts, fmin_std(ts, r[12])), o2 = make_float4(r[13] * dt, r[14] * dt, impulsed, 0.0f);
+			const float4 o0 = make_float4(r1.x, r1.y, r1.z, ts), o1 = make_float4(n.x, n.y, n.z, fmin_std(ts, r[12])), o2 = make_float4(r[13] * dt, r[14] * dt, impulsed, 0.0f);
 			if (dst < chcap) { float4 *ol = reinterpret_cast<float4 *>(chain + dst * CROW); ol[0] = o0; ol[1] = o1; ol[2] = o2; }
 			else { float4 *og = reinterpret_cast<float4 *>(scr + (size_t)dst * CROW); og[0] = o0; og[1] = o1; og[2] = o2; }
 		}
@@ -522,7 +526,8 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	{
 		const bool post = sweep >= ph.iterations;
 		const int tsoff = post ? 1 : 0;                                   // RemoveBias (physics.h:288): ts_post = min(ts, ts_nobias) was stored next to ts
-		// (1) chains: quad q applies the single-body rows of body q (then q+16) in order; momenta, inertia row and mass stay in registers
+		// (1) chains: quad q applies the single-body rows of body q (then q+16) in order; momenta, inertia row and mass stay in registers.
+		//     Lane c < 3 of the quad reads r1[c] and n[c] of a record, lane 3 reads its target speed (ts or ts_post).
 		for (int half = 0; half * 16 < nb; half++)
 		{
 			const int body = quad + 16 * half;
@@ -530,46 +535,42 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			const int cnt = has ? S.ccnt[body] : 0, start = has ? S.cstart[body] : 0;
 			if (cnt > 0)
 			{
-				float l = lin_w[4 * body + cc], av = ang_w[4 * body + cc];
+				float l = lin_w[4 * body + c], av = ang_w[4 * body + c];             // lane 3 carries massinv / friction here and never stores
 				const float minv = lin_w[4 * body + 3];
-				const float Ix = I_w[12 * body + cc], Iy = I_w[12 * body + 4 + cc], Iz = I_w[12 * body + 8 + cc];
-				// one LimitLinear::Iter (physics.h:289-307) on this body; ra = r1[c+1], rb = r1[c+2], n = normal[c]
-				auto row_step = [&](float ra, float rb, float n, float ts, float fmn, float fmx, float effmass, float isum) -> float {
+				const float Ix = I_w[12 * body + c], Iy = I_w[12 * body + 4 + c], Iz = I_w[12 * body + 8 + c];
+				// one LimitLinear::Iter (physics.h:289-307) on this body: rv = r1[c] (lane 3: target speed), n = normal[c], t = (fmin*dt, fmax*dt, effmass, impulsesum)
+				auto row_step = [&](float rv, float n, float4 t) -> float {
 					const float w = (Ix * dpp<QP_BC0>(av) + Iy * dpp<QP_BC1>(av)) + Iz * dpp<QP_BC2>(av);      // (Iinv * angular_momentum)[c]
-					const float v1 = (dpp<QP_ROT1>(w) * rb - dpp<QP_ROT2>(w) * ra) + l * minv;                 // (cross(spin, r1) + lin*massinv)[c]
+					const float m1 = w * dpp<QP_ROT1>(rv), m2 = w * dpp<QP_ROT2>(rv);                          // w[c]*r1[c+1], w[c]*r1[c+2]
+					const float v1 = (dpp<QP_ROT1>(m1) - dpp<QP_ROT2>(m2)) + l * minv;                         // (cross(spin, r1) + lin*massinv)[c]
 					const float p = v1 * n;
 					const float vn = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);
-					const float impulsen = -ts - vn;
-					float impulse = div_ieee(impulsen, effmass);
-					impulse = fmin_std(fmx - isum, impulse);
-					impulse = fmax_std(fmn - isum, impulse);
+					const float impulsen = -dpp<QP_BC3>(rv) - vn;
+					float impulse = div_ieee(impulsen, t.z);
+					impulse = clamp_med3(impulse, t.x - t.w, t.y - t.w);
 					const float imp = n * impulse;
 					l = l + imp;
-					av = av + (ra * dpp<QP_ROT2>(imp) - rb * dpp<QP_ROT1>(imp));                                 // cross(r1, imp)[c]
-					return isum + impulse;
+					const float k1 = rv * dpp<QP_ROT1>(imp), k2 = rv * dpp<QP_ROT2>(imp);                      // r1[c]*imp[c+1], r1[c]*imp[c+2]
+					av = av + (dpp<QP_ROT1>(k1) - dpp<QP_ROT2>(k2));                                           // cross(r1, imp)[c]
+					return t.w + impulse;
 				};
+				const int lane_off = c < 3 ? c : 3 + 4 * tsoff;                      // RemoveBias (physics.h:288): lane 3 switches to ts_post
 				const int nl = (start + cnt <= chcap) ? cnt : (start >= chcap ? 0 : chcap - start);
 				if (nl > 0)
 				{
-					float *rp = chain + start * CROW;
-					float ra = rp[c1], rb = rp[c2], n = rp[3 + cc], ts = rp[6 + tsoff];
-					float4 t = *reinterpret_cast<const float4 *>(rp + 8);
+					float *pv = chain + start * CROW + lane_off, *pn = chain + start * CROW + 4 + c, *pt = chain + start * CROW + 8;
+					float rv = pv[0], n = pn[0]; float4 t = *reinterpret_cast<const float4 *>(pt);
 					for (int k = 0; k < nl; k++)
 					{
-						float *np = rp + ((k + 1 < nl) ? CROW : 0);                                      // prefetch the next row
-						const float nra = np[c1], nrb = np[c2], nn = np[3 + cc], nts = np[6 + tsoff];
-						const float4 nt = *reinterpret_cast<const float4 *>(np + 8);
-						const float isum = row_step(ra, rb, n, ts, t.x, t.y, t.z, t.w);
-						if (c == 3) rp[11] = isum;
-						rp = np; ra = nra; rb = nrb; n = nn; ts = nts; t = nt;
+						const float nrv = pv[CROW], nn = pn[CROW]; const float4 nt = *reinterpret_cast<const float4 *>(pt + CROW);      // next record (or slack)
+						pt[3] = row_step(rv, n, t);
+						rv = nrv; n = nn; t = nt; pv += CROW; pn += CROW; pt += CROW;
 					}
 				}
 				for (int k = nl; k < cnt; k++)
 				{
 					float *rp = scr + (size_t)(start + k) * CROW;
-					const float4 t = *reinterpret_cast<const float4 *>(rp + 8);
-					const float isum = row_step(rp[c1], rp[c2], rp[3 + cc], rp[6 + tsoff], t.x, t.y, t.z, t.w);
-					if (c == 3) rp[11] = isum;
+					rp[11] = row_step(rp[lane_off], rp[4 + c], *reinterpret_cast<const float4 *>(rp + 8));
 				}
 				if (c < 3) { lin_w[4 * body + c] = l; ang_w[4 * body + c] = av; }
 			}
@@ -603,8 +604,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				const float vn = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);
 				const float impulsen = -ts - vn;
 				float impulse = div_ieee(impulsen, effmass);
-				impulse = fmin_std(fmx - isum, impulse);
-				impulse = fmax_std(fmn - isum, impulse);
+				impulse = clamp_med3(impulse, fmn - isum, fmx - isum);
 				const float imp = n * __int_as_float(__float_as_int(impulse) ^ sidesign);                      // rb0: n * -impulse, rb1: n * impulse
 				const float ln = l + imp;
 				const float an = av + (ra * dpp<QP_ROT2>(imp) - rb * dpp<QP_ROT1>(imp));
