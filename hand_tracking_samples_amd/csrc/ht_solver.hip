@@ -34,7 +34,9 @@
 #define MAXL2 (3 * HT_MAXNJ + 3 * HT_MAXCONTACT)      // two-body linear rows (all live in LDS)
 #define ASLOTS 2           // angular rows live in registers: row r in lane r%64, slot r/64  (<= 128 rows)
 #define MAXA2 (64 * ASLOTS)
-#define POOL_FLOATS 7424   // LDS pool shared by the two-body linear rows (front) and the single-body chain rows (rest; overflow: HBM scratch)
+#define AROW 10            // floats per angular row record: axis[3] meta | ts ts_post | mintorque*dt maxtorque*dt | 1/(axis.Iinv.axis) torque
+#define MAXA_LDS 110       // angular rows: 13 + 6 per joint for the 17-bone hand
+#define POOL_FLOATS 7136   // LDS pool shared by the two-body linear rows (front) and the single-body chain rows (rest; overflow: HBM scratch)
 #define LM_FRIC 0x10000    // meta bits of a two-body linear row: friction row (limits from its contact's normal row, physics.h:292)
 #define LM_NORMAL 0x20000  //                                     normal row of a contact (publishes its impulse sum)
 
@@ -46,18 +48,26 @@ struct lds_t
 	float4 I4[HT_MAXNB][3];                // columns of the world inverse inertia (w unused)
 	float pos[HT_MAXNB][3], q[HT_MAXNB][4];
 	int ccnt[HT_MAXNB], cstart[HT_MAXNB];  // chain of body b: rows [cstart, cstart+ccnt) of the partitioned single-body stream
-	unsigned short lorder[MAXL2];          // two-body linear rows sorted by level
-	unsigned short lstart[MAXL2 + 2];      // level L = lorder[lstart[L] .. lstart[L+1])
+	unsigned lorder[MAXL2];                // two-body linear rows sorted by step: row | rb0 << 16 | rb1 << 24
+	unsigned short lstart[MAXL2 + 2];      // step L = lorder[lstart[L] .. lstart[L+1]); a step is a level, split so that it holds <= 8 rows
+	unsigned aorder[MAXA2];                // angular rows likewise (body 255 = none)
+	unsigned short astart[MAXA2 + 2];
 	float cisum[HT_MAXCONTACT];            // impulse sum of each contact's normal row, read by its two friction rows (physics.h:292)
 	int nlev_lin, nlev_ang, nray;
-	// prologue only
-	float jr[HT_MAXNJ][6];                 // joint ranges after HandModelEnhancements
-	float ray[20][HT_ROW];
-	int acount[HT_MAXNJ], aprefix[HT_MAXNJ + 1];
-	unsigned char lrb[MAXL2][2], arb[MAXA2][2];     // body pair of every two-body row (255 = none), for the level schedule
-	unsigned short llev[MAXL2]; unsigned char alev[MAXA2];
-	unsigned short lfill[MAXL2 + 2];
-	int lastlev[HT_MAXNB];                 // scratch of the level scheduler
+	union
+	{
+		struct      // prologue only
+		{
+			float jr[HT_MAXNJ][6];                 // joint ranges after HandModelEnhancements
+			float ray[20][HT_ROW];
+			int acount[HT_MAXNJ], aprefix[HT_MAXNJ + 1];
+			unsigned char lrb[MAXL2][2], arb[MAXA2][2];     // body pair of every two-body row (255 = none), for the level schedule
+			unsigned short llev[MAXL2]; unsigned char alev[MAXA2];
+			unsigned short lfill[MAXL2 + 2];
+			int lastlev[HT_MAXNB];                 // scratch of the level scheduler
+		};
+		float arec[MAXA_LDS * AROW];               // sweeps: angular row records (written once the prologue scratch is dead)
+	};
 	float pool[POOL_FLOATS] __attribute__((aligned(16)));
 };
 
@@ -410,8 +420,9 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	}
 	for (int i = lane; i < HT_MAXCONTACT; i += 64) S.cisum[i] = 0.0f;
 	__syncthreads();
-	// ---- level schedule (one lane, once per solve): level(row) = 1 + max level of an earlier row sharing a body; linear rows are then
-	//      counting-sorted by level so that the p-th lane pair picks the p-th row of a level ----
+	// ---- level schedule (one lane, once per solve): level(row) = 1 + max level of an earlier row sharing a body.  Rows are then
+	//      counting-sorted by level into steps of at most 8 rows (one per lane pair); rows of one level touch disjoint bodies ----
+	if (na > MAXA_LDS) na = MAXA_LDS;
 	if (lane == 0)
 	{
 		int *last = S.lastlev;               // LDS, not a private array: dynamic indexing of a private array goes to scratch memory
@@ -423,13 +434,20 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			int l = (last[b0] > last[b1] ? last[b0] : last[b1]) + 1;
 			last[b0] = l; last[b1] = l; S.llev[r] = (unsigned short)l; if (l > mx) mx = l;
 		}
-		S.nlev_lin = mx;
 		for (int l = 0; l <= mx + 1; l++) S.lfill[l] = 0;
 		for (int r = 0; r < n2; r++) S.lfill[S.llev[r]]++;
-		int acc = 0;
-		for (int l = 1; l <= mx; l++) { S.lstart[l] = (unsigned short)acc; acc += S.lfill[l]; S.lfill[l] = 0; }
-		S.lstart[mx + 1] = (unsigned short)acc;
-		for (int r = 0; r < n2; r++) { const int l = S.llev[r]; S.lorder[S.lstart[l] + S.lfill[l]] = (unsigned short)r; S.lfill[l]++; }
+		int acc = 0, step = 1;
+		for (int l = 1; l <= mx; l++)          // lfill[l] becomes the first slot of level l; steps are cut every 8 rows inside a level
+		{
+			const int m = S.lfill[l];
+			S.lfill[l] = (unsigned short)acc;
+			for (int k = 0; k < m; k += 8) S.lstart[step++] = (unsigned short)(acc + k);
+			acc += m;
+		}
+		S.lstart[step] = (unsigned short)acc; S.lstart[step + 1] = (unsigned short)acc;
+		S.nlev_lin = step - 1;
+		for (int r = 0; r < n2; r++) { const int l = S.llev[r]; S.lorder[S.lfill[l]] = (unsigned)r | ((unsigned)S.lrb[r][0] << 16) | ((unsigned)S.lrb[r][1] << 24); S.lfill[l]++; }
+		// angular rows
 		for (int k = 0; k < nb; k++) last[k] = 0;
 		mx = 0;
 		for (int r = 0; r < na; r++)
@@ -441,11 +459,21 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			if (b1 != 255) last[b1] = l;
 			S.alev[r] = (unsigned char)l; if (l > mx) mx = l;
 		}
-		S.nlev_ang = mx;
+		for (int l = 0; l <= mx + 1; l++) S.lfill[l] = 0;
+		for (int r = 0; r < na; r++) S.lfill[S.alev[r]]++;
+		acc = 0; step = 1;
+		for (int l = 1; l <= mx; l++)
+		{
+			const int m = S.lfill[l];
+			S.lfill[l] = (unsigned short)acc;
+			for (int k = 0; k < m; k += 8) S.astart[step++] = (unsigned short)(acc + k);
+			acc += m;
+		}
+		S.astart[step] = (unsigned short)acc; S.astart[step + 1] = (unsigned short)acc;
+		S.nlev_ang = step - 1;
+		for (int r = 0; r < na; r++) { const int l = S.alev[r]; S.aorder[S.lfill[l]] = (unsigned)r | ((unsigned)S.arb[r][0] << 16) | ((unsigned)S.arb[r][1] << 24); S.lfill[l]++; }
 	}
 	__syncthreads();
-#pragma unroll
-	for (int s = 0; s < ASLOTS; s++) if (lane + 64 * s < na) AR[s].lev = S.alev[lane + 64 * s];
 	const int nlev_lin = S.nlev_lin, nlev_ang = S.nlev_ang;
 	if (a.dbg & 64) return;
 
@@ -509,6 +537,21 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			const float4 o0 = make_float4(r1.x, r1.y, r1.z, ts), o1 = make_float4(n.x, n.y, n.z, fmin_std(ts, r[12])), o2 = make_float4(r[13] * dt, r[14] * dt, impulsed, 0.0f);
 			if (dst < chcap) { float4 *ol = reinterpret_cast<float4 *>(chain + dst * CROW); ol[0] = o0; ol[1] = o1; ol[2] = o2; }
 			else { float4 *og = reinterpret_cast<float4 *>(scr + (size_t)dst * CROW); og[0] = o0; og[1] = o1; og[2] = o2; }
+		}
+	}
+	__syncthreads();
+	// ---- the prologue scratch is dead now: angular rows move from their builder lanes into LDS records ----
+#pragma unroll
+	for (int s = 0; s < ASLOTS; s++)
+	{
+		const int r = lane + 64 * s;
+		if (r < na)
+		{
+			const arow &R = AR[s];
+			float *o = S.arec + r * AROW;
+			o[0] = R.axis.x; o[1] = R.axis.y; o[2] = R.axis.z; o[3] = 0.0f;
+			o[4] = R.targetspin; o[5] = (R.mintorque < 0) ? 0 : fmin_std(R.targetspin, 0.0f);            // RemoveBias physics.h:250
+			o[6] = R.mn; o[7] = R.mx; o[8] = R.s2t; o[9] = 0.0f;
 		}
 	}
 	__syncthreads();
@@ -576,77 +619,123 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			}
 		}
 		__builtin_amdgcn_wave_barrier();
-		// (2) two-body linear rows, level by level (LimitLinear::Iter physics.h:289-307): lane pair p takes the p-th row of the level
-		for (int L = 1; L <= ((a.dbg & 2) ? 0 : nlev_lin); L++)
+		// (2) two-body linear rows, step by step (LimitLinear::Iter physics.h:289-307): lane pair p takes the p-th row of the step.
+		//     Three-stage software pipeline: the sort entry is fetched two steps ahead, the row record and the (sweep-invariant) inverse
+		//     inertia and mass one step ahead; only the momenta are read after the previous step's stores.
+		if (!(a.dbg & 2) && nlev_lin > 0)
 		{
-			for (int idx = S.lstart[L] + (lane >> 3); idx < S.lstart[L + 1]; idx += 8)
-			{
-				float *R = S.pool + (int)S.lorder[idx] * LROW;
-				const int meta = __float_as_int(R[6]);
-				const int body = side ? ((meta >> 8) & 255) : (meta & 255);
-				const float *rv = R + 7 + 3 * side;
-				const float ra = rv[c1], rb = rv[c2], n = R[13 + cc];
-				const float ts = R[tsoff], effmass = R[4], isum = R[5];
-				float fmn = R[2], fmx = R[3];
-				const float l = lin_w[4 * body + cc], av = ang_w[4 * body + cc], minv = lin_w[4 * body + 3];
-				const float Ix = I_w[12 * body + cc], Iy = I_w[12 * body + 4 + cc], Iz = I_w[12 * body + 8 + cc];
-				if (meta & LM_FRIC)
+			const int pslot = lane >> 3;
+			auto entry = [&](int L) -> unsigned {
+				if (L > nlev_lin) return 0xFFFFFFFFu;
+				const int idx = S.lstart[L] + pslot;
+				return idx < S.lstart[L + 1] ? S.lorder[idx] : 0xFFFFFFFFu;
+			};
+			unsigned e_cur = entry(1), e_nxt = entry(2);
+			float ts = 0, fmn = 0, fmx = 0, effmass = 1, isum = 0, rv = 0, n = 0, Ix = 0, Iy = 0, Iz = 0, minv = 0; int meta = 0;
+			auto fetch = [&](unsigned e, float &ts_, float &fmn_, float &fmx_, float &eff_, float &isum_, int &meta_, float &rv_, float &n_, float &Ix_, float &Iy_, float &Iz_, float &minv_) {
+				if (e != 0xFFFFFFFFu)
 				{
-					const float master = S.cisum[(meta >> 24) & 255];
-					const float lim = fmx * master / dt;       // physics.h:292 (fmx slot holds max(friction0, friction1))
-					fmx = lim * dt; fmn = (-lim) * dt;
+					const float *R = S.pool + (int)(e & 0xFFFF) * LROW;
+					const int body = side ? (int)(e >> 24) : (int)((e >> 16) & 255);
+					ts_ = R[tsoff]; fmn_ = R[2]; fmx_ = R[3]; eff_ = R[4]; isum_ = R[5]; meta_ = __float_as_int(R[6]);
+					rv_ = R[7 + 3 * side + c]; n_ = R[13 + c];
+					Ix_ = I_w[12 * body + c]; Iy_ = I_w[12 * body + 4 + c]; Iz_ = I_w[12 * body + 8 + c]; minv_ = lin_w[4 * body + 3];
 				}
-				const float w = (Ix * dpp<QP_BC0>(av) + Iy * dpp<QP_BC1>(av)) + Iz * dpp<QP_BC2>(av);
-				const float v = (dpp<QP_ROT1>(w) * rb - dpp<QP_ROT2>(w) * ra) + l * minv;                     // velocity of this side's anchor
-				const float u = __int_as_float(__float_as_int(v) ^ sidesign);                                 // rb1 side: v1, rb0 side: -v0
-				const float d = u + pair_swap(u);                                                              // (v1 - v0)[c] on both sides (v1 + -v0)
-				const float p = d * n;
-				const float vn = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);
-				const float impulsen = -ts - vn;
-				float impulse = div_ieee(impulsen, effmass);
-				impulse = clamp_med3(impulse, fmn - isum, fmx - isum);
-				const float imp = n * __int_as_float(__float_as_int(impulse) ^ sidesign);                      // rb0: n * -impulse, rb1: n * impulse
-				const float ln = l + imp;
-				const float an = av + (ra * dpp<QP_ROT2>(imp) - rb * dpp<QP_ROT1>(imp));
-				if (c < 3) { lin_w[4 * body + c] = ln; ang_w[4 * body + c] = an; }
-				else if (side == 0)
-				{
-					const float ns = isum + impulse;
-					R[5] = ns;
-					if (meta & LM_NORMAL) S.cisum[(meta >> 24) & 255] = ns;
-				}
-			}
-			__builtin_amdgcn_wave_barrier();
-		}
-		__syncthreads();
-		// (3) angular rows, level by level (LimitAngular::Iter physics.h:251-265)
-		for (int L = 1; L <= ((a.dbg & 4) ? 0 : nlev_ang); L++)
-		{
-#pragma unroll
-			for (int s = 0; s < ASLOTS; s++)
+			};
+			fetch(e_cur, ts, fmn, fmx, effmass, isum, meta, rv, n, Ix, Iy, Iz, minv);
+			for (int L = 1; L <= nlev_lin; L++)
 			{
-				arow &R = AR[s];
-				if (R.lev == L)
+				float nts = 0, nfmn = 0, nfmx = 0, neff = 1, nisum = 0, nrv = 0, nn = 0, nIx = 0, nIy = 0, nIz = 0, nminv = 0; int nmeta = 0;
+				fetch(e_nxt, nts, nfmn, nfmx, neff, nisum, nmeta, nrv, nn, nIx, nIy, nIz, nminv);
+				const unsigned e_nn = entry(L + 2);
+				__builtin_amdgcn_wave_barrier();
+				if (e_cur != 0xFFFFFFFFu)
 				{
-					float targetspin = R.targetspin;
-					if (post) targetspin = (R.mintorque < 0) ? 0 : fmin_std(targetspin, 0.0f);            // RemoveBias physics.h:250
-					if (!(targetspin == -FLT_MAX))
+					const int body = side ? (int)(e_cur >> 24) : (int)((e_cur >> 16) & 255);
+					const float l = lin_w[4 * body + c], av = ang_w[4 * body + c];
+					if (meta & LM_FRIC)
 					{
-						const float4 A0 = R.rb0 >= 0 ? S.ang4[R.rb0] : make_float4(0, 0, 0, 0), A1 = R.rb1 >= 0 ? S.ang4[R.rb1] : make_float4(0, 0, 0, 0);
-						const v3 a0 = F3(A0), a1 = F3(A1);
-						const float currentspin = ((R.rb1 >= 0) ? dot(mul(body_I(S, R.rb1), a1), R.axis) : 0.0f) - ((R.rb0 >= 0) ? dot(mul(body_I(S, R.rb0), a0), R.axis) : 0.0f);
-						const float dspin = targetspin - currentspin;
-						float dtorque = dspin * R.s2t;
-						dtorque = fmin_std(dtorque, R.mx - R.torque);
-						dtorque = fmax_std(dtorque, R.mn - R.torque);
-						if (R.rb0 >= 0) { const v3 na = a0 - R.axis * dtorque; S.ang4[R.rb0] = make_float4(na.x, na.y, na.z, A0.w); }
-						if (R.rb1 >= 0) { const v3 na = a1 + R.axis * dtorque; S.ang4[R.rb1] = make_float4(na.x, na.y, na.z, A1.w); }
-						R.torque = R.torque + dtorque;
+						const float master = S.cisum[(meta >> 24) & 255];
+						const float lim = fmx * master / dt;       // physics.h:292 (fmx slot holds max(friction0, friction1))
+						fmx = lim * dt; fmn = (-lim) * dt;
+					}
+					const float w = (Ix * dpp<QP_BC0>(av) + Iy * dpp<QP_BC1>(av)) + Iz * dpp<QP_BC2>(av);
+					const float m1 = w * dpp<QP_ROT1>(rv), m2 = w * dpp<QP_ROT2>(rv);
+					const float v = (dpp<QP_ROT1>(m1) - dpp<QP_ROT2>(m2)) + l * minv;                         // velocity of this side's anchor
+					const float u = __int_as_float(__float_as_int(v) ^ sidesign);                             // rb1 side: v1, rb0 side: -v0
+					const float d = u + pair_swap(u);                                                          // (v1 - v0)[c] on both sides (v1 + -v0)
+					const float p = d * n;
+					const float vn = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);
+					const float impulsen = -ts - vn;
+					float impulse = div_ieee(impulsen, effmass);
+					impulse = clamp_med3(impulse, fmn - isum, fmx - isum);
+					const float imp = n * __int_as_float(__float_as_int(impulse) ^ sidesign);                  // rb0: n * -impulse, rb1: n * impulse
+					const float ln = l + imp;
+					const float k1 = rv * dpp<QP_ROT1>(imp), k2 = rv * dpp<QP_ROT2>(imp);
+					const float an = av + (dpp<QP_ROT1>(k1) - dpp<QP_ROT2>(k2));                               // + cross(r, imp)[c]
+					if (c < 3) { lin_w[4 * body + c] = ln; ang_w[4 * body + c] = an; }
+					else if (side == 0)
+					{
+						const float ns = isum + impulse;
+						S.pool[(int)(e_cur & 0xFFFF) * LROW + 5] = ns;
+						if (meta & LM_NORMAL) S.cisum[(meta >> 24) & 255] = ns;
 					}
 				}
+				e_cur = e_nxt; e_nxt = e_nn;
+				ts = nts; fmn = nfmn; fmx = nfmx; effmass = neff; isum = nisum; meta = nmeta; rv = nrv; n = nn; Ix = nIx; Iy = nIy; Iz = nIz; minv = nminv;
 			}
-			__syncthreads();
 		}
+		__builtin_amdgcn_wave_barrier();
+		// (3) angular rows, step by step (LimitAngular::Iter physics.h:251-265), same lane mapping and pipeline
+		if (!(a.dbg & 4) && nlev_ang > 0)
+		{
+			const int pslot = lane >> 3;
+			auto entry = [&](int L) -> unsigned {
+				if (L > nlev_ang) return 0xFFFFFFFFu;
+				const int idx = S.astart[L] + pslot;
+				return idx < S.astart[L + 1] ? S.aorder[idx] : 0xFFFFFFFFu;
+			};
+			unsigned e_cur = entry(1), e_nxt = entry(2);
+			float ax = 0, ts = 0, mn = 0, mx = 0, s2t = 0, torque = 0, Ix = 0, Iy = 0, Iz = 0;
+			auto fetch = [&](unsigned e, float &ax_, float &ts_, float &mn_, float &mx_, float &s2t_, float &tq_, float &Ix_, float &Iy_, float &Iz_) {
+				if (e != 0xFFFFFFFFu)
+				{
+					const float *R = S.arec + (int)(e & 0xFFFF) * AROW;
+					const int body = side ? (int)(e >> 24) : (int)((e >> 16) & 255);
+					ax_ = R[c]; ts_ = R[4 + tsoff]; mn_ = R[6]; mx_ = R[7]; s2t_ = R[8]; tq_ = R[9];
+					Ix_ = 0; Iy_ = 0; Iz_ = 0;
+					if (body != 255) { Ix_ = I_w[12 * body + c]; Iy_ = I_w[12 * body + 4 + c]; Iz_ = I_w[12 * body + 8 + c]; }
+				}
+			};
+			fetch(e_cur, ax, ts, mn, mx, s2t, torque, Ix, Iy, Iz);
+			for (int L = 1; L <= nlev_ang; L++)
+			{
+				float nax = 0, nts = 0, nmn = 0, nmx = 0, ns2t = 0, ntq = 0, nIx = 0, nIy = 0, nIz = 0;
+				fetch(e_nxt, nax, nts, nmn, nmx, ns2t, ntq, nIx, nIy, nIz);
+				const unsigned e_nn = entry(L + 2);
+				__builtin_amdgcn_wave_barrier();
+				if (e_cur != 0xFFFFFFFFu && !(ts == -FLT_MAX))
+				{
+					const int body = side ? (int)(e_cur >> 24) : (int)((e_cur >> 16) & 255);
+					const bool bv = body != 255;
+					const float av = bv ? ang_w[4 * body + c] : 0.0f;
+					const float w = (Ix * dpp<QP_BC0>(av) + Iy * dpp<QP_BC1>(av)) + Iz * dpp<QP_BC2>(av);
+					const float p = w * ax;
+					const float sp = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);                       // dot(Iinv*angular_momentum, axis) of this side
+					const float u = __int_as_float(__float_as_int(bv ? sp : 0.0f) ^ sidesign);
+					const float currentspin = u + pair_swap(u);                                                // spin1 - spin0
+					const float dspin = ts - currentspin;
+					float dtorque = dspin * s2t;
+					dtorque = clamp_med3(dtorque, mn - torque, mx - torque);
+					const float an = av + __int_as_float(__float_as_int(ax * dtorque) ^ sidesign);             // rb0: a - axis*dtorque, rb1: a + axis*dtorque
+					if (c < 3) { if (bv) ang_w[4 * body + c] = an; }
+					else if (side == 0) S.arec[(int)(e_cur & 0xFFFF) * AROW + 9] = torque + dtorque;
+				}
+				e_cur = e_nxt; e_nxt = e_nn;
+				ax = nax; ts = nts; mn = nmn; mx = nmx; s2t = ns2t; torque = ntq; Ix = nIx; Iy = nIy; Iz = nIz;
+			}
+		}
+		__syncthreads();
 		if (sweep + 1 == ph.iterations && lane < nb)
 		{
 			// rbcalcnextpose physics.h:522-531 with rkupdateq :211-218 (momentum-preserving RK4 on the quaternion)
