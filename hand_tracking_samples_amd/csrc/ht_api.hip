@@ -51,7 +51,7 @@ static int load_model(ht_ctx *ctx, const char *path)
 	const fx_arr *a;
 	if (!(a = need("nb"))) return HT_ERR_IO; int nb = a->i()[0];
 	if (!(a = need("nj"))) return HT_ERR_IO; int nj = a->i()[0];
-	if (nb < 1 || nb > HT_MAXNB || nj > HT_MAXNJ) { ctx->err = "model too large"; return HT_ERR_IO; }
+	if (nb < 1 || nb >= HT_MAXNB || nj > HT_MAXNJ) { ctx->err = "model too large"; return HT_ERR_IO; }      // body slot HT_MAXNB-1 is the solver's idle body
 	ht_model_dev &m = ctx->model;
 	memset(&m, 0, sizeof m);
 	m.nb = nb; m.nj = nj;

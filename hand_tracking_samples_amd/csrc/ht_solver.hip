@@ -37,6 +37,7 @@
 #define AROW 10            // floats per angular row record: axis[3] meta | ts ts_post | mintorque*dt maxtorque*dt | 1/(axis.Iinv.axis) torque
 #define MAXA_LDS 110       // angular rows: 13 + 6 per joint for the 17-bone hand
 #define POOL_FLOATS 7136   // LDS pool shared by the two-body linear rows (front) and the single-body chain rows (rest; overflow: HBM scratch)
+#define IDLE_BODY (HT_MAXNB - 1)      // lane pairs without a row in a step work on this all-zero body and on an all-zero record
 #define LM_FRIC 0x10000    // meta bits of a two-body linear row: friction row (limits from its contact's normal row, physics.h:292)
 #define LM_NORMAL 0x20000  //                                     normal row of a contact (publishes its impulse sum)
 
@@ -48,9 +49,9 @@ struct lds_t
 	float4 I4[HT_MAXNB][3];                // columns of the world inverse inertia (w unused)
 	float pos[HT_MAXNB][3], q[HT_MAXNB][4];
 	int ccnt[HT_MAXNB], cstart[HT_MAXNB];  // chain of body b: rows [cstart, cstart+ccnt) of the partitioned single-body stream
-	unsigned lorder[MAXL2];                // two-body linear rows sorted by step: row | rb0 << 16 | rb1 << 24
+	unsigned lorder[MAXL2 + 1];            // two-body linear rows sorted by step: row | rb0 << 16 | rb1 << 24; last slot = the idle entry
 	unsigned short lstart[MAXL2 + 2];      // step L = lorder[lstart[L] .. lstart[L+1]); a step is a level, split so that it holds <= 8 rows
-	unsigned aorder[MAXA2];                // angular rows likewise (body 255 = none)
+	unsigned aorder[MAXA2 + 1];            // angular rows likewise (a missing body is the idle body)
 	unsigned short astart[MAXA2 + 2];
 	float cisum[HT_MAXCONTACT];            // impulse sum of each contact's normal row, read by its two friction rows (physics.h:292)
 	int nlev_lin, nlev_ang, nray;
@@ -66,7 +67,7 @@ struct lds_t
 			unsigned short lfill[MAXL2 + 2];
 			int lastlev[HT_MAXNB];                 // scratch of the level scheduler
 		};
-		float arec[MAXA_LDS * AROW];               // sweeps: angular row records (written once the prologue scratch is dead)
+		float arec[(MAXA_LDS + 1) * AROW];         // sweeps: angular row records (written once the prologue scratch is dead) + the idle record
 	};
 	float pool[POOL_FLOATS] __attribute__((aligned(16)));
 };
@@ -419,6 +420,13 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		S.lrb[r][0] = (unsigned char)rb0; S.lrb[r][1] = (unsigned char)rb1;
 	}
 	for (int i = lane; i < HT_MAXCONTACT; i += 64) S.cisum[i] = 0.0f;
+	if (lane < LROW) S.pool[n2 * LROW + lane] = lane == 4 ? 1.0f : lane == 6 ? __int_as_float(IDLE_BODY | (IDLE_BODY << 8)) : 0.0f;      // idle record: zero limits, unit effective mass
+	if (lane == 0)
+	{
+		S.lin4[IDLE_BODY] = make_float4(0, 0, 0, 0); S.ang4[IDLE_BODY] = make_float4(0, 0, 0, 0);
+		S.I4[IDLE_BODY][0] = S.I4[IDLE_BODY][1] = S.I4[IDLE_BODY][2] = make_float4(0, 0, 0, 0);
+		S.lorder[MAXL2] = (unsigned)n2 | ((unsigned)IDLE_BODY << 16) | ((unsigned)IDLE_BODY << 24);
+	}
 	__syncthreads();
 	// ---- level schedule (one lane, once per solve): level(row) = 1 + max level of an earlier row sharing a body.  Rows are then
 	//      counting-sorted by level into steps of at most 8 rows (one per lane pair); rows of one level touch disjoint bodies ----
@@ -471,7 +479,8 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		}
 		S.astart[step] = (unsigned short)acc; S.astart[step + 1] = (unsigned short)acc;
 		S.nlev_ang = step - 1;
-		for (int r = 0; r < na; r++) { const int l = S.alev[r]; S.aorder[S.lfill[l]] = (unsigned)r | ((unsigned)S.arb[r][0] << 16) | ((unsigned)S.arb[r][1] << 24); S.lfill[l]++; }
+		for (int r = 0; r < na; r++) { const int l = S.alev[r]; const unsigned b0 = S.arb[r][0] == 255 ? IDLE_BODY : S.arb[r][0], b1 = S.arb[r][1] == 255 ? IDLE_BODY : S.arb[r][1]; S.aorder[S.lfill[l]] = (unsigned)r | (b0 << 16) | (b1 << 24); S.lfill[l]++; }
+		S.aorder[MAXA2] = (unsigned)na | ((unsigned)IDLE_BODY << 16) | ((unsigned)IDLE_BODY << 24);
 	}
 	__syncthreads();
 	const int nlev_lin = S.nlev_lin, nlev_ang = S.nlev_ang;
@@ -482,8 +491,8 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	const int npre = a.ray_rows ? S.nray : npre_g;
 	const int ncl = a.rows_cloud ? a.n_cloud[b] : 0;
 	const int n1 = npre + ncl;
-	float *const chain = S.pool + n2 * LROW;                      // chain rows follow the two-body rows in the pool
-	int chcap = (POOL_FLOATS - n2 * LROW) / CROW - 2;             // rows that fit in LDS (the sweep reads up to 2 records ahead); the rest stream from the HBM scratch
+	float *const chain = S.pool + (n2 + 1) * LROW;                // chain rows follow the two-body rows (+ the idle record) in the pool
+	int chcap = (POOL_FLOATS - (n2 + 1) * LROW) / CROW - 2;             // rows that fit in LDS (the sweep reads up to 2 records ahead); the rest stream from the HBM scratch
 	if (chcap < 0) chcap = 0;
 	float *scr = a.scratch + (size_t)b * a.scratch_stride * CROW;
 	auto row_ptr = [&](int i) -> const float * {
@@ -554,10 +563,14 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			o[6] = R.mn; o[7] = R.mx; o[8] = R.s2t; o[9] = 0.0f;
 		}
 	}
+	if (lane < AROW) S.arec[na * AROW + lane] = 0.0f;      // idle record
 	__syncthreads();
 
 	if (a.dbg & 128) return;
 	// ---- Gauss-Seidel sweeps ----
+	const bool stats = (a.dbg & 2048) != 0;          // timing experiments: per-frame cycle counts accumulated in the last scratch record
+	long long cyc_chain = 0, cyc_lin = 0, cyc_ang = 0, t_mark = stats ? clock64() : 0;
+	const long long t_begin = t_mark;
 	v3 pos_next = V3(0, 0, 0); v4 q_next = V4(0, 0, 0, 1);
 	const int total_sweeps = ph.iterations + ph.iterations_post;
 	const int quad = lane >> 2, c = lane & 3, cc = c < 3 ? c : 2;         // lane 3 of a quad shadows component z; its vector results are never stored
@@ -565,6 +578,8 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	const int side = quad & 1;                                            // two-body rows: even quad = rb0, odd quad = rb1
 	const int sidesign = side ? 0 : (int)0x80000000;                      // rb0 receives -impulse, and contributes -v0 to v1 - v0
 	float *const lin_w = reinterpret_cast<float *>(S.lin4), *const ang_w = reinterpret_cast<float *>(S.ang4), *const I_w = reinterpret_cast<float *>(S.I4);
+	const int pslot = lane >> 3;
+	const int ls_lin = S.lstart[lane], ls_ang = S.astart[lane];      // step boundaries of the first 63 steps, read back with v_readlane
 	for (int sweep = 0; sweep < total_sweeps; sweep++)
 	{
 		const bool post = sweep >= ph.iterations;
@@ -619,123 +634,129 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			}
 		}
 		__builtin_amdgcn_wave_barrier();
-		// (2) two-body linear rows, step by step (LimitLinear::Iter physics.h:289-307): lane pair p takes the p-th row of the step.
-		//     Three-stage software pipeline: the sort entry is fetched two steps ahead, the row record and the (sweep-invariant) inverse
-		//     inertia and mass one step ahead; only the momenta are read after the previous step's stores.
+		if (stats) { const long long t = clock64(); cyc_chain += t - t_mark; t_mark = t; }
+		// (2) two-body linear rows, step by step (LimitLinear::Iter physics.h:289-307): lane pair p takes the p-th row of the step, pairs
+		//     without a row work on the idle record / idle body, so a step is branch-free.  Three-stage software pipeline: the sort entry
+		//     is fetched two steps ahead, the row record and the (sweep-invariant) inverse inertia and mass one step ahead; only the
+		//     momenta are read after the previous step's stores.  Two register sets alternate, so nothing is copied between steps.
 		if (!(a.dbg & 2) && nlev_lin > 0)
 		{
-			const int pslot = lane >> 3;
+			struct lset { unsigned e; float ts, fmn, fmx, eff, isum, rv, n, Ix, Iy, Iz, minv; int meta; };
 			auto entry = [&](int L) -> unsigned {
-				if (L > nlev_lin) return 0xFFFFFFFFu;
-				const int idx = S.lstart[L] + pslot;
-				return idx < S.lstart[L + 1] ? S.lorder[idx] : 0xFFFFFFFFu;
+				if (L > nlev_lin) return S.lorder[MAXL2];
+				int lo, hi;
+				if (L < 63) { lo = __builtin_amdgcn_readlane(ls_lin, L); hi = __builtin_amdgcn_readlane(ls_lin, L + 1); }
+				else { lo = S.lstart[L]; hi = S.lstart[L + 1]; }
+				const int idx = lo + pslot;
+				return S.lorder[idx < hi ? idx : MAXL2];
 			};
-			unsigned e_cur = entry(1), e_nxt = entry(2);
-			float ts = 0, fmn = 0, fmx = 0, effmass = 1, isum = 0, rv = 0, n = 0, Ix = 0, Iy = 0, Iz = 0, minv = 0; int meta = 0;
-			auto fetch = [&](unsigned e, float &ts_, float &fmn_, float &fmx_, float &eff_, float &isum_, int &meta_, float &rv_, float &n_, float &Ix_, float &Iy_, float &Iz_, float &minv_) {
-				if (e != 0xFFFFFFFFu)
+			auto fetch = [&](lset &r, unsigned e) {
+				r.e = e;
+				const float *R = S.pool + (int)(e & 0xFFFF) * LROW;
+				const int body = side ? (int)(e >> 24) : (int)((e >> 16) & 255);
+				r.ts = R[tsoff]; r.fmn = R[2]; r.fmx = R[3]; r.eff = R[4]; r.isum = R[5]; r.meta = __float_as_int(R[6]);
+				r.rv = R[7 + 3 * side + c]; r.n = R[13 + c];
+				r.Ix = I_w[12 * body + c]; r.Iy = I_w[12 * body + 4 + c]; r.Iz = I_w[12 * body + 8 + c]; r.minv = lin_w[4 * body + 3];
+			};
+			auto step = [&](const lset &r) {
+				const int body = side ? (int)(r.e >> 24) : (int)((r.e >> 16) & 255);
+				const float l = lin_w[4 * body + c], av = ang_w[4 * body + c];
+				float fmn = r.fmn, fmx = r.fmx;
+				if (r.meta & LM_FRIC)
 				{
-					const float *R = S.pool + (int)(e & 0xFFFF) * LROW;
-					const int body = side ? (int)(e >> 24) : (int)((e >> 16) & 255);
-					ts_ = R[tsoff]; fmn_ = R[2]; fmx_ = R[3]; eff_ = R[4]; isum_ = R[5]; meta_ = __float_as_int(R[6]);
-					rv_ = R[7 + 3 * side + c]; n_ = R[13 + c];
-					Ix_ = I_w[12 * body + c]; Iy_ = I_w[12 * body + 4 + c]; Iz_ = I_w[12 * body + 8 + c]; minv_ = lin_w[4 * body + 3];
+					const float master = S.cisum[(r.meta >> 24) & 255];
+					const float lim = fmx * master / dt;       // physics.h:292 (fmx slot holds max(friction0, friction1))
+					fmx = lim * dt; fmn = (-lim) * dt;
+				}
+				const float w = (r.Ix * dpp<QP_BC0>(av) + r.Iy * dpp<QP_BC1>(av)) + r.Iz * dpp<QP_BC2>(av);
+				const float m1 = w * dpp<QP_ROT1>(r.rv), m2 = w * dpp<QP_ROT2>(r.rv);
+				const float v = (dpp<QP_ROT1>(m1) - dpp<QP_ROT2>(m2)) + l * r.minv;                       // velocity of this side's anchor
+				const float u = __int_as_float(__float_as_int(v) ^ sidesign);                             // rb1 side: v1, rb0 side: -v0
+				const float d = u + pair_swap(u);                                                          // (v1 - v0)[c] on both sides (v1 + -v0)
+				const float p = d * r.n;
+				const float vn = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);
+				const float impulsen = -r.ts - vn;
+				float impulse = div_ieee(impulsen, r.eff);
+				impulse = clamp_med3(impulse, fmn - r.isum, fmx - r.isum);
+				const float imp = r.n * __int_as_float(__float_as_int(impulse) ^ sidesign);                // rb0: n * -impulse, rb1: n * impulse
+				const float ln = l + imp;
+				const float k1 = r.rv * dpp<QP_ROT1>(imp), k2 = r.rv * dpp<QP_ROT2>(imp);
+				const float an = av + (dpp<QP_ROT1>(k1) - dpp<QP_ROT2>(k2));                               // + cross(r, imp)[c]
+				if (c < 3) { lin_w[4 * body + c] = ln; ang_w[4 * body + c] = an; }
+				else if (side == 0)
+				{
+					const float ns = r.isum + impulse;
+					S.pool[(int)(r.e & 0xFFFF) * LROW + 5] = ns;
+					if (r.meta & LM_NORMAL) S.cisum[(r.meta >> 24) & 255] = ns;
 				}
 			};
-			fetch(e_cur, ts, fmn, fmx, effmass, isum, meta, rv, n, Ix, Iy, Iz, minv);
-			for (int L = 1; L <= nlev_lin; L++)
+			lset A, Bs;
+			fetch(A, entry(1));
+			unsigned e_b = entry(2), e_a;
+			for (int L = 1; L <= nlev_lin; L += 2)
 			{
-				float nts = 0, nfmn = 0, nfmx = 0, neff = 1, nisum = 0, nrv = 0, nn = 0, nIx = 0, nIy = 0, nIz = 0, nminv = 0; int nmeta = 0;
-				fetch(e_nxt, nts, nfmn, nfmx, neff, nisum, nmeta, nrv, nn, nIx, nIy, nIz, nminv);
-				const unsigned e_nn = entry(L + 2);
+				fetch(Bs, e_b); e_a = entry(L + 2);
 				__builtin_amdgcn_wave_barrier();
-				if (e_cur != 0xFFFFFFFFu)
-				{
-					const int body = side ? (int)(e_cur >> 24) : (int)((e_cur >> 16) & 255);
-					const float l = lin_w[4 * body + c], av = ang_w[4 * body + c];
-					if (meta & LM_FRIC)
-					{
-						const float master = S.cisum[(meta >> 24) & 255];
-						const float lim = fmx * master / dt;       // physics.h:292 (fmx slot holds max(friction0, friction1))
-						fmx = lim * dt; fmn = (-lim) * dt;
-					}
-					const float w = (Ix * dpp<QP_BC0>(av) + Iy * dpp<QP_BC1>(av)) + Iz * dpp<QP_BC2>(av);
-					const float m1 = w * dpp<QP_ROT1>(rv), m2 = w * dpp<QP_ROT2>(rv);
-					const float v = (dpp<QP_ROT1>(m1) - dpp<QP_ROT2>(m2)) + l * minv;                         // velocity of this side's anchor
-					const float u = __int_as_float(__float_as_int(v) ^ sidesign);                             // rb1 side: v1, rb0 side: -v0
-					const float d = u + pair_swap(u);                                                          // (v1 - v0)[c] on both sides (v1 + -v0)
-					const float p = d * n;
-					const float vn = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);
-					const float impulsen = -ts - vn;
-					float impulse = div_ieee(impulsen, effmass);
-					impulse = clamp_med3(impulse, fmn - isum, fmx - isum);
-					const float imp = n * __int_as_float(__float_as_int(impulse) ^ sidesign);                  // rb0: n * -impulse, rb1: n * impulse
-					const float ln = l + imp;
-					const float k1 = rv * dpp<QP_ROT1>(imp), k2 = rv * dpp<QP_ROT2>(imp);
-					const float an = av + (dpp<QP_ROT1>(k1) - dpp<QP_ROT2>(k2));                               // + cross(r, imp)[c]
-					if (c < 3) { lin_w[4 * body + c] = ln; ang_w[4 * body + c] = an; }
-					else if (side == 0)
-					{
-						const float ns = isum + impulse;
-						S.pool[(int)(e_cur & 0xFFFF) * LROW + 5] = ns;
-						if (meta & LM_NORMAL) S.cisum[(meta >> 24) & 255] = ns;
-					}
-				}
-				e_cur = e_nxt; e_nxt = e_nn;
-				ts = nts; fmn = nfmn; fmx = nfmx; effmass = neff; isum = nisum; meta = nmeta; rv = nrv; n = nn; Ix = nIx; Iy = nIy; Iz = nIz; minv = nminv;
+				step(A);
+				if (L + 1 > nlev_lin) break;
+				fetch(A, e_a); e_b = entry(L + 3);
+				__builtin_amdgcn_wave_barrier();
+				step(Bs);
 			}
 		}
 		__builtin_amdgcn_wave_barrier();
+		if (stats) { const long long t = clock64(); cyc_lin += t - t_mark; t_mark = t; }
 		// (3) angular rows, step by step (LimitAngular::Iter physics.h:251-265), same lane mapping and pipeline
 		if (!(a.dbg & 4) && nlev_ang > 0)
 		{
-			const int pslot = lane >> 3;
+			struct aset { unsigned e; float ax, ts, mn, mx, s2t, torque, Ix, Iy, Iz; };
 			auto entry = [&](int L) -> unsigned {
-				if (L > nlev_ang) return 0xFFFFFFFFu;
-				const int idx = S.astart[L] + pslot;
-				return idx < S.astart[L + 1] ? S.aorder[idx] : 0xFFFFFFFFu;
+				if (L > nlev_ang) return S.aorder[MAXA2];
+				int lo, hi;
+				if (L < 63) { lo = __builtin_amdgcn_readlane(ls_ang, L); hi = __builtin_amdgcn_readlane(ls_ang, L + 1); }
+				else { lo = S.astart[L]; hi = S.astart[L + 1]; }
+				const int idx = lo + pslot;
+				return S.aorder[idx < hi ? idx : MAXA2];
 			};
-			unsigned e_cur = entry(1), e_nxt = entry(2);
-			float ax = 0, ts = 0, mn = 0, mx = 0, s2t = 0, torque = 0, Ix = 0, Iy = 0, Iz = 0;
-			auto fetch = [&](unsigned e, float &ax_, float &ts_, float &mn_, float &mx_, float &s2t_, float &tq_, float &Ix_, float &Iy_, float &Iz_) {
-				if (e != 0xFFFFFFFFu)
-				{
-					const float *R = S.arec + (int)(e & 0xFFFF) * AROW;
-					const int body = side ? (int)(e >> 24) : (int)((e >> 16) & 255);
-					ax_ = R[c]; ts_ = R[4 + tsoff]; mn_ = R[6]; mx_ = R[7]; s2t_ = R[8]; tq_ = R[9];
-					Ix_ = 0; Iy_ = 0; Iz_ = 0;
-					if (body != 255) { Ix_ = I_w[12 * body + c]; Iy_ = I_w[12 * body + 4 + c]; Iz_ = I_w[12 * body + 8 + c]; }
-				}
+			auto fetch = [&](aset &r, unsigned e) {
+				r.e = e;
+				const float *R = S.arec + (int)(e & 0xFFFF) * AROW;
+				const int body = side ? (int)(e >> 24) : (int)((e >> 16) & 255);
+				r.ax = R[c]; r.ts = R[4 + tsoff]; r.mn = R[6]; r.mx = R[7]; r.s2t = R[8]; r.torque = R[9];
+				r.Ix = I_w[12 * body + c]; r.Iy = I_w[12 * body + 4 + c]; r.Iz = I_w[12 * body + 8 + c];
 			};
-			fetch(e_cur, ax, ts, mn, mx, s2t, torque, Ix, Iy, Iz);
-			for (int L = 1; L <= nlev_ang; L++)
+			auto step = [&](const aset &r) {
+				const int body = side ? (int)(r.e >> 24) : (int)((r.e >> 16) & 255);
+				const float av = ang_w[4 * body + c];
+				const float w = (r.Ix * dpp<QP_BC0>(av) + r.Iy * dpp<QP_BC1>(av)) + r.Iz * dpp<QP_BC2>(av);
+				const float p = w * r.ax;
+				const float sp = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);                       // dot(Iinv*angular_momentum, axis) of this side
+				const float u = __int_as_float(__float_as_int(body != IDLE_BODY ? sp : 0.0f) ^ sidesign);     // a missing body contributes exactly 0
+				const float currentspin = u + pair_swap(u);                                                // spin1 - spin0
+				const float dspin = r.ts - currentspin;
+				float dtorque = dspin * r.s2t;
+				dtorque = clamp_med3(dtorque, r.mn - r.torque, r.mx - r.torque);
+				if (r.ts == -FLT_MAX) dtorque = 0.0f;                                                      // disabled row (physics.h:252)
+				const float an = av + __int_as_float(__float_as_int(r.ax * dtorque) ^ sidesign);           // rb0: a - axis*dtorque, rb1: a + axis*dtorque
+				if (c < 3) { if (body != IDLE_BODY) ang_w[4 * body + c] = an; }
+				else if (side == 0) S.arec[(int)(r.e & 0xFFFF) * AROW + 9] = r.torque + dtorque;
+			};
+			aset A, Bs;
+			fetch(A, entry(1));
+			unsigned e_b = entry(2), e_a;
+			for (int L = 1; L <= nlev_ang; L += 2)
 			{
-				float nax = 0, nts = 0, nmn = 0, nmx = 0, ns2t = 0, ntq = 0, nIx = 0, nIy = 0, nIz = 0;
-				fetch(e_nxt, nax, nts, nmn, nmx, ns2t, ntq, nIx, nIy, nIz);
-				const unsigned e_nn = entry(L + 2);
+				fetch(Bs, e_b); e_a = entry(L + 2);
 				__builtin_amdgcn_wave_barrier();
-				if (e_cur != 0xFFFFFFFFu && !(ts == -FLT_MAX))
-				{
-					const int body = side ? (int)(e_cur >> 24) : (int)((e_cur >> 16) & 255);
-					const bool bv = body != 255;
-					const float av = bv ? ang_w[4 * body + c] : 0.0f;
-					const float w = (Ix * dpp<QP_BC0>(av) + Iy * dpp<QP_BC1>(av)) + Iz * dpp<QP_BC2>(av);
-					const float p = w * ax;
-					const float sp = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);                       // dot(Iinv*angular_momentum, axis) of this side
-					const float u = __int_as_float(__float_as_int(bv ? sp : 0.0f) ^ sidesign);
-					const float currentspin = u + pair_swap(u);                                                // spin1 - spin0
-					const float dspin = ts - currentspin;
-					float dtorque = dspin * s2t;
-					dtorque = clamp_med3(dtorque, mn - torque, mx - torque);
-					const float an = av + __int_as_float(__float_as_int(ax * dtorque) ^ sidesign);             // rb0: a - axis*dtorque, rb1: a + axis*dtorque
-					if (c < 3) { if (bv) ang_w[4 * body + c] = an; }
-					else if (side == 0) S.arec[(int)(e_cur & 0xFFFF) * AROW + 9] = torque + dtorque;
-				}
-				e_cur = e_nxt; e_nxt = e_nn;
-				ax = nax; ts = nts; mn = nmn; mx = nmx; s2t = ns2t; torque = ntq; Ix = nIx; Iy = nIy; Iz = nIz;
+				step(A);
+				if (L + 1 > nlev_ang) break;
+				fetch(A, e_a); e_b = entry(L + 3);
+				__builtin_amdgcn_wave_barrier();
+				step(Bs);
 			}
 		}
 		__syncthreads();
+		if (stats) { const long long t = clock64(); cyc_ang += t - t_mark; t_mark = t; }
 		if (sweep + 1 == ph.iterations && lane < nb)
 		{
 			// rbcalcnextpose physics.h:522-531 with rkupdateq :211-218 (momentum-preserving RK4 on the quaternion)
@@ -761,6 +782,13 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		}
 	}
 
+	if (stats && lane == 0)
+	{
+		float *o = scr + (size_t)(a.scratch_stride - 1) * CROW;
+		int mc = 0; for (int k = 0; k < nb; k++) if (S.ccnt[k] > mc) mc = S.ccnt[k];
+		o[0] += 1.0f; o[1] += (float)cyc_chain; o[2] += (float)cyc_lin; o[3] += (float)cyc_ang; o[4] += (float)(clock64() - t_begin);
+		o[5] += (float)nlev_lin; o[6] += (float)nlev_ang; o[7] += (float)mc; o[8] += (float)n1; o[9] += (float)n2; o[10] += (float)na; o[11] += (float)(t_begin);
+	}
 	// ---- rbupdatepose (physics.h:533-541), SanityCheck (physmodel.h:437-442), optional momentum reset (handtrack.h:686-687) ----
 	if (lane < nb)
 	{

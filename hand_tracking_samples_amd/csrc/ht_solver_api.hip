@@ -273,3 +273,19 @@ extern "C" int ht_stage_scratch_unibody(ht_ctx *ctx, const float *analysis, int 
 	HIPCHK(ctx, hipGetLastError());
 	return HT_OK;
 }
+
+// Timing experiments only (HT_DEBUG_SKIP & 2048): per-frame k_solve statistics accumulated in the last scratch record of each frame:
+// launches, cycles in chains / two-body linear / angular, cycles in all sweeps, steps (linear, angular), longest chain, row counts.
+extern "C" int ht_debug_solve_stats(ht_ctx *ctx, int B, float *out, int reset)
+{
+	if (!ctx || !ctx->ready || B < 1 || B > ctx->B) return HT_ERR_ARG;
+	const int stride = scratch_stride(ctx);
+	if (hipStreamSynchronize(ctx->stream) != hipSuccess) return HT_ERR_HIP;
+	for (int b = 0; b < B; b++)
+	{
+		float *src = ctx->d_scratch + ((size_t)b * stride + (stride - 1)) * 12;
+		if (out && hipMemcpy(out + (size_t)b * 12, src, 12 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return HT_ERR_HIP;
+		if (reset && hipMemset(src, 0, 12 * sizeof(float)) != hipSuccess) return HT_ERR_HIP;
+	}
+	return HT_OK;
+}

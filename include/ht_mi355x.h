@@ -139,6 +139,9 @@ int ht_stage_scratch_unibody(ht_ctx *ctx, const float *analysis, int B, int n_un
  * on = 2: every phase is bracketed and the side streams are serialised (phase table). ----- */
 int ht_profile_enable(ht_ctx *ctx, int on);
 int ht_profile_read(ht_ctx *ctx, int reset, int max_entries, char *names, int name_stride, float *total_ms, int *launches, int *n_entries);
+/* Tuning aid, no reference counterpart: with the environment variable HT_DEBUG_SKIP=2048 every k_solve launch accumulates per-frame
+ * statistics (launches, cycles in chains / two-body linear / angular rows / all sweeps, steps, longest chain, row counts), 12 floats per frame. */
+int ht_debug_solve_stats(ht_ctx *ctx, int B, float *out, int reset);
 
 #ifdef __cplusplus
 }

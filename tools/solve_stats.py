@@ -1,0 +1,34 @@
+"""Per-frame k_solve cycle statistics on the bench workload (tuning aid).  Run with HT_DEBUG_SKIP=2048."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HT_DEBUG_SKIP", "2048")
+from hand_tracking_samples_amd import native, weights  # noqa: E402
+
+B = 1024
+d = np.load(os.path.join(ROOT, "tests", "golden", "frames256.npz"))
+idx = np.arange(B) % len(d["depth"])
+depth, cams, start = d["depth"][idx], d["cam"][idx], d["startpose"][idx]
+ctx = native.Context(os.path.join(ROOT, "tests", "golden", "model_hand17.htfx"), B)
+ctx.load_weights(weights.make_cnnb())
+ctx.set_params(microforce=3.0, mainthreadpasses=3)
+ctx.debug_solve_stats(B, reset=True)
+for it in range(2):
+    ctx.tracker_reset(start)
+    ctx.update_sync(depth, cams)
+    st = ctx.debug_solve_stats(B, reset=True)
+n = st[:, 0:1]
+print("launches/frame", np.unique(st[:, 0]))
+names = ["chain", "linear", "angular", "sweeps_total"]
+for k, nm in enumerate(names):
+    c = st[:, 1 + k]
+    print("%-12s cycles/frame: mean %.0f  p50 %.0f  p90 %.0f  max %.0f (frame %d)" % (nm, c.mean(), np.median(c), np.percentile(c, 90), c.max(), c.argmax()))
+for k, nm in zip(range(5, 11), ["steps_lin", "steps_ang", "maxchain", "n1", "n2", "na"]):
+    c = st[:, k] / st[:, 0]
+    print("%-12s per launch: mean %.1f  p90 %.1f  max %.1f" % (nm, c.mean(), np.percentile(c, 90), c.max()))
+w = st[:, 4].argmax()
+print("worst frame", w, st[w])
