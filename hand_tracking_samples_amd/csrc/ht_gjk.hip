@@ -40,11 +40,20 @@ __device__ __forceinline__ v3 support_inner(const support_t &s, v3 dir)
 	const float4 *vs = g_sm + s.voff;
 	float4 q0 = vs[0];
 	float best = dot(V3(q0.x, q0.y, q0.z), dl); int bi = 0;
-	for (int i = 1; i < s.n; i++)
+	// six vertices per trip (162 and 258 are multiples of 6): the LDS reads of a trip are issued together, then compared in index order.
+	// Indices past the end are clamped to the last vertex, which cannot displace an earlier equal maximum.
+	const int last = s.n - 1;
+	for (int i = 1; i < s.n; i += 6)
 	{
-		float4 q = vs[i];
-		float d = dot(V3(q.x, q.y, q.z), dl);
-		if (best < d) { best = d; bi = i; }
+		float4 q[6];
+#pragma unroll
+		for (int k = 0; k < 6; k++) q[k] = vs[min(i + k, last)];
+#pragma unroll
+		for (int k = 0; k < 6; k++)
+		{
+			const float d = dot(V3(q[k].x, q[k].y, q[k].z), dl);
+			if (best < d) { best = d; bi = min(i + k, last); }
+		}
 	}
 	float4 q = vs[bi];
 	return s.pos + qrot(s.q, V3(q.x, q.y, q.z));
@@ -366,8 +375,9 @@ __device__ __forceinline__ support_t bcast(const support_t &s, int src)
 }
 // One GJK run per lane (lanes with run == false idle), then the expanding polytope for the lanes that need it, one pair at a time on the
 // whole wave.  On return status is 0 (hit valid) or 1 (far apart).
-__device__ void separated_wave(bool run, const support_t &A, const support_t &B, float cutoff, epa_mem &em, int lane, int &status, gjk_hit &hit, int dbg)
+__device__ void separated_wave(bool run, const support_t &A, const support_t &B, float cutoff, epa_mem &em, int lane, int &status, gjk_hit &hit, int dbg, long long *cyc = nullptr)
 {
+	const long long t0 = cyc ? clock64() : 0;
 	simplex tet;
 	tet.count = 0;
 	for (int i = 0; i < 4; i++) { tet.W[i].a = tet.W[i].b = tet.W[i].p = V3(0, 0, 0); tet.W[i].t = 0; }
@@ -375,6 +385,8 @@ __device__ void separated_wave(bool run, const support_t &A, const support_t &B,
 	status = 1;
 	if (run) status = gjk_run(A, B, cutoff, hit, tet);
 	unsigned long long need = __ballot(run && status == 2);
+	const long long t1 = cyc ? clock64() : 0;
+	if (cyc) { cyc[0] += t1 - t0; cyc[2] += __popcll(need); }
 	while (need)
 	{
 		const int src = __ffsll((long long)need) - 1;
@@ -394,6 +406,7 @@ __device__ void separated_wave(bool run, const support_t &A, const support_t &B,
 			status = 0;
 		}
 	}
+	if (cyc) cyc[1] += clock64() - t1;
 }
 
 // ------------------------------------------------------------------------------------------------- k_contacts
@@ -445,6 +458,7 @@ __global__ __launch_bounds__(64 * GJK_FRAMES) void k_contacts(ht_model_dev M, co
 	}
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the candidate list is read back by other lanes of this wave
 	__builtin_amdgcn_wave_barrier();
+	long long cyc[3] = { 0, 0, 0 }, cycj[3] = { 0, 0, 0 }; const bool stats = (dbg & 2048) != 0; const long long t_begin = stats ? clock64() : 0; int njig = 0;
 	int nout = 0;                       // contacts written so far for this frame (wave-uniform)
 	for (int base = 0; base < ncand; base += 64)
 	{
@@ -457,11 +471,12 @@ __global__ __launch_bounds__(64 * GJK_FRAMES) void k_contacts(ht_model_dev M, co
 		Bs.voff = M.vert_off[j]; Bs.n = M.vert_off[j + 1] - M.vert_off[j]; Bs.pos = V3(P[j][0], P[j][1], P[j][2]); Bs.q = V4(P[j][3], P[j][4], P[j][5], P[j][6]); Bs.outer = 0; Bs.opos = V3(0, 0, 0); Bs.oq = V4(0, 0, 0, 1);
 		gjk_hit hits[5];
 		int hc = 0, status;
-		separated_wave(keep, A, Bs, (dbg & 16) ? 0.0f : driftmax, em, lane, status, hits[0], dbg);
+		separated_wave(keep, A, Bs, (dbg & 16) ? 0.0f : driftmax, em, lane, status, hits[0], dbg, stats ? cyc : nullptr);
 		const bool touching = keep && status == 0 && !(hits[0].separation > driftmax);
 		if (touching) hc = 1;
 		const float dmin = fminf(M.bodyc[i * HT_BC + HT_BC_DIAM], M.bodyc[j * HT_BC + HT_BC_DIAM]);
 		const bool jig = touching && !(dmin < 0.049f);      // otherwise every jiggle sample is rejected by the 0.05 m proximity test (see header)
+		if (stats) njig += __popcll(__ballot(jig));
 		if (__any(jig))
 		{
 			const v3 n = jig ? hits[0].normal : V3(0, 0, 1);
@@ -476,7 +491,7 @@ __global__ __launch_bounds__(64 * GJK_FRAMES) void k_contacts(ht_model_dev M, co
 				xf ar = mul(mul(mul(XF(n * 0.2f, id), XF(-pivot, id)), XF(V3(0, 0, 0), jiggle)), XF(pivot, id));
 				support_t AJ = A; AJ.outer = 1; AJ.opos = ar.p; AJ.oq = ar.q;
 				gjk_hit hj; int st;
-				separated_wave(jig, AJ, Bs, 0.0f, em, lane, st, hj, dbg);
+				separated_wave(jig, AJ, Bs, 0.0f, em, lane, st, hj, dbg, stats ? cycj : nullptr);
 				if (jig)
 				{
 					hj.normal = n;
@@ -509,6 +524,12 @@ __global__ __launch_bounds__(64 * GJK_FRAMES) void k_contacts(ht_model_dev M, co
 		nout += total;
 	}
 	if (lane == 0) ncontacts[b] = nout < HT_MAXCONTACT ? nout : HT_MAXCONTACT;
+	if (stats && lane == 0 && nout < HT_MAXCONTACT - 1)      // timing experiments: statistics accumulate in the last contact slot
+	{
+		float *o = contacts + ((size_t)b * HT_MAXCONTACT + HT_MAXCONTACT - 1) * HT_CONTACT;
+		o[0] += 1.0f; o[1] += (float)cyc[0]; o[2] += (float)cyc[1]; o[3] += (float)cyc[2]; o[4] += (float)cycj[0]; o[5] += (float)cycj[1]; o[6] += (float)cycj[2];
+		o[7] += (float)(clock64() - t_begin); o[8] += (float)ncand; o[9] += (float)njig; o[10] += (float)nout;
+	}
 }
 
 size_t ht_contacts_workspace_bytes(int B) { (void)B; return 16; }      // the polytope mesh lives in LDS now

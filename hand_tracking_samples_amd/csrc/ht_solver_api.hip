@@ -289,3 +289,17 @@ extern "C" int ht_debug_solve_stats(ht_ctx *ctx, int B, float *out, int reset)
 	}
 	return HT_OK;
 }
+// Same for k_contacts (last contact slot of each frame): launches, cycles in first GJK / its polytope runs, polytope runs, cycles in the
+// jiggle GJK runs / their polytope runs, polytope runs, total cycles, candidate pairs, pairs that jiggle, contacts.
+extern "C" int ht_debug_contact_stats(ht_ctx *ctx, int B, float *out, int reset)
+{
+	if (!ctx || !ctx->ready || B < 1 || B > ctx->B) return HT_ERR_ARG;
+	if (hipDeviceSynchronize() != hipSuccess) return HT_ERR_HIP;
+	for (int b = 0; b < B; b++)
+	{
+		float *src = ctx->d_contacts + ((size_t)b * HT_MAXCONTACT + HT_MAXCONTACT - 1) * HT_CONTACT;
+		if (out && hipMemcpy(out + (size_t)b * 12, src, 12 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return HT_ERR_HIP;
+		if (reset && hipMemset(src, 0, 12 * sizeof(float)) != hipSuccess) return HT_ERR_HIP;
+	}
+	return HT_OK;
+}

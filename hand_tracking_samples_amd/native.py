@@ -21,7 +21,7 @@ SYMBOLS = (
     "ht_cnn_load_weights", "ht_cnn_eval", "ht_cnn_eval_dev",
     "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev",
     "ht_stage_prepare", "ht_stage_decode", "ht_stage_fit_error", "ht_stage_cloud_rows", "ht_stage_contacts", "ht_stage_fit",
-    "ht_stage_multistep", "ht_stage_scratch_unibody", "ht_profile_enable", "ht_profile_read", "ht_debug_solve_stats",
+    "ht_stage_multistep", "ht_stage_scratch_unibody", "ht_profile_enable", "ht_profile_read", "ht_debug_solve_stats", "ht_debug_contact_stats",
 )
 
 
@@ -82,6 +82,7 @@ def load(build_if_missing=True):
     L.ht_profile_enable.argtypes = [vp, C.c_int]
     L.ht_profile_read.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_int, fp, ip, ip]
     L.ht_debug_solve_stats.argtypes = [vp, C.c_int, fp, C.c_int]
+    L.ht_debug_contact_stats.argtypes = [vp, C.c_int, fp, C.c_int]
     for name in SYMBOLS:
         if name != "ht_last_error":
             getattr(L, name).restype = C.c_int
@@ -265,4 +266,10 @@ class Context:
         """Per-frame k_solve statistics [B,12] (only filled when HT_DEBUG_SKIP=2048 is set in the environment)."""
         out = np.zeros((B, 12), np.float32)
         self._chk(self.L.ht_debug_solve_stats(self.h, int(B), _f(out), int(reset)))
+        return out
+
+    def debug_contact_stats(self, B, reset=True):
+        """Per-frame k_contacts statistics [B,12] (only filled when HT_DEBUG_SKIP=2048 is set in the environment)."""
+        out = np.zeros((B, 12), np.float32)
+        self._chk(self.L.ht_debug_contact_stats(self.h, int(B), _f(out), int(reset)))
         return out

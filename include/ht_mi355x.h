@@ -142,6 +142,7 @@ int ht_profile_read(ht_ctx *ctx, int reset, int max_entries, char *names, int na
 /* Tuning aid, no reference counterpart: with the environment variable HT_DEBUG_SKIP=2048 every k_solve launch accumulates per-frame
  * statistics (launches, cycles in chains / two-body linear / angular rows / all sweeps, steps, longest chain, row counts), 12 floats per frame. */
 int ht_debug_solve_stats(ht_ctx *ctx, int B, float *out, int reset);
+int ht_debug_contact_stats(ht_ctx *ctx, int B, float *out, int reset);      /* same for k_contacts */
 
 #ifdef __cplusplus
 }

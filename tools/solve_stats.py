@@ -16,11 +16,12 @@ depth, cams, start = d["depth"][idx], d["cam"][idx], d["startpose"][idx]
 ctx = native.Context(os.path.join(ROOT, "tests", "golden", "model_hand17.htfx"), B)
 ctx.load_weights(weights.make_cnnb())
 ctx.set_params(microforce=3.0, mainthreadpasses=3)
-ctx.debug_solve_stats(B, reset=True)
+ctx.debug_solve_stats(B, reset=True); ctx.debug_contact_stats(B, reset=True)
 for it in range(2):
     ctx.tracker_reset(start)
     ctx.update_sync(depth, cams)
     st = ctx.debug_solve_stats(B, reset=True)
+    cs = ctx.debug_contact_stats(B, reset=True)
 n = st[:, 0:1]
 print("launches/frame", np.unique(st[:, 0]))
 names = ["chain", "linear", "angular", "sweeps_total"]
@@ -32,3 +33,8 @@ for k, nm in zip(range(5, 11), ["steps_lin", "steps_ang", "maxchain", "n1", "n2"
     print("%-12s per launch: mean %.1f  p90 %.1f  max %.1f" % (nm, c.mean(), np.percentile(c, 90), c.max()))
 w = st[:, 4].argmax()
 print("worst frame", w, st[w])
+
+print("---- k_contacts (sum over %s launches per frame)" % np.unique(cs[:, 0]))
+for k, nm in zip(range(1, 11), ["gjk1_cycles", "epa1_cycles", "epa1_runs", "gjkJ_cycles", "epaJ_cycles", "epaJ_runs", "total_cycles", "candidates", "jiggle_pairs", "contacts"]):
+    c = cs[:, k]
+    print("%-13s per frame: mean %.0f  p50 %.0f  p90 %.0f  max %.0f (frame %d)" % (nm, c.mean(), np.median(c), np.percentile(c, 90), c.max(), c.argmax()))
