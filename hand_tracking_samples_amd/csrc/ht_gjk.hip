@@ -311,18 +311,22 @@ __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 
 		if (nv >= EPA_MAXV) break;
 		const int vid = nv;
 		m.vx[nv] = v.x; m.vy[nv] = v.y; m.vz[nv] = v.z; nv++;
-		// which triangles see the new vertex (independent of the surgery order: vertices of existing triangles never change)
-		for (int i = lane; i < nt; i += 64) m.ab[i] = (!tri_dead(m, i) && above(m, i, v, 0.01f * epsilon)) ? 1 : 0;
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-		__builtin_amdgcn_wave_barrier();
+		// Which triangles see the new vertex is tested one triangle per lane (vertices of existing triangles never change, and a triangle
+		// that died during the surgery is skipped when its turn comes); the reference's descending scan then only visits the set bits.
 		bool okk = true;
-		int j = nt;
-		while (j--)
+		const int nt0 = nt;
+		for (int base = ((nt0 - 1) >> 6) << 6; base >= 0; base -= 64)
 		{
-			if (tri_dead(m, j)) continue;
-			if (m.ab[j]) okk = okk && extrude(m, nt, j, vid);
+			const int i = base + lane;
+			unsigned long long mask = __ballot(i < nt0 && !tri_dead(m, i) && above(m, i, v, 0.01f * epsilon));
+			while (mask)
+			{
+				const int bit = 63 - __clzll((long long)mask);
+				mask &= ~(1ull << bit);
+				if (!tri_dead(m, base + bit)) okk = okk && extrude(m, nt, base + bit, vid);
+			}
 		}
-		j = nt;
+		int j = nt;
 		while (okk && j--)
 		{
 			if (tri_dead(m, j)) continue;
@@ -336,12 +340,19 @@ __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 
 			}
 		}
 		if (!okk) break;
-		j = nt;
-		while (j--)
+		// compaction (hull.h:300-306): dead triangles are found one per lane; moving the last (live) triangle into a dead slot never
+		// changes which of the lower slots are dead, so the descending scan again only visits the set bits
+		for (int base = ((nt - 1) >> 6) << 6; base >= 0; base -= 64)
 		{
-			if (!tri_dead(m, j)) continue;
-			swapn(m, j, nt - 1);
-			nt--;
+			const int i = base + lane;
+			unsigned long long mask = __ballot(i < nt && tri_dead(m, i));
+			while (mask)
+			{
+				const int bit = 63 - __clzll((long long)mask);
+				mask &= ~(1ull << bit);
+				swapn(m, base + bit, nt - 1);
+				nt--;
+			}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 		__builtin_amdgcn_wave_barrier();
