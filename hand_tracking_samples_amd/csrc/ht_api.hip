@@ -74,7 +74,7 @@ static int load_model(ht_ctx *ctx, const char *path)
 		snprintf(nm, sizeof nm, "b%d/planes", b); const fx_arr *pl = need(nm); if (!pl) return HT_ERR_IO;
 		m.vert_off[b] = (int)verts.size(); m.plane_off[b] = (int)planes.size();
 		float diam2 = 0.0f;
-		for (uint32_t i = 0; i < v->dims[0]; i++) verts.push_back(make_float4(v->f()[3 * i], v->f()[3 * i + 1], v->f()[3 * i + 2], 0.0f));
+		for (uint32_t i = 0; i < v->dims[0]; i++) { float4 q = make_float4(v->f()[3 * i], v->f()[3 * i + 1], v->f()[3 * i + 2], 0.0f); memcpy(&q.w, &i, 4); verts.push_back(q); }      // w = index within the body (bit pattern), used by the support scans
 		for (uint32_t i = 0; i < v->dims[0]; i++) for (uint32_t j = i + 1; j < v->dims[0]; j++)
 		{
 			float dx = v->f()[3 * i] - v->f()[3 * j], dy = v->f()[3 * i + 1] - v->f()[3 * j + 1], dz = v->f()[3 * i + 2] - v->f()[3 * j + 2];

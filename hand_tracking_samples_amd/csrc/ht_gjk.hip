@@ -27,6 +27,7 @@
 
 extern __shared__ __attribute__((aligned(16))) float4 g_sm[];      // [0, nvert): collision vertices of all bodies; then per-wave areas
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct support_t { int voff, n; v3 pos; v4 q; int outer; v3 opos; v4 oq; };
 struct mkpoint { v3 a, b, p; float t; };
 struct simplex { v3 v; mkpoint W[4]; int count; };
@@ -40,20 +41,30 @@ __device__ __forceinline__ v3 support_inner(const support_t &s, v3 dir)
 	const float4 *vs = g_sm + s.voff;
 	float4 q0 = vs[0];
 	float best = dot(V3(q0.x, q0.y, q0.z), dl); int bi = 0;
+	const f32x2 dlxy = { dl.x, dl.y };
 	// six vertices per trip (162 and 258 are multiples of 6): the LDS reads of a trip are issued together, then compared in index order.
-	// Indices past the end are clamped to the last vertex, which cannot displace an earlier equal maximum.
-	const int last = s.n - 1;
-	for (int i = 1; i < s.n; i += 6)
+	// Vertex 0 is simply tested again (it cannot displace itself); a tail shorter than 6 is handled one by one.
+	int i = 0;
+	for (; i + 6 <= s.n; i += 6)
 	{
-		float4 q[6];
-#pragma unroll
-		for (int k = 0; k < 6; k++) q[k] = vs[min(i + k, last)];
+		const float4 *g = vs + i;
+		float d[6]; int id[6];
 #pragma unroll
 		for (int k = 0; k < 6; k++)
 		{
-			const float d = dot(V3(q[k].x, q[k].y, q[k].z), dl);
-			if (best < d) { best = d; bi = min(i + k, last); }
+			const float4 q = g[k];
+			const f32x2 xy = f32x2{ q.x, q.y } * dlxy;       // packed multiply on the register pair the 128-bit read delivers
+			d[k] = (xy.x + xy.y) + q.z * dl.z;                // = dot(vertex, dl) in the reference's order
+			id[k] = __float_as_int(q.w);                       // w carries the vertex index
 		}
+#pragma unroll
+		for (int k = 0; k < 6; k++) if (best < d[k]) { best = d[k]; bi = id[k]; }
+	}
+	for (; i < s.n; i++)
+	{
+		const float4 q = vs[i];
+		const float d = dot(V3(q.x, q.y, q.z), dl);
+		if (best < d) { best = d; bi = i; }
 	}
 	float4 q = vs[bi];
 	return s.pos + qrot(s.q, V3(q.x, q.y, q.z));
