@@ -97,26 +97,55 @@ __device__ __forceinline__ void closest_feature(const ht_model_dev &M, const flo
 // ------------------------------------------------------------------------------------------------- k_cloud_rows
 // mode 0: forcelimit (-1,1) (CloudConstraints as is)     1: FitPointCloud scaling (physmodel.h:347)
 //      2: MultiStepSim scaling (handtrack.h:656,681)     3: UnibodyFit scaling (handtrack.h:461)
-__global__ __launch_bounds__(64) void k_cloud_rows(ht_model_dev M, const float *__restrict__ state, const float4 *__restrict__ pts, const int *__restrict__ npts,
-                                                   const float *__restrict__ cams, const int *__restrict__ active_flag, int stride, int use_cam_origin, int mode,
-                                                   float microforce, float weak_force, float cf_max_point, float cf_max_sum, float unibody_force,
-                                                   float *__restrict__ rows, int *__restrict__ nrows)
+// One block per frame.  Points are first binned by the body the cheap sphere test of physmodel.h:140-147 prefers, so that the 64 points
+// a wave then works on sit on the same part of the hand and cull the same bodies: the plane loops below are wave-uniform and run for a
+// body as soon as one lane needs it.  The grouping changes which bodies a wave evaluates, never a point's result.
+#define CR_THREADS 256
+__global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const float *__restrict__ state, const float4 *__restrict__ pts, const int *__restrict__ npts,
+                                                           const float *__restrict__ cams, const int *__restrict__ active_flag, int stride, int use_cam_origin, int mode,
+                                                           float microforce, float weak_force, float cf_max_point, float cf_max_sum, float unibody_force,
+                                                           float *__restrict__ rows, int *__restrict__ nrows)
 {
 	__shared__ float tab[HT_MAXNB * BT];
-	const int b = blockIdx.y, lane = threadIdx.x;
+	__shared__ unsigned short perm[HT_MAXPTS];
+	__shared__ unsigned char key[HT_MAXPTS];
+	__shared__ int bin[HT_MAXNB];
+	const int b = blockIdx.x, t = threadIdx.x;
 	const int n = npts[b];
 	const int nsub = (n + stride - 1) / stride;
-	if (blockIdx.x == 0 && lane == 0) nrows[b] = (active_flag && !active_flag[b]) ? 0 : nsub;
+	if (t == 0) nrows[b] = (active_flag && !active_flag[b]) ? 0 : nsub;
 	if (active_flag && !active_flag[b]) return;
-	const int i = blockIdx.x * 64 + lane;
-	if (blockIdx.x * 64 >= nsub) return;
-	body_table_build(M, state + (size_t)b * M.nb * HT_STATE_STRIDE, tab, lane);
+	if (t < 64) body_table_build(M, state + (size_t)b * M.nb * HT_STATE_STRIDE, tab, t);
+	if (t < HT_MAXNB) bin[t] = 0;
 	__syncthreads();
-	const bool active = i < nsub;
-	float4 pv = pts[(size_t)b * HT_MAXPTS + (active ? i * stride : 0)];
-	const v3 v = V3(pv.x, pv.y, pv.z);
+	for (int i = t; i < nsub; i += CR_THREADS)
+	{
+		const float4 pv = pts[(size_t)b * HT_MAXPTS + i * stride];
+		const v3 v = V3(pv.x, pv.y, pv.z);
+		float dmin = FLT_MAX; int rb = 0;       // first loop of closest(): nearest body by the inner-sphere plane
+		for (int k = 0; k < M.nb; k++)
+		{
+			const float *tb = tab + k * BT;
+			const v3 nn = safenormalize(v - tab_pos(tb));
+			const float d = dot_plane(V4(nn, -dot(tab_pos(tb), nn) - tb[8]), v);
+			if (d < dmin) { dmin = d; rb = k; }
+		}
+		key[i] = (unsigned char)rb;
+		atomicAdd(&bin[rb], 1);
+	}
+	__syncthreads();
+	if (t == 0) { int acc = 0; for (int k = 0; k < M.nb; k++) { const int c = bin[k]; bin[k] = acc; acc += c; } }
+	__syncthreads();
+	for (int i = t; i < nsub; i += CR_THREADS) perm[atomicAdd(&bin[key[i]], 1)] = (unsigned short)i;
+	__syncthreads();
 	const float *cam = cams + (size_t)b * HT_CAM;
 	const v3 origin = use_cam_origin ? V3(cam[5], cam[6], cam[7]) : V3(0, 0, 0);
+	for (int base = 0; base < nsub; base += CR_THREADS)
+	{
+	const bool active = base + t < nsub;
+	const int i = active ? perm[base + t] : 0;
+	float4 pv = pts[(size_t)b * HT_MAXPTS + i * stride];
+	const v3 v = V3(pv.x, pv.y, pv.z);
 	int rb; v4 p; float dmin;
 	closest_feature(M, tab, active, v, rb, p, dmin);
 	if (rb < 0) rb = 0;
@@ -154,12 +183,12 @@ __global__ __launch_bounds__(64) void k_cloud_rows(ht_model_dev M, const float *
 		}
 		if (mine && ok) { hit = true; impact = tab_to_world(t, v0); }
 	}
-	if (!active) return;
-	const float *t = tab + rb * BT;
+	if (!active) continue;
+	const float *tr = tab + rb * BT;
 	v3 position1, normal;
-	if (hit) { position1 = tab_to_local(t, impact); normal = normalize(v - origin); }
-	else { position1 = tab_to_local(t, v - xyz(p) * dot_plane(p, v)); normal = xyz(p); }
-	const float targetdist = dot(tab_to_world(t, position1) - v, normal);                  // ConstrainAlongDirection physics.h:328-331
+	if (hit) { position1 = tab_to_local(tr, impact); normal = normalize(v - origin); }
+	else { position1 = tab_to_local(tr, v - xyz(p) * dot_plane(p, v)); normal = xyz(p); }
+	const float targetdist = dot(tab_to_world(tr, position1) - v, normal);                  // ConstrainAlongDirection physics.h:328-331
 	float fmin = -1.0f, fmax = 1.0f;
 	if (mode == 1) { float k = (rb == 0 || rb == 1 || rb == 2) ? weak_force : 1.0f; fmin = -1.0f * k * microforce; fmax = 1.0f * k * microforce; }
 	else if (mode == 2) { float cloudforce = fmin_std(cf_max_point, cf_max_sum / (float)n); float k = (rb == 0) ? 0.1f : 1.0f; fmin = -cloudforce * k; fmax = cloudforce * k; }
@@ -169,6 +198,7 @@ __global__ __launch_bounds__(64) void k_cloud_rows(ht_model_dev M, const float *
 	out[1] = make_float4(v.z, position1.x, position1.y, position1.z);
 	out[2] = make_float4(normal.x, normal.y, normal.z, targetdist);
 	out[3] = make_float4(0.0f, fmin_std(fmin, fmax), fmax_std(fmin, fmax), 0.0f);
+	}
 }
 
 // ------------------------------------------------------------------------------------------------- k_fit_error
@@ -270,8 +300,7 @@ __global__ __launch_bounds__(64) void k_chamber(ht_model_dev M, const float *__r
 void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const float *cams, const int *active_flag, int stride, int use_cam_origin, int mode,
                           const ht_params &par, float *rows, int *nrows, int B, hipStream_t s)
 {
-	dim3 grid((HT_MAXPTS / stride + 63) / 64, B);
-	hipLaunchKernelGGL(k_cloud_rows, grid, dim3(64), 0, s, M, state, pts, npts, cams, active_flag, stride, use_cam_origin, mode, par.microforce, par.physics_weak_force,
+	hipLaunchKernelGGL(k_cloud_rows, dim3(B), dim3(CR_THREADS), 0, s, M, state, pts, npts, cams, active_flag, stride, use_cam_origin, mode, par.microforce, par.physics_weak_force,
 	                   par.cloudforce_max_point, par.cloudforce_max_sum, par.unibody_force, rows, nrows);
 }
 void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, float scale, float *err, int B, hipStream_t s)
