@@ -72,38 +72,7 @@ struct lds_t
 	float pool[POOL_FLOATS] __attribute__((aligned(16)));
 };
 
-// ---- DPP helpers (quad layout) -------------------------------------------------------------------
-#define QP_BC0 0x00        // quad_perm:[0,0,0,0]
-#define QP_BC1 0x55        // quad_perm:[1,1,1,1]
-#define QP_BC2 0xAA        // quad_perm:[2,2,2,2]
-#define QP_BC3 0xFF        // quad_perm:[3,3,3,3]
-#define QP_ROT1 0xC9       // quad_perm:[1,2,0,3]: lane c reads component (c+1)%3
-#define QP_ROT2 0xD2       // quad_perm:[2,0,1,3]: lane c reads component (c+2)%3
-#define DPP_ROW_SHL4 0x104 // lane i reads lane i+4 of its 16-lane row
-#define DPP_ROW_SHR4 0x114 // lane i reads lane i-4
-template <int CTRL> __device__ __forceinline__ float dpp(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true)); }
-// value of the same component held by the other quad of a lane pair (quads 2p and 2p+1)
-__device__ __forceinline__ float pair_swap(float v)
-{
-	int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_SHL4, 0xF, 0x5, false);       // quads 0 and 2 of a row read lane+4
-	t = __builtin_amdgcn_update_dpp(t, __float_as_int(v), DPP_ROW_SHR4, 0xF, 0xA, false);           // quads 1 and 3 read lane-4
-	return __int_as_float(t);
-}
-// max(lo, min(hi, x)) for lo <= hi in one instruction; equals the reference's std::min/std::max pair except for the sign of a zero
-// result and NaN operands (a NaN impulse ends in the SanityCheck reset either way)
-__device__ __forceinline__ float clamp_med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
-// x / y as the IEEE fp32 division expands (reciprocal estimate, one Newton step, quotient with two residual corrections)
-__device__ __forceinline__ float div_ieee(float x, float y)
-{
-	float r = __builtin_amdgcn_rcpf(y);
-	const float e = __fmaf_rn(-y, r, 1.0f);
-	r = __fmaf_rn(e, r, r);
-	float q = x * r;
-	float rem = __fmaf_rn(-y, q, x);
-	q = __fmaf_rn(rem, r, q);
-	rem = __fmaf_rn(-y, q, x);
-	return __fmaf_rn(rem, r, q);
-}
+#include "ht_quad.hpp"
 
 __device__ __forceinline__ v3 L3(const float *p) { return V3(p[0], p[1], p[2]); }
 __device__ __forceinline__ v4 L4(const float *p) { return V4(p[0], p[1], p[2], p[3]); }
@@ -593,25 +562,11 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			const int cnt = has ? S.ccnt[body] : 0, start = has ? S.cstart[body] : 0;
 			if (cnt > 0)
 			{
-				float l = lin_w[4 * body + c], av = ang_w[4 * body + c];             // lane 3 carries massinv / friction here and never stores
+				const float l = lin_w[4 * body + c], av = ang_w[4 * body + c];       // lane 3 carries massinv / friction here and never stores
 				const float minv = lin_w[4 * body + 3];
 				const float Ix = I_w[12 * body + c], Iy = I_w[12 * body + 4 + c], Iz = I_w[12 * body + 8 + c];
-				// one LimitLinear::Iter (physics.h:289-307) on this body: rv = r1[c] (lane 3: target speed), n = normal[c], t = (fmin*dt, fmax*dt, effmass, impulsesum)
-				auto row_step = [&](float rv, float n, float4 t) -> float {
-					const float w = (Ix * dpp<QP_BC0>(av) + Iy * dpp<QP_BC1>(av)) + Iz * dpp<QP_BC2>(av);      // (Iinv * angular_momentum)[c]
-					const float m1 = w * dpp<QP_ROT1>(rv), m2 = w * dpp<QP_ROT2>(rv);                          // w[c]*r1[c+1], w[c]*r1[c+2]
-					const float v1 = (dpp<QP_ROT1>(m1) - dpp<QP_ROT2>(m2)) + l * minv;                         // (cross(spin, r1) + lin*massinv)[c]
-					const float p = v1 * n;
-					const float vn = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);
-					const float impulsen = -dpp<QP_BC3>(rv) - vn;
-					float impulse = div_ieee(impulsen, t.z);
-					impulse = clamp_med3(impulse, t.x - t.w, t.y - t.w);
-					const float imp = n * impulse;
-					l = l + imp;
-					const float k1 = rv * dpp<QP_ROT1>(imp), k2 = rv * dpp<QP_ROT2>(imp);                      // r1[c]*imp[c+1], r1[c]*imp[c+2]
-					av = av + (dpp<QP_ROT1>(k1) - dpp<QP_ROT2>(k2));                                           // cross(r1, imp)[c]
-					return t.w + impulse;
-				};
+				quad_body qb = { l, av, minv, Ix, Iy, Iz };
+				auto row_step = [&](float rv, float n, float4 t) -> float { return quad_row_step(qb, rv, n, t); };
 				const int lane_off = c < 3 ? c : 3 + 4 * tsoff;                      // RemoveBias (physics.h:288): lane 3 switches to ts_post
 				const int nl = (start + cnt <= chcap) ? cnt : (start >= chcap ? 0 : chcap - start);
 				if (nl > 0)
@@ -630,7 +585,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 					float *rp = scr + (size_t)(start + k) * CROW;
 					rp[11] = row_step(rp[lane_off], rp[4 + c], *reinterpret_cast<const float4 *>(rp + 8));
 				}
-				if (c < 3) { lin_w[4 * body + c] = l; ang_w[4 * body + c] = av; }
+				if (c < 3) { lin_w[4 * body + c] = qb.l; ang_w[4 * body + c] = qb.av; }
 			}
 		}
 		__builtin_amdgcn_wave_barrier();

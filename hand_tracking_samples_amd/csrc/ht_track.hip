@@ -8,6 +8,7 @@
 //   PhysModel::GetPoseUser / SetPose           include/physmodel.h:433-435, third_party/physics.h:142
 #include "ht_device.hpp"
 #include "ht_launch.hpp"
+#include "ht_quad.hpp"
 
 __device__ __forceinline__ v3 G3(const float *p) { return V3(p[0], p[1], p[2]); }
 __device__ __forceinline__ v4 G4(const float *p) { return V4(p[0], p[1], p[2], p[3]); }
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 	const m3 tinv = GM(M.ub_tinv);
 	const m3 Iinv = world_inertia(ubq, tinv, minv);
 	(void)scratch; (void)scratch_stride;
-	__shared__ __attribute__((aligned(16))) float urow[HT_MAXPTS / 4][12];      // rows of this solve (<= 256: every 4th of <= 1024 points)
+	__shared__ __attribute__((aligned(16))) float urow[HT_MAXPTS / 4 + 2][12];  // rows of this solve (<= 256: every 4th of <= 1024 points) + read-ahead slack
 	const int nr = n < HT_MAXPTS / 4 ? n : HT_MAXPTS / 4;
 	for (int i = lane; i < nr; i += 64)     // re-express every cloud row on the proxy body and pre-compute (handtrack.h:457-462)
 	{
@@ -166,42 +167,37 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 		const v3 nrm = G3(r + 8);
 		const v3 r1 = qrot(ubq, p1);
 		const float impulsed = minv + dot(cross(mul(Iinv, cross(r1, nrm)), r1), nrm);
-		float4 *o = reinterpret_cast<float4 *>(&urow[i][0]);
-		o[0] = make_float4(r1.x, r1.y, r1.z, nrm.x);
-		o[1] = make_float4(nrm.y, nrm.z, r[11] / dt, r[12]);
+		const float ts = r[11] / dt;
+		float4 *o = reinterpret_cast<float4 *>(&urow[i][0]);      // record layout of k_solve's chains: r1 ts | n ts_post | fmin*dt fmax*dt effmass sum
+		o[0] = make_float4(r1.x, r1.y, r1.z, ts);
+		o[1] = make_float4(nrm.x, nrm.y, nrm.z, fmin_std(ts, r[12]));
 		o[2] = make_float4(r[13] * dt, r[14] * dt, impulsed, 0.0f);
 	}
+	if (lane < 24) urow[nr + lane / 12][lane % 12] = 0.0f;      // the sweep reads one record ahead
 	__syncthreads();
-	if (lane == 0)
+	if (lane < 4)       // the proxy body in quad layout (ht_quad.hpp): lane c < 3 owns component c, lane 3 carries the row's target speed
 	{
-		v3 lin = V3(0, 0, 0), ang = V3(0, 0, 0);
-		lin = lin * M.ub_dampleft; ang = ang * M.ub_dampleft;            // rbinitvelocity on a body at rest
-		lin = lin + V3(0, 0, 0); ang = ang + V3(0, 0, 0);
+		const int c = lane;
+		// rbinitvelocity on a body at rest: 0 * damping + 0
+		quad_body qb = { (0.0f * M.ub_dampleft) + 0.0f, (0.0f * M.ub_dampleft) + 0.0f, minv,
+		                 c == 0 ? Iinv.x.x : c == 1 ? Iinv.x.y : c == 2 ? Iinv.x.z : 0.0f, c == 0 ? Iinv.y.x : c == 1 ? Iinv.y.y : c == 2 ? Iinv.y.z : 0.0f, c == 0 ? Iinv.z.x : c == 1 ? Iinv.z.y : c == 2 ? Iinv.z.z : 0.0f };
 		v3 pn = ubpos; v4 qn = ubq;
 		const int total = ph.iterations + ph.iterations_post;
 		for (int sweep = 0; sweep < total; sweep++)
 		{
-			const bool post = sweep >= ph.iterations;
-			const float4 *c = reinterpret_cast<const float4 *>(&urow[0][0]);
-			float4 c0 = c[0], c1 = c[1], c2 = c[2];
+			const int tsoff = sweep >= ph.iterations ? 1 : 0;        // RemoveBias: lane 3 switches to ts_post
+			const float *pv = &urow[0][0] + (c < 3 ? c : 3 + 4 * tsoff), *pnm = &urow[0][0] + 4 + c;
+			float *pt = &urow[0][0] + 8;
+			float rv = pv[0], n = pnm[0]; float4 t = *reinterpret_cast<const float4 *>(pt);
 			for (int k = 0; k < nr; k++)
 			{
-				float4 n0 = c0, n1 = c1, n2 = c2;
-				if (k + 1 < nr) { n0 = c[3 * (k + 1)]; n1 = c[3 * (k + 1) + 1]; n2 = c[3 * (k + 1) + 2]; }      // prefetch the next row
-				const v3 r1 = V3(c0.x, c0.y, c0.z), nrm = V3(c0.w, c1.x, c1.y);
-				const float ts = post ? fmin_std(c1.z, c1.w) : c1.z;
-				const v3 v1 = cross(mul(Iinv, ang), r1) + lin * minv;
-				const float vn = dot(v1, nrm);
-				float impulse = (-ts - vn) / c2.z;
-				impulse = fmin_std(c2.y - c2.w, impulse);
-				impulse = fmax_std(c2.x - c2.w, impulse);
-				const v3 imp = nrm * impulse;
-				lin = lin + imp; ang = ang + cross(r1, imp);
-				urow[k][11] = c2.w + impulse;
-				c0 = n0; c1 = n1; c2 = n2;
+				const float nrv = pv[12], nn = pnm[12]; const float4 nt = *reinterpret_cast<const float4 *>(pt + 12);
+				pt[3] = quad_row_step(qb, rv, n, t);
+				rv = nrv; n = nn; t = nt; pv += 12; pnm += 12; pt += 12;
 			}
 			if (sweep + 1 == ph.iterations)
 			{
+				const v3 lin = V3(dpp<QP_BC0>(qb.l), dpp<QP_BC1>(qb.l), dpp<QP_BC2>(qb.l)), ang = V3(dpp<QP_BC0>(qb.av), dpp<QP_BC1>(qb.av), dpp<QP_BC2>(qb.av));
 				pn = ubpos + (lin * minv) * dt;
 				const m3 tm = tinv * minv;
 				auto diffq = [&](v4 o) -> v4 { v4 sn = normalize(o); m3 Mx = qmat(sn); m3 Ii = mul(Mx, mul(tm, transpose(Mx))); v3 hs = mul(Ii, ang) * 0.5f; return qmul(V4(hs.x, hs.y, hs.z, 0), sn); };
@@ -213,7 +209,8 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 				qn = o;
 			}
 		}
-		res[0] = pn.x; res[1] = pn.y; res[2] = pn.z; res[3] = qn.x; res[4] = qn.y; res[5] = qn.z; res[6] = qn.w;
+		if (lane == 0) {
+		res[0] = pn.x; res[1] = pn.y; res[2] = pn.z; res[3] = qn.x; res[4] = qn.y; res[5] = qn.z; res[6] = qn.w; }
 	}
 	__syncthreads();
 	const xf dp = mul(XF(V3(res[0], res[1], res[2]), V4(res[3], res[4], res[5], res[6])), inverse(XF(G3(pos[1]), G4(q[1]))));
