@@ -88,10 +88,17 @@ __device__ __forceinline__ void put_ang(float *o, int rb0, int rb1, v3 axis, flo
 {
 	o[0] = __int_as_float(rb0); o[1] = __int_as_float(rb1); o[2] = axis.x; o[3] = axis.y; o[4] = axis.z; o[5] = targetspin; o[6] = mintorque; o[7] = maxtorque;
 }
-// ConstrainAngularRangeW physics.h:351-393; sin() there is the C double overload, the sums are formed in double and rounded once
-__device__ int angular_range_w(const ht_physics_dev &ph, int rb0, v4 jb0, int rb1, v4 jf1, v3 lmin, v3 lmax, float (*out)[8])
+// Row builders that can emit several rows take a sink that keeps only the row its lane owns: nothing is indexed dynamically, so the
+// rows stay in registers (a private array indexed with a run-time value would live in scratch memory).
+struct ang_sink { int want, n; float row[8]; };
+__device__ __forceinline__ void emit_ang(ang_sink &k, int rb0, int rb1, v3 axis, float targetspin, float mintorque, float maxtorque)
 {
-	int n = 0;
+	if (k.n == k.want) put_ang(k.row, rb0, rb1, axis, targetspin, mintorque, maxtorque);
+	k.n++;
+}
+// ConstrainAngularRangeW physics.h:351-393; sin() there is the C double overload, the sums are formed in double and rounded once
+__device__ __forceinline__ void angular_range_w(const ht_physics_dev &ph, int rb0, v4 jb0, int rb1, v4 jf1, v3 lmin, v3 lmax, ang_sink &out)
+{
 	const float dt = ph.deltaT;
 	v3 jmin = (lmin * 3.14f) / 180.0f, jmax = (lmax * 3.14f) / 180.0f;
 	if (jmin.x == 0 && jmax.x == 0 && jmin.z < jmax.z)
@@ -107,30 +114,29 @@ __device__ int angular_range_w(const ht_physics_dev &ph, int rb0, v4 jb0, int rb
 	v4 s = quat_from_to(V3(0, 0, 1.0f), qzdir(r));
 	v4 t = qmul(qconj(s), r);
 	if (jmax.x == jmin.x)
-		put_ang(out[n++], rb0, rb1, qxdir(jf1), (float)(2 * ((double)(-s.x) + sin((double)(jmin.x / 2.0f))) / (double)dt), -FLT_MAX, FLT_MAX);
+		emit_ang(out, rb0, rb1, qxdir(jf1), (float)(2 * ((double)(-s.x) + sin((double)(jmin.x / 2.0f))) / (double)dt), -FLT_MAX, FLT_MAX);
 	else if (jmax.x - jmin.x < 360.0f * 3.14f / 180.0f)
 	{
-		put_ang(out[n++], rb0, rb1, qxdir(jf1), (float)(2 * ((double)(-s.x) + sin((double)(jmin.x / 2.0f))) / (double)dt), 0, FLT_MAX);
-		put_ang(out[n++], rb0, rb1, -qxdir(jf1), (float)(2 * ((double)(s.x) - sin((double)(jmax.x / 2.0f))) / (double)dt), 0, FLT_MAX);
+		emit_ang(out, rb0, rb1, qxdir(jf1), (float)(2 * ((double)(-s.x) + sin((double)(jmin.x / 2.0f))) / (double)dt), 0, FLT_MAX);
+		emit_ang(out, rb0, rb1, -qxdir(jf1), (float)(2 * ((double)(s.x) - sin((double)(jmax.x / 2.0f))) / (double)dt), 0, FLT_MAX);
 	}
 	if (jmax.y == jmin.y)
-		put_ang(out[n++], rb0, rb1, qydir(jf1), ph.biasfactorjoint * 2 * (-s.y + jmin.y) / dt, -FLT_MAX, FLT_MAX);
+		emit_ang(out, rb0, rb1, qydir(jf1), ph.biasfactorjoint * 2 * (-s.y + jmin.y) / dt, -FLT_MAX, FLT_MAX);
 	else
 	{
-		put_ang(out[n++], rb0, rb1, qydir(jf1), (float)(2 * ((double)(-s.y) + sin((double)(jmin.y / 2.0f))) / (double)dt), 0, FLT_MAX);
-		put_ang(out[n++], rb0, rb1, -qydir(jf1), (float)(2 * ((double)(s.y) - sin((double)(jmax.y / 2.0f))) / (double)dt), 0, FLT_MAX);
+		emit_ang(out, rb0, rb1, qydir(jf1), (float)(2 * ((double)(-s.y) + sin((double)(jmin.y / 2.0f))) / (double)dt), 0, FLT_MAX);
+		emit_ang(out, rb0, rb1, -qydir(jf1), (float)(2 * ((double)(s.y) - sin((double)(jmax.y / 2.0f))) / (double)dt), 0, FLT_MAX);
 	}
 	if (jmin.z == jmax.z)
-		put_ang(out[n++], rb0, rb1, qzdir(jf1), ph.biasfactorjoint * 2 * -t.z / dt, -FLT_MAX, FLT_MAX);
+		emit_ang(out, rb0, rb1, qzdir(jf1), ph.biasfactorjoint * 2 * -t.z / dt, -FLT_MAX, FLT_MAX);
 	else
 	{
-		put_ang(out[n++], rb0, rb1, qzdir(jf1), (float)(2 * ((double)(-t.z) + sin((double)(jmin.z / 2.0f))) / (double)dt), 0, FLT_MAX);
-		put_ang(out[n++], rb0, rb1, -qzdir(jf1), (float)(2 * ((double)(t.z) - sin((double)(jmax.z / 2.0f))) / (double)dt), 0, FLT_MAX);
+		emit_ang(out, rb0, rb1, qzdir(jf1), (float)(2 * ((double)(-t.z) + sin((double)(jmin.z / 2.0f))) / (double)dt), 0, FLT_MAX);
+		emit_ang(out, rb0, rb1, -qzdir(jf1), (float)(2 * ((double)(t.z) - sin((double)(jmax.z / 2.0f))) / (double)dt), 0, FLT_MAX);
 	}
-	return n;
 }
 // ConstrainConeAngle physics.h:402-414
-__device__ void cone_angle(const ht_physics_dev &ph, const lds_t &S, int rb0, v3 n0, int rb1, v3 n1, float limitangle_degrees, float *out)
+__device__ __forceinline__ void cone_angle(const ht_physics_dev &ph, const lds_t &S, int rb0, v3 n0, int rb1, v3 n1, float limitangle_degrees, float *out)
 {
 	int equality = (limitangle_degrees == 0);
 	v3 a0 = rb0 >= 0 ? qrot(L4(S.q[rb0]), n0) : n0;
@@ -142,7 +148,7 @@ __device__ void cone_angle(const ht_physics_dev &ph, const lds_t &S, int rb0, v3
 	put_ang(out, rb0, rb1, axis, targetspin, (limitangle_degrees > 0.0f) ? 0 : -FLT_MAX, FLT_MAX);
 }
 // ConstrainAngularDrive physics.h:313-326
-__device__ void angular_drive(const ht_physics_dev &ph, const lds_t &S, int rb0, int rb1, v4 target, float maxtorque, float (*out)[8])
+__device__ __forceinline__ void angular_drive(const ht_physics_dev &ph, const lds_t &S, int rb0, int rb1, v4 target, float maxtorque, float (*out)[8])
 {
 	v4 q0 = rb0 >= 0 ? L4(S.q[rb0]) : V4(0, 0, 0, 1), q1 = rb1 >= 0 ? L4(S.q[rb1]) : V4(0, 0, 0, 1);
 	v4 dq = qmul(q1, qconj(qmul(q0, target)));
@@ -318,9 +324,10 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				const float *jc = M.jointc + j * HT_JC;
 				const int rb0 = (int)jc[HT_JC_RB0], rb1 = (int)jc[HT_JC_RB1];
 				const v4 jf = L4(jc + HT_JC_FRAME);
-				float jrows[6][8];
-				angular_range_w(ph, rb0, rb0 >= 0 ? qmul(L4(S.q[rb0]), jf) : jf, rb1, rb1 >= 0 ? L4(S.q[rb1]) : V4(0, 0, 0, 1), L3(S.jr[j]), L3(S.jr[j] + 3), jrows);
-				for (int k = 0; k < 8; k++) row[k] = sub == 0 ? jrows[0][k] : sub == 1 ? jrows[1][k] : sub == 2 ? jrows[2][k] : sub == 3 ? jrows[3][k] : sub == 4 ? jrows[4][k] : jrows[5][k];
+				ang_sink sink; sink.want = sub; sink.n = 0;
+				for (int k = 0; k < 8; k++) sink.row[k] = 0.0f;
+				angular_range_w(ph, rb0, rb0 >= 0 ? qmul(L4(S.q[rb0]), jf) : jf, rb1, rb1 >= 0 ? L4(S.q[rb1]) : V4(0, 0, 0, 1), L3(S.jr[j]), L3(S.jr[j] + 3), sink);
+				for (int k = 0; k < 8; k++) row[k] = sink.row[k];
 			}
 			R.rb0 = __float_as_int(row[0]); R.rb1 = __float_as_int(row[1]); R.axis = V3(row[2], row[3], row[4]); R.targetspin = row[5];
 			const float mintorque = row[6], maxtorque = row[7];
