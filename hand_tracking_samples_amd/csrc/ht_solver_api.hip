@@ -303,3 +303,44 @@ extern "C" int ht_debug_contact_stats(ht_ctx *ctx, int B, float *out, int reset)
 	}
 	return HT_OK;
 }
+
+// ------------------------------------------------------------------------------------------------- segmentation (before the tracker)
+extern "C" int ht_segment_vr_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, int w, int h, int B, int entry_options, float wrange_lo, float wrange_hi, float diam,
+                                 uint16_t *d_tiles, float *d_cams_out, void *stream)
+{
+	CHECK_READY(ctx);
+	(void)wrange_lo;      // the reference's lower bound is commented out (handtrack.h:288)
+	if (!d_depth || !d_cams || !d_tiles || !d_cams_out || B < 1) return HT_ERR_ARG;
+	hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+	if (w == 64 && h == 64)      // handtrack.h:283-284: a 64x64 frame is returned as it is
+	{
+		HIPCHK(ctx, hipMemcpyAsync(d_tiles, d_depth, (size_t)B * 4096 * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
+		HIPCHK(ctx, hipMemcpyAsync(d_cams_out, d_cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyDeviceToDevice, s));
+		return HT_OK;
+	}
+	if (!ht_segment_supported(w, h)) { ctx->err = "ht_segment_vr: frame size must be a multiple of 4 and at most 320x240 pixels"; return HT_ERR_ARG; }
+	ht_launch_segment(d_depth, d_cams, w, h, entry_options, wrange_hi, diam, d_tiles, d_cams_out, B, s);
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
+extern "C" int ht_segment_vr(ht_ctx *ctx, const uint16_t *depth, const float *cams, int w, int h, int B, int entry_options, float wrange_lo, float wrange_hi, float diam,
+                             uint16_t *tiles, float *cams_out)
+{
+	CHECK_READY(ctx);
+	if (!depth || !cams || !tiles || !cams_out || B < 1 || w < 1 || h < 1) return HT_ERR_ARG;
+	uint16_t *d_in = nullptr, *d_tiles = nullptr; float *d_cams = nullptr, *d_co = nullptr;
+	const size_t nin = (size_t)B * w * h;
+	int rc = HT_OK;
+	if (hipMalloc((void **)&d_in, nin * sizeof(uint16_t)) != hipSuccess || hipMalloc((void **)&d_tiles, (size_t)B * 4096 * sizeof(uint16_t)) != hipSuccess ||
+	    hipMalloc((void **)&d_cams, (size_t)B * HT_CAM * sizeof(float)) != hipSuccess || hipMalloc((void **)&d_co, (size_t)B * HT_CAM * sizeof(float)) != hipSuccess)
+	{ ctx->err = "ht_segment_vr: out of device memory"; rc = HT_ERR_HIP; }
+	hipStream_t s = ctx->stream;
+	if (rc == HT_OK && (hipMemcpyAsync(d_in, depth, nin * sizeof(uint16_t), hipMemcpyHostToDevice, s) != hipSuccess ||
+	                    hipMemcpyAsync(d_cams, cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess)) { ctx->err = "ht_segment_vr: upload failed"; rc = HT_ERR_HIP; }
+	if (rc == HT_OK) rc = ht_segment_vr_dev(ctx, d_in, d_cams, w, h, B, entry_options, wrange_lo, wrange_hi, diam, d_tiles, d_co, s);
+	if (rc == HT_OK && (hipMemcpyAsync(tiles, d_tiles, (size_t)B * 4096 * sizeof(uint16_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+	                    hipMemcpyAsync(cams_out, d_co, (size_t)B * HT_CAM * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess ||
+	                    hipStreamSynchronize(s) != hipSuccess)) { ctx->err = "ht_segment_vr: download failed"; rc = HT_ERR_HIP; }
+	(void)hipFree(d_in); (void)hipFree(d_tiles); (void)hipFree(d_cams); (void)hipFree(d_co);
+	return rc;
+}

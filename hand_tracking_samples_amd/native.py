@@ -19,7 +19,7 @@ MAXPTS, ROW, CONTACT = 1024, 16, 12
 SYMBOLS = (
     "ht_create", "ht_destroy", "ht_model_bake", "ht_last_error", "ht_get_params", "ht_set_params", "ht_model_info",
     "ht_cnn_load_weights", "ht_cnn_eval", "ht_cnn_eval_dev",
-    "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev",
+    "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_segment_vr", "ht_segment_vr_dev",
     "ht_stage_prepare", "ht_stage_decode", "ht_stage_fit_error", "ht_stage_cloud_rows", "ht_stage_contacts", "ht_stage_fit",
     "ht_stage_multistep", "ht_stage_scratch_unibody", "ht_profile_enable", "ht_profile_read", "ht_debug_solve_stats", "ht_debug_contact_stats",
 )
@@ -80,6 +80,8 @@ def load(build_if_missing=True):
     L.ht_stage_multistep.argtypes = [vp, fp, C.c_int]
     L.ht_stage_scratch_unibody.argtypes = [vp, fp, C.c_int, C.c_int]
     L.ht_profile_enable.argtypes = [vp, C.c_int]
+    L.ht_segment_vr.argtypes = [vp, C.POINTER(C.c_uint16), fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_uint16), fp]
+    L.ht_segment_vr_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp, vp, vp]
     L.ht_profile_read.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_int, fp, ip, ip]
     L.ht_debug_solve_stats.argtypes = [vp, C.c_int, fp, C.c_int]
     L.ht_debug_contact_stats.argtypes = [vp, C.c_int, fp, C.c_int]
@@ -273,3 +275,12 @@ class Context:
         out = np.zeros((B, 12), np.float32)
         self._chk(self.L.ht_debug_contact_stats(self.h, int(B), _f(out), int(reset)))
         return out
+
+    def segment_vr(self, depth, cams, entry_options=0xF, wrange=(0.1, 0.65), diam=0.17):
+        """HandSegmentVR (handtrack.h:280-344) for a batch: depth u16[B,h,w], cams [B,12] -> (tiles u16[B,64,64], cams [B,12])."""
+        depth = _c(depth, np.uint16); B, h, w = depth.shape
+        cams = _c(cams, np.float32).reshape(B, CAM)
+        tiles = np.empty((B, 64, 64), np.uint16); co = np.empty((B, CAM), np.float32)
+        self._chk(self.L.ht_segment_vr(self.h, depth.ctypes.data_as(C.POINTER(C.c_uint16)), _f(cams), w, h, B, int(entry_options), float(wrange[0]), float(wrange[1]), float(diam),
+                                       tiles.ctypes.data_as(C.POINTER(C.c_uint16)), _f(co)))
+        return tiles, co

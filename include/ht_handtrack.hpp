@@ -47,6 +47,7 @@ template <class T> struct Image                                                 
 	T &pixel(int2 p) { return raster[(size_t)p.y * dim().x + p.x]; }
 };
 
+namespace detail { inline ht_ctx *&live_ctx() { static ht_ctx *c = nullptr; return c; } }      // a context the free functions below can run on
 inline void check(ht_ctx *ctx, int rc) { if (rc != HT_OK) throw std::runtime_error(std::string("ht_mi355x: ") + (ctx ? ht_last_error(ctx) : "no context")); }
 
 class CNN                                                                                    // third_party/cnn.h:100-605 (forward surface)
@@ -74,6 +75,7 @@ public:
 struct HandTracker                                                                            // include/handtrack.h:513-846
 {
 	// tunables with the reference's names and defaults (handtrack.h:523-547); pushed to the device context before every update
+	float segment_scale = 0.17f;
 	float full_reset_on_error = 0.6f; bool angles_only = false; bool always_take_cnn = false; float drangey = 0.7f; int boundary_planes = 1;
 	float microforce = 1.0f; float cloudforce_max_point = 15.0f; float cloudforce_max_sum = 3000.0f; int mainthreadpasses = 1; int subsample_fraction = 4;
 	size_t min_point_num = 400; float accum_error_threshold = 0.0f; float min_cray_prob = 0.0f;
@@ -92,18 +94,22 @@ struct HandTracker                                                              
 		int rc = ht_create(model_path.c_str(), 1, device, &ctx_);
 		if (rc != HT_OK) { std::string msg = ctx_ ? ht_last_error(ctx_) : "ht_create failed"; if (ctx_) ht_destroy(ctx_); ctx_ = nullptr; throw std::runtime_error("HandTracker: " + msg); }
 		cnn.ctx_ = ctx_;
+		if (!detail::live_ctx()) detail::live_ctx() = ctx_;
 		ht_model_info(ctx_, &nb_, nullptr, nullptr);
 		if (!cnnb_path.empty()) { std::ifstream is(cnnb_path, std::ios_base::in | std::ios_base::binary); if (is.is_open()) cnn.loadb(is); }
 		cnn_output.assign(HT_CNN_OUT, 0.01f);
 	}
-	~HandTracker() { if (ctx_) ht_destroy(ctx_); }
+	~HandTracker() { if (detail::live_ctx() == ctx_) detail::live_ctx() = nullptr; if (ctx_) ht_destroy(ctx_); }
 	HandTracker(const HandTracker &) = delete; HandTracker &operator=(const HandTracker &) = delete;
 
 	void SetPose(const std::vector<Pose> &pose) { check(ctx_, ht_tracker_reset(ctx_, 0, 1, flat(pose).data())); }          // handmodel/othermodel.SetPose
 
 	std::vector<Pose> update(Image<unsigned short> dimage)                                   // handtrack.h:748
 	{
-		if (dimage.dim().x != 64 || dimage.dim().y != 64) throw std::runtime_error("HandTracker::update: 64x64 tiles only (run HandSegmentVR first)");
+		// A full-size frame is segmented first, with the arguments of update_cnn_model_threadsafe (handtrack.h:697-698), which is also what
+		// synthetic-tracker.cpp:204-215 does before calling update().  (Given a full-size frame the reference's update() would fit the
+		// full-resolution cloud in its main-thread passes; here all passes work on the tile.)
+		if (dimage.dim().x != 64 || dimage.dim().y != 64) dimage = segment(dimage, 0xF, { 0.1f, drangey }, segment_scale);
 		push_params();
 		const DCamera &c = dimage.cam;
 		float cam[HT_CAM] = { c.focal().x, c.focal().y, c.principal().x, c.principal().y, c.depth_scale, c.pose.position.x, c.pose.position.y, c.pose.position.z,
@@ -127,6 +133,18 @@ struct HandTracker                                                              
 		for (int b = 0; b < nb_; b++) { const float *p = &out[(size_t)b * HT_POSE]; pose[b].position = { p[0], p[1], p[2] }; pose[b].orientation = { p[3], p[4], p[5], p[6] }; }
 		return pose;
 	}
+	// HandSegmentVR (handtrack.h:280-344) on this tracker's device
+	Image<unsigned short> segment(const Image<unsigned short> &depth, int entry_options = 0xF, float2 wrange = { 0.1f, 0.65f }, float diam = 0.17f) const { return segment_on(ctx_, depth, entry_options, wrange, diam); }
+	static Image<unsigned short> segment_on(ht_ctx *ctx, const Image<unsigned short> &depth, int entry_options, float2 wrange, float diam)
+	{
+		const DCamera &c = depth.cam;
+		float cam[HT_CAM] = { c.focal().x, c.focal().y, c.principal().x, c.principal().y, c.depth_scale, c.pose.position.x, c.pose.position.y, c.pose.position.z,
+		                      c.pose.orientation.x, c.pose.orientation.y, c.pose.orientation.z, c.pose.orientation.w };
+		float co[HT_CAM]; std::vector<unsigned short> tile(4096);
+		check(ctx, ht_segment_vr(ctx, depth.raster.data(), cam, depth.dim().x, depth.dim().y, 1, entry_options, wrange.x, wrange.y, diam, tile.data(), co));
+		Pose pose; pose.position = { co[5], co[6], co[7] }; pose.orientation = { co[8], co[9], co[10], co[11] };
+		return Image<unsigned short>(DCamera({ 64, 64 }, { co[0], co[1] }, { co[2], co[3] }, co[4], pose), std::move(tile));
+	}
 private:
 	ht_ctx *ctx_ = nullptr; int nb_ = 0;
 	std::vector<float> flat(const std::vector<Pose> &pose) const
@@ -145,4 +163,10 @@ private:
 		check(ctx_, ht_set_params(ctx_, &p));
 	}
 };
+// Free function with the reference's signature (handtrack.h:280); it runs on the device of the first live HandTracker.
+inline Image<unsigned short> HandSegmentVR(const Image<unsigned short> &depth, int entry_options = 0xF, float2 wrange = { 0.1f, 0.65f }, float diam = 0.17f)
+{
+	if (!detail::live_ctx()) throw std::runtime_error("HandSegmentVR: construct a HandTracker first (the segmentation runs on its device)");
+	return HandTracker::segment_on(detail::live_ctx(), depth, entry_options, wrange, diam);
+}
 }  // namespace ht_mi355x

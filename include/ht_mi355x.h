@@ -111,6 +111,18 @@ int ht_set_tracker_flags(ht_ctx *ctx, int first, int n, const float *prev_frame_
 int ht_update_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int B, float *poses_out, float *cnn_out);
 int ht_update_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, const float *d_start_poses, int B, float *d_poses_out, void *stream);
 
+/* ---- segmentation: the step before the tracker for full-size frames --------------------------------------------------
+ * ht_segment_vr       replaces  Image<unsigned short> HandSegmentVR(const Image<unsigned short> &depth, int entry_options = 0xF,
+ *                     float2 wrange = {0.1f, 0.65f}, float diam = 0.17f) (handtrack.h:280-344) for B frames of w x h pixels:
+ *                     depth [B][h*w], cams [B][12] -> tiles [B][64*64] and the segment cameras cams_out [B][12] (focal, principal
+ *                     (32,32), depth_scale, pose = (0, rotation)), ready for ht_update_sync.  A 64x64 frame is passed through.
+ *                     Frames up to 320x240 (the reference's camera), dimensions multiples of 4.
+ * ht_segment_vr_dev   the same on device buffers, asynchronous on `stream`. */
+int ht_segment_vr(ht_ctx *ctx, const uint16_t *depth, const float *cams, int w, int h, int B, int entry_options, float wrange_lo, float wrange_hi, float diam,
+                  uint16_t *tiles, float *cams_out);
+int ht_segment_vr_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, int w, int h, int B, int entry_options, float wrange_lo, float wrange_hi, float diam,
+                      uint16_t *d_tiles, float *d_cams_out, void *stream);
+
 /* ---- stage entry points (same kernels, exposed one reference function at a time so parity tests can pin each) -----
  * All take HOST buffers and are synchronous.  `which` selects the model (0 handmodel, 1 othermodel) of slots [0,B).
  * ht_stage_prepare    depth -> CNN input (handtrack.h:700) and sub-sampled point cloud (misc_image.h:409-417, physmodel.h:58-64):

@@ -21,6 +21,7 @@
 //   scan   <animbank.pose> <stride>                workload statistics per animation row
 //   frames <animbank.pose> <first> <stride> <n> <out.htfx>    64x64 frames + cameras + start poses
 //   golden <animbank.pose> <rows,comma> <seed> <fc2gain> <out.htfx>   per-stage goldens
+//   segment <animbank.pose> <rows,comma> <out.htfx>   320x240 frames and what HandSegmentVR makes of them
 //   bench  <frames.htfx> <seed> <fc2gain> <reps>   reference CPU time for the unit of work
 //
 #include "/root/reference/include/handtrack.h"
@@ -322,6 +323,45 @@ static void dump_contacts(Out &o, const std::string &n, PhysModel &m, const std:
 	o.f32(n, v, { (uint32_t)C.size(), 18 });
 }
 
+// HandSegmentVR fixtures: the full-size rendered depth frame, its camera, and what the reference's segmentation returns
+// (handtrack.h:280-344), for several entry options.  The two intermediate images come from the same reference functions.
+static int mode_segment(const char *bankfn, const char *rowscsv, const char *outfn)
+{
+	PhysModel fake = LoadHandModel();
+	auto bank = read_animbank(bankfn, fake.rigidbodies.size());
+	std::vector<int> rows; { std::stringstream ss(rowscsv); std::string t; while (std::getline(ss, t, ',')) rows.push_back(atoi(t.c_str())); }
+	Out o; if (htfx_open(&o.w, outfn)) return 2;
+	o.i32("rows", rows);
+	const int opts[] = { 0xF, 1, 2, 4, 8, 5 };
+	std::vector<int> optv(opts, opts + 6); o.i32("entry_options", optv);
+	for (size_t fi = 0; fi < rows.size(); fi++)
+	{
+		std::string pre = "s" + std::to_string(fi) + "/";
+		DCamera dcam({ 320,240 }, { 305,305 }, { 160,120 }, 0.001f);
+		fake.SetPose(bank[rows[fi] % bank.size()]);
+		auto depth = raycast_depth(fake, dcam);
+		o.u16(pre + "depth", depth.raster, { 240, 320 });
+		o.f32(pre + "cam", camvec(depth.cam));
+		auto small = DownSampleMin(DownSampleMin(depth));
+		o.u16(pre + "small", small.raster, { (uint32_t)small.dim().y, (uint32_t)small.dim().x });
+		ushort2 wranged = ushort2(float2(0.1f, 0.70f) / depth.cam.depth_scale);
+		auto dt = DistanceTransform(Threshold(small, [wranged](unsigned short d) { return d < wranged.y; }));
+		std::vector<int> dti(dt.raster.begin(), dt.raster.end());
+		o.i32(pre + "dt", dti, { (uint32_t)dt.dim().y, (uint32_t)dt.dim().x });
+		for (int k = 0; k < 6; k++)
+		{
+			if (k > 0 && fi > 1) break;      // the alternative entry options only on the first two frames
+			auto seg = HandSegmentVR(depth, opts[k], { 0.1f,0.70f });
+			std::string q = pre + "o" + std::to_string(opts[k]) + "/";
+			o.u16(q + "tile", seg.raster, { 64, 64 });
+			o.f32(q + "cam", camvec(seg.cam));
+		}
+	}
+	htfx_close(&o.w);
+	printf("segment: %d frames -> %s\n", (int)rows.size(), outfn);
+	return 0;
+}
+
 static int mode_golden(const char *bankfn, const char *rowscsv, uint64_t seed, double gain, const char *outfn)
 {
 	HandTracker htk;
@@ -550,6 +590,7 @@ int main(int argc, char **argv) try
 	if (mode == "modelfile" && a.size() == 2) return mode_modelfile(a[0].c_str(), a[1].c_str());
 	if (mode == "scan" && a.size() == 2) return mode_scan(a[0].c_str(), atoi(a[1].c_str()));
 	if (mode == "frames" && a.size() == 5) return mode_frames(a[0].c_str(), atoi(a[1].c_str()), atoi(a[2].c_str()), atoi(a[3].c_str()), a[4].c_str());
+	if (mode == "segment" && a.size() == 3) return mode_segment(a[0].c_str(), a[1].c_str(), a[2].c_str());
 	if (mode == "golden" && a.size() == 5) return mode_golden(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());
 	if (mode == "bench" && a.size() >= 4) return mode_bench(a[0].c_str(), strtoull(a[1].c_str(), 0, 0), atof(a[2].c_str()), atoi(a[3].c_str()), a.size() > 4 ? atoi(a[4].c_str()) : 0);
 	fprintf(stderr, "bad arguments\n");

@@ -116,6 +116,7 @@ def lib():
         L.ho_contact_patch_bodies.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.POINTER(GjkContact)]; L.ho_contact_patch_bodies.restype = C.c_int
         L.ho_separated_bodies.argtypes = [C.c_void_p, C.c_void_p]; L.ho_separated_bodies.restype = GjkContact
         L.ho_body_ptr.argtypes = [C.c_void_p, C.c_int]; L.ho_body_ptr.restype = C.c_void_p
+        L.ho_segment_vr.argtypes = [C.POINTER(C.c_uint16), C.c_int, C.c_int, fp, C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_uint16), fp, C.POINTER(C.c_uint16), C.POINTER(C.c_uint8)]; L.ho_segment_vr.restype = C.c_int
         _lib = L
     return _lib
 
@@ -192,3 +193,14 @@ class Oracle:
 
     def reset(self, pose7):
         self.L.ho_reset_tracker(self.h, fptr(np.ascontiguousarray(pose7, dtype=np.float32)))
+
+
+def segment_vr(depth, cam12, entry_options=0xF, wrange=(0.1, 0.65), diam=0.17):
+    """HandSegmentVR restatement: depth u16[h,w] + camera[12] -> (tile u16[64,64], camera[12], small u16[h/4,w/4], dt u8[h/4,w/4])."""
+    depth = np.ascontiguousarray(depth, np.uint16); h, w = depth.shape
+    cam12 = np.ascontiguousarray(cam12, np.float32)
+    tile = np.zeros((64, 64), np.uint16); cam = np.zeros(12, np.float32)
+    small = np.zeros((h // 4, w // 4), np.uint16); dt = np.zeros((h // 4, w // 4), np.uint8)
+    lib().ho_segment_vr(u16ptr(depth), w, h, fptr(cam12), int(entry_options), float(wrange[0]), float(wrange[1]), float(diam),
+                        u16ptr(tile), fptr(cam), u16ptr(small), dt.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return tile, cam, small, dt
