@@ -154,6 +154,27 @@ extern "C" int ht_model_bake(const char *json_path, const char *out_path, int fl
 	if (!ht_build_model(json_path, flags, fx, err)) { fprintf(stderr, "ht_model_bake: %s\n", err.c_str()); return HT_ERR_IO; }
 	return fx_save(out_path, fx) ? HT_OK : HT_ERR_IO;
 }
+// HandTracker::load_config (handtrack.h:822-828) = from_json over visit_fields (:549-581).  The reference's decoder assigns every listed
+// field from the file, and a member that is missing (or is not a number) reads as 0 (json.h:104,140,145); a missing file changes nothing.
+extern "C" int ht_config_read(const char *jsonfile, ht_params *p, float *segment_scale, float *prev_frame_error)
+{
+	if (!jsonfile || !p) return HT_ERR_ARG;
+	{ FILE *fp = fopen(jsonfile, "rb"); if (!fp) return HT_OK; fclose(fp); }
+	std::map<std::string, std::string> num; std::string err;
+	if (!ht_json_top_level(jsonfile, num, err)) { fprintf(stderr, "ht_config_read: %s\n", err.c_str()); return HT_ERR_IO; }
+	auto F = [&](const char *k) -> float { auto it = num.find(k); return it == num.end() ? 0.0f : strtof(it->second.c_str(), nullptr); };       // istringstream >> float
+	auto I = [&](const char *k) -> int { auto it = num.find(k); return it == num.end() ? 0 : (int)strtol(it->second.c_str(), nullptr, 10); };    // istringstream >> int
+	if (segment_scale) *segment_scale = F("segment_scale");
+	p->full_reset_on_error = F("full_reset_on_error"); p->angles_only = I("angles_only") != 0; p->always_take_cnn = I("always_take_cnn"); p->drangey = F("drangey");
+	p->boundary_planes = I("boundary_planes"); p->microforce = F("microforce"); p->mainthreadpasses = I("mainthreadpasses"); p->subsample_fraction = I("subsample_fraction");
+	p->min_point_num = I("min_point_num"); p->accum_error_threshold = F("accum_error_threshold"); p->cloudforce_max_point = F("cloudforce_max_point"); p->cloudforce_max_sum = F("cloudforce_max_sum");
+	p->steps = I("steps"); p->steps_keypoints = I("steps_keypoints"); p->steps_keyangles = I("steps_keyangles"); p->steps_palmangle = I("steps_palmangle"); p->steps_cloudstart = I("steps_cloudstart");
+	if (prev_frame_error) *prev_frame_error = F("prev_frame_error");
+	p->physics_iterations = I("physics_iterations"); p->physics_iterations_post = I("physics_iterations_post"); p->physics_use_collision = I("physics_use_collision");
+	p->physics_weak_force = F("physics_weak_force"); p->steps_unibody = I("steps_unibody"); p->bone_sum_error_scale = F("bone_sum_error_scale"); p->min_cray_prob = F("min_cray_prob");
+	p->unibody_force = F("unibody_force");
+	return HT_OK;
+}
 extern "C" int ht_destroy(ht_ctx *ctx)
 {
 	if (!ctx) return HT_ERR_ARG;

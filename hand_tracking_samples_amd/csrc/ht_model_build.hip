@@ -662,3 +662,18 @@ bool ht_build_model(const char *json_path, int flags, fx_map &out, std::string &
 	}
 	return true;
 }
+
+// Top-level members of a JSON object file as raw text (numbers keep their digits); used by ht_config_read.
+bool ht_json_top_level(const char *path, std::map<std::string, std::string> &numbers, std::string &err)
+{
+	std::string text;
+	FILE *fp = fopen(path, "rb");
+	if (!fp) { err = std::string("cannot open ") + path; return false; }
+	char buf[65536]; size_t n;
+	while ((n = fread(buf, 1, sizeof buf, fp)) > 0) text.append(buf, n);
+	fclose(fp);
+	jnode root; jparser jp = { text.data(), text.data() + text.size(), "" };
+	if (!jp.value(root, 0) || root.kind != jnode::OBJ) { err = std::string("json: ") + (jp.err.empty() ? "object expected" : jp.err); return false; }
+	for (size_t i = 0; i < root.keys.size(); i++) if (root.items[i].kind == jnode::NUM) numbers[root.keys[i]] = root.items[i].text;
+	return true;
+}

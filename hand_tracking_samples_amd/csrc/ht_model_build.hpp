@@ -23,3 +23,6 @@ enum { HT_BUILD_HAND_TWEAKS = 1 };      // LoadHandModel()'s post-processing (ha
 
 // Parses a PhysModel JSON ("controlcages", "joints") and builds bodies, joints, physics constants and the UnibodyFit proxy.
 bool ht_build_model(const char *json_path, int flags, fx_map &out, std::string &err);
+
+// numeric top-level members of a JSON object file, as text
+bool ht_json_top_level(const char *path, std::map<std::string, std::string> &numbers, std::string &err);

@@ -17,7 +17,7 @@ MAXPTS, ROW, CONTACT = 1024, 16, 12
 
 # every symbol include/ht_mi355x.h declares (checked by tests/test_abi.py)
 SYMBOLS = (
-    "ht_create", "ht_destroy", "ht_model_bake", "ht_last_error", "ht_get_params", "ht_set_params", "ht_model_info",
+    "ht_create", "ht_destroy", "ht_model_bake", "ht_last_error", "ht_get_params", "ht_set_params", "ht_model_info", "ht_config_read",
     "ht_cnn_load_weights", "ht_cnn_eval", "ht_cnn_eval_dev",
     "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_segment_vr", "ht_segment_vr_dev",
     "ht_stage_prepare", "ht_stage_decode", "ht_stage_fit_error", "ht_stage_cloud_rows", "ht_stage_contacts", "ht_stage_fit",

@@ -102,6 +102,21 @@ struct HandTracker                                                              
 	~HandTracker() { if (detail::live_ctx() == ctx_) detail::live_ctx() = nullptr; if (ctx_) ht_destroy(ctx_); }
 	HandTracker(const HandTracker &) = delete; HandTracker &operator=(const HandTracker &) = delete;
 
+	void load_config(const std::string &jsonfile)                                            // handtrack.h:822-828
+	{
+		ht_params p; pull_params(p);
+		float pfe = 0.0f; float seg = segment_scale; int ini = 0;
+		check(ctx_, ht_get_tracker_flags(ctx_, 0, 1, &pfe, &ini));
+		const float pfe0 = pfe;
+		if (ht_config_read(jsonfile.c_str(), &p, &seg, &pfe) != HT_OK) throw std::runtime_error("json parse error - " + jsonfile);
+		segment_scale = seg;
+		full_reset_on_error = p.full_reset_on_error; angles_only = p.angles_only != 0; always_take_cnn = p.always_take_cnn != 0; drangey = p.drangey; boundary_planes = p.boundary_planes;
+		microforce = p.microforce; cloudforce_max_point = p.cloudforce_max_point; cloudforce_max_sum = p.cloudforce_max_sum; mainthreadpasses = p.mainthreadpasses;
+		subsample_fraction = p.subsample_fraction; min_point_num = p.min_point_num; accum_error_threshold = p.accum_error_threshold; min_cray_prob = p.min_cray_prob;
+		steps = p.steps; steps_keypoints = p.steps_keypoints; steps_keyangles = p.steps_keyangles; steps_palmangle = p.steps_palmangle; steps_cloudstart = p.steps_cloudstart; steps_unibody = p.steps_unibody;
+		check(ctx_, ht_set_params(ctx_, &p));      // also carries physics_iterations(_post), physics_use_collision, physics_weak_force, bone_sum_error_scale, unibody_force
+		if (pfe != pfe0) check(ctx_, ht_set_tracker_flags(ctx_, 0, 1, &pfe, &ini));
+	}
 	void SetPose(const std::vector<Pose> &pose) { check(ctx_, ht_tracker_reset(ctx_, 0, 1, flat(pose).data())); }          // handmodel/othermodel.SetPose
 
 	std::vector<Pose> update(Image<unsigned short> dimage)                                   // handtrack.h:748
@@ -153,13 +168,17 @@ private:
 		for (int b = 0; b < nb_ && b < (int)pose.size(); b++) { float *p = &f[(size_t)b * HT_POSE]; p[0] = pose[b].position.x; p[1] = pose[b].position.y; p[2] = pose[b].position.z; p[3] = pose[b].orientation.x; p[4] = pose[b].orientation.y; p[5] = pose[b].orientation.z; p[6] = pose[b].orientation.w; }
 		return f;
 	}
-	void push_params()
+	void pull_params(ht_params &p)
 	{
-		ht_params p; check(ctx_, ht_get_params(ctx_, &p));
+		check(ctx_, ht_get_params(ctx_, &p));
 		p.full_reset_on_error = full_reset_on_error; p.angles_only = angles_only; p.always_take_cnn = always_take_cnn; p.drangey = drangey; p.boundary_planes = boundary_planes;
 		p.microforce = microforce; p.cloudforce_max_point = cloudforce_max_point; p.cloudforce_max_sum = cloudforce_max_sum; p.mainthreadpasses = mainthreadpasses;
 		p.subsample_fraction = subsample_fraction; p.min_point_num = (int)min_point_num; p.accum_error_threshold = accum_error_threshold; p.min_cray_prob = min_cray_prob;
 		p.steps = steps; p.steps_keypoints = steps_keypoints; p.steps_keyangles = steps_keyangles; p.steps_palmangle = steps_palmangle; p.steps_cloudstart = steps_cloudstart; p.steps_unibody = steps_unibody;
+	}
+	void push_params()
+	{
+		ht_params p; pull_params(p);
 		check(ctx_, ht_set_params(ctx_, &p));
 	}
 };

@@ -83,6 +83,11 @@ const char *ht_last_error(const ht_ctx *ctx);
 int ht_get_params(const ht_ctx *ctx, ht_params *p);
 int ht_set_params(ht_ctx *ctx, const ht_params *p);                    /* replaces HandTracker::load_config / visit_fields (handtrack.h:549-581, 822-828) */
 int ht_model_info(const ht_ctx *ctx, int *n_bodies, int *n_joints, int *max_batch);
+/* ht_config_read  replaces  HandTracker::load_config(const std::string &jsonfile) (handtrack.h:822-828): host only.  Applies the file to
+ *                *params the way the reference's field decoder does: every field of visit_fields (handtrack.h:549-581) is assigned, one that
+ *                the file does not give as a number becomes 0; a missing file leaves everything untouched.  segment_scale and
+ *                prev_frame_error (optional) are the two listed fields that live outside ht_params. */
+int ht_config_read(const char *jsonfile, ht_params *params, float *segment_scale, float *prev_frame_error);
 
 /* ---- CNN ---------------------------------------------------------------------------------------------------------
  * ht_cnn_load_weights  replaces  CNN::loadb(std::istream&) (cnn.h:590) / PoseInitializerCNN (handtrack.h:103-130): n must be HT_CNNB_COUNT.

@@ -96,3 +96,22 @@ def test_cxx_compat_header_compiles_and_links(tmp_path):
     if not torch.cuda.is_available():
         r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "model_hand17.htfx")], capture_output=True, text=True)
         assert r.returncode == 1 and "no HIP device" in r.stdout      # fails loudly, no fallback
+
+
+def test_config_read_follows_the_reference_decoder(tmp_path):
+    """load_config (handtrack.h:822-828): listed fields are assigned from the file, a missing member reads as 0, a missing file is ignored."""
+    from hand_tracking_samples_amd import native
+    L = native.load()
+    L.ht_config_read.argtypes = [C.c_char_p, C.POINTER(native.Params), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    p = native.Params(); p.microforce = 9.0; p.steps = 5; p.drangey = 0.7
+    seg, pfe = C.c_float(0.17), C.c_float(1.5)
+    assert L.ht_config_read(str(tmp_path / "absent.json").encode(), C.byref(p), C.byref(seg), C.byref(pfe)) == 0
+    assert p.microforce == 9.0 and p.steps == 5 and seg.value == C.c_float(0.17).value and pfe.value == 1.5
+    cfg = tmp_path / "config.json"
+    cfg.write_text('{"microforce": 3, "drangey": 0.65, "steps": 4.9, "always_take_cnn": 1, "segment_scale": 0.2, "comment": "x", "physics_iterations": 12}')
+    assert L.ht_config_read(str(cfg).encode(), C.byref(p), C.byref(seg), C.byref(pfe)) == 0
+    assert p.microforce == 3.0 and abs(p.drangey - 0.65) < 1e-7 and p.steps == 4 and p.always_take_cnn == 1 and p.physics_iterations == 12
+    assert abs(seg.value - 0.2) < 1e-7
+    assert p.mainthreadpasses == 0 and p.min_point_num == 0 and pfe.value == 0.0      # not in the file: the reference's decoder reads 0
+    bad = tmp_path / "bad.json"; bad.write_text('{"microforce": ')
+    assert L.ht_config_read(str(bad).encode(), C.byref(p), C.byref(seg), C.byref(pfe)) != 0
