@@ -28,13 +28,15 @@
 extern __shared__ __attribute__((aligned(16))) float4 g_sm[];      // [0, nvert): collision vertices of all bodies; then per-wave areas
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-struct support_t { int voff, n; v3 pos; v4 q; int outer; v3 opos; v4 oq; };
+struct support_t { int voff, n; v3 pos; v4 q; int outer; v3 opos; v4 oq; int sub, grp; };      // sub/grp: this lane is member `sub` of a group of `grp` (1, 2 or 4) lanes sharing the pair
 struct mkpoint { v3 a, b, p; float t; };
 struct simplex { v3 v; mkpoint W[4]; int count; };
 struct gjk_hit { v3 normal, p0w, p1w; float separation; };
 
 // ---- support maps ----------------------------------------------------------------------------------------------------
 // per-lane scan (every lane its own shape)
+// Per-pair scan.  A pair is served by a group of 1, 2 or 4 neighbouring lanes (same quad) that hold identical state; the members scan
+// interleaved 6-vertex blocks and then agree on the first maximum (largest value, lowest index) through DPP quad permutes.
 __device__ __forceinline__ v3 support_inner(const support_t &s, v3 dir)
 {
 	const v3 dl = qrot(qconj(s.q), dir);
@@ -43,9 +45,9 @@ __device__ __forceinline__ v3 support_inner(const support_t &s, v3 dir)
 	float best = dot(V3(q0.x, q0.y, q0.z), dl); int bi = 0;
 	const f32x2 dlxy = { dl.x, dl.y };
 	// six vertices per trip (162 and 258 are multiples of 6): the LDS reads of a trip are issued together, then compared in index order.
-	// Vertex 0 is simply tested again (it cannot displace itself); a tail shorter than 6 is handled one by one.
-	int i = 0;
-	for (; i + 6 <= s.n; i += 6)
+	// Vertex 0 is simply tested again (it cannot displace itself); a tail shorter than 6 is handled one by one by member 0.
+	int i = 6 * s.sub;
+	for (; i + 6 <= s.n; i += 6 * s.grp)
 	{
 		const float4 *g = vs + i;
 		float d[6]; int id[6];
@@ -60,11 +62,21 @@ __device__ __forceinline__ v3 support_inner(const support_t &s, v3 dir)
 #pragma unroll
 		for (int k = 0; k < 6; k++) if (best < d[k]) { best = d[k]; bi = id[k]; }
 	}
-	for (; i < s.n; i++)
+	if (s.sub == 0) for (i = (s.n / 6) * 6; i < s.n; i++)
 	{
 		const float4 q = vs[i];
 		const float d = dot(V3(q.x, q.y, q.z), dl);
 		if (best < d) { best = d; bi = i; }
+	}
+	if (s.grp > 1)
+	{
+		float ob = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(best), 0xB1, 0xF, 0xF, true)); int oi = __builtin_amdgcn_mov_dpp(bi, 0xB1, 0xF, 0xF, true);      // quad_perm:[1,0,3,2]
+		if (best < ob || (ob == best && oi < bi)) { best = ob; bi = oi; }
+		if (s.grp > 2)
+		{
+			ob = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(best), 0x4E, 0xF, 0xF, true)); oi = __builtin_amdgcn_mov_dpp(bi, 0x4E, 0xF, 0xF, true);              // quad_perm:[2,3,0,1]
+			if (best < ob || (ob == best && oi < bi)) { best = ob; bi = oi; }
+		}
 	}
 	float4 q = vs[bi];
 	return s.pos + qrot(s.q, V3(q.x, q.y, q.z));
@@ -388,7 +400,7 @@ __device__ v4 inverse_w(v3 c0, v3 c1, v3 c2, v3 c3)
 __device__ __forceinline__ support_t bcast(const support_t &s, int src)
 {
 	support_t r;
-	r.voff = __shfl(s.voff, src); r.n = __shfl(s.n, src); r.outer = __shfl(s.outer, src);
+	r.voff = __shfl(s.voff, src); r.n = __shfl(s.n, src); r.outer = __shfl(s.outer, src); r.sub = 0; r.grp = 1;
 	r.pos = V3(__shfl(s.pos.x, src), __shfl(s.pos.y, src), __shfl(s.pos.z, src));
 	r.q = V4(__shfl(s.q.x, src), __shfl(s.q.y, src), __shfl(s.q.z, src), __shfl(s.q.w, src));
 	r.opos = V3(__shfl(s.opos.x, src), __shfl(s.opos.y, src), __shfl(s.opos.z, src));
@@ -406,7 +418,7 @@ __device__ void separated_wave(bool run, const support_t &A, const support_t &B,
 	tet.v = V3(0, 0, 0);
 	status = 1;
 	if (run) status = gjk_run(A, B, cutoff, hit, tet);
-	unsigned long long need = __ballot(run && status == 2);
+	unsigned long long need = __ballot(run && status == 2 && A.sub == 0);
 	const long long t1 = cyc ? clock64() : 0;
 	if (cyc) { cyc[0] += t1 - t0; cyc[2] += __popcll(need); }
 	while (need)
@@ -427,6 +439,16 @@ __device__ void separated_wave(bool run, const support_t &A, const support_t &B,
 			hit.p1w = ((tet.W[0].b * bw.x + tet.W[1].b * bw.y) + tet.W[2].b * bw.z) + tet.W[3].b * bw.w;
 			status = 0;
 		}
+	}
+	// the polytope ran for member 0 of a group only: hand its result to the other members so that a group stays in lock step
+	if (A.grp > 1 && __any(run && status == 2))
+	{
+		auto m0 = [&](float v) -> float { return A.grp == 4 ? __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x00, 0xF, 0xF, true)) : __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xA0, 0xF, 0xF, true)); };
+		const int st0 = A.grp == 4 ? __builtin_amdgcn_mov_dpp(status, 0x00, 0xF, 0xF, true) : __builtin_amdgcn_mov_dpp(status, 0xA0, 0xF, 0xF, true);
+		gjk_hit h0;
+		h0.normal = V3(m0(hit.normal.x), m0(hit.normal.y), m0(hit.normal.z)); h0.p0w = V3(m0(hit.p0w.x), m0(hit.p0w.y), m0(hit.p0w.z));
+		h0.p1w = V3(m0(hit.p1w.x), m0(hit.p1w.y), m0(hit.p1w.z)); h0.separation = m0(hit.separation);
+		if (run && status == 2) { hit = h0; status = st0; }
 	}
 	if (cyc) cyc[1] += clock64() - t1;
 }
@@ -482,19 +504,21 @@ __global__ __launch_bounds__(64 * GJK_FRAMES) void k_contacts(ht_model_dev M, co
 	__builtin_amdgcn_wave_barrier();
 	long long cyc[3] = { 0, 0, 0 }, cycj[3] = { 0, 0, 0 }; const bool stats = (dbg & 2048) != 0; const long long t_begin = stats ? clock64() : 0; int njig = 0;
 	int nout = 0;                       // contacts written so far for this frame (wave-uniform)
-	for (int base = 0; base < ncand; base += 64)
+	const int grp = ncand <= 16 ? 4 : ncand <= 32 ? 2 : 1;      // lanes per pair: spare lanes share the support scans
+	const int gsh = grp == 4 ? 2 : grp == 2 ? 1 : 0, sub = lane & (grp - 1);
+	for (int base = 0; base < ncand; base += 64 >> gsh)
 	{
-		const int cidx = base + lane;
+		const int cidx = base + (lane >> gsh);
 		const bool keep = cidx < ncand;
 		const int i = keep ? cand[cidx][0] : 0, j = keep ? cand[cidx][1] : 1;
 		// narrow phase, one lane per surviving pair (ContactPatch gjk.h:607-643)
 		support_t A, Bs;
-		A.voff = M.vert_off[i]; A.n = M.vert_off[i + 1] - M.vert_off[i]; A.pos = V3(P[i][0], P[i][1], P[i][2]); A.q = V4(P[i][3], P[i][4], P[i][5], P[i][6]); A.outer = 0; A.opos = V3(0, 0, 0); A.oq = V4(0, 0, 0, 1);
-		Bs.voff = M.vert_off[j]; Bs.n = M.vert_off[j + 1] - M.vert_off[j]; Bs.pos = V3(P[j][0], P[j][1], P[j][2]); Bs.q = V4(P[j][3], P[j][4], P[j][5], P[j][6]); Bs.outer = 0; Bs.opos = V3(0, 0, 0); Bs.oq = V4(0, 0, 0, 1);
+		A.voff = M.vert_off[i]; A.n = M.vert_off[i + 1] - M.vert_off[i]; A.pos = V3(P[i][0], P[i][1], P[i][2]); A.q = V4(P[i][3], P[i][4], P[i][5], P[i][6]); A.outer = 0; A.opos = V3(0, 0, 0); A.oq = V4(0, 0, 0, 1); A.sub = sub; A.grp = grp;
+		Bs.voff = M.vert_off[j]; Bs.n = M.vert_off[j + 1] - M.vert_off[j]; Bs.pos = V3(P[j][0], P[j][1], P[j][2]); Bs.q = V4(P[j][3], P[j][4], P[j][5], P[j][6]); Bs.outer = 0; Bs.opos = V3(0, 0, 0); Bs.oq = V4(0, 0, 0, 1); Bs.sub = sub; Bs.grp = grp;
 		gjk_hit hits[5];
 		int hc = 0, status;
 		separated_wave(keep, A, Bs, (dbg & 16) ? 0.0f : driftmax, em, lane, status, hits[0], dbg, stats ? cyc : nullptr);
-		const bool touching = keep && status == 0 && !(hits[0].separation > driftmax);
+		const bool touching = keep && status == 0 && !(hits[0].separation > driftmax);      // identical in all members of a group
 		if (touching) hc = 1;
 		const float dmin = fminf(M.bodyc[i * HT_BC + HT_BC_DIAM], M.bodyc[j * HT_BC + HT_BC_DIAM]);
 		const bool jig = touching && !(dmin < 0.049f);      // otherwise every jiggle sample is rejected by the 0.05 m proximity test (see header)
@@ -529,6 +553,7 @@ __global__ __launch_bounds__(64 * GJK_FRAMES) void k_contacts(ht_model_dev M, co
 				}
 			}
 		}
+		if (sub != 0) hc = 0;               // member 0 of a group reports the pair
 		// compaction in pair order: exclusive prefix of the per-lane contact counts across the wave
 		int incl = hc;
 #pragma unroll
