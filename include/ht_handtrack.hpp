@@ -148,6 +148,8 @@ struct HandTracker                                                              
 		for (int b = 0; b < nb_; b++) { const float *p = &out[(size_t)b * HT_POSE]; pose[b].position = { p[0], p[1], p[2] }; pose[b].orientation = { p[3], p[4], p[5], p[6] }; }
 		return pose;
 	}
+	// kickstart (handtrack.h:743-746): the CNN job in the calling thread, its pose taken over when it is accepted; no main-thread passes
+	void kickstart(Image<unsigned short> dimage) { const int keep = mainthreadpasses; mainthreadpasses = 0; try { update(std::move(dimage)); } catch (...) { mainthreadpasses = keep; throw; } mainthreadpasses = keep; }
 	// HandSegmentVR (handtrack.h:280-344) on this tracker's device
 	Image<unsigned short> segment(const Image<unsigned short> &depth, int entry_options = 0xF, float2 wrange = { 0.1f, 0.65f }, float diam = 0.17f) const { return segment_on(ctx_, depth, entry_options, wrange, diam); }
 	static Image<unsigned short> segment_on(ht_ctx *ctx, const Image<unsigned short> &depth, int entry_options, float2 wrange, float diam)
