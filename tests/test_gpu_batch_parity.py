@@ -1,0 +1,49 @@
+"""Whole unit of work (CNN + decode + MultiStepSim + accept + 3 FitPointCloud passes) on a batch of the bench's own frames,
+device against the C restatement frame by frame.  The restatement is pinned bit for bit to the reference on the 8 golden
+frames (test_oracle_vs_golden.py); this test widens the comparison to frames the goldens do not cover, including the data-
+dependent branches (chamber on/off at 400 points, full reset, CNN pose accepted / rejected).
+
+The device CNN accumulates in a different order (MFMA tiles), so heat-maps differ by ~1e-6; where that flips nothing the poses
+agree to float rounding.  A flipped accept/reject or arg-max decision changes a pose visibly, so the test bounds how often
+that happens instead of hiding it behind a loose tolerance."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+N = 96
+
+
+def test_batch_against_restatement(weights):
+    from hand_tracking_samples_amd import native
+    d = np.load(os.path.join(HERE, "golden", "frames256.npz"))
+    idx = np.arange(N) * 256 // N
+    depth, cams, start = d["depth"][idx].reshape(N, -1), d["cam"][idx], d["startpose"][idx]
+    ctx = native.Context(ol.MODEL, N)
+    ctx.load_weights(weights)
+    ctx.set_params(microforce=3.0, mainthreadpasses=3)
+    ctx.tracker_reset(start)
+    got = ctx.update_sync(depth, cams)
+    ctx.close()
+    orc = ol.Oracle(weights)
+    orc.head.par.microforce = 3.0; orc.head.par.mainthreadpasses = 3
+    ref = np.zeros((N, 17, 7), np.float32)
+    for k in range(N):
+        orc.reset(start[k])
+        cam = ol.camera(cams[k])
+        orc.L.ho_update(orc.h, ol.u16ptr(np.ascontiguousarray(depth[k])), C.byref(cam), ol.fptr(ref[k]))
+    orc.close()
+    dp = np.abs(got[:, :, :3] - ref[:, :, :3]).max(axis=(1, 2))
+    dq = np.minimum(np.abs(got[:, :, 3:] - ref[:, :, 3:]), np.abs(got[:, :, 3:] + ref[:, :, 3:])).max(axis=(1, 2))
+    tight = (dp <= 2e-5) & (dq <= 2e-4)
+    loose = (dp <= 2e-4) & (dq <= 2e-3)
+    print("frames exact %d, within 2e-5 m / 2e-4: %d, within 2e-4 m / 2e-3: %d of %d; worst |dpos| %.2e m |dquat| %.2e (frame %d)"
+          % (int(((dp == 0) & (dq == 0)).sum()), int(tight.sum()), int(loose.sum()), N, dp.max(), dq.max(), int(dp.argmax())))
+    assert loose.sum() >= N - 2, "more than 2 of %d frames outside 2e-4 m / 2e-3: %s" % (N, np.nonzero(~loose)[0])
+    assert tight.sum() >= N * 3 // 4
+    assert dp.max() < 5e-3      # even a flipped decision stays a small pose change on these frames
