@@ -293,8 +293,9 @@ __device__ __forceinline__ bool above(const epa_mem &m, int t, v3 p, float epsil
 	return dot(n, p - ev(m, m.tv[t][0])) > epsilon;
 }
 // all 64 lanes call this with identical arguments
-__device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 s2, v3 s3, const support_t &A, const support_t &B, int lane)
+__device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 s2, v3 s3, const support_t &A, const support_t &B, int lane, long long *ec)
 {
+	long long tm = ec ? clock64() : 0;
 	v4 plane = V4(0, 0, 0, -FLT_MAX);
 	const float epsilon = 0.001f;
 	int nv = 4, nt = 0;
@@ -324,7 +325,9 @@ __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 
 			if (oi != 0x7fffffff && (bi == 0x7fffffff || ob > bd || (ob == bd && oi < bi))) { bd = ob; bi = oi; bn = V3(ox, oy, oz); }
 		}
 		v4 face = (bi == 0x7fffffff) ? V4(0, 0, 0, -FLT_MAX) : V4(bn, bd);
+		if (ec) { const long long t = clock64(); ec[3] += t - tm; tm = t; ec[6] += 1; }
 		v3 v = support_wave(A, xyz(face), lane) - support_wave(B, -xyz(face), lane);
+		if (ec) { const long long t = clock64(); ec[4] += t - tm; tm = t; }
 		v4 p = V4(xyz(face), -dot(xyz(face), v));
 		if (p.w > plane.w) plane = p;
 		bool dup = false;
@@ -379,6 +382,7 @@ __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 
 		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 		__builtin_amdgcn_wave_barrier();
+		if (ec) { const long long t = clock64(); ec[5] += t - tm; tm = t; }
 	}
 	return plane;
 }
@@ -429,7 +433,7 @@ __device__ void separated_wave(bool run, const support_t &A, const support_t &B,
 		v3 s[4];
 #pragma unroll
 		for (int k = 0; k < 4; k++) s[k] = V3(__shfl(tet.W[k].p.x, src), __shfl(tet.W[k].p.y, src), __shfl(tet.W[k].p.z, src));
-		v4 mpp = (dbg & 32) ? V4(0, 0, 1, -0.001f) : expanding_polytope_wave(em, s[0], s[1], s[2], s[3], Ab, Bb, lane);
+		v4 mpp = (dbg & 32) ? V4(0, 0, 1, -0.001f) : expanding_polytope_wave(em, s[0], s[1], s[2], s[3], Ab, Bb, lane, cyc);
 		if (lane == src)
 		{
 			hit.normal = -xyz(mpp);                                  // gjk.h:417-423
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(64 * GJK_FRAMES) void k_contacts(ht_model_dev M, co
 	}
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the candidate list is read back by other lanes of this wave
 	__builtin_amdgcn_wave_barrier();
-	long long cyc[3] = { 0, 0, 0 }, cycj[3] = { 0, 0, 0 }; const bool stats = (dbg & 2048) != 0; const long long t_begin = stats ? clock64() : 0; int njig = 0;
+	long long cyc[7] = { 0, 0, 0, 0, 0, 0, 0 }, cycj[7] = { 0, 0, 0, 0, 0, 0, 0 }; const bool stats = (dbg & 2048) != 0; const long long t_begin = stats ? clock64() : 0; int njig = 0;
 	int nout = 0;                       // contacts written so far for this frame (wave-uniform)
 	const int grp = ncand <= 16 ? 4 : ncand <= 32 ? 2 : 1;      // lanes per pair: spare lanes share the support scans
 	const int gsh = grp == 4 ? 2 : grp == 2 ? 1 : 0, sub = lane & (grp - 1);
@@ -574,7 +578,7 @@ __global__ __launch_bounds__(64 * GJK_FRAMES) void k_contacts(ht_model_dev M, co
 	if (stats && lane == 0 && nout < HT_MAXCONTACT - 1)      // timing experiments: statistics accumulate in the last contact slot
 	{
 		float *o = contacts + ((size_t)b * HT_MAXCONTACT + HT_MAXCONTACT - 1) * HT_CONTACT;
-		o[0] += 1.0f; o[1] += (float)cyc[0]; o[2] += (float)cyc[1]; o[3] += (float)cyc[2]; o[4] += (float)cycj[0]; o[5] += (float)cycj[1]; o[6] += (float)cycj[2];
+		o[0] += 1.0f; o[1] += (float)cyc[0]; o[2] += (float)cyc[1]; o[3] += (float)cyc[2]; o[4] += (float)cyc[3]; o[5] += (float)cyc[4]; o[6] += (float)cyc[5]; o[11] += (float)cyc[6];
 		o[7] += (float)(clock64() - t_begin); o[8] += (float)ncand; o[9] += (float)njig; o[10] += (float)nout;
 	}
 }

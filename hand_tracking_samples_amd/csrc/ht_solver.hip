@@ -49,11 +49,10 @@ struct lds_t
 	float4 I4[HT_MAXNB][3];                // columns of the world inverse inertia (w unused)
 	float pos[HT_MAXNB][3], q[HT_MAXNB][4];
 	int ccnt[HT_MAXNB], cstart[HT_MAXNB];  // chain of body b: rows [cstart, cstart+ccnt) of the partitioned single-body stream
-	unsigned lorder[MAXL2 + 1];            // two-body linear rows sorted by step: row | rb0 << 16 | rb1 << 24; last slot = the idle entry
-	unsigned short lstart[MAXL2 + 2];      // step L = lorder[lstart[L] .. lstart[L+1]); a step is a level, split so that it holds <= 8 rows
-	unsigned aorder[MAXA2 + 1];            // angular rows likewise (a missing body is the idle body)
+	unsigned lorder[MAXL2 / 3 + 1];        // two-body linear row groups (3 consecutive rows of a joint / a contact) sorted by step: group | rb0 << 16 | rb1 << 24; last slot = the idle entry
+	unsigned short lstart[MAXL2 / 3 + 2];  // step L = lorder[lstart[L] .. lstart[L+1]); a step is a level, split so that it holds <= 8 groups
+	unsigned aorder[MAXA2 + 1];            // angular row groups (runs of consecutive rows on the same body pair): first row | count << 8 | rb0 << 16 | rb1 << 24
 	unsigned short astart[MAXA2 + 2];
-	float cisum[HT_MAXCONTACT];            // impulse sum of each contact's normal row, read by its two friction rows (physics.h:292)
 	int nlev_lin, nlev_ang, nray;
 	union
 	{
@@ -63,7 +62,7 @@ struct lds_t
 			float ray[20][HT_ROW];
 			int acount[HT_MAXNJ], aprefix[HT_MAXNJ + 1];
 			unsigned char lrb[MAXL2][2], arb[MAXA2][2];     // body pair of every two-body row (255 = none), for the level schedule
-			unsigned short llev[MAXL2]; unsigned char alev[MAXA2];
+			unsigned short llev[MAXL2]; unsigned char alev[MAXA2], gst[MAXA2];
 			unsigned short lfill[MAXL2 + 2];
 			int lastlev[HT_MAXNB];                 // scratch of the level scheduler
 		};
@@ -395,33 +394,45 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		o[7] = r0.x; o[8] = r0.y; o[9] = r0.z; o[10] = r1.x; o[11] = r1.y; o[12] = r1.z; o[13] = n.x; o[14] = n.y; o[15] = n.z;
 		S.lrb[r][0] = (unsigned char)rb0; S.lrb[r][1] = (unsigned char)rb1;
 	}
-	for (int i = lane; i < HT_MAXCONTACT; i += 64) S.cisum[i] = 0.0f;
-	if (lane < LROW) S.pool[n2 * LROW + lane] = lane == 4 ? 1.0f : lane == 6 ? __int_as_float(IDLE_BODY | (IDLE_BODY << 8)) : 0.0f;      // idle record: zero limits, unit effective mass
+	if (lane < 3 * LROW) S.pool[n2 * LROW + lane] = (lane % LROW) == 4 ? 1.0f : (lane % LROW) == 6 ? __int_as_float(IDLE_BODY | (IDLE_BODY << 8)) : 0.0f;      // idle group: zero limits, unit effective mass
 	if (lane == 0)
 	{
 		S.lin4[IDLE_BODY] = make_float4(0, 0, 0, 0); S.ang4[IDLE_BODY] = make_float4(0, 0, 0, 0);
 		S.I4[IDLE_BODY][0] = S.I4[IDLE_BODY][1] = S.I4[IDLE_BODY][2] = make_float4(0, 0, 0, 0);
-		S.lorder[MAXL2] = (unsigned)n2 | ((unsigned)IDLE_BODY << 16) | ((unsigned)IDLE_BODY << 24);
+		S.lorder[MAXL2 / 3] = (unsigned)(n2 / 3) | ((unsigned)IDLE_BODY << 16) | ((unsigned)IDLE_BODY << 24);
 	}
 	__syncthreads();
-	// ---- level schedule (one lane, once per solve): level(row) = 1 + max level of an earlier row sharing a body.  Rows are then
-	//      counting-sorted by level into steps of at most 8 rows (one per lane pair); rows of one level touch disjoint bodies ----
+	// ---- level schedule, once per solve.  The unit is a group: the 3 consecutive rows of a joint or of a contact (same two bodies, same lever
+	//      arms), respectively a run of consecutive angular rows on the same body pair.  level(group) = 1 + max level of an earlier group sharing
+	//      a body, so conflicting rows keep the reference's order; a group's own rows run back to back in one lane pair with the momenta in
+	//      registers.  Groups are counting-sorted by level into steps of at most 8 groups (one per lane pair). ----
 	if (na > MAXA_LDS) na = MAXA_LDS;
+	int nga = 0;
+	for (int base = 0; base < na; base += 64)          // heads of the angular runs, found one row per lane
+	{
+		const int r = base + lane;
+		const bool head = r < na && (r == 0 || S.arb[r][0] != S.arb[r - 1][0] || S.arb[r][1] != S.arb[r - 1][1]);
+		const unsigned long long m = __ballot(head);
+		if (head) S.gst[nga + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned char)r;
+		nga += __popcll(m);
+	}
+	__syncthreads();
 	if (lane == 0)
 	{
 		int *last = S.lastlev;               // LDS, not a private array: dynamic indexing of a private array goes to scratch memory
+		const int ng2 = n2 / 3;
 		for (int k = 0; k < nb; k++) last[k] = 0;
 		int mx = 0;
-		for (int r = 0; r < n2; r++)
+		for (int g = 0; g < ng2; g++)
 		{
-			const int b0 = S.lrb[r][0], b1 = S.lrb[r][1];
+			const int b0 = S.lrb[3 * g][0], b1 = S.lrb[3 * g][1];
 			int l = (last[b0] > last[b1] ? last[b0] : last[b1]) + 1;
-			last[b0] = l; last[b1] = l; S.llev[r] = (unsigned short)l; if (l > mx) mx = l;
+			last[b0] = l; last[b1] = l; S.llev[g] = (unsigned short)l; if (l > mx) mx = l;
 		}
 		for (int l = 0; l <= mx + 1; l++) S.lfill[l] = 0;
-		for (int r = 0; r < n2; r++) S.lfill[S.llev[r]]++;
+		for (int g = 0; g < ng2; g++) S.lfill[S.llev[g]]++;
 		int acc = 0, step = 1;
-		for (int l = 1; l <= mx; l++)          // lfill[l] becomes the first slot of level l; steps are cut every 8 rows inside a level
+		for (int l = 1; l <= mx; l++)          // lfill[l] becomes the first slot of level l; steps are cut every 8 groups inside a level
 		{
 			const int m = S.lfill[l];
 			S.lfill[l] = (unsigned short)acc;
@@ -430,21 +441,22 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		}
 		S.lstart[step] = (unsigned short)acc; S.lstart[step + 1] = (unsigned short)acc;
 		S.nlev_lin = step - 1;
-		for (int r = 0; r < n2; r++) { const int l = S.llev[r]; S.lorder[S.lfill[l]] = (unsigned)r | ((unsigned)S.lrb[r][0] << 16) | ((unsigned)S.lrb[r][1] << 24); S.lfill[l]++; }
-		// angular rows
+		for (int g = 0; g < ng2; g++) { const int l = S.llev[g]; S.lorder[S.lfill[l]] = (unsigned)g | ((unsigned)S.lrb[3 * g][0] << 16) | ((unsigned)S.lrb[3 * g][1] << 24); S.lfill[l]++; }
+		// angular groups
 		for (int k = 0; k < nb; k++) last[k] = 0;
 		mx = 0;
-		for (int r = 0; r < na; r++)
+		for (int g = 0; g < nga; g++)
 		{
+			const int r = S.gst[g];
 			const int b0 = S.arb[r][0], b1 = S.arb[r][1];
 			int l0 = b0 != 255 ? last[b0] : 0, l1 = b1 != 255 ? last[b1] : 0;
 			int l = (l0 > l1 ? l0 : l1) + 1;
 			if (b0 != 255) last[b0] = l;
 			if (b1 != 255) last[b1] = l;
-			S.alev[r] = (unsigned char)l; if (l > mx) mx = l;
+			S.alev[g] = (unsigned char)l; if (l > mx) mx = l;
 		}
 		for (int l = 0; l <= mx + 1; l++) S.lfill[l] = 0;
-		for (int r = 0; r < na; r++) S.lfill[S.alev[r]]++;
+		for (int g = 0; g < nga; g++) S.lfill[S.alev[g]]++;
 		acc = 0; step = 1;
 		for (int l = 1; l <= mx; l++)
 		{
@@ -455,8 +467,13 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		}
 		S.astart[step] = (unsigned short)acc; S.astart[step + 1] = (unsigned short)acc;
 		S.nlev_ang = step - 1;
-		for (int r = 0; r < na; r++) { const int l = S.alev[r]; const unsigned b0 = S.arb[r][0] == 255 ? IDLE_BODY : S.arb[r][0], b1 = S.arb[r][1] == 255 ? IDLE_BODY : S.arb[r][1]; S.aorder[S.lfill[l]] = (unsigned)r | (b0 << 16) | (b1 << 24); S.lfill[l]++; }
-		S.aorder[MAXA2] = (unsigned)na | ((unsigned)IDLE_BODY << 16) | ((unsigned)IDLE_BODY << 24);
+		for (int g = 0; g < nga; g++)
+		{
+			const int l = S.alev[g], r = S.gst[g], cnt = (g + 1 < nga ? (int)S.gst[g + 1] : na) - r;
+			const unsigned b0 = S.arb[r][0] == 255 ? IDLE_BODY : S.arb[r][0], b1 = S.arb[r][1] == 255 ? IDLE_BODY : S.arb[r][1];
+			S.aorder[S.lfill[l]] = (unsigned)r | ((unsigned)cnt << 8) | (b0 << 16) | (b1 << 24); S.lfill[l]++;
+		}
+		S.aorder[MAXA2] = (unsigned)na | (1u << 8) | ((unsigned)IDLE_BODY << 16) | ((unsigned)IDLE_BODY << 24);
 	}
 	__syncthreads();
 	const int nlev_lin = S.nlev_lin, nlev_ang = S.nlev_ang;
@@ -467,8 +484,8 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	const int npre = a.ray_rows ? S.nray : npre_g;
 	const int ncl = a.rows_cloud ? a.n_cloud[b] : 0;
 	const int n1 = npre + ncl;
-	float *const chain = S.pool + (n2 + 1) * LROW;                // chain rows follow the two-body rows (+ the idle record) in the pool
-	int chcap = (POOL_FLOATS - (n2 + 1) * LROW) / CROW - 2;             // rows that fit in LDS (the sweep reads up to 2 records ahead); the rest stream from the HBM scratch
+	float *const chain = S.pool + (n2 + 3) * LROW;                // chain rows follow the two-body rows (+ the idle group) in the pool
+	int chcap = (POOL_FLOATS - (n2 + 3) * LROW) / CROW - 2;             // rows that fit in LDS (the sweep reads up to 2 records ahead); the rest stream from the HBM scratch
 	if (chcap < 0) chcap = 0;
 	float *scr = a.scratch + (size_t)b * a.scratch_stride * CROW;
 	auto row_ptr = [&](int i) -> const float * {
@@ -597,59 +614,67 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		}
 		__builtin_amdgcn_wave_barrier();
 		if (stats) { const long long t = clock64(); cyc_chain += t - t_mark; t_mark = t; }
-		// (2) two-body linear rows, step by step (LimitLinear::Iter physics.h:289-307): lane pair p takes the p-th row of the step, pairs
-		//     without a row work on the idle record / idle body, so a step is branch-free.  Three-stage software pipeline: the sort entry
-		//     is fetched two steps ahead, the row record and the (sweep-invariant) inverse inertia and mass one step ahead; only the
-		//     momenta are read after the previous step's stores.  Two register sets alternate, so nothing is copied between steps.
+		// (2) two-body linear rows (LimitLinear::Iter physics.h:289-307), one group per lane pair and step: the 3 rows of a joint (x, y, z) or
+		//     of a contact (normal, two friction rows) share bodies and lever arms and are applied back to back with the momenta in
+		//     registers.  Pairs without a group work on the idle group / idle body, so a step is branch-free.  Three-stage software
+		//     pipeline: the sort entry is fetched two steps ahead, the group's records and the (sweep-invariant) inverse inertia and mass
+		//     one step ahead; only the momenta are read after the previous step's stores.  Two register sets alternate.
 		if (!(a.dbg & 2) && nlev_lin > 0)
 		{
-			struct lset { unsigned e; float ts, fmn, fmx, eff, isum, rv, n, Ix, Iy, Iz, minv; int meta; };
+			struct lset { unsigned e; int meta; float rv, n0, n1, n2, Ix, Iy, Iz, minv; float4 s0, s1, s2; float e0, e1, e2, i0, i1, i2; };
 			auto entry = [&](int L) -> unsigned {
-				if (L > nlev_lin) return S.lorder[MAXL2];
+				if (L > nlev_lin) return S.lorder[MAXL2 / 3];
 				int lo, hi;
 				if (L < 63) { lo = __builtin_amdgcn_readlane(ls_lin, L); hi = __builtin_amdgcn_readlane(ls_lin, L + 1); }
 				else { lo = S.lstart[L]; hi = S.lstart[L + 1]; }
 				const int idx = lo + pslot;
-				return S.lorder[idx < hi ? idx : MAXL2];
+				return S.lorder[idx < hi ? idx : MAXL2 / 3];
 			};
 			auto fetch = [&](lset &r, unsigned e) {
 				r.e = e;
-				const float *R = S.pool + (int)(e & 0xFFFF) * LROW;
+				const float *R = S.pool + (int)(e & 0xFFFF) * (3 * LROW);
 				const int body = side ? (int)(e >> 24) : (int)((e >> 16) & 255);
-				r.ts = R[tsoff]; r.fmn = R[2]; r.fmx = R[3]; r.eff = R[4]; r.isum = R[5]; r.meta = __float_as_int(R[6]);
-				r.rv = R[7 + 3 * side + c]; r.n = R[13 + c];
+				r.meta = __float_as_int(R[6]);
+				r.rv = R[7 + 3 * side + c];                                   // the lever arm is the same for the 3 rows
+				r.n0 = R[13 + c]; r.n1 = R[LROW + 13 + c]; r.n2 = R[2 * LROW + 13 + c];
+				r.s0 = *reinterpret_cast<const float4 *>(R); r.s1 = *reinterpret_cast<const float4 *>(R + LROW); r.s2 = *reinterpret_cast<const float4 *>(R + 2 * LROW);      // ts ts_post fmin fmax
+				r.e0 = R[4]; r.i0 = R[5]; r.e1 = R[LROW + 4]; r.i1 = R[LROW + 5]; r.e2 = R[2 * LROW + 4]; r.i2 = R[2 * LROW + 5];
 				r.Ix = I_w[12 * body + c]; r.Iy = I_w[12 * body + 4 + c]; r.Iz = I_w[12 * body + 8 + c]; r.minv = lin_w[4 * body + 3];
 			};
 			auto step = [&](const lset &r) {
 				const int body = side ? (int)(r.e >> 24) : (int)((r.e >> 16) & 255);
-				const float l = lin_w[4 * body + c], av = ang_w[4 * body + c];
-				float fmn = r.fmn, fmx = r.fmx;
-				if (r.meta & LM_FRIC)
+				float l = lin_w[4 * body + c], av = ang_w[4 * body + c];
+				auto row = [&](float n, float ts, float fmn, float fmx, float eff, float isum) -> float {
+					const float w = (r.Ix * dpp<QP_BC0>(av) + r.Iy * dpp<QP_BC1>(av)) + r.Iz * dpp<QP_BC2>(av);
+					const float m1 = w * dpp<QP_ROT1>(r.rv), m2 = w * dpp<QP_ROT2>(r.rv);
+					const float v = (dpp<QP_ROT1>(m1) - dpp<QP_ROT2>(m2)) + l * r.minv;                       // velocity of this side's anchor
+					const float u = __int_as_float(__float_as_int(v) ^ sidesign);                             // rb1 side: v1, rb0 side: -v0
+					const float d = u + pair_swap(u);                                                          // (v1 - v0)[c] on both sides (v1 + -v0)
+					const float p = d * n;
+					const float vn = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);
+					const float impulsen = -ts - vn;
+					float impulse = div_ieee(impulsen, eff);
+					impulse = clamp_med3(impulse, fmn - isum, fmx - isum);
+					const float imp = n * __int_as_float(__float_as_int(impulse) ^ sidesign);                  // rb0: n * -impulse, rb1: n * impulse
+					l = l + imp;
+					const float k1 = r.rv * dpp<QP_ROT1>(imp), k2 = r.rv * dpp<QP_ROT2>(imp);
+					av = av + (dpp<QP_ROT1>(k1) - dpp<QP_ROT2>(k2));                                           // + cross(r, imp)[c]
+					return isum + impulse;
+				};
+				const float ns0 = row(r.n0, post ? r.s0.y : r.s0.x, r.s0.z, r.s0.w, r.e0, r.i0);
+				float f1n = r.s1.z, f1x = r.s1.w, f2n = r.s2.z, f2x = r.s2.w;
+				if (r.meta & LM_NORMAL)       // a contact: the friction rows are limited by the normal row's impulse sum (physics.h:292); their fmax slot holds mu
 				{
-					const float master = S.cisum[(r.meta >> 24) & 255];
-					const float lim = fmx * master / dt;       // physics.h:292 (fmx slot holds max(friction0, friction1))
-					fmx = lim * dt; fmn = (-lim) * dt;
+					const float lim1 = f1x * ns0 / dt; f1x = lim1 * dt; f1n = (-lim1) * dt;
+					const float lim2 = f2x * ns0 / dt; f2x = lim2 * dt; f2n = (-lim2) * dt;
 				}
-				const float w = (r.Ix * dpp<QP_BC0>(av) + r.Iy * dpp<QP_BC1>(av)) + r.Iz * dpp<QP_BC2>(av);
-				const float m1 = w * dpp<QP_ROT1>(r.rv), m2 = w * dpp<QP_ROT2>(r.rv);
-				const float v = (dpp<QP_ROT1>(m1) - dpp<QP_ROT2>(m2)) + l * r.minv;                       // velocity of this side's anchor
-				const float u = __int_as_float(__float_as_int(v) ^ sidesign);                             // rb1 side: v1, rb0 side: -v0
-				const float d = u + pair_swap(u);                                                          // (v1 - v0)[c] on both sides (v1 + -v0)
-				const float p = d * r.n;
-				const float vn = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);
-				const float impulsen = -r.ts - vn;
-				float impulse = div_ieee(impulsen, r.eff);
-				impulse = clamp_med3(impulse, fmn - r.isum, fmx - r.isum);
-				const float imp = r.n * __int_as_float(__float_as_int(impulse) ^ sidesign);                // rb0: n * -impulse, rb1: n * impulse
-				const float ln = l + imp;
-				const float k1 = r.rv * dpp<QP_ROT1>(imp), k2 = r.rv * dpp<QP_ROT2>(imp);
-				const float an = av + (dpp<QP_ROT1>(k1) - dpp<QP_ROT2>(k2));                               // + cross(r, imp)[c]
-				if (c < 3) { lin_w[4 * body + c] = ln; ang_w[4 * body + c] = an; }
+				const float ns1 = row(r.n1, post ? r.s1.y : r.s1.x, f1n, f1x, r.e1, r.i1);
+				const float ns2 = row(r.n2, post ? r.s2.y : r.s2.x, f2n, f2x, r.e2, r.i2);
+				if (c < 3) { lin_w[4 * body + c] = l; ang_w[4 * body + c] = av; }
 				else if (side == 0)
 				{
-					const float ns = r.isum + impulse;
-					S.pool[(int)(r.e & 0xFFFF) * LROW + 5] = ns;
-					if (r.meta & LM_NORMAL) S.cisum[(r.meta >> 24) & 255] = ns;
+					float *R = S.pool + (int)(r.e & 0xFFFF) * (3 * LROW);
+					R[5] = ns0; R[LROW + 5] = ns1; R[2 * LROW + 5] = ns2;
 				}
 			};
 			lset A, Bs;
@@ -668,7 +693,8 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		}
 		__builtin_amdgcn_wave_barrier();
 		if (stats) { const long long t = clock64(); cyc_lin += t - t_mark; t_mark = t; }
-		// (3) angular rows, step by step (LimitAngular::Iter physics.h:251-265), same lane mapping and pipeline
+		// (3) angular rows (LimitAngular::Iter physics.h:251-265): one run of consecutive rows on the same body pair per lane pair and step,
+		//     same pipeline; inside a run the next row's record is read while the current row is applied
 		if (!(a.dbg & 4) && nlev_ang > 0)
 		{
 			struct aset { unsigned e; float ax, ts, mn, mx, s2t, torque, Ix, Iy, Iz; };
@@ -682,26 +708,36 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			};
 			auto fetch = [&](aset &r, unsigned e) {
 				r.e = e;
-				const float *R = S.arec + (int)(e & 0xFFFF) * AROW;
+				const float *R = S.arec + (int)(e & 0xFF) * AROW;
 				const int body = side ? (int)(e >> 24) : (int)((e >> 16) & 255);
 				r.ax = R[c]; r.ts = R[4 + tsoff]; r.mn = R[6]; r.mx = R[7]; r.s2t = R[8]; r.torque = R[9];
 				r.Ix = I_w[12 * body + c]; r.Iy = I_w[12 * body + 4 + c]; r.Iz = I_w[12 * body + 8 + c];
 			};
 			auto step = [&](const aset &r) {
 				const int body = side ? (int)(r.e >> 24) : (int)((r.e >> 16) & 255);
-				const float av = ang_w[4 * body + c];
-				const float w = (r.Ix * dpp<QP_BC0>(av) + r.Iy * dpp<QP_BC1>(av)) + r.Iz * dpp<QP_BC2>(av);
-				const float p = w * r.ax;
-				const float sp = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);                       // dot(Iinv*angular_momentum, axis) of this side
-				const float u = __int_as_float(__float_as_int(body != IDLE_BODY ? sp : 0.0f) ^ sidesign);     // a missing body contributes exactly 0
-				const float currentspin = u + pair_swap(u);                                                // spin1 - spin0
-				const float dspin = r.ts - currentspin;
-				float dtorque = dspin * r.s2t;
-				dtorque = clamp_med3(dtorque, r.mn - r.torque, r.mx - r.torque);
-				if (r.ts == -FLT_MAX) dtorque = 0.0f;                                                      // disabled row (physics.h:252)
-				const float an = av + __int_as_float(__float_as_int(r.ax * dtorque) ^ sidesign);           // rb0: a - axis*dtorque, rb1: a + axis*dtorque
-				if (c < 3) { if (body != IDLE_BODY) ang_w[4 * body + c] = an; }
-				else if (side == 0) S.arec[(int)(r.e & 0xFFFF) * AROW + 9] = r.torque + dtorque;
+				const int cnt = (int)((r.e >> 8) & 255);
+				const bool bv = body != IDLE_BODY;
+				float av = ang_w[4 * body + c];
+				float *R = S.arec + (int)(r.e & 0xFF) * AROW;
+				float ax = r.ax, ts = r.ts, mn = r.mn, mx = r.mx, s2t = r.s2t, torque = r.torque;
+				for (int k = 0; k < cnt; k++)
+				{
+					const float *N = R + ((k + 1 < cnt) ? AROW : 0);
+					const float nax = N[c], nts = N[4 + tsoff], nmn = N[6], nmx = N[7], ns2t = N[8], ntq = N[9];      // next row of the run
+					const float w = (r.Ix * dpp<QP_BC0>(av) + r.Iy * dpp<QP_BC1>(av)) + r.Iz * dpp<QP_BC2>(av);
+					const float p = w * ax;
+					const float sp = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);                       // dot(Iinv*angular_momentum, axis) of this side
+					const float u = __int_as_float(__float_as_int(bv ? sp : 0.0f) ^ sidesign);                 // a missing body contributes exactly 0
+					const float currentspin = u + pair_swap(u);                                                // spin1 - spin0
+					const float dspin = ts - currentspin;
+					float dtorque = dspin * s2t;
+					dtorque = clamp_med3(dtorque, mn - torque, mx - torque);
+					if (ts == -FLT_MAX) dtorque = 0.0f;                                                        // disabled row (physics.h:252)
+					av = av + __int_as_float(__float_as_int(ax * dtorque) ^ sidesign);                         // rb0: a - axis*dtorque, rb1: a + axis*dtorque
+					if (c == 3 && side == 0) R[9] = torque + dtorque;
+					R += AROW; ax = nax; ts = nts; mn = nmn; mx = nmx; s2t = ns2t; torque = ntq;
+				}
+				if (c < 3 && bv) ang_w[4 * body + c] = av;
 			};
 			aset A, Bs;
 			fetch(A, entry(1));

@@ -289,8 +289,8 @@ extern "C" int ht_debug_solve_stats(ht_ctx *ctx, int B, float *out, int reset)
 	}
 	return HT_OK;
 }
-// Same for k_contacts (last contact slot of each frame): launches, cycles in first GJK / its polytope runs, polytope runs, cycles in the
-// jiggle GJK runs / their polytope runs, polytope runs, total cycles, candidate pairs, pairs that jiggle, contacts.
+// Same for k_contacts (last contact slot of each frame): launches, cycles in GJK / polytope runs, polytope runs, polytope cycles in
+// face scoring / support scans / mesh surgery, total cycles, candidate pairs, pairs that jiggle, contacts, polytope iterations.
 extern "C" int ht_debug_contact_stats(ht_ctx *ctx, int B, float *out, int reset)
 {
 	if (!ctx || !ctx->ready || B < 1 || B > ctx->B) return HT_ERR_ARG;

@@ -35,6 +35,6 @@ w = st[:, 4].argmax()
 print("worst frame", w, st[w])
 
 print("---- k_contacts (sum over %s launches per frame)" % np.unique(cs[:, 0]))
-for k, nm in zip(range(1, 11), ["gjk1_cycles", "epa1_cycles", "epa1_runs", "gjkJ_cycles", "epaJ_cycles", "epaJ_runs", "total_cycles", "candidates", "jiggle_pairs", "contacts"]):
+for k, nm in zip(range(1, 12), ["gjk1_cycles", "epa1_cycles", "epa1_runs", "epa_score", "epa_support", "epa_surgery", "total_cycles", "candidates", "jiggle_pairs", "contacts", "epa_iters"]):
     c = cs[:, k]
     print("%-13s per frame: mean %.0f  p50 %.0f  p90 %.0f  max %.0f (frame %d)" % (nm, c.mean(), np.median(c), np.percentile(c, 90), c.max(), c.argmax()))
