@@ -66,7 +66,7 @@ struct lds_t
 			unsigned short lfill[MAXL2 + 2];
 			int lastlev[HT_MAXNB];                 // scratch of the level scheduler
 		};
-		float arec[(MAXA_LDS + 1) * AROW];         // sweeps: angular row records (written once the prologue scratch is dead) + the idle record
+		float arec[(MAXA_LDS + 2) * AROW];         // sweeps: angular row records (written once the prologue scratch is dead) + the idle record + read-ahead slack
 	};
 	float pool[POOL_FLOATS] __attribute__((aligned(16)));
 };
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			o[6] = R.mn; o[7] = R.mx; o[8] = R.s2t; o[9] = 0.0f;
 		}
 	}
-	if (lane < AROW) S.arec[na * AROW + lane] = 0.0f;      // idle record
+	if (lane < 2 * AROW) S.arec[na * AROW + lane] = 0.0f;      // idle record + read-ahead slack
 	__syncthreads();
 
 	if (a.dbg & 128) return;
@@ -722,8 +722,8 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				float ax = r.ax, ts = r.ts, mn = r.mn, mx = r.mx, s2t = r.s2t, torque = r.torque;
 				for (int k = 0; k < cnt; k++)
 				{
-					const float *N = R + ((k + 1 < cnt) ? AROW : 0);
-					const float nax = N[c], nts = N[4 + tsoff], nmn = N[6], nmx = N[7], ns2t = N[8], ntq = N[9];      // next row of the run
+					const float *N = R + AROW;
+					const float nax = N[c], nts = N[4 + tsoff], nmn = N[6], nmx = N[7], ns2t = N[8], ntq = N[9];      // next row of the run (or the record after it)
 					const float w = (r.Ix * dpp<QP_BC0>(av) + r.Iy * dpp<QP_BC1>(av)) + r.Iz * dpp<QP_BC2>(av);
 					const float p = w * ax;
 					const float sp = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);                       // dot(Iinv*angular_momentum, axis) of this side
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 					dtorque = clamp_med3(dtorque, mn - torque, mx - torque);
 					if (ts == -FLT_MAX) dtorque = 0.0f;                                                        // disabled row (physics.h:252)
 					av = av + __int_as_float(__float_as_int(ax * dtorque) ^ sidesign);                         // rb0: a - axis*dtorque, rb1: a + axis*dtorque
-					if (c == 3 && side == 0) R[9] = torque + dtorque;
+					R[9] = torque + dtorque;                                                                    // the same value from every lane of the pair
 					R += AROW; ax = nax; ts = nts; mn = nmn; mx = nmx; s2t = ns2t; torque = ntq;
 				}
 				if (c < 3 && bv) ang_w[4 * body + c] = av;
