@@ -485,7 +485,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	const int ncl = a.rows_cloud ? a.n_cloud[b] : 0;
 	const int n1 = npre + ncl;
 	float *const chain = S.pool + (n2 + 3) * LROW;                // chain rows follow the two-body rows (+ the idle group) in the pool
-	int chcap = (POOL_FLOATS - (n2 + 3) * LROW) / CROW - 2;             // rows that fit in LDS (the sweep reads up to 2 records ahead); the rest stream from the HBM scratch
+	int chcap = (POOL_FLOATS - (n2 + 3) * LROW) / CROW - 4;             // rows that fit in LDS (the sweep reads up to 2 records ahead); the rest stream from the HBM scratch
 	if (chcap < 0) chcap = 0;
 	float *scr = a.scratch + (size_t)b * a.scratch_stride * CROW;
 	auto row_ptr = [&](int i) -> const float * {
@@ -595,14 +595,20 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				const int nl = (start + cnt <= chcap) ? cnt : (start >= chcap ? 0 : chcap - start);
 				if (nl > 0)
 				{
+					// two rows per trip on alternating register sets: while one row is applied the other's record is already on its way
 					float *pv = chain + start * CROW + lane_off, *pn = chain + start * CROW + 4 + c, *pt = chain + start * CROW + 8;
-					float rv = pv[0], n = pn[0]; float4 t = *reinterpret_cast<const float4 *>(pt);
-					for (int k = 0; k < nl; k++)
+					float rvA = pv[0], nA = pn[0]; float4 tA = *reinterpret_cast<const float4 *>(pt);
+					float rvB = pv[CROW], nB = pn[CROW]; float4 tB = *reinterpret_cast<const float4 *>(pt + CROW);
+					int k = 0;
+					for (; k + 2 <= nl; k += 2)
 					{
-						const float nrv = pv[CROW], nn = pn[CROW]; const float4 nt = *reinterpret_cast<const float4 *>(pt + CROW);      // next record (or slack)
-						pt[3] = row_step(rv, n, t);
-						rv = nrv; n = nn; t = nt; pv += CROW; pn += CROW; pt += CROW;
+						pt[3] = row_step(rvA, nA, tA);
+						rvA = pv[2 * CROW]; nA = pn[2 * CROW]; tA = *reinterpret_cast<const float4 *>(pt + 2 * CROW);
+						pt[CROW + 3] = row_step(rvB, nB, tB);
+						rvB = pv[3 * CROW]; nB = pn[3 * CROW]; tB = *reinterpret_cast<const float4 *>(pt + 3 * CROW);
+						pv += 2 * CROW; pn += 2 * CROW; pt += 2 * CROW;
 					}
+					if (k < nl) pt[3] = row_step(rvA, nA, tA);
 				}
 				for (int k = nl; k < cnt; k++)
 				{
