@@ -36,7 +36,7 @@ static void join(ht_ctx *ctx, hipStream_t s, int n) { for (int i = 0; i < n; i++
 
 // HandTracker::MultiStepSim on othermodel (handtrack.h:642-690)
 // `first_active`: when given, step 0 only touches the frames whose flag is set (the others did it already, see run_update)
-static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int to_step = 1 << 30, const int *active = nullptr)
+static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int to_step = 1 << 30, const int *active = nullptr, bool first_contacts_done = false)
 {
 	const ht_params &p = ctx->par;
 	for (int st = from_step; st < p.steps && st < to_step; st++)
@@ -45,10 +45,11 @@ static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int 
 		const bool rays = (st < p.steps_keypoints) && !p.angles_only;
 		const bool cloud = (st >= p.steps_cloudstart) && !p.angles_only;
 		const bool coll = ctx->phys.use_collision != 0;
-		const bool par = cloud && coll && !ctx->profile_phases;
+		static const bool no_side = getenv("HT_NO_SIDE") != nullptr;      // timing experiments
+		const bool par = cloud && coll && !ctx->profile_phases && !no_side;
 		if (par) fork(ctx, s);
 		if (cloud) { ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, active, 4, 1, 2, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[0] : s); }
-		if (coll) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, active, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s); }
+		if (coll && !(first_contacts_done && st == from_step)) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, active, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s); }
 		if (par) join(ctx, s, 1);
 		ht_prof_scope ps(ctx, "solve", s);
 		solve_step(ctx, 1, nullptr, nullptr, cloud, coll, active, angles, st < p.steps_palmangle ? 10000.0f : 0.0f, rays, 1, 1, B, s);
@@ -59,7 +60,8 @@ static void main_pass(ht_ctx *ctx, int B, hipStream_t s)
 {
 	const ht_params &p = ctx->par;
 	const bool coll = ctx->phys.use_collision != 0;
-	const bool par = !ctx->profile_phases;
+	static const bool no_side = getenv("HT_NO_SIDE") != nullptr;
+	const bool par = !ctx->profile_phases && !no_side;
 	if (par) fork(ctx, s);
 	{ ht_prof_scope ps(ctx, "chamber", s, true); ht_launch_chamber(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, p.min_point_num, p.boundary_planes, 10.0f, ctx->d_chamber, ctx->d_nchamber, B, par ? ctx->side[1] : s); }
 	{ ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, ctx->d_cams, nullptr, 1, 0, 1, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[0] : s); }
@@ -94,27 +96,41 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 	}
 	{ ht_prof_scope ps(ctx, "prepare", s, true); ht_launch_prepare(d_depth, ctx->d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, ctx->d_pts, ctx->d_npts, B, s); }
 	float *cnn_out = d_cnn_out ? d_cnn_out : ctx->d_cnn_out;
+	static const bool no_overlap = getenv("HT_NO_OVERLAP") != nullptr;      // timing experiments
+	const bool overlap = !no_overlap && !ctx->profile_phases && p.steps >= 1 && p.steps_cloudstart >= 1 && !p.angles_only;
+	if (overlap)
+	{
+		// Nothing on this side branch needs the CNN: the error of the carried pose, the reset decision, and the contacts of MultiStepSim's
+		// first step for the frames that keep their pose only read the point cloud and the tracker state, so they run beside the CNN.
+		hipStream_t t = ctx->side[1];
+		fork(ctx, s);
+		ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, t);                       // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757
+		ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, ctx->d_cams, p.bone_sum_error_scale, ctx->d_err_old, B, t);
+		ht_launch_decide_reset(ctx->d_err_old, p.full_reset_on_error, p.angles_only, ctx->d_flags, ctx->d_nflags, B, t);
+		if (ctx->phys.use_collision) ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, ctx->d_nflags, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, t);
+	}
 	{
 		ht_prof_scope ps(ctx, "cnn", s, true);
 		ht_launch_cnn(ctx->cnnw, ctx->d_cnn_in, ctx->d_act1, ctx->d_act2, ctx->d_act3, ctx->d_logits, B, s);
 		ht_launch_softmax_decode(ctx->d_logits, cnn_out, ctx->d_cams, ctx->d_analysis, 1, B, s);
 	}
-	ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, s);                       // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757
-	{ ht_prof_scope ps(ctx, "fit_error", s, true); ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, ctx->d_cams, p.bone_sum_error_scale, ctx->d_err_old, B, s); }
-	ht_launch_decide_reset(ctx->d_err_old, p.full_reset_on_error, p.angles_only, ctx->d_flags, ctx->d_nflags, B, s);
-	if (!ctx->profile_phases && p.steps >= 1 && p.steps_cloudstart >= 1 && !p.angles_only)
+	if (overlap)
 	{
+		(void)hipEventRecord(ctx->ev_join[1], ctx->side[1]); (void)hipStreamWaitEvent(s, ctx->ev_join[1], 0);
 		// the full-reset path touches few frames but is long (3 sequential single-body solves): it runs on a side stream while step 0 of
 		// MultiStepSim (which uses no cloud rows) proceeds for all other frames; the reset frames then do their step 0 on their own
 		fork(ctx, s);
 		reset_path(ctx, ctx->d_flags, p.steps_unibody, B, ctx->side[0], s);
-		multistep(ctx, B, s, 0, 1, ctx->d_nflags);
+		multistep(ctx, B, s, 0, 1, ctx->d_nflags, true);
 		join(ctx, s, 1);
 		multistep(ctx, B, s, 0, 1, ctx->d_flags);
 		multistep(ctx, B, s, 1);
 	}
 	else
 	{
+		ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, s);                       // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757
+		{ ht_prof_scope ps(ctx, "fit_error", s, true); ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, ctx->d_cams, p.bone_sum_error_scale, ctx->d_err_old, B, s); }
+		ht_launch_decide_reset(ctx->d_err_old, p.full_reset_on_error, p.angles_only, ctx->d_flags, ctx->d_nflags, B, s);
 		reset_path(ctx, ctx->d_flags, p.steps_unibody, B, s, s);
 		multistep(ctx, B, s);
 	}
