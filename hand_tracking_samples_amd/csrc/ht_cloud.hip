@@ -101,26 +101,16 @@ __device__ __forceinline__ void closest_feature(const ht_model_dev &M, const flo
 // a wave then works on sit on the same part of the hand and cull the same bodies: the plane loops below are wave-uniform and run for a
 // body as soon as one lane needs it.  The grouping changes which bodies a wave evaluates, never a point's result.
 #define CR_THREADS 256
-__global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const float *__restrict__ state, const float4 *__restrict__ pts, const int *__restrict__ npts,
-                                                           const float *__restrict__ cams, const int *__restrict__ active_flag, int stride, int use_cam_origin, int mode,
-                                                           float microforce, float weak_force, float cf_max_point, float cf_max_sum, float unibody_force,
-                                                           float *__restrict__ rows, int *__restrict__ nrows)
+// Bins the `nsub` points (every `stride`-th of the frame's cloud) by the body the inner-sphere test prefers; perm lists the point
+// indices bin after bin.  Called by all CR_THREADS threads of a block.
+__device__ void bin_points_by_body(const ht_model_dev &M, const float *tab, const float4 *__restrict__ fpts, int nsub, int stride, unsigned short *perm, unsigned char *key, int *bin)
 {
-	__shared__ float tab[HT_MAXNB * BT];
-	__shared__ unsigned short perm[HT_MAXPTS];
-	__shared__ unsigned char key[HT_MAXPTS];
-	__shared__ int bin[HT_MAXNB];
-	const int b = blockIdx.x, t = threadIdx.x;
-	const int n = npts[b];
-	const int nsub = (n + stride - 1) / stride;
-	if (t == 0) nrows[b] = (active_flag && !active_flag[b]) ? 0 : nsub;
-	if (active_flag && !active_flag[b]) return;
-	if (t < 64) body_table_build(M, state + (size_t)b * M.nb * HT_STATE_STRIDE, tab, t);
+	const int t = threadIdx.x;
 	if (t < HT_MAXNB) bin[t] = 0;
 	__syncthreads();
 	for (int i = t; i < nsub; i += CR_THREADS)
 	{
-		const float4 pv = pts[(size_t)b * HT_MAXPTS + i * stride];
+		const float4 pv = fpts[i * stride];
 		const v3 v = V3(pv.x, pv.y, pv.z);
 		float dmin = FLT_MAX; int rb = 0;       // first loop of closest(): nearest body by the inner-sphere plane
 		for (int k = 0; k < M.nb; k++)
@@ -138,6 +128,24 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 	__syncthreads();
 	for (int i = t; i < nsub; i += CR_THREADS) perm[atomicAdd(&bin[key[i]], 1)] = (unsigned short)i;
 	__syncthreads();
+}
+__global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const float *__restrict__ state, const float4 *__restrict__ pts, const int *__restrict__ npts,
+                                                           const float *__restrict__ cams, const int *__restrict__ active_flag, int stride, int use_cam_origin, int mode,
+                                                           float microforce, float weak_force, float cf_max_point, float cf_max_sum, float unibody_force,
+                                                           float *__restrict__ rows, int *__restrict__ nrows)
+{
+	__shared__ float tab[HT_MAXNB * BT];
+	__shared__ unsigned short perm[HT_MAXPTS];
+	__shared__ unsigned char key[HT_MAXPTS];
+	__shared__ int bin[HT_MAXNB];
+	const int b = blockIdx.x, t = threadIdx.x;
+	const int n = npts[b];
+	const int nsub = (n + stride - 1) / stride;
+	if (t == 0) nrows[b] = (active_flag && !active_flag[b]) ? 0 : nsub;
+	if (active_flag && !active_flag[b]) return;
+	if (t < 64) body_table_build(M, state + (size_t)b * M.nb * HT_STATE_STRIDE, tab, t);
+	__syncthreads();
+	bin_points_by_body(M, tab, pts + (size_t)b * HT_MAXPTS, nsub, stride, perm, key, bin);
 	const float *cam = cams + (size_t)b * HT_CAM;
 	const v3 origin = use_cam_origin ? V3(cam[5], cam[6], cam[7]) : V3(0, 0, 0);
 	for (int base = 0; base < nsub; base += CR_THREADS)
