@@ -7,14 +7,16 @@
 //   ExpandingPolytopeAlgorithm        third_party/hull.h:233-310 (Tri bookkeeping :79-186)
 //   SupportFunc / SupportFuncTrans    third_party/gjk.h:568-582, maxdir third_party/geometric.h:218-224
 //
-// Mapping.  A 128-thread block serves two frames (one wave each) and stages all collision vertices (3042 x float4 = 48 KB) in
-// LDS once.  GJK runs one lane per candidate pair (measured on the animation bank: 3.5 iterations per pair on average, 10 at
-// most, ~28 pairs per frame): the support map is a plain scan over the 162/258 vertices of the lane's bone (first maximum wins,
-// as std::max_element does) and the simplex logic is the reference's branchy code executed per lane.  A pair whose simplex
-// encloses the origin needs the expanding polytope; that part is rare but long, so it is run wave-cooperatively, one pair at a
-// time: triangles are scored one per lane, support scans are strided over the 64 lanes with a butterfly arg-max, and only the
-// mesh surgery (extrude / back-to-back fix / compaction, hull.h:136-186) stays sequential on a per-wave LDS mesh.
-// Contacts are compacted in pair order with a prefix sum, so the solver sees the reference's row order.
+// Mapping.  A block serves two frames (one wave each) and stages all collision vertices (3042 x float4 = 48 KB, w = vertex index) in
+// LDS once.  GJK runs on lane groups: a candidate pair is served by 1, 2 or 4 neighbouring lanes (4 when a frame has <= 16 candidates,
+// 2 up to 32) that hold identical simplex state, scan interleaved 6-vertex blocks of the support map (128-bit LDS reads issued
+// together, packed x/y multiply, compare in index order: first maximum wins as std::max_element does) and agree through DPP quad
+// permutes; the simplex logic is the reference's branchy code executed per lane.  Measured on the animation bank: 3.5 iterations per
+// pair on average, ~23 pairs per frame.  A pair whose simplex encloses the origin needs the expanding polytope; that part is rare but
+// long, so it runs wave-cooperatively, one pair at a time: triangles are scored one per lane, support scans are strided over the 64
+// lanes with a butterfly arg-max, and the mesh surgery (extrude / back-to-back fix / compaction, hull.h:136-186) visits only the
+// triangles a ballot marks.  Contacts are compacted in pair order with a prefix sum, so the solver sees the reference's row order.
+// (Two waves per frame were measured slower: the per-lane support scans are bound by the CU's LDS throughput, not by lanes.)
 //
 // The 4 extra "jiggle" GJK runs of the contact patch are skipped when they provably cannot add a contact: an extra
 // sample is rejected if it lies within 0.05 m of an accepted one on either shape (gjk.h:637) and every sample lies in the
@@ -229,12 +231,12 @@ __device__ int gjk_run(const support_t &A, const support_t &B, float cutoff, gjk
 // ---- expanding polytope, wave-cooperative on a per-wave LDS mesh (hull.h:233-310) ---------------------------------------
 #define EPA_MAXT 192
 #define EPA_MAXV 96
-struct epa_mem { int tv[EPA_MAXT][3]; int tn[EPA_MAXT][3]; float vx[EPA_MAXV], vy[EPA_MAXV], vz[EPA_MAXV]; unsigned char ab[EPA_MAXT]; };
+struct epa_mem { short tv[EPA_MAXT][3]; short tn[EPA_MAXT][3]; float vx[EPA_MAXV], vy[EPA_MAXV], vz[EPA_MAXV]; };
 // the mesh surgery is executed by every lane on the same values (same stores from all lanes), so each lane's own program order keeps it coherent
 __device__ __forceinline__ v3 ev(const epa_mem &m, int i) { return V3(m.vx[i], m.vy[i], m.vz[i]); }
 __device__ __forceinline__ bool tri_dead(const epa_mem &m, int t) { return m.tn[t][0] == -1; }
 __device__ __forceinline__ bool hasvert(const epa_mem &m, int t, int x) { return m.tv[t][0] == x || m.tv[t][1] == x || m.tv[t][2] == x; }
-__device__ int *neib(epa_mem &m, int t, int va, int vb)      // hull.h:97-109
+__device__ short *neib(epa_mem &m, int t, int va, int vb)      // hull.h:97-109
 {
 	for (int i = 0; i < 3; i++)
 	{
@@ -258,7 +260,7 @@ __device__ void nnfix(epa_mem &m, int k)      // hull.h:112-127
 }
 __device__ void swapn(epa_mem &m, int a, int b)      // hull.h:128-134 (the ids are swapped back by the reference's second std::swap)
 {
-	for (int i = 0; i < 3; i++) { int t = m.tv[a][i]; m.tv[a][i] = m.tv[b][i]; m.tv[b][i] = t; t = m.tn[a][i]; m.tn[a][i] = m.tn[b][i]; m.tn[b][i] = t; }
+	for (int i = 0; i < 3; i++) { short t = m.tv[a][i]; m.tv[a][i] = m.tv[b][i]; m.tv[b][i] = t; t = m.tn[a][i]; m.tn[a][i] = m.tn[b][i]; m.tn[b][i] = t; }
 	nnfix(m, a); nnfix(m, b);
 }
 __device__ void b2bfix(epa_mem &m, int s, int t)      // hull.h:136-150
@@ -458,64 +460,73 @@ __device__ void separated_wave(bool run, const support_t &A, const support_t &B,
 }
 
 // ------------------------------------------------------------------------------------------------- k_contacts
-#define GJK_FRAMES 2        // frames (waves) per block sharing the LDS vertex copy
-__global__ __launch_bounds__(64 * GJK_FRAMES) void k_contacts(ht_model_dev M, const float *__restrict__ state, float driftmax, float jiggle_sin, const int *__restrict__ active_flag,
-                                                              float *__restrict__ contacts, int *__restrict__ ncontacts, int B, int dbg)
+#define GJK_FRAMES 2        // frames per block sharing the LDS vertex copy
+#define GJK_WPF 1           // waves per frame (2 was measured slower: the support scans are bound by LDS throughput per CU, not by lanes)
+#define GJK_LANES (64 * GJK_WPF)
+struct gjk_frame_mem { float P[HT_MAXNB][8]; unsigned char cand[HT_MAXNB * (HT_MAXNB - 1) / 2][2]; int ncand, nchunk, cnt[GJK_WPF]; };      // poses (pos3 q4 radius), candidate pairs
+__host__ __device__ inline size_t gjk_frame_stride() { return (sizeof(gjk_frame_mem) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t gjk_wave_stride() { return (sizeof(epa_mem) + 15) & ~(size_t)15; }
+__global__ __launch_bounds__(64 * GJK_FRAMES * GJK_WPF) void k_contacts(ht_model_dev M, const float *__restrict__ state, float driftmax, float jiggle_sin, const int *__restrict__ active_flag,
+                                                                        float *__restrict__ contacts, int *__restrict__ ncontacts, int B, int dbg)
 {
 	const int nvert = M.vert_off[M.nb];
 	float4 *sverts = g_sm;
-	// per-wave LDS areas after the vertices: body poses, candidate list, polytope mesh
-	unsigned char *wbase = reinterpret_cast<unsigned char *>(g_sm + nvert);
-	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-	const size_t wstride = (sizeof(float) * HT_MAXNB * 8 + HT_MAXNB * HT_MAXNB + sizeof(epa_mem) + 15) & ~(size_t)15;
-	float (*P)[8] = reinterpret_cast<float (*)[8]>(wbase + wave * wstride);                       // [nb][pos3 q4 radius]
-	unsigned char (*cand)[2] = reinterpret_cast<unsigned char (*)[2]>(wbase + wave * wstride + sizeof(float) * HT_MAXNB * 8);
-	epa_mem &em = *reinterpret_cast<epa_mem *>(wbase + wave * wstride + sizeof(float) * HT_MAXNB * 8 + HT_MAXNB * HT_MAXNB);
-	const int b = blockIdx.x * GJK_FRAMES + wave;
-	for (int i = t; i < nvert; i += 64 * GJK_FRAMES) sverts[i] = M.verts[i];
-	const bool live = b < B && !(active_flag && !active_flag[b]);
-	if (live && lane < M.nb)
+	unsigned char *fbase = reinterpret_cast<unsigned char *>(g_sm + nvert);
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fr = wave / GJK_WPF, half = wave % GJK_WPF;
+	gjk_frame_mem &F = *reinterpret_cast<gjk_frame_mem *>(fbase + fr * gjk_frame_stride());
+	epa_mem &em = *reinterpret_cast<epa_mem *>(fbase + GJK_FRAMES * gjk_frame_stride() + wave * gjk_wave_stride());
+	float (*P)[8] = F.P;
+	const int b = blockIdx.x * GJK_FRAMES + fr;
+	for (int i = t; i < nvert; i += 64 * GJK_FRAMES * GJK_WPF) sverts[i] = M.verts[i];
+	const bool live = b < B && !(active_flag && !active_flag[b]);      // frames outside the active set keep whatever another launch produced for them
+	if (live && half == 0 && lane < M.nb)
 	{
 		const float *s = state + ((size_t)b * M.nb + lane) * HT_STATE_STRIDE;
 		for (int i = 0; i < 7; i++) P[lane][i] = s[i];
 		P[lane][7] = M.bodyc[lane * HT_BC + HT_BC_RADIUS];
 	}
 	__syncthreads();
-	if (!live) return;      // frames outside the active set keep whatever another launch produced for them
-	const int npairs = M.nb * (M.nb - 1) / 2;
-	// broad phase in the reference's pair order (physics.h:453-457), compacted with a ballot; pair index -> (i, j), i < j, row-major
-	int ncand = 0;
-	for (int base = 0; base < npairs; base += 64)
+	// broad phase in the reference's pair order (physics.h:453-457), compacted with a ballot by the frame's first wave; pair index -> (i, j), i < j, row-major
+	if (half == 0)
 	{
-		const int pidx = base + lane;
-		int i = 0, rem = pidx;
-		while (i < M.nb - 1 && rem >= M.nb - 1 - i) { rem -= M.nb - 1 - i; i++; }
-		const int j = i + 1 + rem;
-		bool keep = false;
-		if (pidx < npairs)
+		const int npairs = M.nb * (M.nb - 1) / 2;
+		int nc = 0;
+		for (int base = 0; live && base < npairs; base += 64)
 		{
-			keep = (M.collide[i] & M.collide[j] & 2) != 0;
-			v3 d = V3(P[j][0], P[j][1], P[j][2]) - V3(P[i][0], P[i][1], P[i][2]);
-			if (length(d) > P[i][7] + P[j][7]) keep = false;
-			if (M.ignore[i] & (1u << j)) keep = false;
+			const int pidx = base + lane;
+			int i = 0, rem = pidx;
+			while (i < M.nb - 1 && rem >= M.nb - 1 - i) { rem -= M.nb - 1 - i; i++; }
+			const int j = i + 1 + rem;
+			bool keep = false;
+			if (pidx < npairs)
+			{
+				keep = (M.collide[i] & M.collide[j] & 2) != 0;
+				v3 d = V3(P[j][0], P[j][1], P[j][2]) - V3(P[i][0], P[i][1], P[i][2]);
+				if (length(d) > P[i][7] + P[j][7]) keep = false;
+				if (M.ignore[i] & (1u << j)) keep = false;
+			}
+			if (dbg & 8) keep = false;
+			const unsigned long long m = __ballot(keep);
+			if (keep) { const int dst = nc + __popcll(m & ((1ull << lane) - 1ull)); F.cand[dst][0] = (unsigned char)i; F.cand[dst][1] = (unsigned char)j; }
+			nc += __popcll(m);
 		}
-		if (dbg & 8) keep = false;
-		const unsigned long long m = __ballot(keep);
-		if (keep) { const int dst = ncand + __popcll(m & ((1ull << lane) - 1ull)); cand[dst][0] = (unsigned char)i; cand[dst][1] = (unsigned char)j; }
-		ncand += __popcll(m);
+		// lanes per pair: spare lanes share the support scans
+		const int gshf = nc <= GJK_LANES / 4 ? 2 : nc <= GJK_LANES / 2 ? 1 : 0;
+		if (lane == 0) { F.ncand = nc; F.nchunk = (nc + (GJK_LANES >> gshf) - 1) / (GJK_LANES >> gshf); }
 	}
-	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the candidate list is read back by other lanes of this wave
-	__builtin_amdgcn_wave_barrier();
+	__syncthreads();
+	const int ncand = F.ncand;
+	int nchunk = 0;       // the block's frames step through the same number of chunks so that they can share barriers
+	for (int f = 0; f < GJK_FRAMES; f++) { const int n = reinterpret_cast<gjk_frame_mem *>(fbase + f * gjk_frame_stride())->nchunk; nchunk = n > nchunk ? n : nchunk; }
+	const int gsh = ncand <= GJK_LANES / 4 ? 2 : ncand <= GJK_LANES / 2 ? 1 : 0, grp = 1 << gsh, sub = lane & (grp - 1);
 	long long cyc[7] = { 0, 0, 0, 0, 0, 0, 0 }, cycj[7] = { 0, 0, 0, 0, 0, 0, 0 }; const bool stats = (dbg & 2048) != 0; const long long t_begin = stats ? clock64() : 0; int njig = 0;
-	int nout = 0;                       // contacts written so far for this frame (wave-uniform)
-	const int grp = ncand <= 16 ? 4 : ncand <= 32 ? 2 : 1;      // lanes per pair: spare lanes share the support scans
-	const int gsh = grp == 4 ? 2 : grp == 2 ? 1 : 0, sub = lane & (grp - 1);
-	for (int base = 0; base < ncand; base += 64 >> gsh)
+	int nout = 0;                       // contacts written so far for this frame (frame-uniform)
+	for (int ch = 0; ch < nchunk; ch++)
 	{
-		const int cidx = base + (lane >> gsh);
-		const bool keep = cidx < ncand;
-		const int i = keep ? cand[cidx][0] : 0, j = keep ? cand[cidx][1] : 1;
-		// narrow phase, one lane per surviving pair (ContactPatch gjk.h:607-643)
+		const int cidx = ch * (GJK_LANES >> gsh) + ((half * 64 + lane) >> gsh);
+		const bool keep = live && cidx < ncand;
+		const int i = keep ? F.cand[cidx][0] : 0, j = keep ? F.cand[cidx][1] : 1;
+		// narrow phase, one lane group per surviving pair (ContactPatch gjk.h:607-643)
 		support_t A, Bs;
 		A.voff = M.vert_off[i]; A.n = M.vert_off[i + 1] - M.vert_off[i]; A.pos = V3(P[i][0], P[i][1], P[i][2]); A.q = V4(P[i][3], P[i][4], P[i][5], P[i][6]); A.outer = 0; A.opos = V3(0, 0, 0); A.oq = V4(0, 0, 0, 1); A.sub = sub; A.grp = grp;
 		Bs.voff = M.vert_off[j]; Bs.n = M.vert_off[j + 1] - M.vert_off[j]; Bs.pos = V3(P[j][0], P[j][1], P[j][2]); Bs.q = V4(P[j][3], P[j][4], P[j][5], P[j][6]); Bs.outer = 0; Bs.opos = V3(0, 0, 0); Bs.oq = V4(0, 0, 0, 1); Bs.sub = sub; Bs.grp = grp;
@@ -558,12 +569,15 @@ __global__ __launch_bounds__(64 * GJK_FRAMES) void k_contacts(ht_model_dev M, co
 			}
 		}
 		if (sub != 0) hc = 0;               // member 0 of a group reports the pair
-		// compaction in pair order: exclusive prefix of the per-lane contact counts across the wave
+		// compaction in pair order: exclusive prefix of the per-lane contact counts across the frame's waves
 		int incl = hc;
 #pragma unroll
 		for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-		const int total = __shfl(incl, 63);
-		int dst = nout + incl - hc;
+		if (lane == 63) F.cnt[half] = incl;
+		__syncthreads();
+		int before = 0, total = 0;
+		for (int h = 0; h < GJK_WPF; h++) { const int cw = F.cnt[h]; if (h < half) before += cw; total += cw; }
+		const int dst = nout + before + incl - hc;
 		for (int k = 0; k < 5; k++) if (k < hc && dst + k < HT_MAXCONTACT)
 		{
 			const gjk_hit &h = k == 0 ? hits[0] : k == 1 ? hits[1] : k == 2 ? hits[2] : k == 3 ? hits[3] : hits[4];
@@ -573,9 +587,10 @@ __global__ __launch_bounds__(64 * GJK_FRAMES) void k_contacts(ht_model_dev M, co
 			o[2] = make_float4(h.p1w.x, h.p1w.y, h.p1w.z, h.separation);
 		}
 		nout += total;
+		__syncthreads();
 	}
-	if (lane == 0) ncontacts[b] = nout < HT_MAXCONTACT ? nout : HT_MAXCONTACT;
-	if (stats && lane == 0 && nout < HT_MAXCONTACT - 1)      // timing experiments: statistics accumulate in the last contact slot
+	if (live && half == 0 && lane == 0) ncontacts[b] = nout < HT_MAXCONTACT ? nout : HT_MAXCONTACT;
+	if (stats && live && half == 0 && lane == 0 && nout < HT_MAXCONTACT - 1)      // timing experiments: statistics of the frame's first wave accumulate in the last contact slot
 	{
 		float *o = contacts + ((size_t)b * HT_MAXCONTACT + HT_MAXCONTACT - 1) * HT_CONTACT;
 		o[0] += 1.0f; o[1] += (float)cyc[0]; o[2] += (float)cyc[1]; o[3] += (float)cyc[2]; o[4] += (float)cyc[3]; o[5] += (float)cyc[4]; o[6] += (float)cyc[5]; o[11] += (float)cyc[6];
@@ -591,8 +606,7 @@ void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftma
 	static int dbg = -1;
 	static bool attr_set = false;
 	if (dbg < 0) { const char *e = getenv("HT_DEBUG_SKIP"); dbg = e ? atoi(e) : 0; }
-	const size_t wstride = (sizeof(float) * HT_MAXNB * 8 + HT_MAXNB * HT_MAXNB + sizeof(epa_mem) + 15) & ~(size_t)15;
-	const size_t smem = (size_t)M.vert_off[M.nb] * sizeof(float4) + GJK_FRAMES * wstride;
+	const size_t smem = (size_t)M.vert_off[M.nb] * sizeof(float4) + GJK_FRAMES * gjk_frame_stride() + GJK_FRAMES * GJK_WPF * gjk_wave_stride();
 	if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_contacts), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-	hipLaunchKernelGGL(k_contacts, dim3((B + GJK_FRAMES - 1) / GJK_FRAMES), dim3(64 * GJK_FRAMES), smem, s, M, state, driftmax, jiggle_sin, active_flag, contacts, ncontacts, B, dbg);
+	hipLaunchKernelGGL(k_contacts, dim3((B + GJK_FRAMES - 1) / GJK_FRAMES), dim3(64 * GJK_FRAMES * GJK_WPF), smem, s, M, state, driftmax, jiggle_sin, active_flag, contacts, ncontacts, B, dbg);
 }
