@@ -115,3 +115,17 @@ def test_config_read_follows_the_reference_decoder(tmp_path):
     assert p.mainthreadpasses == 0 and p.min_point_num == 0 and pfe.value == 0.0      # not in the file: the reference's decoder reads 0
     bad = tmp_path / "bad.json"; bad.write_text('{"microforce": ')
     assert L.ht_config_read(str(bad).encode(), C.byref(p), C.byref(seg), C.byref(pfe)) != 0
+
+
+def test_dataset_formats_round_trip(tmp_path):
+    """include/ht_formats.hpp: .rs/.ir/.pose/.json written like DepthDataStreamOut (dataset.h:62-104) and read back like load_dataset / LoadAnimBank."""
+    lib = os.path.join(ROOT, "hand_tracking_samples_amd")
+    exe = str(tmp_path / "formats")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cxx_formats_example.cpp"), "-o", exe,
+                           "-L" + lib, "-lht_mi355x", "-Wl,-rpath," + lib])
+    args = [exe, str(tmp_path / "set0")]
+    ref_bank = "/root/reference/assets/animbank.pose"
+    if os.path.exists(ref_bank):
+        args.append(ref_bank)      # the reference's own animation bank parses to 2336 rows of 17 poses
+    out = subprocess.check_output(args).decode()
+    assert out.strip().endswith("OK"), out
