@@ -7,7 +7,7 @@
 //   k_prepare   u16 depth tile -> fp32 CNN input + order-preserving compacted point cloud  (HBM-bound, 8 KB in / 16 KB out per frame)
 //   k_conv1     5x5x1->16 valid conv + 4x4 max-pool + tanh, input tile staged in LDS, fp32 VALU in the reference's tap order
 //   k_conv2     4x4x16->64 valid conv as an implicit GEMM on v_mfma_f32_16x16x4_f32, + 2x2 max-pool + tanh
-//   k_fc        [B,K]x[K,N]+bias (+tanh) on v_mfma_f32_32x32x2_f32, 128x64 block tile, LDS-staged, register prefetch
+//   k_fc        [B,K]x[K,N]+bias (+tanh) on v_mfma_f32_32x32x2_f32, 128x64 block tile on 8 waves, double-buffered LDS, register prefetch
 //   k_softmax_decode   chunked softmax (cnn.h:497-511) fused with the heat-map decode (handtrack.h:218-241)
 //
 // Numerics: the MFMA accumulator starts at the bias and sums k in ascending order, which is the reference's own order
@@ -178,74 +178,78 @@ __global__ __launch_bounds__(256) void k_conv2(const float *__restrict__ act1, c
 
 // ------------------------------------------------------------------------------------------------- k_fc
 // C[M][N] = bias[N] + A[M][K] * W[K][N]  (W row-major as stored in the .cnnb, cnn.h:417)  [+ tanh]
-// block tile 128(M) x 64(N) x 32(K); 4 waves as 2(M) x 2(N); wave tile 64x32 = two 32x32x2 MFMA tiles.
+// Block tile 128(M) x 64(N) x 32(K) on 8 waves laid out 4(M) x 2(N), one 32x32 accumulator tile (v_mfma_f32_32x32x2_f32) per wave: a CU
+// holds two waves per SIMD, so one wave's LDS reads and the global prefetch of the next k-slab overlap the other's matrix instructions
+// (an fp32 32x32x2 MFMA occupies the pipe for 64 cycles).  LDS tiles are double-buffered: one barrier per k-slab.
+// Every output element accumulates k in ascending order from its bias, like the reference's loop (cnn.h:407-426).
 #define FC_BM 128
 #define FC_BN 64
 #define FC_BK 32
 #define FC_LDA (FC_BM + 1)
+#define FC_THREADS 512
 template <bool TANH>
-__global__ __launch_bounds__(256) void k_fc(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K)
+__global__ __launch_bounds__(FC_THREADS) void k_fc(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K)
 {
-	__shared__ float As[FC_BK * FC_LDA];
-	__shared__ __attribute__((aligned(16))) float Bs[FC_BK * FC_BN];
+	__shared__ float As[2][FC_BK * FC_LDA];
+	__shared__ __attribute__((aligned(16))) float Bs[2][FC_BK * FC_BN];
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
 	const int m0 = blockIdx.y * FC_BM, n0 = blockIdx.x * FC_BN;
 	// staging assignments
-	const int ar = t >> 3, akc = (t & 7) * 4;          // A: rows ar + 32*i, 4 consecutive k
-	const int bk = t >> 4, bnc = (t & 15) * 4;         // B: rows bk + 16*i, 4 consecutive n
-	float4 ra[4], rb[2];
+	const int ar = t >> 3, akc = (t & 7) * 4;          // A: rows ar + 64*i (i < 2), 4 consecutive k
+	const int bk = t >> 4, bnc = (t & 15) * 4;         // B: row bk (0..31), 4 consecutive n
+	float4 ra[2], rb;
 	auto gload = [&](int k0) {
 #pragma unroll
-		for (int i = 0; i < 4; i++)
+		for (int i = 0; i < 2; i++)
 		{
-			int row = m0 + ar + 32 * i;
+			int row = m0 + ar + 64 * i;
 			ra[i] = row < M ? *reinterpret_cast<const float4 *>(A + (size_t)row * K + k0 + akc) : make_float4(0, 0, 0, 0);
 		}
-#pragma unroll
-		for (int i = 0; i < 2; i++) rb[i] = *reinterpret_cast<const float4 *>(W + (size_t)(k0 + bk + 16 * i) * N + n0 + bnc);
+		rb = *reinterpret_cast<const float4 *>(W + (size_t)(k0 + bk) * N + n0 + bnc);
 	};
-	auto lstore = [&]() {
+	auto lstore = [&](int buf) {
 #pragma unroll
-		for (int i = 0; i < 4; i++)
+		for (int i = 0; i < 2; i++)
 		{
-			int row = ar + 32 * i;
-			As[(akc + 0) * FC_LDA + row] = ra[i].x; As[(akc + 1) * FC_LDA + row] = ra[i].y; As[(akc + 2) * FC_LDA + row] = ra[i].z; As[(akc + 3) * FC_LDA + row] = ra[i].w;
+			int row = ar + 64 * i;
+			float *a = As[buf];
+			a[(akc + 0) * FC_LDA + row] = ra[i].x; a[(akc + 1) * FC_LDA + row] = ra[i].y; a[(akc + 2) * FC_LDA + row] = ra[i].z; a[(akc + 3) * FC_LDA + row] = ra[i].w;
 		}
-#pragma unroll
-		for (int i = 0; i < 2; i++) *reinterpret_cast<float4 *>(Bs + (bk + 16 * i) * FC_BN + bnc) = rb[i];
+		*reinterpret_cast<float4 *>(Bs[buf] + bk * FC_BN + bnc) = rb;
 	};
 	const float bv = bias[n0 + wn * 32 + (lane & 31)];
-	f32x16 acc0, acc1;
+	f32x16 acc;
 #pragma unroll
-	for (int r = 0; r < 16; r++) { acc0[r] = bv; acc1[r] = bv; }
+	for (int r = 0; r < 16; r++) acc[r] = bv;
 	gload(0);
+	lstore(0);
+	int buf = 0;
 	for (int k0 = 0; k0 < K; k0 += FC_BK)
 	{
-		__syncthreads();
-		lstore();
-		__syncthreads();
-		if (k0 + FC_BK < K) gload(k0 + FC_BK);
-		const float *ap = As + (lane >> 5) * FC_LDA + wm * 64 + (lane & 31);
-		const float *bp = Bs + (lane >> 5) * FC_BN + wn * 32 + (lane & 31);
+		__syncthreads();                                   // slab `buf` is complete; the other buffer is free (its readers passed this barrier)
+		const bool more = k0 + FC_BK < K;
+		if (more) gload(k0 + FC_BK);
+		const float *ap = As[buf] + (lane >> 5) * FC_LDA + wm * 32 + (lane & 31);
+		const float *bp = Bs[buf] + (lane >> 5) * FC_BN + wn * 32 + (lane & 31);
 #pragma unroll
 		for (int kk = 0; kk < FC_BK / 2; kk++)
 		{
-			float a0 = ap[2 * kk * FC_LDA], a1 = ap[2 * kk * FC_LDA + 32], bb = bp[2 * kk * FC_BN];
-			acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bb, acc0, 0, 0, 0);
-			acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bb, acc1, 0, 0, 0);
+			const float a0 = ap[2 * kk * FC_LDA], bb = bp[2 * kk * FC_BN];
+			acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bb, acc, 0, 0, 0);
 		}
+		if (more) lstore(buf ^ 1);
+		buf ^= 1;
 	}
 	// C/D map 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 	const int col = n0 + wn * 32 + (lane & 31);
 #pragma unroll
 	for (int r = 0; r < 16; r++)
 	{
-		int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-		int g0 = m0 + wm * 64 + row, g1 = g0 + 32;
-		float v0 = acc0[r], v1 = acc1[r];
-		if (TANH) { v0 = tanh_ref(v0); v1 = tanh_ref(v1); }
+		const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+		const int g0 = m0 + wm * 32 + row;
+		float v0 = acc[r];
+		if (TANH) v0 = tanh_ref(v0);
 		if (g0 < M) C[(size_t)g0 * N + col] = v0;
-		if (g1 < M) C[(size_t)g1 * N + col] = v1;
 	}
 }
 
@@ -343,8 +347,8 @@ void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, fl
 	hipLaunchKernelGGL(k_conv1, dim3(B), dim3(256), 0, s, cnn_in, w.W1, w.B1, act1);
 	hipLaunchKernelGGL(k_conv2, dim3(B), dim3(256), 0, s, act1, w.W2p, w.B2, act2);
 	dim3 g1(2048 / FC_BN, (B + FC_BM - 1) / FC_BM), g2(2304 / FC_BN, (B + FC_BM - 1) / FC_BM);
-	hipLaunchKernelGGL(k_fc<true>, g1, dim3(256), 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
-	hipLaunchKernelGGL(k_fc<false>, g2, dim3(256), 0, s, act3, w.W4, w.B4, logits, B, 2304, 2048);
+	hipLaunchKernelGGL(k_fc<true>, g1, dim3(FC_THREADS), 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
+	hipLaunchKernelGGL(k_fc<false>, g2, dim3(FC_THREADS), 0, s, act3, w.W4, w.B4, logits, B, 2304, 2048);
 }
 void ht_launch_softmax_decode(const float *logits, float *cnn_out, const float *cams, float *analysis, int softmax, int B, hipStream_t s)
 {
