@@ -260,11 +260,26 @@ __device__ void decode_frame(const float *__restrict__ y, const float *__restric
 {
 	// hcam = camsub(cam,4) misc_image.h:60
 	const float fx = cam[0] / 4.0f, fy = cam[1] / 4.0f, cx = cam[2] / 4.0f, cy = cam[3] / 4.0f;
+	// ImageFindMax (misc_image.h:298-305: first maximum in a row-major scan) of the 8 heat-maps: 8 lanes per map take 32 consecutive values
+	// each, then the partial results are merged in index order (a later segment only wins with a strictly larger value)
+	int amax;
+	{
+		const int m = lane >> 3, seg = lane & 7;
+		const float *base = y + 256 * m + 32 * seg;
+		float best = base[0]; int bi = 32 * seg;
+		for (int i = 1; i < 32; i++) { const float v = base[i]; if (v > best) { best = v; bi = 32 * seg + i; } }
+#pragma unroll
+		for (int o = 1; o < 8; o <<= 1)
+		{
+			const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+			if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+		}
+		amax = __shfl(bi, lane * 8);      // lane m (< 8) picks up the result of map m
+	}
 	if (lane < 8)
 	{
 		const float *base = y + 256 * lane;
-		int mxx = 0, mxy = 0; float best = base[0];
-		for (int i = 1; i < 256; i++) { float v = base[i]; if (v > best) { best = v; mxx = i & 15; mxy = i >> 4; } }      // ImageFindMax misc_image.h:298-305
+		const int mxx = amax & 15, mxy = amax >> 4;
 		float wsum = 0.0f, vx = 0.0f, vy = 0.0f;
 		for (int sy = max(0, mxy - 1); sy < min(16, mxy + 2); sy++) for (int sx = max(0, mxx - 1); sx < min(16, mxx + 2); sx++)
 		{
@@ -314,15 +329,28 @@ __global__ __launch_bounds__(64) void k_softmax_decode(const float *__restrict__
 	{
 		for (int i = lane; i < HT_CNN_OUT; i += 64) y[i] = (float)exp((double)logits[(size_t)b * HT_CNN_OUT + i]);
 		__syncthreads();
-		if (lane < 24)
+		__shared__ float csum[24];
+		if (lane < 24)       // chunk sums in ascending order like cnn.h:503-505 (one lane per chunk; 16 values are read per trip, then added one by one)
 		{
 			const int s = lane < 8 ? 256 : 16, base = lane < 8 ? 256 * lane : 2048 + 16 * (lane - 8);
 			float sum = 0.0f;
-			for (int i = base; i < base + s; i++) sum += y[i];
-			for (int i = base; i < base + s; i++) y[i] /= sum;
+			for (int i = base; i < base + s; i += 16)
+			{
+				float v[16];
+#pragma unroll
+				for (int k = 0; k < 16; k++) v[k] = y[i + k];
+#pragma unroll
+				for (int k = 0; k < 16; k++) sum += v[k];
+			}
+			csum[lane] = sum;
 		}
 		__syncthreads();
-		for (int i = lane; i < HT_CNN_OUT; i += 64) cnn_out[(size_t)b * HT_CNN_OUT + i] = y[i];
+		for (int i = lane; i < HT_CNN_OUT; i += 64)
+		{
+			const float v = y[i] / csum[i < 2048 ? (i >> 8) : 8 + ((i - 2048) >> 4)];
+			y[i] = v; cnn_out[(size_t)b * HT_CNN_OUT + i] = v;
+		}
+		__syncthreads();
 	}
 	else
 	{
