@@ -14,6 +14,12 @@
 #include "ht_device.hpp"
 #include "ht_launch.hpp"
 
+extern __shared__ __attribute__((aligned(16))) float4 s_planes[];      // all face planes of the model, staged once per block (25 KB for the hand)
+__device__ __forceinline__ void stage_planes(const ht_model_dev &M, int t, int nthreads)
+{
+	const int np = M.plane_off[M.nb];
+	for (int i = t; i < np; i += nthreads) s_planes[i] = M.planes[i];
+}
 #define BT 32       // floats per body-table entry
 // pos 0..2 | q 3..6 | radius 7 | rinner 8 | invp 9..11 (= qrot(qconj(q), -pos)) | RI columns 12..20 (qmat(qconj(q))) | RF columns 21..29 (qmat(q))
 __device__ __forceinline__ void body_table_build(const ht_model_dev &M, const float *__restrict__ st, float *tab, int lane)
@@ -66,10 +72,10 @@ __device__ __forceinline__ void closest_feature(const ht_model_dev &M, const flo
 		bool consider = active && !(length(v - tab_pos(t)) - t[7] > dmin);
 		if (!__any(consider)) continue;
 		v3 vl = tab_to_local(t, v);
-		const float4 *pl = M.planes + M.plane_off[b];
+		const float4 *pl = s_planes + M.plane_off[b];
 		const int np = M.plane_off[b + 1] - M.plane_off[b];
 		float best = 0.0f; int bi = 0;
-		// planes arrive through scalar loads (uniform address); 8 are requested per group so that one wait covers 8 planes
+		// planes are read from the LDS copy (uniform address: one broadcast read per plane); 8 are requested per group so that one wait covers 8 planes
 		for (int i0 = 0; i0 < np; i0 += 8)
 		{
 			float4 q[8];
@@ -144,6 +150,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 	if (t == 0) nrows[b] = (active_flag && !active_flag[b]) ? 0 : nsub;
 	if (active_flag && !active_flag[b]) return;
 	if (t < 64) body_table_build(M, state + (size_t)b * M.nb * HT_STATE_STRIDE, tab, t);
+	stage_planes(M, t, CR_THREADS);
 	__syncthreads();
 	bin_points_by_body(M, tab, pts + (size_t)b * HT_MAXPTS, nsub, stride, perm, key, bin);
 	const float *cam = cams + (size_t)b * HT_CAM;
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 		if (!__any(mine)) continue;
 		const float *t = tab + bb * BT;
 		v3 v0 = tab_to_local(t, origin), v1 = tab_to_local(t, v);
-		const float4 *pl = M.planes + M.plane_off[bb];
+		const float4 *pl = s_planes + M.plane_off[bb];
 		const int np = M.plane_off[bb + 1] - M.plane_off[bb];
 		bool done = !mine, ok = true;
 		for (int k0 = 0; k0 < np; k0 += 8)
@@ -218,6 +225,7 @@ __global__ __launch_bounds__(256) void k_fit_error(ht_model_dev M, const float *
 	const int b = blockIdx.x, t = threadIdx.x;
 	if (t < 64) body_table_build(M, state + (size_t)b * M.nb * HT_STATE_STRIDE, tab, t);
 	if (t < HT_MAXNB) perr[t] = 0;
+	stage_planes(M, t, 256);
 	__syncthreads();
 	const int n = npts[b];
 	for (int base = 0; base < n; base += 256)
@@ -308,12 +316,12 @@ __global__ __launch_bounds__(64) void k_chamber(ht_model_dev M, const float *__r
 void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const float *cams, const int *active_flag, int stride, int use_cam_origin, int mode,
                           const ht_params &par, float *rows, int *nrows, int B, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_cloud_rows, dim3(B), dim3(CR_THREADS), 0, s, M, state, pts, npts, cams, active_flag, stride, use_cam_origin, mode, par.microforce, par.physics_weak_force,
+	hipLaunchKernelGGL(k_cloud_rows, dim3(B), dim3(CR_THREADS), (size_t)M.plane_off[M.nb] * sizeof(float4), s, M, state, pts, npts, cams, active_flag, stride, use_cam_origin, mode, par.microforce, par.physics_weak_force,
 	                   par.cloudforce_max_point, par.cloudforce_max_sum, par.unibody_force, rows, nrows);
 }
 void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, float scale, float *err, int B, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_fit_error, dim3(B), dim3(256), 0, s, M, state, pts, npts, depth, cams, scale, err);
+	hipLaunchKernelGGL(k_fit_error, dim3(B), dim3(256), (size_t)M.plane_off[M.nb] * sizeof(float4), s, M, state, pts, npts, depth, cams, scale, err);
 }
 void ht_launch_chamber(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, int min_point_num, int enabled, float maxforce, float *rows, int *nch, int B, hipStream_t s)
 {
