@@ -183,39 +183,40 @@ __global__ __launch_bounds__(256) void k_conv2(const float *__restrict__ act1, c
 // (an fp32 32x32x2 MFMA occupies the pipe for 64 cycles).  LDS tiles are double-buffered: one barrier per k-slab.
 // Every output element accumulates k in ascending order from its bias, like the reference's loop (cnn.h:407-426).
 #define FC_BM 128
-#define FC_BN 64
 #define FC_BK 32
 #define FC_LDA (FC_BM + 1)
-#define FC_THREADS 512
-template <bool TANH>
-__global__ __launch_bounds__(FC_THREADS) void k_fc(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K)
+// WN = waves along N: the block tile is 128 x 32*WN.  N = 2048 uses WN = 2 (256 blocks = one per CU); N = 2304 uses WN = 3 (192 blocks of
+// 12 waves) because 288 blocks of the smaller tile would leave 32 CUs with two blocks and everyone waiting for them.
+template <bool TANH, int WN>
+__global__ __launch_bounds__(256 * WN) void k_fc(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K)
 {
+	constexpr int BN = 32 * WN, NT = 256 * WN;
 	__shared__ float As[2][FC_BK * FC_LDA];
-	__shared__ __attribute__((aligned(16))) float Bs[2][FC_BK * FC_BN];
-	const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
-	const int m0 = blockIdx.y * FC_BM, n0 = blockIdx.x * FC_BN;
-	// staging assignments
-	const int ar = t >> 3, akc = (t & 7) * 4;          // A: rows ar + 64*i (i < 2), 4 consecutive k
-	const int bk = t >> 4, bnc = (t & 15) * 4;         // B: row bk (0..31), 4 consecutive n
-	float4 ra[2], rb;
+	__shared__ __attribute__((aligned(16))) float Bs[2][FC_BK * BN];
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / WN, wn = wave % WN;
+	const int m0 = blockIdx.y * FC_BM, n0 = blockIdx.x * BN;
+	// staging assignments: A tile = 1024 float4 (row = i >> 3, 4 consecutive k), B tile = 8*BN float4 = NT of them (one per thread)
+	const int bk = t / (8 * WN), bnc = (t % (8 * WN)) * 4;
+	constexpr int NA = (1024 + NT - 1) / NT;
+	float4 ra[NA], rb;
 	auto gload = [&](int k0) {
 #pragma unroll
-		for (int i = 0; i < 2; i++)
+		for (int i = 0; i < NA; i++)
 		{
-			int row = m0 + ar + 64 * i;
-			ra[i] = row < M ? *reinterpret_cast<const float4 *>(A + (size_t)row * K + k0 + akc) : make_float4(0, 0, 0, 0);
+			const int e = t + NT * i, row = m0 + (e >> 3);
+			ra[i] = (e < 1024 && row < M) ? *reinterpret_cast<const float4 *>(A + (size_t)row * K + k0 + (e & 7) * 4) : make_float4(0, 0, 0, 0);
 		}
 		rb = *reinterpret_cast<const float4 *>(W + (size_t)(k0 + bk) * N + n0 + bnc);
 	};
 	auto lstore = [&](int buf) {
 #pragma unroll
-		for (int i = 0; i < 2; i++)
+		for (int i = 0; i < NA; i++)
 		{
-			int row = ar + 64 * i;
+			const int e = t + NT * i, row = e >> 3, akc = (e & 7) * 4;
 			float *a = As[buf];
-			a[(akc + 0) * FC_LDA + row] = ra[i].x; a[(akc + 1) * FC_LDA + row] = ra[i].y; a[(akc + 2) * FC_LDA + row] = ra[i].z; a[(akc + 3) * FC_LDA + row] = ra[i].w;
+			if (e < 1024) { a[(akc + 0) * FC_LDA + row] = ra[i].x; a[(akc + 1) * FC_LDA + row] = ra[i].y; a[(akc + 2) * FC_LDA + row] = ra[i].z; a[(akc + 3) * FC_LDA + row] = ra[i].w; }
 		}
-		*reinterpret_cast<float4 *>(Bs[buf] + bk * FC_BN + bnc) = rb;
+		*reinterpret_cast<float4 *>(Bs[buf] + bk * BN + bnc) = rb;
 	};
 	const float bv = bias[n0 + wn * 32 + (lane & 31)];
 	f32x16 acc;
@@ -230,11 +231,11 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc(const float *__restrict__ A, 
 		const bool more = k0 + FC_BK < K;
 		if (more) gload(k0 + FC_BK);
 		const float *ap = As[buf] + (lane >> 5) * FC_LDA + wm * 32 + (lane & 31);
-		const float *bp = Bs[buf] + (lane >> 5) * FC_BN + wn * 32 + (lane & 31);
+		const float *bp = Bs[buf] + (lane >> 5) * BN + wn * 32 + (lane & 31);
 #pragma unroll
 		for (int kk = 0; kk < FC_BK / 2; kk++)
 		{
-			const float a0 = ap[2 * kk * FC_LDA], bb = bp[2 * kk * FC_BN];
+			const float a0 = ap[2 * kk * FC_LDA], bb = bp[2 * kk * BN];
 			acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bb, acc, 0, 0, 0);
 		}
 		if (more) lstore(buf ^ 1);
@@ -374,9 +375,9 @@ void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, fl
 {
 	hipLaunchKernelGGL(k_conv1, dim3(B), dim3(256), 0, s, cnn_in, w.W1, w.B1, act1);
 	hipLaunchKernelGGL(k_conv2, dim3(B), dim3(256), 0, s, act1, w.W2p, w.B2, act2);
-	dim3 g1(2048 / FC_BN, (B + FC_BM - 1) / FC_BM), g2(2304 / FC_BN, (B + FC_BM - 1) / FC_BM);
-	hipLaunchKernelGGL(k_fc<true>, g1, dim3(FC_THREADS), 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
-	hipLaunchKernelGGL(k_fc<false>, g2, dim3(FC_THREADS), 0, s, act3, w.W4, w.B4, logits, B, 2304, 2048);
+	dim3 g1(2048 / 64, (B + FC_BM - 1) / FC_BM), g2(2304 / 96, (B + FC_BM - 1) / FC_BM);
+	hipLaunchKernelGGL((k_fc<true, 2>), g1, dim3(512), 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
+	hipLaunchKernelGGL((k_fc<false, 3>), g2, dim3(768), 0, s, act3, w.W4, w.B4, logits, B, 2304, 2048);
 }
 void ht_launch_softmax_decode(const float *logits, float *cnn_out, const float *cams, float *analysis, int softmax, int B, hipStream_t s)
 {
