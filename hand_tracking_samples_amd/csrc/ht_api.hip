@@ -114,6 +114,7 @@ static int load_model(ht_ctx *ctx, const char *path)
 	int r;
 	if ((r = dev_upload(ctx, &dv, verts)) || (r = dev_upload(ctx, &dp, planes)) || (r = dev_upload(ctx, &dbc, bodyc)) || (r = dev_upload(ctx, &djc, jointc))) return r;
 	m.verts = dv; m.planes = dp; m.bodyc = dbc; m.jointc = djc;
+	ctx->h_verts = verts; ctx->h_planes = planes; ctx->d_verts_rw = dv; ctx->d_planes_rw = dp; ctx->d_bodyc_rw = dbc; ctx->d_jointc_rw = djc;
 	return HT_OK;
 }
 
@@ -173,6 +174,43 @@ extern "C" int ht_config_read(const char *jsonfile, ht_params *p, float *segment
 	p->physics_iterations = I("physics_iterations"); p->physics_iterations_post = I("physics_iterations_post"); p->physics_use_collision = I("physics_use_collision");
 	p->physics_weak_force = F("physics_weak_force"); p->steps_unibody = I("steps_unibody"); p->bone_sum_error_scale = F("bone_sum_error_scale"); p->min_cray_prob = F("min_cray_prob");
 	p->unibody_force = F("unibody_force");
+	return HT_OK;
+}
+// HandTracker::scale (handtrack.h:591) = PhysModel::scale on both models (physmodel.h:196-219,304-319): geometry, centres of mass, radii and
+// joint anchors times s, inverse inertia over s*s, body positions stretched about the wrist.  The caller keeps segment_scale.
+extern "C" int ht_scale(ht_ctx *ctx, float s)
+{
+	if (!ctx) return HT_ERR_ARG;
+	if (!ctx->ready) { ctx->err = "context not initialised (ht_create failed)"; return HT_ERR_STATE; }
+	const int nb = ctx->model.nb, nj = ctx->model.nj;
+	const float ss = s * s;
+	for (auto &v : ctx->h_verts) { v.x *= s; v.y *= s; v.z *= s; }      // w keeps the vertex index
+	for (auto &p : ctx->h_planes) p.w *= s;
+	for (int b = 0; b < nb; b++)
+	{
+		float *c = &ctx->h_bodyc[(size_t)b * HT_BC];
+		for (int i = 0; i < 3; i++) c[HT_BC_COM + i] *= s;
+		c[HT_BC_RADIUS] *= s; c[HT_BC_RINNER] *= s;
+		for (int i = 0; i < 9; i++) c[HT_BC_TINV + i] /= ss;
+		float diam2 = 0.0f;      // vertex diameter (used by the exact contact-patch shortcut) of the scaled shape
+		const int v0 = ctx->model.vert_off[b], v1 = ctx->model.vert_off[b + 1];
+		for (int i = v0; i < v1; i++) for (int j = i + 1; j < v1; j++)
+		{
+			const float dx = ctx->h_verts[i].x - ctx->h_verts[j].x, dy = ctx->h_verts[i].y - ctx->h_verts[j].y, dz = ctx->h_verts[i].z - ctx->h_verts[j].z;
+			const float d2 = dx * dx + dy * dy + dz * dz; if (d2 > diam2) diam2 = d2;
+		}
+		c[HT_BC_DIAM] = sqrtf(diam2);
+	}
+	for (int j = 0; j < nj; j++) { float *c = &ctx->h_jointc[(size_t)j * HT_JC]; for (int i = 0; i < 3; i++) { c[HT_JC_P0 + i] *= s; c[HT_JC_P1 + i] *= s; } }
+	hipStream_t st = ctx->stream;
+	HIPCHK(ctx, hipStreamSynchronize(st));
+	HIPCHK(ctx, hipMemcpy(ctx->d_verts_rw, ctx->h_verts.data(), ctx->h_verts.size() * sizeof(float4), hipMemcpyHostToDevice));
+	HIPCHK(ctx, hipMemcpy(ctx->d_planes_rw, ctx->h_planes.data(), ctx->h_planes.size() * sizeof(float4), hipMemcpyHostToDevice));
+	HIPCHK(ctx, hipMemcpy(ctx->d_bodyc_rw, ctx->h_bodyc.data(), ctx->h_bodyc.size() * sizeof(float), hipMemcpyHostToDevice));
+	HIPCHK(ctx, hipMemcpy(ctx->d_jointc_rw, ctx->h_jointc.data(), ctx->h_jointc.size() * sizeof(float), hipMemcpyHostToDevice));
+	for (int w = 0; w < 2; w++) ht_launch_scale_state(ctx->d_state[w], nb, ctx->B, s, st);
+	HIPCHK(ctx, hipStreamSynchronize(st));
+	HIPCHK(ctx, hipGetLastError());
 	return HT_OK;
 }
 extern "C" int ht_destroy(ht_ctx *ctx)

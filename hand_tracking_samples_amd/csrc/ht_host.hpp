@@ -21,6 +21,8 @@ struct ht_ctx
 	ht_model_dev model;
 	ht_cnn_weights cnnw;
 	std::vector<float> h_bodyc, h_jointc;
+	std::vector<float4> h_verts, h_planes;                        // host copies of the model geometry (ht_scale rewrites them)
+	float4 *d_verts_rw = nullptr, *d_planes_rw = nullptr; float *d_bodyc_rw = nullptr, *d_jointc_rw = nullptr;
 	std::vector<void *> allocs;
 	std::map<std::string, ht_prof_entry> prof;
 

@@ -33,3 +33,4 @@ void ht_launch_output(const ht_model_dev &M, const float *hand, const int *npts,
 // ht_segment.hip
 bool ht_segment_supported(int w, int h);
 void ht_launch_segment(const uint16_t *depth, const float *cams, int w, int h, int entry_options, float wrange_hi, float diam, uint16_t *tiles, float *cams_out, int B, hipStream_t s);
+void ht_launch_scale_state(float *state, int nb, int n, float s, hipStream_t st);      // ht_track.hip

@@ -266,6 +266,21 @@ void ht_launch_scratch(const ht_model_dev &M, float *state, const float4 *pts, c
 {
 	hipLaunchKernelGGL(k_scratch, dim3(B), dim3(64), 0, s, M, state, pts, npts, analysis, cams, flags);
 }
+// PhysModel::scale, the pose part (physmodel.h:312-313): rb.position = rb0.position + (rb.position - rb0.position) * s
+__global__ void k_scale_state(float *__restrict__ state, int nb, int n, float s)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n * nb) return;
+	const int f = i / nb, b = i % nb;
+	const float *p0 = state + (size_t)f * nb * HT_STATE_STRIDE;
+	float *p = state + ((size_t)f * nb + b) * HT_STATE_STRIDE;
+	if (b == 0) return;      // p0 + (p0 - p0) * s = p0
+	for (int k = 0; k < 3; k++) p[k] = p0[k] + (p[k] - p0[k]) * s;
+}
+void ht_launch_scale_state(float *state, int nb, int n, float s, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_scale_state, dim3((n * nb + 255) / 256), dim3(256), 0, st, state, nb, n, s);
+}
 void ht_launch_unibody(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float *rows, const int *nrows, const int *flags, float *scratch, int scratch_stride, int B, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_unibody, dim3(B), dim3(64), 0, s, M, ph, state, rows, nrows, flags, scratch, scratch_stride);

@@ -17,7 +17,7 @@ MAXPTS, ROW, CONTACT = 1024, 16, 12
 
 # every symbol include/ht_mi355x.h declares (checked by tests/test_abi.py)
 SYMBOLS = (
-    "ht_create", "ht_destroy", "ht_model_bake", "ht_last_error", "ht_get_params", "ht_set_params", "ht_model_info", "ht_config_read",
+    "ht_create", "ht_destroy", "ht_model_bake", "ht_last_error", "ht_get_params", "ht_set_params", "ht_model_info", "ht_config_read", "ht_scale",
     "ht_cnn_load_weights", "ht_cnn_eval", "ht_cnn_eval_dev",
     "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_segment_vr", "ht_segment_vr_dev",
     "ht_stage_prepare", "ht_stage_decode", "ht_stage_fit_error", "ht_stage_cloud_rows", "ht_stage_contacts", "ht_stage_fit",
@@ -80,6 +80,7 @@ def load(build_if_missing=True):
     L.ht_stage_multistep.argtypes = [vp, fp, C.c_int]
     L.ht_stage_scratch_unibody.argtypes = [vp, fp, C.c_int, C.c_int]
     L.ht_profile_enable.argtypes = [vp, C.c_int]
+    L.ht_scale.argtypes = [vp, C.c_float]
     L.ht_segment_vr.argtypes = [vp, C.POINTER(C.c_uint16), fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_uint16), fp]
     L.ht_segment_vr_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp, vp, vp]
     L.ht_profile_read.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_int, fp, ip, ip]
@@ -284,3 +285,7 @@ class Context:
         self._chk(self.L.ht_segment_vr(self.h, depth.ctypes.data_as(C.POINTER(C.c_uint16)), _f(cams), w, h, B, int(entry_options), float(wrange[0]), float(wrange[1]), float(diam),
                                        tiles.ctypes.data_as(C.POINTER(C.c_uint16)), _f(co)))
         return tiles, co
+
+    def scale(self, s):
+        """HandTracker::scale (handtrack.h:591): both models of every slot grow by the factor s."""
+        self._chk(self.L.ht_scale(self.h, float(s)))

@@ -148,6 +148,7 @@ struct HandTracker                                                              
 		for (int b = 0; b < nb_; b++) { const float *p = &out[(size_t)b * HT_POSE]; pose[b].position = { p[0], p[1], p[2] }; pose[b].orientation = { p[3], p[4], p[5], p[6] }; }
 		return pose;
 	}
+	float scale(float s) { check(ctx_, ht_scale(ctx_, s)); segment_scale *= s; return segment_scale; }                     // handtrack.h:591
 	// kickstart (handtrack.h:743-746): the CNN job in the calling thread, its pose taken over when it is accepted; no main-thread passes
 	void kickstart(Image<unsigned short> dimage) { const int keep = mainthreadpasses; mainthreadpasses = 0; try { update(std::move(dimage)); } catch (...) { mainthreadpasses = keep; throw; } mainthreadpasses = keep; }
 	// HandSegmentVR (handtrack.h:280-344) on this tracker's device

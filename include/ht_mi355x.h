@@ -83,6 +83,9 @@ const char *ht_last_error(const ht_ctx *ctx);
 int ht_get_params(const ht_ctx *ctx, ht_params *p);
 int ht_set_params(ht_ctx *ctx, const ht_params *p);                    /* replaces HandTracker::load_config / visit_fields (handtrack.h:549-581, 822-828) */
 int ht_model_info(const ht_ctx *ctx, int *n_bodies, int *n_joints, int *max_batch);
+/* ht_scale        replaces  float HandTracker::scale(float s) (handtrack.h:591): PhysModel::scale (physmodel.h:196-219,304-319) on both models of
+ *                every tracker slot; the caller multiplies its segment_scale (the compatibility header does). */
+int ht_scale(ht_ctx *ctx, float s);
 /* ht_config_read  replaces  HandTracker::load_config(const std::string &jsonfile) (handtrack.h:822-828): host only.  Applies the file to
  *                *params the way the reference's field decoder does: every field of visit_fields (handtrack.h:549-581) is assigned, one that
  *                the file does not give as a number becomes 0; a missing file leaves everything untouched.  segment_scale and

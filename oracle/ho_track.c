@@ -627,3 +627,23 @@ void ho_update(ho_tracker *t, const uint16_t *depth, const ho_camera *cam, float
 	}
 	free(points);
 }
+
+/* PhysModel::scale (physmodel.h:196-219,304-319) on both models, as HandTracker::scale does (handtrack.h:591) */
+static void ho_scale_model(ho_model *m, float s)
+{
+	for (int b = 0; b < m->nb; b++)
+	{
+		ho_body *rb = &m->bodies[b];
+		for (int i = 0; i < rb->shape.nverts; i++) rb->shape.verts[i] = scale3(rb->shape.verts[i], s);
+		for (int i = 0; i < rb->shape.nplanes; i++) rb->shape.planes[i].w *= s;
+		rb->com = scale3(rb->com, s);
+		rb->radius *= s; rb->radius_inner *= s;
+		const float ss = s * s;
+		rb->tensorinv_massless.x = div3(rb->tensorinv_massless.x, ss); rb->tensorinv_massless.y = div3(rb->tensorinv_massless.y, ss); rb->tensorinv_massless.z = div3(rb->tensorinv_massless.z, ss);
+		rb->Iinv.x = div3(rb->Iinv.x, ss); rb->Iinv.y = div3(rb->Iinv.y, ss); rb->Iinv.z = div3(rb->Iinv.z, ss);
+	}
+	for (int b = 0; b < m->nb; b++)
+		m->bodies[b].position = add3(m->bodies[0].position, scale3(sub3(m->bodies[b].position, m->bodies[0].position), s));
+	for (int j = 0; j < m->nj; j++) { m->joints[j].p0 = scale3(m->joints[j].p0, s); m->joints[j].p1 = scale3(m->joints[j].p1, s); }
+}
+void ho_scale(ho_tracker *t, float s) { ho_scale_model(&t->handmodel, s); ho_scale_model(&t->othermodel, s); }

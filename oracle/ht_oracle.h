@@ -135,6 +135,7 @@ ho_body *ho_body_ptr(ho_model *m, int b);
 #ifdef __cplusplus
 }
 #endif
+void ho_scale(ho_tracker *t, float s);                                 /* HandTracker::scale handtrack.h:591 (segment_scale is the caller's) */
 /* HandSegmentVR (handtrack.h:280-344): full-size depth frame -> 64x64 tile + its camera (ho_segment.c) */
 int ho_segment_vr(const uint16_t *depth, int w, int h, const float *cam12, int entry_options, float wrange_lo, float wrange_hi, float diam,
                   uint16_t *tile, float *camout12, uint16_t *small_out, unsigned char *dt_out);

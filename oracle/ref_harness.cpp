@@ -21,6 +21,7 @@
 //   scan   <animbank.pose> <stride>                workload statistics per animation row
 //   frames <animbank.pose> <first> <stride> <n> <out.htfx>    64x64 frames + cameras + start poses
 //   golden <animbank.pose> <rows,comma> <seed> <fc2gain> <out.htfx>   per-stage goldens
+//   scale  <animbank.pose> <rows,comma> <seed> <fc2gain> <s> <out.htfx>   HandTracker::scale(s): scaled model (<out>.model) + unit of work
 //   segment <animbank.pose> <rows,comma> <out.htfx>   320x240 frames and what HandSegmentVR makes of them
 //   bench  <frames.htfx> <seed> <fc2gain> <reps>   reference CPU time for the unit of work
 //
@@ -362,6 +363,44 @@ static int mode_segment(const char *bankfn, const char *rowscsv, const char *out
 	return 0;
 }
 
+// HandTracker::scale (handtrack.h:591): the scaled model as the reference holds it, and the unit of work on two frames with that model
+static int mode_scale(const char *bankfn, const char *rowscsv, uint64_t seed, double gain, double sc, const char *outfn)
+{
+	HandTracker htk;
+	htk.microforce = 3.0f; htk.mainthreadpasses = 3; htk.always_take_cnn = 0;
+	load_weights(htk, seed, gain);
+	PhysModel fake = LoadHandModel();
+	auto bank = read_animbank(bankfn, fake.rigidbodies.size());
+	std::vector<int> rows; { std::stringstream ss(rowscsv); std::string t; while (std::getline(ss, t, ',')) rows.push_back(atoi(t.c_str())); }
+	const float seg = htk.scale((float)sc);
+	{ std::string mf = std::string(outfn) + ".model"; if (dump_model(htk.handmodel, mf.c_str())) return 2; }
+	Out o; if (htfx_open(&o.w, outfn)) return 2;
+	o.i32("rows", rows); o.f32("scale_segment", { (float)sc, seg });
+	for (size_t fi = 0; fi < rows.size(); fi++)
+	{
+		std::string pre = "f" + std::to_string(fi) + "/";
+		Frame fr = make_frame(fake, bank, rows[fi]);
+		o.u16(pre + "depth", fr.seg.raster, { 64, 64 }); o.f32(pre + "cam", camvec(fr.seg.cam)); o.f32(pre + "startpose", flat(fr.start), { 17, 7 });
+		htk.handmodel.SetPose(fr.start); htk.othermodel.SetPose(fr.start); zero_momenta(htk.handmodel); zero_momenta(htk.othermodel);
+		htk.prev_frame_error = 0; htk.initializing = 0;
+		auto pose = htk.update_cnn_model(fr.seg);
+		if (pose.size()) htk.handmodel.SetPose(pose);
+		auto points = takesubsample(PointCloud(fr.seg, { 0.1f,htk.drangey }), htk.subsample_fraction);
+		for (int i = 0; i < htk.mainthreadpasses; i++)
+		{
+			std::vector<LimitAngular> angulars; std::vector<LimitLinear> linears;
+			HandModelEnhancements(htk.handmodel, angulars, false, float3(0, 0, 0), float3(0, 0, 0), 0);
+			if (htk.boundary_planes && points.size() > htk.min_point_num) linears = cloud_chamber(htk.handmodel, points, { { -1,-0.25f,0 },{ -1,-1,0 },{ 0,-1,0 },{ 1,-1,0 },{ 1,-0.25f,0 } }, float3(0, 0, 0), float3(0, 0, 1), 10.0f);
+			htk.handmodel.FitPointCloud(points, linears, angulars, htk.microforce);
+		}
+		o.state(pre + "hand", htk.handmodel);
+		o.f32(pre + "pose_user", flat(htk.handmodel.GetPoseUser()), { 17, 7 });
+	}
+	htfx_close(&o.w);
+	printf("scale %.3f: %d frames -> %s (+ .model)\n", sc, (int)rows.size(), outfn);
+	return 0;
+}
+
 static int mode_golden(const char *bankfn, const char *rowscsv, uint64_t seed, double gain, const char *outfn)
 {
 	HandTracker htk;
@@ -590,6 +629,7 @@ int main(int argc, char **argv) try
 	if (mode == "modelfile" && a.size() == 2) return mode_modelfile(a[0].c_str(), a[1].c_str());
 	if (mode == "scan" && a.size() == 2) return mode_scan(a[0].c_str(), atoi(a[1].c_str()));
 	if (mode == "frames" && a.size() == 5) return mode_frames(a[0].c_str(), atoi(a[1].c_str()), atoi(a[2].c_str()), atoi(a[3].c_str()), a[4].c_str());
+	if (mode == "scale" && a.size() == 6) return mode_scale(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), atof(a[4].c_str()), a[5].c_str());
 	if (mode == "segment" && a.size() == 3) return mode_segment(a[0].c_str(), a[1].c_str(), a[2].c_str());
 	if (mode == "golden" && a.size() == 5) return mode_golden(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());
 	if (mode == "bench" && a.size() >= 4) return mode_bench(a[0].c_str(), strtoull(a[1].c_str(), 0, 0), atof(a[2].c_str()), atoi(a[3].c_str()), a.size() > 4 ? atoi(a[4].c_str()) : 0);
