@@ -647,3 +647,62 @@ static void ho_scale_model(ho_model *m, float s)
 	for (int j = 0; j < m->nj; j++) { m->joints[j].p0 = scale3(m->joints[j].p0, s); m->joints[j].p1 = scale3(m->joints[j].p1, s); }
 }
 void ho_scale(ho_tracker *t, float s) { ho_scale_model(&t->handmodel, s); ho_scale_model(&t->othermodel, s); }
+
+/* PhysModel::RelativeAngularConstraints(refpose, filter) physmodel.h:423-432 with slowfit's filter (handtrack.h:799):
+ * joint j passes when (j != 0 && hold == 2) || j > 3.  Uses the joint ranges HandModelEnhancements just wrote. */
+static pose_t body_pose(const ho_body *b) { return POSE(b->position, b->orientation); }
+static int relative_angular(ho_tracker *t, ho_model *m, const float *refpose7, int hold, ho_angular *out)
+{
+	int k = 0;
+	for (int j = 0; j < m->nj; j++)
+	{
+		if (!((j != 0 && hold == 2) || j > 3)) continue;
+		const ho_joint *jt = &m->joints[j];
+		const float *r0 = refpose7 + 7 * jt->rbi0, *r1 = refpose7 + 7 * jt->rbi1;
+		pose_t ref0 = POSE(F3(r0[0], r0[1], r0[2]), F4(r0[3], r0[4], r0[5], r0[6])), ref1 = POSE(F3(r1[0], r1[1], r1[2]), F4(r1[3], r1[4], r1[5], r1[6]));
+		/* dq = (ref0^-1 * ref1)^-1 * rb0.pose^-1 * rb1.pose, evaluated left to right */
+		pose_t dq = pose_mul(pose_mul(pose_inverse(pose_mul(pose_inverse(ref0), ref1)), pose_inverse(body_pose(&m->bodies[jt->rbi0]))), body_pose(&m->bodies[jt->rbi1]));
+		m33 R = qmat(m->bodies[jt->rbi0].orientation);
+		for (int a = 0; a < 3; a++) if (f3_get(jt->rangemin, a) != f3_get(jt->rangemax, a))
+		{
+			ho_angular *o = &out[k++];
+			o->rb0 = jt->rbi0; o->rb1 = jt->rbi1; o->axis = a == 0 ? R.x : a == 1 ? R.y : R.z; o->torque = 0;
+			o->targetspin = -f4_get(dq.orientation, a) * 2.0f / t->phys.deltaT; o->mintorque = -FLT_MAX; o->maxtorque = FLT_MAX;
+		}
+	}
+	return k;
+}
+/* HandTracker::slowfit handtrack.h:786-821 on handmodel; selectrb < 0: none; crays: ncray x (dir3, weight) */
+void ho_slowfit(ho_tracker *t, const f3 *points, int n, int hold, const float *refpose7, int steps_, int selectrb, f3 spoint, f3 rbpoint, const float *crays4, int ncray)
+{
+	ho_model *m = &t->handmodel;
+	ho_body *B[HO_MAXB]; model_ptrs(m, B);
+	ho_linear *lin = malloc(sizeof(ho_linear) * MAXLIN); ho_angular ang[MAXANG];
+	for (int st = 0; st < steps_; st++)
+	{
+		int nl = 0, na = 0;
+		ho_enhancements(t, m, ang, &na, 0, F3(0, 0, 0), F3(0, 0, 0), 0);
+		if (hold && refpose7) na += relative_angular(t, m, refpose7, hold, ang + na);
+		for (int i = 0; st < 5 && i < ncray && i < 8; i++)
+		{
+			f4 q = quat_from_to(F3(0, 0, 1), F3(crays4[4 * i], crays4[4 * i + 1], crays4[4 * i + 2]));
+			f3 off = F3(FEATURE[i].off[0], FEATURE[i].off[1], FEATURE[i].off[2]);
+			f2 fl = { -100000.0f, 100000.0f };
+			nl += ho_along_direction_deadzone(B, -1, F3(0, 0, 0), FEATURE[i].bone, off, qxdir(q), 0.01f, fl, lin + nl);
+			nl += ho_along_direction_deadzone(B, -1, F3(0, 0, 0), FEATURE[i].bone, off, qydir(q), 0.01f, fl, lin + nl);
+		}
+		if (selectrb >= 0) nl += ho_position_nailed(B, -1, spoint, selectrb, rbpoint, lin + nl);
+		if (st < steps_ - 1)
+		{
+			int c0 = nl;
+			nl += cloud_constraints(m, points, n, 1, F3(0, 0, 0), lin + nl);
+			for (int i = c0; i < nl; i++)
+			{
+				const float k = t->par.microforce * (1.0f * (steps_ - st) / (float)steps_) * ((lin[i].rb1 == 0) ? 0.1f * (st < steps_ - 2) : 1.0f);
+				lin[i].forcelimit.x *= k; lin[i].forcelimit.y *= k;
+			}
+		}
+		ho_fit_pointcloud(t, m, NULL, 0, lin, nl, ang, na, 1.0f);
+	}
+	free(lin);
+}

@@ -135,6 +135,7 @@ ho_body *ho_body_ptr(ho_model *m, int b);
 #ifdef __cplusplus
 }
 #endif
+void ho_slowfit(ho_tracker *t, const f3 *points, int n, int hold, const float *refpose7, int steps_, int selectrb, f3 spoint, f3 rbpoint, const float *crays4, int ncray);   /* handtrack.h:786-821 */
 void ho_scale(ho_tracker *t, float s);                                 /* HandTracker::scale handtrack.h:591 (segment_scale is the caller's) */
 /* HandSegmentVR (handtrack.h:280-344): full-size depth frame -> 64x64 tile + its camera (ho_segment.c) */
 int ho_segment_vr(const uint16_t *depth, int w, int h, const float *cam12, int entry_options, float wrange_lo, float wrange_hi, float diam,

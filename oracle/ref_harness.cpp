@@ -22,6 +22,7 @@
 //   frames <animbank.pose> <first> <stride> <n> <out.htfx>    64x64 frames + cameras + start poses
 //   golden <animbank.pose> <rows,comma> <seed> <fc2gain> <out.htfx>   per-stage goldens
 //   scale  <animbank.pose> <rows,comma> <seed> <fc2gain> <s> <out.htfx>   HandTracker::scale(s): scaled model (<out>.model) + unit of work
+//   slowfit <animbank.pose> <rows,comma> <out.htfx>   HandTracker::slowfit with several argument sets
 //   segment <animbank.pose> <rows,comma> <out.htfx>   320x240 frames and what HandSegmentVR makes of them
 //   bench  <frames.htfx> <seed> <fc2gain> <reps>   reference CPU time for the unit of work
 //
@@ -401,6 +402,41 @@ static int mode_scale(const char *bankfn, const char *rowscsv, uint64_t seed, do
 	return 0;
 }
 
+// HandTracker::slowfit (handtrack.h:786-821), the annotation fit loop: a few argument combinations per frame
+static int mode_slowfit(const char *bankfn, const char *rowscsv, const char *outfn)
+{
+	HandTracker htk;
+	htk.microforce = 3.0f;
+	PhysModel fake = LoadHandModel();
+	auto bank = read_animbank(bankfn, fake.rigidbodies.size());
+	std::vector<int> rows; { std::stringstream ss(rowscsv); std::string t; while (std::getline(ss, t, ',')) rows.push_back(atoi(t.c_str())); }
+	Out o; if (htfx_open(&o.w, outfn)) return 2;
+	o.i32("rows", rows);
+	for (size_t fi = 0; fi < rows.size(); fi++)
+	{
+		std::string pre = "f" + std::to_string(fi) + "/";
+		Frame fr = make_frame(fake, bank, rows[fi]);
+		o.u16(pre + "depth", fr.seg.raster, { 64, 64 }); o.f32(pre + "cam", camvec(fr.seg.cam)); o.f32(pre + "startpose", flat(fr.start), { 17, 7 }); o.f32(pre + "refpose", flat(fr.gt), { 17, 7 });
+		auto points = takesubsample(PointCloud(fr.seg, { 0.1f,htk.drangey }), htk.subsample_fraction);
+		std::vector<float4> crays;      // unit rays from the camera to the ground-truth feature points, weight 1
+		for (auto p : Skin(fr.gt, handmodelfeaturepoints)) crays.push_back(float4(normalize(p), 1.0f));
+		std::vector<float> cf; for (auto &c : crays) for (int i = 0; i < 4; i++) cf.push_back(c[i]);
+		o.f32(pre + "crays", cf, { 8, 4 });
+		const float3 spoint = fr.gt[7] * float3(0, 0, 0.01f), rbpoint = float3(0, 0, 0.01f);
+		o.f32(pre + "select", { 7.0f, spoint.x, spoint.y, spoint.z, rbpoint.x, rbpoint.y, rbpoint.z });
+		struct { const char *name; int hold, steps; bool sel, rays; } cases[] = { { "plain", 0, 6, false, false }, { "hold1", 1, 6, false, false }, { "hold2", 2, 4, false, false }, { "rays", 0, 6, false, true }, { "nail", 1, 6, true, true } };
+		for (auto &c : cases)
+		{
+			htk.handmodel.SetPose(fr.start); zero_momenta(htk.handmodel);
+			htk.slowfit(points, c.hold, fr.gt, c.steps, c.sel ? &htk.handmodel.rigidbodies[7] : NULL, spoint, rbpoint, c.rays ? crays : std::vector<float4>(0));
+			o.state(pre + c.name, htk.handmodel);
+		}
+	}
+	htfx_close(&o.w);
+	printf("slowfit: %d frames -> %s\n", (int)rows.size(), outfn);
+	return 0;
+}
+
 static int mode_golden(const char *bankfn, const char *rowscsv, uint64_t seed, double gain, const char *outfn)
 {
 	HandTracker htk;
@@ -630,6 +666,7 @@ int main(int argc, char **argv) try
 	if (mode == "scan" && a.size() == 2) return mode_scan(a[0].c_str(), atoi(a[1].c_str()));
 	if (mode == "frames" && a.size() == 5) return mode_frames(a[0].c_str(), atoi(a[1].c_str()), atoi(a[2].c_str()), atoi(a[3].c_str()), a[4].c_str());
 	if (mode == "scale" && a.size() == 6) return mode_scale(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), atof(a[4].c_str()), a[5].c_str());
+	if (mode == "slowfit" && a.size() == 3) return mode_slowfit(a[0].c_str(), a[1].c_str(), a[2].c_str());
 	if (mode == "segment" && a.size() == 3) return mode_segment(a[0].c_str(), a[1].c_str(), a[2].c_str());
 	if (mode == "golden" && a.size() == 5) return mode_golden(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());
 	if (mode == "bench" && a.size() >= 4) return mode_bench(a[0].c_str(), strtoull(a[1].c_str(), 0, 0), atof(a[2].c_str()), atoi(a[3].c_str()), a.size() > 4 ? atoi(a[4].c_str()) : 0);

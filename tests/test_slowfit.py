@@ -1,0 +1,37 @@
+"""HandTracker::slowfit (handtrack.h:786-821), the annotation tools' fit loop.  tests/golden/slowfit3.htfx holds, for three
+animation-bank frames, the hand model state the reference reaches for five argument sets (no hold / hold 1 / hold 2 with fewer steps /
+landmark rays / rays + a nailed bone)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import htfx
+import oracle_lib as ol
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = htfx.load(os.path.join(HERE, "golden", "slowfit3.htfx"))
+CASES = [("plain", 0, 6, False, False), ("hold1", 1, 6, False, False), ("hold2", 2, 4, False, False), ("rays", 0, 6, False, True), ("nail", 1, 6, True, True)]
+
+
+def _points(orc, f):
+    cam = ol.camera(G["f%d/cam" % f])
+    buf = (ol.F3 * 4096)(); nfull = C.c_int()
+    n = orc.L.ho_pointcloud(ol.u16ptr(np.ascontiguousarray(G["f%d/depth" % f].reshape(-1))), C.byref(cam), 0.1, 0.7, 4, buf, 4096, C.byref(nfull))
+    return buf, n
+
+
+@pytest.mark.parametrize("f", range(3))
+def test_oracle_slowfit(weights, f):
+    orc = ol.Oracle(weights)
+    orc.head.par.microforce = 3.0
+    pts, n = _points(orc, f)
+    pre = "f%d/" % f
+    sel = G[pre + "select"]
+    for name, hold, steps, use_sel, use_rays in CASES:
+        orc.reset(G[pre + "startpose"])
+        ref = np.ascontiguousarray(G[pre + "refpose"]); crays = np.ascontiguousarray(G[pre + "crays"])
+        orc.L.ho_slowfit(orc.h, pts, n, hold, ol.fptr(ref), steps, int(sel[0]) if use_sel else -1, ol.F3(*sel[1:4]), ol.F3(*sel[4:7]), ol.fptr(crays), 8 if use_rays else 0)
+        assert np.array_equal(orc.get_state(0), G[pre + name]), (f, name, np.abs(orc.get_state(0) - G[pre + name]).max())
+    orc.close()
