@@ -102,7 +102,7 @@ __device__ __forceinline__ void closest_feature(const ht_model_dev &M, const flo
 
 // ------------------------------------------------------------------------------------------------- k_cloud_rows
 // mode 0: forcelimit (-1,1) (CloudConstraints as is)     1: FitPointCloud scaling (physmodel.h:347)
-//      2: MultiStepSim scaling (handtrack.h:656,681)     3: UnibodyFit scaling (handtrack.h:461)
+//      2: MultiStepSim scaling (handtrack.h:656,681)     3: UnibodyFit scaling (handtrack.h:461)     4: slowfit scaling (handtrack.h:815-816)
 // One block per frame.  Points are first binned by the body the cheap sphere test of physmodel.h:140-147 prefers, so that the 64 points
 // a wave then works on sit on the same part of the hand and cull the same bodies: the plane loops below are wave-uniform and run for a
 // body as soon as one lane needs it.  The grouping changes which bodies a wave evaluates, never a point's result.
@@ -208,6 +208,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 	if (mode == 1) { float k = (rb == 0 || rb == 1 || rb == 2) ? weak_force : 1.0f; fmin = -1.0f * k * microforce; fmax = 1.0f * k * microforce; }
 	else if (mode == 2) { float cloudforce = fmin_std(cf_max_point, cf_max_sum / (float)n); float k = (rb == 0) ? 0.1f : 1.0f; fmin = -cloudforce * k; fmax = cloudforce * k; }
 	else if (mode == 3) { fmin = -1.0f * unibody_force; fmax = 1.0f * unibody_force; }
+	else if (mode == 4) { const float k = (microforce * weak_force) * ((rb == 0) ? cf_max_point : 1.0f); fmin = -1.0f * k; fmax = 1.0f * k; }      // slowfit handtrack.h:815-816: weak_force = step ratio, cf_max_point = wrist factor
 	float4 *out = reinterpret_cast<float4 *>(rows + ((size_t)b * HT_MAXPTS + i) * HT_ROW);
 	out[0] = make_float4(-1.0f, (float)rb, v.x, v.y);
 	out[1] = make_float4(v.z, position1.x, position1.y, position1.z);
@@ -314,10 +315,10 @@ __global__ __launch_bounds__(64) void k_chamber(ht_model_dev M, const float *__r
 
 // ------------------------------------------------------------------------------------------------- launchers
 void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const float *cams, const int *active_flag, int stride, int use_cam_origin, int mode,
-                          const ht_params &par, float *rows, int *nrows, int B, hipStream_t s)
+                          const ht_params &par, float *rows, int *nrows, int B, hipStream_t s, float sf_ratio, float sf_wrist)
 {
-	hipLaunchKernelGGL(k_cloud_rows, dim3(B), dim3(CR_THREADS), (size_t)M.plane_off[M.nb] * sizeof(float4), s, M, state, pts, npts, cams, active_flag, stride, use_cam_origin, mode, par.microforce, par.physics_weak_force,
-	                   par.cloudforce_max_point, par.cloudforce_max_sum, par.unibody_force, rows, nrows);
+	hipLaunchKernelGGL(k_cloud_rows, dim3(B), dim3(CR_THREADS), (size_t)M.plane_off[M.nb] * sizeof(float4), s, M, state, pts, npts, cams, active_flag, stride, use_cam_origin, mode, par.microforce,
+	                   mode == 4 ? sf_ratio : par.physics_weak_force, mode == 4 ? sf_wrist : par.cloudforce_max_point, par.cloudforce_max_sum, par.unibody_force, rows, nrows);
 }
 void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, float scale, float *err, int B, hipStream_t s)
 {

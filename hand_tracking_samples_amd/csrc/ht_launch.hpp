@@ -12,11 +12,14 @@ struct solve_args
 	float *state;                                                   // [B][nb][HT_STATE_STRIDE] of the model being solved
 	float *scratch; int scratch_stride;                             // [B][scratch_stride][12] pre-computed single-body row stream
 	int apply_angles; float drive_force; int ray_rows; int arm_cone; int zero_momenta; int steps_keyangles; float min_cray_prob;
+	// slowfit (handtrack.h:786-821): landmark rays from the origin (sf_crays [B][8][4], first sf_ncray used), a bone nailed to a point, and
+	// RelativeAngularConstraints against a reference pose (sf_refpose [B][nb][7], sf_hold = 1 or 2); all off when zero / null
+	const float *sf_crays; int sf_ncray; int sf_select; float sf_spoint[3], sf_rbpoint[3]; const float *sf_refpose; int sf_hold;
 	int dbg;                                                        // timing experiments only (HT_DEBUG_SKIP): 1 skip chains, 2 skip two-body linear, 4 skip angular
 };
 
 void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const float *cams, const int *active_flag, int stride, int use_cam_origin, int mode,
-                          const ht_params &par, float *rows, int *nrows, int B, hipStream_t s);
+                          const ht_params &par, float *rows, int *nrows, int B, hipStream_t s, float sf_ratio = 0.0f, float sf_wrist = 0.0f);
 void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, float scale, float *err, int B, hipStream_t s);
 void ht_launch_chamber(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, int min_point_num, int enabled, float maxforce, float *rows, int *nch, int B, hipStream_t s);
 void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s);

@@ -35,7 +35,7 @@
 #define ASLOTS 2           // angular rows live in registers: row r in lane r%64, slot r/64  (<= 128 rows)
 #define MAXA2 (64 * ASLOTS)
 #define AROW 10            // floats per angular row record: axis[3] meta | ts ts_post | mintorque*dt maxtorque*dt | 1/(axis.Iinv.axis) torque
-#define MAXA_LDS 110       // angular rows: 13 + 6 per joint for the 17-bone hand
+#define MAXA_LDS 126       // angular rows held in LDS: 13 + up to 6 per joint for the 17-bone hand, plus slowfit's relative rows
 #define POOL_FLOATS 7136   // LDS pool shared by the two-body linear rows (front) and the single-body chain rows (rest; overflow: HBM scratch)
 #define IDLE_BODY (HT_MAXNB - 1)      // lane pairs without a row in a step work on this all-zero body and on an all-zero record
 #define LM_FRIC 0x10000    // meta bits of a two-body linear row: friction row (limits from its contact's normal row, physics.h:292)
@@ -59,8 +59,8 @@ struct lds_t
 		struct      // prologue only
 		{
 			float jr[HT_MAXNJ][6];                 // joint ranges after HandModelEnhancements
-			float ray[20][HT_ROW];
-			int acount[HT_MAXNJ], aprefix[HT_MAXNJ + 1];
+			float ray[36][HT_ROW];                 // landmark-ray rows: 4 per ray (MultiStepSim: 5 rays; slowfit: 8 rays + 3 nail rows)
+			int acount[HT_MAXNJ], aprefix[HT_MAXNJ + 1], rprefix[HT_MAXNJ + 1];
 			unsigned char lrb[MAXL2][2], arb[MAXA2][2];     // body pair of every two-body row (255 = none), for the level schedule
 			unsigned short llev[MAXL2]; unsigned char alev[MAXA2], gst[MAXA2];
 			unsigned short lfill[MAXL2 + 2];
@@ -236,7 +236,45 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		}
 	}
 	// ---- landmark-ray rows of MultiStepSim (handtrack.h:666-676): 2 dead-zone pairs per open finger ----
-	if (a.ray_rows && lane == 8)
+	if (a.ray_rows && a.sf_ncray + (a.sf_select >= 0) > 0 && lane == 8)
+	{
+		// slowfit (handtrack.h:803-810): dead-zone pairs along the two axes perpendicular to each landmark ray, rays from the origin, then the nail
+		int k = 0;
+		for (int i = 0; i < a.sf_ncray && i < 8; i++)
+		{
+			const float *cr = a.sf_crays + ((size_t)b * 8 + i) * 4;
+			v4 q = quat_from_to(V3(0, 0, 1), L3(cr));
+			const int rb = FEATURE_BONE[i];
+			const v3 off = V3(FEATURE_OFF[i][0], FEATURE_OFF[i][1], FEATURE_OFF[i][2]);
+			for (int ax = 0; ax < 2; ax++)
+			{
+				const v3 axis = ax == 0 ? qxdir(q) : qydir(q);
+				const float base = dot(anchor_world(S, rb, off) - V3(0, 0, 0), axis);       // ConstrainAlongDirectionDeadzone physics.h:332-340
+				for (int sd = 0; sd < 2; sd++)
+				{
+					float *o = S.ray[k++];
+					o[0] = -1.0f; o[1] = (float)rb; o[2] = 0.0f; o[3] = 0.0f; o[4] = 0.0f; o[5] = off.x; o[6] = off.y; o[7] = off.z;
+					o[8] = axis.x; o[9] = axis.y; o[10] = axis.z; o[11] = sd == 0 ? base + 0.01f : base - 0.01f; o[12] = 0.0f;
+					o[13] = sd == 0 ? fmin_std(0.0f, 100000.0f) : fmin_std(-100000.0f, 0.0f); o[14] = sd == 0 ? fmax_std(0.0f, 100000.0f) : fmax_std(-100000.0f, 0.0f); o[15] = 0.0f;
+				}
+			}
+		}
+		if (a.sf_select >= 0)      // ConstrainPositionNailed(NULL, spoint, selectrb, rbpoint) physics.h:342-346
+		{
+			const int rb = a.sf_select;
+			const v3 sp = V3(a.sf_spoint[0], a.sf_spoint[1], a.sf_spoint[2]), rp = V3(a.sf_rbpoint[0], a.sf_rbpoint[1], a.sf_rbpoint[2]);
+			const v3 d = anchor_world(S, rb, rp) - sp;
+			for (int ax = 0; ax < 3; ax++)
+			{
+				float *o = S.ray[k++];
+				o[0] = -1.0f; o[1] = (float)rb; o[2] = sp.x; o[3] = sp.y; o[4] = sp.z; o[5] = rp.x; o[6] = rp.y; o[7] = rp.z;
+				o[8] = ax == 0 ? 1.0f : 0.0f; o[9] = ax == 1 ? 1.0f : 0.0f; o[10] = ax == 2 ? 1.0f : 0.0f; o[11] = ax == 0 ? d.x : ax == 1 ? d.y : d.z; o[12] = 0.0f;
+				o[13] = -FLT_MAX; o[14] = FLT_MAX; o[15] = 0.0f;
+			}
+		}
+		S.nray = k;
+	}
+	else if (a.ray_rows && lane == 8)
 	{
 		const float *an = a.analysis + (size_t)b * HT_ANALYSIS;
 		const float *cam = a.cams + (size_t)b * HT_CAM;
@@ -267,11 +305,24 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 
 	if (a.dbg & 256) return;
 	// ---- angular rows: [ApplyAngles 12] [arm cone 1] [joint ranges], generated by the lane that owns them ----
-	const int na_pre = (a.apply_angles ? 12 : 0) + (a.arm_cone ? 1 : 0);
+	// slowfit's RelativeAngularConstraints (physmodel.h:423-432, filter handtrack.h:799): one row per ranged axis of every joint that passes
+	const bool rel = a.sf_refpose && a.sf_hold;
 	if (lane < nj) S.acount[lane] = angular_range_count(L3(S.jr[lane]), L3(S.jr[lane] + 3));
 	__syncthreads();
-	if (lane == 0) { int acc = na_pre; for (int j = 0; j < nj; j++) { S.aprefix[j] = acc; acc += S.acount[j]; } S.aprefix[nj] = acc; }
+	if (lane == 0)
+	{
+		int acc = (a.apply_angles ? 12 : 0) + (a.arm_cone ? 1 : 0);
+		for (int j = 0; j < nj; j++)
+		{
+			S.rprefix[j] = acc;
+			if (rel && ((j != 0 && a.sf_hold == 2) || j > 3)) for (int ax = 0; ax < 3; ax++) acc += S.jr[j][ax] != S.jr[j][3 + ax];
+		}
+		S.rprefix[nj] = acc;
+		for (int j = 0; j < nj; j++) { S.aprefix[j] = acc; acc += S.acount[j]; }
+		S.aprefix[nj] = acc;
+	}
 	__syncthreads();
+	const int na_fix = (a.apply_angles ? 12 : 0) + (a.arm_cone ? 1 : 0), na_pre = S.rprefix[nj];      // [ApplyAngles, arm cone | relative rows | joint ranges]
 	int na = S.aprefix[nj];
 	if (na > MAXA2) na = MAXA2;
 	arow AR[ASLOTS];
@@ -284,7 +335,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		if (r < na)
 		{
 			float row[8];
-			if (r < na_pre)
+			if (r < na_fix)
 			{
 				const float *cam = a.cams + (size_t)b * HT_CAM;
 				const v4 camq = V4(cam[8], cam[9], cam[10], cam[11]);
@@ -314,6 +365,22 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 						}
 					}
 				}
+			}
+			else if (r < na_pre)      // RelativeAngularConstraints (physmodel.h:423-432): keep the joint's rotation relative to the reference pose
+			{
+				int j = 0;
+				while (j + 1 < nj && S.rprefix[j + 1] <= r) j++;
+				int sub = r - S.rprefix[j], ax = 0;
+				for (int k = 0; k < 3; k++) if (S.jr[j][k] != S.jr[j][3 + k]) { if (sub == 0) { ax = k; sub = -1; } else if (sub > 0) sub--; }
+				const float *jc = M.jointc + j * HT_JC;
+				const int rb0 = (int)jc[HT_JC_RB0], rb1 = (int)jc[HT_JC_RB1];
+				const float *r0 = a.sf_refpose + ((size_t)b * nb + rb0) * HT_POSE, *r1 = a.sf_refpose + ((size_t)b * nb + rb1) * HT_POSE;
+				const xf ref0 = XF(L3(r0), L4(r0 + 3)), ref1 = XF(L3(r1), L4(r1 + 3));
+				const xf dq = mul(mul(inverse(mul(inverse(ref0), ref1)), inverse(body_xf(S, rb0))), body_xf(S, rb1));
+				const m3 R0 = qmat(L4(S.q[rb0]));
+				const v3 axis = ax == 0 ? R0.x : ax == 1 ? R0.y : R0.z;
+				const float qa = ax == 0 ? dq.q.x : ax == 1 ? dq.q.y : dq.q.z;
+				put_ang(row, rb0, rb1, axis, -qa * 2.0f / dt, -FLT_MAX, FLT_MAX);
 			}
 			else
 			{

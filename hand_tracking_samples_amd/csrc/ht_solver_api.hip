@@ -19,6 +19,7 @@ static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int 
 {
 	solve_args a;
 	memset(&a, 0, sizeof a);
+	a.sf_select = -1;
 	a.rows_pre = rows_pre; a.n_pre = n_pre; a.pre_stride = 5 * ctx->model.nb;
 	a.rows_cloud = cloud ? ctx->d_rows : nullptr; a.n_cloud = ctx->d_nrows;
 	a.contacts = contacts ? ctx->d_contacts : nullptr; a.ncontacts = ctx->d_ncontacts;
@@ -359,4 +360,63 @@ extern "C" int ht_segment_vr(ht_ctx *ctx, const uint16_t *depth, const float *ca
 	                    hipStreamSynchronize(s) != hipSuccess)) { ctx->err = "ht_segment_vr: download failed"; rc = HT_ERR_HIP; }
 	(void)hipFree(d_in); (void)hipFree(d_tiles); (void)hipFree(d_cams); (void)hipFree(d_co);
 	return rc;
+}
+
+// ------------------------------------------------------------------------------------------------- slowfit (annotation fit loop)
+// HandTracker::slowfit (handtrack.h:786-821) on the handmodel of slots [0,B) against the points ht_stage_prepare left on the device.
+extern "C" int ht_slowfit(ht_ctx *ctx, int B, int hold, const float *refpose, int steps, int select_rb, const float *spoint, const float *rbpoint, const float *crays, int ncray)
+{
+	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	const int nb = ctx->model.nb;
+	if (steps < 1 || ncray < 0 || ncray > 8 || select_rb >= nb || (select_rb >= 0 && (!spoint || !rbpoint)) || (ncray > 0 && !crays)) { ctx->err = "ht_slowfit: bad arguments"; return HT_ERR_ARG; }
+	hipStream_t s = ctx->stream;
+	if (!ctx->d_sf_ref)
+	{
+		void *p = nullptr, *q = nullptr;
+		HIPCHK(ctx, hipMalloc(&p, (size_t)ctx->B * nb * HT_POSE * sizeof(float))); ctx->allocs.push_back(p); ctx->d_sf_ref = (float *)p;
+		HIPCHK(ctx, hipMalloc(&q, (size_t)ctx->B * 8 * 4 * sizeof(float))); ctx->allocs.push_back(q); ctx->d_sf_crays = (float *)q;
+	}
+	const bool rel = hold && refpose;
+	if (rel) HIPCHK(ctx, hipMemcpyAsync(ctx->d_sf_ref, refpose, (size_t)B * nb * HT_POSE * sizeof(float), hipMemcpyHostToDevice, s));
+	if (ncray) HIPCHK(ctx, hipMemcpyAsync(ctx->d_sf_crays, crays, (size_t)B * 8 * 4 * sizeof(float), hipMemcpyHostToDevice, s));
+	const bool coll = ctx->phys.use_collision != 0;
+	for (int st = 0; st < steps; st++)
+	{
+		const bool cloud = st < steps - 1;
+		if (cloud) ht_launch_cloud_rows(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, ctx->d_cams, nullptr, 1, 0, 4, ctx->par, ctx->d_rows, ctx->d_nrows, B, s,
+		                                1.0f * (float)(steps - st) / (float)steps, 0.1f * (float)(st < steps - 2));
+		if (coll) ht_launch_contacts(ctx->model, ctx->d_state[0], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s);
+		solve_args a;
+		memset(&a, 0, sizeof a);
+		a.rows_cloud = cloud ? ctx->d_rows : nullptr; a.n_cloud = ctx->d_nrows;
+		a.contacts = coll ? ctx->d_contacts : nullptr; a.ncontacts = ctx->d_ncontacts;
+		a.analysis = ctx->d_analysis; a.cams = ctx->d_cams;
+		a.state = ctx->d_state[0]; a.scratch = ctx->d_scratch; a.scratch_stride = scratch_stride(ctx);
+		a.sf_ncray = st < 5 ? ncray : 0; a.sf_crays = ctx->d_sf_crays; a.sf_select = select_rb;
+		for (int i = 0; i < 3; i++) { a.sf_spoint[i] = spoint ? spoint[i] : 0.0f; a.sf_rbpoint[i] = rbpoint ? rbpoint[i] : 0.0f; }
+		a.ray_rows = (a.sf_ncray > 0 || select_rb >= 0) ? 1 : 0;
+		a.sf_refpose = rel ? ctx->d_sf_ref : nullptr; a.sf_hold = rel ? hold : 0;
+		a.steps_keyangles = ctx->par.steps_keyangles; a.min_cray_prob = ctx->par.min_cray_prob;
+		ht_launch_solve(ctx->model, ctx->phys, a, B, s);
+	}
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
+
+// Caller-supplied point clouds for the stage functions / ht_slowfit (the reference's slowfit takes its points as an argument):
+// points [B][cap][3] (cap <= 1024 used per frame), npoints [B].
+extern "C" int ht_set_points(ht_ctx *ctx, int B, const float *points, int cap, const int *npoints)
+{
+	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	if (!points || !npoints || cap < 1) return HT_ERR_ARG;
+	std::vector<float4> h((size_t)B * HT_MAXPTS, make_float4(0, 0, 0, 0)); std::vector<int> n(B);
+	for (int b = 0; b < B; b++)
+	{
+		n[b] = npoints[b] < 0 ? 0 : npoints[b] > cap ? cap : npoints[b]; if (n[b] > HT_MAXPTS) n[b] = HT_MAXPTS;
+		for (int i = 0; i < n[b]; i++) { const float *p = points + ((size_t)b * cap + i) * 3; h[(size_t)b * HT_MAXPTS + i] = make_float4(p[0], p[1], p[2], 0.0f); }
+	}
+	HIPCHK(ctx, hipMemcpy(ctx->d_pts, h.data(), h.size() * sizeof(float4), hipMemcpyHostToDevice));
+	HIPCHK(ctx, hipMemcpy(ctx->d_npts, n.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice));
+	return HT_OK;
 }

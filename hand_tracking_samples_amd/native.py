@@ -19,7 +19,7 @@ MAXPTS, ROW, CONTACT = 1024, 16, 12
 SYMBOLS = (
     "ht_create", "ht_destroy", "ht_model_bake", "ht_last_error", "ht_get_params", "ht_set_params", "ht_model_info", "ht_config_read", "ht_scale",
     "ht_cnn_load_weights", "ht_cnn_eval", "ht_cnn_eval_dev",
-    "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_segment_vr", "ht_segment_vr_dev",
+    "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_segment_vr", "ht_segment_vr_dev", "ht_slowfit", "ht_set_points",
     "ht_stage_prepare", "ht_stage_decode", "ht_stage_fit_error", "ht_stage_cloud_rows", "ht_stage_contacts", "ht_stage_fit",
     "ht_stage_multistep", "ht_stage_scratch_unibody", "ht_profile_enable", "ht_profile_read", "ht_debug_solve_stats", "ht_debug_contact_stats",
 )
@@ -81,6 +81,7 @@ def load(build_if_missing=True):
     L.ht_stage_scratch_unibody.argtypes = [vp, fp, C.c_int, C.c_int]
     L.ht_profile_enable.argtypes = [vp, C.c_int]
     L.ht_scale.argtypes = [vp, C.c_float]
+    L.ht_slowfit.argtypes = [vp, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp, fp, fp, C.c_int]
     L.ht_segment_vr.argtypes = [vp, C.POINTER(C.c_uint16), fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_uint16), fp]
     L.ht_segment_vr_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp, vp, vp]
     L.ht_profile_read.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_int, fp, ip, ip]
@@ -289,3 +290,11 @@ class Context:
     def scale(self, s):
         """HandTracker::scale (handtrack.h:591): both models of every slot grow by the factor s."""
         self._chk(self.L.ht_scale(self.h, float(s)))
+
+    def slowfit(self, B, hold=0, refpose=None, steps=6, select_rb=-1, spoint=None, rbpoint=None, crays=None):
+        """HandTracker::slowfit (handtrack.h:786-821) on the handmodel of slots [0,B) with the points of the last stage_prepare."""
+        ref = None if refpose is None else _c(refpose, np.float32)
+        sp = None if spoint is None else _c(spoint, np.float32); rp = None if rbpoint is None else _c(rbpoint, np.float32)
+        cr = None if crays is None else _c(crays, np.float32)
+        self._chk(self.L.ht_slowfit(self.h, int(B), int(hold), None if ref is None else _f(ref), int(steps), int(select_rb), None if sp is None else _f(sp), None if rp is None else _f(rp),
+                                    None if cr is None else _f(cr), 0 if cr is None else int(cr.reshape(-1, 8, 4).shape[1])))

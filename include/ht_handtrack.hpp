@@ -148,6 +148,18 @@ struct HandTracker                                                              
 		for (int b = 0; b < nb_; b++) { const float *p = &out[(size_t)b * HT_POSE]; pose[b].position = { p[0], p[1], p[2] }; pose[b].orientation = { p[3], p[4], p[5], p[6] }; }
 		return pose;
 	}
+	// slowfit (handtrack.h:786-821); the selected bone is given by index (-1: none) instead of a RigidBody pointer
+	void slowfit(const std::vector<float3> &points, int hold, const std::vector<Pose> &refpose, int steps_ = 6, int selectrb = -1, float3 spoint = { 0, 0, 0 }, float3 rbpoint = { 0, 0, 0 },
+	             const std::vector<float4> &crays = std::vector<float4>())
+	{
+		push_params();
+		const int n = (int)points.size();
+		check(ctx_, ht_set_points(ctx_, 1, n ? &points[0].x : &spoint.x, n > 0 ? n : 1, &n));
+		std::vector<float> ref = flat(refpose), cr(32, 0.0f);
+		const int ncray = crays.size() < 8 ? (int)crays.size() : 8;
+		for (int i = 0; i < ncray; i++) { cr[4 * i] = crays[i].x; cr[4 * i + 1] = crays[i].y; cr[4 * i + 2] = crays[i].z; cr[4 * i + 3] = crays[i].w; }
+		check(ctx_, ht_slowfit(ctx_, 1, refpose.empty() ? 0 : hold, refpose.empty() ? nullptr : ref.data(), steps_, selectrb, &spoint.x, &rbpoint.x, ncray ? cr.data() : nullptr, ncray));
+	}
 	float scale(float s) { check(ctx_, ht_scale(ctx_, s)); segment_scale *= s; return segment_scale; }                     // handtrack.h:591
 	// kickstart (handtrack.h:743-746): the CNN job in the calling thread, its pose taken over when it is accepted; no main-thread passes
 	void kickstart(Image<unsigned short> dimage) { const int keep = mainthreadpasses; mainthreadpasses = 0; try { update(std::move(dimage)); } catch (...) { mainthreadpasses = keep; throw; } mainthreadpasses = keep; }

@@ -131,6 +131,15 @@ int ht_segment_vr(ht_ctx *ctx, const uint16_t *depth, const float *cams, int w, 
 int ht_segment_vr_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, int w, int h, int B, int entry_options, float wrange_lo, float wrange_hi, float diam,
                       uint16_t *d_tiles, float *d_cams_out, void *stream);
 
+/* ---- annotation fit loop ---------------------------------------------------------------------------------------------
+ * ht_slowfit          replaces  void HandTracker::slowfit(const std::vector<float3> &points, int hold, const std::vector<Pose> &refpose,
+ *                     int steps_ = 6, RigidBody *selectrb = NULL, const float3 &spoint, const float3 &rbpoint, const std::vector<float4> &crays)
+ *                     (handtrack.h:786-821) on the handmodel of slots [0,B), with the points ht_stage_prepare left on the device.
+ *                     refpose [B][nb][7] (NULL or hold = 0: no RelativeAngularConstraints), select_rb < 0: no nailed bone,
+ *                     crays [B][8][4] (first ncray used for the reference's 8 model feature points). */
+int ht_set_points(ht_ctx *ctx, int B, const float *points, int cap, const int *npoints);      /* caller-supplied clouds [B][cap][3] instead of ht_stage_prepare's */
+int ht_slowfit(ht_ctx *ctx, int B, int hold, const float *refpose, int steps, int select_rb, const float *spoint, const float *rbpoint, const float *crays, int ncray);
+
 /* ---- stage entry points (same kernels, exposed one reference function at a time so parity tests can pin each) -----
  * All take HOST buffers and are synchronous.  `which` selects the model (0 handmodel, 1 othermodel) of slots [0,B).
  * ht_stage_prepare    depth -> CNN input (handtrack.h:700) and sub-sampled point cloud (misc_image.h:409-417, physmodel.h:58-64):

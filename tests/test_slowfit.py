@@ -35,3 +35,35 @@ def test_oracle_slowfit(weights, f):
         orc.L.ho_slowfit(orc.h, pts, n, hold, ol.fptr(ref), steps, int(sel[0]) if use_sel else -1, ol.F3(*sel[1:4]), ol.F3(*sel[4:7]), ol.fptr(crays), 8 if use_rays else 0)
         assert np.array_equal(orc.get_state(0), G[pre + name]), (f, name, np.abs(orc.get_state(0) - G[pre + name]).max())
     orc.close()
+
+
+@pytest.mark.gpu
+def test_gpu_slowfit(weights):
+    from hand_tracking_samples_amd import native
+    ctx = native.Context(ol.MODEL, 3)
+    ctx.load_weights(weights)
+    ctx.set_params(microforce=3.0)
+    depth = np.stack([G["f%d/depth" % f].reshape(-1) for f in range(3)]); cams = np.stack([G["f%d/cam" % f] for f in range(3)])
+    start = np.stack([G["f%d/startpose" % f] for f in range(3)]); ref = np.stack([G["f%d/refpose" % f] for f in range(3)])
+    crays = np.stack([G["f%d/crays" % f] for f in range(3)])
+    ctx.stage_prepare(depth, cams)
+    worst = 0.0
+    for name, hold, steps, use_sel, use_rays in CASES:
+        # the nailed point differs per frame in the fixture, so the nail case runs frame by frame through slot 0
+        frames = [[0], [1], [2]] if use_sel else [[0, 1, 2]]
+        for fs in frames:
+            if use_sel:
+                ctx.stage_prepare(depth[fs], cams[fs])
+            ctx.tracker_reset(start[fs])
+            sel = G["f%d/select" % fs[0]]
+            ctx.slowfit(len(fs), hold, ref[fs], steps, int(sel[0]) if use_sel else -1, sel[1:4] if use_sel else None, sel[4:7] if use_sel else None, crays[fs] if use_rays else None)
+            st = ctx.get_state(0, len(fs))
+            for k, f in enumerate(fs):
+                want = G["f%d/%s" % (f, name)]
+                dp, dq = np.abs(st[k][:, :3] - want[:, :3]).max(), np.abs(st[k][:, 3:7] - want[:, 3:7]).max()
+                worst = max(worst, dp)
+                assert dp <= 2e-5 and dq <= 2e-4, (name, f, dp, dq)
+        if use_sel:
+            ctx.stage_prepare(depth, cams)
+    print("slowfit worst |dpos| %.2e" % worst)
+    ctx.close()
