@@ -100,6 +100,8 @@ void ho_reset_tracker(ho_tracker *t, const float *pose7);               /* both 
 
 /* ---- stages ---- */
 void ho_cnn_eval(const float *weights, const float *input, float *output, float *const *layers);
+void ho_expected_cnn(const float *pose7, const ho_camera *hcam, float *expected2304, float *vals16);      /* GatherHandExpectedCNN handtrack.h:160-173 */
+float ho_cnn_train(float *weights, const float *input, const float *target, float alpha);      /* CNN::Train cnn.h:558-580 on .cnnb-ordered weights */
 void ho_cnn_input(const uint16_t *depth, int n, float depth_scale, float drange_x, float drange_y, float *out);
 void ho_decode(const float *cnn_output, const ho_camera *hcam, ho_analysis *out);
 int ho_pointcloud(const uint16_t *depth, const ho_camera *cam, float rmin, float rmax, int fraction, f3 *out, int cap, int *n_full);

@@ -22,6 +22,7 @@
 //   frames <animbank.pose> <first> <stride> <n> <out.htfx>    64x64 frames + cameras + start poses
 //   golden <animbank.pose> <rows,comma> <seed> <fc2gain> <out.htfx>   per-stage goldens
 //   scale  <animbank.pose> <rows,comma> <seed> <fc2gain> <s> <out.htfx>   HandTracker::scale(s): scaled model (<out>.model) + unit of work
+//   train  <animbank.pose> <rows,comma> <seed> <fc2gain> <epochs> <out.htfx>   CNN::Train on the frames' inputs and GatherHandExpectedCNN labels
 //   slowfit <animbank.pose> <rows,comma> <out.htfx>   HandTracker::slowfit with several argument sets
 //   segment <animbank.pose> <rows,comma> <out.htfx>   320x240 frames and what HandSegmentVR makes of them
 //   bench  <frames.htfx> <seed> <fc2gain> <reps>   reference CPU time for the unit of work
@@ -437,6 +438,42 @@ static int mode_slowfit(const char *bankfn, const char *rowscsv, const char *out
 	return 0;
 }
 
+// CNN::Train (cnn.h:558-580) with the labels of GatherHandExpectedCNN (handtrack.h:160-173), as train-cnn.cpp:156-162 drives it
+static int mode_train(const char *bankfn, const char *rowscsv, uint64_t seed, double gain, int epochs, const char *outfn)
+{
+	HandTracker htk;
+	load_weights(htk, seed, gain);
+	PhysModel fake = LoadHandModel();
+	auto bank = read_animbank(bankfn, fake.rigidbodies.size());
+	std::vector<int> rows; { std::stringstream ss(rowscsv); std::string t; while (std::getline(ss, t, ',')) rows.push_back(atoi(t.c_str())); }
+	Out o; if (htfx_open(&o.w, outfn)) return 2;
+	o.i32("rows", rows); o.f32("seed_gain_epochs_alpha", { (float)seed, (float)gain, (float)epochs, 0.001f });
+	std::vector<std::vector<float>> inputs, labels;
+	for (size_t fi = 0; fi < rows.size(); fi++)
+	{
+		std::string pre = "f" + std::to_string(fi) + "/";
+		Frame fr = make_frame(fake, bank, rows[fi]);
+		float2 drange = { 0.1f, htk.drangey };
+		auto cnn_input = Transform(fr.seg, [drange, &fr](unsigned short d) { return (float)clamp(1.0f - (d*fr.seg.cam.depth_scale - drange.x) / (drange.y - drange.x), 0.0f, 1.0f); });
+		auto lab = GatherHandExpectedCNN(fr.gt, camsub(fr.seg.cam, 4));
+		o.u16(pre + "depth", fr.seg.raster, { 64, 64 }); o.f32(pre + "cam", camvec(fr.seg.cam)); o.f32(pre + "pose", flat(fr.gt), { 17, 7 });
+		o.f32(pre + "labels", lab.cnn_expected); o.f32(pre + "vals", lab.vals);
+		inputs.push_back(cnn_input.raster); labels.push_back(lab.cnn_expected);
+	}
+	std::vector<float> mse;
+	for (int e = 0; e < epochs; e++) for (size_t fi = 0; fi < rows.size(); fi++) mse.push_back(htk.cnn.Train(inputs[fi], labels[fi], 0.001f));
+	o.f32("mse", mse);
+	o.f32("eval0_after", htk.cnn.Eval(inputs[0]));
+	auto *c1 = (CNN::LConv *)htk.cnn.layers[0]; auto *c2 = (CNN::LConv *)htk.cnn.layers[4]; auto *f1 = (CNN::LFull *)htk.cnn.layers[7]; auto *f2 = (CNN::LFull *)htk.cnn.layers[9];
+	o.f32("W1", c1->W); o.f32("B1", c1->B); o.f32("B2", c2->B); o.f32("B3", f1->B); o.f32("B4", f2->B);
+	o.f32("W2_head", std::vector<float>(c2->W.begin(), c2->W.begin() + 1024));
+	std::vector<float> s3, s4; for (size_t i = 0; i < f1->W.size(); i += 9973) s3.push_back(f1->W[i]); for (size_t i = 0; i < f2->W.size(); i += 9973) s4.push_back(f2->W[i]);
+	o.f32("W3_every9973", s3); o.f32("W4_every9973", s4);
+	htfx_close(&o.w);
+	printf("train: %d frames x %d epochs -> %s (mse first %.6g last %.6g)\n", (int)rows.size(), epochs, outfn, mse.front(), mse.back());
+	return 0;
+}
+
 static int mode_golden(const char *bankfn, const char *rowscsv, uint64_t seed, double gain, const char *outfn)
 {
 	HandTracker htk;
@@ -666,6 +703,7 @@ int main(int argc, char **argv) try
 	if (mode == "scan" && a.size() == 2) return mode_scan(a[0].c_str(), atoi(a[1].c_str()));
 	if (mode == "frames" && a.size() == 5) return mode_frames(a[0].c_str(), atoi(a[1].c_str()), atoi(a[2].c_str()), atoi(a[3].c_str()), a[4].c_str());
 	if (mode == "scale" && a.size() == 6) return mode_scale(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), atof(a[4].c_str()), a[5].c_str());
+	if (mode == "train" && a.size() == 6) return mode_train(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), atoi(a[4].c_str()), a[5].c_str());
 	if (mode == "slowfit" && a.size() == 3) return mode_slowfit(a[0].c_str(), a[1].c_str(), a[2].c_str());
 	if (mode == "segment" && a.size() == 3) return mode_segment(a[0].c_str(), a[1].c_str(), a[2].c_str());
 	if (mode == "golden" && a.size() == 5) return mode_golden(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());

@@ -117,6 +117,8 @@ def lib():
         L.ho_separated_bodies.argtypes = [C.c_void_p, C.c_void_p]; L.ho_separated_bodies.restype = GjkContact
         L.ho_body_ptr.argtypes = [C.c_void_p, C.c_int]; L.ho_body_ptr.restype = C.c_void_p
         L.ho_scale.argtypes = [C.c_void_p, C.c_float]
+        L.ho_cnn_train.argtypes = [fp, fp, fp, C.c_float]; L.ho_cnn_train.restype = C.c_float
+        L.ho_expected_cnn.argtypes = [fp, C.POINTER(Camera), fp, fp]
         L.ho_slowfit.argtypes = [C.c_void_p, C.POINTER(F3), C.c_int, C.c_int, fp, C.c_int, C.c_int, F3, F3, fp, C.c_int]
         L.ho_segment_vr.argtypes = [C.POINTER(C.c_uint16), C.c_int, C.c_int, fp, C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_uint16), fp, C.POINTER(C.c_uint16), C.POINTER(C.c_uint8)]; L.ho_segment_vr.restype = C.c_int
         _lib = L
