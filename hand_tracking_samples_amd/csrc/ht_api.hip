@@ -213,6 +213,91 @@ extern "C" int ht_scale(ht_ctx *ctx, float s)
 	HIPCHK(ctx, hipGetLastError());
 	return HT_OK;
 }
+// CNN::Train (cnn.h:558-580), one SGD step per sample in the order given (train-cnn.cpp:156-162 calls it with alpha = 0.001), on the weights
+// held by the context; ht_cnn_get_weights reads them back in .cnnb order (CNN::saveb cnn.h:591-593).
+extern "C" int ht_cnn_train(ht_ctx *ctx, const float *inputs, const float *targets, int n, float alpha, float *mse_out)
+{
+	if (!ctx) return HT_ERR_ARG;
+	if (!ctx->ready) { ctx->err = "context not initialised (ht_create failed)"; return HT_ERR_STATE; }
+	if (!ctx->have_weights) { ctx->err = "CNN weights not loaded (ht_cnn_load_weights)"; return HT_ERR_STATE; }
+	if (!inputs || !targets || n < 1) return HT_ERR_ARG;
+	const size_t na = ht_train_act_floats(), np = ht_train_part_floats();
+	if (!ctx->d_train) { int r = dev_alloc(ctx, &ctx->d_train, 2 * na + np); if (r) return r; }
+	float *d_x = nullptr, *d_t = nullptr, *d_mse = nullptr;
+	int rc = HT_OK;
+	if (hipMalloc((void **)&d_x, (size_t)n * HT_CNN_IN * sizeof(float)) != hipSuccess || hipMalloc((void **)&d_t, (size_t)n * HT_CNN_OUT * sizeof(float)) != hipSuccess ||
+	    hipMalloc((void **)&d_mse, (size_t)n * sizeof(float)) != hipSuccess) { ctx->err = "ht_cnn_train: out of device memory"; rc = HT_ERR_HIP; }
+	hipStream_t s = ctx->stream;
+	if (rc == HT_OK && (hipMemcpyAsync(d_x, inputs, (size_t)n * HT_CNN_IN * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess ||
+	                    hipMemcpyAsync(d_t, targets, (size_t)n * HT_CNN_OUT * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess)) { ctx->err = "ht_cnn_train: upload failed"; rc = HT_ERR_HIP; }
+	if (rc == HT_OK)
+	{
+		for (int k = 0; k < n; k++)
+			ht_launch_train_step(ctx->d_weights, ctx->d_weights + HT_CNNB_COUNT, d_x + (size_t)k * HT_CNN_IN, d_t + (size_t)k * HT_CNN_OUT, alpha, ctx->d_train, ctx->d_train + na, ctx->d_train + 2 * na, d_mse + k, s);
+		if ((mse_out && hipMemcpyAsync(mse_out, d_mse, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) || hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess)
+		{ ctx->err = "ht_cnn_train: device error"; rc = HT_ERR_HIP; }
+	}
+	(void)hipFree(d_x); (void)hipFree(d_t); (void)hipFree(d_mse);
+	return rc;
+}
+extern "C" int ht_cnn_get_weights(ht_ctx *ctx, float *w, size_t n)
+{
+	if (!ctx || !w) return HT_ERR_ARG;
+	if (!ctx->ready || !ctx->have_weights) { ctx->err = "no weights to read"; return HT_ERR_STATE; }
+	if (n != HT_CNNB_COUNT) { ctx->err = "weights: expected HT_CNNB_COUNT fp32 values in .cnnb order"; return HT_ERR_ARG; }
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	HIPCHK(ctx, hipMemcpy(w, ctx->d_weights, n * sizeof(float), hipMemcpyDeviceToHost));
+	return HT_OK;
+}
+// Label synthesis, host only.  GatherHandExpectedCNN (handtrack.h:160-173): 8 landmark heat-maps (ImageFeaturePoints :92-96, RenderHeatMap /
+// NormalizeHeatMap misc_image.h:246-272) and 16 one-dimensional maps of the key angles (HandPoseToKeyAngleSet handtrack.h:132-151,
+// Render1DHeatMaps misc_image.h:281-295), as bytes scaled by 1/255.  atan2 / asin / acos / exp / pow without std:: are the C double functions there.
+static unsigned char gray_of(float x) { float v = x * 255.0f; v = fmin_std(fmax_std(v, 0.0f), 255.0f); return (unsigned char)v; }
+extern "C" int ht_expected_cnn(const float *pose, const float *cam, float *expected)
+{
+	if (!pose || !cam || !expected) return HT_ERR_ARG;
+	static const int fbone[8] = { 1, 1, 1, 4, 7, 10, 13, 16 };
+	static const float foff[8][3] = { { 0, 0, 0 }, { -0.03f, 0, -0.03f }, { 0.03f, 0, -0.03f }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
+	const float fx = cam[0] / 4.0f, fy = cam[1] / 4.0f, px = cam[2] / 4.0f, py = cam[3] / 4.0f;      // hcam = camsub(cam, 4), 16 x 16
+	const xf campose = XF(V3(cam[5], cam[6], cam[7]), V4(cam[8], cam[9], cam[10], cam[11])), ci = inverse(campose);
+	auto P = [&](int b) { return XF(V3(pose[7 * b], pose[7 * b + 1], pose[7 * b + 2]), V4(pose[7 * b + 3], pose[7 * b + 4], pose[7 * b + 5], pose[7 * b + 6])); };
+	unsigned char img[HT_CNN_OUT];
+	memset(img, 0, sizeof img);
+	for (int k = 0; k < 8; k++)
+	{
+		const v3 v = apply(ci, apply(P(fbone[k]), V3(foff[k][0], foff[k][1], foff[k][2])));
+		const float ux = v.x / v.z * fx + px, uy = v.y / v.z * fy + py;
+		unsigned char *h = img + 256 * k;
+		const int hx = (int)ux, hy = (int)uy;
+		for (int y = (hy - 2 > 0 ? hy - 2 : 0); y < (hy + 3 < 16 ? hy + 3 : 16); y++) for (int x = (hx - 2 > 0 ? hx - 2 : 0); x < (hx + 3 < 16 ? hx + 3 : 16); x++)
+		{
+			const float dx = ux - (float)x, dy = uy - (float)y;
+			h[y * 16 + x] = gray_of(expf(-(dx * dx + dy * dy) / (2.0f * 0.33f)));
+		}
+		int sum = 0; for (int i = 0; i < 256; i++) sum += h[i];
+		if (sum) for (int i = 0; i < 256; i++) h[i] = (unsigned char)(h[i] * 255 / sum);
+	}
+	float vals[16]; int nv = 0;
+	const v4 q1 = P(1).q, palmq = qmul(ci.q, q1);
+	vals[nv++] = (float)(atan2((double)qxdir(palmq).x, (double)-qxdir(palmq).z) / (double)(3.14159f * 2.0f) + (double)0.5f);
+	vals[nv++] = (float)(asin((double)clamp_std(qzdir(palmq).z, -1.0f, 1.0f)) / (double)3.14159f + (double)0.5f);
+	vals[nv++] = (float)(asin((double)clamp_std(qzdir(palmq).x, -1.0f, 1.0f)) / (double)3.14159f + (double)0.5f);
+	vals[nv++] = (float)(acos((double)dot(qxdir(q1), qzdir(P(4).q))) / (double)3.14159f);
+	for (int b : { 6, 9, 12, 15 }) vals[nv++] = (float)(acos((double)clamp_std(dot(qydir(q1), qydir(P(b).q)), -1.0f, 1.0f)) / (double)3.14159f);
+	{ const v3 pz = qzdir(palmq); vals[nv++] = (float)((double)0.5f + atan2((double)-pz.x, (double)-pz.y) / (double)(3.14159f * 2.0f)); }
+	while (nv < 16) vals[nv++] = 0.0f;
+	unsigned char *vm = img + 2048;
+	for (int y = 0; y < 16; y++)
+	{
+		const float v = vals[y] * (float)(16 - 1);
+		const int x0 = ((int)v - 2 > 0 ? (int)v - 2 : 0), x1 = ((int)v + 3 < 16 ? (int)v + 3 : 16);
+		int sum = 0;
+		for (int x = x0; x < x1; x++) { const float d2 = (float)pow((double)((float)x - v), (double)2.0f); sum += vm[y * 16 + x] = gray_of((float)exp((double)(-d2 / (2.0f * 0.5f)))); }
+		for (int x = x0; sum && x < x1; x++) vm[y * 16 + x] = (unsigned char)(vm[y * 16 + x] * 255 / sum);
+	}
+	for (int i = 0; i < HT_CNN_OUT; i++) expected[i] = img[i] / 255.0f;
+	return HT_OK;
+}
 extern "C" int ht_destroy(ht_ctx *ctx)
 {
 	if (!ctx) return HT_ERR_ARG;

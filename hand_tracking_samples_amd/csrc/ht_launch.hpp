@@ -37,3 +37,7 @@ void ht_launch_output(const ht_model_dev &M, const float *hand, const int *npts,
 bool ht_segment_supported(int w, int h);
 void ht_launch_segment(const uint16_t *depth, const float *cams, int w, int h, int entry_options, float wrange_hi, float diam, uint16_t *tiles, float *cams_out, int B, hipStream_t s);
 void ht_launch_scale_state(float *state, int nb, int n, float s, hipStream_t st);      // ht_track.hip
+// ht_train.hip
+void ht_launch_train_step(float *w, float *W2p, const float *x, const float *target, float alpha, float *act, float *err, float *part, float *mse_out, hipStream_t s);
+size_t ht_train_act_floats();
+size_t ht_train_part_floats();

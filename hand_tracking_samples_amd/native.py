@@ -18,7 +18,7 @@ MAXPTS, ROW, CONTACT = 1024, 16, 12
 # every symbol include/ht_mi355x.h declares (checked by tests/test_abi.py)
 SYMBOLS = (
     "ht_create", "ht_destroy", "ht_model_bake", "ht_last_error", "ht_get_params", "ht_set_params", "ht_model_info", "ht_config_read", "ht_scale",
-    "ht_cnn_load_weights", "ht_cnn_eval", "ht_cnn_eval_dev",
+    "ht_cnn_load_weights", "ht_cnn_eval", "ht_cnn_eval_dev", "ht_cnn_train", "ht_cnn_get_weights", "ht_expected_cnn",
     "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_segment_vr", "ht_segment_vr_dev", "ht_slowfit", "ht_set_points",
     "ht_stage_prepare", "ht_stage_decode", "ht_stage_fit_error", "ht_stage_cloud_rows", "ht_stage_contacts", "ht_stage_fit",
     "ht_stage_multistep", "ht_stage_scratch_unibody", "ht_profile_enable", "ht_profile_read", "ht_debug_solve_stats", "ht_debug_contact_stats",
@@ -81,6 +81,9 @@ def load(build_if_missing=True):
     L.ht_stage_scratch_unibody.argtypes = [vp, fp, C.c_int, C.c_int]
     L.ht_profile_enable.argtypes = [vp, C.c_int]
     L.ht_scale.argtypes = [vp, C.c_float]
+    L.ht_cnn_train.argtypes = [vp, fp, fp, C.c_int, C.c_float, fp]
+    L.ht_cnn_get_weights.argtypes = [vp, fp, C.c_size_t]
+    L.ht_expected_cnn.argtypes = [fp, fp, fp]
     L.ht_slowfit.argtypes = [vp, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp, fp, fp, C.c_int]
     L.ht_segment_vr.argtypes = [vp, C.POINTER(C.c_uint16), fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_uint16), fp]
     L.ht_segment_vr_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp, vp, vp]
@@ -298,3 +301,24 @@ class Context:
         cr = None if crays is None else _c(crays, np.float32)
         self._chk(self.L.ht_slowfit(self.h, int(B), int(hold), None if ref is None else _f(ref), int(steps), int(select_rb), None if sp is None else _f(sp), None if rp is None else _f(rp),
                                     None if cr is None else _f(cr), 0 if cr is None else int(cr.reshape(-1, 8, 4).shape[1])))
+
+    def cnn_train(self, inputs, targets, alpha=0.001):
+        """CNN::Train (cnn.h:558-580) sample after sample; returns the per-sample mean squared errors."""
+        x = _c(inputs, np.float32).reshape(-1, CNN_IN); t = _c(targets, np.float32).reshape(-1, CNN_OUT)
+        mse = np.zeros(x.shape[0], np.float32)
+        self._chk(self.L.ht_cnn_train(self.h, _f(x), _f(t), x.shape[0], float(alpha), _f(mse)))
+        return mse
+
+    def cnn_get_weights(self):
+        w = np.empty(9458400, np.float32)
+        self._chk(self.L.ht_cnn_get_weights(self.h, _f(w), w.size))
+        return w
+
+
+def expected_cnn(pose, cam):
+    """GatherHandExpectedCNN(pose, camsub(cam, 4)).cnn_expected (handtrack.h:160-173), host only."""
+    out = np.empty(CNN_OUT, np.float32)
+    r = load().ht_expected_cnn(_f(_c(pose, np.float32)), _f(_c(cam, np.float32)), _f(out))
+    if r != 0:
+        raise HTError("ht_expected_cnn failed with status %d" % r)
+    return out

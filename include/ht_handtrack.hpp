@@ -50,7 +50,7 @@ template <class T> struct Image                                                 
 namespace detail { inline ht_ctx *&live_ctx() { static ht_ctx *c = nullptr; return c; } }      // a context the free functions below can run on
 inline void check(ht_ctx *ctx, int rc) { if (rc != HT_OK) throw std::runtime_error(std::string("ht_mi355x: ") + (ctx ? ht_last_error(ctx) : "no context")); }
 
-class CNN                                                                                    // third_party/cnn.h:100-605 (forward surface)
+class CNN                                                                                    // third_party/cnn.h:100-605 (Eval / Train / loadb / saveb)
 {
 	ht_ctx *ctx_ = nullptr;
 	friend struct HandTracker;
@@ -69,6 +69,21 @@ public:
 		if ((size_t)s.gcount() != w.size() * sizeof(float)) throw std::runtime_error("CNN::loadb: short .cnnb stream");
 		check(ctx_, ht_cnn_load_weights(ctx_, w.data(), w.size()));
 	}
+	// one SGD step; returns the mean squared error of the forward pass, as cnn.h:558 does
+	float Train(const std::vector<float> &x, const std::vector<float> &expected, float alpha = 0.01f)
+	{
+		if (x.size() != HT_CNN_IN || expected.size() != HT_CNN_OUT) throw std::runtime_error("CNN::Train expects 64*64 inputs and 2304 labels");
+		float mse = 0;
+		check(ctx_, ht_cnn_train(ctx_, x.data(), expected.data(), 1, alpha, &mse));
+		return mse;
+	}
+	void saveb(std::ostream &s)                                                              // cnn.h:591
+	{
+		std::vector<float> w(HT_CNNB_COUNT);
+		check(ctx_, ht_cnn_get_weights(ctx_, w.data(), w.size()));
+		s.write((const char *)w.data(), (std::streamsize)(w.size() * sizeof(float)));
+	}
+	void saveb(std::string fname) { std::ofstream os(fname, std::ios_base::binary | std::ios_base::out); if (!os.is_open()) throw std::runtime_error("cannot open " + fname); saveb(os); }   // cnn.h:593
 	void loadb(std::string fname) { std::ifstream is(fname, std::ios_base::binary | std::ios_base::in); if (!is.is_open()) throw std::runtime_error("cannot open " + fname); loadb(is); }   // cnn.h:592
 };
 

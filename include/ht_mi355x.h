@@ -119,6 +119,17 @@ int ht_set_tracker_flags(ht_ctx *ctx, int first, int n, const float *prev_frame_
 int ht_update_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int B, float *poses_out, float *cnn_out);
 int ht_update_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, const float *d_start_poses, int B, float *d_poses_out, void *stream);
 
+/* ---- training ----------------------------------------------------------------------------------------------------------
+ * ht_cnn_train        replaces  float CNN::Train(const std::vector<float> &x, const std::vector<float> &t, float alpha) (cnn.h:558-580) called for
+ *                     n samples in sequence (batch-1 SGD as train-cnn.cpp:156-162 does with alpha = 0.001): inputs [n][4096], targets
+ *                     [n][2304], mse_out [n] (optional) = the value Train returns for each sample.  The context's weights are updated in place.
+ * ht_cnn_get_weights  replaces  CNN::saveb (cnn.h:591-593): the weights in .cnnb order.
+ * ht_expected_cnn     replaces  GatherHandExpectedCNN(pose, hcam).cnn_expected (handtrack.h:160-173), host only: pose [17][7] and the TILE
+ *                     camera [12] (the heat-map camera camsub(cam, 4) is formed inside) -> expected [2304]. */
+int ht_cnn_train(ht_ctx *ctx, const float *inputs, const float *targets, int n, float alpha, float *mse_out);
+int ht_cnn_get_weights(ht_ctx *ctx, float *w, size_t n);
+int ht_expected_cnn(const float *pose, const float *cam, float *expected);
+
 /* ---- segmentation: the step before the tracker for full-size frames --------------------------------------------------
  * ht_segment_vr       replaces  Image<unsigned short> HandSegmentVR(const Image<unsigned short> &depth, int entry_options = 0xF,
  *                     float2 wrange = {0.1f, 0.65f}, float diam = 0.17f) (handtrack.h:280-344) for B frames of w x h pixels:

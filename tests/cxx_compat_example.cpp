@@ -1,5 +1,6 @@
 // Compile-and-link check of the C++ compatibility header (and, on a GPU box, a one-frame run).
 #include <cstdio>
+#include <sstream>
 #include "../include/ht_handtrack.hpp"
 using namespace ht_mi355x;
 int main(int argc, char **argv)
@@ -12,7 +13,9 @@ int main(int argc, char **argv)
 		Image<unsigned short> dimage(DCamera({ 64, 64 }, { 164.f, 164.f }, { 32.f, 32.f }, 0.001f));
 		for (auto &d : dimage.raster) d = 4000;
 		std::vector<float> x(HT_CNN_IN, 0.5f);
-		if (argc > 2) { auto y = htk.cnn.Eval(x); printf("cnn out[0]=%g\n", y[0]); auto pose = htk.update(std::move(dimage)); printf("bones=%zu\n", pose.size()); }
+		if (argc > 2) { auto y = htk.cnn.Eval(x); printf("cnn out[0]=%g\n", y[0]); auto pose = htk.update(std::move(dimage)); printf("bones=%zu\n", pose.size());
+			std::vector<float> t(HT_CNN_OUT, 0.0f); for (int m = 0; m < 24; m++) t[(m < 8 ? 256 * m : 2048 + 16 * (m - 8)) + 3] = 1.0f;
+			float mse = htk.cnn.Train(x, t, 0.001f); std::ostringstream os; htk.cnn.saveb(os); printf("train mse=%g saved=%zu\n", mse, os.str().size()); }
 	}
 	catch (const std::exception &e) { printf("error: %s\n", e.what()); return 1; }
 	return 0;
