@@ -221,8 +221,8 @@ extern "C" int ht_cnn_train(ht_ctx *ctx, const float *inputs, const float *targe
 	if (!ctx->ready) { ctx->err = "context not initialised (ht_create failed)"; return HT_ERR_STATE; }
 	if (!ctx->have_weights) { ctx->err = "CNN weights not loaded (ht_cnn_load_weights)"; return HT_ERR_STATE; }
 	if (!inputs || !targets || n < 1) return HT_ERR_ARG;
-	const size_t na = ht_train_act_floats(), np = ht_train_part_floats();
-	if (!ctx->d_train) { int r = dev_alloc(ctx, &ctx->d_train, 2 * na + np); if (r) return r; }
+	const size_t na = ht_train_act_floats(), ne = ht_train_err_floats(), np = ht_train_part_floats();
+	if (!ctx->d_train) { int r = dev_alloc(ctx, &ctx->d_train, na + ne + np); if (r) return r; }
 	float *d_x = nullptr, *d_t = nullptr, *d_mse = nullptr;
 	int rc = HT_OK;
 	if (hipMalloc((void **)&d_x, (size_t)n * HT_CNN_IN * sizeof(float)) != hipSuccess || hipMalloc((void **)&d_t, (size_t)n * HT_CNN_OUT * sizeof(float)) != hipSuccess ||
@@ -233,7 +233,7 @@ extern "C" int ht_cnn_train(ht_ctx *ctx, const float *inputs, const float *targe
 	if (rc == HT_OK)
 	{
 		for (int k = 0; k < n; k++)
-			ht_launch_train_step(ctx->d_weights, ctx->d_weights + HT_CNNB_COUNT, d_x + (size_t)k * HT_CNN_IN, d_t + (size_t)k * HT_CNN_OUT, alpha, ctx->d_train, ctx->d_train + na, ctx->d_train + 2 * na, d_mse + k, s);
+			ht_launch_train_step(ctx->d_weights, ctx->d_weights + HT_CNNB_COUNT, d_x + (size_t)k * HT_CNN_IN, d_t + (size_t)k * HT_CNN_OUT, alpha, ctx->d_train, ctx->d_train + na, ctx->d_train + na + ne, d_mse + k, s);
 		if ((mse_out && hipMemcpyAsync(mse_out, d_mse, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) || hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess)
 		{ ctx->err = "ht_cnn_train: device error"; rc = HT_ERR_HIP; }
 	}

@@ -40,4 +40,5 @@ void ht_launch_scale_state(float *state, int nb, int n, float s, hipStream_t st)
 // ht_train.hip
 void ht_launch_train_step(float *w, float *W2p, const float *x, const float *target, float alpha, float *act, float *err, float *part, float *mse_out, hipStream_t s);
 size_t ht_train_act_floats();
+size_t ht_train_err_floats();
 size_t ht_train_part_floats();

@@ -461,7 +461,10 @@ static int mode_train(const char *bankfn, const char *rowscsv, uint64_t seed, do
 		inputs.push_back(cnn_input.raster); labels.push_back(lab.cnn_expected);
 	}
 	std::vector<float> mse;
+	auto t0 = std::chrono::steady_clock::now();
 	for (int e = 0; e < epochs; e++) for (size_t fi = 0; fi < rows.size(); fi++) mse.push_back(htk.cnn.Train(inputs[fi], labels[fi], 0.001f));
+	const double train_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	printf("train: %.2f ms per CNN::Train call (1 thread)\n", train_ms / (double)mse.size());
 	o.f32("mse", mse);
 	o.f32("eval0_after", htk.cnn.Eval(inputs[0]));
 	auto *c1 = (CNN::LConv *)htk.cnn.layers[0]; auto *c2 = (CNN::LConv *)htk.cnn.layers[4]; auto *f1 = (CNN::LFull *)htk.cnn.layers[7]; auto *f2 = (CNN::LFull *)htk.cnn.layers[9];
