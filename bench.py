@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--frames-per-gpu", type=int, default=1024)
     ap.add_argument("--workload", default="cnn+solver", choices=["cnn+solver", "cnn"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the pose gather even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -111,7 +112,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist      # --force-dist: rehearse the RCCL code path with a single rank on a 1-GPU box
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
     B = args.frames_per_gpu
@@ -131,7 +136,7 @@ def main():
     d_poses = torch.empty((B, ctx.nb, 7), dtype=torch.float32, device=dev)
     d_cnn_in = torch.empty((B, 4096), dtype=torch.float32, device=dev)
     d_cnn_out = torch.empty((B, 2304), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world * B, ctx.nb, 7), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * B, ctx.nb, 7), dtype=torch.float32, device=dev) if use_dist else None
     stream = torch.cuda.current_stream(dev)
 
     if args.workload == "cnn":
@@ -143,7 +148,7 @@ def main():
             ctx.cnn_eval_dev(d_cnn_in.data_ptr(), d_cnn_out.data_ptr(), B, stream.cuda_stream)
         else:
             ctx.update_dev(d_depth.data_ptr(), d_cams.data_ptr(), d_start.data_ptr(), B, d_poses.data_ptr(), stream.cuda_stream)
-            if world > 1:
+            if use_dist:
                 gather_poses(d_poses, world, out=gathered)
 
     for _ in range(args.warmup):
@@ -151,18 +156,18 @@ def main():
     torch.cuda.synchronize()
     ctx.profile_enable(1)          # HIP events around the dominant kernel only (on its launch stream), inside the timed region
     ctx.profile_read(reset=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -234,7 +239,7 @@ def main():
             out["speedup_vs_cpu_1thread"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
