@@ -564,9 +564,23 @@ int ho_update_cnn_model(ho_tracker *t, const uint16_t *depth, const ho_camera *c
 {
 	const ho_params *P = &t->par;
 	float drx = 0.1f, dry = P->drangey;
-	ho_camera hcam = *cam;   /* camsub(cam,4) misc_image.h:60 */
-	hcam.w = cam->w / 4; hcam.h = cam->h / 4; hcam.focal.x = cam->focal.x / 4.0f; hcam.focal.y = cam->focal.y / 4.0f; hcam.principal.x = cam->principal.x / 4.0f; hcam.principal.y = cam->principal.y / 4.0f;
-	ho_cnn_input(depth, cam->w * cam->h, cam->depth_scale, drx, dry, t->cnn_input);
+	/* handtrack.h:697-698: segment = HandSegmentVR(dimage, 0xF, drange, segment_scale); a 64x64 image is its own segment (:283-284).
+	 * The CNN sees the segment; points and FitError keep using the full image; segment.cam.pose goes to the pose-driven stages. */
+	uint16_t tile[64 * 64];
+	ho_camera scam = *cam;
+	const uint16_t *seg = depth;
+	if (cam->w != 64 || cam->h != 64)
+	{
+		const float c12[12] = { cam->focal.x, cam->focal.y, cam->principal.x, cam->principal.y, cam->depth_scale, cam->pose.position.x, cam->pose.position.y, cam->pose.position.z,
+		                        cam->pose.orientation.x, cam->pose.orientation.y, cam->pose.orientation.z, cam->pose.orientation.w };
+		float o12[12];
+		ho_segment_vr(depth, cam->w, cam->h, c12, 0xF, drx, dry, P->segment_scale, tile, o12, NULL, NULL);
+		ho_camera_from12(o12, 64, 64, &scam);
+		seg = tile;
+	}
+	ho_camera hcam = scam;   /* camsub(cam,4) misc_image.h:60 */
+	hcam.w = scam.w / 4; hcam.h = scam.h / 4; hcam.focal.x = scam.focal.x / 4.0f; hcam.focal.y = scam.focal.y / 4.0f; hcam.principal.x = scam.principal.x / 4.0f; hcam.principal.y = scam.principal.y / 4.0f;
+	ho_cnn_input(seg, 64 * 64, scam.depth_scale, drx, dry, t->cnn_input);
 	ho_cnn_eval(t->weights, t->cnn_input, t->cnn_output, NULL);
 	ho_decode(t->cnn_output, &hcam, &t->analysis);
 	f3 *vpts = malloc(sizeof(f3) * cam->w * cam->h);
@@ -574,10 +588,10 @@ int ho_update_cnn_model(ho_tracker *t, const uint16_t *depth, const ho_camera *c
 	float olderror = ho_fit_error(t, &t->handmodel, vpts, n, depth, cam);
 	if (P->angles_only || olderror > P->full_reset_on_error)
 	{
-		ho_pose_from_scratch(t, &t->othermodel, vpts, n, &t->analysis, cam->pose);
-		for (int i = 0; i < P->steps_unibody; i++) ho_unibody_fit(t, &t->othermodel, vpts, n, cam->pose.position);
+		ho_pose_from_scratch(t, &t->othermodel, vpts, n, &t->analysis, scam.pose);
+		for (int i = 0; i < P->steps_unibody; i++) ho_unibody_fit(t, &t->othermodel, vpts, n, scam.pose.position);
 	}
-	ho_multistep(t, &t->othermodel, &t->analysis, vpts, n, cam->pose);
+	ho_multistep(t, &t->othermodel, &t->analysis, vpts, n, scam.pose);
 	float newerror = ho_fit_error(t, &t->othermodel, vpts, n, depth, cam);
 	if (newerror > olderror) t->prev_frame_error = 0.0f; else t->prev_frame_error += olderror - newerror;
 	int np = 0;
@@ -596,6 +610,12 @@ int ho_update_cnn_model(ho_tracker *t, const uint16_t *depth, const ho_camera *c
 	t->last_accept = np;
 	free(vpts);
 	return np;
+}
+void ho_get_flags(const ho_tracker *t, float *prev_frame_error, int *initializing, int *last_npoints)
+{
+	if (prev_frame_error) *prev_frame_error = t->prev_frame_error;
+	if (initializing) *initializing = t->initializing;
+	if (last_npoints) *last_npoints = t->last_npoints;
 }
 /* HandTracker::update handtrack.h:748-785 with the background job run synchronously every frame */
 void ho_update(ho_tracker *t, const uint16_t *depth, const ho_camera *cam, float *pose_user_out7)

@@ -93,6 +93,7 @@ ho_tracker *ho_create(const char *model_htfx_path);
 void ho_destroy(ho_tracker *t);
 int ho_load_weights(ho_tracker *t, const float *w, size_t n);          /* .cnnb order, cnn.h:590 */
 void ho_default_params(ho_params *p);
+void ho_get_flags(const ho_tracker *t, float *prev_frame_error, int *initializing, int *last_npoints);
 void ho_set_state(ho_tracker *t, int which, const float *state13);      /* which: 0 handmodel 1 othermodel; [nb][13] pos quat linmom angmom */
 void ho_get_state(ho_tracker *t, int which, float *state13);
 void ho_set_pose(ho_tracker *t, int which, const float *pose7);         /* PhysModel::SetPose: momenta untouched */

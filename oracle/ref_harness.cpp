@@ -51,7 +51,13 @@ static void stage_assets()
 	std::string root(d);
 	mkdir((root + "/assets").c_str(), 0700);
 	mkdir((root + "/run").c_str(), 0700);
-	{ std::ofstream o(root + "/assets/model_hand.json", std::ios::binary); o.write(ht_asset_model, ht_asset_model_end - ht_asset_model); }
+	if (const char *alt = getenv("HT_REF_MODEL_JSON"))      // another hand model in the reference's schema (tests/golden/make_model_hand26.py); LoadHandModel reads ../assets/model_hand.json
+	{
+		std::ifstream in(alt, std::ios::binary);
+		if (!in.is_open()) { fprintf(stderr, "cannot open %s\n", alt); exit(2); }
+		std::ofstream o(root + "/assets/model_hand.json", std::ios::binary); o << in.rdbuf();
+	}
+	else { std::ofstream o(root + "/assets/model_hand.json", std::ios::binary); o.write(ht_asset_model, ht_asset_model_end - ht_asset_model); }
 	{ std::ofstream o(root + "/assets/vanity_bones.json", std::ios::binary); o.write(ht_asset_vanity, ht_asset_vanity_end - ht_asset_vanity); }
 	if (chdir((root + "/run").c_str())) { perror("chdir"); exit(2); }
 }
@@ -202,6 +208,105 @@ static std::vector<Pose> unit_of_work(HandTracker &htk, const Image<unsigned sho
 	}
 	if (points.size() < htk.min_point_num) htk.initializing = 50;
 	return htk.handmodel.GetPoseUser();
+}
+
+// poses of the 26-bone hand of tests/golden/make_model_hand26.py from 17-bone poses: clone bone = source bone shifted by R(palm)*(0, 0.03, 0)
+static void extend_bank(std::vector<std::vector<Pose>> &bank, size_t nb)
+{
+	static const int src[9] = { 5, 6, 7, 8, 9, 10, 11, 12, 13 };
+	if (nb != 26) return;
+	for (auto &row : bank)
+	{
+		const float3 off = qrot(row[1].orientation, float3(0, 0.03f, 0));
+		for (int i = 0; i < 9; i++) row.push_back(Pose(row[src[i]].position + off, row[src[i]].orientation));
+	}
+}
+// BASELINE configs[4]: 128x128 frames of whatever hand model is staged (the 26-bone one), through the application's own sequence
+// (synthetic-tracker.cpp:204-215: HandSegmentVR, poses re-based into the segment camera, then the tracker on the 64x64 tile)
+static int mode_config5(const char *bankfn, const char *rowscsv, uint64_t seed, double gain, const char *outfn)
+{
+	HandTracker htk;
+	htk.microforce = 3.0f; htk.mainthreadpasses = 3; htk.always_take_cnn = 0;
+	load_weights(htk, seed, gain);
+	PhysModel fake = LoadHandModel();
+	const size_t nb = fake.rigidbodies.size();
+	auto bank = read_animbank(bankfn, 17);
+	extend_bank(bank, nb);
+	std::vector<int> rows; { std::stringstream ss(rowscsv); std::string t; while (std::getline(ss, t, ',')) rows.push_back(atoi(t.c_str())); }
+	Out o; if (htfx_open(&o.w, outfn)) return 2;
+	o.i32("rows", rows); o.f32("weights_seed_gain", { (float)seed, (float)gain });
+	DCamera dcam({ 128,128 }, { 163,163 }, { 64,64 }, 0.001f);
+	for (size_t fi = 0; fi < rows.size(); fi++)
+	{
+		std::string pre = "f" + std::to_string(fi) + "/";
+		const size_t k = (size_t)rows[fi];
+		fake.SetPose(bank[k % bank.size()]);
+		auto depth = raycast_depth(fake, dcam);
+		auto seg = HandSegmentVR(depth, 0xF, { 0.1f, htk.drangey }, htk.segment_scale);      // arguments of handtrack.h:697-698
+		std::vector<Pose> gt = bank[k % bank.size()], start = bank[(k + 1) % bank.size()];
+		o.u16(pre + "depth128", depth.raster, { 128,128 }); o.f32(pre + "cam128", camvec(depth.cam));
+		o.u16(pre + "tile", seg.raster, { 64,64 }); o.f32(pre + "segcam", camvec(seg.cam));
+		o.f32(pre + "startpose_cam", flat(start), { (uint32_t)nb,7 });
+		Pose inv = seg.cam.pose.inverse();
+		for (auto &p : gt) p = inv * p;
+		for (auto &p : start) p = inv * p;
+		seg.cam.pose = Pose();
+		o.f32(pre + "cam", camvec(seg.cam)); o.f32(pre + "startpose", flat(start), { (uint32_t)nb,7 }); o.f32(pre + "gtpose", flat(gt), { (uint32_t)nb,7 });
+		reset_tracker(htk, start);
+		auto points = takesubsample(PointCloud(seg, { 0.1f,htk.drangey }), htk.subsample_fraction, htk.subsample_voxel, htk.subsample_size);
+		auto pose = unit_of_work(htk, seg, &o, pre);
+		o.f32(pre + "cnn_output", htk.cnn_output);
+		o.f32(pre + "uw_pose_user", flat(pose), { (uint32_t)nb,7 });
+		o.state(pre + "uw_other_final", htk.othermodel);
+		// contact load of the final pose (what the extra fingers add)
+		{
+			std::vector<PhysContact> C; FindShapeShapeContacts(C, Addresses(htk.handmodel.rigidbodies));     // physics.h:451-462
+			o.i32(pre + "ncontacts_final", { (int)C.size(), (int)points.size() });
+		}
+		printf("config5 frame %d row %d P=%d\n", (int)fi, rows[fi], (int)points.size()); fflush(stdout);
+	}
+	htfx_close(&o.w);
+	return 0;
+}
+
+// HandTracker::update on frames that are not 64x64 (handtrack.h:693-785): the tracker segments the frame for the CNN itself and fits the
+// full-resolution cloud.  Camera `camspec` = "w,h,focal"; the staged hand model may be the 17- or the 26-bone one.
+static int mode_fullframe(const char *bankfn, const char *rowscsv, const char *camspec, uint64_t seed, double gain, const char *outfn)
+{
+	HandTracker htk;
+	htk.microforce = 3.0f; htk.mainthreadpasses = 3; htk.always_take_cnn = 0;
+	load_weights(htk, seed, gain);
+	PhysModel fake = LoadHandModel();
+	const size_t nb = fake.rigidbodies.size();
+	auto bank = read_animbank(bankfn, 17);
+	extend_bank(bank, nb);
+	std::vector<int> rows; { std::stringstream ss(rowscsv); std::string t; while (std::getline(ss, t, ',')) rows.push_back(atoi(t.c_str())); }
+	int w = 128, h = 128; float focal = 163; sscanf(camspec, "%d,%d,%f", &w, &h, &focal);
+	DCamera dcam({ w,h }, { focal,focal }, { w * 0.5f, h * 0.5f }, 0.001f);
+	Out o; if (htfx_open(&o.w, outfn)) return 2;
+	o.i32("rows", rows); o.f32("weights_seed_gain", { (float)seed, (float)gain }); o.i32("dims", { w, h });
+	for (size_t fi = 0; fi < rows.size(); fi++)
+	{
+		std::string pre = "f" + std::to_string(fi) + "/";
+		const size_t k = (size_t)rows[fi];
+		fake.SetPose(bank[k % bank.size()]);
+		auto depth = raycast_depth(fake, dcam);
+		const std::vector<Pose> &start = bank[(k + 1) % bank.size()];
+		o.u16(pre + "depth", depth.raster, { (uint32_t)h,(uint32_t)w }); o.f32(pre + "cam", camvec(depth.cam));
+		o.f32(pre + "startpose", flat(start), { (uint32_t)nb,7 }); o.f32(pre + "gtpose", flat(bank[k % bank.size()]), { (uint32_t)nb,7 });
+		reset_tracker(htk, start);
+		auto points = takesubsample(PointCloud(depth, { 0.1f,htk.drangey }), htk.subsample_fraction, htk.subsample_voxel, htk.subsample_size);
+		auto pose = unit_of_work(htk, depth, &o, pre);
+		o.f32(pre + "cnn_input", htk.cnn_input.raster); o.f32(pre + "cnn_output", htk.cnn_output);
+		o.f32(pre + "uw_pose_user", flat(pose), { (uint32_t)nb,7 });
+		o.f32(pre + "uw_final", { htk.prev_frame_error, (float)htk.initializing, (float)points.size() });
+		// the same frame again with the carried state (streaming use)
+		auto pose2 = unit_of_work(htk, depth);
+		o.f32(pre + "uw2_pose_user", flat(pose2), { (uint32_t)nb,7 }); o.state(pre + "uw2_hand", htk.handmodel);
+		printf("fullframe %dx%d frame %d row %d P=%d accepted %d\n", w, h, (int)fi, rows[fi], (int)points.size(), 0); fflush(stdout);
+	}
+	htfx_close(&o.w);
+	return 0;
 }
 
 // ---- modes ---------------------------------------------------------------------------------------
@@ -709,6 +814,8 @@ int main(int argc, char **argv) try
 	if (mode == "train" && a.size() == 6) return mode_train(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), atoi(a[4].c_str()), a[5].c_str());
 	if (mode == "slowfit" && a.size() == 3) return mode_slowfit(a[0].c_str(), a[1].c_str(), a[2].c_str());
 	if (mode == "segment" && a.size() == 3) return mode_segment(a[0].c_str(), a[1].c_str(), a[2].c_str());
+	if (mode == "fullframe" && a.size() == 6) return mode_fullframe(a[0].c_str(), a[1].c_str(), a[2].c_str(), strtoull(a[3].c_str(), 0, 0), atof(a[4].c_str()), a[5].c_str());
+	if (mode == "config5" && a.size() == 5) return mode_config5(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());
 	if (mode == "golden" && a.size() == 5) return mode_golden(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());
 	if (mode == "bench" && a.size() >= 4) return mode_bench(a[0].c_str(), strtoull(a[1].c_str(), 0, 0), atof(a[2].c_str()), atoi(a[3].c_str()), a.size() > 4 ? atoi(a[4].c_str()) : 0);
 	fprintf(stderr, "bad arguments\n");

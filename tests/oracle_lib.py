@@ -92,6 +92,7 @@ def lib():
         L.ho_load_weights.argtypes = [C.c_void_p, fp, C.c_size_t]; L.ho_load_weights.restype = C.c_int
         L.ho_set_state.argtypes = [C.c_void_p, C.c_int, fp]; L.ho_get_state.argtypes = [C.c_void_p, C.c_int, fp]
         L.ho_set_pose.argtypes = [C.c_void_p, C.c_int, fp]; L.ho_reset_tracker.argtypes = [C.c_void_p, fp]
+        L.ho_get_flags.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]; L.ho_get_flags.restype = None
         L.ho_cnn_eval.argtypes = [fp, fp, fp, C.POINTER(fp)]
         L.ho_cnn_input.argtypes = [C.POINTER(C.c_uint16), C.c_int, C.c_float, C.c_float, C.c_float, fp]
         L.ho_decode.argtypes = [fp, C.POINTER(Camera), C.POINTER(Analysis)]
@@ -171,9 +172,12 @@ def angulars_to_array(rows, n):
 class Oracle:
     """Thin object wrapper over ho_tracker."""
 
-    def __init__(self, weights=None):
+    def __init__(self, weights=None, model=None):
         self.L = lib()
-        self.h = self.L.ho_create(MODEL.encode())
+        model = model or MODEL
+        import htfx
+        self.nb = len(htfx.load(model)["nverts"])
+        self.h = self.L.ho_create(model.encode())
         assert self.h, "ho_create failed"
         self.head = TrackerHead.from_address(self.h)
         if weights is not None:
@@ -191,9 +195,15 @@ class Oracle:
         self.L.ho_set_state(self.h, which, fptr(np.ascontiguousarray(s, dtype=np.float32)))
 
     def get_state(self, which):
-        s = np.zeros((17, 13), dtype=np.float32)
+        s = np.zeros((self.nb, 13), dtype=np.float32)
         self.L.ho_get_state(self.h, which, fptr(s))
         return s
+
+    def flags(self):
+        """(prev_frame_error, initializing, points of the last update)"""
+        e, i, n = C.c_float(), C.c_int(), C.c_int()
+        self.L.ho_get_flags(self.h, C.byref(e), C.byref(i), C.byref(n))
+        return e.value, i.value, n.value
 
     def reset(self, pose7):
         self.L.ho_reset_tracker(self.h, fptr(np.ascontiguousarray(pose7, dtype=np.float32)))

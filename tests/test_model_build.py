@@ -54,6 +54,20 @@ def test_hand_model_matches_reference_build(tmp_path):
     assert_same_model(htfx.load(str(out)), htfx.load(os.path.join(GOLD, "model_hand17.htfx")))
 
 
+@pytest.mark.skipif(not os.path.exists(REF_HAND_JSON), reason="reference asset only exists in the build container")
+def test_hand26_model_matches_reference_build(tmp_path):
+    """BASELINE configs[4] model (tests/golden/make_model_hand26.py): 26 bones, built by our builder and by the reference's constructor."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_model_hand26", os.path.join(GOLD, "make_model_hand26.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    js, out = tmp_path / "hand26.json", tmp_path / "hand26.htfx"
+    mod.main(REF_HAND_JSON, str(js))
+    native.model_bake(str(js), out, hand_tweaks=True)
+    built, expected = htfx.load(str(out)), htfx.load(os.path.join(GOLD, "model_hand26.htfx"))
+    assert_same_model(built, expected)
+    assert len(built["nverts"]) == 26
+
+
 @pytest.mark.parametrize("text", [
     "",                                                                  # empty file
     "[1, 2, 3]",                                                         # not an object
