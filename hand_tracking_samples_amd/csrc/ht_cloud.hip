@@ -219,7 +219,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 
 // ------------------------------------------------------------------------------------------------- k_fit_error
 __global__ __launch_bounds__(256) void k_fit_error(ht_model_dev M, const float *__restrict__ state, const float4 *__restrict__ pts, const int *__restrict__ npts,
-                                                  const uint16_t *__restrict__ depth, const float *__restrict__ cams, float bone_sum_error_scale, float *__restrict__ err)
+                                                  const uint16_t *__restrict__ depth, const float *__restrict__ cams, int w, int h, float bone_sum_error_scale, float *__restrict__ err)
 {
 	__shared__ float tab[HT_MAXNB * BT];
 	__shared__ int perr[HT_MAXNB];
@@ -252,8 +252,8 @@ __global__ __launch_bounds__(256) void k_fit_error(ht_model_dev M, const float *
 		{
 			v3 position = apply(ci, tab_pos(tab + k * BT));
 			int px = (int)(position.x / position.z * cam[0] + cam[2]), py = (int)(position.y / position.z * cam[1] + cam[3]);     // projectz misc_image.h:50
-			if (!(px >= 0 && px <= 63 && py >= 0 && py <= 63)) continue;
-			float bone_error = (float)(int)depth[(size_t)b * 4096 + py * 64 + px] * cam[4] - position.z;
+			if (!(px >= 0 && px <= w - 1 && py >= 0 && py <= h - 1)) continue;
+			float bone_error = (float)(int)depth[((size_t)b * h + py) * w + px] * cam[4] - position.z;
 			bone_error_sum += clamp_std(bone_error, 0.0f, 0.01f);
 		}
 		err[b] = point_error_sum + bone_error_sum * bone_sum_error_scale;
@@ -320,9 +320,9 @@ void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float
 	hipLaunchKernelGGL(k_cloud_rows, dim3(B), dim3(CR_THREADS), (size_t)M.plane_off[M.nb] * sizeof(float4), s, M, state, pts, npts, cams, active_flag, stride, use_cam_origin, mode, par.microforce,
 	                   mode == 4 ? sf_ratio : par.physics_weak_force, mode == 4 ? sf_wrist : par.cloudforce_max_point, par.cloudforce_max_sum, par.unibody_force, rows, nrows);
 }
-void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, float scale, float *err, int B, hipStream_t s)
+void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, int w, int h, float scale, float *err, int B, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_fit_error, dim3(B), dim3(256), (size_t)M.plane_off[M.nb] * sizeof(float4), s, M, state, pts, npts, depth, cams, scale, err);
+	hipLaunchKernelGGL(k_fit_error, dim3(B), dim3(256), (size_t)M.plane_off[M.nb] * sizeof(float4), s, M, state, pts, npts, depth, cams, w, h, scale, err);
 }
 void ht_launch_chamber(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, int min_point_num, int enabled, float maxforce, float *rows, int *nch, int B, hipStream_t s)
 {

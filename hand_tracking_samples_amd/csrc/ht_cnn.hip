@@ -77,6 +77,47 @@ __global__ __launch_bounds__(256) void k_prepare(const uint16_t *__restrict__ de
 	}
 }
 
+// Point cloud of a full-size frame (w x h, any size): takesubsample(PointCloud(dimage, {0.1, drangey}), fraction) of handtrack.h:703,751 --
+// every fraction-th in-range pixel in row-major order, deprojected with the frame's own camera.  One block per frame; thread t owns
+// the pixels [t*chunk, (t+1)*chunk), counts, the block forms the exclusive prefix, and a second walk emits.  *overflow counts frames with
+// more than HT_MAXPTS points (their cloud is truncated; the host API turns that into an error).
+__global__ __launch_bounds__(256) void k_prepare_frame(const uint16_t *__restrict__ depth, const float *__restrict__ cams, int w, int h, float drangey, int fraction,
+                                                        float4 *__restrict__ pts, int *__restrict__ npts, int *__restrict__ overflow)
+{
+	const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const float *cam = cams + (size_t)b * HT_CAM;
+	const float fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3], dscale = cam[4];
+	const int npx = w * h, chunk = (npx + 255) / 256, p0 = min(npx, t * chunk), p1 = min(npx, p0 + chunk);
+	const uint16_t *src = depth + (size_t)b * npx;
+	int cnt = 0;
+	for (int p = p0; p < p1; p++) { const float d = (float)(int)src[p] * dscale; cnt += (d >= 0.1f && d < drangey) ? 1 : 0; }
+	int incl = cnt;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+	__shared__ int wsum[4];
+	if (lane == 63) wsum[wave] = incl;
+	__syncthreads();
+	int rank = incl - cnt;
+	for (int i = 0; i < wave; i++) rank += wsum[i];
+	for (int p = p0; p < p1; p++)
+	{
+		const float d = (float)(int)src[p] * dscale;
+		if (!(d >= 0.1f && d < drangey)) continue;
+		if (rank % fraction == 0 && rank / fraction < HT_MAXPTS)
+		{
+			const float x = (float)(p % w), y = (float)(p / w);
+			pts[(size_t)b * HT_MAXPTS + rank / fraction] = make_float4(((x - cx) / fx) * d, ((y - cy) / fy) * d, 1.0f * d, 0.0f);      // deprojectz misc_image.h:48
+		}
+		rank++;
+	}
+	if (t == 255)
+	{
+		const int n = (rank + fraction - 1) / fraction;
+		npts[b] = n < HT_MAXPTS ? n : HT_MAXPTS;
+		if (n > HT_MAXPTS && overflow) atomicAdd(overflow, 1);
+	}
+}
+
 // ------------------------------------------------------------------------------------------------- k_conv1
 __device__ __forceinline__ float tanh_ref(float t) { float e = (float)exp((double)(2 * t)); return (e - 1) / (e + 1); }   // cnn.h:31
 
@@ -370,6 +411,10 @@ __global__ __launch_bounds__(64) void k_softmax_decode(const float *__restrict__
 void ht_launch_prepare(const uint16_t *depth, const float *cams, float drangey, int fraction, float *cnn_in, float4 *pts, int *npts, int B, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_prepare, dim3(B), dim3(256), 0, s, depth, cams, drangey, fraction, cnn_in, pts, npts);
+}
+void ht_launch_prepare_frame(const uint16_t *depth, const float *cams, int w, int h, float drangey, int fraction, float4 *pts, int *npts, int *overflow, int B, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_prepare_frame, dim3(B), dim3(256), 0, s, depth, cams, w, h, drangey, fraction, pts, npts, overflow);
 }
 void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, float *act2, float *act3, float *logits, int B, hipStream_t s)
 {

@@ -12,7 +12,8 @@
 #include "../../include/ht_mi355x.h"
 #include "ht_math.hpp"
 
-#define HT_MAXPTS 1024          // sub-sampled points per 64x64 frame (4096 / 4)
+#define HT_MAXPTS 4096          // sub-sampled points per frame: all of a 64x64 tile's (4096 / 4) or of a 128x128 frame's (16384 / 4); larger frames must stay below it
+static_assert(HT_MAXPTS == HT_MAX_POINTS, "public header and kernels disagree on the point capacity");
 #define HT_MAXNB 32             // bodies
 #define HT_MAXNJ 32             // joints
 #define HT_STATE_STRIDE 16      // floats per body in device state arrays
@@ -83,5 +84,6 @@ struct ht_cnn_weights { const float *W1, *B1, *W2p, *B2, *W3, *B3, *W4, *B4; };
 
 // ---- kernel launchers (defined in the .hip files) ----
 void ht_launch_prepare(const uint16_t *depth, const float *cams, float drangey, int fraction, float *cnn_in, float4 *pts, int *npts, int B, hipStream_t s);
+void ht_launch_prepare_frame(const uint16_t *depth, const float *cams, int w, int h, float drangey, int fraction, float4 *pts, int *npts, int *overflow, int B, hipStream_t s);
 void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, float *act2, float *act3, float *logits, int B, hipStream_t s);
 void ht_launch_softmax_decode(const float *logits, float *cnn_out, const float *cams, float *analysis, int softmax, int B, hipStream_t s);

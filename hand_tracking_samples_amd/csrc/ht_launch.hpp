@@ -20,7 +20,7 @@ struct solve_args
 
 void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const float *cams, const int *active_flag, int stride, int use_cam_origin, int mode,
                           const ht_params &par, float *rows, int *nrows, int B, hipStream_t s, float sf_ratio = 0.0f, float sf_wrist = 0.0f);
-void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, float scale, float *err, int B, hipStream_t s);
+void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, int w, int h, float scale, float *err, int B, hipStream_t s);
 void ht_launch_chamber(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, int min_point_num, int enabled, float maxforce, float *rows, int *nch, int B, hipStream_t s);
 void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s);
 size_t ht_contacts_workspace_bytes(int B);

@@ -83,19 +83,47 @@ static void reset_path(ht_ctx *ctx, const int *flags, int n_unibody, int B, hipS
 }
 
 // the whole unit of work on device buffers
-static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, const float *d_start, int B, float *d_poses_out, float *d_cnn_out, hipStream_t s)
+// `fs` != null: d_depth / d_cams are full-size frames (handtrack.h:693-785 with dim != 64x64).  The tracker segments them for the CNN
+// (handtrack.h:697-698) and from then on ctx->d_cams holds the SEGMENT cameras (CNN decode, landmark rays, PoseFromScratch, UnibodyFit and
+// MultiStepSim take segment.cam.pose); the point cloud and FitError keep the full frame and its camera.
+struct frame_src { int w, h; float segment_scale; };
+static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, const float *d_start, int B, float *d_poses_out, float *d_cnn_out, hipStream_t s, const frame_src *fs = nullptr)
 {
 	if (!ctx->have_weights) { ctx->err = "CNN weights not loaded (ht_cnn_load_weights)"; return HT_ERR_STATE; }
 	const ht_params &p = ctx->par;
 	const int nb = ctx->model.nb;
-	if (d_cams != ctx->d_cams) HIPCHK(ctx, hipMemcpyAsync(ctx->d_cams, d_cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyDeviceToDevice, s));
+	const int iw = fs ? fs->w : 64, ih = fs ? fs->h : 64;      // the image FitError looks at
+	const float *img_cams = ctx->d_cams;
+	if (fs)
+	{
+		if (!ctx->d_seg_tiles)
+		{
+			void *a = nullptr, *b = nullptr, *c = nullptr;
+			HIPCHK(ctx, hipMalloc(&a, (size_t)ctx->B * 4096 * sizeof(uint16_t))); ctx->allocs.push_back(a); ctx->d_seg_tiles = (uint16_t *)a;
+			HIPCHK(ctx, hipMalloc(&b, (size_t)ctx->B * HT_CAM * sizeof(float))); ctx->allocs.push_back(b); ctx->d_frame_cams = (float *)b;
+			HIPCHK(ctx, hipMalloc(&c, sizeof(int))); ctx->allocs.push_back(c); ctx->d_overflow = (int *)c;
+		}
+		HIPCHK(ctx, hipMemcpyAsync(ctx->d_frame_cams, d_cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyDeviceToDevice, s));
+		HIPCHK(ctx, hipMemsetAsync(ctx->d_overflow, 0, sizeof(int), s));
+		ht_launch_segment(d_depth, ctx->d_frame_cams, fs->w, fs->h, 0xF, p.drangey, fs->segment_scale, ctx->d_seg_tiles, ctx->d_cams, B, s);
+		img_cams = ctx->d_frame_cams;
+	}
+	else if (d_cams != ctx->d_cams) HIPCHK(ctx, hipMemcpyAsync(ctx->d_cams, d_cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyDeviceToDevice, s));
 	if (d_start)
 	{
 		ht_launch_set_pose(ctx->d_state[0], d_start, nb, B, 1, s);
 		ht_launch_set_pose(ctx->d_state[1], d_start, nb, B, 1, s);
 		ht_launch_clear_flags(ctx->d_prev_err, ctx->d_initializing, B, s);
 	}
-	{ ht_prof_scope ps(ctx, "prepare", s, true); ht_launch_prepare(d_depth, ctx->d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, ctx->d_pts, ctx->d_npts, B, s); }
+	{
+		ht_prof_scope ps(ctx, "prepare", s, true);
+		if (fs)
+		{
+			ht_launch_prepare(ctx->d_seg_tiles, ctx->d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, nullptr, nullptr, B, s);
+			ht_launch_prepare_frame(d_depth, img_cams, fs->w, fs->h, p.drangey, p.subsample_fraction, ctx->d_pts, ctx->d_npts, ctx->d_overflow, B, s);
+		}
+		else ht_launch_prepare(d_depth, ctx->d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, ctx->d_pts, ctx->d_npts, B, s);
+	}
 	float *cnn_out = d_cnn_out ? d_cnn_out : ctx->d_cnn_out;
 	static const bool no_overlap = getenv("HT_NO_OVERLAP") != nullptr;      // timing experiments
 	const bool overlap = !no_overlap && !ctx->profile_phases && p.steps >= 1 && p.steps_cloudstart >= 1 && !p.angles_only;
@@ -106,7 +134,7 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		hipStream_t t = ctx->side[1];
 		fork(ctx, s);
 		ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, t);                       // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757
-		ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, ctx->d_cams, p.bone_sum_error_scale, ctx->d_err_old, B, t);
+		ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_old, B, t);
 		ht_launch_decide_reset(ctx->d_err_old, p.full_reset_on_error, p.angles_only, ctx->d_flags, ctx->d_nflags, B, t);
 		if (ctx->phys.use_collision) ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, ctx->d_nflags, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, t);
 	}
@@ -130,12 +158,12 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 	else
 	{
 		ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, s);                       // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757
-		{ ht_prof_scope ps(ctx, "fit_error", s, true); ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, ctx->d_cams, p.bone_sum_error_scale, ctx->d_err_old, B, s); }
+		{ ht_prof_scope ps(ctx, "fit_error", s, true); ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_old, B, s); }
 		ht_launch_decide_reset(ctx->d_err_old, p.full_reset_on_error, p.angles_only, ctx->d_flags, ctx->d_nflags, B, s);
 		reset_path(ctx, ctx->d_flags, p.steps_unibody, B, s, s);
 		multistep(ctx, B, s);
 	}
-	{ ht_prof_scope ps(ctx, "fit_error", s, true); ht_launch_fit_error(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, d_depth, ctx->d_cams, p.bone_sum_error_scale, ctx->d_err_new, B, s); }
+	{ ht_prof_scope ps(ctx, "fit_error", s, true); ht_launch_fit_error(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_new, B, s); }
 	ht_launch_accept(ctx->d_state[0], ctx->d_state[1], ctx->d_err_old, ctx->d_err_new, ctx->d_npts, ctx->d_prev_err, ctx->d_initializing, ctx->d_accepted, nb, B, p, s);
 	for (int i = 0; !p.angles_only && i < p.mainthreadpasses; i++) main_pass(ctx, B, s);
 	ht_launch_output(ctx->model, ctx->d_state[0], ctx->d_npts, ctx->d_initializing, p.min_point_num, d_poses_out, B, s);
@@ -220,13 +248,70 @@ extern "C" int ht_update_sync(ht_ctx *ctx, const uint16_t *depth, const float *c
 	return HT_OK;
 }
 
+// HandTracker::update on frames of any size up to 320x240 (handtrack.h:693-785): segmentation for the CNN inside, the cloud of the full frame
+static int frames_args_ok(ht_ctx *ctx, int w, int h)
+{
+	if (w == 64 && h == 64) return 1;
+	if (!ht_segment_supported(w, h)) { ctx->err = "ht_update_frames: frame size must be a multiple of 4 and at most 320x240 pixels"; return 0; }
+	return 1;
+}
+extern "C" int ht_update_frames_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, int w, int h, float segment_scale, const float *d_start_poses, int B, float *d_poses_out, void *stream)
+{
+	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	if (!d_depth || !d_cams || !d_poses_out) return HT_ERR_ARG;
+	if (!frames_args_ok(ctx, w, h)) return HT_ERR_ARG;
+	hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+	const frame_src fs = { w, h, segment_scale };
+	int r = run_update(ctx, d_depth, d_cams, d_start_poses, B, d_poses_out, nullptr, s, (w == 64 && h == 64) ? nullptr : &fs);
+	if (r) return r;
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
+extern "C" int ht_frames_overflow(ht_ctx *ctx, int *frames_over)
+{
+	CHECK_READY(ctx);
+	if (!frames_over) return HT_ERR_ARG;
+	*frames_over = 0;
+	if (ctx->d_overflow) HIPCHK(ctx, hipMemcpy(frames_over, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost));
+	return HT_OK;
+}
+extern "C" int ht_update_frames_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int w, int h, float segment_scale, int B, float *poses_out, float *cnn_out)
+{
+	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	if (!depth || !cams || !poses_out) return HT_ERR_ARG;
+	if (w == 64 && h == 64) return ht_update_sync(ctx, depth, cams, B, poses_out, cnn_out);
+	if (!frames_args_ok(ctx, w, h)) return HT_ERR_ARG;
+	hipStream_t s = ctx->stream;
+	const int nb = ctx->model.nb;
+	const size_t npx = (size_t)w * h;
+	if (ctx->frames_cap < (size_t)B * npx)
+	{
+		void *a = nullptr;
+		HIPCHK(ctx, hipMalloc(&a, (size_t)ctx->B * npx * sizeof(uint16_t))); ctx->allocs.push_back(a); ctx->d_frames = (uint16_t *)a; ctx->frames_cap = (size_t)ctx->B * npx;
+	}
+	if (!ctx->d_frame_cams_in) { void *a = nullptr; HIPCHK(ctx, hipMalloc(&a, (size_t)ctx->B * HT_CAM * sizeof(float))); ctx->allocs.push_back(a); ctx->d_frame_cams_in = (float *)a; }
+	HIPCHK(ctx, hipMemcpyAsync(ctx->d_frames, depth, (size_t)B * npx * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+	HIPCHK(ctx, hipMemcpyAsync(ctx->d_frame_cams_in, cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyHostToDevice, s));
+	const frame_src fs = { w, h, segment_scale };
+	int r = run_update(ctx, ctx->d_frames, ctx->d_frame_cams_in, nullptr, B, ctx->d_poses_out, nullptr, s, &fs);
+	if (r) return r;
+	HIPCHK(ctx, hipMemcpyAsync(poses_out, ctx->d_poses_out, (size_t)B * nb * HT_POSE * sizeof(float), hipMemcpyDeviceToHost, s));
+	if (cnn_out) HIPCHK(ctx, hipMemcpyAsync(cnn_out, ctx->d_cnn_out, (size_t)B * HT_CNN_OUT * sizeof(float), hipMemcpyDeviceToHost, s));
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	HIPCHK(ctx, hipGetLastError());
+	int over = 0;
+	HIPCHK(ctx, hipMemcpy(&over, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost));
+	if (over) { ctx->err = "ht_update_frames: " + std::to_string(over) + " frame(s) have more in-range points than the solver's capacity (4096 after sub-sampling); their result is not the reference's"; return HT_ERR_ARG; }
+	return HT_OK;
+}
+
 // ---- stage entry points (operate on the buffers ht_stage_prepare filled and on the tracker state of slots [0,B)) -------------
 extern "C" int ht_stage_fit_error(ht_ctx *ctx, int which, int B, float *err)
 {
 	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
 	if (!err || which < 0 || which > 1) return HT_ERR_ARG;
 	hipStream_t s = ctx->stream;
-	ht_launch_fit_error(ctx->model, ctx->d_state[which], ctx->d_pts, ctx->d_npts, ctx->d_depth, ctx->d_cams, ctx->par.bone_sum_error_scale, ctx->d_err_old, B, s);
+	ht_launch_fit_error(ctx->model, ctx->d_state[which], ctx->d_pts, ctx->d_npts, ctx->d_depth, ctx->d_cams, 64, 64, ctx->par.bone_sum_error_scale, ctx->d_err_old, B, s);
 	HIPCHK(ctx, hipMemcpyAsync(err, ctx->d_err_old, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, s));
 	HIPCHK(ctx, hipStreamSynchronize(s));
 	HIPCHK(ctx, hipGetLastError());

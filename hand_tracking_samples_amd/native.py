@@ -13,13 +13,13 @@ from . import build as _build
 HERE = os.path.dirname(os.path.abspath(__file__))
 HT_OK = 0
 CNN_IN, CNN_OUT, CNNB_COUNT, POSE, STATE, CAM, ANALYSIS = 4096, 2304, 9458400, 7, 13, 12, 84
-MAXPTS, ROW, CONTACT = 1024, 16, 12
+MAXPTS, ROW, CONTACT = 4096, 16, 12      # HT_MAX_POINTS
 
 # every symbol include/ht_mi355x.h declares (checked by tests/test_abi.py)
 SYMBOLS = (
     "ht_create", "ht_destroy", "ht_model_bake", "ht_last_error", "ht_get_params", "ht_set_params", "ht_model_info", "ht_config_read", "ht_scale",
     "ht_cnn_load_weights", "ht_cnn_eval", "ht_cnn_eval_dev", "ht_cnn_train", "ht_cnn_get_weights", "ht_expected_cnn",
-    "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_segment_vr", "ht_segment_vr_dev", "ht_slowfit", "ht_set_points",
+    "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_update_frames_sync", "ht_update_frames_dev", "ht_frames_overflow", "ht_segment_vr", "ht_segment_vr_dev", "ht_slowfit", "ht_set_points",
     "ht_stage_prepare", "ht_stage_decode", "ht_stage_fit_error", "ht_stage_cloud_rows", "ht_stage_contacts", "ht_stage_fit",
     "ht_stage_multistep", "ht_stage_scratch_unibody", "ht_profile_enable", "ht_profile_read", "ht_debug_solve_stats", "ht_debug_contact_stats",
 )
@@ -71,6 +71,9 @@ def load(build_if_missing=True):
     L.ht_set_tracker_flags.argtypes = [vp, C.c_int, C.c_int, fp, ip]
     L.ht_update_sync.argtypes = [vp, u16p, fp, C.c_int, fp, fp]
     L.ht_update_dev.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp]
+    L.ht_update_frames_sync.argtypes = [vp, u16p, fp, C.c_int, C.c_int, C.c_float, C.c_int, fp, fp]
+    L.ht_update_frames_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, C.c_int, vp, vp]
+    L.ht_frames_overflow.argtypes = [vp, ip]
     L.ht_stage_prepare.argtypes = [vp, u16p, fp, C.c_int, fp, fp, ip]
     L.ht_stage_decode.argtypes = [vp, fp, fp, C.c_int, fp]
     L.ht_stage_fit_error.argtypes = [vp, C.c_int, C.c_int, fp]
@@ -213,6 +216,23 @@ class Context:
 
     def update_dev(self, d_depth, d_cams, d_start, B, d_poses_out, stream):
         self._chk(self.L.ht_update_dev(self.h, d_depth, d_cams, d_start, B, d_poses_out, stream))
+
+    def update_frames_sync(self, depth, cams, segment_scale=0.17, want_cnn=False):
+        """HandTracker::update on frames of any size (handtrack.h:693-785): depth u16[B,h,w], cams [B,12] = the frames' cameras."""
+        depth = _c(depth, np.uint16); B, h, w = depth.shape
+        cams = _c(cams, np.float32).reshape(B, CAM)
+        poses = np.empty((B, self.nb, POSE), np.float32)
+        cnn = np.empty((B, CNN_OUT), np.float32) if want_cnn else None
+        self._chk(self.L.ht_update_frames_sync(self.h, depth.ctypes.data_as(C.POINTER(C.c_uint16)), _f(cams), w, h, float(segment_scale), B, _f(poses), _f(cnn) if want_cnn else None))
+        return (poses, cnn) if want_cnn else poses
+
+    def update_frames_dev(self, d_depth, d_cams, w, h, segment_scale, d_start, B, d_poses_out, stream):
+        self._chk(self.L.ht_update_frames_dev(self.h, d_depth, d_cams, int(w), int(h), float(segment_scale), d_start, B, d_poses_out, stream))
+
+    def frames_overflow(self):
+        n = C.c_int(0)
+        self._chk(self.L.ht_frames_overflow(self.h, C.byref(n)))
+        return n.value
 
     # -- stages
     def stage_prepare(self, depth, cams):

@@ -38,6 +38,7 @@ extern "C" {
 #define HT_POSE 7
 #define HT_STATE 13
 #define HT_CAM 12
+#define HT_MAX_POINTS 4096   /* sub-sampled cloud points a frame can carry: stride of the point / cloud-row arrays of the stage calls */
 #define HT_ANALYSIS 84        /* floats per frame, see ht_stage_decode */
 
 typedef struct ht_ctx ht_ctx;
@@ -118,6 +119,15 @@ int ht_get_tracker_flags(ht_ctx *ctx, int first, int n, float *prev_frame_error,
 int ht_set_tracker_flags(ht_ctx *ctx, int first, int n, const float *prev_frame_error, const int *initializing);
 int ht_update_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int B, float *poses_out, float *cnn_out);
 int ht_update_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, const float *d_start_poses, int B, float *d_poses_out, void *stream);
+/* ht_update_frames_*  the same call on frames that are not 64x64 (w, h multiples of 4, at most 320x240), as HandTracker::update treats them
+ *                     (handtrack.h:693-785): HandSegmentVR(dimage, 0xF, {0.1, drangey}, segment_scale) feeds the CNN (:697-701), the point cloud and
+ *                     FitError come from the full frame with its own camera (:703-704, :751), and segment.cam.pose goes to PoseFromScratch,
+ *                     UnibodyFit and MultiStepSim (:708-713).  depth [B][h*w], cams [B][12] = the frames' cameras.  A frame with more than 4096
+ *                     sub-sampled in-range points exceeds the solver's row capacity: the sync call then returns HT_ERR_ARG, after the dev call
+ *                     ht_frames_overflow reports how many frames of the last call were truncated. */
+int ht_update_frames_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int w, int h, float segment_scale, int B, float *poses_out, float *cnn_out);
+int ht_update_frames_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, int w, int h, float segment_scale, const float *d_start_poses, int B, float *d_poses_out, void *stream);
+int ht_frames_overflow(ht_ctx *ctx, int *frames_over);
 
 /* ---- training ----------------------------------------------------------------------------------------------------------
  * ht_cnn_train        replaces  float CNN::Train(const std::vector<float> &x, const std::vector<float> &t, float alpha) (cnn.h:558-580) called for
@@ -154,12 +164,12 @@ int ht_slowfit(ht_ctx *ctx, int B, int hold, const float *refpose, int steps, in
 /* ---- stage entry points (same kernels, exposed one reference function at a time so parity tests can pin each) -----
  * All take HOST buffers and are synchronous.  `which` selects the model (0 handmodel, 1 othermodel) of slots [0,B).
  * ht_stage_prepare    depth -> CNN input (handtrack.h:700) and sub-sampled point cloud (misc_image.h:409-417, physmodel.h:58-64):
- *                     cnn_in [B][4096] (optional), points [B][1024][4] (optional), npoints [B] (optional).
+ *                     cnn_in [B][4096] (optional), points [B][HT_MAX_POINTS][4] (optional), npoints [B] (optional).
  * ht_stage_decode     CNNOutputAnalysis (handtrack.h:218-241): cnn_out [B][2304] -> analysis [B][HT_ANALYSIS]:
  *                     crays 8x4 | image_points 8x2 | confidence 8 | vals 16 | wristroll pitch tilt | palmq 4 | finger_clenched 5.
  * ht_stage_fit_error  FitError (handtrack.h:371-399) of model `which` against the prepared points / depth: err [B].
  * ht_stage_cloud_rows CloudConstraints (physmodel.h:164-181) of model `which`, every `stride`-th prepared point, ray origin =
- *                     camera position if use_cam_origin else 0: rows [B][1024][16] (layout: rb0 rb1 position0 position1 normal
+ *                     camera position if use_cam_origin else 0: rows [B][HT_MAX_POINTS][16] (layout: rb0 rb1 position0 position1 normal
  *                     targetdist targetspeednobias forcelimit.xy friction_master), nrows [B].
  * ht_stage_contacts   FindShapeShapeContacts (physics.h:451-462): contacts [B][cap][12] (rb0 rb1 normal p0w p1w separation), n [B].
  * ht_stage_fit        one PhysModel::FitPointCloud(points, chamber-rows-if-enabled, HandModelEnhancements) pass on handmodel

@@ -50,3 +50,44 @@ def test_oracle_full_frame_update_matches_reference(weights, case, f):
         assert np.array_equal(orc.get_state(0), G[pre + "uw2_hand"])
     finally:
         orc.close()
+
+
+# same tolerances and reasons as tests/test_gpu_solver.py
+POS_TOL, QUAT_TOL, FULL_POS_TOL, FULL_QUAT_TOL = 2e-5, 2e-4, 2e-4, 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", list(CASES))
+def test_gpu_full_frame_update_matches_reference(weights, case):
+    """ht_update_frames_sync: k_segment -> CNN on the tile, cloud + FitError on the full frame, the segment camera's pose in the solver."""
+    from hand_tracking_samples_amd import native
+    G, (_, model, nb) = GOLD[case], CASES[case]
+    nf = len(G["rows"])
+    ctx = native.Context(model, nf)
+    try:
+        ctx.load_weights(weights)
+        ctx.set_params(microforce=3.0, mainthreadpasses=3)
+        depth = np.stack([G["f%d/depth" % f] for f in range(nf)]); cams = np.stack([G["f%d/cam" % f] for f in range(nf)])
+        ctx.tracker_reset(np.stack([G["f%d/startpose" % f] for f in range(nf)]))
+        poses, cnn = ctx.update_frames_sync(depth, cams, 0.17, want_cnn=True)
+        assert ctx.frames_overflow() == 0
+        assert np.abs(cnn - np.stack([G["f%d/cnn_output" % f] for f in range(nf)])).max() <= 2e-5
+        pfe, ini = ctx.tracker_flags(nf)
+        for f in range(nf):
+            ref = G["f%d/uw_pose_user" % f]
+            accepted = G["f%d/uw_accept" % f][0] > 0
+            dp = np.abs(poses[f, :, :3] - ref[:, :3]).max(); dq = np.abs(poses[f, :, 3:] - ref[:, 3:]).max()
+            print("%s frame %d (%d points, cnn pose %s): |dpos| %.2e |dquat| %.2e" % (case, f, G["f%d/uw_final" % f][2], "accepted" if accepted else "rejected", dp, dq))
+            assert dp <= (FULL_POS_TOL if accepted else POS_TOL) and dq <= (FULL_QUAT_TOL if accepted else QUAT_TOL)
+            assert ini[f] == int(G["f%d/uw_final" % f][1]) and abs(pfe[f] - G["f%d/uw_final" % f][0]) <= 1e-4
+        # second update of the same frames, teacher-forced from the reference's state (as tests/test_gpu_solver.py does)
+        ctx.set_state(0, np.stack([G["f%d/uw_hand_pass2" % f] for f in range(nf)]))
+        ctx.set_tracker_flags([G["f%d/uw_final" % f][0] for f in range(nf)], [int(G["f%d/uw_final" % f][1]) for f in range(nf)])
+        poses2 = ctx.update_frames_sync(depth, cams, 0.17)
+        for f in range(nf):
+            ref = G["f%d/uw2_pose_user" % f]
+            dp = np.abs(poses2[f, :, :3] - ref[:, :3]).max(); dq = np.abs(poses2[f, :, 3:] - ref[:, 3:]).max()
+            print("%s second update %d: |dpos| %.2e |dquat| %.2e" % (case, f, dp, dq))
+            assert dp <= FULL_POS_TOL and dq <= FULL_QUAT_TOL
+    finally:
+        ctx.close()
