@@ -375,6 +375,7 @@ extern "C" int ht_stage_prepare(ht_ctx *ctx, const uint16_t *depth, const float 
 	HIPCHK(ctx, hipMemcpyAsync(ctx->d_depth, depth, (size_t)B * 4096 * sizeof(uint16_t), hipMemcpyHostToDevice, s));
 	HIPCHK(ctx, hipMemcpyAsync(ctx->d_cams, cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyHostToDevice, s));
 	ht_launch_prepare(ctx->d_depth, ctx->d_cams, ctx->par.drangey, ctx->par.subsample_fraction, ctx->d_cnn_in, ctx->d_pts, ctx->d_npts, B, s);
+	ctx->model.pts_bound = 0;      // stage calls: no assumption about the cloud size
 	if (cnn_in) HIPCHK(ctx, hipMemcpyAsync(cnn_in, ctx->d_cnn_in, (size_t)B * HT_CNN_IN * sizeof(float), hipMemcpyDeviceToHost, s));
 	if (points) HIPCHK(ctx, hipMemcpyAsync(points, ctx->d_pts, (size_t)B * HT_MAXPTS * sizeof(float4), hipMemcpyDeviceToHost, s));
 	if (npoints) HIPCHK(ctx, hipMemcpyAsync(npoints, ctx->d_npts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));

@@ -141,9 +141,11 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
                                                            float *__restrict__ rows, int *__restrict__ nrows)
 {
 	__shared__ float tab[HT_MAXNB * BT];
-	__shared__ unsigned short perm[HT_MAXPTS];
-	__shared__ unsigned char key[HT_MAXPTS];
 	__shared__ int bin[HT_MAXNB];
+	// per-point sort arrays live in the dynamic segment behind the planes, sized by the launch's point bound (3 B per point)
+	const int cap = M.pts_bound > 0 ? M.pts_bound : HT_MAXPTS;
+	unsigned short *perm = reinterpret_cast<unsigned short *>(s_planes + M.plane_off[M.nb]);
+	unsigned char *key = reinterpret_cast<unsigned char *>(perm + cap);
 	const int b = blockIdx.x, t = threadIdx.x;
 	const int n = npts[b];
 	const int nsub = (n + stride - 1) / stride;
@@ -317,7 +319,8 @@ __global__ __launch_bounds__(64) void k_chamber(ht_model_dev M, const float *__r
 void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const float *cams, const int *active_flag, int stride, int use_cam_origin, int mode,
                           const ht_params &par, float *rows, int *nrows, int B, hipStream_t s, float sf_ratio, float sf_wrist)
 {
-	hipLaunchKernelGGL(k_cloud_rows, dim3(B), dim3(CR_THREADS), (size_t)M.plane_off[M.nb] * sizeof(float4), s, M, state, pts, npts, cams, active_flag, stride, use_cam_origin, mode, par.microforce,
+	const size_t cap = M.pts_bound > 0 ? (size_t)M.pts_bound : (size_t)HT_MAXPTS;
+	hipLaunchKernelGGL(k_cloud_rows, dim3(B), dim3(CR_THREADS), (size_t)M.plane_off[M.nb] * sizeof(float4) + ((cap * 3 + 15) & ~(size_t)15), s, M, state, pts, npts, cams, active_flag, stride, use_cam_origin, mode, par.microforce,
 	                   mode == 4 ? sf_ratio : par.physics_weak_force, mode == 4 ? sf_wrist : par.cloudforce_max_point, par.cloudforce_max_sum, par.unibody_force, rows, nrows);
 }
 void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, int w, int h, float scale, float *err, int B, hipStream_t s)

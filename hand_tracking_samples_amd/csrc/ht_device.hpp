@@ -58,6 +58,7 @@ static_assert(HT_MAXPTS == HT_MAX_POINTS, "public header and kernels disagree on
 struct ht_model_dev
 {
 	int nb, nj;
+	int pts_bound;            // most sub-sampled points a frame of the current call can carry (<= HT_MAXPTS; 0 = HT_MAXPTS): sizes per-point LDS arrays
 	const float4 *verts;      // all bodies back to back (com-centred collision vertices)
 	const float4 *planes;     // all bodies back to back (local half-space planes)
 	const float *bodyc;       // [nb][HT_BC]

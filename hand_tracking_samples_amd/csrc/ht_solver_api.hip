@@ -93,6 +93,7 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 	const ht_params &p = ctx->par;
 	const int nb = ctx->model.nb;
 	const int iw = fs ? fs->w : 64, ih = fs ? fs->h : 64;      // the image FitError looks at
+	{ const int npx = iw * ih, fr = p.subsample_fraction > 0 ? p.subsample_fraction : 1, n = (npx + fr - 1) / fr; ctx->model.pts_bound = n < HT_MAXPTS ? ((n + 63) & ~63) : HT_MAXPTS; }
 	const float *img_cams = ctx->d_cams;
 	if (fs)
 	{
@@ -495,6 +496,7 @@ extern "C" int ht_set_points(ht_ctx *ctx, int B, const float *points, int cap, c
 {
 	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
 	if (!points || !npoints || cap < 1) return HT_ERR_ARG;
+	ctx->model.pts_bound = 0;
 	std::vector<float4> h((size_t)B * HT_MAXPTS, make_float4(0, 0, 0, 0)); std::vector<int> n(B);
 	for (int b = 0; b < B; b++)
 	{
