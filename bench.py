@@ -38,6 +38,38 @@ def _load_frames(n):
     return (tile(z["depth"].reshape(-1, 4096)).astype(np.uint16), tile(z["cam"]).astype(np.float32), tile(z["startpose"]).astype(np.float32))
 
 
+def _load_frames5(n):
+    """BASELINE configs[4]: 128x128 frames of the 26-bone hand (tests/golden/make_frames5.py), tiled"""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "frames5_64.npz"))
+    reps = (n + len(z["depth"]) - 1) // len(z["depth"])
+    tile = lambda a: np.concatenate([a] * reps)[:n]
+    return (tile(z["depth"]).astype(np.uint16), tile(z["cam"]).astype(np.float32), tile(z["startpose"]).astype(np.float32))
+
+
+def cpu_baseline_config5(depth, cams, start, seed, gain):
+    """C oracle (pinned bit for bit on the reference's full-frame goldens, tests/test_fullframe.py) on a bounded sample, one thread."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import oracle_lib as ol
+    from hand_tracking_samples_amd import weights as W
+    o = ol.Oracle(W.make_cnnb(seed, gain), model=os.path.join(ROOT, "tests", "golden", "model_hand26.htfx"))
+    o.head.par.microforce = 3.0
+    o.head.par.mainthreadpasses = 3
+    nsample = min(64, len(depth))
+    user = np.zeros((26, 7), np.float32)
+    best = 1e30
+    for rep in range(2):
+        t0 = time.perf_counter()
+        for i in range(nsample):
+            o.reset(start[i])
+            cam = ol.camera(cams[i], 128, 128)
+            o.L.ho_update(o.h, ol.u16ptr(np.ascontiguousarray(depth[i])), C.byref(cam), ol.fptr(user))
+        best = min(best, (time.perf_counter() - t0) / nsample)
+    o.close()
+    return {"value": 1.0 / best, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames x 2 reps (best), C oracle -O2 -ffp-contract=off: HandSegmentVR + update_cnn_model + 3 passes, 26 bones" % nsample}
+
+
 def _write_htfx(path, arrays):
     code = {np.dtype(np.float32): 0, np.dtype(np.int32): 1, np.dtype(np.uint16): 2, np.dtype(np.uint8): 3}
     with open(path, "wb") as f:
@@ -94,7 +126,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames-per-gpu", type=int, default=1024)
-    ap.add_argument("--workload", default="cnn+solver", choices=["cnn+solver", "cnn"])
+    ap.add_argument("--workload", default="cnn+solver", choices=["cnn+solver", "cnn", "config5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the pose gather even with one rank")
     args = ap.parse_args()
@@ -123,11 +155,12 @@ def main():
     seed, gain = W.DEFAULT_SEED, W.DEFAULT_FC2_GAIN
 
     # contiguous shard of the global frame list for this rank (frames differ across ranks through the tiling offset)
-    depth_all, cams_all, start_all = _load_frames(B * world)
+    cfg5 = args.workload == "config5"
+    depth_all, cams_all, start_all = (_load_frames5 if cfg5 else _load_frames)(B * world)
     sl = slice(*shard_range(B * world, rank, world))
     depth, cams, start = depth_all[sl], cams_all[sl], start_all[sl]
 
-    ctx = native.Context(os.path.join(ROOT, "tests", "golden", "model_hand17.htfx"), B, device=local)
+    ctx = native.Context(os.path.join(ROOT, "tests", "golden", "model_hand26.htfx" if cfg5 else "model_hand17.htfx"), B, device=local)
     ctx.load_weights(W.make_cnnb(seed, gain))
     ctx.set_params(microforce=3.0, mainthreadpasses=3)        # synthetic-tracker.cpp:91-93
     d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
@@ -146,6 +179,8 @@ def main():
     def step():
         if args.workload == "cnn":
             ctx.cnn_eval_dev(d_cnn_in.data_ptr(), d_cnn_out.data_ptr(), B, stream.cuda_stream)
+        elif cfg5:
+            ctx.update_frames_dev(d_depth.data_ptr(), d_cams.data_ptr(), 128, 128, 0.17, d_start.data_ptr(), B, d_poses.data_ptr(), stream.cuda_stream)
         else:
             ctx.update_dev(d_depth.data_ptr(), d_cams.data_ptr(), d_start.data_ptr(), B, d_poses.data_ptr(), stream.cuda_stream)
             if use_dist:
@@ -197,7 +232,7 @@ def main():
             # algorithmic HBM bytes of one k_solve launch: per frame the body state in and out
             # (2 x 17 x 52 B) plus the constraint rows it consumes (64 B each); mean rows per frame measured from the data
             npts = np.array([int(((d.astype(np.float32) * c[4] >= 0.1) & (d.astype(np.float32) * c[4] < 0.7)).sum() + 3) // 4 for d, c in zip(depth, cams)])
-            main_rows = float(np.mean(npts + np.where(npts > 400, 85, 0))); sim_rows = float(np.mean((npts + 3) // 4))
+            main_rows = float(np.mean(npts + np.where(npts > 400, 5 * ctx.nb, 0))); sim_rows = float(np.mean((npts + 3) // 4))
             rows_mean = (3 * main_rows + 4 * sim_rows) / 8.0
             per_frame = 2 * ctx.nb * 52 + 64.0 * rows_mean
             avg_ms = phases[dom][0] / phases[dom][1]
@@ -210,6 +245,15 @@ def main():
             roof = {"kernel": "k_solve", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                     "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches": phases[dom][1], "algorithmic_bytes_per_launch": int(per_frame * B),
                     "note": "sequential Gauss-Seidel: latency/VALU-bound, not a streaming kernel (SURVEY 8d)"}
+        elif dom == "contacts":
+            # k_contacts reads the poses of the frame's bodies and writes its contacts (48 B each, data dependent, not counted): like the
+            # solve it is a latency-bound kernel (one wave walks the candidate pairs' GJK/EPA iterations), priced against HBM for the record
+            per_frame = ctx.nb * 28 + 4
+            avg_ms = phases[dom][0] / phases[dom][1]
+            achieved = per_frame * B / (avg_ms * 1e-3) / 1e9
+            roof = {"kernel": "k_contacts", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4), "launches": phases[dom][1], "algorithmic_bytes_per_launch": int(per_frame * B),
+                    "note": "broad phase + GJK/EPA over %d body pairs per frame: latency/LDS-bound, not a streaming kernel" % (ctx.nb * (ctx.nb - 1) // 2)}
         elif dom == "cnn":
             avg_ms = phases[dom][0] / phases[dom][1]
             achieved = 26.47e6 * B / (avg_ms * 1e-3) / 1e12
@@ -221,12 +265,15 @@ def main():
             ach = 26.47e6 * B / (avg_ms * 1e-3) / 1e12
             cnn_roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 5), "avg_ms": round(avg_ms, 4)}
         out = {
-            "metric": "synthetic depth frames/sec (CNN+solver), 64x64x1 input, 17-bone hand" if args.workload == "cnn+solver" else "synthetic depth frames/sec (CNN forward only), 64x64x1 input",
+            "metric": "synthetic depth frames/sec (CNN+solver), 64x64x1 input, 17-bone hand" if args.workload == "cnn+solver" else
+                      "synthetic depth frames/sec (segmentation+CNN+solver), 128x128x1 input, 26-bone hand" if cfg5 else "synthetic depth frames/sec (CNN forward only), 64x64x1 input",
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (256 software-rendered animbank frames tiled; seeded weights 0x5EED0001)",
+            "dtype": "f32", "data": "synthetic (%d software-rendered animbank frames tiled; seeded weights 0x5EED0001)" % (64 if cfg5 else 256),
             "config": {"workload": "BASELINE configs[2]: %d independent 64x64 frames per GPU, CNN + decode + 5-step MultiStepSim + 3 FitPointCloud passes (GJK + PGS), 17 bones" % B
-                       if args.workload == "cnn+solver" else "BASELINE configs[1]: %d frames per GPU, CNN forward only" % B,
+                       if args.workload == "cnn+solver" else
+                       "BASELINE configs[4]: %d independent 128x128 frames per GPU, HandTracker::update on full frames (HandSegmentVR + CNN + 5-step MultiStepSim + 3 FitPointCloud passes), 26 bones" % B
+                       if cfg5 else "BASELINE configs[1]: %d frames per GPU, CNN forward only" % B,
                        "frames_per_gpu": B, "global_frames_per_step": B * world, "parallelism": "frames sharded per GPU, RCCL all-gather of poses" if world > 1 else "single GPU"},
             "roofline": roof,
             "phase_ms_per_step": {k: round(v[0] / nphase, 4) for k, v in sorted(all_phases.items())},
@@ -235,7 +282,7 @@ def main():
         if cnn_roof:
             out["roofline_cnn"] = cnn_roof
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(depth, cams, start, seed, gain)
+            out["cpu_baseline"] = (cpu_baseline_config5 if cfg5 else cpu_baseline)(depth, cams, start, seed, gain)
             out["speedup_vs_cpu_1thread"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     ctx.close()

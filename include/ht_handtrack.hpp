@@ -136,16 +136,20 @@ struct HandTracker                                                              
 
 	std::vector<Pose> update(Image<unsigned short> dimage)                                   // handtrack.h:748
 	{
-		// A full-size frame is segmented first, with the arguments of update_cnn_model_threadsafe (handtrack.h:697-698), which is also what
-		// synthetic-tracker.cpp:204-215 does before calling update().  (Given a full-size frame the reference's update() would fit the
-		// full-resolution cloud in its main-thread passes; here all passes work on the tile.)
-		if (dimage.dim().x != 64 || dimage.dim().y != 64) dimage = segment(dimage, 0xF, { 0.1f, drangey }, segment_scale);
+		// A frame that is not 64x64 goes through ht_update_frames_sync, which does what update() does with it (handtrack.h:693-785): the CNN
+		// sees HandSegmentVR(dimage, 0xF, {0.1, drangey}, segment_scale), the cloud and FitError come from the full frame.  The segment is
+		// fetched once more below, only for the visualisation members (cnn_input and the heat-map camera).
 		push_params();
-		const DCamera &c = dimage.cam;
-		float cam[HT_CAM] = { c.focal().x, c.focal().y, c.principal().x, c.principal().y, c.depth_scale, c.pose.position.x, c.pose.position.y, c.pose.position.z,
-		                      c.pose.orientation.x, c.pose.orientation.y, c.pose.orientation.z, c.pose.orientation.w };
+		const bool full = dimage.dim().x != 64 || dimage.dim().y != 64;
 		std::vector<float> out((size_t)nb_ * HT_POSE);
-		check(ctx_, ht_update_sync(ctx_, dimage.raster.data(), cam, 1, out.data(), cnn_output.data()));
+		{
+			const DCamera &fc = dimage.cam;
+			float fcam[HT_CAM] = { fc.focal().x, fc.focal().y, fc.principal().x, fc.principal().y, fc.depth_scale, fc.pose.position.x, fc.pose.position.y, fc.pose.position.z,
+			                       fc.pose.orientation.x, fc.pose.orientation.y, fc.pose.orientation.z, fc.pose.orientation.w };
+			check(ctx_, ht_update_frames_sync(ctx_, dimage.raster.data(), fcam, dimage.dim().x, dimage.dim().y, segment_scale, 1, out.data(), cnn_output.data()));
+		}
+		if (full) dimage = segment(dimage, 0xF, { 0.1f, drangey }, segment_scale);
+		const DCamera &c = dimage.cam;
 		// visualisation members, filled on the host from what the device returned (handtrack.h:700, 225, 236-238)
 		const float dr = drangey - 0.1f;
 		cnn_input = Image<float>(c);

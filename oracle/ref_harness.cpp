@@ -309,6 +309,34 @@ static int mode_fullframe(const char *bankfn, const char *rowscsv, const char *c
 	return 0;
 }
 
+// bench input for full-size frames: n frames of the staged model seen by camera `camspec` ("w,h,focal"), start pose = the next bank row
+static int mode_fullframes(const char *bankfn, int first, int stride, int n, const char *camspec, const char *outfn)
+{
+	PhysModel fake = LoadHandModel();
+	const size_t nb = fake.rigidbodies.size();
+	auto bank = read_animbank(bankfn, 17);
+	extend_bank(bank, nb);
+	int w = 128, h = 128; float focal = 163; sscanf(camspec, "%d,%d,%f", &w, &h, &focal);
+	DCamera dcam({ w,h }, { focal,focal }, { w * 0.5f, h * 0.5f }, 0.001f);
+	std::vector<unsigned short> depth; std::vector<float> cams, start; std::vector<int> rows;
+	for (int i = 0; i < n; i++)
+	{
+		size_t k = (size_t)(first + (long)i * stride) % bank.size();
+		fake.SetPose(bank[k]);
+		auto d = raycast_depth(fake, dcam);
+		depth.insert(depth.end(), d.raster.begin(), d.raster.end());
+		auto c = camvec(d.cam); cams.insert(cams.end(), c.begin(), c.end());
+		auto s = flat(bank[(k + 1) % bank.size()]); start.insert(start.end(), s.begin(), s.end());
+		rows.push_back((int)k);
+		if (i % 16 == 0) { printf("frame %d/%d row %d\n", i, n, (int)k); fflush(stdout); }
+	}
+	Out o; if (htfx_open(&o.w, outfn)) return 2;
+	o.u16("depth", depth, { (uint32_t)n, (uint32_t)h, (uint32_t)w }); o.f32("cam", cams, { (uint32_t)n, 12 });
+	o.f32("startpose", start, { (uint32_t)n, (uint32_t)nb, 7 }); o.i32("rows", rows);
+	htfx_close(&o.w);
+	return 0;
+}
+
 // ---- modes ---------------------------------------------------------------------------------------
 static int dump_model(PhysModel &m, const char *outfn)
 {
@@ -814,6 +842,7 @@ int main(int argc, char **argv) try
 	if (mode == "train" && a.size() == 6) return mode_train(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), atoi(a[4].c_str()), a[5].c_str());
 	if (mode == "slowfit" && a.size() == 3) return mode_slowfit(a[0].c_str(), a[1].c_str(), a[2].c_str());
 	if (mode == "segment" && a.size() == 3) return mode_segment(a[0].c_str(), a[1].c_str(), a[2].c_str());
+	if (mode == "fullframes" && a.size() == 6) return mode_fullframes(a[0].c_str(), atoi(a[1].c_str()), atoi(a[2].c_str()), atoi(a[3].c_str()), a[4].c_str(), a[5].c_str());
 	if (mode == "fullframe" && a.size() == 6) return mode_fullframe(a[0].c_str(), a[1].c_str(), a[2].c_str(), strtoull(a[3].c_str(), 0, 0), atof(a[4].c_str()), a[5].c_str());
 	if (mode == "config5" && a.size() == 5) return mode_config5(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());
 	if (mode == "golden" && a.size() == 5) return mode_golden(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());
