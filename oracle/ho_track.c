@@ -21,7 +21,7 @@ int ho_angular_drive(const ho_physics *ph, ho_body *const *B, int rb0, int rb1, 
 ho_angular ho_cone_angle(const ho_physics *ph, ho_body *const *B, int rb0, f3 n0, int rb1, f3 n1, float limitangle_degrees);
 void ho_sanity_check(ho_model *m);
 
-#define MAXLIN 4096
+#define MAXLIN 32768      /* rows of one solve: cloud points (up to a full 320x240 frame sub-sampled by 1... 4) + chamber + joints + contacts */
 #define MAXANG 256
 
 /* ------------------------------------------------------------------------------------------------ HTFX reader */
