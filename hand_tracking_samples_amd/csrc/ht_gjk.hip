@@ -88,7 +88,33 @@ __device__ __forceinline__ v3 support(const support_t &s, v3 dir)
 	if (s.outer) return s.opos + qrot(s.oq, support_inner(s, qrot(qconj(s.oq), dir)));
 	return support_inner(s, dir);
 }
-// wave-cooperative scan (all lanes the same shape and direction): strided partial arg-max + butterfly; ties go to the lower index
+// Wave-wide arg-max of (value, index): the larger value wins, equal values go to the lower index, index 0x7fffffff marks "nothing".  That
+// order is total, so any reduction tree gives the same winner: four DPP exchanges inside each row of 16 lanes (no LDS round trips as with
+// ds_bpermute shuffles), then the four row results are folded through v_readlane.  Every lane returns the winner.
+__device__ __forceinline__ void amax_take(float &b, int &i, float ob, int oi)
+{
+	const bool take = oi != 0x7fffffff && (i == 0x7fffffff || b < ob || (ob == b && oi < i));
+	b = take ? ob : b; i = take ? oi : i;
+}
+template <int CTRL> __device__ __forceinline__ void amax_dpp(float &b, int &i)
+{
+	const float ob = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b), CTRL, 0xF, 0xF, false));
+	const int oi = __builtin_amdgcn_update_dpp(0, i, CTRL, 0xF, 0xF, false);
+	amax_take(b, i, ob, oi);
+}
+__device__ __forceinline__ void wave_argmax(float &b, int &i)
+{
+	amax_dpp<0xB1>(b, i);       // quad_perm [1,0,3,2]
+	amax_dpp<0x4E>(b, i);       // quad_perm [2,3,0,1]
+	amax_dpp<0x141>(b, i);      // row_half_mirror
+	amax_dpp<0x140>(b, i);      // row_mirror
+	float rb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 0)); int ri = __builtin_amdgcn_readlane(i, 0);
+	amax_take(rb, ri, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 16)), __builtin_amdgcn_readlane(i, 16));
+	amax_take(rb, ri, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 32)), __builtin_amdgcn_readlane(i, 32));
+	amax_take(rb, ri, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 48)), __builtin_amdgcn_readlane(i, 48));
+	b = rb; i = ri;
+}
+// wave-cooperative scan (all lanes the same shape and direction): strided partial arg-max + wave_argmax; ties go to the lower index
 __device__ __forceinline__ v3 support_inner_wave(const support_t &s, v3 dir, int lane)
 {
 	const v3 dl = qrot(qconj(s.q), dir);
@@ -100,12 +126,7 @@ __device__ __forceinline__ v3 support_inner_wave(const support_t &s, v3 dir, int
 		float d = dot(V3(q.x, q.y, q.z), dl);
 		if (bi == 0x7fffffff || best < d) { best = d; bi = i; }
 	}
-#pragma unroll
-	for (int o = 32; o >= 1; o >>= 1)
-	{
-		float ob = __shfl_xor(best, o); int oi = __shfl_xor(bi, o);
-		if (oi != 0x7fffffff && (bi == 0x7fffffff || best < ob || (ob == best && oi < bi))) { best = ob; bi = oi; }
-	}
+	wave_argmax(best, bi);
 	float4 q = vs[bi];
 	return s.pos + qrot(s.q, V3(q.x, q.y, q.z));
 }
@@ -231,68 +252,93 @@ __device__ int gjk_run(const support_t &A, const support_t &B, float cutoff, gjk
 // ---- expanding polytope, wave-cooperative on a per-wave LDS mesh (hull.h:233-310) ---------------------------------------
 #define EPA_MAXT 192
 #define EPA_MAXV 96
-struct epa_mem { short tv[EPA_MAXT][3]; short tn[EPA_MAXT][3]; float vx[EPA_MAXV], vy[EPA_MAXV], vz[EPA_MAXV]; };
+// A triangle is one 16-byte record (vertex ids, pad, neighbour ids, pad) so that the mesh surgery, which is a chain of dependent look-ups,
+// fetches a whole triangle with one 128-bit LDS read and decides in registers; neighbour slots are patched with 16-bit stores.
+struct __attribute__((aligned(16))) epa_tri { short v[3], pad0, n[3], pad1; };
+struct epa_mem { epa_tri t[EPA_MAXT]; float vx[EPA_MAXV], vy[EPA_MAXV], vz[EPA_MAXV]; };
+struct tri_r { int v0, v1, v2, n0, n1, n2; };
 // the mesh surgery is executed by every lane on the same values (same stores from all lanes), so each lane's own program order keeps it coherent
 __device__ __forceinline__ v3 ev(const epa_mem &m, int i) { return V3(m.vx[i], m.vy[i], m.vz[i]); }
-__device__ __forceinline__ bool tri_dead(const epa_mem &m, int t) { return m.tn[t][0] == -1; }
-__device__ __forceinline__ bool hasvert(const epa_mem &m, int t, int x) { return m.tv[t][0] == x || m.tv[t][1] == x || m.tv[t][2] == x; }
-__device__ short *neib(epa_mem &m, int t, int va, int vb)      // hull.h:97-109
+__device__ __forceinline__ tri_r tri_ld(const epa_mem &m, int t)
 {
-	for (int i = 0; i < 3; i++)
-	{
-		int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
-		if (m.tv[t][i] == va && m.tv[t][i1] == vb) return &m.tn[t][i2];
-		if (m.tv[t][i] == vb && m.tv[t][i1] == va) return &m.tn[t][i2];
-	}
-	return &m.tn[t][0];      // unreachable for a consistent mesh (the reference asserts)
+	const int4 q = *reinterpret_cast<const int4 *>(&m.t[t]);
+	tri_r r = { (int)(short)(q.x & 0xffff), q.x >> 16, (int)(short)(q.y & 0xffff), (int)(short)(q.z & 0xffff), q.z >> 16, (int)(short)(q.w & 0xffff) };
+	return r;
 }
-__device__ void tri_set(epa_mem &m, int t, int a, int b, int c, int n0, int n1, int n2)
+__device__ __forceinline__ void tri_set(epa_mem &m, int t, int a, int b, int c, int n0, int n1, int n2)
 {
-	m.tv[t][0] = a; m.tv[t][1] = b; m.tv[t][2] = c; m.tn[t][0] = n0; m.tn[t][1] = n1; m.tn[t][2] = n2;
+	*reinterpret_cast<int4 *>(&m.t[t]) = make_int4((a & 0xffff) | (b << 16), c & 0xffff, (n0 & 0xffff) | (n1 << 16), n2 & 0xffff);
 }
-__device__ void nnfix(epa_mem &m, int k)      // hull.h:112-127
+__device__ __forceinline__ void tri_kill(epa_mem &m, int t) { *reinterpret_cast<int2 *>(&m.t[t].n[0]) = make_int2(-1, 0xffff); }      // n = -1, -1, -1
+__device__ __forceinline__ bool tri_dead(const epa_mem &m, int t) { return m.t[t].n[0] == -1; }
+__device__ __forceinline__ bool hasvert(const tri_r &T, int x) { return T.v0 == x || T.v1 == x || T.v2 == x; }
+__device__ __forceinline__ int tri_n(const tri_r &T, int slot) { return slot == 0 ? T.n0 : (slot == 1 ? T.n1 : T.n2); }
+// which neighbour slot of T lies across the edge (va, vb), either direction: hull.h:97-109 (edge i -> slot (i+2)%3, first match wins)
+__device__ __forceinline__ int nslot(const tri_r &T, int va, int vb)
 {
-	for (int i = 0; i < 3; i++)
-	{
-		int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
-		if (m.tn[k][i] != -1) *neib(m, m.tn[k][i], m.tv[k][i2], m.tv[k][i1]) = k;
-	}
+	if ((T.v0 == va && T.v1 == vb) || (T.v0 == vb && T.v1 == va)) return 2;
+	if ((T.v1 == va && T.v2 == vb) || (T.v1 == vb && T.v2 == va)) return 0;
+	if ((T.v2 == va && T.v0 == vb) || (T.v2 == vb && T.v0 == va)) return 1;
+	return 0;      // unreachable for a consistent mesh (the reference asserts)
+}
+__device__ __forceinline__ void set_n(epa_mem &m, int t, int slot, int val) { m.t[t].n[slot] = (short)val; }
+// *neib(m, t, va, vb) = val
+__device__ __forceinline__ void patch(epa_mem &m, int t, int va, int vb, int val) { const tri_r T = tri_ld(m, t); set_n(m, t, nslot(T, va, vb), val); }
+// Patches only ever change neighbour ids and nslot() only looks at vertex ids, which are fixed once a triangle exists: the records a step
+// needs for its slot look-ups can therefore be fetched together up front (independent LDS reads in flight) instead of one after another.
+__device__ void nnfix_rec(epa_mem &m, int k, const tri_r &K)      // hull.h:112-127 for the triangle k whose record is K
+{
+	tri_r R0, R1, R2;
+	if (K.n0 != -1) R0 = tri_ld(m, K.n0);
+	if (K.n1 != -1) R1 = tri_ld(m, K.n1);
+	if (K.n2 != -1) R2 = tri_ld(m, K.n2);
+	if (K.n0 != -1) set_n(m, K.n0, nslot(R0, K.v2, K.v1), k);
+	if (K.n1 != -1) set_n(m, K.n1, nslot(R1, K.v0, K.v2), k);
+	if (K.n2 != -1) set_n(m, K.n2, nslot(R2, K.v1, K.v0), k);
 }
 __device__ void swapn(epa_mem &m, int a, int b)      // hull.h:128-134 (the ids are swapped back by the reference's second std::swap)
 {
-	for (int i = 0; i < 3; i++) { short t = m.tv[a][i]; m.tv[a][i] = m.tv[b][i]; m.tv[b][i] = t; t = m.tn[a][i]; m.tn[a][i] = m.tn[b][i]; m.tn[b][i] = t; }
-	nnfix(m, a); nnfix(m, b);
+	const int4 ra = *reinterpret_cast<const int4 *>(&m.t[a]), rb = *reinterpret_cast<const int4 *>(&m.t[b]);
+	*reinterpret_cast<int4 *>(&m.t[a]) = rb; *reinterpret_cast<int4 *>(&m.t[b]) = ra;
+	nnfix_rec(m, a, tri_ld(m, a));
+	nnfix_rec(m, b, tri_ld(m, b));      // fetched after a's patches: b can be a neighbour of a
 }
 __device__ void b2bfix(epa_mem &m, int s, int t)      // hull.h:136-150
 {
 	for (int i = 0; i < 3; i++)
 	{
-		int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
-		int va = m.tv[s][i1], vb = m.tv[s][i2];
-		*neib(m, *neib(m, s, va, vb), vb, va) = *neib(m, t, vb, va);
-		*neib(m, *neib(m, t, vb, va), va, vb) = *neib(m, s, va, vb);
+		tri_r S = tri_ld(m, s), T = tri_ld(m, t);      // fresh neighbour ids: the previous round may have patched s or t
+		const int va = i == 0 ? S.v1 : (i == 1 ? S.v2 : S.v0), vb = i == 0 ? S.v2 : (i == 1 ? S.v0 : S.v1);      // tv[s][(i+1)%3], tv[s][(i+2)%3]
+		const int ss = nslot(S, va, vb), ts = nslot(T, vb, va);
+		const int X = tri_n(S, ss), Y = tri_n(T, ts);
+		const tri_r RX = tri_ld(m, X), RY = tri_ld(m, Y);
+		set_n(m, X, nslot(RX, vb, va), Y);                       // *neib(*neib(s, va, vb), vb, va) = *neib(t, vb, va)
+		int sval = X, yy = Y;
+		if (X == s || X == t) { S = tri_ld(m, s); T = tri_ld(m, t); sval = tri_n(S, ss); yy = tri_n(T, ts); }      // the store above hit s or t itself
+		set_n(m, yy, nslot(yy == Y ? RY : tri_ld(m, yy), va, vb), sval);      // *neib(*neib(t, vb, va), va, vb) = *neib(s, va, vb)
 	}
-	for (int i = 0; i < 3; i++) { m.tn[s][i] = -1; m.tn[t][i] = -1; }
+	tri_kill(m, s); tri_kill(m, t);
 }
 __device__ bool extrude(epa_mem &m, int &nt, int t0, int v)      // hull.h:167-186
 {
 	if (nt + 3 > EPA_MAXT) return false;
-	int t[3] = { m.tv[t0][0], m.tv[t0][1], m.tv[t0][2] };
-	int b = nt;
-	int n[3] = { m.tn[t0][0], m.tn[t0][1], m.tn[t0][2] };
-	tri_set(m, nt++, v, t[1], t[2], n[0], b + 1, b + 2); *neib(m, n[0], t[1], t[2]) = b + 0;
-	tri_set(m, nt++, v, t[2], t[0], n[1], b + 2, b + 0); *neib(m, n[1], t[2], t[0]) = b + 1;
-	tri_set(m, nt++, v, t[0], t[1], n[2], b + 0, b + 1); *neib(m, n[2], t[0], t[1]) = b + 2;
-	m.tn[t0][0] = m.tn[t0][1] = m.tn[t0][2] = -1;
-	if (hasvert(m, n[0], v)) b2bfix(m, b + 0, n[0]);
-	if (hasvert(m, n[1], v)) b2bfix(m, b + 1, n[1]);
-	if (hasvert(m, n[2], v)) b2bfix(m, b + 2, n[2]);
+	const tri_r T0 = tri_ld(m, t0);
+	const tri_r R0 = tri_ld(m, T0.n0), R1 = tri_ld(m, T0.n1), R2 = tri_ld(m, T0.n2);
+	const int b = nt;
+	tri_set(m, nt++, v, T0.v1, T0.v2, T0.n0, b + 1, b + 2); set_n(m, T0.n0, nslot(R0, T0.v1, T0.v2), b + 0);
+	tri_set(m, nt++, v, T0.v2, T0.v0, T0.n1, b + 2, b + 0); set_n(m, T0.n1, nslot(R1, T0.v2, T0.v0), b + 1);
+	tri_set(m, nt++, v, T0.v0, T0.v1, T0.n2, b + 0, b + 1); set_n(m, T0.n2, nslot(R2, T0.v0, T0.v1), b + 2);
+	tri_kill(m, t0);
+	if (hasvert(R0, v)) b2bfix(m, b + 0, T0.n0);
+	if (hasvert(R1, v)) b2bfix(m, b + 1, T0.n1);
+	if (hasvert(R2, v)) b2bfix(m, b + 2, T0.n2);
 	return true;
 }
 __device__ __forceinline__ bool above(const epa_mem &m, int t, v3 p, float epsilon)      // hull.h:50-54
 {
-	v3 n = tri_normal(ev(m, m.tv[t][0]), ev(m, m.tv[t][1]), ev(m, m.tv[t][2]));
-	return dot(n, p - ev(m, m.tv[t][0])) > epsilon;
+	const tri_r T = tri_ld(m, t);
+	v3 n = tri_normal(ev(m, T.v0), ev(m, T.v1), ev(m, T.v2));
+	return dot(n, p - ev(m, T.v0)) > epsilon;
 }
 // all 64 lanes call this with identical arguments
 __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 s2, v3 s3, const support_t &A, const support_t &B, int lane, long long *ec)
@@ -315,16 +361,17 @@ __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 
 		float bd = 0.0f; int bi = 0x7fffffff; v3 bn = V3(0, 0, 0);
 		for (int i = lane; i < nt; i += 64)
 		{
-			v3 n = tri_normal(ev(m, m.tv[i][0]), ev(m, m.tv[i][1]), ev(m, m.tv[i][2]));
-			float d = -dot(n, ev(m, m.tv[i][0]));
+			const tri_r T = tri_ld(m, i);
+			v3 n = tri_normal(ev(m, T.v0), ev(m, T.v1), ev(m, T.v2));
+			float d = -dot(n, ev(m, T.v0));
 			if (d > -FLT_MAX && (bi == 0x7fffffff || d > bd)) { bd = d; bi = i; bn = n; }
 		}
-#pragma unroll
-		for (int o = 32; o >= 1; o >>= 1)
+		wave_argmax(bd, bi);
+		if (bi != 0x7fffffff)      // the winner's normal sits in the lane that scored it (triangle i was scored by lane i % 64)
 		{
-			float ob = __shfl_xor(bd, o); int oi = __shfl_xor(bi, o);
-			float ox = __shfl_xor(bn.x, o), oy = __shfl_xor(bn.y, o), oz = __shfl_xor(bn.z, o);
-			if (oi != 0x7fffffff && (bi == 0x7fffffff || ob > bd || (ob == bd && oi < bi))) { bd = ob; bi = oi; bn = V3(ox, oy, oz); }
+			const int src = __builtin_amdgcn_readfirstlane(bi) & 63;
+			bn = V3(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(bn.x), src)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bn.y), src)),
+			        __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bn.z), src)));
 		}
 		v4 face = (bi == 0x7fffffff) ? V4(0, 0, 0, -FLT_MAX) : V4(bn, bd);
 		if (ec) { const long long t = clock64(); ec[3] += t - tm; tm = t; ec[6] += 1; }
@@ -357,12 +404,13 @@ __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 
 		int j = nt;
 		while (okk && j--)
 		{
-			if (tri_dead(m, j)) continue;
-			if (!hasvert(m, j, vid)) break;
-			v3 a = ev(m, m.tv[j][0]), b = ev(m, m.tv[j][1]), c = ev(m, m.tv[j][2]);
+			const tri_r J = tri_ld(m, j);
+			if (J.n0 == -1) continue;
+			if (!hasvert(J, vid)) break;
+			v3 a = ev(m, J.v0), b = ev(m, J.v1), c = ev(m, J.v2);
 			if (above(m, j, center, 0.01f * epsilon) || length(cross(b - a, c - b)) < epsilon * epsilon * 0.1f)
 			{
-				int nb = m.tn[j][0];
+				int nb = J.n0;
 				okk = extrude(m, nt, nb, vid);
 				j = nt;
 			}
