@@ -98,6 +98,22 @@ def test_cxx_compat_header_compiles_and_links(tmp_path):
         assert r.returncode == 1 and "no HIP device" in r.stdout      # fails loudly, no fallback
 
 
+@pytest.mark.gpu
+def test_cxx_compat_example_runs_on_the_device(tmp_path):
+    """The reference-named C++ surface end to end: CNN::Eval, HandTracker::update on a 64x64 and on a 128x128 frame, CNN::Train, saveb."""
+    from hand_tracking_samples_amd import native, weights as W
+    native.load()
+    exe = str(tmp_path / "compat")
+    libdir = os.path.dirname(native.lib_path())
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", os.path.join(ROOT, "tests", "cxx_compat_example.cpp"), "-o", exe, "-L" + libdir, "-lht_mi355x", "-Wl,-rpath," + libdir])
+    cnnb = str(tmp_path / "w.cnnb")
+    W.save_cnnb(cnnb, W.make_cnnb())
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "model_hand17.htfx"), cnnb], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0
+    assert "bones=17" in r.stdout and "full frame bones=17 cnn_input 64x64" in r.stdout and "train mse=" in r.stdout and "saved=37833600" in r.stdout
+
+
 def test_config_read_follows_the_reference_decoder(tmp_path):
     """load_config (handtrack.h:822-828): listed fields are assigned from the file, a missing member reads as 0, a missing file is ignored."""
     from hand_tracking_samples_amd import native

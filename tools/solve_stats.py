@@ -16,7 +16,7 @@ idx = np.arange(B) % len(d["depth"])
 depth, cams, start = d["depth"][idx], d["cam"][idx], d["startpose"][idx]
 ctx = native.Context(os.path.join(ROOT, "tests", "golden", "model_hand26.htfx" if CFG5 else "model_hand17.htfx"), B)
 ctx.load_weights(weights.make_cnnb())
-ctx.set_params(microforce=3.0, mainthreadpasses=3)
+ctx.set_params(microforce=3.0, mainthreadpasses=int(os.environ.get('PASSES', '3')))
 ctx.debug_solve_stats(B, reset=True); ctx.debug_contact_stats(B, reset=True)
 for it in range(2):
     ctx.tracker_reset(start)
