@@ -43,6 +43,7 @@
 
 struct lds_t
 {
+	float pool[POOL_FLOATS] __attribute__((aligned(16)));      // first member: row addresses then fit the short offsets of two-address LDS reads
 	// body state in 16-byte records: component c of body b is word 4*b + c
 	float4 lin4[HT_MAXNB];                 // xyz linear momentum, w = massinv
 	float4 ang4[HT_MAXNB];                 // xyz angular momentum, w = friction
@@ -68,7 +69,6 @@ struct lds_t
 		};
 		float arec[(MAXA_LDS + 2) * AROW];         // sweeps: angular row records (written once the prologue scratch is dead) + the idle record + read-ahead slack
 	};
-	float pool[POOL_FLOATS] __attribute__((aligned(16)));
 };
 
 #include "ht_quad.hpp"
