@@ -667,6 +667,18 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 					float rvA = pv[0], nA = pn[0]; float4 tA = *reinterpret_cast<const float4 *>(pt);
 					float rvB = pv[CROW], nB = pn[CROW]; float4 tB = *reinterpret_cast<const float4 *>(pt + CROW);
 					int k = 0;
+					for (; k + 4 <= nl; k += 4)      // four rows per trip (loop control is a tenth of a row's instructions), records two rows ahead
+					{
+						pt[3] = row_step(rvA, nA, tA);
+						rvA = pv[2 * CROW]; nA = pn[2 * CROW]; tA = *reinterpret_cast<const float4 *>(pt + 2 * CROW);
+						pt[CROW + 3] = row_step(rvB, nB, tB);
+						rvB = pv[3 * CROW]; nB = pn[3 * CROW]; tB = *reinterpret_cast<const float4 *>(pt + 3 * CROW);
+						pt[2 * CROW + 3] = row_step(rvA, nA, tA);
+						rvA = pv[4 * CROW]; nA = pn[4 * CROW]; tA = *reinterpret_cast<const float4 *>(pt + 4 * CROW);
+						pt[3 * CROW + 3] = row_step(rvB, nB, tB);
+						rvB = pv[5 * CROW]; nB = pn[5 * CROW]; tB = *reinterpret_cast<const float4 *>(pt + 5 * CROW);
+						pv += 4 * CROW; pn += 4 * CROW; pt += 4 * CROW;
+					}
 					for (; k + 2 <= nl; k += 2)
 					{
 						pt[3] = row_step(rvA, nA, tA);
