@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 	const m3 tinv = GM(M.ub_tinv);
 	const m3 Iinv = world_inertia(ubq, tinv, minv);
 	(void)scratch; (void)scratch_stride;
-	__shared__ __attribute__((aligned(16))) float urow[HT_MAXPTS / 4 + 2][12];  // rows of this solve (<= 256: every 4th of <= 1024 points) + read-ahead slack
+	__shared__ __attribute__((aligned(16))) float urow[HT_MAXPTS / 4 + 6][12];  // rows of this solve (every 4th of <= 4096 points) + read-ahead slack
 	const int nr = n < HT_MAXPTS / 4 ? n : HT_MAXPTS / 4;
 	for (int i = lane; i < nr; i += 64)     // re-express every cloud row on the proxy body and pre-compute (handtrack.h:457-462)
 	{
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 		o[1] = make_float4(nrm.x, nrm.y, nrm.z, fmin_std(ts, r[12]));
 		o[2] = make_float4(r[13] * dt, r[14] * dt, impulsed, 0.0f);
 	}
-	if (lane < 24) urow[nr + lane / 12][lane % 12] = 0.0f;      // the sweep reads one record ahead
+	for (int i = lane; i < 72; i += 64) urow[nr + i / 12][i % 12] = 0.0f;      // the sweep reads up to six records ahead
 	__syncthreads();
 	if (lane < 4)       // the proxy body in quad layout (ht_quad.hpp): lane c < 3 owns component c, lane 3 carries the row's target speed
 	{
@@ -188,12 +188,28 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 			const int tsoff = sweep >= ph.iterations ? 1 : 0;        // RemoveBias: lane 3 switches to ts_post
 			const float *pv = &urow[0][0] + (c < 3 ? c : 3 + 4 * tsoff), *pnm = &urow[0][0] + 4 + c;
 			float *pt = &urow[0][0] + 8;
-			float rv = pv[0], n = pnm[0]; float4 t = *reinterpret_cast<const float4 *>(pt);
-			for (int k = 0; k < nr; k++)
+			// as k_solve's chains: two register sets, records fetched two rows ahead, four rows per trip
+			float rvA = pv[0], nA = pnm[0]; float4 tA = *reinterpret_cast<const float4 *>(pt);
+			float rvB = pv[12], nB = pnm[12]; float4 tB = *reinterpret_cast<const float4 *>(pt + 12);
+			int k = 0;
+			for (; k + 4 <= nr; k += 4)
 			{
-				const float nrv = pv[12], nn = pnm[12]; const float4 nt = *reinterpret_cast<const float4 *>(pt + 12);
-				pt[3] = quad_row_step(qb, rv, n, t);
-				rv = nrv; n = nn; t = nt; pv += 12; pnm += 12; pt += 12;
+				pt[3] = quad_row_step(qb, rvA, nA, tA);
+				rvA = pv[24]; nA = pnm[24]; tA = *reinterpret_cast<const float4 *>(pt + 24);
+				pt[15] = quad_row_step(qb, rvB, nB, tB);
+				rvB = pv[36]; nB = pnm[36]; tB = *reinterpret_cast<const float4 *>(pt + 36);
+				pt[27] = quad_row_step(qb, rvA, nA, tA);
+				rvA = pv[48]; nA = pnm[48]; tA = *reinterpret_cast<const float4 *>(pt + 48);
+				pt[39] = quad_row_step(qb, rvB, nB, tB);
+				rvB = pv[60]; nB = pnm[60]; tB = *reinterpret_cast<const float4 *>(pt + 60);
+				pv += 48; pnm += 48; pt += 48;
+			}
+			for (; k < nr; k++)
+			{
+				pt[3] = quad_row_step(qb, rvA, nA, tA);
+				rvA = rvB; nA = nB; tA = tB;
+				rvB = pv[24]; nB = pnm[24]; tB = *reinterpret_cast<const float4 *>(pt + 24);
+				pv += 12; pnm += 12; pt += 12;
 			}
 			if (sweep + 1 == ph.iterations)
 			{
