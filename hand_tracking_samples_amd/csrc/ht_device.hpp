@@ -4,7 +4,7 @@
 //   constants  : model (vertices, planes, per-body and per-joint constants), CNN weights (37.8 MB, conv2 repacked k-major)
 //   per slot   : handmodel / othermodel state [nb][16] floats (pos3 quat4 linmom3 angmom3 pad3), prev_frame_error, initializing
 //   per frame  : depth u16[4096] (only for host-buffer calls), cam[12], cnn_in[4096], act1[3600], act2[2304], act3[2048],
-//                logits/cnn_out[2304], analysis[84], points float4[1024] + count, cloud rows [1024][16], chamber rows [5*nb][16],
+//                logits/cnn_out[2304], analysis[84], points float4[HT_MAXPTS] + count, cloud rows [HT_MAXPTS][16], chamber rows [5*nb][16],
 //                contacts, solver scratch (pre-computed row stream)
 #pragma once
 #include <hip/hip_runtime.h>
