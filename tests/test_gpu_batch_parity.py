@@ -16,7 +16,7 @@ import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-N = 96
+N = 256
 
 
 def test_batch_against_restatement(weights):
