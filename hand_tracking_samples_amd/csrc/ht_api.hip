@@ -165,6 +165,10 @@ extern "C" int ht_config_read(const char *jsonfile, ht_params *p, float *segment
 	if (!ht_json_top_level(jsonfile, num, err)) { fprintf(stderr, "ht_config_read: %s\n", err.c_str()); return HT_ERR_IO; }
 	auto F = [&](const char *k) -> float { auto it = num.find(k); return it == num.end() ? 0.0f : strtof(it->second.c_str(), nullptr); };       // istringstream >> float
 	auto I = [&](const char *k) -> int { auto it = num.find(k); return it == num.end() ? 0 : (int)strtol(it->second.c_str(), nullptr, 10); };    // istringstream >> int
+	// The one option of the tracker that is not built: voxel sub-sampling of the main-thread cloud (physmodel.h:66-118, default off, no
+	// application sets it).  It converts negative floats to unsigned int (undefined behaviour in C++), so there is no reference result to
+	// reproduce beyond one compiler's; a configuration that asks for it is refused instead of being silently run with the spatial rule.
+	if (I("subsample_voxel") != 0) { fprintf(stderr, "ht_config_read: %s sets subsample_voxel, which this library does not implement\n", jsonfile); return HT_ERR_ARG; }
 	if (segment_scale) *segment_scale = F("segment_scale");
 	p->full_reset_on_error = F("full_reset_on_error"); p->angles_only = I("angles_only") != 0; p->always_take_cnn = I("always_take_cnn"); p->drangey = F("drangey");
 	p->boundary_planes = I("boundary_planes"); p->microforce = F("microforce"); p->mainthreadpasses = I("mainthreadpasses"); p->subsample_fraction = I("subsample_fraction");

@@ -123,7 +123,9 @@ struct HandTracker                                                              
 		float pfe = 0.0f; float seg = segment_scale; int ini = 0;
 		check(ctx_, ht_get_tracker_flags(ctx_, 0, 1, &pfe, &ini));
 		const float pfe0 = pfe;
-		if (ht_config_read(jsonfile.c_str(), &p, &seg, &pfe) != HT_OK) throw std::runtime_error("json parse error - " + jsonfile);
+		const int rc = ht_config_read(jsonfile.c_str(), &p, &seg, &pfe);
+		if (rc == HT_ERR_ARG) throw std::runtime_error("unsupported option (subsample_voxel) in " + jsonfile);
+		if (rc != HT_OK) throw std::runtime_error("json parse error - " + jsonfile);
 		segment_scale = seg;
 		full_reset_on_error = p.full_reset_on_error; angles_only = p.angles_only != 0; always_take_cnn = p.always_take_cnn != 0; drangey = p.drangey; boundary_planes = p.boundary_planes;
 		microforce = p.microforce; cloudforce_max_point = p.cloudforce_max_point; cloudforce_max_sum = p.cloudforce_max_sum; mainthreadpasses = p.mainthreadpasses;

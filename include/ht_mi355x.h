@@ -90,7 +90,8 @@ int ht_scale(ht_ctx *ctx, float s);
 /* ht_config_read  replaces  HandTracker::load_config(const std::string &jsonfile) (handtrack.h:822-828): host only.  Applies the file to
  *                *params the way the reference's field decoder does: every field of visit_fields (handtrack.h:549-581) is assigned, one that
  *                the file does not give as a number becomes 0; a missing file leaves everything untouched.  segment_scale and
- *                prev_frame_error (optional) are the two listed fields that live outside ht_params. */
+ *                prev_frame_error (optional) are the two listed fields that live outside ht_params.  A file that sets subsample_voxel (the
+ *                optional voxel sub-sampling of physmodel.h:66-118, not implemented) is refused with HT_ERR_ARG. */
 int ht_config_read(const char *jsonfile, ht_params *params, float *segment_scale, float *prev_frame_error);
 
 /* ---- CNN ---------------------------------------------------------------------------------------------------------

@@ -129,6 +129,8 @@ def test_config_read_follows_the_reference_decoder(tmp_path):
     assert p.microforce == 3.0 and abs(p.drangey - 0.65) < 1e-7 and p.steps == 4 and p.always_take_cnn == 1 and p.physics_iterations == 12
     assert abs(seg.value - 0.2) < 1e-7
     assert p.mainthreadpasses == 0 and p.min_point_num == 0 and pfe.value == 0.0      # not in the file: the reference's decoder reads 0
+    vox = tmp_path / "voxel.json"; vox.write_text('{"microforce": 3, "subsample_voxel": 1, "subsample_size": 0.01}')
+    assert L.ht_config_read(str(vox).encode(), C.byref(p), C.byref(seg), C.byref(pfe)) == 1      # HT_ERR_ARG: the voxel option is refused, not ignored
     bad = tmp_path / "bad.json"; bad.write_text('{"microforce": ')
     assert L.ht_config_read(str(bad).encode(), C.byref(p), C.byref(seg), C.byref(pfe)) != 0
 
