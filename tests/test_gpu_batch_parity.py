@@ -47,3 +47,30 @@ def test_batch_against_restatement(weights):
     assert loose.sum() >= N - 2, "more than 2 of %d frames outside 2e-4 m / 2e-3: %s" % (N, np.nonzero(~loose)[0])
     assert tight.sum() >= N * 3 // 4
     assert dp.max() < 5e-3      # even a flipped decision stays a small pose change on these frames
+
+
+def test_full_size_batch_properties(weights):
+    """BASELINE configs[2] at its full size (1024 frames = the 256 bench frames four times): size-independent properties instead of a
+    frame-by-frame oracle run.  (1) A frame's result does not depend on where it sits in the batch: the four copies of every frame agree
+    bit for bit.  (2) The whole step is deterministic: a second run from the same start poses reproduces every pose bit for bit (atomics
+    are only used where the order cannot matter).  (3) Every pose is finite with unit quaternions."""
+    from hand_tracking_samples_amd import native
+    B = 1024
+    d = np.load(os.path.join(HERE, "golden", "frames256.npz"))
+    idx = np.arange(B) % 256
+    depth, cams, start = d["depth"][idx].reshape(B, -1), d["cam"][idx], d["startpose"][idx]
+    ctx = native.Context(ol.MODEL, B)
+    try:
+        ctx.load_weights(weights)
+        ctx.set_params(microforce=3.0, mainthreadpasses=3)
+        ctx.tracker_reset(start)
+        a = ctx.update_sync(depth, cams)
+        ctx.tracker_reset(start)
+        b = ctx.update_sync(depth, cams)
+    finally:
+        ctx.close()
+    assert np.array_equal(a, b)
+    for k in range(1, 4):
+        assert np.array_equal(a[:256], a[256 * k:256 * (k + 1)])
+    assert np.isfinite(a).all()
+    assert np.abs(np.linalg.norm(a[:, :, 3:], axis=2) - 1.0).max() < 1e-5
