@@ -91,3 +91,29 @@ def test_gpu_full_frame_update_matches_reference(weights, case):
             assert dp <= FULL_POS_TOL and dq <= FULL_QUAT_TOL
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_config5_full_size_properties(weights):
+    """BASELINE configs[4] at bench size (1024 frames of 128x128 = 64 frames sixteen times, 26 bones): a frame's result does not depend on
+    its position in the batch, the step is deterministic, no frame exceeds the point capacity."""
+    from hand_tracking_samples_amd import native
+    B = 1024
+    z = np.load(os.path.join(HERE, "golden", "frames5_64.npz"))
+    idx = np.arange(B) % 64
+    depth, cams, start = z["depth"][idx], z["cam"][idx], z["startpose"][idx]
+    ctx = native.Context(CASES["config5"][1], B)
+    try:
+        ctx.load_weights(weights)
+        ctx.set_params(microforce=3.0, mainthreadpasses=3)
+        ctx.tracker_reset(start)
+        a = ctx.update_frames_sync(depth, cams, 0.17)
+        ctx.tracker_reset(start)
+        b = ctx.update_frames_sync(depth, cams, 0.17)
+        assert ctx.frames_overflow() == 0
+    finally:
+        ctx.close()
+    assert np.array_equal(a, b)
+    for k in range(1, 16):
+        assert np.array_equal(a[:64], a[64 * k:64 * (k + 1)])
+    assert np.isfinite(a).all() and np.abs(np.linalg.norm(a[:, :, 3:], axis=2) - 1.0).max() < 1e-5
