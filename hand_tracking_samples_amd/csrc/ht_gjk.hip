@@ -509,14 +509,17 @@ __device__ void separated_wave(bool run, const support_t &A, const support_t &B,
 
 // ------------------------------------------------------------------------------------------------- k_contacts
 #define GJK_FRAMES 2        // frames per block sharing the LDS vertex copy
-#define GJK_WPF 1           // waves per frame (2 was measured slower: the support scans are bound by LDS throughput per CU, not by lanes)
-#define GJK_LANES (64 * GJK_WPF)
-struct gjk_frame_mem { float P[HT_MAXNB][8]; unsigned char cand[HT_MAXNB * (HT_MAXNB - 1) / 2][2]; int ncand, nchunk, cnt[GJK_WPF]; };      // poses (pos3 q4 radius), candidate pairs
+// Waves per frame (template parameter GJK_WPF): the per-lane support scans are bound by the CU's LDS throughput, so for the 17-bone hand (about
+// 23 candidate pairs per frame: two or four lanes per pair on one wave) a second wave is slower (contacts 2.10 -> 2.39 ms per step); with 26
+// bones (325 pairs, about 58 candidates per frame: one lane per pair) the second wave wins (9.2 -> 6.8 ms).  The launcher picks by pair count.
+#define GJK_MAXWPF 2
+struct gjk_frame_mem { float P[HT_MAXNB][8]; unsigned char cand[HT_MAXNB * (HT_MAXNB - 1) / 2][2]; int ncand, nchunk, cnt[GJK_MAXWPF]; };      // poses (pos3 q4 radius), candidate pairs
 __host__ __device__ inline size_t gjk_frame_stride() { return (sizeof(gjk_frame_mem) + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t gjk_wave_stride() { return (sizeof(epa_mem) + 15) & ~(size_t)15; }
-__global__ __launch_bounds__(64 * GJK_FRAMES * GJK_WPF) void k_contacts(ht_model_dev M, const float *__restrict__ state, float driftmax, float jiggle_sin, const int *__restrict__ active_flag,
+template <int GJK_WPF> __global__ __launch_bounds__(64 * GJK_FRAMES * GJK_WPF) void k_contacts(ht_model_dev M, const float *__restrict__ state, float driftmax, float jiggle_sin, const int *__restrict__ active_flag,
                                                                         float *__restrict__ contacts, int *__restrict__ ncontacts, int B, int dbg)
 {
+	constexpr int GJK_LANES = 64 * GJK_WPF;
 	const int nvert = M.vert_off[M.nb];
 	float4 *sverts = g_sm;
 	unsigned char *fbase = reinterpret_cast<unsigned char *>(g_sm + nvert);
@@ -654,7 +657,15 @@ void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftma
 	static int dbg = -1;
 	static bool attr_set = false;
 	if (dbg < 0) { const char *e = getenv("HT_DEBUG_SKIP"); dbg = e ? atoi(e) : 0; }
-	const size_t smem = (size_t)M.vert_off[M.nb] * sizeof(float4) + GJK_FRAMES * gjk_frame_stride() + GJK_FRAMES * GJK_WPF * gjk_wave_stride();
-	if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_contacts), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-	hipLaunchKernelGGL(k_contacts, dim3((B + GJK_FRAMES - 1) / GJK_FRAMES), dim3(64 * GJK_FRAMES * GJK_WPF), smem, s, M, state, driftmax, jiggle_sin, active_flag, contacts, ncontacts, B, dbg);
+	const int wpf = M.nb * (M.nb - 1) / 2 > 200 ? 2 : 1;
+	const size_t smem = (size_t)M.vert_off[M.nb] * sizeof(float4) + GJK_FRAMES * gjk_frame_stride() + GJK_FRAMES * wpf * gjk_wave_stride();
+	if (!attr_set)
+	{
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_contacts<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_contacts<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		attr_set = true;
+	}
+	const dim3 grid((B + GJK_FRAMES - 1) / GJK_FRAMES);
+	if (wpf == 2) hipLaunchKernelGGL(k_contacts<2>, grid, dim3(64 * GJK_FRAMES * 2), smem, s, M, state, driftmax, jiggle_sin, active_flag, contacts, ncontacts, B, dbg);
+	else hipLaunchKernelGGL(k_contacts<1>, grid, dim3(64 * GJK_FRAMES), smem, s, M, state, driftmax, jiggle_sin, active_flag, contacts, ncontacts, B, dbg);
 }
