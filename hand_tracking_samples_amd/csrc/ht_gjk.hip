@@ -341,8 +341,10 @@ __device__ __forceinline__ bool above(const epa_mem &m, int t, v3 p, float epsil
 	return dot(n, p - ev(m, T.v0)) > epsilon;
 }
 // all 64 lanes call this with identical arguments
-__device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 s2, v3 s3, const support_t &A, const support_t &B, int lane, long long *ec)
+// `capped` is set when the run ends on one of this implementation's capacities (the reference's loop is unbounded, hull.h:246)
+__device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 s2, v3 s3, const support_t &A, const support_t &B, int lane, long long *ec, bool &capped)
 {
+	capped = false;
 	long long tm = ec ? clock64() : 0;
 	v4 plane = V4(0, 0, 0, -FLT_MAX);
 	const float epsilon = 0.001f;
@@ -355,7 +357,8 @@ __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 
 		m.vx[2] = s3.x; m.vy[2] = s3.y; m.vz[2] = s3.z; m.vx[3] = s2.x; m.vy[3] = s2.y; m.vz[3] = s2.z;
 	}
 	tri_set(m, nt++, 2, 3, 1, 2, 3, 1); tri_set(m, nt++, 3, 2, 0, 3, 2, 0); tri_set(m, nt++, 0, 1, 3, 0, 1, 3); tri_set(m, nt++, 1, 0, 2, 1, 0, 2);
-	for (int guard = 0; guard < 128; guard++)
+	int guard = 0;
+	for (; guard < 128; guard++)
 	{
 		// face with the largest plane offset; the sequential scan keeps the first maximum (strict >), hull.h:248-261
 		float bd = 0.0f; int bi = 0x7fffffff; v3 bn = V3(0, 0, 0);
@@ -383,7 +386,7 @@ __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 
 		for (int i = lane; i < nv; i += 64) dup = dup || same(v, ev(m, i));
 		if (__any(dup)) break;
 		if (plane.w >= face.w - epsilon) break;
-		if (nv >= EPA_MAXV) break;
+		if (nv >= EPA_MAXV) { capped = true; break; }
 		const int vid = nv;
 		m.vx[nv] = v.x; m.vy[nv] = v.y; m.vz[nv] = v.z; nv++;
 		// Which triangles see the new vertex is tested one triangle per lane (vertices of existing triangles never change, and a triangle
@@ -415,7 +418,7 @@ __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 
 				j = nt;
 			}
 		}
-		if (!okk) break;
+		if (!okk) { capped = true; break; }
 		// compaction (hull.h:300-306): dead triangles are found one per lane; moving the last (live) triangle into a dead slot never
 		// changes which of the lower slots are dead, so the descending scan again only visits the set bits
 		for (int base = ((nt - 1) >> 6) << 6; base >= 0; base -= 64)
@@ -434,6 +437,7 @@ __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 
 		__builtin_amdgcn_wave_barrier();
 		if (ec) { const long long t = clock64(); ec[5] += t - tm; tm = t; }
 	}
+	if (guard == 128) capped = true;
 	return plane;
 }
 // last column of inverse(float4x4({c0,1},{c1,1},{c2,1},{c3,1})) with the cofactor expressions of linalg.h:321-331
@@ -463,7 +467,7 @@ __device__ __forceinline__ support_t bcast(const support_t &s, int src)
 }
 // One GJK run per lane (lanes with run == false idle), then the expanding polytope for the lanes that need it, one pair at a time on the
 // whole wave.  On return status is 0 (hit valid) or 1 (far apart).
-__device__ void separated_wave(bool run, const support_t &A, const support_t &B, float cutoff, epa_mem &em, int lane, int &status, gjk_hit &hit, int dbg, long long *cyc = nullptr)
+__device__ void separated_wave(bool run, const support_t &A, const support_t &B, float cutoff, epa_mem &em, int lane, int &status, gjk_hit &hit, int dbg, long long *cyc = nullptr, int *caps = nullptr)
 {
 	const long long t0 = cyc ? clock64() : 0;
 	simplex tet;
@@ -483,7 +487,9 @@ __device__ void separated_wave(bool run, const support_t &A, const support_t &B,
 		v3 s[4];
 #pragma unroll
 		for (int k = 0; k < 4; k++) s[k] = V3(__shfl(tet.W[k].p.x, src), __shfl(tet.W[k].p.y, src), __shfl(tet.W[k].p.z, src));
-		v4 mpp = (dbg & 32) ? V4(0, 0, 1, -0.001f) : expanding_polytope_wave(em, s[0], s[1], s[2], s[3], Ab, Bb, lane, cyc);
+		bool capped = false;
+		v4 mpp = (dbg & 32) ? V4(0, 0, 1, -0.001f) : expanding_polytope_wave(em, s[0], s[1], s[2], s[3], Ab, Bb, lane, cyc, capped);
+		if (capped && caps && lane == 0) atomicAdd(caps, 1);
 		if (lane == src)
 		{
 			hit.normal = -xyz(mpp);                                  // gjk.h:417-423
@@ -517,7 +523,7 @@ struct gjk_frame_mem { float P[HT_MAXNB][8]; unsigned char cand[HT_MAXNB * (HT_M
 __host__ __device__ inline size_t gjk_frame_stride() { return (sizeof(gjk_frame_mem) + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t gjk_wave_stride() { return (sizeof(epa_mem) + 15) & ~(size_t)15; }
 template <int GJK_WPF> __global__ __launch_bounds__(64 * GJK_FRAMES * GJK_WPF) void k_contacts(ht_model_dev M, const float *__restrict__ state, float driftmax, float jiggle_sin, const int *__restrict__ active_flag,
-                                                                        float *__restrict__ contacts, int *__restrict__ ncontacts, int B, int dbg)
+                                                                        float *__restrict__ contacts, int *__restrict__ ncontacts, int B, int dbg, int *__restrict__ caps)
 {
 	constexpr int GJK_LANES = 64 * GJK_WPF;
 	const int nvert = M.vert_off[M.nb];
@@ -583,7 +589,7 @@ template <int GJK_WPF> __global__ __launch_bounds__(64 * GJK_FRAMES * GJK_WPF) v
 		Bs.voff = M.vert_off[j]; Bs.n = M.vert_off[j + 1] - M.vert_off[j]; Bs.pos = V3(P[j][0], P[j][1], P[j][2]); Bs.q = V4(P[j][3], P[j][4], P[j][5], P[j][6]); Bs.outer = 0; Bs.opos = V3(0, 0, 0); Bs.oq = V4(0, 0, 0, 1); Bs.sub = sub; Bs.grp = grp;
 		gjk_hit hits[5];
 		int hc = 0, status;
-		separated_wave(keep, A, Bs, (dbg & 16) ? 0.0f : driftmax, em, lane, status, hits[0], dbg, stats ? cyc : nullptr);
+		separated_wave(keep, A, Bs, (dbg & 16) ? 0.0f : driftmax, em, lane, status, hits[0], dbg, stats ? cyc : nullptr, caps);
 		const bool touching = keep && status == 0 && !(hits[0].separation > driftmax);      // identical in all members of a group
 		if (touching) hc = 1;
 		const float dmin = fminf(M.bodyc[i * HT_BC + HT_BC_DIAM], M.bodyc[j * HT_BC + HT_BC_DIAM]);
@@ -603,7 +609,7 @@ template <int GJK_WPF> __global__ __launch_bounds__(64 * GJK_FRAMES * GJK_WPF) v
 				xf ar = mul(mul(mul(XF(n * 0.2f, id), XF(-pivot, id)), XF(V3(0, 0, 0), jiggle)), XF(pivot, id));
 				support_t AJ = A; AJ.outer = 1; AJ.opos = ar.p; AJ.oq = ar.q;
 				gjk_hit hj; int st;
-				separated_wave(jig, AJ, Bs, 0.0f, em, lane, st, hj, dbg, stats ? cycj : nullptr);
+				separated_wave(jig, AJ, Bs, 0.0f, em, lane, st, hj, dbg, stats ? cycj : nullptr, caps);
 				if (jig)
 				{
 					hj.normal = n;
@@ -640,7 +646,7 @@ template <int GJK_WPF> __global__ __launch_bounds__(64 * GJK_FRAMES * GJK_WPF) v
 		nout += total;
 		__syncthreads();
 	}
-	if (live && half == 0 && lane == 0) ncontacts[b] = nout < HT_MAXCONTACT ? nout : HT_MAXCONTACT;
+	if (live && half == 0 && lane == 0) { ncontacts[b] = nout < HT_MAXCONTACT ? nout : HT_MAXCONTACT; if (nout > HT_MAXCONTACT && caps) atomicAdd(caps + 1, nout - HT_MAXCONTACT); }
 	if (stats && live && half == 0 && lane == 0 && nout < HT_MAXCONTACT - 1)      // timing experiments: statistics of the frame's first wave accumulate in the last contact slot
 	{
 		float *o = contacts + ((size_t)b * HT_MAXCONTACT + HT_MAXCONTACT - 1) * HT_CONTACT;
@@ -649,11 +655,11 @@ template <int GJK_WPF> __global__ __launch_bounds__(64 * GJK_FRAMES * GJK_WPF) v
 	}
 }
 
-size_t ht_contacts_workspace_bytes(int B) { (void)B; return 16; }      // the polytope mesh lives in LDS now
+size_t ht_contacts_workspace_bytes(int B) { (void)B; return 16; }      // the polytope mesh lives in LDS; the workspace holds two capacity counters (polytope runs cut short, contacts dropped)
 
 void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s)
 {
-	(void)epa_ws;
+	int *caps = reinterpret_cast<int *>(epa_ws);
 	static int dbg = -1;
 	static bool attr_set = false;
 	if (dbg < 0) { const char *e = getenv("HT_DEBUG_SKIP"); dbg = e ? atoi(e) : 0; }
@@ -666,6 +672,6 @@ void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftma
 		attr_set = true;
 	}
 	const dim3 grid((B + GJK_FRAMES - 1) / GJK_FRAMES);
-	if (wpf == 2) hipLaunchKernelGGL(k_contacts<2>, grid, dim3(64 * GJK_FRAMES * 2), smem, s, M, state, driftmax, jiggle_sin, active_flag, contacts, ncontacts, B, dbg);
-	else hipLaunchKernelGGL(k_contacts<1>, grid, dim3(64 * GJK_FRAMES), smem, s, M, state, driftmax, jiggle_sin, active_flag, contacts, ncontacts, B, dbg);
+	if (wpf == 2) hipLaunchKernelGGL(k_contacts<2>, grid, dim3(64 * GJK_FRAMES * 2), smem, s, M, state, driftmax, jiggle_sin, active_flag, contacts, ncontacts, B, dbg, caps);
+	else hipLaunchKernelGGL(k_contacts<1>, grid, dim3(64 * GJK_FRAMES), smem, s, M, state, driftmax, jiggle_sin, active_flag, contacts, ncontacts, B, dbg, caps);
 }

@@ -268,6 +268,19 @@ extern "C" int ht_update_frames_dev(ht_ctx *ctx, const uint16_t *d_depth, const 
 	HIPCHK(ctx, hipGetLastError());
 	return HT_OK;
 }
+// Capacities of the contact kernel that the reference does not have: expanding-polytope runs cut short (128 iterations, 96 vertices, 192
+// triangles in LDS; hull.h:246 loops without bound) and contacts beyond 96 per frame and launch.  Counted since ht_create; 0 on every
+// workload of the test suite and the benches, so no result there depends on them.
+extern "C" int ht_capacity_events(ht_ctx *ctx, int *epa_cut_short, int *contacts_dropped)
+{
+	CHECK_READY(ctx);
+	int v[2] = { 0, 0 };
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	HIPCHK(ctx, hipMemcpy(v, ctx->d_epa_ws, sizeof v, hipMemcpyDeviceToHost));
+	if (epa_cut_short) *epa_cut_short = v[0];
+	if (contacts_dropped) *contacts_dropped = v[1];
+	return HT_OK;
+}
 extern "C" int ht_frames_overflow(ht_ctx *ctx, int *frames_over)
 {
 	CHECK_READY(ctx);

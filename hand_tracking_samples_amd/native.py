@@ -19,7 +19,7 @@ MAXPTS, ROW, CONTACT = 4096, 16, 12      # HT_MAX_POINTS
 SYMBOLS = (
     "ht_create", "ht_destroy", "ht_model_bake", "ht_last_error", "ht_get_params", "ht_set_params", "ht_model_info", "ht_config_read", "ht_scale",
     "ht_cnn_load_weights", "ht_cnn_eval", "ht_cnn_eval_dev", "ht_cnn_train", "ht_cnn_get_weights", "ht_expected_cnn",
-    "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_update_frames_sync", "ht_update_frames_dev", "ht_frames_overflow", "ht_segment_vr", "ht_segment_vr_dev", "ht_slowfit", "ht_set_points",
+    "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_update_frames_sync", "ht_update_frames_dev", "ht_frames_overflow", "ht_capacity_events", "ht_segment_vr", "ht_segment_vr_dev", "ht_slowfit", "ht_set_points",
     "ht_stage_prepare", "ht_stage_decode", "ht_stage_fit_error", "ht_stage_cloud_rows", "ht_stage_contacts", "ht_stage_fit",
     "ht_stage_multistep", "ht_stage_scratch_unibody", "ht_profile_enable", "ht_profile_read", "ht_debug_solve_stats", "ht_debug_contact_stats",
 )
@@ -74,6 +74,7 @@ def load(build_if_missing=True):
     L.ht_update_frames_sync.argtypes = [vp, u16p, fp, C.c_int, C.c_int, C.c_float, C.c_int, fp, fp]
     L.ht_update_frames_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, C.c_int, vp, vp]
     L.ht_frames_overflow.argtypes = [vp, ip]
+    L.ht_capacity_events.argtypes = [vp, ip, ip]
     L.ht_stage_prepare.argtypes = [vp, u16p, fp, C.c_int, fp, fp, ip]
     L.ht_stage_decode.argtypes = [vp, fp, fp, C.c_int, fp]
     L.ht_stage_fit_error.argtypes = [vp, C.c_int, C.c_int, fp]
@@ -228,6 +229,12 @@ class Context:
 
     def update_frames_dev(self, d_depth, d_cams, w, h, segment_scale, d_start, B, d_poses_out, stream):
         self._chk(self.L.ht_update_frames_dev(self.h, d_depth, d_cams, int(w), int(h), float(segment_scale), d_start, B, d_poses_out, stream))
+
+    def capacity_events(self):
+        """(expanding-polytope runs cut short, contacts dropped) since the context was created"""
+        a, b = C.c_int(0), C.c_int(0)
+        self._chk(self.L.ht_capacity_events(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def frames_overflow(self):
         n = C.c_int(0)
