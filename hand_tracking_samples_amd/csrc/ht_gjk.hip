@@ -655,7 +655,7 @@ template <int GJK_WPF> __global__ __launch_bounds__(64 * GJK_FRAMES * GJK_WPF) v
 	}
 }
 
-size_t ht_contacts_workspace_bytes(int B) { (void)B; return 16; }      // the polytope mesh lives in LDS; the workspace holds two capacity counters (polytope runs cut short, contacts dropped)
+size_t ht_contacts_workspace_bytes(int B) { (void)B; return 16; }      // the polytope mesh lives in LDS; the workspace holds the capacity counters (polytope runs cut short, contacts dropped, k_solve's angular overflow)
 
 void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s)
 {

@@ -15,6 +15,7 @@ struct solve_args
 	// slowfit (handtrack.h:786-821): landmark rays from the origin (sf_crays [B][8][4], first sf_ncray used), a bone nailed to a point, and
 	// RelativeAngularConstraints against a reference pose (sf_refpose [B][nb][7], sf_hold = 1 or 2); all off when zero / null
 	const float *sf_crays; int sf_ncray; int sf_select; float sf_spoint[3], sf_rbpoint[3]; const float *sf_refpose; int sf_hold;
+	int *caps;                                                      // capacity counter: frames x launches whose angular rows exceeded the LDS records (may be null)
 	int dbg;                                                        // timing experiments only (HT_DEBUG_SKIP): 1 skip chains, 2 skip two-body linear, 4 skip angular
 };
 

@@ -324,6 +324,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	__syncthreads();
 	const int na_fix = (a.apply_angles ? 12 : 0) + (a.arm_cone ? 1 : 0), na_pre = S.rprefix[nj];      // [ApplyAngles, arm cone | relative rows | joint ranges]
 	int na = S.aprefix[nj];
+	if (na > MAXA_LDS && a.caps && lane == 0) atomicAdd(a.caps, 1);      // more angular rows than the kernel holds: the excess is dropped, and reported
 	if (na > MAXA2) na = MAXA2;
 	arow AR[ASLOTS];
 #pragma unroll

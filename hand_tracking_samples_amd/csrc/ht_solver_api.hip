@@ -20,6 +20,7 @@ static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int 
 	solve_args a;
 	memset(&a, 0, sizeof a);
 	a.sf_select = -1;
+	a.caps = reinterpret_cast<int *>(ctx->d_epa_ws) + 2;
 	a.rows_pre = rows_pre; a.n_pre = n_pre; a.pre_stride = 5 * ctx->model.nb;
 	a.rows_cloud = cloud ? ctx->d_rows : nullptr; a.n_cloud = ctx->d_nrows;
 	a.contacts = contacts ? ctx->d_contacts : nullptr; a.ncontacts = ctx->d_ncontacts;
@@ -269,16 +270,18 @@ extern "C" int ht_update_frames_dev(ht_ctx *ctx, const uint16_t *d_depth, const 
 	return HT_OK;
 }
 // Capacities of the contact kernel that the reference does not have: expanding-polytope runs cut short (128 iterations, 96 vertices, 192
-// triangles in LDS; hull.h:246 loops without bound) and contacts beyond 96 per frame and launch.  Counted since ht_create; 0 on every
+// triangles in LDS; hull.h:246 loops without bound), contacts beyond 96 per frame and launch, and solves whose angular rows exceed the 126
+// the solver keeps (a model with many ranged joints).  Counted since ht_create; 0 on every
 // workload of the test suite and the benches, so no result there depends on them.
-extern "C" int ht_capacity_events(ht_ctx *ctx, int *epa_cut_short, int *contacts_dropped)
+extern "C" int ht_capacity_events(ht_ctx *ctx, int *epa_cut_short, int *contacts_dropped, int *angular_rows_over)
 {
 	CHECK_READY(ctx);
-	int v[2] = { 0, 0 };
+	int v[3] = { 0, 0, 0 };
 	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 	HIPCHK(ctx, hipMemcpy(v, ctx->d_epa_ws, sizeof v, hipMemcpyDeviceToHost));
 	if (epa_cut_short) *epa_cut_short = v[0];
 	if (contacts_dropped) *contacts_dropped = v[1];
+	if (angular_rows_over) *angular_rows_over = v[2];
 	return HT_OK;
 }
 extern "C" int ht_frames_overflow(ht_ctx *ctx, int *frames_over)
@@ -487,6 +490,7 @@ extern "C" int ht_slowfit(ht_ctx *ctx, int B, int hold, const float *refpose, in
 		if (coll) ht_launch_contacts(ctx->model, ctx->d_state[0], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s);
 		solve_args a;
 		memset(&a, 0, sizeof a);
+		a.caps = reinterpret_cast<int *>(ctx->d_epa_ws) + 2;
 		a.rows_cloud = cloud ? ctx->d_rows : nullptr; a.n_cloud = ctx->d_nrows;
 		a.contacts = coll ? ctx->d_contacts : nullptr; a.ncontacts = ctx->d_ncontacts;
 		a.analysis = ctx->d_analysis; a.cams = ctx->d_cams;

@@ -74,7 +74,7 @@ def load(build_if_missing=True):
     L.ht_update_frames_sync.argtypes = [vp, u16p, fp, C.c_int, C.c_int, C.c_float, C.c_int, fp, fp]
     L.ht_update_frames_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, C.c_int, vp, vp]
     L.ht_frames_overflow.argtypes = [vp, ip]
-    L.ht_capacity_events.argtypes = [vp, ip, ip]
+    L.ht_capacity_events.argtypes = [vp, ip, ip, ip]
     L.ht_stage_prepare.argtypes = [vp, u16p, fp, C.c_int, fp, fp, ip]
     L.ht_stage_decode.argtypes = [vp, fp, fp, C.c_int, fp]
     L.ht_stage_fit_error.argtypes = [vp, C.c_int, C.c_int, fp]
@@ -231,10 +231,10 @@ class Context:
         self._chk(self.L.ht_update_frames_dev(self.h, d_depth, d_cams, int(w), int(h), float(segment_scale), d_start, B, d_poses_out, stream))
 
     def capacity_events(self):
-        """(expanding-polytope runs cut short, contacts dropped) since the context was created"""
-        a, b = C.c_int(0), C.c_int(0)
-        self._chk(self.L.ht_capacity_events(self.h, C.byref(a), C.byref(b)))
-        return a.value, b.value
+        """(expanding-polytope runs cut short, contacts dropped, solves with angular rows over capacity) since the context was created"""
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._chk(self.L.ht_capacity_events(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def frames_overflow(self):
         n = C.c_int(0)

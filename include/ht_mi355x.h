@@ -131,8 +131,9 @@ int ht_update_frames_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_ca
 int ht_frames_overflow(ht_ctx *ctx, int *frames_over);
 /* ht_capacity_events  how often, since ht_create, the contact kernel hit a capacity the reference does not have: expanding-polytope runs cut
  *                     short (gjk.h:417 / hull.h:233-310 loop without bound; here at most 128 iterations, 96 vertices, 192 triangles) and contacts
- *                     beyond 96 per frame and launch (physics.h:451-462 keeps them all).  Both are 0 unless a scene is pathological. */
-int ht_capacity_events(ht_ctx *ctx, int *epa_cut_short, int *contacts_dropped);
+ *                     beyond 96 per frame and launch (physics.h:451-462 keeps them all); solves in which a model's angular rows exceeded the 126
+ *                     the solver keeps.  All are 0 unless a scene or a model is out of the ordinary. */
+int ht_capacity_events(ht_ctx *ctx, int *epa_cut_short, int *contacts_dropped, int *angular_rows_over);
 
 /* ---- training ----------------------------------------------------------------------------------------------------------
  * ht_cnn_train        replaces  float CNN::Train(const std::vector<float> &x, const std::vector<float> &t, float alpha) (cnn.h:558-580) called for

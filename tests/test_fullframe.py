@@ -111,7 +111,7 @@ def test_gpu_config5_full_size_properties(weights):
         ctx.tracker_reset(start)
         b = ctx.update_frames_sync(depth, cams, 0.17)
         assert ctx.frames_overflow() == 0
-        assert ctx.capacity_events() == (0, 0)      # no result depends on the contact kernel's capacities
+        assert ctx.capacity_events() == (0, 0, 0)      # no result depends on the contact kernel's capacities
     finally:
         ctx.close()
     assert np.array_equal(a, b)

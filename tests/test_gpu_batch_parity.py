@@ -67,7 +67,7 @@ def test_full_size_batch_properties(weights):
         a = ctx.update_sync(depth, cams)
         ctx.tracker_reset(start)
         b = ctx.update_sync(depth, cams)
-        assert ctx.capacity_events() == (0, 0)      # no result depends on the contact kernel's capacities
+        assert ctx.capacity_events() == (0, 0, 0)      # no result depends on the contact kernel's capacities
     finally:
         ctx.close()
     assert np.array_equal(a, b)
