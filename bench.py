@@ -2,52 +2,96 @@
 """bench.py -- synthetic depth frames/s of the MI355X hand-tracking hot path (CNN + pose solver), 1..8 GPUs of one node.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8                       (starts its own 8 workers; the parent never touches a GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A step = one pass of the whole per-frame path (BASELINE.json configs[2]: depth normalise -> CNN -> decode -> FitError ->
 [reset path] -> 5-step MultiStepSim -> accept -> 3 FitPointCloud passes -> poses) over one batch of independent 64x64
 synthetic frames per GPU, inputs resident in HBM, every tracker re-seeded from its start pose (independent frames).
 Frames are sharded contiguous per rank with no data-path collective; with N>1 the poses are all-gathered over RCCL once
-per step (inside the timed region).  Scaling is weak: --frames-per-gpu (default 1024) is fixed as N grows.
+per step (inside the timed region).  Scaling is weak: --frames-per-gpu (default 1024) is fixed as N grows; BASELINE
+configs[3] (65536 frames over 8 GPUs) is `--gpus 8 --frames-per-gpu 8192`.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP-event timed on the
 stream it runs on) and `cpu_baseline` (the reference's own code from oracle/_ref when present, else the C oracle port).
+The first eight tracker slots of rank 0 carry the frames of tests/golden/golden8.htfx; after the timed loop their poses
+are compared with what the reference produced for them (`verified`), so a number from a build that computes something
+else is reported as such.  Tuning switches of the library (HT_DEBUG_SKIP, HT_NO_SIDE, HT_NO_OVERLAP) make the run refuse.
 """
 import argparse
+import glob
 import json
 import os
+import socket
 import struct
 import subprocess
 import sys
 import tempfile
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3      # dense fp32 MFMA (= fp32 vector) peak
+FP32_VALU_PEAK_TF = 157.3
+CNN_FLOP = {"cnn": 26.47e6,    # 2*(1440000 + 2359296 + 4718592 + 4718592), SURVEY 8(d)
+            "cnn128": 2.0 * (124 * 124 * 25 * 16 + 28 * 28 * 256 * 64 + 12544 * 2048 + 2048 * 2304)}
+TUNING_ENV = ("HT_DEBUG_SKIP", "HT_NO_SIDE", "HT_NO_OVERLAP")
+VERIFY_POS_TOL, VERIFY_QUAT_TOL, VERIFY_CNN_TOL = 2e-4, 2e-3, 2e-5      # the tolerances of tests/test_gpu_solver.py (whole path)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames-per-gpu", type=int, default=1024)
+    ap.add_argument("--workload", default="cnn+solver", choices=["cnn+solver", "cnn", "config5", "config5-cnn128"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the pose gather even with one rank")
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: start N ranks as children of this process, which has not touched a GPU (and never does:
+    no process that has initialised HIP is replaced or re-executed).  Rank 0's JSON line passes through on stdout."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def _tile(a, n):
+    import numpy as np
+    reps = (n + len(a) - 1) // len(a)
+    return np.concatenate([a] * reps)[:n]
 
 
 def _load_frames(n):
+    import numpy as np
     z = np.load(os.path.join(ROOT, "tests", "golden", "frames256.npz"))
-    reps = (n + len(z["depth"]) - 1) // len(z["depth"])
-    tile = lambda a: np.concatenate([a] * reps)[:n]
-    return (tile(z["depth"].reshape(-1, 4096)).astype(np.uint16), tile(z["cam"]).astype(np.float32), tile(z["startpose"]).astype(np.float32))
+    return (_tile(z["depth"].reshape(-1, 4096), n).astype(np.uint16), _tile(z["cam"], n).astype(np.float32), _tile(z["startpose"], n).astype(np.float32))
 
 
 def _load_frames5(n):
     """BASELINE configs[4]: 128x128 frames of the 26-bone hand (tests/golden/make_frames5.py), tiled"""
+    import numpy as np
     z = np.load(os.path.join(ROOT, "tests", "golden", "frames5_64.npz"))
-    reps = (n + len(z["depth"]) - 1) // len(z["depth"])
-    tile = lambda a: np.concatenate([a] * reps)[:n]
-    return (tile(z["depth"]).astype(np.uint16), tile(z["cam"]).astype(np.float32), tile(z["startpose"]).astype(np.float32))
+    return (_tile(z["depth"], n).astype(np.uint16), _tile(z["cam"], n).astype(np.float32), _tile(z["startpose"], n).astype(np.float32))
+
+
+def _golden8():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import htfx
+    return htfx.load(os.path.join(ROOT, "tests", "golden", "golden8.htfx"))
 
 
 def cpu_baseline_config5(depth, cams, start, seed, gain):
     """C oracle (pinned bit for bit on the reference's full-frame goldens, tests/test_fullframe.py) on a bounded sample, one thread."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ctypes as C
     import oracle_lib as ol
@@ -70,7 +114,22 @@ def cpu_baseline_config5(depth, cams, start, seed, gain):
             "sample": "%d frames x 2 reps (best), C oracle -O2 -ffp-contract=off: HandSegmentVR + update_cnn_model + 3 passes, 26 bones" % nsample}
 
 
+def cpu_baseline_cnn128(x, w128):
+    """C oracle of the 128x128-input net (pinned bit for bit on the reference's own layer classes, tests/test_cnn128.py), one thread."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    nsample = min(48, len(x))
+    best = 1e30
+    for rep in range(2):
+        t0 = time.perf_counter()
+        ol.cnn128_eval(w128, x[:nsample])
+        best = min(best, (time.perf_counter() - t0) / nsample)
+    return {"value": 1.0 / best, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "%d frames x 2 reps (best), C oracle -O2 -ffp-contract=off, CNN forward 128x128 only" % nsample}
+
+
 def _write_htfx(path, arrays):
+    import numpy as np
     code = {np.dtype(np.float32): 0, np.dtype(np.int32): 1, np.dtype(np.uint16): 2, np.dtype(np.uint8): 3}
     with open(path, "wb") as f:
         f.write(b"HTFX0001" + struct.pack("<I", len(arrays)))
@@ -84,6 +143,7 @@ def _write_htfx(path, arrays):
 
 def cpu_baseline(depth, cams, start, seed, gain):
     """Reference CPU path on a bounded sample of the same workload (single thread)."""
+    import numpy as np
     nsample = min(192, len(depth))
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     if os.path.exists(ref_bin):
@@ -120,17 +180,20 @@ def cpu_baseline(depth, cams, start, seed, gain):
             "sample": "%d frames x 2 reps (best), C oracle -O2 -ffp-contract=off, update_cnn_model + 3 passes" % nsample}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-gpu", type=int, default=1024)
-    ap.add_argument("--workload", default="cnn+solver", choices=["cnn+solver", "cnn", "config5"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the pose gather even with one rank")
-    args = ap.parse_args()
+def _latest_profile(pattern):
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return fs[-1] if fs else None
 
+
+def main():
+    args = parse_args()
+    bad = [k for k in TUNING_ENV if os.environ.get(k)]
+    if bad:
+        raise SystemExit("bench.py refuses to run with the library's tuning switches set (%s): the kernels would skip work" % ", ".join(bad))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     from hand_tracking_samples_amd import native, weights as W
@@ -153,12 +216,20 @@ def main():
     dev = torch.device("cuda", local)
     B = args.frames_per_gpu
     seed, gain = W.DEFAULT_SEED, W.DEFAULT_FC2_GAIN
+    wl = args.workload
+    cfg5 = wl == "config5"
+    cnn_only = wl in ("cnn", "config5-cnn128")
+    cnn128 = wl == "config5-cnn128"
 
     # contiguous shard of the global frame list for this rank (frames differ across ranks through the tiling offset)
-    cfg5 = args.workload == "config5"
-    depth_all, cams_all, start_all = (_load_frames5 if cfg5 else _load_frames)(B * world)
+    depth_all, cams_all, start_all = (_load_frames5 if (cfg5 or cnn128) else _load_frames)(B * world)
     sl = slice(*shard_range(B * world, rank, world))
-    depth, cams, start = depth_all[sl], cams_all[sl], start_all[sl]
+    depth, cams, start = depth_all[sl].copy(), cams_all[sl].copy(), start_all[sl].copy()
+    gold = None
+    if rank == 0 and wl in ("cnn+solver", "cnn") and B >= 8:      # slots 0..7: the frames the reference's results are committed for
+        gold = _golden8()
+        for f in range(8):
+            depth[f] = gold["f%d/depth" % f].reshape(-1); cams[f] = gold["f%d/cam" % f]; start[f] = gold["f%d/startpose" % f]
 
     ctx = native.Context(os.path.join(ROOT, "tests", "golden", "model_hand26.htfx" if cfg5 else "model_hand17.htfx"), B, device=local)
     ctx.load_weights(W.make_cnnb(seed, gain))
@@ -167,24 +238,32 @@ def main():
     d_cams = torch.from_numpy(cams).to(dev)
     d_start = torch.from_numpy(start).to(dev)
     d_poses = torch.empty((B, ctx.nb, 7), dtype=torch.float32, device=dev)
-    d_cnn_in = torch.empty((B, 4096), dtype=torch.float32, device=dev)
     d_cnn_out = torch.empty((B, 2304), dtype=torch.float32, device=dev)
     gathered = torch.empty((world * B, ctx.nb, 7), dtype=torch.float32, device=dev) if use_dist else None
     stream = torch.cuda.current_stream(dev)
 
-    if args.workload == "cnn":
+    w128 = x128 = None
+    if cnn128:
+        w128 = W.make_cnnb128(seed, gain)
+        ctx.load_weights128(w128)
+        cam_scale = cams[:, 4].astype(np.float32)[:, None, None]
+        x128 = np.clip(1.0 - (depth.astype(np.float32) * cam_scale - 0.1) / np.float32(0.7 - 0.1), 0.0, 1.0).astype(np.float32).reshape(B, -1)      # handtrack.h:700 on the whole 128x128 frame
+        d_cnn_in = torch.from_numpy(x128).to(dev)
+    elif wl == "cnn":
         cnn_in, _, _ = ctx.stage_prepare(depth, cams)
-        d_cnn_in.copy_(torch.from_numpy(cnn_in))
+        d_cnn_in = torch.from_numpy(cnn_in).to(dev)
 
     def step():
-        if args.workload == "cnn":
+        if cnn128:
+            ctx.cnn128_eval_dev(d_cnn_in.data_ptr(), d_cnn_out.data_ptr(), B, stream.cuda_stream)
+        elif wl == "cnn":
             ctx.cnn_eval_dev(d_cnn_in.data_ptr(), d_cnn_out.data_ptr(), B, stream.cuda_stream)
         elif cfg5:
             ctx.update_frames_dev(d_depth.data_ptr(), d_cams.data_ptr(), 128, 128, 0.17, d_start.data_ptr(), B, d_poses.data_ptr(), stream.cuda_stream)
         else:
             ctx.update_dev(d_depth.data_ptr(), d_cams.data_ptr(), d_start.data_ptr(), B, d_poses.data_ptr(), stream.cuda_stream)
-            if use_dist:
-                gather_poses(d_poses, world, out=gathered)
+        if use_dist and not cnn_only:
+            gather_poses(d_poses, world, out=gathered)
 
     for _ in range(args.warmup):
         step()
@@ -207,6 +286,33 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     prof = ctx.profile_read(reset=True)
+
+    # ---- the timed steps' own output against the reference's committed results (rank 0, slots 0..7) ----
+    verify = None
+    if gold is not None and args.steps > 0:
+        if wl == "cnn":
+            got = d_cnn_out[:8].cpu().numpy()
+            dc = float(max(np.abs(got[f] - gold["f%d/cnn_output" % f]).max() for f in range(8)))
+            verify = {"verified": bool(dc <= VERIFY_CNN_TOL), "against": "tests/golden/golden8.htfx cnn_output (reference)", "max_abs_dcnn": dc, "tol": VERIFY_CNN_TOL}
+        else:
+            got = d_poses[:8].cpu().numpy()
+            dp = float(max(np.abs(got[f][:, :3] - gold["f%d/uw_pose_user" % f][:, :3]).max() for f in range(8)))
+            dq = float(max(np.abs(got[f][:, 3:] - gold["f%d/uw_pose_user" % f][:, 3:]).max() for f in range(8)))
+            verify = {"verified": bool(dp <= VERIFY_POS_TOL and dq <= VERIFY_QUAT_TOL), "against": "tests/golden/golden8.htfx uw_pose_user (reference), slots 0-7 of the timed batch",
+                      "max_abs_dpos_m": dp, "max_abs_dquat": dq, "tol": [VERIFY_POS_TOL, VERIFY_QUAT_TOL]}
+            if use_dist:
+                verify["gather_consistent"] = bool(torch.equal(gathered[:B], d_poses))
+        if not cnn_only:
+            verify["capacity_events"] = list(ctx.capacity_events())
+    elif cnn128 and rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as ol
+        ref = ol.cnn128_eval(w128, x128[:4])
+        dc = float(np.abs(d_cnn_out[:4].cpu().numpy() - ref).max())
+        verify = {"verified": bool(dc <= VERIFY_CNN_TOL), "against": "C oracle of the 128x128 net (pinned on the reference's layer classes), frames 0-3 of the timed batch", "max_abs_dcnn": dc, "tol": VERIFY_CNN_TOL}
+    elif cfg5 and rank == 0:
+        verify = {"verified": None, "capacity_events": list(ctx.capacity_events()), "frames_overflow": ctx.frames_overflow(), "note": "parity of this workload: tests/test_fullframe.py, tests/test_config5.py"}
+
     # phase table from a second, untimed pass with every phase bracketed (this serialises the side streams)
     ctx.profile_enable(2)
     nphase = max(2, min(5, args.steps))
@@ -219,9 +325,10 @@ def main():
     if rank == 0:
         total_frames = B * world * args.steps
         value = total_frames / elapsed
+        flop_cnn = CNN_FLOP["cnn128" if cnn128 else "cnn"]
         # dominant kernel of the workload by HIP-event time
         phases = {k: v for k, v in prof.items() if v[1] > 0}
-        if args.workload == "cnn":
+        if cnn_only:
             phases = {k: (v[0] * args.steps / nphase, v[1] * args.steps // nphase) for k, v in prof_all.items() if v[1] > 0}
         all_phases = {k: v for k, v in prof_all.items() if v[1] > 0}
         dom = max(all_phases, key=lambda k: all_phases[k][0] / nphase) if all_phases else None
@@ -229,65 +336,91 @@ def main():
             phases[dom] = (all_phases[dom][0] * args.steps / nphase, all_phases[dom][1] * args.steps // nphase)
         roof = None
         if dom == "solve":
-            # algorithmic HBM bytes of one k_solve launch: per frame the body state in and out
-            # (2 x 17 x 52 B) plus the constraint rows it consumes (64 B each); mean rows per frame measured from the data
-            npts = np.array([int(((d.astype(np.float32) * c[4] >= 0.1) & (d.astype(np.float32) * c[4] < 0.7)).sum() + 3) // 4 for d, c in zip(depth, cams)])
+            # One k_solve launch per frame.  HBM side: the body state in and out (2 x nb x 52 B) plus the constraint rows it
+            # consumes (64 B each).  VALU side: 20 sweeps x (120 flop per linear row + 60 per angular row).  Row counts per frame from the data.
+            scale = cams[:, 4].astype(np.float32)[:, None]
+            z = depth.reshape(B, -1).astype(np.float32) * scale
+            npts = (((z >= 0.1) & (z < 0.7)).sum(axis=1) + 3) // 4
             main_rows = float(np.mean(npts + np.where(npts > 400, 5 * ctx.nb, 0))); sim_rows = float(np.mean((npts + 3) // 4))
-            rows_mean = (3 * main_rows + 4 * sim_rows) / 8.0
+            rows_mean = (3 * main_rows + 4 * sim_rows) / 8.0              # 3 main passes, 4 cloud-bearing MultiStepSim steps (+ 1 without cloud rows)
+            joint_rows, ang_rows, contact_rows = 3.0 * ctx.nj, 71.0 * ctx.nj / 16.0, 3 * 5.1      # 71 angular rows, 5.1 contacts per frame (17-bone hand)
             per_frame = 2 * ctx.nb * 52 + 64.0 * rows_mean
+            flop_frame = 20.0 * ((rows_mean + joint_rows + contact_rows) * 120.0 + ang_rows * 60.0)
             avg_ms = phases[dom][0] / phases[dom][1]
             achieved = per_frame * B / (avg_ms * 1e-3) / 1e9
+            valu = flop_frame * B / (avg_ms * 1e-3) / 1e12
             traffic = None
             try:      # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), if present
-                traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["k_solve"]["hbm_bytes_per_launch"]
+                traffic = json.load(open(_latest_profile("r*_pmc_hbm_traffic.json")))["k_solve"]["hbm_bytes_per_launch"]
             except Exception:
                 pass
-            roof = {"kernel": "k_solve", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                    "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches": phases[dom][1], "algorithmic_bytes_per_launch": int(per_frame * B),
-                    "note": "sequential Gauss-Seidel: latency/VALU-bound, not a streaming kernel (SURVEY 8d)"}
+            roof = {"kernel": "k_solve", "bound": "latency", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                    "hbm_frac": round(achieved / HBM_PEAK_GBS, 6), "valu_achieved_tflops": round(valu, 3), "valu_peak_tflops": FP32_VALU_PEAK_TF, "valu_frac": round(valu / FP32_VALU_PEAK_TF, 6),
+                    "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches": phases[dom][1], "algorithmic_bytes_per_launch": int(per_frame * B), "algorithmic_flop_per_launch": int(flop_frame * B),
+                    "note": "sequential Gauss-Seidel (physics.h:556-562): bound by the dependent-instruction latency of the longest per-body row chain, neither by HBM nor by VALU throughput; both fractions are reported (SURVEY 8d)"}
         elif dom == "contacts":
             # k_contacts reads the poses of the frame's bodies and writes its contacts (48 B each, data dependent, not counted): like the
             # solve it is a latency-bound kernel (one wave walks the candidate pairs' GJK/EPA iterations), priced against HBM for the record
             per_frame = ctx.nb * 28 + 4
             avg_ms = phases[dom][0] / phases[dom][1]
             achieved = per_frame * B / (avg_ms * 1e-3) / 1e9
-            roof = {"kernel": "k_contacts", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+            roof = {"kernel": "k_contacts", "bound": "latency", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                     "avg_launch_ms": round(avg_ms, 4), "launches": phases[dom][1], "algorithmic_bytes_per_launch": int(per_frame * B),
                     "note": "broad phase + GJK/EPA over %d body pairs per frame: latency/LDS-bound, not a streaming kernel" % (ctx.nb * (ctx.nb - 1) // 2)}
-        elif dom == "cnn":
+        elif dom in ("cnn", "cnn128"):
             avg_ms = phases[dom][0] / phases[dom][1]
-            achieved = 26.47e6 * B / (avg_ms * 1e-3) / 1e12
+            achieved = flop_cnn * B / (avg_ms * 1e-3) / 1e12
             roof = {"kernel": "cnn (k_conv1+k_conv2+k_fc x2+k_softmax_decode)", "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": round(achieved / FP32_MFMA_PEAK_TF, 5), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": phases[dom][1]}
+                    "frac": round(achieved / FP32_MFMA_PEAK_TF, 5), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": phases[dom][1], "flop_per_frame": flop_cnn}
         cnn_roof = None
         if "cnn" in all_phases and dom != "cnn":
             avg_ms = all_phases["cnn"][0] / all_phases["cnn"][1]
-            ach = 26.47e6 * B / (avg_ms * 1e-3) / 1e12
+            ach = CNN_FLOP["cnn"] * B / (avg_ms * 1e-3) / 1e12
             cnn_roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 5), "avg_ms": round(avg_ms, 4)}
+        shard_note = ("; layout of BASELINE configs[3] (contiguous shard per GPU, RCCL all-gather of the poses inside the timed step; configs[3] itself = --gpus 8 --frames-per-gpu 8192)"
+                      if world > 1 else "")
+        workloads = {
+            "cnn+solver": ("synthetic depth frames/sec (CNN+solver), 64x64x1 input, 17-bone hand",
+                           "BASELINE configs[2]: %d independent 64x64 frames per GPU, CNN + decode + 5-step MultiStepSim + 3 FitPointCloud passes (GJK + PGS), 17 bones%s" % (B, shard_note)),
+            "cnn": ("synthetic depth frames/sec (CNN forward only), 64x64x1 input", "BASELINE configs[1]: %d frames per GPU, CNN forward only" % B),
+            "config5": ("synthetic depth frames/sec (segmentation+CNN+solver), 128x128x1 input, 26-bone hand",
+                        "BASELINE configs[4]: %d independent 128x128 frames per GPU, HandTracker::update on full frames (HandSegmentVR + CNN + 5-step MultiStepSim + 3 FitPointCloud passes), 26 bones%s" % (B, shard_note)),
+            "config5-cnn128": ("synthetic depth frames/sec (CNN forward only), 128x128x1 input",
+                               "BASELINE configs[4], CNN part at full input size (SURVEY 8d config 5 ii): %d frames per GPU, conv5x5 1->16 @124, 2x pool, conv4x4 16->64 @28, pool, FC 12544->2048->2304, chunked softmax" % B),
+        }
         out = {
-            "metric": "synthetic depth frames/sec (CNN+solver), 64x64x1 input, 17-bone hand" if args.workload == "cnn+solver" else
-                      "synthetic depth frames/sec (segmentation+CNN+solver), 128x128x1 input, 26-bone hand" if cfg5 else "synthetic depth frames/sec (CNN forward only), 64x64x1 input",
+            "metric": workloads[wl][0],
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (%d software-rendered animbank frames tiled; seeded weights 0x5EED0001)" % (64 if cfg5 else 256),
-            "config": {"workload": "BASELINE configs[2]: %d independent 64x64 frames per GPU, CNN + decode + 5-step MultiStepSim + 3 FitPointCloud passes (GJK + PGS), 17 bones" % B
-                       if args.workload == "cnn+solver" else
-                       "BASELINE configs[4]: %d independent 128x128 frames per GPU, HandTracker::update on full frames (HandSegmentVR + CNN + 5-step MultiStepSim + 3 FitPointCloud passes), 26 bones" % B
-                       if cfg5 else "BASELINE configs[1]: %d frames per GPU, CNN forward only" % B,
-                       "frames_per_gpu": B, "global_frames_per_step": B * world, "parallelism": "frames sharded per GPU, RCCL all-gather of poses" if world > 1 else "single GPU"},
+            "dtype": "f32", "data": "synthetic (%d software-rendered animbank frames tiled; seeded weights 0x5EED0001)" % (64 if (cfg5 or cnn128) else 256),
+            "config": {"workload": workloads[wl][1], "frames_per_gpu": B, "global_frames_per_step": B * world,
+                       "parallelism": ("frames sharded per GPU, RCCL all-gather of poses" if not cnn_only else "frames sharded per GPU, no exchange") if world > 1 else "single GPU"},
             "roofline": roof,
             "phase_ms_per_step": {k: round(v[0] / nphase, 4) for k, v in sorted(all_phases.items())},
             "phase_note": "from an extra untimed pass with every phase bracketed and the side streams serialised",
         }
+        if verify is not None:
+            out["verified"] = verify["verified"]
+            out["verify"] = verify
         if cnn_roof:
             out["roofline_cnn"] = cnn_roof
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = (cpu_baseline_config5 if cfg5 else cpu_baseline)(depth, cams, start, seed, gain)
+            if cnn128:
+                out["cpu_baseline"] = cpu_baseline_cnn128(x128, w128)
+            else:
+                out["cpu_baseline"] = (cpu_baseline_config5 if cfg5 else cpu_baseline)(depth, cams, start, seed, gain)
+                if wl == "cnn" and "cnn_only_fps" in out["cpu_baseline"]:
+                    out["cpu_baseline"]["frame_fps_cnn_plus_solver"] = out["cpu_baseline"]["value"]
+                    out["cpu_baseline"]["value"] = out["cpu_baseline"].pop("cnn_only_fps")
+                    out["cpu_baseline"]["sample"] += "; value = CNN::Eval only"
             out["speedup_vs_cpu_1thread"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
+    if verify is not None and verify.get("verified") is False:
+        sys.stderr.write("bench.py: the timed steps' output does NOT match the reference's committed results: %s\n" % json.dumps(verify))
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -12,6 +12,7 @@
 #pragma once
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <map>
 #include <sstream>
@@ -23,28 +24,81 @@
 namespace ht_mi355x {
 
 // ---- .pose ---------------------------------------------------------------------------------------------------------------
+// The format (what DepthDataStreamOut::SaveFrame writes, include/dataset.h:97-99, and what synthetic-tracker.cpp:39-55 / dataset.h:144-146 read):
+// plain text, numbers separated by blanks, 7 per bone in the order position x y z, orientation x y z w; an animation bank holds one frame
+// per line and ends at the first empty line, a dataset's pose file is read as one stream of numbers, frame after frame.
+namespace detail {
+// the whole file as bytes; *found tells whether it could be opened
+inline std::string file_bytes(const std::string &path, bool *found = nullptr)
+{
+	std::string bytes;
+	FILE *f = std::fopen(path.c_str(), "rb");
+	if (found) *found = f != nullptr;
+	if (!f) return bytes;
+	char chunk[1 << 16];
+	for (size_t got; (got = std::fread(chunk, 1, sizeof chunk, f)) > 0;) bytes.append(chunk, got);
+	std::fclose(f);
+	return bytes;
+}
+// Reads up to `want` numbers from the text in [at, end) into out[]; stops early where no number follows.  Returns how many were read.
+inline size_t take_numbers(const char *&at, const char *end, float *out, size_t want)
+{
+	size_t n = 0;
+	while (n < want)
+	{
+		while (at < end && (*at == ' ' || *at == '\t' || *at == '\r' || *at == '\n')) at++;
+		if (at >= end) break;
+		char *stop = nullptr;
+		const float v = std::strtof(at, &stop);      // the text ends in a NUL (std::string), so strtof cannot run past `end`
+		if (stop == at) break;
+		out[n++] = v; at = stop;
+	}
+	return n;
+}
+// fills as many of the bones as there are numbers for; a bone that is cut short keeps the numbers it got (the rest stay at the identity pose)
+inline size_t take_poses(const char *&at, const char *end, std::vector<Pose> &bones)
+{
+	size_t whole = 0;
+	for (auto &b : bones)
+	{
+		float v[7] = { b.position.x, b.position.y, b.position.z, b.orientation.x, b.orientation.y, b.orientation.z, b.orientation.w };
+		const size_t got = take_numbers(at, end, v, 7);
+		b.position = { v[0], v[1], v[2] }; b.orientation = { v[3], v[4], v[5], v[6] };
+		if (got < 7) break;
+		whole++;
+	}
+	return whole;
+}
+}  // namespace detail
+
 inline std::istream &operator>>(std::istream &in, Pose &p) { return in >> p.position.x >> p.position.y >> p.position.z >> p.orientation.x >> p.orientation.y >> p.orientation.z >> p.orientation.w; }      // geometric.h:139
 inline std::ostream &operator<<(std::ostream &out, const Pose &p)      // geometric.h:138
 {
 	return out << p.position.x << " " << p.position.y << " " << p.position.z << " " << p.orientation.x << " " << p.orientation.y << " " << p.orientation.z << " " << p.orientation.w;
 }
-// synthetic-tracker.cpp:39-55: one line = one frame, reading stops at the first empty line
+// Same call as synthetic-tracker.cpp:39 (one line = one frame of pose_array_size bones; the bank ends at the first empty line or at the end of the file)
 inline std::vector<std::vector<Pose>> LoadAnimBank(const std::string &filename, size_t pose_array_size)
 {
-	std::vector<std::vector<Pose>> animbank;
-	std::ifstream pfile(filename);
-	if (!pfile.is_open()) throw std::runtime_error("unable to open animation bank file");
-	std::string line;
-	while (std::getline(pfile, line) && line != "")
+	bool found = false;
+	const std::string text = detail::file_bytes(filename, &found);
+	if (!found) throw std::runtime_error("animation bank not found: " + filename);
+	std::vector<std::vector<Pose>> bank;
+	for (size_t from = 0; from < text.size();)
 	{
-		std::vector<Pose> pose(pose_array_size);
-		std::stringstream linestream(line);
-		for (auto &p : pose) linestream >> p;
-		animbank.push_back(pose);
+		size_t to = text.find('\n', from);
+		if (to == std::string::npos) to = text.size();
+		size_t len = to - from;
+		if (len && text[from + len - 1] == '\r') len--;      // a bank edited on Windows
+		if (len == 0) break;
+		const std::string line = text.substr(from, len);      // own NUL-terminated copy: numbers never run into the next line
+		const char *at = line.c_str();
+		bank.emplace_back(pose_array_size);
+		detail::take_poses(at, at + line.size(), bank.back());
+		from = to + 1;
 	}
-	return animbank;
+	return bank;
 }
-// the line DepthDataStreamOut::SaveFrame writes (dataset.h:97-99): "px py pz  qx qy qz qw   " per bone
+// one line of a .pose file: "px py pz  qx qy qz qw   " per bone (the spacing DepthDataStreamOut::SaveFrame uses, dataset.h:97-99)
 inline void WritePoseLine(std::ostream &out, const std::vector<Pose> &pose)
 {
 	for (const auto &p : pose) out << p.position.x << " " << p.position.y << " " << p.position.z << "  " << p.orientation.x << " " << p.orientation.y << " " << p.orientation.z << " " << p.orientation.w << "   ";
@@ -76,7 +130,8 @@ struct jparse
 		if (e - p >= 5 && !std::string(p, 5).compare("false")) { v.kind = 'b'; v.text = "0"; p += 5; return v; }
 		if (e - p >= 4 && !std::string(p, 4).compare("null")) { p += 4; return v; }
 		const char *s = p; while (p < e && (std::string("+-.eE").find(*p) != std::string::npos || (*p >= '0' && *p <= '9'))) p++;
-		if (p == s) fail("unexpected character"); v.kind = '#'; v.text.assign(s, p); return v;
+		if (p == s) fail("unexpected character");
+		v.kind = '#'; v.text.assign(s, p); return v;
 	}
 };
 inline jv parse_json_file(const std::string &path)
@@ -119,44 +174,64 @@ inline void WriteDatasetInfo(const std::string &jsonfile, const DatasetInfo &d)
 }
 
 // ---- .rs / .ir / .pose datasets ------------------------------------------------------------------------------------------
+// A dataset is four files with one base name (dataset.h:62-163): base.json = the DatasetInfo header above; base.rs = the depth frames, raw
+// little-endian u16, width x height of the header's camera, back to back (with the deprecated hasir flag each depth frame is followed by its
+// u8 infra-red frame in the same file); base.ir = the infra-red frames, raw u8, same size, optional; base.pose = the poses as text.
 struct Frame { Image<unsigned short> depth; std::vector<Pose> pose; Image<unsigned char> ir; std::string fname; int fid = 0; };      // dataset.h:40-51 (depth, pose, ir)
-// dataset.h:118-163
+
+// Same call as dataset.h:118: every complete frame of the dataset, in file order.
 inline std::vector<Frame> load_dataset(const std::string &bname, unsigned int pose_array_size)
 {
-	std::ifstream file_in_depth(bname + ".rs", std::ios_base::binary | std::ios_base::in);
-	if (!file_in_depth.is_open()) throw std::runtime_error("unable to open .rs file");
-	const DatasetInfo dsi = ReadDatasetInfo(bname + ".json");
-	std::ifstream file_in_pose(bname + ".pose", std::ios_base::in), file_in_ir(bname + ".ir", std::ios_base::in | std::ios_base::binary);
-	const size_t npix = (size_t)dsi.dcamera.dim().x * dsi.dcamera.dim().y;
-	std::vector<Frame> frames;
-	for (int k = 0;; k++)
+	bool have_rs = false, have_ir = false, have_pose = false;
+	const std::string rs = detail::file_bytes(bname + ".rs", &have_rs);
+	if (!have_rs) throw std::runtime_error("dataset has no depth file: " + bname + ".rs");
+	const DatasetInfo info = ReadDatasetInfo(bname + ".json");
+	const std::string irb = detail::file_bytes(bname + ".ir", &have_ir), posetext = detail::file_bytes(bname + ".pose", &have_pose);
+	const size_t px = (size_t)info.dcamera.dim().x * (size_t)info.dcamera.dim().y;
+	const size_t depth_bytes = px * sizeof(unsigned short), record = depth_bytes + (info.hasir ? px : 0);
+	const size_t count = record ? rs.size() / record : 0;
+	const char *pose_at = posetext.c_str(), *pose_end = pose_at + posetext.size();
+	std::vector<Frame> frames(count);
+	for (size_t k = 0; k < count; k++)
 	{
-		std::vector<unsigned short> dbuf(npix); std::vector<unsigned char> ibuf(npix, (unsigned char)0);
-		if (!file_in_depth.read((char *)dbuf.data(), (std::streamsize)(npix * sizeof(unsigned short)))) break;
-		if (dsi.hasir && !file_in_depth.read((char *)ibuf.data(), (std::streamsize)npix)) break;      // interleaved depth and ir (deprecated layout)
-		if (file_in_ir.is_open()) file_in_ir.read((char *)ibuf.data(), (std::streamsize)npix);
-		std::vector<Pose> pose(pose_array_size);
-		if (file_in_pose.is_open()) for (auto &p : pose) file_in_pose >> p;
-		Frame f; f.depth = Image<unsigned short>(dsi.dcamera, std::move(dbuf)); f.ir = Image<unsigned char>(dsi.dcamera, std::move(ibuf)); f.pose = std::move(pose); f.fname = bname; f.fid = k;
-		frames.push_back(std::move(f));
+		Frame &f = frames[k];
+		const char *rec = rs.data() + k * record;
+		std::vector<unsigned short> d(px);
+		std::memcpy(d.data(), rec, depth_bytes);
+		std::vector<unsigned char> ir(px, (unsigned char)0);
+		if (info.hasir) std::memcpy(ir.data(), rec + depth_bytes, px);
+		if (have_ir && (k + 1) * px <= irb.size()) std::memcpy(ir.data(), irb.data() + k * px, px);      // the separate file wins, as it is read last in the reference
+		f.depth = Image<unsigned short>(info.dcamera, std::move(d));
+		f.ir = Image<unsigned char>(info.dcamera, std::move(ir));
+		f.pose.assign(pose_array_size, Pose());
+		if (have_pose) detail::take_poses(pose_at, pose_end, f.pose);
+		f.fname = bname; f.fid = (int)k;
 	}
 	return frames;
 }
-// dataset.h:62-104 (depth, ir, pose streams + the .json header)
-struct DepthDataStreamOut
+// Same surface as dataset.h:62-104: opened on a base name (or on a header, which is then written), SaveFrame appends one frame to all three streams.
+class DepthDataStreamOut
 {
-	std::string prefix; std::ofstream file_out_depth, file_out_poses, file_out_ir;
-	explicit DepthDataStreamOut(const std::string &prefix_) : prefix(prefix_)
+	std::FILE *depth_out = nullptr, *ir_out = nullptr, *pose_out = nullptr;
+	static void put(std::FILE *f, const void *p, size_t n, const char *what) { if (n && std::fwrite(p, 1, n, f) != n) throw std::runtime_error(std::string("dataset: short write to the ") + what + " stream"); }
+public:
+	const std::string prefix;
+	explicit DepthDataStreamOut(const std::string &base) : prefix(base)
 	{
-		file_out_depth.open(prefix + ".rs", std::ios::binary | std::ios::trunc); file_out_ir.open(prefix + ".ir", std::ios::binary | std::ios::trunc); file_out_poses.open(prefix + ".pose", std::ios::out | std::ios::trunc);
+		depth_out = std::fopen((base + ".rs").c_str(), "wb"); ir_out = std::fopen((base + ".ir").c_str(), "wb"); pose_out = std::fopen((base + ".pose").c_str(), "w");
 	}
-	explicit DepthDataStreamOut(const DatasetInfo &dsi) : DepthDataStreamOut(dsi.fname) { WriteDatasetInfo(dsi.fname + ".json", dsi); }
+	explicit DepthDataStreamOut(const DatasetInfo &header) : DepthDataStreamOut(header.fname) { WriteDatasetInfo(header.fname + ".json", header); }
+	DepthDataStreamOut(const DepthDataStreamOut &) = delete;
+	DepthDataStreamOut &operator=(const DepthDataStreamOut &) = delete;
+	~DepthDataStreamOut() { for (std::FILE *f : { depth_out, ir_out, pose_out }) if (f) std::fclose(f); }
 	void SaveFrame(const Image<unsigned short> &dimage, const Image<unsigned char> &irimage, const std::vector<Pose> &pose)
 	{
-		if (!file_out_depth.is_open()) throw std::runtime_error("hey file wasn't opened");
-		file_out_depth.write((const char *)dimage.raster.data(), (std::streamsize)(dimage.raster.size() * sizeof(unsigned short)));
-		file_out_ir.write((const char *)irimage.raster.data(), (std::streamsize)irimage.raster.size());
-		WritePoseLine(file_out_poses, pose);
+		if (!depth_out || !ir_out || !pose_out) throw std::runtime_error("dataset: cannot write " + prefix + ".rs/.ir/.pose");
+		put(depth_out, dimage.raster.data(), dimage.raster.size() * sizeof(unsigned short), "depth");
+		put(ir_out, irimage.raster.data(), irimage.raster.size(), "infra-red");
+		std::ostringstream line;
+		WritePoseLine(line, pose);
+		put(pose_out, line.str().data(), line.str().size(), "pose");
 	}
 };
 }  // namespace ht_mi355x

@@ -2,7 +2,7 @@
 the model builder on shapes the hand model does not have: a hexahedron, a triangular prism (3-sided faces) and an
 8-sided two-ring cage.  The expected build (model_chain3.htfx) comes from the reference's own PhysModel constructor:
 
-    python tests/golden/make_model_chain3.py
+    python tests/golden/make_model_chain3.py [out.json]
     oracle/_ref/ref_harness modelfile tests/golden/model_chain3.json tests/golden/model_chain3.htfx
 """
 import json
@@ -50,7 +50,8 @@ model = {
         {"jointframe": [0, 0.0871557, 0, 0.996195], "p0": [0.001, 0.0005, 0.058], "p1": [0, 0, -0.002], "rangemax": [90, 0, 0], "rangemin": [-10, 0, 0], "rbi0": 1, "rbi1": 2},
     ],
 }
-out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "model_chain3.json")
+import sys
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "model_chain3.json")
 with open(out, "w") as fp:
     json.dump(model, fp, indent=1)
 print(out)

@@ -44,9 +44,11 @@ def test_batch_against_restatement(weights):
     loose = (dp <= 2e-4) & (dq <= 2e-3)
     print("frames exact %d, within 2e-5 m / 2e-4: %d, within 2e-4 m / 2e-3: %d of %d; worst |dpos| %.2e m |dquat| %.2e (frame %d)"
           % (int(((dp == 0) & (dq == 0)).sum()), int(tight.sum()), int(loose.sum()), N, dp.max(), dq.max(), int(dp.argmax())))
-    assert loose.sum() >= N - 2, "more than 2 of %d frames outside 2e-4 m / 2e-3: %s" % (N, np.nonzero(~loose)[0])
-    assert tight.sum() >= N * 3 // 4
-    assert dp.max() < 5e-3      # even a flipped decision stays a small pose change on these frames
+    # observed on MI355X: 249 frames identical to the last bit, 255 tight, all 256 within 2e-4 m / 2e-3 (worst 1.9e-5 m / 5.5e-4)
+    assert loose.sum() >= N - 1, "more than 1 of %d frames outside 2e-4 m / 2e-3: %s" % (N, np.nonzero(~loose)[0])
+    assert tight.sum() >= N - 4
+    assert int(((dp == 0) & (dq == 0)).sum()) >= 240
+    assert dp.max() < 1e-3      # even a flipped decision stays a small pose change on these frames
 
 
 def test_full_size_batch_properties(weights):
@@ -75,3 +77,46 @@ def test_full_size_batch_properties(weights):
         assert np.array_equal(a[:256], a[256 * k:256 * (k + 1)])
     assert np.isfinite(a).all()
     assert np.abs(np.linalg.norm(a[:, :, 3:], axis=2) - 1.0).max() < 1e-5
+
+
+def test_config4_shard_of_8192_frames(weights):
+    """BASELINE configs[3]: one GPU's shard of the 65536-frame job = 8192 independent frames in one call (the 256 bench frames 32 times).
+    (1) deterministic, (2) a frame's result does not depend on its slot (all 32 copies agree bit for bit), (3) no capacity of the kernels is
+    touched, (4) a strided sample of 64 slots (64 distinct frames) agrees with the C restatement frame by frame."""
+    from hand_tracking_samples_amd import native
+    B = 8192
+    d = np.load(os.path.join(HERE, "golden", "frames256.npz"))
+    idx = np.arange(B) % 256
+    depth, cams, start = d["depth"][idx].reshape(B, -1), d["cam"][idx], d["startpose"][idx]
+    ctx = native.Context(ol.MODEL, B)
+    try:
+        ctx.load_weights(weights)
+        ctx.set_params(microforce=3.0, mainthreadpasses=3)
+        ctx.tracker_reset(start)
+        a = ctx.update_sync(depth, cams)
+        ctx.tracker_reset(start)
+        b = ctx.update_sync(depth, cams)
+        assert ctx.capacity_events() == (0, 0, 0)
+    finally:
+        ctx.close()
+    assert np.array_equal(a, b)
+    for k in range(1, B // 256):
+        assert np.array_equal(a[:256], a[256 * k:256 * (k + 1)]), "copy %d of the bench frames differs" % k
+    assert np.isfinite(a).all() and np.abs(np.linalg.norm(a[:, :, 3:], axis=2) - 1.0).max() < 1e-5
+    slots = np.arange(64) * 127                      # 64 slots spread over the shard; slot % 256 are 64 different frames
+    assert len(set(slots % 256)) == 64 and slots.max() < B
+    orc = ol.Oracle(weights)
+    orc.head.par.microforce = 3.0; orc.head.par.mainthreadpasses = 3
+    ref = np.zeros((64, 17, 7), np.float32)
+    for k, s in enumerate(slots):
+        orc.reset(start[s])
+        cam = ol.camera(cams[s])
+        orc.L.ho_update(orc.h, ol.u16ptr(np.ascontiguousarray(depth[s])), C.byref(cam), ol.fptr(ref[k]))
+    orc.close()
+    got = a[slots]
+    dp = np.abs(got[:, :, :3] - ref[:, :, :3]).max(axis=(1, 2))
+    dq = np.minimum(np.abs(got[:, :, 3:] - ref[:, :, 3:]), np.abs(got[:, :, 3:] + ref[:, :, 3:])).max(axis=(1, 2))
+    tight = (dp <= 2e-5) & (dq <= 2e-4)
+    loose = (dp <= 2e-4) & (dq <= 2e-3)
+    print("8192-frame shard, 64 sampled slots: exact %d, tight %d, loose %d; worst |dpos| %.2e m |dquat| %.2e" % (int(((dp == 0) & (dq == 0)).sum()), int(tight.sum()), int(loose.sum()), dp.max(), dq.max()))
+    assert loose.sum() >= 63 and tight.sum() >= 61

@@ -1,0 +1,79 @@
+#!/bin/bash
+# tools/regen_goldens.sh -- rebuilds oracle/_ref/ref_harness from the reference headers where they lie (/root/reference, build container only) and
+# regenerates EVERY fixture under tests/golden/ with the exact arguments it was made with, into a scratch directory, then compares each with the
+# committed file (cmp for the .htfx containers, array by array for the .npz archives).  Exit status 0 = every committed fixture is reproduced.
+#
+#   bash tools/regen_goldens.sh            compare only
+#   bash tools/regen_goldens.sh --write    also overwrite tests/golden/ with the regenerated files
+#
+# Fixed inputs: animation bank /root/reference/assets/animbank.pose; CNN weights from the seeded generator (hand_tracking_samples_amd/weights.py,
+# restated in ref_harness): seed 0x5EED0001, FC2 gain 24.
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+REF=${REF:-/root/reference}
+BANK=$REF/assets/animbank.pose
+SEED=0x5EED0001
+GAIN=24
+[ -f "$BANK" ] || { echo "reference tree not present at $REF: fixtures can only be regenerated in the build container"; exit 2; }
+make -s -C "$ROOT/oracle" ref
+H=$ROOT/oracle/_ref/ref_harness
+G=$ROOT/tests/golden
+T=$(mktemp -d /tmp/regen_goldens.XXXXXX)
+WRITE=0; [ "$1" = "--write" ] && WRITE=1
+cd "$ROOT"
+
+# models: the reference's own hand (17 bones), the 26-bone hand of BASELINE configs[4] and a 3-body chain with unusual faces, all in the reference's JSON schema
+$H model $T/model_hand17.htfx
+python3 tests/golden/make_model_hand26.py $T/model_hand26.json
+HT_REF_MODEL_JSON=$T/model_hand26.json $H model $T/model_hand26.htfx
+python3 tests/golden/make_model_chain3.py $T/model_chain3.json
+$H modelfile $T/model_chain3.json $T/model_chain3.htfx
+# per-stage goldens of the 64x64 path: 8 animation-bank rows (open hand, fists, P < 400 and P > 400 points, one full-reset frame), 48 GJK/EPA cases
+$H golden $BANK 0,16,144,1584,2224,912,1504,2048 $SEED $GAIN $T/golden8.htfx
+# bench / batch-parity input: 256 frames, rows 3, 12, 21, ... (first 3, stride 9)
+$H frames $BANK 3 9 256 $T/frames256.htfx
+# next rows of SURVEY 8(f)
+$H segment $BANK 0,144,912,1504,2048,2224 $T/seg.htfx
+$H scale $BANK 0,912 $SEED $GAIN 1.15 $T/scale115.htfx
+$H slowfit $BANK 0,912,2224 $T/slowfit3.htfx
+$H train $BANK 0,912,2224 $SEED $GAIN 2 $T/train3.htfx
+# full-size frames: the application's 320x240 camera with the 17-bone hand; BASELINE configs[4] (128x128, 26 bones) both ways the reference can run it
+$H fullframe $BANK 40,1234 320,240,305 $SEED $GAIN $T/fullframe320.htfx
+HT_REF_MODEL_JSON=$T/model_hand26.json $H fullframe $BANK 0,300,912,1500 128,128,163 $SEED $GAIN $T/fullframe5.htfx
+HT_REF_MODEL_JSON=$T/model_hand26.json $H config5 $BANK 0,300,912,1500 $SEED $GAIN $T/config5.htfx
+HT_REF_MODEL_JSON=$T/model_hand26.json $H fullframes $BANK 3 36 64 128,128,163 $T/frames5.htfx
+# the 128x128-input net of SURVEY 8(d) config 5 (ii), built from the reference's own layer classes, on four of those 128x128 frames
+$H cnn128 $T/frames5.htfx 0,9,33,60 $SEED $GAIN $T/cnn128.htfx
+
+rc=0
+for f in model_hand17 model_hand26 model_chain3 golden8 scale115 slowfit3 train3 fullframe320 fullframe5 config5 cnn128; do
+	if cmp -s $T/$f.htfx $G/$f.htfx; then echo "identical  $f.htfx"; else echo "DIFFERENT  $f.htfx"; rc=1; fi
+	[ $WRITE = 1 ] && cp $T/$f.htfx $G/$f.htfx
+done
+if cmp -s $T/model_chain3.json $G/model_chain3.json; then echo "identical  model_chain3.json"; else echo "DIFFERENT  model_chain3.json"; rc=1; fi
+python3 - "$T" "$G" "$WRITE" <<'PY' || rc=1
+import sys, numpy as np
+sys.path.insert(0, "tests")
+import htfx
+T, G, write = sys.argv[1], sys.argv[2], sys.argv[3] == "1"
+bad = 0
+def same(name, new, old):
+    global bad
+    ok = set(new) == set(old) and all(np.array_equal(new[k], old[k]) for k in new)
+    print(("identical  " if ok else "DIFFERENT  ") + name + " (array by array)")
+    bad += not ok
+f = htfx.load(T + "/frames256.htfx"); f256 = {k: f[k] for k in ("depth", "cam", "startpose", "gtpose", "rows")}
+same("frames256.npz", f256, dict(np.load(G + "/frames256.npz")))
+g = htfx.load(T + "/frames5.htfx"); f5 = {k: g[k] for k in ("depth", "cam", "startpose", "rows")}
+same("frames5_64.npz", f5, dict(np.load(G + "/frames5_64.npz")))
+s = htfx.load(T + "/seg.htfx"); seg = {k.replace("/", "__"): v for k, v in s.items()}
+same("segment6.npz", seg, dict(np.load(G + "/segment6.npz")))
+if write:
+    np.savez_compressed(G + "/frames256.npz", **f256)
+    np.savez_compressed(G + "/frames5_64.npz", **f5)
+    np.savez_compressed(G + "/segment6.npz", **seg)
+sys.exit(1 if bad else 0)
+PY
+rm -rf "$T"
+if [ $rc = 0 ]; then echo "all fixtures reproduced"; else echo "SOME FIXTURES DIFFER"; fi
+exit $rc
