@@ -193,6 +193,11 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 
+    # stdout carries exactly one JSON line: whatever libraries print there (RCCL's version banner does) is sent to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -263,7 +268,7 @@ def main():
         else:
             ctx.update_dev(d_depth.data_ptr(), d_cams.data_ptr(), d_start.data_ptr(), B, d_poses.data_ptr(), stream.cuda_stream)
         if use_dist and not cnn_only:
-            gather_poses(d_poses, world, out=gathered)
+            gather_poses(d_poses, world, out=gathered, force=True)
 
     for _ in range(args.warmup):
         step()
@@ -301,7 +306,7 @@ def main():
             verify = {"verified": bool(dp <= VERIFY_POS_TOL and dq <= VERIFY_QUAT_TOL), "against": "tests/golden/golden8.htfx uw_pose_user (reference), slots 0-7 of the timed batch",
                       "max_abs_dpos_m": dp, "max_abs_dquat": dq, "tol": [VERIFY_POS_TOL, VERIFY_QUAT_TOL]}
             if use_dist:
-                verify["gather_consistent"] = bool(torch.equal(gathered[:B], d_poses))
+                verify["gather_consistent"] = bool(torch.equal(gathered[rank * B:(rank + 1) * B], d_poses))
         if not cnn_only:
             verify["capacity_events"] = list(ctx.capacity_events())
     elif cnn128 and rank == 0:
@@ -414,7 +419,8 @@ def main():
                     out["cpu_baseline"]["value"] = out["cpu_baseline"].pop("cnn_only_fps")
                     out["cpu_baseline"]["sample"] += "; value = CNN::Eval only"
             out["speedup_vs_cpu_1thread"] = round(value / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     ctx.close()
     if use_dist:
         dist.destroy_process_group()

@@ -19,6 +19,8 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fn
 # chain rows; same arithmetic, another order of independent instructions).  Measured per file; it slows the other kernels down.
 FILE_FLAGS = {"ht_solver.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 OBJDIR = os.path.join(HERE, "build")
+if os.environ.get("HT_TUNING"):      # measurement builds only: lets HT_DEBUG_SKIP / HT_NO_SIDE / HT_NO_OVERLAP reach the kernels (tools/ablate_*.sh, tools/solve_stats.py)
+    FLAGS = FLAGS + ["-DHT_TUNING"]
 
 
 def sources():

@@ -14,6 +14,9 @@
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return HT_ERR_HIP; } } while (0)
 
+#define CHECK_READY(ctx) if (!(ctx)) return HT_ERR_ARG; if (!(ctx)->ready) { (ctx)->err = "context not initialised (ht_create failed)"; return HT_ERR_STATE; } ht_device_guard dev_guard_((ctx)->device)
+#define CHECK_BATCH(ctx, B) do { if ((B) < 1 || (B) > (ctx)->B) { (ctx)->err = "batch exceeds the capacity given to ht_create"; return HT_ERR_ARG; } } while (0)
+
 // ------------------------------------------------------------------------------------------------- context
 static void default_params(ht_params &p)     // handtrack.h:523-547, physics.h:45-47, physmodel.h:234, handtrack.h:369,450
 {
@@ -133,7 +136,8 @@ extern "C" int ht_create(const char *model_path, int max_batch, int device, ht_c
 	default_params(ctx->par);
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { ctx->err = "no HIP device: the MI355X hot path has no CPU fallback"; return HT_ERR_HIP; }
-	HIPCHK(ctx, hipSetDevice(device));
+	if (device < 0 || device >= ndev) { ctx->err = "no such HIP device"; return HT_ERR_ARG; }
+	ht_device_guard dev_guard_(device);      // the caller's current device is restored on return
 	hipDeviceProp_t prop;
 	HIPCHK(ctx, hipGetDeviceProperties(&prop, device));
 	if (!strstr(prop.gcnArchName, "gfx950")) { ctx->err = std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only"; return HT_ERR_HIP; }
@@ -184,8 +188,7 @@ extern "C" int ht_config_read(const char *jsonfile, ht_params *p, float *segment
 // joint anchors times s, inverse inertia over s*s, body positions stretched about the wrist.  The caller keeps segment_scale.
 extern "C" int ht_scale(ht_ctx *ctx, float s)
 {
-	if (!ctx) return HT_ERR_ARG;
-	if (!ctx->ready) { ctx->err = "context not initialised (ht_create failed)"; return HT_ERR_STATE; }
+	CHECK_READY(ctx);
 	const int nb = ctx->model.nb, nj = ctx->model.nj;
 	const float ss = s * s;
 	for (auto &v : ctx->h_verts) { v.x *= s; v.y *= s; v.z *= s; }      // w keeps the vertex index
@@ -221,8 +224,7 @@ extern "C" int ht_scale(ht_ctx *ctx, float s)
 // held by the context; ht_cnn_get_weights reads them back in .cnnb order (CNN::saveb cnn.h:591-593).
 extern "C" int ht_cnn_train(ht_ctx *ctx, const float *inputs, const float *targets, int n, float alpha, float *mse_out)
 {
-	if (!ctx) return HT_ERR_ARG;
-	if (!ctx->ready) { ctx->err = "context not initialised (ht_create failed)"; return HT_ERR_STATE; }
+	CHECK_READY(ctx);
 	if (!ctx->have_weights) { ctx->err = "CNN weights not loaded (ht_cnn_load_weights)"; return HT_ERR_STATE; }
 	if (!inputs || !targets || n < 1) return HT_ERR_ARG;
 	const size_t na = ht_train_act_floats(), ne = ht_train_err_floats(), np = ht_train_part_floats();
@@ -246,8 +248,9 @@ extern "C" int ht_cnn_train(ht_ctx *ctx, const float *inputs, const float *targe
 }
 extern "C" int ht_cnn_get_weights(ht_ctx *ctx, float *w, size_t n)
 {
-	if (!ctx || !w) return HT_ERR_ARG;
-	if (!ctx->ready || !ctx->have_weights) { ctx->err = "no weights to read"; return HT_ERR_STATE; }
+	CHECK_READY(ctx);
+	if (!w) return HT_ERR_ARG;
+	if (!ctx->have_weights) { ctx->err = "no weights to read"; return HT_ERR_STATE; }
 	if (n != HT_CNNB_COUNT) { ctx->err = "weights: expected HT_CNNB_COUNT fp32 values in .cnnb order"; return HT_ERR_ARG; }
 	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 	HIPCHK(ctx, hipMemcpy(w, ctx->d_weights, n * sizeof(float), hipMemcpyDeviceToHost));
@@ -305,6 +308,8 @@ extern "C" int ht_expected_cnn(const float *pose, const float *cam, float *expec
 extern "C" int ht_destroy(ht_ctx *ctx)
 {
 	if (!ctx) return HT_ERR_ARG;
+	ht_device_guard dev_guard_(ctx->device);
+	if (ctx->ready) (void)hipDeviceSynchronize();      // nothing of this context may still run when its buffers go
 	for (void *p : ctx->allocs) (void)hipFree(p);
 	for (auto &kv : ctx->prof) for (hipEvent_t e : kv.second.ev) (void)hipEventDestroy(e);
 	for (int i = 0; i < 2; i++) { if (ctx->side[i]) (void)hipStreamDestroy(ctx->side[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
@@ -315,11 +320,24 @@ extern "C" int ht_destroy(ht_ctx *ctx)
 }
 extern "C" const char *ht_last_error(const ht_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 extern "C" int ht_get_params(const ht_ctx *ctx, ht_params *p) { if (!ctx || !p) return HT_ERR_ARG; *p = ctx->par; return HT_OK; }
-extern "C" int ht_set_params(ht_ctx *ctx, const ht_params *p) { if (!ctx || !p) return HT_ERR_ARG; ctx->par = *p; sync_params(ctx); return HT_OK; }
+// The reference takes any value (load_config writes 0 into every field its file omits, handtrack.h:822-828) and then divides by subsample_fraction
+// (physmodel.h:58-64) or loops forever; here a configuration the kernels cannot run is refused with a message instead.
+extern "C" int ht_set_params(ht_ctx *ctx, const ht_params *p)
+{
+	if (!ctx || !p) return HT_ERR_ARG;
+	const char *bad = nullptr;
+	if (p->subsample_fraction < 1) bad = "subsample_fraction must be >= 1";
+	else if (!(p->drangey > 0.1f)) bad = "drangey must exceed the near limit 0.1";
+	else if (p->steps < 0 || p->steps_keypoints < 0 || p->steps_keyangles < 0 || p->steps_palmangle < 0 || p->steps_cloudstart < 0 || p->steps_unibody < 0) bad = "step counts must be >= 0";
+	else if (p->physics_iterations < 0 || p->physics_iterations_post < 0) bad = "physics iteration counts must be >= 0";
+	else if (p->mainthreadpasses < 0) bad = "mainthreadpasses must be >= 0";
+	else if (p->min_point_num < 0) bad = "min_point_num must be >= 0";
+	if (bad) { ctx->err = std::string("ht_set_params: ") + bad; return HT_ERR_ARG; }
+	ctx->par = *p; sync_params(ctx);
+	return HT_OK;
+}
 extern "C" int ht_model_info(const ht_ctx *ctx, int *nb, int *nj, int *mb) { if (!ctx) return HT_ERR_ARG; if (nb) *nb = ctx->model.nb; if (nj) *nj = ctx->model.nj; if (mb) *mb = ctx->B; return HT_OK; }
 
-#define CHECK_READY(ctx) do { if (!(ctx)) return HT_ERR_ARG; if (!(ctx)->ready) { (ctx)->err = "context not initialised (ht_create failed)"; return HT_ERR_STATE; } } while (0)
-#define CHECK_BATCH(ctx, B) do { if ((B) < 1 || (B) > (ctx)->B) { (ctx)->err = "batch exceeds the capacity given to ht_create"; return HT_ERR_ARG; } } while (0)
 
 // ------------------------------------------------------------------------------------------------- CNN
 extern "C" int ht_cnn_load_weights(ht_ctx *ctx, const float *w, size_t n)
@@ -352,7 +370,7 @@ extern "C" int ht_cnn_eval_dev(ht_ctx *ctx, const float *d_in, float *d_out, int
 {
 	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
 	if (!d_in || !d_out) return HT_ERR_ARG;
-	int r = cnn_forward(ctx, d_in, d_out, B, (hipStream_t)stream);
+	int r = cnn_forward(ctx, d_in, d_out, B, ht_user_stream(ctx, stream));
 	if (r) return r;
 	HIPCHK(ctx, hipGetLastError());
 	return HT_OK;
@@ -363,6 +381,66 @@ extern "C" int ht_cnn_eval(ht_ctx *ctx, const float *in, float *out, int B)
 	if (!in || !out) return HT_ERR_ARG;
 	HIPCHK(ctx, hipMemcpyAsync(ctx->d_cnn_in, in, (size_t)B * HT_CNN_IN * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
 	int r = cnn_forward(ctx, ctx->d_cnn_in, ctx->d_cnn_out, B, ctx->stream);
+	if (r) return r;
+	HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_cnn_out, (size_t)B * HT_CNN_OUT * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
+
+// The same layer list on a 128x128 input (BASELINE configs[4] / SURVEY 8d "config 5 (ii)"): conv5 -> 124, pool -> 62 -> 31, conv4 -> 28, pool -> 14,
+// FC 12544 -> 2048 -> 2304, chunked softmax.  A second set of weights and activations beside the 64x64 net's, allocated on first use.
+extern "C" int ht_cnn_load_weights_sized(ht_ctx *ctx, int side, const float *w, size_t n)
+{
+	CHECK_READY(ctx);
+	if (side == 64) return ht_cnn_load_weights(ctx, w, n);
+	if (side != 128) { ctx->err = "CNN input side must be 64 or 128"; return HT_ERR_ARG; }
+	if (!w || n != HT_CNNB128_COUNT) { ctx->err = "weights: expected HT_CNNB128_COUNT fp32 values in .cnnb order"; return HT_ERR_ARG; }
+	if (!ctx->d_weights128)
+	{
+		int r;
+		const size_t B = (size_t)ctx->B;
+		if ((r = dev_alloc(ctx, &ctx->d_weights128, (size_t)HT_CNNB128_COUNT + 16384)) || (r = dev_alloc(ctx, &ctx->d_in128, B * HT_CNN128_IN)) ||
+		    (r = dev_alloc(ctx, &ctx->d_act1_128, B * 16 * 31 * 31)) || (r = dev_alloc(ctx, &ctx->d_act2_128, B * 12544))) return r;
+	}
+	float *d = ctx->d_weights128;
+	HIPCHK(ctx, hipMemcpy(d, w, n * sizeof(float), hipMemcpyHostToDevice));
+	const float *W2 = w + 416;
+	std::vector<float> w2p(16384);      // conv2 repacked as for the 64x64 net
+	for (int oc = 0; oc < 64; oc++) for (int ic = 0; ic < 16; ic++) for (int ky = 0; ky < 4; ky++) for (int kx = 0; kx < 4; kx++)
+		w2p[(size_t)((ky * 4 + kx) * 16 + ic) * 64 + oc] = W2[kx + 4 * (ky + 4 * (ic + 16 * oc))];
+	HIPCHK(ctx, hipMemcpy(d + HT_CNNB128_COUNT, w2p.data(), 16384 * sizeof(float), hipMemcpyHostToDevice));
+	ht_cnn_weights &cw = ctx->cnnw128;
+	cw.W1 = d; cw.B1 = d + 400; cw.W2p = d + HT_CNNB128_COUNT; cw.B2 = d + 416 + 16384; cw.W3 = d + 416 + 16448; cw.B3 = cw.W3 + (size_t)12544 * 2048; cw.W4 = cw.B3 + 2048; cw.B4 = cw.W4 + (size_t)2048 * 2304;
+	ctx->have_weights128 = true;
+	return HT_OK;
+}
+static int cnn128_forward(ht_ctx *ctx, const float *d_in, float *d_out, int B, hipStream_t s)
+{
+	if (!ctx->have_weights128) { ctx->err = "weights of the 128x128 net not loaded (ht_cnn_load_weights_sized)"; return HT_ERR_STATE; }
+	ht_prof_scope p0(ctx, "cnn128", s, true);
+	ht_launch_cnn(ctx->cnnw128, d_in, ctx->d_act1_128, ctx->d_act2_128, ctx->d_act3, ctx->d_logits, B, s, 128);
+	ht_launch_softmax_decode(ctx->d_logits, d_out, nullptr, nullptr, 1, B, s);
+	return HT_OK;
+}
+extern "C" int ht_cnn_eval_sized_dev(ht_ctx *ctx, int side, const float *d_in, float *d_out, int B, void *stream)
+{
+	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	if (side == 64) return ht_cnn_eval_dev(ctx, d_in, d_out, B, stream);
+	if (side != 128 || !d_in || !d_out) { ctx->err = "CNN input side must be 64 or 128"; return HT_ERR_ARG; }
+	int r = cnn128_forward(ctx, d_in, d_out, B, ht_user_stream(ctx, stream));
+	if (r) return r;
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
+extern "C" int ht_cnn_eval_sized(ht_ctx *ctx, int side, const float *in, float *out, int B)
+{
+	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	if (side == 64) return ht_cnn_eval(ctx, in, out, B);
+	if (side != 128 || !in || !out) { ctx->err = "CNN input side must be 64 or 128"; return HT_ERR_ARG; }
+	if (!ctx->have_weights128) { ctx->err = "weights of the 128x128 net not loaded (ht_cnn_load_weights_sized)"; return HT_ERR_STATE; }
+	HIPCHK(ctx, hipMemcpyAsync(ctx->d_in128, in, (size_t)B * HT_CNN128_IN * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+	int r = cnn128_forward(ctx, ctx->d_in128, ctx->d_cnn_out, B, ctx->stream);
 	if (r) return r;
 	HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_cnn_out, (size_t)B * HT_CNN_OUT * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
 	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -438,6 +516,7 @@ extern "C" int ht_profile_enable(ht_ctx *ctx, int on) { if (!ctx) return HT_ERR_
 extern "C" int ht_profile_read(ht_ctx *ctx, int reset, int max_entries, char *names, int name_stride, float *total_ms, int *launches, int *n_entries)
 {
 	if (!ctx || !n_entries) return HT_ERR_ARG;
+	ht_device_guard dev_guard_(ctx->device);
 	int k = 0;
 	for (auto &kv : ctx->prof)
 	{

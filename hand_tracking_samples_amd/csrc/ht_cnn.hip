@@ -121,23 +121,30 @@ __global__ __launch_bounds__(256) void k_prepare_frame(const uint16_t *__restric
 // ------------------------------------------------------------------------------------------------- k_conv1
 __device__ __forceinline__ float tanh_ref(float t) { float e = (float)exp((double)(2 * t)); return (e - 1) / (e + 1); }   // cnn.h:31
 
-// block per frame; thread <-> pooled pixel (15x15), loops the 16 output channels over an 8x8 register patch
+// Thread <-> pooled pixel, loops the 16 output channels over an 8x8 register patch.  A block takes PR pooled rows of one frame: the
+// 4*PR + 4 input rows they need are staged in LDS.  64x64 input: IW = 64, PW = 15, PR = 15 (one block per frame, the whole 16 KB tile).
+// 128x128 input (BASELINE configs[4]): IW = 128, PW = 31, PR = 8 -> 4 bands of 36 rows = 18 KB each instead of one 64 KB tile, so several
+// blocks stay resident per CU.
+template <int IW, int PW, int PR>
 __global__ __launch_bounds__(256) void k_conv1(const float *__restrict__ cnn_in, const float *__restrict__ W1, const float *__restrict__ B1, float *__restrict__ act1)
 {
-	__shared__ __attribute__((aligned(16))) float tile[64 * 64];
-	const int b = blockIdx.x, t = threadIdx.x;
-	const float4 *src = reinterpret_cast<const float4 *>(cnn_in + (size_t)b * 4096);
+	constexpr int TR = 4 * PR + 4;                       // input rows a band touches
+	static_assert(PR * PW <= 256 && TR <= IW && (IW % 4) == 0, "band does not fit the block");
+	__shared__ __attribute__((aligned(16))) float tile[TR * IW];
+	const int b = blockIdx.x, band = blockIdx.y, t = threadIdx.x;
+	const int row0 = 4 * PR * band;
+	const int nrows = min(TR, IW - row0);
+	const float4 *src = reinterpret_cast<const float4 *>(cnn_in + (size_t)b * IW * IW + (size_t)row0 * IW);
 	float4 *tl = reinterpret_cast<float4 *>(tile);
-#pragma unroll
-	for (int i = 0; i < 4; i++) tl[t + 256 * i] = src[t + 256 * i];
+	for (int i = t; i < nrows * IW / 4; i += 256) tl[i] = src[i];
 	__syncthreads();
-	if (t >= 225) return;
-	const int px = t % 15, py = t / 15;
+	const int px = t % PW, pyl = t / PW, py = PR * band + pyl;
+	if (pyl >= PR || py >= PW) return;
 	float patch[8][8];
 #pragma unroll
 	for (int r = 0; r < 8; r++)
 	{
-		float4 a = tl[((4 * py + r) * 64 + 4 * px) / 4], c = tl[((4 * py + r) * 64 + 4 * px) / 4 + 1];
+		float4 a = tl[((4 * pyl + r) * IW + 4 * px) / 4], c = tl[((4 * pyl + r) * IW + 4 * px) / 4 + 1];
 		patch[r][0] = a.x; patch[r][1] = a.y; patch[r][2] = a.z; patch[r][3] = a.w; patch[r][4] = c.x; patch[r][5] = c.y; patch[r][6] = c.z; patch[r][7] = c.w;
 	}
 	for (int c = 0; c < 16; c++)
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(256) void k_conv1(const float *__restrict__ cnn_in,
 			for (int qx = 0; qx < 2; qx++)
 				m[qy][qx] = fmax_std(fmax_std(fmax_std(acc[2 * qy][2 * qx], acc[2 * qy][2 * qx + 1]), acc[2 * qy + 1][2 * qx]), acc[2 * qy + 1][2 * qx + 1]);
 		float mm = fmax_std(fmax_std(fmax_std(m[0][0], m[0][1]), m[1][0]), m[1][1]);
-		act1[(size_t)b * 3600 + c * 225 + py * 15 + px] = tanh_ref(mm);
+		act1[(size_t)b * (16 * PW * PW) + c * (PW * PW) + py * PW + px] = tanh_ref(mm);
 	}
 }
 
@@ -175,13 +182,20 @@ __global__ __launch_bounds__(256) void k_conv1(const float *__restrict__ cnn_in,
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// W2p: weights repacked to [k][oc] with k = (ky*4+kx)*16 + ic, i.e. the reference's accumulation order (cnn.h:223-225)
+// W2p: weights repacked to [k][oc] with k = (ky*4+kx)*16 + ic, i.e. the reference's accumulation order (cnn.h:223-225).
+// A block takes BAND output rows of one frame (all 64 output channels, 16 per wave): implicit GEMM M = BAND*OW, N = 64, K = 256.
+// 64x64 net: IWD = 15, OW = 12, BAND = 12 (M = 144, the whole frame).  128x128 net: IWD = 31, OW = 28, BAND = 4 (M = 112; 7 bands per frame,
+// 14 KB of input rows + 28 KB of pre-pool outputs in LDS instead of 61 KB + 200 KB for the whole frame).
+template <int IWD, int OW, int BAND>
 __global__ __launch_bounds__(256) void k_conv2(const float *__restrict__ act1, const float *__restrict__ W2p, const float *__restrict__ B2, float *__restrict__ act2)
 {
-	__shared__ float in[3600];
-	__shared__ float out[64 * 144];
-	const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-	for (int i = t; i < 3600; i += 256) in[i] = act1[(size_t)b * 3600 + i];
+	constexpr int M = BAND * OW, MT = M / 16, IR = BAND + 3, PO = OW / 2, CH = IR * IWD;
+	static_assert(M % 16 == 0 && BAND % 2 == 0 && OW % BAND == 0, "band must hold whole MFMA tiles and whole pooling windows");
+	__shared__ float in[16 * CH];
+	__shared__ float out[64 * M];
+	const int b = blockIdx.x, band = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const int oy0 = band * BAND;
+	for (int i = t; i < 16 * CH; i += 256) { const int ic = i / CH, r = i % CH; in[i] = act1[(size_t)b * (16 * IWD * IWD) + ic * (IWD * IWD) + oy0 * IWD + r]; }
 	const int n = 16 * wave + (lane & 15);
 	float breg[64];
 #pragma unroll
@@ -190,30 +204,31 @@ __global__ __launch_bounds__(256) void k_conv2(const float *__restrict__ act1, c
 	__syncthreads();
 	// per lane k decomposition is fixed per k-step: k = 4*ks + (lane>>4): tap p = k>>4 = ks>>2, ic = 4*(ks&3) + (lane>>4)
 	const int icl = lane >> 4;
-	for (int mt = 0; mt < 9; mt++)
+	for (int mt = 0; mt < MT; mt++)
 	{
 		const int m = mt * 16 + (lane & 15);
-		const int oy = m / 12, ox = m % 12;
+		const int oy = m / OW, ox = m % OW;
 		f32x4 acc = { bias, bias, bias, bias };
-		const float *base = in + oy * 15 + ox;
+		const float *base = in + oy * IWD + ox;
 #pragma unroll
 		for (int ks = 0; ks < 64; ks++)
 		{
 			const int p = ks >> 2, ky = p >> 2, kx = p & 3, ic = 4 * (ks & 3) + icl;
-			float a = base[ic * 225 + ky * 15 + kx];
+			float a = base[ic * CH + ky * IWD + kx];
 			acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[ks], acc, 0, 0, 0);
 		}
 		// C/D map 16x16: col = lane&15 (oc), row = (lane>>4)*4 + r (pixel within the tile)
 #pragma unroll
-		for (int r = 0; r < 4; r++) out[n * 144 + mt * 16 + (lane >> 4) * 4 + r] = acc[r];
+		for (int r = 0; r < 4; r++) out[n * M + mt * 16 + (lane >> 4) * 4 + r] = acc[r];
 	}
 	__syncthreads();
-	for (int i = t; i < 2304; i += 256)
+	constexpr int PB = (BAND / 2) * PO;                  // pooled pixels per channel in this band
+	for (int i = t; i < 64 * PB; i += 256)
 	{
-		const int c = i / 36, py = (i % 36) / 6, pxx = i % 6;
-		const float *o = out + c * 144 + (2 * py) * 12 + 2 * pxx;
-		float mm = fmax_std(fmax_std(fmax_std(o[0], o[1]), o[12]), o[13]);
-		act2[(size_t)b * 2304 + i] = tanh_ref(mm);        // index = x + 6y + 36c, the layout LFull consumes
+		const int c = i / PB, py = (i % PB) / PO, pxx = i % PO;
+		const float *o = out + c * M + (2 * py) * OW + 2 * pxx;
+		float mm = fmax_std(fmax_std(fmax_std(o[0], o[1]), o[OW]), o[OW + 1]);
+		act2[(size_t)b * (64 * PO * PO) + c * (PO * PO) + (oy0 / 2 + py) * PO + pxx] = tanh_ref(mm);        // index = x + PO*y + PO*PO*c, the layout LFull consumes
 	}
 }
 
@@ -416,12 +431,22 @@ void ht_launch_prepare_frame(const uint16_t *depth, const float *cams, int w, in
 {
 	hipLaunchKernelGGL(k_prepare_frame, dim3(B), dim3(256), 0, s, depth, cams, w, h, drangey, fraction, pts, npts, overflow);
 }
-void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, float *act2, float *act3, float *logits, int B, hipStream_t s)
+// side = 64: PoseInitializerCNN's topology (handtrack.h:108-118); side = 128: the same layers on a 128x128 input (act1 [B][16*31*31], act2 [B][12544])
+void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, float *act2, float *act3, float *logits, int B, hipStream_t s, int side)
 {
-	hipLaunchKernelGGL(k_conv1, dim3(B), dim3(256), 0, s, cnn_in, w.W1, w.B1, act1);
-	hipLaunchKernelGGL(k_conv2, dim3(B), dim3(256), 0, s, act1, w.W2p, w.B2, act2);
 	dim3 g1(2048 / 64, (B + FC_BM - 1) / FC_BM), g2(2304 / 96, (B + FC_BM - 1) / FC_BM);
-	hipLaunchKernelGGL((k_fc<true, 2>), g1, dim3(512), 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
+	if (side == 128)
+	{
+		hipLaunchKernelGGL((k_conv1<128, 31, 8>), dim3(B, 4), dim3(256), 0, s, cnn_in, w.W1, w.B1, act1);
+		hipLaunchKernelGGL((k_conv2<31, 28, 4>), dim3(B, 7), dim3(256), 0, s, act1, w.W2p, w.B2, act2);
+		hipLaunchKernelGGL((k_fc<true, 2>), g1, dim3(512), 0, s, act2, w.W3, w.B3, act3, B, 2048, 12544);
+	}
+	else
+	{
+		hipLaunchKernelGGL((k_conv1<64, 15, 15>), dim3(B, 1), dim3(256), 0, s, cnn_in, w.W1, w.B1, act1);
+		hipLaunchKernelGGL((k_conv2<15, 12, 12>), dim3(B, 1), dim3(256), 0, s, act1, w.W2p, w.B2, act2);
+		hipLaunchKernelGGL((k_fc<true, 2>), g1, dim3(512), 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
+	}
 	hipLaunchKernelGGL((k_fc<false, 3>), g2, dim3(768), 0, s, act3, w.W4, w.B4, logits, B, 2304, 2048);
 }
 void ht_launch_softmax_decode(const float *logits, float *cnn_out, const float *cams, float *analysis, int softmax, int B, hipStream_t s)

@@ -10,7 +10,40 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/ht_mi355x.h"
+#include <stdlib.h>
 #include "ht_math.hpp"
+
+// Every extern "C" entry point that touches the device makes its context's GPU current for the duration of the call and restores the caller's
+// device afterwards: a process may hold contexts on several GPUs and call from any thread (first-use allocations, blocking copies and kernel
+// lookups all go to the current device).
+struct ht_device_guard
+{
+	int prev = -1, want;
+	explicit ht_device_guard(int dev) : want(dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); }
+	~ht_device_guard() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+	ht_device_guard(const ht_device_guard &) = delete;
+	ht_device_guard &operator=(const ht_device_guard &) = delete;
+};
+// Tuning switches (skip parts of a kernel, serialise streams) exist only in builds made with -DHT_TUNING (HT_TUNING=1 python -m
+// hand_tracking_samples_amd.build, used by tools/ablate_*.sh and tools/solve_stats.py): the shipped library ignores the environment.
+static inline int ht_tuning_flags()
+{
+#ifdef HT_TUNING
+	static int v = -1;
+	if (v < 0) { const char *e = getenv("HT_DEBUG_SKIP"); v = e ? atoi(e) : 0; }
+	return v;
+#else
+	return 0;
+#endif
+}
+static inline bool ht_tuning_env(const char *name)
+{
+#ifdef HT_TUNING
+	return getenv(name) != nullptr;
+#else
+	(void)name; return false;
+#endif
+}
 
 #define HT_MAXPTS 4096          // sub-sampled points per frame: all of a 64x64 tile's (4096 / 4) or of a 128x128 frame's (16384 / 4); larger frames must stay below it
 static_assert(HT_MAXPTS == HT_MAX_POINTS, "public header and kernels disagree on the point capacity");
@@ -86,5 +119,5 @@ struct ht_cnn_weights { const float *W1, *B1, *W2p, *B2, *W3, *B3, *W4, *B4; };
 // ---- kernel launchers (defined in the .hip files) ----
 void ht_launch_prepare(const uint16_t *depth, const float *cams, float drangey, int fraction, float *cnn_in, float4 *pts, int *npts, int B, hipStream_t s);
 void ht_launch_prepare_frame(const uint16_t *depth, const float *cams, int w, int h, float drangey, int fraction, float4 *pts, int *npts, int *overflow, int B, hipStream_t s);
-void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, float *act2, float *act3, float *logits, int B, hipStream_t s);
+void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, float *act2, float *act3, float *logits, int B, hipStream_t s, int side = 64);
 void ht_launch_softmax_decode(const float *logits, float *cnn_out, const float *cams, float *analysis, int softmax, int B, hipStream_t s);

@@ -660,16 +660,16 @@ size_t ht_contacts_workspace_bytes(int B) { (void)B; return 16; }      // the po
 void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s)
 {
 	int *caps = reinterpret_cast<int *>(epa_ws);
-	static int dbg = -1;
-	static bool attr_set = false;
-	if (dbg < 0) { const char *e = getenv("HT_DEBUG_SKIP"); dbg = e ? atoi(e) : 0; }
+	const int dbg = ht_tuning_flags();
+	static bool attr_set[64];                 // per device: the attribute belongs to the device's copy of the code object
+	int dev = 0; (void)hipGetDevice(&dev); dev &= 63;
 	const int wpf = M.nb * (M.nb - 1) / 2 > 200 ? 2 : 1;
 	const size_t smem = (size_t)M.vert_off[M.nb] * sizeof(float4) + GJK_FRAMES * gjk_frame_stride() + GJK_FRAMES * wpf * gjk_wave_stride();
-	if (!attr_set)
+	if (!attr_set[dev])
 	{
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_contacts<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_contacts<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		attr_set = true;
+		attr_set[dev] = true;
 	}
 	const dim3 grid((B + GJK_FRAMES - 1) / GJK_FRAMES);
 	if (wpf == 2) hipLaunchKernelGGL(k_contacts<2>, grid, dim3(64 * GJK_FRAMES * 2), smem, s, M, state, driftmax, jiggle_sin, active_flag, contacts, ncontacts, B, dbg, caps);

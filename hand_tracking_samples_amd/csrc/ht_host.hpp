@@ -14,12 +14,15 @@ struct ht_ctx
 	int B = 0, device = 0;
 	std::string err;
 	hipStream_t stream = nullptr;
+	hipStream_t last_user_stream = nullptr;         // stream of the latest *_dev call (host-read helpers wait for it too)
 	hipStream_t side[2] = { nullptr, nullptr };     // independent kernels of one fit step (cloud rows, contacts, chamber) run side by side
 	hipEvent_t ev_fork = nullptr, ev_join[2] = { nullptr, nullptr };
 	ht_params par;
 	ht_physics_dev phys;
 	ht_model_dev model;
 	ht_cnn_weights cnnw;
+	ht_cnn_weights cnnw128; bool have_weights128 = false;         // the 128x128-input variant of the net (BASELINE configs[4]); buffers allocated on first use
+	float *d_weights128 = nullptr, *d_in128 = nullptr, *d_act1_128 = nullptr, *d_act2_128 = nullptr;
 	std::vector<float> h_bodyc, h_jointc;
 	std::vector<float4> h_verts, h_planes;                        // host copies of the model geometry (ht_scale rewrites them)
 	float *d_train = nullptr;                                    // training arena: layer outputs, errors, split-K partial sums (allocated on first use)
@@ -55,3 +58,12 @@ struct ht_prof_scope
 };
 
 int ht_alloc_buffers(ht_ctx *ctx);
+// *_dev entry points: a NULL stream means the context's own stream (never the legacy default stream); the choice is remembered so that the
+// host-read helpers (ht_capacity_events, ht_frames_overflow, ht_get_tracker_flags, ...) can wait for work enqueued on a caller's stream
+static inline hipStream_t ht_user_stream(ht_ctx *ctx, void *stream) { hipStream_t s = stream ? (hipStream_t)stream : ctx->stream; ctx->last_user_stream = s; return s; }
+static inline hipError_t ht_sync_all(ht_ctx *ctx)
+{
+	hipError_t e = hipStreamSynchronize(ctx->stream);
+	if (e == hipSuccess && ctx->last_user_stream && ctx->last_user_stream != ctx->stream) e = hipStreamSynchronize(ctx->last_user_stream);
+	return e;
+}

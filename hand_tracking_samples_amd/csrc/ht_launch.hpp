@@ -33,7 +33,7 @@ void ht_launch_decide_reset(const float *err_old, float thr, int angles_only, in
 void ht_launch_scratch(const ht_model_dev &M, float *state, const float4 *pts, const int *npts, const float *analysis, const float *cams, const int *flags, int B, hipStream_t s);
 void ht_launch_unibody(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float *rows, const int *nrows, const int *flags, float *scratch, int scratch_stride, int B, hipStream_t s);
 void ht_launch_accept(float *hand, const float *other, const float *err_old, const float *err_new, const int *npts, float *prev_err, int *initializing, int *accepted, int nb, int n, const ht_params &p, hipStream_t s);
-void ht_launch_output(const ht_model_dev &M, const float *hand, const int *npts, int *initializing, int min_point_num, float *poses, int n, hipStream_t s);
+void ht_launch_output(const ht_model_dev &M, const float *hand, const int *npts, int *initializing, int min_point_num, float *poses, int n, hipStream_t s, int raw = 0);
 // ht_segment.hip
 bool ht_segment_supported(int w, int h);
 void ht_launch_segment(const uint16_t *depth, const float *cams, int w, int h, int entry_options, float wrange_hi, float diam, uint16_t *tiles, float *cams_out, int B, hipStream_t s);

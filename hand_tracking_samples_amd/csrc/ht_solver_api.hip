@@ -7,7 +7,7 @@
 #include "ht_launch.hpp"
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return HT_ERR_HIP; } } while (0)
-#define CHECK_READY(ctx) do { if (!(ctx)) return HT_ERR_ARG; if (!(ctx)->ready) { (ctx)->err = "context not initialised (ht_create failed)"; return HT_ERR_STATE; } } while (0)
+#define CHECK_READY(ctx) if (!(ctx)) return HT_ERR_ARG; if (!(ctx)->ready) { (ctx)->err = "context not initialised (ht_create failed)"; return HT_ERR_STATE; } ht_device_guard dev_guard_((ctx)->device)
 #define CHECK_BATCH(ctx, B) do { if ((B) < 1 || (B) > (ctx)->B) { (ctx)->err = "batch exceeds the capacity given to ht_create"; return HT_ERR_ARG; } } while (0)
 #define CHECK_RANGE(ctx, first, n) do { if ((first) < 0 || (n) < 1 || (first) + (n) > (ctx)->B) { (ctx)->err = "slot range exceeds the capacity given to ht_create"; return HT_ERR_ARG; } } while (0)
 
@@ -28,7 +28,7 @@ static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int 
 	a.state = ctx->d_state[which]; a.scratch = ctx->d_scratch; a.scratch_stride = scratch_stride(ctx);
 	a.apply_angles = apply_angles; a.drive_force = drive_force; a.ray_rows = ray_rows; a.arm_cone = arm_cone; a.zero_momenta = zero_momenta;
 	a.steps_keyangles = ctx->par.steps_keyangles; a.min_cray_prob = ctx->par.min_cray_prob;
-	{ static int dbg = -1; if (dbg < 0) { const char *e = getenv("HT_DEBUG_SKIP"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
+	a.dbg = ht_tuning_flags();
 	ht_launch_solve(ctx->model, ctx->phys, a, B, s);
 }
 // Fork/join helpers: the row-producing kernels of one fit step only read the pose, so they run side by side on two extra streams
@@ -47,7 +47,7 @@ static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int 
 		const bool rays = (st < p.steps_keypoints) && !p.angles_only;
 		const bool cloud = (st >= p.steps_cloudstart) && !p.angles_only;
 		const bool coll = ctx->phys.use_collision != 0;
-		static const bool no_side = getenv("HT_NO_SIDE") != nullptr;      // timing experiments
+		static const bool no_side = ht_tuning_env("HT_NO_SIDE");      // timing experiments (-DHT_TUNING builds only)
 		const bool par = cloud && coll && !ctx->profile_phases && !no_side;
 		if (par) fork(ctx, s);
 		if (cloud) { ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, active, 4, 1, 2, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[0] : s); }
@@ -62,7 +62,7 @@ static void main_pass(ht_ctx *ctx, int B, hipStream_t s)
 {
 	const ht_params &p = ctx->par;
 	const bool coll = ctx->phys.use_collision != 0;
-	static const bool no_side = getenv("HT_NO_SIDE") != nullptr;
+	static const bool no_side = ht_tuning_env("HT_NO_SIDE");
 	const bool par = !ctx->profile_phases && !no_side;
 	if (par) fork(ctx, s);
 	{ ht_prof_scope ps(ctx, "chamber", s, true); ht_launch_chamber(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, p.min_point_num, p.boundary_planes, 10.0f, ctx->d_chamber, ctx->d_nchamber, B, par ? ctx->side[1] : s); }
@@ -88,7 +88,11 @@ static void reset_path(ht_ctx *ctx, const int *flags, int n_unibody, int B, hipS
 // (handtrack.h:697-698) and from then on ctx->d_cams holds the SEGMENT cameras (CNN decode, landmark rays, PoseFromScratch, UnibodyFit and
 // MultiStepSim take segment.cam.pose); the point cloud and FitError keep the full frame and its camera.
 struct frame_src { int w, h; float segment_scale; };
-static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, const float *d_start, int B, float *d_poses_out, float *d_cnn_out, hipStream_t s, const frame_src *fs = nullptr)
+// `mode`: UPD_FULL = HandTracker::update (handtrack.h:748-785); UPD_CNN_MODEL = update_cnn_model alone (:734-741): othermodel is NOT re-seeded from
+// handmodel, no main-thread passes, no "initializing = 50" rule, the result is othermodel.GetPose() plus the accept decision, handmodel untouched;
+// UPD_KICKSTART = kickstart (:743-746) = the same followed by handmodel.SetPose(pose) where the pose was accepted.
+enum { UPD_FULL = 0, UPD_CNN_MODEL = 1, UPD_KICKSTART = 2 };
+static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, const float *d_start, int B, float *d_poses_out, float *d_cnn_out, hipStream_t s, const frame_src *fs = nullptr, int mode = UPD_FULL)
 {
 	if (!ctx->have_weights) { ctx->err = "CNN weights not loaded (ht_cnn_load_weights)"; return HT_ERR_STATE; }
 	const ht_params &p = ctx->par;
@@ -127,7 +131,7 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		else ht_launch_prepare(d_depth, ctx->d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, ctx->d_pts, ctx->d_npts, B, s);
 	}
 	float *cnn_out = d_cnn_out ? d_cnn_out : ctx->d_cnn_out;
-	static const bool no_overlap = getenv("HT_NO_OVERLAP") != nullptr;      // timing experiments
+	static const bool no_overlap = ht_tuning_env("HT_NO_OVERLAP");      // timing experiments (-DHT_TUNING builds only)
 	const bool overlap = !no_overlap && !ctx->profile_phases && p.steps >= 1 && p.steps_cloudstart >= 1 && !p.angles_only;
 	if (overlap)
 	{
@@ -135,7 +139,7 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		// first step for the frames that keep their pose only read the point cloud and the tracker state, so they run beside the CNN.
 		hipStream_t t = ctx->side[1];
 		fork(ctx, s);
-		ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, t);                       // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757
+		if (mode == UPD_FULL) ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, t);     // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757
 		ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_old, B, t);
 		ht_launch_decide_reset(ctx->d_err_old, p.full_reset_on_error, p.angles_only, ctx->d_flags, ctx->d_nflags, B, t);
 		if (ctx->phys.use_collision) ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, ctx->d_nflags, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, t);
@@ -159,14 +163,15 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 	}
 	else
 	{
-		ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, s);                       // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757
+		if (mode == UPD_FULL) ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, s);     // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757
 		{ ht_prof_scope ps(ctx, "fit_error", s, true); ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_old, B, s); }
 		ht_launch_decide_reset(ctx->d_err_old, p.full_reset_on_error, p.angles_only, ctx->d_flags, ctx->d_nflags, B, s);
 		reset_path(ctx, ctx->d_flags, p.steps_unibody, B, s, s);
 		multistep(ctx, B, s);
 	}
 	{ ht_prof_scope ps(ctx, "fit_error", s, true); ht_launch_fit_error(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_new, B, s); }
-	ht_launch_accept(ctx->d_state[0], ctx->d_state[1], ctx->d_err_old, ctx->d_err_new, ctx->d_npts, ctx->d_prev_err, ctx->d_initializing, ctx->d_accepted, nb, B, p, s);
+	ht_launch_accept(mode == UPD_CNN_MODEL ? nullptr : ctx->d_state[0], ctx->d_state[1], ctx->d_err_old, ctx->d_err_new, ctx->d_npts, ctx->d_prev_err, ctx->d_initializing, ctx->d_accepted, nb, B, p, s);
+	if (mode != UPD_FULL) { ht_launch_output(ctx->model, ctx->d_state[1], ctx->d_npts, ctx->d_initializing, p.min_point_num, d_poses_out, B, s, 1); return HT_OK; }      // othermodel.GetPose()
 	for (int i = 0; !p.angles_only && i < p.mainthreadpasses; i++) main_pass(ctx, B, s);
 	ht_launch_output(ctx->model, ctx->d_state[0], ctx->d_npts, ctx->d_initializing, p.min_point_num, d_poses_out, B, s);
 	return HT_OK;
@@ -213,6 +218,7 @@ extern "C" int ht_set_state(ht_ctx *ctx, int which, int first, int n, const floa
 extern "C" int ht_get_tracker_flags(ht_ctx *ctx, int first, int n, float *prev_frame_error, int *initializing)
 {
 	CHECK_READY(ctx); CHECK_RANGE(ctx, first, n);
+	HIPCHK(ctx, ht_sync_all(ctx));
 	if (prev_frame_error) HIPCHK(ctx, hipMemcpy(prev_frame_error, ctx->d_prev_err + first, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
 	if (initializing) HIPCHK(ctx, hipMemcpy(initializing, ctx->d_initializing + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
 	return HT_OK;
@@ -228,7 +234,7 @@ extern "C" int ht_update_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *
 {
 	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
 	if (!d_depth || !d_cams || !d_poses_out) return HT_ERR_ARG;
-	int r = run_update(ctx, d_depth, d_cams, d_start_poses, B, d_poses_out, nullptr, (hipStream_t)stream);
+	int r = run_update(ctx, d_depth, d_cams, d_start_poses, B, d_poses_out, nullptr, ht_user_stream(ctx, stream));
 	if (r) return r;
 	HIPCHK(ctx, hipGetLastError());
 	return HT_OK;
@@ -262,7 +268,7 @@ extern "C" int ht_update_frames_dev(ht_ctx *ctx, const uint16_t *d_depth, const 
 	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
 	if (!d_depth || !d_cams || !d_poses_out) return HT_ERR_ARG;
 	if (!frames_args_ok(ctx, w, h)) return HT_ERR_ARG;
-	hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+	hipStream_t s = ht_user_stream(ctx, stream);
 	const frame_src fs = { w, h, segment_scale };
 	int r = run_update(ctx, d_depth, d_cams, d_start_poses, B, d_poses_out, nullptr, s, (w == 64 && h == 64) ? nullptr : &fs);
 	if (r) return r;
@@ -277,7 +283,7 @@ extern "C" int ht_capacity_events(ht_ctx *ctx, int *epa_cut_short, int *contacts
 {
 	CHECK_READY(ctx);
 	int v[3] = { 0, 0, 0 };
-	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	HIPCHK(ctx, ht_sync_all(ctx));
 	HIPCHK(ctx, hipMemcpy(v, ctx->d_epa_ws, sizeof v, hipMemcpyDeviceToHost));
 	if (epa_cut_short) *epa_cut_short = v[0];
 	if (contacts_dropped) *contacts_dropped = v[1];
@@ -289,6 +295,7 @@ extern "C" int ht_frames_overflow(ht_ctx *ctx, int *frames_over)
 	CHECK_READY(ctx);
 	if (!frames_over) return HT_ERR_ARG;
 	*frames_over = 0;
+	HIPCHK(ctx, ht_sync_all(ctx));
 	if (ctx->d_overflow) HIPCHK(ctx, hipMemcpy(frames_over, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost));
 	return HT_OK;
 }
@@ -319,6 +326,56 @@ extern "C" int ht_update_frames_sync(ht_ctx *ctx, const uint16_t *depth, const f
 	int over = 0;
 	HIPCHK(ctx, hipMemcpy(&over, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost));
 	if (over) { ctx->err = "ht_update_frames: " + std::to_string(over) + " frame(s) have more in-range points than the solver's capacity (4096 after sub-sampling); their result is not the reference's"; return HT_ERR_ARG; }
+	return HT_OK;
+}
+
+// HandTracker::update_cnn_model (handtrack.h:734-741) and kickstart (:743-746) for B trackers, frames of any supported size
+extern "C" int ht_update_cnn_model_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int w, int h, float segment_scale, int B, int apply_to_handmodel,
+                                        float *poses_out, int *accepted_out, float *cnn_out)
+{
+	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	if (!depth || !cams) return HT_ERR_ARG;
+	const bool tile = (w == 64 && h == 64);
+	if (!tile && !frames_args_ok(ctx, w, h)) return HT_ERR_ARG;
+	hipStream_t s = ctx->stream;
+	const int nb = ctx->model.nb;
+	const size_t npx = (size_t)w * h;
+	const uint16_t *d_in; const float *d_cin;
+	if (tile)
+	{
+		HIPCHK(ctx, hipMemcpyAsync(ctx->d_depth, depth, (size_t)B * npx * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+		HIPCHK(ctx, hipMemcpyAsync(ctx->d_cams, cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyHostToDevice, s));
+		d_in = ctx->d_depth; d_cin = ctx->d_cams;
+	}
+	else
+	{
+		if (ctx->frames_cap < (size_t)B * npx) { void *a = nullptr; HIPCHK(ctx, hipMalloc(&a, (size_t)ctx->B * npx * sizeof(uint16_t))); ctx->allocs.push_back(a); ctx->d_frames = (uint16_t *)a; ctx->frames_cap = (size_t)ctx->B * npx; }
+		if (!ctx->d_frame_cams_in) { void *a = nullptr; HIPCHK(ctx, hipMalloc(&a, (size_t)ctx->B * HT_CAM * sizeof(float))); ctx->allocs.push_back(a); ctx->d_frame_cams_in = (float *)a; }
+		HIPCHK(ctx, hipMemcpyAsync(ctx->d_frames, depth, (size_t)B * npx * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+		HIPCHK(ctx, hipMemcpyAsync(ctx->d_frame_cams_in, cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyHostToDevice, s));
+		d_in = ctx->d_frames; d_cin = ctx->d_frame_cams_in;
+	}
+	const frame_src fs = { w, h, segment_scale };
+	int r = run_update(ctx, d_in, d_cin, nullptr, B, ctx->d_poses_out, nullptr, s, tile ? nullptr : &fs, apply_to_handmodel ? UPD_KICKSTART : UPD_CNN_MODEL);
+	if (r) return r;
+	if (poses_out) HIPCHK(ctx, hipMemcpyAsync(poses_out, ctx->d_poses_out, (size_t)B * nb * HT_POSE * sizeof(float), hipMemcpyDeviceToHost, s));
+	if (accepted_out) HIPCHK(ctx, hipMemcpyAsync(accepted_out, ctx->d_accepted, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+	if (cnn_out) HIPCHK(ctx, hipMemcpyAsync(cnn_out, ctx->d_cnn_out, (size_t)B * HT_CNN_OUT * sizeof(float), hipMemcpyDeviceToHost, s));
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	HIPCHK(ctx, hipGetLastError());
+	if (accepted_out) for (int b = 0; b < B; b++) accepted_out[b] = accepted_out[b] != 0;
+	if (!tile) { int over = 0; HIPCHK(ctx, hipMemcpy(&over, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost)); if (over) { ctx->err = "ht_update_cnn_model: frame(s) with more in-range points than the solver's capacity"; return HT_ERR_ARG; } }
+	return HT_OK;
+}
+// Results of the CNN job of the latest update call of slots [first, first + n): HandTracker::cnn_input / cnn_output (handtrack.h:583-584) and the
+// decoded CNNOutputAnalysis (:182-242; layout as ht_stage_decode).  Any pointer may be NULL.
+extern "C" int ht_get_cnn_results(ht_ctx *ctx, int first, int n, float *cnn_input, float *cnn_output, float *analysis)
+{
+	CHECK_READY(ctx); CHECK_RANGE(ctx, first, n);
+	HIPCHK(ctx, ht_sync_all(ctx));
+	if (cnn_input) HIPCHK(ctx, hipMemcpy(cnn_input, ctx->d_cnn_in + (size_t)first * HT_CNN_IN, (size_t)n * HT_CNN_IN * sizeof(float), hipMemcpyDeviceToHost));
+	if (cnn_output) HIPCHK(ctx, hipMemcpy(cnn_output, ctx->d_cnn_out + (size_t)first * HT_CNN_OUT, (size_t)n * HT_CNN_OUT * sizeof(float), hipMemcpyDeviceToHost));
+	if (analysis) HIPCHK(ctx, hipMemcpy(analysis, ctx->d_analysis + (size_t)first * HT_ANALYSIS, (size_t)n * HT_ANALYSIS * sizeof(float), hipMemcpyDeviceToHost));
 	return HT_OK;
 }
 
@@ -398,8 +455,9 @@ extern "C" int ht_stage_scratch_unibody(ht_ctx *ctx, const float *analysis, int 
 extern "C" int ht_debug_solve_stats(ht_ctx *ctx, int B, float *out, int reset)
 {
 	if (!ctx || !ctx->ready || B < 1 || B > ctx->B) return HT_ERR_ARG;
+	ht_device_guard dev_guard_(ctx->device);
 	const int stride = scratch_stride(ctx);
-	if (hipStreamSynchronize(ctx->stream) != hipSuccess) return HT_ERR_HIP;
+	if (ht_sync_all(ctx) != hipSuccess) return HT_ERR_HIP;
 	for (int b = 0; b < B; b++)
 	{
 		float *src = ctx->d_scratch + ((size_t)b * stride + (stride - 1)) * 12;
@@ -413,6 +471,7 @@ extern "C" int ht_debug_solve_stats(ht_ctx *ctx, int B, float *out, int reset)
 extern "C" int ht_debug_contact_stats(ht_ctx *ctx, int B, float *out, int reset)
 {
 	if (!ctx || !ctx->ready || B < 1 || B > ctx->B) return HT_ERR_ARG;
+	ht_device_guard dev_guard_(ctx->device);
 	if (hipDeviceSynchronize() != hipSuccess) return HT_ERR_HIP;
 	for (int b = 0; b < B; b++)
 	{
@@ -430,7 +489,7 @@ extern "C" int ht_segment_vr_dev(ht_ctx *ctx, const uint16_t *d_depth, const flo
 	CHECK_READY(ctx);
 	(void)wrange_lo;      // the reference's lower bound is commented out (handtrack.h:288)
 	if (!d_depth || !d_cams || !d_tiles || !d_cams_out || B < 1) return HT_ERR_ARG;
-	hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+	hipStream_t s = ht_user_stream(ctx, stream);
 	if (w == 64 && h == 64)      // handtrack.h:283-284: a 64x64 frame is returned as it is
 	{
 		HIPCHK(ctx, hipMemcpyAsync(d_tiles, d_depth, (size_t)B * 4096 * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));

@@ -252,7 +252,7 @@ __global__ void k_accept(float *__restrict__ hand, const float *__restrict__ oth
 	const float olderror = err_old[b], newerror = err_new[b];
 	if (newerror > olderror) pfe = 0.0f; else pfe += olderror - newerror;
 	const bool take = (npts[b] > min_point_num && initializing[b]) || always_take_cnn || angles_only || pfe > accum_error_threshold;
-	if (take)
+	if (take && hand)
 		for (int i = 0; i < nb; i++) for (int k = 0; k < 7; k++) hand[((size_t)b * nb + i) * HT_STATE_STRIDE + k] = other[((size_t)b * nb + i) * HT_STATE_STRIDE + k];      // handmodel.SetPose (momenta kept)
 	if (pfe > accum_error_threshold) pfe = 0.0f;
 	prev_err[b] = pfe;
@@ -261,12 +261,14 @@ __global__ void k_accept(float *__restrict__ hand, const float *__restrict__ oth
 	if (accepted) accepted[b] = take ? nb : 0;
 }
 // GetPoseUser (physmodel.h:434) + the "initializing = 50" rule of handtrack.h:781-782
-__global__ void k_output(ht_model_dev M, const float *__restrict__ hand, const int *__restrict__ npts, int *__restrict__ initializing, int min_point_num, float *__restrict__ poses, int n)
+// raw != 0: GetPose (physmodel.h:433) of the given model, no rule
+__global__ void k_output(ht_model_dev M, const float *__restrict__ hand, const int *__restrict__ npts, int *__restrict__ initializing, int min_point_num, float *__restrict__ poses, int n, int raw)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n * M.nb) return;
 	const int b = i / M.nb, rb = i % M.nb;
 	const float *s = hand + (size_t)i * HT_STATE_STRIDE;
+	if (raw) { for (int k = 0; k < 7; k++) poses[(size_t)i * HT_POSE + k] = s[k]; return; }
 	v3 pu = apply(XF(G3(s), G4(s + 3)), -G3(M.bodyc + rb * HT_BC + HT_BC_COM));
 	float *o = poses + (size_t)i * HT_POSE;
 	o[0] = pu.x; o[1] = pu.y; o[2] = pu.z; o[3] = s[3]; o[4] = s[4]; o[5] = s[5]; o[6] = s[6];
@@ -305,7 +307,7 @@ void ht_launch_accept(float *hand, const float *other, const float *err_old, con
 {
 	hipLaunchKernelGGL(k_accept, dim3((n + 63) / 64), dim3(64), 0, s, hand, other, err_old, err_new, npts, prev_err, initializing, accepted, nb, n, p.min_point_num, p.always_take_cnn, p.angles_only, p.accum_error_threshold);
 }
-void ht_launch_output(const ht_model_dev &M, const float *hand, const int *npts, int *initializing, int min_point_num, float *poses, int n, hipStream_t s)
+void ht_launch_output(const ht_model_dev &M, const float *hand, const int *npts, int *initializing, int min_point_num, float *poses, int n, hipStream_t s, int raw)
 {
-	hipLaunchKernelGGL(k_output, dim3((n * M.nb + 255) / 256), dim3(256), 0, s, M, hand, npts, initializing, min_point_num, poses, n);
+	hipLaunchKernelGGL(k_output, dim3((n * M.nb + 255) / 256), dim3(256), 0, s, M, hand, npts, initializing, min_point_num, poses, n, raw);
 }

@@ -18,8 +18,8 @@ MAXPTS, ROW, CONTACT = 4096, 16, 12      # HT_MAX_POINTS
 # every symbol include/ht_mi355x.h declares (checked by tests/test_abi.py)
 SYMBOLS = (
     "ht_create", "ht_destroy", "ht_model_bake", "ht_last_error", "ht_get_params", "ht_set_params", "ht_model_info", "ht_config_read", "ht_scale",
-    "ht_cnn_load_weights", "ht_cnn_eval", "ht_cnn_eval_dev", "ht_cnn_train", "ht_cnn_get_weights", "ht_expected_cnn",
-    "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_update_frames_sync", "ht_update_frames_dev", "ht_frames_overflow", "ht_capacity_events", "ht_segment_vr", "ht_segment_vr_dev", "ht_slowfit", "ht_set_points",
+    "ht_cnn_load_weights", "ht_cnn_eval", "ht_cnn_eval_dev", "ht_cnn_load_weights_sized", "ht_cnn_eval_sized", "ht_cnn_eval_sized_dev", "ht_cnn_train", "ht_cnn_get_weights", "ht_expected_cnn",
+    "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_update_frames_sync", "ht_update_frames_dev", "ht_update_cnn_model_sync", "ht_get_cnn_results", "ht_frames_overflow", "ht_capacity_events", "ht_segment_vr", "ht_segment_vr_dev", "ht_slowfit", "ht_set_points",
     "ht_stage_prepare", "ht_stage_decode", "ht_stage_fit_error", "ht_stage_cloud_rows", "ht_stage_contacts", "ht_stage_fit",
     "ht_stage_multistep", "ht_stage_scratch_unibody", "ht_profile_enable", "ht_profile_read", "ht_debug_solve_stats", "ht_debug_contact_stats",
 )
@@ -65,6 +65,9 @@ def load(build_if_missing=True):
     L.ht_cnn_load_weights.argtypes = [vp, fp, C.c_size_t]
     L.ht_cnn_eval.argtypes = [vp, fp, fp, C.c_int]
     L.ht_cnn_eval_dev.argtypes = [vp, vp, vp, C.c_int, vp]
+    L.ht_cnn_load_weights_sized.argtypes = [vp, C.c_int, fp, C.c_size_t]
+    L.ht_cnn_eval_sized.argtypes = [vp, C.c_int, fp, fp, C.c_int]
+    L.ht_cnn_eval_sized_dev.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
     L.ht_tracker_reset.argtypes = [vp, C.c_int, C.c_int, fp]
     L.ht_get_state.argtypes = [vp, C.c_int, C.c_int, C.c_int, fp]; L.ht_set_state.argtypes = [vp, C.c_int, C.c_int, C.c_int, fp]
     L.ht_get_tracker_flags.argtypes = [vp, C.c_int, C.c_int, fp, ip]
@@ -74,6 +77,8 @@ def load(build_if_missing=True):
     L.ht_update_frames_sync.argtypes = [vp, u16p, fp, C.c_int, C.c_int, C.c_float, C.c_int, fp, fp]
     L.ht_update_frames_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, C.c_int, vp, vp]
     L.ht_frames_overflow.argtypes = [vp, ip]
+    L.ht_update_cnn_model_sync.argtypes = [vp, u16p, fp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, fp, ip, fp]
+    L.ht_get_cnn_results.argtypes = [vp, C.c_int, C.c_int, fp, fp, fp]
     L.ht_capacity_events.argtypes = [vp, ip, ip, ip]
     L.ht_stage_prepare.argtypes = [vp, u16p, fp, C.c_int, fp, fp, ip]
     L.ht_stage_decode.argtypes = [vp, fp, fp, C.c_int, fp]
@@ -183,6 +188,20 @@ class Context:
     def cnn_eval_dev(self, d_in, d_out, B, stream):
         self._chk(self.L.ht_cnn_eval_dev(self.h, d_in, d_out, B, stream))
 
+    # -- the same layers on a 128x128 input (BASELINE configs[4])
+    def load_weights128(self, w):
+        w = _c(w, np.float32)
+        self._chk(self.L.ht_cnn_load_weights_sized(self.h, 128, _f(w), w.size))
+
+    def cnn128_eval(self, x):
+        x = _c(x, np.float32).reshape(-1, 128 * 128)
+        out = np.empty((x.shape[0], CNN_OUT), np.float32)
+        self._chk(self.L.ht_cnn_eval_sized(self.h, 128, _f(x), _f(out), x.shape[0]))
+        return out
+
+    def cnn128_eval_dev(self, d_in, d_out, B, stream):
+        self._chk(self.L.ht_cnn_eval_sized_dev(self.h, 128, d_in, d_out, B, stream))
+
     # -- tracker
     def tracker_reset(self, poses, first=0):
         poses = _c(poses, np.float32).reshape(-1, self.nb, POSE)
@@ -229,6 +248,23 @@ class Context:
 
     def update_frames_dev(self, d_depth, d_cams, w, h, segment_scale, d_start, B, d_poses_out, stream):
         self._chk(self.L.ht_update_frames_dev(self.h, d_depth, d_cams, int(w), int(h), float(segment_scale), d_start, B, d_poses_out, stream))
+
+    def update_cnn_model_sync(self, depth, cams, kickstart=False, segment_scale=0.17):
+        """HandTracker::update_cnn_model (handtrack.h:734-741) / kickstart (:743-746): depth u16[B,h,w] -> (othermodel poses [B,nb,7], accepted [B])."""
+        depth = _c(depth, np.uint16)
+        if depth.ndim == 2:
+            depth = depth.reshape(-1, 64, 64)
+        B, h, w = depth.shape
+        cams = _c(cams, np.float32).reshape(B, CAM)
+        poses = np.empty((B, self.nb, POSE), np.float32); acc = np.empty(B, np.int32)
+        self._chk(self.L.ht_update_cnn_model_sync(self.h, depth.ctypes.data_as(C.POINTER(C.c_uint16)), _f(cams), w, h, float(segment_scale), B, int(bool(kickstart)), _f(poses), _i(acc), None))
+        return poses, acc
+
+    def cnn_results(self, n, first=0):
+        """(cnn_input [n,4096], cnn_output [n,2304], analysis [n,84]) of the latest update of those slots (HandTracker::cnn_input / cnn_output / cnn_output_analysis)"""
+        a = np.empty((n, CNN_IN), np.float32); b = np.empty((n, CNN_OUT), np.float32); c = np.empty((n, ANALYSIS), np.float32)
+        self._chk(self.L.ht_get_cnn_results(self.h, first, n, _f(a), _f(b), _f(c)))
+        return a, b, c
 
     def capacity_events(self):
         """(expanding-polytope runs cut short, contacts dropped, solves with angular rows over capacity) since the context was created"""

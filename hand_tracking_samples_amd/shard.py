@@ -14,11 +14,12 @@ def shard_range(n_frames, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_poses(local_poses, world, out=None):
-    """All-gather per-rank pose tensors [n_r, nb, 7] (equal n_r on every rank) into [world * n_r, nb, 7]."""
+def gather_poses(local_poses, world, out=None, force=False):
+    """All-gather per-rank pose tensors [n_r, nb, 7] (equal n_r on every rank) into [world * n_r, nb, 7].
+    `force`: run the collective even for a single rank (rehearsal of the RCCL path on a one-GPU box)."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not force:
         return local_poses
     if out is None:
         out = torch.empty((world * local_poses.shape[0],) + tuple(local_poses.shape[1:]), dtype=local_poses.dtype, device=local_poses.device)

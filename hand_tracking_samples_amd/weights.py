@@ -6,6 +6,10 @@ weights drawn from a counter-based splitmix64 stream in the Xavier range the ref
 fc1 W[2304*2048] B[2048]; fc2 W[2048*2304] B[2304] -- raw little-endian fp32, 9 458 400 values.
 
 The same generator is restated in oracle/ref_harness.cpp so the reference CNN can be loaded with identical bits.
+
+`side=128` gives the weights of the 128x128-input variant of the same net (BASELINE configs[4], SURVEY 8d "config 5 (ii)":
+conv 5x5 -> 124, 2 pools -> 31, conv 4x4 -> 28, pool -> 14, FC 12544 -> 2048 -> 2304): same stream, same ranges, only the first
+fully connected layer is larger (30 429 920 values).
 """
 import numpy as np
 
@@ -13,12 +17,25 @@ CNNB_COUNT = 9458400
 DEFAULT_SEED = 0x5EED0001
 DEFAULT_FC2_GAIN = 24.0      # makes the softmax heat-maps peaky, so arg-max decoding is well conditioned
 
-_LAYERS = (  # (n_weights, n_bias, fan_in + fan_out)
-    (400, 16, 25.0 * 1 + 25.0 * 16),
-    (16384, 64, 16.0 * 16 + 16.0 * 64),
-    (2304 * 2048, 2048, 2304.0 + 2048.0),
-    (2048 * 2304, 2304, 2048.0 + 2304.0),
-)
+
+
+def features(side=64):
+    """inputs of the first fully connected layer: 64 channels x (pooled side)^2 -- 2304 for a 64x64 input, 12544 for 128x128"""
+    p = (((side - 4) // 4) - 3) // 2
+    return 64 * p * p
+
+
+def _layers(side=64):  # (n_weights, n_bias, fan_in + fan_out)
+    f = features(side)
+    return ((400, 16, 25.0 * 1 + 25.0 * 16),
+            (16384, 64, 16.0 * 16 + 16.0 * 64),
+            (f * 2048, 2048, float(f) + 2048.0),
+            (2048 * 2304, 2304, 2048.0 + 2304.0))
+
+
+def cnnb_count(side=64):
+    return sum(nw + nb for nw, nb, _ in _layers(side))
+
 
 
 def _splitmix64(seed, idx):
@@ -29,12 +46,12 @@ def _splitmix64(seed, idx):
         return z ^ (z >> np.uint64(31))
 
 
-def make_cnnb(seed=DEFAULT_SEED, fc2_gain=DEFAULT_FC2_GAIN):
-    """Return the flat fp32 weight vector (len CNNB_COUNT)."""
-    out = np.empty(CNNB_COUNT, dtype=np.float32)
+def make_cnnb(seed=DEFAULT_SEED, fc2_gain=DEFAULT_FC2_GAIN, side=64):
+    """Return the flat fp32 weight vector (len CNNB_COUNT for side 64)."""
+    out = np.empty(cnnb_count(side), dtype=np.float32)
     ctr = 0
     pos = 0
-    for li, (nw, nb, fan) in enumerate(_LAYERS):
+    for li, (nw, nb, fan) in enumerate(_layers(side)):
         gain = fc2_gain if li == 3 else 1.0
         for n, rng in ((nw, np.sqrt(6.0 / fan) * gain), (nb, 0.05 * gain)):
             idx = np.arange(ctr, ctr + n, dtype=np.uint64)
@@ -43,6 +60,10 @@ def make_cnnb(seed=DEFAULT_SEED, fc2_gain=DEFAULT_FC2_GAIN):
             ctr += n
             pos += n
     return out
+
+
+def make_cnnb128(seed=DEFAULT_SEED, fc2_gain=DEFAULT_FC2_GAIN):
+    return make_cnnb(seed, fc2_gain, side=128)
 
 
 def load_cnnb(path):

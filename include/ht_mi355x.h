@@ -10,8 +10,12 @@
  *
  * Conventions: plain pointers and sizes, no exceptions across the ABI, every function returns an int status
  * (HT_OK == 0); the caller owns all buffers it passes, the library owns its device memory; one context per
- * (GPU, stream); a context is not thread safe.  *_dev entry points take DEVICE pointers and a hipStream_t
- * (passed as void*) and are asynchronous; the others take HOST pointers and are synchronous.
+ * (GPU, stream); a context is not thread safe, but contexts on different GPUs may be used from one process or
+ * from several threads: every entry point makes its context's device current for the call and restores the
+ * caller's afterwards.  *_dev entry points take DEVICE pointers and a hipStream_t (passed as void*) and are
+ * asynchronous; a NULL stream means the context's own stream (not the legacy default stream); the host-read helpers
+ * (ht_capacity_events, ht_frames_overflow, ht_get_tracker_flags, ht_get_cnn_results) wait for the stream of the latest
+ * *_dev call before they read.  The other entry points take HOST pointers and are synchronous.
  *
  * Layouts: a pose is 7 floats (position xyz, orientation quaternion xyzw) like Pose (third_party/geometric.h:111-125);
  * a body state is 13 floats (pose, linear momentum, angular momentum, physics.h:103-116);
@@ -35,6 +39,8 @@ extern "C" {
 #define HT_CNN_IN 4096        /* 64x64x1 input, handtrack.h:108 */
 #define HT_CNN_OUT 2304       /* 8 heat-maps 16x16 + 16 rows x 16 bins, handtrack.h:117-118 */
 #define HT_CNNB_COUNT 9458400 /* fp32 values in a .cnnb file, cnn.h:288,454,590 */
+#define HT_CNN128_IN 16384    /* 128x128x1 input of the larger variant (BASELINE configs[4]) */
+#define HT_CNNB128_COUNT 30429920 /* its weights: conv1 416, conv2 16448, fc1 12544*2048 + 2048, fc2 2048*2304 + 2304 */
 #define HT_POSE 7
 #define HT_STATE 13
 #define HT_CAM 12
@@ -101,6 +107,13 @@ int ht_config_read(const char *jsonfile, ht_params *params, float *segment_scale
 int ht_cnn_load_weights(ht_ctx *ctx, const float *weights, size_t n);
 int ht_cnn_eval(ht_ctx *ctx, const float *in, float *out, int B);
 int ht_cnn_eval_dev(ht_ctx *ctx, const float *d_in, float *d_out, int B, void *stream);
+/* ht_cnn_*_sized       the same three calls for a CNN object built from the reference's layer classes (cnn.h:136-511: LConv, LActivation<TanH>, LMaxPool,
+ *                      LFull, LSoftMaxChunked) in PoseInitializerCNN's order but on a `side` x `side` input: side = 64 is the net above; side = 128 is
+ *                      BASELINE configs[4]'s input size (conv5 -> 124, pool -> 62 -> 31, conv4 -> 28, pool -> 14, FC 12544 -> 2048 -> 2304; weights
+ *                      HT_CNNB128_COUNT values in the same .cnnb order, in [B][16384] -> out [B][2304]).  The two nets of a context are independent. */
+int ht_cnn_load_weights_sized(ht_ctx *ctx, int side, const float *weights, size_t n);
+int ht_cnn_eval_sized(ht_ctx *ctx, int side, const float *in, float *out, int B);
+int ht_cnn_eval_sized_dev(ht_ctx *ctx, int side, const float *d_in, float *d_out, int B, void *stream);
 
 /* ---- tracker -----------------------------------------------------------------------------------------------------
  * ht_tracker_reset    replaces  handmodel.SetPose(p) + othermodel.SetPose(p) with momenta, prev_frame_error and initializing
@@ -129,6 +142,17 @@ int ht_update_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, con
 int ht_update_frames_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int w, int h, float segment_scale, int B, float *poses_out, float *cnn_out);
 int ht_update_frames_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, int w, int h, float segment_scale, const float *d_start_poses, int B, float *d_poses_out, void *stream);
 int ht_frames_overflow(ht_ctx *ctx, int *frames_over);
+/* ht_update_cnn_model_sync  replaces  std::vector<Pose> HandTracker::update_cnn_model(Image<unsigned short>) (handtrack.h:734-741) and, with
+ *                     apply_to_handmodel != 0, void HandTracker::kickstart(Image<unsigned short>) (:743-746) for B trackers: the CNN job alone --
+ *                     othermodel is NOT re-seeded from handmodel first, no main-thread passes, no "initializing = 50" rule.  poses_out [B][nb][7] =
+ *                     othermodel.GetPose() (physmodel.h:433, body poses, not rig space), accepted_out [B] = 1 where the reference returns that pose and
+ *                     0 where it returns an empty vector (:720-722); kickstart copies the accepted poses into handmodel.  Frames w x h as
+ *                     ht_update_frames_sync (64x64 tiles: segment_scale unused).  cnn_out optional.
+ * ht_get_cnn_results  replaces  the members HandTracker::cnn_input, cnn_output and cnn_output_analysis (handtrack.h:583-585) after an update call:
+ *                     cnn_input [n][4096], cnn_output [n][2304], analysis [n][HT_ANALYSIS] (layout: ht_stage_decode); any may be NULL. */
+int ht_update_cnn_model_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int w, int h, float segment_scale, int B, int apply_to_handmodel,
+                             float *poses_out, int *accepted_out, float *cnn_out);
+int ht_get_cnn_results(ht_ctx *ctx, int first, int n, float *cnn_input, float *cnn_output, float *analysis);
 /* ht_capacity_events  how often, since ht_create, the contact kernel hit a capacity the reference does not have: expanding-polytope runs cut
  *                     short (gjk.h:417 / hull.h:233-310 loop without bound; here at most 128 iterations, 96 vertices, 192 triangles) and contacts
  *                     beyond 96 per frame and launch (physics.h:451-462 keeps them all); solves in which a model's angular rows exceeded the 126

@@ -51,20 +51,25 @@ static void full(const float *x, int M, const float *W, const float *B, int N, f
 	for (int i = 0; i < M; i++) { float xi = x[i]; const float *w = W + (size_t)i * N; for (int j = 0; j < N; j++) Y[j] += xi * w[j]; }
 }
 
-/* layer outputs kept by index like CNN::Eval's outputs[] (cnn.h:550-556); layers==NULL to skip */
-void ho_cnn_eval(const float *weights, const float *input, float *output, float *const *layers)
+/* layer outputs kept by index like CNN::Eval's outputs[] (cnn.h:550-556); layers==NULL to skip.
+ * `side` = 64: the topology of PoseInitializerCNN (handtrack.h:108-118).  `side` = 128: the same layer list on a 128x128 input (SURVEY 8d
+ * "config 5 (ii)": conv5 -> 124, pool -> 62 -> 31, conv4 -> 28, pool -> 14, FC 12544 -> 2048 -> 2304), pinned against the reference's own
+ * LConv / LMaxPool / LFull / LActivation<TanH> / LSoftMaxChunked classes assembled that way (tests/golden/cnn128.htfx). */
+void ho_cnn_eval_sized(const float *weights, int side, const float *input, float *output, float *const *layers)
 {
-	const float *W1 = weights, *B1 = W1 + 400, *W2 = B1 + 16, *B2 = W2 + 16384, *W3 = B2 + 64, *B3 = W3 + (size_t)2304 * 2048, *W4 = B3 + 2048, *B4 = W4 + (size_t)2048 * 2304;
-	float *a = malloc(sizeof(float) * 57600), *b = malloc(sizeof(float) * 57600);
+	const int c1 = side - 4, p1 = c1 / 2, p2 = p1 / 2, c2 = p2 - 3, p3 = c2 / 2, feat = 64 * p3 * p3;
+	const float *W1 = weights, *B1 = W1 + 400, *W2 = B1 + 16, *B2 = W2 + 16384, *W3 = B2 + 64, *B3 = W3 + (size_t)feat * 2048, *W4 = B3 + 2048, *B4 = W4 + (size_t)2048 * 2304;
+	const size_t big = (size_t)16 * c1 * c1;
+	float *a = malloc(sizeof(float) * big), *b = malloc(sizeof(float) * big);
 #define KEEP(i, p, n) do { if (layers && layers[i]) memcpy(layers[i], p, sizeof(float) * (n)); } while (0)
-	conv_valid(input, 64, 64, 1, W1, B1, 5, 5, 16, a);   KEEP(0, a, 57600);
-	tanh_ref(a, 57600);                                   KEEP(1, a, 57600);
-	maxpool2(a, 60, 60, 16, b);                           KEEP(2, b, 14400);
-	maxpool2(b, 30, 30, 16, a);                           KEEP(3, a, 3600);
-	conv_valid(a, 15, 15, 16, W2, B2, 4, 4, 64, b);       KEEP(4, b, 9216);
-	tanh_ref(b, 9216);                                    KEEP(5, b, 9216);
-	maxpool2(b, 12, 12, 64, a);                           KEEP(6, a, 2304);
-	full(a, 2304, W3, B3, 2048, b);                       KEEP(7, b, 2048);
+	conv_valid(input, side, side, 1, W1, B1, 5, 5, 16, a); KEEP(0, a, big);
+	tanh_ref(a, (int)big);                                KEEP(1, a, big);
+	maxpool2(a, c1, c1, 16, b);                           KEEP(2, b, 16 * p1 * p1);
+	maxpool2(b, p1, p1, 16, a);                           KEEP(3, a, 16 * p2 * p2);
+	conv_valid(a, p2, p2, 16, W2, B2, 4, 4, 64, b);       KEEP(4, b, 64 * c2 * c2);
+	tanh_ref(b, 64 * c2 * c2);                            KEEP(5, b, 64 * c2 * c2);
+	maxpool2(b, c2, c2, 64, a);                           KEEP(6, a, feat);
+	full(a, feat, W3, B3, 2048, b);                       KEEP(7, b, 2048);
 	tanh_ref(b, 2048);                                    KEEP(8, b, 2048);
 	full(b, 2048, W4, B4, 2304, a);                       KEEP(9, a, 2304);
 	for (int i = 0; i < 2304; i++) a[i] = expf(a[i]);
@@ -81,6 +86,7 @@ void ho_cnn_eval(const float *weights, const float *input, float *output, float 
 	free(a); free(b);
 #undef KEEP
 }
+void ho_cnn_eval(const float *weights, const float *input, float *output, float *const *layers) { ho_cnn_eval_sized(weights, 64, input, output, layers); }
 
 /* depth -> CNN input, handtrack.h:700 */
 void ho_cnn_input(const uint16_t *depth, int n, float depth_scale, float drange_x, float drange_y, float *out)

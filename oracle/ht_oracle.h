@@ -101,6 +101,7 @@ void ho_reset_tracker(ho_tracker *t, const float *pose7);               /* both 
 
 /* ---- stages ---- */
 void ho_cnn_eval(const float *weights, const float *input, float *output, float *const *layers);
+void ho_cnn_eval_sized(const float *weights, int side, const float *input, float *output, float *const *layers);      /* side 64 (handtrack.h:108-118) or 128 (the same layers on a 128x128 input) */
 void ho_expected_cnn(const float *pose7, const ho_camera *hcam, float *expected2304, float *vals16);      /* GatherHandExpectedCNN handtrack.h:160-173 */
 float ho_cnn_train(float *weights, const float *input, const float *target, float alpha);      /* CNN::Train cnn.h:558-580 on .cnnb-ordered weights */
 void ho_cnn_input(const uint16_t *depth, int n, float depth_scale, float drange_x, float drange_y, float *out);

@@ -26,6 +26,8 @@
 //   slowfit <animbank.pose> <rows,comma> <out.htfx>   HandTracker::slowfit with several argument sets
 //   segment <animbank.pose> <rows,comma> <out.htfx>   320x240 frames and what HandSegmentVR makes of them
 //   bench  <frames.htfx> <seed> <fc2gain> <reps>   reference CPU time for the unit of work
+//   cnn128 <frames128.htfx> <idx,comma> <seed> <fc2gain> <out.htfx>   the layer list of PoseInitializerCNN on a 128x128 input (SURVEY 8d config 5 ii),
+//                                                  assembled from the reference's own layer classes, evaluated on frames of a `fullframes` file
 //
 #include "/root/reference/include/handtrack.h"
 #include <sys/stat.h>
@@ -70,12 +72,12 @@ static inline uint64_t splitmix64_at(uint64_t seed, uint64_t i)
 	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
 	return z ^ (z >> 31);
 }
-static std::vector<float> make_cnnb(uint64_t seed, double fc2gain)
+static std::vector<float> make_cnnb(uint64_t seed, double fc2gain, size_t feat = 2304)
 {
-	// .cnnb layout (cnn.h:288,454,590): conv1 W[400] B[16]; conv2 W[16384] B[64]; fc1 W[2304*2048] B[2048]; fc2 W[2048*2304] B[2304]
+	// .cnnb layout (cnn.h:288,454,590): conv1 W[400] B[16]; conv2 W[16384] B[64]; fc1 W[feat*2048] B[2048]; fc2 W[2048*2304] B[2304]; feat = 2304 for the 64x64 net
 	struct L { size_t nw, nb; double fan; double gain; } layers[4] = {
 		{ 400, 16, 25.0 * 1 + 25.0 * 16, 1.0 }, { 16384, 64, 16.0 * 16 + 16.0 * 64, 1.0 },
-		{ (size_t)2304 * 2048, 2048, 2304.0 + 2048.0, 1.0 }, { (size_t)2048 * 2304, 2304, 2048.0 + 2304.0, fc2gain } };
+		{ feat * 2048, 2048, (double)feat + 2048.0, 1.0 }, { (size_t)2048 * 2304, 2304, 2048.0 + 2304.0, fc2gain } };
 	std::vector<float> out;
 	uint64_t ctr = 0;
 	for (auto &l : layers)
@@ -781,6 +783,67 @@ static std::vector<Arr> htfx_read(const char *fn)
 	}
 	fclose(f); return v;
 }
+// The 128x128-input variant of the pose net (BASELINE configs[4] / SURVEY 8d "config 5 (ii)").  The reference ships one topology (handtrack.h:108-118, 64x64);
+// this is the same list of the reference's OWN layer classes with the dimensions a 128x128 input gives: conv5 -> 124, pool -> 62 -> 31, conv4 -> 28,
+// pool -> 14, FC 12544 -> 2048 -> 2304, chunked softmax.  Weights: our seeded generator with the larger first FC layer, loaded through CNN::loadb.
+static int mode_cnn128(const char *framesfn, const char *idxcsv, uint64_t seed, double gain, const char *outfn)
+{
+	CNN cnn({});
+	cnn.layers.push_back(new CNN::LConv({ 128,128,1 }, { 5,5,1,16 }, { 124,124,16 }));
+	cnn.layers.push_back(new CNN::LActivation<TanH>(124 * 124 * 16));
+	cnn.layers.push_back(new CNN::LMaxPool({ 124,124,16 }));
+	cnn.layers.push_back(new CNN::LMaxPool({ 62,62,16 }));
+	cnn.layers.push_back(new CNN::LConv({ 31,31,16 }, { 4,4,16,64 }, { 28,28,64 }));
+	cnn.layers.push_back(new CNN::LActivation<TanH>(28 * 28 * 64));
+	cnn.layers.push_back(new CNN::LMaxPool({ 28,28,64 }));
+	cnn.layers.push_back(new CNN::LFull(14 * 14 * 64, 16 * 16 * 8));
+	cnn.layers.push_back(new CNN::LActivation<TanH>(16 * 16 * 8));
+	cnn.layers.push_back(new CNN::LFull(16 * 16 * 8, 16 * 16 * 8 + 16 * 16));
+	cnn.layers.push_back(new CNN::LSoftMaxChunked(concat(std::vector<int>(8, 16 * 16), std::vector<int>(16, 16))));
+	{
+		auto w = make_cnnb(seed, gain, 14 * 14 * 64);
+		std::string s((const char*)w.data(), w.size() * sizeof(float));
+		std::istringstream is(s, std::ios::binary);
+		cnn.loadb(is);
+	}
+	auto arrs = htfx_read(framesfn);
+	const Arr *ad = NULL, *ac = NULL;
+	for (auto &a : arrs) { if (a.name == "depth") ad = &a; if (a.name == "cam") ac = &a; }
+	if (!ad || !ac || ad->dims[1] != 128 || ad->dims[2] != 128) { fprintf(stderr, "frames file lacks 128x128 depth / cam\n"); return 2; }
+	std::vector<int> idx; { std::stringstream ss(idxcsv); std::string t; while (std::getline(ss, t, ',')) idx.push_back(atoi(t.c_str())); }
+	Out o; if (htfx_open(&o.w, outfn)) return 2;
+	o.i32("frames", idx); o.f32("weights_seed_gain", { (float)seed, (float)gain });
+	double ms = 0;
+	for (size_t k = 0; k < idx.size(); k++)
+	{
+		if (idx[k] < 0 || idx[k] >= (int)ad->dims[0]) { fprintf(stderr, "frame index out of range\n"); return 2; }
+		const float *c = (const float*)ac->data.data() + 12 * idx[k];
+		DCamera cam({ 128,128 }, { c[0],c[1] }, { c[2],c[3] }, c[4]);
+		const unsigned short *d = (const unsigned short*)ad->data.data() + (size_t)128 * 128 * idx[k];
+		Image<unsigned short> frame(cam, std::vector<unsigned short>(d, d + 128 * 128));
+		const float2 drange = { 0.1f, 0.7f };
+		auto cnn_input = Transform(frame, [drange, &frame](unsigned short dd) { return (float)clamp(1.0f - (dd*frame.cam.depth_scale - drange.x) / (drange.y - drange.x), 0.0f, 1.0f); });      // as handtrack.h:700
+		std::string pre = "f" + std::to_string(k) + "/";
+		auto t0 = std::chrono::steady_clock::now();
+		auto y = cnn.Eval(cnn_input.raster);
+		ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+		o.f32(pre + "cnn_output", y);
+		if (k == 0)
+		{
+			o.f32(pre + "cnn_input", cnn_input.raster, { 128, 128 });
+			std::vector<float> x = cnn_input.raster;
+			for (size_t l = 0; l < cnn.layers.size(); l++)
+			{
+				x = cnn.layers[l]->forward(x);
+				if (l == 3 || l == 6 || l == 8 || l == 9) o.f32(pre + "layer" + std::to_string(l), x);
+			}
+		}
+	}
+	htfx_close(&o.w);
+	printf("cnn128: %d frames -> %s (%.2f ms per CNN::Eval, 1 thread)\n", (int)idx.size(), outfn, ms / (double)idx.size());
+	return 0;
+}
+
 static int mode_bench(const char *framesfn, uint64_t seed, double gain, int reps, int maxframes)
 {
 	HandTracker htk;
@@ -846,6 +909,7 @@ int main(int argc, char **argv) try
 	if (mode == "fullframe" && a.size() == 6) return mode_fullframe(a[0].c_str(), a[1].c_str(), a[2].c_str(), strtoull(a[3].c_str(), 0, 0), atof(a[4].c_str()), a[5].c_str());
 	if (mode == "config5" && a.size() == 5) return mode_config5(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());
 	if (mode == "golden" && a.size() == 5) return mode_golden(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());
+	if (mode == "cnn128" && a.size() == 5) return mode_cnn128(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());
 	if (mode == "bench" && a.size() >= 4) return mode_bench(a[0].c_str(), strtoull(a[1].c_str(), 0, 0), atof(a[2].c_str()), atoi(a[3].c_str()), a.size() > 4 ? atoi(a[4].c_str()) : 0);
 	fprintf(stderr, "bad arguments\n");
 	return 1;

@@ -94,6 +94,7 @@ def lib():
         L.ho_set_pose.argtypes = [C.c_void_p, C.c_int, fp]; L.ho_reset_tracker.argtypes = [C.c_void_p, fp]
         L.ho_get_flags.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]; L.ho_get_flags.restype = None
         L.ho_cnn_eval.argtypes = [fp, fp, fp, C.POINTER(fp)]
+        L.ho_cnn_eval_sized.argtypes = [fp, C.c_int, fp, fp, C.POINTER(fp)]
         L.ho_cnn_input.argtypes = [C.POINTER(C.c_uint16), C.c_int, C.c_float, C.c_float, C.c_float, fp]
         L.ho_decode.argtypes = [fp, C.POINTER(Camera), C.POINTER(Analysis)]
         L.ho_pointcloud.argtypes = [C.POINTER(C.c_uint16), C.POINTER(Camera), C.c_float, C.c_float, C.c_int, C.POINTER(F3), C.c_int, C.POINTER(C.c_int)]; L.ho_pointcloud.restype = C.c_int
@@ -218,3 +219,19 @@ def segment_vr(depth, cam12, entry_options=0xF, wrange=(0.1, 0.65), diam=0.17):
     lib().ho_segment_vr(u16ptr(depth), w, h, fptr(cam12), int(entry_options), float(wrange[0]), float(wrange[1]), float(diam),
                         u16ptr(tile), fptr(cam), u16ptr(small), dt.ctypes.data_as(C.POINTER(C.c_uint8)))
     return tile, cam, small, dt
+
+
+def cnn128_eval(weights128, x, layers=None):
+    """The 128x128-input net (SURVEY 8d config 5 ii) on inputs x [n, 16384] -> [n, 2304]; `layers`: optional dict index -> array to fill for x[0]."""
+    x = np.ascontiguousarray(x, np.float32).reshape(-1, 128 * 128)
+    w = np.ascontiguousarray(weights128, np.float32)
+    out = np.zeros((len(x), 2304), np.float32)
+    for i in range(len(x)):
+        keep = None
+        if layers is not None and i == 0:
+            arr = (C.POINTER(C.c_float) * 11)()
+            for k, a in layers.items():
+                arr[k] = fptr(a)
+            keep = arr
+        lib().ho_cnn_eval_sized(fptr(w), 128, fptr(x[i]), fptr(out[i]), keep)
+    return out

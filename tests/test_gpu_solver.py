@@ -215,3 +215,51 @@ def test_unit_of_work_two_frames(ctx, golden):
         print("second frame %d: |dpos| %.2e |dquat| %.2e" % (f, dp, dq))
         assert dp <= FULL_POS_TOL and dq <= FULL_QUAT_TOL
         assert ini[f] == int(golden["f%d/uw2_final" % f][1])
+
+
+@pytest.mark.parametrize("kick", [False, True])
+def test_update_cnn_model_and_kickstart(ctx, golden, weights, kick):
+    """HandTracker::update_cnn_model (handtrack.h:734-741) and kickstart (:743-746) against the C restatement: the CNN job alone.  othermodel starts
+    from a pose that is NOT handmodel's, which the full update would overwrite (:757) and these calls must not; no main-thread passes; handmodel
+    changes only in kickstart and only where the pose is accepted."""
+    depth, cams, start = _inputs(golden)
+    other = np.roll(start, 1, axis=0)
+    ctx.tracker_reset(start)
+    st = ctx.get_state(1, NF); st[:, :, :7] = other; st[:, :, 7:] = 0.0
+    ctx.set_state(1, st)
+    poses, acc = ctx.update_cnn_model_sync(depth, cams, kickstart=kick)
+    hand = ctx.get_state(0, NF)
+    pfe, ini = ctx.tracker_flags(NF)
+    orc = ol.Oracle(weights)
+    orc.head.par.microforce = 3.0; orc.head.par.mainthreadpasses = 3
+    n_acc = 0
+    for f in range(NF):
+        orc.reset(start[f])
+        so = orc.get_state(1); so[:, :7] = other[f]; orc.set_state(1, so)
+        ref = np.zeros((17, 7), np.float32)
+        cam = ol.camera(cams[f])
+        n = orc.L.ho_update_cnn_model(orc.h, ol.u16ptr(np.ascontiguousarray(depth[f])), C.byref(cam), ol.fptr(ref))
+        assert (n > 0) == bool(acc[f]), "frame %d: accept decision" % f
+        ro = orc.get_state(1)
+        dp = np.abs(poses[f][:, :3] - ro[:, :3]).max(); dq = np.abs(poses[f][:, 3:] - ro[:, 3:7]).max()
+        print("update_cnn_model frame %d (%s): |dpos| %.2e |dquat| %.2e" % (f, "accepted" if acc[f] else "rejected", dp, dq))
+        assert dp <= FULL_POS_TOL and dq <= FULL_QUAT_TOL
+        if n:
+            assert np.abs(poses[f] - ref).max() <= FULL_POS_TOL * 10      # the returned pose is othermodel.GetPose()
+        expect_hand = ro[:, :7] if (kick and acc[f]) else start[f]
+        tol = FULL_POS_TOL if (kick and acc[f]) else 0.0
+        assert np.abs(hand[f][:, :3] - expect_hand[:, :3]).max() <= tol and np.abs(hand[f][:, 3:7] - expect_hand[:, 3:]).max() <= tol * 10
+        assert np.all(hand[f][:, 7:] == 0.0)      # no main-thread pass ran
+        e, i, _ = orc.flags()
+        assert ini[f] == i and abs(pfe[f] - e) <= 1e-4
+        n_acc += int(acc[f])
+    orc.close()
+    assert 0 < n_acc      # the case really covers accepted poses
+
+
+def test_set_params_refuses_what_the_kernels_cannot_run(ctx):
+    from hand_tracking_samples_amd import native
+    for bad in ({"subsample_fraction": 0}, {"drangey": 0.05}, {"steps": -1}, {"physics_iterations": -2}):
+        with pytest.raises(native.HTError, match="ht_set_params"):
+            ctx.set_params(**bad)
+    assert ctx.params.subsample_fraction == 4 and abs(ctx.params.drangey - 0.7) < 1e-7      # a refused call changes nothing
