@@ -34,7 +34,17 @@ $H golden $BANK 0,16,144,1584,2224,912,1504,2048 $SEED $GAIN $T/golden8.htfx
 $H frames $BANK 3 9 256 $T/frames256.htfx
 # next rows of SURVEY 8(f)
 $H segment $BANK 0,144,912,1504,2048,2224 $T/seg.htfx
-$H scale $BANK 0,912 $SEED $GAIN 1.15 $T/scale115.htfx
+$H scale $BANK 0,912 $SEED $GAIN 1.15 $T/scale_frames.htfx      # writes the tracked frames and, beside them, the scaled model (<out>.model)
+python3 - "$T/scale_frames.htfx" "$T/scale115.htfx" <<'PY'
+# scale115.htfx = the tracked frames followed by the scaled model's arrays under "model/"
+import sys
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import htfx
+from bench import _write_htfx
+a = htfx.load(sys.argv[1]); m = htfx.load(sys.argv[1] + ".model")
+out = dict(a); out.update({"model/" + k: v for k, v in m.items()})
+_write_htfx(sys.argv[2], out)
+PY
 $H slowfit $BANK 0,912,2224 $T/slowfit3.htfx
 $H train $BANK 0,912,2224 $SEED $GAIN 2 $T/train3.htfx
 # full-size frames: the application's 320x240 camera with the 17-bone hand; BASELINE configs[4] (128x128, 26 bones) both ways the reference can run it
