@@ -15,6 +15,7 @@
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return HT_ERR_HIP; } } while (0)
 
 #define CHECK_READY(ctx) if (!(ctx)) return HT_ERR_ARG; if (!(ctx)->ready) { (ctx)->err = "context not initialised (ht_create failed)"; return HT_ERR_STATE; } ht_device_guard dev_guard_((ctx)->device)
+#define CHECK_MODEL(ctx) do { if ((ctx)->cnn_only) { (ctx)->err = "this context was created without a hand model (CNN only)"; return HT_ERR_STATE; } } while (0)
 #define CHECK_BATCH(ctx, B) do { if ((B) < 1 || (B) > (ctx)->B) { (ctx)->err = "batch exceeds the capacity given to ht_create"; return HT_ERR_ARG; } } while (0)
 
 // ------------------------------------------------------------------------------------------------- context
@@ -129,7 +130,7 @@ static void sync_params(ht_ctx *ctx)
 
 extern "C" int ht_create(const char *model_path, int max_batch, int device, ht_ctx **out)
 {
-	if (!out || !model_path || max_batch < 1) return HT_ERR_ARG;
+	if (!out || max_batch < 1) return HT_ERR_ARG;
 	ht_ctx *ctx = new ht_ctx();
 	*out = ctx;      // returned even on failure so that ht_last_error can be read; caller destroys it
 	ctx->B = max_batch; ctx->device = device;
@@ -144,8 +145,10 @@ extern "C" int ht_create(const char *model_path, int max_batch, int device, ht_c
 	HIPCHK(ctx, hipStreamCreate(&ctx->stream));
 	for (int i = 0; i < 2; i++) { HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking)); HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming)); }
 	HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-	int r = load_model(ctx, model_path);
+	// model_path == NULL: a context that only evaluates / trains the CNN (what a stand-alone CNN object of the reference is, cnn.h:100-605)
+	int r = model_path ? load_model(ctx, model_path) : HT_OK;
 	if (r) return r;
+	ctx->cnn_only = model_path == nullptr;
 	sync_params(ctx);
 	r = ht_alloc_buffers(ctx);
 	if (r) return r;
@@ -188,7 +191,7 @@ extern "C" int ht_config_read(const char *jsonfile, ht_params *p, float *segment
 // joint anchors times s, inverse inertia over s*s, body positions stretched about the wrist.  The caller keeps segment_scale.
 extern "C" int ht_scale(ht_ctx *ctx, float s)
 {
-	CHECK_READY(ctx);
+	CHECK_READY(ctx); CHECK_MODEL(ctx);
 	const int nb = ctx->model.nb, nj = ctx->model.nj;
 	const float ss = s * s;
 	for (auto &v : ctx->h_verts) { v.x *= s; v.y *= s; v.z *= s; }      // w keeps the vertex index
@@ -260,7 +263,10 @@ extern "C" int ht_cnn_get_weights(ht_ctx *ctx, float *w, size_t n)
 // NormalizeHeatMap misc_image.h:246-272) and 16 one-dimensional maps of the key angles (HandPoseToKeyAngleSet handtrack.h:132-151,
 // Render1DHeatMaps misc_image.h:281-295), as bytes scaled by 1/255.  atan2 / asin / acos / exp / pow without std:: are the C double functions there.
 static unsigned char gray_of(float x) { float v = x * 255.0f; v = fmin_std(fmax_std(v, 0.0f), 255.0f); return (unsigned char)v; }
-extern "C" int ht_expected_cnn(const float *pose, const float *cam, float *expected)
+extern "C" int ht_expected_cnn_full(const float *pose, const float *cam, float *expected, float *image_points, float *vals_out);
+extern "C" int ht_expected_cnn(const float *pose, const float *cam, float *expected) { return ht_expected_cnn_full(pose, cam, expected, nullptr, nullptr); }
+// the same with the other members of the Set the reference returns: image_points [8][2] (ImageFeaturePoints handtrack.h:92-96) and vals [16]
+extern "C" int ht_expected_cnn_full(const float *pose, const float *cam, float *expected, float *image_points, float *vals_out)
 {
 	if (!pose || !cam || !expected) return HT_ERR_ARG;
 	static const int fbone[8] = { 1, 1, 1, 4, 7, 10, 13, 16 };
@@ -274,6 +280,7 @@ extern "C" int ht_expected_cnn(const float *pose, const float *cam, float *expec
 	{
 		const v3 v = apply(ci, apply(P(fbone[k]), V3(foff[k][0], foff[k][1], foff[k][2])));
 		const float ux = v.x / v.z * fx + px, uy = v.y / v.z * fy + py;
+		if (image_points) { image_points[2 * k] = ux; image_points[2 * k + 1] = uy; }
 		unsigned char *h = img + 256 * k;
 		const int hx = (int)ux, hy = (int)uy;
 		for (int y = (hy - 2 > 0 ? hy - 2 : 0); y < (hy + 3 < 16 ? hy + 3 : 16); y++) for (int x = (hx - 2 > 0 ? hx - 2 : 0); x < (hx + 3 < 16 ? hx + 3 : 16); x++)
@@ -293,6 +300,7 @@ extern "C" int ht_expected_cnn(const float *pose, const float *cam, float *expec
 	for (int b : { 6, 9, 12, 15 }) vals[nv++] = (float)(acos((double)clamp_std(dot(qydir(q1), qydir(P(b).q)), -1.0f, 1.0f)) / (double)3.14159f);
 	{ const v3 pz = qzdir(palmq); vals[nv++] = (float)((double)0.5f + atan2((double)-pz.x, (double)-pz.y) / (double)(3.14159f * 2.0f)); }
 	while (nv < 16) vals[nv++] = 0.0f;
+	if (vals_out) memcpy(vals_out, vals, sizeof vals);
 	unsigned char *vm = img + 2048;
 	for (int y = 0; y < 16; y++)
 	{
@@ -451,7 +459,7 @@ extern "C" int ht_cnn_eval_sized(ht_ctx *ctx, int side, const float *in, float *
 // ------------------------------------------------------------------------------------------------- stage: prepare / decode
 extern "C" int ht_stage_prepare(ht_ctx *ctx, const uint16_t *depth, const float *cams, int B, float *cnn_in, float *points, int *npoints)
 {
-	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
 	if (!depth || !cams) return HT_ERR_ARG;
 	hipStream_t s = ctx->stream;
 	HIPCHK(ctx, hipMemcpyAsync(ctx->d_depth, depth, (size_t)B * 4096 * sizeof(uint16_t), hipMemcpyHostToDevice, s));
@@ -543,6 +551,7 @@ int ht_alloc_buffers(ht_ctx *ctx)
 #define A(ptr, n) if ((r = dev_alloc(ctx, &ctx->ptr, (n)))) return r
 	A(d_depth, B * 4096); A(d_cams, B * HT_CAM); A(d_cnn_in, B * HT_CNN_IN); A(d_act1, B * 3600); A(d_act2, B * 2304); A(d_act3, B * 2048);
 	A(d_logits, B * HT_CNN_OUT); A(d_cnn_out, B * HT_CNN_OUT); A(d_analysis, B * HT_ANALYSIS);
+	if (ctx->cnn_only) return HT_OK;
 	A(d_pts, B * HT_MAXPTS); A(d_npts, B);
 	A(d_state[0], B * nb * HT_STATE_STRIDE); A(d_state[1], B * nb * HT_STATE_STRIDE);
 	A(d_prev_err, B); A(d_initializing, B); A(d_err_old, B); A(d_err_new, B); A(d_flags, B); A(d_nflags, B);

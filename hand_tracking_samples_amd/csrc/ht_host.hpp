@@ -10,6 +10,7 @@ struct ht_prof_entry { std::vector<hipEvent_t> ev; size_t used; float total_ms; 
 struct ht_ctx
 {
 	bool ready = false, have_weights = false, profile = false;
+	bool cnn_only = false;          // created without a hand model: only the CNN entry points work
 	bool profile_phases = false;     // also time the minor phases (serialises the side streams; used for the phase table, not for the timed region)
 	int B = 0, device = 0;
 	std::string err;

@@ -8,6 +8,7 @@
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return HT_ERR_HIP; } } while (0)
 #define CHECK_READY(ctx) if (!(ctx)) return HT_ERR_ARG; if (!(ctx)->ready) { (ctx)->err = "context not initialised (ht_create failed)"; return HT_ERR_STATE; } ht_device_guard dev_guard_((ctx)->device)
+#define CHECK_MODEL(ctx) do { if ((ctx)->cnn_only) { (ctx)->err = "this context was created without a hand model (CNN only)"; return HT_ERR_STATE; } } while (0)
 #define CHECK_BATCH(ctx, B) do { if ((B) < 1 || (B) > (ctx)->B) { (ctx)->err = "batch exceeds the capacity given to ht_create"; return HT_ERR_ARG; } } while (0)
 #define CHECK_RANGE(ctx, first, n) do { if ((first) < 0 || (n) < 1 || (first) + (n) > (ctx)->B) { (ctx)->err = "slot range exceeds the capacity given to ht_create"; return HT_ERR_ARG; } } while (0)
 
@@ -180,7 +181,7 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 // ---- public entry points ----------------------------------------------------------------------------------------------
 extern "C" int ht_tracker_reset(ht_ctx *ctx, int first, int n, const float *poses)
 {
-	CHECK_READY(ctx); CHECK_RANGE(ctx, first, n);
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_RANGE(ctx, first, n);
 	if (!poses) return HT_ERR_ARG;
 	hipStream_t s = ctx->stream;
 	const int nb = ctx->model.nb;
@@ -193,7 +194,7 @@ extern "C" int ht_tracker_reset(ht_ctx *ctx, int first, int n, const float *pose
 }
 extern "C" int ht_get_state(ht_ctx *ctx, int which, int first, int n, float *state)
 {
-	CHECK_READY(ctx); CHECK_RANGE(ctx, first, n);
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_RANGE(ctx, first, n);
 	if (!state || which < 0 || which > 1) return HT_ERR_ARG;
 	hipStream_t s = ctx->stream;
 	const int nb = ctx->model.nb;
@@ -205,7 +206,7 @@ extern "C" int ht_get_state(ht_ctx *ctx, int which, int first, int n, float *sta
 }
 extern "C" int ht_set_state(ht_ctx *ctx, int which, int first, int n, const float *state)
 {
-	CHECK_READY(ctx); CHECK_RANGE(ctx, first, n);
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_RANGE(ctx, first, n);
 	if (!state || which < 0 || which > 1) return HT_ERR_ARG;
 	hipStream_t s = ctx->stream;
 	const int nb = ctx->model.nb;
@@ -217,7 +218,7 @@ extern "C" int ht_set_state(ht_ctx *ctx, int which, int first, int n, const floa
 }
 extern "C" int ht_get_tracker_flags(ht_ctx *ctx, int first, int n, float *prev_frame_error, int *initializing)
 {
-	CHECK_READY(ctx); CHECK_RANGE(ctx, first, n);
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_RANGE(ctx, first, n);
 	HIPCHK(ctx, ht_sync_all(ctx));
 	if (prev_frame_error) HIPCHK(ctx, hipMemcpy(prev_frame_error, ctx->d_prev_err + first, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
 	if (initializing) HIPCHK(ctx, hipMemcpy(initializing, ctx->d_initializing + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
@@ -225,14 +226,14 @@ extern "C" int ht_get_tracker_flags(ht_ctx *ctx, int first, int n, float *prev_f
 }
 extern "C" int ht_set_tracker_flags(ht_ctx *ctx, int first, int n, const float *prev_frame_error, const int *initializing)
 {
-	CHECK_READY(ctx); CHECK_RANGE(ctx, first, n);
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_RANGE(ctx, first, n);
 	if (prev_frame_error) HIPCHK(ctx, hipMemcpy(ctx->d_prev_err + first, prev_frame_error, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
 	if (initializing) HIPCHK(ctx, hipMemcpy(ctx->d_initializing + first, initializing, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
 	return HT_OK;
 }
 extern "C" int ht_update_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, const float *d_start_poses, int B, float *d_poses_out, void *stream)
 {
-	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
 	if (!d_depth || !d_cams || !d_poses_out) return HT_ERR_ARG;
 	int r = run_update(ctx, d_depth, d_cams, d_start_poses, B, d_poses_out, nullptr, ht_user_stream(ctx, stream));
 	if (r) return r;
@@ -241,7 +242,7 @@ extern "C" int ht_update_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *
 }
 extern "C" int ht_update_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int B, float *poses_out, float *cnn_out)
 {
-	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
 	if (!depth || !cams || !poses_out) return HT_ERR_ARG;
 	hipStream_t s = ctx->stream;
 	const int nb = ctx->model.nb;
@@ -265,7 +266,7 @@ static int frames_args_ok(ht_ctx *ctx, int w, int h)
 }
 extern "C" int ht_update_frames_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, int w, int h, float segment_scale, const float *d_start_poses, int B, float *d_poses_out, void *stream)
 {
-	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
 	if (!d_depth || !d_cams || !d_poses_out) return HT_ERR_ARG;
 	if (!frames_args_ok(ctx, w, h)) return HT_ERR_ARG;
 	hipStream_t s = ht_user_stream(ctx, stream);
@@ -281,7 +282,7 @@ extern "C" int ht_update_frames_dev(ht_ctx *ctx, const uint16_t *d_depth, const 
 // workload of the test suite and the benches, so no result there depends on them.
 extern "C" int ht_capacity_events(ht_ctx *ctx, int *epa_cut_short, int *contacts_dropped, int *angular_rows_over)
 {
-	CHECK_READY(ctx);
+	CHECK_READY(ctx); CHECK_MODEL(ctx);
 	int v[3] = { 0, 0, 0 };
 	HIPCHK(ctx, ht_sync_all(ctx));
 	HIPCHK(ctx, hipMemcpy(v, ctx->d_epa_ws, sizeof v, hipMemcpyDeviceToHost));
@@ -301,7 +302,7 @@ extern "C" int ht_frames_overflow(ht_ctx *ctx, int *frames_over)
 }
 extern "C" int ht_update_frames_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int w, int h, float segment_scale, int B, float *poses_out, float *cnn_out)
 {
-	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
 	if (!depth || !cams || !poses_out) return HT_ERR_ARG;
 	if (w == 64 && h == 64) return ht_update_sync(ctx, depth, cams, B, poses_out, cnn_out);
 	if (!frames_args_ok(ctx, w, h)) return HT_ERR_ARG;
@@ -333,7 +334,7 @@ extern "C" int ht_update_frames_sync(ht_ctx *ctx, const uint16_t *depth, const f
 extern "C" int ht_update_cnn_model_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int w, int h, float segment_scale, int B, int apply_to_handmodel,
                                         float *poses_out, int *accepted_out, float *cnn_out)
 {
-	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
 	if (!depth || !cams) return HT_ERR_ARG;
 	const bool tile = (w == 64 && h == 64);
 	if (!tile && !frames_args_ok(ctx, w, h)) return HT_ERR_ARG;
@@ -371,7 +372,7 @@ extern "C" int ht_update_cnn_model_sync(ht_ctx *ctx, const uint16_t *depth, cons
 // decoded CNNOutputAnalysis (:182-242; layout as ht_stage_decode).  Any pointer may be NULL.
 extern "C" int ht_get_cnn_results(ht_ctx *ctx, int first, int n, float *cnn_input, float *cnn_output, float *analysis)
 {
-	CHECK_READY(ctx); CHECK_RANGE(ctx, first, n);
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_RANGE(ctx, first, n);
 	HIPCHK(ctx, ht_sync_all(ctx));
 	if (cnn_input) HIPCHK(ctx, hipMemcpy(cnn_input, ctx->d_cnn_in + (size_t)first * HT_CNN_IN, (size_t)n * HT_CNN_IN * sizeof(float), hipMemcpyDeviceToHost));
 	if (cnn_output) HIPCHK(ctx, hipMemcpy(cnn_output, ctx->d_cnn_out + (size_t)first * HT_CNN_OUT, (size_t)n * HT_CNN_OUT * sizeof(float), hipMemcpyDeviceToHost));
@@ -382,7 +383,7 @@ extern "C" int ht_get_cnn_results(ht_ctx *ctx, int first, int n, float *cnn_inpu
 // ---- stage entry points (operate on the buffers ht_stage_prepare filled and on the tracker state of slots [0,B)) -------------
 extern "C" int ht_stage_fit_error(ht_ctx *ctx, int which, int B, float *err)
 {
-	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
 	if (!err || which < 0 || which > 1) return HT_ERR_ARG;
 	hipStream_t s = ctx->stream;
 	ht_launch_fit_error(ctx->model, ctx->d_state[which], ctx->d_pts, ctx->d_npts, ctx->d_depth, ctx->d_cams, 64, 64, ctx->par.bone_sum_error_scale, ctx->d_err_old, B, s);
@@ -393,7 +394,7 @@ extern "C" int ht_stage_fit_error(ht_ctx *ctx, int which, int B, float *err)
 }
 extern "C" int ht_stage_cloud_rows(ht_ctx *ctx, int which, int stride, int use_cam_origin, int B, float *rows, int *nrows)
 {
-	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
 	if (!rows || !nrows || which < 0 || which > 1 || stride < 1) return HT_ERR_ARG;
 	hipStream_t s = ctx->stream;
 	HIPCHK(ctx, hipMemsetAsync(ctx->d_rows, 0, (size_t)B * HT_MAXPTS * HT_ROW * sizeof(float), s));
@@ -406,7 +407,7 @@ extern "C" int ht_stage_cloud_rows(ht_ctx *ctx, int which, int stride, int use_c
 }
 extern "C" int ht_stage_contacts(ht_ctx *ctx, int which, int B, int cap, float *contacts, int *ncontacts)
 {
-	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
 	if (!contacts || !ncontacts || which < 0 || which > 1 || cap < 1) return HT_ERR_ARG;
 	hipStream_t s = ctx->stream;
 	ht_launch_contacts(ctx->model, ctx->d_state[which], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s);
@@ -421,7 +422,7 @@ extern "C" int ht_stage_contacts(ht_ctx *ctx, int which, int B, int cap, float *
 }
 extern "C" int ht_stage_fit(ht_ctx *ctx, int B)
 {
-	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
 	main_pass(ctx, B, ctx->stream);
 	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 	HIPCHK(ctx, hipGetLastError());
@@ -429,7 +430,7 @@ extern "C" int ht_stage_fit(ht_ctx *ctx, int B)
 }
 extern "C" int ht_stage_multistep(ht_ctx *ctx, const float *analysis, int B)
 {
-	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
 	if (!analysis) return HT_ERR_ARG;
 	hipStream_t s = ctx->stream;
 	HIPCHK(ctx, hipMemcpyAsync(ctx->d_analysis, analysis, (size_t)B * HT_ANALYSIS * sizeof(float), hipMemcpyHostToDevice, s));
@@ -440,7 +441,7 @@ extern "C" int ht_stage_multistep(ht_ctx *ctx, const float *analysis, int B)
 }
 extern "C" int ht_stage_scratch_unibody(ht_ctx *ctx, const float *analysis, int B, int n_unibody)
 {
-	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
 	if (!analysis) return HT_ERR_ARG;
 	hipStream_t s = ctx->stream;
 	HIPCHK(ctx, hipMemcpyAsync(ctx->d_analysis, analysis, (size_t)B * HT_ANALYSIS * sizeof(float), hipMemcpyHostToDevice, s));
@@ -527,7 +528,7 @@ extern "C" int ht_segment_vr(ht_ctx *ctx, const uint16_t *depth, const float *ca
 // HandTracker::slowfit (handtrack.h:786-821) on the handmodel of slots [0,B) against the points ht_stage_prepare left on the device.
 extern "C" int ht_slowfit(ht_ctx *ctx, int B, int hold, const float *refpose, int steps, int select_rb, const float *spoint, const float *rbpoint, const float *crays, int ncray)
 {
-	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
 	const int nb = ctx->model.nb;
 	if (steps < 1 || ncray < 0 || ncray > 8 || select_rb >= nb || (select_rb >= 0 && (!spoint || !rbpoint)) || (ncray > 0 && !crays)) { ctx->err = "ht_slowfit: bad arguments"; return HT_ERR_ARG; }
 	hipStream_t s = ctx->stream;
@@ -570,7 +571,7 @@ extern "C" int ht_slowfit(ht_ctx *ctx, int B, int hold, const float *refpose, in
 // points [B][cap][3] (cap <= 1024 used per frame), npoints [B].
 extern "C" int ht_set_points(ht_ctx *ctx, int B, const float *points, int cap, const int *npoints)
 {
-	CHECK_READY(ctx); CHECK_BATCH(ctx, B);
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
 	if (!points || !npoints || cap < 1) return HT_ERR_ARG;
 	ctx->model.pts_bound = 0;
 	std::vector<float4> h((size_t)B * HT_MAXPTS, make_float4(0, 0, 0, 0)); std::vector<int> n(B);

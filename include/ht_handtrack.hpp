@@ -6,13 +6,19 @@
 //     std::vector<Pose> pose = htk.update(std::move(dimage));      // handtrack.h:748
 //     std::vector<float> y = htk.cnn.Eval(x);                        // cnn.h:550
 //
-// Only the members the per-frame path and synthetic-tracker.cpp touch are provided.  Documented deviation: update()
+// Provided: the members the per-frame path and synthetic-tracker.cpp touch: HandTracker {update, update_cnn_model, kickstart, slowfit,
+// scale, load_config, handmodel / othermodel facades, cnn, cnn_input, cnn_output, cnn_output_analysis}, CNN {Eval, Train, loadb, saveb},
+// PoseInitializerCNN, PhysModel / LoadHandModel (a host-side model that is posed, drawn and ray-cast, never tracked), HandSegmentVR, camsub,
+// GatherHandExpectedCNN, Pose / Image<T> / DCamera / Mesh.  Define HT_MI355X_GLOBAL_NAMES before including to have these names in the global
+// namespace, as the reference's headers put them.  Not provided: the free PhysicsUpdate() and caller-built LimitLinear / LimitAngular vectors
+// (PhysModel::FitPointCloud takes the points and the force scale only): the constraint rows live on the device.  Documented deviation: update()
 // runs the CNN job synchronously every frame (the reference polls a background std::async job for 1 ms, which makes its output
 // timing dependent, handtrack.h:755-768); this is HandTracker::update_cnn_model followed by the main-thread passes.
 // Errors are reported the way the reference's apps expect them: by throwing std::runtime_error (synthetic-tracker.cpp:255-264).
 #pragma once
 #include <cstdint>
 #include <fstream>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -22,6 +28,7 @@ namespace ht_mi355x
 {
 struct float2 { float x, y; };
 struct int2 { int x, y; };
+struct int3 { int x, y, z; };
 struct float3 { float x, y, z; };
 struct float4 { float x, y, z, w; };
 struct Pose { float3 position{ 0, 0, 0 }; float4 orientation{ 0, 0, 0, 1 }; };            // geometric.h:111-125
@@ -47,13 +54,31 @@ template <class T> struct Image                                                 
 	T &pixel(int2 p) { return raster[(size_t)p.y * dim().x + p.x]; }
 };
 
+inline DCamera camsub(const DCamera &c, int s)                                               // misc_image.h:60
+{
+	return DCamera({ c.dim().x / s, c.dim().y / s }, { c.focal().x / (float)s, c.focal().y / (float)s }, { c.principal().x / (float)s, c.principal().y / (float)s }, c.depth_scale, c.pose);
+}
+struct Mesh { std::vector<float3> verts; std::vector<int3> tris; Pose pose; float4 hack{ 1, 1, 1, 1 }; std::string material; };      // mesh.h (what GetMeshes hands to a renderer)
+inline float3 qrot_(const float4 &q, const float3 &v)                                       // linalg.h:288
+{
+	const float3 X{ q.w * q.w + q.x * q.x - q.y * q.y - q.z * q.z, (q.x * q.y + q.z * q.w) * 2, (q.z * q.x - q.y * q.w) * 2 };
+	const float3 Y{ (q.x * q.y - q.z * q.w) * 2, q.w * q.w - q.x * q.x + q.y * q.y - q.z * q.z, (q.y * q.z + q.x * q.w) * 2 };
+	const float3 Z{ (q.z * q.x + q.y * q.w) * 2, (q.y * q.z - q.x * q.w) * 2, q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z };
+	return { (X.x * v.x + Y.x * v.y) + Z.x * v.z, (X.y * v.x + Y.y * v.y) + Z.y * v.z, (X.z * v.x + Y.z * v.y) + Z.z * v.z };
+}
+inline float3 operator*(const Pose &p, const float3 &v) { const float3 r = qrot_(p.orientation, v); return { p.position.x + r.x, p.position.y + r.y, p.position.z + r.z }; }      // geometric.h:119
+
 namespace detail { inline ht_ctx *&live_ctx() { static ht_ctx *c = nullptr; return c; } }      // a context the free functions below can run on
 inline void check(ht_ctx *ctx, int rc) { if (rc != HT_OK) throw std::runtime_error(std::string("ht_mi355x: ") + (ctx ? ht_last_error(ctx) : "no context")); }
 
+class CNN;
+CNN PoseInitializerCNN(std::string filename, int device);
 class CNN                                                                                    // third_party/cnn.h:100-605 (Eval / Train / loadb / saveb)
 {
 	ht_ctx *ctx_ = nullptr;
+	std::shared_ptr<ht_ctx> own_;      // set when the object owns its (CNN-only) context: PoseInitializerCNN
 	friend struct HandTracker;
+	friend CNN PoseInitializerCNN(std::string, int);
 public:
 	std::vector<float> Eval(const std::vector<float> &x)                                     // cnn.h:550
 	{
@@ -96,6 +121,51 @@ struct HandTracker                                                              
 	size_t min_point_num = 400; float accum_error_threshold = 0.0f; float min_cray_prob = 0.0f;
 	int steps = 5, steps_keypoints = 3, steps_keyangles = 2, steps_palmangle = 2, steps_cloudstart = 1, steps_unibody = 3;
 	CNN cnn;
+	// PhysModel facade of the two tracked models (handtrack.h:517-518): the members the applications use on them (physmodel.h:295-303,345,433-435)
+	struct TrackedModel
+	{
+		std::vector<Pose> GetPose() const { return read(false); }                                                    // body poses (centre-of-mass frames)
+		std::vector<Pose> GetPoseUser() const { return read(true); }                                                 // rig space: RigidBody::PositionUser physics.h:142
+		TrackedModel &SetPose(const std::vector<Pose> &poses)                                                        // poses only, momenta untouched (physmodel.h:435)
+		{
+			std::vector<float> st((size_t)nb_ * HT_STATE);
+			check(ctx_, ht_get_state(ctx_, which_, 0, 1, st.data()));
+			for (size_t b = 0; b < poses.size() && (int)b < nb_; b++) { float *s = &st[b * HT_STATE]; s[0] = poses[b].position.x; s[1] = poses[b].position.y; s[2] = poses[b].position.z; s[3] = poses[b].orientation.x; s[4] = poses[b].orientation.y; s[5] = poses[b].orientation.z; s[6] = poses[b].orientation.w; }
+			check(ctx_, ht_set_state(ctx_, which_, 0, 1, st.data()));
+			return *this;
+		}
+		std::vector<Mesh> &GetMeshes(int = 0) { const std::vector<Pose> p = GetPose(); for (size_t b = 0; b < meshes_.size() && b < p.size(); b++) meshes_[b].pose = p[b]; return meshes_; }
+		// one fit step of this model against a point cloud with the tracker's current tunables (physmodel.h:345-356 as HandTracker::update calls it,
+		// handtrack.h:779, without the boundary planes); caller-built constraint vectors are not part of this surface
+		void FitPointCloud(const std::vector<float3> &points, float microforce = 1.0f)
+		{
+			if (which_ != 0) throw std::runtime_error("FitPointCloud: only the handmodel takes main-thread passes");
+			const int n = (int)points.size(); const float3 none{ 0, 0, 0 };
+			check(ctx_, ht_set_points(ctx_, 1, n ? &points[0].x : &none.x, n > 0 ? n : 1, &n));
+			ht_params p, keep; check(ctx_, ht_get_params(ctx_, &p)); keep = p;
+			p.microforce = microforce; p.boundary_planes = 0;
+			check(ctx_, ht_set_params(ctx_, &p));
+			const int rc = ht_stage_fit(ctx_, 1);
+			ht_set_params(ctx_, &keep);
+			check(ctx_, rc);
+		}
+	private:
+		friend struct HandTracker;
+		ht_ctx *ctx_ = nullptr; int which_ = 0, nb_ = 0; std::vector<float3> com_; std::vector<Mesh> meshes_;
+		std::vector<Pose> read(bool user) const
+		{
+			std::vector<float> st((size_t)nb_ * HT_STATE);
+			check(ctx_, ht_get_state(ctx_, which_, 0, 1, st.data()));
+			std::vector<Pose> out(nb_);
+			for (int b = 0; b < nb_; b++)
+			{
+				const float *s = &st[(size_t)b * HT_STATE];
+				out[b].position = { s[0], s[1], s[2] }; out[b].orientation = { s[3], s[4], s[5], s[6] };
+				if (user && (size_t)b < com_.size()) out[b].position = out[b] * float3{ -com_[b].x, -com_[b].y, -com_[b].z };
+			}
+			return out;
+		}
+	} handmodel, othermodel;
 	Image<float> cnn_input; std::vector<float> cnn_output;
 	// the parts of CNNOutputAnalysis that synthetic-tracker.cpp draws (handtrack.h:186,188; synthetic-tracker.cpp:221-222)
 	struct { std::vector<Image<unsigned char>> hmaps; Image<float> vmap; } cnn_output_analysis;
@@ -111,6 +181,24 @@ struct HandTracker                                                              
 		cnn.ctx_ = ctx_;
 		if (!detail::live_ctx()) detail::live_ctx() = ctx_;
 		ht_model_info(ctx_, &nb_, nullptr, nullptr);
+		{
+			// geometry for the facades (GetPoseUser needs the centres of mass, GetMeshes the hulls): the same host build, no device involved
+			ht_model *m = nullptr;
+			if (ht_model_open(model_path.c_str(), 1, &m) == HT_OK)
+				for (int b = 0; b < nb_; b++)
+				{
+					int nv = 0, nt = 0; float com[3] = { 0, 0, 0 };
+					ht_model_body(m, b, &nv, &nt, nullptr, com, nullptr);
+					Mesh mesh; std::vector<float> v((size_t)nv * 3); std::vector<int> t((size_t)nt * 3);
+					ht_model_body_mesh(m, b, v.data(), t.data());
+					for (int i = 0; i < nv; i++) mesh.verts.push_back({ v[3 * i], v[3 * i + 1], v[3 * i + 2] });
+					for (int i = 0; i < nt; i++) mesh.tris.push_back({ t[3 * i], t[3 * i + 1], t[3 * i + 2] });
+					handmodel.com_.push_back({ com[0], com[1], com[2] }); handmodel.meshes_.push_back(mesh);
+				}
+			if (m) ht_model_close(m);
+			othermodel.com_ = handmodel.com_; othermodel.meshes_ = handmodel.meshes_;
+			handmodel.ctx_ = othermodel.ctx_ = ctx_; handmodel.nb_ = othermodel.nb_ = nb_; handmodel.which_ = 0; othermodel.which_ = 1;
+		}
 		if (!cnnb_path.empty()) { std::ifstream is(cnnb_path, std::ios_base::in | std::ios_base::binary); if (is.is_open()) cnn.loadb(is); }
 		cnn_output.assign(HT_CNN_OUT, 0.01f);
 	}
@@ -151,20 +239,7 @@ struct HandTracker                                                              
 			check(ctx_, ht_update_frames_sync(ctx_, dimage.raster.data(), fcam, dimage.dim().x, dimage.dim().y, segment_scale, 1, out.data(), cnn_output.data()));
 		}
 		if (full) dimage = segment(dimage, 0xF, { 0.1f, drangey }, segment_scale);
-		const DCamera &c = dimage.cam;
-		// visualisation members, filled on the host from what the device returned (handtrack.h:700, 225, 236-238)
-		const float dr = drangey - 0.1f;
-		cnn_input = Image<float>(c);
-		for (size_t i = 0; i < dimage.raster.size(); i++) { float v = 1.0f - (dimage.raster[i] * c.depth_scale - 0.1f) / dr; cnn_input.raster[i] = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
-		DCamera hcam({ 16, 16 }, { c.focal().x / 4.0f, c.focal().y / 4.0f }, { c.principal().x / 4.0f, c.principal().y / 4.0f }, c.depth_scale, c.pose);
-		cnn_output_analysis.hmaps.clear();
-		for (int m = 0; m < 8; m++)
-		{
-			Image<unsigned char> h(hcam);
-			for (int i = 0; i < 256; i++) { float y = cnn_output[(size_t)256 * m + i] * 255.0f; h.raster[i] = (unsigned char)(y < 0.0f ? 0.0f : (y > 255.0f ? 255.0f : y)); }      // ToGrayScale misc_image.h:169
-			cnn_output_analysis.hmaps.push_back(h);
-		}
-		cnn_output_analysis.vmap = Image<float>(DCamera({ 16, 16 }, { 16.f, 16.f }, { 8.f, 8.f }, c.depth_scale), std::vector<float>(cnn_output.begin() + 2048, cnn_output.end()));
+		fill_visualisation(dimage);
 		std::vector<Pose> pose(nb_);
 		for (int b = 0; b < nb_; b++) { const float *p = &out[(size_t)b * HT_POSE]; pose[b].position = { p[0], p[1], p[2] }; pose[b].orientation = { p[3], p[4], p[5], p[6] }; }
 		return pose;
@@ -182,8 +257,11 @@ struct HandTracker                                                              
 		check(ctx_, ht_slowfit(ctx_, 1, refpose.empty() ? 0 : hold, refpose.empty() ? nullptr : ref.data(), steps_, selectrb, &spoint.x, &rbpoint.x, ncray ? cr.data() : nullptr, ncray));
 	}
 	float scale(float s) { check(ctx_, ht_scale(ctx_, s)); segment_scale *= s; return segment_scale; }                     // handtrack.h:591
-	// kickstart (handtrack.h:743-746): the CNN job in the calling thread, its pose taken over when it is accepted; no main-thread passes
-	void kickstart(Image<unsigned short> dimage) { const int keep = mainthreadpasses; mainthreadpasses = 0; try { update(std::move(dimage)); } catch (...) { mainthreadpasses = keep; throw; } mainthreadpasses = keep; }
+	// update_cnn_model (handtrack.h:734-741): the CNN job alone, synchronously -- othermodel is not re-seeded from handmodel, no main-thread pass;
+	// returns othermodel.GetPose() when the tracker would take it over (:720-722) and an empty vector otherwise
+	std::vector<Pose> update_cnn_model(Image<unsigned short> dimage) { return cnn_job(std::move(dimage), false); }
+	// kickstart (handtrack.h:743-746): handmodel.SetPose(update_cnn_model(dimage))
+	void kickstart(Image<unsigned short> dimage) { cnn_job(std::move(dimage), true); }
 	// HandSegmentVR (handtrack.h:280-344) on this tracker's device
 	Image<unsigned short> segment(const Image<unsigned short> &depth, int entry_options = 0xF, float2 wrange = { 0.1f, 0.65f }, float diam = 0.17f) const { return segment_on(ctx_, depth, entry_options, wrange, diam); }
 	static Image<unsigned short> segment_on(ht_ctx *ctx, const Image<unsigned short> &depth, int entry_options, float2 wrange, float diam)
@@ -198,6 +276,37 @@ struct HandTracker                                                              
 	}
 private:
 	ht_ctx *ctx_ = nullptr; int nb_ = 0;
+	std::vector<Pose> cnn_job(Image<unsigned short> dimage, bool apply)
+	{
+		push_params();
+		const DCamera &fc = dimage.cam;
+		const float fcam[HT_CAM] = { fc.focal().x, fc.focal().y, fc.principal().x, fc.principal().y, fc.depth_scale, fc.pose.position.x, fc.pose.position.y, fc.pose.position.z,
+		                             fc.pose.orientation.x, fc.pose.orientation.y, fc.pose.orientation.z, fc.pose.orientation.w };
+		std::vector<float> out((size_t)nb_ * HT_POSE); int accepted = 0;
+		check(ctx_, ht_update_cnn_model_sync(ctx_, dimage.raster.data(), fcam, dimage.dim().x, dimage.dim().y, segment_scale, 1, apply ? 1 : 0, out.data(), &accepted, cnn_output.data()));
+		if (dimage.dim().x != 64 || dimage.dim().y != 64) dimage = segment(dimage, 0xF, { 0.1f, drangey }, segment_scale);
+		fill_visualisation(dimage);
+		std::vector<Pose> pose;
+		if (accepted) { pose.resize(nb_); for (int b = 0; b < nb_; b++) { const float *p = &out[(size_t)b * HT_POSE]; pose[b].position = { p[0], p[1], p[2] }; pose[b].orientation = { p[3], p[4], p[5], p[6] }; } }
+		return pose;
+	}
+	// cnn_input and the drawn parts of cnn_output_analysis, filled on the host from what the device returned (handtrack.h:700, 225, 236-238)
+	void fill_visualisation(const Image<unsigned short> &tile)
+	{
+		const DCamera &c = tile.cam;
+		const float dr = drangey - 0.1f;
+		cnn_input = Image<float>(c);
+		for (size_t i = 0; i < tile.raster.size(); i++) { float v = 1.0f - (tile.raster[i] * c.depth_scale - 0.1f) / dr; cnn_input.raster[i] = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+		const DCamera hcam = camsub(c, 4);
+		cnn_output_analysis.hmaps.clear();
+		for (int m = 0; m < 8; m++)
+		{
+			Image<unsigned char> h(hcam);
+			for (int i = 0; i < 256; i++) { float y = cnn_output[(size_t)256 * m + i] * 255.0f; h.raster[i] = (unsigned char)(y < 0.0f ? 0.0f : (y > 255.0f ? 255.0f : y)); }      // ToGrayScale misc_image.h:169
+			cnn_output_analysis.hmaps.push_back(h);
+		}
+		cnn_output_analysis.vmap = Image<float>(DCamera({ 16, 16 }, { 16.f, 16.f }, { 8.f, 8.f }, c.depth_scale), std::vector<float>(cnn_output.begin() + 2048, cnn_output.end()));
+	}
 	std::vector<float> flat(const std::vector<Pose> &pose) const
 	{
 		std::vector<float> f((size_t)nb_ * HT_POSE, 0.f);
@@ -224,4 +333,91 @@ inline Image<unsigned short> HandSegmentVR(const Image<unsigned short> &depth, i
 	if (!detail::live_ctx()) throw std::runtime_error("HandSegmentVR: construct a HandTracker first (the segmentation runs on its device)");
 	return HandTracker::segment_on(detail::live_ctx(), depth, entry_options, wrange, diam);
 }
+
+// CNN PoseInitializerCNN(std::string filename) (handtrack.h:103-130): the pose net as an object of its own (own CNN-only device context); like the
+// reference, a missing weight file is not an error here -- Eval then fails loudly instead of running on random weights.
+inline CNN PoseInitializerCNN(std::string filename, int device = 0)
+{
+	ht_ctx *ctx = nullptr;
+	const int rc = ht_create(nullptr, 1, device, &ctx);
+	if (rc != HT_OK) { const std::string msg = ctx ? ht_last_error(ctx) : "ht_create failed"; if (ctx) ht_destroy(ctx); throw std::runtime_error("PoseInitializerCNN: " + msg); }
+	CNN cnn; cnn.ctx_ = ctx; cnn.own_ = std::shared_ptr<ht_ctx>(ctx, [](ht_ctx *c) { ht_destroy(c); });
+	std::ifstream is(filename, std::ios_base::in | std::ios_base::binary);
+	if (is.is_open()) cnn.loadb(is);
+	return cnn;
+}
+
+// GatherHandExpectedCNN(pose, hcam) (handtrack.h:160-173): the labels the net is trained to produce for a hand pose seen by the 16x16 heat-map camera
+struct ExpectedCNN { std::vector<float> cnn_expected; std::vector<float2> image_points; std::vector<Image<unsigned char>> hmaps; Image<unsigned char> vmap; std::vector<float> vals; };
+inline ExpectedCNN GatherHandExpectedCNN(const std::vector<Pose> &pose, const DCamera &hcam)
+{
+	if (pose.size() < 17) throw std::runtime_error("GatherHandExpectedCNN: the landmark table names bones up to 16 (handtrack.h:77-81)");
+	std::vector<float> p7(pose.size() * HT_POSE);
+	for (size_t b = 0; b < pose.size(); b++) { float *p = &p7[b * HT_POSE]; p[0] = pose[b].position.x; p[1] = pose[b].position.y; p[2] = pose[b].position.z; p[3] = pose[b].orientation.x; p[4] = pose[b].orientation.y; p[5] = pose[b].orientation.z; p[6] = pose[b].orientation.w; }
+	// the C-ABI takes the 64x64 tile camera and forms camsub(cam, 4) itself; scaling by 4 and back is exact in binary floating point
+	const float cam[HT_CAM] = { hcam.focal().x * 4.0f, hcam.focal().y * 4.0f, hcam.principal().x * 4.0f, hcam.principal().y * 4.0f, hcam.depth_scale,
+	                            hcam.pose.position.x, hcam.pose.position.y, hcam.pose.position.z, hcam.pose.orientation.x, hcam.pose.orientation.y, hcam.pose.orientation.z, hcam.pose.orientation.w };
+	ExpectedCNN e; e.cnn_expected.resize(HT_CNN_OUT); e.vals.resize(16);
+	float ip[16];
+	if (ht_expected_cnn_full(p7.data(), cam, e.cnn_expected.data(), ip, e.vals.data()) != HT_OK) throw std::runtime_error("GatherHandExpectedCNN failed");
+	for (int k = 0; k < 8; k++) e.image_points.push_back({ ip[2 * k], ip[2 * k + 1] });
+	auto gray = [](float v) { v *= 255.0f; return (unsigned char)(v < 0.0f ? 0.0f : v > 255.0f ? 255.0f : v + 0.5f); };      // the labels are bytes / 255: this recovers the byte
+	for (int m = 0; m < 8; m++) { Image<unsigned char> h(hcam); for (int i = 0; i < 256; i++) h.raster[i] = gray(e.cnn_expected[(size_t)256 * m + i]); e.hmaps.push_back(h); }
+	e.vmap = Image<unsigned char>(DCamera({ 16, 16 }, { 16.f, 16.f }, { 8.f, 8.f }, hcam.depth_scale));
+	for (int i = 0; i < 256; i++) e.vmap.raster[i] = gray(e.cnn_expected[2048 + i]);
+	return e;
+}
+
+// A hand model that is posed, drawn and ray-cast but not tracked (host only): `PhysModel fakehand = LoadHandModel();` (synthetic-tracker.cpp:94)
+class PhysModel                                                                               // include/physmodel.h:236-477, the members the applications use
+{
+	std::shared_ptr<ht_model> m_;
+public:
+	struct Body { float3 position{ 0, 0, 0 }; float4 orientation{ 0, 0, 0, 1 }; float3 com{ 0, 0, 0 };
+		Pose pose() const { Pose p; p.position = position; p.orientation = orientation; return p; }
+		float3 PositionUser() const { return pose() * float3{ -com.x, -com.y, -com.z }; } };                          // physics.h:142
+	struct ModelHitInfo { bool hit = false; float3 impact{ 0, 0, 0 }, normal{ 0, 0, 0 }; int rb = -1; operator bool() const { return hit; } };      // physmodel.h:280-286
+	std::vector<Body> rigidbodies;
+	std::vector<Mesh> sdmeshes;
+	explicit PhysModel(const char *jsonfile, bool hand_tweaks = false)
+	{
+		ht_model *m = nullptr;
+		const int rc = ht_model_open(jsonfile, hand_tweaks ? 1 : 0, &m);
+		if (rc != HT_OK) { const std::string msg = m ? ht_model_error(m) : "ht_model_open failed"; if (m) ht_model_close(m); throw std::runtime_error("PhysModel: " + msg); }
+		m_ = std::shared_ptr<ht_model>(m, [](ht_model *x) { ht_model_close(x); });
+		int nb = 0; ht_model_counts(m, &nb, nullptr);
+		for (int b = 0; b < nb; b++)
+		{
+			int nv = 0, nt = 0; float com[3], rest[7];
+			ht_model_body(m, b, &nv, &nt, nullptr, com, rest);
+			Body rb; rb.position = { rest[0], rest[1], rest[2] }; rb.orientation = { rest[3], rest[4], rest[5], rest[6] }; rb.com = { com[0], com[1], com[2] };
+			rigidbodies.push_back(rb);
+			Mesh mesh; std::vector<float> v((size_t)nv * 3); std::vector<int> t((size_t)nt * 3);
+			ht_model_body_mesh(m, b, v.data(), t.data());
+			for (int i = 0; i < nv; i++) mesh.verts.push_back({ v[3 * i], v[3 * i + 1], v[3 * i + 2] });
+			for (int i = 0; i < nt; i++) mesh.tris.push_back({ t[3 * i], t[3 * i + 1], t[3 * i + 2] });
+			sdmeshes.push_back(mesh);
+		}
+	}
+	std::vector<Pose> GetPose() const { std::vector<Pose> p; for (auto &rb : rigidbodies) p.push_back(rb.pose()); return p; }                                            // physmodel.h:433
+	std::vector<Pose> GetPoseUser() const { std::vector<Pose> p; for (auto &rb : rigidbodies) { Pose q = rb.pose(); q.position = rb.PositionUser(); p.push_back(q); } return p; }      // :434
+	PhysModel &SetPose(const std::vector<Pose> &poses) { for (size_t i = 0; i < poses.size() && i < rigidbodies.size(); i++) { rigidbodies[i].position = poses[i].position; rigidbodies[i].orientation = poses[i].orientation; } return *this; }      // :435
+	std::vector<Mesh> &GetMeshes(int = 0) { for (size_t i = 0; i < rigidbodies.size(); i++) sdmeshes[i].pose = rigidbodies[i].pose(); return sdmeshes; }                 // :295-303 (hull meshes in the bodies' own frames)
+	ModelHitInfo HitCheck(const float3 &v0, const float3 &v1) const                                                                                                      // :287-294
+	{
+		std::vector<float> p7(rigidbodies.size() * HT_POSE);
+		for (size_t b = 0; b < rigidbodies.size(); b++) { const Body &rb = rigidbodies[b]; float *p = &p7[b * HT_POSE]; p[0] = rb.position.x; p[1] = rb.position.y; p[2] = rb.position.z; p[3] = rb.orientation.x; p[4] = rb.orientation.y; p[5] = rb.orientation.z; p[6] = rb.orientation.w; }
+		ModelHitInfo h;
+		ht_model_hitcheck(m_.get(), p7.data(), &v0.x, &v1.x, &h.impact.x, &h.normal.x, &h.rb);
+		h.hit = h.rb >= 0;
+		return h;
+	}
+};
+inline PhysModel LoadHandModel(const char *jsonfile = "../assets/model_hand.json") { return PhysModel(jsonfile, true); }                                                    // handtrack.h:347-366
 }  // namespace ht_mi355x
+
+#ifdef HT_MI355X_GLOBAL_NAMES      // the reference's headers declare these names at global scope
+using ht_mi355x::float2; using ht_mi355x::float3; using ht_mi355x::float4; using ht_mi355x::int2; using ht_mi355x::int3;
+using ht_mi355x::Pose; using ht_mi355x::DCamera; using ht_mi355x::Image; using ht_mi355x::Mesh; using ht_mi355x::CNN; using ht_mi355x::HandTracker; using ht_mi355x::PhysModel;
+using ht_mi355x::HandSegmentVR; using ht_mi355x::camsub; using ht_mi355x::GatherHandExpectedCNN; using ht_mi355x::PoseInitializerCNN; using ht_mi355x::LoadHandModel;
+#endif

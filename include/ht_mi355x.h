@@ -79,6 +79,8 @@ typedef struct ht_params
  *                handtrack.h:347-366: 2x subdivision, 48-vertex hull, mass properties, planes, ignore lists), or a model
  *                baked earlier by ht_model_bake (recognised by its "HTFX0001" magic).
  *                max_batch: number of independent tracker slots (frames processed per call).
+ *                model_path == NULL gives a context without a hand model that only serves the CNN entry points (ht_cnn_*): what a stand-alone
+ *                CNN object is in the reference (CNN PoseInitializerCNN(std::string), handtrack.h:103-130); tracker calls on it return HT_ERR_STATE.
  * ht_destroy     replaces  HandTracker::~HandTracker() (handtrack.h:841-844). */
 int ht_create(const char *model_path, int max_batch, int device, ht_ctx **out);
 int ht_destroy(ht_ctx *ctx);
@@ -169,6 +171,26 @@ int ht_capacity_events(ht_ctx *ctx, int *epa_cut_short, int *contacts_dropped, i
 int ht_cnn_train(ht_ctx *ctx, const float *inputs, const float *targets, int n, float alpha, float *mse_out);
 int ht_cnn_get_weights(ht_ctx *ctx, float *w, size_t n);
 int ht_expected_cnn(const float *pose, const float *cam, float *expected);
+int ht_expected_cnn_full(const float *pose, const float *cam, float *expected, float *image_points /* [8][2], may be NULL */, float *vals /* [16], may be NULL */);
+
+/* ---- a hand model that is not being tracked (host only, no device needed) ---------------------------------------------------
+ * The reference's applications keep a second PhysModel to pose, draw and ray-cast their synthetic input
+ * (`PhysModel fakehand = LoadHandModel();` synthetic-tracker.cpp:94, FakeDepth :69-76).
+ * ht_model_open      replaces  PhysModel::PhysModel(const char *jsonfile) (physmodel.h:444-475) and, with hand_tweaks != 0, LoadHandModel()
+ *                    (handtrack.h:347-366); a model baked by ht_model_bake is accepted too.  *out is set even on failure (ht_model_error), close it.
+ * ht_model_body      per body: vertex / hull-triangle / plane counts, centre of mass in rig space (RigidBody::com) and the rest pose.
+ * ht_model_body_mesh the body's collision vertices [nverts][3] (centre-of-mass frame) and hull triangles [ntris][3]: what PhysModel::GetMeshes()
+ *                    hands to a renderer (physmodel.h:295-303), posed by the caller.
+ * ht_model_hitcheck  replaces  PhysModel::HitCheck(v0, v1) (physmodel.h:287-294) for bodies at poses [nb][7]: nearest hit of the segment with the
+ *                    bodies' hulls; *body = -1 and impact = v1 when nothing is hit. */
+typedef struct ht_model ht_model;
+int ht_model_open(const char *path, int hand_tweaks, ht_model **out);
+int ht_model_close(ht_model *m);
+const char *ht_model_error(const ht_model *m);
+int ht_model_counts(const ht_model *m, int *n_bodies, int *n_joints);
+int ht_model_body(const ht_model *m, int body, int *nverts, int *ntris, int *nplanes, float *com3, float *rest_pose7);
+int ht_model_body_mesh(const ht_model *m, int body, float *verts, int *tris);
+int ht_model_hitcheck(const ht_model *m, const float *poses, const float *v0, const float *v1, float *impact3, float *normal3, int *body);
 
 /* ---- segmentation: the step before the tracker for full-size frames --------------------------------------------------
  * ht_segment_vr       replaces  Image<unsigned short> HandSegmentVR(const Image<unsigned short> &depth, int entry_options = 0xF,

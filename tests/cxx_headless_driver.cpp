@@ -1,0 +1,98 @@
+// A headless stand-in for synthetic-hand-tracker/synthetic-tracker.cpp written against include/ht_handtrack.hpp with the reference's global names:
+// the same calls in the same order (tracker set-up :90-93, fake hand :94-96,139, software depth raster :69-76, per-frame sequence :204-216),
+// without the window.  Our own code: the reference's application is not copied, only its use of the API is followed.
+//
+//   driver fakedepth <model> <in.bin> <out.bin>      host only: pose a fake hand, ray-cast a depth frame (FakeDepth)
+//   driver track <model> <weights.cnnb> <in.bin> <out.bin>      the tracking loop on given frames (needs the GPU)
+//
+// in.bin:  int32 n, w, h, nb; then n records { u16 depth[w*h]; f32 cam[12]; f32 start[nb][7]; f32 gt[nb][7] }
+// out.bin (track): n records { f32 pose_user[nb][7]; f32 cnn_output[2304]; f32 labels[2304]; f32 cnn_pose_accepted; f32 handpose_via_facade[nb][7] }
+// out.bin (fakedepth): n records { u16 depth[w*h] }
+#define HT_MI355X_GLOBAL_NAMES
+#include <cstdio>
+#include <cstring>
+#include "../include/ht_formats.hpp"
+
+static Image<unsigned short> FakeDepth(PhysModel &model, const DCamera &dcam)      // the application's software rasteriser: one HitCheck per pixel
+{
+	Image<unsigned short> depth(dcam);
+	for (int y = 0; y < dcam.dim().y; y++) for (int x = 0; x < dcam.dim().x; x++)
+	{
+		// deprojectz(p, 4.0): the point 4 m out along the pixel's ray (misc_image.h:48)
+		const float3 far{ ((float)x - dcam.principal().x) / dcam.focal().x * 4.0f, ((float)y - dcam.principal().y) / dcam.focal().y * 4.0f, 4.0f };
+		depth.pixel({ x, y }) = (unsigned short)(model.HitCheck({ 0, 0, 0 }, far).impact.z / dcam.depth_scale);
+	}
+	return depth;
+}
+struct Record { std::vector<unsigned short> depth; float cam[12]; std::vector<Pose> start, gt; };
+static std::vector<Pose> poses_of(const float *p, int nb) { std::vector<Pose> v(nb); for (int b = 0; b < nb; b++) { v[b].position = { p[7 * b], p[7 * b + 1], p[7 * b + 2] }; v[b].orientation = { p[7 * b + 3], p[7 * b + 4], p[7 * b + 5], p[7 * b + 6] }; } return v; }
+static void put_poses(FILE *f, const std::vector<Pose> &v) { for (auto &p : v) { const float r[7] = { p.position.x, p.position.y, p.position.z, p.orientation.x, p.orientation.y, p.orientation.z, p.orientation.w }; fwrite(r, 4, 7, f); } }
+static std::vector<Record> read_input(const char *fn, int &w, int &h, int &nb)
+{
+	FILE *f = fopen(fn, "rb"); if (!f) throw std::runtime_error("cannot open input");
+	int hdr[4]; if (fread(hdr, 4, 4, f) != 4) throw std::runtime_error("short input");
+	w = hdr[1]; h = hdr[2]; nb = hdr[3];
+	std::vector<Record> recs(hdr[0]);
+	for (auto &r : recs)
+	{
+		r.depth.resize((size_t)w * h); std::vector<float> a((size_t)nb * 7), b((size_t)nb * 7);
+		if (fread(r.depth.data(), 2, r.depth.size(), f) != r.depth.size() || fread(r.cam, 4, 12, f) != 12 || fread(a.data(), 4, a.size(), f) != a.size() || fread(b.data(), 4, b.size(), f) != b.size()) throw std::runtime_error("short record");
+		r.start = poses_of(a.data(), nb); r.gt = poses_of(b.data(), nb);
+	}
+	fclose(f);
+	return recs;
+}
+static DCamera camera_of(const float *c, int w, int h) { Pose p; p.position = { c[5], c[6], c[7] }; p.orientation = { c[8], c[9], c[10], c[11] }; return DCamera({ w, h }, { c[0], c[1] }, { c[2], c[3] }, c[4], p); }
+
+int main(int argc, char **argv)
+{
+	if (argc < 5) { printf("usage: %s fakedepth <model> <in> <out> | track <model> <cnnb> <in> <out>\n", argv[0]); return 2; }
+	try
+	{
+		const std::string mode = argv[1];
+		int w = 0, h = 0, nb = 0;
+		if (mode == "fakedepth")
+		{
+			auto recs = read_input(argv[3], w, h, nb);
+			PhysModel fakehand = LoadHandModel(argv[2]);                       // synthetic-tracker.cpp:94
+			if ((int)fakehand.rigidbodies.size() != nb) throw std::runtime_error("bone count mismatch");
+			FILE *o = fopen(argv[4], "wb");
+			for (auto &r : recs)
+			{
+				fakehand.SetPose(r.gt);                                        // :139
+				auto dimage = FakeDepth(fakehand, camera_of(r.cam, w, h));     // :182 (software_rasterizer)
+				fwrite(dimage.raster.data(), 2, dimage.raster.size(), o);
+			}
+			fclose(o);
+			printf("fakedepth: %zu frames of %dx%d, %zu mesh triangles on bone 1\n", recs.size(), w, h, fakehand.GetMeshes(true)[1].tris.size());
+			return 0;
+		}
+		if (mode != "track" || argc < 6) return 2;
+		auto recs = read_input(argv[4], w, h, nb);
+		HandTracker htk(argv[2], argv[3]);                                     // :90 (asset paths are arguments here)
+		htk.always_take_cnn = 0;                                               // :91
+		htk.microforce = 3.0f;                                                 // :92
+		htk.mainthreadpasses = 3;                                              // :93
+		htk.load_config("../config.json");                                     // :111 (absent: a no-op, as in the reference)
+		FILE *o = fopen(argv[5], "wb");
+		for (auto &r : recs)
+		{
+			Image<unsigned short> dimage(camera_of(r.cam, w, h), r.depth);
+			htk.SetPose(r.start);                                              // every record is an independent tracker start (both models, flags cleared)
+			auto segment = HandSegmentVR(dimage);                              // :204
+			DCamera hcam = camsub(segment.cam, 4);                             // :206
+			auto fake_labels = GatherHandExpectedCNN(r.gt, hcam);              // :207
+			auto pose = htk.update(std::move(dimage));                         // :215
+			put_poses(o, pose);
+			fwrite(htk.cnn_output.data(), 4, htk.cnn_output.size(), o);
+			fwrite(fake_labels.cnn_expected.data(), 4, fake_labels.cnn_expected.size(), o);
+			const float shown = (htk.cnn_input.raster.size() == 4096 && htk.cnn_output_analysis.hmaps.size() == 8) ? 1.0f : 0.0f;      // :218-222 draw these
+			fwrite(&shown, 4, 1, o);
+			put_poses(o, htk.handmodel.GetPoseUser());                         // :233 reads the tracked model back through the facade
+		}
+		fclose(o);
+		printf("track: %zu frames, %d bones\n", recs.size(), nb);
+		return 0;
+	}
+	catch (const std::exception &e) { printf("error: %s\n", e.what()); return 1; }
+}

@@ -1,0 +1,82 @@
+"""The reference-named C++ surface (include/ht_handtrack.hpp, global names) driven the way synthetic-hand-tracker/synthetic-tracker.cpp drives the
+reference (tests/cxx_headless_driver.cpp follows its call sequence :90-96,139,204-216 without the window), compared with what the reference
+itself produced:
+
+  fakedepth   LoadHandModel + PhysModel::SetPose + HitCheck per pixel (the application's software rasteriser, :69-76) on the host
+              vs the 320x240 depth frames the reference rendered (tests/golden/fullframe320.htfx)
+  track       HandSegmentVR, camsub, GatherHandExpectedCNN, HandTracker::update, cnn_output, handmodel.GetPoseUser on the device
+              vs the reference's poses for the same frames (tests/golden/golden8.htfx `uw_pose_user`)"""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import htfx
+import oracle_lib as ol
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+POS_TOL, QUAT_TOL = 2e-4, 2e-3      # whole path with the CNN on MFMA, as tests/test_gpu_solver.py
+
+
+def _build(tmp_path):
+    from hand_tracking_samples_amd import native
+    native.load()
+    exe = str(tmp_path / "driver")
+    lib = os.path.dirname(native.lib_path())
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(HERE, "cxx_headless_driver.cpp"), "-o", exe, "-L" + lib, "-lht_mi355x", "-Wl,-rpath," + lib])
+    return exe
+
+
+def _write_input(path, depth, cams, start, gt):
+    n, h, w = depth.shape
+    nb = start.shape[1]
+    with open(path, "wb") as f:
+        f.write(struct.pack("<4i", n, w, h, nb))
+        for k in range(n):
+            f.write(np.ascontiguousarray(depth[k], np.uint16).tobytes()); f.write(np.ascontiguousarray(cams[k], np.float32).tobytes())
+            f.write(np.ascontiguousarray(start[k], np.float32).tobytes()); f.write(np.ascontiguousarray(gt[k], np.float32).tobytes())
+
+
+def test_fake_hand_depth_raster_matches_the_reference(tmp_path):
+    """host only: the model facade (ht_model_open / ht_model_hitcheck behind PhysModel::HitCheck) renders the frames the reference rendered"""
+    exe = _build(tmp_path)
+    G = htfx.load(os.path.join(HERE, "golden", "fullframe320.htfx"))
+    n = len(G["rows"])
+    depth = np.stack([G["f%d/depth" % f] for f in range(n)]); cams = np.stack([G["f%d/cam" % f] for f in range(n)])
+    gt = np.stack([G["f%d/gtpose" % f] for f in range(n)]); start = np.stack([G["f%d/startpose" % f] for f in range(n)])
+    _write_input(tmp_path / "in.bin", depth, cams, start, gt)
+    out = subprocess.check_output([exe, "fakedepth", ol.MODEL, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")]).decode()
+    assert "92 mesh triangles" in out
+    got = np.fromfile(tmp_path / "out.bin", np.uint16).reshape(depth.shape)
+    hand = depth < 4000
+    assert hand.sum() > 2000
+    assert np.array_equal(got, depth), "%d of %d pixels differ" % ((got != depth).sum(), depth.size)
+
+
+@pytest.mark.gpu
+def test_tracking_loop_through_the_cxx_surface_matches_the_reference(tmp_path, golden, weights):
+    from hand_tracking_samples_amd import native, weights as W
+    exe = _build(tmp_path)
+    nf = 8
+    depth = np.stack([golden["f%d/depth" % f] for f in range(nf)]); cams = np.stack([golden["f%d/cam" % f] for f in range(nf)])
+    start = np.stack([golden["f%d/startpose" % f] for f in range(nf)]); gt = np.stack([golden["f%d/gtpose" % f] for f in range(nf)])
+    _write_input(tmp_path / "in.bin", depth, cams, start, gt)
+    cnnb = str(tmp_path / "w.cnnb")
+    W.save_cnnb(cnnb, weights)
+    r = subprocess.run([exe, "track", ol.MODEL, cnnb, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "track: 8 frames, 17 bones" in r.stdout
+    rec = np.fromfile(tmp_path / "out.bin", np.float32).reshape(nf, 17 * 7 + 2304 + 2304 + 1 + 17 * 7)
+    for f in range(nf):
+        pose = rec[f, :119].reshape(17, 7); cnn = rec[f, 119:119 + 2304]; labels = rec[f, 119 + 2304:119 + 4608]; shown = rec[f, 119 + 4608]; facade = rec[f, 120 + 4608:].reshape(17, 7)
+        ref = golden["f%d/uw_pose_user" % f]
+        dp = np.abs(pose[:, :3] - ref[:, :3]).max(); dq = np.abs(pose[:, 3:] - ref[:, 3:]).max()
+        print("C++ surface frame %d: |dpos| %.2e |dquat| %.2e vs the reference" % (f, dp, dq))
+        assert dp <= POS_TOL and dq <= QUAT_TOL
+        assert np.abs(cnn - golden["f%d/cnn_output" % f]).max() <= 2e-5
+        assert np.array_equal(labels, native.expected_cnn(gt[f], cams[f]))      # GatherHandExpectedCNN through camsub(segment.cam, 4)
+        assert shown == 1.0
+        assert np.array_equal(facade, pose)                                      # handmodel.GetPoseUser() == what update() returned
