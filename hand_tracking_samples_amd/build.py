@@ -11,13 +11,17 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libht_mi355x.so")
+LIB = os.environ.get("HT_LIB_PATH") or os.path.join(HERE, "libht_mi355x.so")      # HT_LIB_PATH: measurement only (A/B of two builds on one device)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 # k_solve runs one wave per SIMD, where every issued instruction (an s_nop covering a DPP hazard included) costs its 4-cycle slot: for that
 # file the ILP-first scheduler fills hazard slots with independent work (58 -> 46 no-ops per pair of linear steps, 11 -> 3 per pair of
 # chain rows; same arithmetic, another order of independent instructions).  Measured per file; it slows the other kernels down.
-FILE_FLAGS = {"ht_solver.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+# -fno-slp-vectorize for the same file: packing the two multiplies of a cross product into v_pk_mul_f32 takes their DPP operands away (packed
+# instructions cannot carry one), which costs two v_mov_b32_dpp and register shuffles per row: 42.5 -> 38.75 issued instructions per chain row, 179 -> 112 VGPRs.
+FILE_FLAGS = {"ht_solver.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fno-slp-vectorize"]}
+if os.environ.get("HT_SOLVER_FLAGS") is not None:      # measurement builds: try other per-file flags for the solver
+    FILE_FLAGS = {"ht_solver.hip": os.environ["HT_SOLVER_FLAGS"].split()}
 OBJDIR = os.path.join(HERE, "build")
 if os.environ.get("HT_TUNING"):      # measurement builds only: lets HT_DEBUG_SKIP / HT_NO_SIDE / HT_NO_OVERLAP reach the kernels (tools/ablate_*.sh, tools/solve_stats.py)
     FLAGS = FLAGS + ["-DHT_TUNING"]
@@ -28,6 +32,8 @@ def sources():
 
 
 def stale():
+    if os.environ.get("HT_LIB_PATH"):
+        return False
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)

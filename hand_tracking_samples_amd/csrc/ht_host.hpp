@@ -46,7 +46,8 @@ struct ht_ctx
 	int *d_accepted = nullptr;
 	float *d_contacts = nullptr; int *d_ncontacts = nullptr;    // [B][HT_MAXCONTACT][HT_CONTACT]
 	unsigned char *d_epa_ws = nullptr;                           // expanding-polytope workspace, one per (frame, wave)
-	float *d_scratch = nullptr;                                  // solver row stream [B][HT_MAXPTS + 5*nb + 32][12]
+	float *d_scratch = nullptr;                                  // solver row records [B][HT_MAXPTS + 5*nb + 32][20] (ht_quad.hpp)
+	int *d_retry = nullptr;                                      // [B] k_solve: frames handed from the small-pool build to the large one
 	float *d_poses_out = nullptr, *d_start = nullptr;
 	float *d_stage = nullptr;                                    // staging for host<->device state copies
 };

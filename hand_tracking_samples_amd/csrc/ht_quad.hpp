@@ -37,22 +37,106 @@ __device__ __forceinline__ float div_ieee(float x, float y)
 }
 
 
-// One LimitLinear::Iter (physics.h:289-307) on a body held in quad layout.  Lane c < 3 passes rv = r1[c] (lever arm, world frame) and
-// n = normal[c]; lane 3 passes the row's target speed in rv.  t = (fmin*dt, fmax*dt, effective mass, impulse sum).  Returns the new sum.
-struct quad_body { float l, av, minv, Ix, Iy, Iz; };      // this lane's component of the linear / angular momentum, 1/mass, row c of Iinv
-__device__ __forceinline__ float quad_row_step(quad_body &B, float rv, float n, float4 t)
+// refined reciprocal of the IEEE division above: depends on the divisor only, so rows whose divisor is sweep-invariant store it once
+__device__ __forceinline__ float rcp_refined(float y)
 {
+	float r = __builtin_amdgcn_rcpf(y);
+	const float e = __fmaf_rn(-y, r, 1.0f);
+	return __fmaf_rn(e, r, r);
+}
+// x / y given r = rcp_refined(y): the remaining five operations of div_ieee, bit for bit the same quotient
+__device__ __forceinline__ float div_ieee_r(float x, float y, float r)
+{
+	float q = x * r;
+	float rem = __fmaf_rn(-y, q, x);
+	q = __fmaf_rn(rem, r, q);
+	rem = __fmaf_rn(-y, q, x);
+	return __fmaf_rn(rem, r, q);
+}
+
+// ---- single-body row chains ------------------------------------------------------------------------------------------------------
+// Record of one single-body row (LimitLinear with rb0 == NULL), 5 x 16 bytes, laid out by the lane that reads each part:
+//   slot c (c = 0,1,2)  lane c of the quad:  r1[c+1], r1[c+2], n[c], and in the fourth word fmin*dt (slot 0) / fmax*dt (slot 1)
+//                       (r1 = lever arm in the world frame: the two components a cross product needs on lane c; n = row direction)
+//   slot 3              lane 3, sweeps with bias:             targetspeed,        rinv, effective mass, 0      (rinv = rcp_refined(effective mass))
+//   slot 4              lane 3, sweeps after RemoveBias (physics.h:288): min(ts, ts_nobias), rinv, effective mass, 0
+// The records are read-only during the sweeps; the one value a row changes, its impulse sum, lives in an LDS array beside them (a store into
+// the record would sit in the same in-order memory queue as the reads of the rows ahead and hold them back until it is acknowledged).
+// Lane c < 3 carries component c of the body's momenta; lane 3 does the scalar part of the row (division, clamp, impulse sum), takes the two
+// force limits from lanes 0 and 1 and hands the impulse to the others, all through DPP operands.  Per row each lane issues ONE 16-byte read
+// (the texture path moves 64 B per clock per CU, i.e. 16 clocks per such wave instruction: with four to eight waves per CU walking chains
+// that path, not the arithmetic, is what a second read per row would saturate), one LDS read and one LDS write.
+#define CREC 20            // floats per record
+#define QP_PREV 0x90       // quad_perm:[0,0,1,2]: lane i reads lane i-1 of its quad
+struct quad_body { float l, av, minv, Ix, Iy, Iz; };      // this lane's component of the linear / angular momentum, 1/mass, row c of Iinv
+
+// One LimitLinear::Iter (physics.h:289-307): a = this lane's slot, sum = the row's impulse sum.  Returns the new impulse sum (on every lane of the quad).
+// Operation order per component is the reference's: w = Iinv * angular momentum (column sum), v = cross(w, r1) + lin * massinv,
+// vn = (v.x*n.x + v.y*n.y) + v.z*n.z, impulse = (-targetspeed - vn) / effmass clamped to [fmin*dt - sum, fmax*dt - sum],
+// lin += n * impulse, ang += cross(r1, n * impulse).
+__device__ __forceinline__ float quad_row_step(quad_body &B, const float4 a, const float sum)
+{
+	const float lm = B.l * B.minv;
 	const float w = (B.Ix * dpp<QP_BC0>(B.av) + B.Iy * dpp<QP_BC1>(B.av)) + B.Iz * dpp<QP_BC2>(B.av);      // (Iinv * angular_momentum)[c]
-	const float m1 = w * dpp<QP_ROT1>(rv), m2 = w * dpp<QP_ROT2>(rv);                                      // w[c]*r1[c+1], w[c]*r1[c+2]
-	const float v1 = (dpp<QP_ROT1>(m1) - dpp<QP_ROT2>(m2)) + B.l * B.minv;                                 // (cross(spin, r1) + lin*massinv)[c]
-	const float p = v1 * n;
-	const float vn = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);
-	const float impulsen = -dpp<QP_BC3>(rv) - vn;
-	float impulse = div_ieee(impulsen, t.z);
-	impulse = clamp_med3(impulse, t.x - t.w, t.y - t.w);
-	const float imp = n * impulse;
+	const float cr = dpp<QP_ROT1>(w) * a.y - dpp<QP_ROT2>(w) * a.x;                                        // w[c+1]*r1[c+2] - w[c+2]*r1[c+1]
+	const float p = (cr + lm) * a.z;
+	const float t = dpp<QP_PREV>(p) + p;                                                                   // lane 1: p0 + p1
+	const float s = dpp<QP_PREV>(t) + p;                                                                   // lane 2: (p0 + p1) + p2 = vn
+	const float x = -a.x - dpp<QP_PREV>(s);                                                                // lane 3: -targetspeed - vn
+	float impulse = div_ieee_r(x, a.z, a.y);                                                               // lane 3: a.y = rinv, a.z = effective mass
+	impulse = clamp_med3(impulse, dpp<QP_BC0>(a.w) - sum, dpp<QP_BC1>(a.w) - sum);
+	const float imp = dpp<QP_BC3>(impulse) * a.z;                                                          // n[c] * impulse
+	const float k = a.x * dpp<QP_ROT2>(imp) - a.y * dpp<QP_ROT1>(imp);                                     // r1[c+1]*imp[c+2] - r1[c+2]*imp[c+1]
 	B.l = B.l + imp;
-	const float k1 = rv * dpp<QP_ROT1>(imp), k2 = rv * dpp<QP_ROT2>(imp);                                  // r1[c]*imp[c+1], r1[c]*imp[c+2]
-	B.av = B.av + (dpp<QP_ROT1>(k1) - dpp<QP_ROT2>(k2));                                                   // cross(r1, imp)[c]
-	return t.w + impulse;
+	B.av = B.av + k;
+	return sum + dpp<QP_BC3>(impulse);      // the same value on all four lanes (they read the same sum): the quad's four writes to one address agree
+}
+// Applies rows [0, cnt) of one chain in order.  rec = the chain's first record, sums = the chain's first impulse sum (LDS), c = lane within the
+// quad, post = 1 after RemoveBias.  Eight register sets rotate, so the read of a row is issued eight rows ahead of its use (records stream from
+// L2 / the Infinity Cache, several hundred clocks away); the loop trips of the quads of a wave differ, the compiler masks finished quads off.
+// Reads run up to 15 records (and sums) past the chain's end: the caller's buffers have that slack.
+#define QUAD_CHAIN_SLACK 16
+__device__ __forceinline__ void quad_chain_run(quad_body &B, const float *rec, float *sums, int cnt, int c, int post)
+{
+	const float4 *pa = reinterpret_cast<const float4 *>(rec) + (c < 3 ? c : 3 + post);
+	float *ps = sums;
+	// first reads in the order the loop consumes them (the wait counts the compiler derives for the loop are the minimum over both entries)
+#define QC_LOAD(i, row) a##i = pa[5 * (row)]; s##i = ps[row]; __builtin_amdgcn_sched_barrier(0)
+	float4 a0, a1, a2, a3, a4, a5, a6, a7; float s0, s1, s2, s3, s4, s5, s6, s7;
+	QC_LOAD(0, 0); QC_LOAD(1, 1); QC_LOAD(2, 2); QC_LOAD(3, 3); QC_LOAD(4, 4); QC_LOAD(5, 5); QC_LOAD(6, 6); QC_LOAD(7, 7);
+	int k = 0;
+	// The scheduling barriers keep every row's instructions between its own pair: left alone, the ILP-first scheduler hoists the first use of the
+	// record that was requested last to the top of the trip as a hazard filler, which turns the wait for it into a wait for every outstanding
+	// read (s_waitcnt vmcnt(0)), i.e. one full memory round trip per trip.
+#define QC_STEP(i) ps[i] = quad_row_step(B, a##i, s##i)
+	for (; k + 8 <= cnt; k += 8)
+	{
+		QC_STEP(0); QC_LOAD(0, 8); QC_STEP(1); QC_LOAD(1, 9); QC_STEP(2); QC_LOAD(2, 10); QC_STEP(3); QC_LOAD(3, 11);
+		QC_STEP(4); QC_LOAD(4, 12); QC_STEP(5); QC_LOAD(5, 13); QC_STEP(6); QC_LOAD(6, 14); QC_STEP(7); QC_LOAD(7, 15);
+		pa += 40; ps += 8;
+	}
+	const int left = cnt - k;      // 0..7 rows, already in the register sets
+	if (left > 0) QC_STEP(0);
+	__builtin_amdgcn_sched_barrier(0);
+	if (left > 1) QC_STEP(1);
+	__builtin_amdgcn_sched_barrier(0);
+	if (left > 2) QC_STEP(2);
+	__builtin_amdgcn_sched_barrier(0);
+	if (left > 3) QC_STEP(3);
+	__builtin_amdgcn_sched_barrier(0);
+	if (left > 4) QC_STEP(4);
+	__builtin_amdgcn_sched_barrier(0);
+	if (left > 5) QC_STEP(5);
+	__builtin_amdgcn_sched_barrier(0);
+	if (left > 6) QC_STEP(6);
+#undef QC_LOAD
+#undef QC_STEP
+}
+// fills one record (see the layout above); r1 = lever arm in the world frame, n = row direction, y = effective mass
+__device__ __forceinline__ void quad_write_record(float *rec, v3 r1, v3 n, float ts, float ts_post, float y, float fmin_dt, float fmax_dt)
+{
+	float4 *o = reinterpret_cast<float4 *>(rec);
+	const float rinv = rcp_refined(y);
+	o[0] = make_float4(r1.y, r1.z, n.x, fmin_dt); o[1] = make_float4(r1.z, r1.x, n.y, fmax_dt); o[2] = make_float4(r1.x, r1.y, n.z, 0.0f);
+	o[3] = make_float4(ts, rinv, y, 0.0f); o[4] = make_float4(ts_post, rinv, y, 0.0f);
 }

@@ -29,29 +29,43 @@
 #include "ht_device.hpp"
 #include "ht_launch.hpp"
 
-#define CROW 12            // floats per single-body row: r1[3] ts | n[3] ts_post | fmin*dt fmax*dt effmass impulsesum
 #define LROW 16            // floats per two-body linear row: ts ts_post fmin*dt fmax*dt(|mu) effmass impulsesum meta r0[3] r1[3] n[3]
-#define MAXL2 (3 * HT_MAXNJ + 3 * HT_MAXCONTACT)      // two-body linear rows (all live in LDS)
 #define ASLOTS 2           // angular rows live in registers: row r in lane r%64, slot r/64  (<= 128 rows)
 #define MAXA2 (64 * ASLOTS)
 #define AROW 10            // floats per angular row record: axis[3] meta | ts ts_post | mintorque*dt maxtorque*dt | 1/(axis.Iinv.axis) torque
 #define MAXA_LDS 126       // angular rows held in LDS: 13 + up to 6 per joint for the 17-bone hand, plus slowfit's relative rows
-#define POOL_FLOATS 7136   // LDS pool shared by the two-body linear rows (front) and the single-body chain rows (rest; overflow: HBM scratch)
+// LDS per frame = the two-body linear rows (joint triples, contact triples, the idle group: 192 B per group), the impulse sums of the single-body rows
+// (4 B each) and ~10 KB of body state, schedule tables and angular records.  Three builds of the kernel, chosen per launch:
+//   small   39 groups, 696 sums: < 20 KB, eight frames per CU (two waves per SIMD).  Every frame of the 17-bone / 64x64 workloads fits.
+//   mid     70 groups, 4272 sums (every point a full-size frame can carry): < 40 KB, four frames per CU.  The first choice for larger models or frames.
+//   large   128 groups (all 96 contacts of the contact kernel's capacity), 1184 sums in LDS, more than that in HBM: 40 KB.  Second launch: it takes the
+//           frames the first build found too big for its LDS and left untouched (their retry flag); every other block exits at once.
+#define POOL_SMALL (40 * 3 * LROW)
+#define POOL_MID (71 * 3 * LROW)
+#define POOL_LARGE ((HT_MAXNJ + HT_MAXCONTACT + 1) * 3 * LROW)
+#define SUMS_SMALL 712
+#define SUMS_MID (HT_MAXPTS + 5 * HT_MAXNB + 32)
+#define SUMS_LARGE 1200
 #define IDLE_BODY (HT_MAXNB - 1)      // lane pairs without a row in a step work on this all-zero body and on an all-zero record
 #define LM_FRIC 0x10000    // meta bits of a two-body linear row: friction row (limits from its contact's normal row, physics.h:292)
 #define LM_NORMAL 0x20000  //                                     normal row of a contact (publishes its impulse sum)
 
-struct lds_t
+template <int POOL_FLOATS, int NSUM_> struct lds_t
 {
-	float pool[POOL_FLOATS] __attribute__((aligned(16)));      // first member: row addresses then fit the short offsets of two-address LDS reads
+	static constexpr int ML2 = POOL_FLOATS / LROW;             // rows the pool holds, the idle group's three included
+	static constexpr int LIDLE = ML2 / 3 - 1;                  // slot of the idle entry in lorder (real groups: at most LIDLE)
+	static constexpr int NLEV = (ML2 / 3 > 64 * 2 ? ML2 / 3 : 64 * 2) + 2;      // levels of either schedule (linear groups, angular runs)
+	static constexpr int NSUM = NSUM_;
+	float pool[POOL_FLOATS] __attribute__((aligned(16)));      // two-body linear rows; first member: row addresses then fit the short offsets of two-address LDS reads
 	// body state in 16-byte records: component c of body b is word 4*b + c
 	float4 lin4[HT_MAXNB];                 // xyz linear momentum, w = massinv
 	float4 ang4[HT_MAXNB];                 // xyz angular momentum, w = friction
 	float4 I4[HT_MAXNB][3];                // columns of the world inverse inertia (w unused)
 	float pos[HT_MAXNB][3], q[HT_MAXNB][4];
+	float csum[NSUM];                      // impulse sum of every single-body row, in the order of the partitioned stream (+ read-ahead slack)
 	int ccnt[HT_MAXNB], cstart[HT_MAXNB];  // chain of body b: rows [cstart, cstart+ccnt) of the partitioned single-body stream
-	unsigned lorder[MAXL2 / 3 + 1];        // two-body linear row groups (3 consecutive rows of a joint / a contact) sorted by step: group | rb0 << 16 | rb1 << 24; last slot = the idle entry
-	unsigned short lstart[MAXL2 / 3 + 2];  // step L = lorder[lstart[L] .. lstart[L+1]); a step is a level, split so that it holds <= 8 groups
+	unsigned lorder[ML2 / 3];            // two-body linear row groups (3 consecutive rows of a joint / a contact) sorted by step: group | rb0 << 16 | rb1 << 24; last slot = the idle entry
+	unsigned short lstart[ML2 / 3 + 2];  // step L = lorder[lstart[L] .. lstart[L+1]); a step is a level, split so that it holds <= 8 groups
 	unsigned aorder[MAXA2 + 1];            // angular row groups (runs of consecutive rows on the same body pair): first row | count << 8 | rb0 << 16 | rb1 << 24
 	unsigned short astart[MAXA2 + 2];
 	int nlev_lin, nlev_ang, nray;
@@ -62,9 +76,9 @@ struct lds_t
 			float jr[HT_MAXNJ][6];                 // joint ranges after HandModelEnhancements
 			float ray[36][HT_ROW];                 // landmark-ray rows: 4 per ray (MultiStepSim: 5 rays; slowfit: 8 rays + 3 nail rows)
 			int acount[HT_MAXNJ], aprefix[HT_MAXNJ + 1], rprefix[HT_MAXNJ + 1];
-			unsigned char lrb[MAXL2][2], arb[MAXA2][2];     // body pair of every two-body row (255 = none), for the level schedule
-			unsigned short llev[MAXL2]; unsigned char alev[MAXA2], gst[MAXA2];
-			unsigned short lfill[MAXL2 + 2];
+			unsigned char lrb[ML2][2], arb[MAXA2][2];     // body pair of every two-body row (255 = none), for the level schedule
+			unsigned short llev[ML2 / 3]; unsigned char alev[MAXA2], gst[MAXA2];
+			unsigned short lfill[NLEV];
 			int lastlev[HT_MAXNB];                 // scratch of the level scheduler
 		};
 		float arec[(MAXA_LDS + 2) * AROW];         // sweeps: angular row records (written once the prologue scratch is dead) + the idle record + read-ahead slack
@@ -77,10 +91,10 @@ __device__ __forceinline__ v3 L3(const float *p) { return V3(p[0], p[1], p[2]); 
 __device__ __forceinline__ v4 L4(const float *p) { return V4(p[0], p[1], p[2], p[3]); }
 __device__ __forceinline__ void S3(float *p, v3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
 __device__ __forceinline__ m3 LM(const float *p) { m3 m; m.x = V3(p[0], p[1], p[2]); m.y = V3(p[3], p[4], p[5]); m.z = V3(p[6], p[7], p[8]); return m; }
-__device__ __forceinline__ xf body_xf(const lds_t &S, int b) { return XF(L3(S.pos[b]), L4(S.q[b])); }
+template <class LDS> __device__ __forceinline__ xf body_xf(const LDS &S, int b) { return XF(L3(S.pos[b]), L4(S.q[b])); }
 __device__ __forceinline__ v3 F3(float4 f) { return V3(f.x, f.y, f.z); }
-__device__ __forceinline__ m3 body_I(const lds_t &S, int b) { m3 m; m.x = F3(S.I4[b][0]); m.y = F3(S.I4[b][1]); m.z = F3(S.I4[b][2]); return m; }
-__device__ __forceinline__ v3 anchor_world(const lds_t &S, int rb, v3 p) { return rb >= 0 ? apply(body_xf(S, rb), p) : p; }
+template <class LDS> __device__ __forceinline__ m3 body_I(const LDS &S, int b) { m3 m; m.x = F3(S.I4[b][0]); m.y = F3(S.I4[b][1]); m.z = F3(S.I4[b][2]); return m; }
+template <class LDS> __device__ __forceinline__ v3 anchor_world(const LDS &S, int rb, v3 p) { return rb >= 0 ? apply(body_xf(S, rb), p) : p; }
 
 // ---- angular row builders ----------------------------------------------------------------------
 __device__ __forceinline__ void put_ang(float *o, int rb0, int rb1, v3 axis, float targetspin, float mintorque, float maxtorque)
@@ -135,7 +149,7 @@ __device__ __forceinline__ void angular_range_w(const ht_physics_dev &ph, int rb
 	}
 }
 // ConstrainConeAngle physics.h:402-414
-__device__ __forceinline__ void cone_angle(const ht_physics_dev &ph, const lds_t &S, int rb0, v3 n0, int rb1, v3 n1, float limitangle_degrees, float *out)
+template <class LDS> __device__ __forceinline__ void cone_angle(const ht_physics_dev &ph, const LDS &S, int rb0, v3 n0, int rb1, v3 n1, float limitangle_degrees, float *out)
 {
 	int equality = (limitangle_degrees == 0);
 	v3 a0 = rb0 >= 0 ? qrot(L4(S.q[rb0]), n0) : n0;
@@ -147,7 +161,7 @@ __device__ __forceinline__ void cone_angle(const ht_physics_dev &ph, const lds_t
 	put_ang(out, rb0, rb1, axis, targetspin, (limitangle_degrees > 0.0f) ? 0 : -FLT_MAX, FLT_MAX);
 }
 // ConstrainAngularDrive physics.h:313-326
-__device__ __forceinline__ void angular_drive(const ht_physics_dev &ph, const lds_t &S, int rb0, int rb1, v4 target, float maxtorque, float (*out)[8])
+template <class LDS> __device__ __forceinline__ void angular_drive(const ht_physics_dev &ph, const LDS &S, int rb0, int rb1, v4 target, float maxtorque, float (*out)[8])
 {
 	v4 q0 = rb0 >= 0 ? L4(S.q[rb0]) : V4(0, 0, 0, 1), q1 = rb1 >= 0 ? L4(S.q[rb1]) : V4(0, 0, 0, 1);
 	v4 dq = qmul(q1, qconj(qmul(q0, target)));
@@ -165,7 +179,7 @@ __constant__ int FEATURE_BONE[8] = { 1, 1, 1, 4, 7, 10, 13, 16 };
 __constant__ float FEATURE_OFF[8][3] = { { 0, 0, 0 }, { -0.03f, 0, -0.03f }, { 0.03f, 0, -0.03f }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
 
 // ---- two-body row maths ------------------------------------------------------------------------
-__device__ __forceinline__ v3 spin_of(const lds_t &S, int b) { return mul(body_I(S, b), F3(S.ang4[b])); }       // physics.h:126
+template <class LDS> __device__ __forceinline__ v3 spin_of(const LDS &S, int b) { return mul(body_I(S, b), F3(S.ang4[b])); }       // physics.h:126
 // ------------------------------------------------------------------------------------------------- k_solve
 struct arow { int rb0, rb1; v3 axis; float targetspin, mn, mx, s2t, torque, mintorque; int lev; };
 
@@ -185,10 +199,13 @@ __device__ __forceinline__ int angular_range_count(v3 lmin, v3 lmax)
 	return n;
 }
 
+template <int POOL_FLOATS, int NSUM_, bool FIRST>
 __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph, solve_args a)
 {
-	__shared__ lds_t S;
+	__shared__ lds_t<POOL_FLOATS, NSUM_> S;
 	const int b = blockIdx.x, lane = threadIdx.x;
+	if (FIRST) { if (lane == 0) a.retry[b] = 0; }
+	else if (!a.retry[b]) return;                                 // the large build only takes the frames the first one passed on
 	if (a.active_flag && !a.active_flag[b]) return;
 	const int nb = M.nb, nj = M.nj;
 	float *st = a.state + (size_t)b * nb * HT_STATE_STRIDE;
@@ -302,6 +319,17 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		S.nray = k;
 	}
 	__syncthreads();
+	if (FIRST)      // a frame with more rows than this build's LDS holds is left untouched for the large build (second launch)
+	{
+		int nc_ = (a.contacts && ph.use_collision) ? a.ncontacts[b] : 0;
+		if (nc_ > HT_MAXCONTACT) nc_ = HT_MAXCONTACT;
+		const int n1_ = (a.ray_rows ? S.nray : (a.rows_pre ? a.n_pre[b] : 0)) + (a.rows_cloud ? a.n_cloud[b] : 0);
+		if ((3 * nj + 3 * nc_ + 3) * LROW > POOL_FLOATS || n1_ > S.NSUM - QUAD_CHAIN_SLACK)
+		{
+			if (lane == 0) a.retry[b] = 1;
+			return;
+		}
+	}
 
 	if (a.dbg & 256) return;
 	// ---- angular rows: [ApplyAngles 12] [arm cone 1] [joint ranges], generated by the lane that owns them ----
@@ -410,6 +438,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	int nc = (a.contacts && ph.use_collision) ? a.ncontacts[b] : 0;
 	if (nc > HT_MAXCONTACT) nc = HT_MAXCONTACT;
 	const int n2 = 3 * nj + 3 * nc;
+
 	for (int r = lane; r < n2; r += 64)
 	{
 		int rb0, rb1, meta = 0;
@@ -467,7 +496,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	{
 		S.lin4[IDLE_BODY] = make_float4(0, 0, 0, 0); S.ang4[IDLE_BODY] = make_float4(0, 0, 0, 0);
 		S.I4[IDLE_BODY][0] = S.I4[IDLE_BODY][1] = S.I4[IDLE_BODY][2] = make_float4(0, 0, 0, 0);
-		S.lorder[MAXL2 / 3] = (unsigned)(n2 / 3) | ((unsigned)IDLE_BODY << 16) | ((unsigned)IDLE_BODY << 24);
+		S.lorder[S.LIDLE] = (unsigned)(n2 / 3) | ((unsigned)IDLE_BODY << 16) | ((unsigned)IDLE_BODY << 24);
 	}
 	__syncthreads();
 	// ---- level schedule, once per solve.  The unit is a group: the 3 consecutive rows of a joint or of a contact (same two bodies, same lever
@@ -547,15 +576,16 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	const int nlev_lin = S.nlev_lin, nlev_ang = S.nlev_ang;
 	if (a.dbg & 64) return;
 
-	// ---- single-body prefix: [ray rows | chamber rows] then cloud rows; stable partition by body + pre-compute -> LDS pool (overflow: HBM) ----
+	// ---- single-body prefix: [ray rows | chamber rows] then cloud rows; stable partition by body + pre-compute -> record stream in the frame's scratch (HBM / L2) ----
 	const int npre_g = a.rows_pre ? a.n_pre[b] : 0;
 	const int npre = a.ray_rows ? S.nray : npre_g;
 	const int ncl = a.rows_cloud ? a.n_cloud[b] : 0;
 	const int n1 = npre + ncl;
-	float *const chain = S.pool + (n2 + 3) * LROW;                // chain rows follow the two-body rows (+ the idle group) in the pool
-	int chcap = (POOL_FLOATS - (n2 + 3) * LROW) / CROW - 4;             // rows that fit in LDS (the sweep reads up to 2 records ahead); the rest stream from the HBM scratch
-	if (chcap < 0) chcap = 0;
-	float *scr = a.scratch + (size_t)b * a.scratch_stride * CROW;
+	float *scr = a.scratch + (size_t)b * a.scratch_stride * CREC;
+	const bool sums_lds = FIRST || n1 + QUAD_CHAIN_SLACK <= S.NSUM;                                         // always true in a first build (checked above)
+	float *const gsum = a.scratch + (size_t)a.batch * a.scratch_stride * CREC + (size_t)b * a.scratch_stride;      // this frame's sums in HBM, behind all frames' records
+	if (sums_lds) { for (int i = lane; i < n1 + QUAD_CHAIN_SLACK; i += 64) S.csum[i] = 0.0f; }
+	else for (int i = lane; i < n1 + QUAD_CHAIN_SLACK && i < a.scratch_stride; i += 64) gsum[i] = 0.0f;
 	auto row_ptr = [&](int i) -> const float * {
 		if (i < npre) return a.ray_rows ? S.ray[i] : a.rows_pre + ((size_t)b * a.pre_stride + i) * HT_ROW;
 		return a.rows_cloud + ((size_t)b * HT_MAXPTS + (i - npre)) * HT_ROW;
@@ -598,17 +628,16 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			if (lane == bb) myrun += __popcll(m);
 			todo &= ~m;
 		}
-		if (r && dst < a.scratch_stride)
+		if (r && dst < a.scratch_stride - QUAD_CHAIN_SLACK)
 		{
 			const v3 p1 = L3(r + 5), n = L3(r + 8);
 			const v3 r1 = qrot(L4(S.q[body]), p1);
 			const float impulsed = S.lin4[body].w + dot(cross(mul(body_I(S, body), cross(r1, n)), r1), n);       // 0 + (...) for the NULL side
 			const float ts = r[11] / dt;
-			const float4 o0 = make_float4(r1.x, r1.y, r1.z, ts), o1 = make_float4(n.x, n.y, n.z, fmin_std(ts, r[12])), o2 = make_float4(r[13] * dt, r[14] * dt, impulsed, 0.0f);
-			if (dst < chcap) { float4 *ol = reinterpret_cast<float4 *>(chain + dst * CROW); ol[0] = o0; ol[1] = o1; ol[2] = o2; }
-			else { float4 *og = reinterpret_cast<float4 *>(scr + (size_t)dst * CROW); og[0] = o0; og[1] = o1; og[2] = o2; }
+			quad_write_record(scr + (size_t)dst * CREC, r1, n, ts, fmin_std(ts, r[12]), impulsed, r[13] * dt, r[14] * dt);
 		}
 	}
+	__threadfence_block();      // the records are read back by other lanes of this wave
 	__syncthreads();
 	// ---- the prologue scratch is dead now: angular rows move from their builder lanes into LDS records ----
 #pragma unroll
@@ -658,43 +687,9 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				const float minv = lin_w[4 * body + 3];
 				const float Ix = I_w[12 * body + c], Iy = I_w[12 * body + 4 + c], Iz = I_w[12 * body + 8 + c];
 				quad_body qb = { l, av, minv, Ix, Iy, Iz };
-				auto row_step = [&](float rv, float n, float4 t) -> float { return quad_row_step(qb, rv, n, t); };
-				const int lane_off = c < 3 ? c : 3 + 4 * tsoff;                      // RemoveBias (physics.h:288): lane 3 switches to ts_post
-				const int nl = (start + cnt <= chcap) ? cnt : (start >= chcap ? 0 : chcap - start);
-				if (nl > 0)
-				{
-					// two rows per trip on alternating register sets: while one row is applied the other's record is already on its way
-					float *pv = chain + start * CROW + lane_off, *pn = chain + start * CROW + 4 + c, *pt = chain + start * CROW + 8;
-					float rvA = pv[0], nA = pn[0]; float4 tA = *reinterpret_cast<const float4 *>(pt);
-					float rvB = pv[CROW], nB = pn[CROW]; float4 tB = *reinterpret_cast<const float4 *>(pt + CROW);
-					int k = 0;
-					for (; k + 4 <= nl; k += 4)      // four rows per trip (loop control is a tenth of a row's instructions), records two rows ahead
-					{
-						pt[3] = row_step(rvA, nA, tA);
-						rvA = pv[2 * CROW]; nA = pn[2 * CROW]; tA = *reinterpret_cast<const float4 *>(pt + 2 * CROW);
-						pt[CROW + 3] = row_step(rvB, nB, tB);
-						rvB = pv[3 * CROW]; nB = pn[3 * CROW]; tB = *reinterpret_cast<const float4 *>(pt + 3 * CROW);
-						pt[2 * CROW + 3] = row_step(rvA, nA, tA);
-						rvA = pv[4 * CROW]; nA = pn[4 * CROW]; tA = *reinterpret_cast<const float4 *>(pt + 4 * CROW);
-						pt[3 * CROW + 3] = row_step(rvB, nB, tB);
-						rvB = pv[5 * CROW]; nB = pn[5 * CROW]; tB = *reinterpret_cast<const float4 *>(pt + 5 * CROW);
-						pv += 4 * CROW; pn += 4 * CROW; pt += 4 * CROW;
-					}
-					for (; k + 2 <= nl; k += 2)
-					{
-						pt[3] = row_step(rvA, nA, tA);
-						rvA = pv[2 * CROW]; nA = pn[2 * CROW]; tA = *reinterpret_cast<const float4 *>(pt + 2 * CROW);
-						pt[CROW + 3] = row_step(rvB, nB, tB);
-						rvB = pv[3 * CROW]; nB = pn[3 * CROW]; tB = *reinterpret_cast<const float4 *>(pt + 3 * CROW);
-						pv += 2 * CROW; pn += 2 * CROW; pt += 2 * CROW;
-					}
-					if (k < nl) pt[3] = row_step(rvA, nA, tA);
-				}
-				for (int k = nl; k < cnt; k++)
-				{
-					float *rp = scr + (size_t)(start + k) * CROW;
-					rp[11] = row_step(rp[lane_off], rp[4 + c], *reinterpret_cast<const float4 *>(rp + 8));
-				}
+				// RemoveBias (physics.h:288): lane 3 switches to the ts_post slot
+				if (FIRST || sums_lds) quad_chain_run(qb, scr + (size_t)start * CREC, S.csum + start, cnt, c, tsoff);
+				else quad_chain_run(qb, scr + (size_t)start * CREC, gsum + start, cnt, c, tsoff);
 				if (c < 3) { lin_w[4 * body + c] = qb.l; ang_w[4 * body + c] = qb.av; }
 			}
 		}
@@ -709,12 +704,12 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		{
 			struct lset { unsigned e; int meta; float rv, n0, n1, n2, Ix, Iy, Iz, minv; float4 s0, s1, s2; float e0, e1, e2, i0, i1, i2; };
 			auto entry = [&](int L) -> unsigned {
-				if (L > nlev_lin) return S.lorder[MAXL2 / 3];
+				if (L > nlev_lin) return S.lorder[S.LIDLE];
 				int lo, hi;
 				if (L < 63) { lo = __builtin_amdgcn_readlane(ls_lin, L); hi = __builtin_amdgcn_readlane(ls_lin, L + 1); }
 				else { lo = S.lstart[L]; hi = S.lstart[L + 1]; }
 				const int idx = lo + pslot;
-				return S.lorder[idx < hi ? idx : MAXL2 / 3];
+				return S.lorder[idx < hi ? idx : S.LIDLE];
 			};
 			auto fetch = [&](lset &r, unsigned e) {
 				r.e = e;
@@ -868,7 +863,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 
 	if (stats && lane == 0)
 	{
-		float *o = scr + (size_t)(a.scratch_stride - 1) * CROW;
+		float *o = scr + (size_t)(a.scratch_stride - 1) * CREC;
 		int mc = 0; for (int k = 0; k < nb; k++) if (S.ccnt[k] > mc) mc = S.ccnt[k];
 		o[0] += 1.0f; o[1] += (float)cyc_chain; o[2] += (float)cyc_lin; o[3] += (float)cyc_ang; o[4] += (float)(clock64() - t_begin);
 		o[5] += (float)nlev_lin; o[6] += (float)nlev_ang; o[7] += (float)mc; o[8] += (float)n1; o[9] += (float)n2; o[10] += (float)na; o[11] += (float)(t_begin);
@@ -891,5 +886,10 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 
 void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solve_args &a, int B, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_solve, dim3(B), dim3(64), 0, s, M, ph, a);
+	// first build by what the host knows of the launch: the model's joints and the most points a frame of this call can carry
+	const int pts = M.pts_bound > 0 ? M.pts_bound : HT_MAXPTS;
+	const bool small = 3 * (M.nj + 8) + 3 <= POOL_SMALL / LROW && pts <= 1024;      // room for a few contacts beside the joints, and a 64x64 tile's cloud
+	if (small) hipLaunchKernelGGL((k_solve<POOL_SMALL, SUMS_SMALL, true>), dim3(B), dim3(64), 0, s, M, ph, a);
+	else hipLaunchKernelGGL((k_solve<POOL_MID, SUMS_MID, true>), dim3(B), dim3(64), 0, s, M, ph, a);
+	hipLaunchKernelGGL((k_solve<POOL_LARGE, SUMS_LARGE, false>), dim3(B), dim3(64), 0, s, M, ph, a);
 }

@@ -156,10 +156,12 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 	const float minv = M.ub_massinv;
 	const m3 tinv = GM(M.ub_tinv);
 	const m3 Iinv = world_inertia(ubq, tinv, minv);
-	(void)scratch; (void)scratch_stride;
-	__shared__ __attribute__((aligned(16))) float urow[HT_MAXPTS / 4 + 6][12];  // rows of this solve (every 4th of <= 4096 points) + read-ahead slack
+	// rows of this solve (every 4th of <= 4096 points): re-expressed on the proxy body and pre-computed into the frame's record stream (handtrack.h:457-462)
+	float *const urow = scratch + (size_t)b * scratch_stride * CREC;
+	__shared__ float usum[HT_MAXPTS / 4 + QUAD_CHAIN_SLACK];      // impulse sums of the rows
 	const int nr = n < HT_MAXPTS / 4 ? n : HT_MAXPTS / 4;
-	for (int i = lane; i < nr; i += 64)     // re-express every cloud row on the proxy body and pre-compute (handtrack.h:457-462)
+	for (int i = lane; i < nr + QUAD_CHAIN_SLACK; i += 64) usum[i] = 0.0f;
+	for (int i = lane; i < nr; i += 64)
 	{
 		const float *r = rows + ((size_t)b * HT_MAXPTS + i) * HT_ROW;
 		const int rb1 = (int)r[1];
@@ -168,12 +170,9 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 		const v3 r1 = qrot(ubq, p1);
 		const float impulsed = minv + dot(cross(mul(Iinv, cross(r1, nrm)), r1), nrm);
 		const float ts = r[11] / dt;
-		float4 *o = reinterpret_cast<float4 *>(&urow[i][0]);      // record layout of k_solve's chains: r1 ts | n ts_post | fmin*dt fmax*dt effmass sum
-		o[0] = make_float4(r1.x, r1.y, r1.z, ts);
-		o[1] = make_float4(nrm.x, nrm.y, nrm.z, fmin_std(ts, r[12]));
-		o[2] = make_float4(r[13] * dt, r[14] * dt, impulsed, 0.0f);
+		quad_write_record(urow + (size_t)i * CREC, r1, nrm, ts, fmin_std(ts, r[12]), impulsed, r[13] * dt, r[14] * dt);
 	}
-	for (int i = lane; i < 72; i += 64) urow[nr + i / 12][i % 12] = 0.0f;      // the sweep reads up to six records ahead
+	__threadfence_block();
 	__syncthreads();
 	if (lane < 4)       // the proxy body in quad layout (ht_quad.hpp): lane c < 3 owns component c, lane 3 carries the row's target speed
 	{
@@ -185,32 +184,8 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 		const int total = ph.iterations + ph.iterations_post;
 		for (int sweep = 0; sweep < total; sweep++)
 		{
-			const int tsoff = sweep >= ph.iterations ? 1 : 0;        // RemoveBias: lane 3 switches to ts_post
-			const float *pv = &urow[0][0] + (c < 3 ? c : 3 + 4 * tsoff), *pnm = &urow[0][0] + 4 + c;
-			float *pt = &urow[0][0] + 8;
-			// as k_solve's chains: two register sets, records fetched two rows ahead, four rows per trip
-			float rvA = pv[0], nA = pnm[0]; float4 tA = *reinterpret_cast<const float4 *>(pt);
-			float rvB = pv[12], nB = pnm[12]; float4 tB = *reinterpret_cast<const float4 *>(pt + 12);
-			int k = 0;
-			for (; k + 4 <= nr; k += 4)
-			{
-				pt[3] = quad_row_step(qb, rvA, nA, tA);
-				rvA = pv[24]; nA = pnm[24]; tA = *reinterpret_cast<const float4 *>(pt + 24);
-				pt[15] = quad_row_step(qb, rvB, nB, tB);
-				rvB = pv[36]; nB = pnm[36]; tB = *reinterpret_cast<const float4 *>(pt + 36);
-				pt[27] = quad_row_step(qb, rvA, nA, tA);
-				rvA = pv[48]; nA = pnm[48]; tA = *reinterpret_cast<const float4 *>(pt + 48);
-				pt[39] = quad_row_step(qb, rvB, nB, tB);
-				rvB = pv[60]; nB = pnm[60]; tB = *reinterpret_cast<const float4 *>(pt + 60);
-				pv += 48; pnm += 48; pt += 48;
-			}
-			for (; k < nr; k++)
-			{
-				pt[3] = quad_row_step(qb, rvA, nA, tA);
-				rvA = rvB; nA = nB; tA = tB;
-				rvB = pv[24]; nB = pnm[24]; tB = *reinterpret_cast<const float4 *>(pt + 24);
-				pv += 12; pnm += 12; pt += 12;
-			}
+			const int tsoff = sweep >= ph.iterations ? 1 : 0;        // RemoveBias: lane 3 switches to the ts_post slot
+			if (nr > 0) quad_chain_run(qb, urow, usum, nr, c, tsoff);
 			if (sweep + 1 == ph.iterations)
 			{
 				const v3 lin = V3(dpp<QP_BC0>(qb.l), dpp<QP_BC1>(qb.l), dpp<QP_BC2>(qb.l)), ang = V3(dpp<QP_BC0>(qb.av), dpp<QP_BC1>(qb.av), dpp<QP_BC2>(qb.av));
