@@ -52,100 +52,138 @@ __device__ __forceinline__ v3 tab_rot(const float *t, v3 v)           // qrot(q,
 }
 __device__ __forceinline__ v3 tab_to_world(const float *t, v3 v) { return tab_pos(t) + tab_rot(t, v); }     // pose * v
 
-// closest(rigidbodies, v): physmodel.h:137-162.  `active` lanes carry a point; loops are wave-uniform.
-__device__ __forceinline__ void closest_feature(const ht_model_dev &M, const float *tab, bool active, v3 v, int &rbmin, v4 &pmin, float &dmin)
+// ---- closest(rigidbodies, v), physmodel.h:137-162, for a chunk of CH points at a time ---------------------------------------------------
+// The reference walks the bodies twice per point: first the inner-sphere planes (cheap), then, for every body whose outer sphere is not
+// farther than the best distance so far, the body's most-above face plane (92 dot products), keeping the minimum in body order.
+// Here the expensive part, "which face plane of body b is point p most above" -- a pure function of (p, b) -- is evaluated for all
+// candidate pairs of the chunk at once, FOUR LANES PER PAIR (each scans every fourth plane, the four partial first-maxima are merged in
+// index order through DPP), and the order-dependent part (which bodies are considered, which minimum wins) is replayed per point
+// afterwards exactly as the reference does it.  Candidates = bodies whose outer sphere passes the test against the best inner-sphere
+// distance: a superset of what the reference considers (its bound only shrinks while it walks), so the replay, which applies the
+// reference's own test with the running minimum, skips exactly the bodies the reference skips.
+#define CH 128                     // points per chunk (lane-per-point phases use the first CH threads of the block)
+#define PAIR_WIN 1024              // (point, body) pairs processed per window
+struct closest_lds
 {
-	pmin = V4(0, 0, 0, FLT_MAX);
-	dmin = dot_plane(pmin, v);
-	rbmin = -1;
-	for (int b = 0; b < M.nb; b++)
+	float4 v[CH];                                  // the chunk's points
+	unsigned mask[CH];                             // candidate bodies of each point
+	int poff[CH + 1];                              // exclusive prefix of the candidate counts
+	unsigned short pair[PAIR_WIN];                 // window of the pair list: point | body << 8
+	unsigned char face[CH][HT_MAXNB];              // most-above face of body b for point p
+	int wsum[8];
+};
+// inner-sphere plane of body t for point v (physmodel.h:141-142) and the outer-sphere bound of the second loop (:153)
+__device__ __forceinline__ v4 inner_plane(const float *t, v3 v) { const v3 n = safenormalize(v - tab_pos(t)); return V4(n, -dot(tab_pos(t), n) - t[8]); }
+__device__ __forceinline__ float outer_bound(const float *t, v3 v) { return length(v - tab_pos(t)) - t[7]; }
+
+// All threads of the block call this.  Thread t < CH carries point `v` (active or not); on return rbmin / pmin / dmin are the reference's result.
+template <int NT>
+__device__ __forceinline__ void closest_chunk(const ht_model_dev &M, const float *tab, closest_lds &L, bool active, v3 v, int &rbmin, v4 &pmin, float &dmin)
+{
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	// ---- A: inner-sphere walk, candidate mask ----
+	pmin = V4(0, 0, 0, FLT_MAX); dmin = dot_plane(pmin, v); rbmin = -1;
+	unsigned mask = 0;
+	if (t < CH)
 	{
-		const float *t = tab + b * BT;
-		v3 n = safenormalize(v - tab_pos(t));
-		v4 p = V4(n, -dot(tab_pos(t), n) - t[8]);
-		float d = dot_plane(p, v);
-		if (d < dmin) { pmin = p; dmin = d; rbmin = b; }
-	}
-	for (int b = 0; b < M.nb; b++)
-	{
-		const float *t = tab + b * BT;
-		bool consider = active && !(length(v - tab_pos(t)) - t[7] > dmin);
-		if (!__any(consider)) continue;
-		v3 vl = tab_to_local(t, v);
-		const float4 *pl = s_planes + M.plane_off[b];
-		const int np = M.plane_off[b + 1] - M.plane_off[b];
-		float best = 0.0f; int bi = 0;
-		// planes are read from the LDS copy (uniform address: one broadcast read per plane); 8 are requested per group so that one wait covers 8 planes
-		for (int i0 = 0; i0 < np; i0 += 8)
+		for (int b = 0; b < M.nb; b++)
 		{
-			float4 q[8];
-#pragma unroll
-			for (int k = 0; k < 8; k++) q[k] = pl[min(i0 + k, np - 1)];
-#pragma unroll
-			for (int k = 0; k < 8; k++)
-			{
-				const int i = i0 + k;
-				float d = dot_plane(V4(q[k].x, q[k].y, q[k].z, q[k].w), vl);
-				if (i < np && (i == 0 || best < d)) { best = d; bi = i; }       // std::max_element: first maximum
-			}
+			const v4 p = inner_plane(tab + b * BT, v);
+			const float d = dot_plane(p, v);
+			if (d < dmin) { pmin = p; dmin = d; rbmin = b; }
 		}
-		if (consider)
+		if (active) for (int b = 0; b < M.nb; b++) if (!(outer_bound(tab + b * BT, v) > dmin)) mask |= 1u << b;
+		L.v[t] = make_float4(v.x, v.y, v.z, 0.0f);
+		L.mask[t] = mask;
+	}
+	// exclusive prefix of the candidate counts over the chunk (CH = 2 waves)
+	int cnt = __popc(mask), incl = cnt;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+	if (lane == 63 && wave < 8) L.wsum[wave] = incl;
+	__syncthreads();
+	int base = 0;
+	for (int w = 0; w < wave; w++) base += L.wsum[w];
+	if (t < CH) L.poff[t] = base + incl - cnt;
+	if (t == CH - 1) L.poff[CH] = base + incl;
+	__syncthreads();
+	const int total = L.poff[CH];
+	// ---- B: most-above face of every candidate pair, four lanes per pair ----
+	for (int w0 = 0; w0 < total; w0 += PAIR_WIN)
+	{
+		if (t < CH)      // this point's pairs that fall into the window
 		{
-			float4 q = pl[bi];
-			v3 n = tab_rot(t, V3(q.x, q.y, q.z));               // Pose::TransformPlane geometric.h:124
-			v4 p = V4(n, q.w - dot(tab_pos(t), n));
-			float d = dot_plane(p, v);
+			int k = L.poff[t];
+			unsigned m = mask;
+			while (m) { const int b = __ffs(m) - 1; m &= m - 1; if (k >= w0 && k < w0 + PAIR_WIN) L.pair[k - w0] = (unsigned short)(t | (b << 8)); k++; }
+		}
+		__syncthreads();
+		const int nwin = min(PAIR_WIN, total - w0);
+		const int g = lane & 3;
+		for (int q0 = wave * 16; q0 < nwin; q0 += (NT / 64) * 16)
+		{
+			const int q = q0 + (lane >> 2);
+			const bool on = q < nwin;
+			const unsigned e = on ? L.pair[q] : 0;
+			const int pt = e & 255, b = e >> 8;
+			const float4 pv = L.v[pt];
+			const v3 vl = tab_to_local(tab + b * BT, V3(pv.x, pv.y, pv.z));
+			const float4 *pl = s_planes + M.plane_off[b];
+			const int np = on ? M.plane_off[b + 1] - M.plane_off[b] : 0;
+			const unsigned long long live = __ballot(on);
+			int npmax = 0;
+			for (int bb = 0; bb < M.nb; bb++) npmax = max(npmax, M.plane_off[bb + 1] - M.plane_off[bb]);      // scalar: the model's largest face count
+			float best = 0.0f; int bi = -1;
+			for (int i = g; i < npmax; i += 4)
+			{
+				const float4 f = pl[i < np ? i : 0];
+				const float d = dot_plane(V4(f.x, f.y, f.z, f.w), vl);
+				if (i < np && (bi < 0 || best < d)) { best = d; bi = i; }       // std::max_element: the first maximum of this lane's faces
+			}
+			(void)live;
+			// merge the four partial results: larger value wins, equal values keep the lower index (the first maximum overall)
+#pragma unroll
+			for (int o = 1; o <= 2; o <<= 1)
+			{
+				const float ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+				const bool take = oi >= 0 && (bi < 0 || best < ob || (best == ob && oi < bi));
+				if (take) { best = ob; bi = oi; }
+			}
+			if (on && g == 0) L.face[pt][b] = (unsigned char)bi;
+		}
+		__syncthreads();
+	}
+	// ---- C: the reference's second walk (physmodel.h:151-160) with the faces found above ----
+	if (t < CH && active)
+	{
+		for (int b = 0; b < M.nb; b++)
+		{
+			if (!((mask >> b) & 1u)) continue;
+			const float *tb = tab + b * BT;
+			if (outer_bound(tb, v) > dmin) continue;
+			const float4 f = s_planes[M.plane_off[b] + L.face[t][b]];
+			const v3 n = tab_rot(tb, V3(f.x, f.y, f.z));               // Pose::TransformPlane geometric.h:124
+			const v4 p = V4(n, f.w - dot(tab_pos(tb), n));
+			const float d = dot_plane(p, v);
 			if (d < dmin) { pmin = p; dmin = d; rbmin = b; }
 		}
 	}
+	__syncthreads();      // the chunk's LDS is free for the next one
 }
 
 // ------------------------------------------------------------------------------------------------- k_cloud_rows
 // mode 0: forcelimit (-1,1) (CloudConstraints as is)     1: FitPointCloud scaling (physmodel.h:347)
 //      2: MultiStepSim scaling (handtrack.h:656,681)     3: UnibodyFit scaling (handtrack.h:461)     4: slowfit scaling (handtrack.h:815-816)
-// One block per frame.  Points are first binned by the body the cheap sphere test of physmodel.h:140-147 prefers, so that the 64 points
-// a wave then works on sit on the same part of the hand and cull the same bodies: the plane loops below are wave-uniform and run for a
-// body as soon as one lane needs it.  The grouping changes which bodies a wave evaluates, never a point's result.
+// One block per frame, CH points per pass: closest feature as above, then ConvexHitCheck (geometric.h:275-297) of the chosen body, one lane per
+// point with the body's faces read per lane from the LDS copy (the clipping of a segment is sequential in the faces; points are independent).
 #define CR_THREADS 256
-// Bins the `nsub` points (every `stride`-th of the frame's cloud) by the body the inner-sphere test prefers; perm lists the point
-// indices bin after bin.  Called by all CR_THREADS threads of a block.
-__device__ void bin_points_by_body(const ht_model_dev &M, const float *tab, const float4 *__restrict__ fpts, int nsub, int stride, unsigned short *perm, unsigned char *key, int *bin)
-{
-	const int t = threadIdx.x;
-	if (t < HT_MAXNB) bin[t] = 0;
-	__syncthreads();
-	for (int i = t; i < nsub; i += CR_THREADS)
-	{
-		const float4 pv = fpts[i * stride];
-		const v3 v = V3(pv.x, pv.y, pv.z);
-		float dmin = FLT_MAX; int rb = 0;       // first loop of closest(): nearest body by the inner-sphere plane
-		for (int k = 0; k < M.nb; k++)
-		{
-			const float *tb = tab + k * BT;
-			const v3 nn = safenormalize(v - tab_pos(tb));
-			const float d = dot_plane(V4(nn, -dot(tab_pos(tb), nn) - tb[8]), v);
-			if (d < dmin) { dmin = d; rb = k; }
-		}
-		key[i] = (unsigned char)rb;
-		atomicAdd(&bin[rb], 1);
-	}
-	__syncthreads();
-	if (t == 0) { int acc = 0; for (int k = 0; k < M.nb; k++) { const int c = bin[k]; bin[k] = acc; acc += c; } }
-	__syncthreads();
-	for (int i = t; i < nsub; i += CR_THREADS) perm[atomicAdd(&bin[key[i]], 1)] = (unsigned short)i;
-	__syncthreads();
-}
 __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const float *__restrict__ state, const float4 *__restrict__ pts, const int *__restrict__ npts,
                                                            const float *__restrict__ cams, const int *__restrict__ active_flag, int stride, int use_cam_origin, int mode,
                                                            float microforce, float weak_force, float cf_max_point, float cf_max_sum, float unibody_force,
                                                            float *__restrict__ rows, int *__restrict__ nrows)
 {
 	__shared__ float tab[HT_MAXNB * BT];
-	__shared__ int bin[HT_MAXNB];
-	// per-point sort arrays live in the dynamic segment behind the planes, sized by the launch's point bound (3 B per point)
-	const int cap = M.pts_bound > 0 ? M.pts_bound : HT_MAXPTS;
-	unsigned short *perm = reinterpret_cast<unsigned short *>(s_planes + M.plane_off[M.nb]);
-	unsigned char *key = reinterpret_cast<unsigned char *>(perm + cap);
+	__shared__ closest_lds L;
 	const int b = blockIdx.x, t = threadIdx.x;
 	const int n = npts[b];
 	const int nsub = (n + stride - 1) / stride;
@@ -154,68 +192,63 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 	if (t < 64) body_table_build(M, state + (size_t)b * M.nb * HT_STATE_STRIDE, tab, t);
 	stage_planes(M, t, CR_THREADS);
 	__syncthreads();
-	bin_points_by_body(M, tab, pts + (size_t)b * HT_MAXPTS, nsub, stride, perm, key, bin);
 	const float *cam = cams + (size_t)b * HT_CAM;
 	const v3 origin = use_cam_origin ? V3(cam[5], cam[6], cam[7]) : V3(0, 0, 0);
-	for (int base = 0; base < nsub; base += CR_THREADS)
+	int npmax = 0;
+	for (int bb = 0; bb < M.nb; bb++) npmax = max(npmax, M.plane_off[bb + 1] - M.plane_off[bb]);
+	for (int base = 0; base < nsub; base += CH)
 	{
-	const bool active = base + t < nsub;
-	const int i = active ? perm[base + t] : 0;
-	float4 pv = pts[(size_t)b * HT_MAXPTS + i * stride];
-	const v3 v = V3(pv.x, pv.y, pv.z);
-	int rb; v4 p; float dmin;
-	closest_feature(M, tab, active, v, rb, p, dmin);
-	if (rb < 0) rb = 0;
-	// ConvexHitCheck from the ray origin, only when the point faces away (physmodel.h:170)
-	const bool want = active && dot(v - origin, xyz(p)) > 0;
-	bool hit = false; v3 impact = V3(0, 0, 0);
-	for (int bb = 0; bb < M.nb; bb++)
-	{
-		bool mine = want && rb == bb;
-		if (!__any(mine)) continue;
-		const float *t = tab + bb * BT;
-		v3 v0 = tab_to_local(t, origin), v1 = tab_to_local(t, v);
-		const float4 *pl = s_planes + M.plane_off[bb];
-		const int np = M.plane_off[bb + 1] - M.plane_off[bb];
-		bool done = !mine, ok = true;
-		for (int k0 = 0; k0 < np; k0 += 8)
+		const int i = base + t;
+		const bool active = t < CH && i < nsub;
+		const float4 pv = active ? pts[(size_t)b * HT_MAXPTS + i * stride] : make_float4(0, 0, 0, 0);
+		const v3 v = V3(pv.x, pv.y, pv.z);
+		int rb; v4 p; float dmin;
+		closest_chunk<CR_THREADS>(M, tab, L, active, v, rb, p, dmin);
+		if (t >= CH) continue;                     // the other waves only help with the pair scans
+		if (rb < 0) rb = 0;
+		// ConvexHitCheck from the ray origin, only when the point faces away (physmodel.h:170)
+		const bool want = active && dot(v - origin, xyz(p)) > 0;
+		bool hit = false; v3 impact = V3(0, 0, 0);
+		if (__any(want))
 		{
-			float4 qq[8];
-#pragma unroll
-			for (int k = 0; k < 8; k++) qq[k] = pl[min(k0 + k, np - 1)];
-#pragma unroll
-			for (int k = 0; k < 8; k++)
+			const float *tr = tab + rb * BT;
+			v3 v0 = tab_to_local(tr, origin), v1 = tab_to_local(tr, v);
+			const float4 *pl = s_planes + M.plane_off[rb];
+			const int np = M.plane_off[rb + 1] - M.plane_off[rb];
+			bool done = !want, ok = true;
+			for (int k = 0; k < npmax; k++)
 			{
-				v4 plane = V4(qq[k].x, qq[k].y, qq[k].z, qq[k].w);
-				float d0 = dot_plane(plane, v0), d1 = dot_plane(plane, v1);
-				const bool live = !done && k0 + k < np;
+				const float4 f = pl[k < np ? k : 0];
+				const v4 plane = V4(f.x, f.y, f.z, f.w);
+				const float d0 = dot_plane(plane, v0), d1 = dot_plane(plane, v1);
+				const bool live = !done && k < np;
 				if (live && d0 >= 0 && d1 >= 0) { ok = false; done = true; }
 				const bool clip = live && !done && !(d0 <= 0 && d1 <= 0);
-				if (__any(clip))      // the three divisions are only issued when some lane's segment really straddles this plane
+				if (__any(clip))      // the three divisions are only issued when some lane's segment really straddles this face
 				{
-					v3 c = v0 + ((v1 - v0) * d0) / (d0 - d1);
+					const v3 c = v0 + ((v1 - v0) * d0) / (d0 - d1);
 					if (clip) { if (d0 >= 0) v0 = c; else v1 = c; }
 				}
+				if (!__any(!done)) break;
 			}
+			if (want && ok) { hit = true; impact = tab_to_world(tr, v0); }
 		}
-		if (mine && ok) { hit = true; impact = tab_to_world(t, v0); }
-	}
-	if (!active) continue;
-	const float *tr = tab + rb * BT;
-	v3 position1, normal;
-	if (hit) { position1 = tab_to_local(tr, impact); normal = normalize(v - origin); }
-	else { position1 = tab_to_local(tr, v - xyz(p) * dot_plane(p, v)); normal = xyz(p); }
-	const float targetdist = dot(tab_to_world(tr, position1) - v, normal);                  // ConstrainAlongDirection physics.h:328-331
-	float fmin = -1.0f, fmax = 1.0f;
-	if (mode == 1) { float k = (rb == 0 || rb == 1 || rb == 2) ? weak_force : 1.0f; fmin = -1.0f * k * microforce; fmax = 1.0f * k * microforce; }
-	else if (mode == 2) { float cloudforce = fmin_std(cf_max_point, cf_max_sum / (float)n); float k = (rb == 0) ? 0.1f : 1.0f; fmin = -cloudforce * k; fmax = cloudforce * k; }
-	else if (mode == 3) { fmin = -1.0f * unibody_force; fmax = 1.0f * unibody_force; }
-	else if (mode == 4) { const float k = (microforce * weak_force) * ((rb == 0) ? cf_max_point : 1.0f); fmin = -1.0f * k; fmax = 1.0f * k; }      // slowfit handtrack.h:815-816: weak_force = step ratio, cf_max_point = wrist factor
-	float4 *out = reinterpret_cast<float4 *>(rows + ((size_t)b * HT_MAXPTS + i) * HT_ROW);
-	out[0] = make_float4(-1.0f, (float)rb, v.x, v.y);
-	out[1] = make_float4(v.z, position1.x, position1.y, position1.z);
-	out[2] = make_float4(normal.x, normal.y, normal.z, targetdist);
-	out[3] = make_float4(0.0f, fmin_std(fmin, fmax), fmax_std(fmin, fmax), 0.0f);
+		if (!active) continue;
+		const float *tr = tab + rb * BT;
+		v3 position1, normal;
+		if (hit) { position1 = tab_to_local(tr, impact); normal = normalize(v - origin); }
+		else { position1 = tab_to_local(tr, v - xyz(p) * dot_plane(p, v)); normal = xyz(p); }
+		const float targetdist = dot(tab_to_world(tr, position1) - v, normal);                  // ConstrainAlongDirection physics.h:328-331
+		float fmin = -1.0f, fmax = 1.0f;
+		if (mode == 1) { float k = (rb == 0 || rb == 1 || rb == 2) ? weak_force : 1.0f; fmin = -1.0f * k * microforce; fmax = 1.0f * k * microforce; }
+		else if (mode == 2) { float cloudforce = fmin_std(cf_max_point, cf_max_sum / (float)n); float k = (rb == 0) ? 0.1f : 1.0f; fmin = -cloudforce * k; fmax = cloudforce * k; }
+		else if (mode == 3) { fmin = -1.0f * unibody_force; fmax = 1.0f * unibody_force; }
+		else if (mode == 4) { const float k = (microforce * weak_force) * ((rb == 0) ? cf_max_point : 1.0f); fmin = -1.0f * k; fmax = 1.0f * k; }      // slowfit handtrack.h:815-816: weak_force = step ratio, cf_max_point = wrist factor
+		float4 *out = reinterpret_cast<float4 *>(rows + ((size_t)b * HT_MAXPTS + i) * HT_ROW);
+		out[0] = make_float4(-1.0f, (float)rb, v.x, v.y);
+		out[1] = make_float4(v.z, position1.x, position1.y, position1.z);
+		out[2] = make_float4(normal.x, normal.y, normal.z, targetdist);
+		out[3] = make_float4(0.0f, fmin_std(fmin, fmax), fmax_std(fmin, fmax), 0.0f);
 	}
 }
 
@@ -224,6 +257,7 @@ __global__ __launch_bounds__(256) void k_fit_error(ht_model_dev M, const float *
                                                   const uint16_t *__restrict__ depth, const float *__restrict__ cams, int w, int h, float bone_sum_error_scale, float *__restrict__ err)
 {
 	__shared__ float tab[HT_MAXNB * BT];
+	__shared__ closest_lds L;
 	__shared__ int perr[HT_MAXNB];
 	const int b = blockIdx.x, t = threadIdx.x;
 	if (t < 64) body_table_build(M, state + (size_t)b * M.nb * HT_STATE_STRIDE, tab, t);
@@ -231,13 +265,13 @@ __global__ __launch_bounds__(256) void k_fit_error(ht_model_dev M, const float *
 	stage_planes(M, t, 256);
 	__syncthreads();
 	const int n = npts[b];
-	for (int base = 0; base < n; base += 256)
+	for (int base = 0; base < n; base += CH)
 	{
 		const int i = base + t;
-		const bool active = i < n;
-		float4 pv = pts[(size_t)b * HT_MAXPTS + (active ? i : 0)];
+		const bool active = t < CH && i < n;
+		const float4 pv = active ? pts[(size_t)b * HT_MAXPTS + i] : make_float4(0, 0, 0, 0);
 		int rb; v4 p; float dmin;
-		closest_feature(M, tab, active, V3(pv.x, pv.y, pv.z), rb, p, dmin);
+		closest_chunk<256>(M, tab, L, active, V3(pv.x, pv.y, pv.z), rb, p, dmin);
 		// pointerror[bone] = max(pointerror[bone], d) with pointerror starting at 0 (handtrack.h:376-383): only d > 0 matters,
 		// and for non-negative floats the integer order of the bit patterns is the float order
 		if (active && rb >= 0 && dmin > 0.0f) atomicMax(&perr[rb], __float_as_int(dmin));
@@ -319,8 +353,7 @@ __global__ __launch_bounds__(64) void k_chamber(ht_model_dev M, const float *__r
 void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const float *cams, const int *active_flag, int stride, int use_cam_origin, int mode,
                           const ht_params &par, float *rows, int *nrows, int B, hipStream_t s, float sf_ratio, float sf_wrist)
 {
-	const size_t cap = M.pts_bound > 0 ? (size_t)M.pts_bound : (size_t)HT_MAXPTS;
-	hipLaunchKernelGGL(k_cloud_rows, dim3(B), dim3(CR_THREADS), (size_t)M.plane_off[M.nb] * sizeof(float4) + ((cap * 3 + 15) & ~(size_t)15), s, M, state, pts, npts, cams, active_flag, stride, use_cam_origin, mode, par.microforce,
+	hipLaunchKernelGGL(k_cloud_rows, dim3(B), dim3(CR_THREADS), (size_t)M.plane_off[M.nb] * sizeof(float4), s, M, state, pts, npts, cams, active_flag, stride, use_cam_origin, mode, par.microforce,
 	                   mode == 4 ? sf_ratio : par.physics_weak_force, mode == 4 ? sf_wrist : par.cloudforce_max_point, par.cloudforce_max_sum, par.unibody_force, rows, nrows);
 }
 void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, int w, int h, float scale, float *err, int B, hipStream_t s)
