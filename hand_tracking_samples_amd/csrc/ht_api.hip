@@ -99,6 +99,21 @@ static int load_model(ht_ctx *ctx, const char *path)
 		m.ignore[b] = mask;
 	}
 	m.vert_off[nb] = (int)verts.size(); m.plane_off[nb] = (int)planes.size();
+	// HandModelEnhancements' one-time rewrite (handtrack.h:408-416): a model whose bone 2 (the thumb base) ignores fewer than 10 bodies gets that
+	// bone out of every collision pair.  The reference does it on the first call, which precedes every solve with collisions (:684-685, :773-779,
+	// :798), so doing it at load gives the same pairs.  The list length counts duplicates there; a baked file without "ignore_count" falls back
+	// to the number of distinct bodies.
+	if (nb > 2)
+	{
+		auto itc = fx.find("ignore_count");
+		int n2 = 0;
+		if (itc != fx.end()) n2 = itc->second.i()[2]; else for (int j = 0; j < nb; j++) n2 += (m.ignore[2] >> j) & 1u;
+		if (n2 < 10)
+		{
+			m.ignore[2] = 0;
+			for (int j = 0; j < nb; j++) if (j != 2) { m.ignore[2] |= 1u << j; m.ignore[j] |= 1u << 2; }
+		}
+	}
 	for (int j = 0; j < nj; j++)
 	{
 		float *c = &jointc[(size_t)j * HT_JC]; const float *r = jf->f() + 16 * j;

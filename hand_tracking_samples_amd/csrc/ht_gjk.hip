@@ -600,6 +600,7 @@ template <int GJK_WPF> __global__ __launch_bounds__(64 * GJK_FRAMES * GJK_WPF) v
 			const v3 n = jig ? hits[0].normal : V3(0, 0, 1);
 			v4 qs = quat_from_to(n, V3(0, 0, 1));
 			v3 tangent = qxdir(qs), bitangent = qydir(qs);
+#pragma unroll 1
 			for (int r = 0; r < 4; r++)
 			{
 				const v3 raxis = r == 0 ? tangent : r == 1 ? bitangent : r == 2 ? -tangent : -bitangent;

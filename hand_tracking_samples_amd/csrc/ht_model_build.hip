@@ -626,17 +626,19 @@ bool ht_build_model(const char *json_path, int flags, fx_map &out, std::string &
 
 	out.clear();
 	out["nb"] = fx_i32({ nb }, { 1 }); out["nj"] = fx_i32({ nj }, { 1 });
-	std::vector<float> bf, rest; std::vector<int> collide, ign((size_t)nb * nb, 0), nverts, nplanes;
+	std::vector<float> bf, rest; std::vector<int> collide, ign((size_t)nb * nb, 0), nverts, nplanes, igncount;
 	for (int i = 0; i < nb; i++)
 	{
 		const body &b = bodies[i];
 		put_body(out, i, b, bf);
 		collide.push_back(b.collide); nverts.push_back((int)b.verts.size()); nplanes.push_back((int)b.planes.size());
 		for (int k : b.ignore) ign[(size_t)i * nb + k] = 1;
+		igncount.push_back((int)b.ignore.size());      // entries incl. duplicates: what `ignore.size()` reads in handtrack.h:408
 		float st[13] = { b.position.x, b.position.y, b.position.z, b.orientation.x, b.orientation.y, b.orientation.z, b.orientation.w, 0, 0, 0, 0, 0, 0 };
 		rest.insert(rest.end(), st, st + 13);
 	}
 	out["body_f"] = fx_f32(bf, { (uint32_t)nb, 26 }); out["body_collide"] = fx_i32(collide, { (uint32_t)nb }); out["ignore"] = fx_i32(ign, { (uint32_t)nb, (uint32_t)nb });
+	out["ignore_count"] = fx_i32(igncount, { (uint32_t)nb });
 	out["nverts"] = fx_i32(nverts, { (uint32_t)nb }); out["nplanes"] = fx_i32(nplanes, { (uint32_t)nb });
 	out["rest_state"] = fx_f32(rest, { (uint32_t)nb, 13 });
 	std::vector<int> ji; std::vector<float> jf;

@@ -92,6 +92,16 @@ static int load_model(const fx_file *f, ho_model *m)
 		rb->shape.nplanes = (int)e->dims[0]; rb->shape.planes = malloc(e->nbytes); memcpy(rb->shape.planes, e->data, e->nbytes);
 		for (int j = 0; j < m->nb; j++) m->ignore[b][j] = (unsigned char)ig[b * m->nb + j];
 	}
+	/* HandModelEnhancements' one-time rewrite, handtrack.h:408-416: if bone 2's ignore list has fewer than 10 entries, bone 2 leaves every
+	 * collision pair.  It happens on the first call, which precedes every solve with collisions, so it is applied at load.  The list length counts
+	 * duplicates in the reference ("ignore_count" of models our builder bakes); files dumped from the reference carry the matrix only. */
+	if (m->nb > 2)
+	{
+		int n2 = 0;
+		const fx_entry *ic = fx_get(f, "ignore_count");
+		if (ic) n2 = ((const int*)ic->data)[2]; else for (int j = 0; j < m->nb; j++) n2 += m->ignore[2][j] != 0;
+		if (n2 < 10) for (int j = 0; j < m->nb; j++) { m->ignore[2][j] = (unsigned char)(j != 2); if (j != 2) m->ignore[j][2] = 1; }
+	}
 	const int *ji = (const int*)fx_get(f, "joint_i")->data; const float *jf = (const float*)fx_get(f, "joint_f")->data;
 	for (int j = 0; j < m->nj; j++)
 	{
@@ -352,7 +362,7 @@ int ho_joint_angulars(ho_tracker *t, ho_model *m, ho_angular *out)   /* physmode
 	return k;
 }
 /* HandModelEnhancements handtrack.h:406-441.  acos()/cos() there are the C double overloads.
- * The ignore-list rewrite at :408-416 is not restated: with the stock model bone 2 already ignores 16 bodies. */
+ * The ignore-list rewrite at :408-416 is applied when the model is loaded (see there). */
 void ho_enhancements(ho_tracker *t, ho_model *m, ho_angular *ang, int *nang, int tiepinkyringmid, f3 palmxdir, f3 armdir, int fingerhold)
 {
 	ho_body *B[HO_MAXB]; model_ptrs(m, B);

@@ -144,3 +144,45 @@ def test_frames_of_a_batch_do_not_interact(ctx):
         ctx.tracker_reset(start[k:k + 1])
         alone = ctx.update_sync(depth[k:k + 1], cams[k:k + 1])
         assert np.array_equal(alone[0], together[k])
+
+
+def test_thumb_base_ignore_rewrite(weights, tmp_path):
+    """HandModelEnhancements' one-time rewrite (handtrack.h:408-416): a model whose bone 2 ignores fewer than 10 bodies gets bone 2 out of every
+    collision pair.  The stock hand never triggers it (12 distinct bodies), so the baked model is doctored: bone 2 keeps only its joint neighbours.
+    Device and C restatement must agree on the contacts of a fist pose, and bone 2 must appear in none of them."""
+    import htfx
+    from hand_tracking_samples_amd import native
+    sys_path = os.path.join(HERE, "..")
+    import sys
+    sys.path.insert(0, sys_path)
+    from bench import _write_htfx
+    m = htfx.load(ol.MODEL)
+    ign = m["ignore"].copy()
+    for j in range(17):
+        if j not in (1, 3):
+            ign[2, j] = 0; ign[j, 2] = 0
+    assert ign[2].sum() == 2
+    m2 = dict(m); m2["ignore"] = ign
+    path = str(tmp_path / "hand_few_ignores.htfx")
+    _write_htfx(path, m2)
+    g = htfx.load(os.path.join(HERE, "golden", "golden8.htfx"))
+    start = np.stack([g["f%d/startpose" % f] for f in range(8)])
+    ctx = native.Context(path, 8)
+    try:
+        ctx.tracker_reset(start)
+        c, n = ctx.stage_contacts(0, 8)
+    finally:
+        ctx.close()
+    orc = ol.Oracle(weights, model=path)
+    total = 0
+    for f in range(8):
+        orc.reset(start[f])
+        buf = (ol.Contact * 96)()
+        k = orc.L.ho_find_contacts(orc.h, orc.model(0), buf, 96)
+        assert k == n[f], "frame %d: %d contacts on the device, %d in the restatement" % (f, n[f], k)
+        for i in range(k):
+            assert (int(c[f, i, 0]), int(c[f, i, 1])) == (buf[i].rb0, buf[i].rb1)
+            assert 2 not in (buf[i].rb0, buf[i].rb1)
+        total += k
+    orc.close()
+    assert total >= 20
