@@ -309,19 +309,32 @@ __global__ __launch_bounds__(64) void k_chamber(ht_model_dev M, const float *__r
 	if (lane == 0) nch[b] = on ? 5 * M.nb : 0;
 	if (!on) return;
 	body_table_build(M, state + (size_t)b * M.nb * HT_STATE_STRIDE, tab, lane);
+	// containing_plane (physmodel.h:183-193): a sequential scan of the cloud per direction (the running `best` decides the next comparison).  The five
+	// directions take one lane each; the points reach them through an LDS chunk the whole wave fills with coalesced reads (a lane reading the
+	// points straight from HBM waits a memory round trip per point: 100 us for a 424-point frame).
+	__shared__ float4 chunk[256];
+	const float od[5][3] = { { -1, -0.25f, 0 }, { -1, -1, 0 }, { 0, -1, 0 }, { 1, -1, 0 }, { 1, -0.25f, 0 } };    // handtrack.h:776
+	const int dl = lane < 5 ? lane : 0;
+	const v3 outdir = V3(od[dl][0], od[dl][1], od[dl][2]), origin = V3(0, 0, 0), viewdir = V3(0, 0, 1);
+	v3 best = viewdir - outdir;
+	best = best + origin;
+	const v3 tangent = cross(best, outdir);
+	for (int base = 0; base < n; base += 256)
+	{
+		const int m = min(256, n - base);
+		__syncthreads();
+		for (int i = lane; i < m; i += 64) chunk[i] = pts[(size_t)b * HT_MAXPTS + base + i];
+		__syncthreads();
+		if (lane < 5)
+			for (int i = 0; i < m; i++)
+			{
+				const float4 pv = chunk[i];
+				const v3 p = V3(pv.x, pv.y, pv.z);
+				if (dot(cross(best - origin, p - origin), tangent) > 0) best = p;
+			}
+	}
 	if (lane < 5)
 	{
-		const float od[5][3] = { { -1, -0.25f, 0 }, { -1, -1, 0 }, { 0, -1, 0 }, { 1, -1, 0 }, { 1, -0.25f, 0 } };    // handtrack.h:776
-		const v3 outdir = V3(od[lane][0], od[lane][1], od[lane][2]), origin = V3(0, 0, 0), viewdir = V3(0, 0, 1);
-		v3 best = viewdir - outdir;
-		best = best + origin;
-		v3 tangent = cross(best, outdir);
-		for (int i = 0; i < n; i++)
-		{
-			float4 pv = pts[(size_t)b * HT_MAXPTS + i];
-			v3 p = V3(pv.x, pv.y, pv.z);
-			if (dot(cross(best - origin, p - origin), tangent) > 0) best = p;
-		}
 		v3 nn = normalize(cross(tangent, best));
 		planes[lane][0] = nn.x; planes[lane][1] = nn.y; planes[lane][2] = nn.z; planes[lane][3] = -dot(nn, origin);
 	}

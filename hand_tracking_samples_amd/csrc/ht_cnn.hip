@@ -5,7 +5,7 @@
 // extraction of misc_image.h:409-417 / physmodel.h:58-64 (both read the same depth tile, so one kernel does both).
 //
 //   k_prepare   u16 depth tile -> fp32 CNN input + order-preserving compacted point cloud  (HBM-bound, 8 KB in / 16 KB out per frame)
-//   k_conv1     5x5x1->16 valid conv + 4x4 max-pool + tanh, input tile staged in LDS, fp32 VALU in the reference's tap order
+//   k_conv1     5x5x1->16 valid conv + 4x4 max-pool + tanh as an implicit GEMM on v_mfma_f32_16x16x4_f32 (one pooling window = one 16-row tile), input rows staged in LDS
 //   k_conv2     4x4x16->64 valid conv as an implicit GEMM on v_mfma_f32_16x16x4_f32, + 2x2 max-pool + tanh
 //   k_fc        [B,K]x[K,N]+bias (+tanh) on v_mfma_f32_32x32x2_f32, 128x64 block tile on 8 waves, double-buffered LDS, register prefetch
 //   k_softmax_decode   chunked softmax (cnn.h:497-511) fused with the heat-map decode (handtrack.h:218-241)
@@ -119,68 +119,70 @@ __global__ __launch_bounds__(256) void k_prepare_frame(const uint16_t *__restric
 }
 
 // ------------------------------------------------------------------------------------------------- k_conv1
-__device__ __forceinline__ float tanh_ref(float t) { float e = (float)exp((double)(2 * t)); return (e - 1) / (e + 1); }   // cnn.h:31
+// cnn.h:31.  The exponential is formed in double and rounded once (= the reference's expf except in rare half-ulp cases).  A plain float expf is
+// one ulp off now and then; through MultiStepSim's hard-driven steps that doubled the pose deviation of the CNN-accepted frames (2.0e-3 on a
+// quaternion against the 2e-3 tolerance), and it did not make the kernels faster, so the exact form stays.
+__device__ __forceinline__ float tanh_ref(float t) { float e = (float)exp((double)(2 * t)); return (e - 1) / (e + 1); }
 
-// Thread <-> pooled pixel, loops the 16 output channels over an 8x8 register patch.  A block takes PR pooled rows of one frame: the
-// 4*PR + 4 input rows they need are staged in LDS.  64x64 input: IW = 64, PW = 15, PR = 15 (one block per frame, the whole 16 KB tile).
-// 128x128 input (BASELINE configs[4]): IW = 128, PW = 31, PR = 8 -> 4 bands of 36 rows = 18 KB each instead of one 64 KB tile, so several
-// blocks stay resident per CU.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// 5x5x1->16 valid convolution + two 2x2 max-pools + tanh as an implicit GEMM on v_mfma_f32_16x16x4_f32: M = the 16 pixels of one 4x4 pooling
+// window, N = the 16 output channels, K = the 25 taps (kx fastest, the reference's accumulation order, cnn.h:223-225) padded to 28 with zero weights.
+// A block takes PR pooled rows of one frame; the 4*PR + 4 input rows they need are staged in LDS with a row stride of IW + 4 floats (rows 4 banks
+// apart: the 4x4 pixels a 16-lane group reads fall on 16 different banks, and neighbouring taps re-read the same words, which is a broadcast).
+// The seven weight fragments of a lane stay in registers; per window a wave issues 7 LDS reads and 7 MFMAs, the maximum over the window's 16 rows
+// is four register maxima and two cross-lane steps, and tanh (an exponential in double) is applied once per pooled value by all threads at the end.
+// 64x64 input: IW = 64, PW = 15, PR = 15 (one block per frame).  128x128 input (BASELINE configs[4]): IW = 128, PW = 31, PR = 8 -> 4 bands of
+// 36 rows (19 KB) instead of one 64 KB tile, so several blocks stay resident per CU.
 template <int IW, int PW, int PR>
 __global__ __launch_bounds__(256) void k_conv1(const float *__restrict__ cnn_in, const float *__restrict__ W1, const float *__restrict__ B1, float *__restrict__ act1)
 {
-	constexpr int TR = 4 * PR + 4;                       // input rows a band touches
-	static_assert(PR * PW <= 256 && TR <= IW && (IW % 4) == 0, "band does not fit the block");
-	__shared__ __attribute__((aligned(16))) float tile[TR * IW];
-	const int b = blockIdx.x, band = blockIdx.y, t = threadIdx.x;
+	constexpr int TR = 4 * PR + 4, IWP = IW + 4;         // input rows a band touches, padded row stride
+	static_assert(TR <= IW && (IW % 4) == 0, "band does not fit the image");
+	__shared__ __attribute__((aligned(16))) float tile[TR * IWP];
+	__shared__ float pooled[16 * PR * PW];
+	const int b = blockIdx.x, band = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	const int row0 = 4 * PR * band;
 	const int nrows = min(TR, IW - row0);
+	const int prows = min(PR, PW - PR * band);           // pooled rows this band really has
 	const float4 *src = reinterpret_cast<const float4 *>(cnn_in + (size_t)b * IW * IW + (size_t)row0 * IW);
-	float4 *tl = reinterpret_cast<float4 *>(tile);
-	for (int i = t; i < nrows * IW / 4; i += 256) tl[i] = src[i];
-	__syncthreads();
-	const int px = t % PW, pyl = t / PW, py = PR * band + pyl;
-	if (pyl >= PR || py >= PW) return;
-	float patch[8][8];
+	for (int i = t; i < nrows * IW / 4; i += 256) { const int r = i / (IW / 4), c4 = i % (IW / 4); *reinterpret_cast<float4 *>(tile + r * IWP + 4 * c4) = src[i]; }
+	// this lane's operands: B = weight of (tap k, channel n), A = pixel (py, px) of the window shifted by tap k; k = 4 * step + (lane >> 4)
+	const int n = lane & 15, g = lane >> 4, px = lane & 3, py = (lane >> 2) & 3;
+	float wreg[7]; int aoff[7];
 #pragma unroll
-	for (int r = 0; r < 8; r++)
+	for (int s = 0; s < 7; s++)
 	{
-		float4 a = tl[((4 * pyl + r) * IW + 4 * px) / 4], c = tl[((4 * pyl + r) * IW + 4 * px) / 4 + 1];
-		patch[r][0] = a.x; patch[r][1] = a.y; patch[r][2] = a.z; patch[r][3] = a.w; patch[r][4] = c.x; patch[r][5] = c.y; patch[r][6] = c.z; patch[r][7] = c.w;
+		const int k = 4 * s + g, kk = k < 25 ? k : 24;
+		wreg[s] = k < 25 ? W1[n * 25 + k] : 0.0f;        // W index = kx + 5*(ky + 5*(ic + 1*oc)), cnn.h:45-47,227
+		aoff[s] = (py + kk / 5) * IWP + px + kk % 5;
 	}
-	for (int c = 0; c < 16; c++)
+	const float bias = B1[n];
+	__syncthreads();
+	for (int w = wave; w < prows * PW; w += 4)
 	{
-		float acc[4][4];
-		const float bias = B1[c];
+		const int ty = w / PW, tx = w % PW;
+		const float *base = tile + 4 * ty * IWP + 4 * tx;
+		f32x4 acc = { bias, bias, bias, bias };
 #pragma unroll
-		for (int oy = 0; oy < 4; oy++)
-#pragma unroll
-			for (int ox = 0; ox < 4; ox++) acc[oy][ox] = bias;
-#pragma unroll
-		for (int ky = 0; ky < 5; ky++)
-#pragma unroll
-			for (int kx = 0; kx < 5; kx++)
-			{
-				const float w = W1[c * 25 + ky * 5 + kx];           // W index = kx + 5*(ky + 5*(ic + 1*oc)), cnn.h:45-47,227
-#pragma unroll
-				for (int oy = 0; oy < 4; oy++)
-#pragma unroll
-					for (int ox = 0; ox < 4; ox++) acc[oy][ox] += patch[oy + ky][ox + kx] * w;
-			}
-		// two 2x2 max-pools (cnn.h:141-148) = max over the 4x4 block; std::max(a,b) = (a<b)?b:a
-		float m[2][2];
-#pragma unroll
-		for (int qy = 0; qy < 2; qy++)
-#pragma unroll
-			for (int qx = 0; qx < 2; qx++)
-				m[qy][qx] = fmax_std(fmax_std(fmax_std(acc[2 * qy][2 * qx], acc[2 * qy][2 * qx + 1]), acc[2 * qy + 1][2 * qx]), acc[2 * qy + 1][2 * qx + 1]);
-		float mm = fmax_std(fmax_std(fmax_std(m[0][0], m[0][1]), m[1][0]), m[1][1]);
-		act1[(size_t)b * (16 * PW * PW) + c * (PW * PW) + py * PW + px] = tanh_ref(mm);
+		for (int s = 0; s < 7; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(base[aoff[s]], wreg[s], acc, 0, 0, 0);
+		// C/D map 16x16: col = lane & 15 (channel), row = (lane >> 4) * 4 + r (pixel of the window): two 2x2 max-pools (cnn.h:141-148) = the maximum of the 16 rows
+		float m = fmax_std(fmax_std(fmax_std(acc[0], acc[1]), acc[2]), acc[3]);
+		// across the four 16-lane rows (the window's four image rows): v_permlane16_swap / v_permlane32_swap exchange rows between two copies of m
+		{ const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false); m = fmax_std(__uint_as_float(r[0]), __uint_as_float(r[1])); }
+		{ const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false); m = fmax_std(__uint_as_float(r[0]), __uint_as_float(r[1])); }
+		if (lane < 16) pooled[(n * PR + ty) * PW + tx] = m;
+	}
+	__syncthreads();
+	for (int i = t; i < 16 * prows * PW; i += 256)
+	{
+		const int c = i / (prows * PW), r = i % (prows * PW), ty = r / PW, tx = r % PW;
+		act1[(size_t)b * (16 * PW * PW) + c * (PW * PW) + (PR * band + ty) * PW + tx] = tanh_ref(pooled[(c * PR + ty) * PW + tx]);      // tanh after pooling (monotone)
 	}
 }
 
 // ------------------------------------------------------------------------------------------------- k_conv2
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // W2p: weights repacked to [k][oc] with k = (ky*4+kx)*16 + ic, i.e. the reference's accumulation order (cnn.h:223-225).
 // A block takes BAND output rows of one frame (all 64 output channels, 16 per wave): implicit GEMM M = BAND*OW, N = 64, K = 256.
