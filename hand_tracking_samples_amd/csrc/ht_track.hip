@@ -56,23 +56,31 @@ __global__ __launch_bounds__(64) void k_scratch(ht_model_dev M, float *__restric
 	if (flags && !flags[b]) return;
 	const float *an = analysis + (size_t)b * HT_ANALYSIS;
 	const float *cam = cams + (size_t)b * HT_CAM;
-	if (lane == 0)
 	{
-		// palm ray from the first three landmark rays, inverse-distance weighted centroid of the cloud (sequential sums, handtrack.h:483-490)
-		v4 cs = (G4(an + HT_AN_CRAYS) + G4(an + HT_AN_CRAYS + 4)) + G4(an + HT_AN_CRAYS + 8);
-		v3 palmray = normalize(xyz(cs));
+		// palm ray from the first three landmark rays, inverse-distance weighted centroid of the cloud (handtrack.h:483-490).  The weights are
+		// independent per point and are formed by all lanes (256 points per pass, through LDS); the sums keep the reference's order on lane 0.
+		__shared__ float4 wp[256];
+		const v4 cs = (G4(an + HT_AN_CRAYS) + G4(an + HT_AN_CRAYS + 4)) + G4(an + HT_AN_CRAYS + 8);
+		const v3 palmray = normalize(xyz(cs));
 		v3 pcom = V3(0, 0, 0); float wsum = 0.00000000001f;
 		const int n = npts[b];
-		for (int i = 0; i < n; i++)
+		for (int base = 0; base < n; base += 256)
 		{
-			float4 pv = pts[(size_t)b * HT_MAXPTS + i];
-			v3 p = V3(pv.x, pv.y, pv.z);
-			v3 c = cross(p, palmray);
-			float w = 1.0f / (0.000001f + dot(c, c));
-			pcom = pcom + p * w; wsum += w;
+			const int m = min(256, n - base);
+			__syncthreads();
+			for (int i = lane; i < m; i += 64)
+			{
+				const float4 pv = pts[(size_t)b * HT_MAXPTS + base + i];
+				const v3 p = V3(pv.x, pv.y, pv.z);
+				const v3 c = cross(p, palmray);
+				const float w = 1.0f / (0.000001f + dot(c, c));
+				const v3 pw = p * w;
+				wp[i] = make_float4(pw.x, pw.y, pw.z, w);
+			}
+			__syncthreads();
+			if (lane == 0) for (int i = 0; i < m; i++) { const float4 e = wp[i]; pcom = pcom + V3(e.x, e.y, e.z); wsum += e.w; }
 		}
-		pcom = pcom / wsum;
-		pc[0] = pcom.x; pc[1] = pcom.y; pc[2] = pcom.z;
+		if (lane == 0) { pcom = pcom / wsum; pc[0] = pcom.x; pc[1] = pcom.y; pc[2] = pcom.z; }
 	}
 	if (lane < M.nb)
 	{
@@ -157,7 +165,10 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 	const m3 tinv = GM(M.ub_tinv);
 	const m3 Iinv = world_inertia(ubq, tinv, minv);
 	// rows of this solve (every 4th of <= 4096 points): re-expressed on the proxy body and pre-computed into the frame's record stream (handtrack.h:457-462)
-	float *const urow = scratch + (size_t)b * scratch_stride * CREC;
+	// The proxy body's records stay in LDS here (83 KB: only the few frames that take the full-reset path run this kernel, so occupancy is no concern,
+	// and a single quad walking its chain alone on a CU would wait a whole L2 round trip for what k_solve's sixteen quads overlap)
+	__shared__ __attribute__((aligned(16))) float urow[(HT_MAXPTS / 4 + QUAD_CHAIN_SLACK) * CREC];
+	(void)scratch; (void)scratch_stride;
 	__shared__ float usum[HT_MAXPTS / 4 + QUAD_CHAIN_SLACK];      // impulse sums of the rows
 	const int nr = n < HT_MAXPTS / 4 ? n : HT_MAXPTS / 4;
 	for (int i = lane; i < nr + QUAD_CHAIN_SLACK; i += 64) usum[i] = 0.0f;
