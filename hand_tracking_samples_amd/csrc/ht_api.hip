@@ -479,10 +479,10 @@ extern "C" int ht_stage_prepare(ht_ctx *ctx, const uint16_t *depth, const float 
 	hipStream_t s = ctx->stream;
 	HIPCHK(ctx, hipMemcpyAsync(ctx->d_depth, depth, (size_t)B * 4096 * sizeof(uint16_t), hipMemcpyHostToDevice, s));
 	HIPCHK(ctx, hipMemcpyAsync(ctx->d_cams, cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyHostToDevice, s));
-	ht_launch_prepare(ctx->d_depth, ctx->d_cams, ctx->par.drangey, ctx->par.subsample_fraction, ctx->d_cnn_in, ctx->d_pts, ctx->d_npts, B, s);
+	ht_launch_prepare(ctx->d_depth, ctx->d_cams, ctx->par.drangey, ctx->par.subsample_fraction, ctx->d_cnn_in, ctx->d_pts, ctx->d_npts, ctx->model.pts_cap, B, s);
 	ctx->model.pts_bound = 0;      // stage calls: no assumption about the cloud size
 	if (cnn_in) HIPCHK(ctx, hipMemcpyAsync(cnn_in, ctx->d_cnn_in, (size_t)B * HT_CNN_IN * sizeof(float), hipMemcpyDeviceToHost, s));
-	if (points) HIPCHK(ctx, hipMemcpyAsync(points, ctx->d_pts, (size_t)B * HT_MAXPTS * sizeof(float4), hipMemcpyDeviceToHost, s));
+	if (points) HIPCHK(ctx, hipMemcpy2DAsync(points, HT_MAXPTS * sizeof(float4), ctx->d_pts, (size_t)ctx->model.pts_cap * sizeof(float4), HT_MAXPTS * sizeof(float4), B, hipMemcpyDeviceToHost, s));
 	if (npoints) HIPCHK(ctx, hipMemcpyAsync(npoints, ctx->d_npts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
 	HIPCHK(ctx, hipStreamSynchronize(s));
 	HIPCHK(ctx, hipGetLastError());
@@ -559,6 +559,38 @@ extern "C" int ht_profile_read(ht_ctx *ctx, int reset, int max_entries, char *na
 }
 
 // ------------------------------------------------------------------------------------------------- buffers
+// The per-point arrays (points, cloud rows, the solver's row records) hold `pts_cap` points per frame.  A context starts with HT_MAXPTS and grows
+// when a call brings frames that can carry more (w*h / subsample_fraction), so that no cloud is ever cut: handtrack.h:751 takes any count.
+// Growing waits for the context's streams, frees the three arrays and allocates them again (their contents are per-call scratch).
+int ht_reserve_points_locked(ht_ctx *ctx, int points)
+{
+	const int want = (points + 63) & ~63;
+	if (ctx->d_pts && want <= ctx->model.pts_cap) return HT_OK;
+	const size_t B = (size_t)ctx->B, nb = (size_t)ctx->model.nb, cap = (size_t)want;
+	HIPCHK(ctx, ht_sync_all(ctx));
+	void *old[3] = { ctx->d_pts, ctx->d_rows, ctx->d_scratch };
+	for (void *o : old) if (o) { for (auto &q : ctx->allocs) if (q == o) { q = ctx->allocs.back(); ctx->allocs.pop_back(); break; } (void)hipFree(o); }
+	ctx->d_pts = nullptr; ctx->d_rows = nullptr; ctx->d_scratch = nullptr; ctx->model.pts_cap = 0;
+	int r;
+	if ((r = dev_alloc(ctx, &ctx->d_pts, B * cap))) return r;
+	if ((r = dev_alloc(ctx, &ctx->d_rows, B * cap * HT_ROW))) return r;
+	if ((r = dev_alloc(ctx, &ctx->d_scratch, B * (cap + 5 * nb + 32) * 21))) return r;      // 20 floats per row record + 1 for the impulse sum of over-size frames
+	ctx->model.pts_cap = want;
+	return HT_OK;
+}
+extern "C" int ht_reserve_points(ht_ctx *ctx, int points)
+{
+	CHECK_READY(ctx); CHECK_MODEL(ctx);
+	if (points < 1 || points > HT_POINTS_LIMIT) { ctx->err = "ht_reserve_points: between 1 and 76800 points (a 320x240 frame with every pixel in range)"; return HT_ERR_ARG; }
+	return ht_reserve_points_locked(ctx, points < HT_MAXPTS ? HT_MAXPTS : points);
+}
+extern "C" int ht_point_capacity(ht_ctx *ctx, int *points)
+{
+	CHECK_READY(ctx); CHECK_MODEL(ctx);
+	if (!points) return HT_ERR_ARG;
+	*points = ctx->model.pts_cap;
+	return HT_OK;
+}
 int ht_alloc_buffers(ht_ctx *ctx)
 {
 	const size_t B = (size_t)ctx->B, nb = (size_t)ctx->model.nb;
@@ -567,13 +599,14 @@ int ht_alloc_buffers(ht_ctx *ctx)
 	A(d_depth, B * 4096); A(d_cams, B * HT_CAM); A(d_cnn_in, B * HT_CNN_IN); A(d_act1, B * 3600); A(d_act2, B * 2304); A(d_act3, B * 2048);
 	A(d_logits, B * HT_CNN_OUT); A(d_cnn_out, B * HT_CNN_OUT); A(d_analysis, B * HT_ANALYSIS);
 	if (ctx->cnn_only) return HT_OK;
-	A(d_pts, B * HT_MAXPTS); A(d_npts, B);
+	A(d_npts, B);
 	A(d_state[0], B * nb * HT_STATE_STRIDE); A(d_state[1], B * nb * HT_STATE_STRIDE);
 	A(d_prev_err, B); A(d_initializing, B); A(d_err_old, B); A(d_err_new, B); A(d_flags, B); A(d_nflags, B);
-	A(d_rows, B * HT_MAXPTS * HT_ROW); A(d_nrows, B);
+	A(d_nrows, B);
 	A(d_chamber, B * 5 * nb * HT_ROW); A(d_nchamber, B); A(d_accepted, B);
 	A(d_contacts, B * HT_MAXCONTACT * HT_CONTACT); A(d_ncontacts, B); A(d_epa_ws, ht_contacts_workspace_bytes((int)B)); HIPCHK(ctx, hipMemset(ctx->d_epa_ws, 0, ht_contacts_workspace_bytes((int)B)));
-	A(d_scratch, B * (HT_MAXPTS + 5 * nb + 32) * 21); A(d_retry, B);      // 20 floats per row record + 1 for the impulse sum of over-size frames
+	A(d_retry, B);
+	if ((r = ht_reserve_points_locked(ctx, HT_MAXPTS))) return r;
 	A(d_poses_out, B * nb * HT_POSE); A(d_start, B * nb * HT_POSE);
 	A(d_stage, B * nb * HT_STATE_STRIDE);
 #undef A

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 	{
 		const int i = base + t;
 		const bool active = t < CH && i < nsub;
-		const float4 pv = active ? pts[(size_t)b * HT_MAXPTS + i * stride] : make_float4(0, 0, 0, 0);
+		const float4 pv = active ? pts[(size_t)b * M.pts_cap + i * stride] : make_float4(0, 0, 0, 0);
 		const v3 v = V3(pv.x, pv.y, pv.z);
 		int rb; v4 p; float dmin;
 		closest_chunk<CR_THREADS>(M, tab, L, active, v, rb, p, dmin);
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 		else if (mode == 2) { float cloudforce = fmin_std(cf_max_point, cf_max_sum / (float)n); float k = (rb == 0) ? 0.1f : 1.0f; fmin = -cloudforce * k; fmax = cloudforce * k; }
 		else if (mode == 3) { fmin = -1.0f * unibody_force; fmax = 1.0f * unibody_force; }
 		else if (mode == 4) { const float k = (microforce * weak_force) * ((rb == 0) ? cf_max_point : 1.0f); fmin = -1.0f * k; fmax = 1.0f * k; }      // slowfit handtrack.h:815-816: weak_force = step ratio, cf_max_point = wrist factor
-		float4 *out = reinterpret_cast<float4 *>(rows + ((size_t)b * HT_MAXPTS + i) * HT_ROW);
+		float4 *out = reinterpret_cast<float4 *>(rows + ((size_t)b * M.pts_cap + i) * HT_ROW);
 		out[0] = make_float4(-1.0f, (float)rb, v.x, v.y);
 		out[1] = make_float4(v.z, position1.x, position1.y, position1.z);
 		out[2] = make_float4(normal.x, normal.y, normal.z, targetdist);
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void k_fit_error(ht_model_dev M, const float *
 	{
 		const int i = base + t;
 		const bool active = t < CH && i < n;
-		const float4 pv = active ? pts[(size_t)b * HT_MAXPTS + i] : make_float4(0, 0, 0, 0);
+		const float4 pv = active ? pts[(size_t)b * M.pts_cap + i] : make_float4(0, 0, 0, 0);
 		int rb; v4 p; float dmin;
 		closest_chunk<256>(M, tab, L, active, V3(pv.x, pv.y, pv.z), rb, p, dmin);
 		// pointerror[bone] = max(pointerror[bone], d) with pointerror starting at 0 (handtrack.h:376-383): only d > 0 matters,
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(64) void k_chamber(ht_model_dev M, const float *__r
 	{
 		const int m = min(256, n - base);
 		__syncthreads();
-		for (int i = lane; i < m; i += 64) chunk[i] = pts[(size_t)b * HT_MAXPTS + base + i];
+		for (int i = lane; i < m; i += 64) chunk[i] = pts[(size_t)b * M.pts_cap + base + i];
 		__syncthreads();
 		if (lane < 5)
 			for (int i = 0; i < m; i++)

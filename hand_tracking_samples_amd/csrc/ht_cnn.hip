@@ -18,7 +18,7 @@
 // ------------------------------------------------------------------------------------------------- k_prepare
 // one block per frame; thread t owns pixels [16t, 16t+16) so that a block-wide prefix sum keeps the row-major order
 __global__ __launch_bounds__(256) void k_prepare(const uint16_t *__restrict__ depth, const float *__restrict__ cams, float drangey, int fraction,
-                                                  float *__restrict__ cnn_in, float4 *__restrict__ pts, int *__restrict__ npts)
+                                                  float *__restrict__ cnn_in, float4 *__restrict__ pts, int *__restrict__ npts, int cap)
 {
 	const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	const float *cam = cams + (size_t)b * HT_CAM;
@@ -60,11 +60,11 @@ __global__ __launch_bounds__(256) void k_prepare(const uint16_t *__restrict__ de
 #pragma unroll
 		for (int i = 0; i < 16; i++) if (mask & (1u << i))
 		{
-			if (rank % fraction == 0 && rank / fraction < HT_MAXPTS)
+			if (rank % fraction == 0 && rank / fraction < cap)
 			{
 				int p = 16 * t + i;
 				float x = (float)(p & 63), y = (float)(p >> 6);
-				pts[(size_t)b * HT_MAXPTS + rank / fraction] = make_float4(((x - cx) / fx) * d[i], ((y - cy) / fy) * d[i], 1.0f * d[i], 0.0f);   // deprojectz misc_image.h:48
+				pts[(size_t)b * cap + rank / fraction] = make_float4(((x - cx) / fx) * d[i], ((y - cy) / fy) * d[i], 1.0f * d[i], 0.0f);   // deprojectz misc_image.h:48
 			}
 			rank++;
 		}
@@ -73,16 +73,16 @@ __global__ __launch_bounds__(256) void k_prepare(const uint16_t *__restrict__ de
 	{
 		int total = base + cnt;
 		int n = (total + fraction - 1) / fraction;
-		npts[b] = n < HT_MAXPTS ? n : HT_MAXPTS;
+		npts[b] = n < cap ? n : cap;
 	}
 }
 
 // Point cloud of a full-size frame (w x h, any size): takesubsample(PointCloud(dimage, {0.1, drangey}), fraction) of handtrack.h:703,751 --
 // every fraction-th in-range pixel in row-major order, deprojected with the frame's own camera.  One block per frame; thread t owns
 // the pixels [t*chunk, (t+1)*chunk), counts, the block forms the exclusive prefix, and a second walk emits.  *overflow counts frames with
-// more than HT_MAXPTS points (their cloud is truncated; the host API turns that into an error).
+// more than `cap` points (their cloud is truncated; the host API sizes cap so that this cannot happen and treats a count as an error).
 __global__ __launch_bounds__(256) void k_prepare_frame(const uint16_t *__restrict__ depth, const float *__restrict__ cams, int w, int h, float drangey, int fraction,
-                                                        float4 *__restrict__ pts, int *__restrict__ npts, int *__restrict__ overflow)
+                                                        float4 *__restrict__ pts, int *__restrict__ npts, int *__restrict__ overflow, int cap)
 {
 	const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	const float *cam = cams + (size_t)b * HT_CAM;
@@ -103,18 +103,18 @@ __global__ __launch_bounds__(256) void k_prepare_frame(const uint16_t *__restric
 	{
 		const float d = (float)(int)src[p] * dscale;
 		if (!(d >= 0.1f && d < drangey)) continue;
-		if (rank % fraction == 0 && rank / fraction < HT_MAXPTS)
+		if (rank % fraction == 0 && rank / fraction < cap)
 		{
 			const float x = (float)(p % w), y = (float)(p / w);
-			pts[(size_t)b * HT_MAXPTS + rank / fraction] = make_float4(((x - cx) / fx) * d, ((y - cy) / fy) * d, 1.0f * d, 0.0f);      // deprojectz misc_image.h:48
+			pts[(size_t)b * cap + rank / fraction] = make_float4(((x - cx) / fx) * d, ((y - cy) / fy) * d, 1.0f * d, 0.0f);      // deprojectz misc_image.h:48
 		}
 		rank++;
 	}
 	if (t == 255)
 	{
 		const int n = (rank + fraction - 1) / fraction;
-		npts[b] = n < HT_MAXPTS ? n : HT_MAXPTS;
-		if (n > HT_MAXPTS && overflow) atomicAdd(overflow, 1);
+		npts[b] = n < cap ? n : cap;
+		if (n > cap && overflow) atomicAdd(overflow, 1);
 	}
 }
 
@@ -425,13 +425,13 @@ __global__ __launch_bounds__(64) void k_softmax_decode(const float *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------- host launchers
-void ht_launch_prepare(const uint16_t *depth, const float *cams, float drangey, int fraction, float *cnn_in, float4 *pts, int *npts, int B, hipStream_t s)
+void ht_launch_prepare(const uint16_t *depth, const float *cams, float drangey, int fraction, float *cnn_in, float4 *pts, int *npts, int cap, int B, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_prepare, dim3(B), dim3(256), 0, s, depth, cams, drangey, fraction, cnn_in, pts, npts);
+	hipLaunchKernelGGL(k_prepare, dim3(B), dim3(256), 0, s, depth, cams, drangey, fraction, cnn_in, pts, npts, cap);
 }
-void ht_launch_prepare_frame(const uint16_t *depth, const float *cams, int w, int h, float drangey, int fraction, float4 *pts, int *npts, int *overflow, int B, hipStream_t s)
+void ht_launch_prepare_frame(const uint16_t *depth, const float *cams, int w, int h, float drangey, int fraction, float4 *pts, int *npts, int *overflow, int cap, int B, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_prepare_frame, dim3(B), dim3(256), 0, s, depth, cams, w, h, drangey, fraction, pts, npts, overflow);
+	hipLaunchKernelGGL(k_prepare_frame, dim3(B), dim3(256), 0, s, depth, cams, w, h, drangey, fraction, pts, npts, overflow, cap);
 }
 // side = 64: PoseInitializerCNN's topology (handtrack.h:108-118); side = 128: the same layers on a 128x128 input (act1 [B][16*31*31], act2 [B][12544])
 void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, float *act2, float *act3, float *logits, int B, hipStream_t s, int side)

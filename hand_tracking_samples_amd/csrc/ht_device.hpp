@@ -45,7 +45,8 @@ static inline bool ht_tuning_env(const char *name)
 #endif
 }
 
-#define HT_MAXPTS 4096          // sub-sampled points per frame: all of a 64x64 tile's (4096 / 4) or of a 128x128 frame's (16384 / 4); larger frames must stay below it
+#define HT_MAXPTS 4096          // default point capacity of a context (ht_model_dev::pts_cap): every point of a 64x64 tile, every 4th of a 128x128 frame; a context grows
+                                // it when a call brings larger frames (ht_reserve_points)
 static_assert(HT_MAXPTS == HT_MAX_POINTS, "public header and kernels disagree on the point capacity");
 #define HT_MAXNB 32             // bodies
 #define HT_MAXNJ 32             // joints
@@ -91,7 +92,8 @@ static_assert(HT_MAXPTS == HT_MAX_POINTS, "public header and kernels disagree on
 struct ht_model_dev
 {
 	int nb, nj;
-	int pts_bound;            // most sub-sampled points a frame of the current call can carry (<= HT_MAXPTS; 0 = HT_MAXPTS): sizes per-point LDS arrays
+	int pts_bound;            // most sub-sampled points a frame of the current call can carry (<= pts_cap; 0 = pts_cap): sizes per-point LDS arrays
+	int pts_cap;              // points a frame's slot of the per-point arrays holds (stride of points / cloud rows; >= HT_MAXPTS)
 	const float4 *verts;      // all bodies back to back (com-centred collision vertices)
 	const float4 *planes;     // all bodies back to back (local half-space planes)
 	const float *bodyc;       // [nb][HT_BC]
@@ -117,7 +119,7 @@ struct ht_physics_dev      // physics.h:34-47 after handtrack.h:837-838
 struct ht_cnn_weights { const float *W1, *B1, *W2p, *B2, *W3, *B3, *W4, *B4; };
 
 // ---- kernel launchers (defined in the .hip files) ----
-void ht_launch_prepare(const uint16_t *depth, const float *cams, float drangey, int fraction, float *cnn_in, float4 *pts, int *npts, int B, hipStream_t s);
-void ht_launch_prepare_frame(const uint16_t *depth, const float *cams, int w, int h, float drangey, int fraction, float4 *pts, int *npts, int *overflow, int B, hipStream_t s);
+void ht_launch_prepare(const uint16_t *depth, const float *cams, float drangey, int fraction, float *cnn_in, float4 *pts, int *npts, int cap, int B, hipStream_t s);
+void ht_launch_prepare_frame(const uint16_t *depth, const float *cams, int w, int h, float drangey, int fraction, float4 *pts, int *npts, int *overflow, int cap, int B, hipStream_t s);
 void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, float *act2, float *act3, float *logits, int B, hipStream_t s, int side = 64);
 void ht_launch_softmax_decode(const float *logits, float *cnn_out, const float *cams, float *analysis, int softmax, int B, hipStream_t s);

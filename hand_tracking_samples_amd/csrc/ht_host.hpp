@@ -41,12 +41,12 @@ struct ht_ctx
 	float *d_state[2] = { nullptr, nullptr };      // [B][nb][HT_STATE_STRIDE]: 0 handmodel, 1 othermodel
 	float *d_prev_err = nullptr; int *d_initializing = nullptr;
 	float *d_err_old = nullptr, *d_err_new = nullptr; int *d_flags = nullptr, *d_nflags = nullptr;
-	float *d_rows = nullptr; int *d_nrows = nullptr;            // cloud rows [B][HT_MAXPTS][HT_ROW]
+	float *d_rows = nullptr; int *d_nrows = nullptr;            // cloud rows [B][pts_cap][HT_ROW]
 	float *d_chamber = nullptr; int *d_nchamber = nullptr;      // [B][5*nb][HT_ROW]
 	int *d_accepted = nullptr;
 	float *d_contacts = nullptr; int *d_ncontacts = nullptr;    // [B][HT_MAXCONTACT][HT_CONTACT]
 	unsigned char *d_epa_ws = nullptr;                           // expanding-polytope workspace, one per (frame, wave)
-	float *d_scratch = nullptr;                                  // solver row records [B][HT_MAXPTS + 5*nb + 32][20] (ht_quad.hpp)
+	float *d_scratch = nullptr;                                  // solver row records [B][pts_cap + 5*nb + 32][20] (ht_quad.hpp)
 	int *d_retry = nullptr;                                      // [B] k_solve: frames handed from the small-pool build to the large one
 	float *d_poses_out = nullptr, *d_start = nullptr;
 	float *d_stage = nullptr;                                    // staging for host<->device state copies
@@ -60,6 +60,7 @@ struct ht_prof_scope
 };
 
 int ht_alloc_buffers(ht_ctx *ctx);
+int ht_reserve_points_locked(ht_ctx *ctx, int points);      // grows the per-point arrays (ht_api.hip); waits for the context's streams
 // *_dev entry points: a NULL stream means the context's own stream (never the legacy default stream); the choice is remembered so that the
 // host-read helpers (ht_capacity_events, ht_frames_overflow, ht_get_tracker_flags, ...) can wait for work enqueued on a caller's stream
 static inline hipStream_t ht_user_stream(ht_ctx *ctx, void *stream) { hipStream_t s = stream ? (hipStream_t)stream : ctx->stream; ctx->last_user_stream = s; return s; }

@@ -5,7 +5,7 @@
 struct solve_args
 {
 	const float *rows_pre; const int *n_pre; int pre_stride;      // chamber rows [B][pre_stride][HT_ROW] (may be null)
-	const float *rows_cloud; const int *n_cloud;                    // cloud rows [B][HT_MAXPTS][HT_ROW] (may be null)
+	const float *rows_cloud; const int *n_cloud;                    // cloud rows [B][pts_cap][HT_ROW] (may be null)
 	const float *contacts; const int *ncontacts;                    // [B][HT_MAXCONTACT][HT_CONTACT] (may be null)
 	const float *analysis; const float *cams;                       // for ApplyAngles / landmark-ray rows / arm cone
 	const int *active_flag;                                         // optional per-frame enable

@@ -588,7 +588,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	else for (int i = lane; i < n1 + QUAD_CHAIN_SLACK && i < a.scratch_stride; i += 64) gsum[i] = 0.0f;
 	auto row_ptr = [&](int i) -> const float * {
 		if (i < npre) return a.ray_rows ? S.ray[i] : a.rows_pre + ((size_t)b * a.pre_stride + i) * HT_ROW;
-		return a.rows_cloud + ((size_t)b * HT_MAXPTS + (i - npre)) * HT_ROW;
+		return a.rows_cloud + ((size_t)b * M.pts_cap + (i - npre)) * HT_ROW;
 	};
 	int mycnt = 0;                                     // lane bb counts the rows of body bb
 	for (int base = 0; base < n1; base += 64)          // pass A: rows per body
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solve_args &a, int B, hipStream_t s)
 {
 	// first build by what the host knows of the launch: the model's joints and the most points a frame of this call can carry
-	const int pts = M.pts_bound > 0 ? M.pts_bound : HT_MAXPTS;
+	const int pts = M.pts_bound > 0 ? M.pts_bound : M.pts_cap;
 	const bool small = 3 * (M.nj + 8) + 3 <= POOL_SMALL / LROW && pts <= 1024;      // room for a few contacts beside the joints, and a 64x64 tile's cloud
 	if (small) hipLaunchKernelGGL((k_solve<POOL_SMALL, SUMS_SMALL, true>), dim3(B), dim3(64), 0, s, M, ph, a);
 	else hipLaunchKernelGGL((k_solve<POOL_MID, SUMS_MID, true>), dim3(B), dim3(64), 0, s, M, ph, a);

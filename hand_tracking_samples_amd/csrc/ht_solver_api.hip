@@ -12,7 +12,7 @@
 #define CHECK_BATCH(ctx, B) do { if ((B) < 1 || (B) > (ctx)->B) { (ctx)->err = "batch exceeds the capacity given to ht_create"; return HT_ERR_ARG; } } while (0)
 #define CHECK_RANGE(ctx, first, n) do { if ((first) < 0 || (n) < 1 || (first) + (n) > (ctx)->B) { (ctx)->err = "slot range exceeds the capacity given to ht_create"; return HT_ERR_ARG; } } while (0)
 
-static int scratch_stride(const ht_ctx *ctx) { return HT_MAXPTS + 5 * ctx->model.nb + 32; }
+static int scratch_stride(const ht_ctx *ctx) { return ctx->model.pts_cap + 5 * ctx->model.nb + 32; }
 
 // ---- building blocks ------------------------------------------------------------------------------------------------
 static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int *n_pre, bool cloud, bool contacts, const int *active,
@@ -99,7 +99,7 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 	const ht_params &p = ctx->par;
 	const int nb = ctx->model.nb;
 	const int iw = fs ? fs->w : 64, ih = fs ? fs->h : 64;      // the image FitError looks at
-	{ const int npx = iw * ih, fr = p.subsample_fraction > 0 ? p.subsample_fraction : 1, n = (npx + fr - 1) / fr; ctx->model.pts_bound = n < HT_MAXPTS ? ((n + 63) & ~63) : HT_MAXPTS; }
+	{ const int npx = iw * ih, fr = p.subsample_fraction > 0 ? p.subsample_fraction : 1, n = (npx + fr - 1) / fr; if (n > ctx->model.pts_cap) { const int r = ht_reserve_points_locked(ctx, n); if (r) return r; } ctx->model.pts_bound = (n + 63) & ~63; }
 	const float *img_cams = ctx->d_cams;
 	if (fs)
 	{
@@ -126,10 +126,10 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		ht_prof_scope ps(ctx, "prepare", s, true);
 		if (fs)
 		{
-			ht_launch_prepare(ctx->d_seg_tiles, ctx->d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, nullptr, nullptr, B, s);
-			ht_launch_prepare_frame(d_depth, img_cams, fs->w, fs->h, p.drangey, p.subsample_fraction, ctx->d_pts, ctx->d_npts, ctx->d_overflow, B, s);
+			ht_launch_prepare(ctx->d_seg_tiles, ctx->d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, nullptr, nullptr, ctx->model.pts_cap, B, s);
+			ht_launch_prepare_frame(d_depth, img_cams, fs->w, fs->h, p.drangey, p.subsample_fraction, ctx->d_pts, ctx->d_npts, ctx->d_overflow, ctx->model.pts_cap, B, s);
 		}
-		else ht_launch_prepare(d_depth, ctx->d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, ctx->d_pts, ctx->d_npts, B, s);
+		else ht_launch_prepare(d_depth, ctx->d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, ctx->d_pts, ctx->d_npts, ctx->model.pts_cap, B, s);
 	}
 	float *cnn_out = d_cnn_out ? d_cnn_out : ctx->d_cnn_out;
 	static const bool no_overlap = ht_tuning_env("HT_NO_OVERLAP");      // timing experiments (-DHT_TUNING builds only)
@@ -326,7 +326,7 @@ extern "C" int ht_update_frames_sync(ht_ctx *ctx, const uint16_t *depth, const f
 	HIPCHK(ctx, hipGetLastError());
 	int over = 0;
 	HIPCHK(ctx, hipMemcpy(&over, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost));
-	if (over) { ctx->err = "ht_update_frames: " + std::to_string(over) + " frame(s) have more in-range points than the solver's capacity (4096 after sub-sampling); their result is not the reference's"; return HT_ERR_ARG; }
+	if (over) { ctx->err = "ht_update_frames: " + std::to_string(over) + " frame(s) have more in-range points than the context's point capacity holds; their result is not the reference's"; return HT_ERR_ARG; }
 	return HT_OK;
 }
 
@@ -397,9 +397,9 @@ extern "C" int ht_stage_cloud_rows(ht_ctx *ctx, int which, int stride, int use_c
 	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
 	if (!rows || !nrows || which < 0 || which > 1 || stride < 1) return HT_ERR_ARG;
 	hipStream_t s = ctx->stream;
-	HIPCHK(ctx, hipMemsetAsync(ctx->d_rows, 0, (size_t)B * HT_MAXPTS * HT_ROW * sizeof(float), s));
+	HIPCHK(ctx, hipMemsetAsync(ctx->d_rows, 0, (size_t)B * ctx->model.pts_cap * HT_ROW * sizeof(float), s));
 	ht_launch_cloud_rows(ctx->model, ctx->d_state[which], ctx->d_pts, ctx->d_npts, ctx->d_cams, nullptr, stride, use_cam_origin, 0, ctx->par, ctx->d_rows, ctx->d_nrows, B, s);
-	HIPCHK(ctx, hipMemcpyAsync(rows, ctx->d_rows, (size_t)B * HT_MAXPTS * HT_ROW * sizeof(float), hipMemcpyDeviceToHost, s));
+	HIPCHK(ctx, hipMemcpy2DAsync(rows, HT_MAXPTS * HT_ROW * sizeof(float), ctx->d_rows, (size_t)ctx->model.pts_cap * HT_ROW * sizeof(float), HT_MAXPTS * HT_ROW * sizeof(float), B, hipMemcpyDeviceToHost, s));
 	HIPCHK(ctx, hipMemcpyAsync(nrows, ctx->d_nrows, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
 	HIPCHK(ctx, hipStreamSynchronize(s));
 	HIPCHK(ctx, hipGetLastError());
@@ -568,17 +568,19 @@ extern "C" int ht_slowfit(ht_ctx *ctx, int B, int hold, const float *refpose, in
 }
 
 // Caller-supplied point clouds for the stage functions / ht_slowfit (the reference's slowfit takes its points as an argument):
-// points [B][cap][3] (cap <= 1024 used per frame), npoints [B].
+// points [B][cap][3], npoints [B] (<= cap; the context's point capacity grows to the largest).
 extern "C" int ht_set_points(ht_ctx *ctx, int B, const float *points, int cap, const int *npoints)
 {
 	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
 	if (!points || !npoints || cap < 1) return HT_ERR_ARG;
 	ctx->model.pts_bound = 0;
-	std::vector<float4> h((size_t)B * HT_MAXPTS, make_float4(0, 0, 0, 0)); std::vector<int> n(B);
+	{ int most = 0; for (int b = 0; b < B; b++) most = std::max(most, std::min(npoints[b], cap)); if (most > HT_POINTS_LIMIT) return HT_ERR_ARG; const int r = ht_reserve_points_locked(ctx, std::max(most, 1)); if (r) return r; }
+	const size_t pc = (size_t)ctx->model.pts_cap;
+	std::vector<float4> h((size_t)B * pc, make_float4(0, 0, 0, 0)); std::vector<int> n(B);
 	for (int b = 0; b < B; b++)
 	{
-		n[b] = npoints[b] < 0 ? 0 : npoints[b] > cap ? cap : npoints[b]; if (n[b] > HT_MAXPTS) n[b] = HT_MAXPTS;
-		for (int i = 0; i < n[b]; i++) { const float *p = points + ((size_t)b * cap + i) * 3; h[(size_t)b * HT_MAXPTS + i] = make_float4(p[0], p[1], p[2], 0.0f); }
+		n[b] = npoints[b] < 0 ? 0 : npoints[b] > cap ? cap : npoints[b]; if (n[b] > (int)pc) n[b] = (int)pc;
+		for (int i = 0; i < n[b]; i++) { const float *p = points + ((size_t)b * cap + i) * 3; h[(size_t)b * pc + i] = make_float4(p[0], p[1], p[2], 0.0f); }
 	}
 	HIPCHK(ctx, hipMemcpy(ctx->d_pts, h.data(), h.size() * sizeof(float4), hipMemcpyHostToDevice));
 	HIPCHK(ctx, hipMemcpy(ctx->d_npts, n.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice));

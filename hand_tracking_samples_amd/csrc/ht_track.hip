@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) void k_scratch(ht_model_dev M, float *__restric
 			__syncthreads();
 			for (int i = lane; i < m; i += 64)
 			{
-				const float4 pv = pts[(size_t)b * HT_MAXPTS + base + i];
+				const float4 pv = pts[(size_t)b * M.pts_cap + base + i];
 				const v3 p = V3(pv.x, pv.y, pv.z);
 				const v3 c = cross(p, palmray);
 				const float w = 1.0f / (0.000001f + dot(c, c));
@@ -164,24 +164,30 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 	const float minv = M.ub_massinv;
 	const m3 tinv = GM(M.ub_tinv);
 	const m3 Iinv = world_inertia(ubq, tinv, minv);
-	// rows of this solve (every 4th of <= 4096 points): re-expressed on the proxy body and pre-computed into the frame's record stream (handtrack.h:457-462)
-	// The proxy body's records stay in LDS here (83 KB: only the few frames that take the full-reset path run this kernel, so occupancy is no concern,
-	// and a single quad walking its chain alone on a CU would wait a whole L2 round trip for what k_solve's sixteen quads overlap)
-	__shared__ __attribute__((aligned(16))) float urow[(HT_MAXPTS / 4 + QUAD_CHAIN_SLACK) * CREC];
-	(void)scratch; (void)scratch_stride;
-	__shared__ float usum[HT_MAXPTS / 4 + QUAD_CHAIN_SLACK];      // impulse sums of the rows
-	const int nr = n < HT_MAXPTS / 4 ? n : HT_MAXPTS / 4;
-	for (int i = lane; i < nr + QUAD_CHAIN_SLACK; i += 64) usum[i] = 0.0f;
+	// rows of this solve (every 4th point): re-expressed on the proxy body and pre-computed into the frame's record stream (handtrack.h:457-462).
+	// Up to UB_LDS_ROWS rows (every frame of the default point capacity) the records stay in LDS (83 KB: only the few frames that take the full-reset
+	// path run this kernel, so occupancy is no concern, and a single quad walking its chain alone on a CU would wait a whole L2 round trip for what
+	// k_solve's sixteen quads overlap); a larger cloud uses the frame's slot of the solver scratch in HBM, sums behind all frames' records as in k_solve.
+	constexpr int UB_LDS_ROWS = HT_MAXPTS / 4;
+	__shared__ __attribute__((aligned(16))) float urow[(UB_LDS_ROWS + QUAD_CHAIN_SLACK) * CREC];
+	__shared__ float usum[UB_LDS_ROWS + QUAD_CHAIN_SLACK];      // impulse sums of the rows
+	const int nr = n < scratch_stride - QUAD_CHAIN_SLACK ? n : scratch_stride - QUAD_CHAIN_SLACK;
+	const bool in_lds = nr <= UB_LDS_ROWS;
+	float *const grec = scratch + (size_t)b * scratch_stride * CREC;
+	float *const gsum = scratch + (size_t)gridDim.x * scratch_stride * CREC + (size_t)b * scratch_stride;
+	if (in_lds) { for (int i = lane; i < nr + QUAD_CHAIN_SLACK; i += 64) usum[i] = 0.0f; }
+	else for (int i = lane; i < nr + QUAD_CHAIN_SLACK; i += 64) gsum[i] = 0.0f;
 	for (int i = lane; i < nr; i += 64)
 	{
-		const float *r = rows + ((size_t)b * HT_MAXPTS + i) * HT_ROW;
+		const float *r = rows + ((size_t)b * M.pts_cap + i) * HT_ROW;
 		const int rb1 = (int)r[1];
 		const v3 p1 = apply(ubi, apply(XF(G3(pos[rb1]), G4(q[rb1])), G3(r + 5)));
 		const v3 nrm = G3(r + 8);
 		const v3 r1 = qrot(ubq, p1);
 		const float impulsed = minv + dot(cross(mul(Iinv, cross(r1, nrm)), r1), nrm);
 		const float ts = r[11] / dt;
-		quad_write_record(urow + (size_t)i * CREC, r1, nrm, ts, fmin_std(ts, r[12]), impulsed, r[13] * dt, r[14] * dt);
+		if (in_lds) quad_write_record(urow + (size_t)i * CREC, r1, nrm, ts, fmin_std(ts, r[12]), impulsed, r[13] * dt, r[14] * dt);
+		else quad_write_record(grec + (size_t)i * CREC, r1, nrm, ts, fmin_std(ts, r[12]), impulsed, r[13] * dt, r[14] * dt);
 	}
 	__threadfence_block();
 	__syncthreads();
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 		for (int sweep = 0; sweep < total; sweep++)
 		{
 			const int tsoff = sweep >= ph.iterations ? 1 : 0;        // RemoveBias: lane 3 switches to the ts_post slot
-			if (nr > 0) quad_chain_run(qb, urow, usum, nr, c, tsoff);
+			if (nr > 0) { if (in_lds) quad_chain_run(qb, urow, usum, nr, c, tsoff); else quad_chain_run(qb, grec, gsum, nr, c, tsoff); }
 			if (sweep + 1 == ph.iterations)
 			{
 				const v3 lin = V3(dpp<QP_BC0>(qb.l), dpp<QP_BC1>(qb.l), dpp<QP_BC2>(qb.l)), ang = V3(dpp<QP_BC0>(qb.av), dpp<QP_BC1>(qb.av), dpp<QP_BC2>(qb.av));

@@ -20,7 +20,7 @@ SYMBOLS = (
     "ht_create", "ht_destroy", "ht_model_bake", "ht_last_error", "ht_get_params", "ht_set_params", "ht_model_info", "ht_config_read", "ht_scale",
     "ht_cnn_load_weights", "ht_cnn_eval", "ht_cnn_eval_dev", "ht_cnn_load_weights_sized", "ht_cnn_eval_sized", "ht_cnn_eval_sized_dev", "ht_cnn_train", "ht_cnn_get_weights", "ht_expected_cnn", "ht_expected_cnn_full",
     "ht_model_open", "ht_model_close", "ht_model_error", "ht_model_counts", "ht_model_body", "ht_model_body_mesh", "ht_model_hitcheck",
-    "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_update_frames_sync", "ht_update_frames_dev", "ht_update_cnn_model_sync", "ht_get_cnn_results", "ht_frames_overflow", "ht_capacity_events", "ht_segment_vr", "ht_segment_vr_dev", "ht_slowfit", "ht_set_points",
+    "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_update_frames_sync", "ht_update_frames_dev", "ht_update_cnn_model_sync", "ht_get_cnn_results", "ht_frames_overflow", "ht_reserve_points", "ht_point_capacity", "ht_capacity_events", "ht_segment_vr", "ht_segment_vr_dev", "ht_slowfit", "ht_set_points",
     "ht_stage_prepare", "ht_stage_decode", "ht_stage_fit_error", "ht_stage_cloud_rows", "ht_stage_contacts", "ht_stage_fit",
     "ht_stage_multistep", "ht_stage_scratch_unibody", "ht_profile_enable", "ht_profile_read", "ht_debug_solve_stats", "ht_debug_contact_stats",
 )
@@ -78,6 +78,8 @@ def load(build_if_missing=True):
     L.ht_update_frames_sync.argtypes = [vp, u16p, fp, C.c_int, C.c_int, C.c_float, C.c_int, fp, fp]
     L.ht_update_frames_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, C.c_int, vp, vp]
     L.ht_frames_overflow.argtypes = [vp, ip]
+    L.ht_reserve_points.argtypes = [vp, C.c_int]
+    L.ht_point_capacity.argtypes = [vp, ip]
     L.ht_update_cnn_model_sync.argtypes = [vp, u16p, fp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, fp, ip, fp]
     L.ht_get_cnn_results.argtypes = [vp, C.c_int, C.c_int, fp, fp, fp]
     L.ht_capacity_events.argtypes = [vp, ip, ip, ip]
@@ -94,6 +96,7 @@ def load(build_if_missing=True):
     L.ht_cnn_train.argtypes = [vp, fp, fp, C.c_int, C.c_float, fp]
     L.ht_cnn_get_weights.argtypes = [vp, fp, C.c_size_t]
     L.ht_expected_cnn.argtypes = [fp, fp, fp]
+    L.ht_set_points.argtypes = [vp, C.c_int, fp, C.c_int, ip]
     L.ht_slowfit.argtypes = [vp, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp, fp, fp, C.c_int]
     L.ht_segment_vr.argtypes = [vp, C.POINTER(C.c_uint16), fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_uint16), fp]
     L.ht_segment_vr_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp, vp, vp]
@@ -272,6 +275,23 @@ class Context:
         a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
         self._chk(self.L.ht_capacity_events(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def set_points(self, clouds):
+        """Caller-supplied clouds for the stage calls (ht_set_points): one (n_i, 3) array per slot."""
+        cap = max(1, max(len(c) for c in clouds))
+        buf = np.zeros((len(clouds), cap, 3), np.float32)
+        for i, c in enumerate(clouds):
+            buf[i, :len(c)] = np.asarray(c, np.float32).reshape(-1, 3)
+        n = np.array([len(c) for c in clouds], np.int32)
+        self._chk(self.L.ht_set_points(self.h, len(clouds), _f(buf), cap, _i(n)))
+
+    def point_capacity(self):
+        n = C.c_int(0)
+        self._chk(self.L.ht_point_capacity(self.h, C.byref(n)))
+        return n.value
+
+    def reserve_points(self, points):
+        self._chk(self.L.ht_reserve_points(self.h, int(points)))
 
     def frames_overflow(self):
         n = C.c_int(0)

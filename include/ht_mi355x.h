@@ -44,7 +44,8 @@ extern "C" {
 #define HT_POSE 7
 #define HT_STATE 13
 #define HT_CAM 12
-#define HT_MAX_POINTS 4096   /* sub-sampled cloud points a frame can carry: stride of the point / cloud-row arrays of the stage calls */
+#define HT_MAX_POINTS 4096   /* stride of the point / cloud-row arrays of the stage calls, and the point capacity a context starts with (ht_reserve_points) */
+#define HT_POINTS_LIMIT 76800 /* 320x240: the largest cloud a frame can carry (every pixel in range, subsample_fraction 1) */
 #define HT_ANALYSIS 84        /* floats per frame, see ht_stage_decode */
 
 typedef struct ht_ctx ht_ctx;
@@ -138,12 +139,16 @@ int ht_update_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, con
 /* ht_update_frames_*  the same call on frames that are not 64x64 (w, h multiples of 4, at most 320x240), as HandTracker::update treats them
  *                     (handtrack.h:693-785): HandSegmentVR(dimage, 0xF, {0.1, drangey}, segment_scale) feeds the CNN (:697-701), the point cloud and
  *                     FitError come from the full frame with its own camera (:703-704, :751), and segment.cam.pose goes to PoseFromScratch,
- *                     UnibodyFit and MultiStepSim (:708-713).  depth [B][h*w], cams [B][12] = the frames' cameras.  A frame with more than 4096
- *                     sub-sampled in-range points exceeds the solver's row capacity: the sync call then returns HT_ERR_ARG, after the dev call
- *                     ht_frames_overflow reports how many frames of the last call were truncated. */
+ *                     UnibodyFit and MultiStepSim (:708-713).  depth [B][h*w], cams [B][12] = the frames' cameras.  Any number of in-range points is
+ *                     taken, as handtrack.h:751 does: a call whose frames can carry more points than the context holds (w*h / subsample_fraction)
+ *                     first grows the per-point arrays (ht_reserve_points; one synchronising re-allocation, 164 bytes per point and frame), so
+ *                     ht_frames_overflow (frames of the last call whose cloud was cut) stays 0.
+ * ht_reserve_points   grows the per-point arrays ahead of time to `points` per frame (<= HT_POINTS_LIMIT; never shrinks); ht_point_capacity reads it. */
 int ht_update_frames_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int w, int h, float segment_scale, int B, float *poses_out, float *cnn_out);
 int ht_update_frames_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, int w, int h, float segment_scale, const float *d_start_poses, int B, float *d_poses_out, void *stream);
 int ht_frames_overflow(ht_ctx *ctx, int *frames_over);
+int ht_reserve_points(ht_ctx *ctx, int points);
+int ht_point_capacity(ht_ctx *ctx, int *points);
 /* ht_update_cnn_model_sync  replaces  std::vector<Pose> HandTracker::update_cnn_model(Image<unsigned short>) (handtrack.h:734-741) and, with
  *                     apply_to_handmodel != 0, void HandTracker::kickstart(Image<unsigned short>) (:743-746) for B trackers: the CNN job alone --
  *                     othermodel is NOT re-seeded from handmodel first, no main-thread passes, no "initializing = 50" rule.  poses_out [B][nb][7] =

@@ -21,7 +21,7 @@ int ho_angular_drive(const ho_physics *ph, ho_body *const *B, int rb0, int rb1, 
 ho_angular ho_cone_angle(const ho_physics *ph, ho_body *const *B, int rb0, f3 n0, int rb1, f3 n1, float limitangle_degrees);
 void ho_sanity_check(ho_model *m);
 
-#define MAXLIN 32768      /* rows of one solve: cloud points (up to a full 320x240 frame sub-sampled by 1... 4) + chamber + joints + contacts */
+#define MAXLIN (76800 + 1024)      /* rows of one solve: cloud points (up to a full 320x240 frame, sub-sampling off) + chamber + joints + contacts */
 #define MAXANG 256
 
 /* ------------------------------------------------------------------------------------------------ HTFX reader */
@@ -47,11 +47,16 @@ static int fx_open(fx_file *f, const char *path)
 	}
 	return 0;
 }
-static const fx_entry *fx_get(const fx_file *f, const char *name)
+static const fx_entry *fx_find(const fx_file *f, const char *name)      /* optional entry: NULL when absent */
 {
 	for (uint32_t i = 0; i < f->n; i++) if (!strcmp(f->e[i].name, name)) return &f->e[i];
-	fprintf(stderr, "ht_oracle: fixture entry '%s' missing\n", name);
 	return NULL;
+}
+static const fx_entry *fx_get(const fx_file *f, const char *name)
+{
+	const fx_entry *e = fx_find(f, name);
+	if (!e) fprintf(stderr, "ht_oracle: fixture entry '%s' missing\n", name);
+	return e;
 }
 static void fx_close(fx_file *f) { free(f->buf); free(f->e); }
 
@@ -98,7 +103,7 @@ static int load_model(const fx_file *f, ho_model *m)
 	if (m->nb > 2)
 	{
 		int n2 = 0;
-		const fx_entry *ic = fx_get(f, "ignore_count");
+		const fx_entry *ic = fx_find(f, "ignore_count");
 		if (ic) n2 = ((const int*)ic->data)[2]; else for (int j = 0; j < m->nb; j++) n2 += m->ignore[2][j] != 0;
 		if (n2 < 10) for (int j = 0; j < m->nb; j++) { m->ignore[2][j] = (unsigned char)(j != 2); if (j != 2) m->ignore[j][2] = 1; }
 	}

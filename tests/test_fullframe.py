@@ -3,6 +3,8 @@ segment_scale), takes the point cloud and FitError from the full-resolution fram
 
   fullframe5.htfx    BASELINE configs[4]: 128x128 frames, the 26-bone hand (tests/golden/make_model_hand26.py), 4 animation-bank rows
   fullframe320.htfx  the application's native 320x240 camera (synthetic-tracker.cpp:98), the 17-bone hand, 2 rows, ~1600 points per frame
+  fullframe320close.htfx  the same camera with a focal length of 900 pixels (a hand close to the lens): 7723 and 10628 sub-sampled points per frame,
+                     more than a context's initial point capacity (4096) -- the call grows the per-point arrays instead of cutting the cloud
 Both from the reference (`ref_harness fullframe`), two consecutive updates per frame."""
 import ctypes as C
 import os
@@ -18,6 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CASES = {
     "config5": (os.path.join(HERE, "golden", "fullframe5.htfx"), os.path.join(HERE, "golden", "model_hand26.htfx"), 26),
     "qvga": (os.path.join(HERE, "golden", "fullframe320.htfx"), ol.MODEL, 17),
+    "qvga_close": (os.path.join(HERE, "golden", "fullframe320close.htfx"), ol.MODEL, 17),
 }
 GOLD = {k: htfx.load(v[0]) for k, v in CASES.items()}
 FRAMES = [(k, f) for k in CASES for f in range(len(GOLD[k]["rows"]))]
@@ -69,8 +72,11 @@ def test_gpu_full_frame_update_matches_reference(weights, case):
         ctx.set_params(microforce=3.0, mainthreadpasses=3)
         depth = np.stack([G["f%d/depth" % f] for f in range(nf)]); cams = np.stack([G["f%d/cam" % f] for f in range(nf)])
         ctx.tracker_reset(np.stack([G["f%d/startpose" % f] for f in range(nf)]))
+        assert ctx.point_capacity() == 4096
         poses, cnn = ctx.update_frames_sync(depth, cams, 0.17, want_cnn=True)
         assert ctx.frames_overflow() == 0
+        npx = depth.shape[1] * depth.shape[2]
+        assert ctx.point_capacity() == max(4096, (npx // 4 + 63) // 64 * 64)      # grown to what a frame of this size can carry (subsample_fraction 4)
         assert np.abs(cnn - np.stack([G["f%d/cnn_output" % f] for f in range(nf)])).max() <= 2e-5
         pfe, ini = ctx.tracker_flags(nf)
         for f in range(nf):
@@ -118,3 +124,84 @@ def test_gpu_config5_full_size_properties(weights):
     for k in range(1, 16):
         assert np.array_equal(a[:64], a[64 * k:64 * (k + 1)])
     assert np.isfinite(a).all() and np.abs(np.linalg.norm(a[:, :, 3:], axis=2) - 1.0).max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_gpu_full_reset_on_clouds_over_the_default_capacity(weights):
+    """The full-reset path (PoseFromScratch + three UnibodyFit solves, handtrack.h:705-712) on the close-hand frames: 7723 / 10628 points give
+    1931 / 2657 single-body rows per UnibodyFit solve, more than the proxy body's LDS records hold (1024), so k_unibody streams them from HBM.
+    full_reset_on_error = 0 sends every frame down that path; the expected result is the pinned oracle's on the same setting."""
+    from hand_tracking_samples_amd import native
+    G, (_, model, nb) = GOLD["qvga_close"], CASES["qvga_close"]
+    nf = len(G["rows"])
+    w, h = (int(x) for x in G["dims"])
+    depth = np.stack([G["f%d/depth" % f] for f in range(nf)]); cams = np.stack([G["f%d/cam" % f] for f in range(nf)])
+    want, want_other = [], []
+    for f in range(nf):
+        orc = ol.Oracle(weights, model=model)
+        try:
+            orc.head.par.microforce = 3.0; orc.head.par.mainthreadpasses = 3; orc.head.par.full_reset_on_error = 0.0
+            orc.reset(G["f%d/startpose" % f])
+            user = np.zeros((nb, 7), np.float32)
+            orc.L.ho_update(orc.h, ol.u16ptr(np.ascontiguousarray(depth[f])), C.byref(ol.camera(cams[f], w, h)), ol.fptr(user))
+            want.append(user.copy()); want_other.append(orc.get_state(1).copy())
+        finally:
+            orc.close()
+    ctx = native.Context(model, nf)
+    try:
+        ctx.load_weights(weights)
+        ctx.set_params(microforce=3.0, mainthreadpasses=3, full_reset_on_error=0.0)
+        ctx.tracker_reset(np.stack([G["f%d/startpose" % f] for f in range(nf)]))
+        poses = ctx.update_frames_sync(depth, cams, 0.17)
+        other = ctx.get_state(1, nf)
+        assert ctx.frames_overflow() == 0
+        for f in range(nf):
+            assert not np.array_equal(want_other[f], G["f%d/uw_other_after_cnn" % f])      # the reset really changed the CNN-side model
+            do = np.abs(other[f][:, :7] - want_other[f][:, :7]).max()
+            dp = np.abs(poses[f, :, :3] - want[f][:, :3]).max(); dq = np.abs(poses[f, :, 3:] - want[f][:, 3:]).max()
+            print("full reset, %d points: |d other| %.2e |dpos| %.2e |dquat| %.2e" % (G["f%d/uw_final" % f][2], do, dp, dq))
+            assert do <= FULL_POS_TOL * 10 and dp <= FULL_POS_TOL and dq <= FULL_QUAT_TOL
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_reset_stages_bit_exact_over_the_default_capacity(weights):
+    """k_scratch and k_unibody on a 10628-point cloud (2657 rows per UnibodyFit solve: the proxy body's records stream from HBM instead of LDS),
+    stage by stage against the oracle on the same inputs: same analysis, same points, same start pose."""
+    from hand_tracking_samples_amd import native
+    G, (_, model, nb) = GOLD["qvga_close"], CASES["qvga_close"]
+    w, h = (int(x) for x in G["dims"])
+    f = 1
+    cam = ol.camera(G["f%d/cam" % f], w, h)
+    depth = np.ascontiguousarray(G["f%d/depth" % f])
+    orc = ol.Oracle(weights, model=model)
+    ctx = native.Context(model, 1)
+    try:
+        pts = np.zeros((w * h, 3), np.float32); nfull = C.c_int(0)
+        n = orc.L.ho_pointcloud(ol.u16ptr(depth), C.byref(cam), 0.1, 0.7, 4, ol.f3ptr(pts), w * h, C.byref(nfull))
+        pts = np.ascontiguousarray(pts[:n])
+        assert n == int(G["f%d/uw_final" % f][2]) and n > 4 * 1024
+        cam12 = G["f%d/cam" % f].copy()
+        an_dev = ctx.stage_decode(G["f%d/cnn_output" % f][None], cam12[None])      # also uploads the camera the pose-driven stages use
+        hcam = ol.camera(cam12, 16, 16)
+        hcam.focal.x /= 4.0; hcam.focal.y /= 4.0; hcam.principal.x /= 4.0; hcam.principal.y /= 4.0
+        an = ol.Analysis(); out = np.ascontiguousarray(G["f%d/cnn_output" % f])
+        orc.L.ho_decode(ol.fptr(out), C.byref(hcam), C.byref(an))
+        ctx.set_points([pts])
+        assert ctx.point_capacity() >= n
+        for k in range(4):
+            orc.reset(G["f%d/startpose" % f])
+            m = orc.model(1)
+            orc.L.ho_pose_from_scratch(orc.h, m, ol.f3ptr(pts), n, C.byref(an), cam.pose)
+            for _ in range(k):
+                orc.L.ho_unibody_fit(orc.h, m, ol.f3ptr(pts), n, cam.pose.position)
+            ctx.tracker_reset(G["f%d/startpose" % f][None])
+            ctx.stage_scratch_unibody(an_dev, 1, k)
+            got = ctx.get_state(1, 1)[0]
+            ref = orc.get_state(1)
+            d = np.abs(got[:, :13] - ref[:, :13]).max()
+            print("PoseFromScratch + %d UnibodyFit on %d points: max |d state| %.2e" % (k, n, d))
+            assert d <= 2e-6      # test_reset_path (64x64 tiles, records in LDS) sees the same last-place differences against the reference
+    finally:
+        ctx.close(); orc.close()

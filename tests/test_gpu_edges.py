@@ -1,7 +1,7 @@
 """Edge cases of the per-frame path on the device against the C restatement (itself pinned bit for bit on the reference's goldens):
 no point at all, a tile with every pixel in range (1024 points: the solver's single-body rows overflow their LDS pool into HBM),
 every pixel of the tile as a point (sub-sampling off: 4096 points, the capacity), a 128x128 frame entirely in range (4096 points through
-the full-frame path), a 320x240 frame entirely in range (19200 points: must be refused, not truncated), and batch independence."""
+the full-frame path), a 320x240 frame entirely in range (19200 points, 76800 with sub-sampling off: the context's point capacity grows), and batch independence."""
 import ctypes as C
 import os
 
@@ -129,11 +129,19 @@ def test_full_frames_at_and_beyond_capacity(ctx, weights):
     ref, npts = _oracle_poses(weights, d128, cam128, start, dims=(128, 128), thr=NEVER_ACCEPT)
     assert npts == [4096] and ctx.frames_overflow() == 0
     _compare("128x128 in range", got, ref, npts, exact=True)
+    # a 320x240 frame with every pixel in range: 19200 points after sub-sampling, 76800 without -- the context's point capacity grows, nothing is cut
     cam320 = np.array([[305, 305, 160, 120, 0.001, 0, 0, 0, 0, 0, 0, 1]], np.float32)
-    ctx.tracker_reset(start)
-    with pytest.raises(native.HTError, match="more in-range points"):
-        ctx.update_frames_sync(_bumpy(240, 320, 31)[None], cam320, 0.17)
-    assert ctx.frames_overflow() == 1
+    d320 = _bumpy(240, 320, 31)[None]
+    for fraction, want in ((4, 19200), (1, 76800)):
+        ctx.set_params(microforce=3.0, mainthreadpasses=3, accum_error_threshold=NEVER_ACCEPT, subsample_fraction=fraction)
+        try:
+            ctx.tracker_reset(start)
+            got = ctx.update_frames_sync(d320, cam320, 0.17)
+        finally:
+            ctx.set_params(microforce=3.0, mainthreadpasses=3, accum_error_threshold=0.0, subsample_fraction=4)
+        ref, npts = _oracle_poses(weights, d320, cam320, start, dims=(320, 240), thr=NEVER_ACCEPT, fraction=fraction)
+        assert npts == [want] and ctx.frames_overflow() == 0 and ctx.point_capacity() == want
+        _compare("320x240 in range, fraction %d" % fraction, got, ref, npts, exact=True)
 
 
 def test_frames_of_a_batch_do_not_interact(ctx):

@@ -49,6 +49,7 @@ $H slowfit $BANK 0,912,2224 $T/slowfit3.htfx
 $H train $BANK 0,912,2224 $SEED $GAIN 2 $T/train3.htfx
 # full-size frames: the application's 320x240 camera with the 17-bone hand; BASELINE configs[4] (128x128, 26 bones) both ways the reference can run it
 $H fullframe $BANK 40,1234 320,240,305 $SEED $GAIN $T/fullframe320.htfx
+$H fullframe $BANK 1504,2048 320,240,900 $SEED $GAIN $T/fullframe320close.htfx      # a hand close to the lens: 7723 / 10628 points per frame
 HT_REF_MODEL_JSON=$T/model_hand26.json $H fullframe $BANK 0,300,912,1500 128,128,163 $SEED $GAIN $T/fullframe5.htfx
 HT_REF_MODEL_JSON=$T/model_hand26.json $H config5 $BANK 0,300,912,1500 $SEED $GAIN $T/config5.htfx
 HT_REF_MODEL_JSON=$T/model_hand26.json $H fullframes $BANK 3 36 64 128,128,163 $T/frames5.htfx
@@ -56,7 +57,7 @@ HT_REF_MODEL_JSON=$T/model_hand26.json $H fullframes $BANK 3 36 64 128,128,163 $
 $H cnn128 $T/frames5.htfx 0,9,33,60 $SEED $GAIN $T/cnn128.htfx
 
 rc=0
-for f in model_hand17 model_hand26 model_chain3 golden8 scale115 slowfit3 train3 fullframe320 fullframe5 config5 cnn128; do
+for f in model_hand17 model_hand26 model_chain3 golden8 scale115 slowfit3 train3 fullframe320 fullframe320close fullframe5 config5 cnn128; do
 	if cmp -s $T/$f.htfx $G/$f.htfx; then echo "identical  $f.htfx"; else echo "DIFFERENT  $f.htfx"; rc=1; fi
 	[ $WRITE = 1 ] && cp $T/$f.htfx $G/$f.htfx
 done
