@@ -43,6 +43,25 @@ template <class T> static int dev_upload(ht_ctx *ctx, T **p, const std::vector<T
 	return HT_OK;
 }
 
+// The contact kernel's image of the collision vertices: every body padded to whole rows of 16 with copies of its vertex 0 (index 0), built from
+// the host copy (again after ht_scale).
+static int upload_padded_verts(ht_ctx *ctx)
+{
+	ht_model_dev &m = ctx->model;
+	std::vector<float4> pv;
+	for (int b = 0; b < m.nb; b++)
+	{
+		m.cvert_off[b] = (int)pv.size();
+		const int n = m.vert_off[b + 1] - m.vert_off[b], np = (n + 15) & ~15;
+		for (int k = 0; k < np; k++) { const int src = k < n ? k : 0; float4 q = ctx->h_verts[(size_t)m.vert_off[b] + src]; memcpy(&q.w, &src, 4); pv.push_back(q); }
+	}
+	m.cvert_off[m.nb] = (int)pv.size();
+	if (!ctx->d_cverts_rw) { int r = dev_alloc(ctx, &ctx->d_cverts_rw, pv.size() ? pv.size() : 1); if (r) return r; }
+	if (pv.size()) HIPCHK(ctx, hipMemcpy(ctx->d_cverts_rw, pv.data(), pv.size() * sizeof(float4), hipMemcpyHostToDevice));
+	m.cverts = ctx->d_cverts_rw;
+	return HT_OK;
+}
+
 static int load_model(ht_ctx *ctx, const char *path)
 {
 	// `path` is either the reference's model JSON (built here, a33) or a model baked earlier with ht_model_bake
@@ -134,7 +153,7 @@ static int load_model(ht_ctx *ctx, const char *path)
 	if ((r = dev_upload(ctx, &dv, verts)) || (r = dev_upload(ctx, &dp, planes)) || (r = dev_upload(ctx, &dbc, bodyc)) || (r = dev_upload(ctx, &djc, jointc))) return r;
 	m.verts = dv; m.planes = dp; m.bodyc = dbc; m.jointc = djc;
 	ctx->h_verts = verts; ctx->h_planes = planes; ctx->d_verts_rw = dv; ctx->d_planes_rw = dp; ctx->d_bodyc_rw = dbc; ctx->d_jointc_rw = djc;
-	return HT_OK;
+	return upload_padded_verts(ctx);
 }
 
 static void sync_params(ht_ctx *ctx)
@@ -230,6 +249,7 @@ extern "C" int ht_scale(ht_ctx *ctx, float s)
 	hipStream_t st = ctx->stream;
 	HIPCHK(ctx, hipStreamSynchronize(st));
 	HIPCHK(ctx, hipMemcpy(ctx->d_verts_rw, ctx->h_verts.data(), ctx->h_verts.size() * sizeof(float4), hipMemcpyHostToDevice));
+	{ const int r = upload_padded_verts(ctx); if (r) return r; }
 	HIPCHK(ctx, hipMemcpy(ctx->d_planes_rw, ctx->h_planes.data(), ctx->h_planes.size() * sizeof(float4), hipMemcpyHostToDevice));
 	HIPCHK(ctx, hipMemcpy(ctx->d_bodyc_rw, ctx->h_bodyc.data(), ctx->h_bodyc.size() * sizeof(float), hipMemcpyHostToDevice));
 	HIPCHK(ctx, hipMemcpy(ctx->d_jointc_rw, ctx->h_jointc.data(), ctx->h_jointc.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -507,7 +527,7 @@ extern "C" int ht_stage_decode(ht_ctx *ctx, const float *cnn_out, const float *c
 // ht_profile_read, so enabling the profile adds no host synchronisation to the launch sequence.
 ht_prof_scope::ht_prof_scope(ht_ctx *c, const char *name, hipStream_t s, bool minor_phase) : ctx(c), ent(nullptr), stream(s), slot(0)
 {
-	if (!c->profile || (minor_phase && !c->profile_phases)) return;
+	if (!name || !c->profile || (minor_phase && !c->profile_phases)) return;      // a null name: this scope is not recorded
 	auto it = c->prof.find(name);
 	if (it == c->prof.end()) { ht_prof_entry e; e.used = 0; e.total_ms = 0; e.launches = 0; it = c->prof.emplace(name, e).first; }
 	ht_prof_entry *e = &it->second;

@@ -187,8 +187,8 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 	const int b = blockIdx.x, t = threadIdx.x;
 	const int n = npts[b];
 	const int nsub = (n + stride - 1) / stride;
-	if (t == 0) nrows[b] = (active_flag && !active_flag[b]) ? 0 : nsub;
-	if (active_flag && !active_flag[b]) return;
+	if (active_flag && !active_flag[b]) return;      // a masked launch leaves the other frames' rows and counts alone (another launch may be producing them)
+	if (t == 0) nrows[b] = nsub;
 	if (t < 64) body_table_build(M, state + (size_t)b * M.nb * HT_STATE_STRIDE, tab, t);
 	stage_planes(M, t, CR_THREADS);
 	__syncthreads();

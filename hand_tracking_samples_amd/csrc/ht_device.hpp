@@ -95,6 +95,8 @@ struct ht_model_dev
 	int pts_bound;            // most sub-sampled points a frame of the current call can carry (<= pts_cap; 0 = pts_cap): sizes per-point LDS arrays
 	int pts_cap;              // points a frame's slot of the per-point arrays holds (stride of points / cloud rows; >= HT_MAXPTS)
 	const float4 *verts;      // all bodies back to back (com-centred collision vertices)
+	const float4 *cverts;     // the same vertices with every body padded to whole rows of 16 (pads repeat vertex 0, index 0): the contact kernel's LDS image
+	int cvert_off[HT_MAXNB + 1];
 	const float4 *planes;     // all bodies back to back (local half-space planes)
 	const float *bodyc;       // [nb][HT_BC]
 	const float *jointc;      // [nj][HT_JC]

@@ -656,6 +656,440 @@ template <int GJK_WPF> __global__ __launch_bounds__(64 * GJK_FRAMES * GJK_WPF) v
 	}
 }
 
+
+// ================================================================================================= k_contacts_coop
+// Second organisation of the narrow phase.  Two kinds of work with opposite shapes are separated:
+//   * the simplex logic of a GJK run (Separated, gjk.h:367-437) is branchy scalar code: it runs one run per lane, the runs of all the block's
+//     frames packed into as few "owner" waves as they need (so that every path through NextMinkSimplex1..3 is paid once per 64 runs);
+//   * the support scans are streaming arg-max reductions: an owner lane posts its two scans of the step (shape, direction in the shape's frame)
+//     to a list in LDS and ALL waves of the block work the list off, one scan per DPP row of 16 lanes: 16 consecutive vertices per read (the
+//     four rows of a wave read four contiguous 256-byte segments -- no bank conflicts, where one-lane-per-pair scans hit random banks), first
+//     maximum by four DPP exchanges.  The scans of a step are balanced over the whole block whatever run or frame they belong to, so a frame
+//     with many candidates or long runs costs the block its share of scans, not a lone wave its whole latency.
+// The body rotations are matrices built once per frame (qrot = qmat(q) * v, linalg.h:284-288; qmat(qconj(q)) is the transpose, entry by entry the
+// same roundings), the vertices lie padded to whole rows (pads repeat vertex 0, which cannot win against itself).  Runs whose simplex encloses the
+// origin queue for the expanding polytope, which every wave of the block takes jobs from.  Touching samples go to a per-frame pool in LDS keyed
+// by (pair, sample) and leave in key order = the reference's contact order.  The four extra samples of a contact patch (gjk.h:626-641) are a
+// second pass over the patches the first pass lists.
+#define GJK_POOL 192        // touching samples a frame can hold before they are ordered (96 contacts are kept)
+#define GJK_JMAX 40         // pairs per frame whose contact patch takes the four extra samples
+#define CO_NW 8             // waves per block
+#define CO_MAXF 4           // frames per block (as many as the LDS holds)
+#define CO_OWN 4            // owner waves per round: 256 runs in flight
+#define CO_EPAQ 32          // polytope jobs per queue round
+struct gjk_sample { float n[3], p0[3], p1[3], sep; int key, flag; };      // key = candidate * 8 + sample number; flag 1 = counts as a contact
+struct co_body { float pos[3], radius, q[4], R[9], pad[3]; };
+struct __attribute__((aligned(16))) co_req { int shape; float dx, dy, dz; };      // shape = padded vertex offset | rows of 16 vertices << 16
+struct __attribute__((aligned(16))) co_job { float p[4][3], opos[3], oq[4]; int f, bi, bj, outer; float res[4]; int capped, pad0, pad1, pad2; };
+struct __attribute__((aligned(16))) co_frame
+{
+	co_body body[HT_MAXNB];
+	unsigned char cand[HT_MAXNB * (HT_MAXNB - 1) / 2][2];
+	gjk_sample pool[GJK_POOL];
+	unsigned short jig[GJK_JMAX];      // pool slot of the first sample of each patch that takes extra samples
+	unsigned short jslot[GJK_JMAX];    // its four extra samples: slots jslot .. jslot+3
+	int ncand, off, npool, njig, joff, nepa;
+};
+struct __attribute__((aligned(16))) co_block { int nreq[2], total, jtotal, nepa, enext, pad[2]; };
+struct co_lds { co_block *H; co_frame *F; co_req *req; int *resp; co_job *jobs; };
+enum { RS_IDLE = 0, RS_INIT0, RS_INIT1, RS_ITER, RS_TET2, RS_TET3, RS_EPA, RS_WAIT, RS_HIT, RS_FAR };
+__device__ __forceinline__ void row_argmax(float &b, int &i) { amax_dpp<0xB1>(b, i); amax_dpp<0x4E>(b, i); amax_dpp<0x141>(b, i); amax_dpp<0x140>(b, i); }      // every lane of the row ends with the row's winner
+__device__ __forceinline__ m3 body_R(const co_body &b) { m3 m; m.x = V3(b.R[0], b.R[1], b.R[2]); m.y = V3(b.R[3], b.R[4], b.R[5]); m.z = V3(b.R[6], b.R[7], b.R[8]); return m; }
+
+// every wave: scans of the current list.  A row takes the two scans of a run (entries 2k and 2k+1: shape A along n, shape B along -n) and walks both
+// shapes together, two vertex rows of each per trip, so that four independent reads are in flight; a row index past a shape's end repeats its last
+// row, which cannot displace itself.  Wave w takes runs 4w.., 4(w+8).. (the scans are alike enough for a fixed split).
+__device__ __forceinline__ void co_scan(co_block &H, int buf, const co_req *req, int *resp, int lane, int wave)
+{
+	const int sub = lane & 15, row = lane >> 4;
+	const int nrun = H.nreq[buf];
+	for (int k = 4 * wave + row; k < nrun; k += 4 * CO_NW)
+	{
+		const co_req ra = req[2 * k], rb = req[2 * k + 1];
+		const float4 *va = g_sm + (ra.shape & 0xffff) + sub, *vb = g_sm + (rb.shape & 0xffff) + sub;
+		const int na = ra.shape >> 16, nb = rb.shape >> 16, nmax = na > nb ? na : nb;
+		const f32x2 axy = { ra.dx, ra.dy }, bxy = { rb.dx, rb.dy };
+		float4 qa = va[0], qb = vb[0];
+		f32x2 pa = f32x2{ qa.x, qa.y } * axy, pb = f32x2{ qb.x, qb.y } * bxy;
+		float ba = (pa.x + pa.y) + qa.z * ra.dz, bb = (pb.x + pb.y) + qb.z * rb.dz;      // = dot(vertex, direction) in the reference's order
+		int ia = __float_as_int(qa.w), ib = __float_as_int(qb.w);
+		for (int r = 1; r < nmax; r += 2)
+		{
+			const int a0 = r < na ? r : na - 1, a1 = r + 1 < na ? r + 1 : na - 1, b0 = r < nb ? r : nb - 1, b1 = r + 1 < nb ? r + 1 : nb - 1;
+			const float4 x0 = va[16 * a0], x1 = va[16 * a1], y0 = vb[16 * b0], y1 = vb[16 * b1];
+			const f32x2 p0 = f32x2{ x0.x, x0.y } * axy, p1 = f32x2{ x1.x, x1.y } * axy, s0 = f32x2{ y0.x, y0.y } * bxy, s1 = f32x2{ y1.x, y1.y } * bxy;
+			const float d0 = (p0.x + p0.y) + x0.z * ra.dz, d1 = (p1.x + p1.y) + x1.z * ra.dz, e0 = (s0.x + s0.y) + y0.z * rb.dz, e1 = (s1.x + s1.y) + y1.z * rb.dz;
+			if (ba < d0) { ba = d0; ia = __float_as_int(x0.w); }
+			if (bb < e0) { bb = e0; ib = __float_as_int(y0.w); }
+			if (ba < d1) { ba = d1; ia = __float_as_int(x1.w); }
+			if (bb < e1) { bb = e1; ib = __float_as_int(y1.w); }
+		}
+		row_argmax(ba, ia); row_argmax(bb, ib);
+		if (sub == 0) { resp[2 * k] = ia; resp[2 * k + 1] = ib; }
+	}
+}
+
+// One pass over a work list: JIG = false: the candidate pairs (Separated with the contact cut-off); JIG = true: the extra samples of the patches.
+template <bool JIG> __device__ void co_pass(const ht_model_dev &M, const co_lds &L, int nfr, epa_mem &em, float driftmax, float jiggle_sin, int t, int dbg, int *caps, int &parity, long long *cyc)
+{
+	co_block &H = *L.H;
+	const int lane = t & 63, wave = t >> 6;
+	const int total = JIG ? H.jtotal : H.total;
+	const float cutoff = JIG ? 0.0f : ((dbg & 16) ? 0.0f : driftmax);
+	for (int x0 = 0; x0 < total; x0 += 64 * CO_OWN)
+	{
+		// ---- this lane's run ----
+		const int x = x0 + t;
+		int st = RS_IDLE, fsel = 0, cidx = 0, bi = 0, bj = 1, slot = 0, iter = 0, myreq = 0, myjob = 0, shA = 0, shB = 0;
+		v3 opos = V3(0, 0, 0), jn = V3(0, 0, 1); v4 oq = V4(0, 0, 0, 1); xf ar = XF(V3(0, 0, 0), V4(0, 0, 0, 1));
+		simplex last, next;
+		last.count = 0; next.count = 0; last.v = next.v = V3(0, 0, 0);
+		for (int i = 0; i < 4; i++) { last.W[i].a = last.W[i].b = last.W[i].p = V3(0, 0, 0); last.W[i].t = 0; next.W[i] = last.W[i]; }
+		mkpoint w = last.W[0]; v3 v = V3(0, 0, 0);
+		gjk_hit hit; hit.normal = V3(0, 0, 1); hit.p0w = hit.p1w = V3(0, 0, 0); hit.separation = 0;
+		if (wave < CO_OWN && x < total)
+		{
+			int f = 0;
+			for (int g = 1; g < nfr; g++) if (x >= (JIG ? L.F[g].joff : L.F[g].off)) f = g;
+			co_frame &F = L.F[f];
+			fsel = f;
+			if (JIG)
+			{
+				const int y = x - F.joff, r = y & 3;
+				slot = F.jslot[y >> 2] + r;
+				const gjk_sample &S0 = F.pool[F.jig[y >> 2]];
+				cidx = S0.key >> 3; jn = V3(S0.n[0], S0.n[1], S0.n[2]);
+				const v3 pivot = V3(S0.p0[0], S0.p0[1], S0.p0[2]);
+				const v4 qs = quat_from_to(jn, V3(0, 0, 1)); const v3 tangent = qxdir(qs), bitangent = qydir(qs);
+				const v3 raxis = r == 0 ? tangent : r == 1 ? bitangent : r == 2 ? -tangent : -bitangent;
+				const v4 jiggle = normalize(V4(raxis * jiggle_sin, 1)); const v4 id = V4(0, 0, 0, 1);
+				ar = mul(mul(mul(XF(jn * 0.2f, id), XF(-pivot, id)), XF(V3(0, 0, 0), jiggle)), XF(pivot, id)); opos = ar.p; oq = ar.q;
+			}
+			else cidx = x - F.off;
+			bi = F.cand[cidx][0]; bj = F.cand[cidx][1];
+			shA = M.cvert_off[bi] | (((M.cvert_off[bi + 1] - M.cvert_off[bi]) >> 4) << 16); shB = M.cvert_off[bj] | (((M.cvert_off[bj + 1] - M.cvert_off[bj]) >> 4) << 16);
+			st = RS_INIT0;
+		}
+		const co_frame &FR = L.F[fsel];
+		// ---- Separated (gjk.h:367-437) unrolled into states around the one place where the two supports of a step are taken ----
+		for (;;)
+		{
+			const long long tc0 = cyc ? clock64() : 0;
+			const bool sup = st >= RS_INIT0 && st <= RS_TET3;
+			{
+				const unsigned long long m = __ballot(sup);
+				if (m)
+				{
+					int base = 0;
+					if (lane == 0) base = atomicAdd(&H.nreq[parity], __popcll(m));
+					base = __builtin_amdgcn_readfirstlane(base);
+					myreq = base + __popcll(m & ((1ull << lane) - 1ull));
+				}
+			}
+			if (sup)
+			{
+				v3 dir = V3(0, 0, 1);
+				if (st == RS_INIT1 || st == RS_ITER) dir = -v;
+				else if (st == RS_TET2) dir = orth(next.W[0].p - next.W[1].p);
+				else if (st == RS_TET3) dir = tri_normal(next.W[0].p, next.W[1].p, next.W[2].p);
+				const v3 da = mul(transpose(body_R(FR.body[bi])), JIG ? qrot(qconj(oq), dir) : dir);      // qrot(qconj(q), .)
+				const v3 db = mul(transpose(body_R(FR.body[bj])), -dir);
+				co_req ra; ra.shape = shA; ra.dx = da.x; ra.dy = da.y; ra.dz = da.z;
+				co_req rb; rb.shape = shB; rb.dx = db.x; rb.dy = db.y; rb.dz = db.z;
+				L.req[2 * myreq] = ra; L.req[2 * myreq + 1] = rb;
+			}
+			if (cyc) cyc[0] += clock64() - tc0;
+			__syncthreads();
+			if (H.nreq[parity] == 0) break;
+			if (t == 0) H.nreq[parity ^ 1] = 0;
+			const long long ts0 = cyc ? clock64() : 0;
+			co_scan(H, parity, L.req, L.resp, lane, wave);
+			if (cyc) { cyc[1] += clock64() - ts0; cyc[3] += 1; }
+			__syncthreads();
+			const long long tc1 = cyc ? clock64() : 0;
+			if (cyc) cyc[4] += tc1 - ts0;
+			parity ^= 1;
+			if (sup)
+			{
+				const co_body &BA = FR.body[bi], &BB = FR.body[bj];
+				const float4 qa = g_sm[(shA & 0xffff) + L.resp[2 * myreq]], qb = g_sm[(shB & 0xffff) + L.resp[2 * myreq + 1]];
+				mkpoint m;
+				const v3 sa = V3(BA.pos[0], BA.pos[1], BA.pos[2]) + mul(body_R(BA), V3(qa.x, qa.y, qa.z));
+				m.a = JIG ? opos + qrot(oq, sa) : sa;
+				m.b = V3(BB.pos[0], BB.pos[1], BB.pos[2]) + mul(body_R(BB), V3(qb.x, qb.y, qb.z));
+				m.p = m.a - m.b; m.t = 0;
+				if (st == RS_INIT0) { v = m.p; last.v = v; st = RS_INIT1; }
+				else if (st == RS_TET2) { next.W[2] = m; next.count = 3; st = RS_TET3; }
+				else if (st == RS_TET3) { next.W[3] = m; next.count = 4; st = RS_EPA; }
+				else
+				{
+					bool fin = false;
+					if (st == RS_INIT1)
+					{
+						w = m; next.W[0] = w; next.W[0].t = 1.0f; next.v = w.p; next.count = 1;      // NextMinkSimplex0
+						iter = 1;                                                                    // first trip of the while: !iter++
+						last = next; v = last.v; st = RS_ITER;
+					}
+					else
+					{
+						w = m;
+						bool far = false;
+						if (cutoff > 0.0f) { const float wv = dot(w.p, v); far = wv > 0.0f && wv > (cutoff * 1.01f + 1e-6f) * length(v); }
+						if (far) st = RS_FAR;
+						else if (dot(w.p, v) >= dot(v, v) - 0.00001f - 0.00001f * dot(v, v)) fin = true;
+						else
+						{
+							if (last.count == 1) next1(next, last, w); else if (last.count == 2) next2(next, last, w); else next3(next, last, w);
+							if (is_zero(next.v)) st = next.count == 2 ? RS_TET2 : next.count == 3 ? RS_TET3 : RS_EPA;
+							else if (dot(next.v, next.v) >= dot(last.v, last.v)) fin = true;
+							else
+							{
+								iter++;                                                              // while(!iter++ || (cond && iter++ < 100))
+								bool go = dot(w.p, v) < dot(v, v) - 0.00001f;
+								if (go) { go = iter < 100; iter++; }
+								if (!go) fin = true; else { last = next; v = last.v; }
+							}
+						}
+					}
+					if (fin) { hit = calcpoints(last); st = RS_HIT; }
+				}
+			}
+			if (cyc) cyc[0] += clock64() - tc1;
+		}
+		// ---- expanding polytope for the runs whose simplex encloses the origin: a queue every wave takes jobs from ----
+		const long long te0 = cyc ? clock64() : 0;
+		for (;;)
+		{
+			if (st == RS_EPA)
+			{
+				const int j = atomicAdd(&H.nepa, 1);
+				if (j < CO_EPAQ)
+				{
+					co_job &J = L.jobs[j];
+					for (int k = 0; k < 4; k++) { J.p[k][0] = next.W[k].p.x; J.p[k][1] = next.W[k].p.y; J.p[k][2] = next.W[k].p.z; }
+					J.opos[0] = opos.x; J.opos[1] = opos.y; J.opos[2] = opos.z; J.oq[0] = oq.x; J.oq[1] = oq.y; J.oq[2] = oq.z; J.oq[3] = oq.w;
+					J.f = fsel; J.bi = bi; J.bj = bj; J.outer = JIG ? 1 : 0;
+					myjob = j; st = RS_WAIT;
+				}
+			}
+			__syncthreads();
+			const int nj = H.nepa < CO_EPAQ ? H.nepa : CO_EPAQ;
+			if (nj == 0) break;
+			for (;;)
+			{
+				int j = 0;
+				if (lane == 0) j = atomicAdd(&H.enext, 1);
+				j = __builtin_amdgcn_readfirstlane(j);
+				if (j >= nj) break;
+				co_job &J = L.jobs[j];
+				const co_frame &F = L.F[J.f];
+				support_t Ab, Bb;
+				const co_body &BA = F.body[J.bi], &BB = F.body[J.bj];
+				Ab.voff = M.cvert_off[J.bi]; Ab.n = M.vert_off[J.bi + 1] - M.vert_off[J.bi]; Ab.pos = V3(BA.pos[0], BA.pos[1], BA.pos[2]); Ab.q = V4(BA.q[0], BA.q[1], BA.q[2], BA.q[3]);
+				Ab.outer = J.outer; Ab.opos = V3(J.opos[0], J.opos[1], J.opos[2]); Ab.oq = V4(J.oq[0], J.oq[1], J.oq[2], J.oq[3]); Ab.sub = 0; Ab.grp = 1;
+				Bb.voff = M.cvert_off[J.bj]; Bb.n = M.vert_off[J.bj + 1] - M.vert_off[J.bj]; Bb.pos = V3(BB.pos[0], BB.pos[1], BB.pos[2]); Bb.q = V4(BB.q[0], BB.q[1], BB.q[2], BB.q[3]);
+				Bb.outer = 0; Bb.opos = V3(0, 0, 0); Bb.oq = V4(0, 0, 0, 1); Bb.sub = 0; Bb.grp = 1;
+				bool capped = false;
+				const v4 mpp = (dbg & 32) ? V4(0, 0, 1, -0.001f) : expanding_polytope_wave(em, V3(J.p[0][0], J.p[0][1], J.p[0][2]), V3(J.p[1][0], J.p[1][1], J.p[1][2]), V3(J.p[2][0], J.p[2][1], J.p[2][2]),
+				                                                                           V3(J.p[3][0], J.p[3][1], J.p[3][2]), Ab, Bb, lane, nullptr, capped);
+				if (lane == 0) { J.res[0] = mpp.x; J.res[1] = mpp.y; J.res[2] = mpp.z; J.res[3] = mpp.w; if (capped && caps) atomicAdd(caps, 1); atomicAdd(&L.F[J.f].nepa, 1); }
+			}
+			__syncthreads();
+			if (st == RS_WAIT)
+			{
+				const co_job &J = L.jobs[myjob];
+				hit.normal = -V3(J.res[0], J.res[1], J.res[2]);                                  // gjk.h:417-423
+				hit.separation = fmin_std(0.0f, J.res[3]);
+				const v4 bw = inverse_w(next.W[0].p, next.W[1].p, next.W[2].p, next.W[3].p);
+				hit.p0w = ((next.W[0].a * bw.x + next.W[1].a * bw.y) + next.W[2].a * bw.z) + next.W[3].a * bw.w;
+				hit.p1w = ((next.W[0].b * bw.x + next.W[1].b * bw.y) + next.W[2].b * bw.z) + next.W[3].b * bw.w;
+				st = RS_HIT;
+			}
+			__syncthreads();
+			if (t == 0) { H.nepa = 0; H.enext = 0; }
+			__syncthreads();
+		}
+		if (cyc) cyc[2] += clock64() - te0;
+		// ---- finished runs: the sample goes to the frame's pool ----
+		if (st == RS_HIT || st == RS_FAR)
+		{
+			co_frame &F = L.F[fsel];
+			if (JIG)
+			{
+				// gjk.h:632-636: the sample is reported on the undisturbed shape, along the patch normal
+				const v3 p0 = apply(inverse(ar), hit.p0w);
+				gjk_sample &S = F.pool[slot];
+				S.n[0] = jn.x; S.n[1] = jn.y; S.n[2] = jn.z; S.p0[0] = p0.x; S.p0[1] = p0.y; S.p0[2] = p0.z; S.p1[0] = hit.p1w.x; S.p1[1] = hit.p1w.y; S.p1[2] = hit.p1w.z; S.sep = dot(jn, p0 - hit.p1w);
+			}
+			else if (st == RS_HIT && !(hit.separation > driftmax))
+			{
+				const float dmin = fminf(M.bodyc[bi * HT_BC + HT_BC_DIAM], M.bodyc[bj * HT_BC + HT_BC_DIAM]);
+				const bool jig = !(dmin < 0.049f);      // otherwise every extra sample is rejected by the 0.05 m proximity test (see the header)
+				const int need = jig ? 5 : 1;
+				const int s0 = atomicAdd(&F.npool, need);
+				if (s0 + need <= GJK_POOL)
+				{
+					gjk_sample &S = F.pool[s0];
+					S.n[0] = hit.normal.x; S.n[1] = hit.normal.y; S.n[2] = hit.normal.z; S.p0[0] = hit.p0w.x; S.p0[1] = hit.p0w.y; S.p0[2] = hit.p0w.z;
+					S.p1[0] = hit.p1w.x; S.p1[1] = hit.p1w.y; S.p1[2] = hit.p1w.z; S.sep = hit.separation; S.key = cidx * 8; S.flag = 1;
+					if (jig)
+					{
+						for (int r = 0; r < 4; r++) { F.pool[s0 + 1 + r].key = cidx * 8 + 1 + r; F.pool[s0 + 1 + r].flag = 0; }
+						const int jx = atomicAdd(&F.njig, 1);
+						if (jx < GJK_JMAX) { F.jig[jx] = (unsigned short)s0; F.jslot[jx] = (unsigned short)(s0 + 1); }
+						else if (caps) atomicAdd(caps + 1, 1);
+					}
+				}
+				else if (caps) atomicAdd(caps + 1, 1);
+			}
+		}
+		__syncthreads();
+	}
+}
+
+__global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, const float *__restrict__ state, float driftmax, float jiggle_sin, const int *__restrict__ active_flag,
+                                                              float *__restrict__ contacts, int *__restrict__ ncontacts, int B, int nfr, int nvp, int dbg, int *__restrict__ caps)
+{
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	// LDS: padded vertices | block header | frames | scan list | answers | polytope jobs | polytope meshes
+	unsigned char *base = reinterpret_cast<unsigned char *>(g_sm + nvp);
+	co_lds L;
+	L.H = reinterpret_cast<co_block *>(base); base += sizeof(co_block);
+	L.F = reinterpret_cast<co_frame *>(base); base += (size_t)nfr * sizeof(co_frame);
+	L.req = reinterpret_cast<co_req *>(base); base += (size_t)CO_OWN * 64 * 2 * sizeof(co_req);
+	L.resp = reinterpret_cast<int *>(base); base += (size_t)CO_OWN * 64 * 2 * sizeof(int);
+	L.jobs = reinterpret_cast<co_job *>(base); base += (size_t)CO_EPAQ * sizeof(co_job);
+	epa_mem &em = *reinterpret_cast<epa_mem *>(base + wave * gjk_wave_stride());
+	co_block &H = *L.H;
+	const long long t_begin = (dbg & 2048) ? clock64() : 0;
+	if (active_flag)      // a masked launch: blocks without a live frame leave at once (a handful of frames of a large batch take this kernel on their own)
+	{
+		bool any = false;
+		for (int f = 0; f < nfr; f++) { const int b = blockIdx.x * nfr + f; any = any || (b < B && active_flag[b] != 0); }
+		if (!any) return;
+	}
+	for (int k = t; k < nvp; k += 64 * CO_NW) g_sm[k] = M.cverts[k];      // the padded vertex image (ht_model_dev::cverts), 16 vertices per row
+	// broad phase in the reference's pair order (physics.h:453-457), one wave per frame, compacted with a ballot; pair index -> (i, j), i < j, row-major
+	if (wave < nfr)
+	{
+		co_frame &F = L.F[wave];
+		const int b = blockIdx.x * nfr + wave;
+		const bool live = b < B && !(active_flag && !active_flag[b]);      // frames outside the active set keep whatever another launch produced for them
+		if (live && lane < M.nb)
+		{
+			const float *s = state + ((size_t)b * M.nb + lane) * HT_STATE_STRIDE;
+			co_body &Y = F.body[lane];
+			for (int i = 0; i < 3; i++) Y.pos[i] = s[i];
+			for (int i = 0; i < 4; i++) Y.q[i] = s[3 + i];
+			Y.radius = M.bodyc[lane * HT_BC + HT_BC_RADIUS];
+			const m3 R = qmat(V4(s[3], s[4], s[5], s[6]));
+			Y.R[0] = R.x.x; Y.R[1] = R.x.y; Y.R[2] = R.x.z; Y.R[3] = R.y.x; Y.R[4] = R.y.y; Y.R[5] = R.y.z; Y.R[6] = R.z.x; Y.R[7] = R.z.y; Y.R[8] = R.z.z;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		const int npairs = M.nb * (M.nb - 1) / 2;
+		int nc = 0;
+		for (int base2 = 0; live && base2 < npairs; base2 += 64)
+		{
+			const int pidx = base2 + lane;
+			int i = 0, rem = pidx;
+			while (i < M.nb - 1 && rem >= M.nb - 1 - i) { rem -= M.nb - 1 - i; i++; }
+			const int j = i + 1 + rem;
+			bool keep = false;
+			if (pidx < npairs)
+			{
+				keep = (M.collide[i] & M.collide[j] & 2) != 0;
+				v3 d = V3(F.body[j].pos[0], F.body[j].pos[1], F.body[j].pos[2]) - V3(F.body[i].pos[0], F.body[i].pos[1], F.body[i].pos[2]);
+				if (length(d) > F.body[i].radius + F.body[j].radius) keep = false;
+				if (M.ignore[i] & (1u << j)) keep = false;
+			}
+			if (dbg & 8) keep = false;
+			const unsigned long long m = __ballot(keep);
+			if (keep) { const int dst = nc + __popcll(m & ((1ull << lane) - 1ull)); F.cand[dst][0] = (unsigned char)i; F.cand[dst][1] = (unsigned char)j; }
+			nc += __popcll(m);
+		}
+		for (int e = lane; e < GJK_POOL; e += 64) { F.pool[e].flag = 0; F.pool[e].key = 0x7fffffff; }
+		if (lane == 0) { F.ncand = nc; F.npool = 0; F.njig = 0; F.nepa = 0; }
+	}
+	__syncthreads();
+	if (t == 0)
+	{
+		int tot = 0;
+		for (int f = 0; f < nfr; f++) { L.F[f].off = tot; tot += L.F[f].ncand; }
+		H.total = tot; H.jtotal = 0; H.nreq[0] = H.nreq[1] = 0; H.nepa = 0; H.enext = 0;
+	}
+	__syncthreads();
+	long long cyc[5] = { 0, 0, 0, 0, 0 };
+	const long long t_pro = (dbg & 2048) ? clock64() : 0;
+	int parity = 0;
+	co_pass<false>(M, L, nfr, em, driftmax, jiggle_sin, t, dbg, caps, parity, (dbg & 2048) ? cyc : nullptr);
+	if (t == 0)
+	{
+		int tot = 0;
+		for (int f = 0; f < nfr; f++) { co_frame &F = L.F[f]; if (F.njig > GJK_JMAX) F.njig = GJK_JMAX; if (F.npool > GJK_POOL) F.npool = GJK_POOL; F.joff = tot; tot += 4 * F.njig; }
+		H.jtotal = tot;
+	}
+	__syncthreads();
+	if (H.jtotal > 0)
+	{
+		co_pass<true>(M, L, nfr, em, driftmax, jiggle_sin, t, dbg, caps, parity, nullptr);
+		// which of the extra samples count (gjk.h:637-640): one lane per patch, samples in order, each against the ones accepted before it
+		for (int f = 0; f < nfr; f++)
+		{
+			co_frame &F = L.F[f];
+			for (int jx = t; jx < F.njig; jx += 64 * CO_NW)
+			{
+				int acc[5]; int hc = 1; acc[0] = F.jig[jx];
+				for (int r = 0; r < 4; r++)
+				{
+					gjk_sample &S = F.pool[F.jslot[jx] + r];
+					const v3 p0 = V3(S.p0[0], S.p0[1], S.p0[2]), p1 = V3(S.p1[0], S.p1[1], S.p1[2]);
+					bool match = false;
+					for (int q = 0; q < 4; q++) if (q < hc && !match) { const gjk_sample &Q = F.pool[acc[q]]; match = length(p0 - V3(Q.p0[0], Q.p0[1], Q.p0[2])) < 0.05f || length(p1 - V3(Q.p1[0], Q.p1[1], Q.p1[2])) < 0.05f; }
+					if (!match) { S.flag = 1; acc[hc] = F.jslot[jx] + r; hc++; }
+				}
+			}
+		}
+		__syncthreads();
+	}
+	// ---- the samples of a frame in key order = the reference's contact order; one wave per frame ----
+	if (wave < nfr)
+	{
+		co_frame &F = L.F[wave];
+		const int b = blockIdx.x * nfr + wave;
+		const bool live = b < B && !(active_flag && !active_flag[b]);
+		const int np = F.npool;
+		int total = 0;
+		for (int e0 = 0; e0 < np; e0 += 64)
+		{
+			const int e = e0 + lane;
+			const bool valid = e < np && F.pool[e].flag != 0;
+			total += __popcll(__ballot(valid));
+			if (valid)
+			{
+				const gjk_sample S = F.pool[e];
+				int rank = 0;
+				for (int o = 0; o < np; o++) rank += (F.pool[o].flag != 0 && F.pool[o].key < S.key) ? 1 : 0;
+				if (live && rank < HT_MAXCONTACT)
+				{
+					const int c = S.key >> 3;
+					float4 *o = reinterpret_cast<float4 *>(contacts + ((size_t)b * HT_MAXCONTACT + rank) * HT_CONTACT);
+					o[0] = make_float4((float)F.cand[c][0], (float)F.cand[c][1], S.n[0], S.n[1]);
+					o[1] = make_float4(S.n[2], S.p0[0], S.p0[1], S.p0[2]);
+					o[2] = make_float4(S.p1[0], S.p1[1], S.p1[2], S.sep);
+				}
+			}
+		}
+		if (live && lane == 0) { ncontacts[b] = total < HT_MAXCONTACT ? total : HT_MAXCONTACT; if (total > HT_MAXCONTACT && caps) atomicAdd(caps + 1, total - HT_MAXCONTACT); }
+		if ((dbg & 2048) && live && lane == 0 && total < HT_MAXCONTACT - 1)      // timing experiments: per-frame statistics accumulate in the last contact slot
+		{
+			float *o = contacts + ((size_t)b * HT_MAXCONTACT + HT_MAXCONTACT - 1) * HT_CONTACT;
+			o[0] += 1.0f; o[1] += (float)cyc[0]; o[2] += (float)cyc[2]; o[3] += (float)F.nepa; o[4] += (float)cyc[3]; o[5] += (float)cyc[1]; o[6] += (float)cyc[4]; o[7] += (float)(clock64() - t_begin);
+			o[8] += (float)F.ncand; o[9] += (float)F.njig; o[10] += (float)total; o[11] += (float)(t_pro - t_begin);
+		}
+	}
+}
+
 size_t ht_contacts_workspace_bytes(int B) { (void)B; return 16; }      // the polytope mesh lives in LDS; the workspace holds the capacity counters (polytope runs cut short, contacts dropped, k_solve's angular overflow)
 
 void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s)
@@ -664,14 +1098,38 @@ void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftma
 	const int dbg = ht_tuning_flags();
 	static bool attr_set[64];                 // per device: the attribute belongs to the device's copy of the code object
 	int dev = 0; (void)hipGetDevice(&dev); dev &= 63;
-	const int wpf = M.nb * (M.nb - 1) / 2 > 200 ? 2 : 1;
-	const size_t smem = (size_t)M.vert_off[M.nb] * sizeof(float4) + GJK_FRAMES * gjk_frame_stride() + GJK_FRAMES * wpf * gjk_wave_stride();
 	if (!attr_set[dev])
 	{
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_contacts<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_contacts<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_contacts_coop), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		attr_set[dev] = true;
 	}
+	// Which organisation: the cooperative kernel owns a CU per block (152 KB of LDS, 255 VGPRs) and finishes a launch of up to a few frames per CU
+	// sooner; once the batch is many times the CU count the lane-per-pair kernel's smaller blocks (61 KB, two per CU) share the CUs with the
+	// cloud-row kernel of the same step, and the whole step is faster with it (measured cross-over between 2048 and 4096 frames).
+	static int coop_max = -1;
+	if (coop_max < 0)
+	{
+		coop_max = 2048;
+#ifdef HT_TUNING
+		if (const char *e = getenv("HT_CONTACTS_COOP_MAX")) coop_max = atoi(e);
+#endif
+	}
+	if (B <= coop_max)
+	{
+		// as many frames per block as the LDS holds beside the padded vertex copy, the scan list and the waves' polytope areas (4 for the 17-bone hand)
+		const int nvp = M.cvert_off[M.nb];
+		const size_t fixed = (size_t)nvp * sizeof(float4) + sizeof(co_block) + (size_t)CO_OWN * 64 * 2 * (sizeof(co_req) + sizeof(int)) + CO_EPAQ * sizeof(co_job) + CO_NW * gjk_wave_stride();
+		int nfr = CO_MAXF;
+		while (nfr > 1 && fixed + nfr * sizeof(co_frame) > 160 * 1024) nfr--;
+		if (B < nfr) nfr = B;
+		const size_t smem = fixed + nfr * sizeof(co_frame);
+		hipLaunchKernelGGL(k_contacts_coop, dim3((B + nfr - 1) / nfr), dim3(64 * CO_NW), smem, s, M, state, driftmax, jiggle_sin, active_flag, contacts, ncontacts, B, nfr, nvp, dbg, caps);
+		return;
+	}
+	const int wpf = M.nb * (M.nb - 1) / 2 > 200 ? 2 : 1;
+	const size_t smem = (size_t)M.vert_off[M.nb] * sizeof(float4) + GJK_FRAMES * gjk_frame_stride() + GJK_FRAMES * wpf * gjk_wave_stride();
 	const dim3 grid((B + GJK_FRAMES - 1) / GJK_FRAMES);
 	if (wpf == 2) hipLaunchKernelGGL(k_contacts<2>, grid, dim3(64 * GJK_FRAMES * 2), smem, s, M, state, driftmax, jiggle_sin, active_flag, contacts, ncontacts, B, dbg, caps);
 	else hipLaunchKernelGGL(k_contacts<1>, grid, dim3(64 * GJK_FRAMES), smem, s, M, state, driftmax, jiggle_sin, active_flag, contacts, ncontacts, B, dbg, caps);

@@ -28,6 +28,7 @@ struct ht_ctx
 	std::vector<float4> h_verts, h_planes;                        // host copies of the model geometry (ht_scale rewrites them)
 	float *d_train = nullptr;                                    // training arena: layer outputs, errors, split-K partial sums (allocated on first use)
 	float *d_sf_ref = nullptr, *d_sf_crays = nullptr;             // slowfit inputs [B][nb][7], [B][8][4] (allocated on first use)
+	float4 *d_cverts_rw = nullptr;                                // padded copy of the collision vertices (ht_model_dev::cverts)
 	float4 *d_verts_rw = nullptr, *d_planes_rw = nullptr; float *d_bodyc_rw = nullptr, *d_jointc_rw = nullptr;
 	std::vector<void *> allocs;
 	std::map<std::string, ht_prof_entry> prof;

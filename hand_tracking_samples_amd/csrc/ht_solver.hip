@@ -204,9 +204,9 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 {
 	__shared__ lds_t<POOL_FLOATS, NSUM_> S;
 	const int b = blockIdx.x, lane = threadIdx.x;
+	if (a.active_flag && !a.active_flag[b]) return;                // first: a launch never touches another launch's frames, not even their retry flags
 	if (FIRST) { if (lane == 0) a.retry[b] = 0; }
 	else if (!a.retry[b]) return;                                 // the large build only takes the frames the first one passed on
-	if (a.active_flag && !a.active_flag[b]) return;
 	const int nb = M.nb, nj = M.nj;
 	float *st = a.state + (size_t)b * nb * HT_STATE_STRIDE;
 	const float dt = ph.deltaT;

@@ -35,11 +35,14 @@ static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int 
 // Fork/join helpers: the row-producing kernels of one fit step only read the pose, so they run side by side on two extra streams
 // and the solve waits for all of them (each of them is latency-bound on its slowest frame and leaves most of the chip idle).
 static void fork(ht_ctx *ctx, hipStream_t s) { (void)hipEventRecord(ctx->ev_fork, s); for (int i = 0; i < 2; i++) (void)hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0); }
+static void fork1(ht_ctx *ctx, hipStream_t s, int i) { (void)hipEventRecord(ctx->ev_fork, s); (void)hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0); }
+static void join1(ht_ctx *ctx, hipStream_t s, int i) { (void)hipEventRecord(ctx->ev_join[i], ctx->side[i]); (void)hipStreamWaitEvent(s, ctx->ev_join[i], 0); }
 static void join(ht_ctx *ctx, hipStream_t s, int n) { for (int i = 0; i < n; i++) { (void)hipEventRecord(ctx->ev_join[i], ctx->side[i]); (void)hipStreamWaitEvent(s, ctx->ev_join[i], 0); } }
 
 // HandTracker::MultiStepSim on othermodel (handtrack.h:642-690)
-// `first_active`: when given, step 0 only touches the frames whose flag is set (the others did it already, see run_update)
-static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int to_step = 1 << 30, const int *active = nullptr, bool first_contacts_done = false)
+// `active`: when given, only the frames whose flag is set are touched.  `side`: index of the side stream the cloud rows of a step run on beside the
+// contacts (-1: everything in order on s).  `prof`: bracket the solves for the profile (off for a concurrent second instance).
+static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int to_step = 1 << 30, const int *active = nullptr, bool first_contacts_done = false, int side = 0, bool prof = true)
 {
 	const ht_params &p = ctx->par;
 	for (int st = from_step; st < p.steps && st < to_step; st++)
@@ -49,12 +52,12 @@ static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int 
 		const bool cloud = (st >= p.steps_cloudstart) && !p.angles_only;
 		const bool coll = ctx->phys.use_collision != 0;
 		static const bool no_side = ht_tuning_env("HT_NO_SIDE");      // timing experiments (-DHT_TUNING builds only)
-		const bool par = cloud && coll && !ctx->profile_phases && !no_side;
-		if (par) fork(ctx, s);
-		if (cloud) { ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, active, 4, 1, 2, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[0] : s); }
+		const bool par = side >= 0 && cloud && coll && !ctx->profile_phases && !no_side;
+		if (par) fork1(ctx, s, side);
+		if (cloud) { ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, active, 4, 1, 2, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[side] : s); }
 		if (coll && !(first_contacts_done && st == from_step)) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, active, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s); }
-		if (par) join(ctx, s, 1);
-		ht_prof_scope ps(ctx, "solve", s);
+		if (par) join1(ctx, s, side);
+		ht_prof_scope ps(ctx, prof ? "solve" : nullptr, s);
 		solve_step(ctx, 1, nullptr, nullptr, cloud, coll, active, angles, st < p.steps_palmangle ? 10000.0f : 0.0f, rays, 1, 1, B, s);
 	}
 }
@@ -154,7 +157,9 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 	{
 		(void)hipEventRecord(ctx->ev_join[1], ctx->side[1]); (void)hipStreamWaitEvent(s, ctx->ev_join[1], 0);
 		// the full-reset path touches few frames but is long (3 sequential single-body solves): it runs on a side stream while step 0 of
-		// MultiStepSim (which uses no cloud rows) proceeds for all other frames; the reset frames then do their step 0 on their own
+		// MultiStepSim (which uses no cloud rows) proceeds for all other frames; the reset frames then do their step 0 on their own.
+		// (Taking the reset frames through ALL their steps on the side stream was measured: their five few-frame steps are pure latency and end
+		// later than the main stream's full-batch steps plus this one extra step, 4.6 against 4.5 ms.)
 		fork(ctx, s);
 		reset_path(ctx, ctx->d_flags, p.steps_unibody, B, ctx->side[0], s);
 		multistep(ctx, B, s, 0, 1, ctx->d_nflags, true);

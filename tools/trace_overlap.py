@@ -14,5 +14,8 @@ for t, d in pts:
     if last is not None: hist[depth] += t - last
     depth += d; last = t
 print("time by number of kernels in flight (ms):", {k: round(v / 1e6, 2) for k, v in sorted(hist.items())})
-if len(sys.argv) > 2:
+if len(sys.argv) == 3:
     for s, e, q, n in ev[-int(sys.argv[2]):]: print("%10.1f %8.1f q%s %s" % ((s - t0) / 1e3, (e - s) / 1e3, q, n))
+if len(sys.argv) > 3:      # window: first kernel index, count
+    a, n = int(sys.argv[2]), int(sys.argv[3])
+    for s, e, q, nm in ev[a:a + n]: print("%10.1f %8.1f q%s %s" % ((s - t0) / 1e3, (e - s) / 1e3, q, nm))
