@@ -188,7 +188,8 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 	const int n = npts[b];
 	const int nsub = (n + stride - 1) / stride;
 	if (active_flag && !active_flag[b]) return;      // a masked launch leaves the other frames' rows and counts alone (another launch may be producing them)
-	if (t == 0) nrows[b] = nsub;
+	if ((int)blockIdx.y * CH >= nsub && blockIdx.y > 0) return;      // gridDim.y blocks share a frame's passes (a row only depends on its own point)
+	if (t == 0 && blockIdx.y == 0) nrows[b] = nsub;
 	if (t < 64) body_table_build(M, state + (size_t)b * M.nb * HT_STATE_STRIDE, tab, t);
 	stage_planes(M, t, CR_THREADS);
 	__syncthreads();
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 	const v3 origin = use_cam_origin ? V3(cam[5], cam[6], cam[7]) : V3(0, 0, 0);
 	int npmax = 0;
 	for (int bb = 0; bb < M.nb; bb++) npmax = max(npmax, M.plane_off[bb + 1] - M.plane_off[bb]);
-	for (int base = 0; base < nsub; base += CH)
+	for (int base = blockIdx.y * CH; base < nsub; base += gridDim.y * CH)
 	{
 		const int i = base + t;
 		const bool active = t < CH && i < nsub;
@@ -366,7 +367,16 @@ __global__ __launch_bounds__(64) void k_chamber(ht_model_dev M, const float *__r
 void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const float *cams, const int *active_flag, int stride, int use_cam_origin, int mode,
                           const ht_params &par, float *rows, int *nrows, int B, hipStream_t s, float sf_ratio, float sf_wrist)
 {
-	hipLaunchKernelGGL(k_cloud_rows, dim3(B), dim3(CR_THREADS), (size_t)M.plane_off[M.nb] * sizeof(float4), s, M, state, pts, npts, cams, active_flag, stride, use_cam_origin, mode, par.microforce,
+	// blocks per frame: a frame's passes of CH points are independent, so while the batch leaves CUs idle they are spread over up to `split` blocks
+	// (each pays the prologue -- body table, 25 KB of planes into LDS -- again, which is why a large batch keeps one block per frame)
+	const int pts_max = M.pts_bound > 0 ? M.pts_bound : M.pts_cap, passes = ((pts_max + stride - 1) / stride + CH - 1) / CH;
+	int split = B <= 2048 ? 4 : 1;
+#ifdef HT_TUNING
+	if (const char *e = getenv("HT_CLOUD_SPLIT")) split = atoi(e);
+#endif
+	if (split > passes) split = passes;
+	if (split < 1) split = 1;
+	hipLaunchKernelGGL(k_cloud_rows, dim3(B, split), dim3(CR_THREADS), (size_t)M.plane_off[M.nb] * sizeof(float4), s, M, state, pts, npts, cams, active_flag, stride, use_cam_origin, mode, par.microforce,
 	                   mode == 4 ? sf_ratio : par.physics_weak_force, mode == 4 ? sf_wrist : par.cloudforce_max_point, par.cloudforce_max_sum, par.unibody_force, rows, nrows);
 }
 void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, int w, int h, float scale, float *err, int B, hipStream_t s)

@@ -312,6 +312,79 @@ __global__ __launch_bounds__(256 * WN) void k_fc(const float *__restrict__ A, co
 	}
 }
 
+// ------------------------------------------------------------------------------------------------- k_fc144
+// The last layer (2048 -> 2304) on a 64 x 144 block tile: 1024 frames x 2304 outputs are then exactly 16 x 16 = 256 blocks, one per CU (the
+// 128 x 96 tile of k_fc<.,3> makes 192 blocks and leaves a quarter of the chip idle; 128 x 64 makes 288 and a second, nearly empty round).
+// 144 is nine 16-wide tiles, so the arithmetic is v_mfma_f32_16x16x4_f32: 12 waves as 4 (rows) x 3 (columns), a wave holds three 16 x 16
+// accumulators that share one A fragment.  LDS: A as [k][row] with stride 81, B as [k][col] with stride 144 (16 mod 32: the four k-groups of a
+// fragment read land in disjoint banks), double-buffered 32-deep slabs like k_fc (64-deep slabs were measured slower: 136 against 105 us);
+// accumulation starts from the bias and runs in ascending k.
+#define F2_BM 64
+#define F2_BN 144
+#define F2_BK 32
+#define F2_LDA 81
+__global__ __launch_bounds__(768) void k_fc144(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K)
+{
+	__shared__ float As[2][F2_BK * F2_LDA];
+	__shared__ __attribute__((aligned(16))) float Bs[2][F2_BK * F2_BN];
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / 3, wn = wave % 3;
+	const int m0 = blockIdx.y * F2_BM, n0 = blockIdx.x * F2_BN;
+	// staging: A tile = 64 rows x F2_BK k as float4 along k (row = e / (F2_BK / 4)); B tile = F2_BK x 144 as float4 along the columns, 36 per k-row
+	constexpr int NA4 = F2_BM * F2_BK / 4, NB4 = F2_BK * 36, NAT = (NA4 + 767) / 768, NBT = (NB4 + 767) / 768, KQ = F2_BK / 4;
+	float4 ra[NAT], rb[NBT];
+	auto gload = [&](int k0) {
+#pragma unroll
+		for (int i = 0; i < NAT; i++) { const int e = t + 768 * i, row = m0 + e / KQ; ra[i] = (e < NA4 && row < M) ? *reinterpret_cast<const float4 *>(A + (size_t)row * K + k0 + (e % KQ) * 4) : make_float4(0, 0, 0, 0); }
+#pragma unroll
+		for (int i = 0; i < NBT; i++) { const int e = t + 768 * i; if (e < NB4) rb[i] = *reinterpret_cast<const float4 *>(W + (size_t)(k0 + e / 36) * N + n0 + (e % 36) * 4); }
+	};
+	auto lstore = [&](int buf) {
+#pragma unroll
+		for (int i = 0; i < NAT; i++)
+		{
+			const int e = t + 768 * i, row = e / KQ, kc = (e % KQ) * 4;
+			float *a = As[buf];
+			if (e < NA4) { a[(kc + 0) * F2_LDA + row] = ra[i].x; a[(kc + 1) * F2_LDA + row] = ra[i].y; a[(kc + 2) * F2_LDA + row] = ra[i].z; a[(kc + 3) * F2_LDA + row] = ra[i].w; }
+		}
+#pragma unroll
+		for (int i = 0; i < NBT; i++) { const int e = t + 768 * i; if (e < NB4) *reinterpret_cast<float4 *>(Bs[buf] + (e / 36) * F2_BN + (e % 36) * 4) = rb[i]; }
+	};
+	f32x4 acc[3];
+#pragma unroll
+	for (int j = 0; j < 3; j++) { const float bv = bias[n0 + wn * 48 + j * 16 + (lane & 15)]; acc[j] = f32x4{ bv, bv, bv, bv }; }
+	gload(0);
+	lstore(0);
+	int buf = 0;
+	for (int k0 = 0; k0 < K; k0 += F2_BK)
+	{
+		__syncthreads();                                   // slab `buf` is complete; the other buffer is free (its readers passed this barrier)
+		const bool more = k0 + F2_BK < K;
+		if (more) gload(k0 + F2_BK);
+		const float *ap = As[buf] + (lane >> 4) * F2_LDA + wm * 16 + (lane & 15);
+		const float *bp = Bs[buf] + (lane >> 4) * F2_BN + wn * 48 + (lane & 15);
+#pragma unroll
+		for (int kk = 0; kk < F2_BK / 4; kk++)
+		{
+			const float a = ap[4 * kk * F2_LDA];
+			const float b0 = bp[4 * kk * F2_BN], b1 = bp[4 * kk * F2_BN + 16], b2 = bp[4 * kk * F2_BN + 32];
+			acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[0], 0, 0, 0);
+			acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[1], 0, 0, 0);
+			acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b2, acc[2], 0, 0, 0);
+		}
+		if (more) lstore(buf ^ 1);
+		buf ^= 1;
+	}
+	// C/D map 16x16: col = lane & 15, row = 4 * (lane >> 4) + r
+#pragma unroll
+	for (int j = 0; j < 3; j++)
+#pragma unroll
+		for (int r = 0; r < 4; r++)
+		{
+			const int row = m0 + wm * 16 + 4 * (lane >> 4) + r;
+			if (row < M) C[(size_t)row * N + n0 + wn * 48 + j * 16 + (lane & 15)] = acc[j][r];
+		}
+}
+
 // ------------------------------------------------------------------------------------------------- k_softmax_decode
 // one wave per frame.  softmax chunks: 8 x 256 then 16 x 16 (handtrack.h:118); sums run in ascending order like cnn.h:503-505.
 // analysis layout (HT_ANALYSIS floats): crays 8x4 | image_points 8x2 | confidence 8 | vals 16 | wristroll pitch tilt | palmq 4 | clenched 5
@@ -436,7 +509,7 @@ void ht_launch_prepare_frame(const uint16_t *depth, const float *cams, int w, in
 // side = 64: PoseInitializerCNN's topology (handtrack.h:108-118); side = 128: the same layers on a 128x128 input (act1 [B][16*31*31], act2 [B][12544])
 void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, float *act2, float *act3, float *logits, int B, hipStream_t s, int side)
 {
-	dim3 g1(2048 / 64, (B + FC_BM - 1) / FC_BM), g2(2304 / 96, (B + FC_BM - 1) / FC_BM);
+	dim3 g1(2048 / 64, (B + FC_BM - 1) / FC_BM);
 	if (side == 128)
 	{
 		hipLaunchKernelGGL((k_conv1<128, 31, 8>), dim3(B, 4), dim3(256), 0, s, cnn_in, w.W1, w.B1, act1);
@@ -449,7 +522,7 @@ void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, fl
 		hipLaunchKernelGGL((k_conv2<15, 12, 12>), dim3(B, 1), dim3(256), 0, s, act1, w.W2p, w.B2, act2);
 		hipLaunchKernelGGL((k_fc<true, 2>), g1, dim3(512), 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
 	}
-	hipLaunchKernelGGL((k_fc<false, 3>), g2, dim3(768), 0, s, act3, w.W4, w.B4, logits, B, 2304, 2048);
+	hipLaunchKernelGGL(k_fc144, dim3(2304 / F2_BN, (B + F2_BM - 1) / F2_BM), dim3(768), 0, s, act3, w.W4, w.B4, logits, B, 2304, 2048);
 }
 void ht_launch_softmax_decode(const float *logits, float *cnn_out, const float *cams, float *analysis, int softmax, int B, hipStream_t s)
 {

@@ -114,27 +114,6 @@ __device__ __forceinline__ void wave_argmax(float &b, int &i)
 	amax_take(rb, ri, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 48)), __builtin_amdgcn_readlane(i, 48));
 	b = rb; i = ri;
 }
-// wave-cooperative scan (all lanes the same shape and direction): strided partial arg-max + wave_argmax; ties go to the lower index
-__device__ __forceinline__ v3 support_inner_wave(const support_t &s, v3 dir, int lane)
-{
-	const v3 dl = qrot(qconj(s.q), dir);
-	const float4 *vs = g_sm + s.voff;
-	float best = 0.0f; int bi = 0x7fffffff;
-	for (int i = lane; i < s.n; i += 64)
-	{
-		float4 q = vs[i];
-		float d = dot(V3(q.x, q.y, q.z), dl);
-		if (bi == 0x7fffffff || best < d) { best = d; bi = i; }
-	}
-	wave_argmax(best, bi);
-	float4 q = vs[bi];
-	return s.pos + qrot(s.q, V3(q.x, q.y, q.z));
-}
-__device__ __forceinline__ v3 support_wave(const support_t &s, v3 dir, int lane)
-{
-	if (s.outer) return s.opos + qrot(s.oq, support_inner_wave(s, qrot(qconj(s.oq), dir), lane));
-	return support_inner_wave(s, dir, lane);
-}
 __device__ __forceinline__ mkpoint point_on_minkowski(const support_t &A, const support_t &B, v3 n)      // gjk.h:68-73
 {
 	mkpoint m; m.a = support(A, n); m.b = support(B, -n); m.p = m.a - m.b; m.t = 0; return m;
@@ -340,12 +319,40 @@ __device__ __forceinline__ bool above(const epa_mem &m, int t, v3 p, float epsil
 	v3 n = tri_normal(ev(m, T.v0), ev(m, T.v1), ev(m, T.v2));
 	return dot(n, p - ev(m, T.v0)) > epsilon;
 }
+// w = support(A, n) - support(B, -n) for the polytope, on the whole wave: both shapes are walked together, lane l takes vertices l, l+64, ..., four
+// reads of each shape in flight (an index past a shape's end repeats its last vertex, which ties with itself).  The rotations are the matrices
+// the caller built once per run: qrot(q, v) = qmat(q) * v and qrot(qconj(q), v) = transpose(qmat(q)) * v, rounding for rounding (linalg.h:284-288).
+__device__ __forceinline__ v3 epa_minkowski(const support_t &A, const support_t &B, const m3 &RA, const m3 &RB, const m3 &RO, v3 n, int lane)
+{
+	const v3 da = mul(transpose(RA), A.outer ? mul(transpose(RO), n) : n), db = mul(transpose(RB), -n);
+	const float4 *va = g_sm + A.voff, *vb = g_sm + B.voff;
+	const int nmax = A.n > B.n ? A.n : B.n;
+	float ba = 0.0f, bb = 0.0f; int ia = 0x7fffffff, ib = 0x7fffffff;
+	for (int base = 0; base < nmax; base += 256)
+	{
+		float4 qa[4], qb[4]; int ka[4], kb[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++) { const int i = base + 64 * k + lane; ka[k] = i < A.n ? i : A.n - 1; kb[k] = i < B.n ? i : B.n - 1; qa[k] = va[ka[k]]; qb[k] = vb[kb[k]]; }
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+		{
+			const float d = dot(V3(qa[k].x, qa[k].y, qa[k].z), da), e = dot(V3(qb[k].x, qb[k].y, qb[k].z), db);
+			if (ia == 0x7fffffff || ba < d) { ba = d; ia = ka[k]; }
+			if (ib == 0x7fffffff || bb < e) { bb = e; ib = kb[k]; }
+		}
+	}
+	wave_argmax(ba, ia); wave_argmax(bb, ib);
+	const float4 pa = va[ia], pb = vb[ib];
+	const v3 sa = A.pos + mul(RA, V3(pa.x, pa.y, pa.z));
+	return (A.outer ? A.opos + mul(RO, sa) : sa) - (B.pos + mul(RB, V3(pb.x, pb.y, pb.z)));
+}
 // all 64 lanes call this with identical arguments
 // `capped` is set when the run ends on one of this implementation's capacities (the reference's loop is unbounded, hull.h:246)
 __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 s2, v3 s3, const support_t &A, const support_t &B, int lane, long long *ec, bool &capped)
 {
 	capped = false;
 	long long tm = ec ? clock64() : 0;
+	const m3 RA = qmat(A.q), RB = qmat(B.q), RO = qmat(A.oq);
 	v4 plane = V4(0, 0, 0, -FLT_MAX);
 	const float epsilon = 0.001f;
 	int nv = 4, nt = 0;
@@ -378,7 +385,7 @@ __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 
 		}
 		v4 face = (bi == 0x7fffffff) ? V4(0, 0, 0, -FLT_MAX) : V4(bn, bd);
 		if (ec) { const long long t = clock64(); ec[3] += t - tm; tm = t; ec[6] += 1; }
-		v3 v = support_wave(A, xyz(face), lane) - support_wave(B, -xyz(face), lane);
+		v3 v = epa_minkowski(A, B, RA, RB, RO, xyz(face), lane);
 		if (ec) { const long long t = clock64(); ec[4] += t - tm; tm = t; }
 		v4 p = V4(xyz(face), -dot(xyz(face), v));
 		if (p.w > plane.w) plane = p;
@@ -1023,6 +1030,7 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 	const long long t_pro = (dbg & 2048) ? clock64() : 0;
 	int parity = 0;
 	co_pass<false>(M, L, nfr, em, driftmax, jiggle_sin, t, dbg, caps, parity, (dbg & 2048) ? cyc : nullptr);
+	const long long t_post = (dbg & 2048) ? clock64() : 0;
 	if (t == 0)
 	{
 		int tot = 0;
@@ -1085,7 +1093,7 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 		{
 			float *o = contacts + ((size_t)b * HT_MAXCONTACT + HT_MAXCONTACT - 1) * HT_CONTACT;
 			o[0] += 1.0f; o[1] += (float)cyc[0]; o[2] += (float)cyc[2]; o[3] += (float)F.nepa; o[4] += (float)cyc[3]; o[5] += (float)cyc[1]; o[6] += (float)cyc[4]; o[7] += (float)(clock64() - t_begin);
-			o[8] += (float)F.ncand; o[9] += (float)F.njig; o[10] += (float)total; o[11] += (float)(t_pro - t_begin);
+			o[8] += (float)F.ncand; o[9] += (float)(clock64() - t_post); o[10] += (float)(t_post - t_pro); o[11] += (float)(t_pro - t_begin);
 		}
 	}
 }

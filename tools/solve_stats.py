@@ -40,7 +40,7 @@ print("worst frame", w, st[w])
 
 print("---- k_contacts (sum over %s launches per frame)" % np.unique(cs[:, 0]))
 # the fields of k_contacts_coop (wave f of a block reports its own cycles beside frame f's counts); the lane-per-pair kernel (HT_CONTACTS_LANES) fills them differently
-for k, nm in zip(range(1, 12), ["owner_cycles", "epa_phase_cycles", "epa_runs", "iterations", "scan_cycles", "scan_and_barriers", "total_cycles", "candidates", "jiggle_pairs", "contacts", "prologue_cycles"]):
+for k, nm in zip(range(1, 12), ["owner_cycles", "epa_phase_cycles", "epa_runs", "iterations", "scan_cycles", "scan_and_barriers", "total_cycles", "candidates", "after_pass_cycles", "pass_cycles", "prologue_cycles"]):
     c = cs[:, k]
     print("%-13s per frame: mean %.0f  p50 %.0f  p90 %.0f  max %.0f (frame %d)" % (nm, c.mean(), np.median(c), np.percentile(c, 90), c.max(), c.argmax()))
 order = np.argsort(-cs[:, 7])[:6]
