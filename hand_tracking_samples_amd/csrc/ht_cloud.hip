@@ -370,7 +370,7 @@ void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float
 	// blocks per frame: a frame's passes of CH points are independent, so while the batch leaves CUs idle they are spread over up to `split` blocks
 	// (each pays the prologue -- body table, 25 KB of planes into LDS -- again, which is why a large batch keeps one block per frame)
 	const int pts_max = M.pts_bound > 0 ? M.pts_bound : M.pts_cap, passes = ((pts_max + stride - 1) / stride + CH - 1) / CH;
-	int split = B <= 2048 ? 4 : 1;
+	int split = B <= 2048 ? 2 : 1;
 #ifdef HT_TUNING
 	if (const char *e = getenv("HT_CLOUD_SPLIT")) split = atoi(e);
 #endif

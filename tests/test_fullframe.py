@@ -124,6 +124,21 @@ def test_gpu_config5_full_size_properties(weights):
     for k in range(1, 16):
         assert np.array_equal(a[:64], a[64 * k:64 * (k + 1)])
     assert np.isfinite(a).all() and np.abs(np.linalg.norm(a[:, :, 3:], axis=2) - 1.0).max() < 1e-5
+    # the same frames in a batch of 2304: above 2048 frames the launcher takes the lane-per-pair contact kernel (two waves per frame for 26 bones)
+    # instead of the cooperative one -- two organisations of the same arithmetic, so the poses must not move by a bit
+    B2 = 2304
+    idx2 = np.arange(B2) % 64
+    ctx = native.Context(CASES["config5"][1], B2)
+    try:
+        ctx.load_weights(weights)
+        ctx.set_params(microforce=3.0, mainthreadpasses=3)
+        ctx.tracker_reset(z["startpose"][idx2])
+        c = ctx.update_frames_sync(z["depth"][idx2], z["cam"][idx2], 0.17)
+        assert ctx.capacity_events() == (0, 0, 0)
+    finally:
+        ctx.close()
+    for k in range(36):
+        assert np.array_equal(a[:64], c[64 * k:64 * (k + 1)])
 
 
 @pytest.mark.gpu

@@ -194,3 +194,55 @@ def test_thumb_base_ignore_rewrite(weights, tmp_path):
         total += k
     orc.close()
     assert total >= 20
+
+
+def test_contact_patch_extra_samples(tmp_path):
+    """ContactPatch's four extra samples (gjk.h:626-641: the shape tilted by 2 degrees about four axes through the first contact point, a sample kept
+    when it lies 5 cm from every kept one).  The hand's bones are smaller than 5 cm, so no test on the hand reaches that code.  Here the box and the
+    prism of the 3-body chain, scaled by 3 (16 x 11 x 27 cm and 7 x 16 cm) and with their joint's ignore entry cleared, are posed touching,
+    penetrating and apart (body 2 leaves every pair through the rewrite of handtrack.h:408-416, as in any model the tracker loads).  Device contacts
+    must equal the restatement's entry by entry, and some patch must really carry more than one sample."""
+    import ctypes as C
+    import sys
+    import htfx
+    from hand_tracking_samples_amd import native
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    from bench import _write_htfx
+    m = dict(htfx.load(os.path.join(HERE, "golden", "model_chain3.htfx")))
+    ign = m["ignore"].copy(); ign[0, 1] = ign[1, 0] = 0; m["ignore"] = ign
+    path = str(tmp_path / "chain3_collide.htfx")
+    _write_htfx(path, m)
+    ctx = native.Context(path, 16)
+    orc = ol.Oracle(None, model=path)
+    try:
+        ctx.scale(3.0)
+        orc.L.ho_scale.argtypes = [C.c_void_p, C.c_float]
+        orc.L.ho_scale(orc.h, 3.0)
+        rest = orc.get_state(0)
+        def quat(axis, deg):
+            a = np.asarray(axis, np.float64); a /= np.linalg.norm(a); h = np.deg2rad(deg) / 2
+            return np.concatenate([a * np.sin(h), [np.cos(h)]]).astype(np.float32)
+        poses = [((dx, 0, 0), quat((0, 0, 1), ang)) for ang, dx in ((-102.5, 0.1075), (-100.0, 0.11), (-97.5, 0.1125), (-95.0, 0.1125), (-92.5, 0.1125), (-90.0, 0.1175), (-90.0, 0.105), (20.0, 0.1125), (65.6, 0.1), (0.0, 0.13))]
+        poses += [((0, 0.082, 0), quat((0, 0, 1), 30)), ((0.003, 0.088, -0.01), quat((0, 0, 1), 77.6)), ((0, 0, 0.2), quat((1, 0, 0), 1)), ((0.02, 0.01, 0.21), quat((0, 1, 0), 175))]
+        states = []
+        for pos, q in poses:
+            s = rest.copy(); s[:, 7:] = 0
+            s[2, :3] = (5.0, 5.0, 5.0)
+            s[1, :3] = np.asarray(pos, np.float32) + rest[0, :3]; s[1, 3:7] = q
+            states.append(s)
+        states = np.stack(states)
+        ctx.set_state(0, states)
+        c, n = ctx.stage_contacts(0, len(states))
+        most = total = 0
+        for k in range(len(states)):
+            orc.set_state(0, states[k])
+            cs = (ol.Contact * 64)()
+            mk = orc.L.ho_find_contacts(orc.h, orc.model(0), cs, 64)
+            ref = np.array([[x.rb0, x.rb1, x.normal.x, x.normal.y, x.normal.z, x.p0w.x, x.p0w.y, x.p0w.z, x.p1w.x, x.p1w.y, x.p1w.z, x.separation] for x in cs[:mk]], np.float32).reshape(mk, 12)
+            print("pose %d: %d contacts (separations %s)" % (k, mk, ["%.4f" % v for v in ref[:, 11]]))
+            assert n[k] == mk
+            assert np.array_equal(c[k, :mk], ref), "pose %d" % k
+            most = max(most, mk); total += mk
+        assert most >= 2 and total >= 14 and ctx.capacity_events() == (0, 0, 0)
+    finally:
+        ctx.close(); orc.close()
