@@ -7,16 +7,22 @@
 //   ExpandingPolytopeAlgorithm        third_party/hull.h:233-310 (Tri bookkeeping :79-186)
 //   SupportFunc / SupportFuncTrans    third_party/gjk.h:568-582, maxdir third_party/geometric.h:218-224
 //
-// Mapping.  A block serves two frames (one wave each) and stages all collision vertices (3042 x float4 = 48 KB, w = vertex index) in
-// LDS once.  GJK runs on lane groups: a candidate pair is served by 1, 2 or 4 neighbouring lanes (4 when a frame has <= 16 candidates,
-// 2 up to 32) that hold identical simplex state, scan interleaved 6-vertex blocks of the support map (128-bit LDS reads issued
-// together, packed x/y multiply, compare in index order: first maximum wins as std::max_element does) and agree through DPP quad
-// permutes; the simplex logic is the reference's branchy code executed per lane.  Measured on the animation bank: 3.5 iterations per
-// pair on average, ~23 pairs per frame.  A pair whose simplex encloses the origin needs the expanding polytope; that part is rare but
-// long, so it runs wave-cooperatively, one pair at a time: triangles are scored one per lane, support scans are strided over the 64
-// lanes with a butterfly arg-max, and the mesh surgery (extrude / back-to-back fix / compaction, hull.h:136-186) visits only the
-// triangles a ballot marks.  Contacts are compacted in pair order with a prefix sum, so the solver sees the reference's row order.
-// (Two waves per frame were measured slower: the per-lane support scans are bound by the CU's LDS throughput, not by lanes.)
+// Two organisations of the same arithmetic, chosen per launch by the batch size (ht_launch_contacts):
+//   k_contacts_coop (up to 2048 frames): lane-per-run simplex logic in owner waves, support scans worked off cooperatively by all waves of a
+//     block, one scan pair per DPP row, polytope jobs taken by any wave -- described at the kernel below.  Shortest launch when the batch is a few
+//     frames per CU; owns the CU (152 KB of LDS, 255 VGPRs).
+//   k_contacts (larger batches): a block serves two frames (one wave each) and stages all collision vertices (3042 x float4 = 48 KB, w = vertex
+//     index) in LDS once.  GJK runs on lane groups: a candidate pair is served by 1, 2 or 4 neighbouring lanes (4 when a frame has <= 16
+//     candidates, 2 up to 32) that hold identical simplex state, scan interleaved 6-vertex blocks of the support map (128-bit LDS reads issued
+//     together, packed x/y multiply, compare in index order: first maximum wins as std::max_element does) and agree through DPP quad permutes; the
+//     simplex logic is the reference's branchy code executed per lane.  Measured on the animation bank: 3.5 iterations per pair on average, ~23
+//     pairs per frame.  Contacts are compacted in pair order with a prefix sum, so the solver sees the reference's row order.  61 KB of LDS: two
+//     blocks per CU, which leaves room for the cloud-row kernel of the same fit step beside it -- with many frames per CU the whole step is faster
+//     this way although the kernel alone is not (cross-over measured between 2048 and 4096 frames).
+// Both hand a pair whose simplex encloses the origin to the expanding polytope; that part is rare but long, so it runs wave-cooperatively, one
+// pair at a time per wave: triangles are scored one per lane, both shapes' support scans are walked together strided over the 64 lanes with a
+// butterfly arg-max, and the mesh surgery (extrude / back-to-back fix / compaction, hull.h:136-186) visits only the triangles a ballot marks.
+// (Tried and dropped: the triangle list in registers with v_readlane look-ups instead of LDS reads -- 2.1 against 1.5 ms per step.)
 //
 // The 4 extra "jiggle" GJK runs of the contact patch are skipped when they provably cannot add a contact: an extra
 // sample is rejected if it lies within 0.05 m of an accepted one on either shape (gjk.h:637) and every sample lies in the

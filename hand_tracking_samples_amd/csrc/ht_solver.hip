@@ -46,6 +46,7 @@
 #define SUMS_SMALL 712
 #define SUMS_MID (HT_MAXPTS + 5 * HT_MAXNB + 32)
 #define SUMS_LARGE 1200
+#define SUMS_ONLY 1024        // the single-launch build (small batches): 39.4 KB with the large pool, four blocks per CU
 #define IDLE_BODY (HT_MAXNB - 1)      // lane pairs without a row in a step work on this all-zero body and on an all-zero record
 #define LM_FRIC 0x10000    // meta bits of a two-body linear row: friction row (limits from its contact's normal row, physics.h:292)
 #define LM_NORMAL 0x20000  //                                     normal row of a contact (publishes its impulse sum)
@@ -199,14 +200,15 @@ __device__ __forceinline__ int angular_range_count(v3 lmin, v3 lmax)
 	return n;
 }
 
-template <int POOL_FLOATS, int NSUM_, bool FIRST>
+enum { SOLVE_FIRST = 0, SOLVE_SECOND = 1, SOLVE_ONLY = 2 };      // first of two launches (may pass a frame on) / second (takes those) / a single launch that holds everything
+template <int POOL_FLOATS, int NSUM_, int MODE>
 __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph, solve_args a)
 {
 	__shared__ lds_t<POOL_FLOATS, NSUM_> S;
 	const int b = blockIdx.x, lane = threadIdx.x;
 	if (a.active_flag && !a.active_flag[b]) return;                // first: a launch never touches another launch's frames, not even their retry flags
-	if (FIRST) { if (lane == 0) a.retry[b] = 0; }
-	else if (!a.retry[b]) return;                                 // the large build only takes the frames the first one passed on
+	if (MODE == SOLVE_FIRST) { if (lane == 0) a.retry[b] = 0; }
+	else if (MODE == SOLVE_SECOND && !a.retry[b]) return;                                 // the large build only takes the frames the first one passed on
 	const int nb = M.nb, nj = M.nj;
 	float *st = a.state + (size_t)b * nb * HT_STATE_STRIDE;
 	const float dt = ph.deltaT;
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		S.nray = k;
 	}
 	__syncthreads();
-	if (FIRST)      // a frame with more rows than this build's LDS holds is left untouched for the large build (second launch)
+	if (MODE == SOLVE_FIRST)      // a frame with more rows than this build's LDS holds is left untouched for the large build (second launch)
 	{
 		int nc_ = (a.contacts && ph.use_collision) ? a.ncontacts[b] : 0;
 		if (nc_ > HT_MAXCONTACT) nc_ = HT_MAXCONTACT;
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	const int ncl = a.rows_cloud ? a.n_cloud[b] : 0;
 	const int n1 = npre + ncl;
 	float *scr = a.scratch + (size_t)b * a.scratch_stride * CREC;
-	const bool sums_lds = FIRST || n1 + QUAD_CHAIN_SLACK <= S.NSUM;                                         // always true in a first build (checked above)
+	const bool sums_lds = MODE == SOLVE_FIRST || n1 + QUAD_CHAIN_SLACK <= S.NSUM;                                         // always true in a first build (checked above)
 	float *const gsum = a.scratch + (size_t)a.batch * a.scratch_stride * CREC + (size_t)b * a.scratch_stride;      // this frame's sums in HBM, behind all frames' records
 	if (sums_lds) { for (int i = lane; i < n1 + QUAD_CHAIN_SLACK; i += 64) S.csum[i] = 0.0f; }
 	else for (int i = lane; i < n1 + QUAD_CHAIN_SLACK && i < a.scratch_stride; i += 64) gsum[i] = 0.0f;
@@ -688,7 +690,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				const float Ix = I_w[12 * body + c], Iy = I_w[12 * body + 4 + c], Iz = I_w[12 * body + 8 + c];
 				quad_body qb = { l, av, minv, Ix, Iy, Iz };
 				// RemoveBias (physics.h:288): lane 3 switches to the ts_post slot
-				if (FIRST || sums_lds) quad_chain_run(qb, scr + (size_t)start * CREC, S.csum + start, cnt, c, tsoff);
+				if (MODE == SOLVE_FIRST || sums_lds) quad_chain_run(qb, scr + (size_t)start * CREC, S.csum + start, cnt, c, tsoff);
 				else quad_chain_run(qb, scr + (size_t)start * CREC, gsum + start, cnt, c, tsoff);
 				if (c < 3) { lin_w[4 * body + c] = qb.l; ang_w[4 * body + c] = qb.av; }
 			}
@@ -889,7 +891,10 @@ void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solv
 	// first build by what the host knows of the launch: the model's joints and the most points a frame of this call can carry
 	const int pts = M.pts_bound > 0 ? M.pts_bound : M.pts_cap;
 	const bool small = 3 * (M.nj + 8) + 3 <= POOL_SMALL / LROW && pts <= 1024;      // room for a few contacts beside the joints, and a 64x64 tile's cloud
-	if (small) hipLaunchKernelGGL((k_solve<POOL_SMALL, SUMS_SMALL, true>), dim3(B), dim3(64), 0, s, M, ph, a);
-	else hipLaunchKernelGGL((k_solve<POOL_MID, SUMS_MID, true>), dim3(B), dim3(64), 0, s, M, ph, a);
-	hipLaunchKernelGGL((k_solve<POOL_LARGE, SUMS_LARGE, false>), dim3(B), dim3(64), 0, s, M, ph, a);
+	// Up to four frames per CU (1024 on the 256 CUs) a launch gains nothing from the small build's 20 KB: the build that holds every contact (39.4 KB,
+	// four blocks per CU) runs alone and the second launch, which costs a dependent launch gap even when no frame needs it, is not made.
+	if (B <= 1024 && small) { hipLaunchKernelGGL((k_solve<POOL_LARGE, SUMS_ONLY, SOLVE_ONLY>), dim3(B), dim3(64), 0, s, M, ph, a); return; }
+	if (small) hipLaunchKernelGGL((k_solve<POOL_SMALL, SUMS_SMALL, SOLVE_FIRST>), dim3(B), dim3(64), 0, s, M, ph, a);
+	else hipLaunchKernelGGL((k_solve<POOL_MID, SUMS_MID, SOLVE_FIRST>), dim3(B), dim3(64), 0, s, M, ph, a);
+	hipLaunchKernelGGL((k_solve<POOL_LARGE, SUMS_LARGE, SOLVE_SECOND>), dim3(B), dim3(64), 0, s, M, ph, a);
 }
