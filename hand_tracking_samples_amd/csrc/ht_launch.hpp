@@ -18,6 +18,7 @@ struct solve_args
 	// RelativeAngularConstraints against a reference pose (sf_refpose [B][nb][7], sf_hold = 1 or 2); all off when zero / null
 	const float *sf_crays; int sf_ncray; int sf_select; float sf_spoint[3], sf_rbpoint[3]; const float *sf_refpose; int sf_hold;
 	int *caps;                                                      // capacity counter: frames x launches whose angular rows exceeded the LDS records (may be null)
+	int shared_gpu;                                                 // other kernels run beside this launch (the reset path): keep the small LDS footprint
 	int dbg;                                                        // timing experiments only (HT_DEBUG_SKIP): 1 skip chains, 2 skip two-body linear, 4 skip angular
 };
 

@@ -892,8 +892,9 @@ void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solv
 	const int pts = M.pts_bound > 0 ? M.pts_bound : M.pts_cap;
 	const bool small = 3 * (M.nj + 8) + 3 <= POOL_SMALL / LROW && pts <= 1024;      // room for a few contacts beside the joints, and a 64x64 tile's cloud
 	// Up to four frames per CU (1024 on the 256 CUs) a launch gains nothing from the small build's 20 KB: the build that holds every contact (39.4 KB,
-	// four blocks per CU) runs alone and the second launch, which costs a dependent launch gap even when no frame needs it, is not made.
-	if (B <= 1024 && small) { hipLaunchKernelGGL((k_solve<POOL_LARGE, SUMS_ONLY, SOLVE_ONLY>), dim3(B), dim3(64), 0, s, M, ph, a); return; }
+	// four blocks per CU) runs alone and the second launch, which costs a dependent launch gap even when no frame needs it, is not made.  Not when
+	// other kernels share the GPU with this launch: with their LDS in the way a CU holds three of these blocks and the launch takes two rounds.
+	if (B <= 1024 && small && !a.shared_gpu) { hipLaunchKernelGGL((k_solve<POOL_LARGE, SUMS_ONLY, SOLVE_ONLY>), dim3(B), dim3(64), 0, s, M, ph, a); return; }
 	if (small) hipLaunchKernelGGL((k_solve<POOL_SMALL, SUMS_SMALL, SOLVE_FIRST>), dim3(B), dim3(64), 0, s, M, ph, a);
 	else hipLaunchKernelGGL((k_solve<POOL_MID, SUMS_MID, SOLVE_FIRST>), dim3(B), dim3(64), 0, s, M, ph, a);
 	hipLaunchKernelGGL((k_solve<POOL_LARGE, SUMS_LARGE, SOLVE_SECOND>), dim3(B), dim3(64), 0, s, M, ph, a);

@@ -16,7 +16,7 @@ static int scratch_stride(const ht_ctx *ctx) { return ctx->model.pts_cap + 5 * c
 
 // ---- building blocks ------------------------------------------------------------------------------------------------
 static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int *n_pre, bool cloud, bool contacts, const int *active,
-                       int apply_angles, float drive_force, int ray_rows, int arm_cone, int zero_momenta, int B, hipStream_t s)
+                       int apply_angles, float drive_force, int ray_rows, int arm_cone, int zero_momenta, int B, hipStream_t s, bool shared_gpu = false)
 {
 	solve_args a;
 	memset(&a, 0, sizeof a);
@@ -30,6 +30,7 @@ static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int 
 	a.apply_angles = apply_angles; a.drive_force = drive_force; a.ray_rows = ray_rows; a.arm_cone = arm_cone; a.zero_momenta = zero_momenta;
 	a.steps_keyangles = ctx->par.steps_keyangles; a.min_cray_prob = ctx->par.min_cray_prob;
 	a.dbg = ht_tuning_flags();
+	a.shared_gpu = shared_gpu ? 1 : 0;
 	ht_launch_solve(ctx->model, ctx->phys, a, B, s);
 }
 // Fork/join helpers: the row-producing kernels of one fit step only read the pose, so they run side by side on two extra streams
@@ -42,7 +43,7 @@ static void join(ht_ctx *ctx, hipStream_t s, int n) { for (int i = 0; i < n; i++
 // HandTracker::MultiStepSim on othermodel (handtrack.h:642-690)
 // `active`: when given, only the frames whose flag is set are touched.  `side`: index of the side stream the cloud rows of a step run on beside the
 // contacts (-1: everything in order on s).  `prof`: bracket the solves for the profile (off for a concurrent second instance).
-static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int to_step = 1 << 30, const int *active = nullptr, bool first_contacts_done = false, int side = 0, bool prof = true)
+static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int to_step = 1 << 30, const int *active = nullptr, bool first_contacts_done = false, int side = 0, bool prof = true, bool shared_gpu = false)
 {
 	const ht_params &p = ctx->par;
 	for (int st = from_step; st < p.steps && st < to_step; st++)
@@ -58,7 +59,7 @@ static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int 
 		if (coll && !(first_contacts_done && st == from_step)) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, active, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s); }
 		if (par) join1(ctx, s, side);
 		ht_prof_scope ps(ctx, prof ? "solve" : nullptr, s);
-		solve_step(ctx, 1, nullptr, nullptr, cloud, coll, active, angles, st < p.steps_palmangle ? 10000.0f : 0.0f, rays, 1, 1, B, s);
+		solve_step(ctx, 1, nullptr, nullptr, cloud, coll, active, angles, st < p.steps_palmangle ? 10000.0f : 0.0f, rays, 1, 1, B, s, shared_gpu);
 	}
 }
 // one main-thread pass of HandTracker::update (handtrack.h:769-780)
@@ -139,14 +140,14 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 	const bool overlap = !no_overlap && !ctx->profile_phases && p.steps >= 1 && p.steps_cloudstart >= 1 && !p.angles_only;
 	if (overlap)
 	{
-		// Nothing on this side branch needs the CNN: the error of the carried pose, the reset decision, and the contacts of MultiStepSim's
-		// first step for the frames that keep their pose only read the point cloud and the tracker state, so they run beside the CNN.
+		// Nothing on this side branch needs the CNN: the error of the carried pose and the reset decision only read the point cloud and the
+		// tracker state, so they run beside the CNN.  (The contacts of MultiStepSim's first step do not need it either, but the contact kernel
+		// owns whole CUs and the FC layers want one block per CU: beside each other they took 0.78 ms, one after the other 0.46.)
 		hipStream_t t = ctx->side[1];
 		fork(ctx, s);
 		if (mode == UPD_FULL) ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, t);     // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757
 		ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_old, B, t);
 		ht_launch_decide_reset(ctx->d_err_old, p.full_reset_on_error, p.angles_only, ctx->d_flags, ctx->d_nflags, B, t);
-		if (ctx->phys.use_collision) ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, ctx->d_nflags, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, t);
 	}
 	{
 		ht_prof_scope ps(ctx, "cnn", s, true);
@@ -162,7 +163,7 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		// later than the main stream's full-batch steps plus this one extra step, 4.6 against 4.5 ms.)
 		fork(ctx, s);
 		reset_path(ctx, ctx->d_flags, p.steps_unibody, B, ctx->side[0], s);
-		multistep(ctx, B, s, 0, 1, ctx->d_nflags, true);
+		multistep(ctx, B, s, 0, 1, ctx->d_nflags, false, 0, true, true);
 		join(ctx, s, 1);
 		multistep(ctx, B, s, 0, 1, ctx->d_flags);
 		multistep(ctx, B, s, 1);

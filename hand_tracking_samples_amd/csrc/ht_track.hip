@@ -165,10 +165,10 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 	const m3 tinv = GM(M.ub_tinv);
 	const m3 Iinv = world_inertia(ubq, tinv, minv);
 	// rows of this solve (every 4th point): re-expressed on the proxy body and pre-computed into the frame's record stream (handtrack.h:457-462).
-	// Up to UB_LDS_ROWS rows (every frame of the default point capacity) the records stay in LDS (83 KB: only the few frames that take the full-reset
+	// Up to UB_LDS_ROWS rows (3584 points) the records stay in LDS (77 KB: only the few frames that take the full-reset
 	// path run this kernel, so occupancy is no concern, and a single quad walking its chain alone on a CU would wait a whole L2 round trip for what
 	// k_solve's sixteen quads overlap); a larger cloud uses the frame's slot of the solver scratch in HBM, sums behind all frames' records as in k_solve.
-	constexpr int UB_LDS_ROWS = HT_MAXPTS / 4;
+	constexpr int UB_LDS_ROWS = 896;      // 77 KB: with four 20 KB solver blocks on a CU (1024 frames) this block still finds room at once
 	__shared__ __attribute__((aligned(16))) float urow[(UB_LDS_ROWS + QUAD_CHAIN_SLACK) * CREC];
 	__shared__ float usum[UB_LDS_ROWS + QUAD_CHAIN_SLACK];      // impulse sums of the rows
 	const int nr = n < scratch_stride - QUAD_CHAIN_SLACK ? n : scratch_stride - QUAD_CHAIN_SLACK;
