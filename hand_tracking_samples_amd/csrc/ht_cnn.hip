@@ -329,25 +329,23 @@ __global__ __launch_bounds__(768) void k_fc144(const float *__restrict__ A, cons
 	__shared__ __attribute__((aligned(16))) float Bs[2][F2_BK * F2_BN];
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / 3, wn = wave % 3;
 	const int m0 = blockIdx.y * F2_BM, n0 = blockIdx.x * F2_BN;
-	// staging: A tile = 64 rows x F2_BK k as float4 along k (row = e / (F2_BK / 4)); B tile = F2_BK x 144 as float4 along the columns, 36 per k-row
-	constexpr int NA4 = F2_BM * F2_BK / 4, NB4 = F2_BK * 36, NAT = (NA4 + 767) / 768, NBT = (NB4 + 767) / 768, KQ = F2_BK / 4;
-	float4 ra[NAT], rb[NBT];
+	// staging: A tile = 64 rows x 32 k = 512 float4 (thread < 512: row = t >> 3, 4 consecutive k); B tile = 32 x 144 = 1152 float4, 36 per k-row (threads t and
+	// t + 768); all index arithmetic is done once, outside the slab loop
+	static_assert(F2_BM * F2_BK / 4 == 512 && F2_BK * 36 == 1152, "staging is written for 64 x 32 and 32 x 144 slabs");
+	const int arow = t >> 3, akc = (t & 7) * 4;
+	const int bk0 = t / 36, bc0 = (t % 36) * 4, bk1 = (t + 768) / 36, bc1 = ((t + 768) % 36) * 4;
+	const bool a_on = t < 512 && m0 + arow < M, b1_on = t < 384;
+	const float *ag = A + (size_t)(m0 + arow) * K + akc, *bg0 = W + (size_t)bk0 * N + n0 + bc0, *bg1 = W + (size_t)bk1 * N + n0 + bc1;
+	float4 ra = make_float4(0, 0, 0, 0), rb0, rb1 = make_float4(0, 0, 0, 0);
 	auto gload = [&](int k0) {
-#pragma unroll
-		for (int i = 0; i < NAT; i++) { const int e = t + 768 * i, row = m0 + e / KQ; ra[i] = (e < NA4 && row < M) ? *reinterpret_cast<const float4 *>(A + (size_t)row * K + k0 + (e % KQ) * 4) : make_float4(0, 0, 0, 0); }
-#pragma unroll
-		for (int i = 0; i < NBT; i++) { const int e = t + 768 * i; if (e < NB4) rb[i] = *reinterpret_cast<const float4 *>(W + (size_t)(k0 + e / 36) * N + n0 + (e % 36) * 4); }
+		if (a_on) ra = *reinterpret_cast<const float4 *>(ag + k0);
+		rb0 = *reinterpret_cast<const float4 *>(bg0 + (size_t)k0 * N);
+		if (b1_on) rb1 = *reinterpret_cast<const float4 *>(bg1 + (size_t)k0 * N);
 	};
 	auto lstore = [&](int buf) {
-#pragma unroll
-		for (int i = 0; i < NAT; i++)
-		{
-			const int e = t + 768 * i, row = e / KQ, kc = (e % KQ) * 4;
-			float *a = As[buf];
-			if (e < NA4) { a[(kc + 0) * F2_LDA + row] = ra[i].x; a[(kc + 1) * F2_LDA + row] = ra[i].y; a[(kc + 2) * F2_LDA + row] = ra[i].z; a[(kc + 3) * F2_LDA + row] = ra[i].w; }
-		}
-#pragma unroll
-		for (int i = 0; i < NBT; i++) { const int e = t + 768 * i; if (e < NB4) *reinterpret_cast<float4 *>(Bs[buf] + (e / 36) * F2_BN + (e % 36) * 4) = rb[i]; }
+		if (t < 512) { float *a = As[buf] + akc * F2_LDA + arow; a[0] = ra.x; a[F2_LDA] = ra.y; a[2 * F2_LDA] = ra.z; a[3 * F2_LDA] = ra.w; }
+		*reinterpret_cast<float4 *>(Bs[buf] + bk0 * F2_BN + bc0) = rb0;
+		if (b1_on) *reinterpret_cast<float4 *>(Bs[buf] + bk1 * F2_BN + bc1) = rb1;
 	};
 	f32x4 acc[3];
 #pragma unroll
