@@ -490,10 +490,15 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		o[0] = ts; o[1] = fmin_std(ts, tsnb); o[2] = fmin_std(fmn, fmx) * dt; o[3] = fmax_std(fmn, fmx) * dt; o[4] = impulsed; o[5] = 0.0f;
 		if (meta & LM_FRIC) o[3] = fmax_std(S.ang4[rb0].w, S.ang4[rb1].w);       // mu of physics.h:292; the limits are formed from the master row's impulse every sweep
 		o[6] = __int_as_float(meta | rb0 | (rb1 << 8));
-		o[7] = r0.x; o[8] = r0.y; o[9] = r0.z; o[10] = r1.x; o[11] = r1.y; o[12] = r1.z; o[13] = n.x; o[14] = n.y; o[15] = n.z;
+		o[13] = n.x; o[14] = n.y; o[15] = n.z;
+		// the lever arms are the same for the three rows of a group: row 0 carries them; the slots they leave free in row 1 hold the refined reciprocals of the
+		// three effective masses (sweep-invariant: the division of every sweep becomes the five operations of div_ieee_r)
+		const int kk = r % 3;
+		if (kk == 0) { o[7] = r0.x; o[8] = r0.y; o[9] = r0.z; o[10] = r1.x; o[11] = r1.y; o[12] = r1.z; }
+		S.pool[(r - kk + 1) * LROW + 7 + kk] = rcp_refined(impulsed);
 		S.lrb[r][0] = (unsigned char)rb0; S.lrb[r][1] = (unsigned char)rb1;
 	}
-	if (lane < 3 * LROW) S.pool[n2 * LROW + lane] = (lane % LROW) == 4 ? 1.0f : (lane % LROW) == 6 ? __int_as_float(IDLE_BODY | (IDLE_BODY << 8)) : 0.0f;      // idle group: zero limits, unit effective mass
+	if (lane < 3 * LROW) S.pool[n2 * LROW + lane] = (lane % LROW) == 4 || (lane >= LROW + 7 && lane <= LROW + 9) ? 1.0f : (lane % LROW) == 6 ? __int_as_float(IDLE_BODY | (IDLE_BODY << 8)) : 0.0f;      // idle group: zero limits, unit effective mass (and its reciprocal)
 	if (lane == 0)
 	{
 		S.lin4[IDLE_BODY] = make_float4(0, 0, 0, 0); S.ang4[IDLE_BODY] = make_float4(0, 0, 0, 0);
@@ -704,7 +709,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		//     one step ahead; only the momenta are read after the previous step's stores.  Two register sets alternate.
 		if (!(a.dbg & 2) && nlev_lin > 0)
 		{
-			struct lset { unsigned e; int meta; float rv, n0, n1, n2, Ix, Iy, Iz, minv; float4 s0, s1, s2; float e0, e1, e2, i0, i1, i2; };
+			struct lset { unsigned e; int meta; float rv1, rv2, n0, n1, n2, Ix, Iy, Iz, minv; float4 s0, s1, s2; float e0, e1, e2, q0, q1, q2, i0, i1, i2; };
 			auto entry = [&](int L) -> unsigned {
 				if (L > nlev_lin) return S.lorder[S.LIDLE];
 				int lo, hi;
@@ -718,7 +723,8 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				const float *R = S.pool + (int)(e & 0xFFFF) * (3 * LROW);
 				const int body = side ? (int)(e >> 24) : (int)((e >> 16) & 255);
 				r.meta = __float_as_int(R[6]);
-				r.rv = R[7 + 3 * side + c];                                   // the lever arm is the same for the 3 rows
+				r.rv1 = R[7 + 3 * side + c1]; r.rv2 = R[7 + 3 * side + c2];      // lever arm components (c+1)%3 and (c+2)%3, the two a cross product needs on lane c; the same for the 3 rows
+				r.q0 = R[LROW + 7]; r.q1 = R[LROW + 8]; r.q2 = R[LROW + 9];        // refined reciprocals of the three effective masses
 				r.n0 = R[13 + c]; r.n1 = R[LROW + 13 + c]; r.n2 = R[2 * LROW + 13 + c];
 				r.s0 = *reinterpret_cast<const float4 *>(R); r.s1 = *reinterpret_cast<const float4 *>(R + LROW); r.s2 = *reinterpret_cast<const float4 *>(R + 2 * LROW);      // ts ts_post fmin fmax
 				r.e0 = R[4]; r.i0 = R[5]; r.e1 = R[LROW + 4]; r.i1 = R[LROW + 5]; r.e2 = R[2 * LROW + 4]; r.i2 = R[2 * LROW + 5];
@@ -727,32 +733,30 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			auto step = [&](const lset &r) {
 				const int body = side ? (int)(r.e >> 24) : (int)((r.e >> 16) & 255);
 				float l = lin_w[4 * body + c], av = ang_w[4 * body + c];
-				auto row = [&](float n, float ts, float fmn, float fmx, float eff, float isum) -> float {
+				auto row = [&](float n, float ts, float fmn, float fmx, float eff, float rinv, float isum) -> float {
 					const float w = (r.Ix * dpp<QP_BC0>(av) + r.Iy * dpp<QP_BC1>(av)) + r.Iz * dpp<QP_BC2>(av);
-					const float m1 = w * dpp<QP_ROT1>(r.rv), m2 = w * dpp<QP_ROT2>(r.rv);
-					const float v = (dpp<QP_ROT1>(m1) - dpp<QP_ROT2>(m2)) + l * r.minv;                       // velocity of this side's anchor
+					const float v = (dpp<QP_ROT1>(w) * r.rv2 - dpp<QP_ROT2>(w) * r.rv1) + l * r.minv;            // cross(w, r)[c] + v_lin[c]: velocity of this side's anchor
 					const float u = __int_as_float(__float_as_int(v) ^ sidesign);                             // rb1 side: v1, rb0 side: -v0
 					const float d = u + pair_swap(u);                                                          // (v1 - v0)[c] on both sides (v1 + -v0)
 					const float p = d * n;
 					const float vn = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);
 					const float impulsen = -ts - vn;
-					float impulse = div_ieee(impulsen, eff);
+					float impulse = div_ieee_r(impulsen, eff, rinv);
 					impulse = clamp_med3(impulse, fmn - isum, fmx - isum);
 					const float imp = n * __int_as_float(__float_as_int(impulse) ^ sidesign);                  // rb0: n * -impulse, rb1: n * impulse
 					l = l + imp;
-					const float k1 = r.rv * dpp<QP_ROT1>(imp), k2 = r.rv * dpp<QP_ROT2>(imp);
-					av = av + (dpp<QP_ROT1>(k1) - dpp<QP_ROT2>(k2));                                           // + cross(r, imp)[c]
+					av = av + (r.rv1 * dpp<QP_ROT2>(imp) - r.rv2 * dpp<QP_ROT1>(imp));                         // + cross(r, imp)[c]
 					return isum + impulse;
 				};
-				const float ns0 = row(r.n0, post ? r.s0.y : r.s0.x, r.s0.z, r.s0.w, r.e0, r.i0);
+				const float ns0 = row(r.n0, post ? r.s0.y : r.s0.x, r.s0.z, r.s0.w, r.e0, r.q0, r.i0);
 				float f1n = r.s1.z, f1x = r.s1.w, f2n = r.s2.z, f2x = r.s2.w;
 				if (r.meta & LM_NORMAL)       // a contact: the friction rows are limited by the normal row's impulse sum (physics.h:292); their fmax slot holds mu
 				{
 					const float lim1 = f1x * ns0 / dt; f1x = lim1 * dt; f1n = (-lim1) * dt;
 					const float lim2 = f2x * ns0 / dt; f2x = lim2 * dt; f2n = (-lim2) * dt;
 				}
-				const float ns1 = row(r.n1, post ? r.s1.y : r.s1.x, f1n, f1x, r.e1, r.i1);
-				const float ns2 = row(r.n2, post ? r.s2.y : r.s2.x, f2n, f2x, r.e2, r.i2);
+				const float ns1 = row(r.n1, post ? r.s1.y : r.s1.x, f1n, f1x, r.e1, r.q1, r.i1);
+				const float ns2 = row(r.n2, post ? r.s2.y : r.s2.x, f2n, f2x, r.e2, r.q2, r.i2);
 				if (c < 3) { lin_w[4 * body + c] = l; ang_w[4 * body + c] = av; }
 				else if (side == 0)
 				{
