@@ -193,6 +193,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 
+    # The context drives three HIP streams (main + two side streams) beside torch's and, with N > 1, RCCL's: more than the four hardware queues the HIP
+    # runtime maps streams onto by default, and streams that share a queue run one after the other.  Measured on one rank (tools/dist_probe.py): with
+    # the process group up a step takes 8.9 ms on 4 queues and 8.0 on 6 or 8 (8.0 - 8.1 without a process group on any count).  Must be set before the
+    # runtime starts.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+
     # stdout carries exactly one JSON line: whatever libraries print there (RCCL's version banner does) is sent to stderr instead
     sys.stdout.flush()
     json_fd = os.dup(1)
@@ -242,9 +248,14 @@ def main():
     d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
     d_cams = torch.from_numpy(cams).to(dev)
     d_start = torch.from_numpy(start).to(dev)
-    d_poses = torch.empty((B, ctx.nb, 7), dtype=torch.float32, device=dev)
+    # two pose buffers (and gather targets): step k's all-gather runs on RCCL's stream while step k+1 already writes the other buffer
+    d_poses2 = [torch.empty((B, ctx.nb, 7), dtype=torch.float32, device=dev) for _ in range(2)]
+    d_poses = d_poses2[0]
     d_cnn_out = torch.empty((B, 2304), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world * B, ctx.nb, 7), dtype=torch.float32, device=dev) if use_dist else None
+    gathered2 = [torch.empty((world * B, ctx.nb, 7), dtype=torch.float32, device=dev) for _ in range(2)] if use_dist else [None, None]
+    gathered = gathered2[0]
+    pending = [None, None]      # the exchange still reading each pose buffer
+    nstep = [0]
     stream = torch.cuda.current_stream(dev)
 
     w128 = x128 = None
@@ -259,6 +270,11 @@ def main():
         d_cnn_in = torch.from_numpy(cnn_in).to(dev)
 
     def step():
+        nonlocal d_poses, gathered
+        k = nstep[0] & 1; nstep[0] += 1
+        d_poses, gathered = d_poses2[k], gathered2[k]
+        if pending[k] is not None:
+            pending[k].wait(); pending[k] = None      # the exchange of two steps ago has to be through with this buffer (it long is)
         if cnn128:
             ctx.cnn128_eval_dev(d_cnn_in.data_ptr(), d_cnn_out.data_ptr(), B, stream.cuda_stream)
         elif wl == "cnn":
@@ -268,7 +284,7 @@ def main():
         else:
             ctx.update_dev(d_depth.data_ptr(), d_cams.data_ptr(), d_start.data_ptr(), B, d_poses.data_ptr(), stream.cuda_stream)
         if use_dist and not cnn_only:
-            gather_poses(d_poses, world, out=gathered, force=True)
+            _, pending[k] = gather_poses(d_poses, world, out=gathered, force=True, async_op=True)
 
     for _ in range(args.warmup):
         step()

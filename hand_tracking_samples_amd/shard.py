@@ -14,17 +14,19 @@ def shard_range(n_frames, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_poses(local_poses, world, out=None, force=False):
+def gather_poses(local_poses, world, out=None, force=False, async_op=False):
     """All-gather per-rank pose tensors [n_r, nb, 7] (equal n_r on every rank) into [world * n_r, nb, 7].
-    `force`: run the collective even for a single rank (rehearsal of the RCCL path on a one-GPU box)."""
+    `force`: run the collective even for a single rank (rehearsal of the RCCL path on a one-GPU box).
+    `async_op`: do not make the caller's stream wait for the collective; returns (out, work) and the caller waits on `work` (or synchronises the
+    device) before it reads `out` or overwrites `local_poses` -- this is how a step's exchange runs beside the next step's kernels."""
     import torch
     import torch.distributed as dist
     if world == 1 and not force:
-        return local_poses
+        return (local_poses, None) if async_op else local_poses
     if out is None:
         out = torch.empty((world * local_poses.shape[0],) + tuple(local_poses.shape[1:]), dtype=local_poses.dtype, device=local_poses.device)
-    dist.all_gather_into_tensor(out, local_poses.contiguous())
-    return out
+    work = dist.all_gather_into_tensor(out, local_poses.contiguous(), async_op=async_op)
+    return (out, work) if async_op else out
 
 
 def gather_poses_ragged(local_poses, counts):
