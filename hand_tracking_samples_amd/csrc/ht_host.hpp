@@ -60,6 +60,9 @@ struct ht_prof_scope
 	~ht_prof_scope();
 };
 
+// rows of a frame's slot of the solver scratch: every point and chamber row, k_solve's read-ahead slack, and the rows that pad a host body's chain
+// to a multiple of 8 when a body beyond the 16th rides on its quad (7 per such body at most)
+static inline size_t ht_scratch_rows(size_t pts_cap, size_t nb) { return pts_cap + 5 * nb + 32 + 7 * 16; }
 int ht_alloc_buffers(ht_ctx *ctx);
 int ht_reserve_points_locked(ht_ctx *ctx, int points);      // grows the per-point arrays (ht_api.hip); waits for the context's streams
 // *_dev entry points: a NULL stream means the context's own stream (never the legacy default stream); the choice is remembered so that the

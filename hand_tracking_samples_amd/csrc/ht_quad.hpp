@@ -96,7 +96,17 @@ __device__ __forceinline__ float quad_row_step(quad_body &B, const float4 a, con
 // L2 / the Infinity Cache, several hundred clocks away); the loop trips of the quads of a wave differ, the compiler masks finished quads off.
 // Reads run up to 15 records (and sums) past the chain's end: the caller's buffers have that slack.
 #define QUAD_CHAIN_SLACK 16
-__device__ __forceinline__ void quad_chain_run(quad_body &B, const float *rec, float *sums, int cnt, int c, int post)
+// A quad can walk TWO bodies' chains back to back (k_solve, models with more than 16 bodies: the 17th body's rows follow the host body's, which are
+// padded to a multiple of 8 with rows that change nothing): at row `kswitch` (a multiple of 8, or < 0 for none) the momenta go back to body `bodyA`'s
+// slots of lin_w / ang_w and body `bodyB`'s state is taken up.
+__device__ __forceinline__ void quad_switch_body(quad_body &B, int c, float *lin_w, float *ang_w, const float *I_w, int bodyA, int bodyB)
+{
+	if (c < 3) { lin_w[4 * bodyA + c] = B.l; ang_w[4 * bodyA + c] = B.av; }
+	B.l = lin_w[4 * bodyB + c]; B.av = ang_w[4 * bodyB + c]; B.minv = lin_w[4 * bodyB + 3];
+	B.Ix = I_w[12 * bodyB + c]; B.Iy = I_w[12 * bodyB + 4 + c]; B.Iz = I_w[12 * bodyB + 8 + c];
+}
+__device__ __forceinline__ void quad_chain_run(quad_body &B, const float *rec, float *sums, int cnt, int c, int post,
+                                               int kswitch = -1, float *lin_w = nullptr, float *ang_w = nullptr, const float *I_w = nullptr, int bodyA = 0, int bodyB = 0)
 {
 	const float4 *pa = reinterpret_cast<const float4 *>(rec) + (c < 3 ? c : 3 + post);
 	float *ps = sums;
@@ -111,10 +121,12 @@ __device__ __forceinline__ void quad_chain_run(quad_body &B, const float *rec, f
 #define QC_STEP(i) ps[i] = quad_row_step(B, a##i, s##i)
 	for (; k + 8 <= cnt; k += 8)
 	{
+		if (k == kswitch) quad_switch_body(B, c, lin_w, ang_w, I_w, bodyA, bodyB);
 		QC_STEP(0); QC_LOAD(0, 8); QC_STEP(1); QC_LOAD(1, 9); QC_STEP(2); QC_LOAD(2, 10); QC_STEP(3); QC_LOAD(3, 11);
 		QC_STEP(4); QC_LOAD(4, 12); QC_STEP(5); QC_LOAD(5, 13); QC_STEP(6); QC_LOAD(6, 14); QC_STEP(7); QC_LOAD(7, 15);
 		pa += 40; ps += 8;
 	}
+	if (k == kswitch) quad_switch_body(B, c, lin_w, ang_w, I_w, bodyA, bodyB);
 	const int left = cnt - k;      // 0..7 rows, already in the register sets
 	if (left > 0) QC_STEP(0);
 	__builtin_amdgcn_sched_barrier(0);

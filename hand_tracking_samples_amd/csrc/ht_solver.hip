@@ -65,6 +65,7 @@ template <int POOL_FLOATS, int NSUM_> struct lds_t
 	float pos[HT_MAXNB][3], q[HT_MAXNB][4];
 	float csum[NSUM];                      // impulse sum of every single-body row, in the order of the partitioned stream (+ read-ahead slack)
 	int ccnt[HT_MAXNB], cstart[HT_MAXNB];  // chain of body b: rows [cstart, cstart+ccnt) of the partitioned single-body stream
+	signed char cextra[HT_MAXNB];          // body b < 16 hosts the chain of this body >= 16 on its quad (-1: none): it follows b's rows, padded to a multiple of 8
 	unsigned lorder[ML2 / 3];            // two-body linear row groups (3 consecutive rows of a joint / a contact) sorted by step: group | rb0 << 16 | rb1 << 24; last slot = the idle entry
 	unsigned short lstart[ML2 / 3 + 2];  // step L = lorder[lstart[L] .. lstart[L+1]); a step is a level, split so that it holds <= 8 groups
 	unsigned aorder[MAXA2 + 1];            // angular row groups (runs of consecutive rows on the same body pair): first row | count << 8 | rb0 << 16 | rb1 << 24
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		int nc_ = (a.contacts && ph.use_collision) ? a.ncontacts[b] : 0;
 		if (nc_ > HT_MAXCONTACT) nc_ = HT_MAXCONTACT;
 		const int n1_ = (a.ray_rows ? S.nray : (a.rows_pre ? a.n_pre[b] : 0)) + (a.rows_cloud ? a.n_cloud[b] : 0);
-		if ((3 * nj + 3 * nc_ + 3) * LROW > POOL_FLOATS || n1_ > S.NSUM - QUAD_CHAIN_SLACK)
+		if ((3 * nj + 3 * nc_ + 3) * LROW > POOL_FLOATS || n1_ + 7 * (nb > 16 ? nb - 16 : 0) > S.NSUM - QUAD_CHAIN_SLACK)
 		{
 			if (lane == 0) a.retry[b] = 1;
 			return;
@@ -589,10 +590,11 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	const int ncl = a.rows_cloud ? a.n_cloud[b] : 0;
 	const int n1 = npre + ncl;
 	float *scr = a.scratch + (size_t)b * a.scratch_stride * CREC;
-	const bool sums_lds = MODE == SOLVE_FIRST || n1 + QUAD_CHAIN_SLACK <= S.NSUM;                                         // always true in a first build (checked above)
+	const int npad_max = 7 * (nb > 16 ? nb - 16 : 0);      // rows that may be added to pad host chains (below)
+	const bool sums_lds = MODE == SOLVE_FIRST || n1 + npad_max + QUAD_CHAIN_SLACK <= S.NSUM;                                         // always true in a first build (checked above)
 	float *const gsum = a.scratch + (size_t)a.batch * a.scratch_stride * CREC + (size_t)b * a.scratch_stride;      // this frame's sums in HBM, behind all frames' records
-	if (sums_lds) { for (int i = lane; i < n1 + QUAD_CHAIN_SLACK; i += 64) S.csum[i] = 0.0f; }
-	else for (int i = lane; i < n1 + QUAD_CHAIN_SLACK && i < a.scratch_stride; i += 64) gsum[i] = 0.0f;
+	if (sums_lds) { for (int i = lane; i < n1 + npad_max + QUAD_CHAIN_SLACK; i += 64) S.csum[i] = 0.0f; }
+	else for (int i = lane; i < n1 + npad_max + QUAD_CHAIN_SLACK && i < a.scratch_stride; i += 64) gsum[i] = 0.0f;
 	auto row_ptr = [&](int i) -> const float * {
 		if (i < npre) return a.ray_rows ? S.ray[i] : a.rows_pre + ((size_t)b * a.pre_stride + i) * HT_ROW;
 		return a.rows_cloud + ((size_t)b * M.pts_cap + (i - npre)) * HT_ROW;
@@ -612,11 +614,37 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			todo &= ~m;
 		}
 	}
-	int mystart = mycnt;                               // exclusive prefix over lanes = segment start of body `lane`
+	// Sixteen quads walk the chains.  A body beyond the 16th rides on the quad of one of the first sixteen: it goes to the one with the fewest rows that
+	// does not host yet, its rows follow the host's in the stream, and the host's rows are padded to a multiple of 8 with records that change nothing
+	// (zero direction, zero limits: impulse 0), so that the quad changes body at a block boundary of the chain walk (quad_chain_run).
+	int myextra = -1, myhost = -1;
+	{
+		int avail = (lane < 16 && lane < nb) ? mycnt : 0x7fffff;
+		for (int e = 16; e < nb; e++)
+		{
+			int key = (avail << 6) | lane;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_xor(key, o); key = v < key ? v : key; }
+			const int h = key & 63;
+			if (lane == h) { myextra = e; avail = 0x7fffff; }
+			if (lane == e) myhost = h;
+		}
+	}
+	const int extracnt = __shfl(mycnt, myextra >= 0 ? myextra : lane);
+	const int mylen = lane >= 16 ? 0 : (myextra >= 0 && extracnt > 0 ? ((mycnt + 7) & ~7) + extracnt : mycnt);      // rows of this lane's slot of the stream
+	if (myextra >= 0 && extracnt == 0) myextra = -1;                                                                  // nothing to host
+	int mystart = mylen;                               // exclusive prefix over lanes = segment start of body `lane`
 #pragma unroll
 	for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(mystart, o); if (lane >= o) mystart += v; }
-	mystart -= mycnt;
-	if (lane < HT_MAXNB) { S.ccnt[lane] = (a.dbg & 1) ? 0 : mycnt; S.cstart[lane] = mystart; }
+	mystart -= mylen;
+	{
+		const int hs = __shfl(mystart, myhost >= 0 ? myhost : lane), hc = __shfl(mycnt, myhost >= 0 ? myhost : lane);
+		if (myhost >= 0) mystart = hs + ((hc + 7) & ~7);      // an extra body's rows start behind its host's padded rows
+	}
+	if (lane < HT_MAXNB) { S.ccnt[lane] = (a.dbg & 1) ? 0 : mycnt; S.cstart[lane] = mystart; S.cextra[lane] = (signed char)((a.dbg & 1) ? -1 : myextra); }
+	if (myextra >= 0)      // the padding records of this host
+		for (int i = mystart + mycnt; i < mystart + ((mycnt + 7) & ~7); i++)
+			if (i < a.scratch_stride - QUAD_CHAIN_SLACK) quad_write_record(scr + (size_t)i * CREC, V3(0, 0, 0), V3(0, 0, 0), 0.0f, 0.0f, 1.0f, 0.0f, 0.0f);
 	int myrun = 0;
 	for (int base = 0; base < n1; base += 64)          // pass B: placement in stable order + pre-compute
 	{
@@ -681,23 +709,26 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	{
 		const bool post = sweep >= ph.iterations;
 		const int tsoff = post ? 1 : 0;                                   // RemoveBias (physics.h:288): ts_post = min(ts, ts_nobias) was stored next to ts
-		// (1) chains: quad q applies the single-body rows of body q (then q+16) in order; momenta, inertia row and mass stay in registers.
+		// (1) chains: quad q applies the single-body rows of body q (then those of a body >= 16 it hosts) in order; momenta, inertia row and mass stay in registers.
 		//     Lane c < 3 of the quad reads r1[c] and n[c] of a record, lane 3 reads its target speed (ts or ts_post).
-		for (int half = 0; half * 16 < nb; half++)
 		{
-			const int body = quad + 16 * half;
+			const int body = quad;
 			const bool has = body < nb;
 			const int cnt = has ? S.ccnt[body] : 0, start = has ? S.cstart[body] : 0;
-			if (cnt > 0)
+			const int ex = has ? S.cextra[body] : -1;                      // a body >= 16 whose rows follow this body's padded ones
+			const int kswitch = ex >= 0 ? (cnt + 7) & ~7 : -1;
+			const int total = ex >= 0 ? kswitch + S.ccnt[ex] : cnt;
+			if (total > 0)
 			{
 				const float l = lin_w[4 * body + c], av = ang_w[4 * body + c];       // lane 3 carries massinv / friction here and never stores
 				const float minv = lin_w[4 * body + 3];
 				const float Ix = I_w[12 * body + c], Iy = I_w[12 * body + 4 + c], Iz = I_w[12 * body + 8 + c];
 				quad_body qb = { l, av, minv, Ix, Iy, Iz };
 				// RemoveBias (physics.h:288): lane 3 switches to the ts_post slot
-				if (MODE == SOLVE_FIRST || sums_lds) quad_chain_run(qb, scr + (size_t)start * CREC, S.csum + start, cnt, c, tsoff);
-				else quad_chain_run(qb, scr + (size_t)start * CREC, gsum + start, cnt, c, tsoff);
-				if (c < 3) { lin_w[4 * body + c] = qb.l; ang_w[4 * body + c] = qb.av; }
+				if (MODE == SOLVE_FIRST || sums_lds) quad_chain_run(qb, scr + (size_t)start * CREC, S.csum + start, total, c, tsoff, kswitch, lin_w, ang_w, I_w, body, ex);
+				else quad_chain_run(qb, scr + (size_t)start * CREC, gsum + start, total, c, tsoff, kswitch, lin_w, ang_w, I_w, body, ex);
+				const int last = ex >= 0 ? ex : body;
+				if (c < 3) { lin_w[4 * last + c] = qb.l; ang_w[4 * last + c] = qb.av; }
 			}
 		}
 		__builtin_amdgcn_wave_barrier();

@@ -12,7 +12,7 @@
 #define CHECK_BATCH(ctx, B) do { if ((B) < 1 || (B) > (ctx)->B) { (ctx)->err = "batch exceeds the capacity given to ht_create"; return HT_ERR_ARG; } } while (0)
 #define CHECK_RANGE(ctx, first, n) do { if ((first) < 0 || (n) < 1 || (first) + (n) > (ctx)->B) { (ctx)->err = "slot range exceeds the capacity given to ht_create"; return HT_ERR_ARG; } } while (0)
 
-static int scratch_stride(const ht_ctx *ctx) { return ctx->model.pts_cap + 5 * ctx->model.nb + 32; }
+static int scratch_stride(const ht_ctx *ctx) { return (int)ht_scratch_rows((size_t)ctx->model.pts_cap, (size_t)ctx->model.nb); }
 
 // ---- building blocks ------------------------------------------------------------------------------------------------
 static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int *n_pre, bool cloud, bool contacts, const int *active,
