@@ -36,6 +36,13 @@ static inline int ht_tuning_flags()
 	return 0;
 #endif
 }
+// In device code the switches are tested through HT_DBG(flags, bit): a constant 0 in the shipped build, so the kernels carry none of the tuning code
+// (no cycle counters, no skip branches), and `flags & bit` in a -DHT_TUNING build.
+#ifdef HT_TUNING
+#define HT_DBG(flags, bit) ((flags) & (bit))
+#else
+#define HT_DBG(flags, bit) 0
+#endif
 static inline bool ht_tuning_env(const char *name)
 {
 #ifdef HT_TUNING

@@ -501,7 +501,7 @@ __device__ void separated_wave(bool run, const support_t &A, const support_t &B,
 #pragma unroll
 		for (int k = 0; k < 4; k++) s[k] = V3(__shfl(tet.W[k].p.x, src), __shfl(tet.W[k].p.y, src), __shfl(tet.W[k].p.z, src));
 		bool capped = false;
-		v4 mpp = (dbg & 32) ? V4(0, 0, 1, -0.001f) : expanding_polytope_wave(em, s[0], s[1], s[2], s[3], Ab, Bb, lane, cyc, capped);
+		v4 mpp = HT_DBG(dbg, 32) ? V4(0, 0, 1, -0.001f) : expanding_polytope_wave(em, s[0], s[1], s[2], s[3], Ab, Bb, lane, cyc, capped);
 		if (capped && caps && lane == 0) atomicAdd(caps, 1);
 		if (lane == src)
 		{
@@ -575,7 +575,7 @@ template <int GJK_WPF> __global__ __launch_bounds__(64 * GJK_FRAMES * GJK_WPF) v
 				if (length(d) > P[i][7] + P[j][7]) keep = false;
 				if (M.ignore[i] & (1u << j)) keep = false;
 			}
-			if (dbg & 8) keep = false;
+			if (HT_DBG(dbg, 8)) keep = false;
 			const unsigned long long m = __ballot(keep);
 			if (keep) { const int dst = nc + __popcll(m & ((1ull << lane) - 1ull)); F.cand[dst][0] = (unsigned char)i; F.cand[dst][1] = (unsigned char)j; }
 			nc += __popcll(m);
@@ -589,7 +589,7 @@ template <int GJK_WPF> __global__ __launch_bounds__(64 * GJK_FRAMES * GJK_WPF) v
 	int nchunk = 0;       // the block's frames step through the same number of chunks so that they can share barriers
 	for (int f = 0; f < GJK_FRAMES; f++) { const int n = reinterpret_cast<gjk_frame_mem *>(fbase + f * gjk_frame_stride())->nchunk; nchunk = n > nchunk ? n : nchunk; }
 	const int gsh = ncand <= GJK_LANES / 4 ? 2 : ncand <= GJK_LANES / 2 ? 1 : 0, grp = 1 << gsh, sub = lane & (grp - 1);
-	long long cyc[7] = { 0, 0, 0, 0, 0, 0, 0 }, cycj[7] = { 0, 0, 0, 0, 0, 0, 0 }; const bool stats = (dbg & 2048) != 0; const long long t_begin = stats ? clock64() : 0; int njig = 0;
+	long long cyc[7] = { 0, 0, 0, 0, 0, 0, 0 }, cycj[7] = { 0, 0, 0, 0, 0, 0, 0 }; const bool stats = HT_DBG(dbg, 2048) != 0; const long long t_begin = stats ? clock64() : 0; int njig = 0;
 	int nout = 0;                       // contacts written so far for this frame (frame-uniform)
 	for (int ch = 0; ch < nchunk; ch++)
 	{
@@ -602,7 +602,7 @@ template <int GJK_WPF> __global__ __launch_bounds__(64 * GJK_FRAMES * GJK_WPF) v
 		Bs.voff = M.vert_off[j]; Bs.n = M.vert_off[j + 1] - M.vert_off[j]; Bs.pos = V3(P[j][0], P[j][1], P[j][2]); Bs.q = V4(P[j][3], P[j][4], P[j][5], P[j][6]); Bs.outer = 0; Bs.opos = V3(0, 0, 0); Bs.oq = V4(0, 0, 0, 1); Bs.sub = sub; Bs.grp = grp;
 		gjk_hit hits[5];
 		int hc = 0, status;
-		separated_wave(keep, A, Bs, (dbg & 16) ? 0.0f : driftmax, em, lane, status, hits[0], dbg, stats ? cyc : nullptr, caps);
+		separated_wave(keep, A, Bs, HT_DBG(dbg, 16) ? 0.0f : driftmax, em, lane, status, hits[0], dbg, stats ? cyc : nullptr, caps);
 		const bool touching = keep && status == 0 && !(hits[0].separation > driftmax);      // identical in all members of a group
 		if (touching) hc = 1;
 		const float dmin = fminf(M.bodyc[i * HT_BC + HT_BC_DIAM], M.bodyc[j * HT_BC + HT_BC_DIAM]);
@@ -748,7 +748,7 @@ template <bool JIG> __device__ void co_pass(const ht_model_dev &M, const co_lds 
 	co_block &H = *L.H;
 	const int lane = t & 63, wave = t >> 6;
 	const int total = JIG ? H.jtotal : H.total;
-	const float cutoff = JIG ? 0.0f : ((dbg & 16) ? 0.0f : driftmax);
+	const float cutoff = JIG ? 0.0f : (HT_DBG(dbg, 16) ? 0.0f : driftmax);
 	for (int x0 = 0; x0 < total; x0 += 64 * CO_OWN)
 	{
 		// ---- this lane's run ----
@@ -903,7 +903,7 @@ template <bool JIG> __device__ void co_pass(const ht_model_dev &M, const co_lds 
 				Bb.voff = M.cvert_off[J.bj]; Bb.n = M.vert_off[J.bj + 1] - M.vert_off[J.bj]; Bb.pos = V3(BB.pos[0], BB.pos[1], BB.pos[2]); Bb.q = V4(BB.q[0], BB.q[1], BB.q[2], BB.q[3]);
 				Bb.outer = 0; Bb.opos = V3(0, 0, 0); Bb.oq = V4(0, 0, 0, 1); Bb.sub = 0; Bb.grp = 1;
 				bool capped = false;
-				const v4 mpp = (dbg & 32) ? V4(0, 0, 1, -0.001f) : expanding_polytope_wave(em, V3(J.p[0][0], J.p[0][1], J.p[0][2]), V3(J.p[1][0], J.p[1][1], J.p[1][2]), V3(J.p[2][0], J.p[2][1], J.p[2][2]),
+				const v4 mpp = HT_DBG(dbg, 32) ? V4(0, 0, 1, -0.001f) : expanding_polytope_wave(em, V3(J.p[0][0], J.p[0][1], J.p[0][2]), V3(J.p[1][0], J.p[1][1], J.p[1][2]), V3(J.p[2][0], J.p[2][1], J.p[2][2]),
 				                                                                           V3(J.p[3][0], J.p[3][1], J.p[3][2]), Ab, Bb, lane, nullptr, capped);
 				if (lane == 0) { J.res[0] = mpp.x; J.res[1] = mpp.y; J.res[2] = mpp.z; J.res[3] = mpp.w; if (capped && caps) atomicAdd(caps, 1); atomicAdd(&L.F[J.f].nepa, 1); }
 			}
@@ -974,7 +974,7 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 	L.jobs = reinterpret_cast<co_job *>(base); base += (size_t)CO_EPAQ * sizeof(co_job);
 	epa_mem &em = *reinterpret_cast<epa_mem *>(base + wave * gjk_wave_stride());
 	co_block &H = *L.H;
-	const long long t_begin = (dbg & 2048) ? clock64() : 0;
+	const long long t_begin = HT_DBG(dbg, 2048) ? clock64() : 0;
 	if (active_flag)      // a masked launch: blocks without a live frame leave at once (a handful of frames of a large batch take this kernel on their own)
 	{
 		bool any = false;
@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 				if (length(d) > F.body[i].radius + F.body[j].radius) keep = false;
 				if (M.ignore[i] & (1u << j)) keep = false;
 			}
-			if (dbg & 8) keep = false;
+			if (HT_DBG(dbg, 8)) keep = false;
 			const unsigned long long m = __ballot(keep);
 			if (keep) { const int dst = nc + __popcll(m & ((1ull << lane) - 1ull)); F.cand[dst][0] = (unsigned char)i; F.cand[dst][1] = (unsigned char)j; }
 			nc += __popcll(m);
@@ -1033,10 +1033,10 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 	}
 	__syncthreads();
 	long long cyc[5] = { 0, 0, 0, 0, 0 };
-	const long long t_pro = (dbg & 2048) ? clock64() : 0;
+	const long long t_pro = HT_DBG(dbg, 2048) ? clock64() : 0;
 	int parity = 0;
-	co_pass<false>(M, L, nfr, em, driftmax, jiggle_sin, t, dbg, caps, parity, (dbg & 2048) ? cyc : nullptr);
-	const long long t_post = (dbg & 2048) ? clock64() : 0;
+	co_pass<false>(M, L, nfr, em, driftmax, jiggle_sin, t, dbg, caps, parity, HT_DBG(dbg, 2048) ? cyc : nullptr);
+	const long long t_post = HT_DBG(dbg, 2048) ? clock64() : 0;
 	if (t == 0)
 	{
 		int tot = 0;
@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 			}
 		}
 		if (live && lane == 0) { ncontacts[b] = total < HT_MAXCONTACT ? total : HT_MAXCONTACT; if (total > HT_MAXCONTACT && caps) atomicAdd(caps + 1, total - HT_MAXCONTACT); }
-		if ((dbg & 2048) && live && lane == 0 && total < HT_MAXCONTACT - 1)      // timing experiments: per-frame statistics accumulate in the last contact slot
+		if (HT_DBG(dbg, 2048) && live && lane == 0 && total < HT_MAXCONTACT - 1)      // timing experiments: per-frame statistics accumulate in the last contact slot
 		{
 			float *o = contacts + ((size_t)b * HT_MAXCONTACT + HT_MAXCONTACT - 1) * HT_CONTACT;
 			o[0] += 1.0f; o[1] += (float)cyc[0]; o[2] += (float)cyc[2]; o[3] += (float)F.nepa; o[4] += (float)cyc[3]; o[5] += (float)cyc[1]; o[6] += (float)cyc[4]; o[7] += (float)(clock64() - t_begin);

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		}
 	}
 
-	if (a.dbg & 256) return;
+	if (HT_DBG(a.dbg, 256)) return;
 	// ---- angular rows: [ApplyAngles 12] [arm cone 1] [joint ranges], generated by the lane that owns them ----
 	// slowfit's RelativeAngularConstraints (physmodel.h:423-432, filter handtrack.h:799): one row per ranged axis of every joint that passes
 	const bool rel = a.sf_refpose && a.sf_hold;
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		}
 	}
 
-	if (a.dbg & 512) return;
+	if (HT_DBG(a.dbg, 512)) return;
 	// ---- two-body linear rows: joints (physmodel.h:328-334) then contacts (physics.h:463-489), each built by one lane into its LDS record ----
 	int nc = (a.contacts && ph.use_collision) ? a.ncontacts[b] : 0;
 	if (nc > HT_MAXCONTACT) nc = HT_MAXCONTACT;
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	}
 	__syncthreads();
 	const int nlev_lin = S.nlev_lin, nlev_ang = S.nlev_ang;
-	if (a.dbg & 64) return;
+	if (HT_DBG(a.dbg, 64)) return;
 
 	// ---- single-body prefix: [ray rows | chamber rows] then cloud rows; stable partition by body + pre-compute -> record stream in the frame's scratch (HBM / L2) ----
 	const int npre_g = a.rows_pre ? a.n_pre[b] : 0;
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		const int hs = __shfl(mystart, myhost >= 0 ? myhost : lane), hc = __shfl(mycnt, myhost >= 0 ? myhost : lane);
 		if (myhost >= 0) mystart = hs + ((hc + 7) & ~7);      // an extra body's rows start behind its host's padded rows
 	}
-	if (lane < HT_MAXNB) { S.ccnt[lane] = (a.dbg & 1) ? 0 : mycnt; S.cstart[lane] = mystart; S.cextra[lane] = (signed char)((a.dbg & 1) ? -1 : myextra); }
+	if (lane < HT_MAXNB) { S.ccnt[lane] = HT_DBG(a.dbg, 1) ? 0 : mycnt; S.cstart[lane] = mystart; S.cextra[lane] = (signed char)(HT_DBG(a.dbg, 1) ? -1 : myextra); }
 	if (myextra >= 0)      // the padding records of this host
 		for (int i = mystart + mycnt; i < mystart + ((mycnt + 7) & ~7); i++)
 			if (i < a.scratch_stride - QUAD_CHAIN_SLACK) quad_write_record(scr + (size_t)i * CREC, V3(0, 0, 0), V3(0, 0, 0), 0.0f, 0.0f, 1.0f, 0.0f, 0.0f);
@@ -691,9 +691,9 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	if (lane < 2 * AROW) S.arec[na * AROW + lane] = 0.0f;      // idle record + read-ahead slack
 	__syncthreads();
 
-	if (a.dbg & 128) return;
+	if (HT_DBG(a.dbg, 128)) return;
 	// ---- Gauss-Seidel sweeps ----
-	const bool stats = (a.dbg & 2048) != 0;          // timing experiments: per-frame cycle counts accumulated in the last scratch record
+	const bool stats = HT_DBG(a.dbg, 2048) != 0;          // timing experiments: per-frame cycle counts accumulated in the last scratch record
 	long long cyc_chain = 0, cyc_lin = 0, cyc_ang = 0, t_mark = stats ? clock64() : 0;
 	const long long t_begin = t_mark;
 	v3 pos_next = V3(0, 0, 0); v4 q_next = V4(0, 0, 0, 1);
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		//     registers.  Pairs without a group work on the idle group / idle body, so a step is branch-free.  Three-stage software
 		//     pipeline: the sort entry is fetched two steps ahead, the group's records and the (sweep-invariant) inverse inertia and mass
 		//     one step ahead; only the momenta are read after the previous step's stores.  Two register sets alternate.
-		if (!(a.dbg & 2) && nlev_lin > 0)
+		if (!HT_DBG(a.dbg, 2) && nlev_lin > 0)
 		{
 			struct lset { unsigned e; int meta; float rv1, rv2, n0, n1, n2, Ix, Iy, Iz, minv; float4 s0, s1, s2; float e0, e1, e2, q0, q1, q2, i0, i1, i2; };
 			auto entry = [&](int L) -> unsigned {
@@ -813,7 +813,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		if (stats) { const long long t = clock64(); cyc_lin += t - t_mark; t_mark = t; }
 		// (3) angular rows (LimitAngular::Iter physics.h:251-265): one run of consecutive rows on the same body pair per lane pair and step,
 		//     same pipeline; inside a run the next row's record is read while the current row is applied
-		if (!(a.dbg & 4) && nlev_ang > 0)
+		if (!HT_DBG(a.dbg, 4) && nlev_ang > 0)
 		{
 			struct aset { unsigned e; float ax, ts, mn, mx, s2t, torque, Ix, Iy, Iz; };
 			auto entry = [&](int L) -> unsigned {
