@@ -22,7 +22,7 @@
 static void default_params(ht_params &p)     // handtrack.h:523-547, physics.h:45-47, physmodel.h:234, handtrack.h:369,450
 {
 	p.full_reset_on_error = 0.6f; p.angles_only = 0; p.always_take_cnn = 0; p.drangey = 0.7f; p.boundary_planes = 1; p.microforce = 1.0f;
-	p.cloudforce_max_point = 15.0f; p.cloudforce_max_sum = 3000.0f; p.mainthreadpasses = 1; p.subsample_fraction = 4; p.min_point_num = 400;
+	p.cloudforce_max_point = 15.0f; p.cloudforce_max_sum = 3000.0f; p.mainthreadpasses = 1; p.subsample_fraction = 4; p.min_point_num = 400; p.subsample_voxel = 0; p.subsample_size = 0.0f;
 	p.accum_error_threshold = 0.0f; p.min_cray_prob = 0.0f; p.steps = 5; p.steps_keypoints = 3; p.steps_keyangles = 2; p.steps_palmangle = 2; p.steps_cloudstart = 1; p.steps_unibody = 3;
 	p.physics_iterations = 16; p.physics_iterations_post = 4; p.physics_use_collision = 1; p.physics_weak_force = 0.4f; p.bone_sum_error_scale = 4.0f; p.unibody_force = 0.1f;
 }
@@ -206,10 +206,7 @@ extern "C" int ht_config_read(const char *jsonfile, ht_params *p, float *segment
 	if (!ht_json_top_level(jsonfile, num, err)) { fprintf(stderr, "ht_config_read: %s\n", err.c_str()); return HT_ERR_IO; }
 	auto F = [&](const char *k) -> float { auto it = num.find(k); return it == num.end() ? 0.0f : strtof(it->second.c_str(), nullptr); };       // istringstream >> float
 	auto I = [&](const char *k) -> int { auto it = num.find(k); return it == num.end() ? 0 : (int)strtol(it->second.c_str(), nullptr, 10); };    // istringstream >> int
-	// The one option of the tracker that is not built: voxel sub-sampling of the main-thread cloud (physmodel.h:66-118, default off, no
-	// application sets it).  It converts negative floats to unsigned int (undefined behaviour in C++), so there is no reference result to
-	// reproduce beyond one compiler's; a configuration that asks for it is refused instead of being silently run with the spatial rule.
-	if (I("subsample_voxel") != 0) { fprintf(stderr, "ht_config_read: %s sets subsample_voxel, which this library does not implement\n", jsonfile); return HT_ERR_ARG; }
+	p->subsample_voxel = I("subsample_voxel"); p->subsample_size = F("subsample_size");
 	if (segment_scale) *segment_scale = F("segment_scale");
 	p->full_reset_on_error = F("full_reset_on_error"); p->angles_only = I("angles_only") != 0; p->always_take_cnn = I("always_take_cnn"); p->drangey = F("drangey");
 	p->boundary_planes = I("boundary_planes"); p->microforce = F("microforce"); p->mainthreadpasses = I("mainthreadpasses"); p->subsample_fraction = I("subsample_fraction");
@@ -375,6 +372,7 @@ extern "C" int ht_set_params(ht_ctx *ctx, const ht_params *p)
 	else if (p->physics_iterations < 0 || p->physics_iterations_post < 0) bad = "physics iteration counts must be >= 0";
 	else if (p->mainthreadpasses < 0) bad = "mainthreadpasses must be >= 0";
 	else if (p->min_point_num < 0) bad = "min_point_num must be >= 0";
+	else if (p->subsample_voxel && !(p->subsample_size > 0.0f)) bad = "subsample_voxel needs a positive subsample_size (the voxel edge in metres)";
 	if (bad) { ctx->err = std::string("ht_set_params: ") + bad; return HT_ERR_ARG; }
 	ctx->par = *p; sync_params(ctx);
 	return HT_OK;
@@ -588,13 +586,15 @@ int ht_reserve_points_locked(ht_ctx *ctx, int points)
 	if (ctx->d_pts && want <= ctx->model.pts_cap) return HT_OK;
 	const size_t B = (size_t)ctx->B, nb = (size_t)ctx->model.nb, cap = (size_t)want;
 	HIPCHK(ctx, ht_sync_all(ctx));
-	void *old[3] = { ctx->d_pts, ctx->d_rows, ctx->d_scratch };
+	const bool had_voxel = ctx->d_ptsv != nullptr;
+	void *old[4] = { ctx->d_pts, ctx->d_rows, ctx->d_scratch, ctx->d_ptsv };
 	for (void *o : old) if (o) { for (auto &q : ctx->allocs) if (q == o) { q = ctx->allocs.back(); ctx->allocs.pop_back(); break; } (void)hipFree(o); }
-	ctx->d_pts = nullptr; ctx->d_rows = nullptr; ctx->d_scratch = nullptr; ctx->model.pts_cap = 0;
+	ctx->d_pts = nullptr; ctx->d_rows = nullptr; ctx->d_scratch = nullptr; ctx->d_ptsv = nullptr; ctx->model.pts_cap = 0;
 	int r;
 	if ((r = dev_alloc(ctx, &ctx->d_pts, B * cap))) return r;
 	if ((r = dev_alloc(ctx, &ctx->d_rows, B * cap * HT_ROW))) return r;
 	if ((r = dev_alloc(ctx, &ctx->d_scratch, B * ht_scratch_rows(cap, nb) * 21))) return r;      // 20 floats per row record + 1 for the impulse sum of over-size frames
+	if (had_voxel && (r = dev_alloc(ctx, &ctx->d_ptsv, B * cap))) return r;
 	ctx->model.pts_cap = want;
 	return HT_OK;
 }

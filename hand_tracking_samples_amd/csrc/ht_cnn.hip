@@ -495,7 +495,81 @@ __global__ __launch_bounds__(64) void k_softmax_decode(const float *__restrict__
 	for (int i = lane; i < HT_ANALYSIS; i += 64) analysis[(size_t)b * HT_ANALYSIS + i] = an[i];
 }
 
+// ------------------------------------------------------------------------------------------------- k_voxel
+// voxelsubsample<2048> (physmodel.h:66-118) of a frame's in-range points, for the main-thread cloud when HandTracker::subsample_voxel is set
+// (handtrack.h:751): the points are summed per voxel in an open-addressing table of 2048 buckets (hash = dot of the integer cell with three
+// primes, linear probing) in the order they come -- a float sum per bucket, so the order is the result -- and a full table flushes the home bucket
+// of the point that found no room; then every bucket holding at least `min_count` points gives its mean, in table order.  One wave per frame: lane
+// 0 inserts (a probe is one 128-bit LDS read of cell + count), all lanes clear the table and compact the output.  The reference converts the
+// floor of a negative coordinate to unsigned (undefined behaviour); the compiled reference wraps, which is what the signed conversion here gives.
+#define VOX_N 2048
+__global__ __launch_bounds__(64) void k_voxel(const float4 *__restrict__ all, const int *__restrict__ nall, int cap, float size, int min_count, float4 *__restrict__ out, int *__restrict__ nout)
+{
+	__shared__ int4 key[VOX_N];        // cell x, y, z, count
+	__shared__ float4 sum[VOX_N];
+	const int b = blockIdx.x, lane = threadIdx.x;
+	for (int i = lane; i < VOX_N; i += 64) { key[i] = make_int4(0, 0, 0, 0); sum[i] = make_float4(0, 0, 0, 0); }
+	__syncthreads();
+	const float4 *src = all + (size_t)b * cap;
+	float4 *dst = out + (size_t)b * cap;
+	const int n = nall[b];
+	__shared__ int nflush;
+	if (lane == 0)
+	{
+		const float ivs = 1.0f / size;
+		int m = 0;
+		for (int k = 0; k < n; k++)
+		{
+			const float4 pt = src[k];
+			const int ix = (int)floorf(pt.x * ivs), iy = (int)floorf(pt.y * ivs), iz = (int)floorf(pt.z * ivs);
+			const unsigned hash = (54851u * (unsigned)ix + 11909u * (unsigned)iy) + 24781u * (unsigned)iz;
+			unsigned i = 0;
+			for (; i < VOX_N; i++)
+			{
+				const unsigned s = (hash + i) & (VOX_N - 1);
+				const int4 q = key[s];
+				if (q.w == 0 || (q.x == ix && q.y == iy && q.z == iz))
+				{
+					const float4 a = sum[s];
+					key[s] = make_int4(ix, iy, iz, q.w + 1);
+					sum[s] = make_float4(a.x + pt.x, a.y + pt.y, a.z + pt.z, 0.0f);
+					break;
+				}
+			}
+			if (i == VOX_N)      // flush on collision
+			{
+				const unsigned s = hash & (VOX_N - 1);
+				const float4 a = sum[s]; const float c = (float)key[s].w;
+				if (m < cap) dst[m] = make_float4(a.x / c, a.y / c, a.z / c, 0.0f);
+				m++;
+				key[s] = make_int4(ix, iy, iz, 1); sum[s] = make_float4(pt.x, pt.y, pt.z, 0.0f);
+			}
+		}
+		nflush = m;
+	}
+	__syncthreads();
+	int m = nflush;
+	for (int base = 0; base < VOX_N; base += 64)
+	{
+		const int4 q = key[base + lane];
+		const bool keep = q.w >= min_count;
+		const unsigned long long mask = __ballot(keep);
+		if (keep)
+		{
+			const int o = m + __popcll(mask & ((1ull << lane) - 1ull));
+			const float4 a = sum[base + lane]; const float c = (float)q.w;
+			if (o < cap) dst[o] = make_float4(a.x / c, a.y / c, a.z / c, 0.0f);
+		}
+		m += __popcll(mask);
+	}
+	if (lane == 0) nout[b] = m < cap ? m : cap;
+}
+
 // ------------------------------------------------------------------------------------------------- host launchers
+void ht_launch_voxel(const float4 *all, const int *nall, int cap, float size, int min_count, float4 *out, int *nout, int B, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_voxel, dim3(B), dim3(64), 0, s, all, nall, cap, size, min_count, out, nout);
+}
 void ht_launch_prepare(const uint16_t *depth, const float *cams, float drangey, int fraction, float *cnn_in, float4 *pts, int *npts, int cap, int B, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_prepare, dim3(B), dim3(256), 0, s, depth, cams, drangey, fraction, cnn_in, pts, npts, cap);

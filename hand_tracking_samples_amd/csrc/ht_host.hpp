@@ -39,6 +39,7 @@ struct ht_ctx
 	uint16_t *d_seg_tiles = nullptr, *d_frames = nullptr; float *d_frame_cams = nullptr, *d_frame_cams_in = nullptr; int *d_overflow = nullptr; size_t frames_cap = 0;      // full-size frame path (ht_update_frames)
 	float *d_cams = nullptr, *d_cnn_in = nullptr, *d_act1 = nullptr, *d_act2 = nullptr, *d_act3 = nullptr, *d_logits = nullptr, *d_cnn_out = nullptr, *d_analysis = nullptr;
 	float4 *d_pts = nullptr; int *d_npts = nullptr;
+	float4 *d_ptsv = nullptr; int *d_nptsv = nullptr;          // the main-thread cloud when subsample_voxel is set (allocated on first use; d_pts stays the CNN job's cloud)
 	float *d_state[2] = { nullptr, nullptr };      // [B][nb][HT_STATE_STRIDE]: 0 handmodel, 1 othermodel
 	float *d_prev_err = nullptr; int *d_initializing = nullptr;
 	float *d_err_old = nullptr, *d_err_new = nullptr; int *d_flags = nullptr, *d_nflags = nullptr;

@@ -15,6 +15,13 @@
 static int scratch_stride(const ht_ctx *ctx) { return (int)ht_scratch_rows((size_t)ctx->model.pts_cap, (size_t)ctx->model.nb); }
 
 // ---- building blocks ------------------------------------------------------------------------------------------------
+static int dev_alloc_points(ht_ctx *ctx)      // the second cloud of a context that uses voxel sub-sampling
+{
+	void *a = nullptr, *b = nullptr;
+	HIPCHK(ctx, hipMalloc(&a, (size_t)ctx->B * ctx->model.pts_cap * sizeof(float4))); ctx->allocs.push_back(a); ctx->d_ptsv = (float4 *)a;
+	if (!ctx->d_nptsv) { HIPCHK(ctx, hipMalloc(&b, (size_t)ctx->B * sizeof(int))); ctx->allocs.push_back(b); ctx->d_nptsv = (int *)b; }
+	return HT_OK;
+}
 static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int *n_pre, bool cloud, bool contacts, const int *active,
                        int apply_angles, float drive_force, int ray_rows, int arm_cone, int zero_momenta, int B, hipStream_t s, bool shared_gpu = false)
 {
@@ -66,12 +73,14 @@ static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int 
 static void main_pass(ht_ctx *ctx, int B, hipStream_t s)
 {
 	const ht_params &p = ctx->par;
+	const float4 *pts = p.subsample_voxel ? ctx->d_ptsv : ctx->d_pts;      // handtrack.h:751: the main-thread cloud
+	const int *npts = p.subsample_voxel ? ctx->d_nptsv : ctx->d_npts;
 	const bool coll = ctx->phys.use_collision != 0;
 	static const bool no_side = ht_tuning_env("HT_NO_SIDE");
 	const bool par = !ctx->profile_phases && !no_side;
 	if (par) fork(ctx, s);
-	{ ht_prof_scope ps(ctx, "chamber", s, true); ht_launch_chamber(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, p.min_point_num, p.boundary_planes, 10.0f, ctx->d_chamber, ctx->d_nchamber, B, par ? ctx->side[1] : s); }
-	{ ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, ctx->d_cams, nullptr, 1, 0, 1, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[0] : s); }
+	{ ht_prof_scope ps(ctx, "chamber", s, true); ht_launch_chamber(ctx->model, ctx->d_state[0], pts, npts, p.min_point_num, p.boundary_planes, 10.0f, ctx->d_chamber, ctx->d_nchamber, B, par ? ctx->side[1] : s); }
+	{ ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[0], pts, npts, ctx->d_cams, nullptr, 1, 0, 1, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[0] : s); }
 	if (coll) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[0], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s); }
 	if (par) join(ctx, s, 2);
 	ht_prof_scope ps(ctx, "solve", s);
@@ -103,7 +112,7 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 	const ht_params &p = ctx->par;
 	const int nb = ctx->model.nb;
 	const int iw = fs ? fs->w : 64, ih = fs ? fs->h : 64;      // the image FitError looks at
-	{ const int npx = iw * ih, fr = p.subsample_fraction > 0 ? p.subsample_fraction : 1, n = (npx + fr - 1) / fr; if (n > ctx->model.pts_cap) { const int r = ht_reserve_points_locked(ctx, n); if (r) return r; } ctx->model.pts_bound = (n + 63) & ~63; }
+	{ const int npx = iw * ih, fr = p.subsample_fraction > 0 ? p.subsample_fraction : 1, n = (mode == UPD_FULL && p.subsample_voxel) ? npx : (npx + fr - 1) / fr; if (n > ctx->model.pts_cap) { const int r = ht_reserve_points_locked(ctx, n); if (r) return r; } ctx->model.pts_bound = (n + 63) & ~63; }
 	const float *img_cams = ctx->d_cams;
 	if (fs)
 	{
@@ -134,6 +143,16 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 			ht_launch_prepare_frame(d_depth, img_cams, fs->w, fs->h, p.drangey, p.subsample_fraction, ctx->d_pts, ctx->d_npts, ctx->d_overflow, ctx->model.pts_cap, B, s);
 		}
 		else ht_launch_prepare(d_depth, ctx->d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, ctx->d_pts, ctx->d_npts, ctx->model.pts_cap, B, s);
+		if (mode == UPD_FULL && p.subsample_voxel)
+		{
+			// the main-thread cloud of handtrack.h:751 with the voxel rule: ALL in-range points (taken once more, into the cloud-row array, which nothing
+			// uses before the first fit step) go through the voxel table; the CNN job keeps the every-n-th cloud above (handtrack.h:703)
+			if (!ctx->d_ptsv) { int r = dev_alloc_points(ctx); if (r) return r; }
+			float4 *all = reinterpret_cast<float4 *>(ctx->d_rows);
+			if (fs) ht_launch_prepare_frame(d_depth, img_cams, fs->w, fs->h, p.drangey, 1, all, ctx->d_nrows, ctx->d_overflow, ctx->model.pts_cap, B, s);
+			else ht_launch_prepare(d_depth, ctx->d_cams, p.drangey, 1, nullptr, all, ctx->d_nrows, ctx->model.pts_cap, B, s);
+			ht_launch_voxel(all, ctx->d_nrows, ctx->model.pts_cap, p.subsample_size, p.subsample_fraction, ctx->d_ptsv, ctx->d_nptsv, B, s);
+		}
 	}
 	float *cnn_out = d_cnn_out ? d_cnn_out : ctx->d_cnn_out;
 	static const bool no_overlap = ht_tuning_env("HT_NO_OVERLAP");      // timing experiments (-DHT_TUNING builds only)
@@ -180,7 +199,7 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 	ht_launch_accept(mode == UPD_CNN_MODEL ? nullptr : ctx->d_state[0], ctx->d_state[1], ctx->d_err_old, ctx->d_err_new, ctx->d_npts, ctx->d_prev_err, ctx->d_initializing, ctx->d_accepted, nb, B, p, s);
 	if (mode != UPD_FULL) { ht_launch_output(ctx->model, ctx->d_state[1], ctx->d_npts, ctx->d_initializing, p.min_point_num, d_poses_out, B, s, 1); return HT_OK; }      // othermodel.GetPose()
 	for (int i = 0; !p.angles_only && i < p.mainthreadpasses; i++) main_pass(ctx, B, s);
-	ht_launch_output(ctx->model, ctx->d_state[0], ctx->d_npts, ctx->d_initializing, p.min_point_num, d_poses_out, B, s);
+	ht_launch_output(ctx->model, ctx->d_state[0], p.subsample_voxel ? ctx->d_nptsv : ctx->d_npts, ctx->d_initializing, p.min_point_num, d_poses_out, B, s);
 	return HT_OK;
 }
 

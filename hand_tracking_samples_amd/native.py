@@ -32,7 +32,8 @@ class Params(C.Structure):
                 ("subsample_fraction", C.c_int), ("min_point_num", C.c_int), ("accum_error_threshold", C.c_float), ("min_cray_prob", C.c_float),
                 ("steps", C.c_int), ("steps_keypoints", C.c_int), ("steps_keyangles", C.c_int), ("steps_palmangle", C.c_int), ("steps_cloudstart", C.c_int), ("steps_unibody", C.c_int),
                 ("physics_iterations", C.c_int), ("physics_iterations_post", C.c_int), ("physics_use_collision", C.c_int),
-                ("physics_weak_force", C.c_float), ("bone_sum_error_scale", C.c_float), ("unibody_force", C.c_float)]
+                ("physics_weak_force", C.c_float), ("bone_sum_error_scale", C.c_float), ("unibody_force", C.c_float),
+                ("subsample_voxel", C.c_int), ("subsample_size", C.c_float)]
 
 
 class HTError(RuntimeError):

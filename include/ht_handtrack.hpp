@@ -118,6 +118,7 @@ struct HandTracker                                                              
 	float segment_scale = 0.17f;
 	float full_reset_on_error = 0.6f; bool angles_only = false; bool always_take_cnn = false; float drangey = 0.7f; int boundary_planes = 1;
 	float microforce = 1.0f; float cloudforce_max_point = 15.0f; float cloudforce_max_sum = 3000.0f; int mainthreadpasses = 1; int subsample_fraction = 4;
+	int subsample_voxel = 0; float subsample_size = 0.0f;                     // handtrack.h:535-536: voxel sub-sampling of the main-thread cloud
 	size_t min_point_num = 400; float accum_error_threshold = 0.0f; float min_cray_prob = 0.0f;
 	int steps = 5, steps_keypoints = 3, steps_keyangles = 2, steps_palmangle = 2, steps_cloudstart = 1, steps_unibody = 3;
 	CNN cnn;
@@ -212,12 +213,12 @@ struct HandTracker                                                              
 		check(ctx_, ht_get_tracker_flags(ctx_, 0, 1, &pfe, &ini));
 		const float pfe0 = pfe;
 		const int rc = ht_config_read(jsonfile.c_str(), &p, &seg, &pfe);
-		if (rc == HT_ERR_ARG) throw std::runtime_error("unsupported option (subsample_voxel) in " + jsonfile);
 		if (rc != HT_OK) throw std::runtime_error("json parse error - " + jsonfile);
 		segment_scale = seg;
 		full_reset_on_error = p.full_reset_on_error; angles_only = p.angles_only != 0; always_take_cnn = p.always_take_cnn != 0; drangey = p.drangey; boundary_planes = p.boundary_planes;
 		microforce = p.microforce; cloudforce_max_point = p.cloudforce_max_point; cloudforce_max_sum = p.cloudforce_max_sum; mainthreadpasses = p.mainthreadpasses;
 		subsample_fraction = p.subsample_fraction; min_point_num = p.min_point_num; accum_error_threshold = p.accum_error_threshold; min_cray_prob = p.min_cray_prob;
+		subsample_voxel = p.subsample_voxel; subsample_size = p.subsample_size;
 		steps = p.steps; steps_keypoints = p.steps_keypoints; steps_keyangles = p.steps_keyangles; steps_palmangle = p.steps_palmangle; steps_cloudstart = p.steps_cloudstart; steps_unibody = p.steps_unibody;
 		check(ctx_, ht_set_params(ctx_, &p));      // also carries physics_iterations(_post), physics_use_collision, physics_weak_force, bone_sum_error_scale, unibody_force
 		if (pfe != pfe0) check(ctx_, ht_set_tracker_flags(ctx_, 0, 1, &pfe, &ini));
@@ -319,6 +320,7 @@ private:
 		p.full_reset_on_error = full_reset_on_error; p.angles_only = angles_only; p.always_take_cnn = always_take_cnn; p.drangey = drangey; p.boundary_planes = boundary_planes;
 		p.microforce = microforce; p.cloudforce_max_point = cloudforce_max_point; p.cloudforce_max_sum = cloudforce_max_sum; p.mainthreadpasses = mainthreadpasses;
 		p.subsample_fraction = subsample_fraction; p.min_point_num = (int)min_point_num; p.accum_error_threshold = accum_error_threshold; p.min_cray_prob = min_cray_prob;
+		p.subsample_voxel = subsample_voxel; p.subsample_size = subsample_size;
 		p.steps = steps; p.steps_keypoints = steps_keypoints; p.steps_keyangles = steps_keyangles; p.steps_palmangle = steps_palmangle; p.steps_cloudstart = steps_cloudstart; p.steps_unibody = steps_unibody;
 	}
 	void push_params()

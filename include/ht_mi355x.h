@@ -71,6 +71,8 @@ typedef struct ht_params
 	float physics_weak_force;       /* 0.4 (physmodel.h:234) */
 	float bone_sum_error_scale;     /* 4   (handtrack.h:369) */
 	float unibody_force;            /* 0.1 (handtrack.h:450) */
+	int   subsample_voxel;          /* 0: every subsample_fraction-th point; != 0: voxelsubsample (physmodel.h:66-118) for the main-thread cloud (handtrack.h:751) */
+	float subsample_size;           /* 0   voxel edge in metres; subsample_fraction is then the least number of points a voxel must hold */
 } ht_params;
 
 /* ---- lifecycle --------------------------------------------------------------------------------------------------
@@ -99,8 +101,7 @@ int ht_scale(ht_ctx *ctx, float s);
 /* ht_config_read  replaces  HandTracker::load_config(const std::string &jsonfile) (handtrack.h:822-828): host only.  Applies the file to
  *                *params the way the reference's field decoder does: every field of visit_fields (handtrack.h:549-581) is assigned, one that
  *                the file does not give as a number becomes 0; a missing file leaves everything untouched.  segment_scale and
- *                prev_frame_error (optional) are the two listed fields that live outside ht_params.  A file that sets subsample_voxel (the
- *                optional voxel sub-sampling of physmodel.h:66-118, not implemented) is refused with HT_ERR_ARG. */
+ *                prev_frame_error (optional) are the two listed fields that live outside ht_params. */
 int ht_config_read(const char *jsonfile, ht_params *params, float *segment_scale, float *prev_frame_error);
 
 /* ---- CNN ---------------------------------------------------------------------------------------------------------

@@ -67,6 +67,7 @@ void ho_default_params(ho_params *p)   /* handtrack.h:523-547 */
 	p->microforce = 1.0f; p->cloudforce_max_point = 15.0f; p->cloudforce_max_sum = 3000.0f; p->mainthreadpasses = 1; p->subsample_fraction = 4;
 	p->min_point_num = 400; p->accum_error_threshold = 0.0f; p->min_cray_prob = 0.0f;
 	p->steps = 5; p->steps_keypoints = 3; p->steps_keyangles = 2; p->steps_palmangle = 2; p->steps_cloudstart = 1; p->steps_unibody = 3;
+	p->subsample_voxel = 0; p->subsample_size = 0.0f;
 }
 static void world_inertia_init(ho_body *rb) { m33 M = qmat(rb->orientation); rb->Iinv = m33_mul(M, m33_mul(m33_scale(rb->tensorinv_massless, rb->massinv), m33_transpose(M))); }
 
@@ -207,6 +208,45 @@ int ho_pointcloud(const uint16_t *depth, const ho_camera *cam, float rmin, float
 	}
 	if (n_full) *n_full = k;
 	return n;
+}
+
+/* voxelsubsample<2048> physmodel.h:66-118: points are summed per voxel of `size` metres in an open-addressing table of 2048 buckets (hash = dot of the
+ * integer cell with three primes, linear probing), in the order the points come; a table that is full flushes the home bucket of the point that
+ * found no room.  Then every bucket with at least `min_count` points gives one point, the mean, in table order.  The reference converts the floor of
+ * a NEGATIVE coordinate to unsigned int (undefined in C++); what the compiled reference does, and what this does, is the two's-complement wrap
+ * (conversion to a signed integer first).  Returns the number of points written. */
+int ho_voxelsubsample(const f3 *pts, int n, float size, int min_count, f3 *out, int cap)
+{
+	enum { NV = 2048 };
+	static struct { int px, py, pz; f3 sum; int cnt; } cand[NV];
+	memset(cand, 0, sizeof cand);
+	const float ivs = 1.0f / size;
+	int m = 0;
+	for (int k = 0; k < n; k++)
+	{
+		const f3 pt = pts[k];
+		const int ix = (int)(unsigned int)(long long)floorf(pt.x * ivs), iy = (int)(unsigned int)(long long)floorf(pt.y * ivs), iz = (int)(unsigned int)(long long)floorf(pt.z * ivs);
+		const unsigned int hash = (unsigned int)((54851u * (unsigned int)ix + 11909u * (unsigned int)iy) + 24781u * (unsigned int)iz);
+		unsigned int i = 0;
+		for (; i < NV; i++)
+		{
+			const unsigned int s = (hash + i) & (NV - 1);
+			if (cand[s].cnt == 0 || (cand[s].px == ix && cand[s].py == iy && cand[s].pz == iz))
+			{
+				cand[s].px = ix; cand[s].py = iy; cand[s].pz = iz;
+				cand[s].sum = add3(cand[s].sum, pt); cand[s].cnt++;
+				break;
+			}
+		}
+		if (i == NV)
+		{
+			const unsigned int s = hash & (NV - 1);
+			if (m < cap) out[m++] = F3(cand[s].sum.x / (float)cand[s].cnt, cand[s].sum.y / (float)cand[s].cnt, cand[s].sum.z / (float)cand[s].cnt);
+			cand[s].cnt = 1; cand[s].px = ix; cand[s].py = iy; cand[s].pz = iz; cand[s].sum = pt;
+		}
+	}
+	for (int s = 0; s < NV; s++) if (cand[s].cnt >= min_count && m < cap) out[m++] = F3(cand[s].sum.x / (float)cand[s].cnt, cand[s].sum.y / (float)cand[s].cnt, cand[s].sum.z / (float)cand[s].cnt);
+	return m;
 }
 
 /* CNNOutputAnalysis handtrack.h:194-202, 218-241 with ImageFindMax / PeakSubPixel / PeakVolume / Peaks1D misc_image.h:298-399 */
@@ -637,7 +677,15 @@ void ho_update(ho_tracker *t, const uint16_t *depth, const ho_camera *cam, float
 {
 	const ho_params *P = &t->par;
 	f3 *points = malloc(sizeof(f3) * cam->w * cam->h);
-	int n = ho_pointcloud(depth, cam, 0.1f, P->drangey, P->subsample_fraction, points, cam->w * cam->h, NULL);
+	int n;
+	if (P->subsample_voxel)      /* takesubsample physmodel.h:120-126: the voxel branch takes ALL in-range points; subsample_fraction is its minimum count */
+	{
+		f3 *all = malloc(sizeof(f3) * cam->w * cam->h);
+		const int na = ho_pointcloud(depth, cam, 0.1f, P->drangey, 1, all, cam->w * cam->h, NULL);
+		n = ho_voxelsubsample(all, na, P->subsample_size, P->subsample_fraction, points, cam->w * cam->h);
+		free(all);
+	}
+	else n = ho_pointcloud(depth, cam, 0.1f, P->drangey, P->subsample_fraction, points, cam->w * cam->h, NULL);
 	t->last_npoints = n;
 	for (int b = 0; b < t->handmodel.nb; b++) { t->othermodel.bodies[b].position = t->handmodel.bodies[b].position; t->othermodel.bodies[b].orientation = t->handmodel.bodies[b].orientation; }
 	float pose[HO_MAXB * 7];

@@ -74,6 +74,7 @@ typedef struct ho_params   /* HandTracker fields handtrack.h:523-547 */
 	float segment_scale, full_reset_on_error; int angles_only, always_take_cnn; float drangey; int boundary_planes; float microforce, cloudforce_max_point, cloudforce_max_sum;
 	int mainthreadpasses, subsample_fraction; int min_point_num; float accum_error_threshold, min_cray_prob;
 	int steps, steps_keypoints, steps_keyangles, steps_palmangle, steps_cloudstart, steps_unibody;
+	int subsample_voxel; float subsample_size;      /* handtrack.h:535-536 */
 } ho_params;
 
 typedef struct ho_tracker
@@ -107,6 +108,7 @@ float ho_cnn_train(float *weights, const float *input, const float *target, floa
 void ho_cnn_input(const uint16_t *depth, int n, float depth_scale, float drange_x, float drange_y, float *out);
 void ho_decode(const float *cnn_output, const ho_camera *hcam, ho_analysis *out);
 int ho_pointcloud(const uint16_t *depth, const ho_camera *cam, float rmin, float rmax, int fraction, f3 *out, int cap, int *n_full);
+int ho_voxelsubsample(const f3 *pts, int n, float size, int min_count, f3 *out, int cap);      /* physmodel.h:66-118 */
 float ho_fit_error(ho_tracker *t, ho_model *m, const f3 *pts, int n, const uint16_t *depth, const ho_camera *cam);
 int ho_closest(ho_model *m, f3 v, f4 *plane);
 ho_linear ho_cloud_constraint(ho_model *m, f3 v, f3 origin);

@@ -339,6 +339,39 @@ static int mode_fullframes(const char *bankfn, int first, int stride, int n, con
 	return 0;
 }
 
+// HandTracker::update with the voxel sub-sampling of the main-thread cloud switched on (handtrack.h:535-536,751; physmodel.h:66-118): the hash-table
+// averaging of the in-range points into voxels of `size` metres, voxels with fewer than subsample_fraction points dropped.  The CNN job keeps its
+// every-4th-point cloud (handtrack.h:703).  Dumps the voxel cloud itself and the unit of work on it.
+static int mode_voxel(const char *bankfn, const char *rowscsv, uint64_t seed, double gain, double size, int min_point_num, const char *outfn)
+{
+	HandTracker htk;
+	htk.microforce = 3.0f; htk.mainthreadpasses = 3; htk.always_take_cnn = 0;
+	htk.subsample_voxel = 1; htk.subsample_size = (float)size; htk.min_point_num = min_point_num;
+	load_weights(htk, seed, gain);
+	PhysModel fake = LoadHandModel();
+	auto bank = read_animbank(bankfn, fake.rigidbodies.size());
+	std::vector<int> rows; { std::stringstream ss(rowscsv); std::string t; while (std::getline(ss, t, ',')) rows.push_back(atoi(t.c_str())); }
+	Out o; if (htfx_open(&o.w, outfn)) return 2;
+	o.i32("rows", rows); o.f32("weights_seed_gain", { (float)seed, (float)gain }); o.f32("voxel", { (float)size, (float)htk.subsample_fraction, (float)min_point_num });
+	for (size_t fi = 0; fi < rows.size(); fi++)
+	{
+		std::string pre = "f" + std::to_string(fi) + "/";
+		Frame fr = make_frame(fake, bank, rows[fi]);
+		o.u16(pre + "depth", fr.seg.raster, { 64,64 }); o.f32(pre + "cam", camvec(fr.seg.cam)); o.f32(pre + "startpose", flat(fr.start), { 17,7 });
+		auto vox = takesubsample(PointCloud(fr.seg, { 0.1f,htk.drangey }), htk.subsample_fraction, htk.subsample_voxel, htk.subsample_size);
+		std::vector<float> vp; for (auto &p : vox) { vp.push_back(p.x); vp.push_back(p.y); vp.push_back(p.z); }
+		o.f32(pre + "voxel_points", vp, { (uint32_t)vox.size(), 3 });
+		reset_tracker(htk, fr.start);
+		auto pose = unit_of_work(htk, fr.seg, &o, pre);
+		o.f32(pre + "cnn_output", htk.cnn_output);
+		o.f32(pre + "uw_pose_user", flat(pose), { 17,7 });
+		o.f32(pre + "uw_final", { htk.prev_frame_error, (float)htk.initializing, (float)vox.size() });
+		printf("voxel frame %d row %d: %d voxels\n", (int)fi, rows[fi], (int)vox.size()); fflush(stdout);
+	}
+	htfx_close(&o.w);
+	return 0;
+}
+
 // ---- modes ---------------------------------------------------------------------------------------
 static int dump_model(PhysModel &m, const char *outfn)
 {
@@ -908,6 +941,7 @@ int main(int argc, char **argv) try
 	if (mode == "fullframes" && a.size() == 6) return mode_fullframes(a[0].c_str(), atoi(a[1].c_str()), atoi(a[2].c_str()), atoi(a[3].c_str()), a[4].c_str(), a[5].c_str());
 	if (mode == "fullframe" && a.size() == 6) return mode_fullframe(a[0].c_str(), a[1].c_str(), a[2].c_str(), strtoull(a[3].c_str(), 0, 0), atof(a[4].c_str()), a[5].c_str());
 	if (mode == "config5" && a.size() == 5) return mode_config5(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());
+	if (mode == "voxel" && a.size() == 7) return mode_voxel(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), atof(a[4].c_str()), atoi(a[5].c_str()), a[6].c_str());
 	if (mode == "golden" && a.size() == 5) return mode_golden(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());
 	if (mode == "cnn128" && a.size() == 5) return mode_cnn128(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());
 	if (mode == "bench" && a.size() >= 4) return mode_bench(a[0].c_str(), strtoull(a[1].c_str(), 0, 0), atof(a[2].c_str()), atoi(a[3].c_str()), a.size() > 4 ? atoi(a[4].c_str()) : 0);

@@ -59,7 +59,8 @@ class Params(C.Structure):
     _fields_ = [("segment_scale", C.c_float), ("full_reset_on_error", C.c_float), ("angles_only", C.c_int), ("always_take_cnn", C.c_int), ("drangey", C.c_float),
                 ("boundary_planes", C.c_int), ("microforce", C.c_float), ("cloudforce_max_point", C.c_float), ("cloudforce_max_sum", C.c_float),
                 ("mainthreadpasses", C.c_int), ("subsample_fraction", C.c_int), ("min_point_num", C.c_int), ("accum_error_threshold", C.c_float), ("min_cray_prob", C.c_float),
-                ("steps", C.c_int), ("steps_keypoints", C.c_int), ("steps_keyangles", C.c_int), ("steps_palmangle", C.c_int), ("steps_cloudstart", C.c_int), ("steps_unibody", C.c_int)]
+                ("steps", C.c_int), ("steps_keypoints", C.c_int), ("steps_keyangles", C.c_int), ("steps_palmangle", C.c_int), ("steps_cloudstart", C.c_int), ("steps_unibody", C.c_int),
+                ("subsample_voxel", C.c_int), ("subsample_size", C.c_float)]
 
 
 class Physics(C.Structure):

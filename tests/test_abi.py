@@ -130,7 +130,8 @@ def test_config_read_follows_the_reference_decoder(tmp_path):
     assert abs(seg.value - 0.2) < 1e-7
     assert p.mainthreadpasses == 0 and p.min_point_num == 0 and pfe.value == 0.0      # not in the file: the reference's decoder reads 0
     vox = tmp_path / "voxel.json"; vox.write_text('{"microforce": 3, "subsample_voxel": 1, "subsample_size": 0.01}')
-    assert L.ht_config_read(str(vox).encode(), C.byref(p), C.byref(seg), C.byref(pfe)) == 1      # HT_ERR_ARG: the voxel option is refused, not ignored
+    assert L.ht_config_read(str(vox).encode(), C.byref(p), C.byref(seg), C.byref(pfe)) == 0
+    assert p.subsample_voxel == 1 and abs(p.subsample_size - 0.01) < 1e-9      # the voxel option (physmodel.h:66-118) is read like every other field
     bad = tmp_path / "bad.json"; bad.write_text('{"microforce": ')
     assert L.ht_config_read(str(bad).encode(), C.byref(p), C.byref(seg), C.byref(pfe)) != 0
 
