@@ -18,10 +18,19 @@
 // ------------------------------------------------------------------------------------------------- k_prepare
 // one block per frame; thread t owns pixels [16t, 16t+16) so that a block-wide prefix sum keeps the row-major order
 __global__ __launch_bounds__(256) void k_prepare(const uint16_t *__restrict__ depth, const float *__restrict__ cams, float drangey, int fraction,
-                                                  float *__restrict__ cnn_in, float4 *__restrict__ pts, int *__restrict__ npts, int cap)
+                                                  float *__restrict__ cnn_in, float4 *__restrict__ pts, int *__restrict__ npts, int cap, ht_prepare_extra x)
 {
 	const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	const float *cam = cams + (size_t)b * HT_CAM;
+	if (x.cams_out && t < HT_CAM) x.cams_out[(size_t)b * HT_CAM + t] = cam[t];
+	if (x.start && t < x.nb)      // ht_tracker_reset for this frame: both models take the start pose, momenta and flags are cleared
+	{
+		const float *o = x.start + ((size_t)b * x.nb + t) * HT_POSE;
+		float *s0 = x.state0 + ((size_t)b * x.nb + t) * HT_STATE_STRIDE, *s1 = x.state1 + ((size_t)b * x.nb + t) * HT_STATE_STRIDE;
+		for (int k = 0; k < 7; k++) { s0[k] = o[k]; s1[k] = o[k]; }
+		for (int k = 7; k < 13; k++) { s0[k] = 0.0f; s1[k] = 0.0f; }
+		if (t == 0) { x.prev_err[b] = 0.0f; x.initializing[b] = 0; }
+	}
 	const float fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3], dscale = cam[4];
 	const uint4 *src = reinterpret_cast<const uint4 *>(depth + (size_t)b * 4096 + 16 * t);
 	uint4 r0 = src[0], r1 = src[1];
@@ -570,9 +579,11 @@ void ht_launch_voxel(const float4 *all, const int *nall, int cap, float size, in
 {
 	hipLaunchKernelGGL(k_voxel, dim3(B), dim3(64), 0, s, all, nall, cap, size, min_count, out, nout);
 }
-void ht_launch_prepare(const uint16_t *depth, const float *cams, float drangey, int fraction, float *cnn_in, float4 *pts, int *npts, int cap, int B, hipStream_t s)
+void ht_launch_prepare(const uint16_t *depth, const float *cams, float drangey, int fraction, float *cnn_in, float4 *pts, int *npts, int cap, int B, hipStream_t s, const ht_prepare_extra *extra)
 {
-	hipLaunchKernelGGL(k_prepare, dim3(B), dim3(256), 0, s, depth, cams, drangey, fraction, cnn_in, pts, npts, cap);
+	ht_prepare_extra x = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0 };
+	if (extra) x = *extra;
+	hipLaunchKernelGGL(k_prepare, dim3(B), dim3(256), 0, s, depth, cams, drangey, fraction, cnn_in, pts, npts, cap, x);
 }
 void ht_launch_prepare_frame(const uint16_t *depth, const float *cams, int w, int h, float drangey, int fraction, float4 *pts, int *npts, int *overflow, int cap, int B, hipStream_t s)
 {

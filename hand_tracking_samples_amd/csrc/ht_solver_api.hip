@@ -128,8 +128,9 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		ht_launch_segment(d_depth, ctx->d_frame_cams, fs->w, fs->h, 0xF, p.drangey, fs->segment_scale, ctx->d_seg_tiles, ctx->d_cams, B, s);
 		img_cams = ctx->d_frame_cams;
 	}
-	else if (d_cams != ctx->d_cams) HIPCHK(ctx, hipMemcpyAsync(ctx->d_cams, d_cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyDeviceToDevice, s));
-	if (d_start)
+	// 64x64 tiles: the camera copy and the re-seeding of the trackers ride on k_prepare (below); full-size frames keep their own small kernels
+	ht_prepare_extra px = { (!fs && d_cams != ctx->d_cams) ? ctx->d_cams : nullptr, ctx->d_state[0], ctx->d_state[1], fs ? nullptr : d_start, ctx->d_prev_err, ctx->d_initializing, nb };
+	if (d_start && fs)
 	{
 		ht_launch_set_pose(ctx->d_state[0], d_start, nb, B, 1, s);
 		ht_launch_set_pose(ctx->d_state[1], d_start, nb, B, 1, s);
@@ -142,7 +143,7 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 			ht_launch_prepare(ctx->d_seg_tiles, ctx->d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, nullptr, nullptr, ctx->model.pts_cap, B, s);
 			ht_launch_prepare_frame(d_depth, img_cams, fs->w, fs->h, p.drangey, p.subsample_fraction, ctx->d_pts, ctx->d_npts, ctx->d_overflow, ctx->model.pts_cap, B, s);
 		}
-		else ht_launch_prepare(d_depth, ctx->d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, ctx->d_pts, ctx->d_npts, ctx->model.pts_cap, B, s);
+		else ht_launch_prepare(d_depth, d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, ctx->d_pts, ctx->d_npts, ctx->model.pts_cap, B, s, &px);
 		if (mode == UPD_FULL && p.subsample_voxel)
 		{
 			// the main-thread cloud of handtrack.h:751 with the voxel rule: ALL in-range points (taken once more, into the cloud-row array, which nothing
@@ -164,7 +165,7 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		// owns whole CUs and the FC layers want one block per CU: beside each other they took 0.78 ms, one after the other 0.46.)
 		hipStream_t t = ctx->side[1];
 		fork(ctx, s);
-		if (mode == UPD_FULL) ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, t);     // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757
+		if (mode == UPD_FULL && !(d_start && !fs)) ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, t);     // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757 (both were just seeded with the same pose otherwise)
 		ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_old, B, t);
 		ht_launch_decide_reset(ctx->d_err_old, p.full_reset_on_error, p.angles_only, ctx->d_flags, ctx->d_nflags, B, t);
 	}
