@@ -267,8 +267,6 @@ __device__ __forceinline__ int nslot(const tri_r &T, int va, int vb)
 	return 0;      // unreachable for a consistent mesh (the reference asserts)
 }
 __device__ __forceinline__ void set_n(epa_mem &m, int t, int slot, int val) { m.t[t].n[slot] = (short)val; }
-// *neib(m, t, va, vb) = val
-__device__ __forceinline__ void patch(epa_mem &m, int t, int va, int vb, int val) { const tri_r T = tri_ld(m, t); set_n(m, t, nslot(T, va, vb), val); }
 // Patches only ever change neighbour ids and nslot() only looks at vertex ids, which are fixed once a triangle exists: the records a step
 // needs for its slot look-ups can therefore be fetched together up front (independent LDS reads in flight) instead of one after another.
 __device__ void nnfix_rec(epa_mem &m, int k, const tri_r &K)      // hull.h:112-127 for the triangle k whose record is K
