@@ -8,7 +8,7 @@
 //   SupportFunc / SupportFuncTrans    third_party/gjk.h:568-582, maxdir third_party/geometric.h:218-224
 //
 // Two organisations of the same arithmetic, chosen per launch by the batch size (ht_launch_contacts):
-//   k_contacts_coop (up to 2048 frames): lane-per-run simplex logic in owner waves, support scans worked off cooperatively by all waves of a
+//   k_contacts_coop (up to 1024 frames): lane-per-run simplex logic in owner waves, support scans worked off cooperatively by all waves of a
 //     block, one scan pair per DPP row, polytope jobs taken by any wave -- described at the kernel below.  Shortest launch when the batch is a few
 //     frames per CU; owns the CU (152 KB of LDS, 255 VGPRs).
 //   k_contacts (larger batches): a block serves two frames (one wave each) and stages all collision vertices (3042 x float4 = 48 KB, w = vertex
@@ -18,7 +18,7 @@
 //     simplex logic is the reference's branchy code executed per lane.  Measured on the animation bank: 3.5 iterations per pair on average, ~23
 //     pairs per frame.  Contacts are compacted in pair order with a prefix sum, so the solver sees the reference's row order.  61 KB of LDS: two
 //     blocks per CU, which leaves room for the cloud-row kernel of the same fit step beside it -- with many frames per CU the whole step is faster
-//     this way although the kernel alone is not (cross-over measured between 2048 and 4096 frames).
+//     this way although the kernel alone is not (cross-over measured a little above 1024 frames).
 // Both hand a pair whose simplex encloses the origin to the expanding polytope; that part is rare but long, so it runs wave-cooperatively, one
 // pair at a time per wave: triangles are scored one per lane, both shapes' support scans are walked together strided over the 64 lanes with a
 // butterfly arg-max, and the mesh surgery (extrude / back-to-back fix / compaction, hull.h:136-186) visits only the triangles a ballot marks.
@@ -1117,13 +1117,14 @@ void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftma
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_contacts_coop), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		attr_set[dev] = true;
 	}
-	// Which organisation: the cooperative kernel owns a CU per block (152 KB of LDS, 255 VGPRs) and finishes a launch of up to a few frames per CU
-	// sooner; once the batch is many times the CU count the lane-per-pair kernel's smaller blocks (61 KB, two per CU) share the CUs with the
-	// cloud-row kernel of the same step, and the whole step is faster with it (measured cross-over between 2048 and 4096 frames).
+	// Which organisation: the cooperative kernel owns a CU per block (152 KB of LDS, 249 VGPRs) and finishes a launch of up to four frames per CU much
+	// sooner (175 against 265 us at 1024 frames); but nothing else fits on its CUs, so the cloud-row kernel of the same fit step waits for it, while the
+	// lane-per-pair kernel's smaller blocks (61 KB, two per CU) run beside the cloud rows.  Whole steps, same device: 512 frames 7.60 against 8.12 ms,
+	// 1024 frames 8.06 against 8.19, 1280 frames 10.28 against 9.85, 2048 frames 12.17 against 11.43 -- the cooperative kernel up to 1024 frames.
 	static int coop_max = -1;
 	if (coop_max < 0)
 	{
-		coop_max = 2048;
+		coop_max = 1024;
 #ifdef HT_TUNING
 		if (const char *e = getenv("HT_CONTACTS_COOP_MAX")) coop_max = atoi(e);
 #endif

@@ -124,7 +124,7 @@ def test_gpu_config5_full_size_properties(weights):
     for k in range(1, 16):
         assert np.array_equal(a[:64], a[64 * k:64 * (k + 1)])
     assert np.isfinite(a).all() and np.abs(np.linalg.norm(a[:, :, 3:], axis=2) - 1.0).max() < 1e-5
-    # the same frames in a batch of 2304: above 2048 frames the launcher takes the lane-per-pair contact kernel (two waves per frame for 26 bones)
+    # the same frames in a batch of 2304: above 1024 frames the launcher takes the lane-per-pair contact kernel (two waves per frame for 26 bones)
     # instead of the cooperative one -- two organisations of the same arithmetic, so the poses must not move by a bit
     B2 = 2304
     idx2 = np.arange(B2) % 64
