@@ -7,6 +7,7 @@
 #   kernel_stats.csv               rocprofv3 --kernel-trace --stats of a short bench run (1024 frames); kernel_stats_frames8192.csv the same at 8192
 #   pmc_fetch / pmc_write          two separate counter passes (FETCH_SIZE, WRITE_SIZE), aggregated by tools/pmc_traffic.py
 #   pmc_mfma, pmc_mfma128          one counter pass each on the CNN-only workloads (MFMA busy cycles), aggregated by tools/pmc_mfma.py
+#   afterwards: python tools/cnn_roofline.py profiles/rNN > profiles/rNN_cnn_kernel_roofline.json (per-kernel MFMA roofline of the CNN workloads)
 # usage: bash tools/profile_round.sh r02
 set -e
 R=${1:-r02}
