@@ -593,7 +593,7 @@ int ht_reserve_points_locked(ht_ctx *ctx, int points)
 	int r;
 	if ((r = dev_alloc(ctx, &ctx->d_pts, B * cap))) return r;
 	if ((r = dev_alloc(ctx, &ctx->d_rows, B * cap * HT_ROW))) return r;
-	if ((r = dev_alloc(ctx, &ctx->d_scratch, B * ht_scratch_rows(cap, nb) * 21))) return r;      // 20 floats per row record + 1 for the impulse sum of over-size frames
+	if ((r = dev_alloc(ctx, &ctx->d_scratch, B * ht_scratch_rows(cap, nb) * (HT_CREC + 1)))) return r;      // a row record + 1 float for the impulse sum of over-size frames
 	if (had_voxel && (r = dev_alloc(ctx, &ctx->d_ptsv, B * cap))) return r;
 	ctx->model.pts_cap = want;
 	return HT_OK;

@@ -10,7 +10,7 @@ struct solve_args
 	const float *analysis; const float *cams;                       // for ApplyAngles / landmark-ray rows / arm cone
 	const int *active_flag;                                         // optional per-frame enable
 	float *state;                                                   // [B][nb][HT_STATE_STRIDE] of the model being solved
-	float *scratch; int scratch_stride;                             // [B][scratch_stride][20] pre-computed single-body row records (ht_quad.hpp)
+	float *scratch; int scratch_stride;                             // [B][scratch_stride][HT_CREC] pre-computed single-body row records (ht_quad.hpp)
 	int batch;                                                      // frames of the launch (the sums of over-size frames live behind all frames' records)
 	int *retry;                                                     // [B] frames the small-pool build of k_solve passes on to the large one
 	int apply_angles; float drive_force; int ray_rows; int arm_cone; int zero_momenta; int steps_keyangles; float min_cray_prob;

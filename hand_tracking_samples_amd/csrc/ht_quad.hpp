@@ -55,41 +55,47 @@ __device__ __forceinline__ float div_ieee_r(float x, float y, float r)
 }
 
 // ---- single-body row chains ------------------------------------------------------------------------------------------------------
-// Record of one single-body row (LimitLinear with rb0 == NULL), 5 x 16 bytes, laid out by the lane that reads each part:
-//   slot c (c = 0,1,2)  lane c of the quad:  r1[c+1], r1[c+2], n[c], and in the fourth word fmin*dt (slot 0) / fmax*dt (slot 1)
-//                       (r1 = lever arm in the world frame: the two components a cross product needs on lane c; n = row direction)
-//   slot 3              lane 3, sweeps with bias:             targetspeed,        rinv, effective mass, 0      (rinv = rcp_refined(effective mass))
-//   slot 4              lane 3, sweeps after RemoveBias (physics.h:288): min(ts, ts_nobias), rinv, effective mass, 0
+// Arithmetic of a row (round 3).  LimitLinear::Iter (physics.h:289-307) forms the anchor velocity from the momenta every time it runs:
+//   vn = dot(cross(Iinv*L, r1) + P*massinv, n)                 (L, P: angular / linear momentum of the body, r1: lever arm, n: row direction)
+// which is linear in the momenta with coefficients that do not change during one PhysicsUpdate (orientation and Iinv are only re-made by
+// rbupdatepose at its end).  The same number in "Jacobian form":
+//   vn = dot(b, L) + dot(n*massinv, P)       with  g = cross(r1, n),  b = Iinv*g   (Iinv is symmetric)
+//   impulse = (-targetspeed - vn) * (1 / effective mass), clamped to [fmin*dt - sum, fmax*dt - sum]
+//   P += n*impulse,  L += g*impulse          (= ApplyImpulse, physics.h:222-226: cross(r1, n*impulse) = g*impulse)
+// g, b and the reciprocal are pre-computed once per row with the reference's own expressions (the effective mass exactly as physics.h:299-300
+// writes it); a sweep then costs 8 dependent operations per row instead of 24, with fused multiply-adds.  It is the reference's algorithm (same
+// rows, same order, same clamps) evaluated in another association order: results differ from the reference's IEEE build by rounding, measured at
+// <= 2e-7 m / 6e-6 (quaternion) per solver stage on the golden frames and, over the whole unit of work on the 256 bench frames, by LESS than the
+// reference itself moves between its IEEE and its FMA-contracted build (tests/golden/ref_flag_spread.py, DESIGN.md section 4 "Numerics").
+//
+// Record of one single-body row (LimitLinear with rb0 == NULL), 4 x 16 bytes, laid out by the lane that reads each part:
+//   slot c (c = 0,1,2)  lane c of the quad:  n[c], g[c], b[c], and in the fourth word fmin*dt (slot 0) / fmax*dt (slot 1)
+//   slot 3              lane 3:  targetspeed, 1 / effective mass, targetspeed after RemoveBias (physics.h:288: min(ts, ts_nobias)), 0
 // The records are read-only during the sweeps; the one value a row changes, its impulse sum, lives in an LDS array beside them (a store into
 // the record would sit in the same in-order memory queue as the reads of the rows ahead and hold them back until it is acknowledged).
-// Lane c < 3 carries component c of the body's momenta; lane 3 does the scalar part of the row (division, clamp, impulse sum), takes the two
+// Lane c < 3 carries component c of the body's momenta; lane 3 does the scalar part of the row (impulse, clamp, impulse sum), takes the two
 // force limits from lanes 0 and 1 and hands the impulse to the others, all through DPP operands.  Per row each lane issues ONE 16-byte read
 // (the texture path moves 64 B per clock per CU, i.e. 16 clocks per such wave instruction: with four to eight waves per CU walking chains
 // that path, not the arithmetic, is what a second read per row would saturate), one LDS read and one LDS write.
-#define CREC 20            // floats per record
+#define CREC HT_CREC       // floats per record
 #define QP_PREV 0x90       // quad_perm:[0,0,1,2]: lane i reads lane i-1 of its quad
-struct quad_body { float l, av, minv, Ix, Iy, Iz; };      // this lane's component of the linear / angular momentum, 1/mass, row c of Iinv
+struct quad_body { float l, av, minv; };      // this lane's component of the linear / angular momentum, 1/mass
 
-// One LimitLinear::Iter (physics.h:289-307): a = this lane's slot, sum = the row's impulse sum.  Returns the new impulse sum (on every lane of the quad).
-// Operation order per component is the reference's: w = Iinv * angular momentum (column sum), v = cross(w, r1) + lin * massinv,
-// vn = (v.x*n.x + v.y*n.y) + v.z*n.z, impulse = (-targetspeed - vn) / effmass clamped to [fmin*dt - sum, fmax*dt - sum],
-// lin += n * impulse, ang += cross(r1, n * impulse).
-__device__ __forceinline__ float quad_row_step(quad_body &B, const float4 a, const float sum)
+// One LimitLinear::Iter: a = this lane's slot, sum = the row's impulse sum, post = sweeps after RemoveBias.  Returns the new impulse sum (on
+// every lane of the quad).
+__device__ __forceinline__ float quad_row_step(quad_body &B, const float4 a, const float sum, const int post)
 {
-	const float lm = B.l * B.minv;
-	const float w = (B.Ix * dpp<QP_BC0>(B.av) + B.Iy * dpp<QP_BC1>(B.av)) + B.Iz * dpp<QP_BC2>(B.av);      // (Iinv * angular_momentum)[c]
-	const float cr = dpp<QP_ROT1>(w) * a.y - dpp<QP_ROT2>(w) * a.x;                                        // w[c+1]*r1[c+2] - w[c+2]*r1[c+1]
-	const float p = (cr + lm) * a.z;
-	const float t = dpp<QP_PREV>(p) + p;                                                                   // lane 1: p0 + p1
-	const float s = dpp<QP_PREV>(t) + p;                                                                   // lane 2: (p0 + p1) + p2 = vn
-	const float x = -a.x - dpp<QP_PREV>(s);                                                                // lane 3: -targetspeed - vn
-	float impulse = div_ieee_r(x, a.z, a.y);                                                               // lane 3: a.y = rinv, a.z = effective mass
+	const float lm = (a.x * B.minv) * B.l;                               // (n[c] * massinv) * P[c]; the first product does not depend on the previous row
+	const float p = __fmaf_rn(a.z, B.av, lm);                            // + b[c] * L[c]
+	const float t = dpp<QP_PREV>(p) + p;                                 // lane 1: p0 + p1
+	const float s = dpp<QP_PREV>(t) + p;                                 // lane 2: (p0 + p1) + p2 = vn
+	const float x = -(post ? a.z : a.x) - dpp<QP_PREV>(s);               // lane 3: -targetspeed - vn
+	float impulse = x * a.y;                                             // lane 3: a.y = 1 / effective mass
 	impulse = clamp_med3(impulse, dpp<QP_BC0>(a.w) - sum, dpp<QP_BC1>(a.w) - sum);
-	const float imp = dpp<QP_BC3>(impulse) * a.z;                                                          // n[c] * impulse
-	const float k = a.x * dpp<QP_ROT2>(imp) - a.y * dpp<QP_ROT1>(imp);                                     // r1[c+1]*imp[c+2] - r1[c+2]*imp[c+1]
-	B.l = B.l + imp;
-	B.av = B.av + k;
-	return sum + dpp<QP_BC3>(impulse);      // the same value on all four lanes (they read the same sum): the quad's four writes to one address agree
+	const float bi = dpp<QP_BC3>(impulse);
+	B.l = __fmaf_rn(a.x, bi, B.l);                                       // P += n * impulse
+	B.av = __fmaf_rn(a.y, bi, B.av);                                     // L += g * impulse
+	return sum + bi;      // the same value on all four lanes (they read the same sum): the quad's four writes to one address agree
 }
 // Applies rows [0, cnt) of one chain in order.  rec = the chain's first record, sums = the chain's first impulse sum (LDS), c = lane within the
 // quad, post = 1 after RemoveBias.  Eight register sets rotate, so the read of a row is issued eight rows ahead of its use (records stream from
@@ -99,34 +105,33 @@ __device__ __forceinline__ float quad_row_step(quad_body &B, const float4 a, con
 // A quad can walk TWO bodies' chains back to back (k_solve, models with more than 16 bodies: the 17th body's rows follow the host body's, which are
 // padded to a multiple of 8 with rows that change nothing): at row `kswitch` (a multiple of 8, or < 0 for none) the momenta go back to body `bodyA`'s
 // slots of lin_w / ang_w and body `bodyB`'s state is taken up.
-__device__ __forceinline__ void quad_switch_body(quad_body &B, int c, float *lin_w, float *ang_w, const float *I_w, int bodyA, int bodyB)
+__device__ __forceinline__ void quad_switch_body(quad_body &B, int c, float *lin_w, float *ang_w, int bodyA, int bodyB)
 {
 	if (c < 3) { lin_w[4 * bodyA + c] = B.l; ang_w[4 * bodyA + c] = B.av; }
 	B.l = lin_w[4 * bodyB + c]; B.av = ang_w[4 * bodyB + c]; B.minv = lin_w[4 * bodyB + 3];
-	B.Ix = I_w[12 * bodyB + c]; B.Iy = I_w[12 * bodyB + 4 + c]; B.Iz = I_w[12 * bodyB + 8 + c];
 }
 __device__ __forceinline__ void quad_chain_run(quad_body &B, const float *rec, float *sums, int cnt, int c, int post,
-                                               int kswitch = -1, float *lin_w = nullptr, float *ang_w = nullptr, const float *I_w = nullptr, int bodyA = 0, int bodyB = 0)
+                                               int kswitch = -1, float *lin_w = nullptr, float *ang_w = nullptr, int bodyA = 0, int bodyB = 0)
 {
-	const float4 *pa = reinterpret_cast<const float4 *>(rec) + (c < 3 ? c : 3 + post);
+	const float4 *pa = reinterpret_cast<const float4 *>(rec) + c;
 	float *ps = sums;
 	// first reads in the order the loop consumes them (the wait counts the compiler derives for the loop are the minimum over both entries)
-#define QC_LOAD(i, row) a##i = pa[5 * (row)]; s##i = ps[row]; __builtin_amdgcn_sched_barrier(0)
+#define QC_LOAD(i, row) a##i = pa[4 * (row)]; s##i = ps[row]; __builtin_amdgcn_sched_barrier(0)
 	float4 a0, a1, a2, a3, a4, a5, a6, a7; float s0, s1, s2, s3, s4, s5, s6, s7;
 	QC_LOAD(0, 0); QC_LOAD(1, 1); QC_LOAD(2, 2); QC_LOAD(3, 3); QC_LOAD(4, 4); QC_LOAD(5, 5); QC_LOAD(6, 6); QC_LOAD(7, 7);
 	int k = 0;
 	// The scheduling barriers keep every row's instructions between its own pair: left alone, the ILP-first scheduler hoists the first use of the
 	// record that was requested last to the top of the trip as a hazard filler, which turns the wait for it into a wait for every outstanding
 	// read (s_waitcnt vmcnt(0)), i.e. one full memory round trip per trip.
-#define QC_STEP(i) ps[i] = quad_row_step(B, a##i, s##i)
+#define QC_STEP(i) ps[i] = quad_row_step(B, a##i, s##i, post)
 	for (; k + 8 <= cnt; k += 8)
 	{
-		if (k == kswitch) quad_switch_body(B, c, lin_w, ang_w, I_w, bodyA, bodyB);
+		if (k == kswitch) quad_switch_body(B, c, lin_w, ang_w, bodyA, bodyB);
 		QC_STEP(0); QC_LOAD(0, 8); QC_STEP(1); QC_LOAD(1, 9); QC_STEP(2); QC_LOAD(2, 10); QC_STEP(3); QC_LOAD(3, 11);
 		QC_STEP(4); QC_LOAD(4, 12); QC_STEP(5); QC_LOAD(5, 13); QC_STEP(6); QC_LOAD(6, 14); QC_STEP(7); QC_LOAD(7, 15);
-		pa += 40; ps += 8;
+		pa += 32; ps += 8;
 	}
-	if (k == kswitch) quad_switch_body(B, c, lin_w, ang_w, I_w, bodyA, bodyB);
+	if (k == kswitch) quad_switch_body(B, c, lin_w, ang_w, bodyA, bodyB);
 	const int left = cnt - k;      // 0..7 rows, already in the register sets
 	if (left > 0) QC_STEP(0);
 	__builtin_amdgcn_sched_barrier(0);
@@ -144,11 +149,18 @@ __device__ __forceinline__ void quad_chain_run(quad_body &B, const float *rec, f
 #undef QC_LOAD
 #undef QC_STEP
 }
-// fills one record (see the layout above); r1 = lever arm in the world frame, n = row direction, y = effective mass
-__device__ __forceinline__ void quad_write_record(float *rec, v3 r1, v3 n, float ts, float ts_post, float y, float fmin_dt, float fmax_dt)
+// fills one record (see the layout above); r1 = lever arm in the world frame, n = row direction, Iinv = the body's world inverse inertia,
+// y = effective mass (physics.h:299-300, formed by the caller with the reference's expression)
+__device__ __forceinline__ void quad_write_record(float *rec, v3 r1, v3 n, const m3 &Iinv, float ts, float ts_post, float y, float fmin_dt, float fmax_dt)
 {
 	float4 *o = reinterpret_cast<float4 *>(rec);
-	const float rinv = rcp_refined(y);
-	o[0] = make_float4(r1.y, r1.z, n.x, fmin_dt); o[1] = make_float4(r1.z, r1.x, n.y, fmax_dt); o[2] = make_float4(r1.x, r1.y, n.z, 0.0f);
-	o[3] = make_float4(ts, rinv, y, 0.0f); o[4] = make_float4(ts_post, rinv, y, 0.0f);
+	const v3 g = cross(r1, n), b = mul(Iinv, g);
+	o[0] = make_float4(n.x, g.x, b.x, fmin_dt); o[1] = make_float4(n.y, g.y, b.y, fmax_dt); o[2] = make_float4(n.z, g.z, b.z, 0.0f);
+	o[3] = make_float4(ts, 1.0f / y, ts_post, 0.0f);
+}
+// a record that changes nothing (zero direction, zero limits: impulse 0)
+__device__ __forceinline__ void quad_write_noop(float *rec)
+{
+	float4 *o = reinterpret_cast<float4 *>(rec);
+	o[0] = o[1] = o[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); o[3] = make_float4(0.0f, 1.0f, 0.0f, 0.0f);
 }

@@ -496,7 +496,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		// three effective masses (sweep-invariant: the division of every sweep becomes the five operations of div_ieee_r)
 		const int kk = r % 3;
 		if (kk == 0) { o[7] = r0.x; o[8] = r0.y; o[9] = r0.z; o[10] = r1.x; o[11] = r1.y; o[12] = r1.z; }
-		S.pool[(r - kk + 1) * LROW + 7 + kk] = rcp_refined(impulsed);
+		S.pool[(r - kk + 1) * LROW + 7 + kk] = 1.0f / impulsed;
 		S.lrb[r][0] = (unsigned char)rb0; S.lrb[r][1] = (unsigned char)rb1;
 	}
 	if (lane < 3 * LROW) S.pool[n2 * LROW + lane] = (lane % LROW) == 4 || (lane >= LROW + 7 && lane <= LROW + 9) ? 1.0f : (lane % LROW) == 6 ? __int_as_float(IDLE_BODY | (IDLE_BODY << 8)) : 0.0f;      // idle group: zero limits, unit effective mass (and its reciprocal)
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	if (lane < HT_MAXNB) { S.ccnt[lane] = HT_DBG(a.dbg, 1) ? 0 : mycnt; S.cstart[lane] = mystart; S.cextra[lane] = (signed char)(HT_DBG(a.dbg, 1) ? -1 : myextra); }
 	if (myextra >= 0)      // the padding records of this host
 		for (int i = mystart + mycnt; i < mystart + ((mycnt + 7) & ~7); i++)
-			if (i < a.scratch_stride - QUAD_CHAIN_SLACK) quad_write_record(scr + (size_t)i * CREC, V3(0, 0, 0), V3(0, 0, 0), 0.0f, 0.0f, 1.0f, 0.0f, 0.0f);
+			if (i < a.scratch_stride - QUAD_CHAIN_SLACK) quad_write_noop(scr + (size_t)i * CREC);
 	int myrun = 0;
 	for (int base = 0; base < n1; base += 64)          // pass B: placement in stable order + pre-compute
 	{
@@ -667,9 +667,10 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		{
 			const v3 p1 = L3(r + 5), n = L3(r + 8);
 			const v3 r1 = qrot(L4(S.q[body]), p1);
-			const float impulsed = S.lin4[body].w + dot(cross(mul(body_I(S, body), cross(r1, n)), r1), n);       // 0 + (...) for the NULL side
+			const m3 Ib = body_I(S, body);
+			const float impulsed = S.lin4[body].w + dot(cross(mul(Ib, cross(r1, n)), r1), n);       // 0 + (...) for the NULL side
 			const float ts = r[11] / dt;
-			quad_write_record(scr + (size_t)dst * CREC, r1, n, ts, fmin_std(ts, r[12]), impulsed, r[13] * dt, r[14] * dt);
+			quad_write_record(scr + (size_t)dst * CREC, r1, n, Ib, ts, fmin_std(ts, r[12]), impulsed, r[13] * dt, r[14] * dt);
 		}
 	}
 	__threadfence_block();      // the records are read back by other lanes of this wave
@@ -698,6 +699,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	const long long t_begin = t_mark;
 	v3 pos_next = V3(0, 0, 0); v4 q_next = V4(0, 0, 0, 1);
 	const int total_sweeps = ph.iterations + ph.iterations_post;
+	const float inv_dt = 1.0f / dt;
 	const int quad = lane >> 2, c = lane & 3, cc = c < 3 ? c : 2;         // lane 3 of a quad shadows component z; its vector results are never stored
 	const int c1 = (cc + 1) % 3, c2 = (cc + 2) % 3;
 	const int side = quad & 1;                                            // two-body rows: even quad = rb0, odd quad = rb1
@@ -722,11 +724,10 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			{
 				const float l = lin_w[4 * body + c], av = ang_w[4 * body + c];       // lane 3 carries massinv / friction here and never stores
 				const float minv = lin_w[4 * body + 3];
-				const float Ix = I_w[12 * body + c], Iy = I_w[12 * body + 4 + c], Iz = I_w[12 * body + 8 + c];
-				quad_body qb = { l, av, minv, Ix, Iy, Iz };
+				quad_body qb = { l, av, minv };
 				// RemoveBias (physics.h:288): lane 3 switches to the ts_post slot
-				if (MODE == SOLVE_FIRST || sums_lds) quad_chain_run(qb, scr + (size_t)start * CREC, S.csum + start, total, c, tsoff, kswitch, lin_w, ang_w, I_w, body, ex);
-				else quad_chain_run(qb, scr + (size_t)start * CREC, gsum + start, total, c, tsoff, kswitch, lin_w, ang_w, I_w, body, ex);
+				if (MODE == SOLVE_FIRST || sums_lds) quad_chain_run(qb, scr + (size_t)start * CREC, S.csum + start, total, c, tsoff, kswitch, lin_w, ang_w, body, ex);
+				else quad_chain_run(qb, scr + (size_t)start * CREC, gsum + start, total, c, tsoff, kswitch, lin_w, ang_w, body, ex);
 				const int last = ex >= 0 ? ex : body;
 				if (c < 3) { lin_w[4 * last + c] = qb.l; ang_w[4 * last + c] = qb.av; }
 			}
@@ -740,7 +741,9 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		//     one step ahead; only the momenta are read after the previous step's stores.  Two register sets alternate.
 		if (!HT_DBG(a.dbg, 2) && nlev_lin > 0)
 		{
-			struct lset { unsigned e; int meta; float rv1, rv2, n0, n1, n2, Ix, Iy, Iz, minv; float4 s0, s1, s2; float e0, e1, e2, q0, q1, q2, i0, i1, i2; };
+			// Jacobian form (ht_quad.hpp): per row and side g = cross(r, n), b = Iinv * g and n * massinv are formed in the fetch stage, one step ahead of
+			// their use and off the dependent chain of the momenta; the sign of the side (rb0 receives -impulse and contributes -v0) rides on n.
+			struct lset { unsigned e; int meta; float n0, n1, n2, g0, g1, g2, b0, b1, b2, a0, a1, a2; float4 s0, s1, s2; float q0, q1, q2, i0, i1, i2; };
 			auto entry = [&](int L) -> unsigned {
 				if (L > nlev_lin) return S.lorder[S.LIDLE];
 				int lo, hi;
@@ -754,40 +757,41 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				const float *R = S.pool + (int)(e & 0xFFFF) * (3 * LROW);
 				const int body = side ? (int)(e >> 24) : (int)((e >> 16) & 255);
 				r.meta = __float_as_int(R[6]);
-				r.rv1 = R[7 + 3 * side + c1]; r.rv2 = R[7 + 3 * side + c2];      // lever arm components (c+1)%3 and (c+2)%3, the two a cross product needs on lane c; the same for the 3 rows
-				r.q0 = R[LROW + 7]; r.q1 = R[LROW + 8]; r.q2 = R[LROW + 9];        // refined reciprocals of the three effective masses
-				r.n0 = R[13 + c]; r.n1 = R[LROW + 13 + c]; r.n2 = R[2 * LROW + 13 + c];
+				const float rv1 = R[7 + 3 * side + c1], rv2 = R[7 + 3 * side + c2];      // lever arm components (c+1)%3 and (c+2)%3 of this side; the same for the 3 rows
+				r.q0 = R[LROW + 7]; r.q1 = R[LROW + 8]; r.q2 = R[LROW + 9];              // reciprocals of the three effective masses
 				r.s0 = *reinterpret_cast<const float4 *>(R); r.s1 = *reinterpret_cast<const float4 *>(R + LROW); r.s2 = *reinterpret_cast<const float4 *>(R + 2 * LROW);      // ts ts_post fmin fmax
-				r.e0 = R[4]; r.i0 = R[5]; r.e1 = R[LROW + 4]; r.i1 = R[LROW + 5]; r.e2 = R[2 * LROW + 4]; r.i2 = R[2 * LROW + 5];
-				r.Ix = I_w[12 * body + c]; r.Iy = I_w[12 * body + 4 + c]; r.Iz = I_w[12 * body + 8 + c]; r.minv = lin_w[4 * body + 3];
+				r.i0 = R[5]; r.i1 = R[LROW + 5]; r.i2 = R[2 * LROW + 5];
+				const float Ix = I_w[12 * body + c], Iy = I_w[12 * body + 4 + c], Iz = I_w[12 * body + 8 + c], minv = lin_w[4 * body + 3];
+				auto prep = [&](float nraw, float &n, float &g, float &bq, float &am) {
+					n = __int_as_float(__float_as_int(nraw) ^ sidesign);                                        // rb0: -n, rb1: n
+					g = __fmaf_rn(rv1, dpp<QP_ROT2>(n), -(rv2 * dpp<QP_ROT1>(n)));                             // cross(r, n)[c] = r[c+1]*n[c+2] - r[c+2]*n[c+1]
+					bq = __fmaf_rn(Iz, dpp<QP_BC2>(g), __fmaf_rn(Iy, dpp<QP_BC1>(g), Ix * dpp<QP_BC0>(g)));  // (Iinv * g)[c]
+					am = n * minv;
+				};
+				prep(R[13 + c], r.n0, r.g0, r.b0, r.a0); prep(R[LROW + 13 + c], r.n1, r.g1, r.b1, r.a1); prep(R[2 * LROW + 13 + c], r.n2, r.g2, r.b2, r.a2);
 			};
 			auto step = [&](const lset &r) {
 				const int body = side ? (int)(r.e >> 24) : (int)((r.e >> 16) & 255);
 				float l = lin_w[4 * body + c], av = ang_w[4 * body + c];
-				auto row = [&](float n, float ts, float fmn, float fmx, float eff, float rinv, float isum) -> float {
-					const float w = (r.Ix * dpp<QP_BC0>(av) + r.Iy * dpp<QP_BC1>(av)) + r.Iz * dpp<QP_BC2>(av);
-					const float v = (dpp<QP_ROT1>(w) * r.rv2 - dpp<QP_ROT2>(w) * r.rv1) + l * r.minv;            // cross(w, r)[c] + v_lin[c]: velocity of this side's anchor
-					const float u = __int_as_float(__float_as_int(v) ^ sidesign);                             // rb1 side: v1, rb0 side: -v0
-					const float d = u + pair_swap(u);                                                          // (v1 - v0)[c] on both sides (v1 + -v0)
-					const float p = d * n;
-					const float vn = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);
-					const float impulsen = -ts - vn;
-					float impulse = div_ieee_r(impulsen, eff, rinv);
+				auto row = [&](float n, float g, float bq, float am, float ts, float fmn, float fmx, float rinv, float isum) -> float {
+					const float p = __fmaf_rn(bq, av, am * l);                                                // this side's share of vn, component c
+					const float sp = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);
+					const float vn = sp + pair_swap(sp);                                                       // v1.n - v0.n
+					float impulse = (-ts - vn) * rinv;
 					impulse = clamp_med3(impulse, fmn - isum, fmx - isum);
-					const float imp = n * __int_as_float(__float_as_int(impulse) ^ sidesign);                  // rb0: n * -impulse, rb1: n * impulse
-					l = l + imp;
-					av = av + (r.rv1 * dpp<QP_ROT2>(imp) - r.rv2 * dpp<QP_ROT1>(imp));                         // + cross(r, imp)[c]
+					l = __fmaf_rn(n, impulse, l);
+					av = __fmaf_rn(g, impulse, av);
 					return isum + impulse;
 				};
-				const float ns0 = row(r.n0, post ? r.s0.y : r.s0.x, r.s0.z, r.s0.w, r.e0, r.q0, r.i0);
+				const float ns0 = row(r.n0, r.g0, r.b0, r.a0, post ? r.s0.y : r.s0.x, r.s0.z, r.s0.w, r.q0, r.i0);
 				float f1n = r.s1.z, f1x = r.s1.w, f2n = r.s2.z, f2x = r.s2.w;
 				if (r.meta & LM_NORMAL)       // a contact: the friction rows are limited by the normal row's impulse sum (physics.h:292); their fmax slot holds mu
 				{
-					const float lim1 = f1x * ns0 / dt; f1x = lim1 * dt; f1n = (-lim1) * dt;
-					const float lim2 = f2x * ns0 / dt; f2x = lim2 * dt; f2n = (-lim2) * dt;
+					const float lim1 = (f1x * ns0) * inv_dt; f1x = lim1 * dt; f1n = (-lim1) * dt;
+					const float lim2 = (f2x * ns0) * inv_dt; f2x = lim2 * dt; f2n = (-lim2) * dt;
 				}
-				const float ns1 = row(r.n1, post ? r.s1.y : r.s1.x, f1n, f1x, r.e1, r.q1, r.i1);
-				const float ns2 = row(r.n2, post ? r.s2.y : r.s2.x, f2n, f2x, r.e2, r.q2, r.i2);
+				const float ns1 = row(r.n1, r.g1, r.b1, r.a1, post ? r.s1.y : r.s1.x, f1n, f1x, r.q1, r.i1);
+				const float ns2 = row(r.n2, r.g2, r.b2, r.a2, post ? r.s2.y : r.s2.x, f2n, f2x, r.q2, r.i2);
 				if (c < 3) { lin_w[4 * body + c] = l; ang_w[4 * body + c] = av; }
 				else if (side == 0)
 				{
@@ -815,6 +819,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		//     same pipeline; inside a run the next row's record is read while the current row is applied
 		if (!HT_DBG(a.dbg, 4) && nlev_ang > 0)
 		{
+			// Jacobian form: dot(Iinv*L, axis) = dot(Iinv*axis, L); ba = Iinv*axis is formed off the dependent chain, the side's sign rides on the axis
 			struct aset { unsigned e; float ax, ts, mn, mx, s2t, torque, Ix, Iy, Iz; };
 			auto entry = [&](int L) -> unsigned {
 				if (L > nlev_ang) return S.aorder[MAXA2];
@@ -834,7 +839,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			auto step = [&](const aset &r) {
 				const int body = side ? (int)(r.e >> 24) : (int)((r.e >> 16) & 255);
 				const int cnt = (int)((r.e >> 8) & 255);
-				const bool bv = body != IDLE_BODY;
+				const bool bv = body != IDLE_BODY;       // a missing body: its inverse inertia and momenta are exact zeros, so it contributes exactly 0
 				float av = ang_w[4 * body + c];
 				float *R = S.arec + (int)(r.e & 0xFF) * AROW;
 				float ax = r.ax, ts = r.ts, mn = r.mn, mx = r.mx, s2t = r.s2t, torque = r.torque;
@@ -842,17 +847,16 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				{
 					const float *N = R + AROW;
 					const float nax = N[c], nts = N[4 + tsoff], nmn = N[6], nmx = N[7], ns2t = N[8], ntq = N[9];      // next row of the run (or the record after it)
-					const float w = (r.Ix * dpp<QP_BC0>(av) + r.Iy * dpp<QP_BC1>(av)) + r.Iz * dpp<QP_BC2>(av);
-					const float p = w * ax;
-					const float sp = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);                       // dot(Iinv*angular_momentum, axis) of this side
-					const float u = __int_as_float(__float_as_int(bv ? sp : 0.0f) ^ sidesign);                 // a missing body contributes exactly 0
-					const float currentspin = u + pair_swap(u);                                                // spin1 - spin0
-					const float dspin = ts - currentspin;
-					float dtorque = dspin * s2t;
+					const float axs = __int_as_float(__float_as_int(ax) ^ sidesign);                              // rb0: -axis, rb1: axis
+					const float ba = __fmaf_rn(r.Iz, dpp<QP_BC2>(axs), __fmaf_rn(r.Iy, dpp<QP_BC1>(axs), r.Ix * dpp<QP_BC0>(axs)));      // (Iinv * axis)[c]
+					const float gain = ts == -FLT_MAX ? 0.0f : s2t;                                                // disabled row (physics.h:252): no torque
+					const float p = ba * av;
+					const float sp = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);                           // this side's signed spin about the axis
+					const float currentspin = sp + pair_swap(sp);                                                  // spin1 - spin0
+					float dtorque = (ts - currentspin) * gain;
 					dtorque = clamp_med3(dtorque, mn - torque, mx - torque);
-					if (ts == -FLT_MAX) dtorque = 0.0f;                                                        // disabled row (physics.h:252)
-					av = av + __int_as_float(__float_as_int(ax * dtorque) ^ sidesign);                         // rb0: a - axis*dtorque, rb1: a + axis*dtorque
-					R[9] = torque + dtorque;                                                                    // the same value from every lane of the pair
+					av = __fmaf_rn(axs, dtorque, av);                                                              // rb0: a - axis*dtorque, rb1: a + axis*dtorque
+					R[9] = torque + dtorque;                                                                       // the same value from every lane of the pair
 					R += AROW; ax = nax; ts = nts; mn = nmn; mx = nmx; s2t = ns2t; torque = ntq;
 				}
 				if (c < 3 && bv) ang_w[4 * body + c] = av;

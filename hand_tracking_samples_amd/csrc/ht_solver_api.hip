@@ -487,7 +487,7 @@ extern "C" int ht_debug_solve_stats(ht_ctx *ctx, int B, float *out, int reset)
 	if (ht_sync_all(ctx) != hipSuccess) return HT_ERR_HIP;
 	for (int b = 0; b < B; b++)
 	{
-		float *src = ctx->d_scratch + ((size_t)b * stride + (stride - 1)) * 20;
+		float *src = ctx->d_scratch + ((size_t)b * stride + (stride - 1)) * HT_CREC;
 		if (out && hipMemcpy(out + (size_t)b * 12, src, 12 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return HT_ERR_HIP;
 		if (reset && hipMemset(src, 0, 12 * sizeof(float)) != hipSuccess) return HT_ERR_HIP;
 	}

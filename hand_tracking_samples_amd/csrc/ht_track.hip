@@ -186,8 +186,7 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 		const v3 r1 = qrot(ubq, p1);
 		const float impulsed = minv + dot(cross(mul(Iinv, cross(r1, nrm)), r1), nrm);
 		const float ts = r[11] / dt;
-		if (in_lds) quad_write_record(urow + (size_t)i * CREC, r1, nrm, ts, fmin_std(ts, r[12]), impulsed, r[13] * dt, r[14] * dt);
-		else quad_write_record(grec + (size_t)i * CREC, r1, nrm, ts, fmin_std(ts, r[12]), impulsed, r[13] * dt, r[14] * dt);
+		quad_write_record((in_lds ? urow : grec) + (size_t)i * CREC, r1, nrm, Iinv, ts, fmin_std(ts, r[12]), impulsed, r[13] * dt, r[14] * dt);
 	}
 	__threadfence_block();
 	__syncthreads();
@@ -195,8 +194,7 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 	{
 		const int c = lane;
 		// rbinitvelocity on a body at rest: 0 * damping + 0
-		quad_body qb = { (0.0f * M.ub_dampleft) + 0.0f, (0.0f * M.ub_dampleft) + 0.0f, minv,
-		                 c == 0 ? Iinv.x.x : c == 1 ? Iinv.x.y : c == 2 ? Iinv.x.z : 0.0f, c == 0 ? Iinv.y.x : c == 1 ? Iinv.y.y : c == 2 ? Iinv.y.z : 0.0f, c == 0 ? Iinv.z.x : c == 1 ? Iinv.z.y : c == 2 ? Iinv.z.z : 0.0f };
+		quad_body qb = { (0.0f * M.ub_dampleft) + 0.0f, (0.0f * M.ub_dampleft) + 0.0f, minv };
 		v3 pn = ubpos; v4 qn = ubq;
 		const int total = ph.iterations + ph.iterations_post;
 		for (int sweep = 0; sweep < total; sweep++)

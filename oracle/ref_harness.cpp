@@ -26,6 +26,7 @@
 //   slowfit <animbank.pose> <rows,comma> <out.htfx>   HandTracker::slowfit with several argument sets
 //   segment <animbank.pose> <rows,comma> <out.htfx>   320x240 frames and what HandSegmentVR makes of them
 //   bench  <frames.htfx> <seed> <fc2gain> <reps>   reference CPU time for the unit of work
+//   poses  <frames.htfx> <seed> <fc2gain> <out.htfx>   the unit of work on every frame of the file: user poses, othermodel poses, tracker flags
 //   cnn128 <frames128.htfx> <idx,comma> <seed> <fc2gain> <out.htfx>   the layer list of PoseInitializerCNN on a 128x128 input (SURVEY 8d config 5 ii),
 //                                                  assembled from the reference's own layer classes, evaluated on frames of a `fullframes` file
 //
@@ -922,6 +923,43 @@ static int mode_bench(const char *framesfn, uint64_t seed, double gain, int reps
 	return 0;
 }
 
+// The unit of work on every frame of a frames file, results only: user-space poses of handmodel, othermodel's state after the CNN job and the
+// accept decision.  Built with other compiler flags (HT_REF_FLAGS of tools/ref_flag_spread.sh) it measures how far the REFERENCE moves between its
+// own builds (IEEE / FMA-contracted / the Makefile's -Ofast) on the very frames the bench uses.
+static int mode_poses(const char *framesfn, uint64_t seed, double gain, const char *outfn)
+{
+	HandTracker htk;
+	htk.microforce = 3.0f; htk.mainthreadpasses = 3; htk.always_take_cnn = 0;
+	load_weights(htk, seed, gain);
+	auto arrs = htfx_read(framesfn);
+	const Arr *ad = NULL, *ac = NULL, *as = NULL;
+	for (auto &a : arrs) { if (a.name == "depth") ad = &a; if (a.name == "cam") ac = &a; if (a.name == "startpose") as = &a; }
+	if (!ad || !ac || !as) { fprintf(stderr, "frames file lacks depth/cam/startpose\n"); return 2; }
+	const int n = (int)ad->dims[0];
+	std::vector<float> user, other, accept;
+	for (int i = 0; i < n; i++)
+	{
+		const float *c = (const float*)ac->data.data() + 12 * i;
+		DCamera cam({ 64,64 }, { c[0],c[1] }, { c[2],c[3] }, c[4], Pose({ c[5],c[6],c[7] }, { c[8],c[9],c[10],c[11] }));
+		const unsigned short *d = (const unsigned short*)ad->data.data() + 4096 * i;
+		Image<unsigned short> seg(cam, std::vector<unsigned short>(d, d + 4096));
+		std::vector<Pose> sp(17); const float *s = (const float*)as->data.data() + 119 * i;
+		for (int b = 0; b < 17; b++) sp[b] = Pose({ s[7 * b],s[7 * b + 1],s[7 * b + 2] }, { s[7 * b + 3],s[7 * b + 4],s[7 * b + 5],s[7 * b + 6] });
+		reset_tracker(htk, sp);
+		auto points = takesubsample(PointCloud(seg, { 0.1f,htk.drangey }), htk.subsample_fraction, htk.subsample_voxel, htk.subsample_size);
+		auto p = unit_of_work(htk, seg);
+		for (float f : flat(p)) user.push_back(f);
+		for (auto &rb : htk.othermodel.rigidbodies) { for (int k = 0; k < 3; k++) other.push_back(rb.position[k]); for (int k = 0; k < 4; k++) other.push_back(rb.orientation[k]); }
+		accept.push_back(htk.prev_frame_error); accept.push_back((float)htk.initializing); accept.push_back((float)points.size());
+	}
+	Out o; if (htfx_open(&o.w, outfn)) return 3;
+	o.f32("uw_pose_user", user, { (uint32_t)n, 17, 7 });
+	o.f32("other_pose", other, { (uint32_t)n, 17, 7 });
+	o.f32("flags", accept, { (uint32_t)n, 3 });
+	htfx_close(&o.w);
+	return 0;
+}
+
 int main(int argc, char **argv) try
 {
 	if (argc < 2) { fprintf(stderr, "usage: see header of ref_harness.cpp\n"); return 1; }
@@ -944,6 +982,7 @@ int main(int argc, char **argv) try
 	if (mode == "voxel" && a.size() == 7) return mode_voxel(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), atof(a[4].c_str()), atoi(a[5].c_str()), a[6].c_str());
 	if (mode == "golden" && a.size() == 5) return mode_golden(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());
 	if (mode == "cnn128" && a.size() == 5) return mode_cnn128(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());
+	if (mode == "poses" && a.size() == 4) return mode_poses(a[0].c_str(), strtoull(a[1].c_str(), 0, 0), atof(a[2].c_str()), a[3].c_str());
 	if (mode == "bench" && a.size() >= 4) return mode_bench(a[0].c_str(), strtoull(a[1].c_str(), 0, 0), atof(a[2].c_str()), atoi(a[3].c_str()), a.size() > 4 ? atoi(a[4].c_str()) : 0);
 	fprintf(stderr, "bad arguments\n");
 	return 1;

@@ -1,17 +1,21 @@
 """Whole unit of work (CNN + decode + MultiStepSim + accept + 3 FitPointCloud passes) on a batch of the bench's own frames,
-device against the C restatement frame by frame.  The restatement is pinned bit for bit to the reference on the 8 golden
-frames (test_oracle_vs_golden.py); this test widens the comparison to frames the goldens do not cover, including the data-
-dependent branches (chamber on/off at 400 points, full reset, CNN pose accepted / rejected).
+device against the REFERENCE frame by frame: tests/golden/poses256.htfx holds what the reference's own code (IEEE build, oracle/ref_harness.cpp
+`poses`) returns for each of the 256 bench frames; the C restatement reproduces all of them bit for bit (test_oracle_vs_golden.py).  The frames
+cover the data-dependent branches (chamber on/off at 400 points, full reset, CNN pose accepted / rejected).
 
-The device CNN accumulates in a different order (MFMA tiles), so heat-maps differ by ~1e-6; where that flips nothing the poses
-agree to float rounding.  A flipped accept/reject or arg-max decision changes a pose visibly, so the test bounds how often
-that happens instead of hiding it behind a loose tolerance."""
+Tolerance.  The device evaluates the reference's algorithm in another association order: the CNN accumulates on MFMA tiles (heat-maps differ by
+~1e-6) and the solver applies each constraint row in Jacobian form with fused multiply-adds (csrc/ht_quad.hpp).  Where that flips no discrete
+decision (closest bone, arg-max, accept / reject, GJK branch) the poses agree to 2e-5 m / 2e-4; a flipped decision changes a pose visibly, so the
+test bounds how often that happens instead of hiding it behind a loose tolerance.  The yardstick is the reference itself: built with FMA
+contraction instead of IEEE (tests/golden/ref_flag_spread.py, profiles/r03_reference_build_spread.json) it keeps 254 of these 256 frames within
+2e-5 m / 2e-4 and 255 within 2e-4 m / 2e-3 (worst 4.1e-4 m / 6.3e-3); built -Ofast, as its own Makefile does, only 15 / 108."""
 import ctypes as C
 import os
 
 import numpy as np
 import pytest
 
+import htfx
 import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
@@ -19,36 +23,66 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 N = 256
 
 
-def test_batch_against_restatement(weights):
+def _diff(got, ref):
+    dp = np.abs(got[:, :, :3] - ref[:, :, :3]).max(axis=(1, 2))
+    dq = np.minimum(np.abs(got[:, :, 3:] - ref[:, :, 3:]), np.abs(got[:, :, 3:] + ref[:, :, 3:])).max(axis=(1, 2))
+    return dp, dq
+
+
+def test_batch_against_reference(weights):
     from hand_tracking_samples_amd import native
     d = np.load(os.path.join(HERE, "golden", "frames256.npz"))
-    idx = np.arange(N) * 256 // N
-    depth, cams, start = d["depth"][idx].reshape(N, -1), d["cam"][idx], d["startpose"][idx]
+    refp = htfx.load(os.path.join(HERE, "golden", "poses256.htfx"))
+    depth, cams, start = d["depth"].reshape(N, -1), d["cam"], d["startpose"]
     ctx = native.Context(ol.MODEL, N)
     ctx.load_weights(weights)
     ctx.set_params(microforce=3.0, mainthreadpasses=3)
     ctx.tracker_reset(start)
     got = ctx.update_sync(depth, cams)
+    pfe, ini = ctx.tracker_flags(N)
     ctx.close()
+    ref = refp["uw_pose_user"]
+    dp, dq = _diff(got, ref)
+    tight = (dp <= 2e-5) & (dq <= 2e-4)
+    loose = (dp <= 2e-4) & (dq <= 2e-3)
+    print("vs reference: frames exact %d, within 2e-5 m / 2e-4: %d, within 2e-4 m / 2e-3: %d of %d; |dpos| p50 %.1e p99 %.1e max %.2e m, |dquat| p50 %.1e p99 %.1e max %.2e (worst frame %d)"
+          % (int(((dp == 0) & (dq == 0)).sum()), int(tight.sum()), int(loose.sum()), N, np.percentile(dp, 50), np.percentile(dp, 99), dp.max(),
+             np.percentile(dq, 50), np.percentile(dq, 99), dq.max(), int(dp.argmax())))
+    # the reference's own FMA-contracted build: 254 tight, 255 loose, worst 4.1e-4 m / 6.3e-3 (module docstring)
+    assert tight.sum() >= N - 4, "frames outside 2e-5 m / 2e-4: %s" % np.nonzero(~tight)[0]
+    assert loose.sum() >= N - 2, "frames outside 2e-4 m / 2e-3: %s" % np.nonzero(~loose)[0]
+    assert np.median(dp) <= 1e-6 and np.median(dq) <= 2e-5
+    assert dp.max() < 5e-3      # even a flipped decision stays a small pose change on these frames
+    # the tracker's discrete state after the frame: `initializing` (handtrack.h:781) on every frame
+    assert np.array_equal(ini, refp["flags"][:, 1].astype(np.int32))
+
+
+def test_batch_against_restatement(weights):
+    """The same comparison against the C restatement run beside the device (it is pinned to the fixture above bit for bit on the build box; here it
+    shows that the checker that travels to the GPU box agrees with the fixture on this host's libm too)."""
+    from hand_tracking_samples_amd import native
+    d = np.load(os.path.join(HERE, "golden", "frames256.npz"))
+    idx = np.arange(64) * 4
+    depth, cams, start = d["depth"][idx].reshape(64, -1), d["cam"][idx], d["startpose"][idx]
     orc = ol.Oracle(weights)
     orc.head.par.microforce = 3.0; orc.head.par.mainthreadpasses = 3
-    ref = np.zeros((N, 17, 7), np.float32)
-    for k in range(N):
+    ref = np.zeros((64, 17, 7), np.float32)
+    for k in range(64):
         orc.reset(start[k])
         cam = ol.camera(cams[k])
         orc.L.ho_update(orc.h, ol.u16ptr(np.ascontiguousarray(depth[k])), C.byref(cam), ol.fptr(ref[k]))
     orc.close()
-    dp = np.abs(got[:, :, :3] - ref[:, :, :3]).max(axis=(1, 2))
-    dq = np.minimum(np.abs(got[:, :, 3:] - ref[:, :, 3:]), np.abs(got[:, :, 3:] + ref[:, :, 3:])).max(axis=(1, 2))
+    assert np.array_equal(ref, htfx.load(os.path.join(HERE, "golden", "poses256.htfx"))["uw_pose_user"][idx])
+    ctx = native.Context(ol.MODEL, 64)
+    ctx.load_weights(weights)
+    ctx.set_params(microforce=3.0, mainthreadpasses=3)
+    ctx.tracker_reset(start)
+    got = ctx.update_sync(depth, cams)
+    ctx.close()
+    dp, dq = _diff(got, ref)
     tight = (dp <= 2e-5) & (dq <= 2e-4)
-    loose = (dp <= 2e-4) & (dq <= 2e-3)
-    print("frames exact %d, within 2e-5 m / 2e-4: %d, within 2e-4 m / 2e-3: %d of %d; worst |dpos| %.2e m |dquat| %.2e (frame %d)"
-          % (int(((dp == 0) & (dq == 0)).sum()), int(tight.sum()), int(loose.sum()), N, dp.max(), dq.max(), int(dp.argmax())))
-    # observed on MI355X: 249 frames identical to the last bit, 255 tight, all 256 within 2e-4 m / 2e-3 (worst 1.9e-5 m / 5.5e-4)
-    assert loose.sum() >= N - 1, "more than 1 of %d frames outside 2e-4 m / 2e-3: %s" % (N, np.nonzero(~loose)[0])
-    assert tight.sum() >= N - 4
-    assert int(((dp == 0) & (dq == 0)).sum()) >= 240
-    assert dp.max() < 1e-3      # even a flipped decision stays a small pose change on these frames
+    print("vs restatement, 64 frames: tight %d, worst |dpos| %.2e m |dquat| %.2e" % (int(tight.sum()), dp.max(), dq.max()))
+    assert tight.sum() >= 62
 
 
 def test_full_size_batch_properties(weights):

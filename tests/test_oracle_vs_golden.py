@@ -9,6 +9,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import htfx
 import oracle_lib as ol
 
 NFRAMES = 8
@@ -253,3 +254,23 @@ def test_unit_of_work_two_frames(orc, golden, f):
     orc.L.ho_update(orc.h, ol.u16ptr(depth), C.byref(cam), ol.fptr(user))
     assert np.array_equal(user, golden[pre + "uw2_pose_user"])
     assert np.array_equal(orc.get_state(0), golden[pre + "uw2_hand"])
+
+
+def test_unit_of_work_on_all_256_bench_frames(weights):
+    """The C restatement against the reference on every frame the bench and the batch parity tests use (tests/golden/poses256.htfx = the reference's
+    user poses, othermodel poses and tracker flags after the whole unit of work, `ref_harness poses`): bit for bit."""
+    import os
+    d = np.load(os.path.join(ol.GOLDEN, "frames256.npz"))
+    ref = htfx.load(os.path.join(ol.GOLDEN, "poses256.htfx"))
+    orc = ol.Oracle(weights)
+    orc.head.par.microforce = 3.0; orc.head.par.mainthreadpasses = 3
+    user = np.zeros((17, 7), np.float32)
+    for k in range(256):
+        orc.reset(d["startpose"][k])
+        cam = ol.camera(d["cam"][k])
+        orc.L.ho_update(orc.h, ol.u16ptr(np.ascontiguousarray(d["depth"][k].reshape(-1))), C.byref(cam), ol.fptr(user))
+        assert np.array_equal(user, ref["uw_pose_user"][k]), "frame %d: user pose" % k
+        assert np.array_equal(orc.get_state(1)[:, :7], ref["other_pose"][k]), "frame %d: othermodel" % k
+        e, i, n = orc.flags()
+        assert (np.float32(e), i, n) == (ref["flags"][k, 0], int(ref["flags"][k, 1]), int(ref["flags"][k, 2])), "frame %d: flags" % k
+    orc.close()

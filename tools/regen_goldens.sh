@@ -32,6 +32,8 @@ $H modelfile $T/model_chain3.json $T/model_chain3.htfx
 $H golden $BANK 0,16,144,1584,2224,912,1504,2048 $SEED $GAIN $T/golden8.htfx
 # bench / batch-parity input: 256 frames, rows 3, 12, 21, ... (first 3, stride 9)
 $H frames $BANK 3 9 256 $T/frames256.htfx
+# the reference's result of the whole unit of work on every one of those 256 frames (user poses, othermodel poses, tracker flags)
+$H poses $T/frames256.htfx $SEED $GAIN $T/poses256.htfx
 # the optional voxel sub-sampling of the main-thread cloud (handtrack.h:535-536): 1 cm voxels, min_point_num 20
 $H voxel $BANK 0,912,2224,1504 $SEED $GAIN 0.01 20 $T/voxel4.htfx
 # next rows of SURVEY 8(f)
@@ -59,7 +61,7 @@ HT_REF_MODEL_JSON=$T/model_hand26.json $H fullframes $BANK 3 36 64 128,128,163 $
 $H cnn128 $T/frames5.htfx 0,9,33,60 $SEED $GAIN $T/cnn128.htfx
 
 rc=0
-for f in model_hand17 model_hand26 model_chain3 golden8 voxel4 scale115 slowfit3 train3 fullframe320 fullframe320close fullframe5 config5 cnn128; do
+for f in model_hand17 model_hand26 model_chain3 golden8 poses256 voxel4 scale115 slowfit3 train3 fullframe320 fullframe320close fullframe5 config5 cnn128; do
 	if cmp -s $T/$f.htfx $G/$f.htfx; then echo "identical  $f.htfx"; else echo "DIFFERENT  $f.htfx"; rc=1; fi
 	[ $WRITE = 1 ] && cp $T/$f.htfx $G/$f.htfx
 done
