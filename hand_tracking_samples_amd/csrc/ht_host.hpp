@@ -49,7 +49,6 @@ struct ht_ctx
 	float *d_contacts = nullptr; int *d_ncontacts = nullptr;    // [B][HT_MAXCONTACT][HT_CONTACT]
 	unsigned char *d_epa_ws = nullptr;                           // expanding-polytope workspace, one per (frame, wave)
 	float *d_scratch = nullptr;                                  // solver row records [B][pts_cap + 5*nb + 32][20] (ht_quad.hpp)
-	int *d_retry = nullptr;                                      // [B] k_solve: frames handed from the small-pool build to the large one
 	float *d_poses_out = nullptr, *d_start = nullptr;
 	float *d_stage = nullptr;                                    // staging for host<->device state copies
 };
@@ -61,9 +60,9 @@ struct ht_prof_scope
 	~ht_prof_scope();
 };
 
-// rows of a frame's slot of the solver scratch: every point and chamber row, k_solve's read-ahead slack, and the rows that pad a host body's chain
-// to a multiple of 8 when a body beyond the 16th rides on its quad (7 per such body at most)
-static inline size_t ht_scratch_rows(size_t pts_cap, size_t nb) { return pts_cap + 5 * nb + 32 + 7 * 16; }
+// rows of a frame's slot of the solver scratch: every point and chamber row, k_solve's read-ahead slack, the rows that pad a host body's chain
+// to a multiple of 8 when a body beyond the 16th rides on its quad (7 per such body at most), and the tail that takes what does not fit k_solve's LDS
+static inline size_t ht_scratch_rows(size_t pts_cap, size_t nb) { return pts_cap + 5 * nb + 32 + 7 * 16 + HT_SCRATCH_TAIL; }
 int ht_alloc_buffers(ht_ctx *ctx);
 int ht_reserve_points_locked(ht_ctx *ctx, int points);      // grows the per-point arrays (ht_api.hip); waits for the context's streams
 // *_dev entry points: a NULL stream means the context's own stream (never the legacy default stream); the choice is remembered so that the

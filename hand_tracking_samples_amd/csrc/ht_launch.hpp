@@ -12,7 +12,6 @@ struct solve_args
 	float *state;                                                   // [B][nb][HT_STATE_STRIDE] of the model being solved
 	float *scratch; int scratch_stride;                             // [B][scratch_stride][HT_CREC] pre-computed single-body row records (ht_quad.hpp)
 	int batch;                                                      // frames of the launch (the sums of over-size frames live behind all frames' records)
-	int *retry;                                                     // [B] frames the small-pool build of k_solve passes on to the large one
 	int apply_angles; float drive_force; int ray_rows; int arm_cone; int zero_momenta; int steps_keyangles; float min_cray_prob;
 	// slowfit (handtrack.h:786-821): landmark rays from the origin (sf_crays [B][8][4], first sf_ncray used), a bone nailed to a point, and
 	// RelativeAngularConstraints against a reference pose (sf_refpose [B][nb][7], sf_hold = 1 or 2); all off when zero / null

@@ -98,10 +98,11 @@ __device__ __forceinline__ float quad_row_step(quad_body &B, const float4 a, con
 	return sum + bi;      // the same value on all four lanes (they read the same sum): the quad's four writes to one address agree
 }
 // Applies rows [0, cnt) of one chain in order.  rec = the chain's first record, sums = the chain's first impulse sum (LDS), c = lane within the
-// quad, post = 1 after RemoveBias.  Eight register sets rotate, so the read of a row is issued eight rows ahead of its use (records stream from
-// L2 / the Infinity Cache, several hundred clocks away); the loop trips of the quads of a wave differ, the compiler masks finished quads off.
-// Reads run up to 15 records (and sums) past the chain's end: the caller's buffers have that slack.
-#define QUAD_CHAIN_SLACK 16
+// quad, post = 1 after RemoveBias.  Sixteen register sets rotate: the read of a record is issued sixteen rows ahead of its use (a row is ~90 clocks
+// and the records stream from L2, the Infinity Cache or HBM: 200 / 550 / 900 clocks away), the read of its impulse sum eight rows ahead (LDS; a wave
+// keeps at most 15 LDS operations in flight).  The loop trips of the quads of a wave differ, the compiler masks finished quads off.
+// Reads run up to 31 records (and 23 sums) past the chain's end: the caller's buffers have that slack.
+#define QUAD_CHAIN_SLACK 32
 // A quad can walk TWO bodies' chains back to back (k_solve, models with more than 16 bodies: the 17th body's rows follow the host body's, which are
 // padded to a multiple of 8 with rows that change nothing): at row `kswitch` (a multiple of 8, or < 0 for none) the momenta go back to body `bodyA`'s
 // slots of lin_w / ang_w and body `bodyB`'s state is taken up.
@@ -116,38 +117,40 @@ __device__ __forceinline__ void quad_chain_run(quad_body &B, const float *rec, f
 	const float4 *pa = reinterpret_cast<const float4 *>(rec) + c;
 	float *ps = sums;
 	// first reads in the order the loop consumes them (the wait counts the compiler derives for the loop are the minimum over both entries)
-#define QC_LOAD(i, row) a##i = pa[4 * (row)]; s##i = ps[row]; __builtin_amdgcn_sched_barrier(0)
-	float4 a0, a1, a2, a3, a4, a5, a6, a7; float s0, s1, s2, s3, s4, s5, s6, s7;
-	QC_LOAD(0, 0); QC_LOAD(1, 1); QC_LOAD(2, 2); QC_LOAD(3, 3); QC_LOAD(4, 4); QC_LOAD(5, 5); QC_LOAD(6, 6); QC_LOAD(7, 7);
+#define QC_LA(i, row) a##i = pa[4 * (row)]; __builtin_amdgcn_sched_barrier(0)
+#define QC_LS(i, row) s##i = ps[row]; __builtin_amdgcn_sched_barrier(0)
+	float4 a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14, a15; float s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15;
+	QC_LA(0, 0); QC_LA(1, 1); QC_LA(2, 2); QC_LA(3, 3); QC_LA(4, 4); QC_LA(5, 5); QC_LA(6, 6); QC_LA(7, 7);
+	QC_LA(8, 8); QC_LA(9, 9); QC_LA(10, 10); QC_LA(11, 11); QC_LA(12, 12); QC_LA(13, 13); QC_LA(14, 14); QC_LA(15, 15);
+	QC_LS(0, 0); QC_LS(1, 1); QC_LS(2, 2); QC_LS(3, 3); QC_LS(4, 4); QC_LS(5, 5); QC_LS(6, 6); QC_LS(7, 7);
 	int k = 0;
 	// The scheduling barriers keep every row's instructions between its own pair: left alone, the ILP-first scheduler hoists the first use of the
 	// record that was requested last to the top of the trip as a hazard filler, which turns the wait for it into a wait for every outstanding
 	// read (s_waitcnt vmcnt(0)), i.e. one full memory round trip per trip.
 #define QC_STEP(i) ps[i] = quad_row_step(B, a##i, s##i, post)
-	for (; k + 8 <= cnt; k += 8)
+	// row i of the trip: apply it, then ask for the record sixteen rows on (same register set) and the impulse sum eight rows on (set i + 8)
+#define QC_ROW(i, j) QC_STEP(i); QC_LA(i, 16 + i); QC_LS(j, 8 + i)
+	for (; k + 16 <= cnt; k += 16)
 	{
 		if (k == kswitch) quad_switch_body(B, c, lin_w, ang_w, bodyA, bodyB);
-		QC_STEP(0); QC_LOAD(0, 8); QC_STEP(1); QC_LOAD(1, 9); QC_STEP(2); QC_LOAD(2, 10); QC_STEP(3); QC_LOAD(3, 11);
-		QC_STEP(4); QC_LOAD(4, 12); QC_STEP(5); QC_LOAD(5, 13); QC_STEP(6); QC_LOAD(6, 14); QC_STEP(7); QC_LOAD(7, 15);
-		pa += 32; ps += 8;
+		QC_ROW(0, 8); QC_ROW(1, 9); QC_ROW(2, 10); QC_ROW(3, 11); QC_ROW(4, 12); QC_ROW(5, 13); QC_ROW(6, 14); QC_ROW(7, 15);
+		if (k + 8 == kswitch) quad_switch_body(B, c, lin_w, ang_w, bodyA, bodyB);
+		QC_ROW(8, 0); QC_ROW(9, 1); QC_ROW(10, 2); QC_ROW(11, 3); QC_ROW(12, 4); QC_ROW(13, 5); QC_ROW(14, 6); QC_ROW(15, 7);
+		pa += 64; ps += 16;
 	}
 	if (k == kswitch) quad_switch_body(B, c, lin_w, ang_w, bodyA, bodyB);
-	const int left = cnt - k;      // 0..7 rows, already in the register sets
-	if (left > 0) QC_STEP(0);
-	__builtin_amdgcn_sched_barrier(0);
-	if (left > 1) QC_STEP(1);
-	__builtin_amdgcn_sched_barrier(0);
-	if (left > 2) QC_STEP(2);
-	__builtin_amdgcn_sched_barrier(0);
-	if (left > 3) QC_STEP(3);
-	__builtin_amdgcn_sched_barrier(0);
-	if (left > 4) QC_STEP(4);
-	__builtin_amdgcn_sched_barrier(0);
-	if (left > 5) QC_STEP(5);
-	__builtin_amdgcn_sched_barrier(0);
-	if (left > 6) QC_STEP(6);
-#undef QC_LOAD
+	const int left = cnt - k;      // 0..15 rows: their records are in the register sets, the sums of the first eight too
+#define QC_TAIL(i) if (left > i) { QC_STEP(i); } __builtin_amdgcn_sched_barrier(0)
+#define QC_TAIL_S(i, j) if (left > i) { QC_STEP(i); QC_LS(j, 8 + i); } __builtin_amdgcn_sched_barrier(0)
+	QC_TAIL_S(0, 8); QC_TAIL_S(1, 9); QC_TAIL_S(2, 10); QC_TAIL_S(3, 11); QC_TAIL_S(4, 12); QC_TAIL_S(5, 13); QC_TAIL_S(6, 14); QC_TAIL_S(7, 15);
+	if (left > 8 && k + 8 == kswitch) quad_switch_body(B, c, lin_w, ang_w, bodyA, bodyB);
+	QC_TAIL(8); QC_TAIL(9); QC_TAIL(10); QC_TAIL(11); QC_TAIL(12); QC_TAIL(13); QC_TAIL(14);
+#undef QC_LA
+#undef QC_LS
 #undef QC_STEP
+#undef QC_ROW
+#undef QC_TAIL
+#undef QC_TAIL_S
 }
 // fills one record (see the layout above); r1 = lever arm in the world frame, n = row direction, Iinv = the body's world inverse inertia,
 // y = effective mass (physics.h:299-300, formed by the caller with the reference's expression)

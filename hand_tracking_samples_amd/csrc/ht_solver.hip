@@ -10,64 +10,74 @@
 //   HandModelEnhancements, CNNOutputAnalysis::ApplyAngles, the landmark-ray rows of MultiStepSim   include/handtrack.h:406-441, 203-216, 666-676
 //   SanityCheck                         include/physmodel.h:437-442
 //
-// Exact-order parallelism.  The reference applies rows strictly in vector order; two rows commute exactly when they touch disjoint
+// Order-preserving parallelism.  The reference applies rows strictly in vector order; two rows commute exactly when they touch disjoint
 // bodies.  (1) Rows with rb0 == NULL touch one body only and form a prefix of the row vector (chamber / landmark-ray rows, then
-// cloud rows): the prefix is stably partitioned by body and pre-computed (lever arm r1 = R*position1, effective mass, limits*dt: all
-// invariant during one PhysicsUpdate) into LDS; the chains of different bodies run side by side.
+// cloud rows): the prefix is stably partitioned by body and pre-computed into 64-byte records (ht_quad.hpp); the chains of different
+// bodies run side by side.
 // (2) The two-body tail (joint rows, contact triples; then all angular rows) is list-scheduled: level(row) = 1 + the highest level
 // of an earlier row sharing a body, so conflicting rows keep their order and rows of one level touch disjoint bodies.
 //
 // Lane mapping of a sweep ("quad layout").  A body's momenta live one component per lane in a quad of 4 lanes (x, y, z, spare):
-// every 3-vector operation of the reference is one scalar instruction per lane, cross products and dot products fetch the other
-// components through DPP quad permutes (no LDS, no extra instruction when the permute folds into the consumer), and the scalar part
-// of a row (impulse, clamps) is computed redundantly by the 4 lanes.  Chains: quad q walks body q, then body q+16.  Two-body linear
-// rows: lanes 8p..8p+7 (two quads = the two bodies) take the p-th row of the current level; the sides meet through DPP row shifts.
-// Angular rows stay one row per lane in registers.  The operations per component and their order are those of the reference, so
-// the result is the reference's bit for bit (compiled -ffp-contract=off) except for acos/sin/cos in a few row builders.
-// The division by the (sweep-invariant) effective mass uses the same reciprocal-refinement + residual-correction FMA sequence the
-// compiler emits for an IEEE fp32 division, without the range scaling (operands are far from the exponent limits).
+// every 3-vector operation is one scalar instruction per lane, dot products meet through DPP quad permutes (no LDS, no extra instruction
+// when the permute folds into the consumer).  Chains: quad q walks body q, then a body >= 16 it hosts.  Two-body rows: lanes 8p..8p+7
+// (two quads = the two bodies) take the p-th group of the current step; the sides meet through DPP row shifts.
+//
+// Arithmetic of a row (round 3): Jacobian form.  What LimitLinear::Iter / LimitAngular::Iter (physics.h:289-307, 251-265) recompute from
+// the momenta every time -- r = R*position, cross(Iinv*L, r), the effective mass -- does not change during one PhysicsUpdate (orientation and
+// Iinv are only re-made by rbupdatepose at its end), so every row is reduced ONCE, by the prologue, to the coefficients of
+//     vn = dot(b, L) + dot(n*massinv, P),  impulse = clamp((-targetspeed - vn) / effective mass),  P += n*impulse,  L += g*impulse
+// with g = cross(r, n), b = Iinv*g (Iinv symmetric), all formed with the reference's expressions.  A sweep then issues ~20 instructions per
+// row instead of ~80 and the dependent chain through the momenta is 8-11 operations.  Same rows, same order, same clamps as the reference;
+// another association order of the floating-point operations: see ht_quad.hpp and DESIGN.md (Numerics) for the measured effect.
 #include "ht_device.hpp"
 #include "ht_launch.hpp"
 
-#define LROW 16            // floats per two-body linear row: ts ts_post fmin*dt fmax*dt(|mu) effmass impulsesum meta r0[3] r1[3] n[3]
-#define ASLOTS 2           // angular rows live in registers: row r in lane r%64, slot r/64  (<= 128 rows)
+// A two-body linear GROUP = the 3 consecutive rows of a joint (x, y, z) or of a contact (normal + 2 friction rows): same two bodies.  64 floats:
+#define LGRP 64
+#define LG_S 0             // 3 x float4: targetspeed, targetspeed after RemoveBias, fmin*dt, fmax*dt (friction rows: fmax slot = mu)
+#define LG_RINV 12         // 3: 1 / effective mass
+#define LG_META 15         // flags | rb0 | rb1 << 8
+#define LG_SUM 16          // 3: impulse sums (the only words a sweep writes)
+#define LG_N 19            // 9: row direction n_k[c] at LG_N + 3k + c
+#define LG_GB 28           // 36: (g, b) of row k, side s, component c at LG_GB + ((2k + s)*3 + c)*2; side 0 (rb0) carries its minus sign
+// An angular row, 16 floats:
+#define AROW 16
+#define AR_S 0             // float4: targetspin, targetspin after RemoveBias, mintorque*dt, maxtorque*dt
+#define AR_GAIN 4          // 1 / (axis.Iinv0.axis + axis.Iinv1.axis); 0 for a disabled row (physics.h:252)
+#define AR_TORQUE 5        // accumulated torque (the only word a sweep writes)
+#define AR_AXIS 6          // 3
+#define AR_BA 10           // 6: -(Iinv0*axis), then Iinv1*axis
+#define ASLOTS 2           // angular rows are built in registers: row r by lane r%64, slot r/64  (<= 128 rows)
 #define MAXA2 (64 * ASLOTS)
-#define AROW 10            // floats per angular row record: axis[3] meta | ts ts_post | mintorque*dt maxtorque*dt | 1/(axis.Iinv.axis) torque
-#define MAXA_LDS 126       // angular rows held in LDS: 13 + up to 6 per joint for the 17-bone hand, plus slowfit's relative rows
-// LDS per frame = the two-body linear rows (joint triples, contact triples, the idle group: 192 B per group), the impulse sums of the single-body rows
-// (4 B each) and ~10 KB of body state, schedule tables and angular records.  Three builds of the kernel, chosen per launch:
-//   small   39 groups, 696 sums: < 20 KB, eight frames per CU (two waves per SIMD).  Every frame of the 17-bone / 64x64 workloads fits.
-//   mid     70 groups, 4272 sums (every point a full-size frame can carry): < 40 KB, four frames per CU.  The first choice for larger models or frames.
-//   large   128 groups (all 96 contacts of the contact kernel's capacity), 1184 sums in LDS, more than that in HBM: 40 KB.  Second launch: it takes the
-//           frames the first build found too big for its LDS and left untouched (their retry flag); every other block exits at once.
-#define POOL_SMALL (40 * 3 * LROW)
-#define POOL_MID (71 * 3 * LROW)
-#define POOL_LARGE ((HT_MAXNJ + HT_MAXCONTACT + 1) * 3 * LROW)
-#define SUMS_SMALL 712
-#define SUMS_MID (HT_MAXPTS + 5 * HT_MAXNB + 32)
-#define SUMS_LARGE 1200
-#define SUMS_ONLY 1024        // the single-launch build (small batches): 39.4 KB with the large pool, four blocks per CU
+#define MAXA_LDS 126       // angular rows kept per solve: 13 + up to 6 per joint for the 17-bone hand, plus slowfit's relative rows
+#define MAXG (HT_MAXNJ + HT_MAXCONTACT + 1)      // groups a frame can have: every joint, every contact the contact kernel keeps, the idle group
+// LDS per frame: ~5 KB of body state and schedule tables, a 5 KB union of prologue scratch and the angular records, and three arrays whose size is
+// the build's choice -- the two-body linear groups (256 B each), the impulse sums of the single-body rows (4 B each), the angular records (64 B each).
+// A frame whose rows do not fit an array keeps THAT array in its slot of the solver scratch in HBM instead (same code through a generic pointer): slower
+// for that frame, correct for every frame, one launch.  Builds (ht_launch_solve):
+//   small   40 groups, 624 sums, 74 angular rows: 22.5 KB = 45 LDS allocation units of 512 B, seven frames per CU.  Batches above 1024 frames of 64x64 tiles.
+//   only    66 groups (16 joints + 49 contacts), 1024 sums, 126 angular rows: 34 KB, four frames per CU (a 1024-frame batch in one round).
+//   mid     71 groups, 2272 sums, 126 angular rows: 40 KB, four frames per CU.  Larger models, full-size frames.
 #define IDLE_BODY (HT_MAXNB - 1)      // lane pairs without a row in a step work on this all-zero body and on an all-zero record
-#define LM_FRIC 0x10000    // meta bits of a two-body linear row: friction row (limits from its contact's normal row, physics.h:292)
-#define LM_NORMAL 0x20000  //                                     normal row of a contact (publishes its impulse sum)
+#define LM_FRIC 0x10000    // meta bits of a group: contact (friction rows limited by the normal row's impulse sum, physics.h:292)
+#define LM_NORMAL 0x20000
 
-template <int POOL_FLOATS, int NSUM_> struct lds_t
+template <int NGRP_, int NSUM_, int NANG_> struct lds_t
 {
-	static constexpr int ML2 = POOL_FLOATS / LROW;             // rows the pool holds, the idle group's three included
-	static constexpr int LIDLE = ML2 / 3 - 1;                  // slot of the idle entry in lorder (real groups: at most LIDLE)
-	static constexpr int NLEV = (ML2 / 3 > 64 * 2 ? ML2 / 3 : 64 * 2) + 2;      // levels of either schedule (linear groups, angular runs)
-	static constexpr int NSUM = NSUM_;
-	float pool[POOL_FLOATS] __attribute__((aligned(16)));      // two-body linear rows; first member: row addresses then fit the short offsets of two-address LDS reads
+	static constexpr int NGRP = NGRP_, NSUM = NSUM_, NANG = NANG_;
+	static constexpr int LIDLE = MAXG - 1;                      // slot of the idle entry in lorder
+	static constexpr int NLEV = (MAXG > 64 * 2 ? MAXG : 64 * 2) + 2;      // levels of either schedule (linear groups, angular runs)
+	float pool[NGRP * LGRP] __attribute__((aligned(16)));      // two-body linear groups; first member: group addresses then fit the short offsets of two-address LDS reads
 	// body state in 16-byte records: component c of body b is word 4*b + c
 	float4 lin4[HT_MAXNB];                 // xyz linear momentum, w = massinv
 	float4 ang4[HT_MAXNB];                 // xyz angular momentum, w = friction
-	float4 I4[HT_MAXNB][3];                // columns of the world inverse inertia (w unused)
+	float4 I4[HT_MAXNB][3];                // columns of the world inverse inertia (w unused); prologue only
 	float pos[HT_MAXNB][3], q[HT_MAXNB][4];
 	float csum[NSUM];                      // impulse sum of every single-body row, in the order of the partitioned stream (+ read-ahead slack)
 	int ccnt[HT_MAXNB], cstart[HT_MAXNB];  // chain of body b: rows [cstart, cstart+ccnt) of the partitioned single-body stream
 	signed char cextra[HT_MAXNB];          // body b < 16 hosts the chain of this body >= 16 on its quad (-1: none): it follows b's rows, padded to a multiple of 8
-	unsigned lorder[ML2 / 3];            // two-body linear row groups (3 consecutive rows of a joint / a contact) sorted by step: group | rb0 << 16 | rb1 << 24; last slot = the idle entry
-	unsigned short lstart[ML2 / 3 + 2];  // step L = lorder[lstart[L] .. lstart[L+1]); a step is a level, split so that it holds <= 8 groups
+	unsigned lorder[MAXG];                 // two-body linear groups sorted by step: group | rb0 << 16 | rb1 << 24; last slot = the idle entry
+	unsigned short lstart[MAXG + 2];       // step L = lorder[lstart[L] .. lstart[L+1]); a step is a level, split so that it holds <= 8 groups
 	unsigned aorder[MAXA2 + 1];            // angular row groups (runs of consecutive rows on the same body pair): first row | count << 8 | rb0 << 16 | rb1 << 24
 	unsigned short astart[MAXA2 + 2];
 	int nlev_lin, nlev_ang, nray;
@@ -78,12 +88,12 @@ template <int POOL_FLOATS, int NSUM_> struct lds_t
 			float jr[HT_MAXNJ][6];                 // joint ranges after HandModelEnhancements
 			float ray[36][HT_ROW];                 // landmark-ray rows: 4 per ray (MultiStepSim: 5 rays; slowfit: 8 rays + 3 nail rows)
 			int acount[HT_MAXNJ], aprefix[HT_MAXNJ + 1], rprefix[HT_MAXNJ + 1];
-			unsigned char lrb[ML2][2], arb[MAXA2][2];     // body pair of every two-body row (255 = none), for the level schedule
-			unsigned short llev[ML2 / 3]; unsigned char alev[MAXA2], gst[MAXA2];
+			unsigned char lrb[MAXG][2], arb[MAXA2][2];     // body pair of every group / angular row (255 = none), for the level schedule
+			unsigned short llev[MAXG]; unsigned char alev[MAXA2], gst[MAXA2];
 			unsigned short lfill[NLEV];
 			int lastlev[HT_MAXNB];                 // scratch of the level scheduler
 		};
-		float arec[(MAXA_LDS + 2) * AROW];         // sweeps: angular row records (written once the prologue scratch is dead) + the idle record + read-ahead slack
+		float arec[(NANG + 4) * AROW] __attribute__((aligned(16)));      // sweeps: angular records (written once the prologue scratch is dead) + the idle record + read-ahead slack
 	};
 };
 
@@ -201,15 +211,12 @@ __device__ __forceinline__ int angular_range_count(v3 lmin, v3 lmax)
 	return n;
 }
 
-enum { SOLVE_FIRST = 0, SOLVE_SECOND = 1, SOLVE_ONLY = 2 };      // first of two launches (may pass a frame on) / second (takes those) / a single launch that holds everything
-template <int POOL_FLOATS, int NSUM_, int MODE>
+template <int NGRP_, int NSUM_, int NANG_>
 __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph, solve_args a)
 {
-	__shared__ lds_t<POOL_FLOATS, NSUM_> S;
+	__shared__ lds_t<NGRP_, NSUM_, NANG_> S;
 	const int b = blockIdx.x, lane = threadIdx.x;
-	if (a.active_flag && !a.active_flag[b]) return;                // first: a launch never touches another launch's frames, not even their retry flags
-	if (MODE == SOLVE_FIRST) { if (lane == 0) a.retry[b] = 0; }
-	else if (MODE == SOLVE_SECOND && !a.retry[b]) return;                                 // the large build only takes the frames the first one passed on
+	if (a.active_flag && !a.active_flag[b]) return;                // a launch never touches another launch's frames
 	const int nb = M.nb, nj = M.nj;
 	float *st = a.state + (size_t)b * nb * HT_STATE_STRIDE;
 	const float dt = ph.deltaT;
@@ -322,18 +329,6 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		S.nray = k;
 	}
 	__syncthreads();
-	if (MODE == SOLVE_FIRST)      // a frame with more rows than this build's LDS holds is left untouched for the large build (second launch)
-	{
-		int nc_ = (a.contacts && ph.use_collision) ? a.ncontacts[b] : 0;
-		if (nc_ > HT_MAXCONTACT) nc_ = HT_MAXCONTACT;
-		const int n1_ = (a.ray_rows ? S.nray : (a.rows_pre ? a.n_pre[b] : 0)) + (a.rows_cloud ? a.n_cloud[b] : 0);
-		if ((3 * nj + 3 * nc_ + 3) * LROW > POOL_FLOATS || n1_ + 7 * (nb > 16 ? nb - 16 : 0) > S.NSUM - QUAD_CHAIN_SLACK)
-		{
-			if (lane == 0) a.retry[b] = 1;
-			return;
-		}
-	}
-
 	if (HT_DBG(a.dbg, 256)) return;
 	// ---- angular rows: [ApplyAngles 12] [arm cone 1] [joint ranges], generated by the lane that owns them ----
 	// slowfit's RelativeAngularConstraints (physmodel.h:423-432, filter handtrack.h:799): one row per ranged axis of every joint that passes
@@ -437,11 +432,16 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	}
 
 	if (HT_DBG(a.dbg, 512)) return;
-	// ---- two-body linear rows: joints (physmodel.h:328-334) then contacts (physics.h:463-489), each built by one lane into its LDS record ----
+	// ---- two-body linear rows: joints (physmodel.h:328-334) then contacts (physics.h:463-489), each row reduced by one lane to its part of the group record ----
 	int nc = (a.contacts && ph.use_collision) ? a.ncontacts[b] : 0;
 	if (nc > HT_MAXCONTACT) nc = HT_MAXCONTACT;
-	const int n2 = 3 * nj + 3 * nc;
-
+	const int n2 = 3 * nj + 3 * nc, ng2 = nj + nc;
+	const int rec_cap = a.scratch_stride - HT_SCRATCH_TAIL;                               // rows of the frame's scratch slot that hold chain records
+	float *scr = a.scratch + (size_t)b * a.scratch_stride * CREC;
+	// the three arrays a build may be too small for (see the top of the file): in LDS when the frame fits, else in the tail of its scratch slot
+	const bool pool_lds = ng2 + 1 <= S.NGRP;
+	float *const gpool = scr + (size_t)rec_cap * CREC, *const garec = gpool + MAXG * LGRP;
+	float *const pool = pool_lds ? S.pool : gpool;
 	for (int r = lane; r < n2; r += 64)
 	{
 		int rb0, rb1, meta = 0;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		{
 			const int ci = (r - 3 * nj) / 3, k = (r - 3 * nj) % 3;
 			const float *c = a.contacts + ((size_t)b * HT_MAXCONTACT + ci) * HT_CONTACT;
-			rb0 = (int)c[0]; rb1 = (int)c[1]; meta = ci << 24;
+			rb0 = (int)c[0]; rb1 = (int)c[1];
 			const v3 normal = L3(c + 2), p0w = L3(c + 5), p1w = L3(c + 8);
 			const float separation = c[11];
 			p0 = apply(inverse(body_xf(S, rb0)), p0w); p1 = apply(inverse(body_xf(S, rb1)), p1w);          // PhysContact physics.h:431-432
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				const float minsep = ph.driftmax * 0.25f;
 				const float bouncevel = fmax_std(0.0f, (-dot(normal, v) - ph.gravity_len * ph.falltime_to_ballistic) * ph.restitution);
 				n = -normal; targetdist = fmin_std((separation - minsep) * ph.biasfactorpositive, separation); tsnb = -bouncevel; fmn = 0; fmx = FLT_MAX;
-				meta |= LM_NORMAL;
+				meta = LM_NORMAL;
 			}
 			else
 			{
@@ -481,31 +481,35 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				n = k == 1 ? qydir(q) : qxdir(q);           // row order: normal, binormal (friction_master -1), tangent (-2)
 				targetdist = 0; tsnb = 0; fmn = 0;
 				fmx = 0;
-				meta |= LM_FRIC;
+				meta = LM_FRIC;
 			}
 		}
+		const int g = r / 3, kk = r % 3;
 		const v3 r0 = qrot(L4(S.q[rb0]), p0), r1 = qrot(L4(S.q[rb1]), p1);
-		const float impulsed = (S.lin4[rb0].w + dot(cross(mul(body_I(S, rb0), cross(r0, n)), r0), n)) + (S.lin4[rb1].w + dot(cross(mul(body_I(S, rb1), cross(r1, n)), r1), n));
+		const m3 I0 = body_I(S, rb0), I1 = body_I(S, rb1);
+		const float impulsed = (S.lin4[rb0].w + dot(cross(mul(I0, cross(r0, n)), r0), n)) + (S.lin4[rb1].w + dot(cross(mul(I1, cross(r1, n)), r1), n));      // physics.h:299-300
 		const float ts = targetdist / dt;
-		float *o = S.pool + r * LROW;
-		o[0] = ts; o[1] = fmin_std(ts, tsnb); o[2] = fmin_std(fmn, fmx) * dt; o[3] = fmax_std(fmn, fmx) * dt; o[4] = impulsed; o[5] = 0.0f;
-		if (meta & LM_FRIC) o[3] = fmax_std(S.ang4[rb0].w, S.ang4[rb1].w);       // mu of physics.h:292; the limits are formed from the master row's impulse every sweep
-		o[6] = __int_as_float(meta | rb0 | (rb1 << 8));
-		o[13] = n.x; o[14] = n.y; o[15] = n.z;
-		// the lever arms are the same for the three rows of a group: row 0 carries them; the slots they leave free in row 1 hold the refined reciprocals of the
-		// three effective masses (sweep-invariant: the division of every sweep becomes the five operations of div_ieee_r)
-		const int kk = r % 3;
-		if (kk == 0) { o[7] = r0.x; o[8] = r0.y; o[9] = r0.z; o[10] = r1.x; o[11] = r1.y; o[12] = r1.z; }
-		S.pool[(r - kk + 1) * LROW + 7 + kk] = 1.0f / impulsed;
-		S.lrb[r][0] = (unsigned char)rb0; S.lrb[r][1] = (unsigned char)rb1;
+		const v3 g0 = -cross(r0, n), g1 = cross(r1, n), b0 = mul(I0, g0), b1 = mul(I1, g1);          // rb0 receives -impulse and contributes -v0: its sign rides on g and b
+		float *o = pool + g * LGRP;
+		float *os = o + LG_S + 4 * kk;
+		os[0] = ts; os[1] = fmin_std(ts, tsnb); os[2] = fmin_std(fmn, fmx) * dt; os[3] = fmax_std(fmn, fmx) * dt;
+		if (meta & LM_FRIC) os[3] = fmax_std(S.ang4[rb0].w, S.ang4[rb1].w);       // mu of physics.h:292; the limits are formed from the normal row's impulse every sweep
+		o[LG_RINV + kk] = 1.0f / impulsed; o[LG_SUM + kk] = 0.0f;
+		if (kk == 0) o[LG_META] = __int_as_float(meta | rb0 | (rb1 << 8));
+		o[LG_N + 3 * kk] = n.x; o[LG_N + 3 * kk + 1] = n.y; o[LG_N + 3 * kk + 2] = n.z;
+		float *og = o + LG_GB + 12 * kk;
+		og[0] = g0.x; og[1] = b0.x; og[2] = g0.y; og[3] = b0.y; og[4] = g0.z; og[5] = b0.z;
+		og[6] = g1.x; og[7] = b1.x; og[8] = g1.y; og[9] = b1.y; og[10] = g1.z; og[11] = b1.z;
+		if (kk == 0) { S.lrb[g][0] = (unsigned char)rb0; S.lrb[g][1] = (unsigned char)rb1; }
 	}
-	if (lane < 3 * LROW) S.pool[n2 * LROW + lane] = (lane % LROW) == 4 || (lane >= LROW + 7 && lane <= LROW + 9) ? 1.0f : (lane % LROW) == 6 ? __int_as_float(IDLE_BODY | (IDLE_BODY << 8)) : 0.0f;      // idle group: zero limits, unit effective mass (and its reciprocal)
+	if (lane < LGRP) pool[ng2 * LGRP + lane] = (lane >= LG_RINV && lane < LG_RINV + 3) ? 1.0f : lane == LG_META ? __int_as_float(IDLE_BODY | (IDLE_BODY << 8)) : 0.0f;      // idle group: zero direction, zero limits
 	if (lane == 0)
 	{
 		S.lin4[IDLE_BODY] = make_float4(0, 0, 0, 0); S.ang4[IDLE_BODY] = make_float4(0, 0, 0, 0);
 		S.I4[IDLE_BODY][0] = S.I4[IDLE_BODY][1] = S.I4[IDLE_BODY][2] = make_float4(0, 0, 0, 0);
-		S.lorder[S.LIDLE] = (unsigned)(n2 / 3) | ((unsigned)IDLE_BODY << 16) | ((unsigned)IDLE_BODY << 24);
+		S.lorder[S.LIDLE] = (unsigned)ng2 | ((unsigned)IDLE_BODY << 16) | ((unsigned)IDLE_BODY << 24);
 	}
+	__threadfence_block();
 	__syncthreads();
 	// ---- level schedule, once per solve.  The unit is a group: the 3 consecutive rows of a joint or of a contact (same two bodies, same lever
 	//      arms), respectively a run of consecutive angular rows on the same body pair.  level(group) = 1 + max level of an earlier group sharing
@@ -525,12 +529,11 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	if (lane == 0)
 	{
 		int *last = S.lastlev;               // LDS, not a private array: dynamic indexing of a private array goes to scratch memory
-		const int ng2 = n2 / 3;
 		for (int k = 0; k < nb; k++) last[k] = 0;
 		int mx = 0;
 		for (int g = 0; g < ng2; g++)
 		{
-			const int b0 = S.lrb[3 * g][0], b1 = S.lrb[3 * g][1];
+			const int b0 = S.lrb[g][0], b1 = S.lrb[g][1];
 			int l = (last[b0] > last[b1] ? last[b0] : last[b1]) + 1;
 			last[b0] = l; last[b1] = l; S.llev[g] = (unsigned short)l; if (l > mx) mx = l;
 		}
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		}
 		S.lstart[step] = (unsigned short)acc; S.lstart[step + 1] = (unsigned short)acc;
 		S.nlev_lin = step - 1;
-		for (int g = 0; g < ng2; g++) { const int l = S.llev[g]; S.lorder[S.lfill[l]] = (unsigned)g | ((unsigned)S.lrb[3 * g][0] << 16) | ((unsigned)S.lrb[3 * g][1] << 24); S.lfill[l]++; }
+		for (int g = 0; g < ng2; g++) { const int l = S.llev[g]; S.lorder[S.lfill[l]] = (unsigned)g | ((unsigned)S.lrb[g][0] << 16) | ((unsigned)S.lrb[g][1] << 24); S.lfill[l]++; }
 		// angular groups
 		for (int k = 0; k < nb; k++) last[k] = 0;
 		mx = 0;
@@ -589,9 +592,8 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	const int npre = a.ray_rows ? S.nray : npre_g;
 	const int ncl = a.rows_cloud ? a.n_cloud[b] : 0;
 	const int n1 = npre + ncl;
-	float *scr = a.scratch + (size_t)b * a.scratch_stride * CREC;
 	const int npad_max = 7 * (nb > 16 ? nb - 16 : 0);      // rows that may be added to pad host chains (below)
-	const bool sums_lds = MODE == SOLVE_FIRST || n1 + npad_max + QUAD_CHAIN_SLACK <= S.NSUM;                                         // always true in a first build (checked above)
+	const bool sums_lds = n1 + npad_max + QUAD_CHAIN_SLACK <= S.NSUM;
 	float *const gsum = a.scratch + (size_t)a.batch * a.scratch_stride * CREC + (size_t)b * a.scratch_stride;      // this frame's sums in HBM, behind all frames' records
 	if (sums_lds) { for (int i = lane; i < n1 + npad_max + QUAD_CHAIN_SLACK; i += 64) S.csum[i] = 0.0f; }
 	else for (int i = lane; i < n1 + npad_max + QUAD_CHAIN_SLACK && i < a.scratch_stride; i += 64) gsum[i] = 0.0f;
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	if (lane < HT_MAXNB) { S.ccnt[lane] = HT_DBG(a.dbg, 1) ? 0 : mycnt; S.cstart[lane] = mystart; S.cextra[lane] = (signed char)(HT_DBG(a.dbg, 1) ? -1 : myextra); }
 	if (myextra >= 0)      // the padding records of this host
 		for (int i = mystart + mycnt; i < mystart + ((mycnt + 7) & ~7); i++)
-			if (i < a.scratch_stride - QUAD_CHAIN_SLACK) quad_write_noop(scr + (size_t)i * CREC);
+			if (i < rec_cap - QUAD_CHAIN_SLACK) quad_write_noop(scr + (size_t)i * CREC);
 	int myrun = 0;
 	for (int base = 0; base < n1; base += 64)          // pass B: placement in stable order + pre-compute
 	{
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			if (lane == bb) myrun += __popcll(m);
 			todo &= ~m;
 		}
-		if (r && dst < a.scratch_stride - QUAD_CHAIN_SLACK)
+		if (r && dst < rec_cap - QUAD_CHAIN_SLACK)
 		{
 			const v3 p1 = L3(r + 5), n = L3(r + 8);
 			const v3 r1 = qrot(L4(S.q[body]), p1);
@@ -675,7 +677,9 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	}
 	__threadfence_block();      // the records are read back by other lanes of this wave
 	__syncthreads();
-	// ---- the prologue scratch is dead now: angular rows move from their builder lanes into LDS records ----
+	// ---- the prologue scratch is dead now: angular rows move from their builder lanes into their records ----
+	const bool arec_lds = na <= S.NANG;
+	float *const arec = arec_lds ? S.arec : garec;
 #pragma unroll
 	for (int s = 0; s < ASLOTS; s++)
 	{
@@ -683,13 +687,17 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		if (r < na)
 		{
 			const arow &R = AR[s];
-			float *o = S.arec + r * AROW;
-			o[0] = R.axis.x; o[1] = R.axis.y; o[2] = R.axis.z; o[3] = 0.0f;
-			o[4] = R.targetspin; o[5] = (R.mintorque < 0) ? 0 : fmin_std(R.targetspin, 0.0f);            // RemoveBias physics.h:250
-			o[6] = R.mn; o[7] = R.mx; o[8] = R.s2t; o[9] = 0.0f;
+			float *o = arec + r * AROW;
+			const float ts_post = (R.mintorque < 0) ? 0 : fmin_std(R.targetspin, 0.0f);                      // RemoveBias physics.h:250
+			o[AR_S] = R.targetspin; o[AR_S + 1] = ts_post; o[AR_S + 2] = R.mn; o[AR_S + 3] = R.mx;
+			o[AR_GAIN] = R.s2t; o[AR_TORQUE] = 0.0f;
+			o[AR_AXIS] = R.axis.x; o[AR_AXIS + 1] = R.axis.y; o[AR_AXIS + 2] = R.axis.z; o[AR_AXIS + 3] = 0.0f;
+			const v3 ba0 = R.rb0 >= 0 ? -mul(body_I(S, R.rb0), R.axis) : V3(0, 0, 0), ba1 = R.rb1 >= 0 ? mul(body_I(S, R.rb1), R.axis) : V3(0, 0, 0);
+			o[AR_BA] = ba0.x; o[AR_BA + 1] = ba0.y; o[AR_BA + 2] = ba0.z; o[AR_BA + 3] = ba1.x; o[AR_BA + 4] = ba1.y; o[AR_BA + 5] = ba1.z;
 		}
 	}
-	if (lane < 2 * AROW) S.arec[na * AROW + lane] = 0.0f;      // idle record + read-ahead slack
+	if (lane < 4 * AROW) arec[na * AROW + lane] = 0.0f;      // idle record + read-ahead slack
+	__threadfence_block();
 	__syncthreads();
 
 	if (HT_DBG(a.dbg, 128)) return;
@@ -707,6 +715,152 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	float *const lin_w = reinterpret_cast<float *>(S.lin4), *const ang_w = reinterpret_cast<float *>(S.ang4), *const I_w = reinterpret_cast<float *>(S.I4);
 	const int pslot = lane >> 3;
 	const int ls_lin = S.lstart[lane], ls_ang = S.astart[lane];      // step boundaries of the first 63 steps, read back with v_readlane
+	// ---- the two phases of the two-body tail, written once and instantiated for records in LDS (the frame fits the build) and in HBM (it does not) ----
+	auto linear_phase = [&](const auto pool_, const bool post) {
+		struct lset { unsigned e; int meta; float n0, n1, n2, g0, g1, g2, b0, b1, b2, minv; float4 s0, s1, s2; float q0, q1, q2, i0, i1, i2; };
+		auto entry = [&](int L) -> unsigned {
+			if (L > nlev_lin) return S.lorder[S.LIDLE];
+			int lo, hi;
+			if (L < 63) { lo = __builtin_amdgcn_readlane(ls_lin, L); hi = __builtin_amdgcn_readlane(ls_lin, L + 1); }
+			else { lo = S.lstart[L]; hi = S.lstart[L + 1]; }
+			const int idx = lo + pslot;
+			return S.lorder[idx < hi ? idx : S.LIDLE];
+		};
+		auto fetch = [&](lset &r, unsigned e) {
+			r.e = e;
+			const float *R = pool_ + (int)(e & 0xFFFF) * LGRP;
+			const int body = side ? (int)(e >> 24) : (int)((e >> 16) & 255);
+			r.s0 = *reinterpret_cast<const float4 *>(R + LG_S); r.s1 = *reinterpret_cast<const float4 *>(R + LG_S + 4); r.s2 = *reinterpret_cast<const float4 *>(R + LG_S + 8);
+			const float4 qm = *reinterpret_cast<const float4 *>(R + LG_RINV), is = *reinterpret_cast<const float4 *>(R + LG_SUM);
+			r.q0 = qm.x; r.q1 = qm.y; r.q2 = qm.z; r.meta = __float_as_int(qm.w); r.i0 = is.x; r.i1 = is.y; r.i2 = is.z;
+			r.n0 = __int_as_float(__float_as_int(R[LG_N + cc]) ^ sidesign); r.n1 = __int_as_float(__float_as_int(R[LG_N + 3 + cc]) ^ sidesign); r.n2 = __int_as_float(__float_as_int(R[LG_N + 6 + cc]) ^ sidesign);      // rb0: -n, rb1: n
+			const float *G = R + LG_GB + (3 * side + cc) * 2;
+			const float2 gb0 = *reinterpret_cast<const float2 *>(G), gb1 = *reinterpret_cast<const float2 *>(G + 12), gb2 = *reinterpret_cast<const float2 *>(G + 24);
+			r.g0 = gb0.x; r.b0 = gb0.y; r.g1 = gb1.x; r.b1 = gb1.y; r.g2 = gb2.x; r.b2 = gb2.y;
+			r.minv = lin_w[4 * body + 3];
+		};
+		// the momenta of a step's bodies are read FIRST (behind the previous step's stores), the next step's record after them: LDS answers a wave in
+		// order, so a momenta read queued behind a dozen record reads would wait for all of them
+		auto momenta = [&](const lset &r, float &l, float &av) {
+			const int body = side ? (int)(r.e >> 24) : (int)((r.e >> 16) & 255);
+			l = lin_w[4 * body + c]; av = ang_w[4 * body + c];
+		};
+		auto step = [&](const lset &r, float l, float av) {
+			const int body = side ? (int)(r.e >> 24) : (int)((r.e >> 16) & 255);
+			auto row = [&](float n, float g, float bq, float ts, float fmn, float fmx, float rinv, float isum) -> float {
+				const float p = __fmaf_rn(bq, av, (n * r.minv) * l);                                      // this side's share of vn, component c
+				const float sp = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);
+				const float vn = sp + pair_swap(sp);                                                       // v1.n - v0.n
+				float impulse = (-ts - vn) * rinv;
+				impulse = clamp_med3(impulse, fmn - isum, fmx - isum);
+				l = __fmaf_rn(n, impulse, l);
+				av = __fmaf_rn(g, impulse, av);
+				return isum + impulse;
+			};
+			const float ns0 = row(r.n0, r.g0, r.b0, post ? r.s0.y : r.s0.x, r.s0.z, r.s0.w, r.q0, r.i0);
+			float f1n = r.s1.z, f1x = r.s1.w, f2n = r.s2.z, f2x = r.s2.w;
+			if (r.meta & LM_NORMAL)       // a contact: the friction rows are limited by the normal row's impulse sum (physics.h:292); their fmax slot holds mu
+			{
+				const float lim1 = (f1x * ns0) * inv_dt; f1x = lim1 * dt; f1n = (-lim1) * dt;
+				const float lim2 = (f2x * ns0) * inv_dt; f2x = lim2 * dt; f2n = (-lim2) * dt;
+			}
+			const float ns1 = row(r.n1, r.g1, r.b1, post ? r.s1.y : r.s1.x, f1n, f1x, r.q1, r.i1);
+			const float ns2 = row(r.n2, r.g2, r.b2, post ? r.s2.y : r.s2.x, f2n, f2x, r.q2, r.i2);
+			if (c < 3) { lin_w[4 * body + c] = l; ang_w[4 * body + c] = av; }
+			else if (side == 0)
+			{
+				float *R = pool_ + (int)(r.e & 0xFFFF) * LGRP + LG_SUM;
+				R[0] = ns0; R[1] = ns1; R[2] = ns2;
+			}
+		};
+		lset A, Bs;
+		fetch(A, entry(1));
+		unsigned e_b = entry(2), e_a;
+		float l, av;
+		for (int L = 1; L <= nlev_lin; L += 2)
+		{
+			momenta(A, l, av);
+			__builtin_amdgcn_sched_barrier(0);
+			fetch(Bs, e_b); e_a = entry(L + 2);
+			__builtin_amdgcn_sched_barrier(0);
+			step(A, l, av);
+			if (L + 1 > nlev_lin) break;
+			__builtin_amdgcn_wave_barrier();
+			momenta(Bs, l, av);
+			__builtin_amdgcn_sched_barrier(0);
+			fetch(A, e_a); e_b = entry(L + 3);
+			__builtin_amdgcn_sched_barrier(0);
+			step(Bs, l, av);
+			__builtin_amdgcn_wave_barrier();
+		}
+	};
+	auto angular_phase = [&](const auto arec_, const int tsoff) {
+		struct aset { unsigned e; float ax, ba, ts, mn, mx, gain, torque; };
+		auto entry = [&](int L) -> unsigned {
+			if (L > nlev_ang) return S.aorder[MAXA2];
+			int lo, hi;
+			if (L < 63) { lo = __builtin_amdgcn_readlane(ls_ang, L); hi = __builtin_amdgcn_readlane(ls_ang, L + 1); }
+			else { lo = S.astart[L]; hi = S.astart[L + 1]; }
+			const int idx = lo + pslot;
+			return S.aorder[idx < hi ? idx : MAXA2];
+		};
+		auto load = [&](aset &r, const float *R) {
+			const float4 sv = *reinterpret_cast<const float4 *>(R + AR_S); const float2 gt = *reinterpret_cast<const float2 *>(R + AR_GAIN);
+			r.ts = tsoff ? sv.y : sv.x; r.mn = sv.z; r.mx = sv.w; r.gain = gt.x; r.torque = gt.y;
+			r.ax = R[AR_AXIS + cc]; r.ba = R[AR_BA + 3 * side + cc];
+		};
+		auto fetch = [&](aset &r, unsigned e) { r.e = e; load(r, arec_ + (int)(e & 0xFF) * AROW); };
+		auto momentum = [&](const aset &r) -> float { const int body = side ? (int)(r.e >> 24) : (int)((r.e >> 16) & 255); return ang_w[4 * body + c]; };
+		// one row of a run: R = its record (the accumulated torque is written back)
+		auto apply = [&](const aset &r, float *R, float &av) {
+			const float axs = __int_as_float(__float_as_int(r.ax) ^ sidesign);                            // rb0: -axis, rb1: axis
+			const float gain = r.ts == -FLT_MAX ? 0.0f : r.gain;                                          // disabled row (physics.h:252): no torque
+			const float p = r.ba * av;
+			const float sp = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);                           // this side's signed spin about the axis
+			const float currentspin = sp + pair_swap(sp);                                                  // spin1 - spin0
+			float dtorque = (r.ts - currentspin) * gain;
+			dtorque = clamp_med3(dtorque, r.mn - r.torque, r.mx - r.torque);
+			av = __fmaf_rn(axs, dtorque, av);                                                              // rb0: a - axis*dtorque, rb1: a + axis*dtorque
+			R[AR_TORQUE] = r.torque + dtorque;                                                             // the same value from every lane of the pair
+		};
+		// a run: the records of its rows rotate through three register sets, each read two rows ahead of its use (a copy from a "next" set into the
+		// current one would wait for the read at the end of every row); reads run up to two records past the run
+		auto step = [&](const aset &r0, float av) {
+			const int body = side ? (int)(r0.e >> 24) : (int)((r0.e >> 16) & 255);
+			const int cnt = (int)((r0.e >> 8) & 255);
+			const bool bv = body != IDLE_BODY;       // a missing body: its ba is an exact zero, so it contributes exactly 0 and its (zero) momenta are never stored
+			float *R = arec_ + (int)(r0.e & 0xFF) * AROW;
+			aset ra = r0, rb, rc;
+			load(rb, R + AROW);
+			for (int k = 0;;)
+			{
+				load(rc, R + 2 * AROW); apply(ra, R, av); if (++k >= cnt) break;
+				load(ra, R + 3 * AROW); apply(rb, R + AROW, av); if (++k >= cnt) break;
+				load(rb, R + 4 * AROW); apply(rc, R + 2 * AROW, av); if (++k >= cnt) break;
+				R += 3 * AROW;
+			}
+			if (c < 3 && bv) ang_w[4 * body + c] = av;
+		};
+		aset A, Bs;
+		fetch(A, entry(1));
+		unsigned e_b = entry(2), e_a;
+		for (int L = 1; L <= nlev_ang; L += 2)
+		{
+			float av = momentum(A);
+			__builtin_amdgcn_sched_barrier(0);
+			fetch(Bs, e_b); e_a = entry(L + 2);
+			__builtin_amdgcn_sched_barrier(0);
+			step(A, av);
+			if (L + 1 > nlev_ang) break;
+			__builtin_amdgcn_wave_barrier();
+			av = momentum(Bs);
+			__builtin_amdgcn_sched_barrier(0);
+			fetch(A, e_a); e_b = entry(L + 3);
+			__builtin_amdgcn_sched_barrier(0);
+			step(Bs, av);
+			__builtin_amdgcn_wave_barrier();
+		}
+	};
 	for (int sweep = 0; sweep < total_sweeps; sweep++)
 	{
 		const bool post = sweep >= ph.iterations;
@@ -726,7 +880,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				const float minv = lin_w[4 * body + 3];
 				quad_body qb = { l, av, minv };
 				// RemoveBias (physics.h:288): lane 3 switches to the ts_post slot
-				if (MODE == SOLVE_FIRST || sums_lds) quad_chain_run(qb, scr + (size_t)start * CREC, S.csum + start, total, c, tsoff, kswitch, lin_w, ang_w, body, ex);
+				if (sums_lds) quad_chain_run(qb, scr + (size_t)start * CREC, S.csum + start, total, c, tsoff, kswitch, lin_w, ang_w, body, ex);
 				else quad_chain_run(qb, scr + (size_t)start * CREC, gsum + start, total, c, tsoff, kswitch, lin_w, ang_w, body, ex);
 				const int last = ex >= 0 ? ex : body;
 				if (c < 3) { lin_w[4 * last + c] = qb.l; ang_w[4 * last + c] = qb.av; }
@@ -735,146 +889,15 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		__builtin_amdgcn_wave_barrier();
 		if (stats) { const long long t = clock64(); cyc_chain += t - t_mark; t_mark = t; }
 		// (2) two-body linear rows (LimitLinear::Iter physics.h:289-307), one group per lane pair and step: the 3 rows of a joint (x, y, z) or
-		//     of a contact (normal, two friction rows) share bodies and lever arms and are applied back to back with the momenta in
-		//     registers.  Pairs without a group work on the idle group / idle body, so a step is branch-free.  Three-stage software
-		//     pipeline: the sort entry is fetched two steps ahead, the group's records and the (sweep-invariant) inverse inertia and mass
-		//     one step ahead; only the momenta are read after the previous step's stores.  Two register sets alternate.
-		if (!HT_DBG(a.dbg, 2) && nlev_lin > 0)
-		{
-			// Jacobian form (ht_quad.hpp): per row and side g = cross(r, n), b = Iinv * g and n * massinv are formed in the fetch stage, one step ahead of
-			// their use and off the dependent chain of the momenta; the sign of the side (rb0 receives -impulse and contributes -v0) rides on n.
-			struct lset { unsigned e; int meta; float n0, n1, n2, g0, g1, g2, b0, b1, b2, a0, a1, a2; float4 s0, s1, s2; float q0, q1, q2, i0, i1, i2; };
-			auto entry = [&](int L) -> unsigned {
-				if (L > nlev_lin) return S.lorder[S.LIDLE];
-				int lo, hi;
-				if (L < 63) { lo = __builtin_amdgcn_readlane(ls_lin, L); hi = __builtin_amdgcn_readlane(ls_lin, L + 1); }
-				else { lo = S.lstart[L]; hi = S.lstart[L + 1]; }
-				const int idx = lo + pslot;
-				return S.lorder[idx < hi ? idx : S.LIDLE];
-			};
-			auto fetch = [&](lset &r, unsigned e) {
-				r.e = e;
-				const float *R = S.pool + (int)(e & 0xFFFF) * (3 * LROW);
-				const int body = side ? (int)(e >> 24) : (int)((e >> 16) & 255);
-				r.meta = __float_as_int(R[6]);
-				const float rv1 = R[7 + 3 * side + c1], rv2 = R[7 + 3 * side + c2];      // lever arm components (c+1)%3 and (c+2)%3 of this side; the same for the 3 rows
-				r.q0 = R[LROW + 7]; r.q1 = R[LROW + 8]; r.q2 = R[LROW + 9];              // reciprocals of the three effective masses
-				r.s0 = *reinterpret_cast<const float4 *>(R); r.s1 = *reinterpret_cast<const float4 *>(R + LROW); r.s2 = *reinterpret_cast<const float4 *>(R + 2 * LROW);      // ts ts_post fmin fmax
-				r.i0 = R[5]; r.i1 = R[LROW + 5]; r.i2 = R[2 * LROW + 5];
-				const float Ix = I_w[12 * body + c], Iy = I_w[12 * body + 4 + c], Iz = I_w[12 * body + 8 + c], minv = lin_w[4 * body + 3];
-				auto prep = [&](float nraw, float &n, float &g, float &bq, float &am) {
-					n = __int_as_float(__float_as_int(nraw) ^ sidesign);                                        // rb0: -n, rb1: n
-					g = __fmaf_rn(rv1, dpp<QP_ROT2>(n), -(rv2 * dpp<QP_ROT1>(n)));                             // cross(r, n)[c] = r[c+1]*n[c+2] - r[c+2]*n[c+1]
-					bq = __fmaf_rn(Iz, dpp<QP_BC2>(g), __fmaf_rn(Iy, dpp<QP_BC1>(g), Ix * dpp<QP_BC0>(g)));  // (Iinv * g)[c]
-					am = n * minv;
-				};
-				prep(R[13 + c], r.n0, r.g0, r.b0, r.a0); prep(R[LROW + 13 + c], r.n1, r.g1, r.b1, r.a1); prep(R[2 * LROW + 13 + c], r.n2, r.g2, r.b2, r.a2);
-			};
-			auto step = [&](const lset &r) {
-				const int body = side ? (int)(r.e >> 24) : (int)((r.e >> 16) & 255);
-				float l = lin_w[4 * body + c], av = ang_w[4 * body + c];
-				auto row = [&](float n, float g, float bq, float am, float ts, float fmn, float fmx, float rinv, float isum) -> float {
-					const float p = __fmaf_rn(bq, av, am * l);                                                // this side's share of vn, component c
-					const float sp = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);
-					const float vn = sp + pair_swap(sp);                                                       // v1.n - v0.n
-					float impulse = (-ts - vn) * rinv;
-					impulse = clamp_med3(impulse, fmn - isum, fmx - isum);
-					l = __fmaf_rn(n, impulse, l);
-					av = __fmaf_rn(g, impulse, av);
-					return isum + impulse;
-				};
-				const float ns0 = row(r.n0, r.g0, r.b0, r.a0, post ? r.s0.y : r.s0.x, r.s0.z, r.s0.w, r.q0, r.i0);
-				float f1n = r.s1.z, f1x = r.s1.w, f2n = r.s2.z, f2x = r.s2.w;
-				if (r.meta & LM_NORMAL)       // a contact: the friction rows are limited by the normal row's impulse sum (physics.h:292); their fmax slot holds mu
-				{
-					const float lim1 = (f1x * ns0) * inv_dt; f1x = lim1 * dt; f1n = (-lim1) * dt;
-					const float lim2 = (f2x * ns0) * inv_dt; f2x = lim2 * dt; f2n = (-lim2) * dt;
-				}
-				const float ns1 = row(r.n1, r.g1, r.b1, r.a1, post ? r.s1.y : r.s1.x, f1n, f1x, r.q1, r.i1);
-				const float ns2 = row(r.n2, r.g2, r.b2, r.a2, post ? r.s2.y : r.s2.x, f2n, f2x, r.q2, r.i2);
-				if (c < 3) { lin_w[4 * body + c] = l; ang_w[4 * body + c] = av; }
-				else if (side == 0)
-				{
-					float *R = S.pool + (int)(r.e & 0xFFFF) * (3 * LROW);
-					R[5] = ns0; R[LROW + 5] = ns1; R[2 * LROW + 5] = ns2;
-				}
-			};
-			lset A, Bs;
-			fetch(A, entry(1));
-			unsigned e_b = entry(2), e_a;
-			for (int L = 1; L <= nlev_lin; L += 2)
-			{
-				fetch(Bs, e_b); e_a = entry(L + 2);
-				__builtin_amdgcn_wave_barrier();
-				step(A);
-				if (L + 1 > nlev_lin) break;
-				fetch(A, e_a); e_b = entry(L + 3);
-				__builtin_amdgcn_wave_barrier();
-				step(Bs);
-			}
-		}
+		//     of a contact (normal, two friction rows) share their bodies and are applied back to back with the momenta in registers.  Pairs
+		//     without a group work on the idle group / idle body, so a step is branch-free.  Three-stage software pipeline: the sort entry is
+		//     fetched two steps ahead, the group's record one step ahead; only the momenta are read after the previous step's stores.
+		if (!HT_DBG(a.dbg, 2) && nlev_lin > 0) { if (pool_lds) linear_phase(S.pool, post); else linear_phase(gpool, post); }
 		__builtin_amdgcn_wave_barrier();
 		if (stats) { const long long t = clock64(); cyc_lin += t - t_mark; t_mark = t; }
 		// (3) angular rows (LimitAngular::Iter physics.h:251-265): one run of consecutive rows on the same body pair per lane pair and step,
 		//     same pipeline; inside a run the next row's record is read while the current row is applied
-		if (!HT_DBG(a.dbg, 4) && nlev_ang > 0)
-		{
-			// Jacobian form: dot(Iinv*L, axis) = dot(Iinv*axis, L); ba = Iinv*axis is formed off the dependent chain, the side's sign rides on the axis
-			struct aset { unsigned e; float ax, ts, mn, mx, s2t, torque, Ix, Iy, Iz; };
-			auto entry = [&](int L) -> unsigned {
-				if (L > nlev_ang) return S.aorder[MAXA2];
-				int lo, hi;
-				if (L < 63) { lo = __builtin_amdgcn_readlane(ls_ang, L); hi = __builtin_amdgcn_readlane(ls_ang, L + 1); }
-				else { lo = S.astart[L]; hi = S.astart[L + 1]; }
-				const int idx = lo + pslot;
-				return S.aorder[idx < hi ? idx : MAXA2];
-			};
-			auto fetch = [&](aset &r, unsigned e) {
-				r.e = e;
-				const float *R = S.arec + (int)(e & 0xFF) * AROW;
-				const int body = side ? (int)(e >> 24) : (int)((e >> 16) & 255);
-				r.ax = R[c]; r.ts = R[4 + tsoff]; r.mn = R[6]; r.mx = R[7]; r.s2t = R[8]; r.torque = R[9];
-				r.Ix = I_w[12 * body + c]; r.Iy = I_w[12 * body + 4 + c]; r.Iz = I_w[12 * body + 8 + c];
-			};
-			auto step = [&](const aset &r) {
-				const int body = side ? (int)(r.e >> 24) : (int)((r.e >> 16) & 255);
-				const int cnt = (int)((r.e >> 8) & 255);
-				const bool bv = body != IDLE_BODY;       // a missing body: its inverse inertia and momenta are exact zeros, so it contributes exactly 0
-				float av = ang_w[4 * body + c];
-				float *R = S.arec + (int)(r.e & 0xFF) * AROW;
-				float ax = r.ax, ts = r.ts, mn = r.mn, mx = r.mx, s2t = r.s2t, torque = r.torque;
-				for (int k = 0; k < cnt; k++)
-				{
-					const float *N = R + AROW;
-					const float nax = N[c], nts = N[4 + tsoff], nmn = N[6], nmx = N[7], ns2t = N[8], ntq = N[9];      // next row of the run (or the record after it)
-					const float axs = __int_as_float(__float_as_int(ax) ^ sidesign);                              // rb0: -axis, rb1: axis
-					const float ba = __fmaf_rn(r.Iz, dpp<QP_BC2>(axs), __fmaf_rn(r.Iy, dpp<QP_BC1>(axs), r.Ix * dpp<QP_BC0>(axs)));      // (Iinv * axis)[c]
-					const float gain = ts == -FLT_MAX ? 0.0f : s2t;                                                // disabled row (physics.h:252): no torque
-					const float p = ba * av;
-					const float sp = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);                           // this side's signed spin about the axis
-					const float currentspin = sp + pair_swap(sp);                                                  // spin1 - spin0
-					float dtorque = (ts - currentspin) * gain;
-					dtorque = clamp_med3(dtorque, mn - torque, mx - torque);
-					av = __fmaf_rn(axs, dtorque, av);                                                              // rb0: a - axis*dtorque, rb1: a + axis*dtorque
-					R[9] = torque + dtorque;                                                                       // the same value from every lane of the pair
-					R += AROW; ax = nax; ts = nts; mn = nmn; mx = nmx; s2t = ns2t; torque = ntq;
-				}
-				if (c < 3 && bv) ang_w[4 * body + c] = av;
-			};
-			aset A, Bs;
-			fetch(A, entry(1));
-			unsigned e_b = entry(2), e_a;
-			for (int L = 1; L <= nlev_ang; L += 2)
-			{
-				fetch(Bs, e_b); e_a = entry(L + 2);
-				__builtin_amdgcn_wave_barrier();
-				step(A);
-				if (L + 1 > nlev_ang) break;
-				fetch(A, e_a); e_b = entry(L + 3);
-				__builtin_amdgcn_wave_barrier();
-				step(Bs);
-			}
-		}
+		if (!HT_DBG(a.dbg, 4) && nlev_ang > 0) { if (arec_lds) angular_phase(S.arec, tsoff); else angular_phase(garec, tsoff); }
 		__syncthreads();
 		if (stats) { const long long t = clock64(); cyc_ang += t - t_mark; t_mark = t; }
 		if (sweep + 1 == ph.iterations && lane < nb)
@@ -925,16 +948,16 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	}
 }
 
+static_assert(HT_SCRATCH_TAIL * HT_CREC >= MAXG * LGRP + (MAXA_LDS + 4) * AROW + HT_CREC, "the tail of a frame's scratch slot must hold its linear groups, its angular records and the tuning record");
 void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solve_args &a, int B, hipStream_t s)
 {
-	// first build by what the host knows of the launch: the model's joints and the most points a frame of this call can carry
+	// the build by what the host knows of the launch: the model's joints and the most points a frame of this call can carry.  A frame that exceeds
+	// the chosen build's arrays (contacts, points: device-side data) keeps the array in question in HBM (top of the file); nothing is relaunched.
 	const int pts = M.pts_bound > 0 ? M.pts_bound : M.pts_cap;
-	const bool small = 3 * (M.nj + 8) + 3 <= POOL_SMALL / LROW && pts <= 1024;      // room for a few contacts beside the joints, and a 64x64 tile's cloud
-	// Up to four frames per CU (1024 on the 256 CUs) a launch gains nothing from the small build's 20 KB: the build that holds every contact (39.4 KB,
-	// four blocks per CU) runs alone and the second launch, which costs a dependent launch gap even when no frame needs it, is not made.  Not when
-	// other kernels share the GPU with this launch: with their LDS in the way a CU holds three of these blocks and the launch takes two rounds.
-	if (B <= 1024 && small && !a.shared_gpu) { hipLaunchKernelGGL((k_solve<POOL_LARGE, SUMS_ONLY, SOLVE_ONLY>), dim3(B), dim3(64), 0, s, M, ph, a); return; }
-	if (small) hipLaunchKernelGGL((k_solve<POOL_SMALL, SUMS_SMALL, SOLVE_FIRST>), dim3(B), dim3(64), 0, s, M, ph, a);
-	else hipLaunchKernelGGL((k_solve<POOL_MID, SUMS_MID, SOLVE_FIRST>), dim3(B), dim3(64), 0, s, M, ph, a);
-	hipLaunchKernelGGL((k_solve<POOL_LARGE, SUMS_LARGE, SOLVE_SECOND>), dim3(B), dim3(64), 0, s, M, ph, a);
+	const bool tile = M.nj + 8 + 1 <= 40 && pts <= 1024;      // room for a few contacts beside the joints, and a 64x64 tile's cloud
+	// Up to four frames per CU (1024 on the 256 CUs) a launch gains nothing from the small build's footprint, so the build that keeps 49 contacts and
+	// 126 angular rows in LDS runs.  Not when other kernels share the GPU with this launch (the reset path): they need LDS on every CU too.
+	if (tile && B <= 1024 && !a.shared_gpu) hipLaunchKernelGGL((k_solve<66, 1024, 126>), dim3(B), dim3(64), 0, s, M, ph, a);
+	else if (tile) hipLaunchKernelGGL((k_solve<40, 624, 74>), dim3(B), dim3(64), 0, s, M, ph, a);
+	else hipLaunchKernelGGL((k_solve<71, 2272, 126>), dim3(B), dim3(64), 0, s, M, ph, a);
 }

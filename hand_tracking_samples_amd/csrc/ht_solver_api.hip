@@ -33,7 +33,7 @@ static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int 
 	a.rows_cloud = cloud ? ctx->d_rows : nullptr; a.n_cloud = ctx->d_nrows;
 	a.contacts = contacts ? ctx->d_contacts : nullptr; a.ncontacts = ctx->d_ncontacts;
 	a.analysis = ctx->d_analysis; a.cams = ctx->d_cams; a.active_flag = active;
-	a.state = ctx->d_state[which]; a.scratch = ctx->d_scratch; a.scratch_stride = scratch_stride(ctx); a.retry = ctx->d_retry; a.batch = ctx->B;
+	a.state = ctx->d_state[which]; a.scratch = ctx->d_scratch; a.scratch_stride = scratch_stride(ctx); a.batch = ctx->B;
 	a.apply_angles = apply_angles; a.drive_force = drive_force; a.ray_rows = ray_rows; a.arm_cone = arm_cone; a.zero_momenta = zero_momenta;
 	a.steps_keyangles = ctx->par.steps_keyangles; a.min_cray_prob = ctx->par.min_cray_prob;
 	a.dbg = ht_tuning_flags();
@@ -580,7 +580,7 @@ extern "C" int ht_slowfit(ht_ctx *ctx, int B, int hold, const float *refpose, in
 		a.rows_cloud = cloud ? ctx->d_rows : nullptr; a.n_cloud = ctx->d_nrows;
 		a.contacts = coll ? ctx->d_contacts : nullptr; a.ncontacts = ctx->d_ncontacts;
 		a.analysis = ctx->d_analysis; a.cams = ctx->d_cams;
-		a.state = ctx->d_state[0]; a.scratch = ctx->d_scratch; a.scratch_stride = scratch_stride(ctx); a.retry = ctx->d_retry; a.batch = ctx->B;
+		a.state = ctx->d_state[0]; a.scratch = ctx->d_scratch; a.scratch_stride = scratch_stride(ctx); a.batch = ctx->B;
 		a.sf_ncray = st < 5 ? ncray : 0; a.sf_crays = ctx->d_sf_crays; a.sf_select = select_rb;
 		for (int i = 0; i < 3; i++) { a.sf_spoint[i] = spoint ? spoint[i] : 0.0f; a.sf_rbpoint[i] = rbpoint ? rbpoint[i] : 0.0f; }
 		a.ray_rows = (a.sf_ncray > 0 || select_rb >= 0) ? 1 : 0;
