@@ -13,6 +13,7 @@ struct ht_ctx
 	bool cnn_only = false;          // created without a hand model: only the CNN entry points work
 	bool profile_phases = false;     // also time the minor phases (serialises the side streams; used for the phase table, not for the timed region)
 	int B = 0, device = 0;
+	int solver_build = 0;           // ht_debug_solver_build: 0 = the launcher's choice
 	std::string err;
 	hipStream_t stream = nullptr;
 	hipStream_t last_user_stream = nullptr;         // stream of the latest *_dev call (host-read helpers wait for it too)
@@ -51,6 +52,9 @@ struct ht_ctx
 	float *d_scratch = nullptr;                                  // solver row records [B][pts_cap + 5*nb + 32][20] (ht_quad.hpp)
 	float *d_poses_out = nullptr, *d_start = nullptr;
 	float *d_stage = nullptr;                                    // staging for host<->device state copies
+	// caller-built constraint rows (ht_fit_rows / ht_physics_update), allocated on first use and grown to the largest call
+	float *d_user_lin = nullptr; unsigned short *d_user_pos = nullptr; float *d_user_ang = nullptr; int *d_user_n = nullptr;      // [B][lin_cap][HT_ROW], [B][lin_cap], [B][ang_cap][HT_AROW], [4][B]
+	int user_lin_cap = 0, user_ang_cap = 0;
 };
 
 struct ht_prof_scope

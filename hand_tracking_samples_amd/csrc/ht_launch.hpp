@@ -7,6 +7,11 @@ struct solve_args
 	const float *rows_pre; const int *n_pre; int pre_stride;      // chamber rows [B][pre_stride][HT_ROW] (may be null)
 	const float *rows_cloud; const int *n_cloud;                    // cloud rows [B][pts_cap][HT_ROW] (may be null)
 	const float *contacts; const int *ncontacts;                    // [B][HT_MAXCONTACT][HT_CONTACT] (may be null)
+	// caller-built rows (ht_fit_rows / ht_physics_update = PhysModel::FitPointCloud's and PhysicsUpdate's row arguments; all may be null):
+	const float *ang_user; const int *n_ang_user; int ang_user_stride;        // angular rows [B][stride][HT_AROW]: first in the angular list
+	const float *lin_tail; const int *n_lin_tail; int lin_tail_stride;        // linear rows from the caller's first two-body row on [B][stride][HT_ROW]: ahead of the joint rows
+	const unsigned short *lin_tail_pos; const int *n_tail_groups;             // their placement, made by the host: group << 2 | slot, bit 15 = the row's group is a contact triple
+	int no_model_rows;                                                        // PhysicsUpdate: the caller's rows are all there is (no joint rows, no HandModelEnhancements)
 	const float *analysis; const float *cams;                       // for ApplyAngles / landmark-ray rows / arm cone
 	const int *active_flag;                                         // optional per-frame enable
 	float *state;                                                   // [B][nb][HT_STATE_STRIDE] of the model being solved
@@ -18,6 +23,7 @@ struct solve_args
 	const float *sf_crays; int sf_ncray; int sf_select; float sf_spoint[3], sf_rbpoint[3]; const float *sf_refpose; int sf_hold;
 	int *caps;                                                      // capacity counter: frames x launches whose angular rows exceeded the LDS records (may be null)
 	int shared_gpu;                                                 // other kernels run beside this launch (the reset path): keep the small LDS footprint
+	int force_build;                                                // 0: the launcher chooses k_solve's build; 1 small, 2 only, 3 mid, 4 tiny (every array in HBM): ht_debug_solver_build
 	int dbg;                                                        // timing experiments only (HT_DEBUG_SKIP): 1 skip chains, 2 skip two-body linear, 4 skip angular
 };
 

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	__syncthreads();
 
 	// ---- HandModelEnhancements (handtrack.h:417-420, 434-440); acos()/cos() are the C double overloads there ----
-	if (nb >= 17)
+	if (nb >= 17 && !a.no_model_rows)
 	{
 		if (lane < 4)
 		{
@@ -333,11 +333,12 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	// ---- angular rows: [ApplyAngles 12] [arm cone 1] [joint ranges], generated by the lane that owns them ----
 	// slowfit's RelativeAngularConstraints (physmodel.h:423-432, filter handtrack.h:799): one row per ranged axis of every joint that passes
 	const bool rel = a.sf_refpose && a.sf_hold;
-	if (lane < nj) S.acount[lane] = angular_range_count(L3(S.jr[lane]), L3(S.jr[lane] + 3));
+	const int na_user = a.ang_user ? (a.n_ang_user[b] < MAXA_LDS ? a.n_ang_user[b] : MAXA_LDS) : 0;      // the caller's rows lead the list (PhysModel::FitPointCloud appends its own, physmodel.h:351)
+	if (lane < nj) S.acount[lane] = a.no_model_rows ? 0 : angular_range_count(L3(S.jr[lane]), L3(S.jr[lane] + 3));
 	__syncthreads();
 	if (lane == 0)
 	{
-		int acc = (a.apply_angles ? 12 : 0) + (a.arm_cone ? 1 : 0);
+		int acc = na_user + (a.apply_angles ? 12 : 0) + (a.arm_cone ? 1 : 0);
 		for (int j = 0; j < nj; j++)
 		{
 			S.rprefix[j] = acc;
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		S.aprefix[nj] = acc;
 	}
 	__syncthreads();
-	const int na_fix = (a.apply_angles ? 12 : 0) + (a.arm_cone ? 1 : 0), na_pre = S.rprefix[nj];      // [ApplyAngles, arm cone | relative rows | joint ranges]
+	const int na_fix = na_user + (a.apply_angles ? 12 : 0) + (a.arm_cone ? 1 : 0), na_pre = S.rprefix[nj];      // [caller's rows | ApplyAngles, arm cone | relative rows | joint ranges]
 	int na = S.aprefix[nj];
 	if (na > MAXA_LDS && a.caps && lane == 0) atomicAdd(a.caps, 1);      // more angular rows than the kernel holds: the excess is dropped, and reported
 	if (na > MAXA2) na = MAXA2;
@@ -362,11 +363,16 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		if (r < na)
 		{
 			float row[8];
-			if (r < na_fix)
+			if (r < na_user)
+			{
+				const float *u = a.ang_user + ((size_t)b * a.ang_user_stride + r) * HT_AROW;
+				put_ang(row, (int)u[0], (int)u[1], V3(u[2], u[3], u[4]), u[5], u[6], u[7]);
+			}
+			else if (r < na_fix)
 			{
 				const float *cam = a.cams + (size_t)b * HT_CAM;
 				const v4 camq = V4(cam[8], cam[9], cam[10], cam[11]);
-				const int ra = a.apply_angles ? r : 12;          // index into the ApplyAngles list, 12 = the arm cone
+				const int ra = a.apply_angles ? r - na_user : 12;          // index into the ApplyAngles list, 12 = the arm cone
 				if (ra == 12) cone_angle(ph, S, -1, qrot(camq, V3(0, -1, 0)), 0, V3(0, 0, 1), 70.0f, row);             // handtrack.h:426, 684
 				else
 				{
@@ -435,20 +441,37 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	// ---- two-body linear rows: joints (physmodel.h:328-334) then contacts (physics.h:463-489), each row reduced by one lane to its part of the group record ----
 	int nc = (a.contacts && ph.use_collision) ? a.ncontacts[b] : 0;
 	if (nc > HT_MAXCONTACT) nc = HT_MAXCONTACT;
-	const int n2 = 3 * nj + 3 * nc, ng2 = nj + nc;
+	const int njg = a.no_model_rows ? 0 : nj;                                             // joint groups
+	const int nt = a.lin_tail ? a.n_lin_tail[b] : 0, ngt = a.lin_tail ? a.n_tail_groups[b] : 0;      // the caller's rows from its first two-body row on, and the groups the host packed them into
+	const int n2 = nt + 3 * njg + 3 * nc, ng2 = ngt + njg + nc;
 	const int rec_cap = a.scratch_stride - HT_SCRATCH_TAIL;                               // rows of the frame's scratch slot that hold chain records
 	float *scr = a.scratch + (size_t)b * a.scratch_stride * CREC;
 	// the three arrays a build may be too small for (see the top of the file): in LDS when the frame fits, else in the tail of its scratch slot
 	const bool pool_lds = ng2 + 1 <= S.NGRP;
 	float *const gpool = scr + (size_t)rec_cap * CREC, *const garec = gpool + MAXG * LGRP;
 	float *const pool = pool_lds ? S.pool : gpool;
+	if (ngt > 0)      // a caller's group may hold fewer than three rows: the slots no row fills change nothing (zero direction, zero limits)
+	{
+		for (int i = lane; i < ngt * LGRP; i += 64) pool[i] = ((i % LGRP) >= LG_RINV && (i % LGRP) < LG_RINV + 3) ? 1.0f : 0.0f;
+		__threadfence_block();
+		__syncthreads();
+	}
 	for (int r = lane; r < n2; r += 64)
 	{
-		int rb0, rb1, meta = 0;
+		int rb0, rb1, meta = 0, g, kk;
 		v3 p0, p1, n; float targetdist, tsnb, fmn, fmx;
-		if (r < 3 * nj)
+		if (r < nt)      // a caller's row (LimitLinear, physics.h:267-287) in the layout of ht_stage_cloud_rows
 		{
-			const int j = r / 3, ax = r % 3;
+			const float *u = a.lin_tail + ((size_t)b * a.lin_tail_stride + r) * HT_ROW;
+			const unsigned pos = a.lin_tail_pos[(size_t)b * a.lin_tail_stride + r];
+			g = (int)((pos & 0x7FFF) >> 2); kk = (int)(pos & 3);
+			rb0 = (int)u[0]; rb1 = (int)u[1]; p0 = L3(u + 2); p1 = L3(u + 5); n = L3(u + 8); targetdist = u[11]; tsnb = u[12]; fmn = u[13]; fmx = u[14];
+			if (pos & 0x8000) meta = kk == 0 ? LM_NORMAL : LM_FRIC;
+		}
+		else if (r < nt + 3 * njg)
+		{
+			const int j = (r - nt) / 3, ax = (r - nt) % 3;
+			g = ngt + j; kk = ax;
 			const float *jc = M.jointc + j * HT_JC;
 			rb0 = (int)jc[HT_JC_RB0]; rb1 = (int)jc[HT_JC_RB1];
 			p0 = L3(jc + HT_JC_P0) - L3(M.bodyc + rb0 * HT_BC + HT_BC_COM); p1 = L3(jc + HT_JC_P1) - L3(M.bodyc + rb1 * HT_BC + HT_BC_COM);
@@ -458,7 +481,8 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		}
 		else
 		{
-			const int ci = (r - 3 * nj) / 3, k = (r - 3 * nj) % 3;
+			const int ci = (r - nt - 3 * njg) / 3, k = (r - nt - 3 * njg) % 3;
+			g = ngt + njg + ci; kk = k;
 			const float *c = a.contacts + ((size_t)b * HT_MAXCONTACT + ci) * HT_CONTACT;
 			rb0 = (int)c[0]; rb1 = (int)c[1];
 			const v3 normal = L3(c + 2), p0w = L3(c + 5), p1w = L3(c + 8);
@@ -484,23 +508,24 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				meta = LM_FRIC;
 			}
 		}
-		const int g = r / 3, kk = r % 3;
-		const v3 r0 = qrot(L4(S.q[rb0]), p0), r1 = qrot(L4(S.q[rb1]), p1);
-		const m3 I0 = body_I(S, rb0), I1 = body_I(S, rb1);
-		const float impulsed = (S.lin4[rb0].w + dot(cross(mul(I0, cross(r0, n)), r0), n)) + (S.lin4[rb1].w + dot(cross(mul(I1, cross(r1, n)), r1), n));      // physics.h:299-300
+		// a side without a body (rb == NULL in the reference, physics.h:293-300): its lever arm is the anchor itself, it adds nothing to the effective mass and moves nothing
+		const m3 Z = { V3(0, 0, 0), V3(0, 0, 0), V3(0, 0, 0) };
+		const v3 r0 = rb0 >= 0 ? qrot(L4(S.q[rb0]), p0) : p0, r1 = rb1 >= 0 ? qrot(L4(S.q[rb1]), p1) : p1;
+		const m3 I0 = rb0 >= 0 ? body_I(S, rb0) : Z, I1 = rb1 >= 0 ? body_I(S, rb1) : Z;
+		const float impulsed = (rb0 >= 0 ? S.lin4[rb0].w + dot(cross(mul(I0, cross(r0, n)), r0), n) : 0.0f) + (rb1 >= 0 ? S.lin4[rb1].w + dot(cross(mul(I1, cross(r1, n)), r1), n) : 0.0f);      // physics.h:299-300
 		const float ts = targetdist / dt;
 		const v3 g0 = -cross(r0, n), g1 = cross(r1, n), b0 = mul(I0, g0), b1 = mul(I1, g1);          // rb0 receives -impulse and contributes -v0: its sign rides on g and b
 		float *o = pool + g * LGRP;
 		float *os = o + LG_S + 4 * kk;
 		os[0] = ts; os[1] = fmin_std(ts, tsnb); os[2] = fmin_std(fmn, fmx) * dt; os[3] = fmax_std(fmn, fmx) * dt;
-		if (meta & LM_FRIC) os[3] = fmax_std(S.ang4[rb0].w, S.ang4[rb1].w);       // mu of physics.h:292; the limits are formed from the normal row's impulse every sweep
+		if (meta & LM_FRIC) os[3] = fmax_std(rb0 >= 0 ? S.ang4[rb0].w : 0.0f, rb1 >= 0 ? S.ang4[rb1].w : 0.0f);       // mu of physics.h:292; the limits are formed from the normal row's impulse every sweep
 		o[LG_RINV + kk] = 1.0f / impulsed; o[LG_SUM + kk] = 0.0f;
-		if (kk == 0) o[LG_META] = __int_as_float(meta | rb0 | (rb1 << 8));
+		if (kk == 0) o[LG_META] = __int_as_float(meta | (rb0 & 255) | ((rb1 & 255) << 8));
 		o[LG_N + 3 * kk] = n.x; o[LG_N + 3 * kk + 1] = n.y; o[LG_N + 3 * kk + 2] = n.z;
 		float *og = o + LG_GB + 12 * kk;
 		og[0] = g0.x; og[1] = b0.x; og[2] = g0.y; og[3] = b0.y; og[4] = g0.z; og[5] = b0.z;
 		og[6] = g1.x; og[7] = b1.x; og[8] = g1.y; og[9] = b1.y; og[10] = g1.z; og[11] = b1.z;
-		if (kk == 0) { S.lrb[g][0] = (unsigned char)rb0; S.lrb[g][1] = (unsigned char)rb1; }
+		if (kk == 0) { S.lrb[g][0] = (unsigned char)(rb0 >= 0 ? rb0 : 255); S.lrb[g][1] = (unsigned char)(rb1 >= 0 ? rb1 : 255); }
 	}
 	if (lane < LGRP) pool[ng2 * LGRP + lane] = (lane >= LG_RINV && lane < LG_RINV + 3) ? 1.0f : lane == LG_META ? __int_as_float(IDLE_BODY | (IDLE_BODY << 8)) : 0.0f;      // idle group: zero direction, zero limits
 	if (lane == 0)
@@ -534,8 +559,11 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		for (int g = 0; g < ng2; g++)
 		{
 			const int b0 = S.lrb[g][0], b1 = S.lrb[g][1];
-			int l = (last[b0] > last[b1] ? last[b0] : last[b1]) + 1;
-			last[b0] = l; last[b1] = l; S.llev[g] = (unsigned short)l; if (l > mx) mx = l;
+			const int l0 = b0 != 255 ? last[b0] : 0, l1 = b1 != 255 ? last[b1] : 0;
+			int l = (l0 > l1 ? l0 : l1) + 1;
+			if (b0 != 255) last[b0] = l;
+			if (b1 != 255) last[b1] = l;
+			S.llev[g] = (unsigned short)l; if (l > mx) mx = l;
 		}
 		for (int l = 0; l <= mx + 1; l++) S.lfill[l] = 0;
 		for (int g = 0; g < ng2; g++) S.lfill[S.llev[g]]++;
@@ -549,7 +577,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		}
 		S.lstart[step] = (unsigned short)acc; S.lstart[step + 1] = (unsigned short)acc;
 		S.nlev_lin = step - 1;
-		for (int g = 0; g < ng2; g++) { const int l = S.llev[g]; S.lorder[S.lfill[l]] = (unsigned)g | ((unsigned)S.lrb[g][0] << 16) | ((unsigned)S.lrb[g][1] << 24); S.lfill[l]++; }
+		for (int g = 0; g < ng2; g++) { const int l = S.llev[g]; S.lorder[S.lfill[l]] = (unsigned)g | ((unsigned)(S.lrb[g][0] == 255 ? IDLE_BODY : S.lrb[g][0]) << 16) | ((unsigned)(S.lrb[g][1] == 255 ? IDLE_BODY : S.lrb[g][1]) << 24); S.lfill[l]++; }
 		// angular groups
 		for (int k = 0; k < nb; k++) last[k] = 0;
 		mx = 0;
@@ -766,7 +794,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			}
 			const float ns1 = row(r.n1, r.g1, r.b1, post ? r.s1.y : r.s1.x, f1n, f1x, r.q1, r.i1);
 			const float ns2 = row(r.n2, r.g2, r.b2, post ? r.s2.y : r.s2.x, f2n, f2x, r.q2, r.i2);
-			if (c < 3) { lin_w[4 * body + c] = l; ang_w[4 * body + c] = av; }
+			if (c < 3) { if (body != IDLE_BODY) { lin_w[4 * body + c] = l; ang_w[4 * body + c] = av; } }      // a side without a body moves nothing (and the idle body stays at rest)
 			else if (side == 0)
 			{
 				float *R = pool_ + (int)(r.e & 0xFFFF) * LGRP + LG_SUM;
@@ -957,7 +985,10 @@ void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solv
 	const bool tile = M.nj + 8 + 1 <= 40 && pts <= 1024;      // room for a few contacts beside the joints, and a 64x64 tile's cloud
 	// Up to four frames per CU (1024 on the 256 CUs) a launch gains nothing from the small build's footprint, so the build that keeps 49 contacts and
 	// 126 angular rows in LDS runs.  Not when other kernels share the GPU with this launch (the reset path): they need LDS on every CU too.
-	if (tile && B <= 1024 && !a.shared_gpu) hipLaunchKernelGGL((k_solve<66, 1024, 126>), dim3(B), dim3(64), 0, s, M, ph, a);
-	else if (tile) hipLaunchKernelGGL((k_solve<40, 624, 74>), dim3(B), dim3(64), 0, s, M, ph, a);
-	else hipLaunchKernelGGL((k_solve<71, 2272, 126>), dim3(B), dim3(64), 0, s, M, ph, a);
+	int build = a.force_build;
+	if (!build) build = tile ? (B <= 1024 && !a.shared_gpu ? 2 : 1) : 3;
+	if (build == 2) hipLaunchKernelGGL((k_solve<66, 1024, 126>), dim3(B), dim3(64), 0, s, M, ph, a);
+	else if (build == 1) hipLaunchKernelGGL((k_solve<40, 624, 74>), dim3(B), dim3(64), 0, s, M, ph, a);
+	else if (build == 3) hipLaunchKernelGGL((k_solve<71, 2272, 126>), dim3(B), dim3(64), 0, s, M, ph, a);
+	else hipLaunchKernelGGL((k_solve<2, 40, 4>), dim3(B), dim3(64), 0, s, M, ph, a);      // tests only: nothing fits, every frame keeps its groups, sums and angular records in HBM
 }

@@ -38,6 +38,7 @@ static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int 
 	a.steps_keyangles = ctx->par.steps_keyangles; a.min_cray_prob = ctx->par.min_cray_prob;
 	a.dbg = ht_tuning_flags();
 	a.shared_gpu = shared_gpu ? 1 : 0;
+	a.force_build = ctx->solver_build;
 	ht_launch_solve(ctx->model, ctx->phys, a, B, s);
 }
 // Fork/join helpers: the row-producing kernels of one fit step only read the pose, so they run side by side on two extra streams
@@ -493,6 +494,15 @@ extern "C" int ht_debug_solve_stats(ht_ctx *ctx, int B, float *out, int reset)
 	}
 	return HT_OK;
 }
+// Tests only: pins the build of k_solve (0 = the launcher's choice by batch and frame size; 1 small, 2 only, 3 mid, 4 tiny = a build whose LDS arrays hold
+// nothing, so that every frame takes the HBM placement of its two-body groups, impulse sums and angular records).  The builds differ in where a
+// frame's arrays live, never in arithmetic: results must agree bit for bit (tests/test_gpu_solver.py).
+extern "C" int ht_debug_solver_build(ht_ctx *ctx, int which)
+{
+	if (!ctx || which < 0 || which > 4) return HT_ERR_ARG;
+	ctx->solver_build = which;
+	return HT_OK;
+}
 // Same for k_contacts (last contact slot of each frame): launches, cycles in GJK / polytope runs, polytope runs, polytope cycles in
 // face scoring / support scans / mesh surgery, total cycles, candidate pairs, pairs that jiggle, contacts, polytope iterations.
 extern "C" int ht_debug_contact_stats(ht_ctx *ctx, int B, float *out, int reset)
@@ -550,6 +560,183 @@ extern "C" int ht_segment_vr(ht_ctx *ctx, const uint16_t *depth, const float *ca
 	return rc;
 }
 
+// ------------------------------------------------------------------------------------------------- caller-built constraint rows
+// PhysModel::FitPointCloud(points, linears, angulars, microforce) (physmodel.h:345-356) and the free PhysicsUpdate(bodies, Linears, Angulars, wgeom)
+// (physics.h:543-587) take rows the CALLER built.  Row layouts are those of the stage calls: a linear row is 16 floats (rb0 rb1 position0[3]
+// position1[3] normal[3] targetdist targetspeednobias forcelimit.x forcelimit.y friction_master), an angular row 8 (rb0 rb1 axis[3] targetspin
+// mintorque maxtorque); a body is its index in PhysModel::rigidbodies, -1 = NULL.
+static int user_rows_reserve(ht_ctx *ctx, int lin_cap, int ang_cap)
+{
+	if (lin_cap > ctx->user_lin_cap)
+	{
+		HIPCHK(ctx, ht_sync_all(ctx));
+		for (void *o : { (void *)ctx->d_user_lin, (void *)ctx->d_user_pos }) if (o) { for (auto &q : ctx->allocs) if (q == o) { q = ctx->allocs.back(); ctx->allocs.pop_back(); break; } (void)hipFree(o); }
+		void *a = nullptr, *b = nullptr;
+		HIPCHK(ctx, hipMalloc(&a, (size_t)ctx->B * lin_cap * HT_ROW * sizeof(float))); ctx->allocs.push_back(a); ctx->d_user_lin = (float *)a;
+		HIPCHK(ctx, hipMalloc(&b, (size_t)ctx->B * lin_cap * sizeof(unsigned short))); ctx->allocs.push_back(b); ctx->d_user_pos = (unsigned short *)b;
+		ctx->user_lin_cap = lin_cap;
+	}
+	if (ang_cap > ctx->user_ang_cap)
+	{
+		HIPCHK(ctx, ht_sync_all(ctx));
+		if (ctx->d_user_ang) { for (auto &q : ctx->allocs) if (q == (void *)ctx->d_user_ang) { q = ctx->allocs.back(); ctx->allocs.pop_back(); break; } (void)hipFree(ctx->d_user_ang); }
+		void *a = nullptr;
+		HIPCHK(ctx, hipMalloc(&a, (size_t)ctx->B * ang_cap * HT_AROW * sizeof(float))); ctx->allocs.push_back(a); ctx->d_user_ang = (float *)a;
+		ctx->user_ang_cap = ang_cap;
+	}
+	if (!ctx->d_user_n) { void *a = nullptr; HIPCHK(ctx, hipMalloc(&a, (size_t)4 * ctx->B * sizeof(int))); ctx->allocs.push_back(a); ctx->d_user_n = (int *)a; }
+	return HT_OK;
+}
+static int upload_angulars(ht_ctx *ctx, int B, const float *angulars, int acap, const int *nangulars, std::vector<int> &na)
+{
+	na.assign(B, 0);
+	for (int b = 0; b < B; b++)
+	{
+		na[b] = (angulars && nangulars) ? nangulars[b] : 0;
+		if (na[b] < 0 || na[b] > acap || na[b] > 126) { ctx->err = "caller-built angular rows: a count is negative, exceeds the stride or exceeds the 126 angular rows a solve keeps (ht_capacity_events)"; return HT_ERR_ARG; }
+		for (int i = 0; i < na[b]; i++) { const float *r = angulars + ((size_t)b * acap + i) * HT_AROW; if ((int)r[0] >= ctx->model.nb || (int)r[1] >= ctx->model.nb) { ctx->err = "caller-built angular rows: body index out of range"; return HT_ERR_ARG; } }
+	}
+	if (acap > 0 && angulars) HIPCHK(ctx, hipMemcpy2D(ctx->d_user_ang, (size_t)ctx->user_ang_cap * HT_AROW * sizeof(float), angulars, (size_t)acap * HT_AROW * sizeof(float), (size_t)acap * HT_AROW * sizeof(float), B, hipMemcpyHostToDevice));
+	HIPCHK(ctx, hipMemcpy(ctx->d_user_n + 3 * (size_t)ctx->B, na.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice));
+	return HT_OK;
+}
+// void PhysModel::FitPointCloud(const std::vector<float3> &points, std::vector<LimitLinear> linears, std::vector<LimitAngular> angulars, float microforce)
+// on model `which` of slots [0,B): the caller's linear rows, then CloudConstraints(points) with the +-microforce limits (x physics_weak_force on
+// bodies 0-2), then the joints' nailed rows; the caller's angular rows, then the joints' range rows; PhysicsUpdate with collision; SanityCheck.  As
+// at every call site of the reference (handtrack.h:672-685, 773-779, 803-819) the joint ranges are first brought up to date from the pose
+// (HandModelEnhancements, :417-420, 434-440).  The caller's linear rows must be anchored in the world (rb0 == NULL), as the rows of every such call
+// site are (landmark rays, boundary planes, the annotator's nail): they join the per-body row chains ahead of the cloud rows.
+extern "C" int ht_fit_rows(ht_ctx *ctx, int which, int B, const float *points, int pcap, const int *npoints, const float *linears, int lcap, const int *nlinears,
+                           const float *angulars, int acap, const int *nangulars, float microforce)
+{
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
+	if (which < 0 || which > 1 || pcap < 0 || lcap < 0 || acap < 0) return HT_ERR_ARG;
+	const int nb = ctx->model.nb;
+	std::vector<int> nl(B, 0), na;
+	for (int b = 0; b < B; b++)
+	{
+		nl[b] = (linears && nlinears) ? nlinears[b] : 0;
+		if (nl[b] < 0 || nl[b] > lcap) { ctx->err = "ht_fit_rows: a linear row count is negative or exceeds the stride"; return HT_ERR_ARG; }
+		for (int i = 0; i < nl[b]; i++)
+		{
+			const float *r = linears + ((size_t)b * lcap + i) * HT_ROW;
+			if ((int)r[0] >= 0 || (int)r[1] < 0 || (int)r[1] >= nb || r[15] != 0.0f) { ctx->err = "ht_fit_rows: the caller's linear rows must act on one body from the world (rb0 == NULL, no friction master); use ht_physics_update for general rows"; return HT_ERR_ARG; }
+		}
+	}
+	{ const int r = user_rows_reserve(ctx, lcap > 1 ? lcap : 1, acap > 1 ? acap : 1); if (r) return r; }
+	{ const int r = upload_angulars(ctx, B, angulars, acap, nangulars, na); if (r) return r; }
+	// the points (ht_set_points grows the point capacity when it has to)
+	{
+		static const float none[3] = { 0, 0, 0 }; std::vector<int> zero(B, 0);
+		const int r = (points && npoints && pcap > 0) ? ht_set_points(ctx, B, points, pcap, npoints) : ht_set_points(ctx, 1, none, 1, zero.data());
+		if (r) return r;
+		if (!(points && npoints && pcap > 0)) HIPCHK(ctx, hipMemset(ctx->d_npts, 0, (size_t)B * sizeof(int)));
+	}
+	if (lcap > 0 && linears) HIPCHK(ctx, hipMemcpy2D(ctx->d_user_lin, (size_t)ctx->user_lin_cap * HT_ROW * sizeof(float), linears, (size_t)lcap * HT_ROW * sizeof(float), (size_t)lcap * HT_ROW * sizeof(float), B, hipMemcpyHostToDevice));
+	HIPCHK(ctx, hipMemcpy(ctx->d_user_n, nl.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice));
+	hipStream_t s = ctx->stream;
+	const bool coll = ctx->phys.use_collision != 0;
+	ht_params par = ctx->par; par.microforce = microforce;
+	ht_launch_cloud_rows(ctx->model, ctx->d_state[which], ctx->d_pts, ctx->d_npts, ctx->d_cams, nullptr, 1, 0, 1, par, ctx->d_rows, ctx->d_nrows, B, s);
+	if (coll) ht_launch_contacts(ctx->model, ctx->d_state[which], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s);
+	solve_args a;
+	memset(&a, 0, sizeof a);
+	a.sf_select = -1;
+	a.caps = reinterpret_cast<int *>(ctx->d_epa_ws) + 2;
+	a.rows_pre = ctx->d_user_lin; a.n_pre = ctx->d_user_n; a.pre_stride = ctx->user_lin_cap;
+	a.rows_cloud = ctx->d_rows; a.n_cloud = ctx->d_nrows;
+	a.contacts = coll ? ctx->d_contacts : nullptr; a.ncontacts = ctx->d_ncontacts;
+	a.ang_user = ctx->d_user_ang; a.n_ang_user = ctx->d_user_n + 3 * (size_t)ctx->B; a.ang_user_stride = ctx->user_ang_cap;
+	a.analysis = ctx->d_analysis; a.cams = ctx->d_cams;
+	a.state = ctx->d_state[which]; a.scratch = ctx->d_scratch; a.scratch_stride = scratch_stride(ctx); a.batch = ctx->B;
+	a.force_build = ctx->solver_build;
+	ctx->model.pts_bound = 0;
+	ht_launch_solve(ctx->model, ctx->phys, a, B, s);
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
+// void PhysicsUpdate(const std::vector<RigidBody*> &rigidbodies, std::vector<LimitLinear> &Linears, std::vector<LimitAngular> &Angulars, wgeom = {})
+// (physics.h:543-587) on model `which` of slots [0,B): the caller's rows are all there is (plus the collision rows when physics_use_collision is set).
+// Rows keep the caller's order: the leading rows that act on one body from the world (rb0 == NULL) run as per-body chains, the rest in groups of up
+// to three consecutive rows on the same body pair; a friction row (friction_master -1 / -2) must follow its master directly, as ConstrainContacts
+// builds them (physics.h:463-489).  At most 32 such groups per frame.
+extern "C" int ht_physics_update(ht_ctx *ctx, int which, int B, const float *linears, int lcap, const int *nlinears, const float *angulars, int acap, const int *nangulars)
+{
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
+	if (which < 0 || which > 1 || lcap < 0 || acap < 0) return HT_ERR_ARG;
+	const int nb = ctx->model.nb;
+	std::vector<int> npre(B, 0), ntail(B, 0), ngrp(B, 0), na;
+	std::vector<unsigned short> pos((size_t)B * (lcap > 1 ? lcap : 1), 0);
+	int most_pre = 0;
+	for (int b = 0; b < B; b++)
+	{
+		const int n = (linears && nlinears) ? nlinears[b] : 0;
+		if (n < 0 || n > lcap) { ctx->err = "ht_physics_update: a linear row count is negative or exceeds the stride"; return HT_ERR_ARG; }
+		const float *rows = linears + (size_t)b * lcap * HT_ROW;
+		for (int i = 0; i < n; i++) if ((int)rows[i * HT_ROW] >= nb || (int)rows[i * HT_ROW + 1] >= nb || ((int)rows[i * HT_ROW] < 0 && (int)rows[i * HT_ROW + 1] < 0)) { ctx->err = "ht_physics_update: body index out of range"; return HT_ERR_ARG; }
+		int p = 0;
+		while (p < n && (int)rows[p * HT_ROW] < 0 && rows[p * HT_ROW + 15] == 0.0f && !(p + 1 < n && rows[(p + 1) * HT_ROW + 15] != 0.0f)) p++;
+		npre[b] = p; ntail[b] = n - p; if (p > most_pre) most_pre = p;
+		// groups of the tail: up to three consecutive rows on one body pair; a row that friction rows follow opens a group
+		int g = -1, slot = 3, g0 = 0; int pa = -2, pb = -2;
+		for (int i = p; i < n; i++)
+		{
+			const float *r = rows + (size_t)i * HT_ROW;
+			const int fm = (int)r[15], ra = (int)r[0], rb = (int)r[1];
+			const bool next_is_friction = i + 1 < n && rows[(size_t)(i + 1) * HT_ROW + 15] != 0.0f && fm == 0;
+			if (fm != 0)
+			{
+				if (g < 0 || -fm != slot || slot > 2 || ra != pa || rb != pb) { ctx->err = "ht_physics_update: a friction row must directly follow its master row (friction_master -1, then -2) on the same bodies"; return HT_ERR_ARG; }
+				for (int k = g0; k <= i; k++) pos[(size_t)b * lcap + (k - p)] |= 0x8000;
+			}
+			else if (g < 0 || slot > 2 || ra != pa || rb != pb || next_is_friction || (pos[(size_t)b * lcap + (g0 - p)] & 0x8000)) { g++; slot = 0; g0 = i; pa = ra; pb = rb; }
+			pos[(size_t)b * lcap + (i - p)] |= (unsigned short)((g << 2) | slot);
+			slot++;
+		}
+		ngrp[b] = g + 1;
+		if (ngrp[b] > HT_MAXNJ) { ctx->err = "ht_physics_update: more than 32 groups of two-body rows in a frame"; return HT_ERR_ARG; }
+	}
+	if (most_pre > ctx->model.pts_cap) { const int r = ht_reserve_points_locked(ctx, most_pre); if (r) return r; }
+	{ const int r = user_rows_reserve(ctx, lcap > 1 ? lcap : 1, acap > 1 ? acap : 1); if (r) return r; }
+	{ const int r = upload_angulars(ctx, B, angulars, acap, nangulars, na); if (r) return r; }
+	const size_t pc = (size_t)ctx->model.pts_cap;
+	for (int b = 0; b < B; b++)
+	{
+		const float *rows = linears ? linears + (size_t)b * lcap * HT_ROW : nullptr;
+		if (npre[b]) HIPCHK(ctx, hipMemcpy(ctx->d_rows + (size_t)b * pc * HT_ROW, rows, (size_t)npre[b] * HT_ROW * sizeof(float), hipMemcpyHostToDevice));
+		if (ntail[b])
+		{
+			HIPCHK(ctx, hipMemcpy(ctx->d_user_lin + (size_t)b * ctx->user_lin_cap * HT_ROW, rows + (size_t)npre[b] * HT_ROW, (size_t)ntail[b] * HT_ROW * sizeof(float), hipMemcpyHostToDevice));
+			HIPCHK(ctx, hipMemcpy(ctx->d_user_pos + (size_t)b * ctx->user_lin_cap, pos.data() + (size_t)b * lcap, (size_t)ntail[b] * sizeof(unsigned short), hipMemcpyHostToDevice));
+		}
+	}
+	HIPCHK(ctx, hipMemcpy(ctx->d_nrows, npre.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice));
+	HIPCHK(ctx, hipMemcpy(ctx->d_user_n + (size_t)ctx->B, ntail.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice));
+	HIPCHK(ctx, hipMemcpy(ctx->d_user_n + 2 * (size_t)ctx->B, ngrp.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice));
+	hipStream_t s = ctx->stream;
+	const bool coll = ctx->phys.use_collision != 0;
+	if (coll) ht_launch_contacts(ctx->model, ctx->d_state[which], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s);
+	solve_args a;
+	memset(&a, 0, sizeof a);
+	a.sf_select = -1;
+	a.caps = reinterpret_cast<int *>(ctx->d_epa_ws) + 2;
+	a.rows_cloud = ctx->d_rows; a.n_cloud = ctx->d_nrows;
+	a.contacts = coll ? ctx->d_contacts : nullptr; a.ncontacts = ctx->d_ncontacts;
+	a.ang_user = ctx->d_user_ang; a.n_ang_user = ctx->d_user_n + 3 * (size_t)ctx->B; a.ang_user_stride = ctx->user_ang_cap;
+	a.lin_tail = ctx->d_user_lin; a.n_lin_tail = ctx->d_user_n + (size_t)ctx->B; a.lin_tail_stride = ctx->user_lin_cap;
+	a.lin_tail_pos = ctx->d_user_pos; a.n_tail_groups = ctx->d_user_n + 2 * (size_t)ctx->B;
+	a.no_model_rows = 1;
+	a.analysis = ctx->d_analysis; a.cams = ctx->d_cams;
+	a.state = ctx->d_state[which]; a.scratch = ctx->d_scratch; a.scratch_stride = scratch_stride(ctx); a.batch = ctx->B;
+	a.force_build = ctx->solver_build;
+	ctx->model.pts_bound = 0;
+	ht_launch_solve(ctx->model, ctx->phys, a, B, s);
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
+
 // ------------------------------------------------------------------------------------------------- slowfit (annotation fit loop)
 // HandTracker::slowfit (handtrack.h:786-821) on the handmodel of slots [0,B) against the points ht_stage_prepare left on the device.
 extern "C" int ht_slowfit(ht_ctx *ctx, int B, int hold, const float *refpose, int steps, int select_rb, const float *spoint, const float *rbpoint, const float *crays, int ncray)
@@ -586,6 +773,7 @@ extern "C" int ht_slowfit(ht_ctx *ctx, int B, int hold, const float *refpose, in
 		a.ray_rows = (a.sf_ncray > 0 || select_rb >= 0) ? 1 : 0;
 		a.sf_refpose = rel ? ctx->d_sf_ref : nullptr; a.sf_hold = rel ? hold : 0;
 		a.steps_keyangles = ctx->par.steps_keyangles; a.min_cray_prob = ctx->par.min_cray_prob;
+		a.force_build = ctx->solver_build;
 		ht_launch_solve(ctx->model, ctx->phys, a, B, s);
 	}
 	HIPCHK(ctx, hipStreamSynchronize(s));

@@ -20,9 +20,9 @@ SYMBOLS = (
     "ht_create", "ht_destroy", "ht_model_bake", "ht_last_error", "ht_get_params", "ht_set_params", "ht_model_info", "ht_config_read", "ht_scale",
     "ht_cnn_load_weights", "ht_cnn_eval", "ht_cnn_eval_dev", "ht_cnn_load_weights_sized", "ht_cnn_eval_sized", "ht_cnn_eval_sized_dev", "ht_cnn_train", "ht_cnn_get_weights", "ht_expected_cnn", "ht_expected_cnn_full",
     "ht_model_open", "ht_model_close", "ht_model_error", "ht_model_counts", "ht_model_body", "ht_model_body_mesh", "ht_model_hitcheck",
-    "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_update_frames_sync", "ht_update_frames_dev", "ht_update_cnn_model_sync", "ht_get_cnn_results", "ht_frames_overflow", "ht_reserve_points", "ht_point_capacity", "ht_capacity_events", "ht_segment_vr", "ht_segment_vr_dev", "ht_slowfit", "ht_set_points",
+    "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_update_frames_sync", "ht_update_frames_dev", "ht_update_cnn_model_sync", "ht_get_cnn_results", "ht_frames_overflow", "ht_reserve_points", "ht_point_capacity", "ht_capacity_events", "ht_segment_vr", "ht_segment_vr_dev", "ht_slowfit", "ht_set_points", "ht_fit_rows", "ht_physics_update",
     "ht_stage_prepare", "ht_stage_decode", "ht_stage_fit_error", "ht_stage_cloud_rows", "ht_stage_contacts", "ht_stage_fit",
-    "ht_stage_multistep", "ht_stage_scratch_unibody", "ht_profile_enable", "ht_profile_read", "ht_debug_solve_stats", "ht_debug_contact_stats",
+    "ht_stage_multistep", "ht_stage_scratch_unibody", "ht_profile_enable", "ht_profile_read", "ht_debug_solve_stats", "ht_debug_contact_stats", "ht_debug_solver_build",
 )
 
 
@@ -99,10 +99,13 @@ def load(build_if_missing=True):
     L.ht_expected_cnn.argtypes = [fp, fp, fp]
     L.ht_set_points.argtypes = [vp, C.c_int, fp, C.c_int, ip]
     L.ht_slowfit.argtypes = [vp, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp, fp, fp, C.c_int]
+    L.ht_fit_rows.argtypes = [vp, C.c_int, C.c_int, fp, C.c_int, ip, fp, C.c_int, ip, fp, C.c_int, ip, C.c_float]
+    L.ht_physics_update.argtypes = [vp, C.c_int, C.c_int, fp, C.c_int, ip, fp, C.c_int, ip]
     L.ht_segment_vr.argtypes = [vp, C.POINTER(C.c_uint16), fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_uint16), fp]
     L.ht_segment_vr_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp, vp, vp]
     L.ht_profile_read.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_int, fp, ip, ip]
     L.ht_debug_solve_stats.argtypes = [vp, C.c_int, fp, C.c_int]
+    L.ht_debug_solver_build.argtypes = [vp, C.c_int]
     L.ht_debug_contact_stats.argtypes = [vp, C.c_int, fp, C.c_int]
     for name in SYMBOLS:
         if name not in ("ht_last_error", "ht_model_error"):
@@ -277,6 +280,29 @@ class Context:
         self._chk(self.L.ht_capacity_events(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    @staticmethod
+    def _ragged(rows, width):
+        """list of (n_i, width) arrays -> ([B, cap, width] float32, counts int32, cap)"""
+        cap = max(1, max((len(r) for r in rows), default=1))
+        buf = np.zeros((len(rows), cap, width), np.float32)
+        for i, r in enumerate(rows):
+            if len(r):
+                buf[i, :len(r)] = np.asarray(r, np.float32).reshape(-1, width)
+        return buf, np.array([len(r) for r in rows], np.int32), cap
+
+    def fit_rows(self, which, clouds, linears, angulars, microforce=1.0):
+        """PhysModel::FitPointCloud(points, linears, angulars, microforce) (physmodel.h:345-356) on model `which` of slots [0, len(clouds)):
+        per slot a point cloud (n,3), the caller's linear rows (n,16) and angular rows (n,8)."""
+        B = len(clouds)
+        pb, pn, pc = self._ragged(clouds, 3); lb, ln, lc = self._ragged(linears, 16); ab, an, ac = self._ragged(angulars, 8)
+        self._chk(self.L.ht_fit_rows(self.h, int(which), B, _f(pb), pc, _i(pn), _f(lb), lc, _i(ln), _f(ab), ac, _i(an), float(microforce)))
+
+    def physics_update(self, which, linears, angulars):
+        """PhysicsUpdate(rigidbodies, Linears, Angulars) (physics.h:543-587) on model `which`: per slot the caller's rows (n,16) / (n,8) are all there is."""
+        B = len(linears)
+        lb, ln, lc = self._ragged(linears, 16); ab, an, ac = self._ragged(angulars, 8)
+        self._chk(self.L.ht_physics_update(self.h, int(which), B, _f(lb), lc, _i(ln), _f(ab), ac, _i(an)))
+
     def set_points(self, clouds):
         """Caller-supplied clouds for the stage calls (ht_set_points): one (n_i, 3) array per slot."""
         cap = max(1, max(len(c) for c in clouds))
@@ -359,6 +385,10 @@ class Context:
         out = np.zeros((B, 12), np.float32)
         self._chk(self.L.ht_debug_solve_stats(self.h, int(B), _f(out), int(reset)))
         return out
+
+    def debug_solver_build(self, which):
+        """Test aid: pin k_solve's build (0 auto, 1 small, 2 only, 3 mid, 4 tiny = every row array in HBM).  Placement only, results identical."""
+        self._chk(self.L.ht_debug_solver_build(self.h, int(which)))
 
     def debug_contact_stats(self, B, reset=True):
         """Per-frame k_contacts statistics [B,12] (only filled when HT_DEBUG_SKIP=2048 is set in the environment)."""

@@ -10,12 +10,14 @@
 // scale, load_config, handmodel / othermodel facades, cnn, cnn_input, cnn_output, cnn_output_analysis}, CNN {Eval, Train, loadb, saveb},
 // PoseInitializerCNN, PhysModel / LoadHandModel (a host-side model that is posed, drawn and ray-cast, never tracked), HandSegmentVR, camsub,
 // GatherHandExpectedCNN, Pose / Image<T> / DCamera / Mesh.  Define HT_MI355X_GLOBAL_NAMES before including to have these names in the global
-// namespace, as the reference's headers put them.  Not provided: the free PhysicsUpdate() and caller-built LimitLinear / LimitAngular vectors
-// (PhysModel::FitPointCloud takes the points and the force scale only): the constraint rows live on the device.  Documented deviation: update()
+// namespace, as the reference's headers put them.  Caller-built constraint rows cross the boundary too: LimitLinear / LimitAngular (physics.h:239-308) hold
+// RigidBody pointers into a tracked model's `rigidbodies`, handmodel.FitPointCloud(points, linears, angulars, microforce) (physmodel.h:345) and the free
+// PhysicsUpdate(Addresses(model.rigidbodies), linears, angulars) (physics.h:543) keep the reference's signatures.  Documented deviation: update()
 // runs the CNN job synchronously every frame (the reference polls a background std::async job for 1 ms, which makes its output
 // timing dependent, handtrack.h:755-768); this is HandTracker::update_cnn_model followed by the main-thread passes.
 // Errors are reported the way the reference's apps expect them: by throwing std::runtime_error (synthetic-tracker.cpp:255-264).
 #pragma once
+#include <cfloat>
 #include <cstdint>
 #include <fstream>
 #include <memory>
@@ -53,6 +55,56 @@ template <class T> struct Image                                                 
 	const int2 dim() const { return cam.dim(); }
 	T &pixel(int2 p) { return raster[(size_t)p.y * dim().x + p.x]; }
 };
+
+// ---- constraint rows a caller builds (physics.h:239-308).  A RigidBody here is a handle to body `index` of one of a tracker's two models: rows hold
+//      RigidBody pointers exactly like the reference's (NULL = the world) and only live as long as the HandTracker they point into.
+struct RigidBody { ht_ctx *ctx = nullptr; int which = 0, index = 0; };
+struct LimitAngular
+{
+	RigidBody *rb0 = nullptr, *rb1 = nullptr; float3 axis{ 0, 0, 1 }; float torque = 0, targetspin = 0, mintorque = -FLT_MAX, maxtorque = FLT_MAX;
+	LimitAngular() {}
+	LimitAngular(RigidBody *rb0, RigidBody *rb1, const float3 &axis, float targetspin = 0, float mintorque = -FLT_MAX, float maxtorque = FLT_MAX)
+		: rb0(rb0), rb1(rb1), axis(axis), targetspin(targetspin), mintorque(mintorque), maxtorque(maxtorque) {}                                 // physics.h:248-249
+};
+struct LimitLinear
+{
+	RigidBody *rb0 = nullptr, *rb1 = nullptr; float3 position0{ 0, 0, 0 }, position1{ 0, 0, 0 }, normal{ 0, 0, 1 };
+	float targetdist = 0, targetspeednobias = 0; float2 forcelimit{ -FLT_MAX, FLT_MAX }; int friction_master = 0; float targetspeed = 0, impulsesum = 0;
+	LimitLinear() {}
+	LimitLinear(RigidBody *rb0, RigidBody *rb1, const float3 &position0, const float3 &position1, const float3 &normal = float3{ 0, 0, 1 }, float targetdist = 0.0f,
+	            float targetspeednobias = 0.0f, const float2 forcelimit = { -FLT_MAX, FLT_MAX })
+		: rb0(rb0), rb1(rb1), position0(position0), position1(position1), normal(normal), targetdist(targetdist), targetspeednobias(targetspeednobias),
+		  forcelimit{ forcelimit.x < forcelimit.y ? forcelimit.x : forcelimit.y, forcelimit.x < forcelimit.y ? forcelimit.y : forcelimit.x } {}   // physics.h:283-287
+};
+template <class T> std::vector<T *> Addresses(std::vector<T> &v) { std::vector<T *> a; for (auto &e : v) a.push_back(&e); return a; }             // misc.h
+namespace detail
+{
+	inline void pack_rows(const std::vector<LimitLinear> &L, const std::vector<LimitAngular> &A, std::vector<float> &l, std::vector<float> &a)
+	{
+		for (auto &c : L)
+		{
+			const float r[16] = { c.rb0 ? (float)c.rb0->index : -1.0f, c.rb1 ? (float)c.rb1->index : -1.0f, c.position0.x, c.position0.y, c.position0.z, c.position1.x, c.position1.y, c.position1.z,
+			                      c.normal.x, c.normal.y, c.normal.z, c.targetdist, c.targetspeednobias, c.forcelimit.x, c.forcelimit.y, (float)c.friction_master };
+			l.insert(l.end(), r, r + 16);
+		}
+		for (auto &c : A)
+		{
+			const float r[8] = { c.rb0 ? (float)c.rb0->index : -1.0f, c.rb1 ? (float)c.rb1->index : -1.0f, c.axis.x, c.axis.y, c.axis.z, c.targetspin, c.mintorque, c.maxtorque };
+			a.insert(a.end(), r, r + 8);
+		}
+	}
+}
+// void PhysicsUpdate(const std::vector<RigidBody*> &rigidbodies, std::vector<LimitLinear> &Linears, std::vector<LimitAngular> &Angulars, wgeom) (physics.h:543-587):
+// one solver step of the model the bodies belong to under the caller's rows (plus the collision rows); `rigidbodies` must be all bodies of one tracked model
+inline void PhysicsUpdate(const std::vector<RigidBody *> &rigidbodies, std::vector<LimitLinear> &Linears, std::vector<LimitAngular> &Angulars, const std::vector<std::vector<float3> *> &wgeom = {})
+{
+	if (rigidbodies.empty() || !rigidbodies[0]) throw std::runtime_error("PhysicsUpdate: no bodies");
+	if (!wgeom.empty()) throw std::runtime_error("PhysicsUpdate: world geometry is not supported (every call site of the reference passes none)");
+	for (size_t i = 0; i < rigidbodies.size(); i++) if (!rigidbodies[i] || rigidbodies[i]->ctx != rigidbodies[0]->ctx || rigidbodies[i]->which != rigidbodies[0]->which || rigidbodies[i]->index != (int)i) throw std::runtime_error("PhysicsUpdate: pass Addresses(model.rigidbodies) of one tracked model");
+	std::vector<float> l, a; detail::pack_rows(Linears, Angulars, l, a);
+	const int nl = (int)Linears.size(), na = (int)Angulars.size();
+	if (ht_physics_update(rigidbodies[0]->ctx, rigidbodies[0]->which, 1, l.data(), nl, &nl, a.data(), na, &na) != HT_OK) throw std::runtime_error(std::string("PhysicsUpdate: ") + ht_last_error(rigidbodies[0]->ctx));
+}
 
 inline DCamera camsub(const DCamera &c, int s)                                               // misc_image.h:60
 {
@@ -136,20 +188,16 @@ struct HandTracker                                                              
 			return *this;
 		}
 		std::vector<Mesh> &GetMeshes(int = 0) { const std::vector<Pose> p = GetPose(); for (size_t b = 0; b < meshes_.size() && b < p.size(); b++) meshes_[b].pose = p[b]; return meshes_; }
-		// one fit step of this model against a point cloud with the tracker's current tunables (physmodel.h:345-356 as HandTracker::update calls it,
-		// handtrack.h:779, without the boundary planes); caller-built constraint vectors are not part of this surface
-		void FitPointCloud(const std::vector<float3> &points, float microforce = 1.0f)
+		// void FitPointCloud(const std::vector<float3> &points, std::vector<LimitLinear> linears = {}, std::vector<LimitAngular> angulars = {}, float microforce = 1.0f)
+		// (physmodel.h:345-356): one fit step of this model against a point cloud under the caller's rows, the cloud rows, the joint rows and the collision rows
+		std::vector<RigidBody> rigidbodies;                                                                          // handles for the rows (physmodel.h:253)
+		void FitPointCloud(const std::vector<float3> &points, std::vector<LimitLinear> linears = {}, std::vector<LimitAngular> angulars = {}, float microforce = 1.0f)
 		{
-			if (which_ != 0) throw std::runtime_error("FitPointCloud: only the handmodel takes main-thread passes");
-			const int n = (int)points.size(); const float3 none{ 0, 0, 0 };
-			check(ctx_, ht_set_points(ctx_, 1, n ? &points[0].x : &none.x, n > 0 ? n : 1, &n));
-			ht_params p, keep; check(ctx_, ht_get_params(ctx_, &p)); keep = p;
-			p.microforce = microforce; p.boundary_planes = 0;
-			check(ctx_, ht_set_params(ctx_, &p));
-			const int rc = ht_stage_fit(ctx_, 1);
-			ht_set_params(ctx_, &keep);
-			check(ctx_, rc);
+			std::vector<float> l, a; detail::pack_rows(linears, angulars, l, a);
+			const int n = (int)points.size(), nl = (int)linears.size(), na = (int)angulars.size();
+			check(ctx_, ht_fit_rows(ctx_, which_, 1, n ? &points[0].x : nullptr, n, &n, l.data(), nl, &nl, a.data(), na, &na, microforce));
 		}
+		void FitPointCloud(const std::vector<float3> &points, float microforce) { FitPointCloud(points, {}, {}, microforce); }      // round-1 shorthand
 	private:
 		friend struct HandTracker;
 		ht_ctx *ctx_ = nullptr; int which_ = 0, nb_ = 0; std::vector<float3> com_; std::vector<Mesh> meshes_;
@@ -199,6 +247,7 @@ struct HandTracker                                                              
 			if (m) ht_model_close(m);
 			othermodel.com_ = handmodel.com_; othermodel.meshes_ = handmodel.meshes_;
 			handmodel.ctx_ = othermodel.ctx_ = ctx_; handmodel.nb_ = othermodel.nb_ = nb_; handmodel.which_ = 0; othermodel.which_ = 1;
+			for (int b = 0; b < nb_; b++) { handmodel.rigidbodies.push_back(RigidBody{ ctx_, 0, b }); othermodel.rigidbodies.push_back(RigidBody{ ctx_, 1, b }); }
 		}
 		if (!cnnb_path.empty()) { std::ifstream is(cnnb_path, std::ios_base::in | std::ios_base::binary); if (is.is_open()) cnn.loadb(is); }
 		cnn_output.assign(HT_CNN_OUT, 0.01f);
@@ -421,5 +470,6 @@ inline PhysModel LoadHandModel(const char *jsonfile = "../assets/model_hand.json
 #ifdef HT_MI355X_GLOBAL_NAMES      // the reference's headers declare these names at global scope
 using ht_mi355x::float2; using ht_mi355x::float3; using ht_mi355x::float4; using ht_mi355x::int2; using ht_mi355x::int3;
 using ht_mi355x::Pose; using ht_mi355x::DCamera; using ht_mi355x::Image; using ht_mi355x::Mesh; using ht_mi355x::CNN; using ht_mi355x::HandTracker; using ht_mi355x::PhysModel;
+using ht_mi355x::RigidBody; using ht_mi355x::LimitLinear; using ht_mi355x::LimitAngular; using ht_mi355x::PhysicsUpdate; using ht_mi355x::Addresses;
 using ht_mi355x::HandSegmentVR; using ht_mi355x::camsub; using ht_mi355x::GatherHandExpectedCNN; using ht_mi355x::PoseInitializerCNN; using ht_mi355x::LoadHandModel;
 #endif

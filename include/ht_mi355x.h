@@ -242,6 +242,27 @@ int ht_stage_fit(ht_ctx *ctx, int B);
 int ht_stage_multistep(ht_ctx *ctx, const float *analysis, int B);
 int ht_stage_scratch_unibody(ht_ctx *ctx, const float *analysis, int B, int n_unibody);
 
+/* ---- caller-built constraint rows ----------------------------------------------------------------------------------------
+ * Row layouts: a linear row (LimitLinear, physics.h:267-308) is 16 floats: rb0 rb1 position0[3] position1[3] normal[3] targetdist targetspeednobias
+ * forcelimit.x forcelimit.y friction_master (the layout ht_stage_cloud_rows returns); an angular row (LimitAngular, physics.h:239-265) is 8 floats:
+ * rb0 rb1 axis[3] targetspin mintorque maxtorque.  A body is its index in PhysModel::rigidbodies, -1 = NULL.  Arrays are [B][cap][16] / [B][cap][8]
+ * with per-frame counts; `which` selects the model (0 handmodel, 1 othermodel) of slots [0,B).  Host buffers, synchronous.
+ * ht_fit_rows        replaces  void PhysModel::FitPointCloud(const std::vector<float3> &points, std::vector<LimitLinear> linears = {},
+ *                    std::vector<LimitAngular> angulars = {}, float microforce = 1.0f) (physmodel.h:345-356): the caller's linear rows, then
+ *                    CloudConstraints(points) limited to +-microforce (x physics_weak_force on bodies 0-2), then the joints' nailed rows; the caller's
+ *                    angular rows, then the joints' range rows; PhysicsUpdate with collision rows; SanityCheck.  points [B][pcap][3].  As at every call
+ *                    site of the reference the joint ranges are first brought up to date from the pose (HandModelEnhancements, handtrack.h:417-420,
+ *                    434-440).  The caller's linear rows must act on one body from the world (rb0 == -1), as those of every such call site do
+ *                    (landmark rays handtrack.h:672-673, boundary planes :774-778, the annotator's nail :803-810); HT_ERR_ARG otherwise.
+ * ht_physics_update  replaces  void PhysicsUpdate(const std::vector<RigidBody*> &rigidbodies, std::vector<LimitLinear> &Linears,
+ *                    std::vector<LimitAngular> &Angulars, const std::vector<std::vector<float3>*> &wgeom) (physics.h:543-587) with an empty wgeom: the
+ *                    caller's rows are all there is (plus the collision rows when physics_use_collision is set), any mix of one- and two-body rows in
+ *                    the caller's order; a friction row (friction_master -1 / -2) must directly follow its master row, as ConstrainContacts emits
+ *                    them (physics.h:463-489).  Capacity: 32 groups of up to three consecutive two-body rows on one body pair, 126 angular rows. */
+int ht_fit_rows(ht_ctx *ctx, int which, int B, const float *points, int pcap, const int *npoints, const float *linears, int lcap, const int *nlinears,
+                const float *angulars, int acap, const int *nangulars, float microforce);
+int ht_physics_update(ht_ctx *ctx, int which, int B, const float *linears, int lcap, const int *nlinears, const float *angulars, int acap, const int *nangulars);
+
 /* ---- timing hooks for bench.py: HIP-event time (ms) per named phase accumulated since the last reset.
  * on = 1: only the dominant kernel ("solve") is bracketed (negligible perturbation, used inside the timed region);
  * on = 2: every phase is bracketed and the side streams are serialised (phase table). ----- */
@@ -251,6 +272,9 @@ int ht_profile_read(ht_ctx *ctx, int reset, int max_entries, char *names, int na
  * statistics (launches, cycles in chains / two-body linear / angular rows / all sweeps, steps, longest chain, row counts), 12 floats per frame. */
 int ht_debug_solve_stats(ht_ctx *ctx, int B, float *out, int reset);
 int ht_debug_contact_stats(ht_ctx *ctx, int B, float *out, int reset);      /* same for k_contacts */
+/* Test aid: pins which build of the solver kernel runs (0 = chosen per launch; 1-3 the LDS sizes for tile batches / small batches / large frames and models;
+ * 4 = a build whose LDS arrays hold nothing, so every frame places its row records in HBM).  Placement only: results are identical bit for bit. */
+int ht_debug_solver_build(ht_ctx *ctx, int which);
 
 #ifdef __cplusplus
 }

@@ -112,6 +112,7 @@ def test_cxx_compat_example_runs_on_the_device(tmp_path):
     print(r.stdout, r.stderr)
     assert r.returncode == 0
     assert "bones=17" in r.stdout and "full frame bones=17 cnn_input 64x64" in r.stdout and "train mse=" in r.stdout and "saved=37833600" in r.stdout
+    assert "rows: fit + update ok" in r.stdout      # PhysModel::FitPointCloud(points, linears, angulars, microforce) and PhysicsUpdate() with caller-built rows
 
 
 def test_config_read_follows_the_reference_decoder(tmp_path):

