@@ -5,6 +5,7 @@
 //           synthetic-tracker.cpp:39-55) and load_dataset (dataset.h:144-146)
 //   .rs     raw little-endian u16 depth frames back to back, width x height from the .json header (dataset.h:62-93,118-163)
 //   .ir     raw u8 frames, same size (optional)
+//   .rgb    raw 3 x u8 colour frames of the header's rgb_dim, .feye raw u8 fish-eye frames of its feyedim (both optional, dataset.h:77-78,102-105,134-139)
 //   .json   DatasetInfo header: dcamera {dims, focal, principal, depth_scale}, mplane, fname, camtype, hasir, rgb_dim, feyedim,
 //           segment_scale (dataset.h:21-37, misc_image.h:57)
 //   .cnnb   raw fp32 weights in layer order (cnn.h:97-98,288,454,590-592): see CNN::loadb in ht_handtrack.hpp
@@ -177,16 +178,29 @@ inline void WriteDatasetInfo(const std::string &jsonfile, const DatasetInfo &d)
 // A dataset is four files with one base name (dataset.h:62-163): base.json = the DatasetInfo header above; base.rs = the depth frames, raw
 // little-endian u16, width x height of the header's camera, back to back (with the deprecated hasir flag each depth frame is followed by its
 // u8 infra-red frame in the same file); base.ir = the infra-red frames, raw u8, same size, optional; base.pose = the poses as text.
-struct Frame { Image<unsigned short> depth; std::vector<Pose> pose; Image<unsigned char> ir; std::string fname; int fid = 0; };      // dataset.h:40-51 (depth, pose, ir)
+struct byte3 { unsigned char x = 0, y = 0, z = 0; };                                                                                      // linalg.h byte3
+struct Frame      // dataset.h:40-51
+{
+	Image<unsigned short> depth; std::vector<Pose> pose, startpose; float4 mplane{ 0, 0, 0, 3.402823466e+38f }; Image<unsigned char> ir; std::string fname; int fid = 0;
+	Image<byte3> rgb; Image<unsigned char> fisheye;
+};
+inline Frame MakeFrame(Image<unsigned short> depth, std::vector<Pose> pose) { Frame f; f.depth = std::move(depth); f.pose = f.startpose = std::move(pose); return f; }      // dataset.h:53-60
+inline Frame MakeFrame(Image<unsigned short> depth, std::vector<Pose> pose, float4 mplane) { Frame f = MakeFrame(std::move(depth), std::move(pose)); f.mplane = mplane; return f; }
+inline Frame MakeFrame(Image<unsigned short> depth, std::vector<Pose> pose, Image<unsigned char> ir, Image<byte3> rgb, Image<unsigned char> fisheye)
+{
+	Frame f = MakeFrame(std::move(depth), std::move(pose)); f.ir = std::move(ir); f.rgb = std::move(rgb); f.fisheye = std::move(fisheye); return f;
+}
 
 // Same call as dataset.h:118: every complete frame of the dataset, in file order.
 inline std::vector<Frame> load_dataset(const std::string &bname, unsigned int pose_array_size)
 {
-	bool have_rs = false, have_ir = false, have_pose = false;
+	bool have_rs = false, have_ir = false, have_pose = false, have_rgb = false, have_feye = false;
 	const std::string rs = detail::file_bytes(bname + ".rs", &have_rs);
 	if (!have_rs) throw std::runtime_error("dataset has no depth file: " + bname + ".rs");
 	const DatasetInfo info = ReadDatasetInfo(bname + ".json");
 	const std::string irb = detail::file_bytes(bname + ".ir", &have_ir), posetext = detail::file_bytes(bname + ".pose", &have_pose);
+	const std::string rgbb = detail::file_bytes(bname + ".rgb", &have_rgb), feyeb = detail::file_bytes(bname + ".feye", &have_feye);
+	const size_t rgb_px = (size_t)(info.rgb_dim.x > 0 ? info.rgb_dim.x : 0) * (size_t)(info.rgb_dim.y > 0 ? info.rgb_dim.y : 0), feye_px = (size_t)(info.feye_dim.x > 0 ? info.feye_dim.x : 0) * (size_t)(info.feye_dim.y > 0 ? info.feye_dim.y : 0);
 	const size_t px = (size_t)info.dcamera.dim().x * (size_t)info.dcamera.dim().y;
 	const size_t depth_bytes = px * sizeof(unsigned short), record = depth_bytes + (info.hasir ? px : 0);
 	const size_t count = record ? rs.size() / record : 0;
@@ -205,6 +219,11 @@ inline std::vector<Frame> load_dataset(const std::string &bname, unsigned int po
 		f.ir = Image<unsigned char>(info.dcamera, std::move(ir));
 		f.pose.assign(pose_array_size, Pose());
 		if (have_pose) detail::take_poses(pose_at, pose_end, f.pose);
+		f.startpose = f.pose;
+		// colour and fish-eye frames have the header's rgb_dim / feyedim (dataset.h:134-139); a frame the stream no longer holds stays black, as a short read leaves it in the reference
+		f.rgb = Image<byte3>(DCamera(info.rgb_dim, { 0, 0 }, { 0, 0 }, 0.0f)); f.fisheye = Image<unsigned char>(DCamera(info.feye_dim, { 0, 0 }, { 0, 0 }, 0.0f));
+		if (have_rgb && rgb_px && (k + 1) * rgb_px * 3 <= rgbb.size()) std::memcpy(f.rgb.raster.data(), rgbb.data() + k * rgb_px * 3, rgb_px * 3);
+		if (have_feye && feye_px && (k + 1) * feye_px <= feyeb.size()) std::memcpy(f.fisheye.raster.data(), feyeb.data() + k * feye_px, feye_px);
 		f.fname = bname; f.fid = (int)k;
 	}
 	return frames;
@@ -212,7 +231,7 @@ inline std::vector<Frame> load_dataset(const std::string &bname, unsigned int po
 // Same surface as dataset.h:62-104: opened on a base name (or on a header, which is then written), SaveFrame appends one frame to all three streams.
 class DepthDataStreamOut
 {
-	std::FILE *depth_out = nullptr, *ir_out = nullptr, *pose_out = nullptr;
+	std::FILE *depth_out = nullptr, *ir_out = nullptr, *pose_out = nullptr, *rgb_out = nullptr, *feye_out = nullptr;
 	static void put(std::FILE *f, const void *p, size_t n, const char *what) { if (n && std::fwrite(p, 1, n, f) != n) throw std::runtime_error(std::string("dataset: short write to the ") + what + " stream"); }
 public:
 	const std::string prefix;
@@ -223,7 +242,9 @@ public:
 	explicit DepthDataStreamOut(const DatasetInfo &header) : DepthDataStreamOut(header.fname) { WriteDatasetInfo(header.fname + ".json", header); }
 	DepthDataStreamOut(const DepthDataStreamOut &) = delete;
 	DepthDataStreamOut &operator=(const DepthDataStreamOut &) = delete;
-	~DepthDataStreamOut() { for (std::FILE *f : { depth_out, ir_out, pose_out }) if (f) std::fclose(f); }
+	~DepthDataStreamOut() { for (std::FILE *f : { depth_out, ir_out, pose_out, rgb_out, feye_out }) if (f) std::fclose(f); }
+	DepthDataStreamOut &AddRGB() { if (!rgb_out) rgb_out = std::fopen((prefix + ".rgb").c_str(), "wb"); return *this; }              // dataset.h:77
+	DepthDataStreamOut &AddFishEye() { if (!feye_out) feye_out = std::fopen((prefix + ".feye").c_str(), "wb"); return *this; }       // dataset.h:78
 	void SaveFrame(const Image<unsigned short> &dimage, const Image<unsigned char> &irimage, const std::vector<Pose> &pose)
 	{
 		if (!depth_out || !ir_out || !pose_out) throw std::runtime_error("dataset: cannot write " + prefix + ".rs/.ir/.pose");
@@ -233,5 +254,13 @@ public:
 		WritePoseLine(line, pose);
 		put(pose_out, line.str().data(), line.str().size(), "pose");
 	}
+	void SaveFrame(const Frame &frame)                                                                                                 // dataset.h:101-107
+	{
+		SaveFrame(frame.depth, frame.ir, frame.pose);
+		if (rgb_out && !frame.rgb.raster.empty()) put(rgb_out, frame.rgb.raster.data(), frame.rgb.raster.size() * 3, "colour");
+		if (feye_out && !frame.fisheye.raster.empty()) put(feye_out, frame.fisheye.raster.data(), frame.fisheye.raster.size(), "fish-eye");
+	}
+	void SaveFrames(const std::vector<Frame> &frames) { for (auto &f : frames) SaveFrame(f); }
 };
+static_assert(sizeof(byte3) == 3, "colour frames are packed 3 bytes per pixel");
 }  // namespace ht_mi355x

@@ -50,7 +50,7 @@ template <class T> struct Image                                                 
 {
 	DCamera cam; std::vector<T> raster;
 	Image() {}
-	Image(DCamera cam) : cam(cam), raster((size_t)cam.dim().x * cam.dim().y, T(0)) {}
+	Image(DCamera cam) : cam(cam), raster((size_t)cam.dim().x * cam.dim().y, T()) {}
 	Image(DCamera cam, std::vector<T> data) : cam(cam), raster(std::move(data)) {}
 	const int2 dim() const { return cam.dim(); }
 	T &pixel(int2 p) { return raster[(size_t)p.y * dim().x + p.x]; }

@@ -27,10 +27,14 @@
 //   segment <animbank.pose> <rows,comma> <out.htfx>   320x240 frames and what HandSegmentVR makes of them
 //   bench  <frames.htfx> <seed> <fc2gain> <reps>   reference CPU time for the unit of work
 //   poses  <frames.htfx> <seed> <fc2gain> <out.htfx>   the unit of work on every frame of the file: user poses, othermodel poses, tracker flags
+//   dataset_write <dir/> <name>                    DepthDataStreamOut (dataset.h:62-106) writes a three-frame set <dir>/<name>.{json,rs,ir,pose,rgb,feye}
+//   dataset_read <prefix> <bones> <out.htfx>       load_dataset (dataset.h:109-163) reads <prefix>.* ; everything it returns
+//   dataset_header <x.json> <x.pose> <bones> <out.htfx>   DatasetInfo as from_json decodes it and the poses the reference's stream operator reads
 //   cnn128 <frames128.htfx> <idx,comma> <seed> <fc2gain> <out.htfx>   the layer list of PoseInitializerCNN on a 128x128 input (SURVEY 8d config 5 ii),
 //                                                  assembled from the reference's own layer classes, evaluated on frames of a `fullframes` file
 //
 #include "/root/reference/include/handtrack.h"
+#include "/root/reference/include/dataset.h"
 #include <sys/stat.h>
 #include <unistd.h>
 #include <chrono>
@@ -126,13 +130,13 @@ static Image<unsigned short> raycast_depth(PhysModel &model, const DCamera &cam)
 	}
 	return depth;
 }
-struct Frame { Image<unsigned short> seg; std::vector<Pose> start, gt; };
-static Frame make_frame(PhysModel &fake, const std::vector<std::vector<Pose>> &bank, size_t k)
+struct TileFrame { Image<unsigned short> seg; std::vector<Pose> start, gt; };
+static TileFrame make_frame(PhysModel &fake, const std::vector<std::vector<Pose>> &bank, size_t k)
 {
 	DCamera dcam({ 320,240 }, { 305,305 }, { 160,120 }, 0.001f);
 	fake.SetPose(bank[k % bank.size()]);
 	auto depth = raycast_depth(fake, dcam);
-	Frame fr;
+	TileFrame fr;
 	fr.seg = HandSegmentVR(depth, 0xF, { 0.1f,0.70f });
 	fr.gt = bank[k % bank.size()];
 	fr.start = bank[(k + 1) % bank.size()];
@@ -357,7 +361,7 @@ static int mode_voxel(const char *bankfn, const char *rowscsv, uint64_t seed, do
 	for (size_t fi = 0; fi < rows.size(); fi++)
 	{
 		std::string pre = "f" + std::to_string(fi) + "/";
-		Frame fr = make_frame(fake, bank, rows[fi]);
+		TileFrame fr = make_frame(fake, bank, rows[fi]);
 		o.u16(pre + "depth", fr.seg.raster, { 64,64 }); o.f32(pre + "cam", camvec(fr.seg.cam)); o.f32(pre + "startpose", flat(fr.start), { 17,7 });
 		auto vox = takesubsample(PointCloud(fr.seg, { 0.1f,htk.drangey }), htk.subsample_fraction, htk.subsample_voxel, htk.subsample_size);
 		std::vector<float> vp; for (auto &p : vox) { vp.push_back(p.x); vp.push_back(p.y); vp.push_back(p.z); }
@@ -441,7 +445,7 @@ static int mode_scan(const char *bankfn, int stride)
 	printf("# animbank rows=%d\n# row inrange P pairs contacts fiterr focal\n", (int)bank.size());
 	for (size_t k = 0; k < bank.size(); k += stride)
 	{
-		Frame fr = make_frame(fake, bank, k);
+		TileFrame fr = make_frame(fake, bank, k);
 		auto pc = PointCloud(fr.seg, { 0.1f,0.7f });
 		auto vp = takesubsample(pc, 4);
 		htk.handmodel.SetPose(fr.start); zero_momenta(htk.handmodel);
@@ -468,7 +472,7 @@ static int mode_frames(const char *bankfn, int first, int stride, int n, const c
 	for (int i = 0; i < n; i++)
 	{
 		size_t k = (size_t)(first + (long)i * stride) % bank.size();
-		Frame fr = make_frame(fake, bank, k);
+		TileFrame fr = make_frame(fake, bank, k);
 		depth.insert(depth.end(), fr.seg.raster.begin(), fr.seg.raster.end());
 		auto c = camvec(fr.seg.cam); cams.insert(cams.end(), c.begin(), c.end());
 		auto s = flat(fr.start); start.insert(start.end(), s.begin(), s.end());
@@ -550,7 +554,7 @@ static int mode_scale(const char *bankfn, const char *rowscsv, uint64_t seed, do
 	for (size_t fi = 0; fi < rows.size(); fi++)
 	{
 		std::string pre = "f" + std::to_string(fi) + "/";
-		Frame fr = make_frame(fake, bank, rows[fi]);
+		TileFrame fr = make_frame(fake, bank, rows[fi]);
 		o.u16(pre + "depth", fr.seg.raster, { 64, 64 }); o.f32(pre + "cam", camvec(fr.seg.cam)); o.f32(pre + "startpose", flat(fr.start), { 17, 7 });
 		htk.handmodel.SetPose(fr.start); htk.othermodel.SetPose(fr.start); zero_momenta(htk.handmodel); zero_momenta(htk.othermodel);
 		htk.prev_frame_error = 0; htk.initializing = 0;
@@ -585,7 +589,7 @@ static int mode_slowfit(const char *bankfn, const char *rowscsv, const char *out
 	for (size_t fi = 0; fi < rows.size(); fi++)
 	{
 		std::string pre = "f" + std::to_string(fi) + "/";
-		Frame fr = make_frame(fake, bank, rows[fi]);
+		TileFrame fr = make_frame(fake, bank, rows[fi]);
 		o.u16(pre + "depth", fr.seg.raster, { 64, 64 }); o.f32(pre + "cam", camvec(fr.seg.cam)); o.f32(pre + "startpose", flat(fr.start), { 17, 7 }); o.f32(pre + "refpose", flat(fr.gt), { 17, 7 });
 		auto points = takesubsample(PointCloud(fr.seg, { 0.1f,htk.drangey }), htk.subsample_fraction);
 		std::vector<float4> crays;      // unit rays from the camera to the ground-truth feature points, weight 1
@@ -621,7 +625,7 @@ static int mode_train(const char *bankfn, const char *rowscsv, uint64_t seed, do
 	for (size_t fi = 0; fi < rows.size(); fi++)
 	{
 		std::string pre = "f" + std::to_string(fi) + "/";
-		Frame fr = make_frame(fake, bank, rows[fi]);
+		TileFrame fr = make_frame(fake, bank, rows[fi]);
 		float2 drange = { 0.1f, htk.drangey };
 		auto cnn_input = Transform(fr.seg, [drange, &fr](unsigned short d) { return (float)clamp(1.0f - (d*fr.seg.cam.depth_scale - drange.x) / (drange.y - drange.x), 0.0f, 1.0f); });
 		auto lab = GatherHandExpectedCNN(fr.gt, camsub(fr.seg.cam, 4));
@@ -659,7 +663,7 @@ static int mode_golden(const char *bankfn, const char *rowscsv, uint64_t seed, d
 	for (size_t fi = 0; fi < rows.size(); fi++)
 	{
 		std::string pre = "f" + std::to_string(fi) + "/";
-		Frame fr = make_frame(fake, bank, rows[fi]);
+		TileFrame fr = make_frame(fake, bank, rows[fi]);
 		auto &seg = fr.seg;
 		o.u16(pre + "depth", seg.raster, { 64,64 }); o.f32(pre + "cam", camvec(seg.cam)); o.f32(pre + "startpose", flat(fr.start), { 17,7 }); o.f32(pre + "gtpose", flat(fr.gt), { 17,7 });
 		float2 drange = { 0.1f, htk.drangey };
@@ -960,6 +964,71 @@ static int mode_poses(const char *framesfn, uint64_t seed, double gain, const ch
 	return 0;
 }
 
+// ---- on-disk dataset formats (include/dataset.h): the reference's own writer and reader -----------------------------------------------------------
+static void dump_dataset_info(Out &o, const DatasetInfo &d)
+{
+	o.f32("info_camera", { (float)d.dcamera.dim().x, (float)d.dcamera.dim().y, d.dcamera.focal().x, d.dcamera.focal().y, d.dcamera.principal().x, d.dcamera.principal().y, d.dcamera.depth_scale });
+	o.f32("info_mplane", { d.mplane.x, d.mplane.y, d.mplane.z, d.mplane.w });
+	o.f32("info_misc", { d.hasir ? 1.0f : 0.0f, (float)d.rgb_dim.x, (float)d.rgb_dim.y, (float)d.feye_dim.x, (float)d.feye_dim.y, d.segment_scale });
+	std::vector<unsigned short> a(d.fname.begin(), d.fname.end()), b(d.camtype.begin(), d.camtype.end());
+	o.u16("info_fname", a, { (uint32_t)a.size() }); o.u16("info_camtype", b, { (uint32_t)b.size() });
+}
+// DepthDataStreamOut (dataset.h:62-106) writes a small three-frame set with every stream (depth, ir, poses, rgb, fish-eye) under <prefix>
+static int mode_dataset_write(const char *dir, const char *prefix)
+{
+	if (chdir(dir)) { fprintf(stderr, "cannot enter %s\n", dir); return 2; }      // the header records the prefix it is given (DatasetInfo::fname): keep it free of this machine's paths
+	DatasetInfo dsi{ DCamera({ 16,12 }, { 14.5f,14.25f }, { 8.25f,5.75f }, 0.000125f), float4(0.0f, 0.6f, 0.8f, -0.35f), prefix, "synthetic", false, { 8,6 }, { 4,2 }, 0.165f };
+	DepthDataStreamOut out(dsi);
+	out.AddRGB().AddFishEye();
+	for (int k = 0; k < 3; k++)
+	{
+		Image<unsigned short> d(dsi.dcamera); Image<unsigned char> ir(dsi.dcamera); Image<byte3> rgb(dsi.rgb_dim); Image<unsigned char> fe(dsi.feye_dim);
+		for (size_t i = 0; i < d.raster.size(); i++) { d.raster[i] = (unsigned short)(1000 * k + 7 * i + 1); ir.raster[i] = (unsigned char)(3 * i + k); }
+		for (size_t i = 0; i < rgb.raster.size(); i++) rgb.raster[i] = byte3((unsigned char)(i + k), (unsigned char)(2 * i + k), (unsigned char)(255 - i));
+		for (size_t i = 0; i < fe.raster.size(); i++) fe.raster[i] = (unsigned char)(17 * i + 5 * k);
+		std::vector<Pose> p(17);
+		for (int b = 0; b < 17; b++) p[b] = Pose(float3(0.0123456f * b - 0.1f, -0.125f * k + 1e-5f * b, 0.3f + 0.001f * k), normalize(float4(0.1f * b, -0.3f, 0.25f * k, 1.0f)));
+		out.SaveFrame(MakeFrame(d, p, ir, rgb, fe));
+	}
+	return 0;
+}
+// load_dataset (dataset.h:109-163) reads <prefix>.* and everything it returns is dumped
+static int mode_dataset_read(const char *prefix, int nposes, const char *outfn)
+{
+	auto frames = load_dataset(prefix, (unsigned)nposes);
+	DatasetInfo dsi; from_json(dsi, json::parsefile(std::string(prefix) + ".json"));
+	Out o; if (htfx_open(&o.w, outfn)) return 2;
+	dump_dataset_info(o, dsi);
+	o.i32("nframes", { (int)frames.size() });
+	for (size_t k = 0; k < frames.size(); k++)
+	{
+		const std::string pre = "f" + std::to_string(k) + "/"; auto &f = frames[k];
+		o.u16(pre + "depth", f.depth.raster, { (uint32_t)f.depth.dim().y, (uint32_t)f.depth.dim().x });
+		std::vector<unsigned short> ir(f.ir.raster.begin(), f.ir.raster.end()), fe(f.fisheye.raster.begin(), f.fisheye.raster.end()), rgb;
+		for (auto &c : f.rgb.raster) { rgb.push_back(c.x); rgb.push_back(c.y); rgb.push_back(c.z); }
+		o.u16(pre + "ir", ir); o.u16(pre + "rgb", rgb); o.u16(pre + "fisheye", fe);
+		o.f32(pre + "pose", flat(f.pose), { (uint32_t)f.pose.size(), 7 });
+		o.f32(pre + "cam", camvec(f.depth.cam));
+		o.i32(pre + "fid", { f.fid });
+	}
+	htfx_close(&o.w);
+	return 0;
+}
+// the reference-held sample datasets/example/hand_data_example.{json,pose} (its .rs/.ir blobs are stripped): the header as from_json decodes it and every
+// pose the reference's stream operator reads from the text
+static int mode_dataset_header(const char *jsonfn, const char *posefn, int nposes, const char *outfn)
+{
+	DatasetInfo dsi; from_json(dsi, json::parsefile(jsonfn));
+	Out o; if (htfx_open(&o.w, outfn)) return 2;
+	dump_dataset_info(o, dsi);
+	std::ifstream in(posefn);
+	std::vector<float> all; int n = 0;
+	for (;;) { std::vector<Pose> p(nposes); bool ok = true; for (auto &q : p) if (!(in >> q)) { ok = false; break; } if (!ok) break; for (float v : flat(p)) all.push_back(v); n++; }
+	o.f32("poses", all, { (uint32_t)n, (uint32_t)nposes, 7 });
+	htfx_close(&o.w);
+	return 0;
+}
+
 int main(int argc, char **argv) try
 {
 	if (argc < 2) { fprintf(stderr, "usage: see header of ref_harness.cpp\n"); return 1; }
@@ -982,6 +1051,9 @@ int main(int argc, char **argv) try
 	if (mode == "voxel" && a.size() == 7) return mode_voxel(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), atof(a[4].c_str()), atoi(a[5].c_str()), a[6].c_str());
 	if (mode == "golden" && a.size() == 5) return mode_golden(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());
 	if (mode == "cnn128" && a.size() == 5) return mode_cnn128(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());
+	if (mode == "dataset_write" && a.size() == 2) return mode_dataset_write(a[0].c_str(), a[1].c_str());
+	if (mode == "dataset_read" && a.size() == 3) return mode_dataset_read(a[0].c_str(), atoi(a[1].c_str()), a[2].c_str());
+	if (mode == "dataset_header" && a.size() == 4) return mode_dataset_header(a[0].c_str(), a[1].c_str(), atoi(a[2].c_str()), a[3].c_str());
 	if (mode == "poses" && a.size() == 4) return mode_poses(a[0].c_str(), strtoull(a[1].c_str(), 0, 0), atof(a[2].c_str()), a[3].c_str());
 	if (mode == "bench" && a.size() >= 4) return mode_bench(a[0].c_str(), strtoull(a[1].c_str(), 0, 0), atof(a[2].c_str()), atoi(a[3].c_str()), a.size() > 4 ? atoi(a[4].c_str()) : 0);
 	fprintf(stderr, "bad arguments\n");

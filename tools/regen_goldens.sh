@@ -36,6 +36,14 @@ $H frames $BANK 3 9 256 $T/frames256.htfx
 $H poses $T/frames256.htfx $SEED $GAIN $T/poses256.htfx
 # the optional voxel sub-sampling of the main-thread cloud (handtrack.h:535-536): 1 cm voxels, min_point_num 20
 $H voxel $BANK 0,912,2224,1504 $SEED $GAIN 0.01 20 $T/voxel4.htfx
+# on-disk dataset formats (dataset.h): a three-frame set written by the reference's DepthDataStreamOut, what its load_dataset returns for it, and the
+# reference-held sample dataset's header and poses as the reference decodes them (the two sample files are copied as data; their .rs/.ir blobs are stripped upstream)
+mkdir -p $T/dataset3
+$H dataset_write $T/dataset3/ set3
+$H dataset_read $T/dataset3/set3 17 $T/dataset3/set3_as_the_reference_reads_it.htfx > /dev/null
+cp $REF/datasets/example/hand_data_example.json $REF/datasets/example/hand_data_example.pose $T/dataset3/
+chmod u+w $T/dataset3/hand_data_example.*
+$H dataset_header $T/dataset3/hand_data_example.json $T/dataset3/hand_data_example.pose 17 $T/dataset3/hand_data_example_as_the_reference_reads_it.htfx
 # next rows of SURVEY 8(f)
 $H segment $BANK 0,144,912,1504,2048,2224 $T/seg.htfx
 $H scale $BANK 0,912 $SEED $GAIN 1.15 $T/scale_frames.htfx      # writes the tracked frames and, beside them, the scaled model (<out>.model)
@@ -64,6 +72,10 @@ rc=0
 for f in model_hand17 model_hand26 model_chain3 golden8 poses256 voxel4 scale115 slowfit3 train3 fullframe320 fullframe320close fullframe5 config5 cnn128; do
 	if cmp -s $T/$f.htfx $G/$f.htfx; then echo "identical  $f.htfx"; else echo "DIFFERENT  $f.htfx"; rc=1; fi
 	[ $WRITE = 1 ] && cp $T/$f.htfx $G/$f.htfx
+done
+for f in $(ls $T/dataset3); do
+	if cmp -s $T/dataset3/$f $G/dataset3/$f; then echo "identical  dataset3/$f"; else echo "DIFFERENT  dataset3/$f"; rc=1; fi
+	[ $WRITE = 1 ] && mkdir -p $G/dataset3 && cp $T/dataset3/$f $G/dataset3/$f
 done
 if cmp -s $T/model_chain3.json $G/model_chain3.json; then echo "identical  model_chain3.json"; else echo "DIFFERENT  model_chain3.json"; rc=1; fi
 python3 - "$T" "$G" "$WRITE" <<'PY' || rc=1
