@@ -90,8 +90,17 @@ def _golden8():
 
 
 def cpu_baseline_config5(depth, cams, start, seed, gain):
-    """C oracle (pinned bit for bit on the reference's full-frame goldens, tests/test_fullframe.py) on a bounded sample, one thread."""
+    """BASELINE configs[4] on the host: the reference itself on the 26-bone model (oracle/_ref/model_hand26.json in its own schema); else the C oracle
+    (pinned bit for bit on the reference's full-frame goldens, tests/test_fullframe.py) on a bounded sample, one thread."""
     import numpy as np
+    mj = os.path.join(ROOT, "oracle", "_ref", "model_hand26.json")
+    if os.path.exists(mj):
+        try:
+            r = _reference_baseline(depth, cams, start, seed, gain, h=128, w=128, model_json=mj, nsample=64, what="HandSegmentVR + update_cnn_model + 3 passes on 128x128 frames, 26 bones")
+            if r:
+                return r
+        except Exception as e:
+            sys.stderr.write("reference baseline for configs[4] unavailable (%s); timing the C oracle port\n" % e)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ctypes as C
     import oracle_lib as ol
@@ -141,23 +150,74 @@ def _write_htfx(path, arrays):
             f.write(raw + b"\0" * ((8 - (len(raw) & 7)) & 7))
 
 
-def cpu_baseline(depth, cams, start, seed, gain):
-    """Reference CPU path on a bounded sample of the same workload (single thread)."""
-    import numpy as np
-    nsample = min(192, len(depth))
+def _host_cores():
+    """Cores this process may use: the cgroup's CPU quota when there is one (a GPU box hands out a share of the host), else the affinity mask; the
+    all-cores leg starts one process per core, so the count is capped at 64 to keep the default run within minutes."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(round(float(quota) / float(period)))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def _reference_baseline(depth, cams, start, seed, gain, h=64, w=64, model_json=None, nsample=192, what="update_cnn_model + 3 passes"):
+    """The reference's own code (oracle/_ref/ref_harness, its headers compiled where they lie) on a bounded sample of the same workload:
+    one thread (IEEE build = the build all fixtures come from, and the -Ofast build of the reference's own Makefile), then every host core
+    with one process per core over the same sample.  None when the harness binary is not there."""
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
-    if os.path.exists(ref_bin):
+    fast_bin = ref_bin + "_ofast"
+    if not os.path.exists(ref_bin):
+        return None
+    nsample = min(nsample, len(depth))
+    env = dict(os.environ)
+    if model_json:
+        env["HT_REF_MODEL_JSON"] = model_json
+    with tempfile.TemporaryDirectory() as td:
+        fn = os.path.join(td, "frames.htfx")
+        _write_htfx(fn, {"depth": depth[:nsample].reshape(-1, h, w), "cam": cams[:nsample], "startpose": start[:nsample]})
+
+        def one(binary, reps):
+            out = subprocess.run([binary, "bench", fn, hex(seed), str(gain), str(reps)], capture_output=True, text=True, timeout=900, env=env)
+            return json.loads(out.stdout.strip().splitlines()[-1])
+        r = one(ref_bin, 3)
+        res = {"value": r["frame_fps"], "unit": "frames/s", "cores": 1, "kind": "reference",
+               "sample": "%d frames x 3 reps (best), reference headers built -O2 -ffp-contract=off (the IEEE build every fixture comes from), %s" % (nsample, what)}
+        if r.get("cnn_fps") and (h, w) == (64, 64):
+            res["cnn_only_fps"] = r["cnn_fps"]
+        if os.path.exists(fast_bin):
+            try:
+                f = one(fast_bin, 3)
+                res["ofast"] = {"value": f["frame_fps"], "cnn_only_fps": f.get("cnn_fps") if (h, w) == (64, 64) else None, "flags": "-Ofast -march=x86-64-v3 (the reference Makefile's -Ofast; its results differ by millimetres, SURVEY F7: timing only)"}
+            except Exception as e:
+                sys.stderr.write("-Ofast reference baseline unavailable (%s)\n" % e)
+        # every host core: one process per core, each over the whole sample once (frames are independent, so this is how the reference would be scaled out)
+        ncpu = _host_cores()
         try:
-            with tempfile.TemporaryDirectory() as td:
-                fn = os.path.join(td, "frames.htfx")
-                _write_htfx(fn, {"depth": depth[:nsample].reshape(-1, 64, 64), "cam": cams[:nsample], "startpose": start[:nsample]})
-                out = subprocess.run([ref_bin, "bench", fn, hex(seed), str(gain), "3"], capture_output=True, text=True, timeout=600)
-                r = json.loads(out.stdout.strip().splitlines()[-1])
-                return {"value": r["frame_fps"], "unit": "frames/s", "cores": 1, "kind": "reference",
-                        "sample": "%d frames x 3 reps (best), reference headers built -O2 -ffp-contract=off, update_cnn_model + 3 passes" % nsample,
-                        "cnn_only_fps": r["cnn_fps"]}
-        except Exception as e:      # fall through to the port
-            sys.stderr.write("reference baseline unavailable (%s); timing the C oracle port\n" % e)
+            t0 = time.perf_counter()
+            procs = [subprocess.Popen([ref_bin, "bench", fn, hex(seed), str(gain), "1"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(ncpu)]
+            outs = [p.communicate(timeout=900)[0] for p in procs]
+            wall = time.perf_counter() - t0
+            per = [json.loads(o.strip().splitlines()[-1]) for o in outs]
+            # the processes' own unit-of-work clocks (start-up and the CNN-only loop excluded), all running at once
+            res["all_cores"] = {"value": round(sum(q["frame_fps"] for q in per), 2), "cores": ncpu, "wall_s": round(wall, 2),
+                                "sample": "%d processes x %d frames at once, sum of the processes' frames/s" % (ncpu, nsample)}
+        except Exception as e:
+            sys.stderr.write("all-cores reference baseline unavailable (%s)\n" % e)
+        return res
+
+
+def cpu_baseline(depth, cams, start, seed, gain):
+    """Reference CPU path on a bounded sample of the same workload."""
+    import numpy as np
+    try:
+        r = _reference_baseline(depth, cams, start, seed, gain)
+        if r:
+            return r
+    except Exception as e:      # fall through to the port
+        sys.stderr.write("reference baseline unavailable (%s); timing the C oracle port\n" % e)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ctypes as C
     import oracle_lib as ol
@@ -180,9 +240,20 @@ def cpu_baseline(depth, cams, start, seed, gain):
             "sample": "%d frames x 2 reps (best), C oracle -O2 -ffp-contract=off, update_cnn_model + 3 passes" % nsample}
 
 
-def _latest_profile(pattern):
-    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
-    return fs[-1] if fs else None
+def _pmc_traffic(kernel_prefix, workload, frames_per_gpu):
+    """HBM bytes per launch of a kernel from the newest committed PMC summary that was measured on this workload at this batch size, else None."""
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic*.json")), reverse=True):
+        try:
+            pmc = json.load(open(fn))
+            meta = pmc.get("_measured_on", {})
+            if meta.get("workload") != workload or int(meta.get("frames_per_gpu", -1)) != int(frames_per_gpu):
+                continue
+            vals = [v["hbm_bytes_per_launch"] for k, v in pmc.items() if k.startswith(kernel_prefix)]
+            if vals:
+                return max(vals)
+        except Exception:
+            continue
+    return None
 
 
 def main():
@@ -252,6 +323,26 @@ def main():
     d_poses2 = [torch.empty((B, ctx.nb, 7), dtype=torch.float32, device=dev) for _ in range(2)]
     d_poses = d_poses2[0]
     d_cnn_out = torch.empty((B, 2304), dtype=torch.float32, device=dev)
+    # The exchange: one RCCL all-gather of the poses per step, issued by the LIBRARY (ht_gather_poses_dev: ncclAllGather on the context's communication
+    # stream, the way a C++ host shards; the unique id travels through the process group that exists anyway for the barrier).  If the communicator
+    # cannot be made, torch.distributed's all-gather does the same exchange and the JSON line says so.
+    gather_impl = None
+    if use_dist and not cnn_only:
+        try:
+            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(native.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            ctx.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
+            gather_impl = "ht_gather_poses_dev (ncclAllGather on the context's communication stream): RCCL reports %d rank(s), this is rank %d" % ctx.comm_info()
+        except Exception as e:
+            sys.stderr.write("rank %d: C-ABI RCCL gather unavailable (%s); using torch.distributed.all_gather_into_tensor\n" % (rank, e))
+            gather_impl = "torch.distributed.all_gather_into_tensor (the library's communicator could not be made: %s)" % e
+        ok = torch.tensor([1 if gather_impl.startswith("ht_") else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # every rank takes the same route
+        if int(ok.item()) == 0 and gather_impl.startswith("ht_"):
+            gather_impl = "torch.distributed.all_gather_into_tensor (another rank could not make the library's communicator)"
+    use_lib_gather = bool(gather_impl and gather_impl.startswith("ht_"))
     gathered2 = [torch.empty((world * B, ctx.nb, 7), dtype=torch.float32, device=dev) for _ in range(2)] if use_dist else [None, None]
     gathered = gathered2[0]
     pending = [None, None]      # the exchange still reading each pose buffer
@@ -273,8 +364,10 @@ def main():
         nonlocal d_poses, gathered
         k = nstep[0] & 1; nstep[0] += 1
         d_poses, gathered = d_poses2[k], gathered2[k]
-        if pending[k] is not None:
-            pending[k].wait(); pending[k] = None      # the exchange of two steps ago has to be through with this buffer (it long is)
+        if use_lib_gather:
+            ctx.gather_wait(k, stream.cuda_stream)       # the exchange of two steps ago has to be through with this buffer pair (it long is)
+        elif pending[k] is not None:
+            pending[k].wait(); pending[k] = None
         if cnn128:
             ctx.cnn128_eval_dev(d_cnn_in.data_ptr(), d_cnn_out.data_ptr(), B, stream.cuda_stream)
         elif wl == "cnn":
@@ -283,7 +376,9 @@ def main():
             ctx.update_frames_dev(d_depth.data_ptr(), d_cams.data_ptr(), 128, 128, 0.17, d_start.data_ptr(), B, d_poses.data_ptr(), stream.cuda_stream)
         else:
             ctx.update_dev(d_depth.data_ptr(), d_cams.data_ptr(), d_start.data_ptr(), B, d_poses.data_ptr(), stream.cuda_stream)
-        if use_dist and not cnn_only:
+        if use_lib_gather:
+            ctx.gather_poses_dev(d_poses.data_ptr(), gathered.data_ptr(), B, k, stream.cuda_stream)
+        elif use_dist and not cnn_only:
             _, pending[k] = gather_poses(d_poses, world, out=gathered, force=True, async_op=True)
 
     for _ in range(args.warmup):
@@ -370,12 +465,9 @@ def main():
             avg_ms = phases[dom][0] / phases[dom][1]
             achieved = per_frame * B / (avg_ms * 1e-3) / 1e9
             valu = flop_frame * B / (avg_ms * 1e-3) / 1e12
-            traffic = None
-            try:      # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), if present
-                pmc = json.load(open(_latest_profile("r*_pmc_hbm_traffic.json")))
-                traffic = max(v["hbm_bytes_per_launch"] for k, v in pmc.items() if k.startswith("k_solve"))      # the build that does the work (the retry launch is nearly empty)
-            except Exception:
-                pass
+            # HBM bytes per launch from the committed rocprofv3 PMC passes of THIS workload and batch size (profiles/rNN_pmc_hbm_traffic*.json carry
+            # what they were measured on); null when no such measurement exists
+            traffic = _pmc_traffic("k_solve", wl, B)
             roof = {"kernel": "k_solve", "bound": "latency", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                     "hbm_frac": round(achieved / HBM_PEAK_GBS, 6), "valu_achieved_tflops": round(valu, 3), "valu_peak_tflops": FP32_VALU_PEAK_TF, "valu_frac": round(valu / FP32_VALU_PEAK_TF, 6),
                     "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches": phases[dom][1], "algorithmic_bytes_per_launch": int(per_frame * B), "algorithmic_flop_per_launch": int(flop_frame * B),
@@ -417,6 +509,7 @@ def main():
             "dtype": "f32", "data": "synthetic (%d software-rendered animbank frames tiled; seeded weights 0x5EED0001)" % (64 if (cfg5 or cnn128) else 256),
             "config": {"workload": workloads[wl][1], "frames_per_gpu": B, "global_frames_per_step": B * world,
                        "parallelism": ("frames sharded per GPU, RCCL all-gather of poses" if not cnn_only else "frames sharded per GPU, no exchange") if world > 1 else "single GPU"},
+            **({"gather": gather_impl} if gather_impl else {}),
             "roofline": roof,
             "phase_ms_per_step": {k: round(v[0] / nphase, 4) for k, v in sorted(all_phases.items())},
             "phase_note": "from an extra untimed pass with every phase bracketed and the side streams serialised",

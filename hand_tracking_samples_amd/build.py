@@ -60,7 +60,7 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(run, jobs))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", LIB]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-ldl", "-o", LIB]      # -ldl: RCCL is opened at run time, only by ht_comm_init (csrc/ht_comm.hip)
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

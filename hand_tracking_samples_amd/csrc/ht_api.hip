@@ -350,6 +350,7 @@ extern "C" int ht_destroy(ht_ctx *ctx)
 	if (!ctx) return HT_ERR_ARG;
 	ht_device_guard dev_guard_(ctx->device);
 	if (ctx->ready) (void)hipDeviceSynchronize();      // nothing of this context may still run when its buffers go
+	if (ctx->comm) (void)ht_comm_destroy(ctx);
 	for (void *p : ctx->allocs) (void)hipFree(p);
 	for (auto &kv : ctx->prof) for (hipEvent_t e : kv.second.ev) (void)hipEventDestroy(e);
 	for (int i = 0; i < 2; i++) { if (ctx->side[i]) (void)hipStreamDestroy(ctx->side[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }

@@ -5,6 +5,7 @@
 #include <vector>
 #include "ht_device.hpp"
 
+struct ht_comm_state;      // RCCL communicator + communication stream (ht_comm.hip)
 struct ht_prof_entry { std::vector<hipEvent_t> ev; size_t used; float total_ms; int launches; };
 
 struct ht_ctx
@@ -55,6 +56,7 @@ struct ht_ctx
 	// caller-built constraint rows (ht_fit_rows / ht_physics_update), allocated on first use and grown to the largest call
 	float *d_user_lin = nullptr; unsigned short *d_user_pos = nullptr; float *d_user_ang = nullptr; int *d_user_n = nullptr;      // [B][lin_cap][HT_ROW], [B][lin_cap], [B][ang_cap][HT_AROW], [4][B]
 	int user_lin_cap = 0, user_ang_cap = 0;
+	ht_comm_state *comm = nullptr;                               // multi-GPU pose gather (ht_comm_init), null on a single-GPU host
 };
 
 struct ht_prof_scope

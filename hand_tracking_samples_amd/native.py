@@ -23,6 +23,7 @@ SYMBOLS = (
     "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_update_frames_sync", "ht_update_frames_dev", "ht_update_cnn_model_sync", "ht_get_cnn_results", "ht_frames_overflow", "ht_reserve_points", "ht_point_capacity", "ht_capacity_events", "ht_segment_vr", "ht_segment_vr_dev", "ht_slowfit", "ht_set_points", "ht_fit_rows", "ht_physics_update",
     "ht_stage_prepare", "ht_stage_decode", "ht_stage_fit_error", "ht_stage_cloud_rows", "ht_stage_contacts", "ht_stage_fit",
     "ht_stage_multistep", "ht_stage_scratch_unibody", "ht_profile_enable", "ht_profile_read", "ht_debug_solve_stats", "ht_debug_contact_stats", "ht_debug_solver_build",
+    "ht_comm_unique_id", "ht_comm_init", "ht_comm_info", "ht_gather_poses_dev", "ht_gather_wait", "ht_comm_destroy",
 )
 
 
@@ -106,6 +107,12 @@ def load(build_if_missing=True):
     L.ht_profile_read.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_int, fp, ip, ip]
     L.ht_debug_solve_stats.argtypes = [vp, C.c_int, fp, C.c_int]
     L.ht_debug_solver_build.argtypes = [vp, C.c_int]
+    L.ht_comm_unique_id.argtypes = [vp]
+    L.ht_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.ht_comm_info.argtypes = [vp, ip, ip]
+    L.ht_gather_poses_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
+    L.ht_gather_wait.argtypes = [vp, C.c_int, vp]
+    L.ht_comm_destroy.argtypes = [vp]
     L.ht_debug_contact_stats.argtypes = [vp, C.c_int, fp, C.c_int]
     for name in SYMBOLS:
         if name not in ("ht_last_error", "ht_model_error"):
@@ -386,6 +393,23 @@ class Context:
         self._chk(self.L.ht_debug_solve_stats(self.h, int(B), _f(out), int(reset)))
         return out
 
+    # ---- multi-GPU result gather (RCCL all-gather on the context's communication stream) ----
+    def comm_init(self, world, rank, unique_id):
+        """Join the RCCL communicator made from `unique_id` (128 bytes from comm_unique_id() on rank 0)."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._chk(self.L.ht_comm_init(self.h, int(world), int(rank), C.cast(buf, C.c_void_p)))
+
+    def comm_info(self):
+        w, r = C.c_int(0), C.c_int(0)
+        self._chk(self.L.ht_comm_info(self.h, C.byref(w), C.byref(r)))
+        return w.value, r.value
+
+    def gather_poses_dev(self, d_local, d_all, frames, slot, stream=None):
+        self._chk(self.L.ht_gather_poses_dev(self.h, C.c_void_p(d_local), C.c_void_p(d_all), int(frames), int(slot), C.c_void_p(stream or 0)))
+
+    def gather_wait(self, slot, stream=None):
+        self._chk(self.L.ht_gather_wait(self.h, int(slot), C.c_void_p(stream or 0)))
+
     def debug_solver_build(self, which):
         """Test aid: pin k_solve's build (0 auto, 1 small, 2 only, 3 mid, 4 tiny = every row array in HBM).  Placement only, results identical."""
         self._chk(self.L.ht_debug_solver_build(self.h, int(which)))
@@ -428,6 +452,15 @@ class Context:
         w = np.empty(9458400, np.float32)
         self._chk(self.L.ht_cnn_get_weights(self.h, _f(w), w.size))
         return w
+
+
+def comm_unique_id():
+    """128-byte RCCL unique id (rank 0 makes it, the host program distributes it)."""
+    L = load()
+    buf = C.create_string_buffer(128)
+    if L.ht_comm_unique_id(C.cast(buf, C.c_void_p)) != 0:
+        raise HTError("ht_comm_unique_id failed (RCCL not available?)")
+    return buf.raw
 
 
 def expected_cnn(pose, cam):

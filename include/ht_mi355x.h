@@ -263,6 +263,24 @@ int ht_fit_rows(ht_ctx *ctx, int which, int B, const float *points, int pcap, co
                 const float *angulars, int acap, const int *nangulars, float microforce);
 int ht_physics_update(ht_ctx *ctx, int which, int B, const float *linears, int lcap, const int *nlinears, const float *angulars, int acap, const int *nangulars);
 
+/* ---- multi-GPU: the result gather -------------------------------------------------------------------------------------------
+ * Frames are independent, so a host shards a batch one GPU (one process, one context) per contiguous block of frames and nothing crosses GPUs but the
+ * results (BASELINE north star: "RCCL over xGMI for the result gather only"; the reference is a single-process CPU program and has no counterpart).
+ * ht_comm_unique_id   rank 0 makes the 128-byte RCCL id (ncclGetUniqueId); the host program hands it to the other ranks (MPI, a socket, a file ...).
+ * ht_comm_init        every rank joins with it (ncclCommInitRank on the context's device).  RCCL is loaded (dlopen) by these two calls only.
+ * ht_comm_info        what the communicator itself reports: ranks and this rank's number (ncclCommCount / ncclCommUserRank).
+ * ht_gather_poses_dev one ncclAllGather of d_local [frames][nb][7] into d_all [world][frames][nb][7] (device pointers), on the context's communication
+ *                     stream behind everything enqueued on `stream` so far: the next step's kernels do not wait for it.  slot (0 / 1) names which of the
+ *                     caller's two buffer pairs the call uses; ht_gather_wait(ctx, slot, stream) makes `stream` (NULL: the calling thread) wait for
+ *                     that slot's gather before the pair is reused or read.
+ * ht_comm_destroy     leaves the communicator (ht_destroy does it too). */
+int ht_comm_unique_id(void *id128);
+int ht_comm_init(ht_ctx *ctx, int world, int rank, const void *id128);
+int ht_comm_info(ht_ctx *ctx, int *world, int *rank);
+int ht_gather_poses_dev(ht_ctx *ctx, const float *d_local, float *d_all, int frames, int slot, void *stream);
+int ht_gather_wait(ht_ctx *ctx, int slot, void *stream);
+int ht_comm_destroy(ht_ctx *ctx);
+
 /* ---- timing hooks for bench.py: HIP-event time (ms) per named phase accumulated since the last reset.
  * on = 1: only the dominant kernel ("solve") is bracketed (negligible perturbation, used inside the timed region);
  * on = 2: every phase is bracketed and the side streams are serialised (phase table). ----- */

@@ -892,22 +892,25 @@ static int mode_bench(const char *framesfn, uint64_t seed, double gain, int reps
 	for (auto &a : arrs) { if (a.name == "depth") ad = &a; if (a.name == "cam") ac = &a; if (a.name == "startpose") as = &a; }
 	if (!ad || !ac || !as) { fprintf(stderr, "frames file lacks depth/cam/startpose\n"); return 2; }
 	int n = (int)ad->dims[0]; if (maxframes > 0 && n > maxframes) n = maxframes;
+	// frames of any size (64x64 tiles; 128x128 frames of BASELINE configs[4], which HandTracker segments itself) and any hand model (HT_REF_MODEL_JSON)
+	const int h = (int)ad->dims[1], w = (int)ad->dims[2], nb = (int)as->dims[1];
+	if ((size_t)nb != htk.handmodel.rigidbodies.size()) { fprintf(stderr, "start poses have %d bones, the model %d\n", nb, (int)htk.handmodel.rigidbodies.size()); return 2; }
 	std::vector<Image<unsigned short>> segs; std::vector<std::vector<Pose>> starts;
 	for (int i = 0; i < n; i++)
 	{
 		const float *c = (const float*)ac->data.data() + 12 * i;
-		DCamera cam({ 64,64 }, { c[0],c[1] }, { c[2],c[3] }, c[4], Pose({ c[5],c[6],c[7] }, { c[8],c[9],c[10],c[11] }));
-		const unsigned short *d = (const unsigned short*)ad->data.data() + 4096 * i;
-		segs.push_back(Image<unsigned short>(cam, std::vector<unsigned short>(d, d + 4096)));
-		std::vector<Pose> sp(17); const float *s = (const float*)as->data.data() + 119 * i;
-		for (int b = 0; b < 17; b++) sp[b] = Pose({ s[7 * b],s[7 * b + 1],s[7 * b + 2] }, { s[7 * b + 3],s[7 * b + 4],s[7 * b + 5],s[7 * b + 6] });
+		DCamera cam({ w,h }, { c[0],c[1] }, { c[2],c[3] }, c[4], Pose({ c[5],c[6],c[7] }, { c[8],c[9],c[10],c[11] }));
+		const unsigned short *d = (const unsigned short*)ad->data.data() + (size_t)w * h * i;
+		segs.push_back(Image<unsigned short>(cam, std::vector<unsigned short>(d, d + (size_t)w * h)));
+		std::vector<Pose> sp(nb); const float *s = (const float*)as->data.data() + (size_t)7 * nb * i;
+		for (int b = 0; b < nb; b++) sp[b] = Pose({ s[7 * b],s[7 * b + 1],s[7 * b + 2] }, { s[7 * b + 3],s[7 * b + 4],s[7 * b + 5],s[7 * b + 6] });
 		starts.push_back(sp);
 	}
 	double best_cnn = 1e30, best_uw = 1e30; double checksum = 0;
 	for (int r = 0; r < reps; r++)
 	{
 		auto t0 = std::chrono::steady_clock::now();
-		for (int i = 0; i < n; i++)
+		if (w == 64 && h == 64) for (int i = 0; i < n; i++)
 		{
 			float2 drange = { 0.1f, htk.drangey }; auto &seg = segs[i];
 			auto in = Transform(seg, [drange, &seg](unsigned short d) {return (float)clamp(1.0f - (d*seg.cam.depth_scale - drange.x) / (drange.y - drange.x), 0.0f, 1.0f); });
@@ -923,7 +926,7 @@ static int mode_bench(const char *framesfn, uint64_t seed, double gain, int reps
 		double c = std::chrono::duration<double>(t1 - t0).count() / n, u = std::chrono::duration<double>(t2 - t1).count() / n;
 		best_cnn = std::min(best_cnn, c); best_uw = std::min(best_uw, u);
 	}
-	printf("{\"frames\": %d, \"reps\": %d, \"cnn_ms\": %.4f, \"cnn_fps\": %.2f, \"frame_ms\": %.4f, \"frame_fps\": %.2f, \"checksum\": %.6f}\n", n, reps, best_cnn * 1e3, 1.0 / best_cnn, best_uw * 1e3, 1.0 / best_uw, checksum);
+	printf("{\"frames\": %d, \"reps\": %d, \"cnn_ms\": %.4f, \"cnn_fps\": %.2f, \"frame_ms\": %.4f, \"frame_fps\": %.2f, \"checksum\": %.6f}\n", n, reps, (w == 64 && h == 64) ? best_cnn * 1e3 : 0.0, (w == 64 && h == 64) ? 1.0 / best_cnn : 0.0, best_uw * 1e3, 1.0 / best_uw, checksum);
 	return 0;
 }
 
