@@ -313,7 +313,9 @@ def main():
         for f in range(8):
             depth[f] = gold["f%d/depth" % f].reshape(-1); cams[f] = gold["f%d/cam" % f]; start[f] = gold["f%d/startpose" % f]
 
-    ctx = native.Context(os.path.join(ROOT, "tests", "golden", "model_hand26.htfx" if cfg5 else "model_hand17.htfx"), B, device=local)
+    # the product's own baked model (hand_tracking_samples_amd/assets/: ht_model_bake of the reference's model_hand.json, tools/bake_assets.sh); the fixtures
+    # under tests/golden/ are what the REFERENCE's constructor built and only check it (tests/test_model_build.py: identical bit for bit)
+    ctx = native.Context(os.path.join(ROOT, "hand_tracking_samples_amd", "assets", "model_hand26.htfx" if cfg5 else "model_hand17.htfx"), B, device=local)
     ctx.load_weights(W.make_cnnb(seed, gain))
     ctx.set_params(microforce=3.0, mainthreadpasses=3)        # synthetic-tracker.cpp:91-93
     d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)

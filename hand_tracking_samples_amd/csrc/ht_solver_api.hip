@@ -407,6 +407,20 @@ extern "C" int ht_get_cnn_results(ht_ctx *ctx, int first, int n, float *cnn_inpu
 	return HT_OK;
 }
 
+// The CNN's intermediate layers of the latest evaluation (ht_cnn_eval, an update call) of slots [first, first + n), for per-layer parity tests:
+// act1 [n][3600] = layer 3 of the reference's list (conv 5x5, tanh, two 2x2 max-pools: 16 x 15 x 15), act2 [n][2304] = layer 6 (conv 4x4, tanh, pool: 64 x 6 x 6),
+// act3 [n][2048] = layer 8 (first fully connected layer + tanh), logits [n][2304] = layer 9 (second fully connected layer, before the chunked soft-max).
+extern "C" int ht_get_cnn_layers(ht_ctx *ctx, int first, int n, float *act1, float *act2, float *act3, float *logits)
+{
+	CHECK_READY(ctx); CHECK_RANGE(ctx, first, n);
+	HIPCHK(ctx, ht_sync_all(ctx));
+	if (act1) HIPCHK(ctx, hipMemcpy(act1, ctx->d_act1 + (size_t)first * 3600, (size_t)n * 3600 * sizeof(float), hipMemcpyDeviceToHost));
+	if (act2) HIPCHK(ctx, hipMemcpy(act2, ctx->d_act2 + (size_t)first * 2304, (size_t)n * 2304 * sizeof(float), hipMemcpyDeviceToHost));
+	if (act3) HIPCHK(ctx, hipMemcpy(act3, ctx->d_act3 + (size_t)first * 2048, (size_t)n * 2048 * sizeof(float), hipMemcpyDeviceToHost));
+	if (logits) HIPCHK(ctx, hipMemcpy(logits, ctx->d_logits + (size_t)first * HT_CNN_OUT, (size_t)n * HT_CNN_OUT * sizeof(float), hipMemcpyDeviceToHost));
+	return HT_OK;
+}
+
 // ---- stage entry points (operate on the buffers ht_stage_prepare filled and on the tracker state of slots [0,B)) -------------
 extern "C" int ht_stage_fit_error(ht_ctx *ctx, int which, int B, float *err)
 {
@@ -428,6 +442,22 @@ extern "C" int ht_stage_cloud_rows(ht_ctx *ctx, int which, int stride, int use_c
 	ht_launch_cloud_rows(ctx->model, ctx->d_state[which], ctx->d_pts, ctx->d_npts, ctx->d_cams, nullptr, stride, use_cam_origin, 0, ctx->par, ctx->d_rows, ctx->d_nrows, B, s);
 	HIPCHK(ctx, hipMemcpy2DAsync(rows, HT_MAXPTS * HT_ROW * sizeof(float), ctx->d_rows, (size_t)ctx->model.pts_cap * HT_ROW * sizeof(float), HT_MAXPTS * HT_ROW * sizeof(float), B, hipMemcpyDeviceToHost, s));
 	HIPCHK(ctx, hipMemcpyAsync(nrows, ctx->d_nrows, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
+// cloud_chamber (physmodel.h:486-496) as HandTracker::update calls it (handtrack.h:774-778): rows [B][5*nb][16], nrows [B] (0 where the frame has no more than
+// min_point_num points or boundary_planes is off)
+extern "C" int ht_stage_chamber(ht_ctx *ctx, int which, int B, float *rows, int *nrows)
+{
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
+	if (!rows || !nrows || which < 0 || which > 1) return HT_ERR_ARG;
+	hipStream_t s = ctx->stream;
+	const size_t per = (size_t)5 * ctx->model.nb * HT_ROW;
+	HIPCHK(ctx, hipMemsetAsync(ctx->d_chamber, 0, (size_t)B * per * sizeof(float), s));
+	ht_launch_chamber(ctx->model, ctx->d_state[which], ctx->d_pts, ctx->d_npts, ctx->par.min_point_num, ctx->par.boundary_planes, 10.0f, ctx->d_chamber, ctx->d_nchamber, B, s);
+	HIPCHK(ctx, hipMemcpyAsync(rows, ctx->d_chamber, (size_t)B * per * sizeof(float), hipMemcpyDeviceToHost, s));
+	HIPCHK(ctx, hipMemcpyAsync(nrows, ctx->d_nchamber, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
 	HIPCHK(ctx, hipStreamSynchronize(s));
 	HIPCHK(ctx, hipGetLastError());
 	return HT_OK;

@@ -20,9 +20,9 @@ SYMBOLS = (
     "ht_create", "ht_destroy", "ht_model_bake", "ht_last_error", "ht_get_params", "ht_set_params", "ht_model_info", "ht_config_read", "ht_scale",
     "ht_cnn_load_weights", "ht_cnn_eval", "ht_cnn_eval_dev", "ht_cnn_load_weights_sized", "ht_cnn_eval_sized", "ht_cnn_eval_sized_dev", "ht_cnn_train", "ht_cnn_get_weights", "ht_expected_cnn", "ht_expected_cnn_full",
     "ht_model_open", "ht_model_close", "ht_model_error", "ht_model_counts", "ht_model_body", "ht_model_body_mesh", "ht_model_hitcheck",
-    "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_update_frames_sync", "ht_update_frames_dev", "ht_update_cnn_model_sync", "ht_get_cnn_results", "ht_frames_overflow", "ht_reserve_points", "ht_point_capacity", "ht_capacity_events", "ht_segment_vr", "ht_segment_vr_dev", "ht_slowfit", "ht_set_points", "ht_fit_rows", "ht_physics_update",
+    "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_update_frames_sync", "ht_update_frames_dev", "ht_update_cnn_model_sync", "ht_get_cnn_results", "ht_get_cnn_layers", "ht_frames_overflow", "ht_reserve_points", "ht_point_capacity", "ht_capacity_events", "ht_segment_vr", "ht_segment_vr_dev", "ht_slowfit", "ht_set_points", "ht_fit_rows", "ht_physics_update",
     "ht_stage_prepare", "ht_stage_decode", "ht_stage_fit_error", "ht_stage_cloud_rows", "ht_stage_contacts", "ht_stage_fit",
-    "ht_stage_multistep", "ht_stage_scratch_unibody", "ht_profile_enable", "ht_profile_read", "ht_debug_solve_stats", "ht_debug_contact_stats", "ht_debug_solver_build",
+    "ht_stage_multistep", "ht_stage_scratch_unibody", "ht_stage_chamber", "ht_profile_enable", "ht_profile_read", "ht_debug_solve_stats", "ht_debug_contact_stats", "ht_debug_solver_build",
     "ht_comm_unique_id", "ht_comm_init", "ht_comm_info", "ht_gather_poses_dev", "ht_gather_wait", "ht_comm_destroy",
 )
 
@@ -100,6 +100,8 @@ def load(build_if_missing=True):
     L.ht_expected_cnn.argtypes = [fp, fp, fp]
     L.ht_set_points.argtypes = [vp, C.c_int, fp, C.c_int, ip]
     L.ht_slowfit.argtypes = [vp, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp, fp, fp, C.c_int]
+    L.ht_get_cnn_layers.argtypes = [vp, C.c_int, C.c_int, fp, fp, fp, fp]
+    L.ht_stage_chamber.argtypes = [vp, C.c_int, C.c_int, fp, ip]
     L.ht_fit_rows.argtypes = [vp, C.c_int, C.c_int, fp, C.c_int, ip, fp, C.c_int, ip, fp, C.c_int, ip, C.c_float]
     L.ht_physics_update.argtypes = [vp, C.c_int, C.c_int, fp, C.c_int, ip, fp, C.c_int, ip]
     L.ht_segment_vr.argtypes = [vp, C.POINTER(C.c_uint16), fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_uint16), fp]
@@ -286,6 +288,18 @@ class Context:
         a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
         self._chk(self.L.ht_capacity_events(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def cnn_layers(self, n, first=0):
+        """(act1 [n,3600], act2 [n,2304], act3 [n,2048], logits [n,2304]) of the latest CNN evaluation (ht_get_cnn_layers)."""
+        a1 = np.zeros((n, 3600), np.float32); a2 = np.zeros((n, 2304), np.float32); a3 = np.zeros((n, 2048), np.float32); lg = np.zeros((n, 2304), np.float32)
+        self._chk(self.L.ht_get_cnn_layers(self.h, int(first), int(n), _f(a1), _f(a2), _f(a3), _f(lg)))
+        return a1, a2, a3, lg
+
+    def stage_chamber(self, which, B):
+        """cloud_chamber rows [B, 5*nb, 16] and their counts (ht_stage_chamber)."""
+        rows = np.zeros((B, 5 * self.nb, 16), np.float32); n = np.zeros(B, np.int32)
+        self._chk(self.L.ht_stage_chamber(self.h, int(which), int(B), _f(rows), _i(n)))
+        return rows, n
 
     @staticmethod
     def _ragged(rows, width):

@@ -106,6 +106,20 @@ inline void PhysicsUpdate(const std::vector<RigidBody *> &rigidbodies, std::vect
 	if (ht_physics_update(rigidbodies[0]->ctx, rigidbodies[0]->which, 1, l.data(), nl, &nl, a.data(), na, &na) != HT_OK) throw std::runtime_error(std::string("PhysicsUpdate: ") + ht_last_error(rigidbodies[0]->ctx));
 }
 
+// std::vector<float3> PointCloud(const Image<T> &dimage, float2 filter_range) (misc_image.h:409-417): the in-range pixels of a depth image as camera-space
+// points, in row-major order (what synthetic-tracker.cpp:233 draws; the tracker's own cloud is made on the device, k_prepare).  Same expressions as the
+// reference: d = pixel * depth_scale, kept when filter_range.x <= d < filter_range.y, point = ((x - cx) / fx, (y - cy) / fy, 1) * d.
+template <class T> std::vector<float3> PointCloud(const Image<T> &dimage, float2 filter_range)
+{
+	std::vector<float3> pointcloud;
+	const DCamera &c = dimage.cam;
+	for (int y = 0; y < dimage.dim().y; y++) for (int x = 0; x < dimage.dim().x; x++)
+	{
+		const float d = dimage.raster[(size_t)y * dimage.dim().x + x] * c.depth_scale;
+		if (d >= filter_range.x && d < filter_range.y) pointcloud.push_back({ ((float)x - c.principal().x) / c.focal().x * d, ((float)y - c.principal().y) / c.focal().y * d, 1.0f * d });
+	}
+	return pointcloud;
+}
 inline DCamera camsub(const DCamera &c, int s)                                               // misc_image.h:60
 {
 	return DCamera({ c.dim().x / s, c.dim().y / s }, { c.focal().x / (float)s, c.focal().y / (float)s }, { c.principal().x / (float)s, c.principal().y / (float)s }, c.depth_scale, c.pose);
@@ -471,5 +485,5 @@ inline PhysModel LoadHandModel(const char *jsonfile = "../assets/model_hand.json
 using ht_mi355x::float2; using ht_mi355x::float3; using ht_mi355x::float4; using ht_mi355x::int2; using ht_mi355x::int3;
 using ht_mi355x::Pose; using ht_mi355x::DCamera; using ht_mi355x::Image; using ht_mi355x::Mesh; using ht_mi355x::CNN; using ht_mi355x::HandTracker; using ht_mi355x::PhysModel;
 using ht_mi355x::RigidBody; using ht_mi355x::LimitLinear; using ht_mi355x::LimitAngular; using ht_mi355x::PhysicsUpdate; using ht_mi355x::Addresses;
-using ht_mi355x::HandSegmentVR; using ht_mi355x::camsub; using ht_mi355x::GatherHandExpectedCNN; using ht_mi355x::PoseInitializerCNN; using ht_mi355x::LoadHandModel;
+using ht_mi355x::HandSegmentVR; using ht_mi355x::PointCloud; using ht_mi355x::camsub; using ht_mi355x::GatherHandExpectedCNN; using ht_mi355x::PoseInitializerCNN; using ht_mi355x::LoadHandModel;
 #endif

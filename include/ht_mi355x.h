@@ -161,6 +161,11 @@ int ht_point_capacity(ht_ctx *ctx, int *points);
 int ht_update_cnn_model_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int w, int h, float segment_scale, int B, int apply_to_handmodel,
                              float *poses_out, int *accepted_out, float *cnn_out);
 int ht_get_cnn_results(ht_ctx *ctx, int first, int n, float *cnn_input, float *cnn_output, float *analysis);
+/* ht_get_cnn_layers   the intermediate layers of the latest CNN evaluation of slots [first, first + n), for per-layer parity tests (the reference returns every
+ *                     layer's output from its forward() calls, cnn.h:550-556): act1 [n][3600] after conv 5x5 + tanh + two max-pools (layer 3 of the list,
+ *                     handtrack.h:108-111), act2 [n][2304] after conv 4x4 + tanh + pool (layer 6), act3 [n][2048] after the first fully connected layer + tanh
+ *                     (layer 8), logits [n][2304] after the second one (layer 9, before the chunked soft-max).  Any pointer may be NULL. */
+int ht_get_cnn_layers(ht_ctx *ctx, int first, int n, float *act1, float *act2, float *act3, float *logits);
 /* ht_capacity_events  how often, since ht_create, the contact kernel hit a capacity the reference does not have: expanding-polytope runs cut
  *                     short (gjk.h:417 / hull.h:233-310 loop without bound; here at most 128 iterations, 96 vertices, 192 triangles) and contacts
  *                     beyond 96 per frame and launch (physics.h:451-462 keeps them all); solves in which a model's angular rows exceeded the 126
@@ -229,6 +234,8 @@ int ht_slowfit(ht_ctx *ctx, int B, int hold, const float *refpose, int steps, in
  * ht_stage_cloud_rows CloudConstraints (physmodel.h:164-181) of model `which`, every `stride`-th prepared point, ray origin =
  *                     camera position if use_cam_origin else 0: rows [B][HT_MAX_POINTS][16] (layout: rb0 rb1 position0 position1 normal
  *                     targetdist targetspeednobias forcelimit.xy friction_master), nrows [B].
+ * ht_stage_chamber    cloud_chamber (physmodel.h:486-496) with the five directions and the force limit of handtrack.h:774-778, of model `which` against the
+ *                     prepared points: rows [B][5*nb][16], nrows [B] (0 unless boundary_planes is set and the frame has more than min_point_num points).
  * ht_stage_contacts   FindShapeShapeContacts (physics.h:451-462): contacts [B][cap][12] (rb0 rb1 normal p0w p1w separation), n [B].
  * ht_stage_fit        one PhysModel::FitPointCloud(points, chamber-rows-if-enabled, HandModelEnhancements) pass on handmodel
  *                     exactly as HandTracker::update runs it (handtrack.h:769-780).
@@ -237,6 +244,7 @@ int ht_stage_prepare(ht_ctx *ctx, const uint16_t *depth, const float *cams, int 
 int ht_stage_decode(ht_ctx *ctx, const float *cnn_out, const float *cams, int B, float *analysis);
 int ht_stage_fit_error(ht_ctx *ctx, int which, int B, float *err);
 int ht_stage_cloud_rows(ht_ctx *ctx, int which, int stride, int use_cam_origin, int B, float *rows, int *nrows);
+int ht_stage_chamber(ht_ctx *ctx, int which, int B, float *rows, int *nrows);
 int ht_stage_contacts(ht_ctx *ctx, int which, int B, int cap, float *contacts, int *ncontacts);
 int ht_stage_fit(ht_ctx *ctx, int B);
 int ht_stage_multistep(ht_ctx *ctx, const float *analysis, int B);

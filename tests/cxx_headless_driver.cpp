@@ -3,6 +3,7 @@
 // without the window.  Our own code: the reference's application is not copied, only its use of the API is followed.
 //
 //   driver fakedepth <model> <in.bin> <out.bin>      host only: pose a fake hand, ray-cast a depth frame (FakeDepth)
+//   driver pointcloud - <in.bin> <out.bin>           host only: PointCloud(dimage, {0.1, 0.7}) of every frame: i32 n, n x float3
 //   driver track <model> <weights.cnnb> <in.bin> <out.bin>      the tracking loop on given frames (needs the GPU)
 //
 // in.bin:  int32 n, w, h, nb; then n records { u16 depth[w*h]; f32 cam[12]; f32 start[nb][7]; f32 gt[nb][7] }
@@ -65,6 +66,21 @@ int main(int argc, char **argv)
 			}
 			fclose(o);
 			printf("fakedepth: %zu frames of %dx%d, %zu mesh triangles on bone 1\n", recs.size(), w, h, fakehand.GetMeshes(true)[1].tris.size());
+			return 0;
+		}
+		if (mode == "pointcloud")      // host only: PointCloud(dimage, {0.1, drangey}) as synthetic-tracker.cpp:233 calls it; argv: pointcloud - <in> <out>
+		{
+			auto recs = read_input(argv[3], w, h, nb);
+			FILE *o = fopen(argv[4], "wb");
+			for (auto &r : recs)
+			{
+				Image<unsigned short> dimage(camera_of(r.cam, w, h), r.depth);
+				auto pts = PointCloud(dimage, { 0.1f, 0.7f });
+				const int n = (int)pts.size();
+				fwrite(&n, 4, 1, o); fwrite(pts.data(), sizeof(float3), pts.size(), o);
+			}
+			fclose(o);
+			printf("pointcloud: %zu frames\n", recs.size());
 			return 0;
 		}
 		if (mode != "track" || argc < 6) return 2;

@@ -53,6 +53,60 @@ def test_cnn_eval_matches_golden(ctx, golden):
     assert np.allclose(out.sum(axis=1), 24.0, atol=1e-3)
 
 
+def test_cnn_layers_match_the_references_layer_outputs(ctx, golden, weights):
+    """Each kernel of the forward pass against the layer outputs of the reference (cnn.h:550-556 returns every layer's vector): k_conv1 = layers 0-3
+    (conv 5x5, tanh, two pools), k_conv2 = layers 4-6, k_fc<tanh> = layers 7-8, k_fc144 = layer 9, soft-max = layer 10.  Frame 0 against the
+    reference's own dump in the fixture, all eight frames against the C restatement (which reproduces that dump bit for bit,
+    test_oracle_vs_golden.py::test_cnn_layers_bit_exact).  A compensating error in two layers cannot pass here."""
+    depth, cams = _frames(golden)
+    cnn_in, _, _ = ctx.stage_prepare(depth, cams)
+    out = ctx.cnn_eval(cnn_in)
+    a1, a2, a3, lg = ctx.cnn_layers(8)
+    names = {3: "conv1+tanh+pool+pool", 6: "conv2+tanh+pool", 8: "fc1+tanh", 9: "fc2", 10: "softmax"}
+    sizes = (57600, 57600, 14400, 3600, 9216, 9216, 2304, 2048, 2048, 2304, 2304)
+    L = ol.lib()
+    worst = {}
+    for f in range(8):
+        layers = [np.zeros(n, np.float32) for n in sizes]
+        arr = (C.POINTER(C.c_float) * 11)(*[ol.fptr(a) for a in layers])
+        ref_out = np.zeros(2304, np.float32)
+        L.ho_cnn_eval(ol.fptr(weights), ol.fptr(np.ascontiguousarray(cnn_in[f])), ol.fptr(ref_out), arr)
+        got = {3: a1[f], 6: a2[f], 8: a3[f], 9: lg[f], 10: out[f]}
+        for li, name in names.items():
+            if f == 0:
+                assert np.array_equal(layers[li], golden["f0/cnn_layer%d" % li])      # the checker is the reference's dump on this frame
+            worst[name] = max(worst.get(name, 0.0), float(np.abs(got[li] - layers[li]).max()))
+    print("per-layer max abs err vs the reference:", {k: "%.2e" % v for k, v in worst.items()})
+    # activations are tanh outputs in [-1, 1] (absolute bound as for the output); the logits reach a few units times the gain of 24
+    assert worst["conv1+tanh+pool+pool"] <= 2e-6 and worst["conv2+tanh+pool"] <= 5e-6 and worst["fc1+tanh"] <= 1e-5 and worst["fc2"] <= 1e-4 and worst["softmax"] <= CNN_ATOL
+
+
+def test_cnn_eval_full_batch_vs_oracle(weights):
+    """ht_cnn_eval at the batch the last fully connected layer is tiled for (1024 frames = 16 x 16 blocks of 64 x 144): a strided sample of 64 frames
+    against the C restatement, and every copy of a frame bit-identical to the others (a frame's result does not depend on its slot)."""
+    from hand_tracking_samples_amd import native
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frames256.npz"))
+    B = 1024
+    idx = np.arange(B) % 256
+    c = native.Context(ol.MODEL, B)
+    try:
+        c.load_weights(weights)
+        cnn_in, _, _ = c.stage_prepare(d["depth"][idx].reshape(B, -1), d["cam"][idx])
+        out = c.cnn_eval(cnn_in)
+    finally:
+        c.close()
+    for k in range(1, 4):
+        assert np.array_equal(out[:256], out[256 * k:256 * (k + 1)])
+    L = ol.lib()
+    worst = 0.0
+    for i in range(0, B, 16):
+        ref = np.zeros(2304, np.float32)
+        L.ho_cnn_eval(ol.fptr(weights), ol.fptr(np.ascontiguousarray(cnn_in[i])), ol.fptr(ref), None)
+        worst = max(worst, float(np.abs(out[i] - ref).max()))
+    print("cnn at B=1024, 64 sampled frames: max abs err %.3e" % worst)
+    assert worst <= CNN_ATOL
+
+
 def test_cnn_eval_random_inputs_vs_oracle(ctx, weights):
     """Seeded random tiles (including all-zero and all-one inputs) at a batch that is not a multiple of the GEMM tile."""
     rng = np.random.default_rng(7)

@@ -85,6 +85,27 @@ def test_cloud_rows_bit_exact(ctx, golden):
         assert np.array_equal(rows[f, :n[f]], ref), "frame %d" % f
 
 
+def test_chamber_rows_bit_exact(ctx, golden):
+    """cloud_chamber (physmodel.h:486-496): the five silhouette planes and one ConstrainUnderPlane row per (plane, body), against the rows the reference
+    built for the start pose and the full cloud of each golden frame.  min_point_num = 0 switches the rows on for every frame (the reference dumped them
+    for every frame); the gate itself (handtrack.h:774) is checked on the frames' real point counts."""
+    depth, cams, start = _inputs(golden)
+    ctx.stage_prepare(depth, cams)
+    ctx.tracker_reset(start)
+    ctx.set_params(min_point_num=0)
+    try:
+        rows, n = ctx.stage_chamber(0, NF)
+    finally:
+        ctx.set_params(min_point_num=400)
+    for f in range(NF):
+        ref = golden["f%d/chamber_rows" % f]
+        assert n[f] == len(ref) == 85
+        assert np.array_equal(rows[f, :n[f]], ref), "frame %d" % f
+    rows, n = ctx.stage_chamber(0, NF)
+    npts = [len(golden["f%d/vpts" % f]) for f in range(NF)]
+    assert list(n) == [85 if p > 400 else 0 for p in npts] and 0 < sum(p > 400 for p in npts) < NF
+
+
 def test_contacts_bit_exact(ctx, golden):
     depth, cams, start = _inputs(golden)
     ctx.tracker_reset(start)

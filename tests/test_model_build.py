@@ -96,3 +96,16 @@ def test_create_from_json_builds_on_the_fly(tmp_path):
         assert (ctx.nb, ctx.nj) == (3, 2)
     finally:
         ctx.close()
+
+
+def test_shipped_model_assets_are_what_the_reference_builds():
+    """bench.py and smoke() run on hand_tracking_samples_amd/assets/model_hand*.htfx, baked by the product's own builder (tools/bake_assets.sh): every array
+    the reference's constructor produced (the fixtures under tests/golden/) is in them, bit for bit."""
+    import htfx
+    for n in ("17", "26"):
+        ours = htfx.load(os.path.join(os.path.dirname(HERE), "hand_tracking_samples_amd", "assets", "model_hand%s.htfx" % n))
+        ref = htfx.load(os.path.join(HERE, "golden", "model_hand%s.htfx" % n))
+        shared = [k for k in ref if k in ours]
+        assert len(shared) >= 60, "only %d arrays in common" % len(shared)
+        for k in shared:
+            assert np.array_equal(ours[k], ref[k]), "model_hand%s: %s" % (n, k)
