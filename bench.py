@@ -37,7 +37,7 @@ FP32_MFMA_PEAK_TF = 157.3      # dense fp32 MFMA (= fp32 vector) peak
 FP32_VALU_PEAK_TF = 157.3
 CNN_FLOP = {"cnn": 26.47e6,    # 2*(1440000 + 2359296 + 4718592 + 4718592), SURVEY 8(d)
             "cnn128": 2.0 * (124 * 124 * 25 * 16 + 28 * 28 * 256 * 64 + 12544 * 2048 + 2048 * 2304)}
-TUNING_ENV = ("HT_DEBUG_SKIP", "HT_NO_SIDE", "HT_NO_OVERLAP")
+TUNING_ENV = ("HT_DEBUG_SKIP", "HT_NO_SIDE", "HT_NO_OVERLAP", "HT_RESET_JOIN")
 VERIFY_POS_TOL, VERIFY_QUAT_TOL, VERIFY_CNN_TOL = 2e-4, 2e-3, 2e-5      # the tolerances of tests/test_gpu_solver.py (whole path)
 
 

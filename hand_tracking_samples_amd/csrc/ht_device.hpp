@@ -43,6 +43,14 @@ static inline int ht_tuning_flags()
 #else
 #define HT_DBG(flags, bit) 0
 #endif
+static inline int ht_tuning_int(const char *name, int def)
+{
+#ifdef HT_TUNING
+	const char *e = getenv(name); return e ? atoi(e) : def;
+#else
+	(void)name; return def;
+#endif
+}
 static inline bool ht_tuning_env(const char *name)
 {
 #ifdef HT_TUNING

@@ -182,12 +182,23 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		// MultiStepSim (which uses no cloud rows) proceeds for all other frames; the reset frames then do their step 0 on their own.
 		// (Taking the reset frames through ALL their steps on the side stream was measured: their five few-frame steps are pure latency and end
 		// later than the main stream's full-batch steps plus this one extra step, 4.6 against 4.5 ms.)
+		static const int join_step = ht_tuning_int("HT_RESET_JOIN", 0);      // experiment (-DHT_TUNING): the reset frames take steps [0, join_step) on the side stream
 		fork(ctx, s);
 		reset_path(ctx, ctx->d_flags, p.steps_unibody, B, ctx->side[0], s);
+		if (join_step > 0)
+		{
+			multistep(ctx, B, ctx->side[0], 0, join_step, ctx->d_flags, false, -1, false, true);
+			multistep(ctx, B, s, 0, join_step, ctx->d_nflags, false, 1, true, true);
+			join(ctx, s, 1);
+			multistep(ctx, B, s, join_step);
+		}
+		else
+		{
 		multistep(ctx, B, s, 0, 1, ctx->d_nflags, false, 0, true, true);
 		join(ctx, s, 1);
 		multistep(ctx, B, s, 0, 1, ctx->d_flags);
 		multistep(ctx, B, s, 1);
+		}
 	}
 	else
 	{
