@@ -588,13 +588,14 @@ int ht_reserve_points_locked(ht_ctx *ctx, int points)
 	const size_t B = (size_t)ctx->B, nb = (size_t)ctx->model.nb, cap = (size_t)want;
 	HIPCHK(ctx, ht_sync_all(ctx));
 	const bool had_voxel = ctx->d_ptsv != nullptr;
-	void *old[4] = { ctx->d_pts, ctx->d_rows, ctx->d_scratch, ctx->d_ptsv };
+	void *old[5] = { ctx->d_pts, ctx->d_rows, ctx->d_scratch, ctx->d_ptsv, ctx->d_rowbody };
 	for (void *o : old) if (o) { for (auto &q : ctx->allocs) if (q == o) { q = ctx->allocs.back(); ctx->allocs.pop_back(); break; } (void)hipFree(o); }
-	ctx->d_pts = nullptr; ctx->d_rows = nullptr; ctx->d_scratch = nullptr; ctx->d_ptsv = nullptr; ctx->model.pts_cap = 0;
+	ctx->d_pts = nullptr; ctx->d_rows = nullptr; ctx->d_scratch = nullptr; ctx->d_ptsv = nullptr; ctx->d_rowbody = nullptr; ctx->model.pts_cap = 0;
 	int r;
 	if ((r = dev_alloc(ctx, &ctx->d_pts, B * cap))) return r;
 	if ((r = dev_alloc(ctx, &ctx->d_rows, B * cap * HT_ROW))) return r;
-	if ((r = dev_alloc(ctx, &ctx->d_scratch, B * ht_scratch_rows(cap, nb) * (HT_CREC + 1)))) return r;      // a row record + 1 float for the impulse sum of over-size frames
+	if ((r = dev_alloc(ctx, &ctx->d_rowbody, B * cap))) return r;
+	if ((r = dev_alloc(ctx, &ctx->d_scratch, B * ht_scratch_rows(cap, nb) * (HT_CREC + 2)))) return r;      // a row record + 1 float for the impulse sum and 1 word for the chain entry of frames that do not fit k_solve's LDS
 	if (had_voxel && (r = dev_alloc(ctx, &ctx->d_ptsv, B * cap))) return r;
 	ctx->model.pts_cap = want;
 	return HT_OK;

@@ -13,6 +13,7 @@
 // All arithmetic keeps the reference's evaluation order (-ffp-contract=off), so rows are bit-identical to the CPU path.
 #include "ht_device.hpp"
 #include "ht_launch.hpp"
+#include "ht_quad.hpp"
 
 extern __shared__ __attribute__((aligned(16))) float4 s_planes[];      // all face planes of the model, staged once per block (25 KB for the hand)
 __device__ __forceinline__ void stage_planes(const ht_model_dev &M, int t, int nthreads)
@@ -180,10 +181,11 @@ __device__ __forceinline__ void closest_chunk(const ht_model_dev &M, const float
 __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const float *__restrict__ state, const float4 *__restrict__ pts, const int *__restrict__ npts,
                                                            const float *__restrict__ cams, const int *__restrict__ active_flag, int stride, int use_cam_origin, int mode,
                                                            float microforce, float weak_force, float cf_max_point, float cf_max_sum, float unibody_force,
-                                                           float *__restrict__ rows, int *__restrict__ nrows)
+                                                           float *__restrict__ rows, int *__restrict__ nrows, cloud_records rec)
 {
 	__shared__ float tab[HT_MAXNB * BT];
 	__shared__ closest_lds L;
+	__shared__ float wq[HT_MAXNB][4], wI[HT_MAXNB][10];      // record mode: the bodies' orientations, world inverse inertia and inverse mass, as k_solve forms them
 	const int b = blockIdx.x, t = threadIdx.x;
 	const int n = npts[b];
 	const int nsub = (n + stride - 1) / stride;
@@ -191,6 +193,16 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 	if ((int)blockIdx.y * CH >= nsub && blockIdx.y > 0) return;      // gridDim.y blocks share a frame's passes (a row only depends on its own point)
 	if (t == 0 && blockIdx.y == 0) nrows[b] = nsub;
 	if (t < 64) body_table_build(M, state + (size_t)b * M.nb * HT_STATE_STRIDE, tab, t);
+	if (rec.scratch && t >= 64 && t < 64 + M.nb)      // rbinitvelocity's world inverse inertia (physics.h:517-518), the expression of k_solve's prologue
+	{
+		const int k = t - 64;
+		const float *s = state + ((size_t)b * M.nb + k) * HT_STATE_STRIDE, *bc = M.bodyc + k * HT_BC;
+		const v4 q = V4(s[3], s[4], s[5], s[6]);
+		m3 T; T.x = V3(bc[HT_BC_TINV], bc[HT_BC_TINV + 1], bc[HT_BC_TINV + 2]); T.y = V3(bc[HT_BC_TINV + 3], bc[HT_BC_TINV + 4], bc[HT_BC_TINV + 5]); T.z = V3(bc[HT_BC_TINV + 6], bc[HT_BC_TINV + 7], bc[HT_BC_TINV + 8]);
+		const m3 I = world_inertia(q, T, bc[HT_BC_MASSINV]);
+		wq[k][0] = q.x; wq[k][1] = q.y; wq[k][2] = q.z; wq[k][3] = q.w;
+		wI[k][0] = I.x.x; wI[k][1] = I.x.y; wI[k][2] = I.x.z; wI[k][3] = I.y.x; wI[k][4] = I.y.y; wI[k][5] = I.y.z; wI[k][6] = I.z.x; wI[k][7] = I.z.y; wI[k][8] = I.z.z; wI[k][9] = bc[HT_BC_MASSINV];
+	}
 	stage_planes(M, t, CR_THREADS);
 	__syncthreads();
 	const float *cam = cams + (size_t)b * HT_CAM;
@@ -245,6 +257,17 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 		else if (mode == 2) { float cloudforce = fmin_std(cf_max_point, cf_max_sum / (float)n); float k = (rb == 0) ? 0.1f : 1.0f; fmin = -cloudforce * k; fmax = cloudforce * k; }
 		else if (mode == 3) { fmin = -1.0f * unibody_force; fmax = 1.0f * unibody_force; }
 		else if (mode == 4) { const float k = (microforce * weak_force) * ((rb == 0) ? cf_max_point : 1.0f); fmin = -1.0f * k; fmax = 1.0f * k; }      // slowfit handtrack.h:815-816: weak_force = step ratio, cf_max_point = wrist factor
+		if (rec.scratch)      // the solver's record of this row (ht_quad.hpp), at the point's index of the frame's scratch slot, and the row's body beside it
+		{
+			const v4 q = V4(wq[rb][0], wq[rb][1], wq[rb][2], wq[rb][3]);
+			m3 I; I.x = V3(wI[rb][0], wI[rb][1], wI[rb][2]); I.y = V3(wI[rb][3], wI[rb][4], wI[rb][5]); I.z = V3(wI[rb][6], wI[rb][7], wI[rb][8]);
+			const v3 r1 = qrot(q, position1);                                                     // LimitLinear::Iter physics.h:294
+			const float impulsed = wI[rb][9] + dot(cross(mul(I, cross(r1, normal)), r1), normal);  // physics.h:299-300 with rb0 == NULL
+			const float ts = targetdist / rec.dt;                                                  // PhysicsUpdate physics.h:553-554
+			quad_write_record(rec.scratch + ((size_t)b * rec.stride + i) * HT_CREC, r1, normal, I, wI[rb][9], ts, fmin_std(ts, 0.0f), impulsed, fmin_std(fmin, fmax) * rec.dt, fmax_std(fmin, fmax) * rec.dt);
+			rec.body[(size_t)b * M.pts_cap + i] = (unsigned char)rb;
+			continue;
+		}
 		float4 *out = reinterpret_cast<float4 *>(rows + ((size_t)b * M.pts_cap + i) * HT_ROW);
 		out[0] = make_float4(-1.0f, (float)rb, v.x, v.y);
 		out[1] = make_float4(v.z, position1.x, position1.y, position1.z);
@@ -364,9 +387,12 @@ __global__ __launch_bounds__(64) void k_chamber(ht_model_dev M, const float *__r
 }
 
 // ------------------------------------------------------------------------------------------------- launchers
+// `rec`: instead of the 16-float rows, write each row's solver record into the frames' scratch slots and the rows' bodies into rec->body (k_solve then only
+// lists them per body); null: the reference-layout rows (stage calls, UnibodyFit)
 void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const float *cams, const int *active_flag, int stride, int use_cam_origin, int mode,
-                          const ht_params &par, float *rows, int *nrows, int B, hipStream_t s, float sf_ratio, float sf_wrist)
+                          const ht_params &par, float *rows, int *nrows, int B, hipStream_t s, float sf_ratio, float sf_wrist, const cloud_records *rec)
 {
+	const cloud_records none = { nullptr, 0, nullptr, 0.0f };
 	// blocks per frame: a frame's passes of CH points are independent, so while the batch leaves CUs idle they are spread over up to `split` blocks
 	// (each pays the prologue -- body table, 25 KB of planes into LDS -- again, which is why a large batch keeps one block per frame)
 	const int pts_max = M.pts_bound > 0 ? M.pts_bound : M.pts_cap, passes = ((pts_max + stride - 1) / stride + CH - 1) / CH;
@@ -377,7 +403,7 @@ void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float
 	if (split > passes) split = passes;
 	if (split < 1) split = 1;
 	hipLaunchKernelGGL(k_cloud_rows, dim3(B, split), dim3(CR_THREADS), (size_t)M.plane_off[M.nb] * sizeof(float4), s, M, state, pts, npts, cams, active_flag, stride, use_cam_origin, mode, par.microforce,
-	                   mode == 4 ? sf_ratio : par.physics_weak_force, mode == 4 ? sf_wrist : par.cloudforce_max_point, par.cloudforce_max_sum, par.unibody_force, rows, nrows);
+	                   mode == 4 ? sf_ratio : par.physics_weak_force, mode == 4 ? sf_wrist : par.cloudforce_max_point, par.cloudforce_max_sum, par.unibody_force, rows, nrows, rec ? *rec : none);
 }
 void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, int w, int h, float scale, float *err, int B, hipStream_t s)
 {

@@ -45,7 +45,8 @@ struct ht_ctx
 	float *d_state[2] = { nullptr, nullptr };      // [B][nb][HT_STATE_STRIDE]: 0 handmodel, 1 othermodel
 	float *d_prev_err = nullptr; int *d_initializing = nullptr;
 	float *d_err_old = nullptr, *d_err_new = nullptr; int *d_flags = nullptr, *d_nflags = nullptr;
-	float *d_rows = nullptr; int *d_nrows = nullptr;            // cloud rows [B][pts_cap][HT_ROW]
+	float *d_rows = nullptr; int *d_nrows = nullptr;            // cloud rows [B][pts_cap][HT_ROW] in the reference's layout (stage calls, UnibodyFit, caller-built rows)
+	unsigned char *d_rowbody = nullptr;                          // [B][pts_cap] body of every cloud row whose solver record k_cloud_rows wrote into d_scratch
 	float *d_chamber = nullptr; int *d_nchamber = nullptr;      // [B][5*nb][HT_ROW]
 	int *d_accepted = nullptr;
 	float *d_contacts = nullptr; int *d_ncontacts = nullptr;    // [B][HT_MAXCONTACT][HT_CONTACT]

@@ -6,6 +6,7 @@ struct solve_args
 {
 	const float *rows_pre; const int *n_pre; int pre_stride;      // chamber rows [B][pre_stride][HT_ROW] (may be null)
 	const float *rows_cloud; const int *n_cloud;                    // cloud rows [B][pts_cap][HT_ROW] (may be null)
+	const unsigned char *cloud_body;                                // [B][pts_cap]: k_cloud_rows has written the cloud rows' RECORDS into the frames' scratch slots (rows_cloud unused) and their bodies here
 	const float *contacts; const int *ncontacts;                    // [B][HT_MAXCONTACT][HT_CONTACT] (may be null)
 	// caller-built rows (ht_fit_rows / ht_physics_update = PhysModel::FitPointCloud's and PhysicsUpdate's row arguments; all may be null):
 	const float *ang_user; const int *n_ang_user; int ang_user_stride;        // angular rows [B][stride][HT_AROW]: first in the angular list
@@ -27,8 +28,10 @@ struct solve_args
 	int dbg;                                                        // timing experiments only (HT_DEBUG_SKIP): 1 skip chains, 2 skip two-body linear, 4 skip angular
 };
 
+// where k_cloud_rows puts the solver's records of its rows (ht_quad.hpp): the frames' scratch slots [B][stride][HT_CREC], the rows' bodies [B][pts_cap], the time step
+struct cloud_records { float *scratch; int stride; unsigned char *body; float dt; };
 void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const float *cams, const int *active_flag, int stride, int use_cam_origin, int mode,
-                          const ht_params &par, float *rows, int *nrows, int B, hipStream_t s, float sf_ratio = 0.0f, float sf_wrist = 0.0f);
+                          const ht_params &par, float *rows, int *nrows, int B, hipStream_t s, float sf_ratio = 0.0f, float sf_wrist = 0.0f, const cloud_records *rec = nullptr);
 void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, int w, int h, float scale, float *err, int B, hipStream_t s);
 void ht_launch_chamber(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, int min_point_num, int enabled, float maxforce, float *rows, int *nch, int B, hipStream_t s);
 void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s);
@@ -39,7 +42,7 @@ void ht_launch_get_state(const float *state, float *dst, int nb, int n, hipStrea
 void ht_launch_clear_flags(float *prev_err, int *initializing, int n, hipStream_t s);
 void ht_launch_decide_reset(const float *err_old, float thr, int angles_only, int *flags, int *nflags, int n, hipStream_t s);
 void ht_launch_scratch(const ht_model_dev &M, float *state, const float4 *pts, const int *npts, const float *analysis, const float *cams, const int *flags, int B, hipStream_t s);
-void ht_launch_unibody(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float *rows, const int *nrows, const int *flags, float *scratch, int scratch_stride, int B, hipStream_t s);
+void ht_launch_unibody(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float *rows, const int *nrows, const int *flags, float *scratch, int scratch_stride, int batch, int B, hipStream_t s);
 void ht_launch_accept(float *hand, const float *other, const float *err_old, const float *err_new, const int *npts, float *prev_err, int *initializing, int *accepted, int nb, int n, const ht_params &p, hipStream_t s);
 void ht_launch_output(const ht_model_dev &M, const float *hand, const int *npts, int *initializing, int min_point_num, float *poses, int n, hipStream_t s, int raw = 0);
 // ht_segment.hip

@@ -68,75 +68,86 @@ __device__ __forceinline__ float div_ieee_r(float x, float y, float r)
 // <= 2e-7 m / 6e-6 (quaternion) per solver stage on the golden frames and, over the whole unit of work on the 256 bench frames, by LESS than the
 // reference itself moves between its IEEE and its FMA-contracted build (tests/golden/ref_flag_spread.py, DESIGN.md section 4 "Numerics").
 //
-// Record of one single-body row (LimitLinear with rb0 == NULL), 4 x 16 bytes, laid out by the lane that reads each part:
-//   slot c (c = 0,1,2)  lane c of the quad:  n[c], g[c], b[c], and in the fourth word fmin*dt (slot 0) / fmax*dt (slot 1)
-//   slot 3              lane 3:  targetspeed, 1 / effective mass, targetspeed after RemoveBias (physics.h:288: min(ts, ts_nobias)), 0
+// Record of one single-body row (LimitLinear with rb0 == NULL), 4 x 16 bytes, laid out by the lane that reads each part (written by the kernel that makes
+// the row: k_cloud_rows for the cloud rows, k_solve's prologue for the landmark-ray, boundary-plane and caller-built rows).  The reciprocal of the effective
+// mass is folded into the coefficients, so the dot product IS vn / effective mass and the impulse is one subtraction away:
+//   slot c (c = 0,1,2)  lane c of the quad:  n[c]*massinv/effmass, g[c], b[c]/effmass, n[c]
+//   slot 3              lane 3:  targetspeed/effmass, the same after RemoveBias (physics.h:288: min(ts, ts_nobias)), fmin*dt, fmax*dt
 // The records are read-only during the sweeps; the one value a row changes, its impulse sum, lives in an LDS array beside them (a store into
 // the record would sit in the same in-order memory queue as the reads of the rows ahead and hold them back until it is acknowledged).
-// Lane c < 3 carries component c of the body's momenta; lane 3 does the scalar part of the row (impulse, clamp, impulse sum), takes the two
-// force limits from lanes 0 and 1 and hands the impulse to the others, all through DPP operands.  Per row each lane issues ONE 16-byte read
-// (the texture path moves 64 B per clock per CU, i.e. 16 clocks per such wave instruction: with four to eight waves per CU walking chains
-// that path, not the arithmetic, is what a second read per row would saturate), one LDS read and one LDS write.
+// Lane c < 3 carries component c of the body's momenta; lane 3 does the scalar part of the row (impulse, clamp, impulse sum) and hands the impulse to
+// the others through a DPP operand.  Per row each lane issues ONE 16-byte read (the texture path moves 64 B per clock per CU, i.e. 16 clocks per
+// such wave instruction: with four to eight waves per CU walking chains that path, not the arithmetic, is what a second read per row would
+// saturate), one LDS read and one LDS write.
 #define CREC HT_CREC       // floats per record
 #define QP_PREV 0x90       // quad_perm:[0,0,1,2]: lane i reads lane i-1 of its quad
-struct quad_body { float l, av, minv; };      // this lane's component of the linear / angular momentum, 1/mass
+struct quad_body { float l, av; };      // this lane's component of the linear / angular momentum
 
-// One LimitLinear::Iter: a = this lane's slot, sum = the row's impulse sum, post = sweeps after RemoveBias.  Returns the new impulse sum (on
+// One LimitLinear::Iter: a = this lane's slot, sum = the row's impulse sum, POST = sweeps after RemoveBias.  Returns the new impulse sum (on
 // every lane of the quad).
-__device__ __forceinline__ float quad_row_step(quad_body &B, const float4 a, const float sum, const int post)
+template <bool POST>
+__device__ __forceinline__ float quad_row_step(quad_body &B, const float4 a, const float sum)
 {
-	const float lm = (a.x * B.minv) * B.l;                               // (n[c] * massinv) * P[c]; the first product does not depend on the previous row
-	const float p = __fmaf_rn(a.z, B.av, lm);                            // + b[c] * L[c]
+	const float p = __fmaf_rn(a.z, B.av, a.x * B.l);                    // (n[c]*massinv*P[c] + b[c]*L[c]) / effective mass
 	const float t = dpp<QP_PREV>(p) + p;                                 // lane 1: p0 + p1
-	const float s = dpp<QP_PREV>(t) + p;                                 // lane 2: (p0 + p1) + p2 = vn
-	const float x = -(post ? a.z : a.x) - dpp<QP_PREV>(s);               // lane 3: -targetspeed - vn
-	float impulse = x * a.y;                                             // lane 3: a.y = 1 / effective mass
-	impulse = clamp_med3(impulse, dpp<QP_BC0>(a.w) - sum, dpp<QP_BC1>(a.w) - sum);
+	const float s = dpp<QP_PREV>(t) + p;                                 // lane 2: (p0 + p1) + p2 = vn / effective mass
+	const float x = -(POST ? a.y : a.x) - dpp<QP_PREV>(s);               // lane 3: (-targetspeed - vn) / effective mass
+	const float impulse = clamp_med3(x, a.z - sum, a.w - sum);           // lane 3: a.z = fmin*dt, a.w = fmax*dt
 	const float bi = dpp<QP_BC3>(impulse);
-	B.l = __fmaf_rn(a.x, bi, B.l);                                       // P += n * impulse
+	B.l = __fmaf_rn(a.w, bi, B.l);                                       // P += n * impulse
 	B.av = __fmaf_rn(a.y, bi, B.av);                                     // L += g * impulse
 	return sum + bi;      // the same value on all four lanes (they read the same sum): the quad's four writes to one address agree
 }
-// Applies rows [0, cnt) of one chain in order.  rec = the chain's first record, sums = the chain's first impulse sum (LDS), c = lane within the
-// quad, post = 1 after RemoveBias.  Sixteen register sets rotate: the read of a record is issued sixteen rows ahead of its use (a row is ~90 clocks
-// and the records stream from L2, the Infinity Cache or HBM: 200 / 550 / 900 clocks away), the read of its impulse sum eight rows ahead (LDS; a wave
-// keeps at most 15 LDS operations in flight).  The loop trips of the quads of a wave differ, the compiler masks finished quads off.
-// Reads run up to 31 records (and 23 sums) past the chain's end: the caller's buffers have that slack.
-#define QUAD_CHAIN_SLACK 32
+// Applies rows [0, cnt) of one chain in order.  The records of a frame lie where their producers wrote them (a cloud row's record at its point's index:
+// k_cloud_rows writes it; the other single-body rows behind them: k_solve's prologue), and a chain is a list of record indices: recs = the frame's first
+// record, idx = the chain's first index (LDS u16 or HBM u32), sums = the chain's first impulse sum, c = lane within the quad, post = 1 after RemoveBias.
+// Sixteen register sets rotate: the read of a record is issued sixteen rows ahead of its use (a row is ~95 clocks and the records stream from L2, the
+// Infinity Cache or HBM: 200 / 550 / 900 clocks away), its index is read another sixteen rows earlier, its impulse sum eight rows ahead (LDS; a wave keeps
+// at most 15 LDS operations in flight).  The loop trips of the quads of a wave differ, the compiler masks finished quads off.
+// Reads run up to 47 indices, 31 records (of valid indices) and 23 sums past the chain's end: the caller's arrays have that slack, zero-filled.
+#define QUAD_CHAIN_SLACK 48
 // A quad can walk TWO bodies' chains back to back (k_solve, models with more than 16 bodies: the 17th body's rows follow the host body's, which are
 // padded to a multiple of 8 with rows that change nothing): at row `kswitch` (a multiple of 8, or < 0 for none) the momenta go back to body `bodyA`'s
 // slots of lin_w / ang_w and body `bodyB`'s state is taken up.
 __device__ __forceinline__ void quad_switch_body(quad_body &B, int c, float *lin_w, float *ang_w, int bodyA, int bodyB)
 {
 	if (c < 3) { lin_w[4 * bodyA + c] = B.l; ang_w[4 * bodyA + c] = B.av; }
-	B.l = lin_w[4 * bodyB + c]; B.av = ang_w[4 * bodyB + c]; B.minv = lin_w[4 * bodyB + 3];
+	B.l = lin_w[4 * bodyB + c]; B.av = ang_w[4 * bodyB + c];
 }
-__device__ __forceinline__ void quad_chain_run(quad_body &B, const float *rec, float *sums, int cnt, int c, int post,
-                                               int kswitch = -1, float *lin_w = nullptr, float *ang_w = nullptr, int bodyA = 0, int bodyB = 0)
+template <bool POST, class IDX>
+__device__ __forceinline__ void quad_chain_run_(quad_body &B, const float *recs, const IDX *idx, float *sums, int cnt, int c,
+                                                int kswitch, float *lin_w, float *ang_w, int bodyA, int bodyB)
 {
-	const float4 *pa = reinterpret_cast<const float4 *>(rec) + c;
+	const float4 *pa = reinterpret_cast<const float4 *>(recs) + c;
+	const IDX *px = idx;
 	float *ps = sums;
 	// first reads in the order the loop consumes them (the wait counts the compiler derives for the loop are the minimum over both entries)
-#define QC_LA(i, row) a##i = pa[4 * (row)]; __builtin_amdgcn_sched_barrier(0)
+#define QC_LX(i, row) x##i = (unsigned)px[row]; __builtin_amdgcn_sched_barrier(0)
+#define QC_LA(i) a##i = pa[4 * x##i]; __builtin_amdgcn_sched_barrier(0)
 #define QC_LS(i, row) s##i = ps[row]; __builtin_amdgcn_sched_barrier(0)
 	float4 a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14, a15; float s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15;
-	QC_LA(0, 0); QC_LA(1, 1); QC_LA(2, 2); QC_LA(3, 3); QC_LA(4, 4); QC_LA(5, 5); QC_LA(6, 6); QC_LA(7, 7);
-	QC_LA(8, 8); QC_LA(9, 9); QC_LA(10, 10); QC_LA(11, 11); QC_LA(12, 12); QC_LA(13, 13); QC_LA(14, 14); QC_LA(15, 15);
+	unsigned x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11, x12, x13, x14, x15;
+	QC_LX(0, 0); QC_LX(1, 1); QC_LX(2, 2); QC_LX(3, 3); QC_LX(4, 4); QC_LX(5, 5); QC_LX(6, 6); QC_LX(7, 7);
+	QC_LX(8, 8); QC_LX(9, 9); QC_LX(10, 10); QC_LX(11, 11); QC_LX(12, 12); QC_LX(13, 13); QC_LX(14, 14); QC_LX(15, 15);
+	QC_LA(0); QC_LA(1); QC_LA(2); QC_LA(3); QC_LA(4); QC_LA(5); QC_LA(6); QC_LA(7); QC_LA(8); QC_LA(9); QC_LA(10); QC_LA(11); QC_LA(12); QC_LA(13); QC_LA(14); QC_LA(15);
+	QC_LX(0, 16); QC_LX(1, 17); QC_LX(2, 18); QC_LX(3, 19); QC_LX(4, 20); QC_LX(5, 21); QC_LX(6, 22); QC_LX(7, 23);
+	QC_LX(8, 24); QC_LX(9, 25); QC_LX(10, 26); QC_LX(11, 27); QC_LX(12, 28); QC_LX(13, 29); QC_LX(14, 30); QC_LX(15, 31);
 	QC_LS(0, 0); QC_LS(1, 1); QC_LS(2, 2); QC_LS(3, 3); QC_LS(4, 4); QC_LS(5, 5); QC_LS(6, 6); QC_LS(7, 7);
 	int k = 0;
 	// The scheduling barriers keep every row's instructions between its own pair: left alone, the ILP-first scheduler hoists the first use of the
 	// record that was requested last to the top of the trip as a hazard filler, which turns the wait for it into a wait for every outstanding
 	// read (s_waitcnt vmcnt(0)), i.e. one full memory round trip per trip.
-#define QC_STEP(i) ps[i] = quad_row_step(B, a##i, s##i, post)
-	// row i of the trip: apply it, then ask for the record sixteen rows on (same register set) and the impulse sum eight rows on (set i + 8)
-#define QC_ROW(i, j) QC_STEP(i); QC_LA(i, 16 + i); QC_LS(j, 8 + i)
+#define QC_STEP(i) ps[i] = quad_row_step<POST>(B, a##i, s##i)
+	// row i of the trip: apply it, then ask for the record sixteen rows on (same register set; its index came in during the last trip), the index
+	// thirty-two rows on and the impulse sum eight rows on (set i + 8)
+#define QC_ROW(i, j) QC_STEP(i); QC_LA(i); QC_LX(i, 32 + i); QC_LS(j, 8 + i)
 	for (; k + 16 <= cnt; k += 16)
 	{
 		if (k == kswitch) quad_switch_body(B, c, lin_w, ang_w, bodyA, bodyB);
 		QC_ROW(0, 8); QC_ROW(1, 9); QC_ROW(2, 10); QC_ROW(3, 11); QC_ROW(4, 12); QC_ROW(5, 13); QC_ROW(6, 14); QC_ROW(7, 15);
 		if (k + 8 == kswitch) quad_switch_body(B, c, lin_w, ang_w, bodyA, bodyB);
 		QC_ROW(8, 0); QC_ROW(9, 1); QC_ROW(10, 2); QC_ROW(11, 3); QC_ROW(12, 4); QC_ROW(13, 5); QC_ROW(14, 6); QC_ROW(15, 7);
-		pa += 64; ps += 16;
+		px += 16; ps += 16;
 	}
 	if (k == kswitch) quad_switch_body(B, c, lin_w, ang_w, bodyA, bodyB);
 	const int left = cnt - k;      // 0..15 rows: their records are in the register sets, the sums of the first eight too
@@ -145,6 +156,7 @@ __device__ __forceinline__ void quad_chain_run(quad_body &B, const float *rec, f
 	QC_TAIL_S(0, 8); QC_TAIL_S(1, 9); QC_TAIL_S(2, 10); QC_TAIL_S(3, 11); QC_TAIL_S(4, 12); QC_TAIL_S(5, 13); QC_TAIL_S(6, 14); QC_TAIL_S(7, 15);
 	if (left > 8 && k + 8 == kswitch) quad_switch_body(B, c, lin_w, ang_w, bodyA, bodyB);
 	QC_TAIL(8); QC_TAIL(9); QC_TAIL(10); QC_TAIL(11); QC_TAIL(12); QC_TAIL(13); QC_TAIL(14);
+#undef QC_LX
 #undef QC_LA
 #undef QC_LS
 #undef QC_STEP
@@ -152,18 +164,27 @@ __device__ __forceinline__ void quad_chain_run(quad_body &B, const float *rec, f
 #undef QC_TAIL
 #undef QC_TAIL_S
 }
-// fills one record (see the layout above); r1 = lever arm in the world frame, n = row direction, Iinv = the body's world inverse inertia,
-// y = effective mass (physics.h:299-300, formed by the caller with the reference's expression)
-__device__ __forceinline__ void quad_write_record(float *rec, v3 r1, v3 n, const m3 &Iinv, float ts, float ts_post, float y, float fmin_dt, float fmax_dt)
+// the sweeps before and after RemoveBias are two instances of the loop (the target-speed slot is chosen at compile time, not per row)
+template <class IDX>
+__device__ __forceinline__ void quad_chain_run(quad_body &B, const float *recs, const IDX *idx, float *sums, int cnt, int c, int post,
+                                               int kswitch = -1, float *lin_w = nullptr, float *ang_w = nullptr, int bodyA = 0, int bodyB = 0)
+{
+	if (post) quad_chain_run_<true>(B, recs, idx, sums, cnt, c, kswitch, lin_w, ang_w, bodyA, bodyB);
+	else quad_chain_run_<false>(B, recs, idx, sums, cnt, c, kswitch, lin_w, ang_w, bodyA, bodyB);
+}
+// fills one record (see the layout above); r1 = lever arm in the world frame, n = row direction, Iinv = the body's world inverse inertia, minv = its inverse
+// mass, y = effective mass (physics.h:299-300, formed by the caller with the reference's expression)
+__device__ __forceinline__ void quad_write_record(float *rec, v3 r1, v3 n, const m3 &Iinv, float minv, float ts, float ts_post, float y, float fmin_dt, float fmax_dt)
 {
 	float4 *o = reinterpret_cast<float4 *>(rec);
 	const v3 g = cross(r1, n), b = mul(Iinv, g);
-	o[0] = make_float4(n.x, g.x, b.x, fmin_dt); o[1] = make_float4(n.y, g.y, b.y, fmax_dt); o[2] = make_float4(n.z, g.z, b.z, 0.0f);
-	o[3] = make_float4(ts, 1.0f / y, ts_post, 0.0f);
+	const float rinv = 1.0f / y;
+	o[0] = make_float4((n.x * minv) * rinv, g.x, b.x * rinv, n.x); o[1] = make_float4((n.y * minv) * rinv, g.y, b.y * rinv, n.y); o[2] = make_float4((n.z * minv) * rinv, g.z, b.z * rinv, n.z);
+	o[3] = make_float4(ts * rinv, ts_post * rinv, fmin_dt, fmax_dt);
 }
 // a record that changes nothing (zero direction, zero limits: impulse 0)
 __device__ __forceinline__ void quad_write_noop(float *rec)
 {
 	float4 *o = reinterpret_cast<float4 *>(rec);
-	o[0] = o[1] = o[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); o[3] = make_float4(0.0f, 1.0f, 0.0f, 0.0f);
+	o[0] = o[1] = o[2] = o[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }

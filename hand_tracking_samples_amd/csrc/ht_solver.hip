@@ -62,9 +62,9 @@
 #define LM_FRIC 0x10000    // meta bits of a group: contact (friction rows limited by the normal row's impulse sum, physics.h:292)
 #define LM_NORMAL 0x20000
 
-template <int NGRP_, int NSUM_, int NANG_> struct lds_t
+template <int NGRP_, int NSUM_, int NANG_, int NIDX_> struct lds_t
 {
-	static constexpr int NGRP = NGRP_, NSUM = NSUM_, NANG = NANG_;
+	static constexpr int NGRP = NGRP_, NSUM = NSUM_, NANG = NANG_, NIDX = NIDX_;
 	static constexpr int LIDLE = MAXG - 1;                      // slot of the idle entry in lorder
 	static constexpr int NLEV = (MAXG > 64 * 2 ? MAXG : 64 * 2) + 2;      // levels of either schedule (linear groups, angular runs)
 	float pool[NGRP * LGRP] __attribute__((aligned(16)));      // two-body linear groups; first member: group addresses then fit the short offsets of two-address LDS reads
@@ -73,7 +73,8 @@ template <int NGRP_, int NSUM_, int NANG_> struct lds_t
 	float4 ang4[HT_MAXNB];                 // xyz angular momentum, w = friction
 	float4 I4[HT_MAXNB][3];                // columns of the world inverse inertia (w unused); prologue only
 	float pos[HT_MAXNB][3], q[HT_MAXNB][4];
-	float csum[NSUM];                      // impulse sum of every single-body row, in the order of the partitioned stream (+ read-ahead slack)
+	float csum[NSUM];                      // impulse sum of every single-body row, in chain order (+ read-ahead slack)
+	unsigned short cidx[NIDX > 0 ? NIDX : 2];   // the chains: record index of every single-body row, in chain order (+ read-ahead slack); in HBM when the build has no room
 	int ccnt[HT_MAXNB], cstart[HT_MAXNB];  // chain of body b: rows [cstart, cstart+ccnt) of the partitioned single-body stream
 	signed char cextra[HT_MAXNB];          // body b < 16 hosts the chain of this body >= 16 on its quad (-1: none): it follows b's rows, padded to a multiple of 8
 	unsigned lorder[MAXG];                 // two-body linear groups sorted by step: group | rb0 << 16 | rb1 << 24; last slot = the idle entry
@@ -211,10 +212,10 @@ __device__ __forceinline__ int angular_range_count(v3 lmin, v3 lmax)
 	return n;
 }
 
-template <int NGRP_, int NSUM_, int NANG_>
+template <int NGRP_, int NSUM_, int NANG_, int NIDX_>
 __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph, solve_args a)
 {
-	__shared__ lds_t<NGRP_, NSUM_, NANG_> S;
+	__shared__ lds_t<NGRP_, NSUM_, NANG_, NIDX_> S;
 	const int b = blockIdx.x, lane = threadIdx.x;
 	if (a.active_flag && !a.active_flag[b]) return;                // a launch never touches another launch's frames
 	const int nb = M.nb, nj = M.nj;
@@ -615,25 +616,37 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	const int nlev_lin = S.nlev_lin, nlev_ang = S.nlev_ang;
 	if (HT_DBG(a.dbg, 64)) return;
 
-	// ---- single-body prefix: [ray rows | chamber rows] then cloud rows; stable partition by body + pre-compute -> record stream in the frame's scratch (HBM / L2) ----
+	// ---- single-body prefix: [landmark-ray / boundary-plane / caller's rows] then the cloud rows.  Every row is reduced to a 64-byte record (ht_quad.hpp) where
+	//      its producer stands: a cloud row's record was written by k_cloud_rows at its point's index (a.cloud_body holds the rows' bodies), the others are
+	//      written here, behind the cloud's slots.  A chain is a list of record indices in the reference's row order (stable partition by body). ----
 	const int npre_g = a.rows_pre ? a.n_pre[b] : 0;
 	const int npre = a.ray_rows ? S.nray : npre_g;
-	const int ncl = a.rows_cloud ? a.n_cloud[b] : 0;
+	const int ncl = (a.rows_cloud || a.cloud_body) ? a.n_cloud[b] : 0;
 	const int n1 = npre + ncl;
-	const int npad_max = 7 * (nb > 16 ? nb - 16 : 0);      // rows that may be added to pad host chains (below)
-	const bool sums_lds = n1 + npad_max + QUAD_CHAIN_SLACK <= S.NSUM;
+	const int pre_base = M.pts_cap, noop_idx = rec_cap - 1;      // record indices: cloud row j -> j, other single-body row i -> pre_base + i, the record that changes nothing -> the last
+	const int npad_max = 7 * (nb > 16 ? nb - 16 : 0);      // entries that may be added to pad host chains (below)
+	const int nlist = n1 + npad_max + QUAD_CHAIN_SLACK;                                     // chain entries incl. read-ahead slack
+	const bool sums_lds = nlist <= S.NSUM;
+	const bool idx_lds = sums_lds && nlist <= S.NIDX && rec_cap <= 65536;
 	float *const gsum = a.scratch + (size_t)a.batch * a.scratch_stride * CREC + (size_t)b * a.scratch_stride;      // this frame's sums in HBM, behind all frames' records
-	if (sums_lds) { for (int i = lane; i < n1 + npad_max + QUAD_CHAIN_SLACK; i += 64) S.csum[i] = 0.0f; }
-	else for (int i = lane; i < n1 + npad_max + QUAD_CHAIN_SLACK && i < a.scratch_stride; i += 64) gsum[i] = 0.0f;
-	auto row_ptr = [&](int i) -> const float * {
-		if (i < npre) return a.ray_rows ? S.ray[i] : a.rows_pre + ((size_t)b * a.pre_stride + i) * HT_ROW;
-		return a.rows_cloud + ((size_t)b * M.pts_cap + (i - npre)) * HT_ROW;
+	unsigned *const gidx = reinterpret_cast<unsigned *>(a.scratch + (size_t)a.batch * a.scratch_stride * (CREC + 1)) + (size_t)b * a.scratch_stride;      // and its chain lists behind those
+	if (sums_lds) { for (int i = lane; i < nlist; i += 64) S.csum[i] = 0.0f; }
+	else for (int i = lane; i < nlist && i < a.scratch_stride; i += 64) gsum[i] = 0.0f;
+	if (idx_lds) { for (int i = lane; i < nlist; i += 64) S.cidx[i] = (unsigned short)noop_idx; }
+	else for (int i = lane; i < nlist && i < a.scratch_stride; i += 64) gidx[i] = (unsigned)noop_idx;
+	if (lane == 0) quad_write_noop(scr + (size_t)noop_idx * CREC);
+	auto pre_ptr = [&](int i) -> const float * { return a.ray_rows ? S.ray[i] : a.rows_pre + ((size_t)b * a.pre_stride + i) * HT_ROW; };
+	auto body_of = [&](int i) -> int {
+		if (i < npre) return (int)pre_ptr(i)[1];
+		if (a.cloud_body) return (int)a.cloud_body[(size_t)b * M.pts_cap + (i - npre)];
+		return (int)a.rows_cloud[((size_t)b * M.pts_cap + (i - npre)) * HT_ROW + 1];
 	};
+	__syncthreads();
 	int mycnt = 0;                                     // lane bb counts the rows of body bb
 	for (int base = 0; base < n1; base += 64)          // pass A: rows per body
 	{
 		const int i = base + lane;
-		int body = (i < n1) ? (int)row_ptr(i)[1] : -1;
+		int body = (i < n1) ? body_of(i) : -1;
 		unsigned long long todo = __ballot(body >= 0);
 		while (todo)
 		{
@@ -645,7 +658,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		}
 	}
 	// Sixteen quads walk the chains.  A body beyond the 16th rides on the quad of one of the first sixteen: it goes to the one with the fewest rows that
-	// does not host yet, its rows follow the host's in the stream, and the host's rows are padded to a multiple of 8 with records that change nothing
+	// does not host yet, its entries follow the host's in the list, and the host's entries are padded to a multiple of 8 with the record that changes nothing
 	// (zero direction, zero limits: impulse 0), so that the quad changes body at a block boundary of the chain walk (quad_chain_run).
 	int myextra = -1, myhost = -1;
 	{
@@ -661,7 +674,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		}
 	}
 	const int extracnt = __shfl(mycnt, myextra >= 0 ? myextra : lane);
-	const int mylen = lane >= 16 ? 0 : (myextra >= 0 && extracnt > 0 ? ((mycnt + 7) & ~7) + extracnt : mycnt);      // rows of this lane's slot of the stream
+	const int mylen = lane >= 16 ? 0 : (myextra >= 0 && extracnt > 0 ? ((mycnt + 7) & ~7) + extracnt : mycnt);      // entries of this lane's slot of the list
 	if (myextra >= 0 && extracnt == 0) myextra = -1;                                                                  // nothing to host
 	int mystart = mylen;                               // exclusive prefix over lanes = segment start of body `lane`
 #pragma unroll
@@ -669,18 +682,14 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	mystart -= mylen;
 	{
 		const int hs = __shfl(mystart, myhost >= 0 ? myhost : lane), hc = __shfl(mycnt, myhost >= 0 ? myhost : lane);
-		if (myhost >= 0) mystart = hs + ((hc + 7) & ~7);      // an extra body's rows start behind its host's padded rows
+		if (myhost >= 0) mystart = hs + ((hc + 7) & ~7);      // an extra body's entries start behind its host's padded ones (which already name the no-op record)
 	}
 	if (lane < HT_MAXNB) { S.ccnt[lane] = HT_DBG(a.dbg, 1) ? 0 : mycnt; S.cstart[lane] = mystart; S.cextra[lane] = (signed char)(HT_DBG(a.dbg, 1) ? -1 : myextra); }
-	if (myextra >= 0)      // the padding records of this host
-		for (int i = mystart + mycnt; i < mystart + ((mycnt + 7) & ~7); i++)
-			if (i < rec_cap - QUAD_CHAIN_SLACK) quad_write_noop(scr + (size_t)i * CREC);
 	int myrun = 0;
-	for (int base = 0; base < n1; base += 64)          // pass B: placement in stable order + pre-compute
+	for (int base = 0; base < n1; base += 64)          // pass B: placement in stable order; records of the rows that have none yet
 	{
 		const int i = base + lane;
-		const float *r = (i < n1) ? row_ptr(i) : nullptr;
-		int body = r ? (int)r[1] : -1;
+		int body = (i < n1) ? body_of(i) : -1;
 		int dst = -1;
 		unsigned long long todo = __ballot(body >= 0);
 		while (todo)
@@ -693,17 +702,27 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			if (lane == bb) myrun += __popcll(m);
 			todo &= ~m;
 		}
-		if (r && dst < rec_cap - QUAD_CHAIN_SLACK)
+		if (body >= 0)
 		{
-			const v3 p1 = L3(r + 5), n = L3(r + 8);
-			const v3 r1 = qrot(L4(S.q[body]), p1);
-			const m3 Ib = body_I(S, body);
-			const float impulsed = S.lin4[body].w + dot(cross(mul(Ib, cross(r1, n)), r1), n);       // 0 + (...) for the NULL side
-			const float ts = r[11] / dt;
-			quad_write_record(scr + (size_t)dst * CREC, r1, n, Ib, ts, fmin_std(ts, r[12]), impulsed, r[13] * dt, r[14] * dt);
+			const bool made = i >= npre && a.cloud_body;                                  // k_cloud_rows wrote this row's record
+			const int src = i < npre ? pre_base + i : i - npre;
+			if (src < noop_idx && dst < nlist - QUAD_CHAIN_SLACK)
+			{
+				if (idx_lds) S.cidx[dst] = (unsigned short)src; else if (dst < a.scratch_stride) gidx[dst] = (unsigned)src;
+				if (!made)
+				{
+					const float *r = i < npre ? pre_ptr(i) : a.rows_cloud + ((size_t)b * M.pts_cap + (i - npre)) * HT_ROW;
+					const v3 p1 = L3(r + 5), n = L3(r + 8);
+					const v3 r1 = qrot(L4(S.q[body]), p1);
+					const m3 Ib = body_I(S, body);
+					const float impulsed = S.lin4[body].w + dot(cross(mul(Ib, cross(r1, n)), r1), n);       // 0 + (...) for the NULL side
+					const float ts = r[11] / dt;
+					quad_write_record(scr + (size_t)src * CREC, r1, n, Ib, S.lin4[body].w, ts, fmin_std(ts, r[12]), impulsed, r[13] * dt, r[14] * dt);
+				}
+			}
 		}
 	}
-	__threadfence_block();      // the records are read back by other lanes of this wave
+	__threadfence_block();      // the records and lists are read back by other lanes of this wave
 	__syncthreads();
 	// ---- the prologue scratch is dead now: angular rows move from their builder lanes into their records ----
 	const bool arec_lds = na <= S.NANG;
@@ -905,11 +924,11 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			if (total > 0)
 			{
 				const float l = lin_w[4 * body + c], av = ang_w[4 * body + c];       // lane 3 carries massinv / friction here and never stores
-				const float minv = lin_w[4 * body + 3];
-				quad_body qb = { l, av, minv };
+				quad_body qb = { l, av };
 				// RemoveBias (physics.h:288): lane 3 switches to the ts_post slot
-				if (sums_lds) quad_chain_run(qb, scr + (size_t)start * CREC, S.csum + start, total, c, tsoff, kswitch, lin_w, ang_w, body, ex);
-				else quad_chain_run(qb, scr + (size_t)start * CREC, gsum + start, total, c, tsoff, kswitch, lin_w, ang_w, body, ex);
+				if (idx_lds) quad_chain_run(qb, scr, S.cidx + start, S.csum + start, total, c, tsoff, kswitch, lin_w, ang_w, body, ex);
+				else if (sums_lds) quad_chain_run(qb, scr, gidx + start, S.csum + start, total, c, tsoff, kswitch, lin_w, ang_w, body, ex);
+				else quad_chain_run(qb, scr, gidx + start, gsum + start, total, c, tsoff, kswitch, lin_w, ang_w, body, ex);
 				const int last = ex >= 0 ? ex : body;
 				if (c < 3) { lin_w[4 * last + c] = qb.l; ang_w[4 * last + c] = qb.av; }
 			}
@@ -987,8 +1006,8 @@ void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solv
 	// 126 angular rows in LDS runs.  Not when other kernels share the GPU with this launch (the reset path): they need LDS on every CU too.
 	int build = a.force_build;
 	if (!build) build = tile ? (B <= 1024 && !a.shared_gpu ? 2 : 1) : 3;
-	if (build == 2) hipLaunchKernelGGL((k_solve<66, 1024, 126>), dim3(B), dim3(64), 0, s, M, ph, a);
-	else if (build == 1) hipLaunchKernelGGL((k_solve<40, 624, 74>), dim3(B), dim3(64), 0, s, M, ph, a);
-	else if (build == 3) hipLaunchKernelGGL((k_solve<71, 2272, 126>), dim3(B), dim3(64), 0, s, M, ph, a);
-	else hipLaunchKernelGGL((k_solve<2, 40, 4>), dim3(B), dim3(64), 0, s, M, ph, a);      // tests only: nothing fits, every frame keeps its groups, sums and angular records in HBM
+	if (build == 2) hipLaunchKernelGGL((k_solve<66, 1024, 126, 1024>), dim3(B), dim3(64), 0, s, M, ph, a);
+	else if (build == 1) hipLaunchKernelGGL((k_solve<40, 616, 74, 0>), dim3(B), dim3(64), 0, s, M, ph, a);
+	else if (build == 3) hipLaunchKernelGGL((k_solve<71, 1520, 126, 1520>), dim3(B), dim3(64), 0, s, M, ph, a);
+	else hipLaunchKernelGGL((k_solve<2, 64, 4, 0>), dim3(B), dim3(64), 0, s, M, ph, a);      // tests only: nothing fits, every frame keeps its groups, sums and angular records in HBM
 }

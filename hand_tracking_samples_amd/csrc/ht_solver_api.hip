@@ -22,6 +22,7 @@ static int dev_alloc_points(ht_ctx *ctx)      // the second cloud of a context t
 	if (!ctx->d_nptsv) { HIPCHK(ctx, hipMalloc(&b, (size_t)ctx->B * sizeof(int))); ctx->allocs.push_back(b); ctx->d_nptsv = (int *)b; }
 	return HT_OK;
 }
+static cloud_records cloud_rec(ht_ctx *ctx) { cloud_records r = { ctx->d_scratch, scratch_stride(ctx), ctx->d_rowbody, ctx->phys.deltaT }; return r; }
 static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int *n_pre, bool cloud, bool contacts, const int *active,
                        int apply_angles, float drive_force, int ray_rows, int arm_cone, int zero_momenta, int B, hipStream_t s, bool shared_gpu = false)
 {
@@ -30,7 +31,7 @@ static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int 
 	a.sf_select = -1;
 	a.caps = reinterpret_cast<int *>(ctx->d_epa_ws) + 2;
 	a.rows_pre = rows_pre; a.n_pre = n_pre; a.pre_stride = 5 * ctx->model.nb;
-	a.rows_cloud = cloud ? ctx->d_rows : nullptr; a.n_cloud = ctx->d_nrows;
+	a.cloud_body = cloud ? ctx->d_rowbody : nullptr; a.n_cloud = ctx->d_nrows;      // k_cloud_rows wrote the rows' records into the scratch slots (cloud_rec below)
 	a.contacts = contacts ? ctx->d_contacts : nullptr; a.ncontacts = ctx->d_ncontacts;
 	a.analysis = ctx->d_analysis; a.cams = ctx->d_cams; a.active_flag = active;
 	a.state = ctx->d_state[which]; a.scratch = ctx->d_scratch; a.scratch_stride = scratch_stride(ctx); a.batch = ctx->B;
@@ -63,7 +64,8 @@ static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int 
 		static const bool no_side = ht_tuning_env("HT_NO_SIDE");      // timing experiments (-DHT_TUNING builds only)
 		const bool par = side >= 0 && cloud && coll && !ctx->profile_phases && !no_side;
 		if (par) fork1(ctx, s, side);
-		if (cloud) { ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, active, 4, 1, 2, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[side] : s); }
+		const cloud_records cr = cloud_rec(ctx);
+		if (cloud) { ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, active, 4, 1, 2, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[side] : s, 0.0f, 0.0f, &cr); }
 		if (coll && !(first_contacts_done && st == from_step)) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, active, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s); }
 		if (par) join1(ctx, s, side);
 		ht_prof_scope ps(ctx, prof ? "solve" : nullptr, s);
@@ -81,7 +83,8 @@ static void main_pass(ht_ctx *ctx, int B, hipStream_t s)
 	const bool par = !ctx->profile_phases && !no_side;
 	if (par) fork(ctx, s);
 	{ ht_prof_scope ps(ctx, "chamber", s, true); ht_launch_chamber(ctx->model, ctx->d_state[0], pts, npts, p.min_point_num, p.boundary_planes, 10.0f, ctx->d_chamber, ctx->d_nchamber, B, par ? ctx->side[1] : s); }
-	{ ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[0], pts, npts, ctx->d_cams, nullptr, 1, 0, 1, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[0] : s); }
+	const cloud_records cr = cloud_rec(ctx);
+	{ ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[0], pts, npts, ctx->d_cams, nullptr, 1, 0, 1, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[0] : s, 0.0f, 0.0f, &cr); }
 	if (coll) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[0], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s); }
 	if (par) join(ctx, s, 2);
 	ht_prof_scope ps(ctx, "solve", s);
@@ -94,7 +97,7 @@ static void reset_path(ht_ctx *ctx, const int *flags, int n_unibody, int B, hipS
 	for (int i = 0; i < n_unibody; i++)
 	{
 		ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, flags, 4, 1, 3, ctx->par, ctx->d_rows, ctx->d_nrows, B, s);
-		ht_launch_unibody(ctx->model, ctx->phys, ctx->d_state[1], ctx->d_rows, ctx->d_nrows, flags, ctx->d_scratch, scratch_stride(ctx), B, s);
+		ht_launch_unibody(ctx->model, ctx->phys, ctx->d_state[1], ctx->d_rows, ctx->d_nrows, flags, ctx->d_scratch, scratch_stride(ctx), ctx->B, B, s);
 	}
 }
 
@@ -657,7 +660,7 @@ extern "C" int ht_fit_rows(ht_ctx *ctx, int which, int B, const float *points, i
 	for (int b = 0; b < B; b++)
 	{
 		nl[b] = (linears && nlinears) ? nlinears[b] : 0;
-		if (nl[b] < 0 || nl[b] > lcap) { ctx->err = "ht_fit_rows: a linear row count is negative or exceeds the stride"; return HT_ERR_ARG; }
+		if (nl[b] < 0 || nl[b] > lcap || nl[b] > 5 * nb + 128) { ctx->err = "ht_fit_rows: a linear row count is negative, exceeds the stride or exceeds the 5 * bodies + 128 caller rows a frame's scratch slot holds"; return HT_ERR_ARG; }
 		for (int i = 0; i < nl[b]; i++)
 		{
 			const float *r = linears + ((size_t)b * lcap + i) * HT_ROW;
@@ -678,14 +681,15 @@ extern "C" int ht_fit_rows(ht_ctx *ctx, int which, int B, const float *points, i
 	hipStream_t s = ctx->stream;
 	const bool coll = ctx->phys.use_collision != 0;
 	ht_params par = ctx->par; par.microforce = microforce;
-	ht_launch_cloud_rows(ctx->model, ctx->d_state[which], ctx->d_pts, ctx->d_npts, ctx->d_cams, nullptr, 1, 0, 1, par, ctx->d_rows, ctx->d_nrows, B, s);
+	const cloud_records cr = cloud_rec(ctx);
+	ht_launch_cloud_rows(ctx->model, ctx->d_state[which], ctx->d_pts, ctx->d_npts, ctx->d_cams, nullptr, 1, 0, 1, par, ctx->d_rows, ctx->d_nrows, B, s, 0.0f, 0.0f, &cr);
 	if (coll) ht_launch_contacts(ctx->model, ctx->d_state[which], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s);
 	solve_args a;
 	memset(&a, 0, sizeof a);
 	a.sf_select = -1;
 	a.caps = reinterpret_cast<int *>(ctx->d_epa_ws) + 2;
 	a.rows_pre = ctx->d_user_lin; a.n_pre = ctx->d_user_n; a.pre_stride = ctx->user_lin_cap;
-	a.rows_cloud = ctx->d_rows; a.n_cloud = ctx->d_nrows;
+	a.cloud_body = ctx->d_rowbody; a.n_cloud = ctx->d_nrows;
 	a.contacts = coll ? ctx->d_contacts : nullptr; a.ncontacts = ctx->d_ncontacts;
 	a.ang_user = ctx->d_user_ang; a.n_ang_user = ctx->d_user_n + 3 * (size_t)ctx->B; a.ang_user_stride = ctx->user_ang_cap;
 	a.analysis = ctx->d_analysis; a.cams = ctx->d_cams;
@@ -799,13 +803,14 @@ extern "C" int ht_slowfit(ht_ctx *ctx, int B, int hold, const float *refpose, in
 	for (int st = 0; st < steps; st++)
 	{
 		const bool cloud = st < steps - 1;
+		const cloud_records cr = cloud_rec(ctx);
 		if (cloud) ht_launch_cloud_rows(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, ctx->d_cams, nullptr, 1, 0, 4, ctx->par, ctx->d_rows, ctx->d_nrows, B, s,
-		                                1.0f * (float)(steps - st) / (float)steps, 0.1f * (float)(st < steps - 2));
+		                                1.0f * (float)(steps - st) / (float)steps, 0.1f * (float)(st < steps - 2), &cr);
 		if (coll) ht_launch_contacts(ctx->model, ctx->d_state[0], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s);
 		solve_args a;
 		memset(&a, 0, sizeof a);
 		a.caps = reinterpret_cast<int *>(ctx->d_epa_ws) + 2;
-		a.rows_cloud = cloud ? ctx->d_rows : nullptr; a.n_cloud = ctx->d_nrows;
+		a.cloud_body = cloud ? ctx->d_rowbody : nullptr; a.n_cloud = ctx->d_nrows;
 		a.contacts = coll ? ctx->d_contacts : nullptr; a.ncontacts = ctx->d_ncontacts;
 		a.analysis = ctx->d_analysis; a.cams = ctx->d_cams;
 		a.state = ctx->d_state[0]; a.scratch = ctx->d_scratch; a.scratch_stride = scratch_stride(ctx); a.batch = ctx->B;

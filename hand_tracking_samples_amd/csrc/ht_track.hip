@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64) void k_scratch(ht_model_dev M, float *__restric
 
 // ---- UnibodyFit: one wave per flagged frame; the rows all act on one proxy body, so the Gauss-Seidel chain is sequential -----------
 __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev ph, float *__restrict__ state, const float *__restrict__ rows, const int *__restrict__ nrows,
-                                                const int *__restrict__ flags, float *__restrict__ scratch, int scratch_stride)
+                                                const int *__restrict__ flags, float *__restrict__ scratch, int scratch_stride, int batch)
 {
 	__shared__ float pos[HT_MAXNB][3], q[HT_MAXNB][4];
 	__shared__ float res[8];
@@ -168,15 +168,17 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 	// Up to UB_LDS_ROWS rows (3584 points) the records stay in LDS (77 KB: only the few frames that take the full-reset
 	// path run this kernel, so occupancy is no concern, and a single quad walking its chain alone on a CU would wait a whole L2 round trip for what
 	// k_solve's sixteen quads overlap); a larger cloud uses the frame's slot of the solver scratch in HBM, sums behind all frames' records as in k_solve.
-	constexpr int UB_LDS_ROWS = 896;      // 77 KB: with four 20 KB solver blocks on a CU (1024 frames) this block still finds room at once
+	constexpr int UB_LDS_ROWS = 896;      // 66 KB: with four 20 KB solver blocks on a CU (1024 frames) this block still finds room at once
 	__shared__ __attribute__((aligned(16))) float urow[(UB_LDS_ROWS + QUAD_CHAIN_SLACK) * CREC];
 	__shared__ float usum[UB_LDS_ROWS + QUAD_CHAIN_SLACK];      // impulse sums of the rows
+	__shared__ unsigned short uidx[UB_LDS_ROWS + QUAD_CHAIN_SLACK];      // the chain as quad_chain_run walks it: here simply every record in order
 	const int nr = n < scratch_stride - QUAD_CHAIN_SLACK ? n : scratch_stride - QUAD_CHAIN_SLACK;
 	const bool in_lds = nr <= UB_LDS_ROWS;
 	float *const grec = scratch + (size_t)b * scratch_stride * CREC;
-	float *const gsum = scratch + (size_t)gridDim.x * scratch_stride * CREC + (size_t)b * scratch_stride;
-	if (in_lds) { for (int i = lane; i < nr + QUAD_CHAIN_SLACK; i += 64) usum[i] = 0.0f; }
-	else for (int i = lane; i < nr + QUAD_CHAIN_SLACK; i += 64) gsum[i] = 0.0f;
+	float *const gsum = scratch + (size_t)batch * scratch_stride * CREC + (size_t)b * scratch_stride;
+	unsigned *const gidx = reinterpret_cast<unsigned *>(scratch + (size_t)batch * scratch_stride * (CREC + 1)) + (size_t)b * scratch_stride;
+	if (in_lds) { for (int i = lane; i < nr + QUAD_CHAIN_SLACK; i += 64) { usum[i] = 0.0f; uidx[i] = (unsigned short)i; } }
+	else for (int i = lane; i < nr + QUAD_CHAIN_SLACK; i += 64) { gsum[i] = 0.0f; gidx[i] = (unsigned)i; }
 	for (int i = lane; i < nr; i += 64)
 	{
 		const float *r = rows + ((size_t)b * M.pts_cap + i) * HT_ROW;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 		const v3 r1 = qrot(ubq, p1);
 		const float impulsed = minv + dot(cross(mul(Iinv, cross(r1, nrm)), r1), nrm);
 		const float ts = r[11] / dt;
-		quad_write_record((in_lds ? urow : grec) + (size_t)i * CREC, r1, nrm, Iinv, ts, fmin_std(ts, r[12]), impulsed, r[13] * dt, r[14] * dt);
+		quad_write_record((in_lds ? urow : grec) + (size_t)i * CREC, r1, nrm, Iinv, minv, ts, fmin_std(ts, r[12]), impulsed, r[13] * dt, r[14] * dt);
 	}
 	__threadfence_block();
 	__syncthreads();
@@ -194,13 +196,13 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 	{
 		const int c = lane;
 		// rbinitvelocity on a body at rest: 0 * damping + 0
-		quad_body qb = { (0.0f * M.ub_dampleft) + 0.0f, (0.0f * M.ub_dampleft) + 0.0f, minv };
+		quad_body qb = { (0.0f * M.ub_dampleft) + 0.0f, (0.0f * M.ub_dampleft) + 0.0f };
 		v3 pn = ubpos; v4 qn = ubq;
 		const int total = ph.iterations + ph.iterations_post;
 		for (int sweep = 0; sweep < total; sweep++)
 		{
 			const int tsoff = sweep >= ph.iterations ? 1 : 0;        // RemoveBias: lane 3 switches to the ts_post slot
-			if (nr > 0) { if (in_lds) quad_chain_run(qb, urow, usum, nr, c, tsoff); else quad_chain_run(qb, grec, gsum, nr, c, tsoff); }
+			if (nr > 0) { if (in_lds) quad_chain_run(qb, urow, uidx, usum, nr, c, tsoff); else quad_chain_run(qb, grec, gidx, gsum, nr, c, tsoff); }
 			if (sweep + 1 == ph.iterations)
 			{
 				const v3 lin = V3(dpp<QP_BC0>(qb.l), dpp<QP_BC1>(qb.l), dpp<QP_BC2>(qb.l)), ang = V3(dpp<QP_BC0>(qb.av), dpp<QP_BC1>(qb.av), dpp<QP_BC2>(qb.av));
@@ -289,9 +291,9 @@ void ht_launch_scale_state(float *state, int nb, int n, float s, hipStream_t st)
 {
 	hipLaunchKernelGGL(k_scale_state, dim3((n * nb + 255) / 256), dim3(256), 0, st, state, nb, n, s);
 }
-void ht_launch_unibody(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float *rows, const int *nrows, const int *flags, float *scratch, int scratch_stride, int B, hipStream_t s)
+void ht_launch_unibody(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float *rows, const int *nrows, const int *flags, float *scratch, int scratch_stride, int batch, int B, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_unibody, dim3(B), dim3(64), 0, s, M, ph, state, rows, nrows, flags, scratch, scratch_stride);
+	hipLaunchKernelGGL(k_unibody, dim3(B), dim3(64), 0, s, M, ph, state, rows, nrows, flags, scratch, scratch_stride, batch);
 }
 void ht_launch_accept(float *hand, const float *other, const float *err_old, const float *err_new, const int *npts, float *prev_err, int *initializing, int *accepted, int nb, int n, const ht_params &p, hipStream_t s)
 {
