@@ -55,9 +55,10 @@
 // the build's choice -- the two-body linear groups (256 B each), the impulse sums of the single-body rows (4 B each), the angular records (64 B each).
 // A frame whose rows do not fit an array keeps THAT array in its slot of the solver scratch in HBM instead (same code through a generic pointer): slower
 // for that frame, correct for every frame, one launch.  Builds (ht_launch_solve):
-//   small   40 groups, 624 sums, 74 angular rows: 22.5 KB = 45 LDS allocation units of 512 B, seven frames per CU.  Batches above 1024 frames of 64x64 tiles.
-//   only    66 groups (16 joints + 49 contacts), 1024 sums, 126 angular rows: 34 KB, four frames per CU (a 1024-frame batch in one round).
-//   mid     71 groups, 2272 sums, 126 angular rows: 40 KB, four frames per CU.  Larger models, full-size frames.
+//   small   38 groups (16 joints + 21 contacts), 584 sums, 84 angular rows (13 CNN-driven + 71 of the hand's joints), chain lists in HBM: 22.5 KB = 45 LDS
+//           allocation units of 512 B, seven frames per CU.  Batches above 1024 frames of 64x64 tiles.
+//   only    66 groups (16 joints + 49 contacts), 1024 sums and chain entries, 126 angular rows: 36 KB, four frames per CU (a 1024-frame batch in one round).
+//   mid     71 groups, 1520 sums and chain entries, 126 angular rows: 40 KB, four frames per CU.  Larger models, full-size frames.
 #define IDLE_BODY (HT_MAXNB - 1)      // lane pairs without a row in a step work on this all-zero body and on an all-zero record
 #define LM_FRIC 0x10000    // meta bits of a group: contact (friction rows limited by the normal row's impulse sum, physics.h:292)
 #define LM_NORMAL 0x20000
@@ -1001,13 +1002,13 @@ void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solv
 	// the build by what the host knows of the launch: the model's joints and the most points a frame of this call can carry.  A frame that exceeds
 	// the chosen build's arrays (contacts, points: device-side data) keeps the array in question in HBM (top of the file); nothing is relaunched.
 	const int pts = M.pts_bound > 0 ? M.pts_bound : M.pts_cap;
-	const bool tile = M.nj + 8 + 1 <= 40 && pts <= 1024;      // room for a few contacts beside the joints, and a 64x64 tile's cloud
+	const bool tile = M.nj + 8 + 1 <= 38 && pts <= 1024;      // room for a few contacts beside the joints, and a 64x64 tile's cloud
 	// Up to four frames per CU (1024 on the 256 CUs) a launch gains nothing from the small build's footprint, so the build that keeps 49 contacts and
 	// 126 angular rows in LDS runs.  Not when other kernels share the GPU with this launch (the reset path): they need LDS on every CU too.
 	int build = a.force_build;
 	if (!build) build = tile ? (B <= 1024 && !a.shared_gpu ? 2 : 1) : 3;
 	if (build == 2) hipLaunchKernelGGL((k_solve<66, 1024, 126, 1024>), dim3(B), dim3(64), 0, s, M, ph, a);
-	else if (build == 1) hipLaunchKernelGGL((k_solve<40, 616, 74, 0>), dim3(B), dim3(64), 0, s, M, ph, a);
+	else if (build == 1) hipLaunchKernelGGL((k_solve<38, 584, 84, 0>), dim3(B), dim3(64), 0, s, M, ph, a);
 	else if (build == 3) hipLaunchKernelGGL((k_solve<71, 1520, 126, 1520>), dim3(B), dim3(64), 0, s, M, ph, a);
 	else hipLaunchKernelGGL((k_solve<2, 64, 4, 0>), dim3(B), dim3(64), 0, s, M, ph, a);      // tests only: nothing fits, every frame keeps its groups, sums and angular records in HBM
 }

@@ -1,16 +1,29 @@
-# Produces the round's measurement artefacts under gpurun_out/prof_rNN/ (copy the summaries into profiles/ with tools/collect_profiles.sh):
+# Produces the round's measurement artefacts under gpurun_out/prof_rNN/; afterwards `bash tools/profile_round.sh --collect rNN` (no GPU) copies the
+# summaries into profiles/rNN_* (the files the README there lists):
 #   bench.json                     python bench.py (default: BASELINE configs[2], 1024 frames, 20 steps, cpu_baseline)
 #   bench_frames8192.json          one GPU's shard of BASELINE configs[3]
 #   bench_cnn.json                 BASELINE configs[1] (CNN forward only)
 #   bench_config5.json             BASELINE configs[4] (128x128 frames, 26 bones, the path the reference runs)
 #   bench_config5_cnn128.json      BASELINE configs[4], the 128x128-input net
 #   kernel_stats.csv               rocprofv3 --kernel-trace --stats of a short bench run (1024 frames); kernel_stats_frames8192.csv the same at 8192
-#   pmc_fetch / pmc_write          two separate counter passes (FETCH_SIZE, WRITE_SIZE), aggregated by tools/pmc_traffic.py
+#   pmc_fetch / pmc_write          two separate counter passes (FETCH_SIZE, WRITE_SIZE) per workload (1024 frames, 8192 frames, configs[4]), each aggregated
+#                                  by tools/pmc_traffic.py into a file that names what it was measured on (bench.py quotes it only for that workload)
 #   pmc_mfma, pmc_mfma128          one counter pass each on the CNN-only workloads (MFMA busy cycles), aggregated by tools/pmc_mfma.py
 #   afterwards: python tools/cnn_roofline.py profiles/rNN > profiles/rNN_cnn_kernel_roofline.json (per-kernel MFMA roofline of the CNN workloads)
 # usage: bash tools/profile_round.sh r02
 set -e
-R=${1:-r02}
+if [ "$1" = "--collect" ]; then
+	R=${2:-r03}; S=gpurun_out/prof_$R; D=profiles
+	for f in bench bench_frames8192 bench_cnn bench_config5 bench_config5_cnn128 bench_under_rocprofv3 bench_dist1 pmc_hbm_traffic pmc_hbm_traffic_frames8192 pmc_hbm_traffic_config5 pmc_mfma_util pmc_mfma128_util; do [ -f $S/$f.json ] && cp $S/$f.json $D/${R}_$f.json; done
+	cp $S/kernel_stats.csv $D/${R}_rocprofv3_kernel_stats.csv; cp $S/kernel_stats_frames8192.csv $D/${R}_rocprofv3_kernel_stats_frames8192.csv
+	cp $S/kernel_stats_cnn.csv $D/${R}_rocprofv3_kernel_stats_cnn.csv; cp $S/kernel_stats_cnn128.csv $D/${R}_rocprofv3_kernel_stats_cnn128.csv
+	[ -f $S/step_timeline.txt ] && cp $S/step_timeline.txt $D/${R}_step_timeline.txt
+	[ -f $S/gpu_tests.log ] && cp $S/gpu_tests.log $D/${R}_gpu_tests.log
+	python3 tools/cnn_roofline.py $D/$R > $D/${R}_cnn_kernel_roofline.json
+	ls $D/${R}_*
+	exit 0
+fi
+R=${1:-r03}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -20,23 +33,32 @@ python3 bench.py --frames-per-gpu 8192 --steps 5 --warmup 2 --no-cpu-baseline > 
 python3 bench.py --workload cnn > $OUT/bench_cnn.json 2> $OUT/bench_cnn.err
 python3 bench.py --workload config5 --steps 10 > $OUT/bench_config5.json 2> $OUT/bench_config5.err
 python3 bench.py --workload config5-cnn128 > $OUT/bench_config5_cnn128.json 2> $OUT/bench_cnn128.err
+python3 bench.py --force-dist --steps 10 --no-cpu-baseline > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err      # the RCCL gather rehearsed on this box's one rank
+python3 -m pytest tests -m gpu -q -s > $OUT/gpu_tests.log 2>&1 || true
 echo "benches done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprofv3.json 2> $OUT/trace.err
-cp $OUT/trace/t_kernel_stats.csv $OUT/kernel_stats.csv
+cp $(find $OUT/trace -name "t_kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+python3 tools/step_timeline.py $(find $OUT/trace -name "t_kernel_trace.csv" | head -1) > $OUT/step_timeline.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace8192 -o t -- python3 bench.py --frames-per-gpu 8192 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/trace8192.err
-cp $OUT/trace8192/t_kernel_stats.csv $OUT/kernel_stats_frames8192.csv
+cp $(find $OUT/trace8192 -name "t_kernel_stats.csv" | head -1) $OUT/kernel_stats_frames8192.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cnn -o t -- python3 bench.py --workload cnn --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/trace_cnn.err
-cp $OUT/trace_cnn/t_kernel_stats.csv $OUT/kernel_stats_cnn.csv
+cp $(find $OUT/trace_cnn -name "t_kernel_stats.csv" | head -1) $OUT/kernel_stats_cnn.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cnn128 -o t -- python3 bench.py --workload config5-cnn128 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/trace_cnn128.err
-cp $OUT/trace_cnn128/t_kernel_stats.csv $OUT/kernel_stats_cnn128.csv
+cp $(find $OUT/trace_cnn128 -name "t_kernel_stats.csv" | head -1) $OUT/kernel_stats_cnn128.csv
 echo "traces done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_write.err
-python3 tools/pmc_traffic.py $OUT/pmc_fetch/f_counter_collection.csv $OUT/pmc_write/w_counter_collection.csv > $OUT/pmc_hbm_traffic.json
+pmc_pair() {      # name, workload, frames per GPU, extra bench arguments
+	rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $4 > /dev/null 2> $OUT/pmc_fetch.err
+	rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $4 > /dev/null 2> $OUT/pmc_write.err
+	python3 tools/pmc_traffic.py $(find $OUT/pmc_fetch -name "f_counter_collection.csv" | head -1) $(find $OUT/pmc_write -name "w_counter_collection.csv" | head -1) $2 $3 > $OUT/$1.json
+	rm -rf $OUT/pmc_fetch $OUT/pmc_write
+}
+pmc_pair pmc_hbm_traffic cnn+solver 1024 ""
+pmc_pair pmc_hbm_traffic_frames8192 cnn+solver 8192 "--frames-per-gpu 8192"
+pmc_pair pmc_hbm_traffic_config5 config5 1024 "--workload config5"
 head -c 300 $OUT/pmc_hbm_traffic.json
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o m -- python3 bench.py --workload cnn --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_mfma.err
-python3 tools/pmc_mfma.py $OUT/pmc_mfma/m_counter_collection.csv > $OUT/pmc_mfma_util.json
+python3 tools/pmc_mfma.py $(find $OUT/pmc_mfma -name "m_counter_collection.csv" | head -1) > $OUT/pmc_mfma_util.json
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma128 -o m -- python3 bench.py --workload config5-cnn128 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_mfma128.err
-python3 tools/pmc_mfma.py $OUT/pmc_mfma128/m_counter_collection.csv > $OUT/pmc_mfma128_util.json
-rm -rf $OUT/trace $OUT/trace8192 $OUT/trace_cnn $OUT/trace_cnn128 $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma $OUT/pmc_mfma128
+python3 tools/pmc_mfma.py $(find $OUT/pmc_mfma128 -name "m_counter_collection.csv" | head -1) > $OUT/pmc_mfma128_util.json
+rm -rf $OUT/trace $OUT/trace8192 $OUT/trace_cnn $OUT/trace_cnn128 $OUT/pmc_mfma $OUT/pmc_mfma128
 echo "profile round $R complete"
