@@ -330,20 +330,30 @@ def main():
     # cannot be made, torch.distributed's all-gather does the same exchange and the JSON line says so.
     gather_impl = None
     if use_dist and not cnn_only:
-        try:
-            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
-            if rank == 0:
-                uid.copy_(torch.frombuffer(bytearray(native.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(uid, 0)
-            ctx.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
+        # every rank goes through the same collectives whatever fails locally: rank 0 makes the id (byte 128 = "valid"), everybody receives it, everybody tries to
+        # join, and the ranks then agree (MIN) on whether all of them did
+        uid = torch.zeros(129, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            try:
+                uid[:128].copy_(torch.frombuffer(bytearray(native.comm_unique_id()), dtype=torch.uint8))
+                uid[128] = 1
+            except Exception as e:
+                sys.stderr.write("rank 0: RCCL unique id unavailable (%s)\n" % e)
+        dist.broadcast(uid, 0)
+        joined, why = 0, "rank 0 could not make an RCCL unique id"
+        if int(uid[128].item()) == 1:
+            try:
+                ctx.comm_init(world, rank, bytes(uid[:128].cpu().numpy().tobytes()))
+                joined = 1
+            except Exception as e:
+                why = str(e)
+                sys.stderr.write("rank %d: ht_comm_init failed (%s)\n" % (rank, e))
+        ok = torch.tensor([joined], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
             gather_impl = "ht_gather_poses_dev (ncclAllGather on the context's communication stream): RCCL reports %d rank(s), this is rank %d" % ctx.comm_info()
-        except Exception as e:
-            sys.stderr.write("rank %d: C-ABI RCCL gather unavailable (%s); using torch.distributed.all_gather_into_tensor\n" % (rank, e))
-            gather_impl = "torch.distributed.all_gather_into_tensor (the library's communicator could not be made: %s)" % e
-        ok = torch.tensor([1 if gather_impl.startswith("ht_") else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # every rank takes the same route
-        if int(ok.item()) == 0 and gather_impl.startswith("ht_"):
-            gather_impl = "torch.distributed.all_gather_into_tensor (another rank could not make the library's communicator)"
+        else:
+            gather_impl = "torch.distributed.all_gather_into_tensor (the library's communicator could not be made on every rank: %s)" % (why if not joined else "another rank failed")
     use_lib_gather = bool(gather_impl and gather_impl.startswith("ht_"))
     gathered2 = [torch.empty((world * B, ctx.nb, 7), dtype=torch.float32, device=dev) for _ in range(2)] if use_dist else [None, None]
     gathered = gathered2[0]
