@@ -240,10 +240,10 @@ __device__ int gjk_run(const support_t &A, const support_t &B, float cutoff, gjk
 // A triangle is one 16-byte record (vertex ids, pad, neighbour ids, pad) so that the mesh surgery, which is a chain of dependent look-ups,
 // fetches a whole triangle with one 128-bit LDS read and decides in registers; neighbour slots are patched with 16-bit stores.
 struct __attribute__((aligned(16))) epa_tri { short v[3], pad0, n[3], pad1; };
-struct epa_mem { epa_tri t[EPA_MAXT]; float vx[EPA_MAXV], vy[EPA_MAXV], vz[EPA_MAXV]; };
+struct epa_mem { epa_tri t[EPA_MAXT]; float4 v[EPA_MAXV]; };      // a vertex is one 128-bit read (the per-lane phases gather three per triangle)
 struct tri_r { int v0, v1, v2, n0, n1, n2; };
 // the mesh surgery is executed by every lane on the same values (same stores from all lanes), so each lane's own program order keeps it coherent
-__device__ __forceinline__ v3 ev(const epa_mem &m, int i) { return V3(m.vx[i], m.vy[i], m.vz[i]); }
+__device__ __forceinline__ v3 ev(const epa_mem &m, int i) { const float4 q = m.v[i]; return V3(q.x, q.y, q.z); }
 __device__ __forceinline__ tri_r tri_ld(const epa_mem &m, int t)
 {
 	const int4 q = *reinterpret_cast<const int4 *>(&m.t[t]);
@@ -360,13 +360,11 @@ __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 
 	v4 plane = V4(0, 0, 0, -FLT_MAX);
 	const float epsilon = 0.001f;
 	int nv = 4, nt = 0;
-	m.vx[0] = s0.x; m.vy[0] = s0.y; m.vz[0] = s0.z; m.vx[1] = s1.x; m.vy[1] = s1.y; m.vz[1] = s1.z;
-	m.vx[2] = s2.x; m.vy[2] = s2.y; m.vz[2] = s2.z; m.vx[3] = s3.x; m.vy[3] = s3.y; m.vz[3] = s3.z;
+	const bool flip = dot(cross(s2 - s0, s1 - s0), s3 - s0) > 0.0f;
+	m.v[0] = make_float4(s0.x, s0.y, s0.z, 0.0f); m.v[1] = make_float4(s1.x, s1.y, s1.z, 0.0f);
+	m.v[2] = flip ? make_float4(s3.x, s3.y, s3.z, 0.0f) : make_float4(s2.x, s2.y, s2.z, 0.0f);
+	m.v[3] = flip ? make_float4(s2.x, s2.y, s2.z, 0.0f) : make_float4(s3.x, s3.y, s3.z, 0.0f);
 	v3 center = (((s0 + s1) + s2) + s3) / 4.0f;
-	if (dot(cross(s2 - s0, s1 - s0), s3 - s0) > 0.0f)
-	{
-		m.vx[2] = s3.x; m.vy[2] = s3.y; m.vz[2] = s3.z; m.vx[3] = s2.x; m.vy[3] = s2.y; m.vz[3] = s2.z;
-	}
 	tri_set(m, nt++, 2, 3, 1, 2, 3, 1); tri_set(m, nt++, 3, 2, 0, 3, 2, 0); tri_set(m, nt++, 0, 1, 3, 0, 1, 3); tri_set(m, nt++, 1, 0, 2, 1, 0, 2);
 	int guard = 0;
 	for (; guard < 128; guard++)
@@ -399,7 +397,7 @@ __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 
 		if (plane.w >= face.w - epsilon) break;
 		if (nv >= EPA_MAXV) { capped = true; break; }
 		const int vid = nv;
-		m.vx[nv] = v.x; m.vy[nv] = v.y; m.vz[nv] = v.z; nv++;
+		m.v[nv] = make_float4(v.x, v.y, v.z, 0.0f); nv++;
 		// Which triangles see the new vertex is tested one triangle per lane (vertices of existing triangles never change, and a triangle
 		// that died during the surgery is skipped when its turn comes); the reference's descending scan then only visits the set bits.
 		bool okk = true;
@@ -415,19 +413,37 @@ __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 
 				if (!tri_dead(m, base + bit)) okk = okk && extrude(m, nt, base + bit, vid);
 			}
 		}
-		int j = nt;
-		while (okk && j--)
+		// The reference then walks down from the newest triangle while triangles carry the new vertex (dead ones skipped) and extrudes from the
+		// neighbour of the first one that faces the centre or is degenerate, starting over after each extrusion (hull.h:283-297).  Every lane
+		// judges one triangle; the first event from the top -- a live triangle without the vertex ends the walk, a bad one extrudes -- is read
+		// off the ballots.
+		while (okk)
 		{
-			const tri_r J = tri_ld(m, j);
-			if (J.n0 == -1) continue;
-			if (!hasvert(J, vid)) break;
-			v3 a = ev(m, J.v0), b = ev(m, J.v1), c = ev(m, J.v2);
-			if (above(m, j, center, 0.01f * epsilon) || length(cross(b - a, c - b)) < epsilon * epsilon * 0.1f)
+			int from = -1; bool done = false;
+			for (int base = ((nt - 1) >> 6) << 6; base >= 0 && !done; base -= 64)
 			{
-				int nb = J.n0;
-				okk = extrude(m, nt, nb, vid);
-				j = nt;
+				const int i = base + lane;
+				bool live = false, hv = false, bad = false;
+				if (i < nt)
+				{
+					const tri_r J = tri_ld(m, i);
+					live = J.n0 != -1; hv = hasvert(J, vid);
+					if (live && hv)
+					{
+						const v3 a = ev(m, J.v0), b = ev(m, J.v1), c = ev(m, J.v2);
+						bad = dot(tri_normal(a, b, c), center - a) > 0.01f * epsilon || length(cross(b - a, c - b)) < epsilon * epsilon * 0.1f;
+					}
+				}
+				const unsigned long long stop = __ballot(live && !hv), badm = __ballot(bad), evm = stop | badm;
+				if (evm)
+				{
+					const int bit = 63 - __clzll((long long)evm);
+					done = true;
+					if ((badm >> bit) & 1ull) from = tri_ld(m, base + bit).n0;
+				}
 			}
+			if (from < 0) break;
+			okk = extrude(m, nt, from, vid);
 		}
 		if (!okk) { capped = true; break; }
 		// compaction (hull.h:300-306): dead triangles are found one per lane; moving the last (live) triangle into a dead slot never
@@ -902,7 +918,8 @@ template <bool JIG> __device__ void co_pass(const ht_model_dev &M, const co_lds 
 				Bb.outer = 0; Bb.opos = V3(0, 0, 0); Bb.oq = V4(0, 0, 0, 1); Bb.sub = 0; Bb.grp = 1;
 				bool capped = false;
 				const v4 mpp = HT_DBG(dbg, 32) ? V4(0, 0, 1, -0.001f) : expanding_polytope_wave(em, V3(J.p[0][0], J.p[0][1], J.p[0][2]), V3(J.p[1][0], J.p[1][1], J.p[1][2]), V3(J.p[2][0], J.p[2][1], J.p[2][2]),
-				                                                                           V3(J.p[3][0], J.p[3][1], J.p[3][2]), Ab, Bb, lane, nullptr, capped);
+				                                                                           V3(J.p[3][0], J.p[3][1], J.p[3][2]), Ab, Bb, lane, cyc ? cyc + 4 : nullptr, capped);
+				if (cyc) cyc[11] += 1;
 				if (lane == 0) { J.res[0] = mpp.x; J.res[1] = mpp.y; J.res[2] = mpp.z; J.res[3] = mpp.w; if (capped && caps) atomicAdd(caps, 1); atomicAdd(&L.F[J.f].nepa, 1); }
 			}
 			__syncthreads();
@@ -1030,7 +1047,7 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 		H.total = tot; H.jtotal = 0; H.nreq[0] = H.nreq[1] = 0; H.nepa = 0; H.enext = 0;
 	}
 	__syncthreads();
-	long long cyc[5] = { 0, 0, 0, 0, 0 };
+	long long cyc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };      // [7..10]: this wave's polytope runs (face search, support, surgery, iterations), [11] their number
 	const long long t_pro = HT_DBG(dbg, 2048) ? clock64() : 0;
 	int parity = 0;
 	co_pass<false>(M, L, nfr, em, driftmax, jiggle_sin, t, dbg, caps, parity, HT_DBG(dbg, 2048) ? cyc : nullptr);
@@ -1093,18 +1110,20 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 			}
 		}
 		if (live && lane == 0) { ncontacts[b] = total < HT_MAXCONTACT ? total : HT_MAXCONTACT; if (total > HT_MAXCONTACT && caps) atomicAdd(caps + 1, total - HT_MAXCONTACT); }
-		if (HT_DBG(dbg, 2048) && live && lane == 0 && total < HT_MAXCONTACT - 1)      // timing experiments: per-frame statistics accumulate in the last contact slot
+		if (HT_DBG(dbg, 2048) && live && lane == 0 && total < HT_MAXCONTACT - 2)      // timing experiments: per-frame statistics accumulate in the last two contact slots
 		{
 			float *o = contacts + ((size_t)b * HT_MAXCONTACT + HT_MAXCONTACT - 1) * HT_CONTACT;
 			o[0] += 1.0f; o[1] += (float)cyc[0]; o[2] += (float)cyc[2]; o[3] += (float)F.nepa; o[4] += (float)cyc[3]; o[5] += (float)cyc[1]; o[6] += (float)cyc[4]; o[7] += (float)(clock64() - t_begin);
 			o[8] += (float)F.ncand; o[9] += (float)(clock64() - t_post); o[10] += (float)(t_post - t_pro); o[11] += (float)(t_pro - t_begin);
+			o -= HT_CONTACT;
+			for (int k = 0; k < 5; k++) o[k] += (float)cyc[7 + k];
 		}
 	}
 }
 
 size_t ht_contacts_workspace_bytes(int B) { (void)B; return 16; }      // the polytope mesh lives in LDS; the workspace holds the capacity counters (polytope runs cut short, contacts dropped, k_solve's angular overflow)
 
-void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s)
+void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s, bool beside_cloud_rows)
 {
 	int *caps = reinterpret_cast<int *>(epa_ws);
 	const int dbg = ht_tuning_flags();
@@ -1129,7 +1148,9 @@ void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftma
 		if (const char *e = getenv("HT_CONTACTS_COOP_MAX")) coop_max = atoi(e);
 #endif
 	}
-	if (B <= coop_max)
+	static int main_lanes = -1;
+	if (main_lanes < 0) main_lanes = ht_tuning_int("HT_CONTACTS_MAIN_LANES", 0);
+	if (B <= coop_max && !(beside_cloud_rows && main_lanes))
 	{
 		// as many frames per block as the LDS holds beside the padded vertex copy, the scan list and the waves' polytope areas (4 for the 17-bone hand)
 		const int nvp = M.cvert_off[M.nb];

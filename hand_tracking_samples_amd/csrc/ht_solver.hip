@@ -213,12 +213,69 @@ __device__ __forceinline__ int angular_range_count(v3 lmin, v3 lmax)
 	return n;
 }
 
+// Level schedule of one solve's groups (two-body linear groups, or runs of angular rows), on the whole wave.
+//   level(group) = 1 + the highest level of an earlier group that shares a body with it, so conflicting rows keep the reference's order;
+//   groups are counting-sorted by level (stable), and every level is cut into steps of at most 8 groups (one per lane pair).
+// Group g is spoken for by lane g & 63 (slot g >> 6) with its bodies b0, b1 (255 = none).  The levels come from one pass in group order whose
+// state -- the level of the latest group on each body -- sits in the lanes (lane k = body k) and is read and written with v_readlane / compare-
+// select; a group's place in the sorted order and its step follow from counting, every lane over all groups.  (One lane walking LDS arrays took
+// 52 k cycles per launch for ~20 groups and ~30 runs, 7 % of the kernel.)
+//   put_order(pos, g, slot): group g takes place pos;  put_start(step, pos): step `step` (from 1) begins at place pos; returns the number of steps,
+//   and start[steps + 1] = start[steps + 2] = n as the sweeps' read-ahead expects.
+template <int NS, class Order, class Start>
+__device__ __forceinline__ int level_schedule(int n, int lane, const int (&b0)[2], const int (&b1)[2], Order put_order, Start put_start)
+{
+	auto rdl = [](int v, int l) -> int { return __builtin_amdgcn_readlane(v, l); };
+	int last = 0, lev[2] = { 0, 0 };
+	for (int g = 0; g < n; g++)
+	{
+		const int l = g & 63;
+		const bool hi = NS > 1 && g >= 64;
+		const int x0 = hi ? rdl(b0[1], l) : rdl(b0[0], l), x1 = hi ? rdl(b1[1], l) : rdl(b1[0], l);
+		const int l0 = x0 != 255 ? rdl(last, x0 & 63) : 0, l1 = x1 != 255 ? rdl(last, x1 & 63) : 0;
+		const int lv = (l0 > l1 ? l0 : l1) + 1;
+		last = (lane == x0 || lane == x1) ? lv : last;
+		lev[0] = (lane == l && !hi) ? lv : lev[0];
+		if (NS > 1) lev[1] = (lane == l && hi) ? lv : lev[1];
+	}
+	int lower[2] = { 0, 0 }, before[2] = { 0, 0 };
+	for (int h = 0; h < n; h++)
+	{
+		const int lh = (NS > 1 && h >= 64) ? rdl(lev[1], h & 63) : rdl(lev[0], h & 63);
+#pragma unroll
+		for (int s = 0; s < NS; s++) { lower[s] += lh < lev[s] ? 1 : 0; before[s] += (lh == lev[s] && h < lane + 64 * s) ? 1 : 0; }
+	}
+	int key[2], sb[2] = { 0, 0 };
+#pragma unroll
+	for (int s = 0; s < 2; s++) key[s] = (s < NS && lane + 64 * s < n) ? lev[s] * 2 + ((before[s] & 7) == 0 ? 1 : 0) : 0x7ffffffe;
+	for (int h = 0; h < n; h++)
+	{
+		const int kh = (NS > 1 && h >= 64) ? rdl(key[1], h & 63) : rdl(key[0], h & 63);
+#pragma unroll
+		for (int s = 0; s < NS; s++) sb[s] += ((kh >> 1) < lev[s]) ? (kh & 1) : 0;
+	}
+	int steps = 0;
+#pragma unroll
+	for (int s = 0; s < NS; s++)
+	{
+		const int g = lane + 64 * s;
+		const bool valid = g < n, first = valid && (before[s] & 7) == 0;
+		const int pos = lower[s] + before[s];
+		if (valid) put_order(pos, g, s);
+		if (first) put_start(1 + sb[s] + (before[s] >> 3), pos);
+		steps += __popcll(__ballot(first));
+	}
+	if (lane == 0) { put_start(steps + 1, n); put_start(steps + 2, n); }
+	return steps;
+}
+
 template <int NGRP_, int NSUM_, int NANG_, int NIDX_>
 __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph, solve_args a)
 {
 	__shared__ lds_t<NGRP_, NSUM_, NANG_, NIDX_> S;
 	const int b = blockIdx.x, lane = threadIdx.x;
 	if (a.active_flag && !a.active_flag[b]) return;                // a launch never touches another launch's frames
+	const long long t_entry = HT_DBG(a.dbg, 2048) ? clock64() : 0;
 	const int nb = M.nb, nj = M.nj;
 	float *st = a.state + (size_t)b * nb * HT_STATE_STRIDE;
 	const float dt = ph.deltaT;
@@ -332,6 +389,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	}
 	__syncthreads();
 	if (HT_DBG(a.dbg, 256)) return;
+	const long long t_m1 = HT_DBG(a.dbg, 2048) ? clock64() : 0;
 	// ---- angular rows: [ApplyAngles 12] [arm cone 1] [joint ranges], generated by the lane that owns them ----
 	// slowfit's RelativeAngularConstraints (physmodel.h:423-432, filter handtrack.h:799): one row per ranged axis of every joint that passes
 	const bool rel = a.sf_refpose && a.sf_hold;
@@ -440,6 +498,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	}
 
 	if (HT_DBG(a.dbg, 512)) return;
+	const long long t_m2 = HT_DBG(a.dbg, 2048) ? clock64() : 0;
 	// ---- two-body linear rows: joints (physmodel.h:328-334) then contacts (physics.h:463-489), each row reduced by one lane to its part of the group record ----
 	int nc = (a.contacts && ph.use_collision) ? a.ncontacts[b] : 0;
 	if (nc > HT_MAXCONTACT) nc = HT_MAXCONTACT;
@@ -538,6 +597,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	}
 	__threadfence_block();
 	__syncthreads();
+	const long long t_m2b = HT_DBG(a.dbg, 2048) ? clock64() : 0;
 	// ---- level schedule, once per solve.  The unit is a group: the 3 consecutive rows of a joint or of a contact (same two bodies, same lever
 	//      arms), respectively a run of consecutive angular rows on the same body pair.  level(group) = 1 + max level of an earlier group sharing
 	//      a body, so conflicting rows keep the reference's order; a group's own rows run back to back in one lane pair with the momenta in
@@ -553,69 +613,37 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		nga += __popcll(m);
 	}
 	__syncthreads();
-	if (lane == 0)
 	{
-		int *last = S.lastlev;               // LDS, not a private array: dynamic indexing of a private array goes to scratch memory
-		for (int k = 0; k < nb; k++) last[k] = 0;
-		int mx = 0;
-		for (int g = 0; g < ng2; g++)
+		// two-body linear groups: lane g (and g + 64) speaks for group g
+		int gb0[2], gb1[2];
+#pragma unroll
+		for (int s = 0; s < 2; s++) { const int g = lane + 64 * s; gb0[s] = g < ng2 ? S.lrb[g][0] : 255; gb1[s] = g < ng2 ? S.lrb[g][1] : 255; }
+		auto put_lorder = [&](int pos, int g, int s) { S.lorder[pos] = (unsigned)g | ((unsigned)(gb0[s] == 255 ? IDLE_BODY : gb0[s]) << 16) | ((unsigned)(gb1[s] == 255 ? IDLE_BODY : gb1[s]) << 24); };
+		auto put_lstart = [&](int step, int v) { S.lstart[step] = (unsigned short)v; };
+		const int nl = ng2 <= 64 ? level_schedule<1>(ng2, lane, gb0, gb1, put_lorder, put_lstart) : level_schedule<2>(ng2, lane, gb0, gb1, put_lorder, put_lstart);
+		// angular runs
+		int ar[2], ac[2];
+#pragma unroll
+		for (int s = 0; s < 2; s++)
 		{
-			const int b0 = S.lrb[g][0], b1 = S.lrb[g][1];
-			const int l0 = b0 != 255 ? last[b0] : 0, l1 = b1 != 255 ? last[b1] : 0;
-			int l = (l0 > l1 ? l0 : l1) + 1;
-			if (b0 != 255) last[b0] = l;
-			if (b1 != 255) last[b1] = l;
-			S.llev[g] = (unsigned short)l; if (l > mx) mx = l;
+			const int g = lane + 64 * s;
+			ar[s] = g < nga ? (int)S.gst[g] : 0;
+			ac[s] = (g + 1 < nga ? (int)S.gst[g + 1] : na) - ar[s];
+			gb0[s] = g < nga ? S.arb[ar[s]][0] : 255; gb1[s] = g < nga ? S.arb[ar[s]][1] : 255;
 		}
-		for (int l = 0; l <= mx + 1; l++) S.lfill[l] = 0;
-		for (int g = 0; g < ng2; g++) S.lfill[S.llev[g]]++;
-		int acc = 0, step = 1;
-		for (int l = 1; l <= mx; l++)          // lfill[l] becomes the first slot of level l; steps are cut every 8 groups inside a level
+		auto put_aorder = [&](int pos, int g, int s) { S.aorder[pos] = (unsigned)ar[s] | ((unsigned)ac[s] << 8) | ((unsigned)(gb0[s] == 255 ? IDLE_BODY : gb0[s]) << 16) | ((unsigned)(gb1[s] == 255 ? IDLE_BODY : gb1[s]) << 24); };
+		auto put_astart = [&](int step, int v) { S.astart[step] = (unsigned short)v; };
+		const int nla = nga <= 64 ? level_schedule<1>(nga, lane, gb0, gb1, put_aorder, put_astart) : level_schedule<2>(nga, lane, gb0, gb1, put_aorder, put_astart);
+		if (lane == 0)
 		{
-			const int m = S.lfill[l];
-			S.lfill[l] = (unsigned short)acc;
-			for (int k = 0; k < m; k += 8) S.lstart[step++] = (unsigned short)(acc + k);
-			acc += m;
+			S.nlev_lin = nl; S.nlev_ang = nla;
+			S.aorder[MAXA2] = (unsigned)na | (1u << 8) | ((unsigned)IDLE_BODY << 16) | ((unsigned)IDLE_BODY << 24);
 		}
-		S.lstart[step] = (unsigned short)acc; S.lstart[step + 1] = (unsigned short)acc;
-		S.nlev_lin = step - 1;
-		for (int g = 0; g < ng2; g++) { const int l = S.llev[g]; S.lorder[S.lfill[l]] = (unsigned)g | ((unsigned)(S.lrb[g][0] == 255 ? IDLE_BODY : S.lrb[g][0]) << 16) | ((unsigned)(S.lrb[g][1] == 255 ? IDLE_BODY : S.lrb[g][1]) << 24); S.lfill[l]++; }
-		// angular groups
-		for (int k = 0; k < nb; k++) last[k] = 0;
-		mx = 0;
-		for (int g = 0; g < nga; g++)
-		{
-			const int r = S.gst[g];
-			const int b0 = S.arb[r][0], b1 = S.arb[r][1];
-			int l0 = b0 != 255 ? last[b0] : 0, l1 = b1 != 255 ? last[b1] : 0;
-			int l = (l0 > l1 ? l0 : l1) + 1;
-			if (b0 != 255) last[b0] = l;
-			if (b1 != 255) last[b1] = l;
-			S.alev[g] = (unsigned char)l; if (l > mx) mx = l;
-		}
-		for (int l = 0; l <= mx + 1; l++) S.lfill[l] = 0;
-		for (int g = 0; g < nga; g++) S.lfill[S.alev[g]]++;
-		acc = 0; step = 1;
-		for (int l = 1; l <= mx; l++)
-		{
-			const int m = S.lfill[l];
-			S.lfill[l] = (unsigned short)acc;
-			for (int k = 0; k < m; k += 8) S.astart[step++] = (unsigned short)(acc + k);
-			acc += m;
-		}
-		S.astart[step] = (unsigned short)acc; S.astart[step + 1] = (unsigned short)acc;
-		S.nlev_ang = step - 1;
-		for (int g = 0; g < nga; g++)
-		{
-			const int l = S.alev[g], r = S.gst[g], cnt = (g + 1 < nga ? (int)S.gst[g + 1] : na) - r;
-			const unsigned b0 = S.arb[r][0] == 255 ? IDLE_BODY : S.arb[r][0], b1 = S.arb[r][1] == 255 ? IDLE_BODY : S.arb[r][1];
-			S.aorder[S.lfill[l]] = (unsigned)r | ((unsigned)cnt << 8) | (b0 << 16) | (b1 << 24); S.lfill[l]++;
-		}
-		S.aorder[MAXA2] = (unsigned)na | (1u << 8) | ((unsigned)IDLE_BODY << 16) | ((unsigned)IDLE_BODY << 24);
 	}
 	__syncthreads();
 	const int nlev_lin = S.nlev_lin, nlev_ang = S.nlev_ang;
 	if (HT_DBG(a.dbg, 64)) return;
+	const long long t_m3 = HT_DBG(a.dbg, 2048) ? clock64() : 0;
 
 	// ---- single-body prefix: [landmark-ray / boundary-plane / caller's rows] then the cloud rows.  Every row is reduced to a 64-byte record (ht_quad.hpp) where
 	//      its producer stands: a cloud row's record was written by k_cloud_rows at its point's index (a.cloud_body holds the rows' bodies), the others are
@@ -978,7 +1006,8 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		float *o = scr + (size_t)(a.scratch_stride - 1) * CREC;
 		int mc = 0; for (int k = 0; k < nb; k++) if (S.ccnt[k] > mc) mc = S.ccnt[k];
 		o[0] += 1.0f; o[1] += (float)cyc_chain; o[2] += (float)cyc_lin; o[3] += (float)cyc_ang; o[4] += (float)(clock64() - t_begin);
-		o[5] += (float)nlev_lin; o[6] += (float)nlev_ang; o[7] += (float)mc; o[8] += (float)n1; o[9] += (float)n2; o[10] += (float)na; o[11] += (float)(t_begin);
+		o[5] += (float)nlev_lin; o[6] += (float)nlev_ang; o[7] += (float)mc; o[8] += (float)n1; o[9] += (float)n2; o[10] += (float)na; o[11] += (float)(t_begin - t_entry);
+		o[12] += (float)(t_m1 - t_entry); o[13] += (float)(t_m2 - t_m1); o[14] += (float)(t_m2b - t_m2); o[15] += (float)(t_m3 - t_m2b);
 	}
 	// ---- rbupdatepose (physics.h:533-541), SanityCheck (physmodel.h:437-442), optional momentum reset (handtrack.h:686-687) ----
 	if (lane < nb)

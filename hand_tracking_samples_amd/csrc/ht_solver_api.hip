@@ -85,7 +85,7 @@ static void main_pass(ht_ctx *ctx, int B, hipStream_t s)
 	{ ht_prof_scope ps(ctx, "chamber", s, true); ht_launch_chamber(ctx->model, ctx->d_state[0], pts, npts, p.min_point_num, p.boundary_planes, 10.0f, ctx->d_chamber, ctx->d_nchamber, B, par ? ctx->side[1] : s); }
 	const cloud_records cr = cloud_rec(ctx);
 	{ ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[0], pts, npts, ctx->d_cams, nullptr, 1, 0, 1, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[0] : s, 0.0f, 0.0f, &cr); }
-	if (coll) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[0], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s); }
+	if (coll) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[0], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, par); }
 	if (par) join(ctx, s, 2);
 	ht_prof_scope ps(ctx, "solve", s);
 	solve_step(ctx, 0, ctx->d_chamber, ctx->d_nchamber, true, coll, nullptr, 0, 0.0f, 0, 0, 0, B, s);
@@ -533,8 +533,8 @@ extern "C" int ht_debug_solve_stats(ht_ctx *ctx, int B, float *out, int reset)
 	for (int b = 0; b < B; b++)
 	{
 		float *src = ctx->d_scratch + ((size_t)b * stride + (stride - 1)) * HT_CREC;
-		if (out && hipMemcpy(out + (size_t)b * 12, src, 12 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return HT_ERR_HIP;
-		if (reset && hipMemset(src, 0, 12 * sizeof(float)) != hipSuccess) return HT_ERR_HIP;
+		if (out && hipMemcpy(out + (size_t)b * 16, src, 16 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return HT_ERR_HIP;
+		if (reset && hipMemset(src, 0, 16 * sizeof(float)) != hipSuccess) return HT_ERR_HIP;
 	}
 	return HT_OK;
 }
@@ -556,9 +556,9 @@ extern "C" int ht_debug_contact_stats(ht_ctx *ctx, int B, float *out, int reset)
 	if (hipDeviceSynchronize() != hipSuccess) return HT_ERR_HIP;
 	for (int b = 0; b < B; b++)
 	{
-		float *src = ctx->d_contacts + ((size_t)b * HT_MAXCONTACT + HT_MAXCONTACT - 1) * HT_CONTACT;
-		if (out && hipMemcpy(out + (size_t)b * 12, src, 12 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return HT_ERR_HIP;
-		if (reset && hipMemset(src, 0, 12 * sizeof(float)) != hipSuccess) return HT_ERR_HIP;
+		float *src = ctx->d_contacts + ((size_t)b * HT_MAXCONTACT + HT_MAXCONTACT - 2) * HT_CONTACT;      // the last two contact slots: [1] the frame's record, [0] its wave's polytope runs
+		if (out && hipMemcpy(out + (size_t)b * 24, src, 24 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return HT_ERR_HIP;
+		if (reset && hipMemset(src, 0, 24 * sizeof(float)) != hipSuccess) return HT_ERR_HIP;
 	}
 	return HT_OK;
 }

@@ -402,8 +402,8 @@ class Context:
         return out
 
     def debug_solve_stats(self, B, reset=True):
-        """Per-frame k_solve statistics [B,12] (only filled when HT_DEBUG_SKIP=2048 is set in the environment)."""
-        out = np.zeros((B, 12), np.float32)
+        """Per-frame k_solve statistics [B,16] (only filled when HT_DEBUG_SKIP=2048 is set in the environment)."""
+        out = np.zeros((B, 16), np.float32)
         self._chk(self.L.ht_debug_solve_stats(self.h, int(B), _f(out), int(reset)))
         return out
 
@@ -429,10 +429,10 @@ class Context:
         self._chk(self.L.ht_debug_solver_build(self.h, int(which)))
 
     def debug_contact_stats(self, B, reset=True):
-        """Per-frame k_contacts statistics [B,12] (only filled when HT_DEBUG_SKIP=2048 is set in the environment)."""
-        out = np.zeros((B, 12), np.float32)
+        """Per-frame k_contacts statistics [B,12] + the polytope runs of the frame's wave [B,5] (only filled when HT_DEBUG_SKIP=2048 is set in the environment)."""
+        out = np.zeros((B, 24), np.float32)
         self._chk(self.L.ht_debug_contact_stats(self.h, int(B), _f(out), int(reset)))
-        return out
+        return np.concatenate([out[:, 12:], out[:, :5]], axis=1)
 
     def segment_vr(self, depth, cams, entry_options=0xF, wrange=(0.1, 0.65), diam=0.17):
         """HandSegmentVR (handtrack.h:280-344) for a batch: depth u16[B,h,w], cams [B,12] -> (tiles u16[B,64,64], cams [B,12])."""

@@ -295,9 +295,9 @@ int ht_comm_destroy(ht_ctx *ctx);
 int ht_profile_enable(ht_ctx *ctx, int on);
 int ht_profile_read(ht_ctx *ctx, int reset, int max_entries, char *names, int name_stride, float *total_ms, int *launches, int *n_entries);
 /* Tuning aid, no reference counterpart: with the environment variable HT_DEBUG_SKIP=2048 every k_solve launch accumulates per-frame
- * statistics (launches, cycles in chains / two-body linear / angular rows / all sweeps, steps, longest chain, row counts), 12 floats per frame. */
+ * statistics (launches, cycles in chains / two-body linear / angular rows / all sweeps, steps, longest chain, row counts, prologue parts), 16 floats per frame. */
 int ht_debug_solve_stats(ht_ctx *ctx, int B, float *out, int reset);
-int ht_debug_contact_stats(ht_ctx *ctx, int B, float *out, int reset);      /* same for k_contacts */
+int ht_debug_contact_stats(ht_ctx *ctx, int B, float *out, int reset);      /* same for k_contacts: 24 floats per frame (5 about its wave's polytope runs, 7 unused, 12 about the frame) */
 /* Test aid: pins which build of the solver kernel runs (0 = chosen per launch; 1-3 the LDS sizes for tile batches / small batches / large frames and models;
  * 4 = a build whose LDS arrays hold nothing, so every frame places its row records in HBM).  Placement only: results are identical bit for bit. */
 int ht_debug_solver_build(ht_ctx *ctx, int which);

@@ -29,6 +29,8 @@ for it in range(2):
 n = st[:, 0:1]
 print("launches/frame", np.unique(st[:, 0]))
 names = ["chain", "linear", "angular", "sweeps_total"]
+print("prologue parts, mean cycles/frame: state+rays %.0f, angular rows %.0f, linear groups %.0f, level schedule %.0f, chain lists+records %.0f" % (tuple(st[:, 12:16].mean(axis=0)) + ((st[:, 11] - st[:, 12:16].sum(axis=1)).mean(),)))
+print("prologue (entry to first sweep) cycles/frame: mean %.0f p90 %.0f max %.0f" % (st[:, 11].mean(), np.percentile(st[:, 11], 90), st[:, 11].max()))
 for k, nm in enumerate(names):
     c = st[:, 1 + k]
     print("%-12s cycles/frame: mean %.0f  p50 %.0f  p90 %.0f  max %.0f (frame %d)" % (nm, c.mean(), np.median(c), np.percentile(c, 90), c.max(), c.argmax()))
@@ -48,3 +50,9 @@ print("slowest blocks (per launch): owner, epa_phase, epa_runs, iterations, scan
 for f in order:
     r = cs[f] / cs[f, 0]
     print("  frame %4d: %7.0f %7.0f %5.2f %5.1f %7.0f %7.0f %7.0f %5.1f %7.0f" % (f, r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[11]))
+for k, nm in zip(range(12, 17), ["epa_face", "epa_support", "epa_surgery", "epa_iters", "epa_jobs"]):
+    c = cs[:, k]
+    print("%-13s of the frame's wave: mean %.0f  p50 %.0f  p90 %.0f  max %.0f (frame %d)" % (nm, c.mean(), np.median(c), np.percentile(c, 90), c.max(), c.argmax()))
+j = cs[:, 16].sum()
+if j > 0:
+    print("per polytope run: face %.0f support %.0f surgery %.0f cycles, %.1f iterations" % (cs[:, 12].sum() / j, cs[:, 13].sum() / j, cs[:, 14].sum() / j, cs[:, 15].sum() / j))
