@@ -55,8 +55,8 @@
 // the build's choice -- the two-body linear groups (256 B each), the impulse sums of the single-body rows (4 B each), the angular records (64 B each).
 // A frame whose rows do not fit an array keeps THAT array in its slot of the solver scratch in HBM instead (same code through a generic pointer): slower
 // for that frame, correct for every frame, one launch.  Builds (ht_launch_solve):
-//   small   38 groups (16 joints + 21 contacts), 584 sums, 84 angular rows (13 CNN-driven + 71 of the hand's joints), chain lists in HBM: 22.5 KB = 45 LDS
-//           allocation units of 512 B, seven frames per CU.  Batches above 1024 frames of 64x64 tiles.
+//   small   34 groups (16 joints + 17 contacts), 584 sums, 84 angular rows (13 CNN-driven + 71 of the hand's joints), chain lists in HBM: 20 KB = 40 LDS
+//           allocation units of 512 B, EIGHT frames per CU (2048 frames fill the GPU in one round, 8192 in four).  Batches above 1024 frames of 64x64 tiles.
 //   only    66 groups (16 joints + 49 contacts), 1024 sums and chain entries, 126 angular rows: 36 KB, four frames per CU (a 1024-frame batch in one round).
 //   mid     71 groups, 1520 sums and chain entries, 126 angular rows: 40 KB, four frames per CU.  Larger models, full-size frames.
 #define IDLE_BODY (HT_MAXNB - 1)      // lane pairs without a row in a step work on this all-zero body and on an all-zero record
@@ -67,12 +67,10 @@ template <int NGRP_, int NSUM_, int NANG_, int NIDX_> struct lds_t
 {
 	static constexpr int NGRP = NGRP_, NSUM = NSUM_, NANG = NANG_, NIDX = NIDX_;
 	static constexpr int LIDLE = MAXG - 1;                      // slot of the idle entry in lorder
-	static constexpr int NLEV = (MAXG > 64 * 2 ? MAXG : 64 * 2) + 2;      // levels of either schedule (linear groups, angular runs)
 	float pool[NGRP * LGRP] __attribute__((aligned(16)));      // two-body linear groups; first member: group addresses then fit the short offsets of two-address LDS reads
 	// body state in 16-byte records: component c of body b is word 4*b + c
 	float4 lin4[HT_MAXNB];                 // xyz linear momentum, w = massinv
 	float4 ang4[HT_MAXNB];                 // xyz angular momentum, w = friction
-	float4 I4[HT_MAXNB][3];                // columns of the world inverse inertia (w unused); prologue only
 	float pos[HT_MAXNB][3], q[HT_MAXNB][4];
 	float csum[NSUM];                      // impulse sum of every single-body row, in chain order (+ read-ahead slack)
 	unsigned short cidx[NIDX > 0 ? NIDX : 2];   // the chains: record index of every single-body row, in chain order (+ read-ahead slack); in HBM when the build has no room
@@ -91,9 +89,8 @@ template <int NGRP_, int NSUM_, int NANG_, int NIDX_> struct lds_t
 			float ray[36][HT_ROW];                 // landmark-ray rows: 4 per ray (MultiStepSim: 5 rays; slowfit: 8 rays + 3 nail rows)
 			int acount[HT_MAXNJ], aprefix[HT_MAXNJ + 1], rprefix[HT_MAXNJ + 1];
 			unsigned char lrb[MAXG][2], arb[MAXA2][2];     // body pair of every group / angular row (255 = none), for the level schedule
-			unsigned short llev[MAXG]; unsigned char alev[MAXA2], gst[MAXA2];
-			unsigned short lfill[NLEV];
-			int lastlev[HT_MAXNB];                 // scratch of the level scheduler
+			unsigned char gst[MAXA2];              // first row of every angular run
+			float4 I4[HT_MAXNB][3];                // columns of the world inverse inertia (w unused): only the row builders need it
 		};
 		float arec[(NANG + 4) * AROW] __attribute__((aligned(16)));      // sweeps: angular records (written once the prologue scratch is dead) + the idle record + read-ahead slack
 	};
@@ -751,6 +748,16 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			}
 		}
 	}
+	// the last use of the inverse inertias, which share LDS with the angular records: every row's Iinv*axis, while the table is still there
+	v3 ABA0[ASLOTS], ABA1[ASLOTS];
+#pragma unroll
+	for (int s = 0; s < ASLOTS; s++)
+	{
+		const arow &R = AR[s];
+		const bool on = lane + 64 * s < na;
+		ABA0[s] = (on && R.rb0 >= 0) ? -mul(body_I(S, R.rb0), R.axis) : V3(0, 0, 0);
+		ABA1[s] = (on && R.rb1 >= 0) ? mul(body_I(S, R.rb1), R.axis) : V3(0, 0, 0);
+	}
 	__threadfence_block();      // the records and lists are read back by other lanes of this wave
 	__syncthreads();
 	// ---- the prologue scratch is dead now: angular rows move from their builder lanes into their records ----
@@ -768,7 +775,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			o[AR_S] = R.targetspin; o[AR_S + 1] = ts_post; o[AR_S + 2] = R.mn; o[AR_S + 3] = R.mx;
 			o[AR_GAIN] = R.s2t; o[AR_TORQUE] = 0.0f;
 			o[AR_AXIS] = R.axis.x; o[AR_AXIS + 1] = R.axis.y; o[AR_AXIS + 2] = R.axis.z; o[AR_AXIS + 3] = 0.0f;
-			const v3 ba0 = R.rb0 >= 0 ? -mul(body_I(S, R.rb0), R.axis) : V3(0, 0, 0), ba1 = R.rb1 >= 0 ? mul(body_I(S, R.rb1), R.axis) : V3(0, 0, 0);
+			const v3 ba0 = ABA0[s], ba1 = ABA1[s];
 			o[AR_BA] = ba0.x; o[AR_BA + 1] = ba0.y; o[AR_BA + 2] = ba0.z; o[AR_BA + 3] = ba1.x; o[AR_BA + 4] = ba1.y; o[AR_BA + 5] = ba1.z;
 		}
 	}
@@ -788,7 +795,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	const int c1 = (cc + 1) % 3, c2 = (cc + 2) % 3;
 	const int side = quad & 1;                                            // two-body rows: even quad = rb0, odd quad = rb1
 	const int sidesign = side ? 0 : (int)0x80000000;                      // rb0 receives -impulse, and contributes -v0 to v1 - v0
-	float *const lin_w = reinterpret_cast<float *>(S.lin4), *const ang_w = reinterpret_cast<float *>(S.ang4), *const I_w = reinterpret_cast<float *>(S.I4);
+	float *const lin_w = reinterpret_cast<float *>(S.lin4), *const ang_w = reinterpret_cast<float *>(S.ang4);
 	const int pslot = lane >> 3;
 	const int ls_lin = S.lstart[lane], ls_ang = S.astart[lane];      // step boundaries of the first 63 steps, read back with v_readlane
 	// ---- the two phases of the two-body tail, written once and instantiated for records in LDS (the frame fits the build) and in HBM (it does not) ----
@@ -1025,6 +1032,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	}
 }
 
+static_assert(sizeof(lds_t<34, 584, 84, 0>) <= 20480, "the small build must leave room for eight frames per CU (160 KB of LDS)");
 static_assert(HT_SCRATCH_TAIL * HT_CREC >= MAXG * LGRP + (MAXA_LDS + 4) * AROW + HT_CREC, "the tail of a frame's scratch slot must hold its linear groups, its angular records and the tuning record");
 void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solve_args &a, int B, hipStream_t s)
 {
@@ -1037,7 +1045,7 @@ void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solv
 	int build = a.force_build;
 	if (!build) build = tile ? (B <= 1024 && !a.shared_gpu ? 2 : 1) : 3;
 	if (build == 2) hipLaunchKernelGGL((k_solve<66, 1024, 126, 1024>), dim3(B), dim3(64), 0, s, M, ph, a);
-	else if (build == 1) hipLaunchKernelGGL((k_solve<38, 584, 84, 0>), dim3(B), dim3(64), 0, s, M, ph, a);
+	else if (build == 1) hipLaunchKernelGGL((k_solve<34, 584, 84, 0>), dim3(B), dim3(64), 0, s, M, ph, a);
 	else if (build == 3) hipLaunchKernelGGL((k_solve<71, 1520, 126, 1520>), dim3(B), dim3(64), 0, s, M, ph, a);
 	else hipLaunchKernelGGL((k_solve<2, 64, 4, 0>), dim3(B), dim3(64), 0, s, M, ph, a);      // tests only: nothing fits, every frame keeps its groups, sums and angular records in HBM
 }
