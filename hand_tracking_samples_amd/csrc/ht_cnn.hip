@@ -158,7 +158,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // apart: the 4x4 pixels a 16-lane group reads fall on 16 different banks, and neighbouring taps re-read the same words, which is a broadcast).
 // The seven weight fragments of a lane stay in registers; per window a wave issues 7 LDS reads and 7 MFMAs, the maximum over the window's 16 rows
 // is four register maxima and two cross-lane steps, and tanh (an exponential in double) is applied once per pooled value by all threads at the end.
-// 64x64 input: IW = 64, PW = 15, PR = 15 (one block per frame).  128x128 input (BASELINE configs[4]): IW = 128, PW = 31, PR = 8 -> 4 bands of
+// 64x64 input: IW = 64, PW = 15, PR = 15 (one block per frame; bands of 8, 5 or 3 pooled rows, which would stagger the blocks' phases, were measured: no change).  128x128 input (BASELINE configs[4]): IW = 128, PW = 31, PR = 8 -> 4 bands of
 // 36 rows (19 KB) instead of one 64 KB tile, so several blocks stay resident per CU.
 template <int IW, int PW, int PR>
 __global__ __launch_bounds__(256) void k_conv1(const float *__restrict__ cnn_in, const float *__restrict__ W1, const float *__restrict__ B1, float *__restrict__ act1)
@@ -265,64 +265,84 @@ __global__ __launch_bounds__(256) void k_conv2(const float *__restrict__ act1, c
 // holds two waves per SIMD, so one wave's LDS reads and the global prefetch of the next k-slab overlap the other's matrix instructions
 // (an fp32 32x32x2 MFMA occupies the pipe for 64 cycles).  LDS tiles are double-buffered: one barrier per k-slab.
 // Every output element accumulates k in ascending order from its bias, like the reference's loop (cnn.h:407-426).
-#define FC_BM 128
-#define FC_BK 32
-#define FC_LDA (FC_BM + 1)
-// WN = waves along N: the block tile is 128 x 32*WN.  N = 2048 uses WN = 2 (256 blocks = one per CU); N = 2304 uses WN = 3 (192 blocks of
-// 12 waves) because 288 blocks of the smaller tile would leave 32 CUs with two blocks and everyone waiting for them.
-template <bool TANH, int WN>
-__global__ __launch_bounds__(256 * WN) void k_fc(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K)
+#define FC_BK 32      // k-depth of a slab (64 was measured slower, here as in k_fc144: 116 against 100 us)
+// WN = waves along N, WM = waves along M: the block tile is 32*WM x 32*WN.  N = 2048 uses WN = 2; N = 2304 used WN = 3 (192 blocks of
+// 12 waves) before k_fc144 took that layer.  WM = 4: 128 rows, 8 waves, one block per CU at 1024 frames.  (Half tiles, WM = 2 with two blocks of
+// four waves per CU so that one block's barrier does not idle the matrix pipes, were measured: 100 us either way.)
+template <bool TANH, int WN, int WM>
+__global__ __launch_bounds__(64 * WM * WN) void k_fc(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K)
 {
-	constexpr int BN = 32 * WN, NT = 256 * WN;
-	__shared__ float As[2][FC_BK * FC_LDA];
+	constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * WM * WN, LDA = BM + 1;
+	__shared__ float As[2][FC_BK * LDA];
 	__shared__ __attribute__((aligned(16))) float Bs[2][FC_BK * BN];
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / WN, wn = wave % WN;
-	const int m0 = blockIdx.y * FC_BM, n0 = blockIdx.x * BN;
-	// staging assignments: A tile = 1024 float4 (row = i >> 3, 4 consecutive k), B tile = 8*BN float4 = NT of them (one per thread)
-	const int bk = t / (8 * WN), bnc = (t % (8 * WN)) * 4;
-	constexpr int NA = (1024 + NT - 1) / NT;
-	float4 ra[NA], rb;
-	auto gload = [&](int k0) {
+	const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+	// staging assignments: A tile = BM*BK/4 float4 (row = e / (BK/4), 4 consecutive k), B tile = BK*BN/4 float4 (k-row = e / (BN/4)).  Global loads run TWO
+	// slabs ahead of the matrix instructions through two register sets (a slab's ~1000 MFMA cycles per wave are shorter than a loaded memory
+	// system's latency: with one slab of distance the LDS store at the end of every slab waited for its loads).
+	constexpr int KV = FC_BK / 4, NAV = BM * KV, NBV = FC_BK * BN / 4;      // float4 per tile row of A, per A tile, per B tile
+	constexpr int NA = (NAV + NT - 1) / NT, NB = (NBV + NT - 1) / NT;
+	float4 ra[2][NA], rb[2][NB];
+	auto gload = [&](float4 (&qa)[NA], float4 (&qb)[NB], int k0) {
 #pragma unroll
 		for (int i = 0; i < NA; i++)
 		{
-			const int e = t + NT * i, row = m0 + (e >> 3);
-			ra[i] = (e < 1024 && row < M) ? *reinterpret_cast<const float4 *>(A + (size_t)row * K + k0 + (e & 7) * 4) : make_float4(0, 0, 0, 0);
+			const int e = t + NT * i, row = m0 + e / KV;
+			qa[i] = (e < NAV && row < M) ? *reinterpret_cast<const float4 *>(A + (size_t)row * K + k0 + (e % KV) * 4) : make_float4(0, 0, 0, 0);
 		}
-		rb = *reinterpret_cast<const float4 *>(W + (size_t)(k0 + bk) * N + n0 + bnc);
+#pragma unroll
+		for (int i = 0; i < NB; i++)
+		{
+			const int e = t + NT * i, bk = e / (BN / 4), bnc = (e % (BN / 4)) * 4;
+			qb[i] = e < NBV ? *reinterpret_cast<const float4 *>(W + (size_t)(k0 + bk) * N + n0 + bnc) : make_float4(0, 0, 0, 0);
+		}
 	};
-	auto lstore = [&](int buf) {
+	auto lstore = [&](const float4 (&qa)[NA], const float4 (&qb)[NB], int buf) {
 #pragma unroll
 		for (int i = 0; i < NA; i++)
 		{
-			const int e = t + NT * i, row = e >> 3, akc = (e & 7) * 4;
+			const int e = t + NT * i, row = e / KV, akc = (e % KV) * 4;
 			float *a = As[buf];
-			if (e < 1024) { a[(akc + 0) * FC_LDA + row] = ra[i].x; a[(akc + 1) * FC_LDA + row] = ra[i].y; a[(akc + 2) * FC_LDA + row] = ra[i].z; a[(akc + 3) * FC_LDA + row] = ra[i].w; }
+			if (e < NAV) { a[(akc + 0) * LDA + row] = qa[i].x; a[(akc + 1) * LDA + row] = qa[i].y; a[(akc + 2) * LDA + row] = qa[i].z; a[(akc + 3) * LDA + row] = qa[i].w; }
 		}
-		*reinterpret_cast<float4 *>(Bs[buf] + bk * BN + bnc) = rb;
+#pragma unroll
+		for (int i = 0; i < NB; i++)
+		{
+			const int e = t + NT * i, bk = e / (BN / 4), bnc = (e % (BN / 4)) * 4;
+			if (e < NBV) *reinterpret_cast<float4 *>(Bs[buf] + bk * BN + bnc) = qb[i];
+		}
 	};
 	const float bv = bias[n0 + wn * 32 + (lane & 31)];
 	f32x16 acc;
 #pragma unroll
 	for (int r = 0; r < 16; r++) acc[r] = bv;
-	gload(0);
-	lstore(0);
-	int buf = 0;
-	for (int k0 = 0; k0 < K; k0 += FC_BK)
+	gload(ra[0], rb[0], 0);
+	if (FC_BK < K) gload(ra[1], rb[1], FC_BK);
+	lstore(ra[0], rb[0], 0);
+	for (int k0 = 0; k0 < K; k0 += 2 * FC_BK)
 	{
-		__syncthreads();                                   // slab `buf` is complete; the other buffer is free (its readers passed this barrier)
-		const bool more = k0 + FC_BK < K;
-		if (more) gload(k0 + FC_BK);
-		const float *ap = As[buf] + (lane >> 5) * FC_LDA + wm * 32 + (lane & 31);
-		const float *bp = Bs[buf] + (lane >> 5) * BN + wn * 32 + (lane & 31);
 #pragma unroll
-		for (int kk = 0; kk < FC_BK / 2; kk++)
+		for (int u = 0; u < 2; u++)      // slab k0/32 + u: its tile is in LDS buffer u, the next slab's loads are in flight in register set u ^ 1
 		{
-			const float a0 = ap[2 * kk * FC_LDA], bb = bp[2 * kk * BN];
-			acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bb, acc, 0, 0, 0);
+			const int kc = k0 + u * FC_BK;
+			if (kc >= K) break;
+			__syncthreads();                               // buffer u is complete; buffer u ^ 1 is free (its readers passed this barrier)
+			if (kc + 2 * FC_BK < K) gload(ra[u], rb[u], kc + 2 * FC_BK);      // set u was stored one slab ago
+			const float *ap = As[u] + (lane >> 5) * LDA + wm * 32 + (lane & 31);
+			const float *bp = Bs[u] + (lane >> 5) * BN + wn * 32 + (lane & 31);
+			// operand fragments: the first half of the slab is read up front, the second half's reads are slotted between the first half's matrix
+			// instructions (left to itself the scheduler issues each B pair right before the two MFMAs that use it: an LDS round trip every 128 pipe cycles)
+			float av[FC_BK / 2], bw[FC_BK / 2];
+#pragma unroll
+			for (int kk = 0; kk < FC_BK / 2; kk++) { av[kk] = ap[2 * kk * LDA]; bw[kk] = bp[2 * kk * BN]; }
+#pragma unroll
+			for (int kk = 0; kk < FC_BK / 2; kk++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bw[kk], acc, 0, 0, 0);
+			__builtin_amdgcn_sched_group_barrier(0x100, 12, 0);      // A 0-7 (8 reads), B 0-7 (4 paired reads)
+#pragma unroll
+			for (int i = 0; i < (FC_BK / 2 - 8) * 3 / 4; i++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+			__builtin_amdgcn_sched_group_barrier(0x008, FC_BK / 2, 0);
+			if (kc + FC_BK < K) lstore(ra[u ^ 1], rb[u ^ 1], u ^ 1);
 		}
-		if (more) lstore(buf ^ 1);
-		buf ^= 1;
 	}
 	// C/D map 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 	const int col = n0 + wn * 32 + (lane & 31);
@@ -608,18 +628,18 @@ void ht_launch_prepare_frame(const uint16_t *depth, const float *cams, int w, in
 // side = 64: PoseInitializerCNN's topology (handtrack.h:108-118); side = 128: the same layers on a 128x128 input (act1 [B][16*31*31], act2 [B][12544])
 void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, float *act2, float *act3, float *logits, int B, hipStream_t s, int side)
 {
-	dim3 g1(2048 / 64, (B + FC_BM - 1) / FC_BM);
+	const dim3 g1(2048 / 64, (B + 127) / 128), t1(512);
 	if (side == 128)
 	{
 		hipLaunchKernelGGL((k_conv1<128, 31, 8>), dim3(B, 4), dim3(256), 0, s, cnn_in, w.W1, w.B1, act1);
 		hipLaunchKernelGGL((k_conv2<31, 28, 4>), dim3(B, 7), dim3(256), 0, s, act1, w.W2p, w.B2, act2);
-		hipLaunchKernelGGL((k_fc<true, 2>), g1, dim3(512), 0, s, act2, w.W3, w.B3, act3, B, 2048, 12544);
+		hipLaunchKernelGGL((k_fc<true, 2, 4>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 12544);
 	}
 	else
 	{
 		hipLaunchKernelGGL((k_conv1<64, 15, 15>), dim3(B, 1), dim3(256), 0, s, cnn_in, w.W1, w.B1, act1);
 		hipLaunchKernelGGL((k_conv2<15, 12, 12>), dim3(B, 1), dim3(256), 0, s, act1, w.W2p, w.B2, act2);
-		hipLaunchKernelGGL((k_fc<true, 2>), g1, dim3(512), 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
+		hipLaunchKernelGGL((k_fc<true, 2, 4>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
 	}
 	hipLaunchKernelGGL(k_fc144, dim3(2304 / F2_BN, (B + F2_BM - 1) / F2_BM), dim3(768), 0, s, act3, w.W4, w.B4, logits, B, 2304, 2048);
 }
