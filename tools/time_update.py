@@ -17,6 +17,7 @@ depth, cams, start = d["depth"][idx].reshape(B, -1), d["cam"][idx], d["startpose
 dev = torch.device("cuda:0")
 c = native.Context(os.path.join(ROOT, "hand_tracking_samples_amd", "assets", "model_hand17.htfx"), B)
 c.load_weights(W.make_cnnb()); c.set_params(microforce=3.0, mainthreadpasses=3, **kw)
+if os.environ.get("BUILD"): c.debug_solver_build(int(os.environ["BUILD"]))      # pin k_solve's build: 1 small (8 frames per CU), 2 only (4 per CU), 3 mid
 bufs = (torch.from_numpy(depth.view(np.int16)).to(dev), torch.from_numpy(cams).to(dev), torch.from_numpy(start).to(dev), torch.empty((B, 17, 7), dtype=torch.float32, device=dev))
 s = torch.cuda.current_stream(dev)
 def step(): c.update_dev(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), B, bufs[3].data_ptr(), s.cuda_stream)
