@@ -87,7 +87,8 @@ template <int NGRP_, int NSUM_, int NANG_, int NIDX_> struct lds_t
 		{
 			float jr[HT_MAXNJ][6];                 // joint ranges after HandModelEnhancements
 			float ray[36][HT_ROW];                 // landmark-ray rows: 4 per ray (MultiStepSim: 5 rays; slowfit: 8 rays + 3 nail rows)
-			int acount[HT_MAXNJ], aprefix[HT_MAXNJ + 1], rprefix[HT_MAXNJ + 1];
+			int aprefix[HT_MAXNJ + 1], rprefix[HT_MAXNJ + 1];
+			unsigned char rowj[MAXA2];             // joint of every joint-range row
 			unsigned char lrb[MAXG][2], arb[MAXA2][2];     // body pair of every group / angular row (255 = none), for the level schedule
 			unsigned char gst[MAXA2];              // first row of every angular run
 			float4 I4[HT_MAXNB][3];                // columns of the world inverse inertia (w unused): only the row builders need it
@@ -158,6 +159,39 @@ __device__ __forceinline__ void angular_range_w(const ht_physics_dev &ph, int rb
 		emit_ang(out, rb0, rb1, qzdir(jf1), (float)(2 * ((double)(-t.z) + sin((double)(jmin.z / 2.0f))) / (double)dt), 0, FLT_MAX);
 		emit_ang(out, rb0, rb1, -qzdir(jf1), (float)(2 * ((double)(t.z) - sin((double)(jmax.z / 2.0f))) / (double)dt), 0, FLT_MAX);
 	}
+}
+// Row `want` of the rows ConstrainAngularRangeW emits for a joint (same order, same expressions as angular_range_w above, which builds them all): a lane
+// that owns one row pays for one double-precision sine instead of up to six.  The two-sided rows' target spins are 2*((-c) + sin(min/2))/dt and
+// 2*(c - sin(max/2))/dt; c - s is evaluated as c + (-s), which is the same IEEE operation.
+__device__ __forceinline__ void angular_range_row(const ht_physics_dev &ph, int rb0, v4 jb0, int rb1, v4 jf1, v3 lmin, v3 lmax, int want, float *row)
+{
+	const float dt = ph.deltaT;
+	v3 jmin = (lmin * 3.14f) / 180.0f, jmax = (lmax * 3.14f) / 180.0f;
+	if (jmin.x == 0 && jmax.x == 0 && jmin.z < jmax.z)
+	{
+		v4 cb = normalize(V4(0, -1, 0, 1));
+		jb0 = qmul(jb0, cb); jf1 = qmul(jf1, cb);
+		v3 nmin = V3(lmin.z, lmin.y, 0), nmax = V3(lmax.z, lmax.y, 0);
+		lmin = nmin; lmax = nmax;
+		jmin = (lmin * 3.14f) / 180.0f; jmax = (lmax * 3.14f) / 180.0f;
+	}
+	const v4 r = qmul(qconj(jb0), jf1);
+	const v4 s = quat_from_to(V3(0, 0, 1.0f), qzdir(r));
+	const v4 t = qmul(qconj(s), r);
+	// which axis and which of its rows
+	const int nx = (jmax.x == jmin.x) ? 1 : ((jmax.x - jmin.x < 360.0f * 3.14f / 180.0f) ? 2 : 0), ny = (jmax.y == jmin.y) ? 1 : 2;
+	int k = want, axis = 0;
+	if (k >= nx) { k -= nx; axis = 1; if (k >= ny) { k -= ny; axis = 2; } }
+	const float lo = axis == 0 ? jmin.x : axis == 1 ? jmin.y : jmin.z, hi = axis == 0 ? jmax.x : axis == 1 ? jmax.y : jmax.z;
+	const float comp = axis == 0 ? s.x : axis == 1 ? s.y : t.z;
+	const v3 dir = axis == 0 ? qxdir(jf1) : axis == 1 ? qydir(jf1) : qzdir(jf1);
+	const bool equal = hi == lo, upper = !equal && k == 1;
+	const double sn = sin((double)((upper ? hi : lo) / 2.0f));
+	const float two_sided = (float)(2 * ((double)(upper ? comp : -comp) + (upper ? -sn : sn)) / (double)dt);
+	float ts = two_sided;
+	if (equal && axis == 1) ts = ph.biasfactorjoint * 2 * (-s.y + jmin.y) / dt;
+	if (equal && axis == 2) ts = ph.biasfactorjoint * 2 * -t.z / dt;
+	put_ang(row, rb0, rb1, upper ? -dir : dir, ts, equal ? -FLT_MAX : 0, FLT_MAX);
 }
 // ConstrainConeAngle physics.h:402-414
 template <class LDS> __device__ __forceinline__ void cone_angle(const ht_physics_dev &ph, const LDS &S, int rb0, v3 n0, int rb1, v3 n1, float limitangle_degrees, float *out)
@@ -391,23 +425,24 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	// slowfit's RelativeAngularConstraints (physmodel.h:423-432, filter handtrack.h:799): one row per ranged axis of every joint that passes
 	const bool rel = a.sf_refpose && a.sf_hold;
 	const int na_user = a.ang_user ? (a.n_ang_user[b] < MAXA_LDS ? a.n_ang_user[b] : MAXA_LDS) : 0;      // the caller's rows lead the list (PhysModel::FitPointCloud appends its own, physmodel.h:351)
-	if (lane < nj) S.acount[lane] = a.no_model_rows ? 0 : angular_range_count(L3(S.jr[lane]), L3(S.jr[lane] + 3));
-	__syncthreads();
-	if (lane == 0)
+	// row counts per joint (lane j = joint j), their prefixes over the joints by a scalar walk through the lanes' registers, and the owner table of the range rows
+	int na_pre, na;
+	const int na_fix = na_user + (a.apply_angles ? 12 : 0) + (a.arm_cone ? 1 : 0);      // [caller's rows | ApplyAngles, arm cone | relative rows | joint ranges]
 	{
-		int acc = na_user + (a.apply_angles ? 12 : 0) + (a.arm_cone ? 1 : 0);
+		const int acnt = (lane < nj && !a.no_model_rows) ? angular_range_count(L3(S.jr[lane]), L3(S.jr[lane] + 3)) : 0;
+		int rcnt = 0;
+		if (rel && lane < nj && ((lane != 0 && a.sf_hold == 2) || lane > 3)) for (int ax = 0; ax < 3; ax++) rcnt += S.jr[lane][ax] != S.jr[lane][3 + ax];
+		int rpre = 0, apre = 0, rtot = 0, atot = 0;
 		for (int j = 0; j < nj; j++)
 		{
-			S.rprefix[j] = acc;
-			if (rel && ((j != 0 && a.sf_hold == 2) || j > 3)) for (int ax = 0; ax < 3; ax++) acc += S.jr[j][ax] != S.jr[j][3 + ax];
+			const int rc = __builtin_amdgcn_readlane(rcnt, j), ac = __builtin_amdgcn_readlane(acnt, j);
+			rpre += j < lane ? rc : 0; apre += j < lane ? ac : 0; rtot += rc; atot += ac;
 		}
-		S.rprefix[nj] = acc;
-		for (int j = 0; j < nj; j++) { S.aprefix[j] = acc; acc += S.acount[j]; }
-		S.aprefix[nj] = acc;
+		na_pre = na_fix + rtot; na = na_pre + atot;
+		if (lane <= nj) { S.rprefix[lane] = na_fix + rpre; S.aprefix[lane] = na_pre + apre; }
+		for (int k = 0; k < acnt; k++) if (na_pre + apre + k < MAXA2) S.rowj[na_pre + apre + k] = (unsigned char)lane;
 	}
 	__syncthreads();
-	const int na_fix = na_user + (a.apply_angles ? 12 : 0) + (a.arm_cone ? 1 : 0), na_pre = S.rprefix[nj];      // [caller's rows | ApplyAngles, arm cone | relative rows | joint ranges]
-	int na = S.aprefix[nj];
 	if (na > MAXA_LDS && a.caps && lane == 0) atomicAdd(a.caps, 1);      // more angular rows than the kernel holds: the excess is dropped, and reported
 	if (na > MAXA2) na = MAXA2;
 	arow AR[ASLOTS];
@@ -474,16 +509,12 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			}
 			else
 			{
-				int j = 0;
-				while (j + 1 < nj && S.aprefix[j + 1] <= r) j++;
+				const int j = S.rowj[r];
 				const int sub = r - S.aprefix[j];
 				const float *jc = M.jointc + j * HT_JC;
 				const int rb0 = (int)jc[HT_JC_RB0], rb1 = (int)jc[HT_JC_RB1];
 				const v4 jf = L4(jc + HT_JC_FRAME);
-				ang_sink sink; sink.want = sub; sink.n = 0;
-				for (int k = 0; k < 8; k++) sink.row[k] = 0.0f;
-				angular_range_w(ph, rb0, rb0 >= 0 ? qmul(L4(S.q[rb0]), jf) : jf, rb1, rb1 >= 0 ? L4(S.q[rb1]) : V4(0, 0, 0, 1), L3(S.jr[j]), L3(S.jr[j] + 3), sink);
-				for (int k = 0; k < 8; k++) row[k] = sink.row[k];
+				angular_range_row(ph, rb0, rb0 >= 0 ? qmul(L4(S.q[rb0]), jf) : jf, rb1, rb1 >= 0 ? L4(S.q[rb1]) : V4(0, 0, 0, 1), L3(S.jr[j]), L3(S.jr[j] + 3), sub, row);
 			}
 			R.rb0 = __float_as_int(row[0]); R.rb1 = __float_as_int(row[1]); R.axis = V3(row[2], row[3], row[4]); R.targetspin = row[5];
 			const float mintorque = row[6], maxtorque = row[7];
