@@ -240,7 +240,7 @@ __device__ int gjk_run(const support_t &A, const support_t &B, float cutoff, gjk
 // A triangle is one 16-byte record (vertex ids, pad, neighbour ids, pad) so that the mesh surgery, which is a chain of dependent look-ups,
 // fetches a whole triangle with one 128-bit LDS read and decides in registers; neighbour slots are patched with 16-bit stores.
 struct __attribute__((aligned(16))) epa_tri { short v[3], pad0, n[3], pad1; };
-struct epa_mem { epa_tri t[EPA_MAXT]; float4 v[EPA_MAXV]; };      // a vertex is one 128-bit read (the per-lane phases gather three per triangle)
+struct epa_mem { epa_tri t[EPA_MAXT]; float4 v[EPA_MAXV]; unsigned char who[EPA_MAXT], map[EPA_MAXT]; };      // a vertex is one 128-bit read (the per-lane phases gather three per triangle); who / map: the compaction's slot tables
 struct tri_r { int v0, v1, v2, n0, n1, n2; };
 // the mesh surgery is executed by every lane on the same values (same stores from all lanes), so each lane's own program order keeps it coherent
 __device__ __forceinline__ v3 ev(const epa_mem &m, int i) { const float4 q = m.v[i]; return V3(q.x, q.y, q.z); }
@@ -257,7 +257,15 @@ __device__ __forceinline__ void tri_set(epa_mem &m, int t, int a, int b, int c, 
 __device__ __forceinline__ void tri_kill(epa_mem &m, int t) { *reinterpret_cast<int2 *>(&m.t[t].n[0]) = make_int2(-1, 0xffff); }      // n = -1, -1, -1
 __device__ __forceinline__ bool tri_dead(const epa_mem &m, int t) { return m.t[t].n[0] == -1; }
 __device__ __forceinline__ bool hasvert(const tri_r &T, int x) { return T.v0 == x || T.v1 == x || T.v2 == x; }
-__device__ __forceinline__ int tri_n(const tri_r &T, int slot) { return slot == 0 ? T.n0 : (slot == 1 ? T.n1 : T.n2); }
+// a field picked by a run-time index comes out of a packed word by a shift: a select chain over the struct's fields is turned into an indexed array on
+// the STACK by the compiler (scratch memory: a round trip to the memory system inside the surgery's dependent chain)
+__device__ __forceinline__ int tri_n(const tri_r &T, int slot)
+{
+	const unsigned p = ((unsigned)T.n0 & 255u) | (((unsigned)T.n1 & 255u) << 8) | (((unsigned)T.n2 & 255u) << 16);
+	const int r = (int)((p >> (8 * slot)) & 255u);
+	return r == 255 ? -1 : r;
+}
+__device__ __forceinline__ int tri_v(const tri_r &T, int k) { return (int)((((unsigned)T.v0 & 255u) | (((unsigned)T.v1 & 255u) << 8) | (((unsigned)T.v2 & 255u) << 16)) >> (8 * k)) & 255; }
 // which neighbour slot of T lies across the edge (va, vb), either direction: hull.h:97-109 (edge i -> slot (i+2)%3, first match wins)
 __device__ __forceinline__ int nslot(const tri_r &T, int va, int vb)
 {
@@ -267,31 +275,12 @@ __device__ __forceinline__ int nslot(const tri_r &T, int va, int vb)
 	return 0;      // unreachable for a consistent mesh (the reference asserts)
 }
 __device__ __forceinline__ void set_n(epa_mem &m, int t, int slot, int val) { m.t[t].n[slot] = (short)val; }
-// Patches only ever change neighbour ids and nslot() only looks at vertex ids, which are fixed once a triangle exists: the records a step
-// needs for its slot look-ups can therefore be fetched together up front (independent LDS reads in flight) instead of one after another.
-__device__ void nnfix_rec(epa_mem &m, int k, const tri_r &K)      // hull.h:112-127 for the triangle k whose record is K
-{
-	tri_r R0, R1, R2;
-	if (K.n0 != -1) R0 = tri_ld(m, K.n0);
-	if (K.n1 != -1) R1 = tri_ld(m, K.n1);
-	if (K.n2 != -1) R2 = tri_ld(m, K.n2);
-	if (K.n0 != -1) set_n(m, K.n0, nslot(R0, K.v2, K.v1), k);
-	if (K.n1 != -1) set_n(m, K.n1, nslot(R1, K.v0, K.v2), k);
-	if (K.n2 != -1) set_n(m, K.n2, nslot(R2, K.v1, K.v0), k);
-}
-__device__ void swapn(epa_mem &m, int a, int b)      // hull.h:128-134 (the ids are swapped back by the reference's second std::swap)
-{
-	const int4 ra = *reinterpret_cast<const int4 *>(&m.t[a]), rb = *reinterpret_cast<const int4 *>(&m.t[b]);
-	*reinterpret_cast<int4 *>(&m.t[a]) = rb; *reinterpret_cast<int4 *>(&m.t[b]) = ra;
-	nnfix_rec(m, a, tri_ld(m, a));
-	nnfix_rec(m, b, tri_ld(m, b));      // fetched after a's patches: b can be a neighbour of a
-}
-__device__ void b2bfix(epa_mem &m, int s, int t)      // hull.h:136-150
-{
+__device__ void b2bfix(epa_mem &m, int s, int t)      // hull.h:136-150 (its three rounds on three lanes at once, with this loop as the fall-back for the
+{                                                      // irregular cases, were measured: no faster)
 	for (int i = 0; i < 3; i++)
 	{
 		tri_r S = tri_ld(m, s), T = tri_ld(m, t);      // fresh neighbour ids: the previous round may have patched s or t
-		const int va = i == 0 ? S.v1 : (i == 1 ? S.v2 : S.v0), vb = i == 0 ? S.v2 : (i == 1 ? S.v0 : S.v1);      // tv[s][(i+1)%3], tv[s][(i+2)%3]
+		const int va = tri_v(S, i == 2 ? 0 : i + 1), vb = tri_v(S, i == 0 ? 2 : i - 1);      // tv[s][(i+1)%3], tv[s][(i+2)%3]
 		const int ss = nslot(S, va, vb), ts = nslot(T, vb, va);
 		const int X = tri_n(S, ss), Y = tri_n(T, ts);
 		const tri_r RX = tri_ld(m, X), RY = tri_ld(m, Y);
@@ -446,18 +435,65 @@ __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 
 			okk = extrude(m, nt, from, vid);
 		}
 		if (!okk) { capped = true; break; }
-		// compaction (hull.h:300-306): dead triangles are found one per lane; moving the last (live) triangle into a dead slot never
-		// changes which of the lower slots are dead, so the descending scan again only visits the set bits
-		for (int base = ((nt - 1) >> 6) << 6; base >= 0; base -= 64)
+		// Compaction (hull.h:300-306): the reference fills every dead slot, highest first, with the then-last triangle (swapn: swap the records, patch the
+		// neighbours' back references).  What that amounts to is a permutation plus a renaming, so it is done as such: (1) the dead slots by ballot;
+		// (2) WHICH triangle ends in which slot by replaying the reference's loop on one byte per slot (who[a] = who[last]; no record is touched: a round
+		// trip per dead triangle instead of five); (3) the moves, one lane per filled slot, noting old -> new in a table; (4) every surviving triangle
+		// renames its neighbours through the table.  A consistent mesh (which the reference asserts) refers to a moved triangle exactly where the
+		// reference's back-reference patch would have written the new id.
 		{
-			const int i = base + lane;
-			unsigned long long mask = __ballot(i < nt && tri_dead(m, i));
-			while (mask)
+			const int nt0 = nt;
+			unsigned long long dead[3]; int ndead = 0;
+#pragma unroll
+			for (int k = 0; k < 3; k++) { const int i = 64 * k + lane; dead[k] = __ballot(i < nt0 && tri_dead(m, i)); ndead += __popcll(dead[k]); }
+			if (ndead)
 			{
-				const int bit = 63 - __clzll((long long)mask);
-				mask &= ~(1ull << bit);
-				swapn(m, base + bit, nt - 1);
-				nt--;
+				const int ntf = nt0 - ndead;
+#pragma unroll
+				for (int k = 0; k < 3; k++) { const int i = 64 * k + lane; if (i >= ntf && i < nt0) m.who[i] = (unsigned char)i; }
+				int last = nt0;
+#pragma unroll
+				for (int k = 2; k >= 0; k--)
+				{
+					unsigned long long mk = dead[k];
+					while (mk)
+					{
+						const int bit = 63 - __clzll((long long)mk);
+						mk &= ~(1ull << bit);
+						const int a = 64 * k + bit;
+						last--;
+						if (a != last) m.who[a] = m.who[last];
+					}
+				}
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+#pragma unroll
+				for (int k = 0; k < 3; k++)
+				{
+					const int i = 64 * k + lane;
+					if (((dead[k] >> lane) & 1ull) && i < ntf)
+					{
+						const int src = m.who[i];
+						*reinterpret_cast<int4 *>(&m.t[i]) = *reinterpret_cast<const int4 *>(&m.t[src]);
+						m.map[src] = (unsigned char)i;
+					}
+				}
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+#pragma unroll
+				for (int k = 0; k < 3; k++)
+				{
+					const int i = 64 * k + lane;
+					if (64 * k < ntf && i < ntf)
+					{
+						const tri_r T = tri_ld(m, i);
+						const bool m0 = T.n0 >= ntf && T.n0 < nt0, m1 = T.n1 >= ntf && T.n1 < nt0, m2 = T.n2 >= ntf && T.n2 < nt0;
+						if (m0) m.t[i].n[0] = (short)m.map[T.n0];
+						if (m1) m.t[i].n[1] = (short)m.map[T.n1];
+						if (m2) m.t[i].n[2] = (short)m.map[T.n2];
+					}
+				}
+				nt = ntf;
 			}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
