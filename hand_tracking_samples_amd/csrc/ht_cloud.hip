@@ -181,7 +181,7 @@ __device__ __forceinline__ void closest_chunk(const ht_model_dev &M, const float
 __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const float *__restrict__ state, const float4 *__restrict__ pts, const int *__restrict__ npts,
                                                            const float *__restrict__ cams, const int *__restrict__ active_flag, int stride, int use_cam_origin, int mode,
                                                            float microforce, float weak_force, float cf_max_point, float cf_max_sum, float unibody_force,
-                                                           float *__restrict__ rows, int *__restrict__ nrows, cloud_records rec)
+                                                           float *__restrict__ rows, int *__restrict__ nrows, cloud_records rec, int dbg)
 {
 	__shared__ float tab[HT_MAXNB * BT];
 	__shared__ closest_lds L;
@@ -217,35 +217,81 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 		const v3 v = V3(pv.x, pv.y, pv.z);
 		int rb; v4 p; float dmin;
 		closest_chunk<CR_THREADS>(M, tab, L, active, v, rb, p, dmin);
-		if (t >= CH) continue;                     // the other waves only help with the pair scans
 		if (rb < 0) rb = 0;
-		// ConvexHitCheck from the ray origin, only when the point faces away (physmodel.h:170)
-		const bool want = active && dot(v - origin, xyz(p)) > 0;
+		// ConvexHitCheck from the ray origin (geometric.h:275-297), only for the points that face away (physmodel.h:170).  Few points do, and the
+		// reference's loop over the body's faces only ACTS on a face the segment does not lie behind (both ends outside: no hit; straddling: the outer
+		// end is clipped to the face): the wanted points of the chunk are listed, a DPP row of sixteen lanes takes one point and looks at the next
+		// sixteen faces at once, applies the FIRST of them that acts on the current segment and looks on from the face after it.
+		// Same faces, same order, same arithmetic on the same segment as the sequential loop -- which ran all 92 faces on two whole waves whenever any
+		// of their points faced away (27 % of the kernel).
+		const bool want = t < CH && active && dot(v - origin, xyz(p)) > 0 && !HT_DBG(dbg, 0x100000);
+		const unsigned long long wm = __ballot(want);
+		if (t < CH && (t & 63) == 0) L.wsum[t >> 6] = __popcll(wm);
+		__syncthreads();
+		const int nw0 = L.wsum[0], nwant = nw0 + L.wsum[1];
+		if (HT_DBG(dbg, 0x200000) && t == 0) atomicAdd(nrows + b, nwant * 1000);      // tuning: how many points face away
 		bool hit = false; v3 impact = V3(0, 0, 0);
-		if (__any(want))
+		if (nwant > 0)
 		{
-			const float *tr = tab + rb * BT;
-			v3 v0 = tab_to_local(tr, origin), v1 = tab_to_local(tr, v);
-			const float4 *pl = s_planes + M.plane_off[rb];
-			const int np = M.plane_off[rb + 1] - M.plane_off[rb];
-			bool done = !want, ok = true;
-			for (int k = 0; k < npmax; k++)
+			if (want) L.pair[((t >> 6) ? nw0 : 0) + __popcll(wm & ((1ull << (t & 63)) - 1ull))] = (unsigned short)(t | (rb << 8));
+			__syncthreads();
+			const int g = t & 15;
+			auto row_min = [](int x) -> int {
+				x = min(x, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false)); x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false));
+				x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false)); x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false));
+				return x;
+			};
+			auto row_or = [](int x) -> int {
+				x |= __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false); x |= __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);
+				x |= __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false); x |= __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false);
+				return x;
+			};
+			for (int q0 = 0; q0 < nwant; q0 += CR_THREADS / 16)
 			{
-				const float4 f = pl[k < np ? k : 0];
-				const v4 plane = V4(f.x, f.y, f.z, f.w);
-				const float d0 = dot_plane(plane, v0), d1 = dot_plane(plane, v1);
-				const bool live = !done && k < np;
-				if (live && d0 >= 0 && d1 >= 0) { ok = false; done = true; }
-				const bool clip = live && !done && !(d0 <= 0 && d1 <= 0);
-				if (__any(clip))      // the three divisions are only issued when some lane's segment really straddles this face
+				const int q = q0 + (t >> 4);
+				const bool on = q < nwant;
+				const unsigned e = on ? L.pair[q] : 0;
+				const int pt = e & 255, body = e >> 8;
+				const float *tr = tab + body * BT;
+				const float4 pw = L.v[pt];
+				v3 v0 = tab_to_local(tr, origin), v1 = tab_to_local(tr, V3(pw.x, pw.y, pw.z));
+				const float4 *pl = s_planes + M.plane_off[body];
+				const int np = on ? M.plane_off[body + 1] - M.plane_off[body] : 0;
+				int k0 = 0; bool done = !on, ok = true;
+				while (__any(!done))
 				{
-					const v3 c = v0 + ((v1 - v0) * d0) / (d0 - d1);
-					if (clip) { if (d0 >= 0) v0 = c; else v1 = c; }
+					// the next 16 faces, one per lane: which is the first that acts on the segment as it is now
+					const int i = k0 + g;
+					int first = 0x7fffffff; float e0 = 0.0f, e1 = 0.0f;
+					if (!done && i < np)
+					{
+						const float4 f = pl[i];
+						const v4 plane = V4(f.x, f.y, f.z, f.w);
+						e0 = dot_plane(plane, v0); e1 = dot_plane(plane, v1);
+						if ((e0 >= 0 && e1 >= 0) || !(e0 <= 0 && e1 <= 0)) first = i;
+					}
+					const int kmin = row_min(first);
+					const bool mine = first == kmin && kmin != 0x7fffffff;      // one lane of the row at most
+					const float d0 = __int_as_float(row_or(mine ? __float_as_int(e0) : 0)), d1 = __int_as_float(row_or(mine ? __float_as_int(e1) : 0));
+					if (!done)
+					{
+						if (kmin == 0x7fffffff) { k0 += 16; if (k0 >= np) done = true; }      // none of the sixteen acts; past the last face the (clipped) segment lies inside
+						else if (d0 >= 0 && d1 >= 0) { ok = false; done = true; }
+						else
+						{
+							const v3 c = v0 + ((v1 - v0) * d0) / (d0 - d1);
+							if (d0 >= 0) v0 = c; else v1 = c;
+							k0 = kmin + 1;
+							if (k0 >= np) done = true;
+						}
+					}
 				}
-				if (!__any(!done)) break;
+				if (on && g == 0) { const v3 w = tab_to_world(tr, v0); L.v[pt] = make_float4(w.x, w.y, w.z, ok ? 1.0f : 0.0f); }
 			}
-			if (want && ok) { hit = true; impact = tab_to_world(tr, v0); }
+			__syncthreads();
+			if (want) { const float4 r = L.v[t]; hit = r.w != 0.0f; impact = V3(r.x, r.y, r.z); }
 		}
+		if (t >= CH) continue;                     // the other waves only help with the pair scans and the hit checks
 		if (!active) continue;
 		const float *tr = tab + rb * BT;
 		v3 position1, normal;
@@ -403,7 +449,7 @@ void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float
 	if (split > passes) split = passes;
 	if (split < 1) split = 1;
 	hipLaunchKernelGGL(k_cloud_rows, dim3(B, split), dim3(CR_THREADS), (size_t)M.plane_off[M.nb] * sizeof(float4), s, M, state, pts, npts, cams, active_flag, stride, use_cam_origin, mode, par.microforce,
-	                   mode == 4 ? sf_ratio : par.physics_weak_force, mode == 4 ? sf_wrist : par.cloudforce_max_point, par.cloudforce_max_sum, par.unibody_force, rows, nrows, rec ? *rec : none);
+	                   mode == 4 ? sf_ratio : par.physics_weak_force, mode == 4 ? sf_wrist : par.cloudforce_max_point, par.cloudforce_max_sum, par.unibody_force, rows, nrows, rec ? *rec : none, ht_tuning_flags());
 }
 void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, int w, int h, float scale, float *err, int B, hipStream_t s)
 {
