@@ -349,6 +349,41 @@ def test_fit_rows_with_caller_rows(ctx, golden, weights):
         ctx.fit_rows(0, clouds[:1], [two_body], [np.zeros((0, 8), np.float32)], microforce=3.0)
 
 
+def test_fit_rows_with_many_angular_runs(ctx, golden, weights):
+    """More than 64 angular runs in one solve (the level schedule then works two groups per lane): 50 caller-built angular rows on changing body pairs in
+    front of the model's own ~66, through PhysModel::FitPointCloud (physmodel.h:345-356), against the C restatement given the same rows."""
+    depth, cams, start = _inputs(golden)
+    clouds = [golden["f%d/vpts" % f] for f in range(NF)]
+    rng = np.random.default_rng(7)
+    ang = []
+    for f in range(NF):
+        rows = np.zeros((50, 8), np.float32)
+        for i in range(50):
+            a = int(rng.integers(0, 17)); b = (a + 1 + int(rng.integers(0, 15))) % 17
+            ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+            rows[i] = [a, b, ax[0], ax[1], ax[2], rng.uniform(-0.2, 0.2), -0.3, 0.3]
+        ang.append(rows)
+    lin = [np.zeros((0, 16), np.float32)] * NF
+    ctx.tracker_reset(start)
+    ctx.fit_rows(0, clouds, lin, ang, microforce=3.0)
+    got = ctx.get_state(0, NF)
+    orc = ol.Oracle(weights)
+    orc.head.par.microforce = 3.0
+    for f in range(NF):
+        orc.reset(start[f])
+        m = orc.model(0)
+        A = (ol.Angular * 64)()
+        n = C.c_int(0); z = ol.F3(0, 0, 0)
+        orc.L.ho_enhancements(orc.h, m, A, C.byref(n), 0, z, z, 0)
+        assert n.value == 0
+        for i, r in enumerate(ang[f]):
+            A[i].rb0 = int(r[0]); A[i].rb1 = int(r[1]); A[i].axis = ol.v3(r[2:5]); A[i].torque = 0.0; A[i].targetspin = float(r[5]); A[i].mintorque = float(r[6]); A[i].maxtorque = float(r[7])
+        orc.L.ho_fit_pointcloud(orc.h, m, ol.f3ptr(np.ascontiguousarray(clouds[f])), len(clouds[f]), None, 0, A, len(ang[f]), 3.0)
+        _check_state(got[f], orc.get_state(0), "FitPointCloud with 50 caller angular rows, frame %d" % f)
+    orc.close()
+    assert ctx.capacity_events()[2] == 0      # 116 rows: inside the 126 the kernel keeps
+
+
 def test_solver_builds_agree_bit_for_bit(ctx, golden):
     """k_solve's builds differ only in which of a frame's arrays (two-body groups, impulse sums, angular records) fit their LDS and which go to the
     frame's scratch slot in HBM.  Build 4 holds nothing in LDS, so every frame takes every HBM path; all builds must return the same bits."""
