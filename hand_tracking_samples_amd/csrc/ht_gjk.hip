@@ -1011,6 +1011,10 @@ template <bool JIG> __device__ void co_pass(const ht_model_dev &M, const co_lds 
 	}
 }
 
+// Which frame is slot f of a block: frame f * blocks + (block + 61 f) mod blocks, a bijection of (block, slot) onto the frames.  Neighbouring frames of a
+// batch are often alike (consecutive frames of one stream, a tiled test set) and a block's time goes with the runs of its heaviest frames, so a block takes
+// its frames from four far-apart places instead of four neighbours: the slowest block of a launch, which is the launch's time, comes closer to the mean.
+__device__ __forceinline__ int co_frame_of(int block, int f, int blocks) { return f * blocks + (block + 61 * f) % blocks; }
 __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, const float *__restrict__ state, float driftmax, float jiggle_sin, const int *__restrict__ active_flag,
                                                               float *__restrict__ contacts, int *__restrict__ ncontacts, int B, int nfr, int nvp, int dbg, int *__restrict__ caps)
 {
@@ -1029,7 +1033,7 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 	if (active_flag)      // a masked launch: blocks without a live frame leave at once (a handful of frames of a large batch take this kernel on their own)
 	{
 		bool any = false;
-		for (int f = 0; f < nfr; f++) { const int b = blockIdx.x * nfr + f; any = any || (b < B && active_flag[b] != 0); }
+		for (int f = 0; f < nfr; f++) { const int b = co_frame_of(blockIdx.x, f, gridDim.x); any = any || (b < B && active_flag[b] != 0); }
 		if (!any) return;
 	}
 	for (int k = t; k < nvp; k += 64 * CO_NW) g_sm[k] = M.cverts[k];      // the padded vertex image (ht_model_dev::cverts), 16 vertices per row
@@ -1037,7 +1041,7 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 	if (wave < nfr)
 	{
 		co_frame &F = L.F[wave];
-		const int b = blockIdx.x * nfr + wave;
+		const int b = co_frame_of(blockIdx.x, wave, gridDim.x);
 		const bool live = b < B && !(active_flag && !active_flag[b]);      // frames outside the active set keep whatever another launch produced for them
 		if (live && lane < M.nb)
 		{
@@ -1121,7 +1125,7 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 	if (wave < nfr)
 	{
 		co_frame &F = L.F[wave];
-		const int b = blockIdx.x * nfr + wave;
+		const int b = co_frame_of(blockIdx.x, wave, gridDim.x);
 		const bool live = b < B && !(active_flag && !active_flag[b]);
 		const int np = F.npool;
 		int total = 0;
