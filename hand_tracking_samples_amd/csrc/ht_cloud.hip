@@ -22,7 +22,9 @@ __device__ __forceinline__ void stage_planes(const ht_model_dev &M, int t, int n
 	for (int i = t; i < np; i += nthreads) s_planes[i] = M.planes[i];
 }
 #define BT 32       // floats per body-table entry
-// pos 0..2 | q 3..6 | radius 7 | rinner 8 | invp 9..11 (= qrot(qconj(q), -pos)) | RI columns 12..20 (qmat(qconj(q))) | RF columns 21..29 (qmat(q))
+// pos 0..2 | q 3..6 | radius 7 | rinner 8 | invp 9..11 (= qrot(qconj(q), -pos)) | RI columns 12..20 (qmat(qconj(q))) | RF columns 21..29 (qmat(q)) |
+// 30, 31: first face plane and number of face planes of the body (as integers: a lane that picks its body at run time would otherwise fetch them from the
+// kernel-argument segment with a global load, a memory round trip inside the pair loop)
 __device__ __forceinline__ void body_table_build(const ht_model_dev &M, const float *__restrict__ st, float *tab, int lane)
 {
 	if (lane < M.nb)
@@ -38,9 +40,12 @@ __device__ __forceinline__ void body_table_build(const ht_model_dev &M, const fl
 		t[9] = invp.x; t[10] = invp.y; t[11] = invp.z;
 		t[12] = ri.x.x; t[13] = ri.x.y; t[14] = ri.x.z; t[15] = ri.y.x; t[16] = ri.y.y; t[17] = ri.y.z; t[18] = ri.z.x; t[19] = ri.z.y; t[20] = ri.z.z;
 		t[21] = rf.x.x; t[22] = rf.x.y; t[23] = rf.x.z; t[24] = rf.y.x; t[25] = rf.y.y; t[26] = rf.y.z; t[27] = rf.z.x; t[28] = rf.z.y; t[29] = rf.z.z;
+		t[30] = __int_as_float(M.plane_off[lane]); t[31] = __int_as_float(M.plane_off[lane + 1] - M.plane_off[lane]);
 	}
 }
 __device__ __forceinline__ v3 tab_pos(const float *t) { return V3(t[0], t[1], t[2]); }
+__device__ __forceinline__ int tab_plane0(const float *t) { return __float_as_int(t[30]); }
+__device__ __forceinline__ int tab_nplanes(const float *t) { return __float_as_int(t[31]); }
 __device__ __forceinline__ v3 tab_to_local(const float *t, v3 w)      // pose.inverse() * w  (geometric.h:119,122)
 {
 	v3 X = V3(t[12], t[13], t[14]), Y = V3(t[15], t[16], t[17]), Z = V3(t[18], t[19], t[20]);
@@ -79,7 +84,7 @@ __device__ __forceinline__ float outer_bound(const float *t, v3 v) { return leng
 
 // All threads of the block call this.  Thread t < CH carries point `v` (active or not); on return rbmin / pmin / dmin are the reference's result.
 template <int NT>
-__device__ __forceinline__ void closest_chunk(const ht_model_dev &M, const float *tab, closest_lds &L, bool active, v3 v, int &rbmin, v4 &pmin, float &dmin)
+__device__ __forceinline__ void closest_chunk(const ht_model_dev &M, const float *tab, closest_lds &L, bool active, v3 v, int npmax, int &rbmin, v4 &pmin, float &dmin)
 {
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	// ---- A: inner-sphere walk, candidate mask ----
@@ -128,18 +133,23 @@ __device__ __forceinline__ void closest_chunk(const ht_model_dev &M, const float
 			const unsigned e = on ? L.pair[q] : 0;
 			const int pt = e & 255, b = e >> 8;
 			const float4 pv = L.v[pt];
-			const v3 vl = tab_to_local(tab + b * BT, V3(pv.x, pv.y, pv.z));
-			const float4 *pl = s_planes + M.plane_off[b];
-			const int np = on ? M.plane_off[b + 1] - M.plane_off[b] : 0;
+			const float *tb = tab + b * BT;
+			const v3 vl = tab_to_local(tb, V3(pv.x, pv.y, pv.z));
+			const float4 *pl = s_planes + tab_plane0(tb);
+			const int np = on ? tab_nplanes(tb) : 0;
 			const unsigned long long live = __ballot(on);
-			int npmax = 0;
-			for (int bb = 0; bb < M.nb; bb++) npmax = max(npmax, M.plane_off[bb + 1] - M.plane_off[bb]);      // scalar: the model's largest face count
 			float best = 0.0f; int bi = -1;
-			for (int i = g; i < npmax; i += 4)
+			// this lane's faces g, g + 4, ..., four of them read ahead of their use (a face index past the body's last reads the next body's planes or the
+			// slack behind the copy and is not taken)
+			for (int i = g; i < npmax; i += 16)
 			{
-				const float4 f = pl[i < np ? i : 0];
-				const float d = dot_plane(V4(f.x, f.y, f.z, f.w), vl);
-				if (i < np && (bi < 0 || best < d)) { best = d; bi = i; }       // std::max_element: the first maximum of this lane's faces
+				const float4 f0 = pl[i], f1 = pl[i + 4], f2 = pl[i + 8], f3 = pl[i + 12];
+				const float d0 = dot_plane(V4(f0.x, f0.y, f0.z, f0.w), vl), d1 = dot_plane(V4(f1.x, f1.y, f1.z, f1.w), vl);
+				const float d2 = dot_plane(V4(f2.x, f2.y, f2.z, f2.w), vl), d3 = dot_plane(V4(f3.x, f3.y, f3.z, f3.w), vl);
+				if (i < np && (bi < 0 || best < d0)) { best = d0; bi = i; }       // std::max_element: the first maximum of this lane's faces
+				if (i + 4 < np && (bi < 0 || best < d1)) { best = d1; bi = i + 4; }
+				if (i + 8 < np && (bi < 0 || best < d2)) { best = d2; bi = i + 8; }
+				if (i + 12 < np && (bi < 0 || best < d3)) { best = d3; bi = i + 12; }
 			}
 			(void)live;
 			// merge the four partial results: larger value wins, equal values keep the lower index (the first maximum overall)
@@ -162,7 +172,7 @@ __device__ __forceinline__ void closest_chunk(const ht_model_dev &M, const float
 			if (!((mask >> b) & 1u)) continue;
 			const float *tb = tab + b * BT;
 			if (outer_bound(tb, v) > dmin) continue;
-			const float4 f = s_planes[M.plane_off[b] + L.face[t][b]];
+			const float4 f = s_planes[tab_plane0(tb) + L.face[t][b]];
 			const v3 n = tab_rot(tb, V3(f.x, f.y, f.z));               // Pose::TransformPlane geometric.h:124
 			const v4 p = V4(n, f.w - dot(tab_pos(tb), n));
 			const float d = dot_plane(p, v);
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 		const float4 pv = active ? pts[(size_t)b * M.pts_cap + i * stride] : make_float4(0, 0, 0, 0);
 		const v3 v = V3(pv.x, pv.y, pv.z);
 		int rb; v4 p; float dmin;
-		closest_chunk<CR_THREADS>(M, tab, L, active, v, rb, p, dmin);
+		closest_chunk<CR_THREADS>(M, tab, L, active, v, npmax, rb, p, dmin);
 		if (rb < 0) rb = 0;
 		// ConvexHitCheck from the ray origin (geometric.h:275-297), only for the points that face away (physmodel.h:170).  Few points do, and the
 		// reference's loop over the body's faces only ACTS on a face the segment does not lie behind (both ends outside: no hit; straddling: the outer
@@ -255,8 +265,8 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 				const float *tr = tab + body * BT;
 				const float4 pw = L.v[pt];
 				v3 v0 = tab_to_local(tr, origin), v1 = tab_to_local(tr, V3(pw.x, pw.y, pw.z));
-				const float4 *pl = s_planes + M.plane_off[body];
-				const int np = on ? M.plane_off[body + 1] - M.plane_off[body] : 0;
+				const float4 *pl = s_planes + tab_plane0(tr);
+				const int np = on ? tab_nplanes(tr) : 0;
 				int k0 = 0; bool done = !on, ok = true;
 				while (__any(!done))
 				{
@@ -335,13 +345,15 @@ __global__ __launch_bounds__(256) void k_fit_error(ht_model_dev M, const float *
 	stage_planes(M, t, 256);
 	__syncthreads();
 	const int n = npts[b];
+	int npmax = 0;
+	for (int bb = 0; bb < M.nb; bb++) npmax = max(npmax, M.plane_off[bb + 1] - M.plane_off[bb]);      // the model's largest face count
 	for (int base = 0; base < n; base += CH)
 	{
 		const int i = base + t;
 		const bool active = t < CH && i < n;
 		const float4 pv = active ? pts[(size_t)b * M.pts_cap + i] : make_float4(0, 0, 0, 0);
 		int rb; v4 p; float dmin;
-		closest_chunk<256>(M, tab, L, active, V3(pv.x, pv.y, pv.z), rb, p, dmin);
+		closest_chunk<256>(M, tab, L, active, V3(pv.x, pv.y, pv.z), npmax, rb, p, dmin);
 		// pointerror[bone] = max(pointerror[bone], d) with pointerror starting at 0 (handtrack.h:376-383): only d > 0 matters,
 		// and for non-negative floats the integer order of the bit patterns is the float order
 		if (active && rb >= 0 && dmin > 0.0f) atomicMax(&perr[rb], __float_as_int(dmin));
@@ -448,12 +460,12 @@ void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float
 #endif
 	if (split > passes) split = passes;
 	if (split < 1) split = 1;
-	hipLaunchKernelGGL(k_cloud_rows, dim3(B, split), dim3(CR_THREADS), (size_t)M.plane_off[M.nb] * sizeof(float4), s, M, state, pts, npts, cams, active_flag, stride, use_cam_origin, mode, par.microforce,
+	hipLaunchKernelGGL(k_cloud_rows, dim3(B, split), dim3(CR_THREADS), ((size_t)M.plane_off[M.nb] + 16) * sizeof(float4), s, M, state, pts, npts, cams, active_flag, stride, use_cam_origin, mode, par.microforce,
 	                   mode == 4 ? sf_ratio : par.physics_weak_force, mode == 4 ? sf_wrist : par.cloudforce_max_point, par.cloudforce_max_sum, par.unibody_force, rows, nrows, rec ? *rec : none, ht_tuning_flags());
 }
 void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, int w, int h, float scale, float *err, int B, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_fit_error, dim3(B), dim3(256), (size_t)M.plane_off[M.nb] * sizeof(float4), s, M, state, pts, npts, depth, cams, w, h, scale, err);
+	hipLaunchKernelGGL(k_fit_error, dim3(B), dim3(256), ((size_t)M.plane_off[M.nb] + 16) * sizeof(float4), s, M, state, pts, npts, depth, cams, w, h, scale, err);
 }
 void ht_launch_chamber(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, int min_point_num, int enabled, float maxforce, float *rows, int *nch, int B, hipStream_t s)
 {
