@@ -385,12 +385,14 @@ __global__ __launch_bounds__(64) void k_chamber(ht_model_dev M, const float *__r
 {
 	__shared__ float tab[HT_MAXNB * BT];
 	__shared__ float planes[5][4];
+	__shared__ int voff[HT_MAXNB + 1];      // vertex ranges of the bodies (picked per lane below: from LDS, not from the kernel-argument segment)
 	const int b = blockIdx.x, lane = threadIdx.x;
 	const int n = npts[b];
 	const bool on = enabled && n > min_point_num;        // handtrack.h:774
 	if (lane == 0) nch[b] = on ? 5 * M.nb : 0;
 	if (!on) return;
 	body_table_build(M, state + (size_t)b * M.nb * HT_STATE_STRIDE, tab, lane);
+	if (lane <= M.nb) voff[lane] = M.vert_off[lane];
 	// containing_plane (physmodel.h:183-193): a sequential scan of the cloud per direction (the running `best` decides the next comparison).  The five
 	// directions take one lane each; the points reach them through an LDS chunk the whole wave fills with coalesced reads (a lane reading the
 	// points straight from HBM waits a memory round trip per point: 100 us for a 424-point frame).
@@ -421,26 +423,56 @@ __global__ __launch_bounds__(64) void k_chamber(ht_model_dev M, const float *__r
 		planes[lane][0] = nn.x; planes[lane][1] = nn.y; planes[lane][2] = nn.z; planes[lane][3] = -dot(nn, origin);
 	}
 	__syncthreads();
-	for (int item = lane; item < 5 * M.nb; item += 64)
+	// one ConstrainUnderPlane row (physics.h:347-350) per (plane, body): the body's support vertex against the plane normal (maxdir geometric.h:218-224: the
+	// FIRST maximum in vertex order).  A DPP row of sixteen lanes takes an item and its vertices sixteen at a time, four reads ahead (one lane walking a
+	// body's ~180 vertices in global memory waited a memory round trip per vertex: 76 of the kernel's 140 us); the sixteen first-maxima merge under
+	// "larger value, then lower index", which is the sequential scan's winner.
+	const int g = lane & 15;
+	for (int item0 = 0; item0 < 5 * M.nb; item0 += 4)
 	{
-		const int d = item / M.nb, rb = item % M.nb;
+		const int item = item0 + (lane >> 4);
+		const bool on = item < 5 * M.nb;
+		const int d = on ? item / M.nb : 0, rb = on ? item % M.nb : 0;
 		const float *t = tab + rb * BT;
 		v4 plane = V4(planes[d][0], planes[d][1], planes[d][2], planes[d][3]);
-		// ConstrainUnderPlane physics.h:347-350: support vertex of the body against the plane normal (maxdir geometric.h:218-224)
 		v3 dirl = qrot(qconj(V4(t[3], t[4], t[5], t[6])), xyz(plane));
-		const float4 *vs = M.verts + M.vert_off[rb];
-		const int nv = M.vert_off[rb + 1] - M.vert_off[rb];
-		int bi = 0; float bd = 0.0f;
-		for (int k = 0; k < nv; k++) { float4 q = vs[k]; float dd = dot(V3(q.x, q.y, q.z), dirl); if (k == 0 || bd < dd) { bd = dd; bi = k; } }
-		float4 q = vs[bi];
-		v3 sv = V3(q.x, q.y, q.z);
-		v3 p0 = xyz(plane) * -plane.w, axis = -xyz(plane);
-		float targetdist = dot(tab_to_world(t, sv) - p0, axis);
-		float4 *out = reinterpret_cast<float4 *>(rows + ((size_t)b * 5 * M.nb + item) * HT_ROW);
-		out[0] = make_float4(-1.0f, (float)rb, p0.x, p0.y);
-		out[1] = make_float4(p0.z, sv.x, sv.y, sv.z);
-		out[2] = make_float4(axis.x, axis.y, axis.z, targetdist);
-		out[3] = make_float4(0.0f, fmin_std(0.0f, maxforce), fmax_std(0.0f, maxforce), 0.0f);
+		const float4 *vs = M.verts + voff[rb];
+		const int nv = on ? voff[rb + 1] - voff[rb] : 0;
+		int bi = 0x7fffffff; float bd = 0.0f;
+		for (int k = g; k < nv; k += 64)
+		{
+			const int k1 = k + 16, k2 = k + 32, k3 = k + 48;
+			const float4 q0 = vs[k], q1 = vs[k1 < nv ? k1 : k], q2 = vs[k2 < nv ? k2 : k], q3 = vs[k3 < nv ? k3 : k];
+			const float d0 = dot(V3(q0.x, q0.y, q0.z), dirl), d1 = dot(V3(q1.x, q1.y, q1.z), dirl), d2 = dot(V3(q2.x, q2.y, q2.z), dirl), d3 = dot(V3(q3.x, q3.y, q3.z), dirl);
+			if (bi == 0x7fffffff || bd < d0) { bd = d0; bi = k; }
+			if (k1 < nv && bd < d1) { bd = d1; bi = k1; }
+			if (k2 < nv && bd < d2) { bd = d2; bi = k2; }
+			if (k3 < nv && bd < d3) { bd = d3; bi = k3; }
+		}
+		// merge over the row: larger value wins, equal values go to the lower vertex index, "nothing" (a lane without a vertex) loses
+#pragma unroll
+		for (int st = 0; st < 4; st++)
+		{
+			float ob; int oi;
+			if (st == 0) { ob = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bd), 0xB1, 0xF, 0xF, false)); oi = __builtin_amdgcn_update_dpp(0, bi, 0xB1, 0xF, 0xF, false); }
+			else if (st == 1) { ob = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bd), 0x4E, 0xF, 0xF, false)); oi = __builtin_amdgcn_update_dpp(0, bi, 0x4E, 0xF, 0xF, false); }
+			else if (st == 2) { ob = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bd), 0x141, 0xF, 0xF, false)); oi = __builtin_amdgcn_update_dpp(0, bi, 0x141, 0xF, 0xF, false); }
+			else { ob = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bd), 0x140, 0xF, 0xF, false)); oi = __builtin_amdgcn_update_dpp(0, bi, 0x140, 0xF, 0xF, false); }
+			const bool take = oi != 0x7fffffff && (bi == 0x7fffffff || bd < ob || (ob == bd && oi < bi));
+			bd = take ? ob : bd; bi = take ? oi : bi;
+		}
+		if (on && g == 0)
+		{
+			float4 q = vs[bi];
+			v3 sv = V3(q.x, q.y, q.z);
+			v3 p0 = xyz(plane) * -plane.w, axis = -xyz(plane);
+			float targetdist = dot(tab_to_world(t, sv) - p0, axis);
+			float4 *out = reinterpret_cast<float4 *>(rows + ((size_t)b * 5 * M.nb + item) * HT_ROW);
+			out[0] = make_float4(-1.0f, (float)rb, p0.x, p0.y);
+			out[1] = make_float4(p0.z, sv.x, sv.y, sv.z);
+			out[2] = make_float4(axis.x, axis.y, axis.z, targetdist);
+			out[3] = make_float4(0.0f, fmin_std(0.0f, maxforce), fmax_std(0.0f, maxforce), 0.0f);
+		}
 	}
 }
 
