@@ -82,26 +82,52 @@ struct closest_lds
 __device__ __forceinline__ v4 inner_plane(const float *t, v3 v) { const v3 n = safenormalize(v - tab_pos(t)); return V4(n, -dot(tab_pos(t), n) - t[8]); }
 __device__ __forceinline__ float outer_bound(const float *t, v3 v) { return length(v - tab_pos(t)) - t[7]; }
 
-// All threads of the block call this.  Thread t < CH carries point `v` (active or not); on return rbmin / pmin / dmin are the reference's result.
+// All threads of the block call this.  Threads t and t + CH carry the same point `v` (`exists`: the chunk has a point there; `active` = exists on the
+// owner lane t < CH); on return rbmin / pmin / dmin are the reference's result on the owner lanes.
 template <int NT>
-__device__ __forceinline__ void closest_chunk(const ht_model_dev &M, const float *tab, closest_lds &L, bool active, v3 v, int npmax, int &rbmin, v4 &pmin, float &dmin)
+__device__ __forceinline__ void closest_chunk(const ht_model_dev &M, const float *tab, closest_lds &L, bool active, bool exists, v3 v, int npmax, int &rbmin, v4 &pmin, float &dmin, long long *cyc = nullptr)
 {
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-	// ---- A: inner-sphere walk, candidate mask ----
+	long long tm = cyc ? clock64() : 0;
+#define CC_MARK(k) if (cyc) { const long long tn = clock64(); cyc[k] += tn - tm; tm = tn; }
+	// ---- A: inner-sphere walk, candidate mask.  Two lanes per point (t and t + CH carry the same point): the lower takes the bodies [0, h), the upper
+	//      [h, nb); "the first strict minimum in body order" of the whole walk is the lower half's unless the upper half's is strictly smaller.  The
+	//      candidate test needs the final bound, so the halves meet twice through LDS (the face table's bytes, free until phase B).
+	static_assert(NT == 2 * CH, "phase A pairs lane t with lane t + CH");
 	pmin = V4(0, 0, 0, FLT_MAX); dmin = dot_plane(pmin, v); rbmin = -1;
 	unsigned mask = 0;
-	if (t < CH)
 	{
-		for (int b = 0; b < M.nb; b++)
+		const bool up = t >= CH; const int tp = t & (CH - 1);
+		const int hb = (M.nb + 1) >> 1, b0 = up ? hb : 0, b1 = up ? M.nb : hb;
+		for (int b = b0; b < b1; b++)
 		{
 			const v4 p = inner_plane(tab + b * BT, v);
 			const float d = dot_plane(p, v);
 			if (d < dmin) { pmin = p; dmin = d; rbmin = b; }
 		}
-		if (active) for (int b = 0; b < M.nb; b++) if (!(outer_bound(tab + b * BT, v) > dmin)) mask |= 1u << b;
-		L.v[t] = make_float4(v.x, v.y, v.z, 0.0f);
-		L.mask[t] = mask;
-	}
+		float *X = reinterpret_cast<float *>(&L.face[0][0]) + 6 * tp;
+		if (up) { X[0] = pmin.x; X[1] = pmin.y; X[2] = pmin.z; X[3] = pmin.w; X[4] = dmin; X[5] = __int_as_float(rbmin); }
+		__syncthreads();
+		if (!up)
+		{
+			const float du = X[4];
+			if (du < dmin) { pmin = V4(X[0], X[1], X[2], X[3]); dmin = du; rbmin = __float_as_int(X[5]); }
+			X[4] = dmin;
+		}
+		__syncthreads();
+		const float bound = up ? X[4] : dmin;
+		unsigned part = 0;
+		if (exists) for (int b = b0; b < b1; b++) if (!(outer_bound(tab + b * BT, v) > bound)) part |= 1u << b;
+		if (up) X[5] = __int_as_float((int)part);
+		__syncthreads();
+		if (!up)
+		{
+			mask = part | (unsigned)__float_as_int(X[5]);
+			L.v[t] = make_float4(v.x, v.y, v.z, 0.0f);
+			L.mask[t] = mask;
+		}
+	}      // (the exchange area becomes the face table again two barriers further down)
+	CC_MARK(0)
 	// exclusive prefix of the candidate counts over the chunk (CH = 2 waves)
 	int cnt = __popc(mask), incl = cnt;
 #pragma unroll
@@ -114,6 +140,8 @@ __device__ __forceinline__ void closest_chunk(const ht_model_dev &M, const float
 	if (t == CH - 1) L.poff[CH] = base + incl;
 	__syncthreads();
 	const int total = L.poff[CH];
+	CC_MARK(1)
+	if (cyc) cyc[5] += total;
 	// ---- B: most-above face of every candidate pair, four lanes per pair ----
 	for (int w0 = 0; w0 < total; w0 += PAIR_WIN)
 	{
@@ -164,6 +192,7 @@ __device__ __forceinline__ void closest_chunk(const ht_model_dev &M, const float
 		}
 		__syncthreads();
 	}
+	CC_MARK(2)
 	// ---- C: the reference's second walk (physmodel.h:151-160) with the faces found above ----
 	if (t < CH && active)
 	{
@@ -180,6 +209,8 @@ __device__ __forceinline__ void closest_chunk(const ht_model_dev &M, const float
 		}
 	}
 	__syncthreads();      // the chunk's LDS is free for the next one
+	CC_MARK(3)
+#undef CC_MARK
 }
 
 // ------------------------------------------------------------------------------------------------- k_cloud_rows
@@ -221,12 +252,12 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 	for (int bb = 0; bb < M.nb; bb++) npmax = max(npmax, M.plane_off[bb + 1] - M.plane_off[bb]);
 	for (int base = blockIdx.y * CH; base < nsub; base += gridDim.y * CH)
 	{
-		const int i = base + t;
-		const bool active = t < CH && i < nsub;
-		const float4 pv = active ? pts[(size_t)b * M.pts_cap + i * stride] : make_float4(0, 0, 0, 0);
+		const int i = base + (t & (CH - 1));
+		const bool exists = i < nsub, active = t < CH && exists;
+		const float4 pv = exists ? pts[(size_t)b * M.pts_cap + i * stride] : make_float4(0, 0, 0, 0);
 		const v3 v = V3(pv.x, pv.y, pv.z);
 		int rb; v4 p; float dmin;
-		closest_chunk<CR_THREADS>(M, tab, L, active, v, npmax, rb, p, dmin);
+		closest_chunk<CR_THREADS>(M, tab, L, active, exists, v, npmax, rb, p, dmin);
 		if (rb < 0) rb = 0;
 		// ConvexHitCheck from the ray origin (geometric.h:275-297), only for the points that face away (physmodel.h:170).  Few points do, and the
 		// reference's loop over the body's faces only ACTS on a face the segment does not lie behind (both ends outside: no hit; straddling: the outer
@@ -333,6 +364,9 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 }
 
 // ------------------------------------------------------------------------------------------------- k_fit_error
+#ifdef HT_TUNING
+__constant__ int ht_fit_error_dbg;
+#endif
 __global__ __launch_bounds__(256) void k_fit_error(ht_model_dev M, const float *__restrict__ state, const float4 *__restrict__ pts, const int *__restrict__ npts,
                                                   const uint16_t *__restrict__ depth, const float *__restrict__ cams, int w, int h, float bone_sum_error_scale, float *__restrict__ err)
 {
@@ -347,18 +381,28 @@ __global__ __launch_bounds__(256) void k_fit_error(ht_model_dev M, const float *
 	const int n = npts[b];
 	int npmax = 0;
 	for (int bb = 0; bb < M.nb; bb++) npmax = max(npmax, M.plane_off[bb + 1] - M.plane_off[bb]);      // the model's largest face count
+#ifdef HT_TUNING
+	long long cyc[6] = { 0, 0, 0, 0, 0, 0 }; const bool stats = (ht_fit_error_dbg & 0x400000) != 0; const long long t_in = stats ? clock64() : 0;
+#endif
 	for (int base = 0; base < n; base += CH)
 	{
-		const int i = base + t;
-		const bool active = t < CH && i < n;
-		const float4 pv = active ? pts[(size_t)b * M.pts_cap + i] : make_float4(0, 0, 0, 0);
+		const int i = base + (t & (CH - 1));
+		const bool exists = i < n, active = t < CH && exists;
+		const float4 pv = exists ? pts[(size_t)b * M.pts_cap + i] : make_float4(0, 0, 0, 0);
 		int rb; v4 p; float dmin;
-		closest_chunk<256>(M, tab, L, active, V3(pv.x, pv.y, pv.z), npmax, rb, p, dmin);
+#ifdef HT_TUNING
+		closest_chunk<256>(M, tab, L, active, exists, V3(pv.x, pv.y, pv.z), npmax, rb, p, dmin, stats ? cyc : nullptr);
+#else
+		closest_chunk<256>(M, tab, L, active, exists, V3(pv.x, pv.y, pv.z), npmax, rb, p, dmin);
+#endif
 		// pointerror[bone] = max(pointerror[bone], d) with pointerror starting at 0 (handtrack.h:376-383): only d > 0 matters,
 		// and for non-negative floats the integer order of the bit patterns is the float order
 		if (active && rb >= 0 && dmin > 0.0f) atomicMax(&perr[rb], __float_as_int(dmin));
 	}
 	__syncthreads();
+#ifdef HT_TUNING
+	if (stats && (b & 127) == 0 && (t == 0 || t == 192)) printf("fit_error frame %d thread %d: points %d pairs %lld; cycles A %lld prefix %lld B %lld C %lld, whole kernel %lld\n", b, t, n, cyc[5], cyc[0], cyc[1], cyc[2], cyc[3], (long long)(clock64() - t_in));
+#endif
 	if (t == 0)
 	{
 		float point_error_sum = 0.0f;
@@ -497,6 +541,9 @@ void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float
 }
 void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, int w, int h, float scale, float *err, int B, hipStream_t s)
 {
+#ifdef HT_TUNING
+	{ static int done = 0; if (!done) { const int f = ht_tuning_flags(); (void)hipMemcpyToSymbol(HIP_SYMBOL(ht_fit_error_dbg), &f, sizeof(int)); done = 1; } }
+#endif
 	hipLaunchKernelGGL(k_fit_error, dim3(B), dim3(256), ((size_t)M.plane_off[M.nb] + 16) * sizeof(float4), s, M, state, pts, npts, depth, cams, w, h, scale, err);
 }
 void ht_launch_chamber(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, int min_point_num, int enabled, float maxforce, float *rows, int *nch, int B, hipStream_t s)
