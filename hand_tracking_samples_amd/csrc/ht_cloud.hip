@@ -196,9 +196,9 @@ __device__ __forceinline__ void closest_chunk(const ht_model_dev &M, const float
 	// ---- C: the reference's second walk (physmodel.h:151-160) with the faces found above ----
 	if (t < CH && active)
 	{
-		for (int b = 0; b < M.nb; b++)
+		for (unsigned m = mask; m; m &= m - 1)      // the candidate bodies in ascending order (a lane has two or three: the loop runs as long as the wave's longest list, not over all bodies)
 		{
-			if (!((mask >> b) & 1u)) continue;
+			const int b = __ffs(m) - 1;
 			const float *tb = tab + b * BT;
 			if (outer_bound(tb, v) > dmin) continue;
 			const float4 f = s_planes[tab_plane0(tb) + L.face[t][b]];
