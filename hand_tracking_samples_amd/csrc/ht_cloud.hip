@@ -166,18 +166,32 @@ __device__ __forceinline__ void closest_chunk(const ht_model_dev &M, const float
 			const float4 *pl = s_planes + tab_plane0(tb);
 			const int np = on ? tab_nplanes(tb) : 0;
 			const unsigned long long live = __ballot(on);
+			// this lane's faces g, g + 4, ...: the first is taken as it is (std::max_element starts from it), the others replace it when strictly larger; four are
+			// read ahead of their use.  When every pair of the wave sits on a body with the model's largest face count (one count for all bodies of the hand) the
+			// faces up to the last round need no range test; a face index past a body's last reads the next body's planes or the slack behind the copy.
 			float best = 0.0f; int bi = -1;
-			// this lane's faces g, g + 4, ..., four of them read ahead of their use (a face index past the body's last reads the next body's planes or the
-			// slack behind the copy and is not taken)
-			for (int i = g; i < npmax; i += 16)
+			if (g < np) { const float4 f = pl[g]; best = dot_plane(V4(f.x, f.y, f.z, f.w), vl); bi = g; }
+			int i = g + 4;
+			if (__all(!on || np == npmax))
+				for (; i + 12 < npmax; i += 16)
+				{
+					const float4 f0 = pl[i], f1 = pl[i + 4], f2 = pl[i + 8], f3 = pl[i + 12];
+					const float d0 = dot_plane(V4(f0.x, f0.y, f0.z, f0.w), vl), d1 = dot_plane(V4(f1.x, f1.y, f1.z, f1.w), vl);
+					const float d2 = dot_plane(V4(f2.x, f2.y, f2.z, f2.w), vl), d3 = dot_plane(V4(f3.x, f3.y, f3.z, f3.w), vl);
+					if (best < d0) { best = d0; bi = i; }
+					if (best < d1) { best = d1; bi = i + 4; }
+					if (best < d2) { best = d2; bi = i + 8; }
+					if (best < d3) { best = d3; bi = i + 12; }
+				}
+			for (; i < npmax; i += 16)
 			{
 				const float4 f0 = pl[i], f1 = pl[i + 4], f2 = pl[i + 8], f3 = pl[i + 12];
 				const float d0 = dot_plane(V4(f0.x, f0.y, f0.z, f0.w), vl), d1 = dot_plane(V4(f1.x, f1.y, f1.z, f1.w), vl);
 				const float d2 = dot_plane(V4(f2.x, f2.y, f2.z, f2.w), vl), d3 = dot_plane(V4(f3.x, f3.y, f3.z, f3.w), vl);
-				if (i < np && (bi < 0 || best < d0)) { best = d0; bi = i; }       // std::max_element: the first maximum of this lane's faces
-				if (i + 4 < np && (bi < 0 || best < d1)) { best = d1; bi = i + 4; }
-				if (i + 8 < np && (bi < 0 || best < d2)) { best = d2; bi = i + 8; }
-				if (i + 12 < np && (bi < 0 || best < d3)) { best = d3; bi = i + 12; }
+				if (i < np && best < d0) { best = d0; bi = i; }
+				if (i + 4 < np && best < d1) { best = d1; bi = i + 4; }
+				if (i + 8 < np && best < d2) { best = d2; bi = i + 8; }
+				if (i + 12 < np && best < d3) { best = d3; bi = i + 12; }
 			}
 			(void)live;
 			// merge the four partial results: larger value wins, equal values keep the lower index (the first maximum overall)
