@@ -45,7 +45,7 @@
 #define AR_S 0             // float4: targetspin, targetspin after RemoveBias, mintorque*dt, maxtorque*dt
 #define AR_GAIN 4          // 1 / (axis.Iinv0.axis + axis.Iinv1.axis); 0 for a disabled row (physics.h:252)
 #define AR_TORQUE 5        // accumulated torque (the only word a sweep writes)
-#define AR_AXIS 6          // 3
+#define AR_AXIS 6          // 3, then the gain of the sweeps after RemoveBias
 #define AR_BA 10           // 6: -(Iinv0*axis), then Iinv1*axis
 #define ASLOTS 2           // angular rows are built in registers: row r by lane r%64, slot r/64  (<= 128 rows)
 #define MAXA2 (64 * ASLOTS)
@@ -226,6 +226,8 @@ __constant__ float FEATURE_OFF[8][3] = { { 0, 0, 0 }, { -0.03f, 0, -0.03f }, { 0
 // ---- two-body row maths ------------------------------------------------------------------------
 template <class LDS> __device__ __forceinline__ v3 spin_of(const LDS &S, int b) { return mul(body_I(S, b), F3(S.ang4[b])); }       // physics.h:126
 // ------------------------------------------------------------------------------------------------- k_solve
+struct ht_true { static constexpr bool value = true; };
+struct ht_false { static constexpr bool value = false; };
 struct arow { int rb0, rb1; v3 axis; float targetspin, mn, mx, s2t, torque, mintorque; int lev; };
 
 // row counts of ConstrainAngularRangeW (physics.h:351-393) for given limits, without building the rows
@@ -804,8 +806,9 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			float *o = arec + r * AROW;
 			const float ts_post = (R.mintorque < 0) ? 0 : fmin_std(R.targetspin, 0.0f);                      // RemoveBias physics.h:250
 			o[AR_S] = R.targetspin; o[AR_S + 1] = ts_post; o[AR_S + 2] = R.mn; o[AR_S + 3] = R.mx;
-			o[AR_GAIN] = R.s2t; o[AR_TORQUE] = 0.0f;
-			o[AR_AXIS] = R.axis.x; o[AR_AXIS + 1] = R.axis.y; o[AR_AXIS + 2] = R.axis.z; o[AR_AXIS + 3] = 0.0f;
+			// a row whose target spin is -FLT_MAX is skipped by LimitAngular::Iter (physics.h:252): gain 0 = no torque; RemoveBias can turn it on (target 0)
+			o[AR_GAIN] = R.targetspin == -FLT_MAX ? 0.0f : R.s2t; o[AR_TORQUE] = 0.0f;
+			o[AR_AXIS] = R.axis.x; o[AR_AXIS + 1] = R.axis.y; o[AR_AXIS + 2] = R.axis.z; o[AR_AXIS + 3] = ts_post == -FLT_MAX ? 0.0f : R.s2t;
 			const v3 ba0 = ABA0[s], ba1 = ABA1[s];
 			o[AR_BA] = ba0.x; o[AR_BA + 1] = ba0.y; o[AR_BA + 2] = ba0.z; o[AR_BA + 3] = ba1.x; o[AR_BA + 4] = ba1.y; o[AR_BA + 5] = ba1.z;
 		}
@@ -830,7 +833,10 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	const int pslot = lane >> 3;
 	const int ls_lin = S.lstart[lane], ls_ang = S.astart[lane];      // step boundaries of the first 63 steps, read back with v_readlane
 	// ---- the two phases of the two-body tail, written once and instantiated for records in LDS (the frame fits the build) and in HBM (it does not) ----
-	auto linear_phase = [&](const auto pool_, const bool post) {
+	// (both phases are compiled once for the sweeps before RemoveBias and once for those after it, like the chains: which target speed a row uses -- and,
+	// for an angular row, whether it is disabled -- is then a compile-time choice)
+	auto linear_phase = [&](const auto pool_, const auto post_c) {
+		constexpr bool post = decltype(post_c)::value;
 		struct lset { unsigned e; int meta; float n0, n1, n2, g0, g1, g2, b0, b1, b2, minv; float4 s0, s1, s2; float q0, q1, q2, i0, i1, i2; };
 		auto entry = [&](int L) -> unsigned {
 			if (L > nlev_lin) return S.lorder[S.LIDLE];
@@ -908,7 +914,8 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			__builtin_amdgcn_wave_barrier();
 		}
 	};
-	auto angular_phase = [&](const auto arec_, const int tsoff) {
+	auto angular_phase = [&](const auto arec_, const auto post_c) {
+		constexpr bool POST = decltype(post_c)::value;
 		struct aset { unsigned e; float ax, ba, ts, mn, mx, gain, torque; };
 		auto entry = [&](int L) -> unsigned {
 			if (L > nlev_ang) return S.aorder[MAXA2];
@@ -920,7 +927,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		};
 		auto load = [&](aset &r, const float *R) {
 			const float4 sv = *reinterpret_cast<const float4 *>(R + AR_S); const float2 gt = *reinterpret_cast<const float2 *>(R + AR_GAIN);
-			r.ts = tsoff ? sv.y : sv.x; r.mn = sv.z; r.mx = sv.w; r.gain = gt.x; r.torque = gt.y;
+			r.ts = POST ? sv.y : sv.x; r.mn = sv.z; r.mx = sv.w; r.gain = POST ? R[AR_AXIS + 3] : gt.x; r.torque = gt.y;
 			r.ax = R[AR_AXIS + cc]; r.ba = R[AR_BA + 3 * side + cc];
 		};
 		auto fetch = [&](aset &r, unsigned e) { r.e = e; load(r, arec_ + (int)(e & 0xFF) * AROW); };
@@ -928,7 +935,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		// one row of a run: R = its record (the accumulated torque is written back)
 		auto apply = [&](const aset &r, float *R, float &av) {
 			const float axs = __int_as_float(__float_as_int(r.ax) ^ sidesign);                            // rb0: -axis, rb1: axis
-			const float gain = r.ts == -FLT_MAX ? 0.0f : r.gain;                                          // disabled row (physics.h:252): no torque
+			const float gain = r.gain;                                                                     // 0 for a disabled row (physics.h:252), decided when the record was written
 			const float p = r.ba * av;
 			const float sp = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);                           // this side's signed spin about the axis
 			const float currentspin = sp + pair_swap(sp);                                                  // spin1 - spin0
@@ -1006,12 +1013,20 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		//     of a contact (normal, two friction rows) share their bodies and are applied back to back with the momenta in registers.  Pairs
 		//     without a group work on the idle group / idle body, so a step is branch-free.  Three-stage software pipeline: the sort entry is
 		//     fetched two steps ahead, the group's record one step ahead; only the momenta are read after the previous step's stores.
-		if (!HT_DBG(a.dbg, 2) && nlev_lin > 0) { if (pool_lds) linear_phase(S.pool, post); else linear_phase(gpool, post); }
+		if (!HT_DBG(a.dbg, 2) && nlev_lin > 0)
+		{
+			if (post) { if (pool_lds) linear_phase(S.pool, ht_true{}); else linear_phase(gpool, ht_true{}); }
+			else { if (pool_lds) linear_phase(S.pool, ht_false{}); else linear_phase(gpool, ht_false{}); }
+		}
 		__builtin_amdgcn_wave_barrier();
 		if (stats) { const long long t = clock64(); cyc_lin += t - t_mark; t_mark = t; }
 		// (3) angular rows (LimitAngular::Iter physics.h:251-265): one run of consecutive rows on the same body pair per lane pair and step,
 		//     same pipeline; inside a run the next row's record is read while the current row is applied
-		if (!HT_DBG(a.dbg, 4) && nlev_ang > 0) { if (arec_lds) angular_phase(S.arec, tsoff); else angular_phase(garec, tsoff); }
+		if (!HT_DBG(a.dbg, 4) && nlev_ang > 0)
+		{
+			if (post) { if (arec_lds) angular_phase(S.arec, ht_true{}); else angular_phase(garec, ht_true{}); }
+			else { if (arec_lds) angular_phase(S.arec, ht_false{}); else angular_phase(garec, ht_false{}); }
+		}
 		__syncthreads();
 		if (stats) { const long long t = clock64(); cyc_ang += t - t_mark; t_mark = t; }
 		if (sweep + 1 == ph.iterations && lane < nb)
