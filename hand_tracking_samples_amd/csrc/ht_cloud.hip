@@ -13,6 +13,7 @@
 // All arithmetic keeps the reference's evaluation order (-ffp-contract=off), so rows are bit-identical to the CPU path.
 #include "ht_device.hpp"
 #include "ht_launch.hpp"
+#include <string.h>
 #include "ht_quad.hpp"
 
 extern __shared__ __attribute__((aligned(16))) float4 s_planes[];      // all face planes of the model, staged once per block (25 KB for the hand)
@@ -382,11 +383,12 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 __constant__ int ht_fit_error_dbg;
 #endif
 __global__ __launch_bounds__(256) void k_fit_error(ht_model_dev M, const float *__restrict__ state, const float4 *__restrict__ pts, const int *__restrict__ npts,
-                                                  const uint16_t *__restrict__ depth, const float *__restrict__ cams, int w, int h, float bone_sum_error_scale, float *__restrict__ err)
+                                                  const uint16_t *__restrict__ depth, const float *__restrict__ cams, int w, int h, float bone_sum_error_scale, float *__restrict__ err, ht_fit_after after)
 {
 	__shared__ float tab[HT_MAXNB * BT];
 	__shared__ closest_lds L;
 	__shared__ int perr[HT_MAXNB];
+	__shared__ int s_take;
 	const int b = blockIdx.x, t = threadIdx.x;
 	if (t < 64) body_table_build(M, state + (size_t)b * M.nb * HT_STATE_STRIDE, tab, t);
 	if (t < HT_MAXNB) perr[t] = 0;
@@ -432,7 +434,28 @@ __global__ __launch_bounds__(256) void k_fit_error(ht_model_dev M, const float *
 			float bone_error = (float)(int)depth[((size_t)b * h + py) * w + px] * cam[4] - position.z;
 			bone_error_sum += clamp_std(bone_error, 0.0f, 0.01f);
 		}
-		err[b] = point_error_sum + bone_error_sum * bone_sum_error_scale;
+		const float e = point_error_sum + bone_error_sum * bone_sum_error_scale;
+		err[b] = e;
+		if (after.mode == 1) { const int f = (after.angles_only || e > after.reset_thr) ? 1 : 0; after.flags[b] = f; after.nflags[b] = !f; }      // handtrack.h:706
+		if (after.mode == 2)      // handtrack.h:713-731: the CNN-driven pose replaces the tracked one when it explains the frame better for long enough
+		{
+			float pfe = after.prev_err[b];
+			const float olderror = after.err_old[b], newerror = e;
+			if (newerror > olderror) pfe = 0.0f; else pfe += olderror - newerror;
+			const bool take = (n > after.min_point_num && after.initializing[b]) || after.always_take_cnn || after.angles_only || pfe > after.accum_thr;
+			if (pfe > after.accum_thr) pfe = 0.0f;
+			after.prev_err[b] = pfe;
+			const int ini = after.initializing[b] - 1;
+			after.initializing[b] = ini < 0 ? 0 : ini;
+			if (after.accepted) after.accepted[b] = take ? after.nb : 0;
+			s_take = take ? 1 : 0;
+		}
+	}
+	if (after.mode == 2)
+	{
+		__syncthreads();
+		if (s_take && after.hand)      // handmodel.SetPose(othermodel pose): the momenta stay
+			for (int i = t; i < after.nb * 7; i += 256) { const size_t o = ((size_t)b * after.nb + i / 7) * HT_STATE_STRIDE + i % 7; after.hand[o] = after.other[o]; }
 	}
 }
 
@@ -553,12 +576,13 @@ void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float
 	hipLaunchKernelGGL(k_cloud_rows, dim3(B, split), dim3(CR_THREADS), ((size_t)M.plane_off[M.nb] + 16) * sizeof(float4), s, M, state, pts, npts, cams, active_flag, stride, use_cam_origin, mode, par.microforce,
 	                   mode == 4 ? sf_ratio : par.physics_weak_force, mode == 4 ? sf_wrist : par.cloudforce_max_point, par.cloudforce_max_sum, par.unibody_force, rows, nrows, rec ? *rec : none, ht_tuning_flags());
 }
-void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, int w, int h, float scale, float *err, int B, hipStream_t s)
+void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, int w, int h, float scale, float *err, int B, hipStream_t s, const ht_fit_after *after)
 {
+	ht_fit_after none; memset(&none, 0, sizeof none);
 #ifdef HT_TUNING
 	{ static int done = 0; if (!done) { const int f = ht_tuning_flags(); (void)hipMemcpyToSymbol(HIP_SYMBOL(ht_fit_error_dbg), &f, sizeof(int)); done = 1; } }
 #endif
-	hipLaunchKernelGGL(k_fit_error, dim3(B), dim3(256), ((size_t)M.plane_off[M.nb] + 16) * sizeof(float4), s, M, state, pts, npts, depth, cams, w, h, scale, err);
+	hipLaunchKernelGGL(k_fit_error, dim3(B), dim3(256), ((size_t)M.plane_off[M.nb] + 16) * sizeof(float4), s, M, state, pts, npts, depth, cams, w, h, scale, err, after ? *after : none);
 }
 void ht_launch_chamber(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, int min_point_num, int enabled, float maxforce, float *rows, int *nch, int B, hipStream_t s)
 {

@@ -25,6 +25,8 @@ struct solve_args
 	int *caps;                                                      // capacity counter: frames x launches whose angular rows exceeded the LDS records (may be null)
 	int shared_gpu;                                                 // other kernels run beside this launch (the reset path): keep the small LDS footprint
 	int force_build;                                                // 0: the launcher chooses k_solve's build; 1 small, 2 only, 3 mid, 4 tiny (every array in HBM): ht_debug_solver_build
+	// the last solve of an update also delivers the poses (GetPoseUser physmodel.h:434 + the "initializing = 50" rule of handtrack.h:781-782), instead of a launch of its own
+	float *out_poses; const int *out_npts; int *out_initializing; int out_min_point_num;
 	int dbg;                                                        // timing experiments only (HT_DEBUG_SKIP): 1 skip chains, 2 skip two-body linear, 4 skip angular
 };
 
@@ -32,7 +34,15 @@ struct solve_args
 struct cloud_records { float *scratch; int stride; unsigned char *body; float dt; };
 void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const float *cams, const int *active_flag, int stride, int use_cam_origin, int mode,
                           const ht_params &par, float *rows, int *nrows, int B, hipStream_t s, float sf_ratio = 0.0f, float sf_wrist = 0.0f, const cloud_records *rec = nullptr);
-void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, int w, int h, float scale, float *err, int B, hipStream_t s);
+// What follows a FitError in HandTracker::update and needs nothing but that frame's error rides on the kernel's last thread instead of a launch of its own:
+// mode 1 = the full-reset decision (handtrack.h:706: flags[b] = angles_only || error > threshold), mode 2 = the accept step (handtrack.h:713-731).
+struct ht_fit_after
+{
+	int mode;
+	float reset_thr; int angles_only; int *flags, *nflags;
+	float *hand; const float *other; const float *err_old; float *prev_err; int *initializing, *accepted; int nb, min_point_num, always_take_cnn; float accum_thr;
+};
+void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, int w, int h, float scale, float *err, int B, hipStream_t s, const ht_fit_after *after = nullptr);
 void ht_launch_chamber(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, int min_point_num, int enabled, float maxforce, float *rows, int *nch, int B, hipStream_t s);
 void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s, bool beside_cloud_rows = false);
 size_t ht_contacts_workspace_bytes(int B);
@@ -40,10 +50,8 @@ void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solv
 void ht_launch_set_pose(float *state, const float *src, int nb, int n, int mode, hipStream_t s);
 void ht_launch_get_state(const float *state, float *dst, int nb, int n, hipStream_t s);
 void ht_launch_clear_flags(float *prev_err, int *initializing, int n, hipStream_t s);
-void ht_launch_decide_reset(const float *err_old, float thr, int angles_only, int *flags, int *nflags, int n, hipStream_t s);
 void ht_launch_scratch(const ht_model_dev &M, float *state, const float4 *pts, const int *npts, const float *analysis, const float *cams, const int *flags, int B, hipStream_t s);
 void ht_launch_unibody(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float *rows, const int *nrows, const int *flags, float *scratch, int scratch_stride, int batch, int B, hipStream_t s);
-void ht_launch_accept(float *hand, const float *other, const float *err_old, const float *err_new, const int *npts, float *prev_err, int *initializing, int *accepted, int nb, int n, const ht_params &p, hipStream_t s);
 void ht_launch_output(const ht_model_dev &M, const float *hand, const int *npts, int *initializing, int min_point_num, float *poses, int n, hipStream_t s, int raw = 0);
 // ht_segment.hip
 bool ht_segment_supported(int w, int h);

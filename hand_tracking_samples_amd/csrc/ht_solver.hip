@@ -1075,6 +1075,13 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		if (a.zero_momenta) { lin = V3(0, 0, 0); ang = V3(0, 0, 0); }
 		s[0] = pos.x; s[1] = pos.y; s[2] = pos.z; s[3] = q.x; s[4] = q.y; s[5] = q.z; s[6] = q.w;
 		s[7] = lin.x; s[8] = lin.y; s[9] = lin.z; s[10] = ang.x; s[11] = ang.y; s[12] = ang.z;
+		if (a.out_poses)      // the update's last solve delivers the user poses too: GetPoseUser (physmodel.h:434) and the "initializing = 50" rule (handtrack.h:781-782)
+		{
+			const v3 pu = apply(XF(pos, q), -L3(bc + HT_BC_COM));
+			float *o = a.out_poses + ((size_t)b * nb + lane) * HT_POSE;
+			o[0] = pu.x; o[1] = pu.y; o[2] = pu.z; o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w;
+			if (lane == 0 && a.out_npts[b] < a.out_min_point_num) a.out_initializing[b] = 50;
+		}
 	}
 }
 

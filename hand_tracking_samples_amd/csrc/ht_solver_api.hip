@@ -24,7 +24,7 @@ static int dev_alloc_points(ht_ctx *ctx)      // the second cloud of a context t
 }
 static cloud_records cloud_rec(ht_ctx *ctx) { cloud_records r = { ctx->d_scratch, scratch_stride(ctx), ctx->d_rowbody, ctx->phys.deltaT }; return r; }
 static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int *n_pre, bool cloud, bool contacts, const int *active,
-                       int apply_angles, float drive_force, int ray_rows, int arm_cone, int zero_momenta, int B, hipStream_t s, bool shared_gpu = false)
+                       int apply_angles, float drive_force, int ray_rows, int arm_cone, int zero_momenta, int B, hipStream_t s, bool shared_gpu = false, float *poses_out = nullptr, const int *out_npts = nullptr)
 {
 	solve_args a;
 	memset(&a, 0, sizeof a);
@@ -40,6 +40,7 @@ static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int 
 	a.dbg = ht_tuning_flags();
 	a.shared_gpu = shared_gpu ? 1 : 0;
 	a.force_build = ctx->solver_build;
+	a.out_poses = poses_out; a.out_npts = out_npts; a.out_initializing = ctx->d_initializing; a.out_min_point_num = ctx->par.min_point_num;
 	ht_launch_solve(ctx->model, ctx->phys, a, B, s);
 }
 // Fork/join helpers: the row-producing kernels of one fit step only read the pose, so they run side by side on two extra streams
@@ -73,7 +74,7 @@ static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int 
 	}
 }
 // one main-thread pass of HandTracker::update (handtrack.h:769-780)
-static void main_pass(ht_ctx *ctx, int B, hipStream_t s)
+static void main_pass(ht_ctx *ctx, int B, hipStream_t s, float *poses_out = nullptr)      // poses_out: the update's last pass also writes the user poses
 {
 	const ht_params &p = ctx->par;
 	const float4 *pts = p.subsample_voxel ? ctx->d_ptsv : ctx->d_pts;      // handtrack.h:751: the main-thread cloud
@@ -88,7 +89,7 @@ static void main_pass(ht_ctx *ctx, int B, hipStream_t s)
 	if (coll) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[0], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, par); }
 	if (par) join(ctx, s, 2);
 	ht_prof_scope ps(ctx, "solve", s);
-	solve_step(ctx, 0, ctx->d_chamber, ctx->d_nchamber, true, coll, nullptr, 0, 0.0f, 0, 0, 0, B, s);
+	solve_step(ctx, 0, ctx->d_chamber, ctx->d_nchamber, true, coll, nullptr, 0, 0.0f, 0, 0, 0, B, s, false, poses_out, npts);
 }
 static void reset_path(ht_ctx *ctx, const int *flags, int n_unibody, int B, hipStream_t s, hipStream_t prof_stream)
 {
@@ -170,8 +171,9 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		hipStream_t t = ctx->side[1];
 		fork(ctx, s);
 		if (mode == UPD_FULL && !(d_start && !fs)) ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, t);     // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757 (both were just seeded with the same pose otherwise)
-		ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_old, B, t);
-		ht_launch_decide_reset(ctx->d_err_old, p.full_reset_on_error, p.angles_only, ctx->d_flags, ctx->d_nflags, B, t);
+		ht_fit_after dec; memset(&dec, 0, sizeof dec);
+		dec.mode = 1; dec.reset_thr = p.full_reset_on_error; dec.angles_only = p.angles_only; dec.flags = ctx->d_flags; dec.nflags = ctx->d_nflags;
+		ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_old, B, t, &dec);      // with the reset decision (handtrack.h:706)
 	}
 	{
 		ht_prof_scope ps(ctx, "cnn", s, true);
@@ -206,16 +208,25 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 	else
 	{
 		if (mode == UPD_FULL) ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, s);     // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757
-		{ ht_prof_scope ps(ctx, "fit_error", s, true); ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_old, B, s); }
-		ht_launch_decide_reset(ctx->d_err_old, p.full_reset_on_error, p.angles_only, ctx->d_flags, ctx->d_nflags, B, s);
+		ht_fit_after dec; memset(&dec, 0, sizeof dec);
+		dec.mode = 1; dec.reset_thr = p.full_reset_on_error; dec.angles_only = p.angles_only; dec.flags = ctx->d_flags; dec.nflags = ctx->d_nflags;
+		{ ht_prof_scope ps(ctx, "fit_error", s, true); ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_old, B, s, &dec); }
 		reset_path(ctx, ctx->d_flags, p.steps_unibody, B, s, s);
 		multistep(ctx, B, s);
 	}
-	{ ht_prof_scope ps(ctx, "fit_error", s, true); ht_launch_fit_error(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_new, B, s); }
-	ht_launch_accept(mode == UPD_CNN_MODEL ? nullptr : ctx->d_state[0], ctx->d_state[1], ctx->d_err_old, ctx->d_err_new, ctx->d_npts, ctx->d_prev_err, ctx->d_initializing, ctx->d_accepted, nb, B, p, s);
+	{
+		// FitError of the CNN-driven pose, and on its last thread the accept step (handtrack.h:713-731)
+		ht_fit_after acc; memset(&acc, 0, sizeof acc);
+		acc.mode = 2; acc.hand = mode == UPD_CNN_MODEL ? nullptr : ctx->d_state[0]; acc.other = ctx->d_state[1]; acc.err_old = ctx->d_err_old; acc.prev_err = ctx->d_prev_err;
+		acc.initializing = ctx->d_initializing; acc.accepted = ctx->d_accepted; acc.nb = nb; acc.min_point_num = p.min_point_num; acc.always_take_cnn = p.always_take_cnn;
+		acc.angles_only = p.angles_only; acc.accum_thr = p.accum_error_threshold;
+		ht_prof_scope ps(ctx, "fit_error", s, true);
+		ht_launch_fit_error(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_new, B, s, &acc);
+	}
 	if (mode != UPD_FULL) { ht_launch_output(ctx->model, ctx->d_state[1], ctx->d_npts, ctx->d_initializing, p.min_point_num, d_poses_out, B, s, 1); return HT_OK; }      // othermodel.GetPose()
-	for (int i = 0; !p.angles_only && i < p.mainthreadpasses; i++) main_pass(ctx, B, s);
-	ht_launch_output(ctx->model, ctx->d_state[0], p.subsample_voxel ? ctx->d_nptsv : ctx->d_npts, ctx->d_initializing, p.min_point_num, d_poses_out, B, s);
+	const int passes = p.angles_only ? 0 : p.mainthreadpasses;
+	for (int i = 0; i < passes; i++) main_pass(ctx, B, s, i + 1 == passes ? d_poses_out : nullptr);      // the last pass's solve writes the poses
+	if (passes < 1) ht_launch_output(ctx->model, ctx->d_state[0], p.subsample_voxel ? ctx->d_nptsv : ctx->d_npts, ctx->d_initializing, p.min_point_num, d_poses_out, B, s);
 	return HT_OK;
 }
 

@@ -39,12 +39,7 @@ __global__ void k_clear_flags(float *prev_err, int *initializing, int n)
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) { prev_err[i] = 0.0f; initializing[i] = 0; }
 }
-// flags[b] = angles_only || olderror > full_reset_on_error (handtrack.h:706)
-__global__ void k_decide_reset(const float *__restrict__ err_old, float thr, int angles_only, int *__restrict__ flags, int *__restrict__ nflags, int n)
-{
-	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) { const int f = (angles_only || err_old[i] > thr) ? 1 : 0; flags[i] = f; nflags[i] = !f; }
-}
+// (the full-reset decision of handtrack.h:706 and the accept step of :713-731 ride on k_fit_error's last thread: ht_fit_after, csrc/ht_cloud.hip)
 
 // ---- PoseFromScratch: one wave per flagged frame -----------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_scratch(ht_model_dev M, float *__restrict__ state, const float4 *__restrict__ pts, const int *__restrict__ npts,
@@ -233,25 +228,7 @@ __global__ __launch_bounds__(64) void k_unibody(ht_model_dev M, ht_physics_dev p
 	}
 }
 
-// ---- accept / reject the CNN-driven pose (handtrack.h:714-726), one thread per frame ---------------------------------------------
-__global__ void k_accept(float *__restrict__ hand, const float *__restrict__ other, const float *__restrict__ err_old, const float *__restrict__ err_new,
-                         const int *__restrict__ npts, float *__restrict__ prev_err, int *__restrict__ initializing, int *__restrict__ accepted,
-                         int nb, int n, int min_point_num, int always_take_cnn, int angles_only, float accum_error_threshold)
-{
-	const int b = blockIdx.x * blockDim.x + threadIdx.x;
-	if (b >= n) return;
-	float pfe = prev_err[b];
-	const float olderror = err_old[b], newerror = err_new[b];
-	if (newerror > olderror) pfe = 0.0f; else pfe += olderror - newerror;
-	const bool take = (npts[b] > min_point_num && initializing[b]) || always_take_cnn || angles_only || pfe > accum_error_threshold;
-	if (take && hand)
-		for (int i = 0; i < nb; i++) for (int k = 0; k < 7; k++) hand[((size_t)b * nb + i) * HT_STATE_STRIDE + k] = other[((size_t)b * nb + i) * HT_STATE_STRIDE + k];      // handmodel.SetPose (momenta kept)
-	if (pfe > accum_error_threshold) pfe = 0.0f;
-	prev_err[b] = pfe;
-	const int ini = initializing[b] - 1;
-	initializing[b] = ini < 0 ? 0 : ini;
-	if (accepted) accepted[b] = take ? nb : 0;
-}
+// ---- the user poses when no main pass follows (with one, its last k_solve writes them) -----------------------------------------------
 // GetPoseUser (physmodel.h:434) + the "initializing = 50" rule of handtrack.h:781-782
 // raw != 0: GetPose (physmodel.h:433) of the given model, no rule
 __global__ void k_output(ht_model_dev M, const float *__restrict__ hand, const int *__restrict__ npts, int *__restrict__ initializing, int min_point_num, float *__restrict__ poses, int n, int raw)
@@ -271,7 +248,6 @@ __global__ void k_output(ht_model_dev M, const float *__restrict__ hand, const i
 void ht_launch_set_pose(float *state, const float *src, int nb, int n, int mode, hipStream_t s) { hipLaunchKernelGGL(k_set_pose, dim3((n * nb + 255) / 256), dim3(256), 0, s, state, src, nb, n, mode); }
 void ht_launch_get_state(const float *state, float *dst, int nb, int n, hipStream_t s) { hipLaunchKernelGGL(k_get_state, dim3((n * nb + 255) / 256), dim3(256), 0, s, state, dst, nb, n); }
 void ht_launch_clear_flags(float *prev_err, int *initializing, int n, hipStream_t s) { hipLaunchKernelGGL(k_clear_flags, dim3((n + 255) / 256), dim3(256), 0, s, prev_err, initializing, n); }
-void ht_launch_decide_reset(const float *err_old, float thr, int angles_only, int *flags, int *nflags, int n, hipStream_t s) { hipLaunchKernelGGL(k_decide_reset, dim3((n + 255) / 256), dim3(256), 0, s, err_old, thr, angles_only, flags, nflags, n); }
 void ht_launch_scratch(const ht_model_dev &M, float *state, const float4 *pts, const int *npts, const float *analysis, const float *cams, const int *flags, int B, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_scratch, dim3(B), dim3(64), 0, s, M, state, pts, npts, analysis, cams, flags);
@@ -294,10 +270,6 @@ void ht_launch_scale_state(float *state, int nb, int n, float s, hipStream_t st)
 void ht_launch_unibody(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float *rows, const int *nrows, const int *flags, float *scratch, int scratch_stride, int batch, int B, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_unibody, dim3(B), dim3(64), 0, s, M, ph, state, rows, nrows, flags, scratch, scratch_stride, batch);
-}
-void ht_launch_accept(float *hand, const float *other, const float *err_old, const float *err_new, const int *npts, float *prev_err, int *initializing, int *accepted, int nb, int n, const ht_params &p, hipStream_t s)
-{
-	hipLaunchKernelGGL(k_accept, dim3((n + 63) / 64), dim3(64), 0, s, hand, other, err_old, err_new, npts, prev_err, initializing, accepted, nb, n, p.min_point_num, p.always_take_cnn, p.angles_only, p.accum_error_threshold);
 }
 void ht_launch_output(const ht_model_dev &M, const float *hand, const int *npts, int *initializing, int min_point_num, float *poses, int n, hipStream_t s, int raw)
 {
