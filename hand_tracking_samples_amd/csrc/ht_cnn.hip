@@ -269,7 +269,13 @@ __global__ __launch_bounds__(256) void k_conv2(const float *__restrict__ act1, c
 // WN = waves along N, WM = waves along M: the block tile is 32*WM x 32*WN.  N = 2048 uses WN = 2; N = 2304 used WN = 3 (192 blocks of
 // 12 waves) before k_fc144 took that layer.  WM = 4: 128 rows, 8 waves, one block per CU at 1024 frames.  (Half tiles, WM = 2 with two blocks of
 // four waves per CU so that one block's barrier does not idle the matrix pipes, were measured: 100 us either way.)
-template <bool TANH, int WN, int WM>
+#ifdef HT_TUNING
+__constant__ int ht_fc_dbg;
+#define FC_MARK(k) if (fcst) { const long long tn = clock64(); fcc[k] += tn - ftm; ftm = tn; }
+#else
+#define FC_MARK(k)
+#endif
+template <bool TANH, int WN, int WM, bool FULL>      // FULL: M is a multiple of the tile's rows (no row test: the slab is then one branch-free region)
 __global__ __launch_bounds__(64 * WM * WN) void k_fc(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K)
 {
 	constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * WM * WN, LDA = BM + 1;
@@ -283,42 +289,50 @@ __global__ __launch_bounds__(64 * WM * WN) void k_fc(const float *__restrict__ A
 	constexpr int KV = FC_BK / 4, NAV = BM * KV, NBV = FC_BK * BN / 4;      // float4 per tile row of A, per A tile, per B tile
 	constexpr int NA = (NAV + NT - 1) / NT, NB = (NBV + NT - 1) / NT;
 	float4 ra[2][NA], rb[2][NB];
+	// every address of the staging is formed once, outside the slab loop (formed per slab they were ~80 instructions of every wave's 72 slabs, during which
+	// the SIMD's matrix pipe had nothing to do: tools/fc_stats.py)
+	const float *ag[NA], *bg[NB]; bool aon[NA], bon[NB]; int al[NA], bl[NB];
+#pragma unroll
+	for (int i = 0; i < NA; i++)
+	{
+		const int e = t + NT * i, row = e / KV, akc = (e % KV) * 4;
+		aon[i] = e < NAV && (FULL || m0 + row < M);
+		ag[i] = A + (size_t)(aon[i] ? m0 + row : 0) * K + (e < NAV ? akc : 0);
+		al[i] = e < NAV ? akc * LDA + row : -1;
+	}
+#pragma unroll
+	for (int i = 0; i < NB; i++)
+	{
+		const int e = t + NT * i, bk = e / (BN / 4), bnc = (e % (BN / 4)) * 4;
+		bon[i] = e < NBV;
+		bg[i] = W + (size_t)(bon[i] ? bk : 0) * N + n0 + (bon[i] ? bnc : 0);
+		bl[i] = bk * BN + bnc;
+	}
 	auto gload = [&](float4 (&qa)[NA], float4 (&qb)[NB], int k0) {
 #pragma unroll
-		for (int i = 0; i < NA; i++)
-		{
-			const int e = t + NT * i, row = m0 + e / KV;
-			qa[i] = (e < NAV && row < M) ? *reinterpret_cast<const float4 *>(A + (size_t)row * K + k0 + (e % KV) * 4) : make_float4(0, 0, 0, 0);
-		}
+		for (int i = 0; i < NA; i++) { const float4 q = *reinterpret_cast<const float4 *>(ag[i] + k0); qa[i] = (FULL && NAV == NA * NT) || aon[i] ? q : make_float4(0, 0, 0, 0); }
 #pragma unroll
-		for (int i = 0; i < NB; i++)
-		{
-			const int e = t + NT * i, bk = e / (BN / 4), bnc = (e % (BN / 4)) * 4;
-			qb[i] = e < NBV ? *reinterpret_cast<const float4 *>(W + (size_t)(k0 + bk) * N + n0 + bnc) : make_float4(0, 0, 0, 0);
-		}
+		for (int i = 0; i < NB; i++) { const float4 q = *reinterpret_cast<const float4 *>(bg[i] + (size_t)k0 * N); qb[i] = NBV == NB * NT || bon[i] ? q : make_float4(0, 0, 0, 0); }
 	};
 	auto lstore = [&](const float4 (&qa)[NA], const float4 (&qb)[NB], int buf) {
 #pragma unroll
 		for (int i = 0; i < NA; i++)
-		{
-			const int e = t + NT * i, row = e / KV, akc = (e % KV) * 4;
-			float *a = As[buf];
-			if (e < NAV) { a[(akc + 0) * LDA + row] = qa[i].x; a[(akc + 1) * LDA + row] = qa[i].y; a[(akc + 2) * LDA + row] = qa[i].z; a[(akc + 3) * LDA + row] = qa[i].w; }
-		}
+			if (NAV == NA * NT || al[i] >= 0) { float *a = As[buf] + al[i]; a[0] = qa[i].x; a[LDA] = qa[i].y; a[2 * LDA] = qa[i].z; a[3 * LDA] = qa[i].w; }
 #pragma unroll
 		for (int i = 0; i < NB; i++)
-		{
-			const int e = t + NT * i, bk = e / (BN / 4), bnc = (e % (BN / 4)) * 4;
-			if (e < NBV) *reinterpret_cast<float4 *>(Bs[buf] + bk * BN + bnc) = qb[i];
-		}
+			if (NBV == NB * NT || bon[i]) *reinterpret_cast<float4 *>(Bs[buf] + bl[i]) = qb[i];
 	};
 	const float bv = bias[n0 + wn * 32 + (lane & 31)];
 	f32x16 acc;
 #pragma unroll
 	for (int r = 0; r < 16; r++) acc[r] = bv;
+#ifdef HT_TUNING
+	const bool fcst = (ht_fc_dbg & 0x800000) != 0; long long fcc[5] = { 0, 0, 0, 0, 0 }, ftm = fcst ? clock64() : 0; const long long fc_t0 = ftm;
+#endif
 	gload(ra[0], rb[0], 0);
 	if (FC_BK < K) gload(ra[1], rb[1], FC_BK);
 	lstore(ra[0], rb[0], 0);
+	FC_MARK(4)
 	for (int k0 = 0; k0 < K; k0 += 2 * FC_BK)
 	{
 #pragma unroll
@@ -327,23 +341,43 @@ __global__ __launch_bounds__(64 * WM * WN) void k_fc(const float *__restrict__ A
 			const int kc = k0 + u * FC_BK;
 			if (kc >= K) break;
 			__syncthreads();                               // buffer u is complete; buffer u ^ 1 is free (its readers passed this barrier)
-			if (kc + 2 * FC_BK < K) gload(ra[u], rb[u], kc + 2 * FC_BK);      // set u was stored one slab ago
+			FC_MARK(0)
 			const float *ap = As[u] + (lane >> 5) * LDA + wm * 32 + (lane & 31);
 			const float *bp = Bs[u] + (lane >> 5) * BN + wn * 32 + (lane & 31);
-			// operand fragments: the first half of the slab is read up front, the second half's reads are slotted between the first half's matrix
-			// instructions (left to itself the scheduler issues each B pair right before the two MFMAs that use it: an LDS round trip every 128 pipe cycles)
+			// Order of a slab's instructions (fenced with sched_barrier): the operand fragments of its first half are read up front, the second half's reads are slotted
+			// between the first matrix instructions (left to itself the scheduler issues each B pair right before the two MFMAs that use it: an LDS round trip
+			// every 128 pipe cycles), and the GLOBAL loads of the slab after next are issued in the middle, behind eight matrix instructions: a wave spends ~300
+			// cycles issuing its three loads and ~250 on the five stores of the next slab's tile (the CU's one address path serves all eight waves: tools/fc_stats.py), and issued first thing after the barrier, as
+			// they were, both waves of a SIMD stood in that queue while the matrix pipe had nothing to do.  (The last slabs load an address again; unused.)
 			float av[FC_BK / 2], bw[FC_BK / 2];
+			constexpr int H = FC_BK / 4;      // matrix instructions per half slab
 #pragma unroll
-			for (int kk = 0; kk < FC_BK / 2; kk++) { av[kk] = ap[2 * kk * LDA]; bw[kk] = bp[2 * kk * BN]; }
+			for (int kk = 0; kk < H; kk++) { av[kk] = ap[2 * kk * LDA]; bw[kk] = bp[2 * kk * BN]; }
+			__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-			for (int kk = 0; kk < FC_BK / 2; kk++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bw[kk], acc, 0, 0, 0);
-			__builtin_amdgcn_sched_group_barrier(0x100, 12, 0);      // A 0-7 (8 reads), B 0-7 (4 paired reads)
+			for (int kk = 0; kk < H; kk++)      // first half, with the second half's fragments read behind each instruction
+			{
+				acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bw[kk], acc, 0, 0, 0);
+				av[H + kk] = ap[2 * (H + kk) * LDA]; bw[H + kk] = bp[2 * (H + kk) * BN];
+			}
+			__builtin_amdgcn_sched_barrier(0);
+			const int kn = kc + 2 * FC_BK < K ? kc + 2 * FC_BK : K - FC_BK;
+			gload(ra[u], rb[u], kn);      // the slab after next (set u was stored one slab ago)
+			__builtin_amdgcn_sched_barrier(0);
+			acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[H], bw[H], acc, 0, 0, 0);
+			acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[H + 1], bw[H + 1], acc, 0, 0, 0);
+			__builtin_amdgcn_sched_barrier(0);
+			lstore(ra[u ^ 1], rb[u ^ 1], u ^ 1);      // the next slab's tile (loaded a slab and a half ago) into the buffer whose readers passed this slab's barrier
+			__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-			for (int i = 0; i < (FC_BK / 2 - 8) * 3 / 4; i++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
-			__builtin_amdgcn_sched_group_barrier(0x008, FC_BK / 2, 0);
-			if (kc + FC_BK < K) lstore(ra[u ^ 1], rb[u ^ 1], u ^ 1);
+			for (int kk = H + 2; kk < 2 * H; kk++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bw[kk], acc, 0, 0, 0);
+			FC_MARK(2)
+			FC_MARK(3)
 		}
 	}
+#ifdef HT_TUNING
+	if (fcst && lane == 0 && (wave == 0 || wave == 5) && (blockIdx.x + blockIdx.y * gridDim.x) % 64 == 0) printf("k_fc block %d,%d wave %d: barrier wait %lld, load issue %lld, reads+mfma issue %lld, store %lld, prologue %lld, whole loop %lld cycles (%d slabs)\n", blockIdx.x, blockIdx.y, wave, fcc[0], fcc[1], fcc[2], fcc[3], fcc[4], (long long)(clock64() - fc_t0), K / FC_BK);
+#endif
 	// C/D map 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 	const int col = n0 + wn * 32 + (lane & 31);
 #pragma unroll
@@ -629,17 +663,22 @@ void ht_launch_prepare_frame(const uint16_t *depth, const float *cams, int w, in
 void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, float *act2, float *act3, float *logits, int B, hipStream_t s, int side)
 {
 	const dim3 g1(2048 / 64, (B + 127) / 128), t1(512);
+#ifdef HT_TUNING
+	{ static int done = 0; if (!done) { const int f = ht_tuning_flags(); (void)hipMemcpyToSymbol(HIP_SYMBOL(ht_fc_dbg), &f, sizeof(int)); done = 1; } }
+#endif
 	if (side == 128)
 	{
 		hipLaunchKernelGGL((k_conv1<128, 31, 8>), dim3(B, 4), dim3(256), 0, s, cnn_in, w.W1, w.B1, act1);
 		hipLaunchKernelGGL((k_conv2<31, 28, 4>), dim3(B, 7), dim3(256), 0, s, act1, w.W2p, w.B2, act2);
-		hipLaunchKernelGGL((k_fc<true, 2, 4>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 12544);
+		if (B % 128 == 0) hipLaunchKernelGGL((k_fc<true, 2, 4, true>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 12544);
+		else hipLaunchKernelGGL((k_fc<true, 2, 4, false>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 12544);
 	}
 	else
 	{
 		hipLaunchKernelGGL((k_conv1<64, 15, 15>), dim3(B, 1), dim3(256), 0, s, cnn_in, w.W1, w.B1, act1);
 		hipLaunchKernelGGL((k_conv2<15, 12, 12>), dim3(B, 1), dim3(256), 0, s, act1, w.W2p, w.B2, act2);
-		hipLaunchKernelGGL((k_fc<true, 2, 4>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
+		if (B % 128 == 0) hipLaunchKernelGGL((k_fc<true, 2, 4, true>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
+		else hipLaunchKernelGGL((k_fc<true, 2, 4, false>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
 	}
 	hipLaunchKernelGGL(k_fc144, dim3(2304 / F2_BN, (B + F2_BM - 1) / F2_BM), dim3(768), 0, s, act3, w.W4, w.B4, logits, B, 2304, 2048);
 }
