@@ -396,7 +396,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_fc(const float *__restrict__ A
 // 128 x 96 tile of k_fc<.,3> makes 192 blocks and leaves a quarter of the chip idle; 128 x 64 makes 288 and a second, nearly empty round).
 // 144 is nine 16-wide tiles, so the arithmetic is v_mfma_f32_16x16x4_f32: 12 waves as 4 (rows) x 3 (columns), a wave holds three 16 x 16
 // accumulators that share one A fragment.  LDS: A as [k][row] with stride 81, B as [k][col] with stride 144 (16 mod 32: the four k-groups of a
-// fragment read land in disjoint banks), double-buffered 32-deep slabs like k_fc (64-deep slabs were measured slower: 136 against 105 us);
+// fragment read land in disjoint banks), double-buffered 32-deep slabs (64-deep slabs were measured slower: 136 against 105 us; so was k_fc's slab
+// organisation -- loads two slabs ahead, loads and stores issued behind matrix instructions: 135 us -- with three waves per SIMD here);
 // accumulation starts from the bias and runs in ascending k.
 #define F2_BM 64
 #define F2_BN 144
