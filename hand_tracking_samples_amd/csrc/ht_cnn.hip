@@ -430,14 +430,19 @@ __global__ __launch_bounds__(768) void k_fc144(const float *__restrict__ A, cons
 	f32x4 acc[3];
 #pragma unroll
 	for (int j = 0; j < 3; j++) { const float bv = bias[n0 + wn * 48 + j * 16 + (lane & 15)]; acc[j] = f32x4{ bv, bv, bv, bv }; }
+#ifdef HT_TUNING
+	const bool fcst = (ht_fc_dbg & 0x800000) != 0; long long fcc[5] = { 0, 0, 0, 0, 0 }, ftm = fcst ? clock64() : 0; const long long fc_t0 = ftm;
+#endif
 	gload(0);
 	lstore(0);
 	int buf = 0;
 	for (int k0 = 0; k0 < K; k0 += F2_BK)
 	{
 		__syncthreads();                                   // slab `buf` is complete; the other buffer is free (its readers passed this barrier)
+		FC_MARK(0)
 		const bool more = k0 + F2_BK < K;
 		if (more) gload(k0 + F2_BK);
+		FC_MARK(1)
 		const float *ap = As[buf] + (lane >> 4) * F2_LDA + wm * 16 + (lane & 15);
 		const float *bp = Bs[buf] + (lane >> 4) * F2_BN + wn * 48 + (lane & 15);
 #pragma unroll
@@ -449,9 +454,14 @@ __global__ __launch_bounds__(768) void k_fc144(const float *__restrict__ A, cons
 			acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[1], 0, 0, 0);
 			acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b2, acc[2], 0, 0, 0);
 		}
+		FC_MARK(2)
 		if (more) lstore(buf ^ 1);
+		FC_MARK(3)
 		buf ^= 1;
 	}
+#ifdef HT_TUNING
+	if (fcst && lane == 0 && (wave == 0 || wave == 4 || wave == 8) && (blockIdx.x + blockIdx.y * gridDim.x) % 128 == 0) printf("k_fc144 block %d,%d wave %d: barrier wait %lld, load issue %lld, reads+mfma issue %lld, store %lld, whole loop %lld cycles (%d slabs)\n", blockIdx.x, blockIdx.y, wave, fcc[0], fcc[1], fcc[2], fcc[3], (long long)(clock64() - fc_t0), K / F2_BK);
+#endif
 	// C/D map 16x16: col = lane & 15, row = 4 * (lane >> 4) + r
 #pragma unroll
 	for (int j = 0; j < 3; j++)

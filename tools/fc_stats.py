@@ -1,4 +1,5 @@
-"""Per-slab cycle account of k_fc on a few waves (tuning build, HT_DEBUG_SKIP=0x800000): one CNN evaluation of 1024 frames."""
+"""Per-slab cycle account of k_fc and k_fc144 on a few waves (tuning build, HT_DEBUG_SKIP=0x800000): one CNN evaluation of 1024 frames.
+k_fc144 at the time of writing: 240 k cycles for 64 slabs of 2304 matrix-pipe cycles; a wave with three loads stands ~1000 cycles per slab in the CU's address path."""
 import os, sys
 import numpy as np
 ROOT = os.getcwd(); sys.path.insert(0, ROOT)
