@@ -7,11 +7,11 @@
 //   ExpandingPolytopeAlgorithm        third_party/hull.h:233-310 (Tri bookkeeping :79-186)
 //   SupportFunc / SupportFuncTrans    third_party/gjk.h:568-582, maxdir third_party/geometric.h:218-224
 //
-// Two organisations of the same arithmetic, chosen per launch by the batch size (ht_launch_contacts):
-//   k_contacts_coop (up to 1024 frames): lane-per-run simplex logic in owner waves, support scans worked off cooperatively by all waves of a
-//     block, one scan pair per DPP row, polytope jobs taken by any wave -- described at the kernel below.  Shortest launch when the batch is a few
-//     frames per CU; owns the CU (152 KB of LDS, 255 VGPRs).
-//   k_contacts (larger batches): a block serves two frames (one wave each) and stages all collision vertices (3042 x float4 = 48 KB, w = vertex
+// Two organisations of the same arithmetic (ht_launch_contacts):
+//   k_contacts_coop (every batch size, when a frame of the model fits its LDS): lane-per-run simplex logic in owner waves, support scans worked off cooperatively by all waves of a
+//     block, one scan pair per DPP row, polytope jobs taken by any wave -- described at the kernel below.  Owns the CU (152 KB of LDS, 255 VGPRs).
+//   k_contacts (the fall-back for models whose padded vertices leave no room for a frame in the other's LDS; until round 3 also the faster one
+//     above ~1100 frames): a block serves two frames (one wave each) and stages all collision vertices (3042 x float4 = 48 KB, w = vertex
 //     index) in LDS once.  GJK runs on lane groups: a candidate pair is served by 1, 2 or 4 neighbouring lanes (4 when a frame has <= 16
 //     candidates, 2 up to 32) that hold identical simplex state, scan interleaved 6-vertex blocks of the support map (128-bit LDS reads issued
 //     together, packed x/y multiply, compare in index order: first maximum wins as std::max_element does) and agree through DPP quad permutes; the
@@ -1163,7 +1163,7 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 
 size_t ht_contacts_workspace_bytes(int B) { (void)B; return 16; }      // the polytope mesh lives in LDS; the workspace holds the capacity counters (polytope runs cut short, contacts dropped, k_solve's angular overflow)
 
-void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s, bool beside_cloud_rows)
+void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s, bool beside_cloud_rows, int force_kernel)
 {
 	int *caps = reinterpret_cast<int *>(epa_ws);
 	const int dbg = ht_tuning_flags();
@@ -1176,21 +1176,23 @@ void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftma
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_contacts_coop), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		attr_set[dev] = true;
 	}
-	// Which organisation: the cooperative kernel owns a CU per block (152 KB of LDS, 249 VGPRs) and finishes a launch of up to four frames per CU much
-	// sooner (175 against 265 us at 1024 frames); but nothing else fits on its CUs, so the cloud-row kernel of the same fit step waits for it, while the
-	// lane-per-pair kernel's smaller blocks (61 KB, two per CU) run beside the cloud rows.  Whole steps, same device: 512 frames 7.60 against 8.12 ms,
-	// 1024 frames 8.06 against 8.19, 1280 frames 10.28 against 9.85, 2048 frames 12.17 against 11.43 -- the cooperative kernel up to 1024 frames.
+	// Which organisation: the cooperative kernel (a CU per block: 152 KB of LDS, 249 VGPRs) whenever a frame of the model fits its LDS beside the padded vertex
+	// copy.  Whole steps on one device, cooperative against lane-per-pair: 1536 frames 7.57 against 7.64 ms, 2048 frames 8.46 / 8.56, 4096 frames 14.74 / 14.96,
+	// 8192 frames 27.00 / 27.57 (tools/exp_coop_max.sh; until the polytope and the frame-to-block assignment were reworked in round 3 the lane-per-pair kernel won
+	// above ~1100 frames because its smaller blocks run beside the cloud-row kernel).  force_kernel (ht_debug_contact_kernel): 1 cooperative, 2 lane-per-pair.
 	static int coop_max = -1;
 	if (coop_max < 0)
 	{
-		coop_max = 1024;
+		coop_max = 1 << 30;
 #ifdef HT_TUNING
 		if (const char *e = getenv("HT_CONTACTS_COOP_MAX")) coop_max = atoi(e);
 #endif
 	}
 	static int main_lanes = -1;
 	if (main_lanes < 0) main_lanes = ht_tuning_int("HT_CONTACTS_MAIN_LANES", 0);
-	if (B <= coop_max && !(beside_cloud_rows && main_lanes))
+	const size_t coop_fixed = (size_t)M.cvert_off[M.nb] * sizeof(float4) + sizeof(co_block) + (size_t)CO_OWN * 64 * 2 * (sizeof(co_req) + sizeof(int)) + CO_EPAQ * sizeof(co_job) + CO_NW * gjk_wave_stride();
+	const bool coop_fits = coop_fixed + sizeof(co_frame) <= 160 * 1024;
+	if (force_kernel == 1 ? coop_fits : (force_kernel != 2 && coop_fits && B <= coop_max && !(beside_cloud_rows && main_lanes)))
 	{
 		// as many frames per block as the LDS holds beside the padded vertex copy, the scan list and the waves' polytope areas (4 for the 17-bone hand)
 		const int nvp = M.cvert_off[M.nb];

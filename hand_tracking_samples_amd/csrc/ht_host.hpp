@@ -15,6 +15,7 @@ struct ht_ctx
 	bool profile_phases = false;     // also time the minor phases (serialises the side streams; used for the phase table, not for the timed region)
 	int B = 0, device = 0;
 	int solver_build = 0;           // ht_debug_solver_build: 0 = the launcher's choice
+	int contact_kernel = 0;         // ht_debug_contact_kernel: 0 = the launcher's choice, 1 cooperative, 2 lane-per-pair
 	std::string err;
 	hipStream_t stream = nullptr;
 	hipStream_t last_user_stream = nullptr;         // stream of the latest *_dev call (host-read helpers wait for it too)

@@ -67,7 +67,7 @@ static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int 
 		if (par) fork1(ctx, s, side);
 		const cloud_records cr = cloud_rec(ctx);
 		if (cloud) { ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, active, 4, 1, 2, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[side] : s, 0.0f, 0.0f, &cr); }
-		if (coll && !(first_contacts_done && st == from_step)) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, active, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s); }
+		if (coll && !(first_contacts_done && st == from_step)) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, active, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, false, ctx->contact_kernel); }
 		if (par) join1(ctx, s, side);
 		ht_prof_scope ps(ctx, prof ? "solve" : nullptr, s);
 		solve_step(ctx, 1, nullptr, nullptr, cloud, coll, active, angles, st < p.steps_palmangle ? 10000.0f : 0.0f, rays, 1, 1, B, s, shared_gpu);
@@ -86,7 +86,7 @@ static void main_pass(ht_ctx *ctx, int B, hipStream_t s, float *poses_out = null
 	{ ht_prof_scope ps(ctx, "chamber", s, true); ht_launch_chamber(ctx->model, ctx->d_state[0], pts, npts, p.min_point_num, p.boundary_planes, 10.0f, ctx->d_chamber, ctx->d_nchamber, B, par ? ctx->side[1] : s); }
 	const cloud_records cr = cloud_rec(ctx);
 	{ ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[0], pts, npts, ctx->d_cams, nullptr, 1, 0, 1, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[0] : s, 0.0f, 0.0f, &cr); }
-	if (coll) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[0], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, par); }
+	if (coll) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[0], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, par, ctx->contact_kernel); }
 	if (par) join(ctx, s, 2);
 	ht_prof_scope ps(ctx, "solve", s);
 	solve_step(ctx, 0, ctx->d_chamber, ctx->d_nchamber, true, coll, nullptr, 0, 0.0f, 0, 0, 0, B, s, false, poses_out, npts);
@@ -492,7 +492,7 @@ extern "C" int ht_stage_contacts(ht_ctx *ctx, int which, int B, int cap, float *
 	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
 	if (!contacts || !ncontacts || which < 0 || which > 1 || cap < 1) return HT_ERR_ARG;
 	hipStream_t s = ctx->stream;
-	ht_launch_contacts(ctx->model, ctx->d_state[which], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s);
+	ht_launch_contacts(ctx->model, ctx->d_state[which], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, false, ctx->contact_kernel);
 	std::vector<float> tmp((size_t)B * HT_MAXCONTACT * HT_CONTACT);
 	HIPCHK(ctx, hipMemcpyAsync(tmp.data(), ctx->d_contacts, tmp.size() * sizeof(float), hipMemcpyDeviceToHost, s));
 	HIPCHK(ctx, hipMemcpyAsync(ncontacts, ctx->d_ncontacts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -556,6 +556,13 @@ extern "C" int ht_debug_solver_build(ht_ctx *ctx, int which)
 {
 	if (!ctx || which < 0 || which > 4) return HT_ERR_ARG;
 	ctx->solver_build = which;
+	return HT_OK;
+}
+// Tests only: pins the organisation of the contact kernel (0 = the launcher's choice; 1 cooperative, 2 lane-per-pair).  Same arithmetic, same contacts in the same order.
+extern "C" int ht_debug_contact_kernel(ht_ctx *ctx, int which)
+{
+	if (!ctx || which < 0 || which > 2) return HT_ERR_ARG;
+	ctx->contact_kernel = which;
 	return HT_OK;
 }
 // Same for k_contacts (last contact slot of each frame): launches, cycles in GJK / polytope runs, polytope runs, polytope cycles in
@@ -694,7 +701,7 @@ extern "C" int ht_fit_rows(ht_ctx *ctx, int which, int B, const float *points, i
 	ht_params par = ctx->par; par.microforce = microforce;
 	const cloud_records cr = cloud_rec(ctx);
 	ht_launch_cloud_rows(ctx->model, ctx->d_state[which], ctx->d_pts, ctx->d_npts, ctx->d_cams, nullptr, 1, 0, 1, par, ctx->d_rows, ctx->d_nrows, B, s, 0.0f, 0.0f, &cr);
-	if (coll) ht_launch_contacts(ctx->model, ctx->d_state[which], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s);
+	if (coll) ht_launch_contacts(ctx->model, ctx->d_state[which], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, false, ctx->contact_kernel);
 	solve_args a;
 	memset(&a, 0, sizeof a);
 	a.sf_select = -1;
@@ -772,7 +779,7 @@ extern "C" int ht_physics_update(ht_ctx *ctx, int which, int B, const float *lin
 	HIPCHK(ctx, hipMemcpy(ctx->d_user_n + 2 * (size_t)ctx->B, ngrp.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice));
 	hipStream_t s = ctx->stream;
 	const bool coll = ctx->phys.use_collision != 0;
-	if (coll) ht_launch_contacts(ctx->model, ctx->d_state[which], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s);
+	if (coll) ht_launch_contacts(ctx->model, ctx->d_state[which], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, false, ctx->contact_kernel);
 	solve_args a;
 	memset(&a, 0, sizeof a);
 	a.sf_select = -1;
@@ -817,7 +824,7 @@ extern "C" int ht_slowfit(ht_ctx *ctx, int B, int hold, const float *refpose, in
 		const cloud_records cr = cloud_rec(ctx);
 		if (cloud) ht_launch_cloud_rows(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, ctx->d_cams, nullptr, 1, 0, 4, ctx->par, ctx->d_rows, ctx->d_nrows, B, s,
 		                                1.0f * (float)(steps - st) / (float)steps, 0.1f * (float)(st < steps - 2), &cr);
-		if (coll) ht_launch_contacts(ctx->model, ctx->d_state[0], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s);
+		if (coll) ht_launch_contacts(ctx->model, ctx->d_state[0], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, false, ctx->contact_kernel);
 		solve_args a;
 		memset(&a, 0, sizeof a);
 		a.caps = reinterpret_cast<int *>(ctx->d_epa_ws) + 2;

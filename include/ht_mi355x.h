@@ -301,6 +301,9 @@ int ht_debug_contact_stats(ht_ctx *ctx, int B, float *out, int reset);      /* s
 /* Test aid: pins which build of the solver kernel runs (0 = chosen per launch; 1-3 the LDS sizes for tile batches / small batches / large frames and models;
  * 4 = a build whose LDS arrays hold nothing, so every frame places its row records in HBM).  Placement only: results are identical bit for bit. */
 int ht_debug_solver_build(ht_ctx *ctx, int which);
+/* Test aid: pins the organisation of the contact kernel (0 = chosen per launch: the cooperative kernel whenever the model fits its LDS; 1 cooperative,
+ * 2 one lane group per body pair).  Same contacts in the same order either way. */
+int ht_debug_contact_kernel(ht_ctx *ctx, int which);
 
 #ifdef __cplusplus
 }

@@ -111,8 +111,7 @@ def test_full_size_batch_properties(weights):
         assert np.array_equal(a[:256], a[256 * k:256 * (k + 1)])
     assert np.isfinite(a).all()
     assert np.abs(np.linalg.norm(a[:, :, 3:], axis=2) - 1.0).max() < 1e-5
-    # (4) A batch size is a scheduling decision, not a numerical one: 1280 frames take the other builds of the contact kernel (lane-per-pair instead of
-    # cooperative), of k_solve (small + second launch instead of the single one) and of the cloud rows (one block per frame instead of two) -- and
+    # (4) A batch size is a scheduling decision, not a numerical one: 1280 frames take the other builds of k_solve (small + second launch instead of the single one) and of the cloud rows (one block per frame instead of two) -- and
     # must give the same poses bit for bit.
     B2 = 1280
     idx2 = np.arange(B2) % 256
@@ -120,13 +119,15 @@ def test_full_size_batch_properties(weights):
     try:
         ctx.load_weights(weights)
         ctx.set_params(microforce=3.0, mainthreadpasses=3)
-        ctx.tracker_reset(d["startpose"][idx2])
-        c = ctx.update_sync(d["depth"][idx2].reshape(B2, -1), d["cam"][idx2])
-        assert ctx.capacity_events() == (0, 0, 0)
+        for kernel in (0, 2):      # the launcher's choice (the cooperative contact kernel), then the lane-per-pair kernel (the fall-back for models too large for the other's LDS)
+            ctx.debug_contact_kernel(kernel)
+            ctx.tracker_reset(d["startpose"][idx2])
+            c = ctx.update_sync(d["depth"][idx2].reshape(B2, -1), d["cam"][idx2])
+            assert ctx.capacity_events() == (0, 0, 0)
+            for k in range(5):
+                assert np.array_equal(a[:256], c[256 * k:256 * (k + 1)]), "contact kernel %d" % kernel
     finally:
         ctx.close()
-    for k in range(5):
-        assert np.array_equal(a[:256], c[256 * k:256 * (k + 1)])
 
 
 def test_config4_shard_of_8192_frames(weights):
