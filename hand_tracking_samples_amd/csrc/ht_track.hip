@@ -73,7 +73,19 @@ __global__ __launch_bounds__(64) void k_scratch(ht_model_dev M, float *__restric
 				wp[i] = make_float4(pw.x, pw.y, pw.z, w);
 			}
 			__syncthreads();
-			if (lane == 0) for (int i = 0; i < m; i++) { const float4 e = wp[i]; pcom = pcom + V3(e.x, e.y, e.z); wsum += e.w; }
+			if (lane == 0)      // the reference's order of additions; eight terms are read ahead of the (dependent) sums
+			{
+				int i = 0;
+				for (; i + 8 <= m; i += 8)
+				{
+					float4 e[8];
+#pragma unroll
+					for (int k = 0; k < 8; k++) e[k] = wp[i + k];
+#pragma unroll
+					for (int k = 0; k < 8; k++) { pcom = pcom + V3(e[k].x, e[k].y, e[k].z); wsum += e[k].w; }
+				}
+				for (; i < m; i++) { const float4 e = wp[i]; pcom = pcom + V3(e.x, e.y, e.z); wsum += e.w; }
+			}
 		}
 		if (lane == 0) { pcom = pcom / wsum; pc[0] = pcom.x; pc[1] = pcom.y; pc[2] = pcom.z; }
 	}
@@ -109,15 +121,27 @@ __global__ __launch_bounds__(64) void k_scratch(ht_model_dev M, float *__restric
 		}
 	}
 	__syncthreads();
-	if (lane == 0)      // FixPositions: ordered top-down (physmodel.h:404-408)
+	// FixPositions: ordered top-down (physmodel.h:404-408).  The joints' constants come in by one lane per joint first (a lane walking them alone waited
+	// two dependent memory round trips per joint), then lane 0 walks the chain in order out of LDS.
+	__shared__ float fj[HT_MAXNJ][12];      // rb0, rb1, p0 (3), p1 (3), then the two bodies' centres of mass are folded below
+	__shared__ float fc[HT_MAXNJ][6];
+	if (lane < M.nj)
+	{
+		const float *jc = M.jointc + lane * HT_JC;
+		const int r0 = (int)jc[HT_JC_RB0], r1 = (int)jc[HT_JC_RB1];
+		fj[lane][0] = (float)r0; fj[lane][1] = (float)r1;
+		for (int i = 0; i < 3; i++) { fj[lane][2 + i] = jc[HT_JC_P0 + i]; fj[lane][5 + i] = jc[HT_JC_P1 + i]; }
+		for (int i = 0; i < 3; i++) { fc[lane][i] = M.bodyc[r0 * HT_BC + HT_BC_COM + i]; fc[lane][3 + i] = M.bodyc[r1 * HT_BC + HT_BC_COM + i]; }
+	}
+	__syncthreads();
+	if (lane == 0)
 	{
 		for (int j = 0; j < M.nj; j++)
 		{
-			const float *jc = M.jointc + j * HT_JC;
-			const int r0 = (int)jc[HT_JC_RB0], r1 = (int)jc[HT_JC_RB1];
-			xf u0 = XF(apply(XF(G3(pos[r0]), G4(q[r0])), -G3(M.bodyc + r0 * HT_BC + HT_BC_COM)), G4(q[r0]));
-			xf u1 = XF(apply(XF(G3(pos[r1]), G4(q[r1])), -G3(M.bodyc + r1 * HT_BC + HT_BC_COM)), G4(q[r1]));
-			v3 np = G3(pos[r1]) + (apply(u0, G3(jc + HT_JC_P0)) - apply(u1, G3(jc + HT_JC_P1)));
+			const int r0 = (int)fj[j][0], r1 = (int)fj[j][1];
+			xf u0 = XF(apply(XF(G3(pos[r0]), G4(q[r0])), -G3(fc[j])), G4(q[r0]));
+			xf u1 = XF(apply(XF(G3(pos[r1]), G4(q[r1])), -G3(fc[j] + 3)), G4(q[r1]));
+			v3 np = G3(pos[r1]) + (apply(u0, G3(fj[j] + 2)) - apply(u1, G3(fj[j] + 5)));
 			pos[r1][0] = np.x; pos[r1][1] = np.y; pos[r1][2] = np.z;
 		}
 	}
