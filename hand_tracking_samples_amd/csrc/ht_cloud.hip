@@ -234,20 +234,15 @@ __device__ __forceinline__ void closest_chunk(const ht_model_dev &M, const float
 // One block per frame, CH points per pass: closest feature as above, then ConvexHitCheck (geometric.h:275-297) of the chosen body, one lane per
 // point with the body's faces read per lane from the LDS copy (the clipping of a segment is sequential in the faces; points are independent).
 #define CR_THREADS 256
-__global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const float *__restrict__ state, const float4 *__restrict__ pts, const int *__restrict__ npts,
-                                                           const float *__restrict__ cams, const int *__restrict__ active_flag, int stride, int use_cam_origin, int mode,
-                                                           float microforce, float weak_force, float cf_max_point, float cf_max_sum, float unibody_force,
-                                                           float *__restrict__ rows, int *__restrict__ nrows, cloud_records rec, int dbg)
+// One frame's rows by one block (or by `ny` blocks that share its passes: block `by` takes every ny-th).  tab / L / wq / wI: the block's LDS (wq, wI only in
+// record mode); the planes go to s_planes.  k_cloud_rows below and the full-reset kernel (k_reset) both run this.
+__device__ __forceinline__ void cloud_rows_frame(const ht_model_dev &M, const float *__restrict__ state, const float4 *__restrict__ pts, const float *__restrict__ cams, int stride,
+                                                 int use_cam_origin, int mode, float microforce, float weak_force, float cf_max_point, float cf_max_sum, float unibody_force,
+                                                 float *__restrict__ rows, int *__restrict__ nrows, const cloud_records &rec, int dbg, int b, int n, int by, int ny,
+                                                 float *tab, closest_lds &L, float (*wq)[4], float (*wI)[10])
 {
-	__shared__ float tab[HT_MAXNB * BT];
-	__shared__ closest_lds L;
-	__shared__ float wq[HT_MAXNB][4], wI[HT_MAXNB][10];      // record mode: the bodies' orientations, world inverse inertia and inverse mass, as k_solve forms them
-	const int b = blockIdx.x, t = threadIdx.x;
-	const int n = npts[b];
+	const int t = threadIdx.x;
 	const int nsub = (n + stride - 1) / stride;
-	if (active_flag && !active_flag[b]) return;      // a masked launch leaves the other frames' rows and counts alone (another launch may be producing them)
-	if ((int)blockIdx.y * CH >= nsub && blockIdx.y > 0) return;      // gridDim.y blocks share a frame's passes (a row only depends on its own point)
-	if (t == 0 && blockIdx.y == 0) nrows[b] = nsub;
 	if (t < 64) body_table_build(M, state + (size_t)b * M.nb * HT_STATE_STRIDE, tab, t);
 	if (rec.scratch && t >= 64 && t < 64 + M.nb)      // rbinitvelocity's world inverse inertia (physics.h:517-518), the expression of k_solve's prologue
 	{
@@ -265,7 +260,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 	const v3 origin = use_cam_origin ? V3(cam[5], cam[6], cam[7]) : V3(0, 0, 0);
 	int npmax = 0;
 	for (int bb = 0; bb < M.nb; bb++) npmax = max(npmax, M.plane_off[bb + 1] - M.plane_off[bb]);
-	for (int base = blockIdx.y * CH; base < nsub; base += gridDim.y * CH)
+	for (int base = by * CH; base < nsub; base += ny * CH)
 	{
 		const int i = base + (t & (CH - 1));
 		const bool exists = i < nsub, active = t < CH && exists;
@@ -375,6 +370,247 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 		out[1] = make_float4(v.z, position1.x, position1.y, position1.z);
 		out[2] = make_float4(normal.x, normal.y, normal.z, targetdist);
 		out[3] = make_float4(0.0f, fmin_std(fmin, fmax), fmax_std(fmin, fmax), 0.0f);
+	}
+}
+__global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const float *__restrict__ state, const float4 *__restrict__ pts, const int *__restrict__ npts,
+                                                           const float *__restrict__ cams, const int *__restrict__ active_flag, int stride, int use_cam_origin, int mode,
+                                                           float microforce, float weak_force, float cf_max_point, float cf_max_sum, float unibody_force,
+                                                           float *__restrict__ rows, int *__restrict__ nrows, cloud_records rec, int dbg)
+{
+	__shared__ float tab[HT_MAXNB * BT];
+	__shared__ closest_lds L;
+	__shared__ float wq[HT_MAXNB][4], wI[HT_MAXNB][10];      // record mode: the bodies' orientations, world inverse inertia and inverse mass, as k_solve forms them
+	const int b = blockIdx.x, t = threadIdx.x;
+	const int n = npts[b];
+	const int nsub = (n + stride - 1) / stride;
+	if (active_flag && !active_flag[b]) return;      // a masked launch leaves the other frames' rows and counts alone (another launch may be producing them)
+	if ((int)blockIdx.y * CH >= nsub && blockIdx.y > 0) return;      // gridDim.y blocks share a frame's passes (a row only depends on its own point)
+	if (t == 0 && blockIdx.y == 0) nrows[b] = nsub;
+	cloud_rows_frame(M, state, pts, cams, stride, use_cam_origin, mode, microforce, weak_force, cf_max_point, cf_max_sum, unibody_force, rows, nrows, rec, dbg, b, n, blockIdx.y, gridDim.y, tab, L, wq, wI);
+}
+
+// ------------------------------------------------------------------------------------------------- k_reset
+// The full-reset branch of HandTracker::update (handtrack.h:706-711) for one flagged frame in ONE block: PoseFromScratch (handtrack.h:478-506), then
+// steps_unibody times UnibodyFit (handtrack.h:451-470: the cloud rows of every 4th point, re-expressed on one proxy body, a single-body solve, the pose moved
+// with it).  As seven launches of one-block-per-flagged-frame kernels the chain paid a cold start per launch (lone blocks: the planes, the body table and the
+// code itself fetched again) while the batch waited for it; the phases share the block's LDS (planes + closest-feature scratch | the solve's records).
+// Two builds: MINB 1 takes the registers the chain wants (297: one block per CU) and is the one an update launches -- few frames reset, and the batch waits for the
+// slowest of them (8 of 1024 frames: 0.48 ms against 0.53); MINB 2 (256 registers, two blocks per CU) serves a launch over ALL frames (1024 frames: 1.13 ms
+// against 2.08; tools/reset_all_frames.py).
+#define RS_THREADS CR_THREADS
+__device__ __forceinline__ v3 G3(const float *p) { return V3(p[0], p[1], p[2]); }
+__device__ __forceinline__ v4 G4(const float *p) { return V4(p[0], p[1], p[2], p[3]); }
+__device__ __forceinline__ m3 GM(const float *p) { m3 m; m.x = V3(p[0], p[1], p[2]); m.y = V3(p[3], p[4], p[5]); m.z = V3(p[6], p[7], p[8]); return m; }
+#define UB_LDS_ROWS 896      // rows of the single-body solve kept in LDS (3584 points); 72 KB with sums and chain: two blocks per CU
+template <int MINB> __global__ __launch_bounds__(RS_THREADS, MINB) void k_reset(ht_model_dev M, ht_physics_dev ph, float *state, const float4 *__restrict__ pts, const int *__restrict__ npts,
+                                                      const float *__restrict__ analysis, const float *__restrict__ cams, const int *__restrict__ flags, int n_unibody, int from_scratch,
+                                                      float unibody_force, float *rows, int *nrows, float *scratch, int scratch_stride, int batch, int dbg)
+{
+	__shared__ float pos[HT_MAXNB][3], q[HT_MAXNB][4];
+	__shared__ float pc[3], res[8];
+	__shared__ float fj[HT_MAXNJ][8], fc[HT_MAXNJ][6];
+	const int b = blockIdx.x, t = threadIdx.x;
+	if (flags && !flags[b]) return;
+	const int nb = M.nb;
+	const int n = npts[b];
+	float *st = state + (size_t)b * nb * HT_STATE_STRIDE;
+	const float *an = analysis + (size_t)b * HT_ANALYSIS;
+	const float *cam = cams + (size_t)b * HT_CAM;
+	// the dynamic LDS, phase by phase
+	float4 *const wp = s_planes;                                                                        // PoseFromScratch: 256 weighted points
+	closest_lds &L = *reinterpret_cast<closest_lds *>(s_planes + ((M.plane_off[nb] + 16 + 3) & ~3));      // cloud rows: planes, closest-feature scratch, body table
+	float *const tab = reinterpret_cast<float *>(reinterpret_cast<char *>(&L) + ((sizeof(closest_lds) + 15) & ~15));
+	float *const urow = reinterpret_cast<float *>(s_planes);                                            // single-body solve: records, impulse sums, chain
+	float *const usum = urow + (UB_LDS_ROWS + QUAD_CHAIN_SLACK) * CREC;
+	unsigned short *const uidx = reinterpret_cast<unsigned short *>(usum + UB_LDS_ROWS + QUAD_CHAIN_SLACK);
+
+	if (from_scratch)
+	{
+		// ---- PoseFromScratch.  Palm ray from the first three landmark rays, inverse-distance weighted centroid of the cloud (handtrack.h:483-490): the weights are
+		// independent per point (256 per pass, one per thread, through LDS); the sums keep the reference's order on thread 0, eight terms read ahead.
+		const v4 cs = (G4(an + HT_AN_CRAYS) + G4(an + HT_AN_CRAYS + 4)) + G4(an + HT_AN_CRAYS + 8);
+		const v3 palmray = normalize(xyz(cs));
+		v3 pcom = V3(0, 0, 0); float wsum = 0.00000000001f;
+		for (int base = 0; base < n; base += RS_THREADS)
+		{
+			const int m = min(RS_THREADS, n - base);
+			__syncthreads();
+			if (t < m)
+			{
+				const float4 pv = pts[(size_t)b * M.pts_cap + base + t];
+				const v3 p = V3(pv.x, pv.y, pv.z);
+				const v3 c = cross(p, palmray);
+				const float w = 1.0f / (0.000001f + dot(c, c));
+				const v3 pw = p * w;
+				wp[t] = make_float4(pw.x, pw.y, pw.z, w);
+			}
+			__syncthreads();
+			if (t == 0)
+			{
+				int i = 0;
+				for (; i + 8 <= m; i += 8)
+				{
+					float4 e[8];
+#pragma unroll
+					for (int k = 0; k < 8; k++) e[k] = wp[i + k];
+#pragma unroll
+					for (int k = 0; k < 8; k++) { pcom = pcom + V3(e[k].x, e[k].y, e[k].z); wsum += e[k].w; }
+				}
+				for (; i < m; i++) { const float4 e = wp[i]; pcom = pcom + V3(e.x, e.y, e.z); wsum += e.w; }
+			}
+		}
+		if (t == 0) { pcom = pcom / wsum; pc[0] = pcom.x; pc[1] = pcom.y; pc[2] = pcom.z; }
+		if (t < nb)
+		{
+			const float *bc = M.bodyc + t * HT_BC;     // Reset(rb) physmodel.h:221-226
+			for (int i = 0; i < 3; i++) pos[t][i] = bc[HT_BC_POS0 + i];
+			for (int i = 0; i < 4; i++) q[t][i] = bc[HT_BC_Q0 + i];
+		}
+		if (t >= 64 && t < 64 + M.nj)      // the joints' constants for FixPositions below
+		{
+			const int j = t - 64;
+			const float *jc = M.jointc + j * HT_JC;
+			const int r0 = (int)jc[HT_JC_RB0], r1 = (int)jc[HT_JC_RB1];
+			fj[j][0] = (float)r0; fj[j][1] = (float)r1;
+			for (int i = 0; i < 3; i++) { fj[j][2 + i] = jc[HT_JC_P0 + i]; fj[j][5 + i] = jc[HT_JC_P1 + i]; }
+			for (int i = 0; i < 3; i++) { fc[j][i] = M.bodyc[r0 * HT_BC + HT_BC_COM + i]; fc[j][3 + i] = M.bodyc[r1 * HT_BC + HT_BC_COM + i]; }
+		}
+		__syncthreads();
+		const v4 camq = V4(cam[8], cam[9], cam[10], cam[11]);
+		const v4 palmq = G4(an + HT_AN_PALMQ);
+		const xf p1 = XF(V3(pc[0], pc[1], pc[2]), qmul(camq, palmq));
+		const xf dp = mul(p1, inverse(XF(G3(pos[1]), G4(q[1]))));
+		__syncthreads();
+		if (t < nb)
+		{
+			const xf np = mul(dp, XF(G3(pos[t]), G4(q[t])));
+			pos[t][0] = np.p.x; pos[t][1] = np.p.y; pos[t][2] = np.p.z; q[t][0] = np.q.x; q[t][1] = np.q.y; q[t][2] = np.q.z; q[t][3] = np.q.w;
+		}
+		__syncthreads();
+		if (t >= 1 && t <= 4 && nb >= 17)     // curl the four fingers by the decoded clench angles (handtrack.h:498-504)
+		{
+			const int finger = t;
+			const float a = an[HT_AN_CLENCH + finger];
+			const v4 jf = G4(M.jointc + (1 + finger * 3) * HT_JC + HT_JC_FRAME);
+			const float ang[3] = { a / 2.0f, a, a * 1.25f };
+			for (int k = 0; k < 3; k++)
+			{
+				const int bb = 2 + k + finger * 3;
+				const v4 o = qmul(jf, qmul(G4(q[bb]), quat_axis_angle(V3(1, 0, 0), ang[k])));
+				q[bb][0] = o.x; q[bb][1] = o.y; q[bb][2] = o.z; q[bb][3] = o.w;
+			}
+		}
+		__syncthreads();
+		if (t == 0)      // FixPositions: ordered top-down (physmodel.h:404-408)
+		{
+			for (int j = 0; j < M.nj; j++)
+			{
+				const int r0 = (int)fj[j][0], r1 = (int)fj[j][1];
+				const xf u0 = XF(apply(XF(G3(pos[r0]), G4(q[r0])), -G3(fc[j])), G4(q[r0]));
+				const xf u1 = XF(apply(XF(G3(pos[r1]), G4(q[r1])), -G3(fc[j] + 3)), G4(q[r1]));
+				const v3 np = G3(pos[r1]) + (apply(u0, G3(fj[j] + 2)) - apply(u1, G3(fj[j] + 5)));
+				pos[r1][0] = np.x; pos[r1][1] = np.y; pos[r1][2] = np.z;
+			}
+		}
+		__syncthreads();
+		if (t < nb)
+		{
+			float *s = st + t * HT_STATE_STRIDE;
+			for (int i = 0; i < 3; i++) s[i] = pos[t][i];
+			for (int i = 0; i < 4; i++) s[3 + i] = q[t][i];
+			for (int i = 7; i < 13; i++) s[i] = 0.0f;
+		}
+		__syncthreads();
+	}
+
+	const int nsub = (n + 3) / 4;
+	if (t == 0 && n_unibody > 0) nrows[b] = nsub;
+	const cloud_records none = { nullptr, 0, nullptr, 0.0f };
+	for (int it = 0; it < n_unibody; it++)
+	{
+		// ---- the cloud rows of every 4th point from the camera's origin, UnibodyFit's force limits (handtrack.h:457-461)
+		cloud_rows_frame(M, state, pts, cams, 4, 1, 3, 0.0f, 0.0f, 0.0f, 0.0f, unibody_force, rows, nrows, none, dbg, b, n, 0, 1, tab, L, nullptr, nullptr);
+		__syncthreads();
+		// ---- UnibodyFit's solve: all rows act on one proxy body, so the Gauss-Seidel chain is sequential (one quad of lanes walks it)
+		if (t < nb) { for (int i = 0; i < 3; i++) pos[t][i] = st[t * HT_STATE_STRIDE + i]; for (int i = 0; i < 4; i++) q[t][i] = st[t * HT_STATE_STRIDE + 3 + i]; }
+		__syncthreads();
+		// SanityCheck before the solve (handtrack.h:463) is a no-op unless the pose already holds NaNs; those bodies are reset
+		if (t < nb)
+		{
+			bool bad = false;
+			for (int i = 0; i < 13; i++) bad = bad || isnan(st[t * HT_STATE_STRIDE + i]);
+			if (bad) { for (int i = 0; i < 3; i++) pos[t][i] = M.bodyc[t * HT_BC + HT_BC_POS0 + i]; for (int i = 0; i < 4; i++) q[t][i] = M.bodyc[t * HT_BC + HT_BC_Q0 + i]; }
+		}
+		__syncthreads();
+		const float dt = ph.deltaT;
+		const v3 ubpos = G3(pos[1]) + V3(M.ub_com[0], M.ub_com[1], M.ub_com[2]);        // RigidBody ctor: position += com (physics.h:157)
+		const v4 ubq = G4(q[1]);
+		const xf ubi = inverse(XF(ubpos, ubq));
+		const float minv = M.ub_massinv;
+		const m3 tinv = GM(M.ub_tinv);
+		const m3 Iinv = world_inertia(ubq, tinv, minv);
+		// The rows re-expressed on the proxy body and pre-computed into records (handtrack.h:457-462).  Up to UB_LDS_ROWS rows the records stay in LDS (a single
+		// quad walking its chain alone on a CU would wait a whole L2 round trip for what k_solve's sixteen quads overlap); a larger cloud uses the frame's slot
+		// of the solver scratch in HBM, sums behind all frames' records as in k_solve.
+		const int nr = nsub < scratch_stride - QUAD_CHAIN_SLACK ? nsub : scratch_stride - QUAD_CHAIN_SLACK;
+		const bool in_lds = nr <= UB_LDS_ROWS;
+		float *const grec = scratch + (size_t)b * scratch_stride * CREC;
+		float *const gsum = scratch + (size_t)batch * scratch_stride * CREC + (size_t)b * scratch_stride;
+		unsigned *const gidx = reinterpret_cast<unsigned *>(scratch + (size_t)batch * scratch_stride * (CREC + 1)) + (size_t)b * scratch_stride;
+		if (in_lds) { for (int i = t; i < nr + QUAD_CHAIN_SLACK; i += RS_THREADS) { usum[i] = 0.0f; uidx[i] = (unsigned short)i; } }
+		else for (int i = t; i < nr + QUAD_CHAIN_SLACK; i += RS_THREADS) { gsum[i] = 0.0f; gidx[i] = (unsigned)i; }
+		for (int i = t; i < nr; i += RS_THREADS)
+		{
+			const float *r = rows + ((size_t)b * M.pts_cap + i) * HT_ROW;
+			const int rb1 = (int)r[1];
+			const v3 p1 = apply(ubi, apply(XF(G3(pos[rb1]), G4(q[rb1])), G3(r + 5)));
+			const v3 nrm = G3(r + 8);
+			const v3 r1 = qrot(ubq, p1);
+			const float impulsed = minv + dot(cross(mul(Iinv, cross(r1, nrm)), r1), nrm);
+			const float ts = r[11] / dt;
+			quad_write_record((in_lds ? urow : grec) + (size_t)i * CREC, r1, nrm, Iinv, minv, ts, fmin_std(ts, r[12]), impulsed, r[13] * dt, r[14] * dt);
+		}
+		__threadfence_block();
+		__syncthreads();
+		if (t < 4)       // the proxy body in quad layout (ht_quad.hpp): lane c < 3 owns component c, lane 3 carries the row's target speed
+		{
+			const int c = t;
+			// rbinitvelocity on a body at rest: 0 * damping + 0
+			quad_body qb = { (0.0f * M.ub_dampleft) + 0.0f, (0.0f * M.ub_dampleft) + 0.0f };
+			v3 pn = ubpos; v4 qn = ubq;
+			const int total = ph.iterations + ph.iterations_post;
+			for (int sweep = 0; sweep < total; sweep++)
+			{
+				const int tsoff = sweep >= ph.iterations ? 1 : 0;        // RemoveBias: lane 3 switches to the ts_post slot
+				if (nr > 0) { if (in_lds) quad_chain_run(qb, urow, uidx, usum, nr, c, tsoff); else quad_chain_run(qb, grec, gidx, gsum, nr, c, tsoff); }
+				if (sweep + 1 == ph.iterations)
+				{
+					const v3 lin = V3(dpp<QP_BC0>(qb.l), dpp<QP_BC1>(qb.l), dpp<QP_BC2>(qb.l)), ang = V3(dpp<QP_BC0>(qb.av), dpp<QP_BC1>(qb.av), dpp<QP_BC2>(qb.av));
+					pn = ubpos + (lin * minv) * dt;
+					const m3 tm = tinv * minv;
+					auto diffq = [&](v4 o) -> v4 { v4 sn = normalize(o); m3 Mx = qmat(sn); m3 Ii = mul(Mx, mul(tm, transpose(Mx))); v3 hs = mul(Ii, ang) * 0.5f; return qmul(V4(hs.x, hs.y, hs.z, 0), sn); };
+					v4 d1 = diffq(ubq), d2 = diffq(ubq + d1 * (dt / 2)), d3 = diffq(ubq + d2 * (dt / 2)), d4 = diffq(ubq + d3 * dt);
+					v4 o = normalize((((ubq + d1 * (dt / 6)) + d2 * (dt / 3)) + d3 * (dt / 3)) + d4 * (dt / 6));
+					if (o.x < FLT_EPSILON / 4.0f && o.x > -FLT_EPSILON / 4.0f) o.x = 0.0f;
+					if (o.y < FLT_EPSILON / 4.0f && o.y > -FLT_EPSILON / 4.0f) o.y = 0.0f;
+					if (o.z < FLT_EPSILON / 4.0f && o.z > -FLT_EPSILON / 4.0f) o.z = 0.0f;
+					qn = o;
+				}
+			}
+			if (t == 0) { res[0] = pn.x; res[1] = pn.y; res[2] = pn.z; res[3] = qn.x; res[4] = qn.y; res[5] = qn.z; res[6] = qn.w; }
+		}
+		__syncthreads();
+		const xf dp = mul(XF(V3(res[0], res[1], res[2]), V4(res[3], res[4], res[5], res[6])), inverse(XF(G3(pos[1]), G4(q[1]))));
+		if (t < nb)
+		{
+			xf np = mul(dp, XF(G3(pos[t]), G4(q[t])));
+			float *s = st + t * HT_STATE_STRIDE;
+			bool bad = isnan(np.p.x) || isnan(np.p.y) || isnan(np.p.z) || isnan(np.q.x) || isnan(np.q.y) || isnan(np.q.z) || isnan(np.q.w);
+			for (int i = 7; i < 13; i++) bad = bad || isnan(s[i]);
+			if (bad) { const float *bc = M.bodyc + t * HT_BC; np = XF(G3(bc + HT_BC_POS0), G4(bc + HT_BC_Q0)); for (int i = 7; i < 13; i++) s[i] = 0.0f; }
+			s[0] = np.p.x; s[1] = np.p.y; s[2] = np.p.z; s[3] = np.q.x; s[4] = np.q.y; s[5] = np.q.z; s[6] = np.q.w;
+		}
+		__syncthreads();      // the next round's body table reads the pose; its planes overwrite the records
 	}
 }
 
@@ -575,6 +811,28 @@ void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float
 	if (split < 1) split = 1;
 	hipLaunchKernelGGL(k_cloud_rows, dim3(B, split), dim3(CR_THREADS), ((size_t)M.plane_off[M.nb] + 16) * sizeof(float4), s, M, state, pts, npts, cams, active_flag, stride, use_cam_origin, mode, par.microforce,
 	                   mode == 4 ? sf_ratio : par.physics_weak_force, mode == 4 ? sf_wrist : par.cloudforce_max_point, par.cloudforce_max_sum, par.unibody_force, rows, nrows, rec ? *rec : none, ht_tuning_flags());
+}
+// the full-reset branch for the flagged frames (all frames with flags == nullptr); from_scratch = 0 leaves out PoseFromScratch
+void ht_launch_reset(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float4 *pts, const int *npts, const float *analysis, const float *cams, const int *flags,
+                     int n_unibody, int from_scratch, const ht_params &par, float *rows, int *nrows, float *scratch, int scratch_stride, int batch, int B, hipStream_t s)
+{
+	const size_t cloud = (((size_t)M.plane_off[M.nb] + 16 + 3) & ~(size_t)3) * sizeof(float4) + ((sizeof(closest_lds) + 15) & ~(size_t)15) + HT_MAXNB * BT * sizeof(float);
+	const size_t solve = (size_t)(UB_LDS_ROWS + QUAD_CHAIN_SLACK) * (CREC * sizeof(float) + sizeof(float) + sizeof(unsigned short));
+	const size_t dyn = cloud > solve ? cloud : solve;
+	static size_t attr_set[64];               // per device: the attribute belongs to the device's copy of the code object
+	int dev = 0; (void)hipGetDevice(&dev); dev &= 63;
+	if (attr_set[dev] < dyn)
+	{
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_reset<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_reset<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+		attr_set[dev] = dyn;
+	}
+	if (flags)
+		hipLaunchKernelGGL(k_reset<1>, dim3(B), dim3(RS_THREADS), dyn, s, M, ph, state, pts, npts, analysis, cams, flags, n_unibody, from_scratch, par.unibody_force, rows, nrows, scratch, scratch_stride, batch,
+		                   ht_tuning_flags());
+	else
+		hipLaunchKernelGGL(k_reset<2>, dim3(B), dim3(RS_THREADS), dyn, s, M, ph, state, pts, npts, analysis, cams, flags, n_unibody, from_scratch, par.unibody_force, rows, nrows, scratch, scratch_stride, batch,
+		                   ht_tuning_flags());
 }
 void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, int w, int h, float scale, float *err, int B, hipStream_t s, const ht_fit_after *after)
 {

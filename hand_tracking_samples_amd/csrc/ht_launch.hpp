@@ -50,8 +50,9 @@ void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solv
 void ht_launch_set_pose(float *state, const float *src, int nb, int n, int mode, hipStream_t s);
 void ht_launch_get_state(const float *state, float *dst, int nb, int n, hipStream_t s);
 void ht_launch_clear_flags(float *prev_err, int *initializing, int n, hipStream_t s);
-void ht_launch_scratch(const ht_model_dev &M, float *state, const float4 *pts, const int *npts, const float *analysis, const float *cams, const int *flags, int B, hipStream_t s);
-void ht_launch_unibody(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float *rows, const int *nrows, const int *flags, float *scratch, int scratch_stride, int batch, int B, hipStream_t s);
+// the full-reset branch (PoseFromScratch when from_scratch, then n_unibody x UnibodyFit) of the flagged frames, one block per frame (k_reset, csrc/ht_cloud.hip)
+void ht_launch_reset(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float4 *pts, const int *npts, const float *analysis, const float *cams, const int *flags,
+                     int n_unibody, int from_scratch, const ht_params &par, float *rows, int *nrows, float *scratch, int scratch_stride, int batch, int B, hipStream_t s);
 void ht_launch_output(const ht_model_dev &M, const float *hand, const int *npts, int *initializing, int min_point_num, float *poses, int n, hipStream_t s, int raw = 0);
 // ht_segment.hip
 bool ht_segment_supported(int w, int h);

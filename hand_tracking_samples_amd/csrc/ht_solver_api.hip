@@ -94,12 +94,8 @@ static void main_pass(ht_ctx *ctx, int B, hipStream_t s, float *poses_out = null
 static void reset_path(ht_ctx *ctx, const int *flags, int n_unibody, int B, hipStream_t s, hipStream_t prof_stream)
 {
 	ht_prof_scope ps(ctx, "reset_path", prof_stream, true);
-	ht_launch_scratch(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_analysis, ctx->d_cams, flags, B, s);
-	for (int i = 0; i < n_unibody; i++)
-	{
-		ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, flags, 4, 1, 3, ctx->par, ctx->d_rows, ctx->d_nrows, B, s);
-		ht_launch_unibody(ctx->model, ctx->phys, ctx->d_state[1], ctx->d_rows, ctx->d_nrows, flags, ctx->d_scratch, scratch_stride(ctx), ctx->B, B, s);
-	}
+	ht_launch_reset(ctx->model, ctx->phys, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_analysis, ctx->d_cams, flags, n_unibody, 1, ctx->par, ctx->d_rows, ctx->d_nrows, ctx->d_scratch,
+	                scratch_stride(ctx), ctx->B, B, s);
 }
 
 // the whole unit of work on device buffers
