@@ -144,7 +144,7 @@ def test_gpu_config5_full_size_properties(weights):
 @pytest.mark.gpu
 def test_gpu_full_reset_on_clouds_over_the_default_capacity(weights):
     """The full-reset path (PoseFromScratch + three UnibodyFit solves, handtrack.h:705-712) on the close-hand frames: 7723 / 10628 points give
-    1931 / 2657 single-body rows per UnibodyFit solve, more than the proxy body's LDS records hold (1024), so k_unibody streams them from HBM.
+    1931 / 2657 single-body rows per UnibodyFit solve, more than the proxy body's LDS records hold (896), so k_reset streams them from HBM.
     full_reset_on_error = 0 sends every frame down that path; the expected result is the pinned oracle's on the same setting."""
     from hand_tracking_samples_amd import native
     G, (_, model, nb) = GOLD["qvga_close"], CASES["qvga_close"]
@@ -182,7 +182,7 @@ def test_gpu_full_reset_on_clouds_over_the_default_capacity(weights):
 
 @pytest.mark.gpu
 def test_gpu_reset_stages_bit_exact_over_the_default_capacity(weights):
-    """k_scratch and k_unibody on a 10628-point cloud (2657 rows per UnibodyFit solve: the proxy body's records stream from HBM instead of LDS),
+    """k_reset (PoseFromScratch, UnibodyFit) on a 10628-point cloud (2657 rows per UnibodyFit solve: the proxy body's records stream from HBM instead of LDS),
     stage by stage against the oracle on the same inputs: same analysis, same points, same start pose."""
     from hand_tracking_samples_amd import native
     G, (_, model, nb) = GOLD["qvga_close"], CASES["qvga_close"]
