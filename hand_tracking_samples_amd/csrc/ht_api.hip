@@ -352,6 +352,7 @@ extern "C" int ht_destroy(ht_ctx *ctx)
 	if (ctx->ready) (void)hipDeviceSynchronize();      // nothing of this context may still run when its buffers go
 	if (ctx->comm) (void)ht_comm_destroy(ctx);
 	for (void *p : ctx->allocs) (void)hipFree(p);
+	if (ctx->h_nreset) (void)hipHostFree(const_cast<unsigned *>(ctx->h_nreset));
 	for (auto &kv : ctx->prof) for (hipEvent_t e : kv.second.ev) (void)hipEventDestroy(e);
 	for (int i = 0; i < 2; i++) { if (ctx->side[i]) (void)hipStreamDestroy(ctx->side[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
 	if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -624,6 +625,14 @@ int ht_alloc_buffers(ht_ctx *ctx)
 	A(d_npts, B);
 	A(d_state[0], B * nb * HT_STATE_STRIDE); A(d_state[1], B * nb * HT_STATE_STRIDE);
 	A(d_prev_err, B); A(d_initializing, B); A(d_err_old, B); A(d_err_new, B); A(d_flags, B); A(d_nflags, B);
+	A(d_nreset, 2); HIPCHK(ctx, hipMemset(ctx->d_nreset, 0, 2 * sizeof(unsigned)));
+	{
+		void *h = nullptr;
+		HIPCHK(ctx, hipHostMalloc(&h, 2 * sizeof(unsigned), hipHostMallocDefault));
+		ctx->h_nreset = static_cast<volatile unsigned *>(h); ctx->h_nreset[0] = ctx->h_nreset[1] = 0;
+		hipDeviceProp_t prop;
+		if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cu = prop.multiProcessorCount;
+	}
 	A(d_nrows, B);
 	A(d_chamber, B * 5 * nb * HT_ROW); A(d_nchamber, B); A(d_accepted, B);
 	A(d_contacts, B * HT_MAXCONTACT * HT_CONTACT); A(d_ncontacts, B); A(d_epa_ws, ht_contacts_workspace_bytes((int)B)); HIPCHK(ctx, hipMemset(ctx->d_epa_ws, 0, ht_contacts_workspace_bytes((int)B)));

@@ -394,9 +394,9 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 // steps_unibody times UnibodyFit (handtrack.h:451-470: the cloud rows of every 4th point, re-expressed on one proxy body, a single-body solve, the pose moved
 // with it).  As seven launches of one-block-per-flagged-frame kernels the chain paid a cold start per launch (lone blocks: the planes, the body table and the
 // code itself fetched again) while the batch waited for it; the phases share the block's LDS (planes + closest-feature scratch | the solve's records).
-// Two builds: MINB 1 takes the registers the chain wants (297: one block per CU) and is the one an update launches -- few frames reset, and the batch waits for the
-// slowest of them (8 of 1024 frames: 0.48 ms against 0.53); MINB 2 (256 registers, two blocks per CU) serves a launch over ALL frames (1024 frames: 1.13 ms
-// against 2.08; tools/reset_all_frames.py).
+// Two builds: MINB 1 takes the registers the chain wants (297: one block per CU) and is the one an update launches while few frames reset -- the batch waits
+// for the slowest of them (8 of 1024 frames: 0.48 ms against 0.53); MINB 2 (256 registers, two blocks per CU) serves a launch over more frames than the device
+// has CUs (all 1024 frames: 1.13 ms against 2.08; tools/reset_all_frames.py).  The context keeps count of the frames that reset (ht_host.hpp: d_nreset).
 #define RS_THREADS CR_THREADS
 __device__ __forceinline__ v3 G3(const float *p) { return V3(p[0], p[1], p[2]); }
 __device__ __forceinline__ v4 G4(const float *p) { return V4(p[0], p[1], p[2], p[3]); }
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(256) void k_fit_error(ht_model_dev M, const float *
 		}
 		const float e = point_error_sum + bone_error_sum * bone_sum_error_scale;
 		err[b] = e;
-		if (after.mode == 1) { const int f = (after.angles_only || e > after.reset_thr) ? 1 : 0; after.flags[b] = f; after.nflags[b] = !f; }      // handtrack.h:706
+		if (after.mode == 1) { const int f = (after.angles_only || e > after.reset_thr) ? 1 : 0; after.flags[b] = f; after.nflags[b] = !f; if (after.nreset) { if (f) atomicAdd(after.nreset, 1u); if (b == 0) atomicAdd(after.nreset + 1, 1u); } }      // handtrack.h:706
 		if (after.mode == 2)      // handtrack.h:713-731: the CNN-driven pose replaces the tracked one when it explains the frame better for long enough
 		{
 			float pfe = after.prev_err[b];
@@ -812,9 +812,10 @@ void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float
 	hipLaunchKernelGGL(k_cloud_rows, dim3(B, split), dim3(CR_THREADS), ((size_t)M.plane_off[M.nb] + 16) * sizeof(float4), s, M, state, pts, npts, cams, active_flag, stride, use_cam_origin, mode, par.microforce,
 	                   mode == 4 ? sf_ratio : par.physics_weak_force, mode == 4 ? sf_wrist : par.cloudforce_max_point, par.cloudforce_max_sum, par.unibody_force, rows, nrows, rec ? *rec : none, ht_tuning_flags());
 }
-// the full-reset branch for the flagged frames (all frames with flags == nullptr); from_scratch = 0 leaves out PoseFromScratch
+// the full-reset branch for the flagged frames (all frames with flags == nullptr); from_scratch = 0 leaves out PoseFromScratch; many_frames: the caller expects
+// more flagged frames than the device has CUs (the two-blocks-per-CU build)
 void ht_launch_reset(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float4 *pts, const int *npts, const float *analysis, const float *cams, const int *flags,
-                     int n_unibody, int from_scratch, const ht_params &par, float *rows, int *nrows, float *scratch, int scratch_stride, int batch, int B, hipStream_t s)
+                     int n_unibody, int from_scratch, const ht_params &par, float *rows, int *nrows, float *scratch, int scratch_stride, int batch, int B, hipStream_t s, bool many_frames)
 {
 	const size_t cloud = (((size_t)M.plane_off[M.nb] + 16 + 3) & ~(size_t)3) * sizeof(float4) + ((sizeof(closest_lds) + 15) & ~(size_t)15) + HT_MAXNB * BT * sizeof(float);
 	const size_t solve = (size_t)(UB_LDS_ROWS + QUAD_CHAIN_SLACK) * (CREC * sizeof(float) + sizeof(float) + sizeof(unsigned short));
@@ -827,7 +828,7 @@ void ht_launch_reset(const ht_model_dev &M, const ht_physics_dev &ph, float *sta
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_reset<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
 		attr_set[dev] = dyn;
 	}
-	if (flags)
+	if (flags && !many_frames)
 		hipLaunchKernelGGL(k_reset<1>, dim3(B), dim3(RS_THREADS), dyn, s, M, ph, state, pts, npts, analysis, cams, flags, n_unibody, from_scratch, par.unibody_force, rows, nrows, scratch, scratch_stride, batch,
 		                   ht_tuning_flags());
 	else

@@ -1163,7 +1163,7 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 
 size_t ht_contacts_workspace_bytes(int B) { (void)B; return 16; }      // the polytope mesh lives in LDS; the workspace holds the capacity counters (polytope runs cut short, contacts dropped, k_solve's angular overflow)
 
-void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s, bool beside_cloud_rows, int force_kernel)
+void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s, bool beside_cloud_rows, int force_kernel, int few_frames)
 {
 	int *caps = reinterpret_cast<int *>(epa_ws);
 	const int dbg = ht_tuning_flags();
@@ -1197,7 +1197,7 @@ void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftma
 		// as many frames per block as the LDS holds beside the padded vertex copy, the scan list and the waves' polytope areas (4 for the 17-bone hand)
 		const int nvp = M.cvert_off[M.nb];
 		const size_t fixed = (size_t)nvp * sizeof(float4) + sizeof(co_block) + (size_t)CO_OWN * 64 * 2 * (sizeof(co_req) + sizeof(int)) + CO_EPAQ * sizeof(co_job) + CO_NW * gjk_wave_stride();
-		int nfr = CO_MAXF;
+		int nfr = few_frames ? 1 : CO_MAXF;      // few_frames: a masked launch that only a handful of frames take (the reset frames' own first step): a block per frame, all waves on it
 		while (nfr > 1 && fixed + nfr * sizeof(co_frame) > 160 * 1024) nfr--;
 		if (B < nfr) nfr = B;
 		const size_t smem = fixed + nfr * sizeof(co_frame);

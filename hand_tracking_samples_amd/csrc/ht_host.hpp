@@ -46,6 +46,11 @@ struct ht_ctx
 	float *d_state[2] = { nullptr, nullptr };      // [B][nb][HT_STATE_STRIDE]: 0 handmodel, 1 othermodel
 	float *d_prev_err = nullptr; int *d_initializing = nullptr;
 	float *d_err_old = nullptr, *d_err_new = nullptr; int *d_flags = nullptr, *d_nflags = nullptr;
+	// How many frames took the full-reset branch so far (device counter, copied to pinned host memory behind every update's reset kernel, never waited for):
+	// an update that follows one with more reset frames than the device has CUs launches the reset branch and those frames' first contact step in their
+	// many-frames organisation (two reset blocks per CU, four frames per contact block) instead of the few-frames one.  A hint only: both are always correct.
+	unsigned *d_nreset = nullptr; volatile unsigned *h_nreset = nullptr;      // [2]: frames that reset, updates that counted them
+	unsigned nreset_seen[2] = { 0, 0 }; bool many_reset = false; int n_cu = 256;
 	float *d_rows = nullptr; int *d_nrows = nullptr;            // cloud rows [B][pts_cap][HT_ROW] in the reference's layout (stage calls, UnibodyFit, caller-built rows)
 	unsigned char *d_rowbody = nullptr;                          // [B][pts_cap] body of every cloud row whose solver record k_cloud_rows wrote into d_scratch
 	float *d_chamber = nullptr; int *d_nchamber = nullptr;      // [B][5*nb][HT_ROW]

@@ -67,7 +67,7 @@ static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int 
 		if (par) fork1(ctx, s, side);
 		const cloud_records cr = cloud_rec(ctx);
 		if (cloud) { ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, active, 4, 1, 2, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[side] : s, 0.0f, 0.0f, &cr); }
-		if (coll && !(first_contacts_done && st == from_step)) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, active, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, false, ctx->contact_kernel); }
+		if (coll && !(first_contacts_done && st == from_step)) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, active, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, false, ctx->contact_kernel, active && active == ctx->d_flags && !ctx->many_reset); }
 		if (par) join1(ctx, s, side);
 		ht_prof_scope ps(ctx, prof ? "solve" : nullptr, s);
 		solve_step(ctx, 1, nullptr, nullptr, cloud, coll, active, angles, st < p.steps_palmangle ? 10000.0f : 0.0f, rays, 1, 1, B, s, shared_gpu);
@@ -91,11 +91,11 @@ static void main_pass(ht_ctx *ctx, int B, hipStream_t s, float *poses_out = null
 	ht_prof_scope ps(ctx, "solve", s);
 	solve_step(ctx, 0, ctx->d_chamber, ctx->d_nchamber, true, coll, nullptr, 0, 0.0f, 0, 0, 0, B, s, false, poses_out, npts);
 }
-static void reset_path(ht_ctx *ctx, const int *flags, int n_unibody, int B, hipStream_t s, hipStream_t prof_stream)
+static void reset_path(ht_ctx *ctx, const int *flags, int n_unibody, int B, hipStream_t s, hipStream_t prof_stream, bool many_frames = false)
 {
 	ht_prof_scope ps(ctx, "reset_path", prof_stream, true);
 	ht_launch_reset(ctx->model, ctx->phys, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_analysis, ctx->d_cams, flags, n_unibody, 1, ctx->par, ctx->d_rows, ctx->d_nrows, ctx->d_scratch,
-	                scratch_stride(ctx), ctx->B, B, s);
+	                scratch_stride(ctx), ctx->B, B, s, many_frames);
 }
 
 // the whole unit of work on device buffers
@@ -168,7 +168,7 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		fork(ctx, s);
 		if (mode == UPD_FULL && !(d_start && !fs)) ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, t);     // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757 (both were just seeded with the same pose otherwise)
 		ht_fit_after dec; memset(&dec, 0, sizeof dec);
-		dec.mode = 1; dec.reset_thr = p.full_reset_on_error; dec.angles_only = p.angles_only; dec.flags = ctx->d_flags; dec.nflags = ctx->d_nflags;
+		dec.mode = 1; dec.reset_thr = p.full_reset_on_error; dec.angles_only = p.angles_only; dec.flags = ctx->d_flags; dec.nflags = ctx->d_nflags; dec.nreset = ctx->d_nreset;
 		ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_old, B, t, &dec);      // with the reset decision (handtrack.h:706)
 	}
 	{
@@ -185,7 +185,16 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		// later than the main stream's full-batch steps plus this one extra step, 4.6 against 4.5 ms.)
 		static const int join_step = ht_tuning_int("HT_RESET_JOIN", 0);      // experiment (-DHT_TUNING): the reset frames take steps [0, join_step) on the side stream
 		fork(ctx, s);
-		reset_path(ctx, ctx->d_flags, p.steps_unibody, B, ctx->side[0], s);
+		{
+			// few or many reset frames (ht_host.hpp: d_nreset): the average over the updates whose counts have arrived since the last look
+			const unsigned frames = ctx->h_nreset[0], updates = ctx->h_nreset[1];
+			if (updates != ctx->nreset_seen[1])
+			{
+				ctx->many_reset = (frames - ctx->nreset_seen[0]) / (updates - ctx->nreset_seen[1]) > (unsigned)ctx->n_cu;
+				ctx->nreset_seen[0] = frames; ctx->nreset_seen[1] = updates;
+			}
+		}
+		reset_path(ctx, ctx->d_flags, p.steps_unibody, B, ctx->side[0], s, ctx->many_reset);
 		if (join_step > 0)
 		{
 			multistep(ctx, B, ctx->side[0], 0, join_step, ctx->d_flags, false, -1, false, true);
@@ -197,6 +206,7 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		{
 		multistep(ctx, B, s, 0, 1, ctx->d_nflags, false, 0, true, true);
 		join(ctx, s, 1);
+		(void)hipMemcpyAsync(const_cast<unsigned *>(ctx->h_nreset), ctx->d_nreset, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->side[0]);      // behind the join: nobody waits for it
 		multistep(ctx, B, s, 0, 1, ctx->d_flags);
 		multistep(ctx, B, s, 1);
 		}
@@ -205,7 +215,7 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 	{
 		if (mode == UPD_FULL) ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, s);     // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757
 		ht_fit_after dec; memset(&dec, 0, sizeof dec);
-		dec.mode = 1; dec.reset_thr = p.full_reset_on_error; dec.angles_only = p.angles_only; dec.flags = ctx->d_flags; dec.nflags = ctx->d_nflags;
+		dec.mode = 1; dec.reset_thr = p.full_reset_on_error; dec.angles_only = p.angles_only; dec.flags = ctx->d_flags; dec.nflags = ctx->d_nflags; dec.nreset = ctx->d_nreset;
 		{ ht_prof_scope ps(ctx, "fit_error", s, true); ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_old, B, s, &dec); }
 		reset_path(ctx, ctx->d_flags, p.steps_unibody, B, s, s);
 		multistep(ctx, B, s);

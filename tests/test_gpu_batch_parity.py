@@ -130,6 +130,32 @@ def test_full_size_batch_properties(weights):
         ctx.close()
 
 
+def test_many_frames_through_the_reset_branch(weights):
+    """How the full-reset branch is launched is a scheduling decision too.  With full_reset_on_error = 0 every frame of a 512-frame batch resets; the
+    context counts them behind each update and, once an update had more reset frames than the device has CUs, launches the branch's many-frames
+    organisation (two k_reset blocks per CU, four frames per contact block in those frames' first step) instead of the few-frames one.  The first
+    update of a context can only take the few-frames one, the third has seen the counts: same inputs, same poses bit for bit."""
+    from hand_tracking_samples_amd import native
+    B = 512
+    d = np.load(os.path.join(HERE, "golden", "frames256.npz"))
+    idx = np.arange(B) % 256
+    depth, cams, start = d["depth"][idx].reshape(B, -1), d["cam"][idx], d["startpose"][idx]
+    ctx = native.Context(ol.MODEL, B)
+    try:
+        ctx.load_weights(weights)
+        ctx.set_params(microforce=3.0, mainthreadpasses=3, full_reset_on_error=0.0)
+        out = []
+        for _ in range(3):
+            ctx.tracker_reset(start)
+            out.append(ctx.update_sync(depth, cams))
+        assert ctx.capacity_events() == (0, 0, 0)
+    finally:
+        ctx.close()
+    assert np.isfinite(out[0]).all()
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
+    assert np.array_equal(out[0][:256], out[0][256:])
+
+
 def test_config4_shard_of_8192_frames(weights):
     """BASELINE configs[3]: one GPU's shard of the 65536-frame job = 8192 independent frames in one call (the 256 bench frames 32 times).
     (1) deterministic, (2) a frame's result does not depend on its slot (all 32 copies agree bit for bit), (3) no capacity of the kernels is
