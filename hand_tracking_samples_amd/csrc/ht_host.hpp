@@ -20,7 +20,7 @@ struct ht_ctx
 	hipStream_t stream = nullptr;
 	hipStream_t last_user_stream = nullptr;         // stream of the latest *_dev call (host-read helpers wait for it too)
 	hipStream_t side[2] = { nullptr, nullptr };     // independent kernels of one fit step (cloud rows, contacts, chamber) run side by side
-	hipEvent_t ev_fork = nullptr, ev_join[2] = { nullptr, nullptr };
+	hipEvent_t ev_fork = nullptr, ev_join[2] = { nullptr, nullptr }, ev_lap = nullptr;
 	ht_params par;
 	ht_physics_dev phys;
 	ht_model_dev model;

@@ -53,7 +53,9 @@ static void join(ht_ctx *ctx, hipStream_t s, int n) { for (int i = 0; i < n; i++
 // HandTracker::MultiStepSim on othermodel (handtrack.h:642-690)
 // `active`: when given, only the frames whose flag is set are touched.  `side`: index of the side stream the cloud rows of a step run on beside the
 // contacts (-1: everything in order on s).  `prof`: bracket the solves for the profile (off for a concurrent second instance).
-static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int to_step = 1 << 30, const int *active = nullptr, bool first_contacts_done = false, int side = 0, bool prof = true, bool shared_gpu = false)
+// `part`: 0 a whole step, 1 only what precedes the solve (cloud rows, contacts), 2 only the solve.
+static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int to_step = 1 << 30, const int *active = nullptr, bool first_contacts_done = false, int side = 0, bool prof = true, bool shared_gpu = false,
+                      int part = 0)
 {
 	const ht_params &p = ctx->par;
 	for (int st = from_step; st < p.steps && st < to_step; st++)
@@ -64,11 +66,15 @@ static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int 
 		const bool coll = ctx->phys.use_collision != 0;
 		static const bool no_side = ht_tuning_env("HT_NO_SIDE");      // timing experiments (-DHT_TUNING builds only)
 		const bool par = side >= 0 && cloud && coll && !ctx->profile_phases && !no_side;
-		if (par) fork1(ctx, s, side);
-		const cloud_records cr = cloud_rec(ctx);
-		if (cloud) { ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, active, 4, 1, 2, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[side] : s, 0.0f, 0.0f, &cr); }
-		if (coll && !(first_contacts_done && st == from_step)) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, active, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, false, ctx->contact_kernel, active && active == ctx->d_flags && !ctx->many_reset); }
-		if (par) join1(ctx, s, side);
+		if (part != 2)
+		{
+			if (par) fork1(ctx, s, side);
+			const cloud_records cr = cloud_rec(ctx);
+			if (cloud) { ht_prof_scope ps(ctx, prof ? "cloud_rows" : nullptr, s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, active, 4, 1, 2, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[side] : s, 0.0f, 0.0f, &cr); }
+			if (coll && !(first_contacts_done && st == from_step)) { ht_prof_scope ps(ctx, prof ? "contacts" : nullptr, s, true); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, active, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, false, ctx->contact_kernel, active && active == ctx->d_flags && !ctx->many_reset); }
+			if (par) join1(ctx, s, side);
+		}
+		if (part == 1) continue;
 		ht_prof_scope ps(ctx, prof ? "solve" : nullptr, s);
 		solve_step(ctx, 1, nullptr, nullptr, cloud, coll, active, angles, st < p.steps_palmangle ? 10000.0f : 0.0f, rays, 1, 1, B, s, shared_gpu);
 	}
@@ -205,10 +211,30 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		else
 		{
 		multistep(ctx, B, s, 0, 1, ctx->d_nflags, false, 0, true, true);
-		join(ctx, s, 1);
-		(void)hipMemcpyAsync(const_cast<unsigned *>(ctx->h_nreset), ctx->d_nreset, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->side[0]);      // behind the join: nobody waits for it
-		multistep(ctx, B, s, 0, 1, ctx->d_flags);
-		multistep(ctx, B, s, 1);
+		static const bool no_lap = ht_tuning_env("HT_NO_STEP1_LAP");      // experiment (-DHT_TUNING)
+		if (p.steps >= 2 && !no_lap)
+		{
+			// The reset frames take their own first step behind the reset kernel on its stream (eight frames: pure latency, 0.38 ms) while the batch prepares
+			// its second step (cloud rows and contacts of the other frames; a frame's rows and contacts are its own).  Then the reset frames' rows for step 1
+			// and ONE solve for all frames.  (The reset frames any further behind the batch was measured and does not pay: DESIGN.md section 4.)
+			// The reset frames' contact blocks go first: each wants a whole CU, and behind the batch's blocks they would wait for one to drain.
+			multistep(ctx, B, ctx->side[0], 0, 1, ctx->d_flags, false, -1, false, false, 1);
+			(void)hipEventRecord(ctx->ev_lap, ctx->side[0]); (void)hipStreamWaitEvent(s, ctx->ev_lap, 0);
+			multistep(ctx, B, ctx->side[0], 0, 1, ctx->d_flags, false, -1, false, false, 2);
+			multistep(ctx, B, s, 1, 2, ctx->d_nflags, false, 1, true, false, 1);
+			join(ctx, s, 1);
+			(void)hipMemcpyAsync(const_cast<unsigned *>(ctx->h_nreset), ctx->d_nreset, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->side[0]);      // behind the join: nobody waits for it
+			multistep(ctx, B, s, 1, 2, ctx->d_flags, false, 1, true, false, 1);
+			multistep(ctx, B, s, 1, 2, nullptr, false, 0, true, false, 2);
+			multistep(ctx, B, s, 2);
+		}
+		else
+		{
+			join(ctx, s, 1);
+			(void)hipMemcpyAsync(const_cast<unsigned *>(ctx->h_nreset), ctx->d_nreset, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->side[0]);      // behind the join: nobody waits for it
+			multistep(ctx, B, s, 0, 1, ctx->d_flags);
+			multistep(ctx, B, s, 1);
+		}
 		}
 	}
 	else
