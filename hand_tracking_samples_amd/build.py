@@ -6,6 +6,7 @@ hipcc cross-compiles without a GPU.  -ffp-contract=off keeps the solver's fp32 e
 reference CPU path (no FMA contraction); divisions and square roots stay correctly rounded (HIP default).
 """
 import os
+import re
 import subprocess
 import sys
 
@@ -53,9 +54,20 @@ def build(force=False, verbose=True):
         jobs.append(([HIPCC] + FLAGS + FILE_FLAGS.get(name, []) + ["-c", src, "-o", obj], obj))
 
     def run(job):
+        # the compiler's per-kernel resource remarks (registers, scratch, LDS) go to build/<file>.usage.txt: resource_usage() below, tests/test_build_resources.py
+        cmd = job[0] + ["-Rpass-analysis=kernel-resource-usage"]
         if verbose:
             print(" ".join(job[0]), flush=True)
-        subprocess.check_call(job[0])
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        remarks = [l for l in r.stderr.splitlines() if "remark:" in l]
+        other = [l for l in r.stderr.splitlines() if "remark:" not in l and not re.match(r"\s*(\d+ \| |\| )", l)]      # without the source lines quoted under the remarks
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr)
+            raise subprocess.CalledProcessError(r.returncode, cmd)
+        if other and verbose:
+            sys.stderr.write("\n".join(other) + "\n")
+        with open(job[1][:-2] + ".usage.txt", "w") as f:
+            f.write("\n".join(remarks) + "\n")
         return job[1]
 
     with ThreadPoolExecutor(max_workers=4) as ex:
@@ -65,6 +77,24 @@ def build(force=False, verbose=True):
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return LIB
+
+
+def resource_usage():
+    """{kernel name (mangled): {"VGPRs": n, "AGPRs": n, "ScratchSize": bytes per lane, "LDS": bytes, "Occupancy": waves per SIMD, ...}} of the last build."""
+    out = {}
+    for f in sorted(os.listdir(OBJDIR)) if os.path.isdir(OBJDIR) else []:
+        if not f.endswith(".usage.txt"):
+            continue
+        cur = None
+        for line in open(os.path.join(OBJDIR, f)):
+            m = re.search(r"remark: Function Name: (\S+)", line)
+            if m:
+                cur = out.setdefault(m.group(1), {})
+                continue
+            m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+            if m and cur is not None:
+                cur[m.group(1).strip().split()[0] if m.group(1).strip() not in ("SGPRs Spill", "VGPRs Spill", "LDS Size") else m.group(1).strip()] = int(m.group(2))
+    return out
 
 
 if __name__ == "__main__":

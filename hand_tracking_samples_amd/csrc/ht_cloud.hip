@@ -402,15 +402,14 @@ __device__ __forceinline__ v3 G3(const float *p) { return V3(p[0], p[1], p[2]); 
 __device__ __forceinline__ v4 G4(const float *p) { return V4(p[0], p[1], p[2], p[3]); }
 __device__ __forceinline__ m3 GM(const float *p) { m3 m; m.x = V3(p[0], p[1], p[2]); m.y = V3(p[3], p[4], p[5]); m.z = V3(p[6], p[7], p[8]); return m; }
 #define UB_LDS_ROWS 896      // rows of the single-body solve kept in LDS (3584 points); 72 KB with sums and chain: two blocks per CU
-template <int MINB> __global__ __launch_bounds__(RS_THREADS, MINB) void k_reset(ht_model_dev M, ht_physics_dev ph, float *state, const float4 *__restrict__ pts, const int *__restrict__ npts,
-                                                      const float *__restrict__ analysis, const float *__restrict__ cams, const int *__restrict__ flags, int n_unibody, int from_scratch,
-                                                      float unibody_force, float *rows, int *nrows, float *scratch, int scratch_stride, int batch, int dbg)
+__device__ __forceinline__ void reset_frame(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float4 *__restrict__ pts, const int *__restrict__ npts,
+                                            const float *__restrict__ analysis, const float *__restrict__ cams, int n_unibody,
+                                            float unibody_force, float *rows, int *nrows, float *scratch, int scratch_stride, int batch, int dbg, const int b)
 {
 	__shared__ float pos[HT_MAXNB][3], q[HT_MAXNB][4];
 	__shared__ float pc[3], res[8];
 	__shared__ float fj[HT_MAXNJ][8], fc[HT_MAXNJ][6];
-	const int b = blockIdx.x, t = threadIdx.x;
-	if (flags && !flags[b]) return;
+	const int t = threadIdx.x;
 	const int nb = M.nb;
 	const int n = npts[b];
 	float *st = state + (size_t)b * nb * HT_STATE_STRIDE;
@@ -424,7 +423,6 @@ template <int MINB> __global__ __launch_bounds__(RS_THREADS, MINB) void k_reset(
 	float *const usum = urow + (UB_LDS_ROWS + QUAD_CHAIN_SLACK) * CREC;
 	unsigned short *const uidx = reinterpret_cast<unsigned short *>(usum + UB_LDS_ROWS + QUAD_CHAIN_SLACK);
 
-	if (from_scratch)
 	{
 		// ---- PoseFromScratch.  Palm ray from the first three landmark rays, inverse-distance weighted centroid of the cloud (handtrack.h:483-490): the weights are
 		// independent per point (256 per pass, one per thread, through LDS); the sums keep the reference's order on thread 0, eight terms read ahead.
@@ -613,6 +611,20 @@ template <int MINB> __global__ __launch_bounds__(RS_THREADS, MINB) void k_reset(
 		__syncthreads();      // the next round's body table reads the pose; its planes overwrite the records
 	}
 }
+// list != null: the frames list[0 .. *nlist) (the decision kernel's list of flagged frames, in no particular order); otherwise all B frames.  A block takes
+// every gridDim.x-th entry: the grid is as large as the device holds blocks at once, not as large as the batch -- a block that finds nothing to do costs a
+// launch of four waves all the same (and this kernel's waves start slowly: 1024 idle blocks cost 70 us, 8192 cost 600).
+template <int MINB> __global__ __launch_bounds__(RS_THREADS, MINB) void k_reset(ht_model_dev M, ht_physics_dev ph, float *state, const float4 *__restrict__ pts, const int *__restrict__ npts,
+                                                                             const float *__restrict__ analysis, const float *__restrict__ cams, const int *__restrict__ list, const int *__restrict__ nlist, int B,
+                                                                             int n_unibody, float unibody_force, float *rows, int *nrows, float *scratch, int scratch_stride, int batch, int dbg)
+{
+	const int n = list ? min(*nlist, B) : B;
+	for (int slot = blockIdx.x; slot < n; slot += gridDim.x)
+	{
+		reset_frame(M, ph, state, pts, npts, analysis, cams, n_unibody, unibody_force, rows, nrows, scratch, scratch_stride, batch, dbg, list ? list[slot] : slot);
+		__syncthreads();
+	}
+}
 
 // ------------------------------------------------------------------------------------------------- k_fit_error
 #ifdef HT_TUNING
@@ -672,7 +684,7 @@ __global__ __launch_bounds__(256) void k_fit_error(ht_model_dev M, const float *
 		}
 		const float e = point_error_sum + bone_error_sum * bone_sum_error_scale;
 		err[b] = e;
-		if (after.mode == 1) { const int f = (after.angles_only || e > after.reset_thr) ? 1 : 0; after.flags[b] = f; after.nflags[b] = !f; if (after.nreset) { if (f) atomicAdd(after.nreset, 1u); if (b == 0) atomicAdd(after.nreset + 1, 1u); } }      // handtrack.h:706
+		if (after.mode == 1) { const int f = (after.angles_only || e > after.reset_thr) ? 1 : 0; after.flags[b] = f; after.nflags[b] = !f; if (f && after.list) { const int k = atomicAdd(after.nlist, 1); if (k < (int)gridDim.x) after.list[k] = b; } if (after.nreset) { if (f) atomicAdd(after.nreset, 1u); if (b == 0) atomicAdd(after.nreset + 1, 1u); } }      // handtrack.h:706
 		if (after.mode == 2)      // handtrack.h:713-731: the CNN-driven pose replaces the tracked one when it explains the frame better for long enough
 		{
 			float pfe = after.prev_err[b];
@@ -812,10 +824,10 @@ void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float
 	hipLaunchKernelGGL(k_cloud_rows, dim3(B, split), dim3(CR_THREADS), ((size_t)M.plane_off[M.nb] + 16) * sizeof(float4), s, M, state, pts, npts, cams, active_flag, stride, use_cam_origin, mode, par.microforce,
 	                   mode == 4 ? sf_ratio : par.physics_weak_force, mode == 4 ? sf_wrist : par.cloudforce_max_point, par.cloudforce_max_sum, par.unibody_force, rows, nrows, rec ? *rec : none, ht_tuning_flags());
 }
-// the full-reset branch for the flagged frames (all frames with flags == nullptr); from_scratch = 0 leaves out PoseFromScratch; many_frames: the caller expects
-// more flagged frames than the device has CUs (the two-blocks-per-CU build)
-void ht_launch_reset(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float4 *pts, const int *npts, const float *analysis, const float *cams, const int *flags,
-                     int n_unibody, int from_scratch, const ht_params &par, float *rows, int *nrows, float *scratch, int scratch_stride, int batch, int B, hipStream_t s, bool many_frames)
+// the full-reset branch for the frames list[0 .. *nlist) (all B frames with list == nullptr); many_frames: the caller expects more of them than the device has CUs
+// (the two-blocks-per-CU build)
+void ht_launch_reset(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float4 *pts, const int *npts, const float *analysis, const float *cams, const int *list, const int *nlist,
+                     int n_unibody, const ht_params &par, float *rows, int *nrows, float *scratch, int scratch_stride, int batch, int B, hipStream_t s, bool many_frames, int n_cu)
 {
 	const size_t cloud = (((size_t)M.plane_off[M.nb] + 16 + 3) & ~(size_t)3) * sizeof(float4) + ((sizeof(closest_lds) + 15) & ~(size_t)15) + HT_MAXNB * BT * sizeof(float);
 	const size_t solve = (size_t)(UB_LDS_ROWS + QUAD_CHAIN_SLACK) * (CREC * sizeof(float) + sizeof(float) + sizeof(unsigned short));
@@ -828,11 +840,13 @@ void ht_launch_reset(const ht_model_dev &M, const ht_physics_dev &ph, float *sta
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_reset<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
 		attr_set[dev] = dyn;
 	}
-	if (flags && !many_frames)
-		hipLaunchKernelGGL(k_reset<1>, dim3(B), dim3(RS_THREADS), dyn, s, M, ph, state, pts, npts, analysis, cams, flags, n_unibody, from_scratch, par.unibody_force, rows, nrows, scratch, scratch_stride, batch,
+	const bool two = !list || many_frames;
+	const int grid = B < (two ? 2 : 1) * n_cu ? B : (two ? 2 : 1) * n_cu;
+	if (!two)
+		hipLaunchKernelGGL(k_reset<1>, dim3(grid), dim3(RS_THREADS), dyn, s, M, ph, state, pts, npts, analysis, cams, list, nlist, B, n_unibody, par.unibody_force, rows, nrows, scratch, scratch_stride, batch,
 		                   ht_tuning_flags());
 	else
-		hipLaunchKernelGGL(k_reset<2>, dim3(B), dim3(RS_THREADS), dyn, s, M, ph, state, pts, npts, analysis, cams, flags, n_unibody, from_scratch, par.unibody_force, rows, nrows, scratch, scratch_stride, batch,
+		hipLaunchKernelGGL(k_reset<2>, dim3(grid), dim3(RS_THREADS), dyn, s, M, ph, state, pts, npts, analysis, cams, list, nlist, B, n_unibody, par.unibody_force, rows, nrows, scratch, scratch_stride, batch,
 		                   ht_tuning_flags());
 }
 void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, int w, int h, float scale, float *err, int B, hipStream_t s, const ht_fit_after *after)

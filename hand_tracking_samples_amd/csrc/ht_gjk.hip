@@ -1197,7 +1197,9 @@ void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftma
 		// as many frames per block as the LDS holds beside the padded vertex copy, the scan list and the waves' polytope areas (4 for the 17-bone hand)
 		const int nvp = M.cvert_off[M.nb];
 		const size_t fixed = (size_t)nvp * sizeof(float4) + sizeof(co_block) + (size_t)CO_OWN * 64 * 2 * (sizeof(co_req) + sizeof(int)) + CO_EPAQ * sizeof(co_job) + CO_NW * gjk_wave_stride();
-		int nfr = few_frames ? 1 : CO_MAXF;      // few_frames: a masked launch that only a handful of frames take (the reset frames' own first step): a block per frame, all waves on it
+		// few_frames: a masked launch that only a handful of frames take (the reset frames' own first step): a block per frame, all waves on it -- while the
+		// batch is small enough that its empty blocks, each of which still asks for a whole CU's LDS, cost less than that gains (1024 frames: four rounds of them)
+		int nfr = few_frames && B <= 2048 ? 1 : CO_MAXF;
 		while (nfr > 1 && fixed + nfr * sizeof(co_frame) > 160 * 1024) nfr--;
 		if (B < nfr) nfr = B;
 		const size_t smem = fixed + nfr * sizeof(co_frame);

@@ -39,7 +39,7 @@ void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float
 struct ht_fit_after
 {
 	int mode;
-	float reset_thr; int angles_only; int *flags, *nflags; unsigned *nreset;      // nreset (may be null): running counts of the frames flagged and of the decisions taken (one per update)
+	float reset_thr; int angles_only; int *flags, *nflags; int *list, *nlist; unsigned *nreset;      // list / nlist (may be null): the flagged frames, appended in no particular order; nreset (may be null): running counts of the frames flagged and of the decisions taken (one per update)
 	float *hand; const float *other; const float *err_old; float *prev_err; int *initializing, *accepted; int nb, min_point_num, always_take_cnn; float accum_thr;
 };
 void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, int w, int h, float scale, float *err, int B, hipStream_t s, const ht_fit_after *after = nullptr);
@@ -50,9 +50,9 @@ void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solv
 void ht_launch_set_pose(float *state, const float *src, int nb, int n, int mode, hipStream_t s);
 void ht_launch_get_state(const float *state, float *dst, int nb, int n, hipStream_t s);
 void ht_launch_clear_flags(float *prev_err, int *initializing, int n, hipStream_t s);
-// the full-reset branch (PoseFromScratch when from_scratch, then n_unibody x UnibodyFit) of the flagged frames, one block per frame (k_reset, csrc/ht_cloud.hip)
-void ht_launch_reset(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float4 *pts, const int *npts, const float *analysis, const float *cams, const int *flags,
-                     int n_unibody, int from_scratch, const ht_params &par, float *rows, int *nrows, float *scratch, int scratch_stride, int batch, int B, hipStream_t s, bool many_frames);
+// the full-reset branch (PoseFromScratch, then n_unibody x UnibodyFit) of the listed frames, one block per frame at a time (k_reset, csrc/ht_cloud.hip)
+void ht_launch_reset(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float4 *pts, const int *npts, const float *analysis, const float *cams, const int *list, const int *nlist,
+                     int n_unibody, const ht_params &par, float *rows, int *nrows, float *scratch, int scratch_stride, int batch, int B, hipStream_t s, bool many_frames, int n_cu);
 void ht_launch_output(const ht_model_dev &M, const float *hand, const int *npts, int *initializing, int min_point_num, float *poses, int n, hipStream_t s, int raw = 0);
 // ht_segment.hip
 bool ht_segment_supported(int w, int h);

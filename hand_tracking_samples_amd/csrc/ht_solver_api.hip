@@ -45,6 +45,26 @@ static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int 
 }
 // Fork/join helpers: the row-producing kernels of one fit step only read the pose, so they run side by side on two extra streams
 // and the solve waits for all of them (each of them is latency-bound on its slowest frame and leaves most of the chip idle).
+// Tuning builds, HT_MARKS=1: events at named points of an update on whichever stream, printed (ms since the first) after the update -- the concurrent streams as
+// they really ran (a kernel trace serialises them).
+#ifdef HT_TUNING
+#include <vector>
+#include <string>
+static std::vector<std::pair<std::string, hipEvent_t>> g_marks;
+static bool marks_on() { static const bool on = getenv("HT_MARKS") != nullptr; return on; }
+static void mark(const char *name, hipStream_t s) { if (!marks_on()) return; hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, s); g_marks.emplace_back(name, e); }
+static void marks_dump()
+{
+	if (!marks_on() || g_marks.empty()) return;
+	(void)hipDeviceSynchronize();
+	for (auto &m : g_marks) { float ms = 0; (void)hipEventElapsedTime(&ms, g_marks[0].second, m.second); fprintf(stderr, "  mark %-28s %8.3f ms\n", m.first.c_str(), ms); }
+	for (auto &m : g_marks) (void)hipEventDestroy(m.second);
+	g_marks.clear();
+}
+#else
+static inline void mark(const char *, hipStream_t) {}
+static inline void marks_dump() {}
+#endif
 static void fork(ht_ctx *ctx, hipStream_t s) { (void)hipEventRecord(ctx->ev_fork, s); for (int i = 0; i < 2; i++) (void)hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0); }
 static void fork1(ht_ctx *ctx, hipStream_t s, int i) { (void)hipEventRecord(ctx->ev_fork, s); (void)hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0); }
 static void join1(ht_ctx *ctx, hipStream_t s, int i) { (void)hipEventRecord(ctx->ev_join[i], ctx->side[i]); (void)hipStreamWaitEvent(s, ctx->ev_join[i], 0); }
@@ -97,11 +117,20 @@ static void main_pass(ht_ctx *ctx, int B, hipStream_t s, float *poses_out = null
 	ht_prof_scope ps(ctx, "solve", s);
 	solve_step(ctx, 0, ctx->d_chamber, ctx->d_nchamber, true, coll, nullptr, 0, 0.0f, 0, 0, 0, B, s, false, poses_out, npts);
 }
-static void reset_path(ht_ctx *ctx, const int *flags, int n_unibody, int B, hipStream_t s, hipStream_t prof_stream, bool many_frames = false)
+// Behind the join of the reset stream, so nobody waits for it: the running counts of reset frames go to the host (ht_host.hpp: d_nreset) and the list of
+// flagged frames is emptied for the next update, whose decision kernel waits for ev_tail.
+static void reset_tail(ht_ctx *ctx)
+{
+	(void)hipMemcpyAsync(const_cast<unsigned *>(ctx->h_nreset), ctx->d_nreset, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->side[0]);
+	(void)hipMemsetAsync(ctx->d_nflist, 0, sizeof(int), ctx->side[0]);
+	(void)hipEventRecord(ctx->ev_tail, ctx->side[0]);
+	ctx->tail_recorded = true;
+}
+static void reset_path(ht_ctx *ctx, bool listed, int n_unibody, int B, hipStream_t s, hipStream_t prof_stream, bool many_frames = false)      // listed: the frames of d_flist; otherwise all
 {
 	ht_prof_scope ps(ctx, "reset_path", prof_stream, true);
-	ht_launch_reset(ctx->model, ctx->phys, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_analysis, ctx->d_cams, flags, n_unibody, 1, ctx->par, ctx->d_rows, ctx->d_nrows, ctx->d_scratch,
-	                scratch_stride(ctx), ctx->B, B, s, many_frames);
+	ht_launch_reset(ctx->model, ctx->phys, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_analysis, ctx->d_cams, listed ? ctx->d_flist : nullptr, listed ? ctx->d_nflist : nullptr, n_unibody, ctx->par,
+	                ctx->d_rows, ctx->d_nrows, ctx->d_scratch, scratch_stride(ctx), ctx->B, B, s, many_frames, ctx->n_cu);
 }
 
 // the whole unit of work on device buffers
@@ -172,9 +201,10 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		// owns whole CUs and the FC layers want one block per CU: beside each other they took 0.78 ms, one after the other 0.46.)
 		hipStream_t t = ctx->side[1];
 		fork(ctx, s);
+		if (ctx->tail_recorded) (void)hipStreamWaitEvent(t, ctx->ev_tail, 0);      // the last update's list of flagged frames has been emptied
 		if (mode == UPD_FULL && !(d_start && !fs)) ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, t);     // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757 (both were just seeded with the same pose otherwise)
 		ht_fit_after dec; memset(&dec, 0, sizeof dec);
-		dec.mode = 1; dec.reset_thr = p.full_reset_on_error; dec.angles_only = p.angles_only; dec.flags = ctx->d_flags; dec.nflags = ctx->d_nflags; dec.nreset = ctx->d_nreset;
+		dec.mode = 1; dec.reset_thr = p.full_reset_on_error; dec.angles_only = p.angles_only; dec.flags = ctx->d_flags; dec.nflags = ctx->d_nflags; dec.list = ctx->d_flist; dec.nlist = ctx->d_nflist; dec.nreset = ctx->d_nreset;
 		ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_old, B, t, &dec);      // with the reset decision (handtrack.h:706)
 	}
 	{
@@ -200,50 +230,65 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 				ctx->nreset_seen[0] = frames; ctx->nreset_seen[1] = updates;
 			}
 		}
-		reset_path(ctx, ctx->d_flags, p.steps_unibody, B, ctx->side[0], s, ctx->many_reset);
+		static const bool no_lap = ht_tuning_env("HT_NO_STEP1_LAP");      // experiment (-DHT_TUNING)
 		if (join_step > 0)
 		{
+			reset_path(ctx, true, p.steps_unibody, B, ctx->side[0], s, ctx->many_reset);
 			multistep(ctx, B, ctx->side[0], 0, join_step, ctx->d_flags, false, -1, false, true);
 			multistep(ctx, B, s, 0, join_step, ctx->d_nflags, false, 1, true, true);
 			join(ctx, s, 1);
+			reset_tail(ctx);
 			multistep(ctx, B, s, join_step);
 		}
-		else
+		else if (p.steps >= 2 && !no_lap)
 		{
-		multistep(ctx, B, s, 0, 1, ctx->d_nflags, false, 0, true, true);
-		static const bool no_lap = ht_tuning_env("HT_NO_STEP1_LAP");      // experiment (-DHT_TUNING)
-		if (p.steps >= 2 && !no_lap)
-		{
-			// The reset frames take their own first step behind the reset kernel on its stream (eight frames: pure latency, 0.38 ms) while the batch prepares
-			// its second step (cloud rows and contacts of the other frames; a frame's rows and contacts are its own).  Then the reset frames' rows for step 1
-			// and ONE solve for all frames.  (The reset frames any further behind the batch was measured and does not pay: DESIGN.md section 4.)
-			// The reset frames' contact blocks go first: each wants a whole CU, and behind the batch's blocks they would wait for one to drain.
-			multistep(ctx, B, ctx->side[0], 0, 1, ctx->d_flags, false, -1, false, false, 1);
-			(void)hipEventRecord(ctx->ev_lap, ctx->side[0]); (void)hipStreamWaitEvent(s, ctx->ev_lap, 0);
-			multistep(ctx, B, ctx->side[0], 0, 1, ctx->d_flags, false, -1, false, false, 2);
-			multistep(ctx, B, s, 1, 2, ctx->d_nflags, false, 1, true, false, 1);
+			// The reset frames' chain -- the reset kernel, then their own first step (eight frames: pure latency) -- is what the batch ends up waiting for, and its
+			// few long blocks must find CUs although the batch's kernels ask for all of them (a cooperative contact block for a whole CU's LDS).  So the chain
+			// stays on THIS stream, where it is dispatched the moment the CNN ends, and the batch's first step goes to the side stream, which only starts
+			// after a cross-queue wait: launched the other way round the reset blocks often found no CU until the batch's contact kernel had finished.
+			// While the reset frames take their first step the batch prepares its second (cloud rows and contacts of the other frames: a frame's rows and
+			// contacts are its own), after the reset frames' contact blocks are in (same reason).  Then the reset frames' rows for step 1 and ONE solve for
+			// all frames.  (The reset frames any further behind the batch was measured and does not pay: DESIGN.md section 4.)
+			hipStream_t u = ctx->side[0];
+			mark("fork", s);
+			reset_path(ctx, true, p.steps_unibody, B, s, s, ctx->many_reset);
+			mark("reset kernel done", s);
+			multistep(ctx, B, u, 0, 1, ctx->d_nflags, false, -1, false, true);
+			mark("batch step 0 done", u);
+			multistep(ctx, B, s, 0, 1, ctx->d_flags, false, -1, true, false, 1);
+			mark("reset frames contacts done", s);
+			(void)hipEventRecord(ctx->ev_lap, s); (void)hipStreamWaitEvent(u, ctx->ev_lap, 0);
+			multistep(ctx, B, s, 0, 1, ctx->d_flags, false, -1, true, false, 2);
+			mark("reset frames step 0 done", s);
+			multistep(ctx, B, u, 1, 2, ctx->d_nflags, false, 1, false, false, 1);
+			mark("batch step 1 rows done", u);
 			join(ctx, s, 1);
-			(void)hipMemcpyAsync(const_cast<unsigned *>(ctx->h_nreset), ctx->d_nreset, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->side[0]);      // behind the join: nobody waits for it
+			reset_tail(ctx);
 			multistep(ctx, B, s, 1, 2, ctx->d_flags, false, 1, true, false, 1);
+			mark("reset frames step 1 rows done", s);
 			multistep(ctx, B, s, 1, 2, nullptr, false, 0, true, false, 2);
+			mark("step 1 done", s);
 			multistep(ctx, B, s, 2);
+			mark("MultiStepSim done", s);
 		}
 		else
 		{
+			reset_path(ctx, true, p.steps_unibody, B, ctx->side[0], s, ctx->many_reset);
+			multistep(ctx, B, s, 0, 1, ctx->d_nflags, false, 0, true, true);
 			join(ctx, s, 1);
-			(void)hipMemcpyAsync(const_cast<unsigned *>(ctx->h_nreset), ctx->d_nreset, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->side[0]);      // behind the join: nobody waits for it
+			reset_tail(ctx);
 			multistep(ctx, B, s, 0, 1, ctx->d_flags);
 			multistep(ctx, B, s, 1);
-		}
 		}
 	}
 	else
 	{
 		if (mode == UPD_FULL) ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, s);     // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757
 		ht_fit_after dec; memset(&dec, 0, sizeof dec);
-		dec.mode = 1; dec.reset_thr = p.full_reset_on_error; dec.angles_only = p.angles_only; dec.flags = ctx->d_flags; dec.nflags = ctx->d_nflags; dec.nreset = ctx->d_nreset;
+		dec.mode = 1; dec.reset_thr = p.full_reset_on_error; dec.angles_only = p.angles_only; dec.flags = ctx->d_flags; dec.nflags = ctx->d_nflags; dec.list = ctx->d_flist; dec.nlist = ctx->d_nflist; dec.nreset = ctx->d_nreset;
 		{ ht_prof_scope ps(ctx, "fit_error", s, true); ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_old, B, s, &dec); }
-		reset_path(ctx, ctx->d_flags, p.steps_unibody, B, s, s);
+		reset_path(ctx, true, p.steps_unibody, B, s, s);
+		(void)hipMemsetAsync(ctx->d_nflist, 0, sizeof(int), s);
 		multistep(ctx, B, s);
 	}
 	{
@@ -259,6 +304,8 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 	const int passes = p.angles_only ? 0 : p.mainthreadpasses;
 	for (int i = 0; i < passes; i++) main_pass(ctx, B, s, i + 1 == passes ? d_poses_out : nullptr);      // the last pass's solve writes the poses
 	if (passes < 1) ht_launch_output(ctx->model, ctx->d_state[0], p.subsample_voxel ? ctx->d_nptsv : ctx->d_npts, ctx->d_initializing, p.min_point_num, d_poses_out, B, s);
+	mark("update done", s);
+	marks_dump();
 	return HT_OK;
 }
 
@@ -559,7 +606,7 @@ extern "C" int ht_stage_scratch_unibody(ht_ctx *ctx, const float *analysis, int 
 	if (!analysis) return HT_ERR_ARG;
 	hipStream_t s = ctx->stream;
 	HIPCHK(ctx, hipMemcpyAsync(ctx->d_analysis, analysis, (size_t)B * HT_ANALYSIS * sizeof(float), hipMemcpyHostToDevice, s));
-	reset_path(ctx, nullptr, n_unibody, B, s, s);
+	reset_path(ctx, false, n_unibody, B, s, s);
 	HIPCHK(ctx, hipStreamSynchronize(s));
 	HIPCHK(ctx, hipGetLastError());
 	return HT_OK;
