@@ -1,0 +1,50 @@
+"""What the compiler made of the kernels whose speed hangs on a resource figure (hipcc's kernel-resource-usage remarks, kept by the build under
+hand_tracking_samples_amd/build/*.usage.txt).  No GPU needed: hipcc cross-compiles."""
+import pytest
+
+from hand_tracking_samples_amd import build
+
+
+@pytest.fixture(scope="module")
+def usage():
+    u = build.resource_usage()
+    if not u:
+        build.build(force=True, verbose=False)
+        u = build.resource_usage()
+    assert u, "no resource remarks: did the build run?"
+    return u
+
+
+def _one(usage, *parts):
+    hits = [k for k in usage if all(p in k for p in parts)]
+    assert len(hits) == 1, (parts, hits)
+    return usage[hits[0]]
+
+
+def test_solver_builds(usage):
+    """k_solve: no scratch memory in any build; the small build is exactly 40 LDS allocation units (eight frames per CU), the one a 1024-frame batch takes
+    fits four times into a CU's 160 KB."""
+    small, only = _one(usage, "k_solveILi34ELi584ELi84ELi0E"), _one(usage, "k_solveILi66ELi1024ELi126ELi1024E")
+    for k in usage:
+        if "k_solve" in k:
+            assert usage[k]["ScratchSize"] == 0 and usage[k]["VGPRs Spill"] == 0, k
+    assert small["LDS Size"] == 20480
+    assert 4 * only["LDS Size"] <= 160 * 1024
+    assert small["VGPRs"] <= 168 and only["VGPRs"] <= 168      # three waves of one SIMD must fit beside each other in the small build
+
+
+def test_reset_kernel(usage):
+    """k_reset: the build an update launches holds everything in registers (no private segment); the two-blocks-per-CU build stays within 256."""
+    few, many = _one(usage, "k_resetILi1E"), _one(usage, "k_resetILi2E")
+    assert few["ScratchSize"] == 0
+    assert many["VGPRs"] + many["AGPRs"] <= 256 and many["Occupancy"] >= 2
+
+
+def test_closest_feature_and_cnn_kernels(usage):
+    """Four blocks per CU for the closest-feature kernels (128 VGPRs at most, no scratch); the CNN's matrix kernels without scratch."""
+    for name in ("k_cloud_rows", "k_fit_error"):
+        k = _one(usage, name)
+        assert k["ScratchSize"] == 0 and k["VGPRs"] <= 128, name
+    for k in usage:
+        if any(n in k for n in ("k_conv1", "k_conv2", "k_fcI", "k_fc144")):
+            assert usage[k]["ScratchSize"] == 0, k
