@@ -93,6 +93,7 @@ static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int 
 			if (cloud) { ht_prof_scope ps(ctx, prof ? "cloud_rows" : nullptr, s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, active, 4, 1, 2, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[side] : s, 0.0f, 0.0f, &cr); }
 			if (coll && !(first_contacts_done && st == from_step)) { ht_prof_scope ps(ctx, prof ? "contacts" : nullptr, s, true); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, active, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, false, ctx->contact_kernel, active && active == ctx->d_flags && !ctx->many_reset); }
 			if (par) join1(ctx, s, side);
+			if (part == 0 && !active) mark("  step: rows done", s);
 		}
 		if (part == 1) continue;
 		ht_prof_scope ps(ctx, prof ? "solve" : nullptr, s);
@@ -113,6 +114,8 @@ static void main_pass(ht_ctx *ctx, int B, hipStream_t s, float *poses_out = null
 	const cloud_records cr = cloud_rec(ctx);
 	{ ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[0], pts, npts, ctx->d_cams, nullptr, 1, 0, 1, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[0] : s, 0.0f, 0.0f, &cr); }
 	if (coll) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[0], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, par, ctx->contact_kernel); }
+	mark("  pass: contacts done", s);
+	if (par) { mark("  pass: cloud rows done", ctx->side[0]); mark("  pass: chamber done", ctx->side[1]); }
 	if (par) join(ctx, s, 2);
 	ht_prof_scope ps(ctx, "solve", s);
 	solve_step(ctx, 0, ctx->d_chamber, ctx->d_nchamber, true, coll, nullptr, 0, 0.0f, 0, 0, 0, B, s, false, poses_out, npts);
@@ -302,7 +305,8 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 	}
 	if (mode != UPD_FULL) { ht_launch_output(ctx->model, ctx->d_state[1], ctx->d_npts, ctx->d_initializing, p.min_point_num, d_poses_out, B, s, 1); return HT_OK; }      // othermodel.GetPose()
 	const int passes = p.angles_only ? 0 : p.mainthreadpasses;
-	for (int i = 0; i < passes; i++) main_pass(ctx, B, s, i + 1 == passes ? d_poses_out : nullptr);      // the last pass's solve writes the poses
+	mark("accept done", s);
+	for (int i = 0; i < passes; i++) { main_pass(ctx, B, s, i + 1 == passes ? d_poses_out : nullptr); mark("pass done", s); }      // the last pass's solve writes the poses
 	if (passes < 1) ht_launch_output(ctx->model, ctx->d_state[0], p.subsample_voxel ? ctx->d_nptsv : ctx->d_npts, ctx->d_initializing, p.min_point_num, d_poses_out, B, s);
 	mark("update done", s);
 	marks_dump();
