@@ -180,7 +180,6 @@ extern "C" int ht_create(const char *model_path, int max_batch, int device, ht_c
 	for (int i = 0; i < 2; i++) { HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking)); HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming)); }
 	HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
 	HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_lap, hipEventDisableTiming));
-	HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_tail, hipEventDisableTiming));
 	// model_path == NULL: a context that only evaluates / trains the CNN (what a stand-alone CNN object of the reference is, cnn.h:100-605)
 	int r = model_path ? load_model(ctx, model_path) : HT_OK;
 	if (r) return r;
@@ -359,7 +358,6 @@ extern "C" int ht_destroy(ht_ctx *ctx)
 	for (int i = 0; i < 2; i++) { if (ctx->side[i]) (void)hipStreamDestroy(ctx->side[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
 	if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
 	if (ctx->ev_lap) (void)hipEventDestroy(ctx->ev_lap);
-	if (ctx->ev_tail) (void)hipEventDestroy(ctx->ev_tail);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 	return HT_OK;

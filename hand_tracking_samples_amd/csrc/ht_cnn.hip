@@ -23,6 +23,7 @@ __global__ __launch_bounds__(256) void k_prepare(const uint16_t *__restrict__ de
 	const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	const float *cam = cams + (size_t)b * HT_CAM;
 	if (x.cams_out && t < HT_CAM) x.cams_out[(size_t)b * HT_CAM + t] = cam[t];
+	if (x.zero && b == 0 && t == 0) *x.zero = 0;
 	if (x.start && t < x.nb)      // ht_tracker_reset for this frame: both models take the start pose, momenta and flags are cleared
 	{
 		const float *o = x.start + ((size_t)b * x.nb + t) * HT_POSE;
@@ -662,7 +663,7 @@ void ht_launch_voxel(const float4 *all, const int *nall, int cap, float size, in
 }
 void ht_launch_prepare(const uint16_t *depth, const float *cams, float drangey, int fraction, float *cnn_in, float4 *pts, int *npts, int cap, int B, hipStream_t s, const ht_prepare_extra *extra)
 {
-	ht_prepare_extra x = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0 };
+	ht_prepare_extra x = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr };
 	if (extra) x = *extra;
 	hipLaunchKernelGGL(k_prepare, dim3(B), dim3(256), 0, s, depth, cams, drangey, fraction, cnn_in, pts, npts, cap, x);
 }

@@ -140,7 +140,7 @@ struct ht_cnn_weights { const float *W1, *B1, *W2p, *B2, *W3, *B3, *W4, *B4; };
 // ---- kernel launchers (defined in the .hip files) ----
 // what k_prepare can do on the side for the frame it has in hand anyway (each replaces a tiny kernel and its dependent launch gap at the head of an update):
 // copy the caller's camera into the context's array, seed both models of the tracker from a start pose (pose taken, momenta zeroed), clear its flags
-struct ht_prepare_extra { float *cams_out; float *state0, *state1; const float *start; float *prev_err; int *initializing; int nb; };
+struct ht_prepare_extra { float *cams_out; float *state0, *state1; const float *start; float *prev_err; int *initializing; int nb; int *zero; };      // zero: an int the kernel clears (the update's list of flagged frames starts empty)
 void ht_launch_prepare(const uint16_t *depth, const float *cams, float drangey, int fraction, float *cnn_in, float4 *pts, int *npts, int cap, int B, hipStream_t s, const ht_prepare_extra *extra = nullptr);
 void ht_launch_voxel(const float4 *all, const int *nall, int cap, float size, int min_count, float4 *out, int *nout, int B, hipStream_t s);
 void ht_launch_prepare_frame(const uint16_t *depth, const float *cams, int w, int h, float drangey, int fraction, float4 *pts, int *npts, int *overflow, int cap, int B, hipStream_t s);

@@ -20,7 +20,7 @@ struct ht_ctx
 	hipStream_t stream = nullptr;
 	hipStream_t last_user_stream = nullptr;         // stream of the latest *_dev call (host-read helpers wait for it too)
 	hipStream_t side[2] = { nullptr, nullptr };     // independent kernels of one fit step (cloud rows, contacts, chamber) run side by side
-	hipEvent_t ev_fork = nullptr, ev_join[2] = { nullptr, nullptr }, ev_lap = nullptr, ev_tail = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_join[2] = { nullptr, nullptr }, ev_lap = nullptr;
 	ht_params par;
 	ht_physics_dev phys;
 	ht_model_dev model;
@@ -46,12 +46,12 @@ struct ht_ctx
 	float *d_state[2] = { nullptr, nullptr };      // [B][nb][HT_STATE_STRIDE]: 0 handmodel, 1 othermodel
 	float *d_prev_err = nullptr; int *d_initializing = nullptr;
 	float *d_err_old = nullptr, *d_err_new = nullptr; int *d_flags = nullptr, *d_nflags = nullptr;
-	int *d_flist = nullptr, *d_nflist = nullptr;      // the flagged frames of an update as a list [B] and its length (zeroed behind each update; ev_lap orders that before the next decision)
+	int *d_flist = nullptr, *d_nflist = nullptr;      // the flagged frames of an update as a list [B] and its length (k_prepare clears it)
 	// How many frames took the full-reset branch so far (device counter, copied to pinned host memory behind every update's reset kernel, never waited for):
 	// an update that follows one with more reset frames than the device has CUs launches the reset branch and those frames' first contact step in their
 	// many-frames organisation (two reset blocks per CU, four frames per contact block) instead of the few-frames one.  A hint only: both are always correct.
 	unsigned *d_nreset = nullptr; volatile unsigned *h_nreset = nullptr;      // [2]: frames that reset, updates that counted them
-	unsigned nreset_seen[2] = { 0, 0 }; bool many_reset = false, tail_recorded = false; int n_cu = 256;
+	unsigned nreset_seen[2] = { 0, 0 }; bool many_reset = false, tail_pending = false; int n_cu = 256;
 	float *d_rows = nullptr; int *d_nrows = nullptr;            // cloud rows [B][pts_cap][HT_ROW] in the reference's layout (stage calls, UnibodyFit, caller-built rows)
 	unsigned char *d_rowbody = nullptr;                          // [B][pts_cap] body of every cloud row whose solver record k_cloud_rows wrote into d_scratch
 	float *d_chamber = nullptr; int *d_nchamber = nullptr;      // [B][5*nb][HT_ROW]

@@ -120,15 +120,15 @@ static void main_pass(ht_ctx *ctx, int B, hipStream_t s, float *poses_out = null
 	ht_prof_scope ps(ctx, "solve", s);
 	solve_step(ctx, 0, ctx->d_chamber, ctx->d_nchamber, true, coll, nullptr, 0, 0.0f, 0, 0, 0, B, s, false, poses_out, npts);
 }
-// Behind the join of the reset stream, so nobody waits for it: the running counts of reset frames go to the host (ht_host.hpp: d_nreset) and the list of
-// flagged frames is emptied for the next update, whose decision kernel waits for ev_tail.
+// Behind the join of the side stream, so nothing of the step waits for it: the running counts of reset frames go to the host (ht_host.hpp: d_nreset).  The
+// update's stream picks the copy up again at its very end (reset_tail_join: long finished by then) -- every stream of an update has to come back to the
+// caller's, or the update could not be captured into a HIP graph.
 static void reset_tail(ht_ctx *ctx)
 {
 	(void)hipMemcpyAsync(const_cast<unsigned *>(ctx->h_nreset), ctx->d_nreset, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->side[0]);
-	(void)hipMemsetAsync(ctx->d_nflist, 0, sizeof(int), ctx->side[0]);
-	(void)hipEventRecord(ctx->ev_tail, ctx->side[0]);
-	ctx->tail_recorded = true;
+	ctx->tail_pending = true;
 }
+static void reset_tail_join(ht_ctx *ctx, hipStream_t s) { if (ctx->tail_pending) { join(ctx, s, 1); ctx->tail_pending = false; } }
 static void reset_path(ht_ctx *ctx, bool listed, int n_unibody, int B, hipStream_t s, hipStream_t prof_stream, bool many_frames = false)      // listed: the frames of d_flist; otherwise all
 {
 	ht_prof_scope ps(ctx, "reset_path", prof_stream, true);
@@ -168,7 +168,7 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		img_cams = ctx->d_frame_cams;
 	}
 	// 64x64 tiles: the camera copy and the re-seeding of the trackers ride on k_prepare (below); full-size frames keep their own small kernels
-	ht_prepare_extra px = { (!fs && d_cams != ctx->d_cams) ? ctx->d_cams : nullptr, ctx->d_state[0], ctx->d_state[1], fs ? nullptr : d_start, ctx->d_prev_err, ctx->d_initializing, nb };
+	ht_prepare_extra px = { (!fs && d_cams != ctx->d_cams) ? ctx->d_cams : nullptr, ctx->d_state[0], ctx->d_state[1], fs ? nullptr : d_start, ctx->d_prev_err, ctx->d_initializing, nb, ctx->d_nflist };
 	if (d_start && fs)
 	{
 		ht_launch_set_pose(ctx->d_state[0], d_start, nb, B, 1, s);
@@ -179,7 +179,8 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		ht_prof_scope ps(ctx, "prepare", s, true);
 		if (fs)
 		{
-			ht_launch_prepare(ctx->d_seg_tiles, ctx->d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, nullptr, nullptr, ctx->model.pts_cap, B, s);
+			const ht_prepare_extra pz = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, ctx->d_nflist };
+			ht_launch_prepare(ctx->d_seg_tiles, ctx->d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, nullptr, nullptr, ctx->model.pts_cap, B, s, &pz);
 			ht_launch_prepare_frame(d_depth, img_cams, fs->w, fs->h, p.drangey, p.subsample_fraction, ctx->d_pts, ctx->d_npts, ctx->d_overflow, ctx->model.pts_cap, B, s);
 		}
 		else ht_launch_prepare(d_depth, d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, ctx->d_pts, ctx->d_npts, ctx->model.pts_cap, B, s, &px);
@@ -204,7 +205,6 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		// owns whole CUs and the FC layers want one block per CU: beside each other they took 0.78 ms, one after the other 0.46.)
 		hipStream_t t = ctx->side[1];
 		fork(ctx, s);
-		if (ctx->tail_recorded) (void)hipStreamWaitEvent(t, ctx->ev_tail, 0);      // the last update's list of flagged frames has been emptied
 		if (mode == UPD_FULL && !(d_start && !fs)) ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, t);     // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757 (both were just seeded with the same pose otherwise)
 		ht_fit_after dec; memset(&dec, 0, sizeof dec);
 		dec.mode = 1; dec.reset_thr = p.full_reset_on_error; dec.angles_only = p.angles_only; dec.flags = ctx->d_flags; dec.nflags = ctx->d_nflags; dec.list = ctx->d_flist; dec.nlist = ctx->d_nflist; dec.nreset = ctx->d_nreset;
@@ -263,7 +263,7 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 			(void)hipEventRecord(ctx->ev_lap, s); (void)hipStreamWaitEvent(u, ctx->ev_lap, 0);
 			multistep(ctx, B, s, 0, 1, ctx->d_flags, false, -1, true, false, 2);
 			mark("reset frames step 0 done", s);
-			multistep(ctx, B, u, 1, 2, ctx->d_nflags, false, 1, false, false, 1);
+			multistep(ctx, B, u, 1, 2, ctx->d_nflags, false, -1, false, false, 1);      // in order on the side stream: there is time (0.76 against 0.82 ms), and a fork out of a forked stream does not survive a HIP graph capture
 			mark("batch step 1 rows done", u);
 			join(ctx, s, 1);
 			reset_tail(ctx);
@@ -291,7 +291,6 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		dec.mode = 1; dec.reset_thr = p.full_reset_on_error; dec.angles_only = p.angles_only; dec.flags = ctx->d_flags; dec.nflags = ctx->d_nflags; dec.list = ctx->d_flist; dec.nlist = ctx->d_nflist; dec.nreset = ctx->d_nreset;
 		{ ht_prof_scope ps(ctx, "fit_error", s, true); ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_old, B, s, &dec); }
 		reset_path(ctx, true, p.steps_unibody, B, s, s);
-		(void)hipMemsetAsync(ctx->d_nflist, 0, sizeof(int), s);
 		multistep(ctx, B, s);
 	}
 	{
@@ -303,11 +302,12 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		ht_prof_scope ps(ctx, "fit_error", s, true);
 		ht_launch_fit_error(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_new, B, s, &acc);
 	}
-	if (mode != UPD_FULL) { ht_launch_output(ctx->model, ctx->d_state[1], ctx->d_npts, ctx->d_initializing, p.min_point_num, d_poses_out, B, s, 1); return HT_OK; }      // othermodel.GetPose()
+	if (mode != UPD_FULL) { ht_launch_output(ctx->model, ctx->d_state[1], ctx->d_npts, ctx->d_initializing, p.min_point_num, d_poses_out, B, s, 1); reset_tail_join(ctx, s); return HT_OK; }      // othermodel.GetPose()
 	const int passes = p.angles_only ? 0 : p.mainthreadpasses;
 	mark("accept done", s);
 	for (int i = 0; i < passes; i++) { main_pass(ctx, B, s, i + 1 == passes ? d_poses_out : nullptr); mark("pass done", s); }      // the last pass's solve writes the poses
 	if (passes < 1) ht_launch_output(ctx->model, ctx->d_state[0], p.subsample_voxel ? ctx->d_nptsv : ctx->d_npts, ctx->d_initializing, p.min_point_num, d_poses_out, B, s);
+	reset_tail_join(ctx, s);
 	mark("update done", s);
 	marks_dump();
 	return HT_OK;

@@ -129,7 +129,9 @@ int ht_cnn_eval_sized_dev(ht_ctx *ctx, int side, const float *d_in, float *d_out
  *                     :283-284), cams [B][12], poses_out [B][nb][7] = GetPoseUser() (physmodel.h:434).
  *                     cnn_out (optional, [B][2304]) receives HandTracker::cnn_output.
  * ht_update_dev       the same on device buffers, asynchronous on `stream`; d_start_poses (optional, [B][nb][7]) re-seeds every
- *                     tracker slot before the update (independent-frame batches, BASELINE config 3). */
+ *                     tracker slot before the update (independent-frame batches, BASELINE config 3).  The call only enqueues (kernels, two
+ *                     side streams forked off `stream` and joined back into it, one 8-byte copy to pinned host memory): it can be captured
+ *                     into a HIP graph and replayed (tests/test_gpu_graph.py). */
 int ht_tracker_reset(ht_ctx *ctx, int first, int n, const float *poses);
 int ht_get_state(ht_ctx *ctx, int which, int first, int n, float *state);
 int ht_set_state(ht_ctx *ctx, int which, int first, int n, const float *state);
