@@ -93,10 +93,15 @@ __device__ __forceinline__ float quad_row_step(quad_body &B, const float4 a, con
 	const float s = dpp<QP_PREV>(t) + p;                                 // lane 2: (p0 + p1) + p2 = vn / effective mass
 	const float x = -(POST ? a.y : a.x) - dpp<QP_PREV>(s);               // lane 3: (-targetspeed - vn) / effective mass
 	const float impulse = clamp_med3(x, a.z - sum, a.w - sum);           // lane 3: a.z = fmin*dt, a.w = fmax*dt
-	const float bi = dpp<QP_BC3>(impulse);
-	B.l = __fmaf_rn(a.w, bi, B.l);                                       // P += n * impulse
-	B.av = __fmaf_rn(a.y, bi, B.av);                                     // L += g * impulse
-	return sum + bi;      // the same value on all four lanes (they read the same sum): the quad's four writes to one address agree
+	// lane 3's impulse to all four lanes: the broadcast rides on the three instructions that use it (a DPP operand each) instead of a move of its own; the two
+	// wait states between the clamp and the first DPP read of its result are spelled out, the compiler does not look into the block
+	float ns;
+	asm volatile("s_nop 1\n\t"
+	             "v_fmac_f32_dpp %0, %3, %4 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      // P += n * impulse
+	             "v_fmac_f32_dpp %1, %3, %5 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      // L += g * impulse
+	             "v_add_f32_dpp %2, %3, %6 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1"             // the row's new impulse sum
+	             : "+v"(B.l), "+v"(B.av), "=&v"(ns) : "v"(impulse), "v"(a.w), "v"(a.y), "v"(sum));
+	return ns;      // the same value on all four lanes (they read the same sum): the quad's four writes to one address agree
 }
 // Applies rows [0, cnt) of one chain in order.  The records of a frame lie where their producers wrote them (a cloud row's record at its point's index:
 // k_cloud_rows writes it; the other single-body rows behind them: k_solve's prologue), and a chain is a list of record indices: recs = the frame's first
