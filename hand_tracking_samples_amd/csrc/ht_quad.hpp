@@ -20,6 +20,9 @@ __device__ __forceinline__ float pair_swap(float v)
 	t = __builtin_amdgcn_update_dpp(t, __float_as_int(v), DPP_ROW_SHR4, 0xF, 0xA, false);           // quads 1 and 3 read lane-4
 	return __int_as_float(t);
 }
+// The other quad's value of something all four lanes of a quad agree on (a quad's reduced sum): the mirror image within the pair's eight lanes is a lane of the
+// other quad -- one DPP operand of the instruction that uses it, where pair_swap is a zero and two masked moves.
+__device__ __forceinline__ float pair_other_uniform(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141 /* row_half_mirror */, 0xF, 0xF, true)); }
 // max(lo, min(hi, x)) for lo <= hi in one instruction; equals the reference's std::min/std::max pair except for the sign of a zero
 // result and NaN operands (a NaN impulse ends in the SanityCheck reset either way)
 __device__ __forceinline__ float clamp_med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }

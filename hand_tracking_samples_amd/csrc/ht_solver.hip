@@ -870,7 +870,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			auto row = [&](float n, float g, float bq, float ts, float fmn, float fmx, float rinv, float isum) -> float {
 				const float p = __fmaf_rn(bq, av, (n * r.minv) * l);                                      // this side's share of vn, component c
 				const float sp = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);
-				const float vn = sp + pair_swap(sp);                                                       // v1.n - v0.n
+				const float vn = sp + pair_other_uniform(sp);                                              // v1.n - v0.n
 				float impulse = (-ts - vn) * rinv;
 				impulse = clamp_med3(impulse, fmn - isum, fmx - isum);
 				l = __fmaf_rn(n, impulse, l);
@@ -938,7 +938,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			const float gain = r.gain;                                                                     // 0 for a disabled row (physics.h:252), decided when the record was written
 			const float p = r.ba * av;
 			const float sp = (dpp<QP_BC0>(p) + dpp<QP_BC1>(p)) + dpp<QP_BC2>(p);                           // this side's signed spin about the axis
-			const float currentspin = sp + pair_swap(sp);                                                  // spin1 - spin0
+			const float currentspin = sp + pair_other_uniform(sp);                                         // spin1 - spin0
 			float dtorque = (r.ts - currentspin) * gain;
 			dtorque = clamp_med3(dtorque, r.mn - r.torque, r.mx - r.torque);
 			av = __fmaf_rn(axs, dtorque, av);                                                              // rb0: a - axis*dtorque, rb1: a + axis*dtorque
