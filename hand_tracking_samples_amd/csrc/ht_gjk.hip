@@ -1128,6 +1128,13 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 		const int b = co_frame_of(blockIdx.x, wave, gridDim.x);
 		const bool live = b < B && !(active_flag && !active_flag[b]);
 		const int np = F.npool;
+		// a sample's place = how many counting samples have a smaller key.  The keys are laid out once as a dense array (a sample that does not count: the
+		// largest int) in the scan list's area, which nothing uses any more, so that a lane reads four per LDS access instead of key and flag of one sample
+		static_assert(CO_MAXF * GJK_POOL * sizeof(int) <= (size_t)CO_OWN * 64 * 2 * sizeof(co_req), "the key arrays of a block's frames fit the scan list's area");
+		int *const kk = reinterpret_cast<int *>(L.req) + wave * GJK_POOL;
+		for (int e = lane; e < ((np + 3) & ~3); e += 64) kk[e] = (e < np && F.pool[e].flag != 0) ? F.pool[e].key : 0x7fffffff;
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+		__builtin_amdgcn_wave_barrier();
 		int total = 0;
 		for (int e0 = 0; e0 < np; e0 += 64)
 		{
@@ -1138,7 +1145,7 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 			{
 				const gjk_sample S = F.pool[e];
 				int rank = 0;
-				for (int o = 0; o < np; o++) rank += (F.pool[o].flag != 0 && F.pool[o].key < S.key) ? 1 : 0;
+				for (int o = 0; o < np; o += 4) { const int4 k4 = *reinterpret_cast<const int4 *>(kk + o); rank += (k4.x < S.key ? 1 : 0) + (k4.y < S.key ? 1 : 0) + (k4.z < S.key ? 1 : 0) + (k4.w < S.key ? 1 : 0); }
 				if (live && rank < HT_MAXCONTACT)
 				{
 					const int c = S.key >> 3;
