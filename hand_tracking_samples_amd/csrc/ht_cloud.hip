@@ -170,30 +170,37 @@ __device__ __forceinline__ void closest_chunk(const ht_model_dev &M, const float
 			// this lane's faces g, g + 4, ...: the first is taken as it is (std::max_element starts from it), the others replace it when strictly larger; four are
 			// read ahead of their use.  When every pair of the wave sits on a body with the model's largest face count (one count for all bodies of the hand) the
 			// faces up to the last round need no range test; a face index past a body's last reads the next body's planes or the slack behind the copy.
-			float best = 0.0f; int bi = -1;
-			if (g < np) { const float4 f = pl[g]; best = dot_plane(V4(f.x, f.y, f.z, f.w), vl); bi = g; }
-			int i = g + 4;
+			// The dot product ((x vx + y vy) + z vz) + w with the x and y products as ONE packed multiply on the (even-aligned) first two registers of the plane
+			// read -- left to itself the compiler packs y with z and copies both into an aligned pair first, two moves per face.  The face index is counted in
+			// its wave-uniform part u (a scalar register; this lane's face is g + u), so that taking a face is a select on a scalar, not an add per face.
+			typedef float f2 __attribute__((ext_vector_type(2)));
+			const f2 vxy = { vl.x, vl.y };
+			auto pdot = [&](const float4 f) -> float { const f2 q = f2{ f.x, f.y } * vxy; return ((q.x + q.y) + f.z * vl.z) + f.w; };
+			float best = 0.0f; int bu = -1;      // bu: the uniform part of the best face's index (-1: none yet)
+			if (g < np) { best = pdot(pl[g]); bu = 0; }
+			const float4 *pg = pl + g;
+			int u = 4;
 			if (__all(!on || np == npmax))
-				for (; i + 12 < npmax; i += 16)
+				for (; u + 3 + 12 < npmax; u += 16)      // a bound all four lanes of a pair share (the loop below takes what it leaves)
 				{
-					const float4 f0 = pl[i], f1 = pl[i + 4], f2 = pl[i + 8], f3 = pl[i + 12];
-					const float d0 = dot_plane(V4(f0.x, f0.y, f0.z, f0.w), vl), d1 = dot_plane(V4(f1.x, f1.y, f1.z, f1.w), vl);
-					const float d2 = dot_plane(V4(f2.x, f2.y, f2.z, f2.w), vl), d3 = dot_plane(V4(f3.x, f3.y, f3.z, f3.w), vl);
-					if (best < d0) { best = d0; bi = i; }
-					if (best < d1) { best = d1; bi = i + 4; }
-					if (best < d2) { best = d2; bi = i + 8; }
-					if (best < d3) { best = d3; bi = i + 12; }
+					const float4 f0 = pg[u], f1 = pg[u + 4], f2_ = pg[u + 8], f3 = pg[u + 12];
+					const float d0 = pdot(f0), d1 = pdot(f1), d2 = pdot(f2_), d3 = pdot(f3);
+					if (best < d0) { best = d0; bu = u; }
+					if (best < d1) { best = d1; bu = u + 4; }
+					if (best < d2) { best = d2; bu = u + 8; }
+					if (best < d3) { best = d3; bu = u + 12; }
 				}
-			for (; i < npmax; i += 16)
+			for (; u + g < npmax; u += 16)
 			{
-				const float4 f0 = pl[i], f1 = pl[i + 4], f2 = pl[i + 8], f3 = pl[i + 12];
-				const float d0 = dot_plane(V4(f0.x, f0.y, f0.z, f0.w), vl), d1 = dot_plane(V4(f1.x, f1.y, f1.z, f1.w), vl);
-				const float d2 = dot_plane(V4(f2.x, f2.y, f2.z, f2.w), vl), d3 = dot_plane(V4(f3.x, f3.y, f3.z, f3.w), vl);
-				if (i < np && best < d0) { best = d0; bi = i; }
-				if (i + 4 < np && best < d1) { best = d1; bi = i + 4; }
-				if (i + 8 < np && best < d2) { best = d2; bi = i + 8; }
-				if (i + 12 < np && best < d3) { best = d3; bi = i + 12; }
+				const float4 f0 = pg[u], f1 = pg[u + 4], f2_ = pg[u + 8], f3 = pg[u + 12];
+				const float d0 = pdot(f0), d1 = pdot(f1), d2 = pdot(f2_), d3 = pdot(f3);
+				const int i = u + g;
+				if (i < np && best < d0) { best = d0; bu = u; }
+				if (i + 4 < np && best < d1) { best = d1; bu = u + 4; }
+				if (i + 8 < np && best < d2) { best = d2; bu = u + 8; }
+				if (i + 12 < np && best < d3) { best = d3; bu = u + 12; }
 			}
+			int bi = bu < 0 ? -1 : bu + g;
 			(void)live;
 			// merge the four partial results: larger value wins, equal values keep the lower index (the first maximum overall)
 #pragma unroll
