@@ -409,7 +409,7 @@ __device__ __forceinline__ v3 G3(const float *p) { return V3(p[0], p[1], p[2]); 
 __device__ __forceinline__ v4 G4(const float *p) { return V4(p[0], p[1], p[2], p[3]); }
 __device__ __forceinline__ m3 GM(const float *p) { m3 m; m.x = V3(p[0], p[1], p[2]); m.y = V3(p[3], p[4], p[5]); m.z = V3(p[6], p[7], p[8]); return m; }
 #define UB_LDS_ROWS 896      // rows of the single-body solve kept in LDS (3584 points); 72 KB with sums and chain: two blocks per CU
-__device__ __forceinline__ void reset_frame(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float4 *__restrict__ pts, const int *__restrict__ npts,
+template <bool EXACT> __device__ __forceinline__ void reset_frame(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float4 *__restrict__ pts, const int *__restrict__ npts,
                                             const float *__restrict__ analysis, const float *__restrict__ cams, int n_unibody,
                                             float unibody_force, float *rows, int *nrows, float *scratch, int scratch_stride, int batch, int dbg, const int b)
 {
@@ -558,6 +558,66 @@ __device__ __forceinline__ void reset_frame(const ht_model_dev &M, const ht_phys
 		// quad walking its chain alone on a CU would wait a whole L2 round trip for what k_solve's sixteen quads overlap); a larger cloud uses the frame's slot
 		// of the solver scratch in HBM, sums behind all frames' records as in k_solve.
 		const int nr = nsub < scratch_stride - QUAD_CHAIN_SLACK ? nsub : scratch_stride - QUAD_CHAIN_SLACK;
+		if constexpr (EXACT)
+		{
+			// tests only (ht_debug_solver_build 5): the reference's own sweeps over the rows as UnibodyFit re-expresses them (handtrack.h:457-462), LimitLinear::Iter
+			// (physics.h:289-307) row by row on one lane, no fused multiply-adds
+			float *const gs = scratch + (size_t)batch * scratch_stride * CREC + (size_t)b * scratch_stride;
+			for (int i = t; i < nr; i += RS_THREADS)
+			{
+				float *r = rows + ((size_t)b * M.pts_cap + i) * HT_ROW;
+				const int rb1 = (int)r[1];
+				const v3 p1 = apply(ubi, apply(XF(G3(pos[rb1]), G4(q[rb1])), G3(r + 5)));
+				r[5] = p1.x; r[6] = p1.y; r[7] = p1.z;
+				gs[i] = 0.0f;
+			}
+			__threadfence_block();
+			__syncthreads();
+			if (t == 0)
+			{
+				v3 lin = V3((0.0f * M.ub_dampleft) + 0.0f, (0.0f * M.ub_dampleft) + 0.0f, (0.0f * M.ub_dampleft) + 0.0f), ang = lin;
+				v3 pn = ubpos; v4 qn = ubq;
+				const int total = ph.iterations + ph.iterations_post;
+				for (int sweep = 0; sweep < total; sweep++)
+				{
+					const bool post = sweep >= ph.iterations;
+					for (int i = 0; i < nr; i++)
+					{
+						const float *r = rows + ((size_t)b * M.pts_cap + i) * HT_ROW;
+						const v3 p0 = G3(r + 2), p1 = G3(r + 5), nrm = G3(r + 8);
+						const float ts0 = r[11] / dt, ts = post ? fmin_std(ts0, r[12]) : ts0;
+						const v3 r1 = qrot(ubq, p1);
+						const v3 v0 = V3(0, 0, 0), v1 = cross(mul(Iinv, ang), r1) + lin * minv;
+						const float vn = dot(v1 - v0, nrm);
+						const float impulsen = -ts - vn;
+						const float impulsed = 0.0f + (minv + dot(cross(mul(Iinv, cross(r1, nrm)), r1), nrm));
+						float impulse = impulsen / impulsed;
+						const float isum = gs[i];
+						impulse = fmin_std(r[14] * dt - isum, impulse);
+						impulse = fmax_std(r[13] * dt - isum, impulse);
+						const v3 im = nrm * impulse;
+						lin = lin + im; ang = ang + cross(r1, im);
+						gs[i] = isum + impulse;
+						(void)p0;
+					}
+					if (sweep + 1 == ph.iterations)
+					{
+						pn = ubpos + (lin * minv) * dt;
+						const m3 tm = tinv * minv;
+						auto diffq = [&](v4 o) -> v4 { v4 sn = normalize(o); m3 Mx = qmat(sn); m3 Ii = mul(Mx, mul(tm, transpose(Mx))); v3 hs = mul(Ii, ang) * 0.5f; return qmul(V4(hs.x, hs.y, hs.z, 0), sn); };
+						v4 d1 = diffq(ubq), d2 = diffq(ubq + d1 * (dt / 2)), d3 = diffq(ubq + d2 * (dt / 2)), d4 = diffq(ubq + d3 * dt);
+						v4 o = normalize((((ubq + d1 * (dt / 6)) + d2 * (dt / 3)) + d3 * (dt / 3)) + d4 * (dt / 6));
+						if (o.x < FLT_EPSILON / 4.0f && o.x > -FLT_EPSILON / 4.0f) o.x = 0.0f;
+						if (o.y < FLT_EPSILON / 4.0f && o.y > -FLT_EPSILON / 4.0f) o.y = 0.0f;
+						if (o.z < FLT_EPSILON / 4.0f && o.z > -FLT_EPSILON / 4.0f) o.z = 0.0f;
+						qn = o;
+					}
+				}
+				res[0] = pn.x; res[1] = pn.y; res[2] = pn.z; res[3] = qn.x; res[4] = qn.y; res[5] = qn.z; res[6] = qn.w;
+			}
+		}
+		else
+		{
 		const bool in_lds = nr <= UB_LDS_ROWS;
 		float *const grec = scratch + (size_t)b * scratch_stride * CREC;
 		float *const gsum = scratch + (size_t)batch * scratch_stride * CREC + (size_t)b * scratch_stride;
@@ -604,6 +664,7 @@ __device__ __forceinline__ void reset_frame(const ht_model_dev &M, const ht_phys
 			}
 			if (t == 0) { res[0] = pn.x; res[1] = pn.y; res[2] = pn.z; res[3] = qn.x; res[4] = qn.y; res[5] = qn.z; res[6] = qn.w; }
 		}
+		}      // !EXACT
 		__syncthreads();
 		const xf dp = mul(XF(V3(res[0], res[1], res[2]), V4(res[3], res[4], res[5], res[6])), inverse(XF(G3(pos[1]), G4(q[1]))));
 		if (t < nb)
@@ -621,14 +682,14 @@ __device__ __forceinline__ void reset_frame(const ht_model_dev &M, const ht_phys
 // list != null: the frames list[0 .. *nlist) (the decision kernel's list of flagged frames, in no particular order); otherwise all B frames.  A block takes
 // every gridDim.x-th entry: the grid is as large as the device holds blocks at once, not as large as the batch -- a block that finds nothing to do costs a
 // launch of four waves all the same (and this kernel's waves start slowly: 1024 idle blocks cost 70 us, 8192 cost 600).
-template <int MINB> __global__ __launch_bounds__(RS_THREADS, MINB) void k_reset(ht_model_dev M, ht_physics_dev ph, float *state, const float4 *__restrict__ pts, const int *__restrict__ npts,
+template <int MINB, bool EXACT = false> __global__ __launch_bounds__(RS_THREADS, MINB) void k_reset(ht_model_dev M, ht_physics_dev ph, float *state, const float4 *__restrict__ pts, const int *__restrict__ npts,
                                                                              const float *__restrict__ analysis, const float *__restrict__ cams, const int *__restrict__ list, const int *__restrict__ nlist, int B,
                                                                              int n_unibody, float unibody_force, float *rows, int *nrows, float *scratch, int scratch_stride, int batch, int dbg)
 {
 	const int n = list ? min(*nlist, B) : B;
 	for (int slot = blockIdx.x; slot < n; slot += gridDim.x)
 	{
-		reset_frame(M, ph, state, pts, npts, analysis, cams, n_unibody, unibody_force, rows, nrows, scratch, scratch_stride, batch, dbg, list ? list[slot] : slot);
+		reset_frame<EXACT>(M, ph, state, pts, npts, analysis, cams, n_unibody, unibody_force, rows, nrows, scratch, scratch_stride, batch, dbg, list ? list[slot] : slot);
 		__syncthreads();
 	}
 }
@@ -834,7 +895,7 @@ void ht_launch_cloud_rows(const ht_model_dev &M, const float *state, const float
 // the full-reset branch for the frames list[0 .. *nlist) (all B frames with list == nullptr); many_frames: the caller expects more of them than the device has CUs
 // (the two-blocks-per-CU build)
 void ht_launch_reset(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float4 *pts, const int *npts, const float *analysis, const float *cams, const int *list, const int *nlist,
-                     int n_unibody, const ht_params &par, float *rows, int *nrows, float *scratch, int scratch_stride, int batch, int B, hipStream_t s, bool many_frames, int n_cu)
+                     int n_unibody, const ht_params &par, float *rows, int *nrows, float *scratch, int scratch_stride, int batch, int B, hipStream_t s, bool many_frames, int n_cu, bool exact)
 {
 	const size_t cloud = (((size_t)M.plane_off[M.nb] + 16 + 3) & ~(size_t)3) * sizeof(float4) + ((sizeof(closest_lds) + 15) & ~(size_t)15) + HT_MAXNB * BT * sizeof(float);
 	const size_t solve = (size_t)(UB_LDS_ROWS + QUAD_CHAIN_SLACK) * (CREC * sizeof(float) + sizeof(float) + sizeof(unsigned short));
@@ -845,11 +906,15 @@ void ht_launch_reset(const ht_model_dev &M, const ht_physics_dev &ph, float *sta
 	{
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_reset<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_reset<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_reset<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
 		attr_set[dev] = dyn;
 	}
 	const bool two = !list || many_frames;
 	const int grid = B < (two ? 2 : 1) * n_cu ? B : (two ? 2 : 1) * n_cu;
-	if (!two)
+	if (exact)      // tests only (ht_debug_solver_build 5)
+		hipLaunchKernelGGL((k_reset<2, true>), dim3(grid), dim3(RS_THREADS), dyn, s, M, ph, state, pts, npts, analysis, cams, list, nlist, B, n_unibody, par.unibody_force, rows, nrows, scratch, scratch_stride, batch,
+		                   ht_tuning_flags());
+	else if (!two)
 		hipLaunchKernelGGL(k_reset<1>, dim3(grid), dim3(RS_THREADS), dyn, s, M, ph, state, pts, npts, analysis, cams, list, nlist, B, n_unibody, par.unibody_force, rows, nrows, scratch, scratch_stride, batch,
 		                   ht_tuning_flags());
 	else

@@ -128,6 +128,26 @@ __global__ __launch_bounds__(256) void k_prepare_frame(const uint16_t *__restric
 	}
 }
 
+// The CNN input of a frame of any size that is its own segment (handtrack.h:700 on the whole frame; BASELINE configs[4] end to end: the 128x128 frame
+// feeds the 128x128-input net directly): eight pixels per thread, one 128-bit read and two 128-bit writes.  npx is a multiple of 8.
+__global__ __launch_bounds__(256) void k_cnn_input(const uint16_t *__restrict__ depth, const float *__restrict__ cams, int npx, float drangey, float *__restrict__ cnn_in)
+{
+	const int b = blockIdx.y, i = (blockIdx.x * 256 + threadIdx.x) * 8;
+	if (i >= npx) return;
+	const float dscale = cams[(size_t)b * HT_CAM + 4];
+	const uint4 r = *reinterpret_cast<const uint4 *>(depth + (size_t)b * npx + i);
+	const unsigned w[4] = { r.x, r.y, r.z, r.w };
+	float c[8];
+#pragma unroll
+	for (int k = 0; k < 8; k++)
+	{
+		const float d = (float)(int)((w[k >> 1] >> ((k & 1) * 16)) & 0xffffu) * dscale;
+		c[k] = clamp_std(1.0f - (d - 0.1f) / (drangey - 0.1f), 0.0f, 1.0f);
+	}
+	float4 *dst = reinterpret_cast<float4 *>(cnn_in + (size_t)b * npx + i);
+	dst[0] = make_float4(c[0], c[1], c[2], c[3]); dst[1] = make_float4(c[4], c[5], c[6], c[7]);
+}
+
 // ------------------------------------------------------------------------------------------------- k_conv1
 // cnn.h:31.  The exponential is formed in double and rounded once (= the reference's expf except in rare half-ulp cases).  A plain float expf is
 // one ulp off now and then; through MultiStepSim's hard-driven steps that doubled the pose deviation of the CNN-accepted frames (2.0e-3 on a
@@ -477,10 +497,10 @@ __global__ __launch_bounds__(768) void k_fc144(const float *__restrict__ A, cons
 // ------------------------------------------------------------------------------------------------- k_softmax_decode
 // one wave per frame.  softmax chunks: 8 x 256 then 16 x 16 (handtrack.h:118); sums run in ascending order like cnn.h:503-505.
 // analysis layout (HT_ANALYSIS floats): crays 8x4 | image_points 8x2 | confidence 8 | vals 16 | wristroll pitch tilt | palmq 4 | clenched 5
-__device__ void decode_frame(const float *__restrict__ y, const float *__restrict__ cam, float *__restrict__ an, int lane)
+__device__ void decode_frame(const float *__restrict__ y, const float *__restrict__ cam, float *__restrict__ an, int lane, float sub)
 {
-	// hcam = camsub(cam,4) misc_image.h:60
-	const float fx = cam[0] / 4.0f, fy = cam[1] / 4.0f, cx = cam[2] / 4.0f, cy = cam[3] / 4.0f;
+	// hcam = camsub(cam,4) misc_image.h:60 (sub = 8 for the 128x128-input net: 16x16 heat-maps again)
+	const float fx = cam[0] / sub, fy = cam[1] / sub, cx = cam[2] / sub, cy = cam[3] / sub;
 	// ImageFindMax (misc_image.h:298-305: first maximum in a row-major scan) of the 8 heat-maps: 8 lanes per map take 32 consecutive values
 	// each, then the partial results are merged in index order (a later segment only wins with a strictly larger value)
 	int amax;
@@ -541,7 +561,7 @@ __device__ void calc_angles(float *an)      // handtrack.h:194-202
 	for (int i = 0; i < 5; i++) an[HT_AN_CLENCH + i] = vals[3 + i] * 3.1415f;
 }
 // softmax=1: logits -> probabilities (written to cnn_out) then decode; softmax=0: decode an existing cnn_out
-__global__ __launch_bounds__(64) void k_softmax_decode(const float *__restrict__ logits, float *__restrict__ cnn_out, const float *__restrict__ cams, float *__restrict__ analysis, int softmax)
+__global__ __launch_bounds__(64) void k_softmax_decode(const float *__restrict__ logits, float *__restrict__ cnn_out, const float *__restrict__ cams, float *__restrict__ analysis, int softmax, float sub)
 {
 	__shared__ float y[HT_CNN_OUT];
 	__shared__ float an[HT_ANALYSIS];
@@ -579,7 +599,7 @@ __global__ __launch_bounds__(64) void k_softmax_decode(const float *__restrict__
 		__syncthreads();
 	}
 	if (!analysis) return;
-	decode_frame(y, cams + (size_t)b * HT_CAM, an, lane);
+	decode_frame(y, cams + (size_t)b * HT_CAM, an, lane, sub);
 	__syncthreads();
 	if (lane == 0) calc_angles(an);
 	__syncthreads();
@@ -694,7 +714,11 @@ void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, fl
 	}
 	hipLaunchKernelGGL(k_fc144, dim3(2304 / F2_BN, (B + F2_BM - 1) / F2_BM), dim3(768), 0, s, act3, w.W4, w.B4, logits, B, 2304, 2048);
 }
-void ht_launch_softmax_decode(const float *logits, float *cnn_out, const float *cams, float *analysis, int softmax, int B, hipStream_t s)
+void ht_launch_softmax_decode(const float *logits, float *cnn_out, const float *cams, float *analysis, int softmax, int B, hipStream_t s, int sub)
 {
-	hipLaunchKernelGGL(k_softmax_decode, dim3(B), dim3(64), 0, s, logits, cnn_out, cams, analysis, softmax);
+	hipLaunchKernelGGL(k_softmax_decode, dim3(B), dim3(64), 0, s, logits, cnn_out, cams, analysis, softmax, (float)sub);
+}
+void ht_launch_cnn_input(const uint16_t *depth, const float *cams, int npx, float drangey, float *cnn_in, int B, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_cnn_input, dim3((npx / 8 + 255) / 256, B), dim3(256), 0, s, depth, cams, npx, drangey, cnn_in);
 }

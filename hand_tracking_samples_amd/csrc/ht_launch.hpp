@@ -27,6 +27,7 @@ struct solve_args
 	int force_build;                                                // 0: the launcher chooses k_solve's build; 1 small, 2 only, 3 mid, 4 tiny (every array in HBM): ht_debug_solver_build
 	// the last solve of an update also delivers the poses (GetPoseUser physmodel.h:434 + the "initializing = 50" rule of handtrack.h:781-782), instead of a launch of its own
 	float *out_poses; const int *out_npts; int *out_initializing; int out_min_point_num;
+	float *exact_lin, *exact_ang;                                   // force_build 5 (tests only, ht_debug_exact_solver): the two-body linear rows [B][512][HT_ROW] and the angular rows [B][128][8] in the reference's layout, for the reference's own sweeps
 	int dbg;                                                        // timing experiments only (HT_DEBUG_SKIP): 1 skip chains, 2 skip two-body linear, 4 skip angular
 };
 
@@ -52,7 +53,7 @@ void ht_launch_get_state(const float *state, float *dst, int nb, int n, hipStrea
 void ht_launch_clear_flags(float *prev_err, int *initializing, int n, hipStream_t s);
 // the full-reset branch (PoseFromScratch, then n_unibody x UnibodyFit) of the listed frames, one block per frame at a time (k_reset, csrc/ht_cloud.hip)
 void ht_launch_reset(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float4 *pts, const int *npts, const float *analysis, const float *cams, const int *list, const int *nlist,
-                     int n_unibody, const ht_params &par, float *rows, int *nrows, float *scratch, int scratch_stride, int batch, int B, hipStream_t s, bool many_frames, int n_cu);
+                     int n_unibody, const ht_params &par, float *rows, int *nrows, float *scratch, int scratch_stride, int batch, int B, hipStream_t s, bool many_frames, int n_cu, bool exact = false);
 void ht_launch_output(const ht_model_dev &M, const float *hand, const int *npts, int *initializing, int min_point_num, float *poses, int n, hipStream_t s, int raw = 0);
 // ht_segment.hip
 bool ht_segment_supported(int w, int h);

@@ -302,7 +302,11 @@ __device__ __forceinline__ int level_schedule(int n, int lane, const int (&b0)[2
 	return steps;
 }
 
-template <int NGRP_, int NSUM_, int NANG_, int NIDX_>
+// EXACT (tests only, ht_debug_exact_solver): the rows are built as always, but the sweeps are the reference's own -- every row's Iter (physics.h:251-265,
+// 289-307) in the reference's row order and association order, no fused multiply-adds, one lane -- instead of the Jacobian-form sweeps.  With it the whole
+// update reproduces the restatement bit for bit, which isolates the Jacobian-form arithmetic as the solver's only difference from the reference.
+#define EX_LIN 512         // two-body linear rows a frame can have in the exact instantiation (a.exact_lin [B][EX_LIN][HT_ROW])
+template <int NGRP_, int NSUM_, int NANG_, int NIDX_, bool EXACT = false>
 __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph, solve_args a)
 {
 	__shared__ lds_t<NGRP_, NSUM_, NANG_, NIDX_> S;
@@ -523,6 +527,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			// physics.h:256-259: Iinv is invariant during the update, so 1/(axis.Iinv0.axis + axis.Iinv1.axis) is computed once
 			R.s2t = 1.0f / (((R.rb0 >= 0) ? dot(R.axis, mul(body_I(S, R.rb0), R.axis)) : 0.0f) + ((R.rb1 >= 0) ? dot(R.axis, mul(body_I(S, R.rb1), R.axis)) : 0.0f));
 			R.mn = mintorque * dt; R.mx = maxtorque * dt; R.mintorque = mintorque; R.torque = 0.0f;
+			if constexpr (EXACT) { float *e = a.exact_ang + ((size_t)b * MAXA2 + r) * 8; for (int k = 0; k < 8; k++) e[k] = row[k]; }
 			S.arb[r][0] = (unsigned char)(R.rb0 >= 0 ? R.rb0 : 255); S.arb[r][1] = (unsigned char)(R.rb1 >= 0 ? R.rb1 : 255);
 		}
 	}
@@ -597,6 +602,15 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				targetdist = 0; tsnb = 0; fmn = 0;
 				fmx = 0;
 				meta = LM_FRIC;
+			}
+		}
+		if constexpr (EXACT)
+		{
+			if (r < EX_LIN)
+			{
+				float *e = a.exact_lin + ((size_t)b * EX_LIN + r) * HT_ROW;
+				e[0] = (float)rb0; e[1] = (float)rb1; e[2] = p0.x; e[3] = p0.y; e[4] = p0.z; e[5] = p1.x; e[6] = p1.y; e[7] = p1.z; e[8] = n.x; e[9] = n.y; e[10] = n.z;
+				e[11] = targetdist; e[12] = tsnb; e[13] = fmin_std(fmn, fmx); e[14] = fmax_std(fmn, fmx); e[15] = (meta & LM_FRIC) ? (float)-kk : 0.0f;      // friction_master (physics.h:477-478)
 			}
 		}
 		// a side without a body (rb == NULL in the reference, physics.h:293-300): its lever arm is the anchor itself, it adds nothing to the effective mass and moves nothing
@@ -793,6 +807,122 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	}
 	__threadfence_block();      // the records and lists are read back by other lanes of this wave
 	__syncthreads();
+	v3 pos_next = V3(0, 0, 0); v4 q_next = V4(0, 0, 0, 1);
+	auto calc_next_pose = [&]() {
+		// rbcalcnextpose physics.h:522-531 with rkupdateq :211-218 (momentum-preserving RK4 on the quaternion)
+		const float *bc = M.bodyc + lane * HT_BC;
+		const float minv = S.lin4[lane].w;
+		pos_next = L3(S.pos[lane]) + (F3(S.lin4[lane]) * minv) * dt;
+		const m3 tinv = LM(bc + HT_BC_TINV) * minv;
+		const v3 angm = F3(S.ang4[lane]);
+		const v4 s = L4(S.q[lane]);
+		auto diffq = [&](v4 o) -> v4 {
+			v4 sn = normalize(o);
+			m3 Mx = qmat(sn);
+			m3 Ii = mul(Mx, mul(tinv, transpose(Mx)));
+			v3 hs = mul(Ii, angm) * 0.5f;
+			return qmul(V4(hs.x, hs.y, hs.z, 0), sn);
+		};
+		v4 d1 = diffq(s), d2 = diffq(s + d1 * (dt / 2)), d3 = diffq(s + d2 * (dt / 2)), d4 = diffq(s + d3 * dt);
+		v4 o = normalize((((s + d1 * (dt / 6)) + d2 * (dt / 3)) + d3 * (dt / 3)) + d4 * (dt / 6));
+		if (o.x < FLT_EPSILON / 4.0f && o.x > -FLT_EPSILON / 4.0f) o.x = 0.0f;
+		if (o.y < FLT_EPSILON / 4.0f && o.y > -FLT_EPSILON / 4.0f) o.y = 0.0f;
+		if (o.z < FLT_EPSILON / 4.0f && o.z > -FLT_EPSILON / 4.0f) o.z = 0.0f;
+		q_next = o;
+	};
+	if constexpr (EXACT)
+	{
+		// ---- the reference's own sweeps (PhysicsUpdate physics.h:556-581), row by row on one lane.  Linears = [landmark-ray / boundary-plane rows][cloud rows]
+		//      [joint rows][contact rows] (physmodel.h:348-350, physics.h:549-551), then the angular rows, all in the reference's order; a row's impulse sum /
+		//      accumulated torque lives in the frame's sums array in HBM.
+		const int nlin2 = n2 < EX_LIN ? n2 : EX_LIN;
+		float *const sums = gsum;
+		for (int i = lane; i < n1 + nlin2 + na && i < a.scratch_stride; i += 64) sums[i] = 0.0f;
+		__threadfence_block();
+		__syncthreads();
+		auto sweeps = [&](int count, bool post) {
+			auto linear = [&](int rb0, int rb1, v3 p0, v3 p1, v3 n, float ts, float fx, float fy, float *sum) {
+				const m3 Z = { V3(0, 0, 0), V3(0, 0, 0), V3(0, 0, 0) };
+				const v3 r0 = rb0 >= 0 ? qrot(L4(S.q[rb0]), p0) : p0, r1 = rb1 >= 0 ? qrot(L4(S.q[rb1]), p1) : p1;
+				const v3 v0 = rb0 >= 0 ? cross(spin_of(S, rb0), r0) + F3(S.lin4[rb0]) * S.lin4[rb0].w : V3(0, 0, 0);
+				const v3 v1 = rb1 >= 0 ? cross(spin_of(S, rb1), r1) + F3(S.lin4[rb1]) * S.lin4[rb1].w : V3(0, 0, 0);
+				const float vn = dot(v1 - v0, n);
+				const float impulsen = -ts - vn;
+				const float impulsed = (rb0 >= 0 ? S.lin4[rb0].w + dot(cross(mul(body_I(S, rb0), cross(r0, n)), r0), n) : 0.0f)
+				                     + (rb1 >= 0 ? S.lin4[rb1].w + dot(cross(mul(body_I(S, rb1), cross(r1, n)), r1), n) : 0.0f);
+				float impulse = impulsen / impulsed;
+				const float isum = *sum;
+				impulse = fmin_std(fy * dt - isum, impulse);
+				impulse = fmax_std(fx * dt - isum, impulse);
+				if (rb0 >= 0)       // ApplyImpulse(rb0, r0, normal * -impulse) physics.h:222-226
+				{
+					const v3 im = n * -impulse;
+					const v3 l = F3(S.lin4[rb0]) + im, av = F3(S.ang4[rb0]) + cross(r0, im);
+					S.lin4[rb0].x = l.x; S.lin4[rb0].y = l.y; S.lin4[rb0].z = l.z; S.ang4[rb0].x = av.x; S.ang4[rb0].y = av.y; S.ang4[rb0].z = av.z;
+				}
+				if (rb1 >= 0)
+				{
+					const v3 im = n * impulse;
+					const v3 l = F3(S.lin4[rb1]) + im, av = F3(S.ang4[rb1]) + cross(r1, im);
+					S.lin4[rb1].x = l.x; S.lin4[rb1].y = l.y; S.lin4[rb1].z = l.z; S.ang4[rb1].x = av.x; S.ang4[rb1].y = av.y; S.ang4[rb1].z = av.z;
+				}
+				*sum = isum + impulse;
+				(void)Z;
+			};
+			for (int sw = 0; sw < count; sw++)
+			{
+				for (int i = 0; i < n1; i++)
+				{
+					const float *r = i < npre ? pre_ptr(i) : a.rows_cloud + ((size_t)b * M.pts_cap + (i - npre)) * HT_ROW;
+					const float ts = r[11] / dt;
+					linear((int)r[0], (int)r[1], L3(r + 2), L3(r + 5), L3(r + 8), post ? fmin_std(ts, r[12]) : ts, r[13], r[14], sums + i);
+				}
+				for (int i = 0; i < nlin2; i++)
+				{
+					const float *r = a.exact_lin + ((size_t)b * EX_LIN + i) * HT_ROW;
+					const int rb0 = (int)r[0], rb1 = (int)r[1], fm = (int)r[15];
+					const float ts = r[11] / dt;
+					float fx = r[13], fy = r[14];
+					if (fm)      // physics.h:292: the friction rows' limits follow the normal row's impulse sum
+					{
+						fy = fmax_std(rb0 >= 0 ? S.ang4[rb0].w : 0.0f, rb1 >= 0 ? S.ang4[rb1].w : 0.0f) * sums[n1 + i + fm] / dt;
+						fx = -fy;
+					}
+					linear(rb0, rb1, L3(r + 2), L3(r + 5), L3(r + 8), post ? fmin_std(ts, r[12]) : ts, fx, fy, sums + n1 + i);
+				}
+				for (int i = 0; i < na; i++)      // LimitAngular::Iter physics.h:251-265
+				{
+					const float *r = a.exact_ang + ((size_t)b * MAXA2 + i) * 8;
+					const int rb0 = __float_as_int(r[0]), rb1 = __float_as_int(r[1]);
+					const v3 axis = L3(r + 2);
+					const float mintorque = r[6], maxtorque = r[7];
+					const float targetspin = post ? ((mintorque < 0) ? 0 : fmin_std(r[5], 0.0f)) : r[5];      // RemoveBias physics.h:250
+					if (targetspin == -FLT_MAX) continue;
+					const float currentspin = ((rb1 >= 0) ? dot(spin_of(S, rb1), axis) : 0.0f) - ((rb0 >= 0) ? dot(spin_of(S, rb0), axis) : 0.0f);
+					const float dspin = targetspin - currentspin;
+					const float spintotorque = 1.0f / (((rb0 >= 0) ? dot(axis, mul(body_I(S, rb0), axis)) : 0.0f) + ((rb1 >= 0) ? dot(axis, mul(body_I(S, rb1), axis)) : 0.0f));
+					float dtorque = dspin * spintotorque;
+					float *tq = sums + n1 + nlin2 + i;
+					const float torque = *tq;
+					dtorque = fmin_std(dtorque, maxtorque * dt - torque);
+					dtorque = fmax_std(dtorque, mintorque * dt - torque);
+					if (rb0 >= 0) { const v3 av = F3(S.ang4[rb0]) - axis * dtorque; S.ang4[rb0].x = av.x; S.ang4[rb0].y = av.y; S.ang4[rb0].z = av.z; }
+					if (rb1 >= 0) { const v3 av = F3(S.ang4[rb1]) + axis * dtorque; S.ang4[rb1].x = av.x; S.ang4[rb1].y = av.y; S.ang4[rb1].z = av.z; }
+					*tq = torque + dtorque;
+				}
+			}
+		};
+		if (lane == 0) sweeps(ph.iterations, false);
+		__threadfence_block();
+		__syncthreads();
+		if (lane < nb) calc_next_pose();
+		__syncthreads();
+		if (lane == 0) sweeps(ph.iterations_post, true);
+		__threadfence_block();
+		__syncthreads();
+	}
+	else
+	{
 	// ---- the prologue scratch is dead now: angular rows move from their builder lanes into their records ----
 	const bool arec_lds = na <= S.NANG;
 	float *const arec = arec_lds ? S.arec : garec;
@@ -822,7 +952,6 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	const bool stats = HT_DBG(a.dbg, 2048) != 0;          // timing experiments: per-frame cycle counts accumulated in the last scratch record
 	long long cyc_chain = 0, cyc_lin = 0, cyc_ang = 0, t_mark = stats ? clock64() : 0;
 	const long long t_begin = t_mark;
-	v3 pos_next = V3(0, 0, 0); v4 q_next = V4(0, 0, 0, 1);
 	const int total_sweeps = ph.iterations + ph.iterations_post;
 	const float inv_dt = 1.0f / dt;
 	const int quad = lane >> 2, c = lane & 3, cc = c < 3 ? c : 2;         // lane 3 of a quad shadows component z; its vector results are never stored
@@ -1029,29 +1158,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		}
 		__syncthreads();
 		if (stats) { const long long t = clock64(); cyc_ang += t - t_mark; t_mark = t; }
-		if (sweep + 1 == ph.iterations && lane < nb)
-		{
-			// rbcalcnextpose physics.h:522-531 with rkupdateq :211-218 (momentum-preserving RK4 on the quaternion)
-			const float *bc = M.bodyc + lane * HT_BC;
-			const float minv = S.lin4[lane].w;
-			pos_next = L3(S.pos[lane]) + (F3(S.lin4[lane]) * minv) * dt;
-			const m3 tinv = LM(bc + HT_BC_TINV) * minv;
-			const v3 angm = F3(S.ang4[lane]);
-			const v4 s = L4(S.q[lane]);
-			auto diffq = [&](v4 o) -> v4 {
-				v4 sn = normalize(o);
-				m3 Mx = qmat(sn);
-				m3 Ii = mul(Mx, mul(tinv, transpose(Mx)));
-				v3 hs = mul(Ii, angm) * 0.5f;
-				return qmul(V4(hs.x, hs.y, hs.z, 0), sn);
-			};
-			v4 d1 = diffq(s), d2 = diffq(s + d1 * (dt / 2)), d3 = diffq(s + d2 * (dt / 2)), d4 = diffq(s + d3 * dt);
-			v4 o = normalize((((s + d1 * (dt / 6)) + d2 * (dt / 3)) + d3 * (dt / 3)) + d4 * (dt / 6));
-			if (o.x < FLT_EPSILON / 4.0f && o.x > -FLT_EPSILON / 4.0f) o.x = 0.0f;
-			if (o.y < FLT_EPSILON / 4.0f && o.y > -FLT_EPSILON / 4.0f) o.y = 0.0f;
-			if (o.z < FLT_EPSILON / 4.0f && o.z > -FLT_EPSILON / 4.0f) o.z = 0.0f;
-			q_next = o;
-		}
+		if (sweep + 1 == ph.iterations && lane < nb) calc_next_pose();
 	}
 
 	if (stats && lane == 0)
@@ -1062,6 +1169,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		o[5] += (float)nlev_lin; o[6] += (float)nlev_ang; o[7] += (float)mc; o[8] += (float)n1; o[9] += (float)n2; o[10] += (float)na; o[11] += (float)(t_begin - t_entry);
 		o[12] += (float)(t_m1 - t_entry); o[13] += (float)(t_m2 - t_m1); o[14] += (float)(t_m2b - t_m2); o[15] += (float)(t_m3 - t_m2b);
 	}
+	}      // !EXACT
 	// ---- rbupdatepose (physics.h:533-541), SanityCheck (physmodel.h:437-442), optional momentum reset (handtrack.h:686-687) ----
 	if (lane < nb)
 	{
@@ -1100,5 +1208,6 @@ void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solv
 	if (build == 2) hipLaunchKernelGGL((k_solve<66, 1024, 126, 1024>), dim3(B), dim3(64), 0, s, M, ph, a);
 	else if (build == 1) hipLaunchKernelGGL((k_solve<34, 584, 84, 0>), dim3(B), dim3(64), 0, s, M, ph, a);
 	else if (build == 3) hipLaunchKernelGGL((k_solve<71, 1520, 126, 1520>), dim3(B), dim3(64), 0, s, M, ph, a);
+	else if (build == 5) hipLaunchKernelGGL((k_solve<71, 1520, 126, 1520, true>), dim3(B), dim3(64), 0, s, M, ph, a);      // tests only: the reference's own sweeps (ht_debug_exact_solver)
 	else hipLaunchKernelGGL((k_solve<2, 64, 4, 0>), dim3(B), dim3(64), 0, s, M, ph, a);      // tests only: nothing fits, every frame keeps its groups, sums and angular records in HBM
 }

@@ -23,6 +23,15 @@ static int dev_alloc_points(ht_ctx *ctx)      // the second cloud of a context t
 	return HT_OK;
 }
 static cloud_records cloud_rec(ht_ctx *ctx) { cloud_records r = { ctx->d_scratch, scratch_stride(ctx), ctx->d_rowbody, ctx->phys.deltaT }; return r; }
+// the exact-order instantiation of the solver (ht_debug_solver_build 5, tests only) takes the cloud rows in the reference's layout (ctx->d_rows) instead of records
+static bool exact_solver(const ht_ctx *ctx) { return ctx->solver_build == 5; }
+static const cloud_records *rec_or_rows(const ht_ctx *ctx, const cloud_records *cr) { return exact_solver(ctx) ? nullptr : cr; }
+static void exact_args(ht_ctx *ctx, solve_args &a, bool cloud)
+{
+	a.force_build = ctx->solver_build;
+	a.exact_lin = ctx->d_exact_lin; a.exact_ang = ctx->d_exact_ang;
+	if (exact_solver(ctx) && cloud) { a.rows_cloud = ctx->d_rows; a.cloud_body = nullptr; }
+}
 static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int *n_pre, bool cloud, bool contacts, const int *active,
                        int apply_angles, float drive_force, int ray_rows, int arm_cone, int zero_momenta, int B, hipStream_t s, bool shared_gpu = false, float *poses_out = nullptr, const int *out_npts = nullptr)
 {
@@ -39,7 +48,7 @@ static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int 
 	a.steps_keyangles = ctx->par.steps_keyangles; a.min_cray_prob = ctx->par.min_cray_prob;
 	a.dbg = ht_tuning_flags();
 	a.shared_gpu = shared_gpu ? 1 : 0;
-	a.force_build = ctx->solver_build;
+	exact_args(ctx, a, cloud);
 	a.out_poses = poses_out; a.out_npts = out_npts; a.out_initializing = ctx->d_initializing; a.out_min_point_num = ctx->par.min_point_num;
 	ht_launch_solve(ctx->model, ctx->phys, a, B, s);
 }
@@ -90,7 +99,7 @@ static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int 
 		{
 			if (par) fork1(ctx, s, side);
 			const cloud_records cr = cloud_rec(ctx);
-			if (cloud) { ht_prof_scope ps(ctx, prof ? "cloud_rows" : nullptr, s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, active, 4, 1, 2, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[side] : s, 0.0f, 0.0f, &cr); }
+			if (cloud) { ht_prof_scope ps(ctx, prof ? "cloud_rows" : nullptr, s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, active, 4, 1, 2, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[side] : s, 0.0f, 0.0f, rec_or_rows(ctx, &cr)); }
 			if (coll && !(first_contacts_done && st == from_step)) { ht_prof_scope ps(ctx, prof ? "contacts" : nullptr, s, true); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, active, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, false, ctx->contact_kernel, active && active == ctx->d_flags && !ctx->many_reset); }
 			if (par) join1(ctx, s, side);
 			if (part == 0 && !active) mark("  step: rows done", s);
@@ -112,7 +121,7 @@ static void main_pass(ht_ctx *ctx, int B, hipStream_t s, float *poses_out = null
 	if (par) fork(ctx, s);
 	{ ht_prof_scope ps(ctx, "chamber", s, true); ht_launch_chamber(ctx->model, ctx->d_state[0], pts, npts, p.min_point_num, p.boundary_planes, 10.0f, ctx->d_chamber, ctx->d_nchamber, B, par ? ctx->side[1] : s); }
 	const cloud_records cr = cloud_rec(ctx);
-	{ ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[0], pts, npts, ctx->d_cams, nullptr, 1, 0, 1, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[0] : s, 0.0f, 0.0f, &cr); }
+	{ ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[0], pts, npts, ctx->d_cams, nullptr, 1, 0, 1, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[0] : s, 0.0f, 0.0f, rec_or_rows(ctx, &cr)); }
 	if (coll) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[0], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, par, ctx->contact_kernel); }
 	mark("  pass: contacts done", s);
 	if (par) { mark("  pass: cloud rows done", ctx->side[0]); mark("  pass: chamber done", ctx->side[1]); }
@@ -133,21 +142,24 @@ static void reset_path(ht_ctx *ctx, bool listed, int n_unibody, int B, hipStream
 {
 	ht_prof_scope ps(ctx, "reset_path", prof_stream, true);
 	ht_launch_reset(ctx->model, ctx->phys, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_analysis, ctx->d_cams, listed ? ctx->d_flist : nullptr, listed ? ctx->d_nflist : nullptr, n_unibody, ctx->par,
-	                ctx->d_rows, ctx->d_nrows, ctx->d_scratch, scratch_stride(ctx), ctx->B, B, s, many_frames, ctx->n_cu);
+	                ctx->d_rows, ctx->d_nrows, ctx->d_scratch, scratch_stride(ctx), ctx->B, B, s, many_frames, ctx->n_cu, exact_solver(ctx));
 }
 
 // the whole unit of work on device buffers
 // `fs` != null: d_depth / d_cams are full-size frames (handtrack.h:693-785 with dim != 64x64).  The tracker segments them for the CNN
 // (handtrack.h:697-698) and from then on ctx->d_cams holds the SEGMENT cameras (CNN decode, landmark rays, PoseFromScratch, UnibodyFit and
 // MultiStepSim take segment.cam.pose); the point cloud and FitError keep the full frame and its camera.
-struct frame_src { int w, h; float segment_scale; };
+// `direct` != 0: the frame (direct x direct pixels) is its own segment and feeds the net of that input size -- what HandSegmentVR returns for a frame of the net's
+// size (handtrack.h:283-284), the stages of :693-729 called directly (BASELINE configs[4] end to end, SURVEY 8d config 5 i-iii); heat-map camera camsub(cam, direct / 16).
+struct frame_src { int w, h; float segment_scale; int direct; };
 // `mode`: UPD_FULL = HandTracker::update (handtrack.h:748-785); UPD_CNN_MODEL = update_cnn_model alone (:734-741): othermodel is NOT re-seeded from
 // handmodel, no main-thread passes, no "initializing = 50" rule, the result is othermodel.GetPose() plus the accept decision, handmodel untouched;
 // UPD_KICKSTART = kickstart (:743-746) = the same followed by handmodel.SetPose(pose) where the pose was accepted.
 enum { UPD_FULL = 0, UPD_CNN_MODEL = 1, UPD_KICKSTART = 2 };
 static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, const float *d_start, int B, float *d_poses_out, float *d_cnn_out, hipStream_t s, const frame_src *fs = nullptr, int mode = UPD_FULL)
 {
-	if (!ctx->have_weights) { ctx->err = "CNN weights not loaded (ht_cnn_load_weights)"; return HT_ERR_STATE; }
+	if (fs && fs->direct) { if (!ctx->have_weights128) { ctx->err = "weights of the 128x128 net not loaded (ht_cnn_load_weights_sized)"; return HT_ERR_STATE; } }
+	else if (!ctx->have_weights) { ctx->err = "CNN weights not loaded (ht_cnn_load_weights)"; return HT_ERR_STATE; }
 	const ht_params &p = ctx->par;
 	const int nb = ctx->model.nb;
 	const int iw = fs ? fs->w : 64, ih = fs ? fs->h : 64;      // the image FitError looks at
@@ -164,7 +176,8 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		}
 		HIPCHK(ctx, hipMemcpyAsync(ctx->d_frame_cams, d_cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyDeviceToDevice, s));
 		HIPCHK(ctx, hipMemsetAsync(ctx->d_overflow, 0, sizeof(int), s));
-		ht_launch_segment(d_depth, ctx->d_frame_cams, fs->w, fs->h, 0xF, p.drangey, fs->segment_scale, ctx->d_seg_tiles, ctx->d_cams, B, s);
+		if (fs->direct) { if (d_cams != ctx->d_cams) HIPCHK(ctx, hipMemcpyAsync(ctx->d_cams, d_cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyDeviceToDevice, s)); }      // segment.cam = the frame's camera
+		else ht_launch_segment(d_depth, ctx->d_frame_cams, fs->w, fs->h, 0xF, p.drangey, fs->segment_scale, ctx->d_seg_tiles, ctx->d_cams, B, s);
 		img_cams = ctx->d_frame_cams;
 	}
 	// 64x64 tiles: the camera copy and the re-seeding of the trackers ride on k_prepare (below); full-size frames keep their own small kernels
@@ -180,7 +193,8 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		if (fs)
 		{
 			const ht_prepare_extra pz = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, ctx->d_nflist };
-			ht_launch_prepare(ctx->d_seg_tiles, ctx->d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, nullptr, nullptr, ctx->model.pts_cap, B, s, &pz);
+			if (fs->direct) { HIPCHK(ctx, hipMemsetAsync(ctx->d_nflist, 0, sizeof(int), s)); ht_launch_cnn_input(d_depth, ctx->d_cams, fs->w * fs->h, p.drangey, ctx->d_in128, B, s); }
+			else ht_launch_prepare(ctx->d_seg_tiles, ctx->d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, nullptr, nullptr, ctx->model.pts_cap, B, s, &pz);
 			ht_launch_prepare_frame(d_depth, img_cams, fs->w, fs->h, p.drangey, p.subsample_fraction, ctx->d_pts, ctx->d_npts, ctx->d_overflow, ctx->model.pts_cap, B, s);
 		}
 		else ht_launch_prepare(d_depth, d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, ctx->d_pts, ctx->d_npts, ctx->model.pts_cap, B, s, &px);
@@ -197,7 +211,7 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 	}
 	float *cnn_out = d_cnn_out ? d_cnn_out : ctx->d_cnn_out;
 	static const bool no_overlap = ht_tuning_env("HT_NO_OVERLAP");      // timing experiments (-DHT_TUNING builds only)
-	const bool overlap = !no_overlap && !ctx->profile_phases && p.steps >= 1 && p.steps_cloudstart >= 1 && !p.angles_only;
+	const bool overlap = !no_overlap && !ctx->profile_phases && p.steps >= 1 && p.steps_cloudstart >= 1 && !p.angles_only && !exact_solver(ctx);
 	if (overlap)
 	{
 		// Nothing on this side branch needs the CNN: the error of the carried pose and the reset decision only read the point cloud and the
@@ -212,8 +226,9 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 	}
 	{
 		ht_prof_scope ps(ctx, "cnn", s, true);
-		ht_launch_cnn(ctx->cnnw, ctx->d_cnn_in, ctx->d_act1, ctx->d_act2, ctx->d_act3, ctx->d_logits, B, s);
-		ht_launch_softmax_decode(ctx->d_logits, cnn_out, ctx->d_cams, ctx->d_analysis, 1, B, s);
+		if (fs && fs->direct) ht_launch_cnn(ctx->cnnw128, ctx->d_in128, ctx->d_act1_128, ctx->d_act2_128, ctx->d_act3, ctx->d_logits, B, s, fs->direct);
+		else ht_launch_cnn(ctx->cnnw, ctx->d_cnn_in, ctx->d_act1, ctx->d_act2, ctx->d_act3, ctx->d_logits, B, s);
+		ht_launch_softmax_decode(ctx->d_logits, cnn_out, ctx->d_cams, ctx->d_analysis, 1, B, s, (fs && fs->direct) ? fs->direct / 16 : 4);
 	}
 	if (overlap)
 	{
@@ -405,7 +420,7 @@ extern "C" int ht_update_frames_dev(ht_ctx *ctx, const uint16_t *d_depth, const 
 	if (!d_depth || !d_cams || !d_poses_out) return HT_ERR_ARG;
 	if (!frames_args_ok(ctx, w, h)) return HT_ERR_ARG;
 	hipStream_t s = ht_user_stream(ctx, stream);
-	const frame_src fs = { w, h, segment_scale };
+	const frame_src fs = { w, h, segment_scale, 0 };
 	int r = run_update(ctx, d_depth, d_cams, d_start_poses, B, d_poses_out, nullptr, s, (w == 64 && h == 64) ? nullptr : &fs);
 	if (r) return r;
 	HIPCHK(ctx, hipGetLastError());
@@ -452,7 +467,7 @@ extern "C" int ht_update_frames_sync(ht_ctx *ctx, const uint16_t *depth, const f
 	if (!ctx->d_frame_cams_in) { void *a = nullptr; HIPCHK(ctx, hipMalloc(&a, (size_t)ctx->B * HT_CAM * sizeof(float))); ctx->allocs.push_back(a); ctx->d_frame_cams_in = (float *)a; }
 	HIPCHK(ctx, hipMemcpyAsync(ctx->d_frames, depth, (size_t)B * npx * sizeof(uint16_t), hipMemcpyHostToDevice, s));
 	HIPCHK(ctx, hipMemcpyAsync(ctx->d_frame_cams_in, cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyHostToDevice, s));
-	const frame_src fs = { w, h, segment_scale };
+	const frame_src fs = { w, h, segment_scale, 0 };
 	int r = run_update(ctx, ctx->d_frames, ctx->d_frame_cams_in, nullptr, B, ctx->d_poses_out, nullptr, s, &fs);
 	if (r) return r;
 	HIPCHK(ctx, hipMemcpyAsync(poses_out, ctx->d_poses_out, (size_t)B * nb * HT_POSE * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -462,6 +477,44 @@ extern "C" int ht_update_frames_sync(ht_ctx *ctx, const uint16_t *depth, const f
 	int over = 0;
 	HIPCHK(ctx, hipMemcpy(&over, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost));
 	if (over) { ctx->err = "ht_update_frames: " + std::to_string(over) + " frame(s) have more in-range points than the context's point capacity holds; their result is not the reference's"; return HT_ERR_ARG; }
+	return HT_OK;
+}
+
+// BASELINE configs[4] end to end (SURVEY 8d "config 5 (i)-(iii)"): HandTracker::update on side x side frames that are their own segment, evaluated by the net of
+// that input size (ht_cnn_load_weights_sized) -- no HandSegmentVR, heat-map camera camsub(cam, side / 16), everything else as handtrack.h:693-785
+extern "C" int ht_update_direct_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, int side, const float *d_start_poses, int B, float *d_poses_out, void *stream)
+{
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
+	if (!d_depth || !d_cams || !d_poses_out) return HT_ERR_ARG;
+	if (side == 64) return ht_update_dev(ctx, d_depth, d_cams, d_start_poses, B, d_poses_out, stream);
+	if (side != 128) { ctx->err = "ht_update_direct: CNN input side must be 64 or 128"; return HT_ERR_ARG; }
+	hipStream_t s = ht_user_stream(ctx, stream);
+	const frame_src fs = { side, side, 0.0f, side };
+	int r = run_update(ctx, d_depth, d_cams, d_start_poses, B, d_poses_out, nullptr, s, &fs);
+	if (r) return r;
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
+extern "C" int ht_update_direct_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int side, int B, float *poses_out, float *cnn_out)
+{
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
+	if (!depth || !cams || !poses_out) return HT_ERR_ARG;
+	if (side == 64) return ht_update_sync(ctx, depth, cams, B, poses_out, cnn_out);
+	if (side != 128) { ctx->err = "ht_update_direct: CNN input side must be 64 or 128"; return HT_ERR_ARG; }
+	hipStream_t s = ctx->stream;
+	const int nb = ctx->model.nb;
+	const size_t npx = (size_t)side * side;
+	if (ctx->frames_cap < (size_t)B * npx) { void *a = nullptr; HIPCHK(ctx, hipMalloc(&a, (size_t)ctx->B * npx * sizeof(uint16_t))); ctx->allocs.push_back(a); ctx->d_frames = (uint16_t *)a; ctx->frames_cap = (size_t)ctx->B * npx; }
+	if (!ctx->d_frame_cams_in) { void *a = nullptr; HIPCHK(ctx, hipMalloc(&a, (size_t)ctx->B * HT_CAM * sizeof(float))); ctx->allocs.push_back(a); ctx->d_frame_cams_in = (float *)a; }
+	HIPCHK(ctx, hipMemcpyAsync(ctx->d_frames, depth, (size_t)B * npx * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+	HIPCHK(ctx, hipMemcpyAsync(ctx->d_frame_cams_in, cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyHostToDevice, s));
+	const frame_src fs = { side, side, 0.0f, side };
+	int r = run_update(ctx, ctx->d_frames, ctx->d_frame_cams_in, nullptr, B, ctx->d_poses_out, nullptr, s, &fs);
+	if (r) return r;
+	HIPCHK(ctx, hipMemcpyAsync(poses_out, ctx->d_poses_out, (size_t)B * nb * HT_POSE * sizeof(float), hipMemcpyDeviceToHost, s));
+	if (cnn_out) HIPCHK(ctx, hipMemcpyAsync(cnn_out, ctx->d_cnn_out, (size_t)B * HT_CNN_OUT * sizeof(float), hipMemcpyDeviceToHost, s));
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	HIPCHK(ctx, hipGetLastError());
 	return HT_OK;
 }
 
@@ -491,7 +544,7 @@ extern "C" int ht_update_cnn_model_sync(ht_ctx *ctx, const uint16_t *depth, cons
 		HIPCHK(ctx, hipMemcpyAsync(ctx->d_frame_cams_in, cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyHostToDevice, s));
 		d_in = ctx->d_frames; d_cin = ctx->d_frame_cams_in;
 	}
-	const frame_src fs = { w, h, segment_scale };
+	const frame_src fs = { w, h, segment_scale, 0 };
 	int r = run_update(ctx, d_in, d_cin, nullptr, B, ctx->d_poses_out, nullptr, s, tile ? nullptr : &fs, apply_to_handmodel ? UPD_KICKSTART : UPD_CNN_MODEL);
 	if (r) return r;
 	if (poses_out) HIPCHK(ctx, hipMemcpyAsync(poses_out, ctx->d_poses_out, (size_t)B * nb * HT_POSE * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -635,9 +688,19 @@ extern "C" int ht_debug_solve_stats(ht_ctx *ctx, int B, float *out, int reset)
 // Tests only: pins the build of k_solve (0 = the launcher's choice by batch and frame size; 1 small, 2 only, 3 mid, 4 tiny = a build whose LDS arrays hold
 // nothing, so that every frame takes the HBM placement of its two-body groups, impulse sums and angular records).  The builds differ in where a
 // frame's arrays live, never in arithmetic: results must agree bit for bit (tests/test_gpu_solver.py).
+// 5 = the EXACT-ORDER instantiation: the same rows, swept by the reference's own Iter functions in the reference's row order (physics.h:251-265, 289-307, 556-581) on one
+// lane per frame, the single-body solves of UnibodyFit too.  With it an update equals the CPU restatement bit for bit (tests/test_gpu_exact_solver.py), which
+// pins the Jacobian-form arithmetic of the product's sweeps as the solver's only difference from the reference.  Far slower; never chosen by a launcher.
 extern "C" int ht_debug_solver_build(ht_ctx *ctx, int which)
 {
-	if (!ctx || which < 0 || which > 4) return HT_ERR_ARG;
+	if (!ctx || which < 0 || which > 5) return HT_ERR_ARG;
+	if (which == 5 && !ctx->d_exact_lin)
+	{
+		ht_device_guard dev_guard_(ctx->device);
+		void *a = nullptr, *b = nullptr;
+		HIPCHK(ctx, hipMalloc(&a, (size_t)ctx->B * 512 * HT_ROW * sizeof(float))); ctx->allocs.push_back(a); ctx->d_exact_lin = (float *)a;
+		HIPCHK(ctx, hipMalloc(&b, (size_t)ctx->B * 128 * 8 * sizeof(float))); ctx->allocs.push_back(b); ctx->d_exact_ang = (float *)b;
+	}
 	ctx->solver_build = which;
 	return HT_OK;
 }
@@ -795,6 +858,7 @@ extern "C" int ht_fit_rows(ht_ctx *ctx, int which, int B, const float *points, i
 	a.ang_user = ctx->d_user_ang; a.n_ang_user = ctx->d_user_n + 3 * (size_t)ctx->B; a.ang_user_stride = ctx->user_ang_cap;
 	a.analysis = ctx->d_analysis; a.cams = ctx->d_cams;
 	a.state = ctx->d_state[which]; a.scratch = ctx->d_scratch; a.scratch_stride = scratch_stride(ctx); a.batch = ctx->B;
+	if (exact_solver(ctx)) { ctx->err = "the exact-order instantiation (ht_debug_solver_build 5) serves the update entry points only"; return HT_ERR_STATE; }
 	a.force_build = ctx->solver_build;
 	ctx->model.pts_bound = 0;
 	ht_launch_solve(ctx->model, ctx->phys, a, B, s);
@@ -875,6 +939,7 @@ extern "C" int ht_physics_update(ht_ctx *ctx, int which, int B, const float *lin
 	a.no_model_rows = 1;
 	a.analysis = ctx->d_analysis; a.cams = ctx->d_cams;
 	a.state = ctx->d_state[which]; a.scratch = ctx->d_scratch; a.scratch_stride = scratch_stride(ctx); a.batch = ctx->B;
+	if (exact_solver(ctx)) { ctx->err = "the exact-order instantiation (ht_debug_solver_build 5) serves the update entry points only"; return HT_ERR_STATE; }
 	a.force_build = ctx->solver_build;
 	ctx->model.pts_bound = 0;
 	ht_launch_solve(ctx->model, ctx->phys, a, B, s);
@@ -920,6 +985,7 @@ extern "C" int ht_slowfit(ht_ctx *ctx, int B, int hold, const float *refpose, in
 		a.ray_rows = (a.sf_ncray > 0 || select_rb >= 0) ? 1 : 0;
 		a.sf_refpose = rel ? ctx->d_sf_ref : nullptr; a.sf_hold = rel ? hold : 0;
 		a.steps_keyangles = ctx->par.steps_keyangles; a.min_cray_prob = ctx->par.min_cray_prob;
+		if (exact_solver(ctx)) { ctx->err = "the exact-order instantiation (ht_debug_solver_build 5) serves the update entry points only"; return HT_ERR_STATE; }
 		a.force_build = ctx->solver_build;
 		ht_launch_solve(ctx->model, ctx->phys, a, B, s);
 	}

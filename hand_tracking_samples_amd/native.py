@@ -20,7 +20,7 @@ SYMBOLS = (
     "ht_create", "ht_destroy", "ht_model_bake", "ht_last_error", "ht_get_params", "ht_set_params", "ht_model_info", "ht_config_read", "ht_scale",
     "ht_cnn_load_weights", "ht_cnn_eval", "ht_cnn_eval_dev", "ht_cnn_load_weights_sized", "ht_cnn_eval_sized", "ht_cnn_eval_sized_dev", "ht_cnn_train", "ht_cnn_get_weights", "ht_expected_cnn", "ht_expected_cnn_full",
     "ht_model_open", "ht_model_close", "ht_model_error", "ht_model_counts", "ht_model_body", "ht_model_body_mesh", "ht_model_hitcheck",
-    "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_update_frames_sync", "ht_update_frames_dev", "ht_update_cnn_model_sync", "ht_get_cnn_results", "ht_get_cnn_layers", "ht_frames_overflow", "ht_reserve_points", "ht_point_capacity", "ht_capacity_events", "ht_segment_vr", "ht_segment_vr_dev", "ht_slowfit", "ht_set_points", "ht_fit_rows", "ht_physics_update",
+    "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_update_frames_sync", "ht_update_frames_dev", "ht_update_direct_sync", "ht_update_direct_dev", "ht_update_cnn_model_sync", "ht_get_cnn_results", "ht_get_cnn_layers", "ht_frames_overflow", "ht_reserve_points", "ht_point_capacity", "ht_capacity_events", "ht_segment_vr", "ht_segment_vr_dev", "ht_slowfit", "ht_set_points", "ht_fit_rows", "ht_physics_update",
     "ht_stage_prepare", "ht_stage_decode", "ht_stage_fit_error", "ht_stage_cloud_rows", "ht_stage_contacts", "ht_stage_fit",
     "ht_stage_multistep", "ht_stage_scratch_unibody", "ht_stage_chamber", "ht_profile_enable", "ht_profile_read", "ht_debug_solve_stats", "ht_debug_contact_stats", "ht_debug_solver_build", "ht_debug_contact_kernel",
     "ht_comm_unique_id", "ht_comm_init", "ht_comm_info", "ht_gather_poses_dev", "ht_gather_wait", "ht_comm_destroy",
@@ -79,6 +79,8 @@ def load(build_if_missing=True):
     L.ht_update_dev.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp]
     L.ht_update_frames_sync.argtypes = [vp, u16p, fp, C.c_int, C.c_int, C.c_float, C.c_int, fp, fp]
     L.ht_update_frames_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, C.c_int, vp, vp]
+    L.ht_update_direct_sync.argtypes = [vp, u16p, fp, C.c_int, C.c_int, fp, fp]
+    L.ht_update_direct_dev.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp]
     L.ht_frames_overflow.argtypes = [vp, ip]
     L.ht_reserve_points.argtypes = [vp, C.c_int]
     L.ht_point_capacity.argtypes = [vp, ip]
@@ -266,6 +268,19 @@ class Context:
 
     def update_frames_dev(self, d_depth, d_cams, w, h, segment_scale, d_start, B, d_poses_out, stream):
         self._chk(self.L.ht_update_frames_dev(self.h, d_depth, d_cams, int(w), int(h), float(segment_scale), d_start, B, d_poses_out, stream))
+
+    def update_direct_sync(self, depth, cams, side=128, want_cnn=False):
+        """BASELINE configs[4] end to end: depth u16[B,side,side] frames that are their own segment, the net of that input size (ht_update_direct_sync)."""
+        depth = _c(depth, np.uint16).reshape(-1, side * side)
+        B = depth.shape[0]
+        cams = _c(cams, np.float32).reshape(B, CAM)
+        poses = np.empty((B, self.nb, POSE), np.float32)
+        cnn = np.empty((B, CNN_OUT), np.float32) if want_cnn else None
+        self._chk(self.L.ht_update_direct_sync(self.h, depth.ctypes.data_as(C.POINTER(C.c_uint16)), _f(cams), int(side), B, _f(poses), _f(cnn) if want_cnn else None))
+        return (poses, cnn) if want_cnn else (poses, None)
+
+    def update_direct_dev(self, d_depth, d_cams, side, d_start, B, d_poses_out, stream):
+        self._chk(self.L.ht_update_direct_dev(self.h, d_depth, d_cams, int(side), d_start, B, d_poses_out, stream))
 
     def update_cnn_model_sync(self, depth, cams, kickstart=False, segment_scale=0.17):
         """HandTracker::update_cnn_model (handtrack.h:734-741) / kickstart (:743-746): depth u16[B,h,w] -> (othermodel poses [B,nb,7], accepted [B])."""

@@ -149,6 +149,14 @@ int ht_update_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, con
  * ht_reserve_points   grows the per-point arrays ahead of time to `points` per frame (<= HT_POINTS_LIMIT; never shrinks); ht_point_capacity reads it. */
 int ht_update_frames_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int w, int h, float segment_scale, int B, float *poses_out, float *cnn_out);
 int ht_update_frames_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, int w, int h, float segment_scale, const float *d_start_poses, int B, float *d_poses_out, void *stream);
+/* ht_update_direct_*  BASELINE configs[4] end to end (SURVEY 8d "config 5 (i)-(iii)"): the same call on side x side frames (side = 128) that are their own segment
+ *                     -- what HandSegmentVR returns for a frame of the net's own size (handtrack.h:283-284) -- evaluated by the net of that input size
+ *                     (ht_cnn_load_weights_sized; the reference's layer classes cnn.h:136-511 in the order of handtrack.h:108-118), decoded with
+ *                     CNNOutputAnalysis(out, camsub(cam, side / 16)) (handtrack.h:218-241), then FitError, the reset branch, MultiStepSim, the accept step and
+ *                     the main-thread passes exactly as handtrack.h:703-785.  The reference has no call of its own for this (PoseInitializerCNN is fixed at
+ *                     64x64); oracle/ref_harness.cpp `e2e128` drives the reference's stage functions in that order.  side = 64 is ht_update_*. */
+int ht_update_direct_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int side, int B, float *poses_out, float *cnn_out);
+int ht_update_direct_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, int side, const float *d_start_poses, int B, float *d_poses_out, void *stream);
 int ht_frames_overflow(ht_ctx *ctx, int *frames_over);
 int ht_reserve_points(ht_ctx *ctx, int points);
 int ht_point_capacity(ht_ctx *ctx, int *points);

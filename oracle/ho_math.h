@@ -95,7 +95,14 @@ static inline pose_t pose_mul(pose_t a, pose_t b) { return POSE(pose_apply(a, b.
 static inline f4 pose_transform_plane(pose_t p, f4 pl) { f3 n = qrot(p.orientation, xyz(pl)); return F4v(n, pl.w - dot3(p.position, n)); }
 
 /* geometric.h:102 / linalg.h:344 */
-static inline f4 quat_axis_angle(f3 axis, float angle) { return F4v(scale3(axis, sinf(angle / 2)), cosf(angle / 2)); }
+/* The reference's float sine / cosine / arc cosine are glibc's (std::sin(float) in geometric.h:102, acos(float) in physics.h:319,408), which are within one ulp but
+ * not always correctly rounded; the device forms them in double and rounds once.  ho_round_once = 1 (tests only: tests/test_gpu_exact_solver.py) makes the
+ * restatement do the same, so that a device result can be compared with it bit for bit; 0 (the default, and the setting every fixture is pinned with) = glibc's. */
+extern int ho_round_once;
+static inline float ho_sinf(float x) { return ho_round_once ? (float)sin((double)x) : sinf(x); }
+static inline float ho_cosf(float x) { return ho_round_once ? (float)cos((double)x) : cosf(x); }
+static inline float ho_acosf(float x) { return ho_round_once ? (float)acos((double)x) : acosf(x); }
+static inline f4 quat_axis_angle(f3 axis, float angle) { return F4v(scale3(axis, ho_sinf(angle / 2)), ho_cosf(angle / 2)); }
 
 /* geometric.h:312-318 Orth: zero the largest-magnitude component of (1,1,1) (first maximum wins), cross, normalise */
 static inline f3 ho_orth(f3 v)

@@ -119,7 +119,7 @@ int ho_angular_drive(const ho_physics *ph, ho_body *const *B, int rb0, int rb1, 
 	f3 axis = safenormalize3(xyz(dq));
 	f3 binormal = ho_orth(axis);
 	f3 normal = cross3(axis, binormal);
-	out[0] = mk_angular(rb0, rb1, axis, -ph->biasfactorjoint * (acosf(ho_clampf(dq.w, -1.0f, 1.0f)) * 2.0f) / ph->deltaT, -maxtorque, maxtorque);
+	out[0] = mk_angular(rb0, rb1, axis, -ph->biasfactorjoint * (ho_acosf(ho_clampf(dq.w, -1.0f, 1.0f)) * 2.0f) / ph->deltaT, -maxtorque, maxtorque);
 	out[1] = mk_angular(rb0, rb1, binormal, 0, -maxtorque, maxtorque);
 	out[2] = mk_angular(rb0, rb1, normal, 0, -maxtorque, maxtorque);
 	return 3;
@@ -131,7 +131,7 @@ ho_angular ho_cone_angle(const ho_physics *ph, ho_body *const *B, int rb0, f3 n0
 	f3 a0 = rb0 >= 0 ? qrot(B[rb0]->orientation, n0) : n0;
 	f3 a1 = rb1 >= 0 ? qrot(B[rb1]->orientation, n1) : n1;
 	f3 axis = safenormalize3(cross3(a1, a0));
-	float rbangle = acosf(ho_clampf(dot3(a0, a1), 0.0f, 1.0f));
+	float rbangle = ho_acosf(ho_clampf(dot3(a0, a1), 0.0f, 1.0f));
 	float dangle = rbangle - (limitangle_degrees) * 3.14f / 180.0f;
 	float targetspin = ((equality) ? ph->biasfactorjoint : 1.0f) * dangle / ph->deltaT;
 	return mk_angular(rb0, rb1, axis, targetspin, (limitangle_degrees > 0.0f) ? 0 : -FLT_MAX, FLT_MAX);

@@ -144,13 +144,28 @@ void ho_destroy(ho_tracker *t)
 {
 	if (!t) return;
 	for (int b = 0; b < t->handmodel.nb; b++) { free(t->handmodel.bodies[b].shape.verts); free(t->handmodel.bodies[b].shape.planes); free(t->othermodel.bodies[b].shape.verts); free(t->othermodel.bodies[b].shape.planes); }
-	free(t->unibody_proto.shape.verts); free(t->weights); free(t);
+	free(t->unibody_proto.shape.verts); free(t->weights); free(t->weights_direct); free(t->cnn_input_direct); free(t);
 }
 int ho_load_weights(ho_tracker *t, const float *w, size_t n)
 {
 	if (n != 9458400u) return -1;
 	free(t->weights); t->weights = malloc(n * sizeof(float)); memcpy(t->weights, w, n * sizeof(float)); t->nweights = n; return 0;
 }
+/* the stages of update_cnn_model_threadsafe called directly on a side x side frame with the side-sized net */
+int ho_set_direct(ho_tracker *t, int side, const float *w, size_t n)
+{
+	free(t->weights_direct); free(t->cnn_input_direct); t->weights_direct = NULL; t->cnn_input_direct = NULL; t->direct_side = 0;
+	if (side == 0) return 0;
+	const size_t feat = (size_t)64 * (((side - 4) / 4 - 3) / 2) * (((side - 4) / 4 - 3) / 2);
+	if (side != 128 || !w || n != 400 + 16 + 16384 + 64 + feat * 2048 + 2048 + (size_t)2048 * 2304 + 2304) return -1;
+	t->weights_direct = malloc(n * sizeof(float)); memcpy(t->weights_direct, w, n * sizeof(float));
+	t->cnn_input_direct = malloc((size_t)side * side * sizeof(float));
+	t->direct_side = side;
+	return 0;
+}
+void ho_set_cnn_override(ho_tracker *t, const float *y) { t->cnn_override = y; }
+int ho_round_once = 0;
+void ho_set_round_once(int on) { ho_round_once = on; }
 ho_model *ho_model_ptr(ho_tracker *t, int which) { return which ? &t->othermodel : &t->handmodel; }
 int ho_sizeof_tracker(void) { return (int)sizeof(ho_tracker); }
 ho_body *ho_body_ptr(ho_model *m, int b) { return &m->bodies[b]; }
@@ -624,7 +639,8 @@ int ho_update_cnn_model(ho_tracker *t, const uint16_t *depth, const ho_camera *c
 	uint16_t tile[64 * 64];
 	ho_camera scam = *cam;
 	const uint16_t *seg = depth;
-	if (cam->w != 64 || cam->h != 64)
+	const int direct = t->direct_side && cam->w == t->direct_side && cam->h == t->direct_side;      /* the frame is its own segment, as a 64x64 one is for the stock net */
+	if (!direct && (cam->w != 64 || cam->h != 64))
 	{
 		const float c12[12] = { cam->focal.x, cam->focal.y, cam->principal.x, cam->principal.y, cam->depth_scale, cam->pose.position.x, cam->pose.position.y, cam->pose.position.z,
 		                        cam->pose.orientation.x, cam->pose.orientation.y, cam->pose.orientation.z, cam->pose.orientation.w };
@@ -633,10 +649,20 @@ int ho_update_cnn_model(ho_tracker *t, const uint16_t *depth, const ho_camera *c
 		ho_camera_from12(o12, 64, 64, &scam);
 		seg = tile;
 	}
-	ho_camera hcam = scam;   /* camsub(cam,4) misc_image.h:60 */
-	hcam.w = scam.w / 4; hcam.h = scam.h / 4; hcam.focal.x = scam.focal.x / 4.0f; hcam.focal.y = scam.focal.y / 4.0f; hcam.principal.x = scam.principal.x / 4.0f; hcam.principal.y = scam.principal.y / 4.0f;
-	ho_cnn_input(seg, 64 * 64, scam.depth_scale, drx, dry, t->cnn_input);
-	ho_cnn_eval(t->weights, t->cnn_input, t->cnn_output, NULL);
+	const int sub = direct ? cam->w / 16 : 4;
+	ho_camera hcam = scam;   /* camsub(cam,4) misc_image.h:60 (direct: camsub(cam, side/16), 16x16 heat-maps again) */
+	hcam.w = scam.w / sub; hcam.h = scam.h / sub; hcam.focal.x = scam.focal.x / (float)sub; hcam.focal.y = scam.focal.y / (float)sub; hcam.principal.x = scam.principal.x / (float)sub; hcam.principal.y = scam.principal.y / (float)sub;
+	if (direct)
+	{
+		ho_cnn_input(seg, cam->w * cam->h, scam.depth_scale, drx, dry, t->cnn_input_direct);
+		ho_cnn_eval_sized(t->weights_direct, t->direct_side, t->cnn_input_direct, t->cnn_output, NULL);
+	}
+	else
+	{
+		ho_cnn_input(seg, 64 * 64, scam.depth_scale, drx, dry, t->cnn_input);
+		ho_cnn_eval(t->weights, t->cnn_input, t->cnn_output, NULL);
+	}
+	if (t->cnn_override) memcpy(t->cnn_output, t->cnn_override, sizeof(float) * HO_NCNN_OUT);
 	ho_decode(t->cnn_output, &hcam, &t->analysis);
 	f3 *vpts = malloc(sizeof(f3) * cam->w * cam->h);
 	int n = ho_pointcloud(depth, cam, drx, dry, P->subsample_fraction, vpts, cam->w * cam->h, NULL);

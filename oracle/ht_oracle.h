@@ -83,6 +83,8 @@ typedef struct ho_tracker
 	ho_model handmodel, othermodel;
 	ho_body unibody_proto;              /* the 0.1 m cube of UnibodyFit handtrack.h:454-455 */
 	float *weights; size_t nweights;
+	const float *cnn_override;          /* tests: when set, ho_update_cnn_model takes these 2304 values as the net's output instead of evaluating it (isolates the tracker from the CNN's rounding) */
+	int direct_side; float *weights_direct; float *cnn_input_direct;      /* BASELINE configs[4] end to end: the net of ho_set_direct() on the frame itself (ho_update_cnn_model) */
 	float prev_frame_error; int initializing;
 	float cnn_input[4096], cnn_output[HO_NCNN_OUT]; ho_analysis analysis;
 	/* statistics of the last update (for benches/tests) */
@@ -93,6 +95,9 @@ typedef struct ho_tracker
 ho_tracker *ho_create(const char *model_htfx_path);
 void ho_destroy(ho_tracker *t);
 int ho_load_weights(ho_tracker *t, const float *w, size_t n);          /* .cnnb order, cnn.h:590 */
+int ho_set_direct(ho_tracker *t, int side, const float *w, size_t n);   /* side 128: frames of side x side are their own segment, evaluated by the side-sized net (weights in .cnnb order), heat-map camera camsub(cam, side/16); side 0: off */
+void ho_set_round_once(int on);   /* tests: 1 = float sin / cos / acos formed in double and rounded once, as the device forms them (ho_math.h); 0 = glibc's float functions, the reference's */
+void ho_set_cnn_override(ho_tracker *t, const float *cnn_output2304);   /* NULL: off.  The caller keeps the array alive. */
 void ho_default_params(ho_params *p);
 void ho_get_flags(const ho_tracker *t, float *prev_frame_error, int *initializing, int *last_npoints);
 void ho_set_state(ho_tracker *t, int which, const float *state13);      /* which: 0 handmodel 1 othermodel; [nb][13] pos quat linmom angmom */

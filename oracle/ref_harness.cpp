@@ -27,11 +27,15 @@
 //   segment <animbank.pose> <rows,comma> <out.htfx>   320x240 frames and what HandSegmentVR makes of them
 //   bench  <frames.htfx> <seed> <fc2gain> <reps>   reference CPU time for the unit of work
 //   poses  <frames.htfx> <seed> <fc2gain> <out.htfx>   the unit of work on every frame of the file: user poses, othermodel poses, tracker flags
+//   posesfull <frames.htfx> <seed> <fc2gain> <out.htfx>   the same for full-size frames of any size (the tracker segments them) and the staged hand model
 //   dataset_write <dir/> <name>                    DepthDataStreamOut (dataset.h:62-106) writes a three-frame set <dir>/<name>.{json,rs,ir,pose,rgb,feye}
 //   dataset_read <prefix> <bones> <out.htfx>       load_dataset (dataset.h:109-163) reads <prefix>.* ; everything it returns
 //   dataset_header <x.json> <x.pose> <bones> <out.htfx>   DatasetInfo as from_json decodes it and the poses the reference's stream operator reads
 //   cnn128 <frames128.htfx> <idx,comma> <seed> <fc2gain> <out.htfx>   the layer list of PoseInitializerCNN on a 128x128 input (SURVEY 8d config 5 ii),
 //                                                  assembled from the reference's own layer classes, evaluated on frames of a `fullframes` file
+//   e2e128 <frames128.htfx> <idx,comma> <seed> <fc2gain> <out.htfx>   BASELINE configs[4] end to end (SURVEY 8d config 5 i-iii): that net, its decode with
+//                                                  camsub(cam, 8) and the tracker's stages called directly on the 128x128 frame, no segmentation
+//   bench128 <frames128.htfx> <seed> <fc2gain> <reps> [maxframes]    reference CPU time of that unit of work
 //
 #include "/root/reference/include/handtrack.h"
 #include "/root/reference/include/dataset.h"
@@ -824,7 +828,7 @@ static std::vector<Arr> htfx_read(const char *fn)
 // The 128x128-input variant of the pose net (BASELINE configs[4] / SURVEY 8d "config 5 (ii)").  The reference ships one topology (handtrack.h:108-118, 64x64);
 // this is the same list of the reference's OWN layer classes with the dimensions a 128x128 input gives: conv5 -> 124, pool -> 62 -> 31, conv4 -> 28,
 // pool -> 14, FC 12544 -> 2048 -> 2304, chunked softmax.  Weights: our seeded generator with the larger first FC layer, loaded through CNN::loadb.
-static int mode_cnn128(const char *framesfn, const char *idxcsv, uint64_t seed, double gain, const char *outfn)
+static CNN make_cnn128(uint64_t seed, double gain)
 {
 	CNN cnn({});
 	cnn.layers.push_back(new CNN::LConv({ 128,128,1 }, { 5,5,1,16 }, { 124,124,16 }));
@@ -838,12 +842,15 @@ static int mode_cnn128(const char *framesfn, const char *idxcsv, uint64_t seed, 
 	cnn.layers.push_back(new CNN::LActivation<TanH>(16 * 16 * 8));
 	cnn.layers.push_back(new CNN::LFull(16 * 16 * 8, 16 * 16 * 8 + 16 * 16));
 	cnn.layers.push_back(new CNN::LSoftMaxChunked(concat(std::vector<int>(8, 16 * 16), std::vector<int>(16, 16))));
-	{
-		auto w = make_cnnb(seed, gain, 14 * 14 * 64);
-		std::string s((const char*)w.data(), w.size() * sizeof(float));
-		std::istringstream is(s, std::ios::binary);
-		cnn.loadb(is);
-	}
+	auto w = make_cnnb(seed, gain, 14 * 14 * 64);
+	std::string s((const char*)w.data(), w.size() * sizeof(float));
+	std::istringstream is(s, std::ios::binary);
+	cnn.loadb(is);
+	return cnn;      // the layer objects are shared by the copies and never freed (CNN holds plain pointers, cnn.h:100-104)
+}
+static int mode_cnn128(const char *framesfn, const char *idxcsv, uint64_t seed, double gain, const char *outfn)
+{
+	CNN cnn = make_cnn128(seed, gain);
 	auto arrs = htfx_read(framesfn);
 	const Arr *ad = NULL, *ac = NULL;
 	for (auto &a : arrs) { if (a.name == "depth") ad = &a; if (a.name == "cam") ac = &a; }
@@ -879,6 +886,165 @@ static int mode_cnn128(const char *framesfn, const char *idxcsv, uint64_t seed, 
 	}
 	htfx_close(&o.w);
 	printf("cnn128: %d frames -> %s (%.2f ms per CNN::Eval, 1 thread)\n", (int)idx.size(), outfn, ms / (double)idx.size());
+	return 0;
+}
+
+// BASELINE configs[4] END TO END as SURVEY 8(d) "config 5 (i)-(iii)" defines it: a 128x128 frame of the 26-bone hand, the 128x128-input net, its decode and
+// the tracker in ONE unit of work.  HandTracker::update_cnn_model_threadsafe itself (handtrack.h:693-729) cannot run it -- it hands every frame that
+// is not 64x64 to HandSegmentVR and decodes with camsub(cam, 4) -- so its statements are restated here one by one with the reference's own
+// functions: the frame is its own segment (what HandSegmentVR returns for a frame of the net's size, :283-284), the 16x16 heat-map camera is
+// camsub(cam, 8), everything else as written there; then the main-thread passes of HandTracker::update (:769-782) exactly as unit_of_work above.
+static std::vector<Pose> unit_of_work_direct(HandTracker &htk, CNN &net, const Image<unsigned short> &dimage, Out *out = NULL, const std::string &pre = "")
+{
+	const float2 drange = { 0.1f, htk.drangey };
+	auto points = takesubsample(PointCloud(dimage, { 0.1f,htk.drangey }), htk.subsample_fraction, htk.subsample_voxel, htk.subsample_size);      // :753
+	htk.othermodel.SetPose(htk.handmodel.GetPose());      // :757
+	std::vector<Pose> pose;
+	{
+		const Image<unsigned short> &segment = dimage;
+		DCamera hcam = camsub(segment.cam, segment.cam.dim().x / 16);
+		auto cnn_input = Transform(segment, [drange, &segment](unsigned short d) {return (float)clamp(1.0f - (d*segment.cam.depth_scale - drange.x) / (drange.y - drange.x), 0.0f, 1.0f); });      // :700
+		auto cnn_output = net.Eval(cnn_input.raster);
+		auto cnn_output_analysis = CNNOutputAnalysis(cnn_output, hcam);
+		auto vpts = takesubsample(PointCloud(dimage, drange), htk.subsample_fraction);
+		float olderror = FitError(htk.handmodel, vpts, dimage);
+		if (htk.angles_only || olderror > htk.full_reset_on_error)
+		{
+			PoseFromScratch(htk.othermodel, vpts, cnn_output_analysis, segment.cam.pose);
+			for (int i = 0; i < htk.steps_unibody; i++) UnibodyFit(htk.othermodel, vpts, segment.cam.pose.position);
+		}
+		htk.MultiStepSim(htk.othermodel, cnn_output_analysis, vpts, segment.cam.pose);
+		float newerror = FitError(htk.othermodel, vpts, dimage);
+		if (newerror > olderror) htk.prev_frame_error = 0.0f; else htk.prev_frame_error += olderror - newerror;
+		if ((vpts.size() > htk.min_point_num && htk.initializing) || htk.always_take_cnn || htk.angles_only || htk.prev_frame_error > htk.accum_error_threshold) pose = htk.othermodel.GetPose();
+		if (htk.prev_frame_error > htk.accum_error_threshold) htk.prev_frame_error = 0.0f;
+		htk.initializing = std::max(htk.initializing - 1, 0);
+		htk.cnn_input = cnn_input; htk.cnn_output = cnn_output; htk.cnn_output_analysis = cnn_output_analysis;      // update_cnn_model :737-739
+		if (out)
+		{
+			out->f32(pre + "cnn_output", cnn_output);
+			std::vector<float> cr; for (auto &c : cnn_output_analysis.crays) { cr.push_back(c.x); cr.push_back(c.y); cr.push_back(c.z); cr.push_back(c.w); }
+			out->f32(pre + "crays", cr, { (uint32_t)cnn_output_analysis.crays.size(), 4 });
+			out->f32(pre + "vals", cnn_output_analysis.vals);
+			out->f32(pre + "errors", { olderror, newerror, (float)vpts.size(), (float)points.size() });
+			out->state(pre + "uw_other_after_cnn", htk.othermodel);
+			out->f32(pre + "uw_accept", { (float)pose.size(), htk.prev_frame_error, (float)htk.initializing });
+		}
+	}
+	htk.handmodel.SetPose(pose);      // :764 (an empty pose changes nothing, physmodel.h:277-282)
+	for (int i = 0; !htk.angles_only && i < htk.mainthreadpasses; i++)
+	{
+		std::vector<LimitLinear> linears; std::vector<LimitAngular> angulars;
+		HandModelEnhancements(htk.handmodel, angulars, false, float3(0, 0, 0), float3(0, 0, 0), 0);
+		if (points.size() > htk.min_point_num && htk.boundary_planes)
+		{
+			std::vector<float3> outdirs = { float3(-1, -0.25f, 0), float3(-1, -1, 0), float3(0, -1, 0), float3(1, -1, 0), float3(1, -0.25f, 0) };
+			Append(linears, cloud_chamber(htk.handmodel, points, outdirs, { 0,0,0 }, { 0,0,1 }, 10.0f));
+		}
+		htk.handmodel.FitPointCloud(points, linears, angulars, htk.microforce);
+		if (out) out->state(pre + "uw_hand_pass" + std::to_string(i), htk.handmodel);
+	}
+	if (points.size() < htk.min_point_num) htk.initializing = 50;
+	return htk.handmodel.GetPoseUser();
+}
+struct Frames128 { std::vector<Image<unsigned short>> frames; std::vector<std::vector<Pose>> starts; int nb = 0; };
+static bool read_frames128(const char *framesfn, Frames128 &F, int maxframes = 0)
+{
+	auto arrs = htfx_read(framesfn);
+	const Arr *ad = NULL, *ac = NULL, *as = NULL;
+	for (auto &a : arrs) { if (a.name == "depth") ad = &a; if (a.name == "cam") ac = &a; if (a.name == "startpose") as = &a; }
+	if (!ad || !ac || !as || ad->dims[1] != 128 || ad->dims[2] != 128) { fprintf(stderr, "frames file lacks 128x128 depth / cam / startpose\n"); return false; }
+	int n = (int)ad->dims[0]; if (maxframes > 0 && n > maxframes) n = maxframes;
+	F.nb = (int)as->dims[1];
+	for (int i = 0; i < n; i++)
+	{
+		const float *c = (const float*)ac->data.data() + 12 * i;
+		DCamera cam({ 128,128 }, { c[0],c[1] }, { c[2],c[3] }, c[4], Pose({ c[5],c[6],c[7] }, { c[8],c[9],c[10],c[11] }));
+		const unsigned short *d = (const unsigned short*)ad->data.data() + (size_t)128 * 128 * i;
+		F.frames.push_back(Image<unsigned short>(cam, std::vector<unsigned short>(d, d + 128 * 128)));
+		std::vector<Pose> sp(F.nb); const float *s = (const float*)as->data.data() + (size_t)7 * F.nb * i;
+		for (int b = 0; b < F.nb; b++) sp[b] = Pose({ s[7 * b],s[7 * b + 1],s[7 * b + 2] }, { s[7 * b + 3],s[7 * b + 4],s[7 * b + 5],s[7 * b + 6] });
+		F.starts.push_back(sp);
+	}
+	return true;
+}
+// e2e128 <frames128.htfx> <idx,comma> <seed> <fc2gain> <out.htfx>: per-stage dumps of the listed frames (two consecutive updates on the first of them), and
+// under "all/" the results of the unit of work on EVERY frame of the file (user poses, othermodel, flags) for the bench's own verification
+static int mode_e2e128(const char *framesfn, const char *idxcsv, uint64_t seed, double gain, const char *outfn)
+{
+	HandTracker htk;
+	htk.microforce = 3.0f; htk.mainthreadpasses = 3; htk.always_take_cnn = 0;
+	CNN net = make_cnn128(seed, gain);
+	Frames128 F; if (!read_frames128(framesfn, F)) return 2;
+	if ((size_t)F.nb != htk.handmodel.rigidbodies.size()) { fprintf(stderr, "start poses have %d bones, the model %d\n", F.nb, (int)htk.handmodel.rigidbodies.size()); return 2; }
+	std::vector<int> idx; { std::stringstream ss(idxcsv); std::string t; while (std::getline(ss, t, ',')) idx.push_back(atoi(t.c_str())); }
+	Out o; if (htfx_open(&o.w, outfn)) return 2;
+	o.i32("frames", idx); o.f32("weights_seed_gain", { (float)seed, (float)gain });
+	for (size_t k = 0; k < idx.size(); k++)
+	{
+		if (idx[k] < 0 || idx[k] >= (int)F.frames.size()) { fprintf(stderr, "frame index out of range\n"); return 2; }
+		const std::string pre = "f" + std::to_string(k) + "/";
+		reset_tracker(htk, F.starts[idx[k]]);
+		auto pose = unit_of_work_direct(htk, net, F.frames[idx[k]], &o, pre);
+		o.f32(pre + "uw_pose_user", flat(pose), { (uint32_t)F.nb,7 });
+		o.state(pre + "uw_other_final", htk.othermodel);
+		if (k == 0)      // a second update on the carried state (momenta, prev_frame_error, initializing carried over)
+		{
+			auto pose2 = unit_of_work_direct(htk, net, F.frames[idx[k]], &o, pre + "second/");
+			o.f32(pre + "second/uw_pose_user", flat(pose2), { (uint32_t)F.nb,7 });
+		}
+		if (k + 1 == idx.size())      // the same frame from a pose far off (another frame's, translated) with always_take_cnn: the full-reset branch (:706-711) and the accept (:721)
+		{
+			std::vector<Pose> far = F.starts[(idx[k] + F.frames.size() / 2) % F.frames.size()];
+			for (auto &q : far) q.position += float3(0.05f, -0.04f, 0.03f);
+			reset_tracker(htk, far); htk.always_take_cnn = 1;
+			o.f32(pre + "far/startpose", flat(far), { (uint32_t)F.nb,7 });
+			auto pose3 = unit_of_work_direct(htk, net, F.frames[idx[k]], &o, pre + "far/");
+			o.f32(pre + "far/uw_pose_user", flat(pose3), { (uint32_t)F.nb,7 });
+			htk.always_take_cnn = 0;
+		}
+		printf("e2e128 frame %d done\n", idx[k]); fflush(stdout);
+	}
+	std::vector<float> user, other, flags;
+	for (size_t i = 0; i < F.frames.size(); i++)
+	{
+		reset_tracker(htk, F.starts[i]);
+		auto p = unit_of_work_direct(htk, net, F.frames[i]);
+		for (float f : flat(p)) user.push_back(f);
+		for (auto &rb : htk.othermodel.rigidbodies) { for (int c = 0; c < 3; c++) other.push_back(rb.position[c]); for (int c = 0; c < 4; c++) other.push_back(rb.orientation[c]); }
+		flags.push_back(htk.prev_frame_error); flags.push_back((float)htk.initializing);
+	}
+	o.f32("all/uw_pose_user", user, { (uint32_t)F.frames.size(), (uint32_t)F.nb, 7 });
+	o.f32("all/other_pose", other, { (uint32_t)F.frames.size(), (uint32_t)F.nb, 7 });
+	o.f32("all/flags", flags, { (uint32_t)F.frames.size(), 2 });
+	htfx_close(&o.w);
+	return 0;
+}
+// bench128 <frames128.htfx> <seed> <fc2gain> <reps> [maxframes]: reference CPU time of that unit of work (and of the 128x128 net alone)
+static int mode_bench128(const char *framesfn, uint64_t seed, double gain, int reps, int maxframes)
+{
+	HandTracker htk;
+	htk.microforce = 3.0f; htk.mainthreadpasses = 3; htk.always_take_cnn = 0;
+	CNN net = make_cnn128(seed, gain);
+	Frames128 F; if (!read_frames128(framesfn, F, maxframes)) return 2;
+	if ((size_t)F.nb != htk.handmodel.rigidbodies.size()) { fprintf(stderr, "start poses have %d bones, the model %d\n", F.nb, (int)htk.handmodel.rigidbodies.size()); return 2; }
+	const int n = (int)F.frames.size();
+	double best_cnn = 1e30, best_uw = 1e30, checksum = 0;
+	for (int r = 0; r < reps; r++)
+	{
+		auto t0 = std::chrono::steady_clock::now();
+		for (int i = 0; i < n; i++)
+		{
+			float2 drange = { 0.1f, htk.drangey }; auto &seg = F.frames[i];
+			auto in = Transform(seg, [drange, &seg](unsigned short d) {return (float)clamp(1.0f - (d*seg.cam.depth_scale - drange.x) / (drange.y - drange.x), 0.0f, 1.0f); });
+			auto y = net.Eval(in.raster); checksum += y[0];
+		}
+		auto t1 = std::chrono::steady_clock::now();
+		for (int i = 0; i < n; i++) { reset_tracker(htk, F.starts[i]); auto p = unit_of_work_direct(htk, net, F.frames[i]); checksum += p[1].position.x; }
+		auto t2 = std::chrono::steady_clock::now();
+		best_cnn = std::min(best_cnn, std::chrono::duration<double>(t1 - t0).count() / n); best_uw = std::min(best_uw, std::chrono::duration<double>(t2 - t1).count() / n);
+	}
+	printf("{\"frames\": %d, \"reps\": %d, \"cnn_ms\": %.4f, \"cnn_fps\": %.2f, \"frame_ms\": %.4f, \"frame_fps\": %.2f, \"checksum\": %.6f}\n", n, reps, best_cnn * 1e3, 1.0 / best_cnn, best_uw * 1e3, 1.0 / best_uw, checksum);
 	return 0;
 }
 
@@ -963,6 +1129,42 @@ static int mode_poses(const char *framesfn, uint64_t seed, double gain, const ch
 	o.f32("uw_pose_user", user, { (uint32_t)n, 17, 7 });
 	o.f32("other_pose", other, { (uint32_t)n, 17, 7 });
 	o.f32("flags", accept, { (uint32_t)n, 3 });
+	htfx_close(&o.w);
+	return 0;
+}
+
+// posesfull <frames.htfx> <seed> <fc2gain> <out.htfx>: HandTracker's unit of work on every frame of a file of FULL-SIZE frames (any w x h: the tracker segments them
+// itself, handtrack.h:697-698) with whatever hand model is staged -- results only, for the bench's verification of BASELINE configs[4] as the reference runs it
+static int mode_posesfull(const char *framesfn, uint64_t seed, double gain, const char *outfn)
+{
+	HandTracker htk;
+	htk.microforce = 3.0f; htk.mainthreadpasses = 3; htk.always_take_cnn = 0;
+	load_weights(htk, seed, gain);
+	auto arrs = htfx_read(framesfn);
+	const Arr *ad = NULL, *ac = NULL, *as = NULL;
+	for (auto &a : arrs) { if (a.name == "depth") ad = &a; if (a.name == "cam") ac = &a; if (a.name == "startpose") as = &a; }
+	if (!ad || !ac || !as) { fprintf(stderr, "frames file lacks depth/cam/startpose\n"); return 2; }
+	const int n = (int)ad->dims[0], h = (int)ad->dims[1], w = (int)ad->dims[2], nb = (int)as->dims[1];
+	if ((size_t)nb != htk.handmodel.rigidbodies.size()) { fprintf(stderr, "start poses have %d bones, the model %d\n", nb, (int)htk.handmodel.rigidbodies.size()); return 2; }
+	std::vector<float> user, other, flags;
+	for (int i = 0; i < n; i++)
+	{
+		const float *c = (const float*)ac->data.data() + 12 * i;
+		DCamera cam({ w,h }, { c[0],c[1] }, { c[2],c[3] }, c[4], Pose({ c[5],c[6],c[7] }, { c[8],c[9],c[10],c[11] }));
+		const unsigned short *d = (const unsigned short*)ad->data.data() + (size_t)w * h * i;
+		Image<unsigned short> frame(cam, std::vector<unsigned short>(d, d + (size_t)w * h));
+		std::vector<Pose> sp(nb); const float *s = (const float*)as->data.data() + (size_t)7 * nb * i;
+		for (int b = 0; b < nb; b++) sp[b] = Pose({ s[7 * b],s[7 * b + 1],s[7 * b + 2] }, { s[7 * b + 3],s[7 * b + 4],s[7 * b + 5],s[7 * b + 6] });
+		reset_tracker(htk, sp);
+		auto p = unit_of_work(htk, frame);
+		for (float f : flat(p)) user.push_back(f);
+		for (auto &rb : htk.othermodel.rigidbodies) { for (int k = 0; k < 3; k++) other.push_back(rb.position[k]); for (int k = 0; k < 4; k++) other.push_back(rb.orientation[k]); }
+		flags.push_back(htk.prev_frame_error); flags.push_back((float)htk.initializing);
+	}
+	Out o; if (htfx_open(&o.w, outfn)) return 3;
+	o.f32("uw_pose_user", user, { (uint32_t)n, (uint32_t)nb, 7 });
+	o.f32("other_pose", other, { (uint32_t)n, (uint32_t)nb, 7 });
+	o.f32("flags", flags, { (uint32_t)n, 2 });
 	htfx_close(&o.w);
 	return 0;
 }
@@ -1054,10 +1256,13 @@ int main(int argc, char **argv) try
 	if (mode == "voxel" && a.size() == 7) return mode_voxel(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), atof(a[4].c_str()), atoi(a[5].c_str()), a[6].c_str());
 	if (mode == "golden" && a.size() == 5) return mode_golden(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());
 	if (mode == "cnn128" && a.size() == 5) return mode_cnn128(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());
+	if (mode == "e2e128" && a.size() == 5) return mode_e2e128(a[0].c_str(), a[1].c_str(), strtoull(a[2].c_str(), 0, 0), atof(a[3].c_str()), a[4].c_str());
+	if (mode == "bench128" && a.size() >= 4) return mode_bench128(a[0].c_str(), strtoull(a[1].c_str(), 0, 0), atof(a[2].c_str()), atoi(a[3].c_str()), a.size() > 4 ? atoi(a[4].c_str()) : 0);
 	if (mode == "dataset_write" && a.size() == 2) return mode_dataset_write(a[0].c_str(), a[1].c_str());
 	if (mode == "dataset_read" && a.size() == 3) return mode_dataset_read(a[0].c_str(), atoi(a[1].c_str()), a[2].c_str());
 	if (mode == "dataset_header" && a.size() == 4) return mode_dataset_header(a[0].c_str(), a[1].c_str(), atoi(a[2].c_str()), a[3].c_str());
 	if (mode == "poses" && a.size() == 4) return mode_poses(a[0].c_str(), strtoull(a[1].c_str(), 0, 0), atof(a[2].c_str()), a[3].c_str());
+	if (mode == "posesfull" && a.size() == 4) return mode_posesfull(a[0].c_str(), strtoull(a[1].c_str(), 0, 0), atof(a[2].c_str()), a[3].c_str());
 	if (mode == "bench" && a.size() >= 4) return mode_bench(a[0].c_str(), strtoull(a[1].c_str(), 0, 0), atof(a[2].c_str()), atoi(a[3].c_str()), a.size() > 4 ? atoi(a[4].c_str()) : 0);
 	fprintf(stderr, "bad arguments\n");
 	return 1;

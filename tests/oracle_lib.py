@@ -91,6 +91,9 @@ def lib():
         L.ho_create.restype = C.c_void_p; L.ho_create.argtypes = [C.c_char_p]
         L.ho_destroy.argtypes = [C.c_void_p]
         L.ho_load_weights.argtypes = [C.c_void_p, fp, C.c_size_t]; L.ho_load_weights.restype = C.c_int
+        L.ho_set_round_once.argtypes = [C.c_int]; L.ho_set_round_once.restype = None
+        L.ho_set_cnn_override.argtypes = [C.c_void_p, fp]; L.ho_set_cnn_override.restype = None
+        L.ho_set_direct.argtypes = [C.c_void_p, C.c_int, fp, C.c_size_t]; L.ho_set_direct.restype = C.c_int
         L.ho_set_state.argtypes = [C.c_void_p, C.c_int, fp]; L.ho_get_state.argtypes = [C.c_void_p, C.c_int, fp]
         L.ho_set_pose.argtypes = [C.c_void_p, C.c_int, fp]; L.ho_reset_tracker.argtypes = [C.c_void_p, fp]
         L.ho_get_flags.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]; L.ho_get_flags.restype = None

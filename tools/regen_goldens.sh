@@ -67,9 +67,12 @@ HT_REF_MODEL_JSON=$T/model_hand26.json $H config5 $BANK 0,300,912,1500 $SEED $GA
 HT_REF_MODEL_JSON=$T/model_hand26.json $H fullframes $BANK 3 36 64 128,128,163 $T/frames5.htfx
 # the 128x128-input net of SURVEY 8(d) config 5 (ii), built from the reference's own layer classes, on four of those 128x128 frames
 $H cnn128 $T/frames5.htfx 0,9,33,60 $SEED $GAIN $T/cnn128.htfx
+# BASELINE configs[4] end to end (SURVEY 8d config 5 i-iii): that net, its decode and the tracker's stages on the 128x128 frame in one unit of work; per-stage dumps
+# of four frames (a second update, a far-off start with always_take_cnn = the reset branch and the accept) and the results for all 64 frames of the bench input
+HT_REF_MODEL_JSON=$T/model_hand26.json $H e2e128 $T/frames5.htfx 0,9,33,60 $SEED $GAIN $T/e2e128.htfx
 
 rc=0
-for f in model_hand17 model_hand26 model_chain3 golden8 poses256 voxel4 scale115 slowfit3 train3 fullframe320 fullframe320close fullframe5 config5 cnn128; do
+for f in model_hand17 model_hand26 model_chain3 golden8 poses256 voxel4 scale115 slowfit3 train3 fullframe320 fullframe320close fullframe5 config5 cnn128 e2e128; do
 	if cmp -s $T/$f.htfx $G/$f.htfx; then echo "identical  $f.htfx"; else echo "DIFFERENT  $f.htfx"; rc=1; fi
 	[ $WRITE = 1 ] && cp $T/$f.htfx $G/$f.htfx
 done
