@@ -14,9 +14,10 @@ configs[3] (65536 frames over 8 GPUs) is `--gpus 8 --frames-per-gpu 8192`.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP-event timed on the
 stream it runs on) and `cpu_baseline` (the reference's own code from oracle/_ref when present, else the C oracle port).
-The first eight tracker slots of rank 0 carry the frames of tests/golden/golden8.htfx; after the timed loop their poses
-are compared with what the reference produced for them (`verified`), so a number from a build that computes something
-else is reported as such.  Tuning switches of the library (HT_DEBUG_SKIP, HT_NO_SIDE, HT_NO_OVERLAP) make the run refuse.
+The batch is 1024 DISTINCT animation-bank frames (tests/golden/frames1024.npz, row (3 + 9 i) mod 2336: SURVEY 8d config 2;
+larger batches repeat them, every rank starts at another offset); after the timed loop EVERY distinct frame of rank 0's
+batch is compared with what the reference itself produced for it (tests/golden/poses1024.htfx, `verified`), so a number
+from a build that computes something else is reported as such.  Tuning switches of the library (HT_DEBUG_SKIP, HT_NO_SIDE, HT_NO_OVERLAP) make the run refuse.
 """
 import argparse
 import glob
@@ -47,7 +48,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames-per-gpu", type=int, default=1024)
-    ap.add_argument("--workload", default="cnn+solver", choices=["cnn+solver", "cnn", "config5", "config5-cnn128"])
+    ap.add_argument("--workload", default="cnn+solver", choices=["cnn+solver", "cnn", "config5", "config5-cnn128", "config5-e2e"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the pose gather even with one rank")
     return ap.parse_args(argv)
@@ -64,23 +65,55 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def _tile(a, n):
+def _tile(a, n, first=0):
     import numpy as np
-    reps = (n + len(a) - 1) // len(a)
-    return np.concatenate([a] * reps)[:n]
+    idx = (first + np.arange(n)) % len(a)
+    return a[idx]
 
 
-def _load_frames(n):
+def _load_frames(n, first=0):
+    """BASELINE configs[2]: 1024 distinct 64x64 frames (animation-bank row (3 + 9 i) mod 2336, tools/regen_goldens.sh), repeated for larger batches, from frame `first` on"""
     import numpy as np
-    z = np.load(os.path.join(ROOT, "tests", "golden", "frames256.npz"))
-    return (_tile(z["depth"].reshape(-1, 4096), n).astype(np.uint16), _tile(z["cam"], n).astype(np.float32), _tile(z["startpose"], n).astype(np.float32))
+    z = np.load(os.path.join(ROOT, "tests", "golden", "frames1024.npz"))
+    return (_tile(z["depth"].reshape(-1, 4096), n, first).astype(np.uint16), _tile(z["cam"], n, first).astype(np.float32), _tile(z["startpose"], n, first).astype(np.float32))
 
 
-def _load_frames5(n):
-    """BASELINE configs[4]: 128x128 frames of the 26-bone hand (tests/golden/make_frames5.py), tiled"""
+def _load_frames5(n, first=0):
+    """BASELINE configs[4]: 64 distinct 128x128 frames of the 26-bone hand (tests/golden/make_frames5.py), repeated"""
     import numpy as np
     z = np.load(os.path.join(ROOT, "tests", "golden", "frames5_64.npz"))
-    return (_tile(z["depth"], n).astype(np.uint16), _tile(z["cam"], n).astype(np.float32), _tile(z["startpose"], n).astype(np.float32))
+    return (_tile(z["depth"], n, first).astype(np.uint16), _tile(z["cam"], n, first).astype(np.float32), _tile(z["startpose"], n, first).astype(np.float32))
+
+
+def _reference_poses(which):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import htfx
+    if which == "cnn+solver":
+        return htfx.load(os.path.join(ROOT, "tests", "golden", "poses1024.htfx"))["uw_pose_user"], "tests/golden/poses1024.htfx (the reference's unit of work on every frame, ref_harness poses)"
+    if which == "config5":
+        return htfx.load(os.path.join(ROOT, "tests", "golden", "poses5full.htfx"))["uw_pose_user"], "tests/golden/poses5full.htfx (the reference's HandTracker on the 128x128 frames, 26 bones, ref_harness posesfull)"
+    return htfx.load(os.path.join(ROOT, "tests", "golden", "e2e128.htfx"))["all/uw_pose_user"], "tests/golden/e2e128.htfx all/ (the reference's stage functions and layer classes, ref_harness e2e128)"
+
+
+def verify_poses(got, ref, idx, against):
+    """Every distinct frame of the timed batch against the reference's result for it.  Tight band 2e-5 m / 2e-4, loose band 2e-4 m / 2e-3 (tests/test_gpu_solver.py);
+    the device solver is one more floating-point build of the reference's algorithm (Jacobian-form rows, tests/test_gpu_exact_solver.py pins that as its only
+    difference), and the reference's own FMA-contracted builds leave 1-2 % of these frames outside the tight band and up to 0.5 % outside the loose one
+    (profiles/r04_reference_build_spread.json): verified = no more than 3 % / 1 % of the frames outside, and a median at rounding level."""
+    import numpy as np
+    first = {}
+    for slot, i in enumerate(idx):
+        first.setdefault(int(i), slot)
+    fr = np.array(sorted(first)); sl = np.array([first[i] for i in fr])
+    g, r = got[sl], ref[fr]
+    dp = np.abs(g[:, :, :3] - r[:, :, :3]).max(axis=(1, 2))
+    dq = np.minimum(np.abs(g[:, :, 3:] - r[:, :, 3:]), np.abs(g[:, :, 3:] + r[:, :, 3:])).max(axis=(1, 2))
+    n = len(fr)
+    tight = int(((dp <= 2e-5) & (dq <= 2e-4)).sum()); loose = int(((dp <= VERIFY_POS_TOL) & (dq <= VERIFY_QUAT_TOL)).sum())
+    ok = bool(tight >= n - max(2, int(0.03 * n)) and loose >= n - max(1, int(0.01 * n)) and float(np.median(dp)) <= 2e-6 and float(np.median(dq)) <= 4e-5)
+    return {"verified": ok, "against": against, "frames_compared": int(n), "within_2e-5m_2e-4": tight, "within_2e-4m_2e-3": loose,
+            "median_abs_dpos_m": float(np.median(dp)), "median_abs_dquat": float(np.median(dq)), "max_abs_dpos_m": float(dp.max()), "max_abs_dquat": float(dq.max()),
+            "worst_frame": int(fr[int(np.argmax(dp))]), "tol": [VERIFY_POS_TOL, VERIFY_QUAT_TOL]}
 
 
 def _golden8():
@@ -121,6 +154,33 @@ def cpu_baseline_config5(depth, cams, start, seed, gain):
     o.close()
     return {"value": 1.0 / best, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": "%d frames x 2 reps (best), C oracle -O2 -ffp-contract=off: HandSegmentVR + update_cnn_model + 3 passes, 26 bones" % nsample}
+
+
+def cpu_baseline_e2e128(depth, cams, start, seed, gain):
+    """BASELINE configs[4] end to end on the host: the reference's own stage functions and layer classes in the order of handtrack.h:693-785 (ref_harness bench128),
+    26-bone model in the reference's schema; one thread, the IEEE build the fixture comes from and the reference Makefile's -Ofast."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "ref_harness"); mj = os.path.join(ROOT, "oracle", "_ref", "model_hand26.json")
+    if not (os.path.exists(ref_bin) and os.path.exists(mj)):
+        return None
+    nsample = min(48, len(depth))
+    env = dict(os.environ); env["HT_REF_MODEL_JSON"] = mj
+    with tempfile.TemporaryDirectory() as td:
+        fn = os.path.join(td, "frames.htfx")
+        _write_htfx(fn, {"depth": depth[:nsample].reshape(-1, 128, 128), "cam": cams[:nsample], "startpose": start[:nsample]})
+        def one(binary):
+            out = subprocess.run([binary, "bench128", fn, hex(seed), str(gain), "2"], capture_output=True, text=True, timeout=900, env=env)
+            return json.loads(out.stdout.strip().splitlines()[-1])
+        r = one(ref_bin)
+        res = {"value": r["frame_fps"], "unit": "frames/s", "cores": 1, "kind": "reference", "cnn_only_fps": r["cnn_fps"],
+               "sample": "%d frames x 2 reps (best), reference headers built -O2 -ffp-contract=off: the 128x128-input net (the reference's layer classes), CNNOutputAnalysis with camsub(cam, 8), "
+                         "FitError / MultiStepSim / accept and 3 FitPointCloud passes on the 26-bone model, stages called directly (ref_harness bench128)" % nsample}
+        if os.path.exists(ref_bin + "_ofast"):
+            try:
+                f = one(ref_bin + "_ofast")
+                res["ofast"] = {"value": f["frame_fps"], "cnn_only_fps": f["cnn_fps"], "flags": "-Ofast -march=x86-64-v3 (timing only)"}
+            except Exception as e:
+                sys.stderr.write("-Ofast reference baseline unavailable (%s)\n" % e)
+        return res
 
 
 def cpu_baseline_cnn128(x, w128):
@@ -299,16 +359,21 @@ def main():
     B = args.frames_per_gpu
     seed, gain = W.DEFAULT_SEED, W.DEFAULT_FC2_GAIN
     wl = args.workload
-    cfg5 = wl == "config5"
+    e2e = wl == "config5-e2e"
+    cfg5 = wl in ("config5", "config5-e2e")
     cnn_only = wl in ("cnn", "config5-cnn128")
     cnn128 = wl == "config5-cnn128"
+    frames5 = cfg5 or cnn128
 
-    # contiguous shard of the global frame list for this rank (frames differ across ranks through the tiling offset)
-    depth_all, cams_all, start_all = (_load_frames5 if (cfg5 or cnn128) else _load_frames)(B * world)
-    sl = slice(*shard_range(B * world, rank, world))
-    depth, cams, start = depth_all[sl].copy(), cams_all[sl].copy(), start_all[sl].copy()
+    # this rank's contiguous shard of the global frame list [rank * B, (rank + 1) * B); the global list walks the distinct frames round and round, every rank's
+    # shard starting 131 frames further on ("same generators, different animbank offsets"), so ranks do not work on identical batches
+    ndistinct = 64 if frames5 else 1024
+    lo, hi = shard_range(B * world, rank, world)
+    first = (lo + 131 * rank) % ndistinct
+    depth, cams, start = (_load_frames5 if frames5 else _load_frames)(hi - lo, first)
+    frame_idx = (first + np.arange(hi - lo)) % ndistinct      # which distinct frame every slot carries
     gold = None
-    if rank == 0 and wl in ("cnn+solver", "cnn") and B >= 8:      # slots 0..7: the frames the reference's results are committed for
+    if rank == 0 and wl == "cnn" and B >= 8:      # slots 0..7: the frames the reference's heat-maps are committed for
         gold = _golden8()
         for f in range(8):
             depth[f] = gold["f%d/depth" % f].reshape(-1); cams[f] = gold["f%d/cam" % f]; start[f] = gold["f%d/startpose" % f]
@@ -316,7 +381,8 @@ def main():
     # the product's own baked model (hand_tracking_samples_amd/assets/: ht_model_bake of the reference's model_hand.json, tools/bake_assets.sh); the fixtures
     # under tests/golden/ are what the REFERENCE's constructor built and only check it (tests/test_model_build.py: identical bit for bit)
     ctx = native.Context(os.path.join(ROOT, "hand_tracking_samples_amd", "assets", "model_hand26.htfx" if cfg5 else "model_hand17.htfx"), B, device=local)
-    ctx.load_weights(W.make_cnnb(seed, gain))
+    if not e2e:
+        ctx.load_weights(W.make_cnnb(seed, gain))
     ctx.set_params(microforce=3.0, mainthreadpasses=3)        # synthetic-tracker.cpp:91-93
     d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
     d_cams = torch.from_numpy(cams).to(dev)
@@ -332,15 +398,19 @@ def main():
     if use_dist and not cnn_only:
         # every rank goes through the same collectives whatever fails locally: rank 0 makes the id (byte 128 = "valid"), everybody receives it, everybody tries to
         # join, and the ranks then agree (MIN) on whether all of them did
+        # (ncclCommInitRank blocks until every rank has arrived: a rank that cannot even load RCCL must be found out BEFORE anybody enters it)
+        avail = torch.tensor([1 if native.comm_available() else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(avail, op=dist.ReduceOp.MIN)
+        all_have_rccl = int(avail.item()) == 1
         uid = torch.zeros(129, dtype=torch.uint8, device=dev)
-        if rank == 0:
+        if rank == 0 and all_have_rccl:
             try:
                 uid[:128].copy_(torch.frombuffer(bytearray(native.comm_unique_id()), dtype=torch.uint8))
                 uid[128] = 1
             except Exception as e:
                 sys.stderr.write("rank 0: RCCL unique id unavailable (%s)\n" % e)
         dist.broadcast(uid, 0)
-        joined, why = 0, "rank 0 could not make an RCCL unique id"
+        joined, why = 0, ("rank 0 could not make an RCCL unique id" if all_have_rccl else "RCCL cannot be loaded on every rank")
         if int(uid[128].item()) == 1:
             try:
                 ctx.comm_init(world, rank, bytes(uid[:128].cpu().numpy().tobytes()))
@@ -362,6 +432,8 @@ def main():
     stream = torch.cuda.current_stream(dev)
 
     w128 = x128 = None
+    if e2e:
+        ctx.load_weights128(W.make_cnnb128(seed, gain))
     if cnn128:
         w128 = W.make_cnnb128(seed, gain)
         ctx.load_weights128(w128)
@@ -384,6 +456,8 @@ def main():
             ctx.cnn128_eval_dev(d_cnn_in.data_ptr(), d_cnn_out.data_ptr(), B, stream.cuda_stream)
         elif wl == "cnn":
             ctx.cnn_eval_dev(d_cnn_in.data_ptr(), d_cnn_out.data_ptr(), B, stream.cuda_stream)
+        elif e2e:
+            ctx.update_direct_dev(d_depth.data_ptr(), d_cams.data_ptr(), 128, d_start.data_ptr(), B, d_poses.data_ptr(), stream.cuda_stream)
         elif cfg5:
             ctx.update_frames_dev(d_depth.data_ptr(), d_cams.data_ptr(), 128, 128, 0.17, d_start.data_ptr(), B, d_poses.data_ptr(), stream.cuda_stream)
         else:
@@ -415,31 +489,27 @@ def main():
         elapsed = float(tmax.item())
     prof = ctx.profile_read(reset=True)
 
-    # ---- the timed steps' own output against the reference's committed results (rank 0, slots 0..7) ----
+    # ---- the timed steps' own output against the reference's committed results: every distinct frame of rank 0's batch ----
     verify = None
-    if gold is not None and args.steps > 0:
-        if wl == "cnn":
+    if rank == 0 and args.steps > 0:
+        if wl == "cnn" and gold is not None:
             got = d_cnn_out[:8].cpu().numpy()
             dc = float(max(np.abs(got[f] - gold["f%d/cnn_output" % f]).max() for f in range(8)))
-            verify = {"verified": bool(dc <= VERIFY_CNN_TOL), "against": "tests/golden/golden8.htfx cnn_output (reference)", "max_abs_dcnn": dc, "tol": VERIFY_CNN_TOL}
-        else:
-            got = d_poses[:8].cpu().numpy()
-            dp = float(max(np.abs(got[f][:, :3] - gold["f%d/uw_pose_user" % f][:, :3]).max() for f in range(8)))
-            dq = float(max(np.abs(got[f][:, 3:] - gold["f%d/uw_pose_user" % f][:, 3:]).max() for f in range(8)))
-            verify = {"verified": bool(dp <= VERIFY_POS_TOL and dq <= VERIFY_QUAT_TOL), "against": "tests/golden/golden8.htfx uw_pose_user (reference), slots 0-7 of the timed batch",
-                      "max_abs_dpos_m": dp, "max_abs_dquat": dq, "tol": [VERIFY_POS_TOL, VERIFY_QUAT_TOL]}
+            verify = {"verified": bool(dc <= VERIFY_CNN_TOL), "against": "tests/golden/golden8.htfx cnn_output (reference), slots 0-7 of the timed batch", "max_abs_dcnn": dc, "tol": VERIFY_CNN_TOL}
+        elif cnn128:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as ol
+            ref = ol.cnn128_eval(w128, x128[:4])
+            dc = float(np.abs(d_cnn_out[:4].cpu().numpy() - ref).max())
+            verify = {"verified": bool(dc <= VERIFY_CNN_TOL), "against": "C oracle of the 128x128 net (pinned on the reference's layer classes), frames 0-3 of the timed batch", "max_abs_dcnn": dc, "tol": VERIFY_CNN_TOL}
+        elif not cnn_only:
+            refp, against = _reference_poses(wl)
+            verify = verify_poses(d_poses.cpu().numpy(), refp, frame_idx, against)
+            verify["capacity_events"] = list(ctx.capacity_events())
+            if wl == "config5":
+                verify["frames_overflow"] = ctx.frames_overflow()
             if use_dist:
                 verify["gather_consistent"] = bool(torch.equal(gathered[rank * B:(rank + 1) * B], d_poses))
-        if not cnn_only:
-            verify["capacity_events"] = list(ctx.capacity_events())
-    elif cnn128 and rank == 0:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib as ol
-        ref = ol.cnn128_eval(w128, x128[:4])
-        dc = float(np.abs(d_cnn_out[:4].cpu().numpy() - ref).max())
-        verify = {"verified": bool(dc <= VERIFY_CNN_TOL), "against": "C oracle of the 128x128 net (pinned on the reference's layer classes), frames 0-3 of the timed batch", "max_abs_dcnn": dc, "tol": VERIFY_CNN_TOL}
-    elif cfg5 and rank == 0:
-        verify = {"verified": None, "capacity_events": list(ctx.capacity_events()), "frames_overflow": ctx.frames_overflow(), "note": "parity of this workload: tests/test_fullframe.py, tests/test_config5.py"}
 
     # phase table from a second, untimed pass with every phase bracketed (this serialises the side streams)
     ctx.profile_enable(2)
@@ -453,7 +523,7 @@ def main():
     if rank == 0:
         total_frames = B * world * args.steps
         value = total_frames / elapsed
-        flop_cnn = CNN_FLOP["cnn128" if cnn128 else "cnn"]
+        flop_cnn = CNN_FLOP["cnn128" if (cnn128 or e2e) else "cnn"]
         # dominant kernel of the workload by HIP-event time
         phases = {k: v for k, v in prof.items() if v[1] > 0}
         if cnn_only:
@@ -499,9 +569,10 @@ def main():
             roof = {"kernel": "cnn (k_conv1+k_conv2+k_fc x2+k_softmax_decode)", "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                     "frac": round(achieved / FP32_MFMA_PEAK_TF, 5), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": phases[dom][1], "flop_per_frame": flop_cnn}
         cnn_roof = None
-        if "cnn" in all_phases and dom != "cnn":
-            avg_ms = all_phases["cnn"][0] / all_phases["cnn"][1]
-            ach = CNN_FLOP["cnn"] * B / (avg_ms * 1e-3) / 1e12
+        cnn_phase = "cnn128" if "cnn128" in all_phases else "cnn"
+        if cnn_phase in all_phases and dom != cnn_phase:
+            avg_ms = all_phases[cnn_phase][0] / all_phases[cnn_phase][1]
+            ach = CNN_FLOP[cnn_phase] * B / (avg_ms * 1e-3) / 1e12
             cnn_roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 5), "avg_ms": round(avg_ms, 4)}
         shard_note = ("; layout of BASELINE configs[3] (contiguous shard per GPU, RCCL all-gather of the poses inside the timed step; configs[3] itself = --gpus 8 --frames-per-gpu 8192)"
                       if world > 1 else "")
@@ -511,6 +582,9 @@ def main():
             "cnn": ("synthetic depth frames/sec (CNN forward only), 64x64x1 input", "BASELINE configs[1]: %d frames per GPU, CNN forward only" % B),
             "config5": ("synthetic depth frames/sec (segmentation+CNN+solver), 128x128x1 input, 26-bone hand",
                         "BASELINE configs[4]: %d independent 128x128 frames per GPU, HandTracker::update on full frames (HandSegmentVR + CNN + 5-step MultiStepSim + 3 FitPointCloud passes), 26 bones%s" % (B, shard_note)),
+            "config5-e2e": ("synthetic depth frames/sec (CNN+solver), 128x128x1 input, 26-bone hand",
+                            "BASELINE configs[4] end to end (SURVEY 8d config 5 i-iii): %d independent 128x128 frames per GPU, the 128x128-input net (conv5x5 @124, conv4x4 @28, FC 12544->2048->2304) -> CNNOutputAnalysis(camsub 8) -> "
+                            "FitError / reset / 5-step MultiStepSim / accept -> 3 FitPointCloud passes (GJK + PGS), 26 bones, no segmentation%s" % (B, shard_note)),
             "config5-cnn128": ("synthetic depth frames/sec (CNN forward only), 128x128x1 input",
                                "BASELINE configs[4], CNN part at full input size (SURVEY 8d config 5 ii): %d frames per GPU, conv5x5 1->16 @124, 2x pool, conv4x4 16->64 @28, pool, FC 12544->2048->2304, chunked softmax" % B),
         }
@@ -518,7 +592,8 @@ def main():
             "metric": workloads[wl][0],
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (%d software-rendered animbank frames tiled; seeded weights 0x5EED0001)" % (64 if (cfg5 or cnn128) else 256),
+            "dtype": "f32", "data": ("synthetic (%d distinct software-rendered animbank frames%s; seeded weights 0x5EED0001)"
+                                      % (min(ndistinct, B * world), "" if B * world <= ndistinct else ", each %d times in the global batch" % ((B * world + ndistinct - 1) // ndistinct))),
             "config": {"workload": workloads[wl][1], "frames_per_gpu": B, "global_frames_per_step": B * world,
                        "parallelism": ("frames sharded per GPU, RCCL all-gather of poses" if not cnn_only else "frames sharded per GPU, no exchange") if world > 1 else "single GPU"},
             **({"gather": gather_impl} if gather_impl else {}),
@@ -537,7 +612,7 @@ def main():
             if cnn128:
                 out["cpu_baseline"] = cpu_baseline_cnn128(x128, w128)
             else:
-                out["cpu_baseline"] = (cpu_baseline_config5 if cfg5 else cpu_baseline)(depth, cams, start, seed, gain)
+                out["cpu_baseline"] = (cpu_baseline_e2e128 if e2e else cpu_baseline_config5 if cfg5 else cpu_baseline)(depth, cams, start, seed, gain)
                 if wl == "cnn" and "cnn_only_fps" in out["cpu_baseline"]:
                     out["cpu_baseline"]["frame_fps_cnn_plus_solver"] = out["cpu_baseline"]["value"]
                     out["cpu_baseline"]["value"] = out["cpu_baseline"].pop("cnn_only_fps")

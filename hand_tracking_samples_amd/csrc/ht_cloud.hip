@@ -11,6 +11,7 @@
 // coefficients arrive through scalar loads and every active lane does the same 6 flops per plane; the sphere cull of
 // physmodel.h:153 is a per-lane predicate.  Body poses are expanded once per block into an LDS table (lane b <-> body b).
 // All arithmetic keeps the reference's evaluation order (-ffp-contract=off), so rows are bit-identical to the CPU path.
+#include <mutex>
 #include "ht_device.hpp"
 #include "ht_launch.hpp"
 #include <string.h>
@@ -901,7 +902,9 @@ void ht_launch_reset(const ht_model_dev &M, const ht_physics_dev &ph, float *sta
 	const size_t solve = (size_t)(UB_LDS_ROWS + QUAD_CHAIN_SLACK) * (CREC * sizeof(float) + sizeof(float) + sizeof(unsigned short));
 	const size_t dyn = cloud > solve ? cloud : solve;
 	static size_t attr_set[64];               // per device: the attribute belongs to the device's copy of the code object
+	static std::mutex attr_lock;              // contexts of several host threads may launch at the same time: the limit is raised before anybody launches with it
 	int dev = 0; (void)hipGetDevice(&dev); dev &= 63;
+	std::unique_lock<std::mutex> lk(attr_lock);
 	if (attr_set[dev] < dyn)
 	{
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_reset<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
@@ -909,6 +912,7 @@ void ht_launch_reset(const ht_model_dev &M, const ht_physics_dev &ph, float *sta
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_reset<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
 		attr_set[dev] = dyn;
 	}
+	lk.unlock();
 	const bool two = !list || many_frames;
 	const int grid = B < (two ? 2 : 1) * n_cu ? B : (two ? 2 : 1) * n_cu;
 	if (exact)      // tests only (ht_debug_solver_build 5)

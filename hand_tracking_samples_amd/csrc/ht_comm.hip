@@ -10,6 +10,7 @@
 // do not wait for it; the caller double-buffers its pose arrays and calls ht_gather_wait(slot) before it reuses a buffer.
 #include <dlfcn.h>
 #include <string.h>
+#include <mutex>
 #include "ht_device.hpp"
 #include "ht_host.hpp"
 
@@ -30,16 +31,18 @@ struct rccl_api
 	const char *(*GetErrorString)(int) = nullptr;
 	std::string err;
 };
-rccl_api &rccl()
+rccl_api &rccl()      // loaded once, under std::call_once: contexts of several host threads may ask at the same time
 {
 	static rccl_api a;
-	if (a.lib || !a.err.empty()) return a;
-	for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) { a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (a.lib) break; }
-	if (!a.lib) { a.err = std::string("RCCL is not available: ") + dlerror(); return a; }
-#define SYM(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.lib, name)); if (!a.field) { a.err = std::string("librccl lacks ") + name; return a; }
-	SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy"); SYM(CommCount, "ncclCommCount");
-	SYM(CommUserRank, "ncclCommUserRank"); SYM(AllGather, "ncclAllGather"); SYM(GetErrorString, "ncclGetErrorString");
+	static std::once_flag once;
+	std::call_once(once, [] {
+		for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) { a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (a.lib) break; }
+		if (!a.lib) { const char *e = dlerror(); a.err = std::string("RCCL is not available: ") + (e ? e : "dlopen failed"); return; }
+#define SYM(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.lib, name)); if (!a.field) { a.err = std::string("librccl lacks ") + name; return; }
+		SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy"); SYM(CommCount, "ncclCommCount");
+		SYM(CommUserRank, "ncclCommUserRank"); SYM(AllGather, "ncclAllGather"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+	});
 	return a;
 }
 int fail(ht_ctx *ctx, const char *what, int rc) { ctx->err = std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "RCCL error"); return HT_ERR_HIP; }
@@ -51,6 +54,9 @@ struct ht_comm_state
 	hipStream_t stream = nullptr; hipEvent_t ready = nullptr, done[2] = { nullptr, nullptr }; bool pending[2] = { false, false };
 };
 
+// 1 when RCCL can be loaded on this host (every symbol the gather needs resolved), else 0: what the ranks of a job agree on BEFORE any of them enters
+// ncclCommInitRank, which blocks until all ranks have arrived -- a rank that cannot load the library would otherwise leave the others waiting
+extern "C" int ht_comm_available(void) { const rccl_api &r = rccl(); return r.lib && r.err.empty() ? 1 : 0; }
 extern "C" int ht_comm_unique_id(void *id128)
 {
 	if (!id128) return HT_ERR_ARG;
@@ -94,6 +100,8 @@ extern "C" int ht_gather_poses_dev(ht_ctx *ctx, const float *d_local, float *d_a
 	ht_device_guard guard(ctx->device);
 	ht_comm_state *c = ctx->comm;
 	hipStream_t s = ht_user_stream(ctx, stream);
+	// a slot whose previous gather nobody waited for: the caller is about to overwrite a buffer pair the exchange may still be reading; this gather waits for it
+	if (c->pending[slot] && hipStreamWaitEvent(c->stream, c->done[slot], 0) != hipSuccess) { ctx->err = "ht_gather_poses_dev: cannot order the gather behind the previous use of its slot"; return HT_ERR_HIP; }
 	if (hipEventRecord(c->ready, s) != hipSuccess || hipStreamWaitEvent(c->stream, c->ready, 0) != hipSuccess) { ctx->err = "ht_gather_poses_dev: cannot order the gather behind the update"; return HT_ERR_HIP; }
 	const int rc = rccl().AllGather(d_local, d_all, (size_t)frames * ctx->model.nb * HT_POSE, 7 /* ncclFloat32 */, c->comm, c->stream);
 	if (rc != 0) return fail(ctx, "ncclAllGather", rc);
@@ -101,15 +109,26 @@ extern "C" int ht_gather_poses_dev(ht_ctx *ctx, const float *d_local, float *d_a
 	c->pending[slot] = true;
 	return HT_OK;
 }
-// makes `stream` wait for the gather last issued with `slot` (stream NULL: the calling thread waits)
+// makes `stream` wait for the gather last issued with `slot`; a NULL stream means the context's own stream, as in every other *_dev entry point.
+// ht_gather_wait_host: the calling thread waits instead.  Either way the slot counts as waited for.
 extern "C" int ht_gather_wait(ht_ctx *ctx, int slot, void *stream)
 {
 	if (!ctx || slot < 0 || slot > 1) return HT_ERR_ARG;
 	if (!ctx->comm || !ctx->comm->pending[slot]) return HT_OK;
 	ht_device_guard guard(ctx->device);
-	const hipError_t e = stream ? hipStreamWaitEvent((hipStream_t)stream, ctx->comm->done[slot], 0) : hipEventSynchronize(ctx->comm->done[slot]);
+	const hipError_t e = hipStreamWaitEvent(ht_user_stream(ctx, stream), ctx->comm->done[slot], 0);
 	if (e != hipSuccess) { ctx->err = std::string("ht_gather_wait: ") + hipGetErrorString(e); return HT_ERR_HIP; }
-	if (!stream) ctx->comm->pending[slot] = false;
+	ctx->comm->pending[slot] = false;
+	return HT_OK;
+}
+extern "C" int ht_gather_wait_host(ht_ctx *ctx, int slot)
+{
+	if (!ctx || slot < 0 || slot > 1) return HT_ERR_ARG;
+	if (!ctx->comm || !ctx->comm->pending[slot]) return HT_OK;
+	ht_device_guard guard(ctx->device);
+	const hipError_t e = hipEventSynchronize(ctx->comm->done[slot]);
+	if (e != hipSuccess) { ctx->err = std::string("ht_gather_wait_host: ") + hipGetErrorString(e); return HT_ERR_HIP; }
+	ctx->comm->pending[slot] = false;
 	return HT_OK;
 }
 extern "C" int ht_comm_destroy(ht_ctx *ctx)

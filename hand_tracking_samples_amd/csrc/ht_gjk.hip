@@ -30,6 +30,7 @@
 // A second exact shortcut: dot(w,v)/|v| is a lower bound of the distance between the shapes and the separation the reference
 // finally reports is never below it, so once the bound exceeds the contact cut-off the pair cannot produce a contact.
 #include <stdlib.h>
+#include <mutex>
 #include "ht_device.hpp"
 #include "ht_launch.hpp"
 
@@ -1175,7 +1176,9 @@ void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftma
 	int *caps = reinterpret_cast<int *>(epa_ws);
 	const int dbg = ht_tuning_flags();
 	static bool attr_set[64];                 // per device: the attribute belongs to the device's copy of the code object
+	static std::mutex attr_lock;              // contexts of several host threads (one per GPU) may launch at the same time
 	int dev = 0; (void)hipGetDevice(&dev); dev &= 63;
+	std::unique_lock<std::mutex> lk(attr_lock);
 	if (!attr_set[dev])
 	{
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_contacts<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1183,20 +1186,18 @@ void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftma
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_contacts_coop), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		attr_set[dev] = true;
 	}
+	lk.unlock();
 	// Which organisation: the cooperative kernel (a CU per block: 152 KB of LDS, 249 VGPRs) whenever a frame of the model fits its LDS beside the padded vertex
 	// copy.  Whole steps on one device, cooperative against lane-per-pair: 1536 frames 7.57 against 7.64 ms, 2048 frames 8.46 / 8.56, 4096 frames 14.74 / 14.96,
 	// 8192 frames 27.00 / 27.57 (tools/exp_coop_max.sh; until the polytope and the frame-to-block assignment were reworked in round 3 the lane-per-pair kernel won
 	// above ~1100 frames because its smaller blocks run beside the cloud-row kernel).  force_kernel (ht_debug_contact_kernel): 1 cooperative, 2 lane-per-pair.
-	static int coop_max = -1;
-	if (coop_max < 0)
-	{
-		coop_max = 1 << 30;
+	static const int coop_max = [] {      // read once, when the first launch gets here (a C++11 static: thread-safe)
 #ifdef HT_TUNING
-		if (const char *e = getenv("HT_CONTACTS_COOP_MAX")) coop_max = atoi(e);
+		if (const char *e = getenv("HT_CONTACTS_COOP_MAX")) return atoi(e);
 #endif
-	}
-	static int main_lanes = -1;
-	if (main_lanes < 0) main_lanes = ht_tuning_int("HT_CONTACTS_MAIN_LANES", 0);
+		return 1 << 30;
+	}();
+	static const int main_lanes = ht_tuning_int("HT_CONTACTS_MAIN_LANES", 0);
 	const size_t coop_fixed = (size_t)M.cvert_off[M.nb] * sizeof(float4) + sizeof(co_block) + (size_t)CO_OWN * 64 * 2 * (sizeof(co_req) + sizeof(int)) + CO_EPAQ * sizeof(co_job) + CO_NW * gjk_wave_stride();
 	const bool coop_fits = coop_fixed + sizeof(co_frame) <= 160 * 1024;
 	if (force_kernel == 1 ? coop_fits : (force_kernel != 2 && coop_fits && B <= coop_max && !(beside_cloud_rows && main_lanes)))

@@ -53,6 +53,7 @@ struct ht_ctx
 	// many-frames organisation (two reset blocks per CU, four frames per contact block) instead of the few-frames one.  A hint only: both are always correct.
 	unsigned *d_nreset = nullptr; volatile unsigned *h_nreset = nullptr;      // [2]: frames that reset, updates that counted them
 	unsigned nreset_seen[2] = { 0, 0 }; bool many_reset = false, tail_pending = false; int n_cu = 256;
+	int last_reset_many = -1;       // which organisation the latest update launched the reset branch in (ht_debug_reset_organisation): 0 few frames, 1 many
 	float *d_rows = nullptr; int *d_nrows = nullptr;            // cloud rows [B][pts_cap][HT_ROW] in the reference's layout (stage calls, UnibodyFit, caller-built rows)
 	unsigned char *d_rowbody = nullptr;                          // [B][pts_cap] body of every cloud row whose solver record k_cloud_rows wrote into d_scratch
 	float *d_chamber = nullptr; int *d_nchamber = nullptr;      // [B][5*nb][HT_ROW]

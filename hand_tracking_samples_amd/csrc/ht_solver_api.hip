@@ -141,6 +141,7 @@ static void reset_tail_join(ht_ctx *ctx, hipStream_t s) { if (ctx->tail_pending)
 static void reset_path(ht_ctx *ctx, bool listed, int n_unibody, int B, hipStream_t s, hipStream_t prof_stream, bool many_frames = false)      // listed: the frames of d_flist; otherwise all
 {
 	ht_prof_scope ps(ctx, "reset_path", prof_stream, true);
+	if (listed) ctx->last_reset_many = many_frames ? 1 : 0;
 	ht_launch_reset(ctx->model, ctx->phys, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_analysis, ctx->d_cams, listed ? ctx->d_flist : nullptr, listed ? ctx->d_nflist : nullptr, n_unibody, ctx->par,
 	                ctx->d_rows, ctx->d_nrows, ctx->d_scratch, scratch_stride(ctx), ctx->B, B, s, many_frames, ctx->n_cu, exact_solver(ctx));
 }
@@ -225,7 +226,7 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_old, B, t, &dec);      // with the reset decision (handtrack.h:706)
 	}
 	{
-		ht_prof_scope ps(ctx, "cnn", s, true);
+		ht_prof_scope ps(ctx, (fs && fs->direct) ? "cnn128" : "cnn", s, true);
 		if (fs && fs->direct) ht_launch_cnn(ctx->cnnw128, ctx->d_in128, ctx->d_act1_128, ctx->d_act2_128, ctx->d_act3, ctx->d_logits, B, s, fs->direct);
 		else ht_launch_cnn(ctx->cnnw, ctx->d_cnn_in, ctx->d_act1, ctx->d_act2, ctx->d_act3, ctx->d_logits, B, s);
 		ht_launch_softmax_decode(ctx->d_logits, cnn_out, ctx->d_cams, ctx->d_analysis, 1, B, s, (fs && fs->direct) ? fs->direct / 16 : 4);
@@ -704,6 +705,14 @@ extern "C" int ht_debug_solver_build(ht_ctx *ctx, int which)
 	ctx->solver_build = which;
 	return HT_OK;
 }
+// Tests only: which organisation the latest update launched the full-reset branch in (0 = few frames: one k_reset block per CU, a contact block per reset frame;
+// 1 = many frames: two blocks per CU, four frames per contact block; -1 = no update yet).  The choice follows the count of reset frames of earlier updates.
+extern "C" int ht_debug_reset_organisation(ht_ctx *ctx, int *many)
+{
+	if (!ctx || !many) return HT_ERR_ARG;
+	*many = ctx->last_reset_many;
+	return HT_OK;
+}
 // Tests only: pins the organisation of the contact kernel (0 = the launcher's choice; 1 cooperative, 2 lane-per-pair).  Same arithmetic, same contacts in the same order.
 extern "C" int ht_debug_contact_kernel(ht_ctx *ctx, int which)
 {
@@ -773,23 +782,27 @@ extern "C" int ht_segment_vr(ht_ctx *ctx, const uint16_t *depth, const float *ca
 // (physics.h:543-587) take rows the CALLER built.  Row layouts are those of the stage calls: a linear row is 16 floats (rb0 rb1 position0[3]
 // position1[3] normal[3] targetdist targetspeednobias forcelimit.x forcelimit.y friction_master), an angular row 8 (rb0 rb1 axis[3] targetspin
 // mintorque maxtorque); a body is its index in PhysModel::rigidbodies, -1 = NULL.
+static void drop_alloc(ht_ctx *ctx, void *o) { if (!o) return; for (auto &q : ctx->allocs) if (q == o) { q = ctx->allocs.back(); ctx->allocs.pop_back(); break; } (void)hipFree(o); }
 static int user_rows_reserve(ht_ctx *ctx, int lin_cap, int ang_cap)
 {
+	// the replacement is allocated FIRST: when an allocation fails the context keeps its old, valid arrays and capacities
 	if (lin_cap > ctx->user_lin_cap)
 	{
 		HIPCHK(ctx, ht_sync_all(ctx));
-		for (void *o : { (void *)ctx->d_user_lin, (void *)ctx->d_user_pos }) if (o) { for (auto &q : ctx->allocs) if (q == o) { q = ctx->allocs.back(); ctx->allocs.pop_back(); break; } (void)hipFree(o); }
 		void *a = nullptr, *b = nullptr;
-		HIPCHK(ctx, hipMalloc(&a, (size_t)ctx->B * lin_cap * HT_ROW * sizeof(float))); ctx->allocs.push_back(a); ctx->d_user_lin = (float *)a;
-		HIPCHK(ctx, hipMalloc(&b, (size_t)ctx->B * lin_cap * sizeof(unsigned short))); ctx->allocs.push_back(b); ctx->d_user_pos = (unsigned short *)b;
+		HIPCHK(ctx, hipMalloc(&a, (size_t)ctx->B * lin_cap * HT_ROW * sizeof(float)));
+		if (hipMalloc(&b, (size_t)ctx->B * lin_cap * sizeof(unsigned short)) != hipSuccess) { (void)hipFree(a); ctx->err = "caller-built rows: out of device memory"; return HT_ERR_HIP; }
+		drop_alloc(ctx, ctx->d_user_lin); drop_alloc(ctx, ctx->d_user_pos);
+		ctx->allocs.push_back(a); ctx->d_user_lin = (float *)a; ctx->allocs.push_back(b); ctx->d_user_pos = (unsigned short *)b;
 		ctx->user_lin_cap = lin_cap;
 	}
 	if (ang_cap > ctx->user_ang_cap)
 	{
 		HIPCHK(ctx, ht_sync_all(ctx));
-		if (ctx->d_user_ang) { for (auto &q : ctx->allocs) if (q == (void *)ctx->d_user_ang) { q = ctx->allocs.back(); ctx->allocs.pop_back(); break; } (void)hipFree(ctx->d_user_ang); }
 		void *a = nullptr;
-		HIPCHK(ctx, hipMalloc(&a, (size_t)ctx->B * ang_cap * HT_AROW * sizeof(float))); ctx->allocs.push_back(a); ctx->d_user_ang = (float *)a;
+		HIPCHK(ctx, hipMalloc(&a, (size_t)ctx->B * ang_cap * HT_AROW * sizeof(float)));
+		drop_alloc(ctx, ctx->d_user_ang);
+		ctx->allocs.push_back(a); ctx->d_user_ang = (float *)a;
 		ctx->user_ang_cap = ang_cap;
 	}
 	if (!ctx->d_user_n) { void *a = nullptr; HIPCHK(ctx, hipMalloc(&a, (size_t)4 * ctx->B * sizeof(int))); ctx->allocs.push_back(a); ctx->d_user_n = (int *)a; }

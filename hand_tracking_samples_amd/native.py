@@ -22,8 +22,8 @@ SYMBOLS = (
     "ht_model_open", "ht_model_close", "ht_model_error", "ht_model_counts", "ht_model_body", "ht_model_body_mesh", "ht_model_hitcheck",
     "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_update_frames_sync", "ht_update_frames_dev", "ht_update_direct_sync", "ht_update_direct_dev", "ht_update_cnn_model_sync", "ht_get_cnn_results", "ht_get_cnn_layers", "ht_frames_overflow", "ht_reserve_points", "ht_point_capacity", "ht_capacity_events", "ht_segment_vr", "ht_segment_vr_dev", "ht_slowfit", "ht_set_points", "ht_fit_rows", "ht_physics_update",
     "ht_stage_prepare", "ht_stage_decode", "ht_stage_fit_error", "ht_stage_cloud_rows", "ht_stage_contacts", "ht_stage_fit",
-    "ht_stage_multistep", "ht_stage_scratch_unibody", "ht_stage_chamber", "ht_profile_enable", "ht_profile_read", "ht_debug_solve_stats", "ht_debug_contact_stats", "ht_debug_solver_build", "ht_debug_contact_kernel",
-    "ht_comm_unique_id", "ht_comm_init", "ht_comm_info", "ht_gather_poses_dev", "ht_gather_wait", "ht_comm_destroy",
+    "ht_stage_multistep", "ht_stage_scratch_unibody", "ht_stage_chamber", "ht_profile_enable", "ht_profile_read", "ht_debug_solve_stats", "ht_debug_contact_stats", "ht_debug_solver_build", "ht_debug_reset_organisation", "ht_debug_contact_kernel",
+    "ht_comm_available", "ht_comm_unique_id", "ht_comm_init", "ht_comm_info", "ht_gather_poses_dev", "ht_gather_wait", "ht_gather_wait_host", "ht_comm_destroy",
 )
 
 
@@ -111,12 +111,15 @@ def load(build_if_missing=True):
     L.ht_profile_read.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_int, fp, ip, ip]
     L.ht_debug_solve_stats.argtypes = [vp, C.c_int, fp, C.c_int]
     L.ht_debug_solver_build.argtypes = [vp, C.c_int]
+    L.ht_debug_reset_organisation.argtypes = [vp, ip]
     L.ht_debug_contact_kernel.argtypes = [vp, C.c_int]
     L.ht_comm_unique_id.argtypes = [vp]
     L.ht_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.ht_comm_info.argtypes = [vp, ip, ip]
     L.ht_gather_poses_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
     L.ht_gather_wait.argtypes = [vp, C.c_int, vp]
+    L.ht_gather_wait_host.argtypes = [vp, C.c_int]
+    L.ht_comm_available.argtypes = []
     L.ht_comm_destroy.argtypes = [vp]
     L.ht_debug_contact_stats.argtypes = [vp, C.c_int, fp, C.c_int]
     for name in SYMBOLS:
@@ -440,8 +443,18 @@ class Context:
     def gather_wait(self, slot, stream=None):
         self._chk(self.L.ht_gather_wait(self.h, int(slot), C.c_void_p(stream or 0)))
 
+    def debug_reset_organisation(self):
+        """0 / 1: the latest update launched the full-reset branch in its few-frames / many-frames organisation; -1 before the first update"""
+        m = C.c_int(-1)
+        self._chk(self.L.ht_debug_reset_organisation(self.h, C.byref(m)))
+        return m.value
+
+    def gather_wait_host(self, slot):
+        self._chk(self.L.ht_gather_wait_host(self.h, int(slot)))
+
     def debug_solver_build(self, which):
-        """Test aid: pin k_solve's build (0 auto, 1 small, 2 only, 3 mid, 4 tiny = every row array in HBM).  Placement only, results identical."""
+        """Test aid: pin k_solve's build (0 auto, 1 small, 2 only, 3 mid, 4 tiny = every row array in HBM: placement only, results identical; 5 = the exact-order
+        instantiation: the reference's own sweeps, tests/test_gpu_exact_solver.py)."""
         self._chk(self.L.ht_debug_solver_build(self.h, int(which)))
 
     def debug_contact_kernel(self, which):
@@ -486,6 +499,11 @@ class Context:
         w = np.empty(9458400, np.float32)
         self._chk(self.L.ht_cnn_get_weights(self.h, _f(w), w.size))
         return w
+
+
+def comm_available():
+    """True when RCCL can be loaded on this host (ht_comm_available): agreed on by all ranks before any of them calls comm_init."""
+    return load().ht_comm_available() == 1
 
 
 def comm_unique_id():

@@ -289,9 +289,14 @@ int ht_physics_update(ht_ctx *ctx, int which, int B, const float *linears, int l
  * ht_comm_info        what the communicator itself reports: ranks and this rank's number (ncclCommCount / ncclCommUserRank).
  * ht_gather_poses_dev one ncclAllGather of d_local [frames][nb][7] into d_all [world][frames][nb][7] (device pointers), on the context's communication
  *                     stream behind everything enqueued on `stream` so far: the next step's kernels do not wait for it.  slot (0 / 1) names which of the
- *                     caller's two buffer pairs the call uses; ht_gather_wait(ctx, slot, stream) makes `stream` (NULL: the calling thread) wait for
- *                     that slot's gather before the pair is reused or read.
+ *                     caller's two buffer pairs the call uses; ht_gather_wait(ctx, slot, stream) makes `stream` (NULL: the context's own stream, as everywhere)
+ *                     wait for that slot's gather before the pair is reused or read, ht_gather_wait_host(ctx, slot) the calling thread.  A gather issued
+ *                     into a slot whose previous gather was never waited for is ordered behind it.
+ * ht_comm_available   1 when RCCL can be loaded here.  ncclCommInitRank blocks until every rank has arrived, so the ranks of a job agree on this (a MIN
+ *                     over the host program's own channel) BEFORE any of them calls ht_comm_init; a rank without the library then cannot strand the others.
  * ht_comm_destroy     leaves the communicator (ht_destroy does it too). */
+int ht_comm_available(void);
+int ht_gather_wait_host(ht_ctx *ctx, int slot);
 int ht_comm_unique_id(void *id128);
 int ht_comm_init(ht_ctx *ctx, int world, int rank, const void *id128);
 int ht_comm_info(ht_ctx *ctx, int *world, int *rank);
@@ -311,6 +316,10 @@ int ht_debug_contact_stats(ht_ctx *ctx, int B, float *out, int reset);      /* s
 /* Test aid: pins which build of the solver kernel runs (0 = chosen per launch; 1-3 the LDS sizes for tile batches / small batches / large frames and models;
  * 4 = a build whose LDS arrays hold nothing, so every frame places its row records in HBM).  Placement only: results are identical bit for bit. */
 int ht_debug_solver_build(ht_ctx *ctx, int which);
+/* Test aid: 5 additionally selects the EXACT-ORDER instantiation of the solver -- the same rows swept by the reference's own LimitLinear::Iter / LimitAngular::Iter
+ * (physics.h:251-265, 289-307) in the reference's row order, no fused multiply-adds (update entry points only; tests/test_gpu_exact_solver.py).
+ * ht_debug_reset_organisation: how the latest update launched the full-reset branch (0 few frames, 1 many frames, -1 none yet). */
+int ht_debug_reset_organisation(ht_ctx *ctx, int *many);
 /* Test aid: pins the organisation of the contact kernel (0 = chosen per launch: the cooperative kernel whenever the model fits its LDS; 1 cooperative,
  * 2 one lane group per body pair).  Same contacts in the same order either way. */
 int ht_debug_contact_kernel(ht_ctx *ctx, int which);

@@ -1,14 +1,16 @@
-"""Whole unit of work (CNN + decode + MultiStepSim + accept + 3 FitPointCloud passes) on a batch of the bench's own frames,
-device against the REFERENCE frame by frame: tests/golden/poses256.htfx holds what the reference's own code (IEEE build, oracle/ref_harness.cpp
-`poses`) returns for each of the 256 bench frames; the C restatement reproduces all of them bit for bit (test_oracle_vs_golden.py).  The frames
-cover the data-dependent branches (chamber on/off at 400 points, full reset, CNN pose accepted / rejected).
+"""Whole unit of work (CNN + decode + MultiStepSim + accept + 3 FitPointCloud passes) on the bench's own 1024 distinct frames, device against the
+REFERENCE frame by frame: tests/golden/poses1024.htfx holds what the reference's own code (IEEE build, oracle/ref_harness.cpp `poses`) returns for each of
+them; the C restatement reproduces them bit for bit (test_oracle_vs_golden.py on the first 256).  The frames cover the data-dependent branches (chamber
+on/off at 400 points, full reset, CNN pose accepted / rejected).
 
-Tolerance.  The device evaluates the reference's algorithm in another association order: the CNN accumulates on MFMA tiles (heat-maps differ by
-~1e-6) and the solver applies each constraint row in Jacobian form with fused multiply-adds (csrc/ht_quad.hpp).  Where that flips no discrete
-decision (closest bone, arg-max, accept / reject, GJK branch) the poses agree to 2e-5 m / 2e-4; a flipped decision changes a pose visibly, so the
-test bounds how often that happens instead of hiding it behind a loose tolerance.  The yardstick is the reference itself: built with FMA
-contraction instead of IEEE (tests/golden/ref_flag_spread.py, profiles/r03_reference_build_spread.json) it keeps 254 of these 256 frames within
-2e-5 m / 2e-4 and 255 within 2e-4 m / 2e-3 (worst 4.1e-4 m / 6.3e-3); built -Ofast, as its own Makefile does, only 15 / 108."""
+Tolerance, and what it is held against.  tests/test_gpu_exact_solver.py shows that the device path IS the reference's computation once its solver sweeps
+are the reference's own: bit for bit on every frame.  The product's sweeps apply the same rows in the same order in Jacobian form with fused multiply-adds
+(csrc/ht_quad.hpp): one more floating-point BUILD of the algorithm, like the reference compiled with FMA contraction.  How far a frame moves under such a
+change is a property of the frame -- a few frames sit next to a discrete decision (closest bone of a point, a contact appearing) and amplify a rounding
+difference a thousandfold, in every build.  tests/golden/ref_spread1024.npz holds, per frame, how far the reference's own two FMA-contracted builds move
+from its IEEE build (tests/golden/ref_flag_spread.py; summary profiles/r04_reference_build_spread.json: 1017 / 1014 of 1024 frames within 2e-5 m / 2e-4,
+1020 / 1019 within 2e-4 m / 2e-3, worst 4.1e-4 m / 9.2e-3).  The device has to do at least as well, frame by frame: a frame may leave the tight band only if
+the reference's own builds leave it there too, and then by no more than twice what they do."""
 import ctypes as C
 import os
 
@@ -31,29 +33,44 @@ def _diff(got, ref):
 
 def test_batch_against_reference(weights):
     from hand_tracking_samples_amd import native
-    d = np.load(os.path.join(HERE, "golden", "frames256.npz"))
-    refp = htfx.load(os.path.join(HERE, "golden", "poses256.htfx"))
-    depth, cams, start = d["depth"].reshape(N, -1), d["cam"], d["startpose"]
-    ctx = native.Context(ol.MODEL, N)
+    n = 1024
+    d = np.load(os.path.join(HERE, "golden", "frames1024.npz"))
+    refp = htfx.load(os.path.join(HERE, "golden", "poses1024.htfx"))
+    spread = np.load(os.path.join(HERE, "golden", "ref_spread1024.npz"))
+    depth, cams, start = d["depth"].reshape(n, -1), d["cam"], d["startpose"]
+    ctx = native.Context(ol.MODEL, n)
     ctx.load_weights(weights)
     ctx.set_params(microforce=3.0, mainthreadpasses=3)
     ctx.tracker_reset(start)
     got = ctx.update_sync(depth, cams)
-    pfe, ini = ctx.tracker_flags(N)
+    other = ctx.get_state(1, n)[:, :, :7]
+    pfe, ini = ctx.tracker_flags(n)
+    assert ctx.capacity_events() == (0, 0, 0)
     ctx.close()
-    ref = refp["uw_pose_user"]
-    dp, dq = _diff(got, ref)
-    tight = (dp <= 2e-5) & (dq <= 2e-4)
-    loose = (dp <= 2e-4) & (dq <= 2e-3)
-    print("vs reference: frames exact %d, within 2e-5 m / 2e-4: %d, within 2e-4 m / 2e-3: %d of %d; |dpos| p50 %.1e p99 %.1e max %.2e m, |dquat| p50 %.1e p99 %.1e max %.2e (worst frame %d)"
-          % (int(((dp == 0) & (dq == 0)).sum()), int(tight.sum()), int(loose.sum()), N, np.percentile(dp, 50), np.percentile(dp, 99), dp.max(),
-             np.percentile(dq, 50), np.percentile(dq, 99), dq.max(), int(dp.argmax())))
-    # the reference's own FMA-contracted build: 254 tight, 255 loose, worst 4.1e-4 m / 6.3e-3 (module docstring)
-    assert tight.sum() >= N - 4, "frames outside 2e-5 m / 2e-4: %s" % np.nonzero(~tight)[0]
-    assert loose.sum() >= N - 2, "frames outside 2e-4 m / 2e-3: %s" % np.nonzero(~loose)[0]
+    dp, dq = _diff(got, refp["uw_pose_user"])
+    sp = np.maximum(spread["fma_on_user_dpos"], spread["fma_fast_user_dpos"]); sq = np.maximum(spread["fma_on_user_dquat"], spread["fma_fast_user_dquat"])      # the frame's sensitivity: the reference's own FMA builds
+    tight = (dp <= 2e-5) & (dq <= 2e-4); loose = (dp <= 2e-4) & (dq <= 2e-3)
+    ref_tight = (sp <= 2e-5) & (sq <= 2e-4)
+    print("vs reference, %d frames: exact %d, within 2e-5 m / 2e-4: %d (the reference's FMA builds: %d / %d), within 2e-4 m / 2e-3: %d (%d / %d); |dpos| p50 %.1e p99 %.1e max %.2e m, |dquat| p50 %.1e p99 %.1e max %.2e"
+          % (n, int(((dp == 0) & (dq == 0)).sum()), int(tight.sum()),
+             int(((spread["fma_on_user_dpos"] <= 2e-5) & (spread["fma_on_user_dquat"] <= 2e-4)).sum()), int(((spread["fma_fast_user_dpos"] <= 2e-5) & (spread["fma_fast_user_dquat"] <= 2e-4)).sum()), int(loose.sum()),
+             int(((spread["fma_on_user_dpos"] <= 2e-4) & (spread["fma_on_user_dquat"] <= 2e-3)).sum()), int(((spread["fma_fast_user_dpos"] <= 2e-4) & (spread["fma_fast_user_dquat"] <= 2e-3)).sum()),
+             np.percentile(dp, 50), np.percentile(dp, 99), dp.max(), np.percentile(dq, 50), np.percentile(dq, 99), dq.max()))
+    for i in np.nonzero(~tight)[0]:
+        print("  frame %4d leaves the tight band: device %.2e m / %.2e, the reference's own FMA builds %.2e m / %.2e (sensitivity rank %d of %d)" % (i, dp[i], dq[i], sp[i], sq[i], int((sq > sq[i]).sum()), n))
+    # (1) frame by frame: outside the tight band only where the reference's own rebuilds are, and by no more than twice their move
+    assert not (~tight & ref_tight).any(), "frames that move on the device but not between the reference's own builds: %s" % np.nonzero(~tight & ref_tight)[0]
+    assert (dp[~tight] <= 2 * sp[~tight]).all() and (dq[~tight] <= 2 * sq[~tight]).all()
+    # (2) in sum: at least as many frames in either band as the better of the reference's FMA builds, medians at rounding level
+    assert tight.sum() >= max(int(((spread[b + "_user_dpos"] <= 2e-5) & (spread[b + "_user_dquat"] <= 2e-4)).sum()) for b in ("fma_on", "fma_fast"))
+    assert loose.sum() >= max(int(((spread[b + "_user_dpos"] <= 2e-4) & (spread[b + "_user_dquat"] <= 2e-3)).sum()) for b in ("fma_on", "fma_fast"))
     assert np.median(dp) <= 1e-6 and np.median(dq) <= 2e-5
-    assert dp.max() < 5e-3      # even a flipped decision stays a small pose change on these frames
-    # the tracker's discrete state after the frame: `initializing` (handtrack.h:781) on every frame
+    # (3) othermodel -- the CNN-driven pose, hard-driven through MultiStepSim from the MFMA-accumulated heat-maps: its distribution against the reference's own rebuilds
+    do = np.maximum(*_diff(other, refp["other_pose"]))
+    so = np.maximum(np.maximum(spread["fma_on_other_dpos"], spread["fma_fast_other_dpos"]), np.maximum(spread["fma_on_other_dquat"], spread["fma_fast_other_dquat"]))
+    print("  othermodel (CNN-driven): device p50 %.1e p90 %.1e p99 %.1e; the reference's FMA builds p50 %.1e p90 %.1e p99 %.1e" % (*np.percentile(do, [50, 90, 99]), *np.percentile(so, [50, 90, 99])))
+    assert (np.percentile(do, [50, 90, 99]) <= 2 * np.percentile(so, [50, 90, 99])).all()
+    # (4) the tracker's discrete state after the frame: `initializing` (handtrack.h:781) on every frame
     assert np.array_equal(ini, refp["flags"][:, 1].astype(np.int32))
 
 
@@ -144,11 +161,13 @@ def test_many_frames_through_the_reset_branch(weights):
     try:
         ctx.load_weights(weights)
         ctx.set_params(microforce=3.0, mainthreadpasses=3, full_reset_on_error=0.0)
-        out = []
+        out = []; org = []
         for _ in range(3):
             ctx.tracker_reset(start)
             out.append(ctx.update_sync(depth, cams))
+            org.append(ctx.debug_reset_organisation())
         assert ctx.capacity_events() == (0, 0, 0)
+        assert org[0] == 0 and org[2] == 1, org      # the many-frames organisation was really taken by the third update (its counts arrive asynchronously: the second may see them or not)
     finally:
         ctx.close()
     assert np.isfinite(out[0]).all()

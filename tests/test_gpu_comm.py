@@ -35,7 +35,7 @@ def test_gather_through_the_library_on_one_rank(golden, weights):
             ctx.gather_wait(k, s)
             ctx.update_dev(d_depth.data_ptr(), d_cams.data_ptr(), d_start.data_ptr(), nf, local[k].data_ptr(), s)
             ctx.gather_poses_dev(local[k].data_ptr(), allp[k].data_ptr(), nf, k, s)
-        ctx.gather_wait(0); ctx.gather_wait(1)      # host waits
+        ctx.gather_wait_host(0); ctx.gather_wait_host(1)
         torch.cuda.synchronize()
         for k in range(2):
             assert torch.equal(local[k], allp[k])

@@ -79,3 +79,28 @@ def test_exact_order_solver_reproduces_the_restatement_bit_for_bit_on_all_256_fr
         assert np.array_equal(flags[u], fl[u])
     # the reset branch (UnibodyFit's single-body solves) was among them
     assert (REF["flags"][:, 0] == 0).any()
+
+
+def test_exact_order_solver_on_config5_end_to_end_26_bones():
+    """The same statement for BASELINE configs[4] end to end (tests/test_config5_e2e.py): 128x128 frames, the 128x128-input net, 26 bones -- 325 body pairs, two
+    chain rounds per sweep, the cloned fingers in permanent contact (15 expanding-polytope runs per frame).  Exact-order sweeps: bit for bit on all 64 frames."""
+    from hand_tracking_samples_amd import native
+    fr = np.load(os.path.join(HERE, "golden", "frames5_64.npz"))
+    model26 = os.path.join(HERE, "golden", "model_hand26.htfx")
+    w128 = W.make_cnnb128()
+    n = len(fr["depth"])
+    ctx = native.Context(model26, n)
+    try:
+        ctx.load_weights128(w128)
+        ctx.set_params(microforce=3.0, mainthreadpasses=3)
+        ctx.debug_solver_build(5)
+        ctx.tracker_reset(fr["startpose"])
+        poses, cnn = ctx.update_direct_sync(fr["depth"], fr["cam"], 128, want_cnn=True)
+        others = ctx.get_state(1, n); hands = ctx.get_state(0, n)
+        assert ctx.capacity_events() == (0, 0, 0)
+    finally:
+        ctx.close()
+    user, other, hand, _ = _restatement_with_cnn(None, [cnn], updates=1, model=model26, depth=fr["depth"], cams=fr["cam"], start=fr["startpose"], wh=(128, 128), direct=(128, w128))
+    bad = [i for i in range(n) if not (np.array_equal(others[i], other[0, i]) and np.array_equal(hands[i], hand[0, i]) and np.array_equal(poses[i], user[0, i]))]
+    print("config 5 end to end, exact-order solver against the restatement given the device's CNN output: %d of %d frames differ" % (len(bad), n))
+    assert not bad, bad

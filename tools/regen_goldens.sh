@@ -34,6 +34,9 @@ $H golden $BANK 0,16,144,1584,2224,912,1504,2048 $SEED $GAIN $T/golden8.htfx
 $H frames $BANK 3 9 256 $T/frames256.htfx
 # the reference's result of the whole unit of work on every one of those 256 frames (user poses, othermodel poses, tracker flags)
 $H poses $T/frames256.htfx $SEED $GAIN $T/poses256.htfx
+# the bench's batch: 1024 DISTINCT frames, rows (3 + 9 i) mod 2336 (the first 256 are the set above), and the reference's results for all of them
+$H frames $BANK 3 9 1024 $T/frames1024.htfx
+$H poses $T/frames1024.htfx $SEED $GAIN $T/poses1024.htfx
 # the optional voxel sub-sampling of the main-thread cloud (handtrack.h:535-536): 1 cm voxels, min_point_num 20
 $H voxel $BANK 0,912,2224,1504 $SEED $GAIN 0.01 20 $T/voxel4.htfx
 # on-disk dataset formats (dataset.h): a three-frame set written by the reference's DepthDataStreamOut, what its load_dataset returns for it, and the
@@ -65,6 +68,7 @@ $H fullframe $BANK 1504,2048 320,240,900 $SEED $GAIN $T/fullframe320close.htfx  
 HT_REF_MODEL_JSON=$T/model_hand26.json $H fullframe $BANK 0,300,912,1500 128,128,163 $SEED $GAIN $T/fullframe5.htfx
 HT_REF_MODEL_JSON=$T/model_hand26.json $H config5 $BANK 0,300,912,1500 $SEED $GAIN $T/config5.htfx
 HT_REF_MODEL_JSON=$T/model_hand26.json $H fullframes $BANK 3 36 64 128,128,163 $T/frames5.htfx
+HT_REF_MODEL_JSON=$T/model_hand26.json $H posesfull $T/frames5.htfx $SEED $GAIN $T/poses5full.htfx      # the reference's HandTracker on all 64 of them (bench.py --workload config5 verifies against it)
 # the 128x128-input net of SURVEY 8(d) config 5 (ii), built from the reference's own layer classes, on four of those 128x128 frames
 $H cnn128 $T/frames5.htfx 0,9,33,60 $SEED $GAIN $T/cnn128.htfx
 # BASELINE configs[4] end to end (SURVEY 8d config 5 i-iii): that net, its decode and the tracker's stages on the 128x128 frame in one unit of work; per-stage dumps
@@ -72,7 +76,7 @@ $H cnn128 $T/frames5.htfx 0,9,33,60 $SEED $GAIN $T/cnn128.htfx
 HT_REF_MODEL_JSON=$T/model_hand26.json $H e2e128 $T/frames5.htfx 0,9,33,60 $SEED $GAIN $T/e2e128.htfx
 
 rc=0
-for f in model_hand17 model_hand26 model_chain3 golden8 poses256 voxel4 scale115 slowfit3 train3 fullframe320 fullframe320close fullframe5 config5 cnn128 e2e128; do
+for f in model_hand17 model_hand26 model_chain3 golden8 poses256 poses1024 poses5full voxel4 scale115 slowfit3 train3 fullframe320 fullframe320close fullframe5 config5 cnn128 e2e128; do
 	if cmp -s $T/$f.htfx $G/$f.htfx; then echo "identical  $f.htfx"; else echo "DIFFERENT  $f.htfx"; rc=1; fi
 	[ $WRITE = 1 ] && cp $T/$f.htfx $G/$f.htfx
 done
@@ -94,12 +98,15 @@ def same(name, new, old):
     bad += not ok
 f = htfx.load(T + "/frames256.htfx"); f256 = {k: f[k] for k in ("depth", "cam", "startpose", "gtpose", "rows")}
 same("frames256.npz", f256, dict(np.load(G + "/frames256.npz")))
+f = htfx.load(T + "/frames1024.htfx"); f1024 = {k: f[k] for k in ("depth", "cam", "startpose", "rows")}
+same("frames1024.npz", f1024, dict(np.load(G + "/frames1024.npz")))
 g = htfx.load(T + "/frames5.htfx"); f5 = {k: g[k] for k in ("depth", "cam", "startpose", "rows")}
 same("frames5_64.npz", f5, dict(np.load(G + "/frames5_64.npz")))
 s = htfx.load(T + "/seg.htfx"); seg = {k.replace("/", "__"): v for k, v in s.items()}
 same("segment6.npz", seg, dict(np.load(G + "/segment6.npz")))
 if write:
     np.savez_compressed(G + "/frames256.npz", **f256)
+    np.savez_compressed(G + "/frames1024.npz", **f1024)
     np.savez_compressed(G + "/frames5_64.npz", **f5)
     np.savez_compressed(G + "/segment6.npz", **seg)
 sys.exit(1 if bad else 0)
