@@ -11,6 +11,7 @@
 // coefficients arrive through scalar loads and every active lane does the same 6 flops per plane; the sphere cull of
 // physmodel.h:153 is a per-lane predicate.  Body poses are expanded once per block into an LDS table (lane b <-> body b).
 // All arithmetic keeps the reference's evaluation order (-ffp-contract=off), so rows are bit-identical to the CPU path.
+#include <limits.h>
 #include <mutex>
 #include "ht_device.hpp"
 #include "ht_launch.hpp"
@@ -746,7 +747,10 @@ __global__ __launch_bounds__(256) void k_fit_error(ht_model_dev M, const float *
 		for (int k = 0; k < M.nb; k++)
 		{
 			v3 position = apply(ci, tab_pos(tab + k * BT));
-			int px = (int)(position.x / position.z * cam[0] + cam[2]), py = (int)(position.y / position.z * cam[1] + cam[3]);     // projectz misc_image.h:50
+			const float fpx = position.x / position.z * cam[0] + cam[2], fpy = position.y / position.z * cam[1] + cam[3];     // projectz misc_image.h:50
+			// int2(float2): a NaN (a body whose carried pose is NaN) converts to INT_MIN in the compiled reference and falls out of the image; the device's conversion
+			// gives 0, which would be pixel (0, 0)
+			const int px = fpx != fpx ? INT_MIN : (int)fpx, py = fpy != fpy ? INT_MIN : (int)fpy;
 			if (!(px >= 0 && px <= w - 1 && py >= 0 && py <= h - 1)) continue;
 			float bone_error = (float)(int)depth[((size_t)b * h + py) * w + px] * cam[4] - position.z;
 			bone_error_sum += clamp_std(bone_error, 0.0f, 0.01f);

@@ -178,7 +178,7 @@ inline void WriteDatasetInfo(const std::string &jsonfile, const DatasetInfo &d)
 // A dataset is four files with one base name (dataset.h:62-163): base.json = the DatasetInfo header above; base.rs = the depth frames, raw
 // little-endian u16, width x height of the header's camera, back to back (with the deprecated hasir flag each depth frame is followed by its
 // u8 infra-red frame in the same file); base.ir = the infra-red frames, raw u8, same size, optional; base.pose = the poses as text.
-struct byte3 { unsigned char x = 0, y = 0, z = 0; };                                                                                      // linalg.h byte3
+// byte3 (linalg.h:355) comes with the image helpers of ht_handtrack.hpp
 struct Frame      // dataset.h:40-51
 {
 	Image<unsigned short> depth; std::vector<Pose> pose, startpose; float4 mplane{ 0, 0, 0, 3.402823466e+38f }; Image<unsigned char> ir; std::string fname; int fid = 0;

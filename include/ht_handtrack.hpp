@@ -125,6 +125,103 @@ inline DCamera camsub(const DCamera &c, int s)                                  
 	return DCamera({ c.dim().x / s, c.dim().y / s }, { c.focal().x / (float)s, c.focal().y / (float)s }, { c.principal().x / (float)s, c.principal().y / (float)s }, c.depth_scale, c.pose);
 }
 struct Mesh { std::vector<float3> verts; std::vector<int3> tris; Pose pose; float4 hack{ 1, 1, 1, 1 }; std::string material; };      // mesh.h (what GetMeshes hands to a renderer)
+
+// ---- the host-side image helpers the applications draw with (synthetic-tracker.cpp:191,206,208-209,218,221-222): plain loops over small rasters, no device work.
+//      Same names and results as the reference's templates; written for this Image / DCamera.
+struct byte3 { unsigned char x, y, z; byte3() : x(0), y(0), z(0) {} byte3(unsigned char a, unsigned char b, unsigned char c) : x(a), y(b), z(c) {} explicit byte3(int v) : x((unsigned char)v), y((unsigned char)v), z((unsigned char)v) {} };      // linalg.h:355
+inline bool operator==(const byte3 &a, const byte3 &b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+// Transform(image, f) (misc_image.h:165): f over every pixel, the camera kept
+template <typename F, typename S> auto Transform(const Image<S> &src, F f) -> Image<decltype(f(S()))>
+{
+	Image<decltype(f(S()))> dst; dst.cam = src.cam; dst.raster.reserve(src.raster.size());
+	for (const S &v : src.raster) dst.raster.push_back(f(v));
+	return dst;
+}
+inline unsigned char ToGrayScale(float x) { const float v = x * 255.0f; return (unsigned char)(v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v)); }      // misc_image.h:169 (truncating, clamp first)
+inline unsigned char ToGrayScale(unsigned char x) { return x; }
+template <class T> Image<unsigned char> ToGrayScale(const Image<T> &src) { return Transform(src, [](T x) { return ToGrayScale(x); }); }                   // misc_image.h:172
+inline Image<byte3> ToRGB(const Image<unsigned char> &src) { return Transform(src, [](unsigned char p) { return byte3(p, p, p); }); }                    // misc_image.h:173
+inline Image<byte3> ToRGB(const Image<float> &src) { return ToRGB(ToGrayScale(src)); }
+// UpSample (misc_image.h:96-102,135): every pixel becomes a 2x2 block; the camera's dimensions, focal lengths and principal point double (operator*, :61)
+template <class T> Image<T> UpSample(const Image<T> &src)
+{
+	const int w = src.dim().x, h = src.dim().y;
+	Image<T> dst; dst.cam = DCamera({ w * 2, h * 2 }, { src.cam.focal().x * 2.0f, src.cam.focal().y * 2.0f }, { src.cam.principal().x * 2.0f, src.cam.principal().y * 2.0f }, src.cam.depth_scale, src.cam.pose);
+	dst.raster.resize(src.raster.size() * 4);
+	for (int y = 0; y < 2 * h; y++) for (int x = 0; x < 2 * w; x++) dst.raster[(size_t)y * 2 * w + x] = src.raster[(size_t)(y / 2) * w + x / 2];
+	return dst;
+}
+// ImageConcat (misc_image.h:225-238): the images stacked top to bottom in a canvas as wide as the widest, each row copied to the left edge
+template <class T> Image<T> ImageConcat(const std::vector<Image<T>> &images)
+{
+	int w = 0, h = 0;
+	for (auto &im : images) { w = im.dim().x > w ? im.dim().x : w; h += im.dim().y; }
+	Image<T> dst; dst.cam = DCamera({ w, h }, { (float)w, (float)h }, { (float)w / 2.0f, (float)h / 2.0f }, 0.001f); dst.cam.depth_scale = DCamera().depth_scale;      // DCamera(int2 dim), misc_image.h:47
+	dst.raster.assign((size_t)w * h, T());
+	size_t row = 0;
+	for (auto &im : images) for (int y = 0; y < im.dim().y; y++, row++) for (int x = 0; x < im.dim().x; x++) dst.raster[row * w + x] = im.raster[(size_t)y * im.dim().x + x];
+	return dst;
+}
+// ImageOverlayYellowBlue (handtrack.h:249-254): red = green = the heat-map, blue = the background image as grey
+template <class T> Image<byte3> ImageOverlayYellowBlue(const Image<unsigned char> &image_rg, const Image<T> &image_b)
+{
+	Image<byte3> o; o.cam = image_rg.cam; o.raster.resize(image_rg.raster.size());
+	for (size_t i = 0; i < image_rg.raster.size(); i++) o.raster[i] = byte3(image_rg.raster[i], image_rg.raster[i], ToGrayScale(image_b.raster[i]));
+	return o;
+}
+// VisualizeHMaps (handtrack.h:256-267): every heat-map blown up to the background's size, laid over it, doubled once more, the eight stacked (synthetic-tracker.cpp:208,221)
+template <class T> Image<byte3> VisualizeHMaps(const std::vector<Image<unsigned char>> &hmaps, Image<T> &dmap_d)
+{
+	std::vector<Image<byte3>> vmaps;
+	for (auto hmap : hmaps)
+	{
+		while ((long)hmap.dim().x * hmap.dim().y < (long)dmap_d.dim().x * dmap_d.dim().y) hmap = UpSample(hmap);
+		vmaps.push_back(UpSample(ImageOverlayYellowBlue(hmap, dmap_d)));
+	}
+	return ImageConcat(vmaps);
+}
+// DepthMesh (misc_image.h:419-450; synthetic-tracker.cpp:191): a triangle mesh over the in-range pixels, one vertex per skip x skip cell (the first in-range pixel of the
+// cell, scanned towards cells that already have a vertex), two triangles per 2x2 block of vertices whose depth steps stay under gaplimit
+template <class T> std::pair<std::vector<float3>, std::vector<int3>> DepthMesh(const Image<T> &dimage, float2 filter_range, float gaplimit = FLT_MAX, int skip = 1)
+{
+	std::vector<float3> verts; std::vector<int3> tris;
+	const int W = dimage.dim().x, H = dimage.dim().y, w = W / skip, h = H / skip;
+	std::vector<int> vmap((size_t)w * h, -1);
+	const DCamera &c = dimage.cam;
+	for (int py = 0; py < h; py++) for (int px = 0; px < w; px++)
+	{
+		const int rvx = (px && vmap[(size_t)py * w + px - 1] != -1) ? 1 : 0, rvy = (py && vmap[(size_t)(py - 1) * w + px] != -1) ? 1 : 0;
+		bool placed = false;
+		for (int sy = 0; sy < skip && !placed; sy++) for (int sx = 0; sx < skip && !placed; sx++)
+		{
+			const int x = px * skip + sx + rvx * ((skip - 1) - sx * 2), y = py * skip + sy + rvy * ((skip - 1) - sy * 2);
+			const float d = dimage.raster[(size_t)y * W + x] * c.depth_scale;
+			if (d >= filter_range.x && d < filter_range.y)
+			{
+				vmap[(size_t)py * w + px] = (int)verts.size();
+				verts.push_back({ ((float)x - c.principal().x) / c.focal().x * d, ((float)y - c.principal().y) / c.focal().y * d, 1.0f * d });
+				placed = true;
+			}
+		}
+	}
+	auto step = [&](int a, int b) { const float dz = verts[a].z - verts[b].z; return (dz < 0 ? -dz : dz) > gaplimit; };
+	auto ok = [&](int a, int b, int cc) { return !(step(a, b) || step(b, cc) || step(cc, a)); };
+	for (int py = 0; py + 1 < h; py++) for (int px = 0; px + 1 < w; px++)
+	{
+		const int a = vmap[(size_t)py * w + px], b = vmap[(size_t)(py + 1) * w + px], cc = vmap[(size_t)(py + 1) * w + px + 1], d = vmap[(size_t)py * w + px + 1];      // counter-clockwise
+		if (a >= 0 && cc >= 0 && ((b >= 0 && ok(a, b, cc)) || (d >= 0 && ok(cc, d, a))))
+		{
+			if (b >= 0 && ok(a, b, cc)) tris.push_back({ a, b, cc });
+			if (d >= 0 && ok(cc, d, a)) tris.push_back({ cc, d, a });
+		}
+		else if (b >= 0 && d >= 0)
+		{
+			if (a >= 0 && ok(d, a, b)) tris.push_back({ d, a, b });
+			if (cc >= 0 && ok(b, cc, d)) tris.push_back({ b, cc, d });
+		}
+	}
+	return { verts, tris };
+}
 inline float3 qrot_(const float4 &q, const float3 &v)                                       // linalg.h:288
 {
 	const float3 X{ q.w * q.w + q.x * q.x - q.y * q.y - q.z * q.z, (q.x * q.y + q.z * q.w) * 2, (q.z * q.x - q.y * q.w) * 2 };

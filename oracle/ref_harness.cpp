@@ -27,6 +27,7 @@
 //   segment <animbank.pose> <rows,comma> <out.htfx>   320x240 frames and what HandSegmentVR makes of them
 //   bench  <frames.htfx> <seed> <fc2gain> <reps>   reference CPU time for the unit of work
 //   poses  <frames.htfx> <seed> <fc2gain> <out.htfx>   the unit of work on every frame of the file: user poses, othermodel poses, tracker flags
+//   viz <animbank.pose> <row> <out.htfx>         DepthMesh and VisualizeHMaps as the application calls them (synthetic-tracker.cpp:191,204-209)
 //   posesfull <frames.htfx> <seed> <fc2gain> <out.htfx>   the same for full-size frames of any size (the tracker segments them) and the staged hand model
 //   dataset_write <dir/> <name>                    DepthDataStreamOut (dataset.h:62-106) writes a three-frame set <dir>/<name>.{json,rs,ir,pose,rgb,feye}
 //   dataset_read <prefix> <bones> <out.htfx>       load_dataset (dataset.h:109-163) reads <prefix>.* ; everything it returns
@@ -1169,6 +1170,38 @@ static int mode_posesfull(const char *framesfn, uint64_t seed, double gain, cons
 	return 0;
 }
 
+// viz <animbank.pose> <row> <out.htfx>: what the application draws beside the tracker (synthetic-tracker.cpp:191,204-209): DepthMesh of the 320x240 frame, and the
+// expected landmark heat-maps laid over the segmented tile by VisualizeHMaps; with the inputs (frame, tile, cameras, pose) the host-side helpers of
+// include/ht_handtrack.hpp are checked against
+static int mode_viz(const char *bankfn, int row, const char *outfn)
+{
+	PhysModel fake = LoadHandModel();
+	auto bank = read_animbank(bankfn, fake.rigidbodies.size());
+	DCamera dcam({ 320,240 }, { 305,305 }, { 160,120 }, 0.001f);
+	fake.SetPose(bank[row % bank.size()]);
+	auto dimage = raycast_depth(fake, dcam);
+	const float2 drange = { 0.1f, 0.7f };
+	Out o; if (htfx_open(&o.w, outfn)) return 2;
+	o.u16("depth", dimage.raster, { 240, 320 }); o.f32("cam", camvec(dimage.cam)); o.f32("pose", flat(fake.GetPose()), { (uint32_t)fake.rigidbodies.size(), 7 });
+	auto dmesh = DepthMesh(dimage, { drange.x, drange.y }, 0.03f, 3);      // synthetic-tracker.cpp:191
+	o.v3("dm_verts", dmesh.first);
+	std::vector<int> t; for (auto &q : dmesh.second) { t.push_back(q.x); t.push_back(q.y); t.push_back(q.z); }
+	o.i32("dm_tris", t, { (uint32_t)dmesh.second.size(), 3 });
+	auto segment = HandSegmentVR(dimage);      // :204
+	auto segment_f = Transform(segment, [drange, &segment](unsigned short d) {return (float)clamp(1.0f - (d*segment.cam.depth_scale - drange.x) / (drange.y - drange.x), 0.0f, 1.0f); });
+	DCamera hcam = camsub(segment_f.cam, 4);
+	auto fake_labels = GatherHandExpectedCNN(fake.GetPose(), hcam);
+	auto landmark_labels = VisualizeHMaps(fake_labels.hmaps, segment_f);      // :208
+	auto angle_labels = ToRGB(UpSample(UpSample(UpSample(fake_labels.vmap))));      // :209
+	o.u16("tile", segment.raster, { 64, 64 }); o.f32("segcam", camvec(segment.cam));
+	auto bytes = [](const Image<byte3> &im) { std::vector<unsigned short> v; for (auto &c : im.raster) { v.push_back(c.x); v.push_back(c.y); v.push_back(c.z); } return v; };
+	o.u16("landmark_labels", bytes(landmark_labels), { (uint32_t)landmark_labels.dim().y, (uint32_t)landmark_labels.dim().x, 3 });
+	o.u16("angle_labels", bytes(angle_labels), { (uint32_t)angle_labels.dim().y, (uint32_t)angle_labels.dim().x, 3 });
+	htfx_close(&o.w);
+	printf("viz: %d mesh vertices, %d triangles, labels %d x %d\n", (int)dmesh.first.size(), (int)dmesh.second.size(), landmark_labels.dim().x, landmark_labels.dim().y);
+	return 0;
+}
+
 // ---- on-disk dataset formats (include/dataset.h): the reference's own writer and reader -----------------------------------------------------------
 static void dump_dataset_info(Out &o, const DatasetInfo &d)
 {
@@ -1262,6 +1295,7 @@ int main(int argc, char **argv) try
 	if (mode == "dataset_read" && a.size() == 3) return mode_dataset_read(a[0].c_str(), atoi(a[1].c_str()), a[2].c_str());
 	if (mode == "dataset_header" && a.size() == 4) return mode_dataset_header(a[0].c_str(), a[1].c_str(), atoi(a[2].c_str()), a[3].c_str());
 	if (mode == "poses" && a.size() == 4) return mode_poses(a[0].c_str(), strtoull(a[1].c_str(), 0, 0), atof(a[2].c_str()), a[3].c_str());
+	if (mode == "viz" && a.size() == 3) return mode_viz(a[0].c_str(), atoi(a[1].c_str()), a[2].c_str());
 	if (mode == "posesfull" && a.size() == 4) return mode_posesfull(a[0].c_str(), strtoull(a[1].c_str(), 0, 0), atof(a[2].c_str()), a[3].c_str());
 	if (mode == "bench" && a.size() >= 4) return mode_bench(a[0].c_str(), strtoull(a[1].c_str(), 0, 0), atof(a[2].c_str()), atoi(a[3].c_str()), a.size() > 4 ? atoi(a[4].c_str()) : 0);
 	fprintf(stderr, "bad arguments\n");

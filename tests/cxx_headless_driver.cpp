@@ -4,6 +4,9 @@
 //
 //   driver fakedepth <model> <in.bin> <out.bin>      host only: pose a fake hand, ray-cast a depth frame (FakeDepth)
 //   driver pointcloud - <in.bin> <out.bin>           host only: PointCloud(dimage, {0.1, 0.7}) of every frame: i32 n, n x float3
+//   driver viz - <in.bin> <out.bin>                  host only: what the application draws beside the tracker (:191, :204-209) on frame 0 of in.bin (320x240) and
+//                                                    the 64x64 tile given as frame 1's first 4096 pixels + camera: DepthMesh, VisualizeHMaps of the expected
+//                                                    landmark maps over the tile, the angle maps as ToRGB(UpSample^3); out: i32 nv, nt; verts; tris; bytes of both images
 //   driver track <model> <weights.cnnb> <in.bin> <out.bin>      the tracking loop on given frames (needs the GPU)
 //
 // in.bin:  int32 n, w, h, nb; then n records { u16 depth[w*h]; f32 cam[12]; f32 start[nb][7]; f32 gt[nb][7] }
@@ -83,6 +86,29 @@ int main(int argc, char **argv)
 			printf("pointcloud: %zu frames\n", recs.size());
 			return 0;
 		}
+		if (mode == "viz")
+		{
+			auto recs = read_input(argv[3], w, h, nb);
+			if (recs.size() != 2) throw std::runtime_error("viz wants two records: the frame, and the tile in the second record's first 4096 pixels");
+			const float2 drange{ 0.1f, 0.7f };
+			Image<unsigned short> dimage(camera_of(recs[0].cam, w, h), recs[0].depth);
+			auto dmesh = DepthMesh(dimage, { drange.x, drange.y }, 0.03f, 3);                              // :191
+			Image<unsigned short> segment(camera_of(recs[1].cam, 64, 64), std::vector<unsigned short>(recs[1].depth.begin(), recs[1].depth.begin() + 4096));      // :204 (HandSegmentVR runs on the device: its result is an input here)
+			auto segment_f = Transform(segment, [drange, &segment](unsigned short d) { const float v = 1.0f - (d * segment.cam.depth_scale - drange.x) / (drange.y - drange.x); return (float)(v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v)); });      // :205
+			DCamera hcam = camsub(segment_f.cam, 4);                                                       // :206
+			auto fake_labels = GatherHandExpectedCNN(recs[0].gt, hcam);                                    // :207
+			auto landmark_labels = VisualizeHMaps(fake_labels.hmaps, segment_f);                           // :208
+			auto angle_labels = ToRGB(UpSample(UpSample(UpSample(fake_labels.vmap))));                     // :209
+			FILE *o = fopen(argv[4], "wb");
+			const int nv = (int)dmesh.first.size(), nt = (int)dmesh.second.size(), dims[4] = { landmark_labels.dim().x, landmark_labels.dim().y, angle_labels.dim().x, angle_labels.dim().y };
+			fwrite(&nv, 4, 1, o); fwrite(&nt, 4, 1, o); fwrite(dims, 4, 4, o);
+			fwrite(dmesh.first.data(), sizeof(float3), nv, o); fwrite(dmesh.second.data(), sizeof(int3), nt, o);
+			for (auto &c : landmark_labels.raster) { const unsigned char b[3] = { c.x, c.y, c.z }; fwrite(b, 1, 3, o); }
+			for (auto &c : angle_labels.raster) { const unsigned char b[3] = { c.x, c.y, c.z }; fwrite(b, 1, 3, o); }
+			fclose(o);
+			printf("viz: %d vertices, %d triangles, labels %dx%d\n", nv, nt, dims[0], dims[1]);
+			return 0;
+		}
 		if (mode != "track" || argc < 6) return 2;
 		auto recs = read_input(argv[4], w, h, nb);
 		HandTracker htk(argv[2], argv[3]);                                     // :90 (asset paths are arguments here)
@@ -102,7 +128,9 @@ int main(int argc, char **argv)
 			put_poses(o, pose);
 			fwrite(htk.cnn_output.data(), 4, htk.cnn_output.size(), o);
 			fwrite(fake_labels.cnn_expected.data(), 4, fake_labels.cnn_expected.size(), o);
-			const float shown = (htk.cnn_input.raster.size() == 4096 && htk.cnn_output_analysis.hmaps.size() == 8) ? 1.0f : 0.0f;      // :218-222 draw these
+			auto landmark_outputs = VisualizeHMaps(htk.cnn_output_analysis.hmaps, htk.cnn_input);     // :221
+			auto angle_outputs = ToRGB(UpSample(UpSample(UpSample(ToGrayScale(htk.cnn_output_analysis.vmap)))));      // :222
+			const float shown = (htk.cnn_input.raster.size() == 4096 && htk.cnn_output_analysis.hmaps.size() == 8 && landmark_outputs.raster.size() == (size_t)128 * 1024 && angle_outputs.raster.size() == (size_t)128 * 128) ? 1.0f : 0.0f;      // :218-222 draw these
 			fwrite(&shown, 4, 1, o);
 			put_poses(o, htk.handmodel.GetPoseUser());                         // :233 reads the tracked model back through the facade
 		}

@@ -99,3 +99,24 @@ def test_tracking_loop_through_the_cxx_surface_matches_the_reference(tmp_path, g
         assert np.array_equal(labels, native.expected_cnn(gt[f], cams[f]))      # GatherHandExpectedCNN through camsub(segment.cam, 4)
         assert shown == 1.0
         assert np.array_equal(facade, pose)                                      # handmodel.GetPoseUser() == what update() returned
+
+
+def test_depth_mesh_and_heat_map_visualisation_match_the_reference(tmp_path):
+    """host only: DepthMesh (misc_image.h:419-450) and VisualizeHMaps (handtrack.h:256-267) as synthetic-tracker.cpp:191,204-209 calls them, against what the
+    reference produced for the same frame (tests/golden/viz1.npz from `ref_harness viz`): vertices, triangles and both label images byte for byte."""
+    exe = _build(tmp_path)
+    G = np.load(os.path.join(HERE, "golden", "viz1.npz"))
+    depth = np.zeros((2, 240, 320), np.uint16); depth[0] = G["depth"]; depth[1].reshape(-1)[:4096] = G["tile"].reshape(-1)
+    cams = np.stack([G["cam"], G["segcam"]]); pose = np.stack([G["pose"], G["pose"]])
+    _write_input(tmp_path / "in.bin", depth, cams, pose, pose)
+    subprocess.check_call([exe, "viz", "-", str(tmp_path / "in.bin"), str(tmp_path / "out.bin")])
+    raw = open(tmp_path / "out.bin", "rb").read()
+    nv, nt, lw, lh, aw, ah = struct.unpack("<6i", raw[:24]); off = 24
+    verts = np.frombuffer(raw, np.float32, nv * 3, off).reshape(nv, 3); off += nv * 12
+    tris = np.frombuffer(raw, np.int32, nt * 3, off).reshape(nt, 3); off += nt * 12
+    lab = np.frombuffer(raw, np.uint8, lw * lh * 3, off).reshape(lh, lw, 3); off += lw * lh * 3
+    ang = np.frombuffer(raw, np.uint8, aw * ah * 3, off).reshape(ah, aw, 3)
+    assert np.array_equal(verts, G["dm_verts"]) and np.array_equal(tris, G["dm_tris"])
+    assert lab.shape == G["landmark_labels"].shape and np.array_equal(lab, G["landmark_labels"])
+    assert np.array_equal(ang, G["angle_labels"])
+    assert lab[..., 0].max() > 0 and (lab[..., 2] > 0).any()      # the heat-maps and the tile are both in the picture

@@ -3,6 +3,9 @@ stream), rehearsed with the one rank a GPU box has: the communicator is made fro
 update on its own stream, and what lands in the gathered array is this rank's poses.  (Sharding arithmetic for N > 1: tests/test_shard_gloo.py.)"""
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- at import (= collection) time on purpose: torch brings its own copies of the ROCm runtime and of RCCL, and a process in which OUR library has
+#                  already initialised HIP when torch is first imported ends up with RCCL bound to a second, uninitialised runtime ("no ROCm-capable device is detected"
+#                  from ncclCommInitRank).  A Python host that uses both imports torch first (bench.py does); a C++ host has only the system's copies.
 
 import oracle_lib as ol
 

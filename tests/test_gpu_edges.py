@@ -252,3 +252,47 @@ def test_contact_patch_extra_samples(tmp_path):
         assert most >= 2 and total >= 14 and ctx.capacity_events() == (0, 0, 0)
     finally:
         ctx.close(); orc.close()
+
+
+def test_nan_in_the_tracked_state_ends_in_the_sanity_check_reset(ctx, weights):
+    """SanityCheck (physmodel.h:437-442, called at the end of every FitPointCloud, :355): a body whose state holds a NaN is put back to its start pose with zero momenta.
+    A NaN written into the hand model's carried state (one body's angular momentum; another tracker's wrist position) spreads through the joint rows to every body during
+    the first pass's sweeps, the pass's SanityCheck resets them all, and the remaining passes track on from the model's rest pose.  Device against the restatement given
+    the same poisoned state: the poses after one pass are the rest pose EXACTLY (nothing of the NaN survives, momenta zero), after three passes they agree to the
+    solver's tolerance; the tracker flags agree too (FitError of a NaN pose is NaN, every comparison with it false: handtrack.h:704-722)."""
+    depth, cams, start = _bank(4)
+    poison = [(1, 5, 10), (2, 0, 0)]      # (tracker slot, body, component of [pos3 quat4 linmom3 angmom3])
+    import htfx
+    rest = htfx.load(ol.MODEL)["body_f"]      # per body: ... pos_start3 at [10:13], quat_start4 at [13:17]
+    for passes in (1, 3):
+        ctx.set_params(mainthreadpasses=passes)
+        ctx.tracker_reset(start)
+        st = ctx.get_state(0, 4)
+        for slot, body, comp in poison:
+            st[slot, body, comp] = np.nan
+        ctx.set_state(0, st)
+        got = ctx.update_sync(depth, cams)
+        hand = ctx.get_state(0, 4)
+        assert np.isfinite(got).all() and np.isfinite(hand).all()
+        orc = ol.Oracle(weights)
+        orc.head.par.microforce = 3.0; orc.head.par.mainthreadpasses = passes
+        ref = np.zeros((4, 17, 7), np.float32); ref_hand = np.zeros((4, 17, 13), np.float32); ref_flags = []
+        for k in range(4):
+            orc.reset(start[k]); s = orc.get_state(0)
+            for slot, body, comp in poison:
+                if slot == k:
+                    s[body, comp] = np.nan
+            orc.set_state(0, s)
+            cam = ol.camera(cams[k])
+            orc.L.ho_update(orc.h, ol.u16ptr(np.ascontiguousarray(depth[k])), C.byref(cam), ol.fptr(ref[k]))
+            ref_hand[k] = orc.get_state(0); ref_flags.append(orc.flags()[:2])
+        orc.close()
+        for slot, _, _ in poison:
+            if passes == 1:      # every body back at its start pose, bit for bit, momenta zero: on the device and in the restatement
+                for h in (hand[slot], ref_hand[slot]):
+                    assert np.array_equal(h[:, :3], rest[:, 10:13]) and np.array_equal(h[:, 3:7], rest[:, 13:17]) and not h[:, 7:].any()
+        _compare("NaN in the carried state, %d pass(es)" % passes, got, ref, [0] * 4)
+        err, ini = ctx.tracker_flags(4)
+        for k in range(4):
+            assert ini[k] == ref_flags[k][1] and (err[k] == ref_flags[k][0] or (np.isnan(err[k]) and np.isnan(ref_flags[k][0]))), (k, err[k], ref_flags[k])
+    ctx.set_params(mainthreadpasses=3)
