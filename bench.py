@@ -339,7 +339,7 @@ def main():
     import torch
     import torch.distributed as dist
     from hand_tracking_samples_amd import native, weights as W
-    from hand_tracking_samples_amd.shard import gather_poses, shard_range
+    from hand_tracking_samples_amd.shard import PoseBuffers, gather_poses, negotiate_library_gather, rank_frames
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -365,13 +365,11 @@ def main():
     cnn128 = wl == "config5-cnn128"
     frames5 = cfg5 or cnn128
 
-    # this rank's contiguous shard of the global frame list [rank * B, (rank + 1) * B); the global list walks the distinct frames round and round, every rank's
-    # shard starting 131 frames further on ("same generators, different animbank offsets"), so ranks do not work on identical batches
+    # this rank's contiguous shard of the global frame list; the list walks the distinct frames round and round, every rank's shard starting 131 frames further on
+    # ("same generators, different animbank offsets"), so ranks do not work on identical batches (hand_tracking_samples_amd/shard.py)
     ndistinct = 64 if frames5 else 1024
-    lo, hi = shard_range(B * world, rank, world)
-    first = (lo + 131 * rank) % ndistinct
-    depth, cams, start = (_load_frames5 if frames5 else _load_frames)(hi - lo, first)
-    frame_idx = (first + np.arange(hi - lo)) % ndistinct      # which distinct frame every slot carries
+    frame_idx = rank_frames(B, rank, world, ndistinct)      # which distinct frame every slot carries
+    depth, cams, start = (_load_frames5 if frames5 else _load_frames)(len(frame_idx), int(frame_idx[0]))
     gold = None
     if rank == 0 and wl == "cnn" and B >= 8:      # slots 0..7: the frames the reference's heat-maps are committed for
         gold = _golden8()
@@ -396,40 +394,18 @@ def main():
     # cannot be made, torch.distributed's all-gather does the same exchange and the JSON line says so.
     gather_impl = None
     if use_dist and not cnn_only:
-        # every rank goes through the same collectives whatever fails locally: rank 0 makes the id (byte 128 = "valid"), everybody receives it, everybody tries to
-        # join, and the ranks then agree (MIN) on whether all of them did
-        # (ncclCommInitRank blocks until every rank has arrived: a rank that cannot even load RCCL must be found out BEFORE anybody enters it)
-        avail = torch.tensor([1 if native.comm_available() else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(avail, op=dist.ReduceOp.MIN)
-        all_have_rccl = int(avail.item()) == 1
-        uid = torch.zeros(129, dtype=torch.uint8, device=dev)
-        if rank == 0 and all_have_rccl:
-            try:
-                uid[:128].copy_(torch.frombuffer(bytearray(native.comm_unique_id()), dtype=torch.uint8))
-                uid[128] = 1
-            except Exception as e:
-                sys.stderr.write("rank 0: RCCL unique id unavailable (%s)\n" % e)
-        dist.broadcast(uid, 0)
-        joined, why = 0, ("rank 0 could not make an RCCL unique id" if all_have_rccl else "RCCL cannot be loaded on every rank")
-        if int(uid[128].item()) == 1:
-            try:
-                ctx.comm_init(world, rank, bytes(uid[:128].cpu().numpy().tobytes()))
-                joined = 1
-            except Exception as e:
-                why = str(e)
-                sys.stderr.write("rank %d: ht_comm_init failed (%s)\n" % (rank, e))
-        ok = torch.tensor([joined], dtype=torch.int32, device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 1:
+        # every rank goes through the same collectives whatever fails locally, and nobody enters ncclCommInitRank before all ranks can load RCCL (shard.py)
+        use_lib, why_not = negotiate_library_gather(dist, dev, rank, world, native.comm_available(), native.comm_unique_id, lambda uid: ctx.comm_init(world, rank, uid))
+        if use_lib:
             gather_impl = "ht_gather_poses_dev (ncclAllGather on the context's communication stream): RCCL reports %d rank(s), this is rank %d" % ctx.comm_info()
         else:
-            gather_impl = "torch.distributed.all_gather_into_tensor (the library's communicator could not be made on every rank: %s)" % (why if not joined else "another rank failed")
+            gather_impl = "torch.distributed.all_gather_into_tensor (the library's communicator could not be made on every rank: %s)" % why_not
     use_lib_gather = bool(gather_impl and gather_impl.startswith("ht_"))
     gathered2 = [torch.empty((world * B, ctx.nb, 7), dtype=torch.float32, device=dev) for _ in range(2)] if use_dist else [None, None]
     gathered = gathered2[0]
-    pending = [None, None]      # the exchange still reading each pose buffer
-    nstep = [0]
     stream = torch.cuda.current_stream(dev)
+    # the exchange still reading each pose buffer pair: the library's gather is waited for on the stream (ht_gather_wait), torch.distributed's through its work handle
+    bufs = PoseBuffers((lambda k, h: ctx.gather_wait(k, stream.cuda_stream)) if use_lib_gather else (lambda k, h: h.wait()))
 
     w128 = x128 = None
     if e2e:
@@ -446,12 +422,8 @@ def main():
 
     def step():
         nonlocal d_poses, gathered
-        k = nstep[0] & 1; nstep[0] += 1
+        k = bufs.next_slot()       # the exchange of two steps ago has to be through with this buffer pair (it long is)
         d_poses, gathered = d_poses2[k], gathered2[k]
-        if use_lib_gather:
-            ctx.gather_wait(k, stream.cuda_stream)       # the exchange of two steps ago has to be through with this buffer pair (it long is)
-        elif pending[k] is not None:
-            pending[k].wait(); pending[k] = None
         if cnn128:
             ctx.cnn128_eval_dev(d_cnn_in.data_ptr(), d_cnn_out.data_ptr(), B, stream.cuda_stream)
         elif wl == "cnn":
@@ -464,8 +436,9 @@ def main():
             ctx.update_dev(d_depth.data_ptr(), d_cams.data_ptr(), d_start.data_ptr(), B, d_poses.data_ptr(), stream.cuda_stream)
         if use_lib_gather:
             ctx.gather_poses_dev(d_poses.data_ptr(), gathered.data_ptr(), B, k, stream.cuda_stream)
+            bufs.issued(k, True)
         elif use_dist and not cnn_only:
-            _, pending[k] = gather_poses(d_poses, world, out=gathered, force=True, async_op=True)
+            bufs.issued(k, gather_poses(d_poses, world, out=gathered, force=True, async_op=True)[1])
 
     for _ in range(args.warmup):
         step()

@@ -23,7 +23,7 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fn
 FILE_FLAGS = {"ht_solver.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fno-slp-vectorize"]}
 if os.environ.get("HT_SOLVER_FLAGS") is not None:      # measurement builds: try other per-file flags for the solver
     FILE_FLAGS = {"ht_solver.hip": os.environ["HT_SOLVER_FLAGS"].split()}
-OBJDIR = os.path.join(HERE, "build")
+OBJDIR = os.path.join(HERE, "build_tuning" if os.environ.get("HT_TUNING") else "build")      # a measurement build keeps its objects apart from the product's
 if os.environ.get("HT_TUNING"):      # measurement builds only: lets HT_DEBUG_SKIP / HT_NO_SIDE / HT_NO_OVERLAP reach the kernels (tools/ablate_*.sh, tools/solve_stats.py)
     FLAGS = FLAGS + ["-DHT_TUNING"]
 
@@ -34,7 +34,7 @@ def sources():
 
 def stale():
     if os.environ.get("HT_LIB_PATH"):
-        return False
+        return not os.path.exists(LIB)
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)

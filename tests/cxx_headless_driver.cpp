@@ -8,11 +8,15 @@
 //                                                    the 64x64 tile given as frame 1's first 4096 pixels + camera: DepthMesh, VisualizeHMaps of the expected
 //                                                    landmark maps over the tile, the angle maps as ToRGB(UpSample^3); out: i32 nv, nt; verts; tris; bytes of both images
 //   driver track <model> <weights.cnnb> <in.bin> <out.bin>      the tracking loop on given frames (needs the GPU)
+//   driver latency <model> <weights.cnnb> <in.bin> <iters>      time per HandTracker::update call as the application makes it (one frame per call, host buffers in, poses
+//                                                    out: synthetic-tracker.cpp:215), then per ht_update_sync call on 8 and 64 trackers; prints p50 / p99 in ms (needs the GPU)
 //
 // in.bin:  int32 n, w, h, nb; then n records { u16 depth[w*h]; f32 cam[12]; f32 start[nb][7]; f32 gt[nb][7] }
 // out.bin (track): n records { f32 pose_user[nb][7]; f32 cnn_output[2304]; f32 labels[2304]; f32 cnn_pose_accepted; f32 handpose_via_facade[nb][7] }
 // out.bin (fakedepth): n records { u16 depth[w*h] }
 #define HT_MI355X_GLOBAL_NAMES
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include "../include/ht_formats.hpp"
@@ -107,6 +111,57 @@ int main(int argc, char **argv)
 			for (auto &c : angle_labels.raster) { const unsigned char b[3] = { c.x, c.y, c.z }; fwrite(b, 1, 3, o); }
 			fclose(o);
 			printf("viz: %d vertices, %d triangles, labels %dx%d\n", nv, nt, dims[0], dims[1]);
+			return 0;
+		}
+		if (mode == "latency" && argc >= 6)
+		{
+			auto recs = read_input(argv[4], w, h, nb);
+			const int iters = atoi(argv[5]);
+			auto pct = [](std::vector<double> v, double p) { std::sort(v.begin(), v.end()); return v[(size_t)(p * (v.size() - 1))]; };
+			{
+				HandTracker htk(argv[2], argv[3]);
+				htk.always_take_cnn = 0; htk.microforce = 3.0f; htk.mainthreadpasses = 3;
+				std::vector<double> ms;
+				for (int i = 0; i < iters + 20; i++)
+				{
+					const Record &r = recs[i % recs.size()];
+					Image<unsigned short> dimage(camera_of(r.cam, w, h), r.depth);
+					if (i % recs.size() == 0) htk.SetPose(r.start);      // a tracker follows its sequence; re-seeded when the frames start over
+					const auto t0 = std::chrono::steady_clock::now();
+					auto pose = htk.update(std::move(dimage));
+					const double dt = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+					if (i >= 20) ms.push_back(dt);
+					if (pose.size() != (size_t)nb) throw std::runtime_error("update returned no pose");
+				}
+				printf("{\"call\": \"HandTracker::update\", \"frames_per_call\": 1, \"iters\": %d, \"p50_ms\": %.4f, \"p99_ms\": %.4f, \"mean_ms\": %.4f}\n", iters, pct(ms, 0.5), pct(ms, 0.99), [&] { double s = 0; for (double v : ms) s += v; return s / ms.size(); }());
+			}
+			for (int B : { 8, 64 })
+			{
+				ht_ctx *ctx = nullptr;
+				if (ht_create(argv[2], B, 0, &ctx) != HT_OK) throw std::runtime_error(ctx ? ht_last_error(ctx) : "ht_create");
+				std::vector<float> wts; { std::ifstream is(argv[3], std::ios::binary); is.seekg(0, std::ios::end); wts.resize((size_t)is.tellg() / 4); is.seekg(0); is.read((char *)wts.data(), (std::streamsize)wts.size() * 4); }
+				using ht_mi355x::check;
+				check(ctx, ht_cnn_load_weights(ctx, wts.data(), wts.size()));
+				ht_params par; ht_get_params(ctx, &par); par.microforce = 3.0f; par.mainthreadpasses = 3; check(ctx, ht_set_params(ctx, &par));
+				std::vector<unsigned short> depth((size_t)B * w * h); std::vector<float> cams((size_t)B * 12), start((size_t)B * nb * 7), poses((size_t)B * nb * 7);
+				for (int k = 0; k < B; k++)
+				{
+					const Record &r = recs[k % recs.size()];
+					memcpy(&depth[(size_t)k * w * h], r.depth.data(), (size_t)w * h * 2); memcpy(&cams[(size_t)k * 12], r.cam, 48);
+					for (int b = 0; b < nb; b++) { const float q[7] = { r.start[b].position.x, r.start[b].position.y, r.start[b].position.z, r.start[b].orientation.x, r.start[b].orientation.y, r.start[b].orientation.z, r.start[b].orientation.w }; memcpy(&start[((size_t)k * nb + b) * 7], q, 28); }
+				}
+				std::vector<double> ms;
+				for (int i = 0; i < iters + 20; i++)
+				{
+					if (i % 16 == 0) check(ctx, ht_tracker_reset(ctx, 0, B, start.data()));
+					const auto t0 = std::chrono::steady_clock::now();
+					check(ctx, ht_update_sync(ctx, depth.data(), cams.data(), B, poses.data(), nullptr));
+					const double dt = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+					if (i >= 20) ms.push_back(dt);
+				}
+				printf("{\"call\": \"ht_update_sync\", \"frames_per_call\": %d, \"iters\": %d, \"p50_ms\": %.4f, \"p99_ms\": %.4f, \"mean_ms\": %.4f}\n", B, iters, pct(ms, 0.5), pct(ms, 0.99), [&] { double s = 0; for (double v : ms) s += v; return s / ms.size(); }());
+				ht_destroy(ctx);
+			}
 			return 0;
 		}
 		if (mode != "track" || argc < 6) return 2;
