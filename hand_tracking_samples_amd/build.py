@@ -22,8 +22,11 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fn
 # instructions cannot carry one), which costs two v_mov_b32_dpp and register shuffles per row: 42.5 -> 38.75 issued instructions per chain row, 179 -> 112 VGPRs.
 FILE_FLAGS = {"ht_solver.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fno-slp-vectorize"]}
 if os.environ.get("HT_SOLVER_FLAGS") is not None:      # measurement builds: try other per-file flags for the solver
-    FILE_FLAGS = {"ht_solver.hip": os.environ["HT_SOLVER_FLAGS"].split()}
+    FILE_FLAGS = dict(FILE_FLAGS, **{"ht_solver.hip": os.environ["HT_SOLVER_FLAGS"].split()})
 OBJDIR = os.path.join(HERE, "build_tuning" if os.environ.get("HT_TUNING") else "build")      # a measurement build keeps its objects apart from the product's
+if os.environ.get("HT_EXTRA_FLAGS"):      # measurement builds only (with HT_LIB_PATH): e.g. -DHT_EPA_INLINE=__noinline__ for an A/B of the contact kernel
+    FLAGS = FLAGS + os.environ["HT_EXTRA_FLAGS"].split()
+    OBJDIR = os.path.join(HERE, "build_alt")
 if os.environ.get("HT_TUNING"):      # measurement builds only: lets HT_DEBUG_SKIP / HT_NO_SIDE / HT_NO_OVERLAP reach the kernels (tools/ablate_*.sh, tools/solve_stats.py)
     FLAGS = FLAGS + ["-DHT_TUNING"]
 

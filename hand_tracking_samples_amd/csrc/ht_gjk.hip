@@ -236,6 +236,9 @@ __device__ int gjk_run(const support_t &A, const support_t &B, float cutoff, gjk
 }
 
 // ---- expanding polytope, wave-cooperative on a per-wave LDS mesh (hull.h:233-310) ---------------------------------------
+#ifndef HT_EPA_INLINE
+#define HT_EPA_INLINE __forceinline__      // inlined into its two callers: no stack frame for the shapes, no register save around a call (round 4; see epa_handover)
+#endif
 #define EPA_MAXT 192
 #define EPA_MAXV 96
 // A triangle is one 16-byte record (vertex ids, pad, neighbour ids, pad) so that the mesh surgery, which is a chain of dependent look-ups,
@@ -340,9 +343,23 @@ __device__ __forceinline__ v3 epa_minkowski(const support_t &A, const support_t 
 	const v3 sa = A.pos + mul(RA, V3(pa.x, pa.y, pa.z));
 	return (A.outer ? A.opos + mul(RO, sa) : sa) - (B.pos + mul(RB, V3(pb.x, pb.y, pb.z)));
 }
+// The mesh lives in the wave's own LDS area and is touched in two ways: UNIFORMLY (every lane executes the same stores with the same values: the surgery) and
+// ONE ELEMENT PER LANE (scoring, the "who sees the new vertex" test, the verification walk, the compaction's moves).  Hardware executes a wave's LDS instructions in
+// order, so a hand-over between the two needs no waiting -- but the COMPILER only reasons per thread: between a store one lane makes and a load another lane makes
+// of it there is, for the compiler, no dependence to respect.  Every such hand-over therefore carries a wavefront-scope fence + wave barrier (nothing but a
+// scheduling fence and an s_waitcnt in the code), which is what keeps the routine correct when the optimiser sees it together with its caller (inlined).
+__device__ __forceinline__ void epa_handover() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+// A value every lane of the wave agrees on, SAID so: whatever decides a loop's exit in this routine (and in the job loop around it) is wave-uniform at run time,
+// but as the result of a vector compare or an LDS read the compiler has to treat it as per-lane, i.e. the loop as one its lanes may leave at different trips --
+// and it restructures such loops around the convergent operations inside them (ballots, v_readfirstlane, DPP exchanges).  As a function of its own the routine's
+// loops were structurised by themselves; inline, nested in a job loop whose own exit test (job number against a count read from LDS) looked divergent too, the
+// restructured code re-read the job number without the atomic that hands it out, and a wave never left the loop (round 3's hang; found in the ISA: a loop level
+// between the job loop and the polytope's whose header was just the v_readfirstlane).  With the exits scalar there is nothing to restructure.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ bool uni(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
 // all 64 lanes call this with identical arguments
 // `capped` is set when the run ends on one of this implementation's capacities (the reference's loop is unbounded, hull.h:246)
-__device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 s2, v3 s3, const support_t &A, const support_t &B, int lane, long long *ec, bool &capped)
+__device__ __forceinline__ v4 expanding_polytope_wave_body(epa_mem &m, v3 s0, v3 s1, v3 s2, v3 s3, const support_t &A, const support_t &B, int lane, long long *ec, bool &capped)
 {
 	capped = false;
 	long long tm = ec ? clock64() : 0;
@@ -359,6 +376,7 @@ __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 
 	int guard = 0;
 	for (; guard < 128; guard++)
 	{
+		epa_handover();      // uniform stores (the start simplex, the previous iteration's compaction) -> one triangle per lane
 		// face with the largest plane offset; the sequential scan keeps the first maximum (strict >), hull.h:248-261
 		float bd = 0.0f; int bi = 0x7fffffff; v3 bn = V3(0, 0, 0);
 		for (int i = lane; i < nt; i += 64)
@@ -384,10 +402,11 @@ __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 
 		bool dup = false;
 		for (int i = lane; i < nv; i += 64) dup = dup || same(v, ev(m, i));
 		if (__any(dup)) break;
-		if (plane.w >= face.w - epsilon) break;
+		if (uni(plane.w >= face.w - epsilon)) break;
 		if (nv >= EPA_MAXV) { capped = true; break; }
 		const int vid = nv;
 		m.v[nv] = make_float4(v.x, v.y, v.z, 0.0f); nv++;
+		epa_handover();      // the new vertex (uniform store) -> read per lane below
 		// Which triangles see the new vertex is tested one triangle per lane (vertices of existing triangles never change, and a triangle
 		// that died during the surgery is skipped when its turn comes); the reference's descending scan then only visits the set bits.
 		bool okk = true;
@@ -400,8 +419,10 @@ __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 
 			{
 				const int bit = 63 - __clzll((long long)mask);
 				mask &= ~(1ull << bit);
-				if (!tri_dead(m, base + bit)) okk = okk && extrude(m, nt, base + bit, vid);
+				if (uni(!tri_dead(m, base + bit))) okk = okk && extrude(m, nt, base + bit, vid);
 			}
+			okk = uni(okk); nt = uni(nt);
+			epa_handover();      // the surgery's uniform stores -> the next block of triangles, one per lane
 		}
 		// The reference then walks down from the newest triangle while triangles carry the new vertex (dead ones skipped) and extrudes from the
 		// neighbour of the first one that faces the centre or is degenerate, starting over after each extrusion (hull.h:283-297).  Every lane
@@ -432,8 +453,10 @@ __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 
 					if ((badm >> bit) & 1ull) from = tri_ld(m, base + bit).n0;
 				}
 			}
+			from = uni(from);
 			if (from < 0) break;
-			okk = extrude(m, nt, from, vid);
+			okk = uni(extrude(m, nt, from, vid)); nt = uni(nt);
+			epa_handover();      // uniform stores -> the walk starts over, one triangle per lane
 		}
 		if (!okk) { capped = true; break; }
 		// Compaction (hull.h:300-306): the reference fills every dead slot, highest first, with the then-last triangle (swapn: swap the records, patch the
@@ -452,6 +475,7 @@ __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 
 				const int ntf = nt0 - ndead;
 #pragma unroll
 				for (int k = 0; k < 3; k++) { const int i = 64 * k + lane; if (i >= ntf && i < nt0) m.who[i] = (unsigned char)i; }
+				epa_handover();      // one byte per lane -> the replay below reads other lanes' bytes
 				int last = nt0;
 #pragma unroll
 				for (int k = 2; k >= 0; k--)
@@ -504,6 +528,15 @@ __device__ __noinline__ v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 
 	if (guard == 128) capped = true;
 	return plane;
 }
+// the cooperative kernel takes the routine inline (HT_EPA_INLINE); the lane-per-pair kernel, whose own register budget is spent on its GJK groups, calls it
+__device__ HT_EPA_INLINE v4 expanding_polytope_wave(epa_mem &m, v3 s0, v3 s1, v3 s2, v3 s3, const support_t &A, const support_t &B, int lane, long long *ec, bool &capped)
+{
+	return expanding_polytope_wave_body(m, s0, s1, s2, s3, A, B, lane, ec, capped);
+}
+__device__ __noinline__ v4 expanding_polytope_wave_call(epa_mem &m, v3 s0, v3 s1, v3 s2, v3 s3, const support_t &A, const support_t &B, int lane, long long *ec, bool &capped)
+{
+	return expanding_polytope_wave_body(m, s0, s1, s2, s3, A, B, lane, ec, capped);
+}
 // last column of inverse(float4x4({c0,1},{c1,1},{c2,1},{c3,1})) with the cofactor expressions of linalg.h:321-331
 __device__ v4 inverse_w(v3 c0, v3 c1, v3 c2, v3 c3)
 {
@@ -552,7 +585,7 @@ __device__ void separated_wave(bool run, const support_t &A, const support_t &B,
 #pragma unroll
 		for (int k = 0; k < 4; k++) s[k] = V3(__shfl(tet.W[k].p.x, src), __shfl(tet.W[k].p.y, src), __shfl(tet.W[k].p.z, src));
 		bool capped = false;
-		v4 mpp = HT_DBG(dbg, 32) ? V4(0, 0, 1, -0.001f) : expanding_polytope_wave(em, s[0], s[1], s[2], s[3], Ab, Bb, lane, cyc, capped);
+		v4 mpp = HT_DBG(dbg, 32) ? V4(0, 0, 1, -0.001f) : expanding_polytope_wave_call(em, s[0], s[1], s[2], s[3], Ab, Bb, lane, cyc, capped);
 		if (capped && caps && lane == 0) atomicAdd(caps, 1);
 		if (lane == src)
 		{
@@ -754,7 +787,9 @@ struct __attribute__((aligned(16))) co_frame
 	unsigned short jslot[GJK_JMAX];    // its four extra samples: slots jslot .. jslot+3
 	int ncand, off, npool, njig, joff, nepa;
 };
-struct __attribute__((aligned(16))) co_block { int nreq[2], total, jtotal, nepa, enext, pad[2]; };
+// (the model's per-body tables sit in the block's LDS: indexing the kernel-argument copy of ht_model_dev with a run-time body number makes the compiler either
+// fetch from the argument segment with dependent global loads or -- with the polytope routine inline -- copy the whole struct to scratch memory, per lane)
+struct __attribute__((aligned(16))) co_block { int nreq[2], total, jtotal, nepa, enext, pad[2]; int cvoff[HT_MAXNB + 1], vn[HT_MAXNB], collide[HT_MAXNB]; unsigned ignore[HT_MAXNB]; float diam[HT_MAXNB]; };
 struct co_lds { co_block *H; co_frame *F; co_req *req; int *resp; co_job *jobs; };
 enum { RS_IDLE = 0, RS_INIT0, RS_INIT1, RS_ITER, RS_TET2, RS_TET3, RS_EPA, RS_WAIT, RS_HIT, RS_FAR };
 __device__ __forceinline__ void row_argmax(float &b, int &i) { amax_dpp<0xB1>(b, i); amax_dpp<0x4E>(b, i); amax_dpp<0x141>(b, i); amax_dpp<0x140>(b, i); }      // every lane of the row ends with the row's winner
@@ -794,7 +829,7 @@ __device__ __forceinline__ void co_scan(co_block &H, int buf, const co_req *req,
 }
 
 // One pass over a work list: JIG = false: the candidate pairs (Separated with the contact cut-off); JIG = true: the extra samples of the patches.
-template <bool JIG> __device__ void co_pass(const ht_model_dev &M, const co_lds &L, int nfr, epa_mem &em, float driftmax, float jiggle_sin, int t, int dbg, int *caps, int &parity, long long *cyc)
+template <bool JIG> __device__ __forceinline__ void co_pass(const co_lds &L, int nfr, epa_mem &em, float driftmax, float jiggle_sin, int t, int dbg, int *caps, int &parity, long long *cyc)
 {
 	co_block &H = *L.H;
 	const int lane = t & 63, wave = t >> 6;
@@ -831,7 +866,7 @@ template <bool JIG> __device__ void co_pass(const ht_model_dev &M, const co_lds 
 			}
 			else cidx = x - F.off;
 			bi = F.cand[cidx][0]; bj = F.cand[cidx][1];
-			shA = M.cvert_off[bi] | (((M.cvert_off[bi + 1] - M.cvert_off[bi]) >> 4) << 16); shB = M.cvert_off[bj] | (((M.cvert_off[bj + 1] - M.cvert_off[bj]) >> 4) << 16);
+			shA = H.cvoff[bi] | (((H.cvoff[bi + 1] - H.cvoff[bi]) >> 4) << 16); shB = H.cvoff[bj] | (((H.cvoff[bj + 1] - H.cvoff[bj]) >> 4) << 16);
 			st = RS_INIT0;
 		}
 		const co_frame &FR = L.F[fsel];
@@ -937,21 +972,22 @@ template <bool JIG> __device__ void co_pass(const ht_model_dev &M, const co_lds 
 				}
 			}
 			__syncthreads();
-			const int nj = H.nepa < CO_EPAQ ? H.nepa : CO_EPAQ;
+			const int nj = uni(H.nepa < CO_EPAQ ? H.nepa : CO_EPAQ);      // every lane reads the same count; a scalar for the job loop's exit test
 			if (nj == 0) break;
-			for (;;)
+			// Jobs go round the waves (wave w takes jobs w, w + 8, ...: a block has a handful).  They used to be handed out by an atomic counter -- lane 0 fetched a
+			// number, v_readfirstlane spread it -- and THAT was round 3's hang once the polytope was inline: the compiler threaded the lanes that are not lane 0
+			// (whose copy of the number is the initial 0) from the store of the result, which only lane 0 makes, straight back to the v_readfirstlane, past the
+			// atomic; the 63 lanes then read job 0 from their own first lane, for ever (seen in the ISA: a loop level between the job loop and the polytope's
+			// with the v_readfirstlane as its header and lane 0 masked out).  No number travels between lanes now.
+			for (int j = wave; j < nj; j += CO_NW)
 			{
-				int j = 0;
-				if (lane == 0) j = atomicAdd(&H.enext, 1);
-				j = __builtin_amdgcn_readfirstlane(j);
-				if (j >= nj) break;
 				co_job &J = L.jobs[j];
 				const co_frame &F = L.F[J.f];
 				support_t Ab, Bb;
 				const co_body &BA = F.body[J.bi], &BB = F.body[J.bj];
-				Ab.voff = M.cvert_off[J.bi]; Ab.n = M.vert_off[J.bi + 1] - M.vert_off[J.bi]; Ab.pos = V3(BA.pos[0], BA.pos[1], BA.pos[2]); Ab.q = V4(BA.q[0], BA.q[1], BA.q[2], BA.q[3]);
+				Ab.voff = H.cvoff[J.bi]; Ab.n = H.vn[J.bi]; Ab.pos = V3(BA.pos[0], BA.pos[1], BA.pos[2]); Ab.q = V4(BA.q[0], BA.q[1], BA.q[2], BA.q[3]);
 				Ab.outer = J.outer; Ab.opos = V3(J.opos[0], J.opos[1], J.opos[2]); Ab.oq = V4(J.oq[0], J.oq[1], J.oq[2], J.oq[3]); Ab.sub = 0; Ab.grp = 1;
-				Bb.voff = M.cvert_off[J.bj]; Bb.n = M.vert_off[J.bj + 1] - M.vert_off[J.bj]; Bb.pos = V3(BB.pos[0], BB.pos[1], BB.pos[2]); Bb.q = V4(BB.q[0], BB.q[1], BB.q[2], BB.q[3]);
+				Bb.voff = H.cvoff[J.bj]; Bb.n = H.vn[J.bj]; Bb.pos = V3(BB.pos[0], BB.pos[1], BB.pos[2]); Bb.q = V4(BB.q[0], BB.q[1], BB.q[2], BB.q[3]);
 				Bb.outer = 0; Bb.opos = V3(0, 0, 0); Bb.oq = V4(0, 0, 0, 1); Bb.sub = 0; Bb.grp = 1;
 				bool capped = false;
 				const v4 mpp = HT_DBG(dbg, 32) ? V4(0, 0, 1, -0.001f) : expanding_polytope_wave(em, V3(J.p[0][0], J.p[0][1], J.p[0][2]), V3(J.p[1][0], J.p[1][1], J.p[1][2]), V3(J.p[2][0], J.p[2][1], J.p[2][2]),
@@ -988,7 +1024,7 @@ template <bool JIG> __device__ void co_pass(const ht_model_dev &M, const co_lds 
 			}
 			else if (st == RS_HIT && !(hit.separation > driftmax))
 			{
-				const float dmin = fminf(M.bodyc[bi * HT_BC + HT_BC_DIAM], M.bodyc[bj * HT_BC + HT_BC_DIAM]);
+				const float dmin = fminf(H.diam[bi], H.diam[bj]);
 				const bool jig = !(dmin < 0.049f);      // otherwise every extra sample is rejected by the 0.05 m proximity test (see the header)
 				const int need = jig ? 5 : 1;
 				const int s0 = atomicAdd(&F.npool, need);
@@ -1038,6 +1074,14 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 		if (!any) return;
 	}
 	for (int k = t; k < nvp; k += 64 * CO_NW) g_sm[k] = M.cverts[k];      // the padded vertex image (ht_model_dev::cverts), 16 vertices per row
+	{
+		// the per-body tables, picked out of the kernel arguments with compile-time indices (thread k takes body k)
+#pragma unroll
+		for (int k = 0; k < HT_MAXNB; k++) if (t == k) { H.cvoff[k] = M.cvert_off[k]; H.vn[k] = M.vert_off[k + 1] - M.vert_off[k]; H.collide[k] = M.collide[k]; H.ignore[k] = M.ignore[k]; }
+		if (t == HT_MAXNB) H.cvoff[HT_MAXNB] = M.cvert_off[HT_MAXNB];
+		if (t < M.nb) H.diam[t] = M.bodyc[t * HT_BC + HT_BC_DIAM];
+	}
+	__syncthreads();
 	// broad phase in the reference's pair order (physics.h:453-457), one wave per frame, compacted with a ballot; pair index -> (i, j), i < j, row-major
 	if (wave < nfr)
 	{
@@ -1067,10 +1111,10 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 			bool keep = false;
 			if (pidx < npairs)
 			{
-				keep = (M.collide[i] & M.collide[j] & 2) != 0;
+				keep = (H.collide[i] & H.collide[j] & 2) != 0;
 				v3 d = V3(F.body[j].pos[0], F.body[j].pos[1], F.body[j].pos[2]) - V3(F.body[i].pos[0], F.body[i].pos[1], F.body[i].pos[2]);
 				if (length(d) > F.body[i].radius + F.body[j].radius) keep = false;
-				if (M.ignore[i] & (1u << j)) keep = false;
+				if (H.ignore[i] & (1u << j)) keep = false;
 			}
 			if (HT_DBG(dbg, 8)) keep = false;
 			const unsigned long long m = __ballot(keep);
@@ -1091,7 +1135,7 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 	long long cyc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };      // [7..10]: this wave's polytope runs (face search, support, surgery, iterations), [11] their number
 	const long long t_pro = HT_DBG(dbg, 2048) ? clock64() : 0;
 	int parity = 0;
-	co_pass<false>(M, L, nfr, em, driftmax, jiggle_sin, t, dbg, caps, parity, HT_DBG(dbg, 2048) ? cyc : nullptr);
+	co_pass<false>(L, nfr, em, driftmax, jiggle_sin, t, dbg, caps, parity, HT_DBG(dbg, 2048) ? cyc : nullptr);
 	const long long t_post = HT_DBG(dbg, 2048) ? clock64() : 0;
 	if (t == 0)
 	{
@@ -1102,7 +1146,7 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 	__syncthreads();
 	if (H.jtotal > 0)
 	{
-		co_pass<true>(M, L, nfr, em, driftmax, jiggle_sin, t, dbg, caps, parity, nullptr);
+		co_pass<true>(L, nfr, em, driftmax, jiggle_sin, t, dbg, caps, parity, nullptr);
 		// which of the extra samples count (gjk.h:637-640): one lane per patch, samples in order, each against the ones accepted before it
 		for (int f = 0; f < nfr; f++)
 		{
