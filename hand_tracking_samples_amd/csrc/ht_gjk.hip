@@ -879,8 +879,9 @@ template <bool JIG> __device__ __forceinline__ void co_pass(const co_lds &L, int
 				const unsigned long long m = __ballot(sup);
 				if (m)
 				{
-					int base = 0;
-					if (lane == 0) base = atomicAdd(&H.nreq[parity], __popcll(m));
+					// every lane takes part in the atomic (lane 0 adds the wave's count, the others 0) and lane 0's return value is the wave's base: no lane-0-only
+					// block whose bypass the compiler could thread the other lanes through (see the polytope's job loop below)
+					int base = atomicAdd(&H.nreq[parity], lane == 0 ? __popcll(m) : 0);
 					base = __builtin_amdgcn_readfirstlane(base);
 					myreq = base + __popcll(m & ((1ull << lane) - 1ull));
 				}

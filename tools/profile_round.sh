@@ -4,7 +4,9 @@
 #   bench_frames8192.json          one GPU's shard of BASELINE configs[3]
 #   bench_cnn.json                 BASELINE configs[1] (CNN forward only)
 #   bench_config5.json             BASELINE configs[4] (128x128 frames, 26 bones, the path the reference runs)
+#   bench_config5_e2e.json         BASELINE configs[4] end to end (SURVEY 8d config 5 i-iii): the 128x128-input net -> decode -> 26-bone tracker in one unit of work
 #   bench_config5_cnn128.json      BASELINE configs[4], the 128x128-input net
+#   latency_dropin.jsonl           the drop-in surface: HandTracker::update one frame per call through the C++ driver, ht_update_sync on 8 / 64 trackers (p50 / p99 ms)
 #   kernel_stats.csv               rocprofv3 --kernel-trace --stats of a short bench run (1024 frames); kernel_stats_frames8192.csv the same at 8192
 #   pmc_fetch / pmc_write          two separate counter passes (FETCH_SIZE, WRITE_SIZE) per workload (1024 frames, 8192 frames, configs[4]), each aggregated
 #                                  by tools/pmc_traffic.py into a file that names what it was measured on (bench.py quotes it only for that workload)
@@ -14,11 +16,12 @@
 set -e
 if [ "$1" = "--collect" ]; then
 	R=${2:-r03}; S=gpurun_out/prof_$R; D=profiles
-	for f in bench bench_frames8192 bench_cnn bench_config5 bench_config5_cnn128 bench_under_rocprofv3 bench_dist1 pmc_hbm_traffic pmc_hbm_traffic_frames8192 pmc_hbm_traffic_config5 pmc_mfma_util pmc_mfma128_util; do [ -f $S/$f.json ] && cp $S/$f.json $D/${R}_$f.json; done
+	for f in bench bench_frames8192 bench_cnn bench_config5 bench_config5_e2e bench_config5_cnn128 bench_under_rocprofv3 bench_dist1 pmc_hbm_traffic pmc_hbm_traffic_frames8192 pmc_hbm_traffic_config5 pmc_hbm_traffic_config5_e2e pmc_mfma_util pmc_mfma128_util; do [ -f $S/$f.json ] && cp $S/$f.json $D/${R}_$f.json; done
 	cp $S/kernel_stats.csv $D/${R}_rocprofv3_kernel_stats.csv; cp $S/kernel_stats_frames8192.csv $D/${R}_rocprofv3_kernel_stats_frames8192.csv
 	cp $S/kernel_stats_cnn.csv $D/${R}_rocprofv3_kernel_stats_cnn.csv; cp $S/kernel_stats_cnn128.csv $D/${R}_rocprofv3_kernel_stats_cnn128.csv
 	[ -f $S/step_timeline.txt ] && cp $S/step_timeline.txt $D/${R}_step_timeline.txt
 	[ -f $S/gpu_tests.log ] && cp $S/gpu_tests.log $D/${R}_gpu_tests.log
+	[ -f $S/latency_dropin.jsonl ] && cp $S/latency_dropin.jsonl $D/${R}_latency_dropin.jsonl
 	python3 tools/cnn_roofline.py $D/$R > $D/${R}_cnn_kernel_roofline.json
 	ls $D/${R}_*
 	exit 0
@@ -32,7 +35,9 @@ cut -c1-400 $OUT/bench.json
 python3 bench.py --frames-per-gpu 8192 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_frames8192.json 2> $OUT/bench8192.err
 python3 bench.py --workload cnn > $OUT/bench_cnn.json 2> $OUT/bench_cnn.err
 python3 bench.py --workload config5 --steps 10 > $OUT/bench_config5.json 2> $OUT/bench_config5.err
+python3 bench.py --workload config5-e2e --steps 10 > $OUT/bench_config5_e2e.json 2> $OUT/bench_config5_e2e.err      # BASELINE configs[4] end to end: 128x128 net -> decode -> 26-bone tracker
 python3 bench.py --workload config5-cnn128 > $OUT/bench_config5_cnn128.json 2> $OUT/bench_cnn128.err
+python3 tools/latency_dropin.py 300 > $OUT/latency_dropin.jsonl 2> $OUT/latency_dropin.err      # HandTracker::update one frame per call, ht_update_sync on 8 / 64 trackers: p50 / p99
 python3 bench.py --force-dist --steps 10 --no-cpu-baseline > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err      # the RCCL gather rehearsed on this box's one rank
 python3 -m pytest tests -m gpu -q -s > $OUT/gpu_tests.log 2>&1 || true
 echo "benches done"
@@ -55,6 +60,7 @@ pmc_pair() {      # name, workload, frames per GPU, extra bench arguments
 pmc_pair pmc_hbm_traffic cnn+solver 1024 ""
 pmc_pair pmc_hbm_traffic_frames8192 cnn+solver 8192 "--frames-per-gpu 8192"
 pmc_pair pmc_hbm_traffic_config5 config5 1024 "--workload config5"
+pmc_pair pmc_hbm_traffic_config5_e2e config5-e2e 1024 "--workload config5-e2e"
 head -c 300 $OUT/pmc_hbm_traffic.json
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o m -- python3 bench.py --workload cnn --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_mfma.err
 python3 tools/pmc_mfma.py $(find $OUT/pmc_mfma -name "m_counter_collection.csv" | head -1) > $OUT/pmc_mfma_util.json
