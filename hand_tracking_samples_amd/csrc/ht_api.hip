@@ -74,7 +74,9 @@ static int load_model(ht_ctx *ctx, const char *path)
 	const fx_arr *a;
 	if (!(a = need("nb"))) return HT_ERR_IO; int nb = a->i()[0];
 	if (!(a = need("nj"))) return HT_ERR_IO; int nj = a->i()[0];
-	if (nb < 1 || nb >= HT_MAXNB || nj > HT_MAXNJ) { ctx->err = "model too large"; return HT_ERR_IO; }      // body slot HT_MAXNB-1 is the solver's idle body
+	// body slot HT_MAXNB-1 is the solver's idle body; 26 joints: the most whose angular rows a solve can always keep (13 CNN-driven + 6 range rows + slowfit's 3 relative
+	// rows per joint = 247 of 252: csrc/ht_solver.hip), so that no model this accepts can run into that capacity
+	if (nb < 1 || nb >= HT_MAXNB || nj > 26) { ctx->err = "model too large (at most 31 bodies and 26 joints)"; return HT_ERR_IO; }
 	ht_model_dev &m = ctx->model;
 	memset(&m, 0, sizeof m);
 	m.nb = nb; m.nj = nj;

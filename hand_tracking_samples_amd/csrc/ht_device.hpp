@@ -72,7 +72,7 @@ static_assert(HT_MAXPTS == HT_MAX_POINTS, "public header and kernels disagree on
 #define HT_CONTACT 12           // floats per contact: rb0 rb1 normal[3] p0w[3] p1w[3] separation
 #define HT_MAXPAIRS 160         // candidate pair slots per frame
 #define HT_CREC 16              // floats per pre-computed single-body row record of the solver scratch (ht_quad.hpp)
-#define HT_SCRATCH_TAIL 648     // records at the end of a frame's scratch slot: its two-body linear groups and angular records when a frame does not fit k_solve's LDS (ht_solver.hip)
+#define HT_SCRATCH_TAIL 776     // records at the end of a frame's scratch slot: its two-body linear groups and angular records when a frame does not fit k_solve's LDS (ht_solver.hip)
 
 // analysis layout (HT_ANALYSIS = 84 floats)
 #define HT_AN_CRAYS 0

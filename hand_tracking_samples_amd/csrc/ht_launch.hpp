@@ -27,7 +27,8 @@ struct solve_args
 	int force_build;                                                // 0: the launcher chooses k_solve's build; 1 small, 2 only, 3 mid, 4 tiny (every array in HBM): ht_debug_solver_build
 	// the last solve of an update also delivers the poses (GetPoseUser physmodel.h:434 + the "initializing = 50" rule of handtrack.h:781-782), instead of a launch of its own
 	float *out_poses; const int *out_npts; int *out_initializing; int out_min_point_num;
-	float *exact_lin, *exact_ang;                                   // force_build 5 (tests only, ht_debug_exact_solver): the two-body linear rows [B][512][HT_ROW] and the angular rows [B][128][8] in the reference's layout, for the reference's own sweeps
+	int ang_extra_bound;                                            // angular rows a frame can have beyond the 13 CNN-driven ones and 6 per joint (slowfit: 3 per joint; caller-built rows: their largest count): picks the build
+	float *exact_lin, *exact_ang;                                   // force_build 5 (tests only, ht_debug_exact_solver): the two-body linear rows [B][512][HT_ROW] and the angular rows [B][256][8] in the reference's layout, for the reference's own sweeps
 	int dbg;                                                        // timing experiments only (HT_DEBUG_SKIP): 1 skip chains, 2 skip two-body linear, 4 skip angular
 };
 

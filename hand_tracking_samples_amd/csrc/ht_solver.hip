@@ -47,9 +47,12 @@
 #define AR_TORQUE 5        // accumulated torque (the only word a sweep writes)
 #define AR_AXIS 6          // 3, then the gain of the sweeps after RemoveBias
 #define AR_BA 10           // 6: -(Iinv0*axis), then Iinv1*axis
-#define ASLOTS 2           // angular rows are built in registers: row r by lane r%64, slot r/64  (<= 128 rows)
-#define MAXA2 (64 * ASLOTS)
-#define MAXA_LDS 126       // angular rows kept per solve: 13 + up to 6 per joint for the 17-bone hand, plus slowfit's relative rows
+// Angular rows are built in registers: row r by lane r % 64, slot r / 64.  AS = slots per lane is a build parameter: 2 (up to 126 rows: the stock hand has 13 CNN-driven +
+// 71 of its joints) for the tile builds, 4 (up to 252 rows) for the build that serves any model ht_create accepts -- 13 + 6 rows per joint + slowfit's 3 relative rows per
+// joint = 13 + 9 * 26 joints = 247 (ht_launch_solve picks it from the bound the caller states; ht_create refuses more than 26 joints).
+#define MAXA2_OF(AS) (64 * (AS))
+#define MAXA_CAP_OF(AS) ((AS) == 2 ? 126 : 252)
+#define MAXA_RUNS 128      // runs of consecutive angular rows on one body pair a solve schedules (a joint's rows are one run: 13 + 2 per joint; beyond: counted, dropped)
 #define MAXG (HT_MAXNJ + HT_MAXCONTACT + 1)      // groups a frame can have: every joint, every contact the contact kernel keeps, the idle group
 // LDS per frame: ~5 KB of body state and schedule tables, a 5 KB union of prologue scratch and the angular records, and three arrays whose size is
 // the build's choice -- the two-body linear groups (256 B each), the impulse sums of the single-body rows (4 B each), the angular records (64 B each).
@@ -63,9 +66,9 @@
 #define LM_FRIC 0x10000    // meta bits of a group: contact (friction rows limited by the normal row's impulse sum, physics.h:292)
 #define LM_NORMAL 0x20000
 
-template <int NGRP_, int NSUM_, int NANG_, int NIDX_> struct lds_t
+template <int NGRP_, int NSUM_, int NANG_, int NIDX_, int AS_ = 2> struct lds_t
 {
-	static constexpr int NGRP = NGRP_, NSUM = NSUM_, NANG = NANG_, NIDX = NIDX_;
+	static constexpr int NGRP = NGRP_, NSUM = NSUM_, NANG = NANG_, NIDX = NIDX_, MAXA2 = MAXA2_OF(AS_);
 	static constexpr int LIDLE = MAXG - 1;                      // slot of the idle entry in lorder
 	float pool[NGRP * LGRP] __attribute__((aligned(16)));      // two-body linear groups; first member: group addresses then fit the short offsets of two-address LDS reads
 	// body state in 16-byte records: component c of body b is word 4*b + c
@@ -90,7 +93,7 @@ template <int NGRP_, int NSUM_, int NANG_, int NIDX_> struct lds_t
 			int aprefix[HT_MAXNJ + 1], rprefix[HT_MAXNJ + 1];
 			unsigned char rowj[MAXA2];             // joint of every joint-range row
 			unsigned char lrb[MAXG][2], arb[MAXA2][2];     // body pair of every group / angular row (255 = none), for the level schedule
-			unsigned char gst[MAXA2];              // first row of every angular run
+			unsigned char gst[MAXA_RUNS + 1];      // first row of every angular run
 			float4 I4[HT_MAXNB][3];                // columns of the world inverse inertia (w unused): only the row builders need it
 		};
 		float arec[(NANG + 4) * AROW] __attribute__((aligned(16)));      // sweeps: angular records (written once the prologue scratch is dead) + the idle record + read-ahead slack
@@ -306,10 +309,11 @@ __device__ __forceinline__ int level_schedule(int n, int lane, const int (&b0)[2
 // 289-307) in the reference's row order and association order, no fused multiply-adds, one lane -- instead of the Jacobian-form sweeps.  With it the whole
 // update reproduces the restatement bit for bit, which isolates the Jacobian-form arithmetic as the solver's only difference from the reference.
 #define EX_LIN 512         // two-body linear rows a frame can have in the exact instantiation (a.exact_lin [B][EX_LIN][HT_ROW])
-template <int NGRP_, int NSUM_, int NANG_, int NIDX_, bool EXACT = false>
+template <int NGRP_, int NSUM_, int NANG_, int NIDX_, bool EXACT = false, int AS = 2>
 __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph, solve_args a)
 {
-	__shared__ lds_t<NGRP_, NSUM_, NANG_, NIDX_> S;
+	__shared__ lds_t<NGRP_, NSUM_, NANG_, NIDX_, AS> S;
+	constexpr int ASLOTS = AS, MAXA2 = MAXA2_OF(AS), MAXA_LDS = MAXA_CAP_OF(AS);
 	const int b = blockIdx.x, lane = threadIdx.x;
 	if (a.active_flag && !a.active_flag[b]) return;                // a launch never touches another launch's frames
 	const long long t_entry = HT_DBG(a.dbg, 2048) ? clock64() : 0;
@@ -527,7 +531,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			// physics.h:256-259: Iinv is invariant during the update, so 1/(axis.Iinv0.axis + axis.Iinv1.axis) is computed once
 			R.s2t = 1.0f / (((R.rb0 >= 0) ? dot(R.axis, mul(body_I(S, R.rb0), R.axis)) : 0.0f) + ((R.rb1 >= 0) ? dot(R.axis, mul(body_I(S, R.rb1), R.axis)) : 0.0f));
 			R.mn = mintorque * dt; R.mx = maxtorque * dt; R.mintorque = mintorque; R.torque = 0.0f;
-			if constexpr (EXACT) { float *e = a.exact_ang + ((size_t)b * MAXA2 + r) * 8; for (int k = 0; k < 8; k++) e[k] = row[k]; }
+			if constexpr (EXACT) { float *e = a.exact_ang + ((size_t)b * 256 + r) * 8; for (int k = 0; k < 8; k++) e[k] = row[k]; }
 			S.arb[r][0] = (unsigned char)(R.rb0 >= 0 ? R.rb0 : 255); S.arb[r][1] = (unsigned char)(R.rb1 >= 0 ? R.rb1 : 255);
 		}
 	}
@@ -653,10 +657,16 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		const int r = base + lane;
 		const bool head = r < na && (r == 0 || S.arb[r][0] != S.arb[r - 1][0] || S.arb[r][1] != S.arb[r - 1][1]);
 		const unsigned long long m = __ballot(head);
-		if (head) S.gst[nga + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned char)r;
+		const int k = nga + __popcll(m & ((1ull << lane) - 1ull));
+		if (head && k <= MAXA_RUNS) S.gst[k] = (unsigned char)r;      // entry MAXA_RUNS, if there is one, is where the rows that are kept end
 		nga += __popcll(m);
 	}
 	__syncthreads();
+	if (nga > MAXA_RUNS)      // more runs than the schedule holds (only a caller's many short runs can do that): the rows from run MAXA_RUNS on are dropped, and reported
+	{
+		if (a.caps && lane == 0) atomicAdd(a.caps, 1);
+		na = S.gst[MAXA_RUNS]; nga = MAXA_RUNS;
+	}
 	{
 		// two-body linear groups: lane g (and g + 64) speaks for group g
 		int gb0[2], gb1[2];
@@ -892,7 +902,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				}
 				for (int i = 0; i < na; i++)      // LimitAngular::Iter physics.h:251-265
 				{
-					const float *r = a.exact_ang + ((size_t)b * MAXA2 + i) * 8;
+					const float *r = a.exact_ang + ((size_t)b * 256 + i) * 8;
 					const int rb0 = __float_as_int(r[0]), rb1 = __float_as_int(r[1]);
 					const v3 axis = L3(r + 2);
 					const float mintorque = r[6], maxtorque = r[7];
@@ -1194,7 +1204,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 }
 
 static_assert(sizeof(lds_t<34, 584, 84, 0>) <= 20480, "the small build must leave room for eight frames per CU (160 KB of LDS)");
-static_assert(HT_SCRATCH_TAIL * HT_CREC >= MAXG * LGRP + (MAXA_LDS + 4) * AROW + HT_CREC, "the tail of a frame's scratch slot must hold its linear groups, its angular records and the tuning record");
+static_assert(HT_SCRATCH_TAIL * HT_CREC >= MAXG * LGRP + (MAXA_CAP_OF(4) + 4) * AROW + HT_CREC, "the tail of a frame's scratch slot must hold its linear groups, its angular records and the tuning record");
 void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solve_args &a, int B, hipStream_t s)
 {
 	// the build by what the host knows of the launch: the model's joints and the most points a frame of this call can carry.  A frame that exceeds
@@ -1205,9 +1215,13 @@ void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solv
 	// 126 angular rows in LDS runs.  Not when other kernels share the GPU with this launch (the reset path): they need LDS on every CU too.
 	int build = a.force_build;
 	if (!build) build = tile ? (B <= 1024 && !a.shared_gpu ? 2 : 1) : 3;
+	// the angular rows a frame of this launch can have at most (13 CNN-driven + 6 per joint + what the caller states on top: slowfit's relative rows, caller-built rows):
+	// beyond the 126 of the ordinary builds the build with four row slots per lane runs (252)
+	if (build >= 1 && build <= 3 && 13 + 6 * M.nj + a.ang_extra_bound > MAXA_CAP_OF(2)) build = 6;
 	if (build == 2) hipLaunchKernelGGL((k_solve<66, 1024, 126, 1024>), dim3(B), dim3(64), 0, s, M, ph, a);
 	else if (build == 1) hipLaunchKernelGGL((k_solve<34, 584, 84, 0>), dim3(B), dim3(64), 0, s, M, ph, a);
 	else if (build == 3) hipLaunchKernelGGL((k_solve<71, 1520, 126, 1520>), dim3(B), dim3(64), 0, s, M, ph, a);
-	else if (build == 5) hipLaunchKernelGGL((k_solve<71, 1520, 126, 1520, true>), dim3(B), dim3(64), 0, s, M, ph, a);      // tests only: the reference's own sweeps (ht_debug_exact_solver)
+	else if (build == 5) hipLaunchKernelGGL((k_solve<71, 1520, 126, 1520, true, 4>), dim3(B), dim3(64), 0, s, M, ph, a);      // tests only: the reference's own sweeps (ht_debug_exact_solver)
+	else if (build == 6) hipLaunchKernelGGL((k_solve<71, 1520, 126, 1520, false, 4>), dim3(B), dim3(64), 0, s, M, ph, a);     // models / calls with up to 252 angular rows (records beyond 126 in HBM)
 	else hipLaunchKernelGGL((k_solve<2, 64, 4, 0>), dim3(B), dim3(64), 0, s, M, ph, a);      // tests only: nothing fits, every frame keeps its groups, sums and angular records in HBM
 }

@@ -694,13 +694,13 @@ extern "C" int ht_debug_solve_stats(ht_ctx *ctx, int B, float *out, int reset)
 // pins the Jacobian-form arithmetic of the product's sweeps as the solver's only difference from the reference.  Far slower; never chosen by a launcher.
 extern "C" int ht_debug_solver_build(ht_ctx *ctx, int which)
 {
-	if (!ctx || which < 0 || which > 5) return HT_ERR_ARG;
+	if (!ctx || which < 0 || which > 6) return HT_ERR_ARG;      // 6: the build with four angular-row slots per lane (up to 252 rows), otherwise chosen by the model's joint count
 	if (which == 5 && !ctx->d_exact_lin)
 	{
 		ht_device_guard dev_guard_(ctx->device);
 		void *a = nullptr, *b = nullptr;
 		HIPCHK(ctx, hipMalloc(&a, (size_t)ctx->B * 512 * HT_ROW * sizeof(float))); ctx->allocs.push_back(a); ctx->d_exact_lin = (float *)a;
-		HIPCHK(ctx, hipMalloc(&b, (size_t)ctx->B * 128 * 8 * sizeof(float))); ctx->allocs.push_back(b); ctx->d_exact_ang = (float *)b;
+		HIPCHK(ctx, hipMalloc(&b, (size_t)ctx->B * 256 * 8 * sizeof(float))); ctx->allocs.push_back(b); ctx->d_exact_ang = (float *)b;
 	}
 	ctx->solver_build = which;
 	return HT_OK;
@@ -814,7 +814,7 @@ static int upload_angulars(ht_ctx *ctx, int B, const float *angulars, int acap, 
 	for (int b = 0; b < B; b++)
 	{
 		na[b] = (angulars && nangulars) ? nangulars[b] : 0;
-		if (na[b] < 0 || na[b] > acap || na[b] > 126) { ctx->err = "caller-built angular rows: a count is negative, exceeds the stride or exceeds the 126 angular rows a solve keeps (ht_capacity_events)"; return HT_ERR_ARG; }
+		if (na[b] < 0 || na[b] > acap || na[b] > 126 || 13 + 6 * ctx->model.nj + na[b] > 252) { ctx->err = "caller-built angular rows: a count is negative, exceeds the stride, exceeds 126 or leaves no room for the model's own rows among the 252 angular rows a solve keeps"; return HT_ERR_ARG; }
 		for (int i = 0; i < na[b]; i++) { const float *r = angulars + ((size_t)b * acap + i) * HT_AROW; if ((int)r[0] >= ctx->model.nb || (int)r[1] >= ctx->model.nb) { ctx->err = "caller-built angular rows: body index out of range"; return HT_ERR_ARG; } }
 	}
 	if (acap > 0 && angulars) HIPCHK(ctx, hipMemcpy2D(ctx->d_user_ang, (size_t)ctx->user_ang_cap * HT_AROW * sizeof(float), angulars, (size_t)acap * HT_AROW * sizeof(float), (size_t)acap * HT_AROW * sizeof(float), B, hipMemcpyHostToDevice));
@@ -869,6 +869,7 @@ extern "C" int ht_fit_rows(ht_ctx *ctx, int which, int B, const float *points, i
 	a.cloud_body = ctx->d_rowbody; a.n_cloud = ctx->d_nrows;
 	a.contacts = coll ? ctx->d_contacts : nullptr; a.ncontacts = ctx->d_ncontacts;
 	a.ang_user = ctx->d_user_ang; a.n_ang_user = ctx->d_user_n + 3 * (size_t)ctx->B; a.ang_user_stride = ctx->user_ang_cap;
+	{ int mx = 0; for (int v : na) mx = v > mx ? v : mx; a.ang_extra_bound = mx; }
 	a.analysis = ctx->d_analysis; a.cams = ctx->d_cams;
 	a.state = ctx->d_state[which]; a.scratch = ctx->d_scratch; a.scratch_stride = scratch_stride(ctx); a.batch = ctx->B;
 	if (exact_solver(ctx)) { ctx->err = "the exact-order instantiation (ht_debug_solver_build 5) serves the update entry points only"; return HT_ERR_STATE; }
@@ -947,6 +948,7 @@ extern "C" int ht_physics_update(ht_ctx *ctx, int which, int B, const float *lin
 	a.rows_cloud = ctx->d_rows; a.n_cloud = ctx->d_nrows;
 	a.contacts = coll ? ctx->d_contacts : nullptr; a.ncontacts = ctx->d_ncontacts;
 	a.ang_user = ctx->d_user_ang; a.n_ang_user = ctx->d_user_n + 3 * (size_t)ctx->B; a.ang_user_stride = ctx->user_ang_cap;
+	{ int mx = 0; for (int v : na) mx = v > mx ? v : mx; a.ang_extra_bound = mx; }
 	a.lin_tail = ctx->d_user_lin; a.n_lin_tail = ctx->d_user_n + (size_t)ctx->B; a.lin_tail_stride = ctx->user_lin_cap;
 	a.lin_tail_pos = ctx->d_user_pos; a.n_tail_groups = ctx->d_user_n + 2 * (size_t)ctx->B;
 	a.no_model_rows = 1;
@@ -997,6 +999,7 @@ extern "C" int ht_slowfit(ht_ctx *ctx, int B, int hold, const float *refpose, in
 		for (int i = 0; i < 3; i++) { a.sf_spoint[i] = spoint ? spoint[i] : 0.0f; a.sf_rbpoint[i] = rbpoint ? rbpoint[i] : 0.0f; }
 		a.ray_rows = (a.sf_ncray > 0 || select_rb >= 0) ? 1 : 0;
 		a.sf_refpose = rel ? ctx->d_sf_ref : nullptr; a.sf_hold = rel ? hold : 0;
+		a.ang_extra_bound = rel ? 3 * ctx->model.nj : 0;      // RelativeAngularConstraints: one row per ranged axis of a joint at most
 		a.steps_keyangles = ctx->par.steps_keyangles; a.min_cray_prob = ctx->par.min_cray_prob;
 		if (exact_solver(ctx)) { ctx->err = "the exact-order instantiation (ht_debug_solver_build 5) serves the update entry points only"; return HT_ERR_STATE; }
 		a.force_build = ctx->solver_build;
