@@ -296,3 +296,70 @@ def test_nan_in_the_tracked_state_ends_in_the_sanity_check_reset(ctx, weights):
         for k in range(4):
             assert ini[k] == ref_flags[k][1] and (err[k] == ref_flags[k][0] or (np.isnan(err[k]) and np.isnan(ref_flags[k][0]))), (k, err[k], ref_flags[k])
     ctx.set_params(mainthreadpasses=3)
+
+
+def _chain_model_json(path, nb, full_ranges=True):
+    """a chain of nb boxes along z in the reference's JSON schema (controlcages + joints), every joint with two-sided ranges on all three axes (six angular rows)"""
+    import json
+    rng = np.random.RandomState(7)
+    cages, joints = [], []
+    for b in range(nb):
+        rx, ry, z1 = 0.012 + 0.0005 * (b % 3), 0.009, 0.02
+        v = [(-rx, -ry, 0.0), (rx, -ry, 0.0), (rx, ry, 0.0), (-rx, ry, 0.0), (-rx, -ry, z1), (rx, -ry, z1), (rx, ry, z1), (-rx, ry, z1)]
+        cages.append({"faces": [[3, 2, 1, 0], [4, 5, 6, 7], [0, 1, 5, 4], [1, 2, 6, 5], [2, 3, 7, 6], [3, 0, 4, 7]],
+                      "verts": [[float("%.6g" % (x + rng.uniform(-0.0005, 0.0005))) for x in p] for p in v]})
+        if b:
+            joints.append({"jointframe": [0, 0, 0, 1], "p0": [0, 0, 0.021], "p1": [0, 0, -0.001], "rangemax": [30, 20, 10] if full_ranges else [30, 0, 0],
+                           "rangemin": [-30, -20, -10] if full_ranges else [-30, 0, 0], "rbi0": b - 1, "rbi1": b})
+    with open(path, "w") as fp:
+        json.dump({"controlcages": cages, "joints": joints}, fp)
+
+
+def test_models_with_many_ranged_joints(weights, tmp_path):
+    """The angular rows of a solve: 13 CNN-driven + up to 6 per joint.  A 27-body chain whose 26 joints are ranged on all three axes brings 13 + 156 = 169 rows
+    (more than the 126 the ordinary solver builds keep): ht_launch_solve takes the build with four row slots per lane (252 rows, records beyond 126 in HBM), no
+    capacity event.  With the exact-order sweeps the update equals the restatement BIT FOR BIT (same rows, same order, nothing dropped); the product's sweeps agree
+    to the solver's tolerance after one MultiStepSim step and one pass (a thin 27-link chain thrown at a hand's cloud amplifies rounding quickly: 2e-3 after two steps).
+    A model with 27 joints is refused by ht_create (13 + 9 per joint would not fit 252)."""
+    from hand_tracking_samples_amd import native
+    ok_json, big_json, baked = str(tmp_path / "chain27.json"), str(tmp_path / "chain28.json"), str(tmp_path / "chain27.htfx")
+    _chain_model_json(ok_json, 27); _chain_model_json(big_json, 28)
+    with pytest.raises(native.HTError, match="26 joints"):
+        native.Context(big_json, 1)
+    native.model_bake(ok_json, baked)
+    depth, cams, _ = _bank(2)
+    start = np.zeros((2, 27, 7), np.float32); start[:, :, 6] = 1.0
+    for b in range(27):      # the chain laid out in front of the camera, inside the cloud
+        start[:, b, :3] = (-0.05 + 0.004 * b, 0.01 * np.sin(0.4 * b), 0.45 + 0.002 * b)
+    L = ol.lib()
+    for build in (0, 5):
+        ctx = native.Context(ok_json, 2)
+        try:
+            assert (ctx.nb, ctx.nj) == (27, 26)
+            ctx.load_weights(weights)
+            ctx.set_params(microforce=3.0, mainthreadpasses=1, steps=1)
+            if build:
+                ctx.debug_solver_build(build)
+            ctx.tracker_reset(start)
+            got, cnn = ctx.update_sync(depth, cams, want_cnn=True)
+            other = ctx.get_state(1, 2)
+            assert ctx.capacity_events() == (0, 0, 0)
+        finally:
+            ctx.close()
+        orc = ol.Oracle(weights, model=baked)
+        orc.head.par.microforce = 3.0; orc.head.par.mainthreadpasses = 1; orc.head.par.steps = 1
+        ref = np.zeros((2, 27, 7), np.float32); ref_other = np.zeros((2, 27, 13), np.float32)
+        L.ho_set_round_once(1)
+        try:
+            for k in range(2):
+                y = np.ascontiguousarray(cnn[k]); L.ho_set_cnn_override(orc.h, ol.fptr(y))      # the same heat-maps on both sides: this test is about the solver
+                orc.reset(start[k]); cam = ol.camera(cams[k])
+                L.ho_update(orc.h, ol.u16ptr(np.ascontiguousarray(depth[k])), C.byref(cam), ol.fptr(ref[k]))
+                ref_other[k] = orc.get_state(1)
+        finally:
+            L.ho_set_cnn_override(orc.h, None); L.ho_set_round_once(0); orc.close()
+        if build == 5:
+            assert np.array_equal(got, ref) and np.array_equal(other, ref_other), "exact-order sweeps on 169 angular rows"
+        else:
+            assert np.abs(other[:, :, :7] - ref_other[:, :, :7]).max() <= TIGHT_POS_TOL      # after one hard-driven step
+            _compare("27-body chain, 169 angular rows", got, ref, [0, 0])
