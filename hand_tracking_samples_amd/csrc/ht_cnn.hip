@@ -169,6 +169,11 @@ __device__ __forceinline__ float expf_via_double(float xf)
 	return (float)__builtin_ldexp(p, ki);
 }
 __device__ __forceinline__ float tanh_ref(float t) { float e = expf_via_double(2 * t); return (e - 1) / (e + 1); }
+// The maximum of a pooling window (cnn.h:141-148 takes std::max) as one v_max_f32 instead of a compare and a select.  The two differ on NaNs (the layers' inputs are
+// finite) and on which zero max(-0, +0) is -- and the pooled value goes through tanh_ref next, which maps either zero to +0.
+// (Spelled as the instruction: through __builtin_fmaxf the compiler first quiets possible signalling NaNs of either operand with a v_max_f32 x, x, x each.)
+__device__ __forceinline__ float max_pool(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float max_pool4(float a, float b, float c, float d) { float r; asm("v_max_f32 %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4" : "=&v"(r) : "v"(a), "v"(b), "v"(c), "v"(d)); return r; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -206,7 +211,12 @@ __global__ __launch_bounds__(256) void k_conv1(const float *__restrict__ cnn_in,
 	}
 	const float bias = B1[n];
 	__syncthreads();
-	for (int w = wave; w < prows * PW; w += 4)
+	// The window loop is bound by the SIMD's one vector issue port, not by the matrix pipe: 7 MFMAs hold the port for 56 of their 224 clocks, and everything else a window
+	// issues has to fit the rest beside three other waves' windows.  So the wave's index is read into a scalar register -- the window's coordinates and its tile address
+	// are then scalar arithmetic -- and a maximum is one v_max_f32 (a compare and a select cost three issue slots with their wait state).
+	const int swave = __builtin_amdgcn_readfirstlane(wave);
+	float *const pdst = pooled + n * PR * PW;
+	for (int w = swave; w < prows * PW; w += 4)
 	{
 		const int ty = w / PW, tx = w % PW;
 		const float *base = tile + 4 * ty * IWP + 4 * tx;
@@ -214,11 +224,11 @@ __global__ __launch_bounds__(256) void k_conv1(const float *__restrict__ cnn_in,
 #pragma unroll
 		for (int s = 0; s < 7; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(base[aoff[s]], wreg[s], acc, 0, 0, 0);
 		// C/D map 16x16: col = lane & 15 (channel), row = (lane >> 4) * 4 + r (pixel of the window): two 2x2 max-pools (cnn.h:141-148) = the maximum of the 16 rows
-		float m = fmax_std(fmax_std(fmax_std(acc[0], acc[1]), acc[2]), acc[3]);
+		float m = max_pool4(acc[0], acc[1], acc[2], acc[3]);
 		// across the four 16-lane rows (the window's four image rows): v_permlane16_swap / v_permlane32_swap exchange rows between two copies of m
-		{ const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false); m = fmax_std(__uint_as_float(r[0]), __uint_as_float(r[1])); }
-		{ const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false); m = fmax_std(__uint_as_float(r[0]), __uint_as_float(r[1])); }
-		if (lane < 16) pooled[(n * PR + ty) * PW + tx] = m;
+		{ const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false); m = max_pool(__uint_as_float(r[0]), __uint_as_float(r[1])); }
+		{ const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false); m = max_pool(__uint_as_float(r[0]), __uint_as_float(r[1])); }
+		if (lane < 16) pdst[ty * PW + tx] = m;
 	}
 	__syncthreads();
 	for (int i = t; i < 16 * prows * PW; i += 256)
@@ -234,13 +244,16 @@ __global__ __launch_bounds__(256) void k_conv1(const float *__restrict__ cnn_in,
 // A block takes BAND output rows of one frame (all 64 output channels, 16 per wave): implicit GEMM M = BAND*OW, N = 64, K = 256.
 // 64x64 net: IWD = 15, OW = 12, BAND = 12 (M = 144, the whole frame).  128x128 net: IWD = 31, OW = 28, BAND = 4 (M = 112; 7 bands per frame,
 // 14 KB of input rows + 28 KB of pre-pool outputs in LDS instead of 61 KB + 200 KB for the whole frame).
+// The 16 rows of an MFMA tile are FOUR 2x2 pooling windows, a window's four pixels on consecutive rows: the C/D map of the instruction (row = (lane >> 4) * 4 + r) then puts
+// a window's four pre-pool values into the four accumulator registers of one lane, the max-pool (cnn.h:141-148) is three register maxima, and every lane ends a tile with
+// one finished output -- tanh and the store follow at once.  (Rows in image order needed 37 KB of LDS for the pre-pool values of a 64x64-net frame, a second pass and a
+// barrier; with 51 KB per block a CU held three of the four blocks it gets at 1024 frames and ran the fourth alone: 56 us, now 14 KB per block and one round.)
 template <int IWD, int OW, int BAND>
 __global__ __launch_bounds__(256) void k_conv2(const float *__restrict__ act1, const float *__restrict__ W2p, const float *__restrict__ B2, float *__restrict__ act2)
 {
-	constexpr int M = BAND * OW, MT = M / 16, IR = BAND + 3, PO = OW / 2, CH = IR * IWD;
-	static_assert(M % 16 == 0 && BAND % 2 == 0 && OW % BAND == 0, "band must hold whole MFMA tiles and whole pooling windows");
+	constexpr int IR = BAND + 3, PO = OW / 2, CH = IR * IWD, NW = (BAND / 2) * PO, MT = NW / 4;      // NW: pooling windows of the band
+	static_assert(NW % 4 == 0 && BAND % 2 == 0 && OW % 2 == 0 && OW % BAND == 0, "band must hold whole MFMA tiles of whole pooling windows");
 	__shared__ float in[16 * CH];
-	__shared__ float out[64 * M];
 	const int b = blockIdx.x, band = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	const int oy0 = band * BAND;
 	for (int i = t; i < 16 * CH; i += 256) { const int ic = i / CH, r = i % CH; in[i] = act1[(size_t)b * (16 * IWD * IWD) + ic * (IWD * IWD) + oy0 * IWD + r]; }
@@ -252,12 +265,13 @@ __global__ __launch_bounds__(256) void k_conv2(const float *__restrict__ act1, c
 	__syncthreads();
 	// per lane k decomposition is fixed per k-step: k = 4*ks + (lane>>4): tap p = k>>4 = ks>>2, ic = 4*(ks&3) + (lane>>4)
 	const int icl = lane >> 4;
+	const int arow = lane & 15, awin = arow >> 2, ady = (arow >> 1) & 1, adx = arow & 1;      // A operand: this lane supplies pixel (ady, adx) of window awin of the tile
+	float *const dst = act2 + (size_t)b * (64 * PO * PO) + n * (PO * PO) + (oy0 / 2) * PO;       // index = x + PO*y + PO*PO*c, the layout LFull consumes
 	for (int mt = 0; mt < MT; mt++)
 	{
-		const int m = mt * 16 + (lane & 15);
-		const int oy = m / OW, ox = m % OW;
+		const int win = 4 * mt + awin, wy = win / PO, wx = win % PO;
 		f32x4 acc = { bias, bias, bias, bias };
-		const float *base = in + oy * IWD + ox;
+		const float *base = in + (2 * wy + ady) * IWD + 2 * wx + adx;
 #pragma unroll
 		for (int ks = 0; ks < 64; ks++)
 		{
@@ -265,18 +279,10 @@ __global__ __launch_bounds__(256) void k_conv2(const float *__restrict__ act1, c
 			float a = base[ic * CH + ky * IWD + kx];
 			acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[ks], acc, 0, 0, 0);
 		}
-		// C/D map 16x16: col = lane&15 (oc), row = (lane>>4)*4 + r (pixel within the tile)
-#pragma unroll
-		for (int r = 0; r < 4; r++) out[n * M + mt * 16 + (lane >> 4) * 4 + r] = acc[r];
-	}
-	__syncthreads();
-	constexpr int PB = (BAND / 2) * PO;                  // pooled pixels per channel in this band
-	for (int i = t; i < 64 * PB; i += 256)
-	{
-		const int c = i / PB, py = (i % PB) / PO, pxx = i % PO;
-		const float *o = out + c * M + (2 * py) * OW + 2 * pxx;
-		float mm = fmax_std(fmax_std(fmax_std(o[0], o[1]), o[OW]), o[OW + 1]);
-		act2[(size_t)b * (64 * PO * PO) + c * (PO * PO) + (oy0 / 2 + py) * PO + pxx] = tanh_ref(mm);        // index = x + PO*y + PO*PO*c, the layout LFull consumes
+		// C/D map 16x16: col = lane&15 (oc), row = (lane>>4)*4 + r = pixel r of window (lane>>4) of the tile, pixels in the order (0,0) (0,1) (1,0) (1,1)
+		const float mm = max_pool4(acc[0], acc[1], acc[2], acc[3]);
+		const int wo = 4 * mt + icl;
+		dst[wo] = tanh_ref(mm);      // window wo of the band: pooled row wo / PO, column wo % PO
 	}
 }
 

@@ -1,6 +1,8 @@
-# average kernel durations of a short bench run under rocprofv3 (1024 frames): bash tools/kernel_avgs.sh [pattern]
+# average kernel durations of a short bench run under rocprofv3 (1024 frames): bash tools/kernel_avgs.sh [workload, default cnn+solver]
+WL=${1:-cnn+solver}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/kavg -o t -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/kavg.err || exit 1
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/kavg
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/kavg -o t -- python3 $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/kavg.err || exit 1
 python3 - <<PY
 import csv,glob
 f=glob.glob("$GRAFT_REPO_ROOT/gpurun_out/kavg/**/t_kernel_stats.csv",recursive=True)[0]
