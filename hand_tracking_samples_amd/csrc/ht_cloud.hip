@@ -411,6 +411,8 @@ __device__ __forceinline__ v3 G3(const float *p) { return V3(p[0], p[1], p[2]); 
 __device__ __forceinline__ v4 G4(const float *p) { return V4(p[0], p[1], p[2], p[3]); }
 __device__ __forceinline__ m3 GM(const float *p) { m3 m; m.x = V3(p[0], p[1], p[2]); m.y = V3(p[3], p[4], p[5]); m.z = V3(p[6], p[7], p[8]); return m; }
 #define UB_LDS_ROWS 896      // rows of the single-body solve kept in LDS (3584 points); 72 KB with sums and chain: two blocks per CU
+#define UB16_ROWS 448        // rows up to which the solve runs sixteen rows at a time (ht_quad.hpp: quad_blocks16_run): records + couplings + sums of 448 + 32 rows are 63 KB of the same 66
+static_assert((size_t)(UB16_ROWS + QUAD_B16_SLACK) * (CREC + 16 + 1) * sizeof(float) <= (size_t)(UB_LDS_ROWS + QUAD_CHAIN_SLACK) * (CREC * sizeof(float) + sizeof(float) + sizeof(unsigned short)), "the blocked solve's arrays must fit the row-by-row solve's LDS");
 template <bool EXACT> __device__ __forceinline__ void reset_frame(const ht_model_dev &M, const ht_physics_dev &ph, float *state, const float4 *__restrict__ pts, const int *__restrict__ npts,
                                             const float *__restrict__ analysis, const float *__restrict__ cams, int n_unibody,
                                             float unibody_force, float *rows, int *nrows, float *scratch, int scratch_stride, int batch, int dbg, const int b)
@@ -431,6 +433,8 @@ template <bool EXACT> __device__ __forceinline__ void reset_frame(const ht_model
 	float *const urow = reinterpret_cast<float *>(s_planes);                                            // single-body solve: records, impulse sums, chain
 	float *const usum = urow + (UB_LDS_ROWS + QUAD_CHAIN_SLACK) * CREC;
 	unsigned short *const uidx = reinterpret_cast<unsigned short *>(usum + UB_LDS_ROWS + QUAD_CHAIN_SLACK);
+	float *const ug = urow + (UB16_ROWS + QUAD_B16_SLACK) * CREC;                                       // the same, sixteen rows at a time (up to UB16_ROWS rows): records, couplings, impulse sums
+	float *const usum16 = ug + (UB16_ROWS + QUAD_B16_SLACK) * 16;
 
 	{
 		// ---- PoseFromScratch.  Palm ray from the first three landmark rays, inverse-distance weighted centroid of the cloud (handtrack.h:483-490): the weights are
@@ -538,7 +542,8 @@ template <bool EXACT> __device__ __forceinline__ void reset_frame(const ht_model
 		// ---- the cloud rows of every 4th point from the camera's origin, UnibodyFit's force limits (handtrack.h:457-461)
 		cloud_rows_frame(M, state, pts, cams, 4, 1, 3, 0.0f, 0.0f, 0.0f, 0.0f, unibody_force, rows, nrows, none, dbg, b, n, 0, 1, tab, L, nullptr, nullptr);
 		__syncthreads();
-		// ---- UnibodyFit's solve: all rows act on one proxy body, so the Gauss-Seidel chain is sequential (one quad of lanes walks it)
+		// ---- UnibodyFit's solve: all rows act on one proxy body, so the Gauss-Seidel chain is sequential: a wave takes it sixteen rows at a time (ht_quad.hpp: the rows' velocity
+		//      terms side by side, the impulses resolved in row order through pre-computed couplings); a cloud too large for that, one quad row by row
 		if (t < nb) { for (int i = 0; i < 3; i++) pos[t][i] = st[t * HT_STATE_STRIDE + i]; for (int i = 0; i < 4; i++) q[t][i] = st[t * HT_STATE_STRIDE + 3 + i]; }
 		__syncthreads();
 		// SanityCheck before the solve (handtrack.h:463) is a no-op unless the pose already holds NaNs; those bodies are reset
@@ -621,10 +626,13 @@ template <bool EXACT> __device__ __forceinline__ void reset_frame(const ht_model
 		else
 		{
 		const bool in_lds = nr <= UB_LDS_ROWS;
+		const bool blk16 = nr <= UB16_ROWS && !HT_DBG(dbg, 8192);      // sixteen rows at a time (ht_quad.hpp); a larger cloud row by row
+		const int nblk16 = (nr + 15) >> 4;
 		float *const grec = scratch + (size_t)b * scratch_stride * CREC;
 		float *const gsum = scratch + (size_t)batch * scratch_stride * CREC + (size_t)b * scratch_stride;
 		unsigned *const gidx = reinterpret_cast<unsigned *>(scratch + (size_t)batch * scratch_stride * (CREC + 1)) + (size_t)b * scratch_stride;
-		if (in_lds) { for (int i = t; i < nr + QUAD_CHAIN_SLACK; i += RS_THREADS) { usum[i] = 0.0f; uidx[i] = (unsigned short)i; } }
+		if (blk16) { for (int i = t; i < 16 * nblk16 + QUAD_B16_SLACK; i += RS_THREADS) { usum16[i] = 0.0f; if (i >= nr) quad_write_noop(urow + (size_t)i * CREC); } }      // the last block is filled up with rows that change nothing
+		else if (in_lds) { for (int i = t; i < nr + QUAD_CHAIN_SLACK; i += RS_THREADS) { usum[i] = 0.0f; uidx[i] = (unsigned short)i; } }
 		else for (int i = t; i < nr + QUAD_CHAIN_SLACK; i += RS_THREADS) { gsum[i] = 0.0f; gidx[i] = (unsigned)i; }
 		for (int i = t; i < nr; i += RS_THREADS)
 		{
@@ -639,9 +647,22 @@ template <bool EXACT> __device__ __forceinline__ void reset_frame(const ht_model
 		}
 		__threadfence_block();
 		__syncthreads();
-		if (t < 4)       // the proxy body in quad layout (ht_quad.hpp): lane c < 3 owns component c, lane 3 carries the row's target speed
+		if (blk16)      // the couplings of every row with the rows before it in its block of sixteen: one float4 (four couplings) per entry
 		{
-			const int c = t;
+			const float4 *const r4 = reinterpret_cast<const float4 *>(urow);
+			for (int e = t; e < 64 * nblk16; e += RS_THREADS)
+			{
+				const int r = e >> 2, k = e & 3, j = r & 15, first = r & ~15;
+				float v[4];
+#pragma unroll
+				for (int u = 0; u < 4; u++) { const int i = 4 * k + u; v[u] = i < j ? quad_coupling16(r4 + 4 * r, r4 + 4 * (first + i)) : 0.0f; }
+				reinterpret_cast<float4 *>(ug)[e] = make_float4(v[0], v[1], v[2], v[3]);
+			}
+			__syncthreads();
+		}
+		if (blk16 ? t < 64 : t < 4)       // the proxy body in quad layout (ht_quad.hpp): lane c < 3 of a quad owns component c, lane 3 carries the row's target speed; one quad walks the rows, or a wave's sixteen quads sixteen rows at a time
+		{
+			const int c = t & 3;
 			// rbinitvelocity on a body at rest: 0 * damping + 0
 			quad_body qb = { (0.0f * M.ub_dampleft) + 0.0f, (0.0f * M.ub_dampleft) + 0.0f };
 			v3 pn = ubpos; v4 qn = ubq;
@@ -649,7 +670,7 @@ template <bool EXACT> __device__ __forceinline__ void reset_frame(const ht_model
 			for (int sweep = 0; sweep < total; sweep++)
 			{
 				const int tsoff = sweep >= ph.iterations ? 1 : 0;        // RemoveBias: lane 3 switches to the ts_post slot
-				if (nr > 0) { if (in_lds) quad_chain_run(qb, urow, uidx, usum, nr, c, tsoff); else quad_chain_run(qb, grec, gidx, gsum, nr, c, tsoff); }
+				if (nr > 0) { if (blk16) quad_blocks16_run(qb, urow, ug, usum16, nblk16, t, tsoff); else if (in_lds) quad_chain_run(qb, urow, uidx, usum, nr, c, tsoff); else quad_chain_run(qb, grec, gidx, gsum, nr, c, tsoff); }
 				if (sweep + 1 == ph.iterations)
 				{
 					const v3 lin = V3(dpp<QP_BC0>(qb.l), dpp<QP_BC1>(qb.l), dpp<QP_BC2>(qb.l)), ang = V3(dpp<QP_BC0>(qb.av), dpp<QP_BC1>(qb.av), dpp<QP_BC2>(qb.av));

@@ -180,6 +180,82 @@ __device__ __forceinline__ void quad_chain_run(quad_body &B, const float *recs, 
 	if (post) quad_chain_run_<true>(B, recs, idx, sums, cnt, c, kswitch, lin_w, ang_w, bodyA, bodyB);
 	else quad_chain_run_<false>(B, recs, idx, sums, cnt, c, kswitch, lin_w, ang_w, bodyA, bodyB);
 }
+// ---- ONE body's rows sixteen at a time (round 4: the single-body solves of k_reset, where one quad walked the whole cloud row by row while the batch waited) --------
+// Consecutive rows of a body depend on each other only through the momenta, and linearly: with M the momenta before row 0 of a block of sixteen rows,
+//   vn_j / effmass_j = c_j . (M + sum_{i<j} d_i imp_i) = c_j . M + sum_{i<j} G(j,i) imp_i,      G(j,i) = c_j . d_i   (c_j = slots x, z of row j's record, d_i = slots w, y of row i's)
+// and G changes during a PhysicsUpdate no more than the records do.  So the sixteen quads of a wave take sixteen rows TOGETHER: every quad holds the body's momenta
+// (the same values), forms its row's c_j . M side by side with the others (the expensive part: two products and a three-lane sum), then the impulses are resolved in
+// row order -- imp_i = clamp(x_i), read from its lane into a scalar register, x_j += -G(j,i) imp_i for the rows behind it: three dependent instructions per row -- and
+// every quad adds all sixteen d_i imp_i to its momenta.  Same rows, same order, same clamps as LimitLinear::Iter (physics.h:289-307); another association order of the
+// same sums (G imp in place of c . (d imp); the sixteen contributions added as a tree), like the step from the reference's expression to quad_row_step was.
+// ~80 instructions per sixteen rows where sixteen single rows issue ~300, the dependent chain ~55 instead of ~130.  (For k_solve's chains, many bodies per frame and 1024
+// frames in flight, a four-row variant of this was measured and bought 10 %: DESIGN.md section 15.  Here one body has all the rows and eight blocks have the chip.)
+// G travels with the records: 16 floats per row, -G(j,i) at position i, zero for i >= j.
+// One block: a = this lane's slot of its quad's row, g = the row's sixteen couplings, sum = the row's impulse sum.  Returns the new impulse sum (all lanes of the quad).
+// Lane 3's column runs through the vector instructions with the scalars of its slot: what it computes in p, t, s, ul, ua is never used.
+template <bool POST>
+__device__ __forceinline__ float quad_block16_step(quad_body &B, const float4 a, const float4 (&g)[4], const float sum)
+{
+	const float p = __fmaf_rn(a.z, B.av, a.x * B.l);
+	const float t = dpp<QP_PREV>(p) + p;
+	const float s = dpp<QP_PREV>(t) + p;
+	float x = -(POST ? a.y : a.x) - dpp<QP_PREV>(s);                     // lane 3: (-targetspeed - c.M) / effective mass
+	const float lo = a.z - sum, hi = a.w - sum;
+	float imp;
+	// row i's impulse is final once the rows before it have been taken into x_i; it goes to the rows behind it through a scalar register (quad i's lane 3 is lane 4i + 3)
+#define QB16(i, G) imp = clamp_med3(x, lo, hi); x = __fmaf_rn(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(imp), 4 * (i) + 3)), G, x)
+	QB16(0, g[0].x); QB16(1, g[0].y); QB16(2, g[0].z); QB16(3, g[0].w); QB16(4, g[1].x); QB16(5, g[1].y); QB16(6, g[1].z); QB16(7, g[1].w);
+	QB16(8, g[2].x); QB16(9, g[2].y); QB16(10, g[2].z); QB16(11, g[2].w); QB16(12, g[3].x); QB16(13, g[3].y); QB16(14, g[3].z);
+#undef QB16
+	imp = clamp_med3(x, lo, hi);
+	const float impq = dpp<QP_BC3>(imp);
+	float ul = a.w * impq, ua = a.y * impq;                              // n[c] * imp_j, g[c] * imp_j
+	// the sixteen rows' contributions, summed the same way in every quad (each step adds two values that both partners hold: additions commute, so the sixteen copies of
+	// the momenta stay equal bit for bit): quads j and j + 2 of a DPP row, then j and j + 1, then the rows pairwise, then the pairs
+	ul += dpp<0x128>(ul); ua += dpp<0x128>(ua);                          // row_ror:8
+	ul += dpp<0x124>(ul); ua += dpp<0x124>(ua);                          // row_ror:4
+	{ const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ul), __float_as_uint(ul), false, false); ul = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+	{ const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ua), __float_as_uint(ua), false, false); ua = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+	{ const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(ul), __float_as_uint(ul), false, false); ul = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+	{ const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(ua), __float_as_uint(ua), false, false); ua = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+	B.l += ul; B.av += ua;
+	return sum + impq;
+}
+// Applies rows [0, 16 * nblk) in order, a whole wave on one body: recs = the rows' records back to back (16 floats each), G = their couplings (16 floats each), sums =
+// their impulse sums; lane = lane of the wave.  Two register sets: a block's operands are read while the block before it is applied; reads run one block past the end.
+#define QUAD_B16_SLACK 32      // rows the arrays hold behind the last block (read ahead, never applied)
+template <bool POST>
+__device__ __forceinline__ void quad_blocks16_run_(quad_body &B, const float *recs, const float *G, float *sums, int nblk, int lane)
+{
+	const int jq = lane >> 2, c = lane & 3;
+	const float4 *pa = reinterpret_cast<const float4 *>(recs) + 4 * jq + c;
+	const float4 *pg = reinterpret_cast<const float4 *>(G) + 4 * jq;
+	float *ps = sums + jq;
+	float4 a0 = pa[0], a1, g0[4] = { pg[0], pg[1], pg[2], pg[3] }, g1[4];
+	float s0 = ps[0], s1;
+	for (int blk = 0; blk < nblk; blk += 2)
+	{
+		a1 = pa[64]; g1[0] = pg[64]; g1[1] = pg[65]; g1[2] = pg[66]; g1[3] = pg[67]; s1 = ps[16];
+		ps[0] = quad_block16_step<POST>(B, a0, g0, s0);
+		if (blk + 1 >= nblk) break;
+		a0 = pa[128]; g0[0] = pg[128]; g0[1] = pg[129]; g0[2] = pg[130]; g0[3] = pg[131]; s0 = ps[32];
+		ps[16] = quad_block16_step<POST>(B, a1, g1, s1);
+		pa += 128; pg += 128; ps += 32;
+	}
+}
+__device__ __forceinline__ void quad_blocks16_run(quad_body &B, const float *recs, const float *G, float *sums, int nblk, int lane, int post)
+{
+	if (post) quad_blocks16_run_<true>(B, recs, G, sums, nblk, lane); else quad_blocks16_run_<false>(B, recs, G, sums, nblk, lane);
+}
+// -G(j,i): what row i's impulse adds to row j's (target speed - velocity) / effective mass; rj, ri = the rows' records
+__device__ __forceinline__ float quad_coupling16(const float4 *rj, const float4 *ri)
+{
+	float gsum = rj[0].x * ri[0].w;
+	gsum = __fmaf_rn(rj[0].z, ri[0].y, gsum);
+	gsum = __fmaf_rn(rj[1].x, ri[1].w, gsum); gsum = __fmaf_rn(rj[1].z, ri[1].y, gsum);
+	gsum = __fmaf_rn(rj[2].x, ri[2].w, gsum); gsum = __fmaf_rn(rj[2].z, ri[2].y, gsum);
+	return -gsum;
+}
 // fills one record (see the layout above); r1 = lever arm in the world frame, n = row direction, Iinv = the body's world inverse inertia, minv = its inverse
 // mass, y = effective mass (physics.h:299-300, formed by the caller with the reference's expression)
 __device__ __forceinline__ void quad_write_record(float *rec, v3 r1, v3 n, const m3 &Iinv, float minv, float ts, float ts_post, float y, float fmin_dt, float fmax_dt)

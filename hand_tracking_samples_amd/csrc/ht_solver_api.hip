@@ -266,8 +266,11 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 			// stays on THIS stream, where it is dispatched the moment the CNN ends, and the batch's first step goes to the side stream, which only starts
 			// after a cross-queue wait: launched the other way round the reset blocks often found no CU until the batch's contact kernel had finished.
 			// While the reset frames take their first step the batch prepares its second (cloud rows and contacts of the other frames: a frame's rows and
-			// contacts are its own), after the reset frames' contact blocks are in (same reason).  Then the reset frames' rows for step 1 and ONE solve for
-			// all frames.  (The reset frames any further behind the batch was measured and does not pay: DESIGN.md section 4.)
+			// contacts are its own), after the reset frames' contact blocks are in (same reason); the reset frames' rows for step 1 follow their solve on this
+			// stream, beside the batch's.  Then ONE solve for all frames.  (The reset frames any further behind the batch was measured and does not pay:
+			// DESIGN.md section 4.)  What the reset frames' contact blocks wait for (event marks): the batch's first solve -- both contact kernels want more
+			// registers than a SIMD has left beside a solver wave (256 and 410 against 512 - 168), so they start when that solve ends, 0.55 ms after the fork,
+			// however early the reset kernel is through (0.25 ms); making the batch's solve wait for them instead was measured: 5.39 against 5.31 ms.
 			hipStream_t u = ctx->side[0];
 			mark("fork", s);
 			reset_path(ctx, true, p.steps_unibody, B, s, s, ctx->many_reset);
@@ -281,10 +284,10 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 			mark("reset frames step 0 done", s);
 			multistep(ctx, B, u, 1, 2, ctx->d_nflags, false, -1, false, false, 1);      // in order on the side stream: there is time (0.76 against 0.82 ms), and a fork out of a forked stream does not survive a HIP graph capture
 			mark("batch step 1 rows done", u);
+			multistep(ctx, B, s, 1, 2, ctx->d_flags, false, 1, true, false, 1);      // the reset frames' rows for step 1, beside the batch's
+			mark("reset frames step 1 rows done", s);
 			join(ctx, s, 1);
 			reset_tail(ctx);
-			multistep(ctx, B, s, 1, 2, ctx->d_flags, false, 1, true, false, 1);
-			mark("reset frames step 1 rows done", s);
 			multistep(ctx, B, s, 1, 2, nullptr, false, 0, true, false, 2);
 			mark("step 1 done", s);
 			multistep(ctx, B, s, 2);
