@@ -500,6 +500,88 @@ __global__ __launch_bounds__(768) void k_fc144(const float *__restrict__ A, cons
 		}
 }
 
+// k_fc144 with the tiles brought in by LDS-DMA (global_load_lds_dwordx4: a wave-instruction writes 64 x 16 bytes to LDS at a wave-uniform base + 16 * lane, no registers,
+// no ds_write pass; the SOURCE address is per lane).  A slab is 26 such pieces -- 8 of A (64 rows x 32 k), 18 of B (32 k x 144 columns, which lies in LDS exactly as it does
+// in a row-major W: contiguous 576-byte k-rows) --, two or three per wave, issued right behind the barrier that frees the buffer and waited for at the next slab's barrier.
+// The A image cannot be padded (a piece is 1 KiB of consecutive LDS: 8 rows of 128 bytes), so its 16-byte chunks are XOR-swizzled on the source side: chunk slot s of row r
+// holds k-quad s ^ (r & 7); a fragment read (16 rows, one k) then meets 8 different quads = 8 x 4 banks, two rows per bank (2-way on one read in four) instead of 16-way.
+typedef const __attribute__((address_space(1))) void *ht_gptr;
+typedef __attribute__((address_space(3))) void *ht_lptr;
+template <int BK>      // k-depth of a slab: 32 or 64
+__global__ __launch_bounds__(768) void k_fc144_dma(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K)
+{
+	constexpr int KQ = BK / 4, NPA = F2_BM * BK / 256, NPB = BK * F2_BN / 256, NP = NPA + NPB, PW = (NP + 11) / 12;      // 16-byte chunks per A row; 1-KiB pieces of A, of B, of a slab; pieces per wave
+	static_assert((F2_BM * BK) % 256 == 0 && (BK * F2_BN) % 256 == 0 && (KQ & (KQ - 1)) == 0 && KQ <= 16, "a slab must be whole pieces");
+	__shared__ __attribute__((aligned(1024))) float As[2][F2_BM * BK];
+	__shared__ __attribute__((aligned(1024))) float Bs[2][BK * F2_BN];
+	const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), wm = wave / 3, wn = wave % 3;
+	const int m0 = blockIdx.y * F2_BM, n0 = blockIdx.x * F2_BN;
+	// this wave's pieces q = wave, wave + 12, ... (< NP): q < NPA an A piece, else B piece q - NPA; per lane the source of its 16 bytes of slab 0
+	const float *src[PW]; int dst[PW]; size_t step[PW];      // dst: float offset of the piece within its tile (wave-uniform); step: floats per slab
+#pragma unroll
+	for (int j = 0; j < PW; j++)
+	{
+		const int q = wave + 12 * j;
+		if (q < NPA)
+		{
+			const int c = 64 * q + lane, row = c / KQ, kq = (c % KQ) ^ (row & (KQ - 1));
+			const int grow = m0 + row < M ? m0 + row : M - 1;      // rows past the batch: any valid address (their outputs are not stored)
+			src[j] = A + (size_t)grow * K + 4 * kq; dst[j] = 256 * q; step[j] = BK;
+		}
+		else
+		{
+			const int c = 64 * (q - NPA) + lane, k = c / 36, n4 = c % 36;
+			src[j] = W + (size_t)(k < BK ? k : 0) * N + n0 + 4 * n4; dst[j] = 256 * (q - NPA); step[j] = (size_t)BK * N;
+		}
+	}
+	auto dma = [&](int buf, int slab) {
+#pragma unroll
+		for (int j = 0; j < PW; j++)
+		{
+			const int q = wave + 12 * j;
+			if (q >= NP) break;
+			float *l = (q < NPA ? As[buf] : Bs[buf]) + dst[j];
+			__builtin_amdgcn_global_load_lds((ht_gptr)(src[j] + (size_t)slab * step[j]), (ht_lptr)l, 16, 0, 0);
+		}
+	};
+	f32x4 acc[3];
+#pragma unroll
+	for (int j = 0; j < 3; j++) { const float bv = bias[n0 + wn * 48 + j * 16 + (lane & 15)]; acc[j] = f32x4{ bv, bv, bv, bv }; }
+	// fragment addresses: A row = wm * 16 + (lane & 15), k = 4 * kk + (lane >> 4) sits in chunk slot kk ^ (row & (KQ - 1)), word lane >> 4
+	int aoff[KQ];
+#pragma unroll
+	for (int kk = 0; kk < KQ; kk++) aoff[kk] = (wm * 16 + (lane & 15)) * BK + ((kk ^ (lane & (KQ - 1))) << 2) + (lane >> 4);
+	const int boff = (lane >> 4) * F2_BN + wn * 48 + (lane & 15);
+	const int nslab = K / BK;
+	dma(0, 0);
+	for (int s = 0; s < nslab; s++)
+	{
+		const int buf = s & 1;
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of slab s have landed (the compiler does not wait for an LDS-DMA on its own) ...
+		__syncthreads();                                   // ... and everybody's; the other buffer's readers are through
+		if (s + 1 < nslab) dma(buf ^ 1, s + 1);
+		const float *ap = As[buf], *bp = Bs[buf] + boff;
+#pragma unroll
+		for (int kk = 0; kk < KQ; kk++)
+		{
+			const float a = ap[aoff[kk]];
+			const float b0 = bp[4 * kk * F2_BN], b1 = bp[4 * kk * F2_BN + 16], b2 = bp[4 * kk * F2_BN + 32];
+			acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[0], 0, 0, 0);
+			acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[1], 0, 0, 0);
+			acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b2, acc[2], 0, 0, 0);
+		}
+	}
+	// C/D map 16x16: col = lane & 15, row = 4 * (lane >> 4) + r
+#pragma unroll
+	for (int j = 0; j < 3; j++)
+#pragma unroll
+		for (int r = 0; r < 4; r++)
+		{
+			const int row = m0 + wm * 16 + 4 * (lane >> 4) + r;
+			if (row < M) C[(size_t)row * N + n0 + wn * 48 + j * 16 + (lane & 15)] = acc[j][r];
+		}
+}
+
 // ------------------------------------------------------------------------------------------------- k_softmax_decode
 // one wave per frame.  softmax chunks: 8 x 256 then 16 x 16 (handtrack.h:118); sums run in ascending order like cnn.h:503-505.
 // analysis layout (HT_ANALYSIS floats): crays 8x4 | image_points 8x2 | confidence 8 | vals 16 | wristroll pitch tilt | palmq 4 | clenched 5
@@ -718,7 +800,12 @@ void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, fl
 		if (B % 128 == 0) hipLaunchKernelGGL((k_fc<true, 2, 4, true>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
 		else hipLaunchKernelGGL((k_fc<true, 2, 4, false>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
 	}
-	hipLaunchKernelGGL(k_fc144, dim3(2304 / F2_BN, (B + F2_BM - 1) / F2_BM), dim3(768), 0, s, act3, w.W4, w.B4, logits, B, 2304, 2048);
+	// the last layer: tiles by LDS-DMA (k_fc144_dma: 100.6 us at 1024 frames); measurement builds (-DHT_TUNING) can run the register-staged kernel (105.5 us) and 64-deep slabs (102.7 us)
+	static const bool fc144_regs = ht_tuning_env("HT_FC144_REGS"), fc144_bk64 = ht_tuning_env("HT_FC144_BK64");
+	const dim3 g2(2304 / F2_BN, (B + F2_BM - 1) / F2_BM);
+	if (fc144_regs) hipLaunchKernelGGL(k_fc144, g2, dim3(768), 0, s, act3, w.W4, w.B4, logits, B, 2304, 2048);
+	else if (fc144_bk64) hipLaunchKernelGGL(k_fc144_dma<64>, g2, dim3(768), 0, s, act3, w.W4, w.B4, logits, B, 2304, 2048);
+	else hipLaunchKernelGGL(k_fc144_dma<32>, g2, dim3(768), 0, s, act3, w.W4, w.B4, logits, B, 2304, 2048);
 }
 void ht_launch_softmax_decode(const float *logits, float *cnn_out, const float *cams, float *analysis, int softmax, int B, hipStream_t s, int sub)
 {
