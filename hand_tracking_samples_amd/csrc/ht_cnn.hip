@@ -553,13 +553,19 @@ __global__ __launch_bounds__(768) void k_fc144_dma(const float *__restrict__ A, 
 	for (int kk = 0; kk < KQ; kk++) aoff[kk] = (wm * 16 + (lane & 15)) * BK + ((kk ^ (lane & (KQ - 1))) << 2) + (lane >> 4);
 	const int boff = (lane >> 4) * F2_BN + wn * 48 + (lane & 15);
 	const int nslab = K / BK;
+#ifdef HT_TUNING
+	const bool fcst = (ht_fc_dbg & 0x800000) != 0; long long fcc[5] = { 0, 0, 0, 0, 0 }, ftm = fcst ? clock64() : 0; const long long fc_t0 = ftm;
+#endif
 	dma(0, 0);
 	for (int s = 0; s < nslab; s++)
 	{
 		const int buf = s & 1;
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of slab s have landed (the compiler does not wait for an LDS-DMA on its own) ...
+		FC_MARK(0)
 		__syncthreads();                                   // ... and everybody's; the other buffer's readers are through
-		if (s + 1 < nslab) dma(buf ^ 1, s + 1);
+		FC_MARK(1)
+		if (s + 1 < nslab) dma(buf ^ 1, s + 1);      // (asked for in the middle of the slab instead, behind 1, 3 or 5 k-steps: no change, 0.302-0.306 ms for the net either way)
+		FC_MARK(2)
 		const float *ap = As[buf], *bp = Bs[buf] + boff;
 #pragma unroll
 		for (int kk = 0; kk < KQ; kk++)
@@ -570,7 +576,11 @@ __global__ __launch_bounds__(768) void k_fc144_dma(const float *__restrict__ A, 
 			acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[1], 0, 0, 0);
 			acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b2, acc[2], 0, 0, 0);
 		}
+		FC_MARK(3)
 	}
+#ifdef HT_TUNING
+	if (fcst && lane == 0 && (wave == 0 || wave == 4 || wave == 8) && (blockIdx.x + blockIdx.y * gridDim.x) % 128 == 0) printf("k_fc144_dma<%d> block %d,%d wave %d: wait for own pieces %lld, barrier %lld, DMA issue %lld, reads + matrix instructions %lld, whole loop %lld cycles (%d slabs)\n", BK, blockIdx.x, blockIdx.y, wave, fcc[0], fcc[1], fcc[2], fcc[3], (long long)(clock64() - fc_t0), nslab);
+#endif
 	// C/D map 16x16: col = lane & 15, row = 4 * (lane >> 4) + r
 #pragma unroll
 	for (int j = 0; j < 3; j++)
