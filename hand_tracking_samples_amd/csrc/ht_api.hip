@@ -278,6 +278,7 @@ extern "C" int ht_cnn_train(ht_ctx *ctx, const float *inputs, const float *targe
 	{
 		for (int k = 0; k < n; k++)
 			ht_launch_train_step(ctx->d_weights, ctx->d_weights + HT_CNNB_COUNT, d_x + (size_t)k * HT_CNN_IN, d_t + (size_t)k * HT_CNN_OUT, alpha, ctx->d_train, ctx->d_train + na, ctx->d_train + na + ne, d_mse + k, s);
+		ht_launch_pack_w4(ctx->cnnw.W4, ctx->d_weights + HT_CNNB_COUNT + 16384, s);      // the forward kernels' copy of the last layer follows the trained weights
 		if ((mse_out && hipMemcpyAsync(mse_out, d_mse, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) || hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess)
 		{ ctx->err = "ht_cnn_train: device error"; rc = HT_ERR_HIP; }
 	}
@@ -391,7 +392,7 @@ extern "C" int ht_cnn_load_weights(ht_ctx *ctx, const float *w, size_t n)
 {
 	CHECK_READY(ctx);
 	if (!w || n != HT_CNNB_COUNT) { ctx->err = "weights: expected HT_CNNB_COUNT fp32 values in .cnnb order"; return HT_ERR_ARG; }
-	if (!ctx->d_weights) { int r = dev_alloc(ctx, &ctx->d_weights, (size_t)HT_CNNB_COUNT + 16384); if (r) return r; }
+	if (!ctx->d_weights) { int r = dev_alloc(ctx, &ctx->d_weights, (size_t)HT_CNNB_COUNT + 16384 + HT_W4_COUNT); if (r) return r; }
 	HIPCHK(ctx, hipMemcpy(ctx->d_weights, w, n * sizeof(float), hipMemcpyHostToDevice));
 	// conv2 weights repacked to [k][oc], k = (ky*4+kx)*16 + ic  (reference index: kx + 4*(ky + 4*(ic + 16*oc)), cnn.h:45-47)
 	const float *W2 = w + 416;
@@ -402,6 +403,9 @@ extern "C" int ht_cnn_load_weights(ht_ctx *ctx, const float *w, size_t n)
 	HIPCHK(ctx, hipMemcpy(d + HT_CNNB_COUNT, w2p.data(), 16384 * sizeof(float), hipMemcpyHostToDevice));
 	ht_cnn_weights &cw = ctx->cnnw;
 	cw.W1 = d; cw.B1 = d + 400; cw.W2p = d + HT_CNNB_COUNT; cw.B2 = d + 416 + 16384; cw.W3 = d + 416 + 16448; cw.B3 = cw.W3 + (size_t)2304 * 2048; cw.W4 = cw.B3 + 2048; cw.B4 = cw.W4 + (size_t)2048 * 2304;
+	cw.W4p = d + HT_CNNB_COUNT + 16384;
+	ht_launch_pack_w4(cw.W4, d + HT_CNNB_COUNT + 16384, ctx->stream);
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 	ctx->have_weights = true;
 	return HT_OK;
 }
@@ -447,7 +451,7 @@ extern "C" int ht_cnn_load_weights_sized(ht_ctx *ctx, int side, const float *w, 
 	{
 		int r;
 		const size_t B = (size_t)ctx->B;
-		if ((r = dev_alloc(ctx, &ctx->d_weights128, (size_t)HT_CNNB128_COUNT + 16384)) || (r = dev_alloc(ctx, &ctx->d_in128, B * HT_CNN128_IN)) ||
+		if ((r = dev_alloc(ctx, &ctx->d_weights128, (size_t)HT_CNNB128_COUNT + 16384 + HT_W4_COUNT)) || (r = dev_alloc(ctx, &ctx->d_in128, B * HT_CNN128_IN)) ||
 		    (r = dev_alloc(ctx, &ctx->d_act1_128, B * 16 * 31 * 31)) || (r = dev_alloc(ctx, &ctx->d_act2_128, B * 12544))) return r;
 	}
 	float *d = ctx->d_weights128;
@@ -459,6 +463,9 @@ extern "C" int ht_cnn_load_weights_sized(ht_ctx *ctx, int side, const float *w, 
 	HIPCHK(ctx, hipMemcpy(d + HT_CNNB128_COUNT, w2p.data(), 16384 * sizeof(float), hipMemcpyHostToDevice));
 	ht_cnn_weights &cw = ctx->cnnw128;
 	cw.W1 = d; cw.B1 = d + 400; cw.W2p = d + HT_CNNB128_COUNT; cw.B2 = d + 416 + 16384; cw.W3 = d + 416 + 16448; cw.B3 = cw.W3 + (size_t)12544 * 2048; cw.W4 = cw.B3 + 2048; cw.B4 = cw.W4 + (size_t)2048 * 2304;
+	cw.W4p = d + HT_CNNB128_COUNT + 16384;
+	ht_launch_pack_w4(cw.W4, d + HT_CNNB128_COUNT + 16384, ctx->stream);
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 	ctx->have_weights128 = true;
 	return HT_OK;
 }

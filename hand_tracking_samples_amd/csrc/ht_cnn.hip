@@ -302,7 +302,12 @@ __constant__ int ht_fc_dbg;
 #else
 #define FC_MARK(k)
 #endif
-template <bool TANH, int WN, int WM, bool FULL>      // FULL: M is a multiple of the tile's rows (no row test: the slab is then one branch-free region)
+// (This layer with ITS operands packed the same way -- act2 from k_conv2 in [k & 1][k >> 1] order within blocks of 8, a packed copy of W3, four + four 128-bit fragment reads per
+// slab instead of 16 + 16 -- was built three ways: tiles by LDS-DMA with two buffers 113 us, with three buffers and the fragments read a slab ahead 100 us, this kernel's own
+// register staging and slab order 100 us, 92 us once the 128-bit stores of A were spread over the banks: against this kernel's 93 us no gain for 19 + 103 MB of packed weights.)
+// PACK16: the output feeds k_fc144_pk, which reads a lane's four k-values of a 16-k block with one 128-bit LDS read: column c of a row is stored at position
+// (c & ~15) | (c & 3) << 2 | (c >> 2) & 3 -- within every block of 16 columns the order [k & 3][k >> 2] (ht_get_cnn_layers undoes it for callers that look at the layer)
+template <bool TANH, int WN, int WM, bool FULL, bool PACK16 = false>      // FULL: M is a multiple of the tile's rows (no row test: the slab is then one branch-free region)
 __global__ __launch_bounds__(64 * WM * WN) void k_fc(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K)
 {
 	constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * WM * WN, LDA = BM + 1;
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_fc(const float *__restrict__ A
 	if (fcst && lane == 0 && (wave == 0 || wave == 5) && (blockIdx.x + blockIdx.y * gridDim.x) % 64 == 0) printf("k_fc block %d,%d wave %d: barrier wait %lld, load issue %lld, reads+mfma issue %lld, store %lld, prologue %lld, whole loop %lld cycles (%d slabs)\n", blockIdx.x, blockIdx.y, wave, fcc[0], fcc[1], fcc[2], fcc[3], fcc[4], (long long)(clock64() - fc_t0), K / FC_BK);
 #endif
 	// C/D map 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-	const int col = n0 + wn * 32 + (lane & 31);
+	const int colu = n0 + wn * 32 + (lane & 31), col = PACK16 ? ((colu & ~15) | ((colu & 3) << 2) | ((colu >> 2) & 3)) : colu;
 #pragma unroll
 	for (int r = 0; r < 16; r++)
 	{
@@ -422,116 +427,44 @@ __global__ __launch_bounds__(64 * WM * WN) void k_fc(const float *__restrict__ A
 // The last layer (2048 -> 2304) on a 64 x 144 block tile: 1024 frames x 2304 outputs are then exactly 16 x 16 = 256 blocks, one per CU (the
 // 128 x 96 tile of k_fc<.,3> makes 192 blocks and leaves a quarter of the chip idle; 128 x 64 makes 288 and a second, nearly empty round).
 // 144 is nine 16-wide tiles, so the arithmetic is v_mfma_f32_16x16x4_f32: 12 waves as 4 (rows) x 3 (columns), a wave holds three 16 x 16
-// accumulators that share one A fragment.  LDS: A as [k][row] with stride 81, B as [k][col] with stride 144 (16 mod 32: the four k-groups of a
-// fragment read land in disjoint banks), double-buffered 32-deep slabs (64-deep slabs were measured slower: 136 against 105 us; so was k_fc's slab
-// organisation -- loads two slabs ahead, loads and stores issued behind matrix instructions: 135 us -- with three waves per SIMD here);
-// accumulation starts from the bias and runs in ascending k.
+// accumulators that share one A fragment; double-buffered 32-deep slabs; accumulation starts from the bias and runs in ascending k.
+// History of the kernel: tiles staged through registers with A stored transposed at stride 81 (105.5 us at 1024 frames; 64-deep slabs 136 us; k_fc's
+// hand-ordered slab 135 us) -> the same tiles by LDS-DMA (100.6 us; 64-deep 102.7; the pieces asked for mid-slab: no change) -> operands packed for 128-bit fragment reads (89.2 us).
 #define F2_BM 64
 #define F2_BN 144
 #define F2_BK 32
-#define F2_LDA 81
-__global__ __launch_bounds__(768) void k_fc144(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K)
-{
-	__shared__ float As[2][F2_BK * F2_LDA];
-	__shared__ __attribute__((aligned(16))) float Bs[2][F2_BK * F2_BN];
-	const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / 3, wn = wave % 3;
-	const int m0 = blockIdx.y * F2_BM, n0 = blockIdx.x * F2_BN;
-	// staging: A tile = 64 rows x 32 k = 512 float4 (thread < 512: row = t >> 3, 4 consecutive k); B tile = 32 x 144 = 1152 float4, 36 per k-row (threads t and
-	// t + 768); all index arithmetic is done once, outside the slab loop
-	static_assert(F2_BM * F2_BK / 4 == 512 && F2_BK * 36 == 1152, "staging is written for 64 x 32 and 32 x 144 slabs");
-	const int arow = t >> 3, akc = (t & 7) * 4;
-	const int bk0 = t / 36, bc0 = (t % 36) * 4, bk1 = (t + 768) / 36, bc1 = ((t + 768) % 36) * 4;
-	const bool a_on = t < 512 && m0 + arow < M, b1_on = t < 384;
-	const float *ag = A + (size_t)(m0 + arow) * K + akc, *bg0 = W + (size_t)bk0 * N + n0 + bc0, *bg1 = W + (size_t)bk1 * N + n0 + bc1;
-	float4 ra = make_float4(0, 0, 0, 0), rb0, rb1 = make_float4(0, 0, 0, 0);
-	auto gload = [&](int k0) {
-		if (a_on) ra = *reinterpret_cast<const float4 *>(ag + k0);
-		rb0 = *reinterpret_cast<const float4 *>(bg0 + (size_t)k0 * N);
-		if (b1_on) rb1 = *reinterpret_cast<const float4 *>(bg1 + (size_t)k0 * N);
-	};
-	auto lstore = [&](int buf) {
-		if (t < 512) { float *a = As[buf] + akc * F2_LDA + arow; a[0] = ra.x; a[F2_LDA] = ra.y; a[2 * F2_LDA] = ra.z; a[3 * F2_LDA] = ra.w; }
-		*reinterpret_cast<float4 *>(Bs[buf] + bk0 * F2_BN + bc0) = rb0;
-		if (b1_on) *reinterpret_cast<float4 *>(Bs[buf] + bk1 * F2_BN + bc1) = rb1;
-	};
-	f32x4 acc[3];
-#pragma unroll
-	for (int j = 0; j < 3; j++) { const float bv = bias[n0 + wn * 48 + j * 16 + (lane & 15)]; acc[j] = f32x4{ bv, bv, bv, bv }; }
-#ifdef HT_TUNING
-	const bool fcst = (ht_fc_dbg & 0x800000) != 0; long long fcc[5] = { 0, 0, 0, 0, 0 }, ftm = fcst ? clock64() : 0; const long long fc_t0 = ftm;
-#endif
-	gload(0);
-	lstore(0);
-	int buf = 0;
-	for (int k0 = 0; k0 < K; k0 += F2_BK)
-	{
-		__syncthreads();                                   // slab `buf` is complete; the other buffer is free (its readers passed this barrier)
-		FC_MARK(0)
-		const bool more = k0 + F2_BK < K;
-		if (more) gload(k0 + F2_BK);
-		FC_MARK(1)
-		const float *ap = As[buf] + (lane >> 4) * F2_LDA + wm * 16 + (lane & 15);
-		const float *bp = Bs[buf] + (lane >> 4) * F2_BN + wn * 48 + (lane & 15);
-#pragma unroll
-		for (int kk = 0; kk < F2_BK / 4; kk++)
-		{
-			const float a = ap[4 * kk * F2_LDA];
-			const float b0 = bp[4 * kk * F2_BN], b1 = bp[4 * kk * F2_BN + 16], b2 = bp[4 * kk * F2_BN + 32];
-			acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[0], 0, 0, 0);
-			acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[1], 0, 0, 0);
-			acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b2, acc[2], 0, 0, 0);
-		}
-		FC_MARK(2)
-		if (more) lstore(buf ^ 1);
-		FC_MARK(3)
-		buf ^= 1;
-	}
-#ifdef HT_TUNING
-	if (fcst && lane == 0 && (wave == 0 || wave == 4 || wave == 8) && (blockIdx.x + blockIdx.y * gridDim.x) % 128 == 0) printf("k_fc144 block %d,%d wave %d: barrier wait %lld, load issue %lld, reads+mfma issue %lld, store %lld, whole loop %lld cycles (%d slabs)\n", blockIdx.x, blockIdx.y, wave, fcc[0], fcc[1], fcc[2], fcc[3], (long long)(clock64() - fc_t0), K / F2_BK);
-#endif
-	// C/D map 16x16: col = lane & 15, row = 4 * (lane >> 4) + r
-#pragma unroll
-	for (int j = 0; j < 3; j++)
-#pragma unroll
-		for (int r = 0; r < 4; r++)
-		{
-			const int row = m0 + wm * 16 + 4 * (lane >> 4) + r;
-			if (row < M) C[(size_t)row * N + n0 + wn * 48 + j * 16 + (lane & 15)] = acc[j][r];
-		}
-}
-
-// k_fc144 with the tiles brought in by LDS-DMA (global_load_lds_dwordx4: a wave-instruction writes 64 x 16 bytes to LDS at a wave-uniform base + 16 * lane, no registers,
-// no ds_write pass; the SOURCE address is per lane).  A slab is 26 such pieces -- 8 of A (64 rows x 32 k), 18 of B (32 k x 144 columns, which lies in LDS exactly as it does
-// in a row-major W: contiguous 576-byte k-rows) --, two or three per wave, issued right behind the barrier that frees the buffer and waited for at the next slab's barrier.
-// The A image cannot be padded (a piece is 1 KiB of consecutive LDS: 8 rows of 128 bytes), so its 16-byte chunks are XOR-swizzled on the source side: chunk slot s of row r
-// holds k-quad s ^ (r & 7); a fragment read (16 rows, one k) then meets 8 different quads = 8 x 4 banks, two rows per bank (2-way on one read in four) instead of 16-way.
 typedef const __attribute__((address_space(1))) void *ht_gptr;
 typedef __attribute__((address_space(3))) void *ht_lptr;
-template <int BK>      // k-depth of a slab: 32 or 64
-__global__ __launch_bounds__(768) void k_fc144_dma(const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K)
+// The last layer with BOTH operands in the order the matrix instruction takes them.  v_mfma_f32_16x16x4_f32 wants from lane l the element (row or column l & 15,
+// k = 4 * step + (l >> 4)); with A and W row-major that is one 32-bit LDS read per operand and instruction, and the reads, their address arithmetic and waits share the
+// SIMD's one issue port with the matrix instructions of the other waves: the pipe was ~75 % busy inside the matrix phase whatever the staging did.
+// Here a lane's four k-values of a 16-k block are contiguous -- A comes from k_fc<PACK16> that way ([row][k >> 4][k & 3][(k >> 2) & 3]), W from ht_launch_pack_w4
+// ([k >> 4][k & 3][n][(k >> 2) & 3]) -- so a 32-deep slab is TWO 128-bit reads of A and SIX of B per wave for its 24 matrix instructions, where it was 8 + 16 reads.
+// Tiles by LDS-DMA (global_load_lds_dwordx4: a wave-instruction writes 64 x 16 bytes to LDS at a wave-uniform base + 16 * lane -- no staging registers, no ds_write pass;
+// the SOURCE address is per lane; the compiler does not wait for such a load on its own, hence the explicit s_waitcnt): per slab 8 pieces of A (64 rows x 8 chunks, chunk slot = (h * 4 + g) ^ (row & 7): XOR-swizzled on the source side) and 18 of B
+// (8 runs (h, g) of 144 columns x 16 bytes, contiguous in W4p); the sums run over k in the same order as before (k = 16 * kb + 4 * kk + g ascending in kb, kk).
+__global__ __launch_bounds__(768) void k_fc144_pk(const float *__restrict__ Ap, const float *__restrict__ W4p, const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K)
 {
-	constexpr int KQ = BK / 4, NPA = F2_BM * BK / 256, NPB = BK * F2_BN / 256, NP = NPA + NPB, PW = (NP + 11) / 12;      // 16-byte chunks per A row; 1-KiB pieces of A, of B, of a slab; pieces per wave
-	static_assert((F2_BM * BK) % 256 == 0 && (BK * F2_BN) % 256 == 0 && (KQ & (KQ - 1)) == 0 && KQ <= 16, "a slab must be whole pieces");
+	constexpr int BK = F2_BK, NPA = 8, NPB = 18, NP = NPA + NPB, PW = 3;
 	__shared__ __attribute__((aligned(1024))) float As[2][F2_BM * BK];
 	__shared__ __attribute__((aligned(1024))) float Bs[2][BK * F2_BN];
 	const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), wm = wave / 3, wn = wave % 3;
 	const int m0 = blockIdx.y * F2_BM, n0 = blockIdx.x * F2_BN;
-	// this wave's pieces q = wave, wave + 12, ... (< NP): q < NPA an A piece, else B piece q - NPA; per lane the source of its 16 bytes of slab 0
-	const float *src[PW]; int dst[PW]; size_t step[PW];      // dst: float offset of the piece within its tile (wave-uniform); step: floats per slab
+	const float *src[PW]; int dst[PW]; size_t step[PW];
 #pragma unroll
 	for (int j = 0; j < PW; j++)
 	{
 		const int q = wave + 12 * j;
 		if (q < NPA)
 		{
-			const int c = 64 * q + lane, row = c / KQ, kq = (c % KQ) ^ (row & (KQ - 1));
-			const int grow = m0 + row < M ? m0 + row : M - 1;      // rows past the batch: any valid address (their outputs are not stored)
-			src[j] = A + (size_t)grow * K + 4 * kq; dst[j] = 256 * q; step[j] = BK;
+			const int c = 64 * q + lane, row = c >> 3, hg = (c & 7) ^ (row & 7);      // chunk (h, g) = hg >> 2, hg & 3 of the row: 16 bytes at [kb = 2 * slab + h][g][0..3]
+			const int grow = m0 + row < M ? m0 + row : M - 1;
+			src[j] = Ap + (size_t)grow * K + 4 * hg; dst[j] = 256 * q; step[j] = BK;
 		}
 		else
 		{
-			const int c = 64 * (q - NPA) + lane, k = c / 36, n4 = c % 36;
-			src[j] = W + (size_t)(k < BK ? k : 0) * N + n0 + 4 * n4; dst[j] = 256 * (q - NPA); step[j] = (size_t)BK * N;
+			const int c = 64 * (q - NPA) + lane, hg = c / F2_BN, nn = c % F2_BN;      // run (h, g), column nn of the block's 144
+			src[j] = W4p + ((size_t)(hg < 8 ? hg : 0) * N + n0 + nn) * 4; dst[j] = 256 * (q - NPA); step[j] = (size_t)8 * N * 4;      // a slab is 2 x 4 runs of N x 4 floats
 		}
 	}
 	auto dma = [&](int buf, int slab) {
@@ -547,39 +480,43 @@ __global__ __launch_bounds__(768) void k_fc144_dma(const float *__restrict__ A, 
 	f32x4 acc[3];
 #pragma unroll
 	for (int j = 0; j < 3; j++) { const float bv = bias[n0 + wn * 48 + j * 16 + (lane & 15)]; acc[j] = f32x4{ bv, bv, bv, bv }; }
-	// fragment addresses: A row = wm * 16 + (lane & 15), k = 4 * kk + (lane >> 4) sits in chunk slot kk ^ (row & (KQ - 1)), word lane >> 4
-	int aoff[KQ];
-#pragma unroll
-	for (int kk = 0; kk < KQ; kk++) aoff[kk] = (wm * 16 + (lane & 15)) * BK + ((kk ^ (lane & (KQ - 1))) << 2) + (lane >> 4);
-	const int boff = (lane >> 4) * F2_BN + wn * 48 + (lane & 15);
+	const int arow = wm * 16 + (lane & 15), g = lane >> 4;
+	const int aoff0 = (arow * 8 + ((0 * 4 + g) ^ (arow & 7))) * 4, aoff1 = (arow * 8 + ((1 * 4 + g) ^ (arow & 7))) * 4;
+	const int boff = (g * F2_BN + wn * 48 + (lane & 15)) * 4;
 	const int nslab = K / BK;
 #ifdef HT_TUNING
 	const bool fcst = (ht_fc_dbg & 0x800000) != 0; long long fcc[5] = { 0, 0, 0, 0, 0 }, ftm = fcst ? clock64() : 0; const long long fc_t0 = ftm;
 #endif
+	// (Three buffers with the tiles asked for two slabs ahead and a slab's fragments read during the slab before it -- nothing between a slab's barrier and its first matrix
+	// instruction -- were measured: 95.8 us against 89.2 for this plain order; three waves per SIMD cover the head of a slab, and the fences the other order needs cost more.)
 	dma(0, 0);
 	for (int s = 0; s < nslab; s++)
 	{
 		const int buf = s & 1;
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of slab s have landed (the compiler does not wait for an LDS-DMA on its own) ...
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of slab s have landed ...
 		FC_MARK(0)
 		__syncthreads();                                   // ... and everybody's; the other buffer's readers are through
 		FC_MARK(1)
-		if (s + 1 < nslab) dma(buf ^ 1, s + 1);      // (asked for in the middle of the slab instead, behind 1, 3 or 5 k-steps: no change, 0.302-0.306 ms for the net either way)
+		if (s + 1 < nslab) dma(buf ^ 1, s + 1);
 		FC_MARK(2)
 		const float *ap = As[buf], *bp = Bs[buf] + boff;
+		const float4 a0 = *reinterpret_cast<const float4 *>(ap + aoff0), a1 = *reinterpret_cast<const float4 *>(ap + aoff1);
+		float4 b[2][3];
 #pragma unroll
-		for (int kk = 0; kk < KQ; kk++)
-		{
-			const float a = ap[aoff[kk]];
-			const float b0 = bp[4 * kk * F2_BN], b1 = bp[4 * kk * F2_BN + 16], b2 = bp[4 * kk * F2_BN + 32];
-			acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[0], 0, 0, 0);
-			acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[1], 0, 0, 0);
-			acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b2, acc[2], 0, 0, 0);
-		}
+		for (int h = 0; h < 2; h++)
+#pragma unroll
+			for (int j = 0; j < 3; j++) b[h][j] = *reinterpret_cast<const float4 *>(bp + (h * 4 * F2_BN + j * 16) * 4);
+#define F2_STEP(av, h, comp) \
+		acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.comp, b[h][0].comp, acc[0], 0, 0, 0); \
+		acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.comp, b[h][1].comp, acc[1], 0, 0, 0); \
+		acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.comp, b[h][2].comp, acc[2], 0, 0, 0);
+		F2_STEP(a0, 0, x) F2_STEP(a0, 0, y) F2_STEP(a0, 0, z) F2_STEP(a0, 0, w)
+		F2_STEP(a1, 1, x) F2_STEP(a1, 1, y) F2_STEP(a1, 1, z) F2_STEP(a1, 1, w)
+#undef F2_STEP
 		FC_MARK(3)
 	}
 #ifdef HT_TUNING
-	if (fcst && lane == 0 && (wave == 0 || wave == 4 || wave == 8) && (blockIdx.x + blockIdx.y * gridDim.x) % 128 == 0) printf("k_fc144_dma<%d> block %d,%d wave %d: wait for own pieces %lld, barrier %lld, DMA issue %lld, reads + matrix instructions %lld, whole loop %lld cycles (%d slabs)\n", BK, blockIdx.x, blockIdx.y, wave, fcc[0], fcc[1], fcc[2], fcc[3], (long long)(clock64() - fc_t0), nslab);
+	if (fcst && lane == 0 && (wave == 0 || wave == 4 || wave == 8) && (blockIdx.x + blockIdx.y * gridDim.x) % 128 == 0) printf("k_fc144_pk block %d,%d wave %d: wait for own pieces %lld, barrier %lld, DMA issue %lld, reads + matrix instructions %lld, whole loop %lld cycles (%d slabs)\n", blockIdx.x, blockIdx.y, wave, fcc[0], fcc[1], fcc[2], fcc[3], (long long)(clock64() - fc_t0), nslab);
 #endif
 	// C/D map 16x16: col = lane & 15, row = 4 * (lane >> 4) + r
 #pragma unroll
@@ -590,6 +527,20 @@ __global__ __launch_bounds__(768) void k_fc144_dma(const float *__restrict__ A, 
 			const int row = m0 + wm * 16 + 4 * (lane >> 4) + r;
 			if (row < M) C[(size_t)row * N + n0 + wn * 48 + j * 16 + (lane & 15)] = acc[j][r];
 		}
+}
+// W4p[((kb * 4 + g) * N + n) * 4 + kk] = W4[(16 * kb + 4 * kk + g) * N + n]      (W4 row-major [K = 2048][N = 2304] as stored in the .cnnb, cnn.h:417)
+__global__ __launch_bounds__(256) void k_pack_w4(const float *__restrict__ W4, float *__restrict__ W4p, int K, int N)
+{
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;      // one 16-byte chunk (kb, g, n) per thread
+	if (i >= (size_t)K * N / 4) return;
+	const int n = (int)(i % N), kg = (int)(i / N), kb = kg >> 2, g = kg & 3;
+	float4 v;
+	v.x = W4[(size_t)(16 * kb + 0 + g) * N + n]; v.y = W4[(size_t)(16 * kb + 4 + g) * N + n]; v.z = W4[(size_t)(16 * kb + 8 + g) * N + n]; v.w = W4[(size_t)(16 * kb + 12 + g) * N + n];
+	reinterpret_cast<float4 *>(W4p)[i] = v;
+}
+void ht_launch_pack_w4(const float *W4, float *W4p, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_pack_w4, dim3((unsigned)((HT_W4_COUNT / 4 + 255) / 256)), dim3(256), 0, s, W4, W4p, 2048, 2304);
 }
 
 // ------------------------------------------------------------------------------------------------- k_softmax_decode
@@ -800,22 +751,18 @@ void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, fl
 	{
 		hipLaunchKernelGGL((k_conv1<128, 31, 8>), dim3(B, 4), dim3(256), 0, s, cnn_in, w.W1, w.B1, act1);
 		hipLaunchKernelGGL((k_conv2<31, 28, 4>), dim3(B, 7), dim3(256), 0, s, act1, w.W2p, w.B2, act2);
-		if (B % 128 == 0) hipLaunchKernelGGL((k_fc<true, 2, 4, true>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 12544);
-		else hipLaunchKernelGGL((k_fc<true, 2, 4, false>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 12544);
+		if (B % 128 == 0) hipLaunchKernelGGL((k_fc<true, 2, 4, true, true>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 12544);
+		else hipLaunchKernelGGL((k_fc<true, 2, 4, false, true>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 12544);
 	}
 	else
 	{
 		hipLaunchKernelGGL((k_conv1<64, 15, 15>), dim3(B, 1), dim3(256), 0, s, cnn_in, w.W1, w.B1, act1);
 		hipLaunchKernelGGL((k_conv2<15, 12, 12>), dim3(B, 1), dim3(256), 0, s, act1, w.W2p, w.B2, act2);
-		if (B % 128 == 0) hipLaunchKernelGGL((k_fc<true, 2, 4, true>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
-		else hipLaunchKernelGGL((k_fc<true, 2, 4, false>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
+		if (B % 128 == 0) hipLaunchKernelGGL((k_fc<true, 2, 4, true, true>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
+		else hipLaunchKernelGGL((k_fc<true, 2, 4, false, true>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
 	}
-	// the last layer: tiles by LDS-DMA (k_fc144_dma: 100.6 us at 1024 frames); measurement builds (-DHT_TUNING) can run the register-staged kernel (105.5 us) and 64-deep slabs (102.7 us)
-	static const bool fc144_regs = ht_tuning_env("HT_FC144_REGS"), fc144_bk64 = ht_tuning_env("HT_FC144_BK64");
-	const dim3 g2(2304 / F2_BN, (B + F2_BM - 1) / F2_BM);
-	if (fc144_regs) hipLaunchKernelGGL(k_fc144, g2, dim3(768), 0, s, act3, w.W4, w.B4, logits, B, 2304, 2048);
-	else if (fc144_bk64) hipLaunchKernelGGL(k_fc144_dma<64>, g2, dim3(768), 0, s, act3, w.W4, w.B4, logits, B, 2304, 2048);
-	else hipLaunchKernelGGL(k_fc144_dma<32>, g2, dim3(768), 0, s, act3, w.W4, w.B4, logits, B, 2304, 2048);
+	// the last layer: act3 comes from k_fc in the packed column order and meets the packed copy of W4 (k_fc144_pk)
+	hipLaunchKernelGGL(k_fc144_pk, dim3(2304 / F2_BN, (B + F2_BM - 1) / F2_BM), dim3(768), 0, s, act3, w.W4p, w.B4, logits, B, 2304, 2048);
 }
 void ht_launch_softmax_decode(const float *logits, float *cnn_out, const float *cams, float *analysis, int softmax, int B, hipStream_t s, int sub)
 {

@@ -135,7 +135,9 @@ struct ht_physics_dev      // physics.h:34-47 after handtrack.h:837-838
 	float jiggle_sin;     // sinf(3.14f/180.0f*4.0f/2.0f), gjk.h:628
 };
 
-struct ht_cnn_weights { const float *W1, *B1, *W2p, *B2, *W3, *B3, *W4, *B4; };
+struct ht_cnn_weights { const float *W1, *B1, *W2p, *B2, *W3, *B3, *W4, *B4, *W4p; };      // W2p, W4p: copies of the conv2 / last-layer weights in the order the matrix kernels read them (ht_cnn.hip)
+#define HT_W4_COUNT ((size_t)2048 * 2304)
+void ht_launch_pack_w4(const float *W4, float *W4p, hipStream_t s);      // refreshes the packed copy (after a weight upload, after a training step)
 
 // ---- kernel launchers (defined in the .hip files) ----
 // what k_prepare can do on the side for the frame it has in hand anyway (each replaces a tiny kernel and its dependent launch gap at the head of an update):

@@ -581,7 +581,12 @@ extern "C" int ht_get_cnn_layers(ht_ctx *ctx, int first, int n, float *act1, flo
 	HIPCHK(ctx, ht_sync_all(ctx));
 	if (act1) HIPCHK(ctx, hipMemcpy(act1, ctx->d_act1 + (size_t)first * 3600, (size_t)n * 3600 * sizeof(float), hipMemcpyDeviceToHost));
 	if (act2) HIPCHK(ctx, hipMemcpy(act2, ctx->d_act2 + (size_t)first * 2304, (size_t)n * 2304 * sizeof(float), hipMemcpyDeviceToHost));
-	if (act3) HIPCHK(ctx, hipMemcpy(act3, ctx->d_act3 + (size_t)first * 2048, (size_t)n * 2048 * sizeof(float), hipMemcpyDeviceToHost));
+	if (act3)      // the device holds the layer in the column order the last layer's kernel reads (k_fc<PACK16>): position (c & ~15) | (c & 3) << 2 | (c >> 2) & 3 holds column c
+	{
+		std::vector<float> packed((size_t)n * 2048);
+		HIPCHK(ctx, hipMemcpy(packed.data(), ctx->d_act3 + (size_t)first * 2048, (size_t)n * 2048 * sizeof(float), hipMemcpyDeviceToHost));
+		for (int r = 0; r < n; r++) for (int c = 0; c < 2048; c++) act3[(size_t)r * 2048 + c] = packed[(size_t)r * 2048 + ((c & ~15) | ((c & 3) << 2) | ((c >> 2) & 3))];
+	}
 	if (logits) HIPCHK(ctx, hipMemcpy(logits, ctx->d_logits + (size_t)first * HT_CNN_OUT, (size_t)n * HT_CNN_OUT * sizeof(float), hipMemcpyDeviceToHost));
 	return HT_OK;
 }
