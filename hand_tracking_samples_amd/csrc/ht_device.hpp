@@ -1,7 +1,7 @@
 // ht_device.hpp -- device-side data model shared by the kernels and the C-ABI layer (product code).
 //
 // HBM layout (per context, capacity = max_batch tracker slots; everything resident for the life of the context):
-//   constants  : model (vertices, planes, per-body and per-joint constants), CNN weights (37.8 MB, conv2 repacked k-major)
+//   constants  : model (vertices, planes, per-body and per-joint constants), CNN weights (37.8 MB in .cnnb order + conv2 repacked k-major + the last layer repacked for k_fc144_pk, 18.9 MB)
 //   per slot   : handmodel / othermodel state [nb][16] floats (pos3 quat4 linmom3 angmom3 pad3), prev_frame_error, initializing
 //   per frame  : depth u16[4096] (only for host-buffer calls), cam[12], cnn_in[4096], act1[3600], act2[2304], act3[2048],
 //                logits/cnn_out[2304], analysis[84], points float4[HT_MAXPTS] + count, cloud rows [HT_MAXPTS][16], chamber rows [5*nb][16],
