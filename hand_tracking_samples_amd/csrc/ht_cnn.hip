@@ -7,7 +7,9 @@
 //   k_prepare   u16 depth tile -> fp32 CNN input + order-preserving compacted point cloud  (HBM-bound, 8 KB in / 16 KB out per frame)
 //   k_conv1     5x5x1->16 valid conv + 4x4 max-pool + tanh as an implicit GEMM on v_mfma_f32_16x16x4_f32 (one pooling window = one 16-row tile), input rows staged in LDS
 //   k_conv2     4x4x16->64 valid conv as an implicit GEMM on v_mfma_f32_16x16x4_f32, + 2x2 max-pool + tanh
+//   k_conv12    both of them in one launch for the 64x64 net (the first layer's pooled array in LDS is the second layer's input image)
 //   k_fc        [B,K]x[K,N]+bias (+tanh) on v_mfma_f32_32x32x2_f32, 128x64 block tile on 8 waves, double-buffered LDS, register prefetch
+//   k_fc144_pk  the last layer on a 64x144 tile (v_mfma_f32_16x16x4_f32), tiles by LDS-DMA, both operands in the instruction's order (128-bit fragment reads)
 //   k_softmax_decode   chunked softmax (cnn.h:497-511) fused with the heat-map decode (handtrack.h:218-241)
 //
 // Numerics: the MFMA accumulator starts at the bias and sums k in ascending order, which is the reference's own order
@@ -283,6 +285,82 @@ __global__ __launch_bounds__(256) void k_conv2(const float *__restrict__ act1, c
 		const float mm = max_pool4(acc[0], acc[1], acc[2], acc[3]);
 		const int wo = 4 * mt + icl;
 		dst[wo] = tanh_ref(mm);      // window wo of the band: pooled row wo / PO, column wo % PO
+	}
+}
+
+// ------------------------------------------------------------------------------------------------- k_conv12
+// Both convolution layers of the 64x64 net in one launch, a block per frame: k_conv1's window loop leaves the 16 x 15 x 15 pooled values in LDS, tanh is applied in place --
+// which makes that array exactly the input image k_conv2 stages ([ic][15 x 15]) -- and k_conv2's tiles follow.  Saved against the two launches: conv2's load phase, 14.7 MB
+// written and read back, a launch boundary with every block of the chip in step, and -- what the phases of a single launch cannot hide from each other (section 15) -- the 64 KB
+// of conv2 weights every block loads into registers, which are asked for HERE before the first layer's window loop and arrive under it.  act1 is still written (the layer
+// getter reads it), nobody waits for it.  Same arithmetic in the same order as the two kernels (the 128x128 net keeps them: its bands do not line up).
+__global__ __launch_bounds__(256) void k_conv12(const float *__restrict__ cnn_in, const float *__restrict__ W1, const float *__restrict__ B1, const float *__restrict__ W2p, const float *__restrict__ B2,
+                                                float *__restrict__ act1, float *__restrict__ act2)
+{
+	constexpr int IW = 64, PW = 15, PR = 15, TR = 4 * PR + 4, IWP = IW + 4;
+	constexpr int IWD = 15, OW = 12, PO = 6, CH = IWD * IWD, MT = 9;
+	__shared__ __attribute__((aligned(16))) float tile[TR * IWP];
+	__shared__ float pooled[16 * CH];      // layer 1's pooled values, then (tanh applied) layer 2's input [ic][15 x 15]
+	const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const float4 *src = reinterpret_cast<const float4 *>(cnn_in + (size_t)b * IW * IW);
+	for (int i = t; i < TR * IW / 4; i += 256) { const int r = i / (IW / 4), c4 = i % (IW / 4); *reinterpret_cast<float4 *>(tile + r * IWP + 4 * c4) = src[i]; }
+	// layer 2's weight fragments, on their way while layer 1 runs
+	const int n2 = 16 * wave + (lane & 15);
+	float breg[64];
+#pragma unroll
+	for (int ks = 0; ks < 64; ks++) breg[ks] = W2p[(4 * ks + (lane >> 4)) * 64 + n2];
+	const float bias2 = B2[n2];
+	// ---- layer 1 (k_conv1)
+	{
+		const int n = lane & 15, g = lane >> 4, px = lane & 3, py = (lane >> 2) & 3;
+		float wreg[7]; int aoff[7];
+#pragma unroll
+		for (int s = 0; s < 7; s++)
+		{
+			const int k = 4 * s + g, kk = k < 25 ? k : 24;
+			wreg[s] = k < 25 ? W1[n * 25 + k] : 0.0f;
+			aoff[s] = (py + kk / 5) * IWP + px + kk % 5;
+		}
+		const float bias = B1[n];
+		__syncthreads();
+		const int swave = __builtin_amdgcn_readfirstlane(wave);
+		float *const pdst = pooled + n * CH;
+		for (int w = swave; w < PR * PW; w += 4)
+		{
+			const int ty = w / PW, tx = w % PW;
+			const float *base = tile + 4 * ty * IWP + 4 * tx;
+			f32x4 acc = { bias, bias, bias, bias };
+#pragma unroll
+			for (int s = 0; s < 7; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(base[aoff[s]], wreg[s], acc, 0, 0, 0);
+			float m = max_pool4(acc[0], acc[1], acc[2], acc[3]);
+			{ const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false); m = max_pool(__uint_as_float(r[0]), __uint_as_float(r[1])); }
+			{ const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false); m = max_pool(__uint_as_float(r[0]), __uint_as_float(r[1])); }
+			if (lane < 16) pdst[ty * PW + tx] = m;
+		}
+		__syncthreads();
+		for (int i = t; i < 16 * CH; i += 256) { const float v = tanh_ref(pooled[i]); pooled[i] = v; act1[(size_t)b * (16 * CH) + i] = v; }      // tanh after pooling (monotone)
+		__syncthreads();
+	}
+	// ---- layer 2 (k_conv2<15, 12, 12>)
+	{
+		const int icl = lane >> 4;
+		const int arow = lane & 15, awin = arow >> 2, ady = (arow >> 1) & 1, adx = arow & 1;
+		float *const dst = act2 + (size_t)b * (64 * PO * PO) + n2 * (PO * PO);
+		for (int mt = 0; mt < MT; mt++)
+		{
+			const int win = 4 * mt + awin, wy = win / PO, wx = win % PO;
+			f32x4 acc = { bias2, bias2, bias2, bias2 };
+			const float *base = pooled + (2 * wy + ady) * IWD + 2 * wx + adx;
+#pragma unroll
+			for (int ks = 0; ks < 64; ks++)
+			{
+				const int p = ks >> 2, ky = p >> 2, kx = p & 3, ic = 4 * (ks & 3) + icl;
+				float a = base[ic * CH + ky * IWD + kx];
+				acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[ks], acc, 0, 0, 0);
+			}
+			const float mm = max_pool4(acc[0], acc[1], acc[2], acc[3]);
+			dst[4 * mt + icl] = tanh_ref(mm);
+		}
 	}
 }
 
@@ -756,8 +834,13 @@ void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, fl
 	}
 	else
 	{
-		hipLaunchKernelGGL((k_conv1<64, 15, 15>), dim3(B, 1), dim3(256), 0, s, cnn_in, w.W1, w.B1, act1);
-		hipLaunchKernelGGL((k_conv2<15, 12, 12>), dim3(B, 1), dim3(256), 0, s, act1, w.W2p, w.B2, act2);
+		static const bool conv_split = ht_tuning_env("HT_CONV_SPLIT");      // measurement (-DHT_TUNING): the two layers as two launches
+		if (conv_split)
+		{
+			hipLaunchKernelGGL((k_conv1<64, 15, 15>), dim3(B, 1), dim3(256), 0, s, cnn_in, w.W1, w.B1, act1);
+			hipLaunchKernelGGL((k_conv2<15, 12, 12>), dim3(B, 1), dim3(256), 0, s, act1, w.W2p, w.B2, act2);
+		}
+		else hipLaunchKernelGGL(k_conv12, dim3(B), dim3(256), 0, s, cnn_in, w.W1, w.B1, w.W2p, w.B2, act1, act2);
 		if (B % 128 == 0) hipLaunchKernelGGL((k_fc<true, 2, 4, true, true>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
 		else hipLaunchKernelGGL((k_fc<true, 2, 4, false, true>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
 	}

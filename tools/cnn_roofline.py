@@ -5,8 +5,8 @@ import csv, json, sys
 pre = sys.argv[1] if len(sys.argv) > 1 else "profiles/r02"
 B, PEAK = 1024, 157.3
 FLOP = {      # per frame
-    "64": {"k_conv1": 2 * 60 * 60 * 25 * 16, "k_conv2": 2 * 12 * 12 * 256 * 64, "k_fc<true, 2, 4, true": 2 * 2304 * 2048, "k_fc144": 2 * 2048 * 2304},
-    "128": {"k_conv1": 2 * 124 * 124 * 25 * 16, "k_conv2": 2 * 28 * 28 * 256 * 64, "k_fc<true, 2, 4, true": 2 * 12544 * 2048, "k_fc144": 2 * 2048 * 2304},
+    "64": {"k_conv12": 2 * 60 * 60 * 25 * 16 + 2 * 12 * 12 * 256 * 64, "k_conv1<": 2 * 60 * 60 * 25 * 16, "k_conv2": 2 * 12 * 12 * 256 * 64, "k_fc<true, 2, 4, true": 2 * 2304 * 2048, "k_fc144": 2 * 2048 * 2304},
+    "128": {"k_conv1<": 2 * 124 * 124 * 25 * 16, "k_conv2": 2 * 28 * 28 * 256 * 64, "k_fc<true, 2, 4, true": 2 * 12544 * 2048, "k_fc144": 2 * 2048 * 2304},
 }
 out = {"_note": "frac = achieved / 157.3 TFLOP/s (dense fp32 MFMA); mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs) from the separate counter pass; B = 1024 frames per launch"}
 for side, stats, pmc in (("64", pre + "_rocprofv3_kernel_stats_cnn.csv", pre + "_pmc_mfma_util.json"), ("128", pre + "_rocprofv3_kernel_stats_cnn128.csv", pre + "_pmc_mfma128_util.json")):
