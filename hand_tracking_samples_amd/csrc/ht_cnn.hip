@@ -255,10 +255,12 @@ __global__ __launch_bounds__(256) void k_conv2(const float *__restrict__ act1, c
 {
 	constexpr int IR = BAND + 3, PO = OW / 2, CH = IR * IWD, NW = (BAND / 2) * PO, MT = NW / 4;      // NW: pooling windows of the band
 	static_assert(NW % 4 == 0 && BAND % 2 == 0 && OW % 2 == 0 && OW % BAND == 0, "band must hold whole MFMA tiles of whole pooling windows");
-	__shared__ float in[16 * CH];
+	__shared__ __attribute__((aligned(16))) float in[16 * CH];
 	const int b = blockIdx.x, band = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	const int oy0 = band * BAND;
-	for (int i = t; i < 16 * CH; i += 256) { const int ic = i / CH, r = i % CH; in[i] = act1[(size_t)b * (16 * IWD * IWD) + ic * (IWD * IWD) + oy0 * IWD + r]; }
+	// the band's input rows in the order the matrix instruction reads them: [position][ic & 3][ic >> 2] -- a lane takes ic = 4 * j + (lane >> 4) for the four k-steps j of a
+	// tap, so its four values are one 128-bit read (16 reads per tile, where [ic][position] took 64 values in 32 double reads)
+	for (int i = t; i < 16 * CH; i += 256) { const int ic = i / CH, r = i % CH; in[(r * 4 + (ic & 3)) * 4 + (ic >> 2)] = act1[(size_t)b * (16 * IWD * IWD) + ic * (IWD * IWD) + oy0 * IWD + r]; }
 	const int n = 16 * wave + (lane & 15);
 	float breg[64];
 #pragma unroll
@@ -273,13 +275,15 @@ __global__ __launch_bounds__(256) void k_conv2(const float *__restrict__ act1, c
 	{
 		const int win = 4 * mt + awin, wy = win / PO, wx = win % PO;
 		f32x4 acc = { bias, bias, bias, bias };
-		const float *base = in + (2 * wy + ady) * IWD + 2 * wx + adx;
+		const float *base = in + (((2 * wy + ady) * IWD + 2 * wx + adx) * 4 + icl) * 4;
 #pragma unroll
-		for (int ks = 0; ks < 64; ks++)
+		for (int p = 0; p < 16; p++)      // tap p = (ky, kx); k = 16 * p + 4 * j + icl ascending
 		{
-			const int p = ks >> 2, ky = p >> 2, kx = p & 3, ic = 4 * (ks & 3) + icl;
-			float a = base[ic * CH + ky * IWD + kx];
-			acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[ks], acc, 0, 0, 0);
+			const float4 a = *reinterpret_cast<const float4 *>(base + ((p >> 2) * IWD + (p & 3)) * 16);
+			acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, breg[4 * p + 0], acc, 0, 0, 0);
+			acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, breg[4 * p + 1], acc, 0, 0, 0);
+			acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, breg[4 * p + 2], acc, 0, 0, 0);
+			acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, breg[4 * p + 3], acc, 0, 0, 0);
 		}
 		// C/D map 16x16: col = lane&15 (oc), row = (lane>>4)*4 + r = pixel r of window (lane>>4) of the tile, pixels in the order (0,0) (0,1) (1,0) (1,1)
 		const float mm = max_pool4(acc[0], acc[1], acc[2], acc[3]);
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256) void k_conv2(const float *__restrict__ act1, c
 // written and read back, a launch boundary with every block of the chip in step, and -- what the phases of a single launch cannot hide from each other (section 15) -- the 64 KB
 // of conv2 weights every block loads into registers, which are asked for HERE before the first layer's window loop and arrive under it.  act1 is still written (the layer
 // getter reads it), nobody waits for it.  Same arithmetic in the same order as the two kernels (the 128x128 net keeps them: its bands do not line up).
-__global__ __launch_bounds__(256) void k_conv12(const float *__restrict__ cnn_in, const float *__restrict__ W1, const float *__restrict__ B1, const float *__restrict__ W2p, const float *__restrict__ B2,
+__global__ __launch_bounds__(256, 4) void k_conv12(const float *__restrict__ cnn_in, const float *__restrict__ W1, const float *__restrict__ B1, const float *__restrict__ W2p, const float *__restrict__ B2,
                                                 float *__restrict__ act1, float *__restrict__ act2)
 {
 	constexpr int IW = 64, PW = 15, PR = 15, TR = 4 * PR + 4, IWP = IW + 4;
@@ -338,10 +342,18 @@ __global__ __launch_bounds__(256) void k_conv12(const float *__restrict__ cnn_in
 			if (lane < 16) pdst[ty * PW + tx] = m;
 		}
 		__syncthreads();
-		for (int i = t; i < 16 * CH; i += 256) { const float v = tanh_ref(pooled[i]); pooled[i] = v; act1[(size_t)b * (16 * CH) + i] = v; }      // tanh after pooling (monotone)
+		// tanh after pooling (monotone), into the dead input tile in the order layer 2 reads it: [position][ic & 3][ic >> 2] -- a lane of the matrix instruction takes
+		// ic = 4 * j + (lane >> 4) for the four k-steps j of a tap, so its four values are one 128-bit read (16 reads per tile instead of 64 values in 32 double reads)
+		for (int i = t; i < 16 * CH; i += 256)
+		{
+			const float v = tanh_ref(pooled[i]);
+			const int ic = i / CH, pos = i % CH;
+			tile[(pos * 4 + (ic & 3)) * 4 + (ic >> 2)] = v;
+			act1[(size_t)b * (16 * CH) + i] = v;
+		}
 		__syncthreads();
 	}
-	// ---- layer 2 (k_conv2<15, 12, 12>)
+	// ---- layer 2 (k_conv2<15, 12, 12>), its input from `tile`
 	{
 		const int icl = lane >> 4;
 		const int arow = lane & 15, awin = arow >> 2, ady = (arow >> 1) & 1, adx = arow & 1;
@@ -350,13 +362,15 @@ __global__ __launch_bounds__(256) void k_conv12(const float *__restrict__ cnn_in
 		{
 			const int win = 4 * mt + awin, wy = win / PO, wx = win % PO;
 			f32x4 acc = { bias2, bias2, bias2, bias2 };
-			const float *base = pooled + (2 * wy + ady) * IWD + 2 * wx + adx;
+			const float *base = tile + (((2 * wy + ady) * IWD + 2 * wx + adx) * 4 + icl) * 4;
 #pragma unroll
-			for (int ks = 0; ks < 64; ks++)
+			for (int p = 0; p < 16; p++)      // tap p = (ky, kx); k = 16 * p + 4 * j + icl, ascending as in k_conv2
 			{
-				const int p = ks >> 2, ky = p >> 2, kx = p & 3, ic = 4 * (ks & 3) + icl;
-				float a = base[ic * CH + ky * IWD + kx];
-				acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[ks], acc, 0, 0, 0);
+				const float4 a = *reinterpret_cast<const float4 *>(base + ((p >> 2) * IWD + (p & 3)) * 16);
+				acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, breg[4 * p + 0], acc, 0, 0, 0);
+				acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, breg[4 * p + 1], acc, 0, 0, 0);
+				acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, breg[4 * p + 2], acc, 0, 0, 0);
+				acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, breg[4 * p + 3], acc, 0, 0, 0);
 			}
 			const float mm = max_pool4(acc[0], acc[1], acc[2], acc[3]);
 			dst[4 * mt + icl] = tanh_ref(mm);
