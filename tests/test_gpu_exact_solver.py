@@ -19,8 +19,8 @@ from hand_tracking_samples_amd import weights as W
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-FR = np.load(os.path.join(HERE, "golden", "frames256.npz"))
-REF = htfx.load(os.path.join(HERE, "golden", "poses256.htfx"))
+FR = np.load(os.path.join(HERE, "golden", "frames1024.npz"))      # the bench's 1024 distinct frames
+REF = htfx.load(os.path.join(HERE, "golden", "poses1024.htfx"))
 N = len(FR["depth"])
 
 
@@ -54,7 +54,7 @@ def _restatement_with_cnn(weights, cnn_out, updates=1, model=None, depth=None, c
     return user, other, hand, flags
 
 
-def test_exact_order_solver_reproduces_the_restatement_bit_for_bit_on_all_256_frames(weights):
+def test_exact_order_solver_reproduces_the_restatement_bit_for_bit_on_all_1024_frames(weights):
     from hand_tracking_samples_amd import native
     ctx = native.Context(ol.MODEL, N)
     try:
