@@ -274,3 +274,26 @@ def test_unit_of_work_on_all_256_bench_frames(weights):
         e, i, n = orc.flags()
         assert (np.float32(e), i, n) == (ref["flags"][k, 0], int(ref["flags"][k, 1]), int(ref["flags"][k, 2])), "frame %d: flags" % k
     orc.close()
+
+
+def test_unit_of_work_on_all_1024_bench_frames(weights):
+    """The same on the 1024 DISTINCT frames bench.py times (tests/golden/frames1024.npz, poses1024.htfx = `ref_harness posesfull`): the checker the device is held
+    to on every frame of the headline number reproduces the reference on every one of them, bit for bit."""
+    import os
+    d = np.load(os.path.join(ol.GOLDEN, "frames1024.npz"))
+    ref = htfx.load(os.path.join(ol.GOLDEN, "poses1024.htfx"))
+    n = len(d["depth"])
+    assert n == 1024 and ref["uw_pose_user"].shape[0] == n
+    orc = ol.Oracle(weights)
+    orc.head.par.microforce = 3.0; orc.head.par.mainthreadpasses = 3
+    user = np.zeros((17, 7), np.float32)
+    bad = []
+    for k in range(n):
+        orc.reset(d["startpose"][k])
+        cam = ol.camera(d["cam"][k])
+        orc.L.ho_update(orc.h, ol.u16ptr(np.ascontiguousarray(d["depth"][k].reshape(-1))), C.byref(cam), ol.fptr(user))
+        e, i, _ = orc.flags()
+        if not (np.array_equal(user, ref["uw_pose_user"][k]) and np.array_equal(orc.get_state(1)[:, :7], ref["other_pose"][k]) and (np.float32(e), i) == (ref["flags"][k, 0], int(ref["flags"][k, 1]))):
+            bad.append(k)
+    orc.close()
+    assert not bad, "frames on which the restatement differs from the reference: %s" % bad[:16]
