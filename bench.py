@@ -539,7 +539,7 @@ def main():
         elif dom in ("cnn", "cnn128"):
             avg_ms = phases[dom][0] / phases[dom][1]
             achieved = flop_cnn * B / (avg_ms * 1e-3) / 1e12
-            roof = {"kernel": "cnn (k_conv1+k_conv2+k_fc x2+k_softmax_decode)", "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+            roof = {"kernel": "cnn (k_conv12 + k_fc + k_fc144_pk + k_softmax_decode)" if dom == "cnn" else "cnn (k_conv1 + k_conv2 + k_fc + k_fc144_pk + k_softmax_decode)", "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                     "frac": round(achieved / FP32_MFMA_PEAK_TF, 5), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": phases[dom][1], "flop_per_frame": flop_cnn}
         cnn_roof = None
         cnn_phase = "cnn128" if "cnn128" in all_phases else "cnn"
