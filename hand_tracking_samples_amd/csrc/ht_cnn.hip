@@ -833,7 +833,7 @@ void ht_launch_prepare_frame(const uint16_t *depth, const float *cams, int w, in
 	hipLaunchKernelGGL(k_prepare_frame, dim3(B), dim3(256), 0, s, depth, cams, w, h, drangey, fraction, pts, npts, overflow, cap);
 }
 // side = 64: PoseInitializerCNN's topology (handtrack.h:108-118); side = 128: the same layers on a 128x128 input (act1 [B][16*31*31], act2 [B][12544])
-void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, float *act2, float *act3, float *logits, int B, hipStream_t s, int side, hipEvent_t before_fc)
+void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, float *act2, float *act3, float *logits, int B, hipStream_t s, int side, bool beside_other_work)
 {
 	const dim3 g1(2048 / 64, (B + 127) / 128), t1(512);
 #ifdef HT_TUNING
@@ -843,24 +843,23 @@ void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, fl
 	{
 		hipLaunchKernelGGL((k_conv1<128, 31, 8>), dim3(B, 4), dim3(256), 0, s, cnn_in, w.W1, w.B1, act1);
 		hipLaunchKernelGGL((k_conv2<31, 28, 4>), dim3(B, 7), dim3(256), 0, s, act1, w.W2p, w.B2, act2);
-		if (before_fc) (void)hipStreamWaitEvent(s, before_fc, 0);
 		if (B % 128 == 0) hipLaunchKernelGGL((k_fc<true, 2, 4, true, true>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 12544);
 		else hipLaunchKernelGGL((k_fc<true, 2, 4, false, true>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 12544);
 	}
 	else
 	{
-		static const bool conv_split = ht_tuning_env("HT_CONV_SPLIT");      // measurement (-DHT_TUNING): the two layers as two launches
-		if (conv_split)
+		// Alone on the chip the two convolution layers run as one launch (k_conv12: 90 us against 49 + 52).  Inside an update the carried pose's FitError runs beside the net on
+		// a side stream (0.115 ms alone; the reset decision right behind the net needs it), and both want the whole chip: while the convolutions took 0.135 ms it ran under them
+		// (conv2 82 us instead of 52); once they took 0.09 it reached into k_fc, whose one block per CU, all in step, lost 70 us to it (161 instead of 92).  Measured on one
+		// device, same build, three runs each (ms per 1024-frame step, tuning build): two launches, FitError beside 5.694; two launches, FC layers waiting for it 5.713; one
+		// launch, waiting 5.707; one launch, beside 5.737.  So an update keeps the two launches and a stand-alone evaluation takes the one: same results bit for bit.
+		static const bool conv_split = ht_tuning_env("HT_CONV_SPLIT"), conv_fused = ht_tuning_env("HT_CONV_FUSED");      // measurement (-DHT_TUNING): force either arrangement
+		if ((beside_other_work && !conv_fused) || conv_split)
 		{
 			hipLaunchKernelGGL((k_conv1<64, 15, 15>), dim3(B, 1), dim3(256), 0, s, cnn_in, w.W1, w.B1, act1);
 			hipLaunchKernelGGL((k_conv2<15, 12, 12>), dim3(B, 1), dim3(256), 0, s, act1, w.W2p, w.B2, act2);
 		}
 		else hipLaunchKernelGGL(k_conv12, dim3(B), dim3(256), 0, s, cnn_in, w.W1, w.B1, w.W2p, w.B2, act1, act2);
-		// The FC layers want every CU to themselves (one block per CU, all in step): a kernel of another stream beside them costs them more than it would take alone -- the
-		// carried pose's FitError ran 0.14 ms beside the CNN, which was under the convolutions while those took 0.135 ms (conv2 82 us instead of 52) and reached into
-		// k_fc once they took 0.09 (k_fc 161 us instead of 92: the faster convolutions made the step SLOWER, 5.77 against 5.70 ms on the tuning build).  So the FC layers wait for
-		// it (5.71: the work of the two is what it is -- both want the whole chip -- but it no longer costs the FC layers more than its own time).
-		if (before_fc) (void)hipStreamWaitEvent(s, before_fc, 0);
 		if (B % 128 == 0) hipLaunchKernelGGL((k_fc<true, 2, 4, true, true>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
 		else hipLaunchKernelGGL((k_fc<true, 2, 4, false, true>), g1, t1, 0, s, act2, w.W3, w.B3, act3, B, 2048, 2304);
 	}

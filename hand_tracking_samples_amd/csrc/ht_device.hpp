@@ -146,6 +146,6 @@ struct ht_prepare_extra { float *cams_out; float *state0, *state1; const float *
 void ht_launch_prepare(const uint16_t *depth, const float *cams, float drangey, int fraction, float *cnn_in, float4 *pts, int *npts, int cap, int B, hipStream_t s, const ht_prepare_extra *extra = nullptr);
 void ht_launch_voxel(const float4 *all, const int *nall, int cap, float size, int min_count, float4 *out, int *nout, int B, hipStream_t s);
 void ht_launch_prepare_frame(const uint16_t *depth, const float *cams, int w, int h, float drangey, int fraction, float4 *pts, int *npts, int *overflow, int cap, int B, hipStream_t s);
-void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, float *act2, float *act3, float *logits, int B, hipStream_t s, int side = 64, hipEvent_t before_fc = nullptr);      // before_fc: the FC layers wait for this event (work that runs beside the convolutions)
+void ht_launch_cnn(const ht_cnn_weights &w, const float *cnn_in, float *act1, float *act2, float *act3, float *logits, int B, hipStream_t s, int side = 64, bool beside_other_work = false);      // beside_other_work: another stream's kernel runs beside the net (an update's side branch): picks the launch arrangement, not the results
 void ht_launch_softmax_decode(const float *logits, float *cnn_out, const float *cams, float *analysis, int softmax, int B, hipStream_t s, int sub = 4);      // sub: the heat-map camera is camsub(cam, sub)
 void ht_launch_cnn_input(const uint16_t *depth, const float *cams, int npx, float drangey, float *cnn_in, int B, hipStream_t s);

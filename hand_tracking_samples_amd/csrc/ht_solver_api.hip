@@ -224,19 +224,16 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		ht_fit_after dec; memset(&dec, 0, sizeof dec);
 		dec.mode = 1; dec.reset_thr = p.full_reset_on_error; dec.angles_only = p.angles_only; dec.flags = ctx->d_flags; dec.nflags = ctx->d_nflags; dec.list = ctx->d_flist; dec.nlist = ctx->d_nflist; dec.nreset = ctx->d_nreset;
 		ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_old, B, t, &dec);      // with the reset decision (handtrack.h:706)
-		(void)hipEventRecord(ctx->ev_join[1], ctx->side[1]);      // the CNN's FC layers wait for it (ht_launch_cnn), and so does everything behind the CNN
 	}
-	static const bool fc_beside = ht_tuning_env("HT_FC_BESIDE");      // measurement (-DHT_TUNING): the FC layers do not wait for the side branch
 	{
 		ht_prof_scope ps(ctx, (fs && fs->direct) ? "cnn128" : "cnn", s, true);
-		hipEvent_t before_fc = overlap && !fc_beside ? ctx->ev_join[1] : nullptr;
-		if (fs && fs->direct) ht_launch_cnn(ctx->cnnw128, ctx->d_in128, ctx->d_act1_128, ctx->d_act2_128, ctx->d_act3, ctx->d_logits, B, s, fs->direct, before_fc);
-		else ht_launch_cnn(ctx->cnnw, ctx->d_cnn_in, ctx->d_act1, ctx->d_act2, ctx->d_act3, ctx->d_logits, B, s, 64, before_fc);
+		if (fs && fs->direct) ht_launch_cnn(ctx->cnnw128, ctx->d_in128, ctx->d_act1_128, ctx->d_act2_128, ctx->d_act3, ctx->d_logits, B, s, fs->direct, overlap);
+		else ht_launch_cnn(ctx->cnnw, ctx->d_cnn_in, ctx->d_act1, ctx->d_act2, ctx->d_act3, ctx->d_logits, B, s, 64, overlap);      // overlap: the side branch's FitError runs beside the net
 		ht_launch_softmax_decode(ctx->d_logits, cnn_out, ctx->d_cams, ctx->d_analysis, 1, B, s, (fs && fs->direct) ? fs->direct / 16 : 4);
 	}
 	if (overlap)
 	{
-		(void)hipStreamWaitEvent(s, ctx->ev_join[1], 0);      // (recorded behind the side branch's FitError above)
+		(void)hipEventRecord(ctx->ev_join[1], ctx->side[1]); (void)hipStreamWaitEvent(s, ctx->ev_join[1], 0);
 		// the full-reset path touches few frames but is long (3 sequential single-body solves): it runs on a side stream while step 0 of
 		// MultiStepSim (which uses no cloud rows) proceeds for all other frames; the reset frames then do their step 0 on their own.
 		// (Taking the reset frames through ALL their steps on the side stream was measured: their five few-frame steps are pure latency and end
