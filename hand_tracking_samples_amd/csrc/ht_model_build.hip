@@ -21,6 +21,7 @@
 #include <utility>
 #include "ht_math.hpp"
 #include "ht_model_build.hpp"
+#include "../../include/ht_json.hpp"
 
 // ------------------------------------------------------------------------------------------------- HTFX container
 bool fx_load(const char *path, fx_map &out)
@@ -70,77 +71,9 @@ static fx_arr fx_i32(const std::vector<int> &v, std::initializer_list<uint32_t> 
 	a.data.resize(v.size() * 4); if (v.size()) memcpy(a.data.data(), v.data(), v.size() * 4); return a;
 }
 
-// ------------------------------------------------------------------------------------------------- JSON (subset the model files use)
-// Numbers keep their text; floats are converted with strtof, which is what the reference's `istringstream >> float` does
-// (third_party/json.h:104), so every coordinate is the correctly rounded fp32 of its decimal text.
+// ------------------------------------------------------------------------------------------------- JSON: include/ht_json.hpp (shared with the data-set reader of include/ht_formats.hpp)
 namespace {
-struct jnode
-{
-	enum kind_t { NUL, BOOL, NUM, STR, ARR, OBJ } kind = NUL;
-	std::string text;
-	std::vector<jnode> items;
-	std::vector<std::string> keys;
-	const jnode *get(const char *k) const { for (size_t i = 0; i < keys.size(); i++) if (keys[i] == k) return &items[i]; return nullptr; }
-	float as_float() const { return kind == NUM ? strtof(text.c_str(), nullptr) : 0.0f; }
-	int as_int() const { return kind == NUM ? (int)strtol(text.c_str(), nullptr, 10) : 0; }
-};
-struct jparser
-{
-	const char *p, *end; std::string err;
-	void ws() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++; }
-	bool fail(const char *m) { if (err.empty()) err = m; return false; }
-	bool value(jnode &n, int depth)
-	{
-		if (depth > 64) return fail("json nesting too deep");
-		ws();
-		if (p >= end) return fail("unexpected end of json");
-		if (*p == '{')
-		{
-			n.kind = jnode::OBJ; p++; ws();
-			if (p < end && *p == '}') { p++; return true; }
-			for (;;)
-			{
-				jnode k; ws();
-				if (p >= end || *p != '"' || !string(k)) return fail("object key expected");
-				ws(); if (p >= end || *p != ':') return fail("':' expected"); p++;
-				n.keys.push_back(k.text); n.items.emplace_back();
-				if (!value(n.items.back(), depth + 1)) return false;
-				ws(); if (p < end && *p == ',') { p++; continue; }
-				if (p < end && *p == '}') { p++; return true; }
-				return fail("',' or '}' expected");
-			}
-		}
-		if (*p == '[')
-		{
-			n.kind = jnode::ARR; p++; ws();
-			if (p < end && *p == ']') { p++; return true; }
-			for (;;)
-			{
-				n.items.emplace_back();
-				if (!value(n.items.back(), depth + 1)) return false;
-				ws(); if (p < end && *p == ',') { p++; continue; }
-				if (p < end && *p == ']') { p++; return true; }
-				return fail("',' or ']' expected");
-			}
-		}
-		if (*p == '"') return string(n);
-		if (!strncmp(p, "true", 4) && end - p >= 4) { n.kind = jnode::BOOL; n.text = "1"; p += 4; return true; }
-		if (!strncmp(p, "false", 5) && end - p >= 5) { n.kind = jnode::BOOL; n.text = "0"; p += 5; return true; }
-		if (!strncmp(p, "null", 4) && end - p >= 4) { n.kind = jnode::NUL; p += 4; return true; }
-		const char *s = p;
-		while (p < end && (strchr("+-.eE", *p) || (*p >= '0' && *p <= '9'))) p++;
-		if (p == s) return fail("unexpected character in json");
-		n.kind = jnode::NUM; n.text.assign(s, p);
-		return true;
-	}
-	bool string(jnode &n)
-	{
-		n.kind = jnode::STR; p++;
-		while (p < end && *p != '"') { if (*p == '\\' && p + 1 < end) p++; n.text.push_back(*p++); }
-		if (p >= end) return fail("unterminated string");
-		p++; return true;
-	}
-};
+using ht_json::jnode; using ht_json::jparser;
 bool read_v3(const jnode *n, v3 &o) { if (!n || n->kind != jnode::ARR || n->items.size() < 3) return false; o = V3(n->items[0].as_float(), n->items[1].as_float(), n->items[2].as_float()); return true; }
 bool read_v4(const jnode *n, v4 &o) { if (!n || n->kind != jnode::ARR || n->items.size() < 4) return false; o = V4(n->items[0].as_float(), n->items[1].as_float(), n->items[2].as_float(), n->items[3].as_float()); return true; }
 

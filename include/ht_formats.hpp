@@ -21,6 +21,7 @@
 #include <string>
 #include <vector>
 #include "ht_handtrack.hpp"
+#include "ht_json.hpp"
 
 namespace ht_mi355x {
 
@@ -106,42 +107,17 @@ inline void WritePoseLine(std::ostream &out, const std::vector<Pose> &pose)
 	out << "\n";
 }
 
-// ---- .json header ----------------------------------------------------------------------------------------------------------
+// ---- .json header (parsed by include/ht_json.hpp, the product's one JSON reader; a syntax error is thrown here as the reference's reader throws) ----
 namespace detail {
-struct jv { char kind = 'n'; std::string text; std::vector<jv> arr; std::vector<std::pair<std::string, jv>> obj;      // kinds: n(ull) b(ool) #(number) s(tring) a(rray) o(bject)
-	const jv *get(const std::string &k) const { for (auto &kv : obj) if (kv.first == k) return &kv.second; return nullptr; }
-	double num(double def = 0) const { return kind == '#' ? strtod(text.c_str(), nullptr) : def; } };
-struct jparse
-{
-	const char *p, *e;
-	void ws() { while (p < e && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++; }
-	[[noreturn]] void fail(const char *m) { throw std::runtime_error(std::string("json parse error - ") + m); }
-	std::string str() { std::string s; p++; while (p < e && *p != '"') { if (*p == '\\' && p + 1 < e) p++; s.push_back(*p++); } if (p >= e) fail("unterminated string"); p++; return s; }
-	jv value(int depth = 0)
-	{
-		if (depth > 64) fail("nesting too deep");
-		jv v; ws(); if (p >= e) fail("unexpected end");
-		if (*p == '{') { v.kind = 'o'; p++; ws(); if (p < e && *p == '}') { p++; return v; }
-			for (;;) { ws(); if (p >= e || *p != '"') fail("key expected"); std::string k = str(); ws(); if (p >= e || *p != ':') fail("':' expected"); p++; v.obj.emplace_back(k, value(depth + 1)); ws();
-				if (p < e && *p == ',') { p++; continue; } if (p < e && *p == '}') { p++; return v; } fail("',' or '}' expected"); } }
-		if (*p == '[') { v.kind = 'a'; p++; ws(); if (p < e && *p == ']') { p++; return v; }
-			for (;;) { v.arr.push_back(value(depth + 1)); ws(); if (p < e && *p == ',') { p++; continue; } if (p < e && *p == ']') { p++; return v; } fail("',' or ']' expected"); } }
-		if (*p == '"') { v.kind = 's'; v.text = str(); return v; }
-		if (e - p >= 4 && !std::string(p, 4).compare("true")) { v.kind = 'b'; v.text = "1"; p += 4; return v; }
-		if (e - p >= 5 && !std::string(p, 5).compare("false")) { v.kind = 'b'; v.text = "0"; p += 5; return v; }
-		if (e - p >= 4 && !std::string(p, 4).compare("null")) { p += 4; return v; }
-		const char *s = p; while (p < e && (std::string("+-.eE").find(*p) != std::string::npos || (*p >= '0' && *p <= '9'))) p++;
-		if (p == s) fail("unexpected character");
-		v.kind = '#'; v.text.assign(s, p); return v;
-	}
-};
-inline jv parse_json_file(const std::string &path)
+inline ht_json::jnode parse_json_file(const std::string &path)
 {
 	std::ifstream in(path, std::ios::binary); if (!in.is_open()) throw std::runtime_error("file not found: " + path);
-	std::stringstream ss; ss << in.rdbuf(); std::string text = ss.str();
-	jparse jp{ text.data(), text.data() + text.size() }; return jp.value();
+	std::stringstream ss; ss << in.rdbuf(); const std::string text = ss.str();
+	ht_json::jnode root; std::string err;
+	if (!ht_json::parse(text.data(), text.size(), root, &err)) throw std::runtime_error("json parse error - " + err);
+	return root;
 }
-inline float jf(const jv *v, size_t i, float def = 0) { return v && v->kind == 'a' && i < v->arr.size() ? (float)strtof(v->arr[i].text.c_str(), nullptr) : def; }
+inline float jf(const ht_json::jnode *v, size_t i, float def = 0) { return v && v->kind == ht_json::jnode::ARR && i < v->items.size() ? v->items[i].as_float() : def; }
 }  // namespace detail
 
 struct DatasetInfo      // dataset.h:21-37
@@ -150,19 +126,19 @@ struct DatasetInfo      // dataset.h:21-37
 };
 inline DatasetInfo ReadDatasetInfo(const std::string &jsonfile)
 {
-	const detail::jv root = detail::parse_json_file(jsonfile);
+	const ht_json::jnode root = detail::parse_json_file(jsonfile);
 	DatasetInfo d;
-	if (const detail::jv *c = root.get("dcamera"))      // visit_fields(DCamera) misc_image.h:57
+	if (const ht_json::jnode *c = root.get("dcamera"))      // visit_fields(DCamera) misc_image.h:57
 	{
-		const detail::jv *dims = c->get("dims"), *focal = c->get("focal"), *pr = c->get("principal"), *ds = c->get("depth_scale");
+		const ht_json::jnode *dims = c->get("dims"), *focal = c->get("focal"), *pr = c->get("principal"), *ds = c->get("depth_scale");
 		d.dcamera = DCamera({ (int)detail::jf(dims, 0), (int)detail::jf(dims, 1) }, { detail::jf(focal, 0), detail::jf(focal, 1) }, { detail::jf(pr, 0), detail::jf(pr, 1) }, ds ? (float)strtof(ds->text.c_str(), nullptr) : 0.0f);
 	}
-	const detail::jv *m = root.get("mplane"); d.mplane = { detail::jf(m, 0), detail::jf(m, 1), detail::jf(m, 2), detail::jf(m, 3) };
-	if (const detail::jv *v = root.get("fname")) d.fname = v->text;
-	if (const detail::jv *v = root.get("camtype")) d.camtype = v->text;
-	if (const detail::jv *v = root.get("hasir")) d.hasir = v->kind == 'b' ? v->text == "1" : v->num() != 0;
-	const detail::jv *r = root.get("rgb_dim"), *f = root.get("feyedim"); d.rgb_dim = { (int)detail::jf(r, 0), (int)detail::jf(r, 1) }; d.feye_dim = { (int)detail::jf(f, 0), (int)detail::jf(f, 1) };
-	if (const detail::jv *v = root.get("segment_scale")) d.segment_scale = (float)strtof(v->text.c_str(), nullptr);
+	const ht_json::jnode *m = root.get("mplane"); d.mplane = { detail::jf(m, 0), detail::jf(m, 1), detail::jf(m, 2), detail::jf(m, 3) };
+	if (const ht_json::jnode *v = root.get("fname")) d.fname = v->text;
+	if (const ht_json::jnode *v = root.get("camtype")) d.camtype = v->text;
+	if (const ht_json::jnode *v = root.get("hasir")) d.hasir = v->kind == ht_json::jnode::BOOL ? v->text == "1" : (v->kind == ht_json::jnode::NUM && strtod(v->text.c_str(), nullptr) != 0);
+	const ht_json::jnode *r = root.get("rgb_dim"), *f = root.get("feyedim"); d.rgb_dim = { (int)detail::jf(r, 0), (int)detail::jf(r, 1) }; d.feye_dim = { (int)detail::jf(f, 0), (int)detail::jf(f, 1) };
+	if (const ht_json::jnode *v = root.get("segment_scale")) d.segment_scale = (float)strtof(v->text.c_str(), nullptr);
 	return d;
 }
 inline void WriteDatasetInfo(const std::string &jsonfile, const DatasetInfo &d)
