@@ -124,6 +124,25 @@ def test_cnn_eval_random_inputs_vs_oracle(ctx, weights):
     assert err <= CNN_ATOL
 
 
+def test_the_net_inside_an_update_equals_the_net_alone(ctx, golden):
+    """ht_launch_cnn picks its launch arrangement by context: an update, whose side branch runs beside the net, keeps the two convolution launches (k_conv1, k_conv2); a
+    stand-alone evaluation takes the fused one (k_conv12).  Same arithmetic in the same order: the heat-maps an update returns equal ht_cnn_eval's on the same tiles bit
+    for bit, and so do the layers in between."""
+    depth, cams = _frames(golden)
+    start = np.stack([golden["f%d/startpose" % f] for f in range(8)]) if "f0/startpose" in golden else None
+    if start is None:
+        start = np.zeros((8, 17, 7), np.float32); start[:, :, 6] = 1.0; start[:, :, 2] = 0.45
+    ctx.tracker_reset(start)
+    _, cnn_update = ctx.update_sync(depth, cams, want_cnn=True)
+    layers_update = ctx.cnn_layers(8)
+    cnn_in, _, _ = ctx.stage_prepare(depth, cams)
+    cnn_alone = ctx.cnn_eval(cnn_in)
+    layers_alone = ctx.cnn_layers(8)
+    assert np.array_equal(cnn_update, cnn_alone)
+    for a, b in zip(layers_update, layers_alone):
+        assert np.array_equal(a, b)
+
+
 def test_decode_matches_golden(ctx, golden):
     depth, cams = _frames(golden)
     cnn_out = np.stack([golden["f%d/cnn_output" % f] for f in range(8)])
