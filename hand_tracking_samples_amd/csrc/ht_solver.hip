@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		// current one would wait for the read at the end of every row); reads run up to two records past the run
 		auto step = [&](const aset &r0, float av) {
 			const int body = side ? (int)(r0.e >> 24) : (int)((r0.e >> 16) & 255);
-			const int cnt = (int)((r0.e >> 8) & 255);
+			const int cnt = HT_DBG(a.dbg, 16384) ? 1 : (int)((r0.e >> 8) & 255);      // timing experiment (-DHT_TUNING, wrong results): only the first row of every run -- what a level costs without its rows
 			const bool bv = body != IDLE_BODY;       // a missing body: its ba is an exact zero, so it contributes exactly 0 and its (zero) momenta are never stored
 			float *R = arec_ + (int)(r0.e & 0xFF) * AROW;
 			aset ra = r0, rb, rc;
