@@ -24,6 +24,7 @@ struct solve_args
 	const float *sf_crays; int sf_ncray; int sf_select; float sf_spoint[3], sf_rbpoint[3]; const float *sf_refpose; int sf_hold;
 	int *caps;                                                      // capacity counter: frames x launches whose angular rows exceeded the LDS records (may be null)
 	int shared_gpu;                                                 // other kernels run beside this launch (the reset path): keep the small LDS footprint
+	int two_body_levels;                                            // tests only (ht_debug_solver_build 7): the two-body rows by the level schedule for every frame, as until round 4 (otherwise only frames the blocked form does not hold)
 	int force_build;                                                // 0: the launcher chooses k_solve's build; 1 small, 2 only, 3 mid, 4 tiny (every array in HBM): ht_debug_solver_build
 	// the last solve of an update also delivers the poses (GetPoseUser physmodel.h:434 + the "initializing = 50" rule of handtrack.h:781-782), instead of a launch of its own
 	float *out_poses; const int *out_npts; int *out_initializing; int out_min_point_num;

@@ -79,7 +79,11 @@ template <int NGRP_, int NSUM_, int NANG_, int NIDX_, int AS_ = 2> struct lds_t
 	unsigned short cidx[NIDX > 0 ? NIDX : 2];   // the chains: record index of every single-body row, in chain order (+ read-ahead slack); in HBM when the build has no room
 	int ccnt[HT_MAXNB], cstart[HT_MAXNB];  // chain of body b: rows [cstart, cstart+ccnt) of the partitioned single-body stream
 	signed char cextra[HT_MAXNB];          // body b < 16 hosts the chain of this body >= 16 on its quad (-1: none): it follows b's rows, padded to a multiple of 8
-	unsigned lorder[MAXG];                 // two-body linear groups sorted by step: group | rb0 << 16 | rb1 << 24; last slot = the idle entry
+	union
+	{
+		unsigned lorder[MAXG];             // two-body linear groups sorted by step: group | rb0 << 16 | rb1 << 24; last slot = the idle entry
+		struct { unsigned short abody[128]; unsigned etmp[64]; } blk;      // frames whose two-body rows are resolved in blocks (ht_block.hpp) have no level schedule: body pair of every angular row (rb0 | rb1 << 8, 255 = none), and the edge sort's table
+	};
 	unsigned short lstart[MAXG + 2];       // step L = lorder[lstart[L] .. lstart[L+1]); a step is a level, split so that it holds <= 8 groups
 	unsigned aorder[MAXA2 + 1];            // angular row groups (runs of consecutive rows on the same body pair): first row | count << 8 | rb0 << 16 | rb1 << 24
 	unsigned short astart[MAXA2 + 2];
@@ -101,6 +105,7 @@ template <int NGRP_, int NSUM_, int NANG_, int NIDX_, int AS_ = 2> struct lds_t
 };
 
 #include "ht_quad.hpp"
+#include "ht_block.hpp"
 
 __device__ __forceinline__ v3 L3(const float *p) { return V3(p[0], p[1], p[2]); }
 __device__ __forceinline__ v4 L4(const float *p) { return V4(p[0], p[1], p[2], p[3]); }
@@ -651,7 +656,21 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	//      a body, so conflicting rows keep the reference's order; a group's own rows run back to back in one lane pair with the momenta in
 	//      registers.  Groups are counting-sorted by level into steps of at most 8 groups (one per lane pair). ----
 	if (na > MAXA_LDS) na = MAXA_LDS;
+	// ---- which way the two-body rows go (round 5).  BLOCKED (ht_block.hpp): the model's own joint and contact triples (at most 4 blocks of ten) and up to 128 angular
+	//      rows, resolved a block at a time in the reference's row order; everything else -- a caller's two-body linear rows, more rows than the blocks hold, an angular
+	//      row that RemoveBias switches on (its gain differs between the sweeps before and after, and a block's couplings carry the gain) -- keeps the level schedule
+	//      below.  The choice follows the frame's rows, never the build or the launch, so every build returns the same bits.
+	bool blocked = false;
+	if constexpr (!EXACT)
+	{
+		bool sw = false;
+#pragma unroll
+		for (int s = 0; s < ASLOTS; s++) sw = sw || (lane + 64 * s < na && AR[s].targetspin == -FLT_MAX && AR[s].mintorque < 0);
+		blocked = !a.two_body_levels && ngt == 0 && n2 <= 4 * BLK_LROWS && na <= 128 && __ballot(sw) == 0ull;
+		blocked = __builtin_amdgcn_readfirstlane((int)blocked) != 0;
+	}
 	int nga = 0;
+	if (!blocked)
 	for (int base = 0; base < na; base += 64)          // heads of the angular runs, found one row per lane
 	{
 		const int r = base + lane;
@@ -667,6 +686,8 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		if (a.caps && lane == 0) atomicAdd(a.caps, 1);
 		na = S.gst[MAXA_RUNS]; nga = MAXA_RUNS;
 	}
+	if (blocked) { if (lane == 0) { S.nlev_lin = 0; S.nlev_ang = 0; } }
+	else
 	{
 		// two-body linear groups: lane g (and g + 64) speaks for group g
 		int gb0[2], gb1[2];
@@ -954,8 +975,156 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		}
 	}
 	if (lane < 4 * AROW) arec[na * AROW + lane] = 0.0f;      // idle record + read-ahead slack
+	if (blocked)
+	{
+#pragma unroll
+		for (int s = 0; s < 2; s++)
+		{
+			const int r = lane + 64 * s;
+			S.blk.abody[r] = (unsigned short)(r < na ? ((AR[s].rb0 >= 0 ? AR[s].rb0 : 255) | ((AR[s].rb1 >= 0 ? AR[s].rb1 : 255) << 8)) : 0xFFFF);
+		}
+	}
 	__threadfence_block();
 	__syncthreads();
+
+	// ---- two-body rows in blocks (ht_block.hpp), once per solve: every row's couplings to the rows before it in its block, and every block's edges sorted by body ----
+	float GL[32], GA[32];                                  // coupling registers of the linear and of the angular rows: lane m holds -k_j c_j . D_i of its forward row (block 2h, row m) with row i in register i < m, of its backward row (block 2h + 1, row 31 - m) with row i in register 31 - i > m
+	unsigned emL0 = 0, emL1 = 0, emL2 = 0, emL3 = 0, emA0 = 0, emA1 = 0, emA2 = 0, emA3 = 0;      // edge words of the blocks (ht_block.hpp)
+#pragma unroll
+	for (int i = 0; i < 32; i++) { GL[i] = 0.0f; GA[i] = 0.0f; }
+	const int nbl = blocked ? (n2 + BLK_LROWS - 1) / BLK_LROWS : 0, nba = blocked ? (na + 31) >> 5 : 0;
+	if (blocked)
+	{
+		const int m = lane & 31, hh = lane >> 5;
+		{
+			// angular rows: row r of the list sits in block r / 32; w_j = ba0_j . L(rb0) + ba1_j . L(rb1), a unit torque of row i adds -axis_i to L(rb0_i) and +axis_i to L(rb1_i)
+			auto own = [&](int r, float &gain, v3 &b0, v3 &b1, int &a0, int &a1) {
+				const bool on = r < na;
+				const float *R = arec + (on ? r : na) * AROW;
+				gain = R[AR_GAIN]; b0 = L3(R + AR_BA); b1 = L3(R + AR_BA + 3);
+				const int bo = on ? (int)S.blk.abody[r] : 0xFFFF; a0 = bo & 255; a1 = bo >> 8;
+			};
+			auto coupling = [&](int rp, float gain, v3 b0, v3 b1, int a0, int a1) -> float {
+				const bool pon = rp < na;
+				const float *P = arec + (pon ? rp : na) * AROW;
+				const v3 ax = L3(P + AR_AXIS);
+				const int pb = pon ? (int)S.blk.abody[rp] : 0xFFFF; const int p0 = pb & 255, p1 = pb >> 8;
+				const float s0 = (float)((int)(a0 != 255 && a0 == p1) - (int)(a0 != 255 && a0 == p0));
+				const float s1 = (float)((int)(a1 != 255 && a1 == p1) - (int)(a1 != 255 && a1 == p0));
+				return -gain * (dot(b0, ax) * s0 + dot(b1, ax) * s1);
+			};
+			float gain; v3 b0, b1; int a0, a1;
+			own(64 * hh + m, gain, b0, b1, a0, a1);
+#pragma unroll
+			for (int rho = 0; rho < 32; rho++) { const float g = coupling(64 * hh + rho, gain, b0, b1, a0, a1); if (rho < m) GA[rho] = g; }
+			if (nba > 1)
+			{
+				own(64 * hh + 63 - m, gain, b0, b1, a0, a1);
+#pragma unroll
+				for (int rho = 0; rho < 32; rho++) { const float g = coupling(64 * hh + 63 - rho, gain, b0, b1, a0, a1); if (rho > m) GA[rho] = g; }
+			}
+		}
+		{
+			// linear rows: row r of the joint and contact triples sits in block r / 30; w_j = b0_j . L(rb0) - n_j minv0 . P(rb0) + b1_j . L(rb1) + n_j minv1 . P(rb1), a unit
+			// impulse of row i adds -n_i to P(rb0_i), g0_i to L(rb0_i), n_i to P(rb1_i), g1_i to L(rb1_i) (the sides' signs ride on g and b: the group record's layout)
+			auto lrow = [&](int blk, int pos, int &g, int &k) -> bool { const int row = BLK_LROWS * blk + pos; g = row / 3; k = row - 3 * g; return pos >= 0 && pos < BLK_LROWS && row < n2; };
+			struct lown { float rinv, ma, mb; v3 n, b0, b1; int a, b; };
+			auto own = [&](int blk, int pos) -> lown {
+				int g, k; const bool on = lrow(blk, pos, g, k);
+				if (!on) { g = ng2; k = 0; }
+				const float *R = pool + g * LGRP;
+				lown o; o.rinv = on ? R[LG_RINV + k] : 0.0f; o.n = L3(R + LG_N + 3 * k);
+				const float *og = R + LG_GB + 12 * k;
+				o.b0 = V3(og[1], og[3], og[5]); o.b1 = V3(og[7], og[9], og[11]);
+				const int meta = __float_as_int(R[LG_META]); o.a = meta & 255; o.b = (meta >> 8) & 255;
+				o.ma = S.lin4[o.a < HT_MAXNB ? o.a : IDLE_BODY].w; o.mb = S.lin4[o.b < HT_MAXNB ? o.b : IDLE_BODY].w;
+				return o;
+			};
+			auto coupling = [&](const lown &o, int blk, int pos) -> float {
+				int g, k; const bool pon = lrow(blk, pos, g, k);
+				if (!pon) { g = ng2; k = 0; }
+				const float *R = pool + g * LGRP;
+				const v3 pn = L3(R + LG_N + 3 * k);
+				const float *og = R + LG_GB + 12 * k;
+				const v3 g0 = V3(og[0], og[2], og[4]), g1 = V3(og[6], og[8], og[10]);
+				const int meta = __float_as_int(R[LG_META]); const int pa = meta & 255, pb = (meta >> 8) & 255;
+				const bool daa = o.a == pa, dab = o.a == pb, dba = o.b == pa, dbb = o.b == pb;
+				const v3 z = V3(0, 0, 0);
+				const v3 gs0 = daa ? g0 : dab ? g1 : z, gs1 = dba ? g0 : dbb ? g1 : z;
+				const float nn = dot(o.n, pn);
+				const float dw = (dot(o.b0, gs0) + dot(o.b1, gs1)) + nn * (o.ma * (float)((int)daa - (int)dab) + o.mb * (float)((int)dbb - (int)dba));
+				return -o.rinv * dw;
+			};
+			if (nbl > 0)
+			{
+				const lown o = own(2 * hh, m);
+#pragma unroll
+				for (int rho = 0; rho < BLK_LROWS; rho++) { const float g = coupling(o, 2 * hh, rho); if (rho < m) GL[rho] = g; }
+			}
+			if (nbl > 1)
+			{
+				const lown o = own(2 * hh + 1, 31 - m);
+#pragma unroll
+				for (int rho = 2; rho < 32; rho++) { const float g = coupling(o, 2 * hh + 1, 31 - rho); if (rho > m) GL[rho] = g; }
+			}
+		}
+		// edge words: a block's (row, side) pairs sorted by body, one per lane (ht_block.hpp)
+		auto edge_word = [&](bool valid, int ba, int bb) -> unsigned {
+			const int ka = (valid && ba < nb) ? ba : 255, kb = (valid && bb < nb) ? bb : 255;
+			const unsigned long long lt = (1ull << lane) - 1ull;
+			int r0 = -1, r1 = -1, base = 0;
+			for (int k = 0; k < nb; k++)
+			{
+				const unsigned long long m0 = __ballot(ka == k), m1 = __ballot(kb == k);
+				const int below = __popcll((m0 | m1) & lt);
+				if (ka == k) r0 = base + below;
+				if (kb == k) r1 = base + below;
+				base += __popcll(m0) + __popcll(m1);
+			}
+			__syncthreads();
+			S.blk.etmp[lane] = 0u;
+			__threadfence_block();
+			__syncthreads();
+			if (r0 >= 0) S.blk.etmp[r0] = (unsigned)lane | BLK_E_VALID | ((unsigned)ka << 16);
+			if (r1 >= 0) S.blk.etmp[r1] = (unsigned)lane | BLK_E_SIDE | BLK_E_VALID | ((unsigned)kb << 16);
+			__threadfence_block();
+			__syncthreads();
+			const unsigned e = S.blk.etmp[lane];
+			const bool v = (e & BLK_E_VALID) != 0;
+			auto same = [&](int other) -> bool { const unsigned o = S.blk.etmp[other & 63]; return v && other >= 0 && other < 64 && (o & BLK_E_VALID) != 0 && (o >> 16) == (e >> 16); };
+			const int rs = lane & ~15;
+			unsigned w = e;
+			if (v && !same(lane + 1)) w |= BLK_E_TAIL;
+			if (lane - 1 >= rs && same(lane - 1)) w |= 1u << 9;
+			if (lane - 2 >= rs && same(lane - 2)) w |= 1u << 10;
+			if (lane - 4 >= rs && same(lane - 4)) w |= 1u << 11;
+			if (lane - 8 >= rs && same(lane - 8)) w |= 1u << 12;
+			if ((lane & 16) && same(rs - 1)) w |= 1u << 13;      // rows 1 and 3 of the wave: row_bcast15 brings the lane before the row
+			if (lane >= 32 && same(31)) w |= 1u << 14;           // rows 2 and 3: row_bcast31 brings lane 31
+			return w;
+		};
+		auto lin_edges = [&](int Q) -> unsigned {
+			const int p = (Q & 1) ? 31 - m : m, row = BLK_LROWS * Q + p;
+			const bool on = hh == (Q >> 1) && p < BLK_LROWS && row < n2;
+			const int meta = __float_as_int(pool[(on ? row / 3 : ng2) * LGRP + LG_META]);
+			return edge_word(on, meta & 255, (meta >> 8) & 255);
+		};
+		auto ang_edges = [&](int Q) -> unsigned {
+			const int p = (Q & 1) ? 31 - m : m, row = 32 * Q + p;
+			const bool on = hh == (Q >> 1) && row < na;
+			const int bo = on ? (int)S.blk.abody[row] : 0xFFFF;
+			return edge_word(on, bo & 255, bo >> 8);
+		};
+		if (nbl > 0) emL0 = lin_edges(0);
+		if (nbl > 1) emL1 = lin_edges(1);
+		if (nbl > 2) emL2 = lin_edges(2);
+		if (nbl > 3) emL3 = lin_edges(3);
+		if (nba > 0) emA0 = ang_edges(0);
+		if (nba > 1) emA1 = ang_edges(1);
+		if (nba > 2) emA2 = ang_edges(2);
+		if (nba > 3) emA3 = ang_edges(3);
+		__syncthreads();
+	}
 
 	if (HT_DBG(a.dbg, 128)) return;
 	// ---- Gauss-Seidel sweeps ----
@@ -1121,6 +1290,105 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			__builtin_amdgcn_wave_barrier();
 		}
 	};
+	// ---- the same two phases a block at a time (ht_block.hpp): every lane of a block's half-wave holds one row.  Per block: the rows' velocity terms against the momenta as
+	//      they stand (LDS), the resolve in row order, the impulse sums / torques stored, the momenta brought up to date through the block's sorted edges ----
+	const int idt_bits = __builtin_amdgcn_readfirstlane(__float_as_int(inv_dt)), dt_bits = __builtin_amdgcn_readfirstlane(__float_as_int(dt));
+	auto blocked_linear = [&](const auto pool_, const bool post) {
+		for (int Q = 0; Q < nbl; Q++)
+		{
+			const int m = lane & 31;
+			const int p = (Q & 1) ? 31 - m : m, row = BLK_LROWS * Q + p;
+			const bool act = (lane >> 5) == (Q >> 1) && p < BLK_LROWS && row < n2;
+			const int g = act ? row / 3 : ng2, k = act ? row - 3 * g : 0;
+			auto *const R = pool_ + g * LGRP;
+			const float4 sv = *reinterpret_cast<const float4 *>(R + LG_S + 4 * k);
+			const float4 qm = *reinterpret_cast<const float4 *>(R + LG_RINV), is = *reinterpret_cast<const float4 *>(R + LG_SUM);
+			const float rinv = k == 0 ? qm.x : k == 1 ? qm.y : qm.z, sum = k == 0 ? is.x : k == 1 ? is.y : is.z;
+			const int meta = __float_as_int(qm.w);
+			const v3 n = L3(R + LG_N + 3 * k);
+			const float4 o0 = *reinterpret_cast<const float4 *>(R + LG_GB + 12 * k), o1 = *reinterpret_cast<const float4 *>(R + LG_GB + 12 * k + 4), o2 = *reinterpret_cast<const float4 *>(R + LG_GB + 12 * k + 8);
+			const v3 g0 = V3(o0.x, o0.z, o1.x), b0 = V3(o0.y, o0.w, o1.y), g1 = V3(o1.z, o2.x, o2.z), b1 = V3(o1.w, o2.y, o2.w);
+			const int ba = (meta & 255) < HT_MAXNB ? (meta & 255) : IDLE_BODY, bb = ((meta >> 8) & 255) < HT_MAXNB ? ((meta >> 8) & 255) : IDLE_BODY;
+			const float4 Pa = S.lin4[ba], La = S.ang4[ba], Pb = S.lin4[bb], Lb = S.ang4[bb];
+			// vn = v1.n - v0.n (physics.h:296-297) against the momenta before the block
+			float w = b0.x * La.x; w = __fmaf_rn(b0.y, La.y, w); w = __fmaf_rn(b0.z, La.z, w);
+			w = __fmaf_rn(b1.x, Lb.x, w); w = __fmaf_rn(b1.y, Lb.y, w); w = __fmaf_rn(b1.z, Lb.z, w);
+			const float na_ = -Pa.w, nb_ = Pb.w;
+			w = __fmaf_rn(n.x * na_, Pa.x, w); w = __fmaf_rn(n.y * na_, Pa.y, w); w = __fmaf_rn(n.z * na_, Pa.z, w);
+			w = __fmaf_rn(n.x * nb_, Pb.x, w); w = __fmaf_rn(n.y * nb_, Pb.y, w); w = __fmaf_rn(n.z * nb_, Pb.z, w);
+			float x = (-(post ? sv.y : sv.x) - w) * rinv;
+			const bool fric = act && k > 0 && (meta & LM_NORMAL);      // limited by the normal row's impulse sum (physics.h:292): set behind that row's step
+			float lo = fric ? 0.0f : sv.z - sum, hi = fric ? 0.0f : sv.w - sum;
+			const int mp = fric ? p - k : 255;
+			float imp = 0.0f;
+			const int nrows = n2 - BLK_LROWS * Q;
+#define BLK_LCASE(QQ) case QQ: blk_resolve15<QQ, 0>(x, lo, hi, imp, GL, is.x, sv.w, sum, mp, idt_bits, dt_bits); if (nrows > 15) blk_resolve15<QQ, 1>(x, lo, hi, imp, GL, is.x, sv.w, sum, mp, idt_bits, dt_bits); break;
+			switch (Q) { BLK_LCASE(0) BLK_LCASE(1) BLK_LCASE(2) default: BLK_LCASE(3) }
+#undef BLK_LCASE
+			if (act) R[LG_SUM + k] = sum + imp;
+			// the momenta: -n d to P(rb0), g0 d to L(rb0), n d to P(rb1), g1 d to L(rb1) (ApplyImpulse physics.h:222-226), summed per body over the block's sorted edges
+			const unsigned e = Q == 0 ? emL0 : Q == 1 ? emL1 : Q == 2 ? emL2 : emL3;
+			const int src = (int)(e & 63);
+			const bool side = (e & BLK_E_SIDE) != 0;
+			const float cf = (e & BLK_E_VALID) ? (side ? 1.0f : -1.0f) : 0.0f, cv = (e & BLK_E_VALID) ? 1.0f : 0.0f;
+			const float dpx = n.x * imp, dpy = n.y * imp, dpz = n.z * imp;
+			const float d0x = g0.x * imp, d0y = g0.y * imp, d0z = g0.z * imp, d1x = g1.x * imp, d1y = g1.y * imp, d1z = g1.z * imp;
+			float vpx = blk_pull(src, dpx) * cf, vpy = blk_pull(src, dpy) * cf, vpz = blk_pull(src, dpz) * cf;
+			const float q0x = blk_pull(src, d0x), q0y = blk_pull(src, d0y), q0z = blk_pull(src, d0z), q1x = blk_pull(src, d1x), q1y = blk_pull(src, d1y), q1z = blk_pull(src, d1z);
+			float vlx = (side ? q1x : q0x) * cv, vly = (side ? q1y : q0y) * cv, vlz = (side ? q1z : q0z) * cv;
+			const blk_scan_mul sm = blk_scan_multipliers(e);
+			blk_seg_scan3(vpx, vpy, vpz, sm);
+			blk_seg_scan3(vlx, vly, vlz, sm);
+			if (e & BLK_E_TAIL)
+			{
+				const int body = (int)(e >> 16);
+				float4 P = S.lin4[body], L = S.ang4[body];
+				P.x += vpx; P.y += vpy; P.z += vpz; L.x += vlx; L.y += vly; L.z += vlz;
+				S.lin4[body] = P; S.ang4[body] = L;
+			}
+			__builtin_amdgcn_wave_barrier();
+		}
+	};
+	auto blocked_angular = [&](const auto arec_, const bool post) {
+		for (int Q = 0; Q < nba; Q++)
+		{
+			const int m = lane & 31;
+			const int p = (Q & 1) ? 31 - m : m, row = 32 * Q + p;
+			const bool act = (lane >> 5) == (Q >> 1) && row < na;
+			auto *const R = arec_ + (act ? row : na) * AROW;      // the record behind the last row is all zeros
+			const float4 sv = *reinterpret_cast<const float4 *>(R + AR_S), gt = *reinterpret_cast<const float4 *>(R + AR_GAIN), ab = *reinterpret_cast<const float4 *>(R + AR_AXIS + 2), bt = *reinterpret_cast<const float4 *>(R + AR_BA + 2);
+			// gt = gain, torque, axis.x, axis.y;  ab = axis.z, gain after RemoveBias (the same: a frame with a row that differs takes the level schedule), ba0.x, ba0.y;  bt = ba0.z, ba1.xyz
+			const int bo = act ? (int)S.blk.abody[row] : 0xFFFF;
+			const int ba = (bo & 255) < HT_MAXNB ? (bo & 255) : IDLE_BODY, bb = (bo >> 8) < HT_MAXNB ? (bo >> 8) : IDLE_BODY;
+			const float4 La = S.ang4[ba], Lb = S.ang4[bb];
+			float w = ab.z * La.x; w = __fmaf_rn(ab.w, La.y, w); w = __fmaf_rn(bt.x, La.z, w);
+			w = __fmaf_rn(bt.y, Lb.x, w); w = __fmaf_rn(bt.z, Lb.y, w); w = __fmaf_rn(bt.w, Lb.z, w);      // spin1.axis - spin0.axis (physics.h:253-254): ba0 carries rb0's minus sign
+			float x = ((post ? sv.y : sv.x) - w) * gt.x;
+			const float lo = sv.z - gt.y, hi = sv.w - gt.y;
+			float imp = 0.0f;
+			const int nrows = na - 32 * Q;
+#define BLK_ACASE(QQ) case QQ: blk_resolve16<QQ, 0>(x, lo, hi, imp, GA); if (nrows > 16) blk_resolve16<QQ, 1>(x, lo, hi, imp, GA); break;
+			switch (Q) { BLK_ACASE(0) BLK_ACASE(1) BLK_ACASE(2) default: BLK_ACASE(3) }
+#undef BLK_ACASE
+			if (act) R[AR_TORQUE] = gt.y + imp;
+			// rb0: L -= axis d, rb1: L += axis d (physics.h:262-263)
+			const unsigned e = Q == 0 ? emA0 : Q == 1 ? emA1 : Q == 2 ? emA2 : emA3;
+			const int src = (int)(e & 63);
+			const float cf = (e & BLK_E_VALID) ? ((e & BLK_E_SIDE) ? 1.0f : -1.0f) : 0.0f;
+			const float tx = gt.z * imp, ty = gt.w * imp, tz = ab.x * imp;
+			float vx = blk_pull(src, tx) * cf, vy = blk_pull(src, ty) * cf, vz = blk_pull(src, tz) * cf;
+			const blk_scan_mul sm = blk_scan_multipliers(e);
+			blk_seg_scan3(vx, vy, vz, sm);
+			if (e & BLK_E_TAIL)
+			{
+				const int body = (int)(e >> 16);
+				float4 L = S.ang4[body];
+				L.x += vx; L.y += vy; L.z += vz;
+				S.ang4[body] = L;
+			}
+			__builtin_amdgcn_wave_barrier();
+		}
+	};
 	for (int sweep = 0; sweep < total_sweeps; sweep++)
 	{
 		const bool post = sweep >= ph.iterations;
@@ -1152,7 +1420,8 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		//     of a contact (normal, two friction rows) share their bodies and are applied back to back with the momenta in registers.  Pairs
 		//     without a group work on the idle group / idle body, so a step is branch-free.  Three-stage software pipeline: the sort entry is
 		//     fetched two steps ahead, the group's record one step ahead; only the momenta are read after the previous step's stores.
-		if (!HT_DBG(a.dbg, 2) && nlev_lin > 0)
+		if (blocked) { if (!HT_DBG(a.dbg, 2)) { if (pool_lds) blocked_linear(S.pool, post); else blocked_linear(gpool, post); } }
+		else if (!HT_DBG(a.dbg, 2) && nlev_lin > 0)
 		{
 			if (post) { if (pool_lds) linear_phase(S.pool, ht_true{}); else linear_phase(gpool, ht_true{}); }
 			else { if (pool_lds) linear_phase(S.pool, ht_false{}); else linear_phase(gpool, ht_false{}); }
@@ -1161,7 +1430,8 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		if (stats) { const long long t = clock64(); cyc_lin += t - t_mark; t_mark = t; }
 		// (3) angular rows (LimitAngular::Iter physics.h:251-265): one run of consecutive rows on the same body pair per lane pair and step,
 		//     same pipeline; inside a run the next row's record is read while the current row is applied
-		if (!HT_DBG(a.dbg, 4) && nlev_ang > 0)
+		if (blocked) { if (!HT_DBG(a.dbg, 4)) { if (arec_lds) blocked_angular(S.arec, post); else blocked_angular(garec, post); } }
+		else if (!HT_DBG(a.dbg, 4) && nlev_ang > 0)
 		{
 			if (post) { if (arec_lds) angular_phase(S.arec, ht_true{}); else angular_phase(garec, ht_true{}); }
 			else { if (arec_lds) angular_phase(S.arec, ht_false{}); else angular_phase(garec, ht_false{}); }
@@ -1214,6 +1484,7 @@ void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solv
 	// Up to four frames per CU (1024 on the 256 CUs) a launch gains nothing from the small build's footprint, so the build that keeps 49 contacts and
 	// 126 angular rows in LDS runs.  Not when other kernels share the GPU with this launch (the reset path): they need LDS on every CU too.
 	int build = a.force_build;
+	if (build == 7) { solve_args b = a; b.force_build = 0; b.two_body_levels = 1; ht_launch_solve(M, ph, b, B, s); return; }      // tests only: the two-body rows by the level schedule for every frame
 	if (!build) build = tile ? (B <= 1024 && !a.shared_gpu ? 2 : 1) : 3;
 	// the angular rows a frame of this launch can have at most (13 CNN-driven + 6 per joint + what the caller states on top: slowfit's relative rows, caller-built rows):
 	// beyond the 126 of the ordinary builds the build with four row slots per lane runs (252)

@@ -702,7 +702,7 @@ extern "C" int ht_debug_solve_stats(ht_ctx *ctx, int B, float *out, int reset)
 // pins the Jacobian-form arithmetic of the product's sweeps as the solver's only difference from the reference.  Far slower; never chosen by a launcher.
 extern "C" int ht_debug_solver_build(ht_ctx *ctx, int which)
 {
-	if (!ctx || which < 0 || which > 6) return HT_ERR_ARG;      // 6: the build with four angular-row slots per lane (up to 252 rows), otherwise chosen by the model's joint count
+	if (!ctx || which < 0 || which > 7) return HT_ERR_ARG;      // 6: the build with four angular-row slots per lane (up to 252 rows), otherwise chosen by the model's joint count; 7: the launcher's choice of build, with the two-body rows of EVERY frame taken by the level schedule (round 4's sweeps; otherwise only frames the blocked form of round 5 does not hold): another rounding of the same sweeps
 	if (which == 5 && !ctx->d_exact_lin)
 	{
 		ht_device_guard dev_guard_(ctx->device);
