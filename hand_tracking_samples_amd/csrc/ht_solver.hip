@@ -990,11 +990,14 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	// ---- two-body rows in blocks (ht_block.hpp), once per solve: every row's couplings to the rows before it in its block, and every block's edges sorted by body ----
 	float GL[32], GA[32];                                  // coupling registers of the linear and of the angular rows: lane m holds -k_j c_j . D_i of its forward row (block 2h, row m) with row i in register i < m, of its backward row (block 2h + 1, row 31 - m) with row i in register 31 - i > m
 	unsigned emL0 = 0, emL1 = 0, emL2 = 0, emL3 = 0, emA0 = 0, emA1 = 0, emA2 = 0, emA3 = 0;      // edge words of the blocks (ht_block.hpp)
+	unsigned lbod = 0xFFFFFFFFu, abod = 0xFFFFFFFFu;      // body pairs (rb0 | rb1 << 8, 255 = none) of this lane's linear / angular rows: forward block's row in the low half, backward block's in the high half
 #pragma unroll
 	for (int i = 0; i < 32; i++) { GL[i] = 0.0f; GA[i] = 0.0f; }
 	const int nbl = blocked ? (n2 + BLK_LROWS - 1) / BLK_LROWS : 0, nba = blocked ? (na + 31) >> 5 : 0;
+	long long t_c0 = 0, t_c1 = 0, t_c2 = 0;
 	if (blocked)
 	{
+		if (HT_DBG(a.dbg, 2048)) t_c0 = clock64();
 		const int m = lane & 31, hh = lane >> 5;
 		{
 			// angular rows: row r of the list sits in block r / 32; w_j = ba0_j . L(rb0) + ba1_j . L(rb1), a unit torque of row i adds -axis_i to L(rb0_i) and +axis_i to L(rb1_i)
@@ -1068,6 +1071,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				for (int rho = 2; rho < 32; rho++) { const float g = coupling(o, 2 * hh + 1, 31 - rho); if (rho > m) GL[rho] = g; }
 			}
 		}
+		if (HT_DBG(a.dbg, 2048)) t_c1 = clock64();
 		// edge words: a block's (row, side) pairs sorted by body, one per lane (ht_block.hpp)
 		auto edge_word = [&](bool valid, int ba, int bb) -> unsigned {
 			const int ka = (valid && ba < nb) ? ba : 255, kb = (valid && bb < nb) ? bb : 255;
@@ -1115,6 +1119,16 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			const int bo = on ? (int)S.blk.abody[row] : 0xFFFF;
 			return edge_word(on, bo & 255, bo >> 8);
 		};
+		{
+			auto lbodies = [&](int Q) -> unsigned {
+				const int p = (Q & 1) ? 31 - m : m, row = BLK_LROWS * Q + p;
+				const bool on = p < BLK_LROWS && row < n2;
+				return on ? ((unsigned)__float_as_int(pool[(row / 3) * LGRP + LG_META]) & 0xFFFFu) : 0xFFFFu;
+			};
+			auto abodies = [&](int Q) -> unsigned { const int row = 32 * Q + ((Q & 1) ? 31 - m : m); return row < na ? (unsigned)S.blk.abody[row] : 0xFFFFu; };
+			lbod = lbodies(2 * hh) | (lbodies(2 * hh + 1) << 16);
+			abod = abodies(2 * hh) | (abodies(2 * hh + 1) << 16);
+		}
 		if (nbl > 0) emL0 = lin_edges(0);
 		if (nbl > 1) emL1 = lin_edges(1);
 		if (nbl > 2) emL2 = lin_edges(2);
@@ -1124,12 +1138,14 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		if (nba > 2) emA2 = ang_edges(2);
 		if (nba > 3) emA3 = ang_edges(3);
 		__syncthreads();
+		if (HT_DBG(a.dbg, 2048)) t_c2 = clock64();
 	}
 
 	if (HT_DBG(a.dbg, 128)) return;
 	// ---- Gauss-Seidel sweeps ----
 	const bool stats = HT_DBG(a.dbg, 2048) != 0;          // timing experiments: per-frame cycle counts accumulated in the last scratch record
 	long long cyc_chain = 0, cyc_lin = 0, cyc_ang = 0, t_mark = stats ? clock64() : 0;
+	long long cyc_bh = 0, cyc_br = 0, cyc_bg = 0;      // blocked phases: head (loads, velocity terms), resolve, gather (impulses to the momenta)
 	const long long t_begin = t_mark;
 	const int total_sweeps = ph.iterations + ph.iterations_post;
 	const float inv_dt = 1.0f / dt;
@@ -1296,19 +1312,20 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 	auto blocked_linear = [&](const auto pool_, const bool post) {
 		for (int Q = 0; Q < nbl; Q++)
 		{
+			const long long tb0 = stats ? clock64() : 0;
 			const int m = lane & 31;
 			const int p = (Q & 1) ? 31 - m : m, row = BLK_LROWS * Q + p;
 			const bool act = (lane >> 5) == (Q >> 1) && p < BLK_LROWS && row < n2;
 			const int g = act ? row / 3 : ng2, k = act ? row - 3 * g : 0;
 			auto *const R = pool_ + g * LGRP;
 			const float4 sv = *reinterpret_cast<const float4 *>(R + LG_S + 4 * k);
-			const float4 qm = *reinterpret_cast<const float4 *>(R + LG_RINV), is = *reinterpret_cast<const float4 *>(R + LG_SUM);
-			const float rinv = k == 0 ? qm.x : k == 1 ? qm.y : qm.z, sum = k == 0 ? is.x : k == 1 ? is.y : is.z;
-			const int meta = __float_as_int(qm.w);
+			const float rinv = R[LG_RINV + k], sum = R[LG_SUM + k], fms = R[LG_SUM];
 			const v3 n = L3(R + LG_N + 3 * k);
 			const float4 o0 = *reinterpret_cast<const float4 *>(R + LG_GB + 12 * k), o1 = *reinterpret_cast<const float4 *>(R + LG_GB + 12 * k + 4), o2 = *reinterpret_cast<const float4 *>(R + LG_GB + 12 * k + 8);
 			const v3 g0 = V3(o0.x, o0.z, o1.x), b0 = V3(o0.y, o0.w, o1.y), g1 = V3(o1.z, o2.x, o2.z), b1 = V3(o1.w, o2.y, o2.w);
-			const int ba = (meta & 255) < HT_MAXNB ? (meta & 255) : IDLE_BODY, bb = ((meta >> 8) & 255) < HT_MAXNB ? ((meta >> 8) & 255) : IDLE_BODY;
+			const unsigned bo = act ? ((Q & 1) ? lbod >> 16 : lbod & 0xFFFFu) : 0xFFFFu;
+			const int ba = (bo & 255u) < HT_MAXNB ? (int)(bo & 255u) : IDLE_BODY, bb = (bo >> 8) < HT_MAXNB ? (int)(bo >> 8) : IDLE_BODY;
+			const bool contact = g >= njg && g < ng2;                  // the joints' triples come first (physmodel.h:350, physics.h:549-551)
 			const float4 Pa = S.lin4[ba], La = S.ang4[ba], Pb = S.lin4[bb], Lb = S.ang4[bb];
 			// vn = v1.n - v0.n (physics.h:296-297) against the momenta before the block
 			float w = b0.x * La.x; w = __fmaf_rn(b0.y, La.y, w); w = __fmaf_rn(b0.z, La.z, w);
@@ -1317,14 +1334,30 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			w = __fmaf_rn(n.x * na_, Pa.x, w); w = __fmaf_rn(n.y * na_, Pa.y, w); w = __fmaf_rn(n.z * na_, Pa.z, w);
 			w = __fmaf_rn(n.x * nb_, Pb.x, w); w = __fmaf_rn(n.y * nb_, Pb.y, w); w = __fmaf_rn(n.z * nb_, Pb.z, w);
 			float x = (-(post ? sv.y : sv.x) - w) * rinv;
-			const bool fric = act && k > 0 && (meta & LM_NORMAL);      // limited by the normal row's impulse sum (physics.h:292): set behind that row's step
+			const bool fric = act && k > 0 && contact;      // limited by the normal row's impulse sum (physics.h:292): set behind that row's step
 			float lo = fric ? 0.0f : sv.z - sum, hi = fric ? 0.0f : sv.w - sum;
 			const int mp = fric ? p - k : 255;
 			float imp = 0.0f;
 			const int nrows = n2 - BLK_LROWS * Q;
-#define BLK_LCASE(QQ) case QQ: blk_resolve15<QQ, 0>(x, lo, hi, imp, GL, is.x, sv.w, sum, mp, idt_bits, dt_bits); if (nrows > 15) blk_resolve15<QQ, 1>(x, lo, hi, imp, GL, is.x, sv.w, sum, mp, idt_bits, dt_bits); break;
+			long long tb1 = 0; if (stats) { asm volatile("" :: "v"(x), "v"(lo), "v"(hi)); tb1 = clock64(); }
+			// per half of the block: its triples, which of them are contacts; a half of five joint triples takes the plain statement
+			int cwl[2]; bool gen[2];
+#pragma unroll
+			for (int hf = 0; hf < 2; hf++)
+			{
+				const int g0_ = 10 * Q + 5 * hf;
+				int np = ng2 - g0_, fc = njg - g0_;                                  // triples the block has from here on, joints among them
+				np = np < 0 ? 0 : np > 5 ? 5 : np; fc = fc < 0 ? 0 : fc > 5 ? 5 : fc;
+				const int pres = (1 << np) - 1;
+				cwl[hf] = __builtin_amdgcn_readfirstlane((pres << 8) | (pres & ~((1 << fc) - 1)));
+				gen[hf] = __builtin_amdgcn_readfirstlane((int)(fc < 5 || np < 5)) != 0;
+			}
+#define BLK_LHALF(QQ, HF) if (gen[HF]) blk_resolve15<QQ, HF, true>(x, lo, hi, imp, GL, fms, sv.w, sum, mp, idt_bits, dt_bits, cwl[HF]); else blk_resolve15<QQ, HF, false>(x, lo, hi, imp, GL, fms, sv.w, sum, mp, idt_bits, dt_bits, 0);
+#define BLK_LCASE(QQ) case QQ: BLK_LHALF(QQ, 0) if (nrows > 15) { BLK_LHALF(QQ, 1) } break;
 			switch (Q) { BLK_LCASE(0) BLK_LCASE(1) BLK_LCASE(2) default: BLK_LCASE(3) }
+#undef BLK_LHALF
 #undef BLK_LCASE
+			long long tb2 = 0; if (stats) { asm volatile("" :: "v"(imp)); tb2 = clock64(); }
 			if (act) R[LG_SUM + k] = sum + imp;
 			// the momenta: -n d to P(rb0), g0 d to L(rb0), n d to P(rb1), g1 d to L(rb1) (ApplyImpulse physics.h:222-226), summed per body over the block's sorted edges
 			const unsigned e = Q == 0 ? emL0 : Q == 1 ? emL1 : Q == 2 ? emL2 : emL3;
@@ -1347,6 +1380,7 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 				S.lin4[body] = P; S.ang4[body] = L;
 			}
 			__builtin_amdgcn_wave_barrier();
+			if (stats) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long tb3 = clock64(); cyc_bh += tb1 - tb0; cyc_br += tb2 - tb1; cyc_bg += tb3 - tb2; }
 		}
 	};
 	auto blocked_angular = [&](const auto arec_, const bool post) {
@@ -1358,8 +1392,8 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			auto *const R = arec_ + (act ? row : na) * AROW;      // the record behind the last row is all zeros
 			const float4 sv = *reinterpret_cast<const float4 *>(R + AR_S), gt = *reinterpret_cast<const float4 *>(R + AR_GAIN), ab = *reinterpret_cast<const float4 *>(R + AR_AXIS + 2), bt = *reinterpret_cast<const float4 *>(R + AR_BA + 2);
 			// gt = gain, torque, axis.x, axis.y;  ab = axis.z, gain after RemoveBias (the same: a frame with a row that differs takes the level schedule), ba0.x, ba0.y;  bt = ba0.z, ba1.xyz
-			const int bo = act ? (int)S.blk.abody[row] : 0xFFFF;
-			const int ba = (bo & 255) < HT_MAXNB ? (bo & 255) : IDLE_BODY, bb = (bo >> 8) < HT_MAXNB ? (bo >> 8) : IDLE_BODY;
+			const unsigned bo = act ? ((Q & 1) ? abod >> 16 : abod & 0xFFFFu) : 0xFFFFu;
+			const int ba = (bo & 255u) < HT_MAXNB ? (int)(bo & 255u) : IDLE_BODY, bb = (bo >> 8) < HT_MAXNB ? (int)(bo >> 8) : IDLE_BODY;
 			const float4 La = S.ang4[ba], Lb = S.ang4[bb];
 			float w = ab.z * La.x; w = __fmaf_rn(ab.w, La.y, w); w = __fmaf_rn(bt.x, La.z, w);
 			w = __fmaf_rn(bt.y, Lb.x, w); w = __fmaf_rn(bt.z, Lb.y, w); w = __fmaf_rn(bt.w, Lb.z, w);      // spin1.axis - spin0.axis (physics.h:253-254): ba0 carries rb0's minus sign
@@ -1367,7 +1401,11 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 			const float lo = sv.z - gt.y, hi = sv.w - gt.y;
 			float imp = 0.0f;
 			const int nrows = na - 32 * Q;
-#define BLK_ACASE(QQ) case QQ: blk_resolve16<QQ, 0>(x, lo, hi, imp, GA); if (nrows > 16) blk_resolve16<QQ, 1>(x, lo, hi, imp, GA); break;
+			// a half with all sixteen rows takes the plain statement, the last one stops behind its rows (tested every four)
+			auto cw16 = [](int nr) -> int { return (nr > 4 ? 2 : 0) | (nr > 8 ? 4 : 0) | (nr > 12 ? 8 : 0); };
+			const int cwa0 = __builtin_amdgcn_readfirstlane(cw16(nrows)), cwa1 = __builtin_amdgcn_readfirstlane(cw16(nrows - 16));
+#define BLK_ACASE(QQ) case QQ: if (nrows >= 16) blk_resolve16<QQ, 0, false>(x, lo, hi, imp, GA, 0); else blk_resolve16<QQ, 0, true>(x, lo, hi, imp, GA, cwa0); \
+	if (nrows >= 32) blk_resolve16<QQ, 1, false>(x, lo, hi, imp, GA, 0); else if (nrows > 16) blk_resolve16<QQ, 1, true>(x, lo, hi, imp, GA, cwa1); break;
 			switch (Q) { BLK_ACASE(0) BLK_ACASE(1) BLK_ACASE(2) default: BLK_ACASE(3) }
 #undef BLK_ACASE
 			if (act) R[AR_TORQUE] = gt.y + imp;
@@ -1446,8 +1484,9 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		float *o = scr + (size_t)(a.scratch_stride - 1) * CREC;
 		int mc = 0; for (int k = 0; k < nb; k++) if (S.ccnt[k] > mc) mc = S.ccnt[k];
 		o[0] += 1.0f; o[1] += (float)cyc_chain; o[2] += (float)cyc_lin; o[3] += (float)cyc_ang; o[4] += (float)(clock64() - t_begin);
-		o[5] += (float)nlev_lin; o[6] += (float)nlev_ang; o[7] += (float)mc; o[8] += (float)n1; o[9] += (float)n2; o[10] += (float)na; o[11] += (float)(t_begin - t_entry);
+		o[5] += blocked ? (float)(t_c1 - t_c0) : (float)nlev_lin; o[6] += blocked ? (float)(t_c2 - t_c1) : (float)nlev_ang;      /* blocked frames: cycles of the couplings / of the edge words */ o[7] += (float)mc; o[8] += (float)n1; o[9] += (float)n2; o[10] += (float)na; o[11] += (float)(t_begin - t_entry);
 		o[12] += (float)(t_m1 - t_entry); o[13] += (float)(t_m2 - t_m1); o[14] += (float)(t_m2b - t_m2); o[15] += (float)(t_m3 - t_m2b);
+		if (HT_DBG(a.dbg, 32768)) { o[12] += (float)cyc_bh - (float)(t_m1 - t_entry); o[13] += (float)cyc_br - (float)(t_m2 - t_m1); o[14] += (float)cyc_bg - (float)(t_m2b - t_m2); }      /* HT_DEBUG_SKIP += 32768: the blocked linear phase's head / resolve / gather cycles instead of the first three prologue parts */
 	}
 	}      // !EXACT
 	// ---- rbupdatepose (physics.h:533-541), SanityCheck (physmodel.h:437-442), optional momentum reset (handtrack.h:686-687) ----
