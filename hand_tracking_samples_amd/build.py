@@ -20,7 +20,9 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fn
 # chain rows; same arithmetic, another order of independent instructions).  Measured per file; it slows the other kernels down.
 # -fno-slp-vectorize for the same file: packing the two multiplies of a cross product into v_pk_mul_f32 takes their DPP operands away (packed
 # instructions cannot carry one), which costs two v_mov_b32_dpp and register shuffles per row: 42.5 -> 38.75 issued instructions per chain row, 179 -> 112 VGPRs.
-FILE_FLAGS = {"ht_solver.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fno-slp-vectorize"]}
+# -Wno-pass-failed: k_solve is compiled for two waves per SIMD (the register budget of its eight-frames-per-CU build); the builds whose LDS footprint allows one wave per
+# SIMD anyway would each warn that the target was missed.
+FILE_FLAGS = {"ht_solver.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fno-slp-vectorize", "-Wno-pass-failed"]}
 if os.environ.get("HT_SOLVER_FLAGS") is not None:      # measurement builds: try other per-file flags for the solver
     FILE_FLAGS = dict(FILE_FLAGS, **{"ht_solver.hip": os.environ["HT_SOLVER_FLAGS"].split()})
 OBJDIR = os.path.join(HERE, "build_tuning" if os.environ.get("HT_TUNING") else "build")      # a measurement build keeps its objects apart from the product's

@@ -315,7 +315,7 @@ __device__ __forceinline__ int level_schedule(int n, int lane, const int (&b0)[2
 // update reproduces the restatement bit for bit, which isolates the Jacobian-form arithmetic as the solver's only difference from the reference.
 #define EX_LIN 512         // two-body linear rows a frame can have in the exact instantiation (a.exact_lin [B][EX_LIN][HT_ROW])
 template <int NGRP_, int NSUM_, int NANG_, int NIDX_, bool EXACT = false, int AS = 2>
-__global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph, solve_args a)
+__global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev ph, solve_args a)      // two waves per SIMD: the register budget (256 with the accumulator file) of eight frames per CU in the small build
 {
 	__shared__ lds_t<NGRP_, NSUM_, NANG_, NIDX_, AS> S;
 	constexpr int ASLOTS = AS, MAXA2 = MAXA2_OF(AS), MAXA_LDS = MAXA_CAP_OF(AS);
@@ -1000,85 +1000,115 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		if (HT_DBG(a.dbg, 2048)) t_c0 = clock64();
 		const int m = lane & 31, hh = lane >> 5;
 		{
-			// angular rows: row r of the list sits in block r / 32; w_j = ba0_j . L(rb0) + ba1_j . L(rb1), a unit torque of row i adds -axis_i to L(rb0_i) and +axis_i to L(rb1_i)
-			auto own = [&](int r, float &gain, v3 &b0, v3 &b1, int &a0, int &a1) {
-				const bool on = r < na;
-				const float *R = arec + (on ? r : na) * AROW;
-				gain = R[AR_GAIN]; b0 = L3(R + AR_BA); b1 = L3(R + AR_BA + 3);
-				const int bo = on ? (int)S.blk.abody[r] : 0xFFFF; a0 = bo & 255; a1 = bo >> 8;
+			auto lbodies = [&](int Q) -> unsigned {
+				const int p = (Q & 1) ? 31 - m : m, row = BLK_LROWS * Q + p;
+				const bool on = p < BLK_LROWS && row < n2;
+				return on ? ((unsigned)__float_as_int(pool[(row / 3) * LGRP + LG_META]) & 0xFFFFu) : 0xFFFFu;
 			};
-			auto coupling = [&](int rp, float gain, v3 b0, v3 b1, int a0, int a1) -> float {
-				const bool pon = rp < na;
-				const float *P = arec + (pon ? rp : na) * AROW;
-				const v3 ax = L3(P + AR_AXIS);
-				const int pb = pon ? (int)S.blk.abody[rp] : 0xFFFF; const int p0 = pb & 255, p1 = pb >> 8;
-				const float s0 = (float)((int)(a0 != 255 && a0 == p1) - (int)(a0 != 255 && a0 == p0));
-				const float s1 = (float)((int)(a1 != 255 && a1 == p1) - (int)(a1 != 255 && a1 == p0));
-				return -gain * (dot(b0, ax) * s0 + dot(b1, ax) * s1);
-			};
-			float gain; v3 b0, b1; int a0, a1;
-			own(64 * hh + m, gain, b0, b1, a0, a1);
-#pragma unroll
-			for (int rho = 0; rho < 32; rho++) { const float g = coupling(64 * hh + rho, gain, b0, b1, a0, a1); if (rho < m) GA[rho] = g; }
-			if (nba > 1)
-			{
-				own(64 * hh + 63 - m, gain, b0, b1, a0, a1);
-#pragma unroll
-				for (int rho = 0; rho < 32; rho++) { const float g = coupling(64 * hh + 63 - rho, gain, b0, b1, a0, a1); if (rho > m) GA[rho] = g; }
-			}
+			auto abodies = [&](int Q) -> unsigned { const int row = 32 * Q + ((Q & 1) ? 31 - m : m); return row < na ? (unsigned)S.blk.abody[row] : 0xFFFFu; };
+			lbod = lbodies(2 * hh) | (lbodies(2 * hh + 1) << 16);
+			abod = abodies(2 * hh) | (abodies(2 * hh + 1) << 16);
 		}
-		{
-			// linear rows: row r of the joint and contact triples sits in block r / 30; w_j = b0_j . L(rb0) - n_j minv0 . P(rb0) + b1_j . L(rb1) + n_j minv1 . P(rb1), a unit
-			// impulse of row i adds -n_i to P(rb0_i), g0_i to L(rb0_i), n_i to P(rb1_i), g1_i to L(rb1_i) (the sides' signs ride on g and b: the group record's layout)
-			auto lrow = [&](int blk, int pos, int &g, int &k) -> bool { const int row = BLK_LROWS * blk + pos; g = row / 3; k = row - 3 * g; return pos >= 0 && pos < BLK_LROWS && row < n2; };
-			struct lown { float rinv, ma, mb; v3 n, b0, b1; int a, b; };
-			auto own = [&](int blk, int pos) -> lown {
-				int g, k; const bool on = lrow(blk, pos, g, k);
-				if (!on) { g = ng2; k = 0; }
-				const float *R = pool + g * LGRP;
-				lown o; o.rinv = on ? R[LG_RINV + k] : 0.0f; o.n = L3(R + LG_N + 3 * k);
-				const float *og = R + LG_GB + 12 * k;
-				o.b0 = V3(og[1], og[3], og[5]); o.b1 = V3(og[7], og[9], og[11]);
-				const int meta = __float_as_int(R[LG_META]); o.a = meta & 255; o.b = (meta >> 8) & 255;
-				o.ma = S.lin4[o.a < HT_MAXNB ? o.a : IDLE_BODY].w; o.mb = S.lin4[o.b < HT_MAXNB ? o.b : IDLE_BODY].w;
-				return o;
-			};
-			auto coupling = [&](const lown &o, int blk, int pos) -> float {
-				int g, k; const bool pon = lrow(blk, pos, g, k);
-				if (!pon) { g = ng2; k = 0; }
-				const float *R = pool + g * LGRP;
-				const v3 pn = L3(R + LG_N + 3 * k);
-				const float *og = R + LG_GB + 12 * k;
-				const v3 g0 = V3(og[0], og[2], og[4]), g1 = V3(og[6], og[8], og[10]);
-				const int meta = __float_as_int(R[LG_META]); const int pa = meta & 255, pb = (meta >> 8) & 255;
-				const bool daa = o.a == pa, dab = o.a == pb, dba = o.b == pa, dbb = o.b == pb;
-				const v3 z = V3(0, 0, 0);
-				const v3 gs0 = daa ? g0 : dab ? g1 : z, gs1 = dba ? g0 : dbb ? g1 : z;
-				const float nn = dot(o.n, pn);
-				const float dw = (dot(o.b0, gs0) + dot(o.b1, gs1)) + nn * (o.ma * (float)((int)daa - (int)dab) + o.mb * (float)((int)dbb - (int)dba));
-				return -o.rinv * dw;
-			};
-			if (nbl > 0)
-			{
-				const lown o = own(2 * hh, m);
+		// Both loops go over the coupling registers rho = 0..31: a lane's forward row (position m of block 2h) takes register rho < m for the row at position rho, its backward
+		// row (position 31 - m of block 2h + 1) takes register rho > m for the row at position 31 - rho.  The partner's record is read by every lane of the half-wave (one address
+		// per half: a broadcast), eight (four) partners ahead of their use; nothing in the loop is conditional but the final select, so the reads overlap the arithmetic.
+		// Angular rows: row r of the list sits in block r / 32; w_j = ba0_j . L(rb0) + ba1_j . L(rb1), a unit torque of row i adds -axis_i to L(rb0_i) and +axis_i to L(rb1_i):
+		//   G(j,i) = -gain_j (ba0_j . axis_i ([rb0_j = rb1_i] - [rb0_j = rb0_i]) + ba1_j . axis_i ([rb1_j = rb1_i] - [rb1_j = rb0_i]))      (a missing body has ba = 0)
+		auto ang_couplings = [&](const auto arec_, const bool bwd) {
+			const int r = bwd ? 64 * hh + 63 - m : 64 * hh + m;
+			const float *R = arec_ + (r < na ? r : na) * AROW;
+			const float ng = -R[AR_GAIN];
+			const v3 b0 = L3(R + AR_BA) * ng, b1 = L3(R + AR_BA + 3) * ng;
+			const int bo = (int)S.blk.abody[r], a0 = bo & 255, a1 = bo >> 8;
 #pragma unroll
-				for (int rho = 0; rho < BLK_LROWS; rho++) { const float g = coupling(o, 2 * hh, rho); if (rho < m) GL[rho] = g; }
-			}
-			if (nbl > 1)
+			for (int c8 = 0; c8 < 32; c8 += 8)
 			{
-				const lown o = own(2 * hh + 1, 31 - m);
+				float ax[8], ay[8], az[8]; int pb[8];
 #pragma unroll
-				for (int rho = 2; rho < 32; rho++) { const float g = coupling(o, 2 * hh + 1, 31 - rho); if (rho > m) GL[rho] = g; }
+				for (int u = 0; u < 8; u++)
+				{
+					const int rp = bwd ? 64 * hh + 63 - (c8 + u) : 64 * hh + c8 + u;
+					const float *P = arec_ + (rp < na ? rp : na) * AROW + AR_AXIS;
+					ax[u] = P[0]; ay[u] = P[1]; az[u] = P[2]; pb[u] = (int)S.blk.abody[rp];
+				}
+#pragma unroll
+				for (int u = 0; u < 8; u++)
+				{
+					const int rho = c8 + u, p0 = pb[u] & 255, p1 = pb[u] >> 8;
+					const float t0 = (b0.x * ax[u] + b0.y * ay[u]) + b0.z * az[u], t1 = (b1.x * ax[u] + b1.y * ay[u]) + b1.z * az[u];
+					float g = (a0 == p1 ? t0 : a0 == p0 ? -t0 : 0.0f) + (a1 == p1 ? t1 : a1 == p0 ? -t1 : 0.0f);
+					asm volatile("" : "+v"(g));      // computed by every lane: the select below must not become a branch around the arithmetic (and its reads)
+					GA[rho] = (bwd ? rho > m : rho < m) ? g : GA[rho];
+				}
 			}
-		}
+		};
+		if (arec_lds) { ang_couplings(S.arec, false); if (nba > 1) ang_couplings(S.arec, true); }
+		else { ang_couplings(garec, false); if (nba > 1) ang_couplings(garec, true); }
+		// Linear rows: row r of the joint and contact triples sits in block r / 30; w_j = b0_j . L(rb0) - n_j minv0 . P(rb0) + b1_j . L(rb1) + n_j minv1 . P(rb1), a unit impulse
+		// of row i adds -n_i to P(rb0_i), g0_i to L(rb0_i), n_i to P(rb1_i), g1_i to L(rb1_i) (the sides' signs ride on g and b: the group record's layout):
+		//   G(j,i) = -rinv_j (b0_j . ([rb0_j = rb0_i] g0_i + [rb0_j = rb1_i] g1_i) + b1_j . ([rb1_j = rb0_i] g0_i + [rb1_j = rb1_i] g1_i)
+		//                     + n_j . n_i (minv0 ([rb0_j = rb0_i] - [rb0_j = rb1_i]) + minv1 ([rb1_j = rb1_i] - [rb1_j = rb0_i])))
+		auto lin_couplings = [&](const auto pool_, const bool bwd) {
+			const int blk = 2 * hh + (bwd ? 1 : 0), pos = bwd ? 31 - m : m, row = BLK_LROWS * blk + pos;
+			const bool on = pos < BLK_LROWS && row < n2;
+			const int g_ = on ? row / 3 : ng2, k_ = on ? row - 3 * g_ : 0;
+			const float *R = pool_ + g_ * LGRP;
+			const float nr = on ? -R[LG_RINV + k_] : 0.0f;
+			const v3 n = L3(R + LG_N + 3 * k_) * nr;
+			const float *og = R + LG_GB + 12 * k_;
+			const v3 b0 = V3(og[1], og[3], og[5]) * nr, b1 = V3(og[7], og[9], og[11]) * nr;
+			const unsigned bo = bwd ? lbod >> 16 : lbod & 0xFFFFu;
+			const int a0 = (int)(bo & 255u), a1 = (int)(bo >> 8);
+			const float ma = S.lin4[a0 < HT_MAXNB ? a0 : IDLE_BODY].w, mb = S.lin4[a1 < HT_MAXNB ? a1 : IDLE_BODY].w;
+#pragma unroll
+			for (int c4 = 0; c4 < 32; c4 += 4)
+			{
+				float pn[4][3], q0[4][3], q1[4][3]; int pb[4];
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+				{
+					const int ppos = bwd ? 31 - (c4 + u) : c4 + u, prow = BLK_LROWS * blk + ppos;       // static position: the group and the row within it are compile-time numbers but for the block
+					const bool pon = ppos >= 0 && ppos < BLK_LROWS && prow < n2;
+					const int pg = pon ? 10 * blk + ppos / 3 : ng2, pk = pon ? ppos % 3 : 0;
+					const float *P = pool_ + pg * LGRP;
+					const float *pgb = P + LG_GB + 12 * pk;
+					pn[u][0] = P[LG_N + 3 * pk]; pn[u][1] = P[LG_N + 3 * pk + 1]; pn[u][2] = P[LG_N + 3 * pk + 2];
+					q0[u][0] = pgb[0]; q0[u][1] = pgb[2]; q0[u][2] = pgb[4]; q1[u][0] = pgb[6]; q1[u][1] = pgb[8]; q1[u][2] = pgb[10];
+					pb[u] = __float_as_int(P[LG_META]);
+				}
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+				{
+					const int rho = c4 + u, p0 = pb[u] & 255, p1 = (pb[u] >> 8) & 255;
+					const bool daa = a0 == p0, dab = a0 == p1, dba = a1 == p0, dbb = a1 == p1;
+					const float t00 = (b0.x * q0[u][0] + b0.y * q0[u][1]) + b0.z * q0[u][2], t01 = (b0.x * q1[u][0] + b0.y * q1[u][1]) + b0.z * q1[u][2];
+					const float t10 = (b1.x * q0[u][0] + b1.y * q0[u][1]) + b1.z * q0[u][2], t11 = (b1.x * q1[u][0] + b1.y * q1[u][1]) + b1.z * q1[u][2];
+					const float nn = (n.x * pn[u][0] + n.y * pn[u][1]) + n.z * pn[u][2];
+					const float mm = (daa ? ma : dab ? -ma : 0.0f) + (dbb ? mb : dba ? -mb : 0.0f);
+					float g = ((daa ? t00 : dab ? t01 : 0.0f) + (dba ? t10 : dbb ? t11 : 0.0f)) + nn * mm;
+					asm volatile("" : "+v"(g));
+					GL[rho] = (bwd ? rho > m : rho < m) ? g : GL[rho];
+				}
+			}
+		};
+		if (pool_lds) { if (nbl > 0) lin_couplings(S.pool, false); if (nbl > 1) lin_couplings(S.pool, true); }
+		else { if (nbl > 0) lin_couplings(gpool, false); if (nbl > 1) lin_couplings(gpool, true); }
 		if (HT_DBG(a.dbg, 2048)) t_c1 = clock64();
 		// edge words: a block's (row, side) pairs sorted by body, one per lane (ht_block.hpp)
 		auto edge_word = [&](bool valid, int ba, int bb) -> unsigned {
 			const int ka = (valid && ba < nb) ? ba : 255, kb = (valid && bb < nb) ? bb : 255;
 			const unsigned long long lt = (1ull << lane) - 1ull;
 			int r0 = -1, r1 = -1, base = 0;
-			for (int k = 0; k < nb; k++)
+			// the bodies the block touches, in ascending order (a wave-wide OR of the lanes' body bits, then one round per set bit)
+			unsigned pm = (ka < 32 ? 1u << ka : 0u) | (kb < 32 ? 1u << kb : 0u);
+			pm |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)pm, 0x111, 0xF, 0xF, false); pm |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)pm, 0x112, 0xF, 0xF, false);
+			pm |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)pm, 0x114, 0xF, 0xF, false); pm |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)pm, 0x118, 0xF, 0xF, false);
+			pm |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)pm, 0x142, 0xA, 0xF, false); pm |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)pm, 0x143, 0xC, 0xF, false);
+			pm = (unsigned)__builtin_amdgcn_readlane((int)pm, 63);
+			while (pm)
 			{
+				const int k = __ffs((int)pm) - 1;
+				pm &= pm - 1u;
 				const unsigned long long m0 = __ballot(ka == k), m1 = __ballot(kb == k);
 				const int below = __popcll((m0 | m1) & lt);
 				if (ka == k) r0 = base + below;
@@ -1110,25 +1140,15 @@ __global__ __launch_bounds__(64) void k_solve(ht_model_dev M, ht_physics_dev ph,
 		auto lin_edges = [&](int Q) -> unsigned {
 			const int p = (Q & 1) ? 31 - m : m, row = BLK_LROWS * Q + p;
 			const bool on = hh == (Q >> 1) && p < BLK_LROWS && row < n2;
-			const int meta = __float_as_int(pool[(on ? row / 3 : ng2) * LGRP + LG_META]);
-			return edge_word(on, meta & 255, (meta >> 8) & 255);
+			const unsigned bo = (Q & 1) ? lbod >> 16 : lbod & 0xFFFFu;
+			return edge_word(on, (int)(bo & 255u), (int)(bo >> 8));
 		};
 		auto ang_edges = [&](int Q) -> unsigned {
 			const int p = (Q & 1) ? 31 - m : m, row = 32 * Q + p;
 			const bool on = hh == (Q >> 1) && row < na;
-			const int bo = on ? (int)S.blk.abody[row] : 0xFFFF;
-			return edge_word(on, bo & 255, bo >> 8);
+			const unsigned bo = (Q & 1) ? abod >> 16 : abod & 0xFFFFu;
+			return edge_word(on, (int)(bo & 255u), (int)(bo >> 8));
 		};
-		{
-			auto lbodies = [&](int Q) -> unsigned {
-				const int p = (Q & 1) ? 31 - m : m, row = BLK_LROWS * Q + p;
-				const bool on = p < BLK_LROWS && row < n2;
-				return on ? ((unsigned)__float_as_int(pool[(row / 3) * LGRP + LG_META]) & 0xFFFFu) : 0xFFFFu;
-			};
-			auto abodies = [&](int Q) -> unsigned { const int row = 32 * Q + ((Q & 1) ? 31 - m : m); return row < na ? (unsigned)S.blk.abody[row] : 0xFFFFu; };
-			lbod = lbodies(2 * hh) | (lbodies(2 * hh + 1) << 16);
-			abod = abodies(2 * hh) | (abodies(2 * hh + 1) << 16);
-		}
 		if (nbl > 0) emL0 = lin_edges(0);
 		if (nbl > 1) emL1 = lin_edges(1);
 		if (nbl > 2) emL2 = lin_edges(2);
