@@ -772,6 +772,8 @@ template <int GJK_WPF> __global__ __launch_bounds__(64 * GJK_FRAMES * GJK_WPF) v
 #define GJK_JMAX 40         // pairs per frame whose contact patch takes the four extra samples
 #define CO_NW 8             // waves per block
 #define CO_MAXF 4           // frames per block (as many as the LDS holds)
+#define CO_WORK_PATCH 2     // weight of a five-sample patch (four more runs on one pair) and of a polytope run in a frame's work estimate, in candidate pairs
+#define CO_WORK_EPA 12
 #define CO_OWN 4            // owner waves per round: 256 runs in flight
 #define CO_EPAQ 32          // polytope jobs per queue round
 struct gjk_sample { float n[3], p0[3], p1[3], sep; int key, flag; };      // key = candidate * 8 + sample number; flag 1 = counts as a contact
@@ -1053,8 +1055,12 @@ template <bool JIG> __device__ __forceinline__ void co_pass(const co_lds &L, int
 // batch are often alike (consecutive frames of one stream, a tiled test set) and a block's time goes with the runs of its heaviest frames, so a block takes
 // its frames from four far-apart places instead of four neighbours: the slowest block of a launch, which is the launch's time, comes closer to the mean.
 __device__ __forceinline__ int co_frame_of(int block, int f, int blocks) { return f * blocks + (block + 61 * f) % blocks; }
+// Round 5: when the frames' work of the same launch of the PREVIOUS update is known (k_contact_order below), slot f of a block is the table's entry instead: the
+// frames dealt heaviest first, back and forth over the blocks, so that the slowest block of a launch -- which is the launch's time -- comes down to the mean.
+// The assignment decides where a frame is computed, never what: contacts are the same bit for bit.
+__device__ __forceinline__ int co_frame_at(const int *__restrict__ order, int block, int f, int blocks) { return order ? order[f * blocks + block] : co_frame_of(block, f, blocks); }
 __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, const float *__restrict__ state, float driftmax, float jiggle_sin, const int *__restrict__ active_flag,
-                                                              float *__restrict__ contacts, int *__restrict__ ncontacts, int B, int nfr, int nvp, int dbg, int *__restrict__ caps)
+                                                              float *__restrict__ contacts, int *__restrict__ ncontacts, int B, int nfr, int nvp, int dbg, int *__restrict__ caps, const int *__restrict__ order, int *__restrict__ work_out)
 {
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	// LDS: padded vertices | block header | frames | scan list | answers | polytope jobs | polytope meshes
@@ -1071,7 +1077,7 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 	if (active_flag)      // a masked launch: blocks without a live frame leave at once (a handful of frames of a large batch take this kernel on their own)
 	{
 		bool any = false;
-		for (int f = 0; f < nfr; f++) { const int b = co_frame_of(blockIdx.x, f, gridDim.x); any = any || (b < B && active_flag[b] != 0); }
+		for (int f = 0; f < nfr; f++) { const int b = co_frame_at(order, blockIdx.x, f, gridDim.x); any = any || (b < B && active_flag[b] != 0); }
 		if (!any) return;
 	}
 	for (int k = t; k < nvp; k += 64 * CO_NW) g_sm[k] = M.cverts[k];      // the padded vertex image (ht_model_dev::cverts), 16 vertices per row
@@ -1087,7 +1093,7 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 	if (wave < nfr)
 	{
 		co_frame &F = L.F[wave];
-		const int b = co_frame_of(blockIdx.x, wave, gridDim.x);
+		const int b = co_frame_at(order, blockIdx.x, wave, gridDim.x);
 		const bool live = b < B && !(active_flag && !active_flag[b]);      // frames outside the active set keep whatever another launch produced for them
 		if (live && lane < M.nb)
 		{
@@ -1171,7 +1177,7 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 	if (wave < nfr)
 	{
 		co_frame &F = L.F[wave];
-		const int b = co_frame_of(blockIdx.x, wave, gridDim.x);
+		const int b = co_frame_at(order, blockIdx.x, wave, gridDim.x);
 		const bool live = b < B && !(active_flag && !active_flag[b]);
 		const int np = F.npool;
 		// a sample's place = how many counting samples have a smaller key.  The keys are laid out once as a dense array (a sample that does not count: the
@@ -1203,6 +1209,7 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 			}
 		}
 		if (live && lane == 0) { ncontacts[b] = total < HT_MAXCONTACT ? total : HT_MAXCONTACT; if (total > HT_MAXCONTACT && caps) atomicAdd(caps + 1, total - HT_MAXCONTACT); }
+		if (live && lane == 0 && work_out) work_out[b] = F.ncand + CO_WORK_PATCH * F.njig + CO_WORK_EPA * F.nepa;      // what the frame cost this launch, for the next update's assignment
 		if (HT_DBG(dbg, 2048) && live && lane == 0 && total < HT_MAXCONTACT - 2)      // timing experiments: per-frame statistics accumulate in the last two contact slots
 		{
 			float *o = contacts + ((size_t)b * HT_MAXCONTACT + HT_MAXCONTACT - 1) * HT_CONTACT;
@@ -1216,7 +1223,48 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 
 size_t ht_contacts_workspace_bytes(int B) { (void)B; return 16; }      // the polytope mesh lives in LDS; the workspace holds the capacity counters (polytope runs cut short, contacts dropped, k_solve's angular overflow)
 
-void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s, bool beside_cloud_rows, int force_kernel, int few_frames)
+// frames per block of the cooperative kernel for a batch of B frames (as many as the LDS holds beside the padded vertex copy, the scan list and the waves' polytope areas:
+// 4 for the 17-bone hand); 0 = the model does not fit it
+int ht_contacts_frames_per_block(const ht_model_dev &M, int B)
+{
+	const size_t fixed = (size_t)M.cvert_off[M.nb] * sizeof(float4) + sizeof(co_block) + (size_t)CO_OWN * 64 * 2 * (sizeof(co_req) + sizeof(int)) + CO_EPAQ * sizeof(co_job) + CO_NW * gjk_wave_stride();
+	if (fixed + sizeof(co_frame) > 160 * 1024) return 0;
+	int nfr = CO_MAXF;
+	while (nfr > 1 && fixed + nfr * sizeof(co_frame) > 160 * 1024) nfr--;
+	return B < nfr ? B : nfr;
+}
+// The frames of a launch sorted by the work they took in the same launch of the previous update (heaviest first; ties by frame index) and dealt back and forth over
+// the blocks: order[slot * blocks + block] = frame, B = no frame.  One block per launch slot of an update (work / order: [slots][stride]); the ranks by counting, the
+// works in LDS.  Runs beside the CNN at the head of an update: off every critical path.
+__global__ __launch_bounds__(1024) void k_contact_order(const int *__restrict__ work, int *__restrict__ order, int B, int nfr, int stride, unsigned slots)
+{
+	extern __shared__ int ko_w[];
+	if (!((slots >> blockIdx.x) & 1u)) return;
+	const int *w = work + (size_t)blockIdx.x * stride;
+	int *o = order + (size_t)blockIdx.x * stride;
+	const int blocks = (B + nfr - 1) / nfr, B4 = (B + 3) & ~3;
+	for (int i = threadIdx.x; i < B4; i += 1024) ko_w[i] = i < B ? w[i] : -1;
+	for (int i = threadIdx.x; i < blocks * nfr; i += 1024) o[i] = B;
+	__syncthreads();
+	for (int i = threadIdx.x; i < B; i += 1024)
+	{
+		const int wi = ko_w[i];
+		int rank = 0;
+		for (int j = 0; j < B4; j += 4)
+		{
+			const int4 k = *reinterpret_cast<const int4 *>(ko_w + j);
+			rank += ((k.x > wi || (k.x == wi && j < i)) ? 1 : 0) + ((k.y > wi || (k.y == wi && j + 1 < i)) ? 1 : 0) + ((k.z > wi || (k.z == wi && j + 2 < i)) ? 1 : 0) + ((k.w > wi || (k.w == wi && j + 3 < i)) ? 1 : 0);
+		}
+		const int round = rank / blocks, pos = rank - round * blocks;
+		o[round * blocks + ((round & 1) ? blocks - 1 - pos : pos)] = i;
+	}
+}
+void ht_launch_contact_order(const int *work, int *order, int B, int nfr, int stride, unsigned slots, int nslots, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_contact_order, dim3(nslots), dim3(1024), (size_t)((B + 3) & ~3) * sizeof(int), s, work, order, B, nfr, stride, slots);
+}
+void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s, bool beside_cloud_rows, int force_kernel, int few_frames,
+                        const int *order, int *work_out)
 {
 	int *caps = reinterpret_cast<int *>(epa_ws);
 	const int dbg = ht_tuning_flags();
@@ -1256,7 +1304,7 @@ void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftma
 		while (nfr > 1 && fixed + nfr * sizeof(co_frame) > 160 * 1024) nfr--;
 		if (B < nfr) nfr = B;
 		const size_t smem = fixed + nfr * sizeof(co_frame);
-		hipLaunchKernelGGL(k_contacts_coop, dim3((B + nfr - 1) / nfr), dim3(64 * CO_NW), smem, s, M, state, driftmax, jiggle_sin, active_flag, contacts, ncontacts, B, nfr, nvp, dbg, caps);
+		hipLaunchKernelGGL(k_contacts_coop, dim3((B + nfr - 1) / nfr), dim3(64 * CO_NW), smem, s, M, state, driftmax, jiggle_sin, active_flag, contacts, ncontacts, B, nfr, nvp, dbg, caps, nfr == ht_contacts_frames_per_block(M, B) ? order : nullptr, work_out);
 		return;
 	}
 	const int wpf = M.nb * (M.nb - 1) / 2 > 200 ? 2 : 1;

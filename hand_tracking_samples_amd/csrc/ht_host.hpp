@@ -59,6 +59,8 @@ struct ht_ctx
 	float *d_chamber = nullptr; int *d_nchamber = nullptr;      // [B][5*nb][HT_ROW]
 	int *d_accepted = nullptr;
 	float *d_contacts = nullptr; int *d_ncontacts = nullptr;    // [B][HT_MAXCONTACT][HT_CONTACT]
+	int *d_cwork = nullptr, *d_corder = nullptr;                  // [HT_CONTACT_SLOTS][cstride]: what every frame cost in every contact launch of the latest update; the assignment of frames to blocks made from it for the current one (ht_gjk.hip: k_contact_order)
+	int cstride = 0, cwork_B = 0; unsigned cwork_mask = 0, corder_mask = 0;      // slots whose work the latest update wrote (for cwork_B frames) / whose order the current update may use
 	unsigned char *d_epa_ws = nullptr;                           // expanding-polytope workspace, one per (frame, wave)
 	float *d_scratch = nullptr;                                  // solver row records [B][pts_cap + 5*nb + 32][20] (ht_quad.hpp)
 	float *d_poses_out = nullptr, *d_start = nullptr;

@@ -47,7 +47,11 @@ struct ht_fit_after
 };
 void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, int w, int h, float scale, float *err, int B, hipStream_t s, const ht_fit_after *after = nullptr);
 void ht_launch_chamber(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, int min_point_num, int enabled, float maxforce, float *rows, int *nch, int B, hipStream_t s);
-void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s, bool beside_cloud_rows = false, int force_kernel = 0, int few_frames = 0);
+void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s, bool beside_cloud_rows = false, int force_kernel = 0, int few_frames = 0,
+                        const int *order = nullptr, int *work_out = nullptr);      // order / work_out (cooperative kernel only, both may be null): the frame of every (slot, block) as k_contact_order dealt them; where every live frame leaves what it cost
+int ht_contacts_frames_per_block(const ht_model_dev &M, int B);
+#define HT_CONTACT_SLOTS 16      // unmasked contact launches of an update that keep a work history: MultiStepSim step st -> slot st (< 8), main-thread pass i -> slot 8 + i
+void ht_launch_contact_order(const int *work, int *order, int B, int nfr, int stride, unsigned slots, int nslots, hipStream_t s);
 size_t ht_contacts_workspace_bytes(int B);
 void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solve_args &a, int B, hipStream_t s);
 void ht_launch_set_pose(float *state, const float *src, int nb, int n, int mode, hipStream_t s);

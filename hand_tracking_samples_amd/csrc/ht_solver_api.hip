@@ -74,6 +74,29 @@ static void marks_dump()
 static inline void mark(const char *, hipStream_t) {}
 static inline void marks_dump() {}
 #endif
+// Contact launches of an update that keep a work history (ht_launch.hpp: HT_CONTACT_SLOTS).  slot < 0 or a launch on the reset frames alone: no history, the fixed assignment.
+struct contact_slot { const int *order; int *work; };
+static contact_slot contact_history(ht_ctx *ctx, int slot, const int *active, int B)
+{
+	contact_slot c = { nullptr, nullptr };
+	if (slot < 0 || slot >= HT_CONTACT_SLOTS || !ctx->d_cwork || active == ctx->d_flags || B != ctx->cwork_B) return c;
+	c.work = ctx->d_cwork + (size_t)slot * ctx->cstride;
+	ctx->cwork_mask |= 1u << slot;
+	if ((ctx->corder_mask >> slot) & 1u) c.order = ctx->d_corder + (size_t)slot * ctx->cstride;
+	return c;
+}
+// At the head of an update, on a stream that has nothing to do while the net runs: the assignments of this update's contact launches from the works of the last one
+static void contact_orders(ht_ctx *ctx, int B, hipStream_t t)
+{
+	const int nfr = ht_contacts_frames_per_block(ctx->model, B);
+	ctx->corder_mask = 0;
+	if (ctx->d_cwork && ctx->cwork_B == B && ctx->cwork_mask && nfr > 1 && B <= 4096 && B + 8 <= ctx->cstride && ctx->contact_kernel != 2)
+	{
+		ht_launch_contact_order(ctx->d_cwork, ctx->d_corder, B, nfr, ctx->cstride, ctx->cwork_mask, HT_CONTACT_SLOTS, t);
+		ctx->corder_mask = ctx->cwork_mask;
+	}
+	ctx->cwork_mask = 0; ctx->cwork_B = B;
+}
 static void fork(ht_ctx *ctx, hipStream_t s) { (void)hipEventRecord(ctx->ev_fork, s); for (int i = 0; i < 2; i++) (void)hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0); }
 static void fork1(ht_ctx *ctx, hipStream_t s, int i) { (void)hipEventRecord(ctx->ev_fork, s); (void)hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0); }
 static void join1(ht_ctx *ctx, hipStream_t s, int i) { (void)hipEventRecord(ctx->ev_join[i], ctx->side[i]); (void)hipStreamWaitEvent(s, ctx->ev_join[i], 0); }
@@ -100,7 +123,7 @@ static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int 
 			if (par) fork1(ctx, s, side);
 			const cloud_records cr = cloud_rec(ctx);
 			if (cloud) { ht_prof_scope ps(ctx, prof ? "cloud_rows" : nullptr, s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, active, 4, 1, 2, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[side] : s, 0.0f, 0.0f, rec_or_rows(ctx, &cr)); }
-			if (coll && !(first_contacts_done && st == from_step)) { ht_prof_scope ps(ctx, prof ? "contacts" : nullptr, s, true); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, active, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, false, ctx->contact_kernel, active && active == ctx->d_flags && !ctx->many_reset); }
+			if (coll && !(first_contacts_done && st == from_step)) { ht_prof_scope ps(ctx, prof ? "contacts" : nullptr, s, true); const contact_slot ch = contact_history(ctx, st < 8 ? st : -1, active, B); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, active, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, false, ctx->contact_kernel, active && active == ctx->d_flags && !ctx->many_reset, ch.order, ch.work); }
 			if (par) join1(ctx, s, side);
 			if (part == 0 && !active) mark("  step: rows done", s);
 		}
@@ -110,7 +133,7 @@ static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int 
 	}
 }
 // one main-thread pass of HandTracker::update (handtrack.h:769-780)
-static void main_pass(ht_ctx *ctx, int B, hipStream_t s, float *poses_out = nullptr)      // poses_out: the update's last pass also writes the user poses
+static void main_pass(ht_ctx *ctx, int B, hipStream_t s, float *poses_out = nullptr, int pass = -1)      // poses_out: the update's last pass also writes the user poses
 {
 	const ht_params &p = ctx->par;
 	const float4 *pts = p.subsample_voxel ? ctx->d_ptsv : ctx->d_pts;      // handtrack.h:751: the main-thread cloud
@@ -122,7 +145,7 @@ static void main_pass(ht_ctx *ctx, int B, hipStream_t s, float *poses_out = null
 	{ ht_prof_scope ps(ctx, "chamber", s, true); ht_launch_chamber(ctx->model, ctx->d_state[0], pts, npts, p.min_point_num, p.boundary_planes, 10.0f, ctx->d_chamber, ctx->d_nchamber, B, par ? ctx->side[1] : s); }
 	const cloud_records cr = cloud_rec(ctx);
 	{ ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[0], pts, npts, ctx->d_cams, nullptr, 1, 0, 1, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[0] : s, 0.0f, 0.0f, rec_or_rows(ctx, &cr)); }
-	if (coll) { ht_prof_scope ps(ctx, "contacts", s, true); ht_launch_contacts(ctx->model, ctx->d_state[0], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, par, ctx->contact_kernel); }
+	if (coll) { ht_prof_scope ps(ctx, "contacts", s, true); const contact_slot ch = contact_history(ctx, pass >= 0 && pass < 8 ? 8 + pass : -1, nullptr, B); ht_launch_contacts(ctx->model, ctx->d_state[0], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, par, ctx->contact_kernel, 0, ch.order, ch.work); }
 	mark("  pass: contacts done", s);
 	if (par) { mark("  pass: cloud rows done", ctx->side[0]); mark("  pass: chamber done", ctx->side[1]); }
 	if (par) join(ctx, s, 2);
@@ -220,11 +243,13 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		// owns whole CUs and the FC layers want one block per CU: beside each other they took 0.78 ms, one after the other 0.46.)
 		hipStream_t t = ctx->side[1];
 		fork(ctx, s);
+		contact_orders(ctx, B, t);
 		if (mode == UPD_FULL && !(d_start && !fs)) ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, t);     // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757 (both were just seeded with the same pose otherwise)
 		ht_fit_after dec; memset(&dec, 0, sizeof dec);
 		dec.mode = 1; dec.reset_thr = p.full_reset_on_error; dec.angles_only = p.angles_only; dec.flags = ctx->d_flags; dec.nflags = ctx->d_nflags; dec.list = ctx->d_flist; dec.nlist = ctx->d_nflist; dec.nreset = ctx->d_nreset;
 		ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_old, B, t, &dec);      // with the reset decision (handtrack.h:706)
 	}
+	if (!overlap) contact_orders(ctx, B, s);
 	{
 		ht_prof_scope ps(ctx, (fs && fs->direct) ? "cnn128" : "cnn", s, true);
 		if (fs && fs->direct) ht_launch_cnn(ctx->cnnw128, ctx->d_in128, ctx->d_act1_128, ctx->d_act2_128, ctx->d_act3, ctx->d_logits, B, s, fs->direct, overlap);
@@ -324,7 +349,7 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 	if (mode != UPD_FULL) { ht_launch_output(ctx->model, ctx->d_state[1], ctx->d_npts, ctx->d_initializing, p.min_point_num, d_poses_out, B, s, 1); reset_tail_join(ctx, s); return HT_OK; }      // othermodel.GetPose()
 	const int passes = p.angles_only ? 0 : p.mainthreadpasses;
 	mark("accept done", s);
-	for (int i = 0; i < passes; i++) { main_pass(ctx, B, s, i + 1 == passes ? d_poses_out : nullptr); mark("pass done", s); }      // the last pass's solve writes the poses
+	for (int i = 0; i < passes; i++) { main_pass(ctx, B, s, i + 1 == passes ? d_poses_out : nullptr, i); mark("pass done", s); }      // the last pass's solve writes the poses
 	if (passes < 1) ht_launch_output(ctx->model, ctx->d_state[0], p.subsample_voxel ? ctx->d_nptsv : ctx->d_npts, ctx->d_initializing, p.min_point_num, d_poses_out, B, s);
 	reset_tail_join(ctx, s);
 	mark("update done", s);
