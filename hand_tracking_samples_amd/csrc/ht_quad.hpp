@@ -109,10 +109,10 @@ __device__ __forceinline__ float quad_row_step(quad_body &B, const float4 a, con
 // Applies rows [0, cnt) of one chain in order.  The records of a frame lie where their producers wrote them (a cloud row's record at its point's index:
 // k_cloud_rows writes it; the other single-body rows behind them: k_solve's prologue), and a chain is a list of record indices: recs = the frame's first
 // record, idx = the chain's first index (LDS u16 or HBM u32), sums = the chain's first impulse sum, c = lane within the quad, post = 1 after RemoveBias.
-// Sixteen register sets rotate: the read of a record is issued sixteen rows ahead of its use (a row is ~95 clocks and the records stream from L2, the
-// Infinity Cache or HBM: 200 / 550 / 900 clocks away), its index is read another sixteen rows earlier, its impulse sum eight rows ahead (LDS; a wave keeps
-// at most 15 LDS operations in flight).  The loop trips of the quads of a wave differ, the compiler masks finished quads off.
-// Reads run up to 47 indices, 31 records (of valid indices) and 23 sums past the chain's end: the caller's arrays have that slack, zero-filled.
+// Eight register sets rotate: the read of a record is issued eight rows ahead of its use (a row is ~95 clocks and the records stream from L2, the
+// Infinity Cache or HBM: 200 / 550 / 900 clocks away), its index is read another eight rows earlier, its impulse sum four rows ahead (LDS).  The loop trips of
+// the quads of a wave differ, the compiler masks finished quads off.
+// Reads run up to 23 indices, 15 records (of valid indices) and 11 sums past the chain's end: the caller's arrays have more slack than that, zero-filled.
 #define QUAD_CHAIN_SLACK 48
 // A quad can walk TWO bodies' chains back to back (k_solve, models with more than 16 bodies: the 17th body's rows follow the host body's, which are
 // padded to a multiple of 8 with rows that change nothing): at row `kswitch` (a multiple of 8, or < 0 for none) the momenta go back to body `bodyA`'s
@@ -126,44 +126,40 @@ template <bool POST, class IDX>
 __device__ __forceinline__ void quad_chain_run_(quad_body &B, const float *recs, const IDX *idx, float *sums, int cnt, int c,
                                                 int kswitch, float *lin_w, float *ang_w, int bodyA, int bodyB)
 {
+	// Round 5: EIGHT register sets (the record of a row is asked for eight rows ahead of its use, its index another eight rows earlier, its impulse sum four rows ahead).
+	// Sixteen sets had measured no faster than eight when they were introduced (dead end (b)); the 48 registers they held are what lets the blocked
+	// two-body phases keep their couplings in registers at two waves per SIMD.  Reads run up to 23 indices, 15 records (of valid indices) and 11 sums past the chain's end.
 	const float4 *pa = reinterpret_cast<const float4 *>(recs) + c;
 	const IDX *px = idx;
 	float *ps = sums;
-	// first reads in the order the loop consumes them (the wait counts the compiler derives for the loop are the minimum over both entries)
 #define QC_LX(i, row) x##i = (unsigned)px[row]; __builtin_amdgcn_sched_barrier(0)
 #define QC_LA(i) a##i = pa[4 * x##i]; __builtin_amdgcn_sched_barrier(0)
 #define QC_LS(i, row) s##i = ps[row]; __builtin_amdgcn_sched_barrier(0)
-	float4 a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14, a15; float s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15;
-	unsigned x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11, x12, x13, x14, x15;
+	float4 a0, a1, a2, a3, a4, a5, a6, a7; float s0, s1, s2, s3, s4, s5, s6, s7;
+	unsigned x0, x1, x2, x3, x4, x5, x6, x7;
 	QC_LX(0, 0); QC_LX(1, 1); QC_LX(2, 2); QC_LX(3, 3); QC_LX(4, 4); QC_LX(5, 5); QC_LX(6, 6); QC_LX(7, 7);
-	QC_LX(8, 8); QC_LX(9, 9); QC_LX(10, 10); QC_LX(11, 11); QC_LX(12, 12); QC_LX(13, 13); QC_LX(14, 14); QC_LX(15, 15);
-	QC_LA(0); QC_LA(1); QC_LA(2); QC_LA(3); QC_LA(4); QC_LA(5); QC_LA(6); QC_LA(7); QC_LA(8); QC_LA(9); QC_LA(10); QC_LA(11); QC_LA(12); QC_LA(13); QC_LA(14); QC_LA(15);
-	QC_LX(0, 16); QC_LX(1, 17); QC_LX(2, 18); QC_LX(3, 19); QC_LX(4, 20); QC_LX(5, 21); QC_LX(6, 22); QC_LX(7, 23);
-	QC_LX(8, 24); QC_LX(9, 25); QC_LX(10, 26); QC_LX(11, 27); QC_LX(12, 28); QC_LX(13, 29); QC_LX(14, 30); QC_LX(15, 31);
-	QC_LS(0, 0); QC_LS(1, 1); QC_LS(2, 2); QC_LS(3, 3); QC_LS(4, 4); QC_LS(5, 5); QC_LS(6, 6); QC_LS(7, 7);
+	QC_LA(0); QC_LA(1); QC_LA(2); QC_LA(3); QC_LA(4); QC_LA(5); QC_LA(6); QC_LA(7);
+	QC_LX(0, 8); QC_LX(1, 9); QC_LX(2, 10); QC_LX(3, 11); QC_LX(4, 12); QC_LX(5, 13); QC_LX(6, 14); QC_LX(7, 15);
+	QC_LS(0, 0); QC_LS(1, 1); QC_LS(2, 2); QC_LS(3, 3);
 	int k = 0;
 	// The scheduling barriers keep every row's instructions between its own pair: left alone, the ILP-first scheduler hoists the first use of the
 	// record that was requested last to the top of the trip as a hazard filler, which turns the wait for it into a wait for every outstanding
 	// read (s_waitcnt vmcnt(0)), i.e. one full memory round trip per trip.
 #define QC_STEP(i) ps[i] = quad_row_step<POST>(B, a##i, s##i)
-	// row i of the trip: apply it, then ask for the record sixteen rows on (same register set; its index came in during the last trip), the index
-	// thirty-two rows on and the impulse sum eight rows on (set i + 8)
-#define QC_ROW(i, j) QC_STEP(i); QC_LA(i); QC_LX(i, 32 + i); QC_LS(j, 8 + i)
-	for (; k + 16 <= cnt; k += 16)
+	// row i of the trip: apply it, then ask for the record eight rows on (same register set; its index came in during the last trip), the index
+	// sixteen rows on and the impulse sum four rows on (set i + 4)
+#define QC_ROW(i, j) QC_STEP(i); QC_LA(i); QC_LX(i, 16 + i); QC_LS(j, 4 + i)
+	for (; k + 8 <= cnt; k += 8)
 	{
 		if (k == kswitch) quad_switch_body(B, c, lin_w, ang_w, bodyA, bodyB);
-		QC_ROW(0, 8); QC_ROW(1, 9); QC_ROW(2, 10); QC_ROW(3, 11); QC_ROW(4, 12); QC_ROW(5, 13); QC_ROW(6, 14); QC_ROW(7, 15);
-		if (k + 8 == kswitch) quad_switch_body(B, c, lin_w, ang_w, bodyA, bodyB);
-		QC_ROW(8, 0); QC_ROW(9, 1); QC_ROW(10, 2); QC_ROW(11, 3); QC_ROW(12, 4); QC_ROW(13, 5); QC_ROW(14, 6); QC_ROW(15, 7);
-		px += 16; ps += 16;
+		QC_ROW(0, 4); QC_ROW(1, 5); QC_ROW(2, 6); QC_ROW(3, 7); QC_ROW(4, 0); QC_ROW(5, 1); QC_ROW(6, 2); QC_ROW(7, 3);
+		px += 8; ps += 8;
 	}
 	if (k == kswitch) quad_switch_body(B, c, lin_w, ang_w, bodyA, bodyB);
-	const int left = cnt - k;      // 0..15 rows: their records are in the register sets, the sums of the first eight too
+	const int left = cnt - k;      // 0..7 rows: their records are in the register sets, the sums of the first four too
 #define QC_TAIL(i) if (left > i) { QC_STEP(i); } __builtin_amdgcn_sched_barrier(0)
-#define QC_TAIL_S(i, j) if (left > i) { QC_STEP(i); QC_LS(j, 8 + i); } __builtin_amdgcn_sched_barrier(0)
-	QC_TAIL_S(0, 8); QC_TAIL_S(1, 9); QC_TAIL_S(2, 10); QC_TAIL_S(3, 11); QC_TAIL_S(4, 12); QC_TAIL_S(5, 13); QC_TAIL_S(6, 14); QC_TAIL_S(7, 15);
-	if (left > 8 && k + 8 == kswitch) quad_switch_body(B, c, lin_w, ang_w, bodyA, bodyB);
-	QC_TAIL(8); QC_TAIL(9); QC_TAIL(10); QC_TAIL(11); QC_TAIL(12); QC_TAIL(13); QC_TAIL(14);
+#define QC_TAIL_S(i, j) if (left > i) { QC_STEP(i); QC_LS(j, 4 + i); } __builtin_amdgcn_sched_barrier(0)
+	QC_TAIL_S(0, 4); QC_TAIL_S(1, 5); QC_TAIL_S(2, 6); QC_TAIL(3); QC_TAIL(4); QC_TAIL(5); QC_TAIL(6);
 #undef QC_LX
 #undef QC_LA
 #undef QC_LS
