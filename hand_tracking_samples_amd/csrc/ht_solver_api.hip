@@ -24,11 +24,11 @@ static int dev_alloc_points(ht_ctx *ctx)      // the second cloud of a context t
 }
 static cloud_records cloud_rec(ht_ctx *ctx) { cloud_records r = { ctx->d_scratch, scratch_stride(ctx), ctx->d_rowbody, ctx->phys.deltaT }; return r; }
 // the exact-order instantiation of the solver (ht_debug_solver_build 5, tests only) takes the cloud rows in the reference's layout (ctx->d_rows) instead of records
-static bool exact_solver(const ht_ctx *ctx) { return ctx->solver_build == 5; }
+static bool exact_solver(const ht_ctx *ctx) { return ctx->solver_build == 5 || ctx->solver_build == 8; }      // 8: the same sweeps with the product's forked launch sequence (5 takes the kernels in order on one stream)
 static const cloud_records *rec_or_rows(const ht_ctx *ctx, const cloud_records *cr) { return exact_solver(ctx) ? nullptr : cr; }
 static void exact_args(ht_ctx *ctx, solve_args &a, bool cloud)
 {
-	a.force_build = ctx->solver_build;
+	a.force_build = exact_solver(ctx) ? 5 : ctx->solver_build;
 	a.exact_lin = ctx->d_exact_lin; a.exact_ang = ctx->d_exact_ang;
 	if (exact_solver(ctx) && cloud) { a.rows_cloud = ctx->d_rows; a.cloud_body = nullptr; }
 }
@@ -235,7 +235,7 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 	}
 	float *cnn_out = d_cnn_out ? d_cnn_out : ctx->d_cnn_out;
 	static const bool no_overlap = ht_tuning_env("HT_NO_OVERLAP");      // timing experiments (-DHT_TUNING builds only)
-	const bool overlap = !no_overlap && !ctx->profile_phases && p.steps >= 1 && p.steps_cloudstart >= 1 && !p.angles_only && !exact_solver(ctx);
+	const bool overlap = !no_overlap && !ctx->profile_phases && p.steps >= 1 && p.steps_cloudstart >= 1 && !p.angles_only && ctx->solver_build != 5;
 	if (overlap)
 	{
 		// Nothing on this side branch needs the CNN: the error of the carried pose and the reset decision only read the point cloud and the
@@ -727,8 +727,8 @@ extern "C" int ht_debug_solve_stats(ht_ctx *ctx, int B, float *out, int reset)
 // pins the Jacobian-form arithmetic of the product's sweeps as the solver's only difference from the reference.  Far slower; never chosen by a launcher.
 extern "C" int ht_debug_solver_build(ht_ctx *ctx, int which)
 {
-	if (!ctx || which < 0 || which > 7) return HT_ERR_ARG;      // 6: the build with four angular-row slots per lane (up to 252 rows), otherwise chosen by the model's joint count; 7: the launcher's choice of build, with the two-body rows of EVERY frame taken by the level schedule (round 4's sweeps; otherwise only frames the blocked form of round 5 does not hold): another rounding of the same sweeps
-	if (which == 5 && !ctx->d_exact_lin)
+	if (!ctx || which < 0 || which > 8) return HT_ERR_ARG;      // 6: the build with four angular-row slots per lane (up to 252 rows), otherwise chosen by the model's joint count; 7: the launcher's choice of build, with the two-body rows of EVERY frame taken by the level schedule (round 4's sweeps; otherwise only frames the blocked form of round 5 does not hold): another rounding of the same sweeps
+	if ((which == 5 || which == 8) && !ctx->d_exact_lin)
 	{
 		ht_device_guard dev_guard_(ctx->device);
 		void *a = nullptr, *b = nullptr;
@@ -744,6 +744,15 @@ extern "C" int ht_debug_reset_organisation(ht_ctx *ctx, int *many)
 {
 	if (!ctx || !many) return HT_ERR_ARG;
 	*many = ctx->last_reset_many;
+	return HT_OK;
+}
+// Tests only: which frames of the latest update took the full-reset branch (handtrack.h:706-711): flags[i] = 1 for tracker slot i (the decision kernel's own array)
+extern "C" int ht_debug_reset_flags(ht_ctx *ctx, int *flags, int n)
+{
+	if (!ctx || !flags || n < 0 || n > ctx->B) return HT_ERR_ARG;
+	ht_device_guard dev_guard_(ctx->device);
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	HIPCHK(ctx, hipMemcpy(flags, ctx->d_flags, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
 	return HT_OK;
 }
 // Tests only: pins the organisation of the contact kernel (0 = the launcher's choice; 1 cooperative, 2 lane-per-pair).  Same arithmetic, same contacts in the same order.

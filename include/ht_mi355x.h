@@ -316,8 +316,10 @@ int ht_debug_contact_stats(ht_ctx *ctx, int B, float *out, int reset);      /* s
 /* Test aid: pins which build of the solver kernel runs (0 = chosen per launch; 1-3 the LDS sizes for tile batches / small batches / large frames and models;
  * 4 = a build whose LDS arrays hold nothing, so every frame places its row records in HBM; 6 = the build with four angular-row slots per lane that models with more
  * than 18 joints take).  Placement only: results are identical bit for bit.  7 = the launcher's choice, with the two-body rows of every frame applied through the level
- * schedule (the sweeps of round 4) instead of block by block (csrc/ht_block.hpp): the same rows in the same order, another rounding. */
+ * schedule (the sweeps of round 4) instead of block by block (csrc/ht_block.hpp): the same rows in the same order, another rounding.  8 = the exact-order sweeps of 5 under
+ * the product's forked launch sequence (5 runs an update's kernels in order on one stream). */
 int ht_debug_solver_build(ht_ctx *ctx, int which);
+int ht_debug_reset_flags(ht_ctx *ctx, int *flags, int n);      /* test aid: flags[i] = 1 if tracker slot i took the full-reset branch (handtrack.h:706-711) in the latest update */
 /* Test aid: 5 additionally selects the EXACT-ORDER instantiation of the solver -- the same rows swept by the reference's own LimitLinear::Iter / LimitAngular::Iter
  * (physics.h:251-265, 289-307) in the reference's row order, no fused multiply-adds (update entry points only; tests/test_gpu_exact_solver.py).
  * ht_debug_reset_organisation: how the latest update launched the full-reset branch (0 few frames, 1 many frames, -1 none yet). */

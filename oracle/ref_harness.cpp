@@ -1100,10 +1100,12 @@ static int mode_bench(const char *framesfn, uint64_t seed, double gain, int reps
 // The unit of work on every frame of a frames file, results only: user-space poses of handmodel, othermodel's state after the CNN job and the
 // accept decision.  Built with other compiler flags (HT_REF_FLAGS of tools/ref_flag_spread.sh) it measures how far the REFERENCE moves between its
 // own builds (IEEE / FMA-contracted / the Makefile's -Ofast) on the very frames the bench uses.
-static int mode_poses(const char *framesfn, uint64_t seed, double gain, const char *outfn)
+// `take_cnn`: the application's switch of the same name (synthetic-tracker.cpp:91,127,240): every frame's CNN-driven pose is accepted (handtrack.h:720-722), so the
+// user pose depends on the net, its decode and MultiStepSim on every frame (without it the accept branch fires on ~3 % of these frames)
+static int mode_poses(const char *framesfn, uint64_t seed, double gain, const char *outfn, int take_cnn = 0)
 {
 	HandTracker htk;
-	htk.microforce = 3.0f; htk.mainthreadpasses = 3; htk.always_take_cnn = 0;
+	htk.microforce = 3.0f; htk.mainthreadpasses = 3; htk.always_take_cnn = take_cnn;
 	load_weights(htk, seed, gain);
 	auto arrs = htfx_read(framesfn);
 	const Arr *ad = NULL, *ac = NULL, *as = NULL;
@@ -1295,6 +1297,7 @@ int main(int argc, char **argv) try
 	if (mode == "dataset_read" && a.size() == 3) return mode_dataset_read(a[0].c_str(), atoi(a[1].c_str()), a[2].c_str());
 	if (mode == "dataset_header" && a.size() == 4) return mode_dataset_header(a[0].c_str(), a[1].c_str(), atoi(a[2].c_str()), a[3].c_str());
 	if (mode == "poses" && a.size() == 4) return mode_poses(a[0].c_str(), strtoull(a[1].c_str(), 0, 0), atof(a[2].c_str()), a[3].c_str());
+	if (mode == "poses" && a.size() == 5 && a[4] == "takecnn") return mode_poses(a[0].c_str(), strtoull(a[1].c_str(), 0, 0), atof(a[2].c_str()), a[3].c_str(), 1);
 	if (mode == "viz" && a.size() == 3) return mode_viz(a[0].c_str(), atoi(a[1].c_str()), a[2].c_str());
 	if (mode == "posesfull" && a.size() == 4) return mode_posesfull(a[0].c_str(), strtoull(a[1].c_str(), 0, 0), atof(a[2].c_str()), a[3].c_str());
 	if (mode == "bench" && a.size() >= 4) return mode_bench(a[0].c_str(), strtoull(a[1].c_str(), 0, 0), atof(a[2].c_str()), atoi(a[3].c_str()), a.size() > 4 ? atoi(a[4].c_str()) : 0);

@@ -6,7 +6,11 @@ Makefile:22-28) -- runs the whole unit of work on the 1024 bench frames (tests/g
 pose differences against the IEEE build.  This is the yardstick for the floating-point tolerance of the device path: the device solver evaluates
 the reference's row updates in Jacobian form with fused multiply-adds (csrc/ht_quad.hpp), i.e. it is one more "build" of the same algorithm.
 
-    python tests/golden/ref_flag_spread.py [out.json [per_frame.npz]]
+    python tests/golden/ref_flag_spread.py [out.json [per_frame.npz [takecnn]]]
+
+With `takecnn` the unit of work runs with always_take_cnn = 1 (every CNN-driven pose accepted: the user pose then depends on the net and MultiStepSim on every frame);
+the per-frame file is committed as tests/golden/ref_spread1024_takecnn.npz and held against tests/golden/poses1024_takecnn.htfx.
+The FMA builds are compiled for -march=x86-64-v3 (a fixed target: the yardstick does not depend on the host that regenerates it).
 
 per_frame.npz (committed as tests/golden/ref_spread1024.npz): for every one of the 1024 bench frames how far the reference's two FMA-contracted builds move
 from its IEEE build (|dpos|, |dquat| of the user poses and of othermodel) -- a frame's SENSITIVITY to rounding, which tests/test_gpu_batch_parity.py holds the
@@ -29,8 +33,8 @@ sys.path.insert(0, ROOT)
 import htfx  # noqa: E402
 
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-BUILDS = {"ieee": ["-O2", "-ffp-contract=off"], "fma_on": ["-O2", "-march=native", "-ffp-contract=on"], "fma_fast": ["-O2", "-march=native", "-ffp-contract=fast"],
-          "Ofast (reference Makefile default)": ["-Ofast", "-march=native"]}
+BUILDS = {"ieee": ["-O2", "-ffp-contract=off"], "fma_on": ["-O2", "-march=x86-64-v3", "-ffp-contract=on"], "fma_fast": ["-O2", "-march=x86-64-v3", "-ffp-contract=fast"],
+          "Ofast (reference Makefile default)": ["-Ofast", "-march=x86-64-v3"]}
 
 
 def spread(a, b):
@@ -46,6 +50,7 @@ def main():
     if not os.path.isdir("/root/reference/include"):
         sys.exit("reference tree not present: this measurement runs in the build container only")
     out = {}
+    take = len(sys.argv) > 3 and sys.argv[3] == "takecnn"
     with tempfile.TemporaryDirectory() as td:
         d = np.load(os.path.join(HERE, "frames1024.npz"))
         frames = os.path.join(td, "frames1024.htfx")
@@ -55,10 +60,10 @@ def main():
             exe = os.path.join(td, "ref_%d" % len(res))
             subprocess.check_call([CLANG, "-std=c++14"] + flags + ["-Wno-narrowing", "-fdelayed-template-parsing", "-w", "-I" + os.path.join(ROOT, "oracle"),
                                    os.path.join(ROOT, "oracle", "ref_harness.cpp"), "-o", exe, "-lpthread"])
-            subprocess.check_call([exe, "poses", frames, "0x5EED0001", "24", exe + ".htfx"])
+            subprocess.check_call([exe, "poses", frames, "0x5EED0001", "24", exe + ".htfx"] + (["takecnn"] if take else []))
             res[name] = htfx.load(exe + ".htfx")
-        committed = htfx.load(os.path.join(HERE, "poses1024.htfx"))
-        assert np.array_equal(committed["uw_pose_user"], res["ieee"]["uw_pose_user"]), "tests/golden/poses1024.htfx is not what the IEEE build produces"
+        committed = htfx.load(os.path.join(HERE, "poses1024_takecnn.htfx" if take else "poses1024.htfx"))
+        assert np.array_equal(committed["uw_pose_user"], res["ieee"]["uw_pose_user"]), "the committed poses fixture is not what the IEEE build produces"
         per_frame = {}
         for name in list(BUILDS)[1:]:
             out[name] = {"handmodel_user_pose": spread(res["ieee"]["uw_pose_user"], res[name]["uw_pose_user"]), "othermodel_pose": spread(res["ieee"]["other_pose"], res[name]["other_pose"])}

@@ -62,10 +62,11 @@ def test_exact_order_solver_reproduces_the_restatement_bit_for_bit_on_all_1024_f
         ctx.set_params(microforce=3.0, mainthreadpasses=3)
         ctx.debug_solver_build(5)
         ctx.tracker_reset(FR["startpose"])
-        cnn = []; poses = []; others = []; hands = []; flags = []
+        cnn = []; poses = []; others = []; hands = []; flags = []; resets = []
         for u in range(2):      # two consecutive updates: the second carries momenta, prev_frame_error and `initializing`
             p, c = ctx.update_sync(FR["depth"].reshape(N, -1), FR["cam"], want_cnn=True)
             poses.append(p); cnn.append(c); others.append(ctx.get_state(1, N)); hands.append(ctx.get_state(0, N)); flags.append(np.stack(ctx.tracker_flags(N), 1).astype(np.float32))
+            resets.append(ctx.debug_reset_flags(N))
         assert ctx.capacity_events() == (0, 0, 0)
     finally:
         ctx.close()
@@ -77,8 +78,37 @@ def test_exact_order_solver_reproduces_the_restatement_bit_for_bit_on_all_1024_f
         print("update %d, exact-order solver against the restatement given the device's CNN output: %d / %d / %d of %d frames differ (othermodel / handmodel / user poses)" % (u, len(bad_other), len(bad_hand), len(bad_user), N))
         assert not bad_other and not bad_hand and not bad_user, (u, bad_other[:8], bad_hand[:8], bad_user[:8])
         assert np.array_equal(flags[u], fl[u])
-    # the reset branch (UnibodyFit's single-body solves) was among them
-    assert (REF["flags"][:, 0] == 0).any()
+    # the full-reset branch (PoseFromScratch + UnibodyFit's single-body solves, handtrack.h:706-711) was among them: the device's own decision flags
+    print("frames through the full-reset branch: first update %s, second update %s" % (np.nonzero(resets[0])[0].tolist(), np.nonzero(resets[1])[0].tolist()))
+    assert resets[0].sum() >= 4
+
+
+def test_exact_order_solver_under_the_products_launch_sequence(weights):
+    """ht_debug_solver_build 5 takes an update's kernels in order on one stream; 8 keeps the PRODUCT's choreography (the carried pose's FitError and the reset decision
+    beside the net, the reset frames' chain lapped with the batch's first two steps, rows phases forked over three streams) around the same exact-order sweeps: the two must
+    agree bit for bit on every frame, i.e. the stream choreography changes no result."""
+    from hand_tracking_samples_amd import native
+    ctx = native.Context(ol.MODEL, N)
+    res = {}
+    try:
+        ctx.load_weights(weights)
+        ctx.set_params(microforce=3.0, mainthreadpasses=3)
+        for build in (5, 8):
+            ctx.debug_solver_build(build)
+            ctx.tracker_reset(FR["startpose"])
+            out = []
+            for u in range(2):
+                p = ctx.update_sync(FR["depth"].reshape(N, -1), FR["cam"])
+                out.append((p, ctx.get_state(1, N), ctx.get_state(0, N), np.stack(ctx.tracker_flags(N), 1), ctx.debug_reset_flags(N)))
+            res[build] = out
+        assert ctx.capacity_events() == (0, 0, 0)
+    finally:
+        ctx.debug_solver_build(0)
+        ctx.close()
+    for u in range(2):
+        for a, b in zip(res[5][u], res[8][u]):
+            assert np.array_equal(a, b), "update %d" % u
+    assert res[8][0][4].sum() >= 4      # reset frames took the lapped chain
 
 
 def test_exact_order_solver_on_config5_end_to_end_26_bones():

@@ -297,3 +297,51 @@ def test_unit_of_work_on_all_1024_bench_frames(weights):
             bad.append(k)
     orc.close()
     assert not bad, "frames on which the restatement differs from the reference: %s" % bad[:16]
+
+
+def test_unit_of_work_always_take_cnn(weights):
+    """The application's always_take_cnn switch (synthetic-tracker.cpp:91; handtrack.h:720-722): the restatement against `ref_harness poses ... takecnn` on every fourth of
+    the 1024 bench frames (tests/golden/poses1024_takecnn.htfx): user poses, othermodel and flags bit for bit.  Every frame takes the accept branch here."""
+    import os
+    d = np.load(os.path.join(ol.GOLDEN, "frames1024.npz"))
+    ref = htfx.load(os.path.join(ol.GOLDEN, "poses1024_takecnn.htfx"))
+    plain = htfx.load(os.path.join(ol.GOLDEN, "poses1024.htfx"))
+    assert not np.array_equal(ref["uw_pose_user"], plain["uw_pose_user"])      # the switch matters
+    orc = ol.Oracle(weights)
+    orc.head.par.microforce = 3.0; orc.head.par.mainthreadpasses = 3; orc.head.par.always_take_cnn = 1
+    user = np.zeros((17, 7), np.float32)
+    for k in range(0, 1024, 4):
+        orc.reset(d["startpose"][k])
+        cam = ol.camera(d["cam"][k])
+        orc.L.ho_update(orc.h, ol.u16ptr(np.ascontiguousarray(d["depth"][k].reshape(-1))), C.byref(cam), ol.fptr(user))
+        assert np.array_equal(user, ref["uw_pose_user"][k]), "frame %d: user pose" % k
+        assert np.array_equal(orc.get_state(1)[:, :7], ref["other_pose"][k]), "frame %d: othermodel" % k
+        e, i, n = orc.flags()
+        assert (np.float32(e), i, n) == (ref["flags"][k, 0], int(ref["flags"][k, 1]), int(ref["flags"][k, 2])), "frame %d: flags" % k
+    orc.close()
+
+
+def test_the_rounding_mode_of_the_exact_order_comparison_moves_frames_at_rounding_level_only(weights):
+    """tests/test_gpu_exact_solver.py runs the restatement with ho_set_round_once(1): its three float libm calls (sinf / cosf / acosf in quat_axis_angle, ConstrainAngularDrive,
+    ConstrainConeAngle) rounded once from double, as the device forms them -- NOT the pinned mode (glibc's float functions, as the reference calls them).  How many frames the
+    two modes differ on, and by how much: every eighth of the 1024 bench frames."""
+    import os
+    d = np.load(os.path.join(ol.GOLDEN, "frames1024.npz"))
+    ref = htfx.load(os.path.join(ol.GOLDEN, "poses1024.htfx"))
+    orc = ol.Oracle(weights)
+    orc.head.par.microforce = 3.0; orc.head.par.mainthreadpasses = 3
+    user = np.zeros((17, 7), np.float32)
+    idx = list(range(0, 1024, 8)); differ = 0; dmax = 0.0; dmed = []
+    try:
+        orc.L.ho_set_round_once(1)
+        for k in idx:
+            orc.reset(d["startpose"][k])
+            cam = ol.camera(d["cam"][k])
+            orc.L.ho_update(orc.h, ol.u16ptr(np.ascontiguousarray(d["depth"][k].reshape(-1))), C.byref(cam), ol.fptr(user))
+            dd = float(np.abs(user - ref["uw_pose_user"][k]).max())
+            differ += dd != 0.0; dmax = max(dmax, dd); dmed.append(dd)
+    finally:
+        orc.L.ho_set_round_once(0)
+        orc.close()
+    print("round-once libm against the pinned mode: %d of %d frames differ, median |d| %.1e, max %.1e" % (differ, len(idx), float(np.median(dmed)), dmax))
+    assert np.median(dmed) <= 2e-6 and dmax <= 5e-3

@@ -37,6 +37,10 @@ $H poses $T/frames256.htfx $SEED $GAIN $T/poses256.htfx
 # the bench's batch: 1024 DISTINCT frames, rows (3 + 9 i) mod 2336 (the first 256 are the set above), and the reference's results for all of them
 $H frames $BANK 3 9 1024 $T/frames1024.htfx
 $H poses $T/frames1024.htfx $SEED $GAIN $T/poses1024.htfx
+# the same with the application's always_take_cnn switch (synthetic-tracker.cpp:91): every frame's user pose then depends on the net, its decode and MultiStepSim
+$H poses $T/frames1024.htfx $SEED $GAIN $T/poses1024_takecnn.htfx takecnn
+# what the application draws (synthetic-tracker.cpp:191,204-209): DepthMesh and the heat-map label images of animation-bank row 144
+$H viz $BANK 144 $T/viz1.htfx
 # the optional voxel sub-sampling of the main-thread cloud (handtrack.h:535-536): 1 cm voxels, min_point_num 20
 $H voxel $BANK 0,912,2224,1504 $SEED $GAIN 0.01 20 $T/voxel4.htfx
 # on-disk dataset formats (dataset.h): a three-frame set written by the reference's DepthDataStreamOut, what its load_dataset returns for it, and the
@@ -76,7 +80,7 @@ $H cnn128 $T/frames5.htfx 0,9,33,60 $SEED $GAIN $T/cnn128.htfx
 HT_REF_MODEL_JSON=$T/model_hand26.json $H e2e128 $T/frames5.htfx 0,9,33,60 $SEED $GAIN $T/e2e128.htfx
 
 rc=0
-for f in model_hand17 model_hand26 model_chain3 golden8 poses256 poses1024 poses5full voxel4 scale115 slowfit3 train3 fullframe320 fullframe320close fullframe5 config5 cnn128 e2e128; do
+for f in model_hand17 model_hand26 model_chain3 golden8 poses256 poses1024 poses1024_takecnn poses5full voxel4 scale115 slowfit3 train3 fullframe320 fullframe320close fullframe5 config5 cnn128 e2e128; do
 	if cmp -s $T/$f.htfx $G/$f.htfx; then echo "identical  $f.htfx"; else echo "DIFFERENT  $f.htfx"; rc=1; fi
 	[ $WRITE = 1 ] && cp $T/$f.htfx $G/$f.htfx
 done
@@ -104,11 +108,30 @@ g = htfx.load(T + "/frames5.htfx"); f5 = {k: g[k] for k in ("depth", "cam", "sta
 same("frames5_64.npz", f5, dict(np.load(G + "/frames5_64.npz")))
 s = htfx.load(T + "/seg.htfx"); seg = {k.replace("/", "__"): v for k, v in s.items()}
 same("segment6.npz", seg, dict(np.load(G + "/segment6.npz")))
+v = htfx.load(T + "/viz1.htfx"); viz = {k: (a.astype(np.uint8) if k.endswith("_labels") else a) for k, a in v.items()}      # the label images travel as 16-bit words in the container
+same("viz1.npz", viz, dict(np.load(G + "/viz1.npz")))
 if write:
     np.savez_compressed(G + "/frames256.npz", **f256)
     np.savez_compressed(G + "/frames1024.npz", **f1024)
     np.savez_compressed(G + "/frames5_64.npz", **f5)
     np.savez_compressed(G + "/segment6.npz", **seg)
+    np.savez_compressed(G + "/viz1.npz", **viz)
+sys.exit(1 if bad else 0)
+PY
+# the tolerance yardsticks: how far the reference moves between its own IEEE and FMA-contracted builds on every bench frame (tests/golden/ref_flag_spread.py compiles the
+# harness four ways for the fixed target x86-64-v3 and runs the 1024 frames with each: a few minutes), without and with always_take_cnn
+python3 tests/golden/ref_flag_spread.py $T/spread.json $T/ref_spread1024.npz > /dev/null
+python3 tests/golden/ref_flag_spread.py $T/spread_take.json $T/ref_spread1024_takecnn.npz takecnn > /dev/null
+python3 - "$T" "$G" "$WRITE" <<'PY' || rc=1
+import sys, shutil, numpy as np
+T, G, write = sys.argv[1], sys.argv[2], sys.argv[3] == "1"
+bad = 0
+for f in ("ref_spread1024.npz", "ref_spread1024_takecnn.npz"):
+    a, b = dict(np.load(T + "/" + f)), dict(np.load(G + "/" + f))
+    ok = set(a) == set(b) and all(np.array_equal(a[k], b[k]) for k in a)
+    print(("identical  " if ok else "DIFFERENT  ") + f + " (array by array)")
+    bad += not ok
+    if write: shutil.copy(T + "/" + f, G + "/" + f)
 sys.exit(1 if bad else 0)
 PY
 rm -rf "$T"
