@@ -361,6 +361,8 @@ extern "C" int ht_destroy(ht_ctx *ctx)
 	for (int i = 0; i < 2; i++) { if (ctx->side[i]) (void)hipStreamDestroy(ctx->side[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
 	if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
 	if (ctx->ev_lap) (void)hipEventDestroy(ctx->ev_lap);
+	if (ctx->ev_job) (void)hipEventDestroy(ctx->ev_job);
+	if (ctx->h_job_in) (void)hipHostFree(ctx->h_job_in);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 	return HT_OK;

@@ -179,10 +179,12 @@ struct frame_src { int w, h; float segment_scale; int direct; };
 // `mode`: UPD_FULL = HandTracker::update (handtrack.h:748-785); UPD_CNN_MODEL = update_cnn_model alone (:734-741): othermodel is NOT re-seeded from
 // handmodel, no main-thread passes, no "initializing = 50" rule, the result is othermodel.GetPose() plus the accept decision, handmodel untouched;
 // UPD_KICKSTART = kickstart (:743-746) = the same followed by handmodel.SetPose(pose) where the pose was accepted.
-enum { UPD_FULL = 0, UPD_CNN_MODEL = 1, UPD_KICKSTART = 2 };
+// UPD_PASSES = only the caller's part of update() (:751-753, 769-785): the cloud of the frame, the main-thread passes on handmodel, the user poses (the overlapped mode, ht_update_passes_sync)
+enum { UPD_FULL = 0, UPD_CNN_MODEL = 1, UPD_KICKSTART = 2, UPD_PASSES = 3 };
 static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, const float *d_start, int B, float *d_poses_out, float *d_cnn_out, hipStream_t s, const frame_src *fs = nullptr, int mode = UPD_FULL)
 {
-	if (fs && fs->direct) { if (!ctx->have_weights128) { ctx->err = "weights of the 128x128 net not loaded (ht_cnn_load_weights_sized)"; return HT_ERR_STATE; } }
+	if (mode == UPD_PASSES) {}      // no net in the caller's part
+	else if (fs && fs->direct) { if (!ctx->have_weights128) { ctx->err = "weights of the 128x128 net not loaded (ht_cnn_load_weights_sized)"; return HT_ERR_STATE; } }
 	else if (!ctx->have_weights) { ctx->err = "CNN weights not loaded (ht_cnn_load_weights)"; return HT_ERR_STATE; }
 	const ht_params &p = ctx->par;
 	const int nb = ctx->model.nb;
@@ -201,7 +203,7 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 		HIPCHK(ctx, hipMemcpyAsync(ctx->d_frame_cams, d_cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyDeviceToDevice, s));
 		HIPCHK(ctx, hipMemsetAsync(ctx->d_overflow, 0, sizeof(int), s));
 		if (fs->direct) { if (d_cams != ctx->d_cams) HIPCHK(ctx, hipMemcpyAsync(ctx->d_cams, d_cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyDeviceToDevice, s)); }      // segment.cam = the frame's camera
-		else ht_launch_segment(d_depth, ctx->d_frame_cams, fs->w, fs->h, 0xF, p.drangey, fs->segment_scale, ctx->d_seg_tiles, ctx->d_cams, B, s);
+		else if (mode != UPD_PASSES) ht_launch_segment(d_depth, ctx->d_frame_cams, fs->w, fs->h, 0xF, p.drangey, fs->segment_scale, ctx->d_seg_tiles, ctx->d_cams, B, s);
 		img_cams = ctx->d_frame_cams;
 	}
 	// 64x64 tiles: the camera copy and the re-seeding of the trackers ride on k_prepare (below); full-size frames keep their own small kernels
@@ -232,6 +234,13 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 			else ht_launch_prepare(d_depth, ctx->d_cams, p.drangey, 1, nullptr, all, ctx->d_nrows, ctx->model.pts_cap, B, s);
 			ht_launch_voxel(all, ctx->d_nrows, ctx->model.pts_cap, p.subsample_size, p.subsample_fraction, ctx->d_ptsv, ctx->d_nptsv, B, s);
 		}
+	}
+	if (mode == UPD_PASSES)
+	{
+		const int passes = p.angles_only ? 0 : p.mainthreadpasses;
+		for (int i = 0; i < passes; i++) main_pass(ctx, B, s, i + 1 == passes ? d_poses_out : nullptr, i);
+		if (passes < 1) ht_launch_output(ctx->model, ctx->d_state[0], p.subsample_voxel ? ctx->d_nptsv : ctx->d_npts, ctx->d_initializing, p.min_point_num, d_poses_out, B, s);
+		return HT_OK;
 	}
 	float *cnn_out = d_cnn_out ? d_cnn_out : ctx->d_cnn_out;
 	static const bool no_overlap = ht_tuning_env("HT_NO_OVERLAP");      // timing experiments (-DHT_TUNING builds only)
@@ -583,6 +592,131 @@ extern "C" int ht_update_cnn_model_sync(ht_ctx *ctx, const uint16_t *depth, cons
 	HIPCHK(ctx, hipGetLastError());
 	if (accepted_out) for (int b = 0; b < B; b++) accepted_out[b] = accepted_out[b] != 0;
 	if (!tile) { int over = 0; HIPCHK(ctx, hipMemcpy(&over, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost)); if (over) { ctx->err = "ht_update_cnn_model: frame(s) with more in-range points than the solver's capacity"; return HT_ERR_ARG; } }
+	return HT_OK;
+}
+// ---- the reference's OVERLAPPED update() (handtrack.h:748-785) on two contexts of one device ----------------------------------------------------------------
+// The reference runs the CNN job (update_cnn_model_threadsafe: net, decode, FitError, reset, MultiStepSim, accept decision) on a background thread and lets the caller go
+// on with the main-thread passes; the job's pose is taken over by a later call, when the job is through (:760-768).  Here the job runs on a second context `job` (its own
+// streams, buffers and othermodel) beside the caller's context `main`, whose update call does the cloud, the passes and the user poses only:
+//   ht_job_start    othermodel.SetPose(handmodel.GetPose()) (:757) -- main's handmodel and tracker flags are copied to `job` --, the frame goes to pinned staging and the
+//                   job is enqueued on job's stream; returns without waiting (what std::async does, :758)
+//   ht_job_poll     pose_estimator.wait_for(...) == ready (:760) as a hipEventQuery
+//   ht_job_collect  handmodel.SetPose(results.pose) (:767) where the job accepted its pose (an empty pose changes nothing); prev_frame_error as the job left it, and the
+//                   job's `initializing = max(initializing - 1, 0)` (:726) applied to main's CURRENT value (the caller's own `initializing = 50` (:781) may have intervened:
+//                   the reference shares the variable between the threads)
+//   ht_update_passes_sync   the caller's part: points, mainthreadpasses x (HandModelEnhancements, cloud_chamber, FitPointCloud), the initializing rule, GetPoseUser
+__global__ void k_job_collect(float *__restrict__ hand, const float *__restrict__ other, const int *__restrict__ accepted, float *__restrict__ prev_err, const float *__restrict__ job_prev_err, int *__restrict__ initializing, int nb, int n)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n * nb) return;
+	const int f = i / nb;
+	if (accepted[f]) { float *s = hand + (size_t)i * HT_STATE_STRIDE; const float *o = other + (size_t)i * HT_STATE_STRIDE; for (int k = 0; k < 7; k++) s[k] = o[k]; }
+	if (i == f * nb) { prev_err[f] = job_prev_err[f]; const int v = initializing[f] - 1; initializing[f] = v < 0 ? 0 : v; }
+}
+extern "C" int ht_update_passes_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int w, int h, int B, float *poses_out)
+{
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
+	if (!depth || !cams || !poses_out) return HT_ERR_ARG;
+	const bool tile = (w == 64 && h == 64);
+	if (!tile && !frames_args_ok(ctx, w, h)) return HT_ERR_ARG;
+	hipStream_t s = ctx->stream;
+	const int nb = ctx->model.nb;
+	const size_t npx = (size_t)w * h;
+	const uint16_t *d_in; const float *d_cin;
+	if (tile)
+	{
+		HIPCHK(ctx, hipMemcpyAsync(ctx->d_depth, depth, (size_t)B * npx * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+		HIPCHK(ctx, hipMemcpyAsync(ctx->d_cams, cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyHostToDevice, s));
+		d_in = ctx->d_depth; d_cin = ctx->d_cams;
+	}
+	else
+	{
+		if (ctx->frames_cap < (size_t)B * npx) { void *a = nullptr; HIPCHK(ctx, hipMalloc(&a, (size_t)ctx->B * npx * sizeof(uint16_t))); ctx->allocs.push_back(a); ctx->d_frames = (uint16_t *)a; ctx->frames_cap = (size_t)ctx->B * npx; }
+		if (!ctx->d_frame_cams_in) { void *a = nullptr; HIPCHK(ctx, hipMalloc(&a, (size_t)ctx->B * HT_CAM * sizeof(float))); ctx->allocs.push_back(a); ctx->d_frame_cams_in = (float *)a; }
+		HIPCHK(ctx, hipMemcpyAsync(ctx->d_frames, depth, (size_t)B * npx * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+		HIPCHK(ctx, hipMemcpyAsync(ctx->d_frame_cams_in, cams, (size_t)B * HT_CAM * sizeof(float), hipMemcpyHostToDevice, s));
+		d_in = ctx->d_frames; d_cin = ctx->d_frame_cams_in;
+	}
+	const frame_src fs = { w, h, 0.17f, 0 };
+	int r = run_update(ctx, d_in, d_cin, nullptr, B, ctx->d_poses_out, nullptr, s, tile ? nullptr : &fs, UPD_PASSES);
+	if (r) return r;
+	HIPCHK(ctx, hipMemcpyAsync(poses_out, ctx->d_poses_out, (size_t)B * nb * HT_POSE * sizeof(float), hipMemcpyDeviceToHost, s));
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	HIPCHK(ctx, hipGetLastError());
+	if (!tile) { int over = 0; HIPCHK(ctx, hipMemcpy(&over, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost)); if (over) { ctx->err = "ht_update_passes: frame(s) with more in-range points than the context's point capacity holds"; return HT_ERR_ARG; } }
+	return HT_OK;
+}
+extern "C" int ht_job_start(ht_ctx *job, ht_ctx *main, const uint16_t *depth, const float *cams, int w, int h, float segment_scale, int B)
+{
+	CHECK_READY(job); CHECK_MODEL(job); CHECK_BATCH(job, B);
+	if (!main || !depth || !cams || main == job || main->device != job->device || main->model.nb != job->model.nb || B > main->B) { job->err = "ht_job_start: the two contexts must be different ones of one device with the same model"; return HT_ERR_ARG; }
+	if (job->job_pending) { job->err = "ht_job_start: a job is in flight on this context (ht_job_collect takes it over)"; return HT_ERR_STATE; }
+	const bool tile = (w == 64 && h == 64);
+	if (!tile && !frames_args_ok(job, w, h)) return HT_ERR_ARG;
+	hipStream_t s = job->stream;
+	const int nb = job->model.nb;
+	const size_t npx = (size_t)w * h, in_bytes = (size_t)B * npx * sizeof(uint16_t), cam_bytes = (size_t)B * HT_CAM * sizeof(float);
+	if (!job->ev_job) HIPCHK(job, hipEventCreateWithFlags(&job->ev_job, hipEventDisableTiming));
+	if (job->h_job_cap < in_bytes + cam_bytes) { if (job->h_job_in) (void)hipHostFree(job->h_job_in); job->h_job_in = nullptr; HIPCHK(job, hipHostMalloc(&job->h_job_in, in_bytes + cam_bytes, hipHostMallocDefault)); job->h_job_cap = in_bytes + cam_bytes; }
+	HIPCHK(job, hipStreamSynchronize(main->stream));      // the caller's context is between two of its (synchronous) calls: its handmodel is final
+	memcpy(job->h_job_in, depth, in_bytes); memcpy((char *)job->h_job_in + in_bytes, cams, cam_bytes);      // the caller's image need not outlive this call (the reference moves it into the task)
+	const uint16_t *d_in; const float *d_cin;
+	if (tile)
+	{
+		HIPCHK(job, hipMemcpyAsync(job->d_depth, job->h_job_in, in_bytes, hipMemcpyHostToDevice, s));
+		HIPCHK(job, hipMemcpyAsync(job->d_cams, (char *)job->h_job_in + in_bytes, cam_bytes, hipMemcpyHostToDevice, s));
+		d_in = job->d_depth; d_cin = job->d_cams;
+	}
+	else
+	{
+		if (job->frames_cap < (size_t)B * npx) { void *a = nullptr; HIPCHK(job, hipMalloc(&a, (size_t)job->B * npx * sizeof(uint16_t))); job->allocs.push_back(a); job->d_frames = (uint16_t *)a; job->frames_cap = (size_t)job->B * npx; }
+		if (!job->d_frame_cams_in) { void *a = nullptr; HIPCHK(job, hipMalloc(&a, (size_t)job->B * HT_CAM * sizeof(float))); job->allocs.push_back(a); job->d_frame_cams_in = (float *)a; }
+		HIPCHK(job, hipMemcpyAsync(job->d_frames, job->h_job_in, in_bytes, hipMemcpyHostToDevice, s));
+		HIPCHK(job, hipMemcpyAsync(job->d_frame_cams_in, (char *)job->h_job_in + in_bytes, cam_bytes, hipMemcpyHostToDevice, s));
+		d_in = job->d_frames; d_cin = job->d_frame_cams_in;
+	}
+	// the job looks at handmodel (FitError of the carried pose, :704) and starts othermodel from its pose (:757); prev_frame_error and initializing as they stand
+	HIPCHK(job, hipMemcpyAsync(job->d_state[0], main->d_state[0], (size_t)B * nb * HT_STATE_STRIDE * sizeof(float), hipMemcpyDeviceToDevice, s));
+	ht_launch_set_pose(job->d_state[1], main->d_state[0], nb, B, 2, s);
+	HIPCHK(job, hipMemcpyAsync(job->d_prev_err, main->d_prev_err, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
+	HIPCHK(job, hipMemcpyAsync(job->d_initializing, main->d_initializing, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s));
+	const frame_src fs = { w, h, segment_scale, 0 };
+	int r = run_update(job, d_in, d_cin, nullptr, B, job->d_poses_out, nullptr, s, tile ? nullptr : &fs, UPD_CNN_MODEL);
+	if (r) return r;
+	HIPCHK(job, hipEventRecord(job->ev_job, s));
+	job->job_pending = true;
+	return HT_OK;
+}
+extern "C" int ht_job_poll(ht_ctx *job, int *ready)
+{
+	if (!job || !ready) return HT_ERR_ARG;
+	ht_device_guard dev_guard_(job->device);
+	*ready = 0;
+	if (!job->job_pending) return HT_OK;
+	const hipError_t e = hipEventQuery(job->ev_job);
+	if (e == hipSuccess) *ready = 1;
+	else if (e != hipErrorNotReady) { job->err = std::string("ht_job_poll: ") + hipGetErrorString(e); return HT_ERR_HIP; }
+	return HT_OK;
+}
+extern "C" int ht_job_wait(ht_ctx *job)
+{
+	if (!job) return HT_ERR_ARG;
+	ht_device_guard dev_guard_(job->device);
+	if (job->job_pending) HIPCHK(job, hipEventSynchronize(job->ev_job));
+	return HT_OK;
+}
+extern "C" int ht_job_collect(ht_ctx *job, ht_ctx *main, int B, int *accepted_out)
+{
+	CHECK_READY(job); CHECK_MODEL(job); CHECK_BATCH(job, B);
+	if (!main || main == job || main->device != job->device || main->model.nb != job->model.nb || B > main->B) return HT_ERR_ARG;
+	if (!job->job_pending) { job->err = "ht_job_collect: no job in flight"; return HT_ERR_STATE; }
+	HIPCHK(job, hipEventSynchronize(job->ev_job));
+	const int nb = job->model.nb;
+	hipLaunchKernelGGL(k_job_collect, dim3((B * nb + 255) / 256), dim3(256), 0, main->stream, main->d_state[0], job->d_state[1], job->d_accepted, main->d_prev_err, job->d_prev_err, main->d_initializing, nb, B);
+	if (accepted_out) { HIPCHK(job, hipMemcpyAsync(accepted_out, job->d_accepted, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, main->stream)); }
+	HIPCHK(job, hipStreamSynchronize(main->stream));
+	if (accepted_out) for (int b = 0; b < B; b++) accepted_out[b] = accepted_out[b] != 0;
+	job->job_pending = false;
 	return HT_OK;
 }
 // Results of the CNN job of the latest update call of slots [first, first + n): HandTracker::cnn_input / cnn_output (handtrack.h:583-584) and the

@@ -285,6 +285,11 @@ struct HandTracker                                                              
 	size_t min_point_num = 400; float accum_error_threshold = 0.0f; float min_cray_prob = 0.0f;
 	int steps = 5, steps_keypoints = 3, steps_keyangles = 2, steps_palmangle = 2, steps_cloudstart = 1, steps_unibody = 3;
 	CNN cnn;
+	// The reference's update() overlaps the CNN job with the caller's passes (std::async, handtrack.h:755-768) and is therefore timing dependent; the default here is the
+	// deterministic synchronous sum (what every parity statement is made on).  overlapped_update = true gives the reference's structure: the job of frame k runs
+	// on a second device context beside the caller's passes and is collected by a later call, when it is through (the 1 ms wait_for = one poll); the caller's latency is
+	// the passes alone.  overlapped_wait = true (tests) waits for the job before the passes: the same sequence of operations as the synchronous call.
+	bool overlapped_update = false, overlapped_wait = false;
 	// PhysModel facade of the two tracked models (handtrack.h:517-518): the members the applications use on them (physmodel.h:295-303,345,433-435)
 	struct TrackedModel
 	{
@@ -338,6 +343,7 @@ struct HandTracker                                                              
 	{
 		int rc = ht_create(model_path.c_str(), 1, device, &ctx_);
 		if (rc != HT_OK) { std::string msg = ctx_ ? ht_last_error(ctx_) : "ht_create failed"; if (ctx_) ht_destroy(ctx_); ctx_ = nullptr; throw std::runtime_error("HandTracker: " + msg); }
+		model_path_ = model_path; device_ = device;
 		cnn.ctx_ = ctx_;
 		if (!detail::live_ctx()) detail::live_ctx() = ctx_;
 		ht_model_info(ctx_, &nb_, nullptr, nullptr);
@@ -363,7 +369,7 @@ struct HandTracker                                                              
 		if (!cnnb_path.empty()) { std::ifstream is(cnnb_path, std::ios_base::in | std::ios_base::binary); if (is.is_open()) cnn.loadb(is); }
 		cnn_output.assign(HT_CNN_OUT, 0.01f);
 	}
-	~HandTracker() { if (detail::live_ctx() == ctx_) detail::live_ctx() = nullptr; if (ctx_) ht_destroy(ctx_); }
+	~HandTracker() { if (job_) { ht_job_wait(job_); ht_destroy(job_); } if (detail::live_ctx() == ctx_) detail::live_ctx() = nullptr; if (ctx_) ht_destroy(ctx_); }      // the reference's destructor joins the job too (handtrack.h:841-844)
 	HandTracker(const HandTracker &) = delete; HandTracker &operator=(const HandTracker &) = delete;
 
 	void load_config(const std::string &jsonfile)                                            // handtrack.h:822-828
@@ -393,14 +399,36 @@ struct HandTracker                                                              
 		push_params();
 		const bool full = dimage.dim().x != 64 || dimage.dim().y != 64;
 		std::vector<float> out((size_t)nb_ * HT_POSE);
+		const DCamera &fc = dimage.cam;
+		const float fcam[HT_CAM] = { fc.focal().x, fc.focal().y, fc.principal().x, fc.principal().y, fc.depth_scale, fc.pose.position.x, fc.pose.position.y, fc.pose.position.z,
+		                             fc.pose.orientation.x, fc.pose.orientation.y, fc.pose.orientation.z, fc.pose.orientation.w };
+		if (overlapped_update)
 		{
-			const DCamera &fc = dimage.cam;
-			float fcam[HT_CAM] = { fc.focal().x, fc.focal().y, fc.principal().x, fc.principal().y, fc.depth_scale, fc.pose.position.x, fc.pose.position.y, fc.pose.position.z,
-			                       fc.pose.orientation.x, fc.pose.orientation.y, fc.pose.orientation.z, fc.pose.orientation.w };
-			check(ctx_, ht_update_frames_sync(ctx_, dimage.raster.data(), fcam, dimage.dim().x, dimage.dim().y, segment_scale, 1, out.data(), cnn_output.data()));
+			// handtrack.h:755-768 on two device contexts (include/ht_mi355x.h: ht_job_start / ht_job_poll / ht_job_collect / ht_update_passes_sync)
+			ensure_job_context();
+			if (!job_in_flight_)
+			{
+				check(job_, ht_job_start(job_, ctx_, dimage.raster.data(), fcam, dimage.dim().x, dimage.dim().y, segment_scale, 1));
+				job_in_flight_ = true; job_image_ = dimage;
+			}
+			int ready = 0;
+			if (overlapped_wait) { check(job_, ht_job_wait(job_)); ready = 1; } else check(job_, ht_job_poll(job_, &ready));
+			if (ready)
+			{
+				check(job_, ht_job_collect(job_, ctx_, 1, nullptr));
+				check(job_, ht_get_cnn_results(job_, 0, 1, nullptr, cnn_output.data(), nullptr));
+				Image<unsigned short> seen = (job_image_.dim().x != 64 || job_image_.dim().y != 64) ? segment(job_image_, 0xF, { 0.1f, drangey }, segment_scale) : job_image_;
+				fill_visualisation(seen);      // cnn_input / cnn_output / the heat-maps of the frame the job saw
+				job_in_flight_ = false;
+			}
+			check(ctx_, ht_update_passes_sync(ctx_, dimage.raster.data(), fcam, dimage.dim().x, dimage.dim().y, 1, out.data()));
 		}
-		if (full) dimage = segment(dimage, 0xF, { 0.1f, drangey }, segment_scale);
-		fill_visualisation(dimage);
+		else
+		{
+			check(ctx_, ht_update_frames_sync(ctx_, dimage.raster.data(), fcam, dimage.dim().x, dimage.dim().y, segment_scale, 1, out.data(), cnn_output.data()));
+			if (full) dimage = segment(dimage, 0xF, { 0.1f, drangey }, segment_scale);
+			fill_visualisation(dimage);
+		}
 		std::vector<Pose> pose(nb_);
 		for (int b = 0; b < nb_; b++) { const float *p = &out[(size_t)b * HT_POSE]; pose[b].position = { p[0], p[1], p[2] }; pose[b].orientation = { p[3], p[4], p[5], p[6] }; }
 		return pose;
@@ -437,6 +465,19 @@ struct HandTracker                                                              
 	}
 private:
 	ht_ctx *ctx_ = nullptr; int nb_ = 0;
+	ht_ctx *job_ = nullptr; bool job_in_flight_ = false; Image<unsigned short> job_image_; std::string model_path_; int device_ = 0;      // the overlapped mode's second context
+	void ensure_job_context()
+	{
+		if (!job_)
+		{
+			int rc = ht_create(model_path_.c_str(), 1, device_, &job_);
+			if (rc != HT_OK) { std::string msg = job_ ? ht_last_error(job_) : "ht_create failed"; if (job_) ht_destroy(job_); job_ = nullptr; throw std::runtime_error("HandTracker (job context): " + msg); }
+			std::vector<float> w(HT_CNNB_COUNT);
+			check(ctx_, ht_cnn_get_weights(ctx_, w.data(), w.size()));      // the net the tracker carries (fails loudly when none was loaded)
+			check(job_, ht_cnn_load_weights(job_, w.data(), w.size()));
+		}
+		if (!job_in_flight_) { ht_params p; pull_params(p); check(job_, ht_set_params(job_, &p)); }      // the job runs with the tunables as they stood when it was started
+	}
 	std::vector<Pose> cnn_job(Image<unsigned short> dimage, bool apply)
 	{
 		push_params();

@@ -171,6 +171,20 @@ int ht_point_capacity(ht_ctx *ctx, int *points);
 int ht_update_cnn_model_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int w, int h, float segment_scale, int B, int apply_to_handmodel,
                              float *poses_out, int *accepted_out, float *cnn_out);
 int ht_get_cnn_results(ht_ctx *ctx, int first, int n, float *cnn_input, float *cnn_output, float *analysis);
+/* The reference's OVERLAPPED update (handtrack.h:748-785: the CNN job on a background thread, collected by a later call) on two contexts of one device, `job` for the CNN job
+ * and `main` for the caller's part.  The synchronous ht_update_* calls stay the definition parity is stated on (the reference's update() is timing dependent).
+ * ht_job_start          replaces :757-758: othermodel.SetPose(handmodel.GetPose()); std::async(update_cnn_model_threadsafe(dimage)).  main's handmodel, prev_frame_error and
+ *                       initializing are copied to `job`, the frame to pinned staging, the job is enqueued on job's stream; does not wait for it.
+ * ht_job_poll           replaces pose_estimator.wait_for(1 ms) == ready (:760): *ready = 1 when the job has finished (hipEventQuery).  ht_job_wait blocks until it has.
+ * ht_job_collect        replaces :761-768: handmodel.SetPose(results.pose) where the job accepted its pose (accepted_out [B], may be NULL), prev_frame_error as the job left it,
+ *                       the job's initializing = max(initializing - 1, 0) applied to main's current value.  The job's cnn_input / cnn_output / analysis: ht_get_cnn_results(job).
+ * ht_update_passes_sync replaces the caller's part of update() (:751-753, 769-785): the frame's cloud, mainthreadpasses x (HandModelEnhancements, cloud_chamber, FitPointCloud)
+ *                       on handmodel, the "initializing = 50" rule, handmodel.GetPoseUser() into poses_out [B][nb][7].  Frames w x h as ht_update_frames_sync. */
+int ht_update_passes_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int w, int h, int B, float *poses_out);
+int ht_job_start(ht_ctx *job, ht_ctx *main, const uint16_t *depth, const float *cams, int w, int h, float segment_scale, int B);
+int ht_job_poll(ht_ctx *job, int *ready);
+int ht_job_wait(ht_ctx *job);
+int ht_job_collect(ht_ctx *job, ht_ctx *main, int B, int *accepted_out);
 /* ht_get_cnn_layers   the intermediate layers of the latest CNN evaluation of slots [first, first + n), for per-layer parity tests (the reference returns every
  *                     layer's output from its forward() calls, cnn.h:550-556): act1 [n][3600] after conv 5x5 + tanh + two max-pools (layer 3 of the list,
  *                     handtrack.h:108-111), act2 [n][2304] after conv 4x4 + tanh + pool (layer 6), act3 [n][2048] after the first fully connected layer + tanh

@@ -76,6 +76,28 @@ def test_point_cloud_free_function_matches_the_reference(tmp_path, golden):
 
 
 @pytest.mark.gpu
+def test_overlapped_update_with_the_job_collected_first_equals_the_synchronous_update(tmp_path, golden, weights):
+    """HandTracker::overlapped_update runs the CNN job on a second device context beside the caller's passes (the reference's std::async structure, handtrack.h:755-768).
+    With overlapped_wait the job is waited for and collected before the passes: that IS the synchronous sequence (othermodel seeded from handmodel, the job, the accepted
+    pose into handmodel, the passes), so every pose, heat-map and facade read must equal the synchronous tracker's bit for bit."""
+    from hand_tracking_samples_amd import weights as W
+    exe = _build(tmp_path)
+    nf = 8
+    depth = np.stack([golden["f%d/depth" % f] for f in range(nf)]); cams = np.stack([golden["f%d/cam" % f] for f in range(nf)])
+    start = np.stack([golden["f%d/startpose" % f] for f in range(nf)]); gt = np.stack([golden["f%d/gtpose" % f] for f in range(nf)])
+    _write_input(tmp_path / "in.bin", depth, cams, start, gt)
+    cnnb = str(tmp_path / "w.cnnb")
+    W.save_cnnb(cnnb, weights)
+    outs = []
+    for extra in ([], ["overlapped_wait"]):
+        r = subprocess.run([exe, "track", ol.MODEL, cnnb, str(tmp_path / "in.bin"), str(tmp_path / ("out%d.bin" % len(outs)))] + extra, capture_output=True, text=True, timeout=300)
+        print(r.stdout, r.stderr)
+        assert r.returncode == 0 and "track: 8 frames, 17 bones" in r.stdout
+        outs.append(np.fromfile(tmp_path / ("out%d.bin" % len(outs)), np.float32))
+    assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
 def test_tracking_loop_through_the_cxx_surface_matches_the_reference(tmp_path, golden, weights):
     from hand_tracking_samples_amd import native, weights as W
     exe = _build(tmp_path)
