@@ -51,6 +51,7 @@ def parse_args(argv=None):
     ap.add_argument("--frames-per-gpu", type=int, default=1024)
     ap.add_argument("--workload", default="cnn+solver", choices=["cnn+solver", "cnn", "config5", "config5-cnn128", "config5-e2e"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the extra leg that times the same steps with pinned host buffers in and out")
     ap.add_argument("--always-take-cnn", action="store_true", help="cnn+solver workload with the application's always_take_cnn switch (synthetic-tracker.cpp:91): every frame accepts the CNN-driven pose; verified against tests/golden/poses1024_takecnn.htfx")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the pose gather even with one rank")
     return ap.parse_args(argv)
@@ -524,6 +525,60 @@ def main():
             if use_dist:
                 verify["gather_consistent"] = bool(torch.equal(gathered[rank * B:(rank + 1) * B], d_poses))
 
+    # ---- the same steps with the HOST in them (SURVEY 8e names host-side staging as a scaling bound; the application hands update() a host image, synthetic-tracker.cpp:215):
+    #      depth and cameras start in pinned host memory, the poses end there; the upload of step k + 1 and the download of step k - 1 run on a copy stream beside step k ----
+    host_io = None
+    if rank == 0 and wl == "cnn+solver" and args.steps > 0 and not args.no_host_io:
+        h_depth = torch.from_numpy(depth.view(np.int16)).pin_memory(); h_cams = torch.from_numpy(cams).pin_memory()
+        h_poses = [torch.empty((B, ctx.nb, 7), dtype=torch.float32).pin_memory() for _ in range(2)]
+        din = [torch.empty_like(d_depth) for _ in range(2)]; cin = [torch.empty_like(d_cams) for _ in range(2)]
+        dout = [torch.empty((B, ctx.nb, 7), dtype=torch.float32, device=dev) for _ in range(2)]
+        copy = torch.cuda.Stream(device=dev)
+        e_in = [torch.cuda.Event() for _ in range(2)]; e_out = [torch.cuda.Event() for _ in range(2)]; e_used = [torch.cuda.Event() for _ in range(2)]
+
+        def upload(k):
+            with torch.cuda.stream(copy):
+                e_used[k % 2].synchronize()      # the HOST waits until the step that read this buffer pair is through: a host that queues many steps ahead slows the device's own streams down (tools/exp_hostio2.py: 5.63 ms per step queued ahead, 5.10 paced)
+                din[k % 2].copy_(h_depth, non_blocking=True); cin[k % 2].copy_(h_cams, non_blocking=True)
+                e_in[k % 2].record(copy)
+
+        def run(n, transfers):
+            for b in range(2):
+                e_used[b].record(stream)
+            if transfers:
+                upload(0)
+            for k in range(n):
+                if transfers and k + 1 < n:
+                    upload(k + 1)
+                elif not transfers:
+                    e_used[(k + 1) % 2].synchronize()      # the same pacing without the transfers: the yardstick of this leg
+                if transfers:
+                    stream.wait_event(e_in[k % 2])
+                ctx.update_dev(din[k % 2].data_ptr(), cin[k % 2].data_ptr(), d_start.data_ptr(), B, dout[k % 2].data_ptr(), stream.cuda_stream)
+                e_out[k % 2].record(stream); e_used[k % 2].record(stream)
+                if transfers:
+                    with torch.cuda.stream(copy):
+                        copy.wait_event(e_out[k % 2])
+                        h_poses[k % 2].copy_(dout[k % 2], non_blocking=True)
+            torch.cuda.synchronize()
+
+        for b in range(2):
+            din[b].copy_(d_depth); cin[b].copy_(d_cams)
+        ctx.profile_enable(0)
+        res = {}
+        for transfers in (False, True):
+            run(max(2, args.warmup), transfers)
+            t0h = time.perf_counter()
+            run(args.steps, transfers)
+            res[transfers] = time.perf_counter() - t0h
+        eh = res[True]
+        same = bool(torch.equal(h_poses[(args.steps - 1) % 2], d_poses.cpu()))
+        host_io = {"value": round(B * args.steps / eh, 2), "unit": "frames/s", "ms_per_step": round(eh / args.steps * 1e3, 4),
+                   "resident_same_loop_ms_per_step": round(res[False] / args.steps * 1e3, 4), "fraction_of_resident_rate": round(res[False] / eh, 4),
+                   "bytes_per_step": {"host_to_device": int(h_depth.numel() * 2 + h_cams.numel() * 4), "device_to_host": int(h_poses[0].numel() * 4)}, "poses_equal_resident_run": same,
+                   "what": "pinned host depth + cameras in, poses out to pinned host memory; upload of step k + 1 and download of step k - 1 on a copy stream beside step k (double buffers, the host one step ahead); "
+                           "resident_same_loop = the same loop and pacing without the transfers"}
+
     # phase table from a second, untimed pass with every phase bracketed (this serialises the side streams)
     ctx.profile_enable(2)
     nphase = max(2, min(5, args.steps))
@@ -621,6 +676,8 @@ def main():
             out["verify"] = verify
         if cnn_roof:
             out["roofline_cnn"] = cnn_roof
+        if host_io:
+            out["host_io"] = host_io
         if world == 1 and not args.no_cpu_baseline:
             if cnn128:
                 out["cpu_baseline"] = cpu_baseline_cnn128(x128, w128)

@@ -1,0 +1,44 @@
+"""bench.py's host_io leg with one part switched off at a time (where do the 3 ms go?)"""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from hand_tracking_samples_amd import native, weights as W
+B = int(os.environ.get("FRAMES", "1024"))
+dev = torch.device("cuda", 0)
+z = np.load(os.path.join(ROOT, "tests", "golden", "frames1024.npz"))
+idx = np.arange(B) % 1024
+depth, cams, start = z["depth"].reshape(-1, 4096)[idx].astype(np.uint16), z["cam"][idx].astype(np.float32), z["startpose"][idx].astype(np.float32)
+ctx = native.Context(os.path.join(ROOT, "hand_tracking_samples_amd", "assets", "model_hand17.htfx"), B)
+ctx.load_weights(W.make_cnnb()); ctx.set_params(microforce=3.0, mainthreadpasses=3)
+d_start = torch.from_numpy(start).to(dev)
+h_depth = torch.from_numpy(depth.view(np.int16)).pin_memory(); h_cams = torch.from_numpy(cams).pin_memory()
+h_poses = [torch.empty((B, 17, 7), dtype=torch.float32).pin_memory() for _ in range(2)]
+din = [h_depth.to(dev) for _ in range(2)]; cin = [h_cams.to(dev) for _ in range(2)]
+dout = [torch.empty((B, 17, 7), dtype=torch.float32, device=dev) for _ in range(2)]
+stream = torch.cuda.current_stream(dev); copy = torch.cuda.Stream(device=dev)
+def run(n, h2d, d2h, same_stream, host_wait):
+    e_in = [torch.cuda.Event() for _ in range(2)]; e_out = [torch.cuda.Event() for _ in range(2)]; e_used = [torch.cuda.Event() for _ in range(2)]
+    cs = stream if same_stream else copy
+    for b in range(2): e_used[b].record(stream)
+    def upload(k):
+        if not h2d: return
+        with torch.cuda.stream(cs):
+            if host_wait: e_used[k % 2].synchronize()
+            else: cs.wait_event(e_used[k % 2])
+            din[k % 2].copy_(h_depth, non_blocking=True); cin[k % 2].copy_(h_cams, non_blocking=True); e_in[k % 2].record(cs)
+    upload(0)
+    for k in range(n):
+        if k + 1 < n: upload(k + 1)
+        if h2d: stream.wait_event(e_in[k % 2])
+        ctx.update_dev(din[k % 2].data_ptr(), cin[k % 2].data_ptr(), d_start.data_ptr(), B, dout[k % 2].data_ptr(), stream.cuda_stream)
+        e_out[k % 2].record(stream); e_used[k % 2].record(stream)
+        if d2h:
+            with torch.cuda.stream(cs):
+                cs.wait_event(e_out[k % 2]); h_poses[k % 2].copy_(dout[k % 2], non_blocking=True)
+    torch.cuda.synchronize()
+for name, args in (("resident", (False, False, False, False)), ("H2D only", (True, False, False, False)), ("D2H only", (False, True, False, False)), ("both, copy stream", (True, True, False, False)),
+                   ("both, same stream", (True, True, True, False)), ("both, copy stream, host waits for the buffer", (True, True, False, True))):
+    run(3, *args); t0 = time.perf_counter(); run(20, *args); dt = (time.perf_counter() - t0) / 20
+    print("%-48s %.3f ms per step" % (name, dt * 1e3))
+ctx.close()
