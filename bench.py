@@ -356,6 +356,26 @@ def _pmc_traffic(kernel_prefix, workload, frames_per_gpu):
     return None
 
 
+def _pmc_issue(kernel_prefix, workload, frames_per_gpu):
+    """issue / L2 figures of a kernel from the newest committed counter summary (tools/pmc_solve.py) measured on this workload at this batch size, else {}"""
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_solve_issue*.json")), reverse=True):
+        try:
+            pmc = json.load(open(fn))
+            meta = pmc.get("_measured_on", {})
+            if meta.get("workload") != workload or int(meta.get("frames_per_gpu", -1)) != int(frames_per_gpu):
+                continue
+            best = None
+            for k, v in pmc.items():
+                if k.startswith(kernel_prefix) and (best is None or v.get("dispatches", 0) > best.get("dispatches", 0)):
+                    best = v
+            if best:
+                return {"issue_frac": best.get("issue_frac"), "clocks_per_instruction": best.get("clocks_per_instruction"), "wait_any_frac": best.get("wait_any_frac"),
+                        "l2_gbps": best.get("l2_gbps"), "l2_hit_rate": best.get("l2_hit_rate"), "counters_from": os.path.relpath(fn, ROOT)}
+        except Exception:
+            continue
+    return {}
+
+
 def main():
     args = parse_args()
     bad = [k for k in TUNING_ENV if os.environ.get(k)]
@@ -621,7 +641,9 @@ def main():
             roof = {"kernel": "k_solve", "bound": "latency", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                     "hbm_frac": round(achieved / HBM_PEAK_GBS, 6), "valu_achieved_tflops": round(valu, 3), "valu_peak_tflops": FP32_VALU_PEAK_TF, "valu_frac": round(valu / FP32_VALU_PEAK_TF, 6),
                     "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches": phases[dom][1], "algorithmic_bytes_per_launch": int(per_frame * B), "algorithmic_flop_per_launch": int(flop_frame * B),
-                    "note": "sequential Gauss-Seidel (physics.h:556-562): bound by the dependent-instruction latency of the longest per-body row chain, neither by HBM nor by VALU throughput; both fractions are reported (SURVEY 8d)"}
+                    "note": "sequential Gauss-Seidel (physics.h:556-562): bound by the dependent-instruction latency of the longest per-body row chain, neither by HBM nor by VALU throughput; both fractions are reported (SURVEY 8d); "
+                            "issue_frac = VALU instructions issued x 4 clocks / the resident waves' clocks (one wave per SIMD at 1024 frames), from the committed counter pass"}
+            roof.update(_pmc_issue("k_solve", wl, B))
         elif dom == "contacts":
             # k_contacts reads the poses of the frame's bodies and writes its contacts (48 B each, data dependent, not counted): like the
             # solve it is a latency-bound kernel (one wave walks the candidate pairs' GJK/EPA iterations), priced against HBM for the record
