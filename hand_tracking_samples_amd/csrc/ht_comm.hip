@@ -51,7 +51,9 @@ int fail(ht_ctx *ctx, const char *what, int rc) { ctx->err = std::string(what) +
 struct ht_comm_state
 {
 	rccl_comm comm = nullptr; int world = 0, rank = 0;
-	hipStream_t stream = nullptr; hipEvent_t ready = nullptr, done[2] = { nullptr, nullptr }; bool pending[2] = { false, false };
+	hipStream_t stream = nullptr; hipEvent_t ready = nullptr, done[2] = { nullptr, nullptr };
+	bool pending[2] = { false, false };      // a gather of the slot is in flight and no stream or thread has been made to wait for it yet
+	bool unseen[2] = { false, false };       // ... and no THREAD has waited for it (a stream-side wait leaves the host none the wiser)
 };
 
 // 1 when RCCL can be loaded on this host (every symbol the gather needs resolved), else 0: what the ranks of a job agree on BEFORE any of them enters
@@ -100,17 +102,18 @@ extern "C" int ht_gather_poses_dev(ht_ctx *ctx, const float *d_local, float *d_a
 	ht_device_guard guard(ctx->device);
 	ht_comm_state *c = ctx->comm;
 	hipStream_t s = ht_user_stream(ctx, stream);
-	// a slot whose previous gather nobody waited for: the caller is about to overwrite a buffer pair the exchange may still be reading; this gather waits for it
-	if (c->pending[slot] && hipStreamWaitEvent(c->stream, c->done[slot], 0) != hipSuccess) { ctx->err = "ht_gather_poses_dev: cannot order the gather behind the previous use of its slot"; return HT_ERR_HIP; }
+	// A slot whose previous gather nobody waited for: the update the caller has just queued on `s` wrote d_local while that exchange may still have been reading it -- nothing
+	// this call does could order that after the fact.  The caller has to put ht_gather_wait(slot, stream) in FRONT of the work that refills the slot's buffers.
+	if (c->pending[slot]) { ctx->err = "ht_gather_poses_dev: the previous gather of this slot was never waited for (ht_gather_wait on the stream that refills the buffers, before it does)"; return HT_ERR_STATE; }
 	if (hipEventRecord(c->ready, s) != hipSuccess || hipStreamWaitEvent(c->stream, c->ready, 0) != hipSuccess) { ctx->err = "ht_gather_poses_dev: cannot order the gather behind the update"; return HT_ERR_HIP; }
 	const int rc = rccl().AllGather(d_local, d_all, (size_t)frames * ctx->model.nb * HT_POSE, 7 /* ncclFloat32 */, c->comm, c->stream);
 	if (rc != 0) return fail(ctx, "ncclAllGather", rc);
 	if (hipEventRecord(c->done[slot], c->stream) != hipSuccess) { ctx->err = "ht_gather_poses_dev: event record failed"; return HT_ERR_HIP; }
-	c->pending[slot] = true;
+	c->pending[slot] = true; c->unseen[slot] = true;
 	return HT_OK;
 }
 // makes `stream` wait for the gather last issued with `slot`; a NULL stream means the context's own stream, as in every other *_dev entry point.
-// ht_gather_wait_host: the calling thread waits instead.  Either way the slot counts as waited for.
+// ht_gather_wait_host: the calling thread waits instead (also after a stream-side wait).  Either way the slot may be refilled behind the wait.
 extern "C" int ht_gather_wait(ht_ctx *ctx, int slot, void *stream)
 {
 	if (!ctx || slot < 0 || slot > 1) return HT_ERR_ARG;
@@ -124,11 +127,11 @@ extern "C" int ht_gather_wait(ht_ctx *ctx, int slot, void *stream)
 extern "C" int ht_gather_wait_host(ht_ctx *ctx, int slot)
 {
 	if (!ctx || slot < 0 || slot > 1) return HT_ERR_ARG;
-	if (!ctx->comm || !ctx->comm->pending[slot]) return HT_OK;
+	if (!ctx->comm || !ctx->comm->unseen[slot]) return HT_OK;      // (a stream-side ht_gather_wait does not count: the calling thread has not seen the exchange end)
 	ht_device_guard guard(ctx->device);
 	const hipError_t e = hipEventSynchronize(ctx->comm->done[slot]);
 	if (e != hipSuccess) { ctx->err = std::string("ht_gather_wait_host: ") + hipGetErrorString(e); return HT_ERR_HIP; }
-	ctx->comm->pending[slot] = false;
+	ctx->comm->pending[slot] = false; ctx->comm->unseen[slot] = false;
 	return HT_OK;
 }
 extern "C" int ht_comm_destroy(ht_ctx *ctx)

@@ -15,7 +15,7 @@ struct ht_ctx
 	bool profile_phases = false;     // also time the minor phases (serialises the side streams; used for the phase table, not for the timed region)
 	int B = 0, device = 0;
 	int solver_build = 0;           // ht_debug_solver_build: 0 = the launcher's choice; 5 = the exact-order instantiation (tests only): the reference's own sweeps, cloud rows in the reference's layout
-	float *d_exact_lin = nullptr, *d_exact_ang = nullptr;      // its two-body linear rows [B][512][HT_ROW] and angular rows [B][128][8] (allocated when first asked for)
+	float *d_exact_lin = nullptr, *d_exact_ang = nullptr;      // its two-body linear rows [B][512][HT_ROW] and angular rows [B][256][8] (allocated when first asked for)
 	int contact_kernel = 0;         // ht_debug_contact_kernel: 0 = the launcher's choice, 1 cooperative, 2 lane-per-pair
 	std::string err;
 	hipStream_t stream = nullptr;

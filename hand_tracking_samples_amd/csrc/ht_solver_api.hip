@@ -526,6 +526,7 @@ extern "C" int ht_update_direct_dev(ht_ctx *ctx, const uint16_t *d_depth, const 
 	if (!d_depth || !d_cams || !d_poses_out) return HT_ERR_ARG;
 	if (side == 64) return ht_update_dev(ctx, d_depth, d_cams, d_start_poses, B, d_poses_out, stream);
 	if (side != 128) { ctx->err = "ht_update_direct: CNN input side must be 64 or 128"; return HT_ERR_ARG; }
+	if (((uintptr_t)d_depth & 15) != 0) { ctx->err = "ht_update_direct_dev: d_depth must be 16-byte aligned (the input transform reads eight pixels per 128-bit load)"; return HT_ERR_ARG; }
 	hipStream_t s = ht_user_stream(ctx, stream);
 	const frame_src fs = { side, side, 0.0f, side };
 	int r = run_update(ctx, d_depth, d_cams, d_start_poses, B, d_poses_out, nullptr, s, &fs);

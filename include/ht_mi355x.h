@@ -154,7 +154,8 @@ int ht_update_frames_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_ca
  *                     (ht_cnn_load_weights_sized; the reference's layer classes cnn.h:136-511 in the order of handtrack.h:108-118), decoded with
  *                     CNNOutputAnalysis(out, camsub(cam, side / 16)) (handtrack.h:218-241), then FitError, the reset branch, MultiStepSim, the accept step and
  *                     the main-thread passes exactly as handtrack.h:703-785.  The reference has no call of its own for this (PoseInitializerCNN is fixed at
- *                     64x64); oracle/ref_harness.cpp `e2e128` drives the reference's stage functions in that order.  side = 64 is ht_update_*. */
+ *                     64x64); oracle/ref_harness.cpp `e2e128` drives the reference's stage functions in that order.  side = 64 is ht_update_*.  d_depth of ht_update_direct_dev must be 16-byte aligned (HT_ERR_ARG otherwise).
+ */
 int ht_update_direct_sync(ht_ctx *ctx, const uint16_t *depth, const float *cams, int side, int B, float *poses_out, float *cnn_out);
 int ht_update_direct_dev(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, int side, const float *d_start_poses, int B, float *d_poses_out, void *stream);
 int ht_frames_overflow(ht_ctx *ctx, int *frames_over);
@@ -305,7 +306,8 @@ int ht_physics_update(ht_ctx *ctx, int which, int B, const float *linears, int l
  *                     stream behind everything enqueued on `stream` so far: the next step's kernels do not wait for it.  slot (0 / 1) names which of the
  *                     caller's two buffer pairs the call uses; ht_gather_wait(ctx, slot, stream) makes `stream` (NULL: the context's own stream, as everywhere)
  *                     wait for that slot's gather before the pair is reused or read, ht_gather_wait_host(ctx, slot) the calling thread.  A gather issued
- *                     into a slot whose previous gather was never waited for is ordered behind it.
+ *                     into a slot whose previous gather was never waited for is refused (HT_ERR_STATE): the wait has to stand in front of the work that refills
+ *                     the slot's buffers, nothing issued afterwards can order that.  ht_gather_wait_host synchronises the thread also after a stream-side wait.
  * ht_comm_available   1 when RCCL can be loaded here.  ncclCommInitRank blocks until every rank has arrived, so the ranks of a job agree on this (a MIN
  *                     over the host program's own channel) BEFORE any of them calls ht_comm_init; a rank without the library then cannot strand the others.
  * ht_comm_destroy     leaves the communicator (ht_destroy does it too). */

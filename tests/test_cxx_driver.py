@@ -75,6 +75,32 @@ def test_point_cloud_free_function_matches_the_reference(tmp_path, golden):
         assert np.array_equal(pts[::4], golden["f%d/vpts" % f]), "frame %d" % f
 
 
+def test_the_applications_include_block_compiles_against_the_compat_headers(tmp_path):
+    """include/compat/ staged where the reference's include/ and third_party/ stand: the application's own include lines (synthetic-tracker.cpp:15-24, tracker side) and its own
+    LoadAnimBank compile and link unchanged, and the animation bank it reads through the binding's Pose extraction has the reference's 2336 rows when the bank is present."""
+    import shutil
+    from hand_tracking_samples_amd import native
+    native.load()
+    lib = os.path.dirname(native.lib_path())
+    root = os.path.dirname(HERE)
+    app = tmp_path / "app"
+    shutil.copytree(os.path.join(root, "include"), app / "real_include")
+    # compat/include -> <app>/include, compat/third_party -> <app>/third_party; the forwarders reach the binding through ../../ht_formats.hpp, i.e. <app>/ht_formats.hpp
+    shutil.copytree(os.path.join(root, "include", "compat", "include"), app / "tree" / "include")
+    shutil.copytree(os.path.join(root, "include", "compat", "third_party"), app / "tree" / "third_party")
+    for f in os.listdir(app / "real_include"):
+        if f.endswith((".hpp", ".h")):
+            shutil.copy(app / "real_include" / f, app / f)
+    os.makedirs(app / "tree" / "synthetic-hand-tracker")
+    shutil.copy(os.path.join(HERE, "cxx_compat_shim.cpp"), app / "tree" / "synthetic-hand-tracker" / "synthetic-tracker-side.cpp")
+    exe = str(tmp_path / "shim")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", str(app / "tree" / "synthetic-hand-tracker" / "synthetic-tracker-side.cpp"), "-o", exe, "-L" + lib, "-lht_mi355x", "-Wl,-rpath," + lib])
+    assert "compiled and linked" in subprocess.check_output([exe]).decode()
+    bank = "/root/reference/assets/animbank.pose"
+    if os.path.exists(bank):
+        assert "animbank rows=2336" in subprocess.check_output([exe, bank]).decode()
+
+
 @pytest.mark.gpu
 def test_overlapped_update_with_the_job_collected_first_equals_the_synchronous_update(tmp_path, golden, weights):
     """HandTracker::overlapped_update runs the CNN job on a second device context beside the caller's passes (the reference's std::async structure, handtrack.h:755-768).
