@@ -68,11 +68,13 @@ static_assert(HT_MAXPTS == HT_MAX_POINTS, "public header and kernels disagree on
 #define HT_STATE_STRIDE 16      // floats per body in device state arrays
 #define HT_ROW 16               // floats per linear row: rb0 rb1 position0[3] position1[3] normal[3] targetdist targetspeednobias fmin fmax friction_master
 #define HT_AROW 8               // floats per angular row: rb0 rb1 axis[3] targetspin mintorque maxtorque
-#define HT_MAXCONTACT 96        // contacts kept per frame (3 rows each)
+#define HT_MAXCONTACT 192       // contacts kept per frame (3 rows each): every touching sample the contact kernel's per-frame pool can hold (GJK_POOL, ht_gjk.hip)
+#define HT_MAXCONTACT_LDS 96    // contacts whose groups k_solve's level schedule has LDS tables for; a frame with more applies its two-body linear rows one group at a time from its HBM scratch slot
+#define HT_EX_LIN 768           // two-body linear rows of a frame in the exact-order instantiation of the tests (3 rows x (32 joints + 192 contacts) and slack)
 #define HT_CONTACT 12           // floats per contact: rb0 rb1 normal[3] p0w[3] p1w[3] separation
 #define HT_MAXPAIRS 160         // candidate pair slots per frame
 #define HT_CREC 16              // floats per pre-computed single-body row record of the solver scratch (ht_quad.hpp)
-#define HT_SCRATCH_TAIL 776     // records at the end of a frame's scratch slot: its two-body linear groups and angular records when a frame does not fit k_solve's LDS (ht_solver.hip)
+#define HT_SCRATCH_TAIL 1288    // records at the end of a frame's scratch slot: its two-body linear groups and angular records when a frame does not fit k_solve's LDS (ht_solver.hip)
 
 // analysis layout (HT_ANALYSIS = 84 floats)
 #define HT_AN_CRAYS 0

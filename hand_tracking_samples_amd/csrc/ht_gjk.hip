@@ -768,7 +768,8 @@ template <int GJK_WPF> __global__ __launch_bounds__(64 * GJK_FRAMES * GJK_WPF) v
 // origin queue for the expanding polytope, which every wave of the block takes jobs from.  Touching samples go to a per-frame pool in LDS keyed
 // by (pair, sample) and leave in key order = the reference's contact order.  The four extra samples of a contact patch (gjk.h:626-641) are a
 // second pass over the patches the first pass lists.
-#define GJK_POOL 192        // touching samples a frame can hold before they are ordered (96 contacts are kept)
+#define GJK_POOL 192        // touching samples a frame can hold before they are ordered (all of them are kept: HT_MAXCONTACT)
+static_assert(HT_MAXCONTACT >= GJK_POOL, "every touching sample the pool holds is kept as a contact");
 #define GJK_JMAX 40         // pairs per frame whose contact patch takes the four extra samples
 #define CO_NW 8             // waves per block
 #define CO_MAXF 4           // frames per block (as many as the LDS holds)

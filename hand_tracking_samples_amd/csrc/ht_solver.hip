@@ -53,7 +53,9 @@
 #define MAXA2_OF(AS) (64 * (AS))
 #define MAXA_CAP_OF(AS) ((AS) == 2 ? 126 : 252)
 #define MAXA_RUNS 128      // runs of consecutive angular rows on one body pair a solve schedules (a joint's rows are one run: 13 + 2 per joint; beyond: counted, dropped)
-#define MAXG (HT_MAXNJ + HT_MAXCONTACT + 1)      // groups a frame can have: every joint, every contact the contact kernel keeps, the idle group
+#define MAXG (HT_MAXNJ + HT_MAXCONTACT_LDS + 1)      // groups the level schedule has LDS tables for: every joint, 96 contacts, the idle group
+#define MAXG_CAP (32 + HT_MAXNJ + HT_MAXCONTACT + 1)      // groups a frame can have (their records in the tail of its scratch slot when they exceed the build's LDS pool): a caller's 32, every joint,
+                                                          // every contact the contact kernel keeps, the idle group.  Beyond MAXG - 1 groups there is no level schedule: one group per step, in row order
 // LDS per frame: ~5 KB of body state and schedule tables, a 5 KB union of prologue scratch and the angular records, and three arrays whose size is
 // the build's choice -- the two-body linear groups (256 B each), the impulse sums of the single-body rows (4 B each), the angular records (64 B each).
 // A frame whose rows do not fit an array keeps THAT array in its slot of the solver scratch in HBM instead (same code through a generic pointer): slower
@@ -313,7 +315,7 @@ __device__ __forceinline__ int level_schedule(int n, int lane, const int (&b0)[2
 // EXACT (tests only, ht_debug_exact_solver): the rows are built as always, but the sweeps are the reference's own -- every row's Iter (physics.h:251-265,
 // 289-307) in the reference's row order and association order, no fused multiply-adds, one lane -- instead of the Jacobian-form sweeps.  With it the whole
 // update reproduces the restatement bit for bit, which isolates the Jacobian-form arithmetic as the solver's only difference from the reference.
-#define EX_LIN 512         // two-body linear rows a frame can have in the exact instantiation (a.exact_lin [B][EX_LIN][HT_ROW])
+#define EX_LIN HT_EX_LIN   // two-body linear rows a frame can have in the exact instantiation (a.exact_lin [B][EX_LIN][HT_ROW])
 template <int NGRP_, int NSUM_, int NANG_, int NIDX_, bool EXACT = false, int AS = 2>
 __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev ph, solve_args a)      // two waves per SIMD: the register budget (256 with the accumulator file) of eight frames per CU in the small build
 {
@@ -549,11 +551,12 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	const int njg = a.no_model_rows ? 0 : nj;                                             // joint groups
 	const int nt = a.lin_tail ? a.n_lin_tail[b] : 0, ngt = a.lin_tail ? a.n_tail_groups[b] : 0;      // the caller's rows from its first two-body row on, and the groups the host packed them into
 	const int n2 = nt + 3 * njg + 3 * nc, ng2 = ngt + njg + nc;
+	const bool seq_lin = ng2 > MAXG - 1;      // more groups than the level schedule has tables for (more than 96 contacts: physics.h:451-462 keeps every contact): one group per step, in row order
 	const int rec_cap = a.scratch_stride - HT_SCRATCH_TAIL;                               // rows of the frame's scratch slot that hold chain records
 	float *scr = a.scratch + (size_t)b * a.scratch_stride * CREC;
 	// the three arrays a build may be too small for (see the top of the file): in LDS when the frame fits, else in the tail of its scratch slot
 	const bool pool_lds = ng2 + 1 <= S.NGRP;
-	float *const gpool = scr + (size_t)rec_cap * CREC, *const garec = gpool + MAXG * LGRP;
+	float *const gpool = scr + (size_t)rec_cap * CREC, *const garec = gpool + MAXG_CAP * LGRP;
 	float *const pool = pool_lds ? S.pool : gpool;
 	if (ngt > 0)      // a caller's group may hold fewer than three rows: the slots no row fills change nothing (zero direction, zero limits)
 	{
@@ -639,7 +642,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 		float *og = o + LG_GB + 12 * kk;
 		og[0] = g0.x; og[1] = b0.x; og[2] = g0.y; og[3] = b0.y; og[4] = g0.z; og[5] = b0.z;
 		og[6] = g1.x; og[7] = b1.x; og[8] = g1.y; og[9] = b1.y; og[10] = g1.z; og[11] = b1.z;
-		if (kk == 0) { S.lrb[g][0] = (unsigned char)(rb0 >= 0 ? rb0 : 255); S.lrb[g][1] = (unsigned char)(rb1 >= 0 ? rb1 : 255); }
+		if (kk == 0 && g < MAXG) { S.lrb[g][0] = (unsigned char)(rb0 >= 0 ? rb0 : 255); S.lrb[g][1] = (unsigned char)(rb1 >= 0 ? rb1 : 255); }
 	}
 	if (lane < LGRP) pool[ng2 * LGRP + lane] = (lane >= LG_RINV && lane < LG_RINV + 3) ? 1.0f : lane == LG_META ? __int_as_float(IDLE_BODY | (IDLE_BODY << 8)) : 0.0f;      // idle group: zero direction, zero limits
 	if (lane == 0)
@@ -691,11 +694,13 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	{
 		// two-body linear groups: lane g (and g + 64) speaks for group g
 		int gb0[2], gb1[2];
+		const int ngs = seq_lin ? 0 : ng2;
 #pragma unroll
-		for (int s = 0; s < 2; s++) { const int g = lane + 64 * s; gb0[s] = g < ng2 ? S.lrb[g][0] : 255; gb1[s] = g < ng2 ? S.lrb[g][1] : 255; }
+		for (int s = 0; s < 2; s++) { const int g = lane + 64 * s; gb0[s] = g < ngs ? S.lrb[g][0] : 255; gb1[s] = g < ngs ? S.lrb[g][1] : 255; }
 		auto put_lorder = [&](int pos, int g, int s) { S.lorder[pos] = (unsigned)g | ((unsigned)(gb0[s] == 255 ? IDLE_BODY : gb0[s]) << 16) | ((unsigned)(gb1[s] == 255 ? IDLE_BODY : gb1[s]) << 24); };
 		auto put_lstart = [&](int step, int v) { S.lstart[step] = (unsigned short)v; };
-		const int nl = ng2 <= 64 ? level_schedule<1>(ng2, lane, gb0, gb1, put_lorder, put_lstart) : level_schedule<2>(ng2, lane, gb0, gb1, put_lorder, put_lstart);
+		int nl = ngs <= 64 ? level_schedule<1>(ngs, lane, gb0, gb1, put_lorder, put_lstart) : level_schedule<2>(ngs, lane, gb0, gb1, put_lorder, put_lstart);
+		if (seq_lin) nl = ng2;      // step L applies group L - 1 (linear_phase's entry())
 		// angular runs
 		int ar[2], ac[2];
 #pragma unroll
@@ -1184,6 +1189,13 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 		struct lset { unsigned e; int meta; float n0, n1, n2, g0, g1, g2, b0, b1, b2, minv; float4 s0, s1, s2; float q0, q1, q2, i0, i1, i2; };
 		auto entry = [&](int L) -> unsigned {
 			if (L > nlev_lin) return S.lorder[S.LIDLE];
+			if (seq_lin)      // no schedule: the first lane pair takes group L - 1, its bodies from the group's own record; the other pairs idle
+			{
+				const int meta = __float_as_int(pool_[(L - 1) * LGRP + LG_META]);
+				const unsigned r0 = (unsigned)meta & 255u, r1 = ((unsigned)meta >> 8) & 255u;
+				const unsigned e = (unsigned)(L - 1) | ((r0 == 255u ? (unsigned)IDLE_BODY : r0) << 16) | ((r1 == 255u ? (unsigned)IDLE_BODY : r1) << 24);
+				return pslot == 0 ? e : S.lorder[S.LIDLE];
+			}
 			int lo, hi;
 			if (L < 63) { lo = __builtin_amdgcn_readlane(ls_lin, L); hi = __builtin_amdgcn_readlane(ls_lin, L + 1); }
 			else { lo = S.lstart[L]; hi = S.lstart[L + 1]; }
@@ -1533,7 +1545,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 }
 
 static_assert(sizeof(lds_t<34, 584, 84, 0>) <= 20480, "the small build must leave room for eight frames per CU (160 KB of LDS)");
-static_assert(HT_SCRATCH_TAIL * HT_CREC >= MAXG * LGRP + (MAXA_CAP_OF(4) + 4) * AROW + HT_CREC, "the tail of a frame's scratch slot must hold its linear groups, its angular records and the tuning record");
+static_assert(HT_SCRATCH_TAIL * HT_CREC >= MAXG_CAP * LGRP + (MAXA_CAP_OF(4) + 4) * AROW + HT_CREC, "the tail of a frame's scratch slot must hold its linear groups, its angular records and the tuning record");
 void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solve_args &a, int B, hipStream_t s)
 {
 	// the build by what the host knows of the launch: the model's joints and the most points a frame of this call can carry.  A frame that exceeds

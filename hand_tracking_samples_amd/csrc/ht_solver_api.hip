@@ -465,7 +465,7 @@ extern "C" int ht_update_frames_dev(ht_ctx *ctx, const uint16_t *d_depth, const 
 	return HT_OK;
 }
 // Capacities of the contact kernel that the reference does not have: expanding-polytope runs cut short (128 iterations, 96 vertices, 192
-// triangles in LDS; hull.h:246 loops without bound), contacts beyond 96 per frame and launch, and solves whose angular rows exceed the 126
+// triangles in LDS; hull.h:246 loops without bound), touching samples beyond the 192 of a frame's pool, and solves whose angular rows exceed the 126
 // the solver keeps (a model with many ranged joints).  Counted since ht_create; 0 on every
 // workload of the test suite and the benches, so no result there depends on them.
 extern "C" int ht_capacity_events(ht_ctx *ctx, int *epa_cut_short, int *contacts_dropped, int *angular_rows_over)
@@ -867,7 +867,7 @@ extern "C" int ht_debug_solver_build(ht_ctx *ctx, int which)
 	{
 		ht_device_guard dev_guard_(ctx->device);
 		void *a = nullptr, *b = nullptr;
-		HIPCHK(ctx, hipMalloc(&a, (size_t)ctx->B * 512 * HT_ROW * sizeof(float))); ctx->allocs.push_back(a); ctx->d_exact_lin = (float *)a;
+		HIPCHK(ctx, hipMalloc(&a, (size_t)ctx->B * HT_EX_LIN * HT_ROW * sizeof(float))); ctx->allocs.push_back(a); ctx->d_exact_lin = (float *)a;
 		HIPCHK(ctx, hipMalloc(&b, (size_t)ctx->B * 256 * 8 * sizeof(float))); ctx->allocs.push_back(b); ctx->d_exact_ang = (float *)b;
 	}
 	ctx->solver_build = which;

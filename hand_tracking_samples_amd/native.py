@@ -392,7 +392,7 @@ class Context:
         self._chk(self.L.ht_stage_cloud_rows(self.h, which, stride, int(use_cam_origin), B, _f(rows), _i(n)))
         return rows, n
 
-    def stage_contacts(self, which, B, cap=96):
+    def stage_contacts(self, which, B, cap=192):
         c = np.empty((B, cap, CONTACT), np.float32); n = np.empty(B, np.int32)
         self._chk(self.L.ht_stage_contacts(self.h, which, B, cap, _f(c), _i(n)))
         return c, n

@@ -191,10 +191,11 @@ int ht_job_collect(ht_ctx *job, ht_ctx *main, int B, int *accepted_out);
  *                     handtrack.h:108-111), act2 [n][2304] after conv 4x4 + tanh + pool (layer 6), act3 [n][2048] after the first fully connected layer + tanh
  *                     (layer 8), logits [n][2304] after the second one (layer 9, before the chunked soft-max).  Any pointer may be NULL. */
 int ht_get_cnn_layers(ht_ctx *ctx, int first, int n, float *act1, float *act2, float *act3, float *logits);
-/* ht_capacity_events  how often, since ht_create, the contact kernel hit a capacity the reference does not have: expanding-polytope runs cut
- *                     short (gjk.h:417 / hull.h:233-310 loop without bound; here at most 128 iterations, 96 vertices, 192 triangles) and contacts
- *                     beyond 96 per frame and launch (physics.h:451-462 keeps them all); solves in which a model's angular rows exceeded the 126
- *                     the solver keeps.  All are 0 unless a scene or a model is out of the ordinary. */
+/* ht_capacity_events  how often, since ht_create, a kernel hit a capacity the reference does not have: expanding-polytope runs cut short (gjk.h:417 /
+ *                     hull.h:233-310 loop without bound; here at most 128 iterations, 96 vertices, 192 triangles); touching samples beyond the 192 the contact
+ *                     kernel's per-frame pool holds, or beyond 40 five-sample patches (physics.h:451-462 keeps them all; every sample the pool holds IS kept and
+ *                     solved -- 192 contacts per frame and launch since round 5, it was 96); solves in which a model's angular rows exceeded what the solver keeps.
+ *                     All are 0 unless a scene or a model is out of the ordinary. */
 int ht_capacity_events(ht_ctx *ctx, int *epa_cut_short, int *contacts_dropped, int *angular_rows_over);
 
 /* ---- training ----------------------------------------------------------------------------------------------------------

@@ -254,6 +254,81 @@ def test_contact_patch_extra_samples(tmp_path):
         ctx.close(); orc.close()
 
 
+def _clenched_model_and_state(tmp_path):
+    """the stock hand with the ignore lists among palm and finger bones cleared (bone 2 keeps its own, so the rewrite of handtrack.h:408-416 stays off) and those sixteen
+    bodies pushed into one another 5 cm above the palm's rest position: every pair of them touches"""
+    import sys
+    import htfx
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    from bench import _write_htfx
+    m = dict(htfx.load(ol.MODEL))
+    ign = m["ignore"].copy()
+    bodies = list(range(1, 17))
+    for i in bodies:
+        for j in bodies:
+            if i != j and i != 2 and j != 2:
+                ign[i, j] = 0
+    m["ignore"] = ign
+    path = str(tmp_path / "hand_clenched.htfx")
+    _write_htfx(path, m)
+    orc = ol.Oracle(None, model=path)
+    rest = orc.get_state(0)
+    s = rest.copy(); s[:, 7:] = 0
+    rng = np.random.default_rng(7)
+    for b in bodies:
+        s[b, :3] = rest[1, :3] + np.array([0.0, 0.0, 0.05], np.float32) + rng.normal(0, 0.004, 3).astype(np.float32)
+    return path, orc, s
+
+
+def test_more_than_96_contacts_are_kept(tmp_path):
+    """physics.h:451-462 keeps every contact FindShapeShapeContacts reports.  Until round 5 the device kept 96 per frame and counted the rest as dropped; now it keeps
+    every touching sample its per-frame pool holds (192) and k_solve applies the groups beyond its level schedule's tables one at a time in row order.  A scene with 109
+    contacts: (1) the contact list equals the restatement's entry by entry, from both contact kernels, and nothing is reported dropped; (2) FitPointCloud on that state
+    (no points: joint rows and the 327 collision rows) agrees with the restatement to the solver's tolerance, as does the rest pose in the slot beside it.  The exact-order
+    build through whole updates of this scene: tests/test_gpu_exact_solver.py."""
+    from hand_tracking_samples_amd import native
+    path, orc, s = _clenched_model_and_state(tmp_path)
+    ctx = native.Context(path, 4)
+    try:
+        ordinary = orc.get_state(0).copy(); ordinary[:, 7:] = 0      # the rest pose
+        orc.set_state(0, s)
+        buf = (ol.Contact * 256)()
+        k = orc.L.ho_find_contacts(orc.h, orc.model(0), buf, 256)
+        assert 96 < k <= 192, k
+        ref = np.array([[x.rb0, x.rb1, x.normal.x, x.normal.y, x.normal.z, x.p0w.x, x.p0w.y, x.p0w.z, x.p1w.x, x.p1w.y, x.p1w.z, x.separation] for x in buf[:k]], np.float32)
+        states = np.stack([s, ordinary])
+        for kernel in (0, 1, 2):      # the launcher's choice, cooperative, lane per pair
+            ctx.debug_contact_kernel(kernel)
+            ctx.set_state(0, states)
+            c, n = ctx.stage_contacts(0, 2, cap=192)
+            print("contact kernel %d: %d contacts on the device, %d in the restatement" % (kernel, n[0], k))
+            assert n[0] == k
+            assert np.array_equal(c[0, :k], ref)
+            assert ctx.capacity_events() == (0, 0, 0)
+        ctx.debug_contact_kernel(0)
+        # FitPointCloud without points: joints + collisions
+        empty = [np.zeros((0, 3), np.float32)] * 2
+        none_l = [np.zeros((0, 16), np.float32)] * 2; none_a = [np.zeros((0, 8), np.float32)] * 2
+        want = []
+        for st in states:
+            orc.set_state(0, st)
+            A = (ol.Angular * 16)(); L = (ol.Linear * 1)(); nn = C.c_int(0); z = ol.F3(0, 0, 0)
+            orc.L.ho_enhancements(orc.h, orc.model(0), A, C.byref(nn), 0, z, z, 0)
+            orc.L.ho_fit_pointcloud(orc.h, orc.model(0), ol.f3ptr(np.zeros((1, 3), np.float32)), 0, L, 0, A, 0, 3.0)
+            want.append(orc.get_state(0).copy())
+        ctx.set_state(0, states)
+        ctx.fit_rows(0, empty, none_l, none_a, microforce=3.0)
+        got = ctx.get_state(0, 2)
+        for f in range(2):
+            dp = np.abs(got[f][:, :3] - want[f][:, :3]).max(); dq = np.abs(got[f][:, 3:7] - want[f][:, 3:7]).max(); dm = np.abs(got[f][:, 7:13] - want[f][:, 7:13]).max()
+            print("FitPointCloud on %s: |dpos| %.2e |dquat| %.2e |dmom| %.2e" % ("109 contacts" if f == 0 else "the rest pose", dp, dq, dm))
+            assert dp <= TIGHT_POS_TOL and dq <= TIGHT_QUAT_TOL
+        assert ctx.capacity_events() == (0, 0, 0)
+        ctx.debug_solver_build(0)
+    finally:
+        ctx.close(); orc.close()
+
+
 def test_nan_in_the_tracked_state_ends_in_the_sanity_check_reset(ctx, weights):
     """SanityCheck (physmodel.h:437-442, called at the end of every FitPointCloud, :355): a body whose state holds a NaN is put back to its start pose with zero momenta.
     A NaN written into the hand model's carried state (one body's angular momentum; another tracker's wrist position) spreads through the joint rows to every body during

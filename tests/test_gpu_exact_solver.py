@@ -111,6 +111,38 @@ def test_exact_order_solver_under_the_products_launch_sequence(weights):
     assert res[8][0][4].sum() >= 4      # reset frames took the lapped chain
 
 
+def test_exact_order_solver_with_more_than_96_contacts(weights, tmp_path):
+    """physics.h:451-462 keeps every contact.  The clenched scene of tests/test_gpu_edges.py (109 contacts at the start) through two whole updates -- the job's five
+    MultiStepSim steps and the three main passes all solve more contacts than k_solve's level schedule has tables for: with the exact-order sweeps the device equals the
+    restatement bit for bit, nothing is dropped."""
+    from hand_tracking_samples_amd import native
+    from test_gpu_edges import _clenched_model_and_state
+    path, orc, s = _clenched_model_and_state(tmp_path)
+    orc.close()
+    depth = np.stack([FR["depth"][0].reshape(-1), np.zeros(4096, np.uint16)])
+    cams = np.stack([FR["cam"][0], FR["cam"][0]]); start = np.stack([s[:, :7], s[:, :7]])
+    ctx = native.Context(path, 2)
+    try:
+        ctx.load_weights(weights)
+        ctx.set_params(microforce=3.0, mainthreadpasses=3)
+        ctx.debug_solver_build(5)
+        ctx.tracker_reset(start)
+        c0, n0 = ctx.stage_contacts(0, 2, cap=192)
+        assert n0.min() > 96
+        cnn = []; poses = []; others = []; hands = []
+        for u in range(2):
+            p, c = ctx.update_sync(depth, cams, want_cnn=True)
+            poses.append(p); cnn.append(c); others.append(ctx.get_state(1, 2)); hands.append(ctx.get_state(0, 2))
+        assert ctx.capacity_events() == (0, 0, 0)
+    finally:
+        ctx.close()
+    user, other, hand, _ = _restatement_with_cnn(weights, cnn, updates=2, model=path, depth=depth, cams=cams, start=start)
+    for u in range(2):
+        for i in range(2):
+            assert np.array_equal(others[u][i], other[u, i]) and np.array_equal(hands[u][i], hand[u, i]) and np.array_equal(poses[u][i], user[u, i]), (u, i)
+    print("more than 96 contacts (%s at the start), exact-order solver against the restatement: two updates bit for bit" % n0.tolist())
+
+
 def test_exact_order_solver_on_config5_end_to_end_26_bones():
     """The same statement for BASELINE configs[4] end to end (tests/test_config5_e2e.py): 128x128 frames, the 128x128-input net, 26 bones -- 325 body pairs, two
     chain rounds per sweep, the cloned fingers in permanent contact (15 expanding-polytope runs per frame).  Exact-order sweeps: bit for bit on all 64 frames."""
