@@ -773,8 +773,7 @@ static_assert(HT_MAXCONTACT >= GJK_POOL, "every touching sample the pool holds i
 #define GJK_JMAX 40         // pairs per frame whose contact patch takes the four extra samples
 #define CO_NW 8             // waves per block
 #define CO_MAXF 4           // frames per block (as many as the LDS holds)
-#define CO_WORK_PATCH 2     // weight of a five-sample patch (four more runs on one pair) and of a polytope run in a frame's work estimate, in candidate pairs
-#define CO_WORK_EPA 12
+#define CO_WORK_PATCH 2     // weight of a five-sample patch (four more runs on one pair) in a frame's work estimate, in candidate pairs
 #define CO_OWN 4            // owner waves per round: 256 runs in flight
 #define CO_EPAQ 32          // polytope jobs per queue round
 struct gjk_sample { float n[3], p0[3], p1[3], sep; int key, flag; };      // key = candidate * 8 + sample number; flag 1 = counts as a contact
@@ -1210,7 +1209,7 @@ __global__ __launch_bounds__(64 * CO_NW) void k_contacts_coop(ht_model_dev M, co
 			}
 		}
 		if (live && lane == 0) { ncontacts[b] = total < HT_MAXCONTACT ? total : HT_MAXCONTACT; if (total > HT_MAXCONTACT && caps) atomicAdd(caps + 1, total - HT_MAXCONTACT); }
-		if (live && lane == 0 && work_out) work_out[b] = F.ncand + CO_WORK_PATCH * F.njig + CO_WORK_EPA * F.nepa;      // what the frame cost this launch, for the next update's assignment
+		if (live && lane == 0 && work_out) work_out[b] = (F.ncand + CO_WORK_PATCH * F.njig) | (F.nepa << 16);      // what the frame took this launch, for the next update's assignment (k_contact_order)
 		if (HT_DBG(dbg, 2048) && live && lane == 0 && total < HT_MAXCONTACT - 2)      // timing experiments: per-frame statistics accumulate in the last two contact slots
 		{
 			float *o = contacts + ((size_t)b * HT_MAXCONTACT + HT_MAXCONTACT - 1) * HT_CONTACT;
@@ -1234,19 +1233,45 @@ int ht_contacts_frames_per_block(const ht_model_dev &M, int B)
 	while (nfr > 1 && fixed + nfr * sizeof(co_frame) > 160 * 1024) nfr--;
 	return B < nfr ? B : nfr;
 }
-// The frames of a launch sorted by the work they took in the same launch of the previous update (heaviest first; ties by frame index) and dealt back and forth over
-// the blocks: order[slot * blocks + block] = frame, B = no frame.  One block per launch slot of an update (work / order: [slots][stride]); the ranks by counting, the
-// works in LDS.  Runs beside the CNN at the head of an update: off every critical path.
-__global__ __launch_bounds__(1024) void k_contact_order(const int *__restrict__ work, int *__restrict__ order, int B, int nfr, int stride, unsigned slots)
+// The frames of a launch dealt to the blocks by what they took in the same launch of the PREVIOUS update (poses move little between updates).  A block's time is its
+// scan rounds (latency: about the same for one frame's runs as for four frames') plus, when any of its frames has a run whose simplex encloses the origin, its polytope
+// phases, which cost about one run's time whether one wave or all eight have a job.  So the frames WITH polytope runs are gathered -- sorted by their number of runs and
+// dealt back and forth, epb to a block, over as few blocks as that takes, which go first in the grid; the lightest of the other frames fill those blocks up -- and the
+// rest, sorted by their candidate pairs, are dealt back and forth over the remaining blocks: fewer blocks pay a polytope phase at all.  epb: all of a block's frames
+// when the batch takes several rounds per CU (the sum of the blocks' times counts, and the long blocks start first), fewer when every block has a CU of its own (the
+// slowest block is the launch's time, and a block of four such frames would be it).
+// work = candidates + 2 x patches | polytope runs << 16 (k_contacts_coop); order[slot * blocks + block] = frame, B = no frame.  One block per launch slot of an
+// update and segment of 4096 frames (work / order: [slots][stride]); ranks by counting, the keys in LDS.  Runs beside the CNN at the head of an update: off every critical path.
+#define CO_ORDER_SEG 4096      // frames a block of k_contact_order ranks (by counting: quadratic); a larger batch is dealt segment by segment, each over its own blocks
+__global__ __launch_bounds__(1024) void k_contact_order(const int *__restrict__ work, int *__restrict__ order, int Ball, int nfr, int stride, unsigned slots, int epb)
 {
 	extern __shared__ int ko_w[];
+	__shared__ int ko_ne;
 	if (!((slots >> blockIdx.x) & 1u)) return;
-	const int *w = work + (size_t)blockIdx.x * stride;
+	const int seg = (CO_ORDER_SEG / nfr) * nfr, f0 = blockIdx.y * seg, B = Ball - f0 < seg ? Ball - f0 : seg;      // this block's frames: [f0, f0 + B)
+	const int blocks_all = (Ball + nfr - 1) / nfr, b0 = f0 / nfr;
+	const int *w = work + (size_t)blockIdx.x * stride + f0;
 	int *o = order + (size_t)blockIdx.x * stride;
 	const int blocks = (B + nfr - 1) / nfr, B4 = (B + 3) & ~3;
-	for (int i = threadIdx.x; i < B4; i += 1024) ko_w[i] = i < B ? w[i] : -1;
-	for (int i = threadIdx.x; i < blocks * nfr; i += 1024) o[i] = B;
+	if (threadIdx.x == 0) ko_ne = 0;
 	__syncthreads();
+	int mine = 0;
+	for (int i = threadIdx.x; i < B4; i += 1024)
+	{
+		const int v = i < B ? w[i] : -1;
+		const int runs = v < 0 ? 0 : (v >> 16), pairs = v < 0 ? 0 : (v & 0xffff);
+		ko_w[i] = v < 0 ? -1 : ((runs > 1023 ? 1023 : runs) << 20) | pairs;
+		mine += runs > 0 ? 1 : 0;
+	}
+	if (mine) atomicAdd(&ko_ne, mine);
+	for (int i = threadIdx.x; i < blocks * nfr; i += 1024) o[(i / blocks) * blocks_all + b0 + i % blocks] = Ball;
+	__syncthreads();
+	const int ne = ko_ne, ng = B - ne;                      // frames with polytope runs (the first ne places of the sorted order) and without
+	if (epb > nfr) epb = nfr;
+	if (epb * blocks < ne) epb = (ne + blocks - 1) / blocks;
+	const int neb = (ne + epb - 1) / epb, ngb = blocks - neb;      // blocks that get frames with polytope runs, epb each, and the others
+	const int nfree = neb * nfr - ne;                       // places left in the first kind: the LIGHTEST frames without runs fill them
+	const int nheavy = ng - nfree > 0 ? ng - nfree : 0;     // frames without runs that go to the second kind
 	for (int i = threadIdx.x; i < B; i += 1024)
 	{
 		const int wi = ko_w[i];
@@ -1256,13 +1281,18 @@ __global__ __launch_bounds__(1024) void k_contact_order(const int *__restrict__ 
 			const int4 k = *reinterpret_cast<const int4 *>(ko_w + j);
 			rank += ((k.x > wi || (k.x == wi && j < i)) ? 1 : 0) + ((k.y > wi || (k.y == wi && j + 1 < i)) ? 1 : 0) + ((k.z > wi || (k.z == wi && j + 2 < i)) ? 1 : 0) + ((k.w > wi || (k.w == wi && j + 3 < i)) ? 1 : 0);
 		}
-		const int round = rank / blocks, pos = rank - round * blocks;
-		o[round * blocks + ((round & 1) ? blocks - 1 - pos : pos)] = i;
+		int nb_, base, r;
+		if (rank < ne) { nb_ = neb; base = 0; r = rank; }                                        // place r of the first kind's grid (neb wide, round by round)
+		else if (rank - ne < nheavy) { nb_ = ngb; base = neb; r = rank - ne; }                   // place r of the second kind's grid
+		else { nb_ = neb; base = 0; r = ne + (rank - ne - nheavy); }                             // the lightest: the places the first kind has left
+		const int round = r / nb_, pos = r - round * nb_;
+		o[round * blocks_all + b0 + base + ((round & 1) ? nb_ - 1 - pos : pos)] = f0 + i;
 	}
 }
-void ht_launch_contact_order(const int *work, int *order, int B, int nfr, int stride, unsigned slots, int nslots, hipStream_t s)
+void ht_launch_contact_order(const int *work, int *order, int B, int nfr, int stride, unsigned slots, int nslots, int epb, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_contact_order, dim3(nslots), dim3(1024), (size_t)((B + 3) & ~3) * sizeof(int), s, work, order, B, nfr, stride, slots);
+	const int seg = (CO_ORDER_SEG / nfr) * nfr, nseg = (B + seg - 1) / seg;
+	hipLaunchKernelGGL(k_contact_order, dim3(nslots, nseg), dim3(1024), (size_t)(((B < seg ? B : seg) + 3) & ~3) * sizeof(int), s, work, order, B, nfr, stride, slots, epb);
 }
 void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s, bool beside_cloud_rows, int force_kernel, int few_frames,
                         const int *order, int *work_out)

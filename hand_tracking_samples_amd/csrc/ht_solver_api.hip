@@ -90,9 +90,13 @@ static void contact_orders(ht_ctx *ctx, int B, hipStream_t t)
 {
 	const int nfr = ht_contacts_frames_per_block(ctx->model, B);
 	ctx->corder_mask = 0;
-	if (ctx->d_cwork && ctx->cwork_B == B && ctx->cwork_mask && nfr > 1 && B <= 4096 && B + 8 <= ctx->cstride && ctx->contact_kernel != 2)
+	if (ctx->d_cwork && ctx->cwork_B == B && ctx->cwork_mask && nfr > 1 && B + 8 <= ctx->cstride && ctx->contact_kernel != 2)
 	{
-		ht_launch_contact_order(ctx->d_cwork, ctx->d_corder, B, nfr, ctx->cstride, ctx->cwork_mask, HT_CONTACT_SLOTS, t);
+		// frames with polytope runs per block: every block a CU of its own (the slowest block is the launch's time) -> one; several rounds per CU (the sum counts) -> all.
+		// tools/exp_contact_epb.sh at 1024 frames, 1 / 2 / 3 / 4 per block: slowest block 329 / 339 / 355 / 369 k cycles, mean frame 2.13 / 2.11 / 2.05 / 2.01 M cycles per step
+		static const int epb_env = ht_tuning_int("HT_CONTACT_EPB", 0);      // -DHT_TUNING builds: pins it
+		const int blocks = (B + nfr - 1) / nfr;
+		ht_launch_contact_order(ctx->d_cwork, ctx->d_corder, B, nfr, ctx->cstride, ctx->cwork_mask, HT_CONTACT_SLOTS, epb_env > 0 ? epb_env : blocks > ctx->n_cu ? nfr : 1, t);
 		ctx->corder_mask = ctx->cwork_mask;
 	}
 	ctx->cwork_mask = 0; ctx->cwork_B = B;
