@@ -24,6 +24,7 @@ struct solve_args
 	const float *sf_crays; int sf_ncray; int sf_select; float sf_spoint[3], sf_rbpoint[3]; const float *sf_refpose; int sf_hold;
 	int *caps;                                                      // capacity counter: frames x launches whose angular rows exceeded the LDS records (may be null)
 	int shared_gpu;                                                 // other kernels run beside this launch (the reset path): keep the small LDS footprint
+	const int *frame_order; int *cost_out;                          // batches of several rounds per CU: block i takes frame frame_order[i] (the frames by what they took in the same launch of the previous update, longest first, so that the launch ends on short ones); cost_out [B]: what each took now.  Both may be null
 	int two_body_levels;                                            // tests only (ht_debug_solver_build 7): the two-body rows by the level schedule for every frame, as until round 4 (otherwise only frames the blocked form does not hold)
 	int force_build;                                                // 0: the launcher chooses k_solve's build; 1 small, 2 only, 3 mid, 4 tiny (every array in HBM): ht_debug_solver_build
 	// the last solve of an update also delivers the poses (GetPoseUser physmodel.h:434 + the "initializing = 50" rule of handtrack.h:781-782), instead of a launch of its own
@@ -51,6 +52,7 @@ void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftma
                         const int *order = nullptr, int *work_out = nullptr);      // order / work_out (cooperative kernel only, both may be null): the frame of every (slot, block) as k_contact_order dealt them; where every live frame leaves what it cost
 int ht_contacts_frames_per_block(const ht_model_dev &M, int B);
 #define HT_CONTACT_SLOTS 16      // unmasked contact launches of an update that keep a work history: MultiStepSim step st -> slot st (< 8), main-thread pass i -> slot 8 + i
+void ht_launch_rank_desc(const int *work, int *order, int B, int stride, unsigned slots, int nslots, hipStream_t s);      // order[slot][.] = the frames of every 4096-frame segment by work[slot][.], largest first
 void ht_launch_contact_order(const int *work, int *order, int B, int nfr, int stride, unsigned slots, int nslots, int epb, hipStream_t s);
 size_t ht_contacts_workspace_bytes(int B);
 void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solve_args &a, int B, hipStream_t s);

@@ -321,8 +321,10 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 {
 	__shared__ lds_t<NGRP_, NSUM_, NANG_, NIDX_, AS> S;
 	constexpr int ASLOTS = AS, MAXA2 = MAXA2_OF(AS), MAXA_LDS = MAXA_CAP_OF(AS);
-	const int b = blockIdx.x, lane = threadIdx.x;
+	const int lane = threadIdx.x;
+	const int b = a.frame_order ? a.frame_order[blockIdx.x] : (int)blockIdx.x;      // which frame: results do not depend on it, only when the frame's turn comes
 	if (a.active_flag && !a.active_flag[b]) return;                // a launch never touches another launch's frames
+	const long long t_cost = a.cost_out ? clock64() : 0;
 	const long long t_entry = HT_DBG(a.dbg, 2048) ? clock64() : 0;
 	const int nb = M.nb, nj = M.nj;
 	float *st = a.state + (size_t)b * nb * HT_STATE_STRIDE;
@@ -1542,6 +1544,35 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 			if (lane == 0 && a.out_npts[b] < a.out_min_point_num) a.out_initializing[b] = 50;
 		}
 	}
+	if (a.cost_out && lane == 0) a.cost_out[b] = (int)((clock64() - t_cost) >> 4);      // what the frame took: the next update's launch order (ht_launch_rank_desc)
+}
+
+// order[slot][f0 + r] = the frame of segment [f0, f0 + 4096) with the r-th largest work[slot][.] (ties by index): ranks by counting, the works in LDS; a block per slot
+// whose bit is set in `slots` and segment.  For launches whose blocks outnumber the resident ones several times: taken in this order the launch ends on short frames.
+__global__ __launch_bounds__(1024) void k_rank_desc(const int *__restrict__ work, int *__restrict__ order, int Ball, int stride, unsigned slots)
+{
+	__shared__ int rk_w[4096];
+	if (!((slots >> blockIdx.x) & 1u)) return;
+	const int f0 = blockIdx.y * 4096, B = Ball - f0 < 4096 ? Ball - f0 : 4096, B4 = (B + 3) & ~3;
+	const int *w = work + (size_t)blockIdx.x * stride + f0;
+	int *o = order + (size_t)blockIdx.x * stride + f0;
+	for (int i = threadIdx.x; i < B4; i += 1024) rk_w[i] = i < B ? w[i] : -1;
+	__syncthreads();
+	for (int i = threadIdx.x; i < B; i += 1024)
+	{
+		const int wi = rk_w[i];
+		int rank = 0;
+		for (int j = 0; j < B4; j += 4)
+		{
+			const int4 k = *reinterpret_cast<const int4 *>(rk_w + j);
+			rank += ((k.x > wi || (k.x == wi && j < i)) ? 1 : 0) + ((k.y > wi || (k.y == wi && j + 1 < i)) ? 1 : 0) + ((k.z > wi || (k.z == wi && j + 2 < i)) ? 1 : 0) + ((k.w > wi || (k.w == wi && j + 3 < i)) ? 1 : 0);
+		}
+		o[rank] = f0 + i;
+	}
+}
+void ht_launch_rank_desc(const int *work, int *order, int B, int stride, unsigned slots, int nslots, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_rank_desc, dim3(nslots, (B + 4095) / 4096), dim3(1024), 0, s, work, order, B, stride, slots);
 }
 
 static_assert(sizeof(lds_t<34, 584, 84, 0>) <= 20480, "the small build must leave room for eight frames per CU (160 KB of LDS)");

@@ -32,8 +32,13 @@ static void exact_args(ht_ctx *ctx, solve_args &a, bool cloud)
 	a.exact_lin = ctx->d_exact_lin; a.exact_ang = ctx->d_exact_ang;
 	if (exact_solver(ctx) && cloud) { a.rows_cloud = ctx->d_rows; a.cloud_body = nullptr; }
 }
+// Solves of an update that keep a history (the slots of the contact launches: MultiStepSim step st -> st, main pass i -> 8 + i), for batches that take several rounds
+// per CU: k_solve notes what every frame took, the next update's launch of the same slot takes the frames longest first (contact_orders ranks them beside the net), so
+// that the launch ends on short frames instead of waiting for a long one that started last.  Results do not depend on the order.
+static bool solve_history_on(const ht_ctx *ctx, int B) { return ctx->d_swork && B > ctx->n_cu * 8 && B + 8 <= ctx->cstride; }
 static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int *n_pre, bool cloud, bool contacts, const int *active,
-                       int apply_angles, float drive_force, int ray_rows, int arm_cone, int zero_momenta, int B, hipStream_t s, bool shared_gpu = false, float *poses_out = nullptr, const int *out_npts = nullptr)
+                       int apply_angles, float drive_force, int ray_rows, int arm_cone, int zero_momenta, int B, hipStream_t s, bool shared_gpu = false, float *poses_out = nullptr, const int *out_npts = nullptr,
+                       int hist_slot = -1)
 {
 	solve_args a;
 	memset(&a, 0, sizeof a);
@@ -50,6 +55,12 @@ static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int 
 	a.shared_gpu = shared_gpu ? 1 : 0;
 	exact_args(ctx, a, cloud);
 	a.out_poses = poses_out; a.out_npts = out_npts; a.out_initializing = ctx->d_initializing; a.out_min_point_num = ctx->par.min_point_num;
+	if (hist_slot >= 0 && hist_slot < HT_CONTACT_SLOTS && !active && !exact_solver(ctx) && solve_history_on(ctx, B) && B == ctx->swork_B)
+	{
+		a.cost_out = ctx->d_swork + (size_t)hist_slot * ctx->cstride;
+		ctx->swork_mask |= 1u << hist_slot;
+		if ((ctx->sorder_mask >> hist_slot) & 1u) a.frame_order = ctx->d_sorder + (size_t)hist_slot * ctx->cstride;
+	}
 	ht_launch_solve(ctx->model, ctx->phys, a, B, s);
 }
 // Fork/join helpers: the row-producing kernels of one fit step only read the pose, so they run side by side on two extra streams
@@ -100,6 +111,13 @@ static void contact_orders(ht_ctx *ctx, int B, hipStream_t t)
 		ctx->corder_mask = ctx->cwork_mask;
 	}
 	ctx->cwork_mask = 0; ctx->cwork_B = B;
+	ctx->sorder_mask = 0;
+	if (solve_history_on(ctx, B) && ctx->swork_B == B && ctx->swork_mask)
+	{
+		ht_launch_rank_desc(ctx->d_swork, ctx->d_sorder, B, ctx->cstride, ctx->swork_mask, HT_CONTACT_SLOTS, t);
+		ctx->sorder_mask = ctx->swork_mask;
+	}
+	ctx->swork_mask = 0; ctx->swork_B = B;
 }
 static void fork(ht_ctx *ctx, hipStream_t s) { (void)hipEventRecord(ctx->ev_fork, s); for (int i = 0; i < 2; i++) (void)hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0); }
 static void fork1(ht_ctx *ctx, hipStream_t s, int i) { (void)hipEventRecord(ctx->ev_fork, s); (void)hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0); }
@@ -133,7 +151,7 @@ static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int 
 		}
 		if (part == 1) continue;
 		ht_prof_scope ps(ctx, prof ? "solve" : nullptr, s);
-		solve_step(ctx, 1, nullptr, nullptr, cloud, coll, active, angles, st < p.steps_palmangle ? 10000.0f : 0.0f, rays, 1, 1, B, s, shared_gpu);
+		solve_step(ctx, 1, nullptr, nullptr, cloud, coll, active, angles, st < p.steps_palmangle ? 10000.0f : 0.0f, rays, 1, 1, B, s, shared_gpu, nullptr, nullptr, st < 8 ? st : -1);
 	}
 }
 // one main-thread pass of HandTracker::update (handtrack.h:769-780)
@@ -154,7 +172,7 @@ static void main_pass(ht_ctx *ctx, int B, hipStream_t s, float *poses_out = null
 	if (par) { mark("  pass: cloud rows done", ctx->side[0]); mark("  pass: chamber done", ctx->side[1]); }
 	if (par) join(ctx, s, 2);
 	ht_prof_scope ps(ctx, "solve", s);
-	solve_step(ctx, 0, ctx->d_chamber, ctx->d_nchamber, true, coll, nullptr, 0, 0.0f, 0, 0, 0, B, s, false, poses_out, npts);
+	solve_step(ctx, 0, ctx->d_chamber, ctx->d_nchamber, true, coll, nullptr, 0, 0.0f, 0, 0, 0, B, s, false, poses_out, npts, pass >= 0 && pass < 8 ? 8 + pass : -1);
 }
 // Behind the join of the side stream, so nothing of the step waits for it: the running counts of reset frames go to the host (ht_host.hpp: d_nreset).  The
 // update's stream picks the copy up again at its very end (reset_tail_join: long finished by then) -- every stream of an update has to come back to the
