@@ -82,9 +82,9 @@ def _load_frames(n, first=0):
 
 
 def _load_frames5(n, first=0):
-    """BASELINE configs[4]: 64 distinct 128x128 frames of the 26-bone hand (tests/golden/make_frames5.py), repeated"""
+    """BASELINE configs[4]: 256 distinct 128x128 frames of the 26-bone hand (animation-bank row 3 + 9 i, ref_harness fullframes: tools/regen_goldens.sh), repeated"""
     import numpy as np
-    z = np.load(os.path.join(ROOT, "tests", "golden", "frames5_64.npz"))
+    z = np.load(os.path.join(ROOT, "tests", "golden", "frames5_256.npz"))
     return (_tile(z["depth"], n, first).astype(np.uint16), _tile(z["cam"], n, first).astype(np.float32), _tile(z["startpose"], n, first).astype(np.float32))
 
 
@@ -101,17 +101,17 @@ def _reference_poses(which, take_cnn=False):
                 "tests/golden/%s.htfx (the reference's unit of work on every frame, ref_harness poses%s)" % (name, " ... takecnn" if take_cnn else ""),
                 np.load(os.path.join(G, "ref_spread1024_takecnn.npz" if take_cnn else "ref_spread1024.npz")))
     if which == "config5":
-        f = htfx.load(os.path.join(G, "poses5full.htfx"))
-        return {"user": f["uw_pose_user"], "other": f["other_pose"], "initializing": f["flags"][:, 1].astype(np.int32)}, "tests/golden/poses5full.htfx (the reference's HandTracker on the 128x128 frames, 26 bones, ref_harness posesfull)", None
-    f = htfx.load(os.path.join(G, "e2e128.htfx"))
-    return {"user": f["all/uw_pose_user"], "other": f["all/other_pose"], "initializing": f["all/flags"][:, 1].astype(np.int32)}, "tests/golden/e2e128.htfx all/ (the reference's stage functions and layer classes, ref_harness e2e128)", None
+        f = htfx.load(os.path.join(G, "poses5full256.htfx"))
+        return {"user": f["uw_pose_user"], "other": f["other_pose"], "initializing": f["flags"][:, 1].astype(np.int32)}, "tests/golden/poses5full256.htfx (the reference's HandTracker on the 256 128x128 frames, 26 bones, ref_harness posesfull)", np.load(os.path.join(G, "ref_spread5_256.npz"))
+    f = htfx.load(os.path.join(G, "e2e128_256.htfx"))
+    return {"user": f["all/uw_pose_user"], "other": f["all/other_pose"], "initializing": f["all/flags"][:, 1].astype(np.int32)}, "tests/golden/e2e128_256.htfx all/ (the reference's stage functions and layer classes on the 256 frames, ref_harness e2e128)", np.load(os.path.join(G, "ref_spread5e2e_256.npz"))
 
 
-def verify_poses(got, other, initializing, ref, idx, against, spread, take_cnn=False):
+def verify_poses(got, other, initializing, ref, idx, against, spread, take_cnn=False, ill_conditioned=False):
     """Every distinct frame of the timed batch against the reference's result for it: the user poses AND othermodel (the CNN-driven half of the step) AND the
-    tracker's `initializing` flag.  With the per-frame spread of the reference's own FMA builds at hand (the 64x64 workloads) the rule is tests/parity_rule.py, the one
+    tracker's `initializing` flag.  With the per-frame spread of the reference's own FMA builds at hand (tests/golden/ref_spread*.npz: every workload since round 5) the rule is tests/parity_rule.py, the one
     tests/test_gpu_batch_parity.py asserts: finite; a frame outside 2e-5 m / 2e-4 only where the reference's own builds are, by at most twice their move; nothing
-    beyond 5e-3 m / 5e-2.  Without it (configs[4]: 64 distinct frames) the band counts with the same absolute cap, othermodel by its percentiles."""
+    beyond 5e-3 m / 5e-2.  Without it (configs[4]: 256 distinct frames) the band counts with the same absolute cap, othermodel by its percentiles."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import parity_rule as pr
@@ -121,16 +121,21 @@ def verify_poses(got, other, initializing, ref, idx, against, spread, take_cnn=F
     fr = np.array(sorted(first)); sl = np.array([first[i] for i in fr])
     out = {"against": against, "frames_compared": int(len(fr)), "tol": [VERIFY_POS_TOL, VERIFY_QUAT_TOL]}
     if spread is not None:
-        def distribution(dev, key):      # CNN-driven poses: no frame-by-frame yardstick against the fixture (tests/test_gpu_batch_parity.py has it against the restatement fed with the device's heat-maps)
+        def distribution(dev, key, cap=pr.CAP_TAKE_CNN):      # CNN-driven poses: no frame-by-frame yardstick against the fixture (tests/test_gpu_batch_parity.py has it against the restatement fed with the device's heat-maps)
             dp, dq = pr.pose_diff(np.nan_to_num(dev[sl], nan=1e9), ref[key][fr]); sp, sq = pr.spread_of(spread, key, fr)
             pd, ps = np.percentile(np.maximum(dp, dq), [50, 90, 99]), np.percentile(np.maximum(sp, sq), [50, 90, 99])
             nd, ns = int(((dp > pr.TIGHT[0]) | (dq > pr.TIGHT[1])).sum()), int(((sp > pr.TIGHT[0]) | (sq > pr.TIGHT[1])).sum())
-            ok = bool(np.isfinite(dev).all() and (pd <= 2 * ps).all() and nd <= ns and dp.max() <= pr.CAP_TAKE_CNN[0] and dq.max() <= pr.CAP_TAKE_CNN[1])
+            ok = bool(np.isfinite(dev).all() and (pd <= 2 * ps).all() and nd <= ns and dp.max() <= cap[0] and dq.max() <= cap[1])
             return ok, {"p50_p90_p99": [float(x) for x in pd], "reference_fma_builds_p50_p90_p99": [float(x) for x in ps], "frames_outside_2e-5m_2e-4": nd, "reference_fma_builds_outside": ns,
                         "max_abs_dpos_m": float(dp.max()), "max_abs_dquat": float(dq.max()), "within_2e-5m_2e-4": int(len(fr) - nd), "within_2e-4m_2e-3": int(((dp <= pr.LOOSE[0]) & (dq <= pr.LOOSE[1])).sum())}
         if take_cnn:
             uok, ud = distribution(got, "user")
             out.update(ud); out["rule"] = "always_take_cnn: user poses and othermodel are CNN-driven: percentiles <= 2x and no more frames outside the tight band than the reference's own FMA builds, cap 0.1 m / 1.0"
+        elif ill_conditioned:
+            # configs[4]'s 26-bone hand (cloned fingers in permanent contact, 15 polytope runs per frame) amplifies a rounding difference on ~10 % of its frames in EVERY build, and which
+            # frames depends on the perturbation (the reference's two FMA builds disagree with each other on them): the frames outside the band are held by number and size, not by name
+            uok, ud = distribution(got, "user", pr.CAP)
+            out.update(ud); out["rule"] = "configs[4] (ill-conditioned model): user poses by distribution -- percentiles <= 2x and no more frames outside 2e-5 m / 2e-4 than the reference's own FMA builds, cap 5e-3 m / 5e-2; othermodel the same with cap 0.1 m / 1.0"
         else:
             u = pr.summary(got[sl], ref["user"][fr], *pr.spread_of(spread, "user", fr))
             uok = u["ok"]
@@ -427,7 +432,7 @@ def main():
 
     # this rank's contiguous shard of the global frame list; the list walks the distinct frames round and round, every rank's shard starting 131 frames further on
     # ("same generators, different animbank offsets"), so ranks do not work on identical batches (hand_tracking_samples_amd/shard.py)
-    ndistinct = 64 if frames5 else 1024
+    ndistinct = 256 if frames5 else 1024
     frame_idx = rank_frames(B, rank, world, ndistinct)      # which distinct frame every slot carries
     depth, cams, start = (_load_frames5 if frames5 else _load_frames)(len(frame_idx), int(frame_idx[0]))
     gold = None
@@ -538,7 +543,7 @@ def main():
         elif not cnn_only:
             refp, against, spread = _reference_poses(wl, args.always_take_cnn)
             _pfe, ini = ctx.tracker_flags(B)
-            verify = verify_poses(d_poses.cpu().numpy(), ctx.get_state(1, B)[:, :, :7], ini, refp, frame_idx, against, spread, args.always_take_cnn)
+            verify = verify_poses(d_poses.cpu().numpy(), ctx.get_state(1, B)[:, :, :7], ini, refp, frame_idx, against, spread, args.always_take_cnn, ill_conditioned=cfg5)
             verify["capacity_events"] = list(ctx.capacity_events())
             if wl == "config5":
                 verify["frames_overflow"] = ctx.frames_overflow()

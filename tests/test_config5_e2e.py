@@ -76,6 +76,62 @@ def test_oracle_reproduces_all_64_bench_frames(oracle):
         assert oracle.flags()[:2] == (G["all/flags"][i][0], int(G["all/flags"][i][1])), i
 
 
+G256 = htfx.load(os.path.join(HERE, "golden", "e2e128_256.htfx"))      # the bench's configs[4] batch: 256 distinct frames, the reference's results for all of them (all/ only)
+FR256 = np.load(os.path.join(HERE, "golden", "frames5_256.npz"))
+
+
+def test_oracle_reproduces_all_256_bench_frames(oracle):
+    """what bench.py --workload config5-e2e verifies against: the restatement reproduces the reference on every one of the 256 frames, bit for bit"""
+    user = np.zeros((26, 7), np.float32)
+    for i in range(len(FR256["depth"])):
+        oracle.reset(FR256["startpose"][i])
+        cam = ol.camera(FR256["cam"][i], 128, 128)
+        oracle.L.ho_update(oracle.h, ol.u16ptr(np.ascontiguousarray(FR256["depth"][i])), C.byref(cam), ol.fptr(user))
+        assert np.array_equal(user, G256["all/uw_pose_user"][i]), i
+        assert np.array_equal(oracle.get_state(1)[:, :7], G256["all/other_pose"][i]), i
+        assert oracle.flags()[:2] == (G256["all/flags"][i][0], int(G256["all/flags"][i][1])), i
+
+
+@pytest.mark.gpu
+def test_gpu_config5_end_to_end_on_the_256_bench_frames(weights128):
+    """the same unit of work on the bench's 256 distinct frames against the reference's results: flags identical, user poses in the bands, othermodel's median at rounding level"""
+    from hand_tracking_samples_amd import native
+    n = len(FR256["depth"])
+    ctx = native.Context(MODEL26, n)
+    try:
+        ctx.load_weights128(weights128)
+        ctx.set_params(microforce=3.0, mainthreadpasses=3)
+        ctx.tracker_reset(FR256["startpose"])
+        poses, _ = ctx.update_direct_sync(FR256["depth"], FR256["cam"], 128, want_cnn=True)
+        other = ctx.get_state(1, n)[:, :, :7]
+        ref = G256["all/uw_pose_user"]
+        dp = np.abs(poses[:, :, :3] - ref[:, :, :3]).max(axis=(1, 2)); dq = np.abs(poses[:, :, 3:] - ref[:, :, 3:]).max(axis=(1, 2))
+        do = np.abs(other - G256["all/other_pose"]).max(axis=(1, 2))
+        err, init = ctx.tracker_flags(n)
+        out = np.nonzero((dp > POS_TOL) | (dq > QUAT_TOL))[0]
+        print("config 5 end to end, 256 frames: user poses |dpos| max %.2e median %.2e, |dquat| max %.2e, %d outside the tight band %s; othermodel max %.2e p90 %.2e median %.2e"
+              % (dp.max(), np.median(dp), dq.max(), len(out), out.tolist(), do.max(), np.percentile(do, 90), np.median(do)))
+        assert np.isfinite(poses).all() and np.isfinite(other).all()
+        assert np.array_equal(init, G256["all/flags"][:, 1].astype(np.int32))
+        assert np.abs(err - G256["all/flags"][:, 0]).max() <= 1e-4
+        # Against how far the reference's OWN FMA builds move these frames (tests/golden/ref_spread5e2e_256.npz).  This model -- cloned fingers in permanent contact, 15 polytope
+        # runs per frame -- amplifies a rounding difference on about a tenth of its frames in every build, and WHICH frames depends on the perturbation (the reference's two FMA
+        # builds disagree with each other there), so the frames outside the band are held by number and size (tests/parity_rule.py's bands and cap), not by name; that nothing
+        # but rounding is at work is shown bit for bit by the exact-order build (tests/test_gpu_exact_solver.py).
+        import parity_rule as pr
+        spread = np.load(os.path.join(HERE, "golden", "ref_spread5e2e_256.npz"))
+        for key, dev, rf, cap in (("user", poses, ref, pr.CAP), ("other", other, G256["all/other_pose"], pr.CAP_TAKE_CNN)):
+            d_p, d_q = pr.pose_diff(dev, rf); sp, sq = pr.spread_of(spread, key)
+            pd, ps = np.percentile(np.maximum(d_p, d_q), [50, 90, 99]), np.percentile(np.maximum(sp, sq), [50, 90, 99])
+            nd, ns = int(((d_p > pr.TIGHT[0]) | (d_q > pr.TIGHT[1])).sum()), int(((sp > pr.TIGHT[0]) | (sq > pr.TIGHT[1])).sum())
+            print("  %s: p50 / p90 / p99 %s (the reference's FMA builds %s), %d frames outside 2e-5 m / 2e-4 (theirs %d), max %.2e m / %.2e" % (key, ["%.1e" % v for v in pd], ["%.1e" % v for v in ps], nd, ns, d_p.max(), d_q.max()))
+            assert (pd <= 2 * ps).all() and nd <= ns and d_p.max() <= cap[0] and d_q.max() <= cap[1], key
+        assert np.median(do) <= FULL_POS_TOL
+        assert ctx.capacity_events() == (0, 0, 0)
+    finally:
+        ctx.close()
+
+
 @pytest.mark.gpu
 def test_gpu_config5_end_to_end_matches_reference(weights128):
     """Device: k_cnn_input<128> -> k_conv1<128> -> k_conv2 -> k_fc(K = 12544) -> k_fc144 -> decode (camsub 8) -> FitError / reset / MultiStepSim / accept

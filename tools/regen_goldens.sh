@@ -79,8 +79,13 @@ $H cnn128 $T/frames5.htfx 0,9,33,60 $SEED $GAIN $T/cnn128.htfx
 # of four frames (a second update, a far-off start with always_take_cnn = the reset branch and the accept) and the results for all 64 frames of the bench input
 HT_REF_MODEL_JSON=$T/model_hand26.json $H e2e128 $T/frames5.htfx 0,9,33,60 $SEED $GAIN $T/e2e128.htfx
 
+# the bench's configs[4] batch: 256 distinct 128x128 frames (rows 3 + 9 i) and the reference's results for every one of them, both ways (bench.py --workload config5 / config5-e2e)
+HT_REF_MODEL_JSON=$T/model_hand26.json $H fullframes $BANK 3 9 256 128,128,163 $T/frames5_256.htfx
+HT_REF_MODEL_JSON=$T/model_hand26.json $H posesfull $T/frames5_256.htfx $SEED $GAIN $T/poses5full256.htfx
+HT_REF_MODEL_JSON=$T/model_hand26.json $H e2e128 $T/frames5_256.htfx "" $SEED $GAIN $T/e2e128_256.htfx      # no per-stage dumps: the all/ results only
+
 rc=0
-for f in model_hand17 model_hand26 model_chain3 golden8 poses256 poses1024 poses1024_takecnn poses5full voxel4 scale115 slowfit3 train3 fullframe320 fullframe320close fullframe5 config5 cnn128 e2e128; do
+for f in model_hand17 model_hand26 model_chain3 golden8 poses256 poses1024 poses1024_takecnn poses5full voxel4 scale115 slowfit3 train3 fullframe320 fullframe320close fullframe5 config5 cnn128 e2e128 poses5full256 e2e128_256; do
 	if cmp -s $T/$f.htfx $G/$f.htfx; then echo "identical  $f.htfx"; else echo "DIFFERENT  $f.htfx"; rc=1; fi
 	[ $WRITE = 1 ] && cp $T/$f.htfx $G/$f.htfx
 done
@@ -106,6 +111,8 @@ f = htfx.load(T + "/frames1024.htfx"); f1024 = {k: f[k] for k in ("depth", "cam"
 same("frames1024.npz", f1024, dict(np.load(G + "/frames1024.npz")))
 g = htfx.load(T + "/frames5.htfx"); f5 = {k: g[k] for k in ("depth", "cam", "startpose", "rows")}
 same("frames5_64.npz", f5, dict(np.load(G + "/frames5_64.npz")))
+g = htfx.load(T + "/frames5_256.htfx"); f5b = {k: g[k] for k in ("depth", "cam", "startpose", "rows")}
+same("frames5_256.npz", f5b, dict(np.load(G + "/frames5_256.npz")))
 s = htfx.load(T + "/seg.htfx"); seg = {k.replace("/", "__"): v for k, v in s.items()}
 same("segment6.npz", seg, dict(np.load(G + "/segment6.npz")))
 v = htfx.load(T + "/viz1.htfx"); viz = {k: (a.astype(np.uint8) if k.endswith("_labels") else a) for k, a in v.items()}      # the label images travel as 16-bit words in the container
@@ -114,6 +121,7 @@ if write:
     np.savez_compressed(G + "/frames256.npz", **f256)
     np.savez_compressed(G + "/frames1024.npz", **f1024)
     np.savez_compressed(G + "/frames5_64.npz", **f5)
+    np.savez_compressed(G + "/frames5_256.npz", **f5b)
     np.savez_compressed(G + "/segment6.npz", **seg)
     np.savez_compressed(G + "/viz1.npz", **viz)
 sys.exit(1 if bad else 0)
