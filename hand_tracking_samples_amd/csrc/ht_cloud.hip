@@ -389,7 +389,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_cloud_rows(ht_model_dev M, const
 	__shared__ float tab[HT_MAXNB * BT];
 	__shared__ closest_lds L;
 	__shared__ float wq[HT_MAXNB][4], wI[HT_MAXNB][10];      // record mode: the bodies' orientations, world inverse inertia and inverse mass, as k_solve forms them
-	const int b = blockIdx.x, t = threadIdx.x;
+	const int b = M.frame_order ? M.frame_order[blockIdx.x] : (int)blockIdx.x, t = threadIdx.x;
 	const int n = npts[b];
 	const int nsub = (n + stride - 1) / stride;
 	if (active_flag && !active_flag[b]) return;      // a masked launch leaves the other frames' rows and counts alone (another launch may be producing them)
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(256) void k_fit_error(ht_model_dev M, const float *
 	__shared__ closest_lds L;
 	__shared__ int perr[HT_MAXNB];
 	__shared__ int s_take;
-	const int b = blockIdx.x, t = threadIdx.x;
+	const int b = M.frame_order ? M.frame_order[blockIdx.x] : (int)blockIdx.x, t = threadIdx.x;
 	if (t < 64) body_table_build(M, state + (size_t)b * M.nb * HT_STATE_STRIDE, tab, t);
 	if (t < HT_MAXNB) perr[t] = 0;
 	stage_planes(M, t, 256);
@@ -962,3 +962,26 @@ void ht_launch_chamber(const ht_model_dev &M, const float *state, const float4 *
 {
 	hipLaunchKernelGGL(k_chamber, dim3(B), dim3(64), 0, s, M, state, pts, npts, min_point_num, enabled, maxforce, rows, nch);
 }
+
+// order[.] = the frames by their point counts, most first (equal counts in whatever order the atomics fall: nothing depends on it): a counting sort in one block
+__global__ __launch_bounds__(1024) void k_order_by_points(const int *__restrict__ npts, int *__restrict__ order, int B)
+{
+	__shared__ int hist[4096 + 1];
+	__shared__ int part[1024];
+	const int t = threadIdx.x;
+	for (int i = t; i <= 4096; i += 1024) hist[i] = 0;
+	__syncthreads();
+	for (int b = t; b < B; b += 1024) { int k = npts[b]; k = 4095 - (k < 0 ? 0 : k > 4095 ? 4095 : k); atomicAdd(&hist[k], 1); }
+	__syncthreads();
+	int loc[4], sum = 0;
+	for (int j = 0; j < 4; j++) { loc[j] = sum; sum += hist[4 * t + j]; }
+	part[t] = sum;
+	__syncthreads();
+	for (int o = 1; o < 1024; o <<= 1) { const int v = t >= o ? part[t - o] : 0; __syncthreads(); part[t] += v; __syncthreads(); }
+	const int base = part[t] - sum;
+	__syncthreads();
+	for (int j = 0; j < 4; j++) hist[4 * t + j] = base + loc[j];
+	__syncthreads();
+	for (int b = t; b < B; b += 1024) { int k = npts[b]; k = 4095 - (k < 0 ? 0 : k > 4095 ? 4095 : k); order[atomicAdd(&hist[k], 1)] = b; }
+}
+void ht_launch_order_by_points(const int *npts, int *order, int B, hipStream_t s) { hipLaunchKernelGGL(k_order_by_points, dim3(1), dim3(1024), 0, s, npts, order, B); }

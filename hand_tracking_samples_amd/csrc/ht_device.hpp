@@ -113,6 +113,8 @@ struct ht_model_dev
 	int nb, nj;
 	int pts_bound;            // most sub-sampled points a frame of the current call can carry (<= pts_cap; 0 = pts_cap): sizes per-point LDS arrays
 	int pts_cap;              // points a frame's slot of the per-point arrays holds (stride of points / cloud rows; >= HT_MAXPTS)
+	const int *frame_order;   // the kernels with one block per frame (k_cloud_rows, k_fit_error): block i takes frame frame_order[i] -- inside an update of a batch of several rounds per CU the frames by
+	                          // their points, most first, so that a launch ends on short blocks; null: block i takes frame i.  Results do not depend on it
 	const float4 *verts;      // all bodies back to back (com-centred collision vertices)
 	const float4 *cverts;     // the same vertices with every body padded to whole rows of 16 (pads repeat vertex 0, index 0): the contact kernel's LDS image
 	int cvert_off[HT_MAXNB + 1];

@@ -61,6 +61,7 @@ struct ht_ctx
 	int *d_accepted = nullptr;
 	float *d_contacts = nullptr; int *d_ncontacts = nullptr;    // [B][HT_MAXCONTACT][HT_CONTACT]
 	int *d_cwork = nullptr, *d_corder = nullptr;                  // [HT_CONTACT_SLOTS][cstride]: what every frame cost in every contact launch of the latest update; the assignment of frames to blocks made from it for the current one (ht_gjk.hip: k_contact_order)
+	int *d_porder = nullptr;      // [B]: the frames by their point counts (ht_model_dev::frame_order inside an update of a batch of several rounds per CU)
 	int *d_swork = nullptr, *d_sorder = nullptr; unsigned swork_mask = 0, sorder_mask = 0; int swork_B = 0;      // the same for the solves of a batch that takes several rounds per CU: what every frame's solve took, the launch order (longest first)
 	int cstride = 0, cwork_B = 0; unsigned cwork_mask = 0, corder_mask = 0;      // slots whose work the latest update wrote (for cwork_B frames) / whose order the current update may use
 	unsigned char *d_epa_ws = nullptr;                           // expanding-polytope workspace, one per (frame, wave)

@@ -52,6 +52,7 @@ void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftma
                         const int *order = nullptr, int *work_out = nullptr);      // order / work_out (cooperative kernel only, both may be null): the frame of every (slot, block) as k_contact_order dealt them; where every live frame leaves what it cost
 int ht_contacts_frames_per_block(const ht_model_dev &M, int B);
 #define HT_CONTACT_SLOTS 16      // unmasked contact launches of an update that keep a work history: MultiStepSim step st -> slot st (< 8), main-thread pass i -> slot 8 + i
+void ht_launch_order_by_points(const int *npts, int *order, int B, hipStream_t s);      // order = the frames by their point counts, most first (ht_model_dev::frame_order)
 void ht_launch_rank_desc(const int *work, int *order, int B, int stride, unsigned slots, int nslots, hipStream_t s);      // order[slot][.] = the frames of every 4096-frame segment by work[slot][.], largest first
 void ht_launch_contact_order(const int *work, int *order, int B, int nfr, int stride, unsigned slots, int nslots, int epb, hipStream_t s);
 size_t ht_contacts_workspace_bytes(int B);

@@ -203,7 +203,14 @@ struct frame_src { int w, h; float segment_scale; int direct; };
 // UPD_KICKSTART = kickstart (:743-746) = the same followed by handmodel.SetPose(pose) where the pose was accepted.
 // UPD_PASSES = only the caller's part of update() (:751-753, 769-785): the cloud of the frame, the main-thread passes on handmodel, the user poses (the overlapped mode, ht_update_passes_sync)
 enum { UPD_FULL = 0, UPD_CNN_MODEL = 1, UPD_KICKSTART = 2, UPD_PASSES = 3 };
+static int run_update_(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, const float *d_start, int B, float *d_poses_out, float *d_cnn_out, hipStream_t s, const frame_src *fs, int mode);
 static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, const float *d_start, int B, float *d_poses_out, float *d_cnn_out, hipStream_t s, const frame_src *fs = nullptr, int mode = UPD_FULL)
+{
+	const int r = run_update_(ctx, d_depth, d_cams, d_start, B, d_poses_out, d_cnn_out, s, fs, mode);
+	ctx->model.frame_order = nullptr;      // the launch order of the block-per-frame kernels belongs to the update that made it
+	return r;
+}
+static int run_update_(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, const float *d_start, int B, float *d_poses_out, float *d_cnn_out, hipStream_t s, const frame_src *fs, int mode)
 {
 	if (mode == UPD_PASSES) {}      // no net in the caller's part
 	else if (fs && fs->direct) { if (!ctx->have_weights128) { ctx->err = "weights of the 128x128 net not loaded (ht_cnn_load_weights_sized)"; return HT_ERR_STATE; } }
@@ -257,6 +264,8 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 			ht_launch_voxel(all, ctx->d_nrows, ctx->model.pts_cap, p.subsample_size, p.subsample_fraction, ctx->d_ptsv, ctx->d_nptsv, B, s);
 		}
 	}
+	// batches of several rounds per CU: the block-per-frame kernels take the frames with the most points first, so that a launch ends on short blocks
+	if (ctx->d_porder && B > ctx->n_cu * 8 && !exact_solver(ctx)) { ht_launch_order_by_points(ctx->d_npts, ctx->d_porder, B, s); ctx->model.frame_order = ctx->d_porder; }
 	if (mode == UPD_PASSES)
 	{
 		const int passes = p.angles_only ? 0 : p.mainthreadpasses;
