@@ -16,7 +16,7 @@
 set -e
 if [ "$1" = "--collect" ]; then
 	R=${2:-r03}; S=gpurun_out/prof_$R; D=profiles
-	for f in bench bench_takecnn pmc_solve_issue bench_frames8192 bench_cnn bench_config5 bench_config5_e2e bench_config5_cnn128 bench_under_rocprofv3 bench_dist1 pmc_hbm_traffic pmc_hbm_traffic_frames8192 pmc_hbm_traffic_config5 pmc_hbm_traffic_config5_e2e pmc_mfma_util pmc_mfma128_util; do [ -f $S/$f.json ] && cp $S/$f.json $D/${R}_$f.json; done
+	for f in bench bench_takecnn pmc_solve_issue pmc_solve_issue_frames8192 bench_frames8192 bench_cnn bench_config5 bench_config5_e2e bench_config5_cnn128 bench_under_rocprofv3 bench_dist1 pmc_hbm_traffic pmc_hbm_traffic_frames8192 pmc_hbm_traffic_config5 pmc_hbm_traffic_config5_e2e pmc_mfma_util pmc_mfma128_util; do [ -f $S/$f.json ] && cp $S/$f.json $D/${R}_$f.json; done
 	cp $S/kernel_stats.csv $D/${R}_rocprofv3_kernel_stats.csv; cp $S/kernel_stats_frames8192.csv $D/${R}_rocprofv3_kernel_stats_frames8192.csv
 	cp $S/kernel_stats_cnn.csv $D/${R}_rocprofv3_kernel_stats_cnn.csv; cp $S/kernel_stats_cnn128.csv $D/${R}_rocprofv3_kernel_stats_cnn128.csv
 	[ -f $S/step_timeline.txt ] && cp $S/step_timeline.txt $D/${R}_step_timeline.txt
@@ -67,6 +67,7 @@ python3 tools/pmc_mfma.py $(find $OUT/pmc_mfma -name "m_counter_collection.csv" 
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma128 -o m -- python3 bench.py --workload config5-cnn128 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_mfma128.err
 python3 tools/pmc_mfma.py $(find $OUT/pmc_mfma128 -name "m_counter_collection.csv" | head -1) > $OUT/pmc_mfma128_util.json
 rm -rf $OUT/trace $OUT/trace8192 $OUT/trace_cnn $OUT/trace_cnn128 $OUT/pmc_mfma $OUT/pmc_mfma128
-bash tools/pmc_solve.sh $OUT/pmc_solve > /dev/null 2>&1 && cp $OUT/pmc_solve/pmc_solve_issue.json $OUT/pmc_solve_issue.json && rm -rf $OUT/pmc_solve      # SQ / TCC counters of the latency-bound kernels (issue rate, waits, L2 reads)
+bash tools/pmc_solve.sh $OUT/pmc_solve > /dev/null 2>&1 && cp $OUT/pmc_solve/pmc_solve_issue.json $OUT/pmc_solve_issue.json && rm -rf $OUT/pmc_solve
+FRAMES=8192 bash tools/pmc_solve.sh $OUT/pmc_solve8192 --frames-per-gpu 8192 > /dev/null 2>&1 && cp $OUT/pmc_solve8192/pmc_solve_issue.json $OUT/pmc_solve_issue_frames8192.json && rm -rf $OUT/pmc_solve8192      # the same at 8192 frames (two waves per SIMD, records beyond the L2)      # SQ / TCC counters of the latency-bound kernels (issue rate, waits, L2 reads)
 python3 bench.py --always-take-cnn --no-cpu-baseline > $OUT/bench_takecnn.json 2> $OUT/bench_takecnn.err      # the headline workload with every CNN-driven pose accepted: verified against poses1024_takecnn.htfx
 echo "profile round $R complete"
