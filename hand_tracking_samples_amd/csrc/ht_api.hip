@@ -609,7 +609,7 @@ int ht_reserve_points_locked(ht_ctx *ctx, int points)
 	if ((r = dev_alloc(ctx, &ctx->d_pts, B * cap))) return r;
 	if ((r = dev_alloc(ctx, &ctx->d_rows, B * cap * HT_ROW))) return r;
 	if ((r = dev_alloc(ctx, &ctx->d_rowbody, B * cap))) return r;
-	if ((r = dev_alloc(ctx, &ctx->d_scratch, B * ht_scratch_rows(cap, nb) * (HT_CREC + 2)))) return r;      // a row record + 1 float for the impulse sum and 1 word for the chain entry of frames that do not fit k_solve's LDS
+	if ((r = dev_alloc(ctx, &ctx->d_scratch, B * ht_scratch_rows(cap, nb) * (HT_CREC + 6)))) return r;      // a row record + 1 float for the impulse sum, 1 word for the chain entry (frames that do not fit k_solve's LDS) and 4 floats of couplings per chain entry (ht_quad.hpp: quad_blocks_run); was: k_solve's LDS
 	if (had_voxel && (r = dev_alloc(ctx, &ctx->d_ptsv, B * cap))) return r;
 	ctx->model.pts_cap = want;
 	return HT_OK;

@@ -176,6 +176,130 @@ __device__ __forceinline__ void quad_chain_run(quad_body &B, const float *recs, 
 	if (post) quad_chain_run_<true>(B, recs, idx, sums, cnt, c, kswitch, lin_w, ang_w, bodyA, bodyB);
 	else quad_chain_run_<false>(B, recs, idx, sums, cnt, c, kswitch, lin_w, ang_w, bodyA, bodyB);
 }
+// ---- single-body rows FOUR at a time on the four quads of a DPP row (round 5; measured in round 4 on a synthetic frame, tools/probe/chain_blocks_probe.hip) -----------
+// Consecutive rows of one body depend on each other only through the momenta, and linearly: with M the momenta before row 0 of a block of four rows,
+//   vn_j / effmass_j = c_j . (M + sum_{i<j} d_i imp_i) = c_j . M + sum_{i<j} G(j,i) imp_i,      G(j,i) = c_j . d_i   (c_j = slots x, z of row j, d_i = slots w, y of row i)
+// and G does not change during a PhysicsUpdate any more than the records do.  So the four quads of a DPP row (16 lanes) take the four rows of a block TOGETHER: every quad
+// holds the body's momenta (the same values), forms its row's c_j . M side by side with the others (the expensive part: two products, a three-lane sum), then the impulses
+// are resolved in row order -- imp_0 = clamp(x_0); x_j += -G(j,0) imp_0; imp_1 = clamp(x_1); ... : two dependent instructions per row -- and all quads add all four
+// d_i imp_i to their momenta.  Same rows, same order, same clamps as LimitLinear::Iter (physics.h:289-307); one more association order of the same sums (G imp in place of
+// c . (d imp)).  The wave's four DPP rows walk FOUR bodies' chains at a time, the bodies dealt out longest first so that the rows carry about equal numbers of blocks
+// (k_solve's prologue), where sixteen quads on sixteen bodies wait for the longest chain: a frame's phase takes (its rows / 16) blocks instead of (its longest chain)
+// rows -- and a depth frame puts a third to a half of its points on one bone.
+// G travels in an array of its own in chain order, 16 bytes per row (-G(j,0), -G(j,1), -G(j,2), 0; zero where i >= j), written once per solve by the prologue.
+//
+// One block: a = this lane's slot of its quad's row, g = the row's couplings, sum = the row's impulse sum.  Returns the new impulse sum (all four lanes of the quad).
+// Lane 3's column runs through the same instructions with the scalars of its slot: what it computes in p, t, s, ul, ua is never used.
+template <bool POST>
+__device__ __forceinline__ float quad_block_step(quad_body &B, const float4 a, const float4 g, const float sum)
+{
+	float ns, p, t, s, x, lo, hi, imp, ul, ua;
+	asm volatile("v_mul_f32 %[p], %[ax], %[l]\n\t"
+	             "v_fmac_f32 %[p], %[az], %[av]\n\t"                                                                        // lanes 0-2: (n[c]*massinv*P[c] + b[c]*L[c]) / effective mass
+	             "v_sub_f32 %[lo], %[az], %[sum]\n\t"                                                                       // lane 3: fmin*dt - sum
+	             "v_sub_f32 %[hi], %[aw], %[sum]\n\t"                                                                       //         fmax*dt - sum
+	             "v_add_f32_dpp %[t], %[p], %[p] quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"           // lane 1: p0 + p1
+	             "s_nop 1\n\t"
+	             "v_add_f32_dpp %[s], %[t], %[p] quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"           // lane 2: (p0 + p1) + p2
+	             "s_nop 1\n\t"
+	             "v_subrev_f32_dpp %[x], %[s], -%[ts] quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      // lane 3: (-targetspeed - c.M) / effective mass
+	             "v_med3_f32 %[imp], %[x], %[lo], %[hi]\n\t"                                                                // row 0's impulse is final
+	             "s_nop 1\n\t"
+	             "v_fmac_f32_dpp %[x], %[imp], %[g0] row_newbcast:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            // rows 1-3: x += -G(j,0) * imp_0
+	             "v_med3_f32 %[imp], %[x], %[lo], %[hi]\n\t"                                                                // row 1's
+	             "s_nop 1\n\t"
+	             "v_fmac_f32_dpp %[x], %[imp], %[g1] row_newbcast:7 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+	             "v_med3_f32 %[imp], %[x], %[lo], %[hi]\n\t"                                                                // row 2's
+	             "s_nop 1\n\t"
+	             "v_fmac_f32_dpp %[x], %[imp], %[g2] row_newbcast:11 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+	             "v_med3_f32 %[imp], %[x], %[lo], %[hi]\n\t"                                                                // row 3's
+	             "s_nop 1\n\t"
+	             "v_mul_f32_dpp %[ul], %[imp], %[aw] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"       // n[c] * imp_j
+	             "v_mul_f32_dpp %[ua], %[imp], %[ay] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"       // g[c] * imp_j
+	             "v_add_f32_dpp %[ns], %[imp], %[sum] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      // the row's new impulse sum
+	             // the four rows' contributions, summed the same way in every quad: (u_j + u_(j+2)) + (u_(j+1) + u_(j+3)) -- additions commute, so the four copies of the
+	             // momenta stay equal bit for bit
+	             "v_add_f32_dpp %[ul], %[ul], %[ul] row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+	             "v_add_f32_dpp %[ua], %[ua], %[ua] row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+	             "s_nop 0\n\t"
+	             "v_add_f32_dpp %[ul], %[ul], %[ul] row_ror:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+	             "v_add_f32_dpp %[ua], %[ua], %[ua] row_ror:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+	             "v_add_f32 %[l], %[l], %[ul]\n\t"
+	             "v_add_f32 %[av], %[av], %[ua]"
+	             : [l] "+v"(B.l), [av] "+v"(B.av), [ns] "=&v"(ns), [p] "=&v"(p), [t] "=&v"(t), [s] "=&v"(s), [x] "=&v"(x), [lo] "=&v"(lo), [hi] "=&v"(hi), [imp] "=&v"(imp),
+	               [ul] "=&v"(ul), [ua] "=&v"(ua)
+	             : [ax] "v"(a.x), [ay] "v"(a.y), [az] "v"(a.z), [aw] "v"(a.w), [ts] "v"(POST ? a.y : a.x), [g0] "v"(g.x), [g1] "v"(g.y), [g2] "v"(g.z), [sum] "v"(sum));
+	return ns;
+}
+// A DPP row's walk: blocks [0, nblk) of its segment of the chain lists (entries e0 .. e0 + 4*nblk: row j of block t is entry e0 + 4t + j), the bodies of the segment one
+// after the other.  idx / G / sums are indexed by entry, recs by record index; c = lane within the quad, j = quad within the DPP row.  Which body a block belongs to: the
+// segment starts with body `head`, a body b has cblk[b] blocks and is followed by body cnext[b]; the momenta of the body in hand live in registers (all four quads hold
+// the same values) and go back to lin_w / ang_w when the row moves on.  Four register sets rotate: a block's record and couplings are asked for four blocks ahead of its
+// use, its index another four blocks earlier, its impulse sum two blocks ahead.  Reads run up to 8 blocks of indices, 4 of records (of valid indices) and couplings and 2
+// of sums past the segment's end: into the next row's segment, or the slack behind the last (QUAD_BLOCK_SLACK entries, indices naming the no-op record).
+#define QUAD_BLOCK_SLACK 32
+template <bool POST, class IDX>
+__device__ __forceinline__ void quad_blocks_run_(const float *recs, const IDX *idx, const float4 *G, float *sums, int e0, int nblk, int c, int j, float *lin_w, float *ang_w, int head,
+                                                 const signed char *cnext, const int *cblk)
+{
+	const float4 *pa = reinterpret_cast<const float4 *>(recs) + c;
+	const IDX *px = idx + e0 + j;
+	const float4 *pg = G + e0 + j;
+	float *ps = sums + e0 + j;
+	quad_body B = { 0.0f, 0.0f };
+	int cur = -1, nxt = head, left = 0;
+#define QB_LX(i, blk) x##i = (unsigned)px[4 * (blk)]; __builtin_amdgcn_sched_barrier(0)
+#define QB_LA(i) a##i = pa[4 * x##i]; __builtin_amdgcn_sched_barrier(0)
+#define QB_LG(i, blk) g##i = pg[4 * (blk)]; __builtin_amdgcn_sched_barrier(0)
+#define QB_LS(i, blk) s##i = ps[4 * (blk)]; __builtin_amdgcn_sched_barrier(0)
+	float4 a0, a1, a2, a3, g0, g1, g2, g3; float s0, s1, s2, s3;
+	unsigned x0, x1, x2, x3;
+	QB_LX(0, 0); QB_LX(1, 1); QB_LX(2, 2); QB_LX(3, 3);
+	QB_LA(0); QB_LA(1); QB_LA(2); QB_LA(3);
+	QB_LG(0, 0); QB_LG(1, 1); QB_LG(2, 2); QB_LG(3, 3);
+	QB_LX(0, 4); QB_LX(1, 5); QB_LX(2, 6); QB_LX(3, 7);
+	QB_LS(0, 0); QB_LS(1, 1);
+	// the row moves on to its next body: the momenta in hand go back, the next body's come in (and are waited for inside the branch: the waits the compiler
+	// derives behind the branch are then those of the blocks that do not change body)
+#define QB_BODY() \
+	if (left == 0) \
+	{ \
+		if (c < 3 && cur >= 0) { lin_w[4 * cur + c] = B.l; ang_w[4 * cur + c] = B.av; } \
+		cur = nxt; B.l = lin_w[4 * cur + c]; B.av = ang_w[4 * cur + c]; left = cblk[cur]; nxt = cnext[cur]; \
+		__builtin_amdgcn_s_waitcnt(0xC07F); \
+	} \
+	left--; __builtin_amdgcn_sched_barrier(0)
+#define QB_STEP(i, blk) ps[4 * (blk)] = quad_block_step<POST>(B, a##i, g##i, s##i); __builtin_amdgcn_sched_barrier(0)
+	// block i of the trip: apply it; then the record and the couplings four blocks on for its register set (their index came in during the last trip), the index eight
+	// blocks on, and the impulse sum two blocks on (set k)
+#define QB_BLK(i, k) QB_BODY(); QB_STEP(i, i); QB_LA(i); QB_LG(i, 4 + i); QB_LX(i, 8 + i); QB_LS(k, 2 + i)
+	int t = 0;
+	for (; t + 4 <= nblk; t += 4)
+	{
+		QB_BLK(0, 2); QB_BLK(1, 3); QB_BLK(2, 0); QB_BLK(3, 1);
+		px += 16; pg += 16; ps += 16;
+	}
+	const int rest = nblk - t;      // 0..3 blocks: their records and couplings are in the register sets, the sums of the first two too
+#define QB_TAIL(i) if (rest > i) { QB_BODY(); QB_STEP(i, i); } __builtin_amdgcn_sched_barrier(0)
+	if (rest > 0) { QB_BODY(); QB_STEP(0, 0); if (rest > 2) { QB_LS(2, 2); } } __builtin_amdgcn_sched_barrier(0);
+	QB_TAIL(1); QB_TAIL(2);
+	if (c < 3 && cur >= 0) { lin_w[4 * cur + c] = B.l; ang_w[4 * cur + c] = B.av; }
+#undef QB_LX
+#undef QB_LA
+#undef QB_LG
+#undef QB_LS
+#undef QB_BODY
+#undef QB_STEP
+#undef QB_BLK
+#undef QB_TAIL
+}
+template <class IDX>
+__device__ __forceinline__ void quad_blocks_run(const float *recs, const IDX *idx, const float4 *G, float *sums, int e0, int nblk, int c, int j, int post, float *lin_w, float *ang_w, int head,
+                                                const signed char *cnext, const int *cblk)
+{
+	if (post) quad_blocks_run_<true>(recs, idx, G, sums, e0, nblk, c, j, lin_w, ang_w, head, cnext, cblk);
+	else quad_blocks_run_<false>(recs, idx, G, sums, e0, nblk, c, j, lin_w, ang_w, head, cnext, cblk);
+}
 // ---- ONE body's rows sixteen at a time (round 4: the single-body solves of k_reset, where one quad walked the whole cloud row by row while the batch waited) --------
 // Consecutive rows of a body depend on each other only through the momenta, and linearly: with M the momenta before row 0 of a block of sixteen rows,
 //   vn_j / effmass_j = c_j . (M + sum_{i<j} d_i imp_i) = c_j . M + sum_{i<j} G(j,i) imp_i,      G(j,i) = c_j . d_i   (c_j = slots x, z of row j's record, d_i = slots w, y of row i's)

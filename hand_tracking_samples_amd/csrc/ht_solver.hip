@@ -736,11 +736,14 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	const int n1 = npre + ncl;
 	const int pre_base = M.pts_cap, noop_idx = rec_cap - 1;      // record indices: cloud row j -> j, other single-body row i -> pre_base + i, the record that changes nothing -> the last
 	const int npad_max = 7 * (nb > 16 ? nb - 16 : 0);      // entries that may be added to pad host chains (below)
-	const int nlist = n1 + npad_max + QUAD_CHAIN_SLACK;                                     // chain entries incl. read-ahead slack
+	// Two layouts of the chain lists (ht_quad.hpp): sixteen quads on sixteen bodies row by row, or the four quads of a DPP row on four consecutive rows of one body, four
+	// bodies at a time (round 5).  The second one's phase takes (rows / 16) blocks where the first takes (longest chain) rows: CHAIN4 per frame (never per build) below.
+	const int nlist = n1 + (npad_max > 3 * nb ? npad_max : 3 * nb) + (QUAD_CHAIN_SLACK > QUAD_BLOCK_SLACK ? QUAD_CHAIN_SLACK : QUAD_BLOCK_SLACK);      // chain entries incl. padding and read-ahead slack, either layout
 	const bool sums_lds = nlist <= S.NSUM;
 	const bool idx_lds = sums_lds && nlist <= S.NIDX && rec_cap <= 65536;
 	float *const gsum = a.scratch + (size_t)a.batch * a.scratch_stride * CREC + (size_t)b * a.scratch_stride;      // this frame's sums in HBM, behind all frames' records
 	unsigned *const gidx = reinterpret_cast<unsigned *>(a.scratch + (size_t)a.batch * a.scratch_stride * (CREC + 1)) + (size_t)b * a.scratch_stride;      // and its chain lists behind those
+	float4 *const gG = reinterpret_cast<float4 *>(a.scratch + (size_t)a.batch * a.scratch_stride * (CREC + 2)) + (size_t)b * a.scratch_stride;      // and, behind those, the couplings of its rows with the rows before them in their block of four (16 B per chain entry)
 	if (sums_lds) { for (int i = lane; i < nlist; i += 64) S.csum[i] = 0.0f; }
 	else for (int i = lane; i < nlist && i < a.scratch_stride; i += 64) gsum[i] = 0.0f;
 	if (idx_lds) { for (int i = lane; i < nlist; i += 64) S.cidx[i] = (unsigned short)noop_idx; }
@@ -767,6 +770,43 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 			if (lane == bb) mycnt += __popcll(m);
 			todo &= ~m;
 		}
+	}
+	// CHAIN4: the bodies' chains in blocks of four rows, dealt longest first to the wave's four DPP rows (each body to the row with the fewest blocks so far); a row's
+	// segment of the lists = its bodies' blocks one after the other, a chain padded to whole blocks with the record that changes nothing
+	const bool chain4 = !EXACT && !HT_DBG(a.dbg, 65536);      // HT_DEBUG_SKIP += 65536 (-DHT_TUNING): the row-by-row walk, for an A/B
+	int c4_e0 = 0, c4_nblk = 0, c4_head = 0, c4_start = 0, c4_next = -1, c4_total = 0;
+	const int myblk = (lane < nb && !HT_DBG(a.dbg, 1)) ? (mycnt + 3) >> 2 : 0;
+	if (chain4)
+	{
+		// everything below is the same on every lane: the per-body values are read out of their lanes into scalars (v_readlane with a scalar lane number), so the
+		// dealing loop is scalar arithmetic
+		int myrank = 0;
+		for (int k = 0; k < nb; k++) { const int o = __builtin_amdgcn_readlane(myblk, k); myrank += (o > myblk || (o == myblk && k < lane)) ? 1 : 0; }
+		if (lane < nb) S.cstart[myrank] = lane;      // the bodies in dealing order (the table takes the chains' starts further down)
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		const int sorted = lane < nb ? S.cstart[lane] : 0;
+		int ld0 = 0, ld1 = 0, ld2 = 0, ld3 = 0, la0 = -1, la1 = -1, la2 = -1, la3 = -1, hd0 = 0, hd1 = 0, hd2 = 0, hd3 = 0, myrow = 0, mypos = 0;
+		for (int r = 0; r < nb; r++)
+		{
+			const int bb = __builtin_amdgcn_readlane(sorted, r);
+			const int blk = __builtin_amdgcn_readlane(myblk, bb);
+			if (blk == 0) break;                       // sorted: the rest have no rows
+			int row = 0, best = ld0;
+			if (ld1 < best) { row = 1; best = ld1; }
+			if (ld2 < best) { row = 2; best = ld2; }
+			if (ld3 < best) { row = 3; best = ld3; }
+			const int prev = row == 0 ? la0 : row == 1 ? la1 : row == 2 ? la2 : la3;
+			if (lane == bb) { myrow = row; mypos = best; }
+			if (lane == prev) c4_next = bb;
+			if (prev < 0) { if (row == 0) hd0 = bb; else if (row == 1) hd1 = bb; else if (row == 2) hd2 = bb; else hd3 = bb; }
+			if (row == 0) { la0 = bb; ld0 += blk; } else if (row == 1) { la1 = bb; ld1 += blk; } else if (row == 2) { la2 = bb; ld2 += blk; } else { la3 = bb; ld3 += blk; }
+		}
+		const int sg1 = 4 * ld0, sg2 = sg1 + 4 * ld1, sg3 = sg2 + 4 * ld2;
+		c4_total = ld0 + ld1 + ld2 + ld3;
+		c4_start = (myrow == 0 ? 0 : myrow == 1 ? sg1 : myrow == 2 ? sg2 : sg3) + 4 * mypos;
+		const int R = lane >> 4;                       // this lane's DPP row in the sweeps
+		c4_e0 = R == 0 ? 0 : R == 1 ? sg1 : R == 2 ? sg2 : sg3; c4_nblk = R == 0 ? ld0 : R == 1 ? ld1 : R == 2 ? ld2 : ld3; c4_head = R == 0 ? hd0 : R == 1 ? hd1 : R == 2 ? hd2 : hd3;
 	}
 	// Sixteen quads walk the chains.  A body beyond the 16th rides on the quad of one of the first sixteen: it goes to the one with the fewest rows that
 	// does not host yet, its entries follow the host's in the list, and the host's entries are padded to a multiple of 8 with the record that changes nothing
@@ -795,7 +835,8 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 		const int hs = __shfl(mystart, myhost >= 0 ? myhost : lane), hc = __shfl(mycnt, myhost >= 0 ? myhost : lane);
 		if (myhost >= 0) mystart = hs + ((hc + 7) & ~7);      // an extra body's entries start behind its host's padded ones (which already name the no-op record)
 	}
-	if (lane < HT_MAXNB) { S.ccnt[lane] = HT_DBG(a.dbg, 1) ? 0 : mycnt; S.cstart[lane] = mystart; S.cextra[lane] = (signed char)(HT_DBG(a.dbg, 1) ? -1 : myextra); }
+	if (chain4) { mystart = c4_start; if (lane < HT_MAXNB) { S.ccnt[lane] = myblk; S.cstart[lane] = mystart; S.cextra[lane] = (signed char)c4_next; } }      // ccnt: blocks, cextra: the next body of the DPP row
+	else if (lane < HT_MAXNB) { S.ccnt[lane] = HT_DBG(a.dbg, 1) ? 0 : mycnt; S.cstart[lane] = mystart; S.cextra[lane] = (signed char)(HT_DBG(a.dbg, 1) ? -1 : myextra); }
 	int myrun = 0;
 	for (int base = 0; base < n1; base += 64)          // pass B: placement in stable order; records of the rows that have none yet
 	{
@@ -845,6 +886,44 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	}
 	__threadfence_block();      // the records and lists are read back by other lanes of this wave
 	__syncthreads();
+	if (chain4 && !HT_DBG(a.dbg, 131072))      // HT_DEBUG_SKIP += 131072 (-DHT_TUNING, wrong results): without this loop, to see what it costs
+	{
+		// the couplings of every block's rows with the rows before them: a quad per block, lane c of it takes slot c of the block's four records; -G(j,i) = -(c_j . d_i),
+		// the three lanes' shares summed (p0 + p1) + p2 on lane 2, which writes the rows' entries
+		const int quad_ = lane >> 2, c_ = lane & 3;
+		// (the read-ahead slack behind the last block is loaded by the walk but never applied: its couplings are not written)
+		for (int blk0 = quad_; blk0 < c4_total; blk0 += 64)      // four blocks per quad and trip: their sixteen record reads are in flight together (the records come from L2 or further)
+		{
+			float4 r_[4][4];
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+#pragma unroll
+				for (int j = 0; j < 4; j++)
+				{
+					const int blk = blk0 + 16 * u, e = 4 * blk + j;
+					const unsigned x = (blk < c4_total) ? (idx_lds ? (unsigned)S.cidx[e] : gidx[e]) : (unsigned)noop_idx;
+					r_[u][j] = reinterpret_cast<const float4 *>(scr + (size_t)x * CREC)[c_];
+				}
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+			{
+				const int blk = blk0 + 16 * u;
+				auto coup = [&](int j, int i) -> float {
+					const float p = __fmaf_rn(r_[u][j].z, r_[u][i].y, r_[u][j].x * r_[u][i].w);
+					const float t = dpp<QP_PREV>(p) + p;
+					return -(dpp<QP_PREV>(t) + p);
+				};
+				const float g10 = coup(1, 0), g20 = coup(2, 0), g21 = coup(2, 1), g30 = coup(3, 0), g31 = coup(3, 1), g32 = coup(3, 2);
+				if (c_ == 2 && blk < c4_total && 4 * blk + 3 < a.scratch_stride)
+				{
+					gG[4 * blk] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); gG[4 * blk + 1] = make_float4(g10, 0.0f, 0.0f, 0.0f);
+					gG[4 * blk + 2] = make_float4(g20, g21, 0.0f, 0.0f); gG[4 * blk + 3] = make_float4(g30, g31, g32, 0.0f);
+				}
+			}
+		}
+		__threadfence_block();
+		__syncthreads();
+	}
 	v3 pos_next = V3(0, 0, 0); v4 q_next = V4(0, 0, 0, 1);
 	auto calc_next_pose = [&]() {
 		// rbcalcnextpose physics.h:522-531 with rkupdateq :211-218 (momentum-preserving RK4 on the quaternion)
@@ -1467,6 +1546,17 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 		const int tsoff = post ? 1 : 0;                                   // RemoveBias (physics.h:288): ts_post = min(ts, ts_nobias) was stored next to ts
 		// (1) chains: quad q applies the single-body rows of body q (then those of a body >= 16 it hosts) in order; momenta, inertia row and mass stay in registers.
 		//     Lane c < 3 of the quad reads r1[c] and n[c] of a record, lane 3 reads its target speed (ts or ts_post).
+		if (chain4)
+		{
+			if (c4_nblk > 0)
+			{
+				const int jq = (lane >> 2) & 3;
+				if (idx_lds) quad_blocks_run(scr, S.cidx, gG, S.csum, c4_e0, c4_nblk, c, jq, tsoff, lin_w, ang_w, c4_head, S.cextra, S.ccnt);
+				else if (sums_lds) quad_blocks_run(scr, gidx, gG, S.csum, c4_e0, c4_nblk, c, jq, tsoff, lin_w, ang_w, c4_head, S.cextra, S.ccnt);
+				else quad_blocks_run(scr, gidx, gG, gsum, c4_e0, c4_nblk, c, jq, tsoff, lin_w, ang_w, c4_head, S.cextra, S.ccnt);
+			}
+		}
+		else
 		{
 			const int body = quad;
 			const bool has = body < nb;

@@ -72,3 +72,20 @@ def test_rows_that_change_nothing_fill_a_block():
     Ma = _sweep_blocked(M0.copy(), sa, c, d, ts, lo, hi)
     Mb = _sweep_blocked(M0.copy(), sb, cp, dp, tsp, lop, hip)
     assert np.array_equal(Ma, Mb) and np.array_equal(sa, sb[:21]) and not sb[21:].any()
+
+
+def test_blocks_of_four_rows_equal_row_by_row_sweeps():
+    """csrc/ht_quad.hpp: quad_block_step (round 5: k_solve's single-body rows four at a time on the four quads of a DPP row; a chain padded to whole blocks with rows that
+    change nothing): the same algebra with W = 4."""
+    rng = np.random.default_rng(12)
+    for n in (1, 3, 4, 5, 109, 284):
+        c, d, ts, lo, hi = _rows(rng, n)
+        pad = (-n) % 4      # the record that changes nothing: zero direction, zero limits
+        cp, dp_, tsp, lop, hip = np.vstack([c, np.zeros((pad, 6))]), np.vstack([d, np.zeros((pad, 6))]), np.concatenate([ts, np.zeros(pad)]), np.concatenate([lo, np.zeros(pad)]), np.concatenate([hi, np.zeros(pad)])
+        Ma = rng.normal(size=6) * 0.01; Mb = Ma.copy()
+        sa = np.zeros(n); sb = np.zeros(n + pad)
+        for sweep in range(20):
+            Ma = _sweep_row_by_row(Ma, sa, c, d, ts, lo, hi)
+            Mb = _sweep_blocked(Mb, sb, cp, dp_, tsp, lop, hip, W=4)
+        assert np.abs(Ma - Mb).max() <= 1e-11 * max(1.0, np.abs(Ma).max()), n
+        assert np.abs(sa - sb[:n]).max() <= 1e-11 and np.all(sb[n:] == 0.0), n

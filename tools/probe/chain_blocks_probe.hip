@@ -1,4 +1,5 @@
-// chain_blocks_probe.hip -- experiment (not adopted): what the single-body rows of a solve cost row by row on sixteen quads (quad_chain_run, the
+// chain_blocks_probe.hip -- experiment of round 4; ADOPTED in round 5 (csrc/ht_quad.hpp: quad_blocks_run) once the real frames' shape was put beside it -- a depth frame puts a
+// third to a half of its single-body rows on ONE body, where the synthetic frame below has a quarter, which is the break-even: what the single-body rows of a solve cost row by row on sixteen quads (quad_chain_run, the
 // product's) and four at a time on four DPP rows (quad_blocks_run, below),
 // on synthetic chains of a main pass's shape: 17 bodies, 1010 rows, the longest chain 250; one wave per frame, every frame its own 64 KB of records, 20 sweeps, 36 KB of
 // LDS per wave (four waves per CU) as in k_solve's build for 1024 frames.
