@@ -764,8 +764,8 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 		unsigned long long todo = __ballot(body >= 0);
 		while (todo)
 		{
-			const int leader = __ffsll((long long)todo) - 1;
-			const int bb = __shfl(body, leader);
+			const int leader = __ffsll((long long)todo) - 1;      // wave-uniform (todo is a ballot): the body comes out of its lane into a scalar (v_readlane: no LDS round trip as with a shuffle)
+			const int bb = __builtin_amdgcn_readlane(body, leader);
 			const unsigned long long m = __ballot(body == bb);
 			if (lane == bb) mycnt += __popcll(m);
 			todo &= ~m;
@@ -847,9 +847,9 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 		while (todo)
 		{
 			const int leader = __ffsll((long long)todo) - 1;
-			const int bb = __shfl(body, leader);
+			const int bb = __builtin_amdgcn_readlane(body, leader);
 			const unsigned long long m = __ballot(body == bb);
-			const int segbase = __shfl(mystart + myrun, bb);
+			const int segbase = __builtin_amdgcn_readlane(mystart + myrun, bb);
 			if (body == bb) dst = segbase + __popcll(m & ((1ull << lane) - 1ull));
 			if (lane == bb) myrun += __popcll(m);
 			todo &= ~m;
