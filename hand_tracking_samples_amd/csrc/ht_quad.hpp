@@ -186,12 +186,17 @@ __device__ __forceinline__ void quad_chain_run(quad_body &B, const float *recs, 
 // c . (d imp)).  The wave's four DPP rows walk FOUR bodies' chains at a time, the bodies dealt out longest first so that the rows carry about equal numbers of blocks
 // (k_solve's prologue), where sixteen quads on sixteen bodies wait for the longest chain: a frame's phase takes (its rows / 16) blocks instead of (its longest chain)
 // rows -- and a depth frame puts a third to a half of its points on one bone.
-// G travels in an array of its own in chain order, 16 bytes per row (-G(j,0), -G(j,1), -G(j,2), 0; zero where i >= j), written once per solve by the prologue.
+// G travels in an array of its own, ten floats per block: -G(3,0) -G(3,1) -G(3,2) | -G(2,0) -G(2,1) 0 | -G(1,0) 0 0 | 0 -- the quad of row j reads three floats from its own
+// offset (QUAD_G_OFF: 0, 3, 6 and, for row 0, 7: three zeros), i.e. its couplings with a zero wherever i >= j; written once per solve by the prologue.  In k_solve's build
+// for 1024 frames the array lives in LDS (the records of the 128 frames resident on an XCD then fit its L2 as they did before the couplings existed).
 //
 // One block: a = this lane's slot of its quad's row, g = the row's couplings, sum = the row's impulse sum.  Returns the new impulse sum (all four lanes of the quad).
 // Lane 3's column runs through the same instructions with the scalars of its slot: what it computes in p, t, s, ul, ua is never used.
+#define QUAD_G_BLOCK 10      // floats of couplings per block of four rows
+#define QUAD_G_OFF(j) ((j) == 3 ? 0 : (j) == 2 ? 3 : (j) == 1 ? 6 : 7)
+struct __attribute__((packed, aligned(4))) quad_g3 { float x, y, z; };
 template <bool POST>
-__device__ __forceinline__ float quad_block_step(quad_body &B, const float4 a, const float4 g, const float sum)
+__device__ __forceinline__ float quad_block_step(quad_body &B, const float4 a, const quad_g3 g, const float sum)
 {
 	float ns, p, t, s, x, lo, hi, imp, ul, ua;
 	asm volatile("v_mul_f32 %[p], %[ax], %[l]\n\t"
@@ -239,20 +244,20 @@ __device__ __forceinline__ float quad_block_step(quad_body &B, const float4 a, c
 // of sums past the segment's end: into the next row's segment, or the slack behind the last (QUAD_BLOCK_SLACK entries, indices naming the no-op record).
 #define QUAD_BLOCK_SLACK 32
 template <bool POST, class IDX>
-__device__ __forceinline__ void quad_blocks_run_(const float *recs, const IDX *idx, const float4 *G, float *sums, int e0, int nblk, int c, int j, float *lin_w, float *ang_w, int head,
+__device__ __forceinline__ void quad_blocks_run_(const float *recs, const IDX *idx, const float *G, float *sums, int e0, int nblk, int c, int j, float *lin_w, float *ang_w, int head,
                                                  const signed char *cnext, const int *cblk)
 {
 	const float4 *pa = reinterpret_cast<const float4 *>(recs) + c;
 	const IDX *px = idx + e0 + j;
-	const float4 *pg = G + e0 + j;
+	const float *pg = G + QUAD_G_BLOCK * (e0 >> 2) + QUAD_G_OFF(j);
 	float *ps = sums + e0 + j;
 	quad_body B = { 0.0f, 0.0f };
 	int cur = -1, nxt = head, left = 0;
 #define QB_LX(i, blk) x##i = (unsigned)px[4 * (blk)]; __builtin_amdgcn_sched_barrier(0)
 #define QB_LA(i) a##i = pa[4 * x##i]; __builtin_amdgcn_sched_barrier(0)
-#define QB_LG(i, blk) g##i = pg[4 * (blk)]; __builtin_amdgcn_sched_barrier(0)
+#define QB_LG(i, blk) g##i = *reinterpret_cast<const quad_g3 *>(pg + QUAD_G_BLOCK * (blk)); __builtin_amdgcn_sched_barrier(0)
 #define QB_LS(i, blk) s##i = ps[4 * (blk)]; __builtin_amdgcn_sched_barrier(0)
-	float4 a0, a1, a2, a3, g0, g1, g2, g3; float s0, s1, s2, s3;
+	float4 a0, a1, a2, a3; quad_g3 g0, g1, g2, g3; float s0, s1, s2, s3;
 	unsigned x0, x1, x2, x3;
 	QB_LX(0, 0); QB_LX(1, 1); QB_LX(2, 2); QB_LX(3, 3);
 	QB_LA(0); QB_LA(1); QB_LA(2); QB_LA(3);
@@ -277,7 +282,7 @@ __device__ __forceinline__ void quad_blocks_run_(const float *recs, const IDX *i
 	for (; t + 4 <= nblk; t += 4)
 	{
 		QB_BLK(0, 2); QB_BLK(1, 3); QB_BLK(2, 0); QB_BLK(3, 1);
-		px += 16; pg += 16; ps += 16;
+		px += 16; pg += 4 * QUAD_G_BLOCK; ps += 16;
 	}
 	const int rest = nblk - t;      // 0..3 blocks: their records and couplings are in the register sets, the sums of the first two too
 #define QB_TAIL(i) if (rest > i) { QB_BODY(); QB_STEP(i, i); } __builtin_amdgcn_sched_barrier(0)
@@ -294,7 +299,7 @@ __device__ __forceinline__ void quad_blocks_run_(const float *recs, const IDX *i
 #undef QB_TAIL
 }
 template <class IDX>
-__device__ __forceinline__ void quad_blocks_run(const float *recs, const IDX *idx, const float4 *G, float *sums, int e0, int nblk, int c, int j, int post, float *lin_w, float *ang_w, int head,
+__device__ __forceinline__ void quad_blocks_run(const float *recs, const IDX *idx, const float *G, float *sums, int e0, int nblk, int c, int j, int post, float *lin_w, float *ang_w, int head,
                                                 const signed char *cnext, const int *cblk)
 {
 	if (post) quad_blocks_run_<true>(recs, idx, G, sums, e0, nblk, c, j, lin_w, ang_w, head, cnext, cblk);

@@ -68,9 +68,9 @@
 #define LM_FRIC 0x10000    // meta bits of a group: contact (friction rows limited by the normal row's impulse sum, physics.h:292)
 #define LM_NORMAL 0x20000
 
-template <int NGRP_, int NSUM_, int NANG_, int NIDX_, int AS_ = 2> struct lds_t
+template <int NGRP_, int NSUM_, int NANG_, int NIDX_, int AS_ = 2, int NCG_ = 0> struct lds_t
 {
-	static constexpr int NGRP = NGRP_, NSUM = NSUM_, NANG = NANG_, NIDX = NIDX_, MAXA2 = MAXA2_OF(AS_);
+	static constexpr int NGRP = NGRP_, NSUM = NSUM_, NANG = NANG_, NIDX = NIDX_, MAXA2 = MAXA2_OF(AS_), NCG = NCG_;
 	static constexpr int LIDLE = MAXG - 1;                      // slot of the idle entry in lorder
 	float pool[NGRP * LGRP] __attribute__((aligned(16)));      // two-body linear groups; first member: group addresses then fit the short offsets of two-address LDS reads
 	// body state in 16-byte records: component c of body b is word 4*b + c
@@ -79,6 +79,7 @@ template <int NGRP_, int NSUM_, int NANG_, int NIDX_, int AS_ = 2> struct lds_t
 	float pos[HT_MAXNB][3], q[HT_MAXNB][4];
 	float csum[NSUM];                      // impulse sum of every single-body row, in chain order (+ read-ahead slack)
 	unsigned short cidx[NIDX > 0 ? NIDX : 2];   // the chains: record index of every single-body row, in chain order (+ read-ahead slack); in HBM when the build has no room
+	float cg[NCG];                         // the couplings of the single-body rows' blocks of four (ht_quad.hpp: QUAD_G_BLOCK floats per block); only the build for 1024 frames has room, else in HBM
 	int ccnt[HT_MAXNB], cstart[HT_MAXNB];  // chain of body b: rows [cstart, cstart+ccnt) of the partitioned single-body stream
 	signed char cextra[HT_MAXNB];          // body b < 16 hosts the chain of this body >= 16 on its quad (-1: none): it follows b's rows, padded to a multiple of 8
 	union
@@ -316,10 +317,10 @@ __device__ __forceinline__ int level_schedule(int n, int lane, const int (&b0)[2
 // 289-307) in the reference's row order and association order, no fused multiply-adds, one lane -- instead of the Jacobian-form sweeps.  With it the whole
 // update reproduces the restatement bit for bit, which isolates the Jacobian-form arithmetic as the solver's only difference from the reference.
 #define EX_LIN HT_EX_LIN   // two-body linear rows a frame can have in the exact instantiation (a.exact_lin [B][EX_LIN][HT_ROW])
-template <int NGRP_, int NSUM_, int NANG_, int NIDX_, bool EXACT = false, int AS = 2>
+template <int NGRP_, int NSUM_, int NANG_, int NIDX_, bool EXACT = false, int AS = 2, int NCG_ = 0>
 __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev ph, solve_args a)      // two waves per SIMD: the register budget (256 with the accumulator file) of eight frames per CU in the small build
 {
-	__shared__ lds_t<NGRP_, NSUM_, NANG_, NIDX_, AS> S;
+	__shared__ lds_t<NGRP_, NSUM_, NANG_, NIDX_, AS, NCG_> S;
 	constexpr int ASLOTS = AS, MAXA2 = MAXA2_OF(AS), MAXA_LDS = MAXA_CAP_OF(AS);
 	const int lane = threadIdx.x;
 	const int b = a.frame_order ? a.frame_order[blockIdx.x] : (int)blockIdx.x;      // which frame: results do not depend on it, only when the frame's turn comes
@@ -743,7 +744,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	const bool idx_lds = sums_lds && nlist <= S.NIDX && rec_cap <= 65536;
 	float *const gsum = a.scratch + (size_t)a.batch * a.scratch_stride * CREC + (size_t)b * a.scratch_stride;      // this frame's sums in HBM, behind all frames' records
 	unsigned *const gidx = reinterpret_cast<unsigned *>(a.scratch + (size_t)a.batch * a.scratch_stride * (CREC + 1)) + (size_t)b * a.scratch_stride;      // and its chain lists behind those
-	float4 *const gG = reinterpret_cast<float4 *>(a.scratch + (size_t)a.batch * a.scratch_stride * (CREC + 2)) + (size_t)b * a.scratch_stride;      // and, behind those, the couplings of its rows with the rows before them in their block of four (16 B per chain entry)
+	float *const gG = a.scratch + (size_t)a.batch * a.scratch_stride * (CREC + 2) + (size_t)b * a.scratch_stride * 4;      // and, behind those, the couplings of its rows' blocks of four when the build's LDS has no room for them (QUAD_G_BLOCK floats per block; the region has 16 B per chain entry)
 	if (sums_lds) { for (int i = lane; i < nlist; i += 64) S.csum[i] = 0.0f; }
 	else for (int i = lane; i < nlist && i < a.scratch_stride; i += 64) gsum[i] = 0.0f;
 	if (idx_lds) { for (int i = lane; i < nlist; i += 64) S.cidx[i] = (unsigned short)noop_idx; }
@@ -886,6 +887,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	}
 	__threadfence_block();      // the records and lists are read back by other lanes of this wave
 	__syncthreads();
+	const bool g_lds = idx_lds && S.NCG > 0 && QUAD_G_BLOCK * (c4_total + 4) <= S.NCG;      // the couplings in LDS (the walk reads four blocks ahead); only beside LDS chain lists: one instance of the walk less
 	if (chain4 && !HT_DBG(a.dbg, 131072))      // HT_DEBUG_SKIP += 131072 (-DHT_TUNING, wrong results): without this loop, to see what it costs
 	{
 		// the couplings of every block's rows with the rows before them: a quad per block, lane c of it takes slot c of the block's four records; -G(j,i) = -(c_j . d_i),
@@ -916,8 +918,8 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 				const float g10 = coup(1, 0), g20 = coup(2, 0), g21 = coup(2, 1), g30 = coup(3, 0), g31 = coup(3, 1), g32 = coup(3, 2);
 				if (c_ == 2 && blk < c4_total && 4 * blk + 3 < a.scratch_stride)
 				{
-					gG[4 * blk] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); gG[4 * blk + 1] = make_float4(g10, 0.0f, 0.0f, 0.0f);
-					gG[4 * blk + 2] = make_float4(g20, g21, 0.0f, 0.0f); gG[4 * blk + 3] = make_float4(g30, g31, g32, 0.0f);
+					float2 *o = reinterpret_cast<float2 *>((g_lds ? S.cg : gG) + QUAD_G_BLOCK * blk);      // row 3's three | row 2's two, 0 | row 1's, 0, 0 | 0 (the quad of row 0 reads the last three)
+					o[0] = make_float2(g30, g31); o[1] = make_float2(g32, g20); o[2] = make_float2(g21, 0.0f); o[3] = make_float2(g10, 0.0f); o[4] = make_float2(0.0f, 0.0f);
 				}
 			}
 		}
@@ -1551,7 +1553,8 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 			if (c4_nblk > 0)
 			{
 				const int jq = (lane >> 2) & 3;
-				if (idx_lds) quad_blocks_run(scr, S.cidx, gG, S.csum, c4_e0, c4_nblk, c, jq, tsoff, lin_w, ang_w, c4_head, S.cextra, S.ccnt);
+				if (idx_lds && g_lds) quad_blocks_run(scr, S.cidx, S.cg, S.csum, c4_e0, c4_nblk, c, jq, tsoff, lin_w, ang_w, c4_head, S.cextra, S.ccnt);
+				else if (idx_lds) quad_blocks_run(scr, S.cidx, gG, S.csum, c4_e0, c4_nblk, c, jq, tsoff, lin_w, ang_w, c4_head, S.cextra, S.ccnt);
 				else if (sums_lds) quad_blocks_run(scr, gidx, gG, S.csum, c4_e0, c4_nblk, c, jq, tsoff, lin_w, ang_w, c4_head, S.cextra, S.ccnt);
 				else quad_blocks_run(scr, gidx, gG, gsum, c4_e0, c4_nblk, c, jq, tsoff, lin_w, ang_w, c4_head, S.cextra, S.ccnt);
 			}
@@ -1665,6 +1668,8 @@ void ht_launch_rank_desc(const int *work, int *order, int B, int stride, unsigne
 	hipLaunchKernelGGL(k_rank_desc, dim3(nslots, (B + 4095) / 4096), dim3(1024), 0, s, work, order, B, stride, slots);
 }
 
+#define SOLVE_ONLY_NCG 1440      // floats of single-body-row couplings the build for 1024 frames keeps in LDS: what is left of a quarter of a CU's 160 KB (144 blocks of four rows)
+static_assert(sizeof(lds_t<66, 1024, 126, 1024, 2, SOLVE_ONLY_NCG>) <= 40960, "the build for 1024 frames must fit four times into a CU's LDS");
 static_assert(sizeof(lds_t<34, 584, 84, 0>) <= 20480, "the small build must leave room for eight frames per CU (160 KB of LDS)");
 static_assert(HT_SCRATCH_TAIL * HT_CREC >= MAXG_CAP * LGRP + (MAXA_CAP_OF(4) + 4) * AROW + HT_CREC, "the tail of a frame's scratch slot must hold its linear groups, its angular records and the tuning record");
 void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solve_args &a, int B, hipStream_t s)
@@ -1681,7 +1686,7 @@ void ht_launch_solve(const ht_model_dev &M, const ht_physics_dev &ph, const solv
 	// the angular rows a frame of this launch can have at most (13 CNN-driven + 6 per joint + what the caller states on top: slowfit's relative rows, caller-built rows):
 	// beyond the 126 of the ordinary builds the build with four row slots per lane runs (252)
 	if (build >= 1 && build <= 3 && 13 + 6 * M.nj + a.ang_extra_bound > MAXA_CAP_OF(2)) build = 6;
-	if (build == 2) hipLaunchKernelGGL((k_solve<66, 1024, 126, 1024>), dim3(B), dim3(64), 0, s, M, ph, a);
+	if (build == 2) hipLaunchKernelGGL((k_solve<66, 1024, 126, 1024, false, 2, SOLVE_ONLY_NCG>), dim3(B), dim3(64), 0, s, M, ph, a);
 	else if (build == 1) hipLaunchKernelGGL((k_solve<34, 584, 84, 0>), dim3(B), dim3(64), 0, s, M, ph, a);
 	else if (build == 3) hipLaunchKernelGGL((k_solve<71, 1520, 126, 1520>), dim3(B), dim3(64), 0, s, M, ph, a);
 	else if (build == 5) hipLaunchKernelGGL((k_solve<71, 1520, 126, 1520, true, 4>), dim3(B), dim3(64), 0, s, M, ph, a);      // tests only: the reference's own sweeps (ht_debug_exact_solver)
