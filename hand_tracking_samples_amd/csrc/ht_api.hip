@@ -362,6 +362,7 @@ extern "C" int ht_destroy(ht_ctx *ctx)
 	if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
 	if (ctx->ev_lap) (void)hipEventDestroy(ctx->ev_lap);
 	if (ctx->ev_job) (void)hipEventDestroy(ctx->ev_job);
+	if (ctx->ev_seed) (void)hipEventDestroy(ctx->ev_seed);
 	if (ctx->h_job_in) (void)hipHostFree(ctx->h_job_in);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -662,5 +663,7 @@ int ht_alloc_buffers(ht_ctx *ctx)
 	HIPCHK(ctx, hipMemset(ctx->d_npts, 0, B * sizeof(int)));
 	HIPCHK(ctx, hipMemset(ctx->d_nrows, 0, B * sizeof(int)));
 	HIPCHK(ctx, hipMemset(ctx->d_ncontacts, 0, B * sizeof(int)));
+	HIPCHK(ctx, hipMemset(ctx->d_cwork, 0, (size_t)HT_CONTACT_SLOTS * ctx->cstride * sizeof(int)));      // the work histories: a slot a launch has not written yet ranks equal keys, not garbage
+	HIPCHK(ctx, hipMemset(ctx->d_swork, 0, (size_t)HT_CONTACT_SLOTS * ctx->cstride * sizeof(int)));
 	return HT_OK;
 }

@@ -33,11 +33,10 @@
 #define BLK_ENTER(ELO, EHI) "s_mov_b64 %[save], exec\n\ts_mov_b32 exec_lo, " ELO "\n\ts_mov_b32 exec_hi, " EHI "\n\t"
 #define BLK_LEAVE "s_mov_b64 exec, %[save]"
 
-// A statement can stop early: its control word cw (the same value on every lane) goes to m0, and a scalar test in front of a group of rows leaves when the block has
-// no row there (PARTIAL statements only: a full statement carries no tests).  m0 is written and read inside the one statement; the compiler keeps nothing in it
-// across (gfx9 LDS instructions do not take m0, the kernel has no indirect register access: checked in the ISA), and naming it as a clobber only draws a warning.
-#define BLK_CW "v_readfirstlane_b32 %[s], %[cw]\n\ts_mov_b32 m0, %[s]\n\t"
-#define BLK_EXIT(BIT) "s_bitcmp0_b32 m0, " #BIT "\n\ts_cbranch_scc1 9f\n\t"
+// A statement can stop early: its control word cw (the same value on every lane) goes to a scalar register of the statement's own, and a scalar test in front of a group of
+// rows leaves when the block has no row there (PARTIAL statements only: a full statement carries no tests).  The exec shifts and the tests write SCC: named as a clobber.
+#define BLK_CW "v_readfirstlane_b32 %[m], %[cw]\n\t"
+#define BLK_EXIT(BIT) "s_bitcmp0_b32 %[m], " #BIT "\n\ts_cbranch_scc1 9f\n\t"
 #define BLK_16P(SH, l0, l1, l2, l3, l4, l5, l6, l7, l8, l9, l10, l11, l12, l13, l14, l15) BLK_CW \
 	BLK_STEP(l0, SH, 0) BLK_STEP(l1, SH, 1) BLK_STEP(l2, SH, 2) BLK_STEP(l3, SH, 3) BLK_EXIT(1) BLK_STEP(l4, SH, 4) BLK_STEP(l5, SH, 5) BLK_STEP(l6, SH, 6) BLK_STEP(l7, SH, 7) \
 	BLK_EXIT(2) BLK_STEP(l8, SH, 8) BLK_STEP(l9, SH, 9) BLK_STEP(l10, SH, 10) BLK_STEP(l11, SH, 11) BLK_EXIT(3) BLK_STEP(l12, SH, 12) BLK_STEP(l13, SH, 13) BLK_STEP(l14, SH, 14) BLK_STEP(l15, SH, 15) "9:\n\t"
@@ -47,12 +46,12 @@
 template <int Q, int HALF, bool PARTIAL>
 __device__ __forceinline__ void blk_resolve16(float &x, const float lo, const float hi, float &imp, const float (&G)[32], const int cw)
 {
-	int s; long long save;
+	int s, m; long long save;
 #define BLK_G(k) (G[(Q & 1) ? 31 - (16 * HALF + (k)) : 16 * HALF + (k)])
 #define BLK_GS [g0] "v"(BLK_G(0)), [g1] "v"(BLK_G(1)), [g2] "v"(BLK_G(2)), [g3] "v"(BLK_G(3)), [g4] "v"(BLK_G(4)), [g5] "v"(BLK_G(5)), [g6] "v"(BLK_G(6)), [g7] "v"(BLK_G(7)), \
 	  [g8] "v"(BLK_G(8)), [g9] "v"(BLK_G(9)), [g10] "v"(BLK_G(10)), [g11] "v"(BLK_G(11)), [g12] "v"(BLK_G(12)), [g13] "v"(BLK_G(13)), [g14] "v"(BLK_G(14)), [g15] "v"(BLK_G(15))
-#define BLK_OPS : [imp] "+v"(imp), [x] "+v"(x), [s] "=&s"(s), [save] "=&s"(save) : [lo] "v"(lo), [hi] "v"(hi), BLK_GS
-#define BLK_OPSP : [imp] "+v"(imp), [x] "+v"(x), [s] "=&s"(s), [save] "=&s"(save) : [lo] "v"(lo), [hi] "v"(hi), [cw] "v"(cw), BLK_GS
+#define BLK_OPS : [imp] "+v"(imp), [x] "+v"(x), [s] "=&s"(s), [save] "=&s"(save) : [lo] "v"(lo), [hi] "v"(hi), BLK_GS : "scc"
+#define BLK_OPSP : [imp] "+v"(imp), [x] "+v"(x), [s] "=&s"(s), [m] "=&s"(m), [save] "=&s"(save) : [lo] "v"(lo), [hi] "v"(hi), [cw] "v"(cw), BLK_GS : "scc"
 #define BLK_BOTH(ELO, EHI, SH, ...) { if constexpr (PARTIAL) asm volatile(BLK_ENTER(ELO, EHI) BLK_16P(SH, __VA_ARGS__) BLK_LEAVE BLK_OPSP); else asm volatile(BLK_ENTER(ELO, EHI) BLK_16(SH, __VA_ARGS__) BLK_LEAVE BLK_OPS); }
 	if constexpr (Q == 0 && HALF == 0) BLK_BOTH("-1", "0", BLK_SHL_LO, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
 	if constexpr (Q == 0 && HALF == 1) BLK_BOTH("0xffff0000", "0", BLK_SHL_LO, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31)
@@ -73,10 +72,10 @@ __device__ __forceinline__ void blk_resolve16(float &x, const float lo, const fl
 // A statement of joint triples only is fifteen plain steps.  The GENERAL statement serves contacts and the block's last, partly filled, half.  The friction rows' limits
 // follow the normal row's impulse sum (physics.h:292): behind the head of a contact triple the two lanes after it set their limits to -+ mu * (the normal row's new sum),
 // written as the row-by-row sweep writes it: lim = (mu * sum) * (1 / dt), hi = lim * dt, lo = (-lim) * dt, each less the row's own sum.  cw: bit T (0..4) = triple T of the
-// statement is a contact, bit 8 + T = the block has triple T (scalar tests on m0: a joint's head costs two scalar instructions, the statement ends at the first triple
+// statement is a contact, bit 8 + T = the block has triple T (scalar tests on the control word: a joint's head costs two scalar instructions, the statement ends at the first triple
 // the block does not have); mp: the position of this lane's head row if the lane holds a friction row, else 255; fms: the head row's sum before this sweep.
 #define BLK_HEAD(LN, SH, GN, T, TP, POS) BLK_EXIT(TP) BLK_STEP(LN, SH, GN) \
-	"s_bitcmp1_b32 m0, " #T "\n\t" \
+	"s_bitcmp1_b32 %[m], " #T "\n\t" \
 	"s_cbranch_scc0 1f\n\t" \
 	"v_add_f32 %[t0], %[s], %[fms]\n\t" \
 	"v_mul_f32 %[t0], %[mu], %[t0]\n\t" \
@@ -101,13 +100,13 @@ template <int Q, int HALF, bool GENERAL>
 __device__ __forceinline__ void blk_resolve15(float &x, float &lo, float &hi, float &imp, const float (&G)[32], const float fms, const float mu, const float own, const int mp,
                                               const int idt_bits, const int dt_bits, const int cw)
 {
-	int s; long long save; float t0, t1;
+	int s, m; long long save; float t0, t1;
 #define BLK_G(k) (G[(Q & 1) ? 31 - (15 * HALF + (k)) : 15 * HALF + (k)])
 #define BLK_GS [g0] "v"(BLK_G(0)), [g1] "v"(BLK_G(1)), [g2] "v"(BLK_G(2)), [g3] "v"(BLK_G(3)), [g4] "v"(BLK_G(4)), [g5] "v"(BLK_G(5)), [g6] "v"(BLK_G(6)), [g7] "v"(BLK_G(7)), \
 	  [g8] "v"(BLK_G(8)), [g9] "v"(BLK_G(9)), [g10] "v"(BLK_G(10)), [g11] "v"(BLK_G(11)), [g12] "v"(BLK_G(12)), [g13] "v"(BLK_G(13)), [g14] "v"(BLK_G(14))
-#define BLK_OPSG : [imp] "+v"(imp), [x] "+v"(x), [lo] "+v"(lo), [hi] "+v"(hi), [s] "=&s"(s), [save] "=&s"(save), [t0] "=&v"(t0), [t1] "=&v"(t1) \
-	: [fms] "v"(fms), [mu] "v"(mu), [own] "v"(own), [mp] "v"(mp), [idt] "s"(idt_bits), [dt] "s"(dt_bits), [cw] "v"(cw), BLK_GS : "vcc"
-#define BLK_OPS : [imp] "+v"(imp), [x] "+v"(x), [s] "=&s"(s), [save] "=&s"(save) : [lo] "v"(lo), [hi] "v"(hi), BLK_GS
+#define BLK_OPSG : [imp] "+v"(imp), [x] "+v"(x), [lo] "+v"(lo), [hi] "+v"(hi), [s] "=&s"(s), [m] "=&s"(m), [save] "=&s"(save), [t0] "=&v"(t0), [t1] "=&v"(t1) \
+	: [fms] "v"(fms), [mu] "v"(mu), [own] "v"(own), [mp] "v"(mp), [idt] "s"(idt_bits), [dt] "s"(dt_bits), [cw] "v"(cw), BLK_GS : "vcc", "scc"
+#define BLK_OPS : [imp] "+v"(imp), [x] "+v"(x), [s] "=&s"(s), [save] "=&s"(save) : [lo] "v"(lo), [hi] "v"(hi), BLK_GS : "scc"
 #define BLK_BOTH(ELO, EHI, SH, ...) { if constexpr (GENERAL) asm volatile(BLK_ENTER(ELO, EHI) BLK_15G(SH, __VA_ARGS__) BLK_LEAVE BLK_OPSG); else asm volatile(BLK_ENTER(ELO, EHI) BLK_15(SH, __VA_ARGS__) BLK_LEAVE BLK_OPS); }
 	if constexpr (Q == 0 && HALF == 0) BLK_BOTH("-1", "0", BLK_SHL_LO, 0, 3, 6, 9, 12, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14)
 	if constexpr (Q == 0 && HALF == 1) BLK_BOTH("0xffff8000", "0", BLK_SHL_LO, 15, 18, 21, 24, 27, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29)

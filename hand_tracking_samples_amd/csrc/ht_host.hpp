@@ -22,7 +22,7 @@ struct ht_ctx
 	hipStream_t last_user_stream = nullptr;         // stream of the latest *_dev call (host-read helpers wait for it too)
 	hipStream_t side[2] = { nullptr, nullptr };     // independent kernels of one fit step (cloud rows, contacts, chamber) run side by side
 	hipEvent_t ev_fork = nullptr, ev_join[2] = { nullptr, nullptr }, ev_lap = nullptr;
-	hipEvent_t ev_job = nullptr; bool job_pending = false; void *h_job_in = nullptr; size_t h_job_cap = 0;      // ht_job_start: the CNN job of the overlapped update() in flight on this context, its pinned input staging
+	hipEvent_t ev_job = nullptr, ev_seed = nullptr; bool job_pending = false; void *h_job_in = nullptr; size_t h_job_cap = 0;      // ht_job_start: the CNN job of the overlapped update() in flight on this context, its pinned input staging
 	ht_params par;
 	ht_physics_dev phys;
 	ht_model_dev model;

@@ -218,7 +218,7 @@ static int run_update_(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams
 	const ht_params &p = ctx->par;
 	const int nb = ctx->model.nb;
 	const int iw = fs ? fs->w : 64, ih = fs ? fs->h : 64;      // the image FitError looks at
-	{ const int npx = iw * ih, fr = p.subsample_fraction > 0 ? p.subsample_fraction : 1, n = (mode == UPD_FULL && p.subsample_voxel) ? npx : (npx + fr - 1) / fr; if (n > ctx->model.pts_cap) { const int r = ht_reserve_points_locked(ctx, n); if (r) return r; } ctx->model.pts_bound = (n + 63) & ~63; }
+	{ const int npx = iw * ih, fr = p.subsample_fraction > 0 ? p.subsample_fraction : 1, n = ((mode == UPD_FULL || mode == UPD_PASSES) && p.subsample_voxel) ? npx : (npx + fr - 1) / fr; if (n > ctx->model.pts_cap) { const int r = ht_reserve_points_locked(ctx, n); if (r) return r; } ctx->model.pts_bound = (n + 63) & ~63; }
 	const float *img_cams = ctx->d_cams;
 	if (fs)
 	{
@@ -249,11 +249,11 @@ static int run_update_(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams
 		{
 			const ht_prepare_extra pz = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, ctx->d_nflist };
 			if (fs->direct) { HIPCHK(ctx, hipMemsetAsync(ctx->d_nflist, 0, sizeof(int), s)); ht_launch_cnn_input(d_depth, ctx->d_cams, fs->w * fs->h, p.drangey, ctx->d_in128, B, s); }
-			else ht_launch_prepare(ctx->d_seg_tiles, ctx->d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, nullptr, nullptr, ctx->model.pts_cap, B, s, &pz);
+			else if (mode != UPD_PASSES) ht_launch_prepare(ctx->d_seg_tiles, ctx->d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, nullptr, nullptr, ctx->model.pts_cap, B, s, &pz);      // (the caller's part of the overlapped update has no segment and no net)
 			ht_launch_prepare_frame(d_depth, img_cams, fs->w, fs->h, p.drangey, p.subsample_fraction, ctx->d_pts, ctx->d_npts, ctx->d_overflow, ctx->model.pts_cap, B, s);
 		}
 		else ht_launch_prepare(d_depth, d_cams, p.drangey, p.subsample_fraction, ctx->d_cnn_in, ctx->d_pts, ctx->d_npts, ctx->model.pts_cap, B, s, &px);
-		if (mode == UPD_FULL && p.subsample_voxel)
+		if ((mode == UPD_FULL || mode == UPD_PASSES) && p.subsample_voxel)      // UPD_PASSES: the caller's part of the overlapped update runs its passes on this very cloud (handtrack.h:753)
 		{
 			// the main-thread cloud of handtrack.h:751 with the voxel rule: ALL in-range points (taken once more, into the cloud-row array, which nothing
 			// uses before the first fit step) go through the voxel table; the CNN job keeps the every-n-th cloud above (handtrack.h:703)
@@ -712,9 +712,14 @@ extern "C" int ht_job_start(ht_ctx *job, ht_ctx *main, const uint16_t *depth, co
 	ht_launch_set_pose(job->d_state[1], main->d_state[0], nb, B, 2, s);
 	HIPCHK(job, hipMemcpyAsync(job->d_prev_err, main->d_prev_err, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
 	HIPCHK(job, hipMemcpyAsync(job->d_initializing, main->d_initializing, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s));
+	// othermodel's seed is taken BEFORE the caller goes on (the reference copies synchronously in front of std::async, :757): the caller's stream waits for these copies, so its
+	// next passes cannot overwrite handmodel under them
+	if (!job->ev_seed) HIPCHK(job, hipEventCreateWithFlags(&job->ev_seed, hipEventDisableTiming));
+	HIPCHK(job, hipEventRecord(job->ev_seed, s));
+	HIPCHK(job, hipStreamWaitEvent(main->stream, job->ev_seed, 0));
 	const frame_src fs = { w, h, segment_scale, 0 };
 	int r = run_update(job, d_in, d_cin, nullptr, B, job->d_poses_out, nullptr, s, tile ? nullptr : &fs, UPD_CNN_MODEL);
-	if (r) return r;
+	if (r) { (void)hipStreamSynchronize(s); return r; }      // the queued uploads read h_job_in: nothing may be in flight when the caller frees or reuses it
 	HIPCHK(job, hipEventRecord(job->ev_job, s));
 	job->job_pending = true;
 	return HT_OK;
