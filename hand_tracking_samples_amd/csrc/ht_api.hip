@@ -650,6 +650,7 @@ int ht_alloc_buffers(ht_ctx *ctx)
 	}
 	A(d_nrows, B);
 	A(d_chamber, B * 5 * nb * HT_ROW); A(d_nchamber, B); A(d_accepted, B);
+	A(d_tables, B * TB_WORDS); A(d_chplanes, B * 20); A(d_chon, B);
 	A(d_contacts, B * HT_MAXCONTACT * HT_CONTACT); A(d_ncontacts, B); A(d_epa_ws, ht_contacts_workspace_bytes((int)B)); HIPCHK(ctx, hipMemset(ctx->d_epa_ws, 0, ht_contacts_workspace_bytes((int)B)));
 	ctx->cstride = (int)B + 8; A(d_cwork, (size_t)HT_CONTACT_SLOTS * ctx->cstride); A(d_corder, (size_t)HT_CONTACT_SLOTS * ctx->cstride); A(d_porder, B); A(d_swork, (size_t)HT_CONTACT_SLOTS * ctx->cstride); A(d_sorder, (size_t)HT_CONTACT_SLOTS * ctx->cstride);
 	if ((r = ht_reserve_points_locked(ctx, HT_MAXPTS))) return r;

@@ -899,6 +899,50 @@ __global__ __launch_bounds__(64) void k_chamber(ht_model_dev M, const float *__r
 	}
 }
 
+// ------------------------------------------------------------------------------------------------- k_chamber_planes
+// The five containing planes alone (physmodel.h:183-193): they follow from the frame's points, not from the pose, so the three main-thread passes of an update
+// (handtrack.h:769-780) share them -- one scan per update, beside the net, instead of one per pass; the planes' rows (one per plane and body) are made pass by pass
+// by k_solve_prep (csrc/ht_prep.hip).  planes [B][5][4], on [B] = the frame has them (handtrack.h:774).  Same statements as k_chamber's first half.
+__global__ __launch_bounds__(64) void k_chamber_planes(ht_model_dev M, const float4 *__restrict__ pts, const int *__restrict__ npts, int min_point_num, int enabled, float *__restrict__ planes, int *__restrict__ onflag)
+{
+	__shared__ float4 chunk[256];
+	const int b = blockIdx.x, lane = threadIdx.x;
+	const int n = npts[b];
+	const bool on = enabled && n > min_point_num;        // handtrack.h:774
+	if (lane == 0) onflag[b] = on ? 1 : 0;
+	if (!on) return;
+	const float od[5][3] = { { -1, -0.25f, 0 }, { -1, -1, 0 }, { 0, -1, 0 }, { 1, -1, 0 }, { 1, -0.25f, 0 } };    // handtrack.h:776
+	const int dl = lane < 5 ? lane : 0;
+	const v3 outdir = V3(od[dl][0], od[dl][1], od[dl][2]), origin = V3(0, 0, 0), viewdir = V3(0, 0, 1);
+	v3 best = viewdir - outdir;
+	best = best + origin;
+	const v3 tangent = cross(best, outdir);
+	for (int base = 0; base < n; base += 256)
+	{
+		const int m = min(256, n - base);
+		__syncthreads();
+		for (int i = lane; i < m; i += 64) chunk[i] = pts[(size_t)b * M.pts_cap + base + i];
+		__syncthreads();
+		if (lane < 5)
+			for (int i = 0; i < m; i++)
+			{
+				const float4 pv = chunk[i];
+				const v3 p = V3(pv.x, pv.y, pv.z);
+				if (dot(cross(best - origin, p - origin), tangent) > 0) best = p;
+			}
+	}
+	if (lane < 5)
+	{
+		v3 nn = normalize(cross(tangent, best));
+		float *o = planes + (size_t)b * 20 + 4 * lane;
+		o[0] = nn.x; o[1] = nn.y; o[2] = nn.z; o[3] = -dot(nn, origin);
+	}
+}
+void ht_launch_chamber_planes(const ht_model_dev &M, const float4 *pts, const int *npts, int min_point_num, int enabled, float *planes, int *on, int B, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_chamber_planes, dim3(B), dim3(64), 0, s, M, pts, npts, min_point_num, enabled, planes, on);
+}
+
 // ------------------------------------------------------------------------------------------------- launchers
 // `rec`: instead of the 16-float rows, write each row's solver record into the frames' scratch slots and the rows' bodies into rec->body (k_solve then only
 // lists them per body); null: the reference-layout rows (stage calls, UnibodyFit)

@@ -58,6 +58,9 @@ struct ht_ctx
 	float *d_rows = nullptr; int *d_nrows = nullptr;            // cloud rows [B][pts_cap][HT_ROW] in the reference's layout (stage calls, UnibodyFit, caller-built rows)
 	unsigned char *d_rowbody = nullptr;                          // [B][pts_cap] body of every cloud row whose solver record k_cloud_rows wrote into d_scratch
 	float *d_chamber = nullptr; int *d_nchamber = nullptr;      // [B][5*nb][HT_ROW]
+	float *d_tables = nullptr;                                   // [B][TB_WORDS] the solve tables k_solve_prep makes and k_solve reads (ht_solve_shared.hpp)
+	float *d_chplanes = nullptr; int *d_chon = nullptr; bool planes_valid = false;      // [B][5][4], [B]: the boundary planes of the update's main-thread cloud (k_chamber_planes: once per update); valid inside the update that made them
+	int solve_tables = 0;                                       // 1 (ht_debug_solve_tables; tools/exp_tables.sh): k_solve_prep makes every solve's tables beside the contact kernel.  Measured slower in round 6 (profiles/r06_notes.md section 1): off
 	int *d_accepted = nullptr;
 	float *d_contacts = nullptr; int *d_ncontacts = nullptr;    // [B][HT_MAXCONTACT][HT_CONTACT]
 	int *d_cwork = nullptr, *d_corder = nullptr;                  // [HT_CONTACT_SLOTS][cstride]: what every frame cost in every contact launch of the latest update; the assignment of frames to blocks made from it for the current one (ht_gjk.hip: k_contact_order)

@@ -31,8 +31,24 @@ struct solve_args
 	float *out_poses; const int *out_npts; int *out_initializing; int out_min_point_num;
 	int ang_extra_bound;                                            // angular rows a frame can have beyond the 13 CNN-driven ones and 6 per joint (slowfit: 3 per joint; caller-built rows: their largest count): picks the build
 	float *exact_lin, *exact_ang;                                   // force_build 5 (tests only, ht_debug_exact_solver): the two-body linear rows [B][512][HT_ROW] and the angular rows [B][256][8] in the reference's layout, for the reference's own sweeps
+	const float *tables;                                            // [B][TB_WORDS] (ht_solve_shared.hpp): k_solve_prep has made this solve's tables; null: k_solve's own prologue
 	int dbg;                                                        // timing experiments only (HT_DEBUG_SKIP): 1 skip chains, 2 skip two-body linear, 4 skip angular
 };
+
+// k_solve_prep (csrc/ht_prep.hip): the tables of one solve, four waves per frame, on a side stream beside the contact kernel (layout: ht_solve_shared.hpp)
+#define TB_WORDS 8928      // words of a frame's tables
+struct prep_args
+{
+	const float *state; const float *analysis; const float *cams; const int *active_flag;
+	float *scratch; int scratch_stride; int batch;
+	const unsigned char *cloud_body; const int *n_cloud;      // the cloud rows' bodies (k_cloud_rows wrote their records into the scratch slots); null: a solve without cloud rows
+	const float *ch_planes; const int *ch_on;                   // boundary planes [B][5][4] of the frames whose ch_on is set (k_chamber_planes); null: a solve without them
+	float *rows_pre; int *n_pre; float ch_maxforce;             // their rows in the reference's layout [B][5 * nb][HT_ROW] and count, for a frame that falls back to k_solve's own prologue
+	int apply_angles; float drive_force; int ray_rows; int arm_cone; int steps_keyangles; float min_cray_prob;
+	float *tables;                                              // [B][TB_WORDS]
+	int dbg;
+};
+void ht_launch_solve_prep(const ht_model_dev &M, const ht_physics_dev &ph, const prep_args &a, int B, hipStream_t s);
 
 // where k_cloud_rows puts the solver's records of its rows (ht_quad.hpp): the frames' scratch slots [B][stride][HT_CREC], the rows' bodies [B][pts_cap], the time step
 struct cloud_records { float *scratch; int stride; unsigned char *body; float dt; };
@@ -48,6 +64,7 @@ struct ht_fit_after
 };
 void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, int w, int h, float scale, float *err, int B, hipStream_t s, const ht_fit_after *after = nullptr);
 void ht_launch_chamber(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, int min_point_num, int enabled, float maxforce, float *rows, int *nch, int B, hipStream_t s);
+void ht_launch_chamber_planes(const ht_model_dev &M, const float4 *pts, const int *npts, int min_point_num, int enabled, float *planes, int *on, int B, hipStream_t s);      // the five planes alone [B][5][4], on [B]: once per update (k_solve_prep makes their rows pass by pass)
 void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s, bool beside_cloud_rows = false, int force_kernel = 0, int few_frames = 0,
                         const int *order = nullptr, int *work_out = nullptr);      // order / work_out (cooperative kernel only, both may be null): the frame of every (slot, block) as k_contact_order dealt them; where every live frame leaves what it cost
 int ht_contacts_frames_per_block(const ht_model_dev &M, int B);

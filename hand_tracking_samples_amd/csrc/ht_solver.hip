@@ -29,44 +29,7 @@
 // with g = cross(r, n), b = Iinv*g (Iinv symmetric), all formed with the reference's expressions.  A sweep then issues ~20 instructions per
 // row instead of ~80 and the dependent chain through the momenta is 8-11 operations.  Same rows, same order, same clamps as the reference;
 // another association order of the floating-point operations: see ht_quad.hpp and DESIGN.md (Numerics) for the measured effect.
-#include "ht_device.hpp"
-#include "ht_launch.hpp"
-
-// A two-body linear GROUP = the 3 consecutive rows of a joint (x, y, z) or of a contact (normal + 2 friction rows): same two bodies.  64 floats:
-#define LGRP 64
-#define LG_S 0             // 3 x float4: targetspeed, targetspeed after RemoveBias, fmin*dt, fmax*dt (friction rows: fmax slot = mu)
-#define LG_RINV 12         // 3: 1 / effective mass
-#define LG_META 15         // flags | rb0 | rb1 << 8
-#define LG_SUM 16          // 3: impulse sums (the only words a sweep writes)
-#define LG_N 19            // 9: row direction n_k[c] at LG_N + 3k + c
-#define LG_GB 28           // 36: (g, b) of row k, side s, component c at LG_GB + ((2k + s)*3 + c)*2; side 0 (rb0) carries its minus sign
-// An angular row, 16 floats:
-#define AROW 16
-#define AR_S 0             // float4: targetspin, targetspin after RemoveBias, mintorque*dt, maxtorque*dt
-#define AR_GAIN 4          // 1 / (axis.Iinv0.axis + axis.Iinv1.axis); 0 for a disabled row (physics.h:252)
-#define AR_TORQUE 5        // accumulated torque (the only word a sweep writes)
-#define AR_AXIS 6          // 3, then the gain of the sweeps after RemoveBias
-#define AR_BA 10           // 6: -(Iinv0*axis), then Iinv1*axis
-// Angular rows are built in registers: row r by lane r % 64, slot r / 64.  AS = slots per lane is a build parameter: 2 (up to 126 rows: the stock hand has 13 CNN-driven +
-// 71 of its joints) for the tile builds, 4 (up to 252 rows) for the build that serves any model ht_create accepts -- 13 + 6 rows per joint + slowfit's 3 relative rows per
-// joint = 13 + 9 * 26 joints = 247 (ht_launch_solve picks it from the bound the caller states; ht_create refuses more than 26 joints).
-#define MAXA2_OF(AS) (64 * (AS))
-#define MAXA_CAP_OF(AS) ((AS) == 2 ? 126 : 252)
-#define MAXA_RUNS 128      // runs of consecutive angular rows on one body pair a solve schedules (a joint's rows are one run: 13 + 2 per joint; beyond: counted, dropped)
-#define MAXG (HT_MAXNJ + HT_MAXCONTACT_LDS + 1)      // groups the level schedule has LDS tables for: every joint, 96 contacts, the idle group
-#define MAXG_CAP (32 + HT_MAXNJ + HT_MAXCONTACT + 1)      // groups a frame can have (their records in the tail of its scratch slot when they exceed the build's LDS pool): a caller's 32, every joint,
-                                                          // every contact the contact kernel keeps, the idle group.  Beyond MAXG - 1 groups there is no level schedule: one group per step, in row order
-// LDS per frame: ~5 KB of body state and schedule tables, a 5 KB union of prologue scratch and the angular records, and three arrays whose size is
-// the build's choice -- the two-body linear groups (256 B each), the impulse sums of the single-body rows (4 B each), the angular records (64 B each).
-// A frame whose rows do not fit an array keeps THAT array in its slot of the solver scratch in HBM instead (same code through a generic pointer): slower
-// for that frame, correct for every frame, one launch.  Builds (ht_launch_solve):
-//   small   34 groups (16 joints + 17 contacts), 584 sums, 84 angular rows (13 CNN-driven + 71 of the hand's joints), chain lists in HBM: 20 KB = 40 LDS
-//           allocation units of 512 B, EIGHT frames per CU (2048 frames fill the GPU in one round, 8192 in four).  Batches above 1024 frames of 64x64 tiles.
-//   only    66 groups (16 joints + 49 contacts), 1024 sums and chain entries, 126 angular rows: 36 KB, four frames per CU (a 1024-frame batch in one round).
-//   mid     71 groups, 1520 sums and chain entries, 126 angular rows: 40 KB, four frames per CU.  Larger models, full-size frames.
-#define IDLE_BODY (HT_MAXNB - 1)      // lane pairs without a row in a step work on this all-zero body and on an all-zero record
-#define LM_FRIC 0x10000    // meta bits of a group: contact (friction rows limited by the normal row's impulse sum, physics.h:292)
-#define LM_NORMAL 0x20000
+#include "ht_solve_shared.hpp"
 
 template <int NGRP_, int NSUM_, int NANG_, int NIDX_, int AS_ = 2, int NCG_ = 0> struct lds_t
 {
@@ -107,155 +70,6 @@ template <int NGRP_, int NSUM_, int NANG_, int NIDX_, int AS_ = 2, int NCG_ = 0>
 	};
 };
 
-#include "ht_quad.hpp"
-#include "ht_block.hpp"
-
-__device__ __forceinline__ v3 L3(const float *p) { return V3(p[0], p[1], p[2]); }
-__device__ __forceinline__ v4 L4(const float *p) { return V4(p[0], p[1], p[2], p[3]); }
-__device__ __forceinline__ void S3(float *p, v3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
-__device__ __forceinline__ m3 LM(const float *p) { m3 m; m.x = V3(p[0], p[1], p[2]); m.y = V3(p[3], p[4], p[5]); m.z = V3(p[6], p[7], p[8]); return m; }
-template <class LDS> __device__ __forceinline__ xf body_xf(const LDS &S, int b) { return XF(L3(S.pos[b]), L4(S.q[b])); }
-__device__ __forceinline__ v3 F3(float4 f) { return V3(f.x, f.y, f.z); }
-template <class LDS> __device__ __forceinline__ m3 body_I(const LDS &S, int b) { m3 m; m.x = F3(S.I4[b][0]); m.y = F3(S.I4[b][1]); m.z = F3(S.I4[b][2]); return m; }
-template <class LDS> __device__ __forceinline__ v3 anchor_world(const LDS &S, int rb, v3 p) { return rb >= 0 ? apply(body_xf(S, rb), p) : p; }
-
-// ---- angular row builders ----------------------------------------------------------------------
-__device__ __forceinline__ void put_ang(float *o, int rb0, int rb1, v3 axis, float targetspin, float mintorque, float maxtorque)
-{
-	o[0] = __int_as_float(rb0); o[1] = __int_as_float(rb1); o[2] = axis.x; o[3] = axis.y; o[4] = axis.z; o[5] = targetspin; o[6] = mintorque; o[7] = maxtorque;
-}
-// Row builders that can emit several rows take a sink that keeps only the row its lane owns: nothing is indexed dynamically, so the
-// rows stay in registers (a private array indexed with a run-time value would live in scratch memory).
-struct ang_sink { int want, n; float row[8]; };
-__device__ __forceinline__ void emit_ang(ang_sink &k, int rb0, int rb1, v3 axis, float targetspin, float mintorque, float maxtorque)
-{
-	if (k.n == k.want) put_ang(k.row, rb0, rb1, axis, targetspin, mintorque, maxtorque);
-	k.n++;
-}
-// ConstrainAngularRangeW physics.h:351-393; sin() there is the C double overload, the sums are formed in double and rounded once
-__device__ __forceinline__ void angular_range_w(const ht_physics_dev &ph, int rb0, v4 jb0, int rb1, v4 jf1, v3 lmin, v3 lmax, ang_sink &out)
-{
-	const float dt = ph.deltaT;
-	v3 jmin = (lmin * 3.14f) / 180.0f, jmax = (lmax * 3.14f) / 180.0f;
-	if (jmin.x == 0 && jmax.x == 0 && jmin.z < jmax.z)
-	{
-		v4 cb = normalize(V4(0, -1, 0, 1));
-		jb0 = qmul(jb0, cb); jf1 = qmul(jf1, cb);
-		v3 nmin = V3(lmin.z, lmin.y, 0), nmax = V3(lmax.z, lmax.y, 0);
-		lmin = nmin; lmax = nmax;
-		jmin = (lmin * 3.14f) / 180.0f; jmax = (lmax * 3.14f) / 180.0f;
-		// (the recursion of the reference can fire at most once more only if the swapped x-range is again 0 with z<..., z is now 0: impossible)
-	}
-	v4 r = qmul(qconj(jb0), jf1);
-	v4 s = quat_from_to(V3(0, 0, 1.0f), qzdir(r));
-	v4 t = qmul(qconj(s), r);
-	if (jmax.x == jmin.x)
-		emit_ang(out, rb0, rb1, qxdir(jf1), (float)(2 * ((double)(-s.x) + sin((double)(jmin.x / 2.0f))) / (double)dt), -FLT_MAX, FLT_MAX);
-	else if (jmax.x - jmin.x < 360.0f * 3.14f / 180.0f)
-	{
-		emit_ang(out, rb0, rb1, qxdir(jf1), (float)(2 * ((double)(-s.x) + sin((double)(jmin.x / 2.0f))) / (double)dt), 0, FLT_MAX);
-		emit_ang(out, rb0, rb1, -qxdir(jf1), (float)(2 * ((double)(s.x) - sin((double)(jmax.x / 2.0f))) / (double)dt), 0, FLT_MAX);
-	}
-	if (jmax.y == jmin.y)
-		emit_ang(out, rb0, rb1, qydir(jf1), ph.biasfactorjoint * 2 * (-s.y + jmin.y) / dt, -FLT_MAX, FLT_MAX);
-	else
-	{
-		emit_ang(out, rb0, rb1, qydir(jf1), (float)(2 * ((double)(-s.y) + sin((double)(jmin.y / 2.0f))) / (double)dt), 0, FLT_MAX);
-		emit_ang(out, rb0, rb1, -qydir(jf1), (float)(2 * ((double)(s.y) - sin((double)(jmax.y / 2.0f))) / (double)dt), 0, FLT_MAX);
-	}
-	if (jmin.z == jmax.z)
-		emit_ang(out, rb0, rb1, qzdir(jf1), ph.biasfactorjoint * 2 * -t.z / dt, -FLT_MAX, FLT_MAX);
-	else
-	{
-		emit_ang(out, rb0, rb1, qzdir(jf1), (float)(2 * ((double)(-t.z) + sin((double)(jmin.z / 2.0f))) / (double)dt), 0, FLT_MAX);
-		emit_ang(out, rb0, rb1, -qzdir(jf1), (float)(2 * ((double)(t.z) - sin((double)(jmax.z / 2.0f))) / (double)dt), 0, FLT_MAX);
-	}
-}
-// Row `want` of the rows ConstrainAngularRangeW emits for a joint (same order, same expressions as angular_range_w above, which builds them all): a lane
-// that owns one row pays for one double-precision sine instead of up to six.  The two-sided rows' target spins are 2*((-c) + sin(min/2))/dt and
-// 2*(c - sin(max/2))/dt; c - s is evaluated as c + (-s), which is the same IEEE operation.
-__device__ __forceinline__ void angular_range_row(const ht_physics_dev &ph, int rb0, v4 jb0, int rb1, v4 jf1, v3 lmin, v3 lmax, int want, float *row)
-{
-	const float dt = ph.deltaT;
-	v3 jmin = (lmin * 3.14f) / 180.0f, jmax = (lmax * 3.14f) / 180.0f;
-	if (jmin.x == 0 && jmax.x == 0 && jmin.z < jmax.z)
-	{
-		v4 cb = normalize(V4(0, -1, 0, 1));
-		jb0 = qmul(jb0, cb); jf1 = qmul(jf1, cb);
-		v3 nmin = V3(lmin.z, lmin.y, 0), nmax = V3(lmax.z, lmax.y, 0);
-		lmin = nmin; lmax = nmax;
-		jmin = (lmin * 3.14f) / 180.0f; jmax = (lmax * 3.14f) / 180.0f;
-	}
-	const v4 r = qmul(qconj(jb0), jf1);
-	const v4 s = quat_from_to(V3(0, 0, 1.0f), qzdir(r));
-	const v4 t = qmul(qconj(s), r);
-	// which axis and which of its rows
-	const int nx = (jmax.x == jmin.x) ? 1 : ((jmax.x - jmin.x < 360.0f * 3.14f / 180.0f) ? 2 : 0), ny = (jmax.y == jmin.y) ? 1 : 2;
-	int k = want, axis = 0;
-	if (k >= nx) { k -= nx; axis = 1; if (k >= ny) { k -= ny; axis = 2; } }
-	const float lo = axis == 0 ? jmin.x : axis == 1 ? jmin.y : jmin.z, hi = axis == 0 ? jmax.x : axis == 1 ? jmax.y : jmax.z;
-	const float comp = axis == 0 ? s.x : axis == 1 ? s.y : t.z;
-	const v3 dir = axis == 0 ? qxdir(jf1) : axis == 1 ? qydir(jf1) : qzdir(jf1);
-	const bool equal = hi == lo, upper = !equal && k == 1;
-	const double sn = sin((double)((upper ? hi : lo) / 2.0f));
-	const float two_sided = (float)(2 * ((double)(upper ? comp : -comp) + (upper ? -sn : sn)) / (double)dt);
-	float ts = two_sided;
-	if (equal && axis == 1) ts = ph.biasfactorjoint * 2 * (-s.y + jmin.y) / dt;
-	if (equal && axis == 2) ts = ph.biasfactorjoint * 2 * -t.z / dt;
-	put_ang(row, rb0, rb1, upper ? -dir : dir, ts, equal ? -FLT_MAX : 0, FLT_MAX);
-}
-// ConstrainConeAngle physics.h:402-414
-template <class LDS> __device__ __forceinline__ void cone_angle(const ht_physics_dev &ph, const LDS &S, int rb0, v3 n0, int rb1, v3 n1, float limitangle_degrees, float *out)
-{
-	int equality = (limitangle_degrees == 0);
-	v3 a0 = rb0 >= 0 ? qrot(L4(S.q[rb0]), n0) : n0;
-	v3 a1 = rb1 >= 0 ? qrot(L4(S.q[rb1]), n1) : n1;
-	v3 axis = safenormalize(cross(a1, a0));
-	float rbangle = acos_f(clamp_std(dot(a0, a1), 0.0f, 1.0f));
-	float dangle = rbangle - (limitangle_degrees) * 3.14f / 180.0f;
-	float targetspin = ((equality) ? ph.biasfactorjoint : 1.0f) * dangle / ph.deltaT;
-	put_ang(out, rb0, rb1, axis, targetspin, (limitangle_degrees > 0.0f) ? 0 : -FLT_MAX, FLT_MAX);
-}
-// ConstrainAngularDrive physics.h:313-326
-template <class LDS> __device__ __forceinline__ void angular_drive(const ht_physics_dev &ph, const LDS &S, int rb0, int rb1, v4 target, float maxtorque, float (*out)[8])
-{
-	v4 q0 = rb0 >= 0 ? L4(S.q[rb0]) : V4(0, 0, 0, 1), q1 = rb1 >= 0 ? L4(S.q[rb1]) : V4(0, 0, 0, 1);
-	v4 dq = qmul(q1, qconj(qmul(q0, target)));
-	if (dq.w < 0) dq = -dq;
-	v3 axis = safenormalize(xyz(dq));
-	v3 binormal = orth(axis);
-	v3 normal = cross(axis, binormal);
-	put_ang(out[0], rb0, rb1, axis, -ph.biasfactorjoint * (acos_f(clamp_std(dq.w, -1.0f, 1.0f)) * 2.0f) / ph.deltaT, -maxtorque, maxtorque);
-	put_ang(out[1], rb0, rb1, binormal, 0, -maxtorque, maxtorque);
-	put_ang(out[2], rb0, rb1, normal, 0, -maxtorque, maxtorque);
-}
-
-// landmark feature points, handtrack.h:77-81
-__constant__ int FEATURE_BONE[8] = { 1, 1, 1, 4, 7, 10, 13, 16 };
-__constant__ float FEATURE_OFF[8][3] = { { 0, 0, 0 }, { -0.03f, 0, -0.03f }, { 0.03f, 0, -0.03f }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
-
-// ---- two-body row maths ------------------------------------------------------------------------
-template <class LDS> __device__ __forceinline__ v3 spin_of(const LDS &S, int b) { return mul(body_I(S, b), F3(S.ang4[b])); }       // physics.h:126
-// ------------------------------------------------------------------------------------------------- k_solve
-struct ht_true { static constexpr bool value = true; };
-struct ht_false { static constexpr bool value = false; };
-struct arow { int rb0, rb1; v3 axis; float targetspin, mn, mx, s2t, torque, mintorque; int lev; };
-
-// row counts of ConstrainAngularRangeW (physics.h:351-393) for given limits, without building the rows
-__device__ __forceinline__ int angular_range_count(v3 lmin, v3 lmax)
-{
-	v3 jmin = (lmin * 3.14f) / 180.0f, jmax = (lmax * 3.14f) / 180.0f;
-	if (jmin.x == 0 && jmax.x == 0 && jmin.z < jmax.z)
-	{
-		v3 nmin = V3(lmin.z, lmin.y, 0), nmax = V3(lmax.z, lmax.y, 0);
-		jmin = (nmin * 3.14f) / 180.0f; jmax = (nmax * 3.14f) / 180.0f;
-	}
-	int n = 0;
-	if (jmax.x == jmin.x) n += 1; else if (jmax.x - jmin.x < 360.0f * 3.14f / 180.0f) n += 2;
-	n += (jmax.y == jmin.y) ? 1 : 2;
-	n += (jmin.z == jmax.z) ? 1 : 2;
-	return n;
-}
 
 // Level schedule of one solve's groups (two-body linear groups, or runs of angular rows), on the whole wave.
 //   level(group) = 1 + the highest level of an earlier group that shares a body with it, so conflicting rows keep the reference's order;
@@ -330,6 +144,27 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	const int nb = M.nb, nj = M.nj;
 	float *st = a.state + (size_t)b * nb * HT_STATE_STRIDE;
 	const float dt = ph.deltaT;
+	// ---- round 6: the solve's tables come ready from k_solve_prep (ht_solve_shared.hpp, csrc/ht_prep.hip) -- the joints' groups, the angular records, the blocks' couplings
+	//      and edges, the chain lists and their blocks' couplings -- unless the frame is one the blocked form does not hold (then everything below runs as it always did).
+	//      `fast` is the same on every lane.  What is left of the prologue for such a frame: the bodies, the contacts' groups and their couplings.
+	const float *const T = a.tables ? a.tables + (size_t)b * TB_WORDS : nullptr;
+	bool fast = false;
+	int t_na = 0, t_npre = 0, t_total = 0, t_e0 = 0, t_nblk = 0, t_head = 0;
+	if constexpr (!EXACT)
+	{
+		if (T && !a.two_body_levels && !a.lin_tail && !a.ang_user && !a.no_model_rows && !(a.sf_refpose && a.sf_hold) && a.sf_select < 0 && a.sf_ncray == 0 && !a.rows_cloud)
+		{
+			const int h = lane < 32 ? reinterpret_cast<const int *>(T + TB_HDR)[lane] : 0;
+			const int nc0 = (a.contacts && ph.use_collision) ? a.ncontacts[b] : 0;
+			const int R = lane >> 4;
+			t_na = __builtin_amdgcn_readlane(h, TH_NA); t_npre = __builtin_amdgcn_readlane(h, TH_NPRE); t_total = __builtin_amdgcn_readlane(h, TH_TOTAL);
+			t_e0 = R == 0 ? __builtin_amdgcn_readlane(h, TH_E0) : R == 1 ? __builtin_amdgcn_readlane(h, TH_E0 + 1) : R == 2 ? __builtin_amdgcn_readlane(h, TH_E0 + 2) : __builtin_amdgcn_readlane(h, TH_E0 + 3);
+			t_nblk = R == 0 ? __builtin_amdgcn_readlane(h, TH_NBLK) : R == 1 ? __builtin_amdgcn_readlane(h, TH_NBLK + 1) : R == 2 ? __builtin_amdgcn_readlane(h, TH_NBLK + 2) : __builtin_amdgcn_readlane(h, TH_NBLK + 3);
+			t_head = R == 0 ? __builtin_amdgcn_readlane(h, TH_HEAD) : R == 1 ? __builtin_amdgcn_readlane(h, TH_HEAD + 1) : R == 2 ? __builtin_amdgcn_readlane(h, TH_HEAD + 2) : __builtin_amdgcn_readlane(h, TH_HEAD + 3);
+			fast = __builtin_amdgcn_readlane(h, TH_OK) != 0 && 3 * nj + 3 * (nc0 > HT_MAXCONTACT ? HT_MAXCONTACT : nc0) <= 4 * BLK_LROWS && !HT_DBG(a.dbg, 65536) && !HT_DBG(a.dbg, 1 << 22);
+			fast = __builtin_amdgcn_readfirstlane((int)fast) != 0;
+		}
+	}
 
 	// ---- load state, rbinitvelocity (physics.h:500-519) ----
 	if (lane < nb)
@@ -348,12 +183,12 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 		m3 I = world_inertia(V4(s[3], s[4], s[5], s[6]), LM(bc + HT_BC_TINV), bc[HT_BC_MASSINV]);
 		S.I4[lane][0] = make_float4(I.x.x, I.x.y, I.x.z, 0.0f); S.I4[lane][1] = make_float4(I.y.x, I.y.y, I.y.z, 0.0f); S.I4[lane][2] = make_float4(I.z.x, I.z.y, I.z.z, 0.0f);
 	}
-	if (lane < nj) for (int i = 0; i < 6; i++) S.jr[lane][i] = M.jointc[lane * HT_JC + HT_JC_RMIN + i];
-	if (lane == 0) S.nray = 0;
+	if (lane < nj && !fast) for (int i = 0; i < 6; i++) S.jr[lane][i] = M.jointc[lane * HT_JC + HT_JC_RMIN + i];
+	if (lane == 0) S.nray = fast && a.ray_rows ? t_npre : 0;
 	__syncthreads();
 
 	// ---- HandModelEnhancements (handtrack.h:417-420, 434-440); acos()/cos() are the C double overloads there ----
-	if (nb >= 17 && !a.no_model_rows)
+	if (nb >= 17 && !a.no_model_rows && !fast)
 	{
 		if (lane < 4)
 		{
@@ -373,7 +208,8 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 		}
 	}
 	// ---- landmark-ray rows of MultiStepSim (handtrack.h:666-676): 2 dead-zone pairs per open finger ----
-	if (a.ray_rows && a.sf_ncray + (a.sf_select >= 0) > 0 && lane == 8)
+	if (fast) {}
+	else if (a.ray_rows && a.sf_ncray + (a.sf_select >= 0) > 0 && lane == 8)
 	{
 		// slowfit (handtrack.h:803-810): dead-zone pairs along the two axes perpendicular to each landmark ray, rays from the origin, then the nail
 		int k = 0;
@@ -448,6 +284,8 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	// row counts per joint (lane j = joint j), their prefixes over the joints by a scalar walk through the lanes' registers, and the owner table of the range rows
 	int na_pre, na;
 	const int na_fix = na_user + (a.apply_angles ? 12 : 0) + (a.arm_cone ? 1 : 0);      // [caller's rows | ApplyAngles, arm cone | relative rows | joint ranges]
+	if (fast) { na_pre = na_fix; na = t_na; }
+	else
 	{
 		const int acnt = (lane < nj && !a.no_model_rows) ? angular_range_count(L3(S.jr[lane]), L3(S.jr[lane] + 3)) : 0;
 		int rcnt = 0;
@@ -472,7 +310,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 		const int r = lane + 64 * s;
 		arow &R = AR[s];
 		R.rb0 = -1; R.rb1 = -1; R.axis = V3(0, 0, 1); R.targetspin = -FLT_MAX; R.mn = 0; R.mx = 0; R.s2t = 0; R.torque = 0; R.mintorque = 0; R.lev = 0;
-		if (r < na)
+		if (r < na && !fast)
 		{
 			float row[8];
 			if (r < na_user)
@@ -567,7 +405,12 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 		__threadfence_block();
 		__syncthreads();
 	}
-	for (int r = lane; r < n2; r += 64)
+	if (fast)      // the joints' groups as k_solve_prep made them (the same statements as the loop below, csrc/ht_prep.hip)
+	{
+		const float4 *src = reinterpret_cast<const float4 *>(T + TB_POOL);
+		for (int i = lane; i < njg * (LGRP / 4); i += 64) reinterpret_cast<float4 *>(pool)[i] = src[i];
+	}
+	for (int r = (fast ? 3 * njg : 0) + lane; r < n2; r += 64)
 	{
 		int rb0, rb1, meta = 0, g, kk;
 		v3 p0, p1, n; float targetdist, tsnb, fmn, fmx;
@@ -674,6 +517,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 		for (int s = 0; s < ASLOTS; s++) sw = sw || (lane + 64 * s < na && AR[s].targetspin == -FLT_MAX && AR[s].mintorque < 0);
 		blocked = !a.two_body_levels && ngt == 0 && n2 <= 4 * BLK_LROWS && na <= 128 && __ballot(sw) == 0ull;
 		blocked = __builtin_amdgcn_readfirstlane((int)blocked) != 0;
+		if (fast) blocked = true;      // k_solve_prep looked at the angular rows (no row RemoveBias switches on, no more than the builds keep), the row count was checked at the top
 	}
 	int nga = 0;
 	if (!blocked)
@@ -747,9 +591,10 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	float *const gG = a.scratch + (size_t)a.batch * a.scratch_stride * (CREC + 2) + (size_t)b * a.scratch_stride * 4;      // and, behind those, the couplings of its rows' blocks of four when the build's LDS has no room for them (QUAD_G_BLOCK floats per block; the region has 16 B per chain entry)
 	if (sums_lds) { for (int i = lane; i < nlist; i += 64) S.csum[i] = 0.0f; }
 	else for (int i = lane; i < nlist && i < a.scratch_stride; i += 64) gsum[i] = 0.0f;
-	if (idx_lds) { for (int i = lane; i < nlist; i += 64) S.cidx[i] = (unsigned short)noop_idx; }
+	if (fast) { if (idx_lds) for (int i = lane; i < nlist; i += 64) S.cidx[i] = (unsigned short)gidx[i]; }      // the lists as k_solve_prep placed them (in HBM for the builds that walk them there)
+	else if (idx_lds) { for (int i = lane; i < nlist; i += 64) S.cidx[i] = (unsigned short)noop_idx; }
 	else for (int i = lane; i < nlist && i < a.scratch_stride; i += 64) gidx[i] = (unsigned)noop_idx;
-	if (lane == 0) quad_write_noop(scr + (size_t)noop_idx * CREC);
+	if (lane == 0 && !fast) quad_write_noop(scr + (size_t)noop_idx * CREC);
 	auto pre_ptr = [&](int i) -> const float * { return a.ray_rows ? S.ray[i] : a.rows_pre + ((size_t)b * a.pre_stride + i) * HT_ROW; };
 	auto body_of = [&](int i) -> int {
 		if (i < npre) return (int)pre_ptr(i)[1];
@@ -758,6 +603,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	};
 	__syncthreads();
 	int mycnt = 0;                                     // lane bb counts the rows of body bb
+	if (!fast)
 	for (int base = 0; base < n1; base += 64)          // pass A: rows per body
 	{
 		const int i = base + lane;
@@ -776,8 +622,13 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	// segment of the lists = its bodies' blocks one after the other, a chain padded to whole blocks with the record that changes nothing
 	const bool chain4 = !EXACT && !HT_DBG(a.dbg, 65536);      // HT_DEBUG_SKIP += 65536 (-DHT_TUNING): the row-by-row walk, for an A/B
 	int c4_e0 = 0, c4_nblk = 0, c4_head = 0, c4_start = 0, c4_next = -1, c4_total = 0;
-	const int myblk = (lane < nb && !HT_DBG(a.dbg, 1)) ? (mycnt + 3) >> 2 : 0;
-	if (chain4)
+	int myblk = (lane < nb && !HT_DBG(a.dbg, 1)) ? (mycnt + 3) >> 2 : 0;
+	if (fast)
+	{
+		c4_e0 = t_e0; c4_nblk = t_nblk; c4_head = t_head; c4_total = t_total;
+		if (lane < HT_MAXNB) { myblk = reinterpret_cast<const int *>(T + TB_CCNT)[lane]; c4_next = reinterpret_cast<const int *>(T + TB_CNEXT)[lane]; }
+	}
+	else if (chain4)
 	{
 		// everything below is the same on every lane: the per-body values are read out of their lanes into scalars (v_readlane with a scalar lane number), so the
 		// dealing loop is scalar arithmetic
@@ -813,6 +664,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	// does not host yet, its entries follow the host's in the list, and the host's entries are padded to a multiple of 8 with the record that changes nothing
 	// (zero direction, zero limits: impulse 0), so that the quad changes body at a block boundary of the chain walk (quad_chain_run).
 	int myextra = -1, myhost = -1;
+	if (!fast)
 	{
 		int avail = (lane < 16 && lane < nb) ? mycnt : 0x7fffff;
 		for (int e = 16; e < nb; e++)
@@ -839,6 +691,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	if (chain4) { mystart = c4_start; if (lane < HT_MAXNB) { S.ccnt[lane] = myblk; S.cstart[lane] = mystart; S.cextra[lane] = (signed char)c4_next; } }      // ccnt: blocks, cextra: the next body of the DPP row
 	else if (lane < HT_MAXNB) { S.ccnt[lane] = HT_DBG(a.dbg, 1) ? 0 : mycnt; S.cstart[lane] = mystart; S.cextra[lane] = (signed char)(HT_DBG(a.dbg, 1) ? -1 : myextra); }
 	int myrun = 0;
+	if (!fast)
 	for (int base = 0; base < n1; base += 64)          // pass B: placement in stable order; records of the rows that have none yet
 	{
 		const int i = base + lane;
@@ -881,14 +734,18 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	for (int s = 0; s < ASLOTS; s++)
 	{
 		const arow &R = AR[s];
-		const bool on = lane + 64 * s < na;
+		const bool on = lane + 64 * s < na && !fast;
 		ABA0[s] = (on && R.rb0 >= 0) ? -mul(body_I(S, R.rb0), R.axis) : V3(0, 0, 0);
 		ABA1[s] = (on && R.rb1 >= 0) ? mul(body_I(S, R.rb1), R.axis) : V3(0, 0, 0);
 	}
 	__threadfence_block();      // the records and lists are read back by other lanes of this wave
 	__syncthreads();
 	const bool g_lds = idx_lds && S.NCG > 0 && QUAD_G_BLOCK * (c4_total + 4) <= S.NCG;      // the couplings in LDS (the walk reads four blocks ahead); only beside LDS chain lists: one instance of the walk less
-	if (chain4 && !HT_DBG(a.dbg, 131072))      // HT_DEBUG_SKIP += 131072 (-DHT_TUNING, wrong results): without this loop, to see what it costs
+	if (fast)
+	{
+		if (g_lds) { for (int i = lane; i < QUAD_G_BLOCK * c4_total; i += 64) S.cg[i] = gG[i]; __threadfence_block(); __syncthreads(); }      // k_solve_prep left them in the frame's HBM slot
+	}
+	else if (chain4 && !HT_DBG(a.dbg, 131072))      // HT_DEBUG_SKIP += 131072 (-DHT_TUNING, wrong results): without this loop, to see what it costs
 	{
 		// the couplings of every block's rows with the rows before them: a quad per block, lane c of it takes slot c of the block's four records; -G(j,i) = -(c_j . d_i),
 		// the three lanes' shares summed (p0 + p1) + p2 on lane 2, which writes the rows' entries
@@ -1045,6 +902,15 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	// ---- the prologue scratch is dead now: angular rows move from their builder lanes into their records ----
 	const bool arec_lds = na <= S.NANG;
 	float *const arec = arec_lds ? S.arec : garec;
+	if (fast)      // the records, the idle record and the slack as k_solve_prep wrote them (the prologue scratch they share LDS with is dead: the contacts' groups are made)
+	{
+		const float4 *src = reinterpret_cast<const float4 *>(T + TB_AREC);
+		for (int i = lane; i < (na + 4) * (AROW / 4); i += 64) reinterpret_cast<float4 *>(arec)[i] = src[i];
+		const unsigned w = reinterpret_cast<const unsigned *>(T + TB_ABODY)[lane];
+		S.blk.abody[2 * lane] = (unsigned short)(w & 0xFFFFu); S.blk.abody[2 * lane + 1] = (unsigned short)(w >> 16);
+	}
+	else
+	{
 #pragma unroll
 	for (int s = 0; s < ASLOTS; s++)
 	{
@@ -1072,6 +938,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 			S.blk.abody[r] = (unsigned short)(r < na ? ((AR[s].rb0 >= 0 ? AR[s].rb0 : 255) | ((AR[s].rb1 >= 0 ? AR[s].rb1 : 255) << 8)) : 0xFFFF);
 		}
 	}
+	}      // !fast
 	__threadfence_block();
 	__syncthreads();
 
@@ -1130,7 +997,17 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 				}
 			}
 		};
-		if (arec_lds) { ang_couplings(S.arec, false); if (nba > 1) ang_couplings(S.arec, true); }
+		if (fast)      // the angular blocks' couplings, and the linear blocks' couplings among the joints' rows, as k_solve_prep left them (register 4k + c of lane l at (k * 64 + l) * 4 + c)
+		{
+#pragma unroll
+			for (int k = 0; k < 8; k++)
+			{
+				const float4 ga = reinterpret_cast<const float4 *>(T + TB_GA)[k * 64 + lane], gl = reinterpret_cast<const float4 *>(T + TB_GL)[k * 64 + lane];
+				GA[4 * k] = ga.x; GA[4 * k + 1] = ga.y; GA[4 * k + 2] = ga.z; GA[4 * k + 3] = ga.w;
+				GL[4 * k] = gl.x; GL[4 * k + 1] = gl.y; GL[4 * k + 2] = gl.z; GL[4 * k + 3] = gl.w;
+			}
+		}
+		else if (arec_lds) { ang_couplings(S.arec, false); if (nba > 1) ang_couplings(S.arec, true); }
 		else { ang_couplings(garec, false); if (nba > 1) ang_couplings(garec, true); }
 		// Linear rows: row r of the joint and contact triples sits in block r / 30; w_j = b0_j . L(rb0) - n_j minv0 . P(rb0) + b1_j . L(rb1) + n_j minv1 . P(rb1), a unit impulse
 		// of row i adds -n_i to P(rb0_i), g0_i to L(rb0_i), n_i to P(rb1_i), g1_i to L(rb1_i) (the sides' signs ride on g and b: the group record's layout):
@@ -1179,8 +1056,13 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 				}
 			}
 		};
-		if (pool_lds) { if (nbl > 0) lin_couplings(S.pool, false); if (nbl > 1) lin_couplings(S.pool, true); }
-		else { if (nbl > 0) lin_couplings(gpool, false); if (nbl > 1) lin_couplings(gpool, true); }
+		// With tables only the CONTACTS' rows are left: a contact row couples to the rows before it (joints among them), never a joint row to a contact.  A call serves the lower
+		// half-wave's block and the upper's in lockstep, so it runs when either holds a contact row; a joint row's lane then forms the values it already has once more.
+		const int njr = 3 * njg;      // the joints' rows lead the list
+		auto has_contacts = [&](int Q) -> bool { return n2 > njr && BLK_LROWS * Q < n2 && BLK_LROWS * (Q + 1) > njr; };
+		const bool fwd = !fast || has_contacts(0) || has_contacts(2), bwd = !fast || has_contacts(1) || has_contacts(3);
+		if (pool_lds) { if (nbl > 0 && fwd) lin_couplings(S.pool, false); if (nbl > 1 && bwd) lin_couplings(S.pool, true); }
+		else { if (nbl > 0 && fwd) lin_couplings(gpool, false); if (nbl > 1 && bwd) lin_couplings(gpool, true); }
 		if (HT_DBG(a.dbg, 2048)) t_c1 = clock64();
 		// edge words: a block's (row, side) pairs sorted by body, one per lane (ht_block.hpp)
 		auto edge_word = [&](bool valid, int ba, int bb) -> unsigned {
@@ -1237,14 +1119,16 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 			const unsigned bo = (Q & 1) ? abod >> 16 : abod & 0xFFFFu;
 			return edge_word(on, (int)(bo & 255u), (int)(bo >> 8));
 		};
-		if (nbl > 0) emL0 = lin_edges(0);
-		if (nbl > 1) emL1 = lin_edges(1);
-		if (nbl > 2) emL2 = lin_edges(2);
-		if (nbl > 3) emL3 = lin_edges(3);
-		if (nba > 0) emA0 = ang_edges(0);
-		if (nba > 1) emA1 = ang_edges(1);
-		if (nba > 2) emA2 = ang_edges(2);
-		if (nba > 3) emA3 = ang_edges(3);
+		// a block without a contact row has the edges k_solve_prep sorted for it; the angular blocks all have
+		auto tab_edges = [&](int off, int Q) -> unsigned { return reinterpret_cast<const unsigned *>(T + off)[Q * 64 + lane]; };
+		if (nbl > 0) emL0 = fast && !has_contacts(0) ? tab_edges(TB_EML, 0) : lin_edges(0);
+		if (nbl > 1) emL1 = fast && !has_contacts(1) ? tab_edges(TB_EML, 1) : lin_edges(1);
+		if (nbl > 2) emL2 = fast && !has_contacts(2) ? tab_edges(TB_EML, 2) : lin_edges(2);
+		if (nbl > 3) emL3 = fast && !has_contacts(3) ? tab_edges(TB_EML, 3) : lin_edges(3);
+		if (nba > 0) emA0 = fast ? tab_edges(TB_EMA, 0) : ang_edges(0);
+		if (nba > 1) emA1 = fast ? tab_edges(TB_EMA, 1) : ang_edges(1);
+		if (nba > 2) emA2 = fast ? tab_edges(TB_EMA, 2) : ang_edges(2);
+		if (nba > 3) emA3 = fast ? tab_edges(TB_EMA, 3) : ang_edges(3);
 		__syncthreads();
 		if (HT_DBG(a.dbg, 2048)) t_c2 = clock64();
 	}

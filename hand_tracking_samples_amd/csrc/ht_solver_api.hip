@@ -38,7 +38,7 @@ static void exact_args(ht_ctx *ctx, solve_args &a, bool cloud)
 static bool solve_history_on(const ht_ctx *ctx, int B) { return ctx->d_swork && B > ctx->n_cu * 8 && B + 8 <= ctx->cstride; }
 static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int *n_pre, bool cloud, bool contacts, const int *active,
                        int apply_angles, float drive_force, int ray_rows, int arm_cone, int zero_momenta, int B, hipStream_t s, bool shared_gpu = false, float *poses_out = nullptr, const int *out_npts = nullptr,
-                       int hist_slot = -1)
+                       int hist_slot = -1, bool tables = false)
 {
 	solve_args a;
 	memset(&a, 0, sizeof a);
@@ -53,6 +53,7 @@ static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int 
 	a.steps_keyangles = ctx->par.steps_keyangles; a.min_cray_prob = ctx->par.min_cray_prob;
 	a.dbg = ht_tuning_flags();
 	a.shared_gpu = shared_gpu ? 1 : 0;
+	a.tables = tables ? ctx->d_tables : nullptr;      // solve_prep below has made them for exactly this solve
 	exact_args(ctx, a, cloud);
 	a.out_poses = poses_out; a.out_npts = out_npts; a.out_initializing = ctx->d_initializing; a.out_min_point_num = ctx->par.min_point_num;
 	if (hist_slot >= 0 && hist_slot < HT_CONTACT_SLOTS && !active && !exact_solver(ctx) && solve_history_on(ctx, B) && B == ctx->swork_B)
@@ -62,6 +63,27 @@ static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int 
 		if ((ctx->sorder_mask >> hist_slot) & 1u) a.frame_order = ctx->d_sorder + (size_t)hist_slot * ctx->cstride;
 	}
 	ht_launch_solve(ctx->model, ctx->phys, a, B, s);
+}
+// Round 6: the tables of a solve (ht_solve_shared.hpp) are made by k_solve_prep on whichever stream runs the solve's row producers, behind the cloud rows (it lists them per
+// body) and beside the contact kernel; the solve_step that follows is told to start from them.  Off for the exact-order builds (their sweeps take the rows as the reference
+// lays them out) and under ht_debug_solve_tables(0).
+static bool solve_tables_on(const ht_ctx *ctx)
+{
+	static const bool on = ht_tuning_env("HT_TABLES");      // timing experiments (-DHT_TUNING builds only): tools/exp_tables.sh
+	return (ctx->solve_tables || on) && ctx->d_tables && !exact_solver(ctx);
+}
+static void solve_prep(ht_ctx *ctx, int which, bool cloud, bool chamber, const int *active, int apply_angles, float drive_force, int ray_rows, int arm_cone, int B, hipStream_t s)
+{
+	prep_args a;
+	memset(&a, 0, sizeof a);
+	a.state = ctx->d_state[which]; a.analysis = ctx->d_analysis; a.cams = ctx->d_cams; a.active_flag = active;
+	a.scratch = ctx->d_scratch; a.scratch_stride = scratch_stride(ctx); a.batch = ctx->B;
+	a.cloud_body = cloud ? ctx->d_rowbody : nullptr; a.n_cloud = ctx->d_nrows;
+	if (chamber) { a.ch_planes = ctx->d_chplanes; a.ch_on = ctx->d_chon; a.rows_pre = ctx->d_chamber; a.n_pre = ctx->d_nchamber; a.ch_maxforce = 10.0f; }
+	a.apply_angles = apply_angles; a.drive_force = drive_force; a.ray_rows = ray_rows; a.arm_cone = arm_cone;
+	a.steps_keyangles = ctx->par.steps_keyangles; a.min_cray_prob = ctx->par.min_cray_prob;
+	a.tables = ctx->d_tables; a.dbg = ht_tuning_flags();
+	ht_launch_solve_prep(ctx->model, ctx->phys, a, B, s);
 }
 // Fork/join helpers: the row-producing kernels of one fit step only read the pose, so they run side by side on two extra streams
 // and the solve waits for all of them (each of them is latency-bound on its slowest frame and leaves most of the chip idle).
@@ -139,19 +161,22 @@ static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int 
 		const bool cloud = (st >= p.steps_cloudstart) && !p.angles_only;
 		const bool coll = ctx->phys.use_collision != 0;
 		static const bool no_side = ht_tuning_env("HT_NO_SIDE");      // timing experiments (-DHT_TUNING builds only)
-		const bool par = side >= 0 && cloud && coll && !ctx->profile_phases && !no_side;
+		const bool tables = solve_tables_on(ctx);
+		// beside the contact kernel: the step's cloud rows, and (round 6) the solve's tables behind them -- a step without cloud rows forks for the tables alone
+		const bool par = side >= 0 && (cloud || tables) && coll && !ctx->profile_phases && !no_side;
 		if (part != 2)
 		{
 			if (par) fork1(ctx, s, side);
 			const cloud_records cr = cloud_rec(ctx);
 			if (cloud) { ht_prof_scope ps(ctx, prof ? "cloud_rows" : nullptr, s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, active, 4, 1, 2, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[side] : s, 0.0f, 0.0f, rec_or_rows(ctx, &cr)); }
+			if (tables) { ht_prof_scope ps(ctx, prof ? "solve_prep" : nullptr, s, true); solve_prep(ctx, 1, cloud, false, active, angles, st < p.steps_palmangle ? 10000.0f : 0.0f, rays, 1, B, par ? ctx->side[side] : s); }
 			if (coll && !(first_contacts_done && st == from_step)) { ht_prof_scope ps(ctx, prof ? "contacts" : nullptr, s, true); const contact_slot ch = contact_history(ctx, st < 8 ? st : -1, active, B); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, active, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, false, ctx->contact_kernel, active && active == ctx->d_flags && !ctx->many_reset, ch.order, ch.work); }
 			if (par) join1(ctx, s, side);
 			if (part == 0 && !active) mark("  step: rows done", s);
 		}
 		if (part == 1) continue;
 		ht_prof_scope ps(ctx, prof ? "solve" : nullptr, s);
-		solve_step(ctx, 1, nullptr, nullptr, cloud, coll, active, angles, st < p.steps_palmangle ? 10000.0f : 0.0f, rays, 1, 1, B, s, shared_gpu, nullptr, nullptr, st < 8 ? st : -1);
+		solve_step(ctx, 1, nullptr, nullptr, cloud, coll, active, angles, st < p.steps_palmangle ? 10000.0f : 0.0f, rays, 1, 1, B, s, shared_gpu, nullptr, nullptr, st < 8 ? st : -1, tables);
 	}
 }
 // one main-thread pass of HandTracker::update (handtrack.h:769-780)
@@ -163,16 +188,21 @@ static void main_pass(ht_ctx *ctx, int B, hipStream_t s, float *poses_out = null
 	const bool coll = ctx->phys.use_collision != 0;
 	static const bool no_side = ht_tuning_env("HT_NO_SIDE");
 	const bool par = !ctx->profile_phases && !no_side;
-	if (par) fork(ctx, s);
-	{ ht_prof_scope ps(ctx, "chamber", s, true); ht_launch_chamber(ctx->model, ctx->d_state[0], pts, npts, p.min_point_num, p.boundary_planes, 10.0f, ctx->d_chamber, ctx->d_nchamber, B, par ? ctx->side[1] : s); }
+	const bool tables = solve_tables_on(ctx);
+	// Round 6: the five boundary planes follow from the points alone, so an update makes them once (beside the net: run_update) and every pass only their rows, inside
+	// k_solve_prep.  A pass outside an update (ht_stage_fit) makes them here.
+	if (tables && !ctx->planes_valid) { ht_prof_scope ps(ctx, "chamber", s, true); ht_launch_chamber_planes(ctx->model, pts, npts, p.min_point_num, p.boundary_planes, ctx->d_chplanes, ctx->d_chon, B, s); }
+	if (par) { if (tables) fork1(ctx, s, 0); else fork(ctx, s); }
+	if (!tables) { ht_prof_scope ps(ctx, "chamber", s, true); ht_launch_chamber(ctx->model, ctx->d_state[0], pts, npts, p.min_point_num, p.boundary_planes, 10.0f, ctx->d_chamber, ctx->d_nchamber, B, par ? ctx->side[1] : s); }
 	const cloud_records cr = cloud_rec(ctx);
 	{ ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[0], pts, npts, ctx->d_cams, nullptr, 1, 0, 1, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[0] : s, 0.0f, 0.0f, rec_or_rows(ctx, &cr)); }
+	if (tables) { ht_prof_scope ps(ctx, "solve_prep", s, true); solve_prep(ctx, 0, true, true, nullptr, 0, 0.0f, 0, 0, B, par ? ctx->side[0] : s); }
 	if (coll) { ht_prof_scope ps(ctx, "contacts", s, true); const contact_slot ch = contact_history(ctx, pass >= 0 && pass < 8 ? 8 + pass : -1, nullptr, B); ht_launch_contacts(ctx->model, ctx->d_state[0], ctx->phys.driftmax, ctx->phys.jiggle_sin, nullptr, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, par, ctx->contact_kernel, 0, ch.order, ch.work); }
 	mark("  pass: contacts done", s);
-	if (par) { mark("  pass: cloud rows done", ctx->side[0]); mark("  pass: chamber done", ctx->side[1]); }
-	if (par) join(ctx, s, 2);
+	if (par) { mark("  pass: cloud rows done", ctx->side[0]); if (!tables) mark("  pass: chamber done", ctx->side[1]); }
+	if (par) join(ctx, s, tables ? 1 : 2);
 	ht_prof_scope ps(ctx, "solve", s);
-	solve_step(ctx, 0, ctx->d_chamber, ctx->d_nchamber, true, coll, nullptr, 0, 0.0f, 0, 0, 0, B, s, false, poses_out, npts, pass >= 0 && pass < 8 ? 8 + pass : -1);
+	solve_step(ctx, 0, ctx->d_chamber, ctx->d_nchamber, true, coll, nullptr, 0, 0.0f, 0, 0, 0, B, s, false, poses_out, npts, pass >= 0 && pass < 8 ? 8 + pass : -1, tables);
 }
 // Behind the join of the side stream, so nothing of the step waits for it: the running counts of reset frames go to the host (ht_host.hpp: d_nreset).  The
 // update's stream picks the copy up again at its very end (reset_tail_join: long finished by then) -- every stream of an update has to come back to the
@@ -208,6 +238,7 @@ static int run_update(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams,
 {
 	const int r = run_update_(ctx, d_depth, d_cams, d_start, B, d_poses_out, d_cnn_out, s, fs, mode);
 	ctx->model.frame_order = nullptr;      // the launch order of the block-per-frame kernels belongs to the update that made it
+	ctx->planes_valid = false;             // and so do the boundary planes of its cloud
 	return r;
 }
 static int run_update_(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams, const float *d_start, int B, float *d_poses_out, float *d_cnn_out, hipStream_t s, const frame_src *fs, int mode)
@@ -266,9 +297,15 @@ static int run_update_(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams
 	}
 	// batches of several rounds per CU: the block-per-frame kernels take the frames with the most points first, so that a launch ends on short blocks
 	if (ctx->d_porder && B > ctx->n_cu * 8 && !exact_solver(ctx)) { ht_launch_order_by_points(ctx->d_npts, ctx->d_porder, B, s); ctx->model.frame_order = ctx->d_porder; }
+	auto update_planes = [&](hipStream_t t) {      // the boundary planes of the main-thread cloud (handtrack.h:751, 774-778), once per update
+		if (!solve_tables_on(ctx) || mode == UPD_CNN_MODEL || mode == UPD_KICKSTART || p.angles_only || p.mainthreadpasses < 1) return;
+		ht_launch_chamber_planes(ctx->model, p.subsample_voxel ? ctx->d_ptsv : ctx->d_pts, p.subsample_voxel ? ctx->d_nptsv : ctx->d_npts, p.min_point_num, p.boundary_planes, ctx->d_chplanes, ctx->d_chon, B, t);
+		ctx->planes_valid = true;
+	};
 	if (mode == UPD_PASSES)
 	{
 		const int passes = p.angles_only ? 0 : p.mainthreadpasses;
+		update_planes(s);
 		for (int i = 0; i < passes; i++) main_pass(ctx, B, s, i + 1 == passes ? d_poses_out : nullptr, i);
 		if (passes < 1) ht_launch_output(ctx->model, ctx->d_state[0], p.subsample_voxel ? ctx->d_nptsv : ctx->d_npts, ctx->d_initializing, p.min_point_num, d_poses_out, B, s);
 		return HT_OK;
@@ -283,13 +320,14 @@ static int run_update_(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams
 		// owns whole CUs and the FC layers want one block per CU: beside each other they took 0.78 ms, one after the other 0.46.)
 		hipStream_t t = ctx->side[1];
 		fork(ctx, s);
+		update_planes(t);
 		contact_orders(ctx, B, t);
 		if (mode == UPD_FULL && !(d_start && !fs)) ht_launch_set_pose(ctx->d_state[1], ctx->d_state[0], nb, B, 2, t);     // othermodel.SetPose(handmodel.GetPose()) handtrack.h:757 (both were just seeded with the same pose otherwise)
 		ht_fit_after dec; memset(&dec, 0, sizeof dec);
 		dec.mode = 1; dec.reset_thr = p.full_reset_on_error; dec.angles_only = p.angles_only; dec.flags = ctx->d_flags; dec.nflags = ctx->d_nflags; dec.list = ctx->d_flist; dec.nlist = ctx->d_nflist; dec.nreset = ctx->d_nreset;
 		ht_launch_fit_error(ctx->model, ctx->d_state[0], ctx->d_pts, ctx->d_npts, d_depth, img_cams, iw, ih, p.bone_sum_error_scale, ctx->d_err_old, B, t, &dec);      // with the reset decision (handtrack.h:706)
 	}
-	if (!overlap) contact_orders(ctx, B, s);
+	if (!overlap) { contact_orders(ctx, B, s); update_planes(s); }
 	{
 		ht_prof_scope ps(ctx, (fs && fs->direct) ? "cnn128" : "cnn", s, true);
 		if (fs && fs->direct) ht_launch_cnn(ctx->cnnw128, ctx->d_in128, ctx->d_act1_128, ctx->d_act2_128, ctx->d_act3, ctx->d_logits, B, s, fs->direct, overlap);
@@ -931,6 +969,20 @@ extern "C" int ht_debug_contact_kernel(ht_ctx *ctx, int which)
 {
 	if (!ctx || which < 0 || which > 2) return HT_ERR_ARG;
 	ctx->contact_kernel = which;
+	return HT_OK;
+}
+extern "C" int ht_debug_solve_tables(ht_ctx *ctx, int on)
+{
+	if (!ctx) return HT_ERR_ARG;
+	ctx->solve_tables = on ? 1 : 0;
+	return HT_OK;
+}
+extern "C" int ht_debug_solve_tables_header(ht_ctx *ctx, int B, int *hdr)
+{
+	if (!ctx || !ctx->ready || !hdr || B < 1 || B > ctx->B || !ctx->d_tables) return HT_ERR_ARG;
+	ht_device_guard dev_guard_(ctx->device);
+	if (ht_sync_all(ctx) != hipSuccess) return HT_ERR_HIP;
+	if (hipMemcpy2D(hdr, 32 * sizeof(int), ctx->d_tables, (size_t)TB_WORDS * sizeof(float), 32 * sizeof(int), B, hipMemcpyDeviceToHost) != hipSuccess) return HT_ERR_HIP;
 	return HT_OK;
 }
 // Same for k_contacts (last contact slot of each frame): launches, cycles in GJK / polytope runs, polytope runs, polytope cycles in

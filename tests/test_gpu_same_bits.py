@@ -1,7 +1,7 @@
 """The product build against ITSELF as it stood at the end of round 5 (commit 43e6687): tests/golden/product_r05.npz holds, for the bench's 1024 frames (two updates
 each, with and without always_take_cnn) and configs[4]'s 256 frames end to end, a hash of every frame's results and the results themselves for the first 48 frames
-(tools/save_product_poses.py on the GPU box, condensed: the tool's docstring).  Round 6 moved WHERE the solver's tables are made (k_solve_prep beside the contact
-kernel instead of k_solve's one-wave prologue), not what is computed: every pose, momentum and tracker flag must come out bit for bit the same."""
+(tools/save_product_poses.py on the GPU box, condensed: the tool's docstring).  Round 6's changes to the solver move WHERE arithmetic runs (k_solve_prep beside the
+contact kernel for the solve tables: tests/test_gpu_solve_tables.py), never what is computed: every pose, momentum and tracker flag must come out bit for bit the same."""
 import hashlib
 import os
 
