@@ -900,6 +900,19 @@ extern "C" int ht_stage_multistep(ht_ctx *ctx, const float *analysis, int B)
 	HIPCHK(ctx, hipGetLastError());
 	return HT_OK;
 }
+// steps [from_step, to_step) of MultiStepSim alone (handtrack.h:660-688: every step has its own mix of CNN-driven angular rows, landmark rays and cloud rows): teacher-forced
+// single-step tests start a step from a given state
+extern "C" int ht_stage_multistep_range(ht_ctx *ctx, const float *analysis, int B, int from_step, int to_step)
+{
+	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);
+	if (!analysis || from_step < 0 || to_step < from_step) return HT_ERR_ARG;
+	hipStream_t s = ctx->stream;
+	HIPCHK(ctx, hipMemcpyAsync(ctx->d_analysis, analysis, (size_t)B * HT_ANALYSIS * sizeof(float), hipMemcpyHostToDevice, s));
+	multistep(ctx, B, s, from_step, to_step);
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	HIPCHK(ctx, hipGetLastError());
+	return HT_OK;
+}
 extern "C" int ht_stage_scratch_unibody(ht_ctx *ctx, const float *analysis, int B, int n_unibody)
 {
 	CHECK_READY(ctx); CHECK_MODEL(ctx); CHECK_BATCH(ctx, B);

@@ -22,7 +22,7 @@ SYMBOLS = (
     "ht_model_open", "ht_model_close", "ht_model_error", "ht_model_counts", "ht_model_body", "ht_model_body_mesh", "ht_model_hitcheck",
     "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_update_frames_sync", "ht_update_frames_dev", "ht_update_direct_sync", "ht_update_direct_dev", "ht_update_cnn_model_sync", "ht_get_cnn_results", "ht_get_cnn_layers", "ht_frames_overflow", "ht_reserve_points", "ht_point_capacity", "ht_capacity_events", "ht_segment_vr", "ht_segment_vr_dev", "ht_slowfit", "ht_set_points", "ht_fit_rows", "ht_physics_update",
     "ht_stage_prepare", "ht_stage_decode", "ht_stage_fit_error", "ht_stage_cloud_rows", "ht_stage_contacts", "ht_stage_fit",
-    "ht_stage_multistep", "ht_stage_scratch_unibody", "ht_stage_chamber", "ht_profile_enable", "ht_profile_read", "ht_debug_solve_stats", "ht_debug_contact_stats", "ht_debug_solver_build", "ht_debug_reset_flags", "ht_debug_reset_organisation", "ht_update_passes_sync", "ht_job_start", "ht_job_poll", "ht_job_wait", "ht_job_collect", "ht_debug_contact_kernel", "ht_debug_solve_tables", "ht_debug_solve_tables_header",
+    "ht_stage_multistep", "ht_stage_multistep_range", "ht_stage_scratch_unibody", "ht_stage_chamber", "ht_profile_enable", "ht_profile_read", "ht_debug_solve_stats", "ht_debug_contact_stats", "ht_debug_solver_build", "ht_debug_reset_flags", "ht_debug_reset_organisation", "ht_update_passes_sync", "ht_job_start", "ht_job_poll", "ht_job_wait", "ht_job_collect", "ht_debug_contact_kernel", "ht_debug_solve_tables", "ht_debug_solve_tables_header",
     "ht_comm_available", "ht_comm_unique_id", "ht_comm_init", "ht_comm_info", "ht_gather_poses_dev", "ht_gather_wait", "ht_gather_wait_host", "ht_comm_destroy",
 )
 
@@ -94,6 +94,7 @@ def load(build_if_missing=True):
     L.ht_stage_contacts.argtypes = [vp, C.c_int, C.c_int, C.c_int, fp, ip]
     L.ht_stage_fit.argtypes = [vp, C.c_int]
     L.ht_stage_multistep.argtypes = [vp, fp, C.c_int]
+    L.ht_stage_multistep_range.argtypes = [vp, fp, C.c_int, C.c_int, C.c_int]
     L.ht_stage_scratch_unibody.argtypes = [vp, fp, C.c_int, C.c_int]
     L.ht_profile_enable.argtypes = [vp, C.c_int]
     L.ht_scale.argtypes = [vp, C.c_float]
@@ -405,6 +406,11 @@ class Context:
     def stage_multistep(self, analysis, B):
         analysis = _c(analysis, np.float32).reshape(B, ANALYSIS)
         self._chk(self.L.ht_stage_multistep(self.h, _f(analysis), B))
+
+    def stage_multistep_range(self, analysis, B, from_step, to_step):
+        """steps [from_step, to_step) of MultiStepSim alone, from othermodel's current state"""
+        analysis = _c(analysis, np.float32).reshape(B, ANALYSIS)
+        self._chk(self.L.ht_stage_multistep_range(self.h, _f(analysis), B, int(from_step), int(to_step)))
 
     def stage_scratch_unibody(self, analysis, B, n_unibody):
         analysis = _c(analysis, np.float32).reshape(B, ANALYSIS)

@@ -274,6 +274,7 @@ int ht_stage_chamber(ht_ctx *ctx, int which, int B, float *rows, int *nrows);
 int ht_stage_contacts(ht_ctx *ctx, int which, int B, int cap, float *contacts, int *ncontacts);
 int ht_stage_fit(ht_ctx *ctx, int B);
 int ht_stage_multistep(ht_ctx *ctx, const float *analysis, int B);
+int ht_stage_multistep_range(ht_ctx *ctx, const float *analysis, int B, int from_step, int to_step);      /* steps [from_step, to_step) of MultiStepSim alone (handtrack.h:660-688) from othermodel's current state: single-step, teacher-forced comparisons */
 int ht_stage_scratch_unibody(ht_ctx *ctx, const float *analysis, int B, int n_unibody);
 
 /* ---- caller-built constraint rows ----------------------------------------------------------------------------------------

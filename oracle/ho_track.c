@@ -174,6 +174,19 @@ void ho_set_state(ho_tracker *t, int which, const float *s)
 	ho_model *m = ho_model_ptr(t, which);
 	for (int b = 0; b < m->nb; b++, s += 13) { ho_body *rb = &m->bodies[b]; rb->position = F3(s[0], s[1], s[2]); rb->orientation = F4(s[3], s[4], s[5], s[6]); rb->linmom = F3(s[7], s[8], s[9]); rb->angmom = F3(s[10], s[11], s[12]); }
 }
+void ho_set_trace(ho_tracker *t, float *states) { t->trace = states; }
+void ho_get_analysis(const ho_tracker *t, float *out84) { memcpy(out84, &t->analysis, 84 * sizeof(float)); }
+static void trace_state(ho_tracker *t, ho_model *m, int slot)
+{
+	if (!t->trace) return;
+	float *s = t->trace + (size_t)slot * m->nb * 13;
+	for (int b = 0; b < m->nb; b++, s += 13)
+	{
+		const ho_body *rb = &m->bodies[b];
+		s[0] = rb->position.x; s[1] = rb->position.y; s[2] = rb->position.z; s[3] = rb->orientation.x; s[4] = rb->orientation.y; s[5] = rb->orientation.z; s[6] = rb->orientation.w;
+		s[7] = rb->linmom.x; s[8] = rb->linmom.y; s[9] = rb->linmom.z; s[10] = rb->angmom.x; s[11] = rb->angmom.y; s[12] = rb->angmom.z;
+	}
+}
 void ho_get_state(ho_tracker *t, int which, float *s)
 {
 	ho_model *m = ho_model_ptr(t, which);
@@ -502,6 +515,7 @@ void ho_multistep(ho_tracker *t, ho_model *m, const ho_analysis *an, const f3 *v
 	ho_linear *lin = malloc(sizeof(ho_linear) * MAXLIN); ho_angular ang[MAXANG];
 	ho_sanity_check(m);
 	float cloudforce = ho_minf(P->cloudforce_max_point, P->cloudforce_max_sum / (float)n);
+	trace_state(t, m, 0);
 	for (int s = 0; s < P->steps; s++)
 	{
 		int nl = 0, na = 0;
@@ -531,6 +545,7 @@ void ho_multistep(ho_tracker *t, ho_model *m, const ho_analysis *an, const f3 *v
 		ho_enhancements(t, m, ang, &na, 0, qrot(camera_pose.orientation, F3(-1, 0, 0)), qrot(camera_pose.orientation, F3(0, -1, 0)), 0);
 		ho_fit_pointcloud(t, m, NULL, 0, lin, nl, ang, na, 1.0f);
 		for (int b = 0; b < m->nb; b++) m->bodies[b].angmom = m->bodies[b].linmom = F3(0, 0, 0);
+		trace_state(t, m, s + 1);
 	}
 	ho_sanity_check(m);
 	free(lin);
@@ -717,6 +732,7 @@ void ho_update(ho_tracker *t, const uint16_t *depth, const ho_camera *cam, float
 	float pose[HO_MAXB * 7];
 	int np = ho_update_cnn_model(t, depth, cam, pose);
 	if (np) ho_set_pose(t, 0, pose);
+	trace_state(t, &t->handmodel, P->steps + 1);
 	for (int i = 0; !P->angles_only && i < P->mainthreadpasses; i++)
 	{
 		ho_linear *lin = malloc(sizeof(ho_linear) * 256); ho_angular ang[16];
@@ -725,6 +741,7 @@ void ho_update(ho_tracker *t, const uint16_t *depth, const ho_camera *cam, float
 		if (n > P->min_point_num && P->boundary_planes) nl += ho_cloud_chamber(&t->handmodel, points, n, lin, 10.0f);
 		ho_fit_pointcloud(t, &t->handmodel, points, n, lin, nl, ang, na, P->microforce);
 		free(lin);
+		trace_state(t, &t->handmodel, P->steps + 2 + i);
 	}
 	if (n < P->min_point_num) t->initializing = 50;
 	for (int b = 0; b < t->handmodel.nb; b++)   /* GetPoseUser physmodel.h:434, physics.h:142 */

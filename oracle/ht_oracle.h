@@ -89,6 +89,7 @@ typedef struct ho_tracker
 	float cnn_input[4096], cnn_output[HO_NCNN_OUT]; ho_analysis analysis;
 	/* statistics of the last update (for benches/tests) */
 	int last_npoints, last_ncontacts, last_accept;
+	float *trace;                       /* ho_set_trace: when set, ho_update / ho_multistep leave the model's state [nb][13] before the first MultiStepSim step and after every step (slots 0 .. steps), then handmodel's before the first main-thread pass and after every pass (slots steps + 1 .. steps + 1 + passes): teacher-forced single-step tests */
 } ho_tracker;
 
 /* ---- lifecycle ---- */
@@ -97,6 +98,8 @@ void ho_destroy(ho_tracker *t);
 int ho_load_weights(ho_tracker *t, const float *w, size_t n);          /* .cnnb order, cnn.h:590 */
 int ho_set_direct(ho_tracker *t, int side, const float *w, size_t n);   /* side 128: frames of side x side are their own segment, evaluated by the side-sized net (weights in .cnnb order), heat-map camera camsub(cam, side/16); side 0: off */
 void ho_set_round_once(int on);   /* tests: 1 = float sin / cos / acos formed in double and rounded once, as the device forms them (ho_math.h); 0 = glibc's float functions, the reference's */
+void ho_get_analysis(const ho_tracker *t, float *out84);   /* the decode of the latest update (layout of ho_analysis = the device's analysis array) */
+void ho_set_trace(ho_tracker *t, float *states);   /* NULL: off; [(steps + 1) + (passes + 1)][nb][13], the caller's array */
 void ho_set_cnn_override(ho_tracker *t, const float *cnn_output2304);   /* NULL: off.  The caller keeps the array alive. */
 void ho_default_params(ho_params *p);
 void ho_get_flags(const ho_tracker *t, float *prev_frame_error, int *initializing, int *last_npoints);

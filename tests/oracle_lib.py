@@ -93,6 +93,8 @@ def lib():
         L.ho_load_weights.argtypes = [C.c_void_p, fp, C.c_size_t]; L.ho_load_weights.restype = C.c_int
         L.ho_set_round_once.argtypes = [C.c_int]; L.ho_set_round_once.restype = None
         L.ho_set_cnn_override.argtypes = [C.c_void_p, fp]; L.ho_set_cnn_override.restype = None
+        L.ho_set_trace.argtypes = [C.c_void_p, fp]; L.ho_set_trace.restype = None
+        L.ho_get_analysis.argtypes = [C.c_void_p, fp]; L.ho_get_analysis.restype = None
         L.ho_set_direct.argtypes = [C.c_void_p, C.c_int, fp, C.c_size_t]; L.ho_set_direct.restype = C.c_int
         L.ho_set_state.argtypes = [C.c_void_p, C.c_int, fp]; L.ho_get_state.argtypes = [C.c_void_p, C.c_int, fp]
         L.ho_set_pose.argtypes = [C.c_void_p, C.c_int, fp]; L.ho_reset_tracker.argtypes = [C.c_void_p, fp]

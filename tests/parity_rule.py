@@ -46,6 +46,18 @@ def frame_rule(dp, dq, sp, sq, factor=2.0, cap=CAP):
     return ok, tight
 
 
+def cross_build_failures(npz, which, factor=2.0, cap=CAP, frames=None):
+    """The allow-list for poses that cannot be held frame by frame by NAME (CNN-driven poses, configs[4]'s model): hold one of the reference's own two FMA builds the way
+    the device is held -- frame_rule against the OTHER build's move as the yardstick -- and count the frames that fail; the smaller of the two directions.  Two legitimate
+    builds of the reference fail each other's per-frame rule on that many frames (the frames next to a discrete decision, which every perturbation moves differently);
+    the device may fail on no more."""
+    a = (npz["fma_on_%s_dpos" % which], npz["fma_on_%s_dquat" % which]); b = (npz["fma_fast_%s_dpos" % which], npz["fma_fast_%s_dquat" % which])
+    if frames is not None:
+        a = (a[0][frames], a[1][frames]); b = (b[0][frames], b[1][frames])
+    ok_ab, _ = frame_rule(a[0], a[1], b[0], b[1], factor, cap); ok_ba, _ = frame_rule(b[0], b[1], a[0], a[1], factor, cap)
+    return int(min((~ok_ab).sum(), (~ok_ba).sum()))
+
+
 def summary(got, ref, sp, sq, factor=2.0, median_tol=(2e-6, 4e-5), cap=CAP):
     """dict for bench.py's verify block / the tests' assertions"""
     finite = bool(np.isfinite(got).all())

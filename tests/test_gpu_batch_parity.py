@@ -115,10 +115,17 @@ def _check_batch(weights, take_cnn, refp, spread, what):
         ok2, tight2 = pr.frame_rule(d2[0], d2[1], sp2, sq2, OTHER_FACTOR if (key == "other" or take_cnn) else 2.0, pr.CAP_TAKE_CNN)
         print("  %s against the restatement given the device's heat-maps: %d of %d within 2e-5 m / 2e-4 (the reference's FMA builds against its IEEE build: %d), max %.2e m / %.2e"
               % (name, int(tight2.sum()), n, int(((sp2 <= pr.TIGHT[0]) & (sq2 <= pr.TIGHT[1])).sum()), d2[0].max(), d2[1].max()))
-        for i in np.nonzero(~ok2)[0][:16]:
+        for i in np.nonzero(~ok2)[0][:40]:
             print("    frame %4d: device %.2e m / %.2e, the reference's own FMA builds %.2e m / %.2e" % (i, d2[0][i], d2[1][i], sp2[i], sq2[i]))
         if key == "user" and not take_cnn:
             assert ok2.all()      # the user poses without always_take_cnn: frame by frame here too
+        else:
+            # CNN-driven: the frames that fail the per-frame rule are counted against what the reference's own two FMA builds do to EACH OTHER under the same rule
+            # (parity_rule.cross_build_failures).  That each of these frames is a rounding difference amplified and not a defect: tests/test_gpu_teacher_forced.py (every
+            # single step of all 1024 frames inside 1e-6 m / 2e-5 from the restatement's state), profiles/r06_notes.md (their growth step by step).
+            allowed = pr.cross_build_failures(spread, key, OTHER_FACTOR, pr.CAP_TAKE_CNN)
+            print("    frames failing the per-frame rule: %d; the reference's own FMA builds held against each other: %d" % (int((~ok2).sum()), allowed))
+            assert int((~ok2).sum()) <= allowed
         _distribution(d2, (sp2, sq2), name + " (solver rounding only)")
     # (3) the tracker's discrete state after the frame: `initializing` (handtrack.h:781) on every frame
     assert np.array_equal(ini, refp["flags"][:, 1].astype(np.int32))

@@ -259,23 +259,29 @@ def test_update_cnn_model_and_kickstart(ctx, golden, weights, kick):
     orc = ol.Oracle(weights)
     orc.head.par.microforce = 3.0; orc.head.par.mainthreadpasses = 3
     n_acc = 0
+    import parity_rule as pr
+    trace = np.zeros((NF, 6, 17, 13), np.float32); an = np.zeros((NF, 84), np.float32)      # the restatement's othermodel before MultiStepSim's first step and after each of the five
+    amplified = []
     for f in range(NF):
         orc.reset(start[f])
         so = orc.get_state(1); so[:, :7] = other[f]; orc.set_state(1, so)
         ref = np.zeros((17, 7), np.float32)
         cam = ol.camera(cams[f])
         y = np.ascontiguousarray(cnn_dev[f]); orc.L.ho_set_cnn_override(orc.h, ol.fptr(y))
+        orc.L.ho_set_trace(orc.h, ol.fptr(trace[f]))
         n = orc.L.ho_update_cnn_model(orc.h, ol.u16ptr(np.ascontiguousarray(depth[f])), C.byref(cam), ol.fptr(ref))
+        orc.L.ho_set_trace(orc.h, None); orc.L.ho_get_analysis(orc.h, ol.fptr(an[f]))
         orc.L.ho_set_cnn_override(orc.h, None)
         assert (n > 0) == bool(acc[f]), "frame %d: accept decision" % f
         ro = orc.get_state(1)
         dp = np.abs(poses[f][:, :3] - ro[:, :3]).max(); dq = np.abs(poses[f][:, 3:] - ro[:, 3:7]).max()
         print("update_cnn_model frame %d (%s): |dpos| %.2e |dquat| %.2e" % (f, "accepted" if acc[f] else "rejected", dp, dq))
-        # golden frame 4 from frame 3's pose sits next to a discrete decision: a 2e-7 difference after one MultiStepSim step grows tenfold or more per step, in either
-        # association order of the solver's sums (tools/diag_frame4.py: 2.5e-7, 3.4e-6, 9.8e-6, 1.4e-4, 3.1e-3 after 1 .. 5 steps with the rows four at a time; 2.7e-7,
-        # 9.7e-7, 4.9e-6, 2.5e-4, 2.9e-3 row by row), while every other frame stays at 1e-6 .. 1e-5
-        loose = 5.0 if f == 4 else 1.0
-        assert dp <= loose * FULL_POS_TOL and dq <= loose * FULL_QUAT_TOL
+        # Five free-running hard-driven steps: a frame that stays inside the bands is done.  One that does not (golden frame 4 from frame 3's pose sits next to a discrete
+        # decision: tools/diag_frame4.py, 2.5e-7 after one step, 3.1e-3 after five, in either association order of the solver's sums) is a rounding difference amplified
+        # or a defect -- which of the two is decided below, step by step from the restatement's state; free-running it only has to stay inside parity_rule's cap.
+        if not (dp <= FULL_POS_TOL and dq <= FULL_QUAT_TOL):
+            amplified.append(f)
+            assert dp <= pr.CAP[0] and dq <= pr.CAP[1]
         if n:
             assert np.abs(poses[f] - ref).max() <= FULL_POS_TOL * 10      # the returned pose is othermodel.GetPose()
         expect_hand = ro[:, :7] if (kick and acc[f]) else start[f]
@@ -287,6 +293,15 @@ def test_update_cnn_model_and_kickstart(ctx, golden, weights, kick):
         n_acc += int(acc[f])
     orc.close()
     assert 0 < n_acc      # the case really covers accepted poses
+    # every MultiStepSim step of every frame ALONE, from the restatement's state before it and the restatement's decode (single-step, teacher-forced)
+    assert len(amplified) <= 1, amplified
+    for s_ in range(5):
+        ctx.set_state(1, trace[:, s_])
+        ctx.stage_multistep_range(an, NF, s_, s_ + 1)
+        got = ctx.get_state(1, NF)
+        dps, dqs = pr.pose_diff(got[:, :, :7], trace[:, s_ + 1, :, :7])
+        print("  step %d alone from the restatement's state: |dpos| max %.1e m, |dquat| max %.1e" % (s_, dps.max(), dqs.max()))
+        assert dps.max() <= 1e-6 and dqs.max() <= 2e-5
 
 
 def _scaled_cloud_rows(golden, f, microforce=3.0, weak=0.4):

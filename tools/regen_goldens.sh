@@ -130,11 +130,13 @@ PY
 # harness four ways for the fixed target x86-64-v3 and runs the 1024 frames with each: a few minutes), without and with always_take_cnn
 python3 tests/golden/ref_flag_spread.py $T/spread.json $T/ref_spread1024.npz > /dev/null
 python3 tests/golden/ref_flag_spread.py $T/spread_take.json $T/ref_spread1024_takecnn.npz takecnn > /dev/null
+python3 tests/golden/ref_flag_spread.py $T/spread5.json $T/ref_spread5_256.npz config5 > /dev/null      # BASELINE configs[4]: the yardsticks bench.py --workload config5 / config5-e2e verify against
+python3 tests/golden/ref_flag_spread.py $T/spread5e.json $T/ref_spread5e2e_256.npz e2e > /dev/null
 python3 - "$T" "$G" "$WRITE" <<'PY' || rc=1
 import sys, shutil, numpy as np
 T, G, write = sys.argv[1], sys.argv[2], sys.argv[3] == "1"
 bad = 0
-for f in ("ref_spread1024.npz", "ref_spread1024_takecnn.npz"):
+for f in ("ref_spread1024.npz", "ref_spread1024_takecnn.npz", "ref_spread5_256.npz", "ref_spread5e2e_256.npz"):
     a, b = dict(np.load(T + "/" + f)), dict(np.load(G + "/" + f))
     ok = set(a) == set(b) and all(np.array_equal(a[k], b[k]) for k in a)
     print(("identical  " if ok else "DIFFERENT  ") + f + " (array by array)")
