@@ -38,7 +38,7 @@ extern __shared__ __attribute__((aligned(16))) float4 g_sm[];      // [0, nvert)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct support_t { int voff, n; v3 pos; v4 q; int outer; v3 opos; v4 oq; int sub, grp; };      // sub/grp: this lane is member `sub` of a group of `grp` (1, 2 or 4) lanes sharing the pair
-struct mkpoint { v3 a, b, p; float t; };
+struct mkpoint { v3 a, b; float t; __device__ __forceinline__ v3 p() const { return a - b; } };      // p = a - b is formed where it is used (the same IEEE subtraction as PointOnMinkowski's, gjk.h:68-73): a run's two simplices hold 24 registers less
 struct simplex { v3 v; mkpoint W[4]; int count; };
 struct gjk_hit { v3 normal, p0w, p1w; float separation; };
 
@@ -123,18 +123,18 @@ __device__ __forceinline__ void wave_argmax(float &b, int &i)
 }
 __device__ __forceinline__ mkpoint point_on_minkowski(const support_t &A, const support_t &B, v3 n)      // gjk.h:68-73
 {
-	mkpoint m; m.a = support(A, n); m.b = support(B, -n); m.p = m.a - m.b; m.t = 0; return m;
+	mkpoint m; m.a = support(A, n); m.b = support(B, -n); m.t = 0; return m;
 }
 
 // ---- simplex updates (NextMinkSimplex1..3, gjk.h:93-275) -------------------------------------------------------------
 __device__ void next1(simplex &dst, const simplex &src, const mkpoint &w)
 {
 	const v3 O = V3(0, 0, 0);
-	float t = line_project_time(w.p, src.W[0].p, O);
-	if (t < 0.0f) { dst.W[0] = w; dst.W[0].t = 1.0f; dst.v = w.p; dst.count = 1; return; }
+	float t = line_project_time(w.p(), src.W[0].p(), O);
+	if (t < 0.0f) { dst.W[0] = w; dst.W[0].t = 1.0f; dst.v = w.p(); dst.count = 1; return; }
 	dst.W[0] = src.W[0]; dst.W[0].t = t;
 	dst.W[1] = w; dst.W[1].t = 1.0f - t;
-	dst.v = w.p + (src.W[0].p - w.p) * t;
+	dst.v = w.p() + (src.W[0].p() - w.p()) * t;
 	dst.count = 2;
 }
 __device__ __forceinline__ void keep_edge(simplex &dst, const mkpoint &keep, const mkpoint &w, float t, v3 v)
@@ -145,45 +145,45 @@ __device__ __forceinline__ void keep_edge(simplex &dst, const mkpoint &keep, con
 __device__ void next2(simplex &dst, const simplex &src, const mkpoint &w)
 {
 	const v3 O = V3(0, 0, 0);
-	const v3 w0 = src.W[0].p, w1 = src.W[1].p;
-	float t0 = line_project_time(w.p, w0, O), t1 = line_project_time(w.p, w1, O);
-	v3 v0 = w.p + (w0 - w.p) * t0, v1 = w.p + (w1 - w.p) * t1;
+	const v3 w0 = src.W[0].p(), w1 = src.W[1].p();
+	float t0 = line_project_time(w.p(), w0, O), t1 = line_project_time(w.p(), w1, O);
+	v3 v0 = w.p() + (w0 - w.p()) * t0, v1 = w.p() + (w1 - w.p()) * t1;
 	int ine0 = (dot(-v0, w1 - v0) > 0.0f), ine1 = (dot(-v1, w0 - v1) > 0.0f);
 	if (ine0 && ine1)
 	{
 		mkpoint a = src.W[0], b = src.W[1];
-		dst.count = 3; dst.v = plane_project_of(w0, w1, w.p, O); dst.W[0] = a; dst.W[1] = b; dst.W[2] = w; return;
+		dst.count = 3; dst.v = plane_project_of(w0, w1, w.p(), O); dst.W[0] = a; dst.W[1] = b; dst.W[2] = w; return;
 	}
 	if (!ine0 && (t0 > 0.0f)) { keep_edge(dst, src.W[0], w, t0, v0); return; }
 	if (!ine1 && (t1 > 0.0f)) { keep_edge(dst, src.W[1], w, t1, v1); return; }
-	dst.W[0] = w; dst.W[0].t = 1.0f; dst.v = w.p; dst.count = 1;
+	dst.W[0] = w; dst.W[0].t = 1.0f; dst.v = w.p(); dst.count = 1;
 }
 __device__ void next3(simplex &dst, const simplex &src, const mkpoint &w)
 {
 	const v3 O = V3(0, 0, 0);
-	const v3 w0 = src.W[0].p, w1 = src.W[1].p, w2 = src.W[2].p;
-	float t0 = line_project_time(w.p, w0, O), t1 = line_project_time(w.p, w1, O), t2 = line_project_time(w.p, w2, O);
-	v3 v0 = w.p + (w0 - w.p) * t0, v1 = w.p + (w1 - w.p) * t1, v2 = w.p + (w2 - w.p) * t2;
-	v3 vc0 = plane_project_of(w.p, w1, w2, O), vc1 = plane_project_of(w.p, w2, w0, O), vc2 = plane_project_of(w.p, w0, w1, O);
+	const v3 w0 = src.W[0].p(), w1 = src.W[1].p(), w2 = src.W[2].p();
+	float t0 = line_project_time(w.p(), w0, O), t1 = line_project_time(w.p(), w1, O), t2 = line_project_time(w.p(), w2, O);
+	v3 v0 = w.p() + (w0 - w.p()) * t0, v1 = w.p() + (w1 - w.p()) * t1, v2 = w.p() + (w2 - w.p()) * t2;
+	v3 vc0 = plane_project_of(w.p(), w1, w2, O), vc1 = plane_project_of(w.p(), w2, w0, O), vc2 = plane_project_of(w.p(), w0, w1, O);
 	int inp0 = (dot(-vc0, w0 - vc0) > 0.0f), inp1 = (dot(-vc1, w1 - vc1) > 0.0f), inp2 = (dot(-vc2, w2 - vc2) > 0.0f);
 	const mkpoint s0 = src.W[0], s1 = src.W[1], s2 = src.W[2];
 	if (inp0 && inp1 && inp2) { dst.W[0] = s0; dst.W[1] = s1; dst.W[2] = s2; dst.count = 4; dst.v = O; dst.W[3] = w; return; }
 	int inp2e0 = (dot(-v0, w1 - v0) > 0.0f), inp2e1 = (dot(-v1, w0 - v1) > 0.0f);
-	if (!inp2 && inp2e0 && inp2e1) { dst.count = 3; dst.v = plane_project_of(w0, w1, w.p, O); dst.W[0] = s0; dst.W[1] = s1; dst.W[2] = w; return; }
+	if (!inp2 && inp2e0 && inp2e1) { dst.count = 3; dst.v = plane_project_of(w0, w1, w.p(), O); dst.W[0] = s0; dst.W[1] = s1; dst.W[2] = w; return; }
 	int inp0e1 = (dot(-v1, w2 - v1) > 0.0f), inp0e2 = (dot(-v2, w1 - v2) > 0.0f);
-	if (!inp0 && inp0e1 && inp0e2) { dst.count = 3; dst.v = plane_project_of(w1, w2, w.p, O); dst.W[0] = s1; dst.W[1] = s2; dst.W[2] = w; return; }
+	if (!inp0 && inp0e1 && inp0e2) { dst.count = 3; dst.v = plane_project_of(w1, w2, w.p(), O); dst.W[0] = s1; dst.W[1] = s2; dst.W[2] = w; return; }
 	int inp1e2 = (dot(-v2, w0 - v2) > 0.0f), inp1e0 = (dot(-v0, w2 - v0) > 0.0f);
-	if (!inp1 && inp1e2 && inp1e0) { dst.count = 3; dst.v = plane_project_of(w2, w0, w.p, O); dst.W[0] = s2; dst.W[1] = s0; dst.W[2] = w; return; }
+	if (!inp1 && inp1e2 && inp1e0) { dst.count = 3; dst.v = plane_project_of(w2, w0, w.p(), O); dst.W[0] = s2; dst.W[1] = s0; dst.W[2] = w; return; }
 	if (!inp1e0 && !inp2e0 && t0 > 0.0f) { keep_edge(dst, s0, w, t0, v0); return; }
 	if (!inp2e1 && !inp0e1 && t1 > 0.0f) { keep_edge(dst, s1, w, t1, v1); return; }
 	if (!inp0e2 && !inp1e2 && t2 > 0.0f) { keep_edge(dst, s2, w, t2, v2); return; }
-	dst.W[0] = w; dst.W[0].t = 1.0f; dst.v = w.p; dst.count = 1;
+	dst.W[0] = w; dst.W[0].t = 1.0f; dst.v = w.p(); dst.count = 1;
 }
 __device__ gjk_hit calcpoints(simplex &src)      // gjk.h:337-363
 {
 	if (src.count == 3)
 	{
-		v3 b = barycentric(src.W[0].p, src.W[1].p, src.W[2].p, src.v);
+		v3 b = barycentric(src.W[0].p(), src.W[1].p(), src.W[2].p(), src.v);
 		src.W[0].t = b.x; src.W[1].t = b.y; src.W[2].t = b.z;
 	}
 	// pa = sum t_i a_i in index order, starting from zero (gjk.h:348-353); static indices keep the simplex in registers
@@ -204,28 +204,28 @@ __device__ int gjk_run(const support_t &A, const support_t &B, float cutoff, gjk
 {
 	simplex last, next;
 	last.count = 0; next.count = 0;
-	for (int i = 0; i < 4; i++) { last.W[i].a = last.W[i].b = last.W[i].p = V3(0, 0, 0); last.W[i].t = 0; next.W[i] = last.W[i]; }
+	for (int i = 0; i < 4; i++) { last.W[i].a = last.W[i].b = V3(0, 0, 0); last.W[i].t = 0; next.W[i] = last.W[i]; }
 	int iter = 0;
-	v3 v = point_on_minkowski(A, B, V3(0, 0, 1)).p;
+	v3 v = point_on_minkowski(A, B, V3(0, 0, 1)).p();
 	last.v = v;
 	mkpoint w = point_on_minkowski(A, B, -v);
-	next.W[0] = w; next.W[0].t = 1.0f; next.v = w.p; next.count = 1;                        // NextMinkSimplex0
+	next.W[0] = w; next.W[0].t = 1.0f; next.v = w.p(); next.count = 1;                        // NextMinkSimplex0
 	for (;;)
 	{
 		bool go;
 		if (iter == 0) { iter++; go = true; }
-		else { iter++; go = (dot(w.p, v) < dot(v, v) - 0.00001f); if (go) { go = (iter < 100); iter++; } }      // while(!iter++ || (... && iter++<100))
+		else { iter++; go = (dot(w.p(), v) < dot(v, v) - 0.00001f); if (go) { go = (iter < 100); iter++; } }      // while(!iter++ || (... && iter++<100))
 		if (!go) break;
 		last = next;
 		v = last.v;
 		w = point_on_minkowski(A, B, -v);
-		if (cutoff > 0.0f) { const float wv = dot(w.p, v); if (wv > 0.0f && wv > (cutoff * 1.01f + 1e-6f) * length(v)) return 1; }
-		if (dot(w.p, v) >= dot(v, v) - 0.00001f - 0.00001f * dot(v, v)) break;
+		if (cutoff > 0.0f) { const float wv = dot(w.p(), v); if (wv > 0.0f && wv > (cutoff * 1.01f + 1e-6f) * length(v)) return 1; }
+		if (dot(w.p(), v) >= dot(v, v) - 0.00001f - 0.00001f * dot(v, v)) break;
 		if (last.count == 1) next1(next, last, w); else if (last.count == 2) next2(next, last, w); else next3(next, last, w);
 		if (is_zero(next.v))
 		{
-			if (next.count == 2) { v3 n = orth(next.W[0].p - next.W[1].p); next.W[2] = point_on_minkowski(A, B, n); next.count = 3; }
-			if (next.count == 3) { v3 n = tri_normal(next.W[0].p, next.W[1].p, next.W[2].p); next.W[3] = point_on_minkowski(A, B, n); next.count = 4; }
+			if (next.count == 2) { v3 n = orth(next.W[0].p() - next.W[1].p()); next.W[2] = point_on_minkowski(A, B, n); next.count = 3; }
+			if (next.count == 3) { v3 n = tri_normal(next.W[0].p(), next.W[1].p(), next.W[2].p()); next.W[3] = point_on_minkowski(A, B, n); next.count = 4; }
 			tet = next;
 			return 2;
 		}
@@ -569,7 +569,7 @@ __device__ void separated_wave(bool run, const support_t &A, const support_t &B,
 	const long long t0 = cyc ? clock64() : 0;
 	simplex tet;
 	tet.count = 0;
-	for (int i = 0; i < 4; i++) { tet.W[i].a = tet.W[i].b = tet.W[i].p = V3(0, 0, 0); tet.W[i].t = 0; }
+	for (int i = 0; i < 4; i++) { tet.W[i].a = tet.W[i].b = V3(0, 0, 0); tet.W[i].t = 0; }
 	tet.v = V3(0, 0, 0);
 	status = 1;
 	if (run) status = gjk_run(A, B, cutoff, hit, tet);
@@ -583,7 +583,7 @@ __device__ void separated_wave(bool run, const support_t &A, const support_t &B,
 		const support_t Ab = bcast(A, src), Bb = bcast(B, src);
 		v3 s[4];
 #pragma unroll
-		for (int k = 0; k < 4; k++) s[k] = V3(__shfl(tet.W[k].p.x, src), __shfl(tet.W[k].p.y, src), __shfl(tet.W[k].p.z, src));
+		for (int k = 0; k < 4; k++) s[k] = V3(__shfl(tet.W[k].p().x, src), __shfl(tet.W[k].p().y, src), __shfl(tet.W[k].p().z, src));
 		bool capped = false;
 		v4 mpp = HT_DBG(dbg, 32) ? V4(0, 0, 1, -0.001f) : expanding_polytope_wave_call(em, s[0], s[1], s[2], s[3], Ab, Bb, lane, cyc, capped);
 		if (capped && caps && lane == 0) atomicAdd(caps, 1);
@@ -591,7 +591,7 @@ __device__ void separated_wave(bool run, const support_t &A, const support_t &B,
 		{
 			hit.normal = -xyz(mpp);                                  // gjk.h:417-423
 			hit.separation = fmin_std(0.0f, mpp.w);
-			v4 bw = inverse_w(tet.W[0].p, tet.W[1].p, tet.W[2].p, tet.W[3].p);
+			v4 bw = inverse_w(tet.W[0].p(), tet.W[1].p(), tet.W[2].p(), tet.W[3].p());
 			hit.p0w = ((tet.W[0].a * bw.x + tet.W[1].a * bw.y) + tet.W[2].a * bw.z) + tet.W[3].a * bw.w;
 			hit.p1w = ((tet.W[0].b * bw.x + tet.W[1].b * bw.y) + tet.W[2].b * bw.z) + tet.W[3].b * bw.w;
 			status = 0;
@@ -845,7 +845,7 @@ template <bool JIG> __device__ __forceinline__ void co_pass(const co_lds &L, int
 		v3 opos = V3(0, 0, 0), jn = V3(0, 0, 1); v4 oq = V4(0, 0, 0, 1); xf ar = XF(V3(0, 0, 0), V4(0, 0, 0, 1));
 		simplex last, next;
 		last.count = 0; next.count = 0; last.v = next.v = V3(0, 0, 0);
-		for (int i = 0; i < 4; i++) { last.W[i].a = last.W[i].b = last.W[i].p = V3(0, 0, 0); last.W[i].t = 0; next.W[i] = last.W[i]; }
+		for (int i = 0; i < 4; i++) { last.W[i].a = last.W[i].b = V3(0, 0, 0); last.W[i].t = 0; next.W[i] = last.W[i]; }
 		mkpoint w = last.W[0]; v3 v = V3(0, 0, 0);
 		gjk_hit hit; hit.normal = V3(0, 0, 1); hit.p0w = hit.p1w = V3(0, 0, 0); hit.separation = 0;
 		if (wave < CO_OWN && x < total)
@@ -892,8 +892,8 @@ template <bool JIG> __device__ __forceinline__ void co_pass(const co_lds &L, int
 			{
 				v3 dir = V3(0, 0, 1);
 				if (st == RS_INIT1 || st == RS_ITER) dir = -v;
-				else if (st == RS_TET2) dir = orth(next.W[0].p - next.W[1].p);
-				else if (st == RS_TET3) dir = tri_normal(next.W[0].p, next.W[1].p, next.W[2].p);
+				else if (st == RS_TET2) dir = orth(next.W[0].p() - next.W[1].p());
+				else if (st == RS_TET3) dir = tri_normal(next.W[0].p(), next.W[1].p(), next.W[2].p());
 				const v3 da = mul(transpose(body_R(FR.body[bi])), JIG ? qrot(qconj(oq), dir) : dir);      // qrot(qconj(q), .)
 				const v3 db = mul(transpose(body_R(FR.body[bj])), -dir);
 				co_req ra; ra.shape = shA; ra.dx = da.x; ra.dy = da.y; ra.dz = da.z;
@@ -919,8 +919,8 @@ template <bool JIG> __device__ __forceinline__ void co_pass(const co_lds &L, int
 				const v3 sa = V3(BA.pos[0], BA.pos[1], BA.pos[2]) + mul(body_R(BA), V3(qa.x, qa.y, qa.z));
 				m.a = JIG ? opos + qrot(oq, sa) : sa;
 				m.b = V3(BB.pos[0], BB.pos[1], BB.pos[2]) + mul(body_R(BB), V3(qb.x, qb.y, qb.z));
-				m.p = m.a - m.b; m.t = 0;
-				if (st == RS_INIT0) { v = m.p; last.v = v; st = RS_INIT1; }
+				m.t = 0;
+				if (st == RS_INIT0) { v = m.p(); last.v = v; st = RS_INIT1; }
 				else if (st == RS_TET2) { next.W[2] = m; next.count = 3; st = RS_TET3; }
 				else if (st == RS_TET3) { next.W[3] = m; next.count = 4; st = RS_EPA; }
 				else
@@ -928,7 +928,7 @@ template <bool JIG> __device__ __forceinline__ void co_pass(const co_lds &L, int
 					bool fin = false;
 					if (st == RS_INIT1)
 					{
-						w = m; next.W[0] = w; next.W[0].t = 1.0f; next.v = w.p; next.count = 1;      // NextMinkSimplex0
+						w = m; next.W[0] = w; next.W[0].t = 1.0f; next.v = w.p(); next.count = 1;      // NextMinkSimplex0
 						iter = 1;                                                                    // first trip of the while: !iter++
 						last = next; v = last.v; st = RS_ITER;
 					}
@@ -936,9 +936,9 @@ template <bool JIG> __device__ __forceinline__ void co_pass(const co_lds &L, int
 					{
 						w = m;
 						bool far = false;
-						if (cutoff > 0.0f) { const float wv = dot(w.p, v); far = wv > 0.0f && wv > (cutoff * 1.01f + 1e-6f) * length(v); }
+						if (cutoff > 0.0f) { const float wv = dot(w.p(), v); far = wv > 0.0f && wv > (cutoff * 1.01f + 1e-6f) * length(v); }
 						if (far) st = RS_FAR;
-						else if (dot(w.p, v) >= dot(v, v) - 0.00001f - 0.00001f * dot(v, v)) fin = true;
+						else if (dot(w.p(), v) >= dot(v, v) - 0.00001f - 0.00001f * dot(v, v)) fin = true;
 						else
 						{
 							if (last.count == 1) next1(next, last, w); else if (last.count == 2) next2(next, last, w); else next3(next, last, w);
@@ -947,7 +947,7 @@ template <bool JIG> __device__ __forceinline__ void co_pass(const co_lds &L, int
 							else
 							{
 								iter++;                                                              // while(!iter++ || (cond && iter++ < 100))
-								bool go = dot(w.p, v) < dot(v, v) - 0.00001f;
+								bool go = dot(w.p(), v) < dot(v, v) - 0.00001f;
 								if (go) { go = iter < 100; iter++; }
 								if (!go) fin = true; else { last = next; v = last.v; }
 							}
@@ -968,7 +968,7 @@ template <bool JIG> __device__ __forceinline__ void co_pass(const co_lds &L, int
 				if (j < CO_EPAQ)
 				{
 					co_job &J = L.jobs[j];
-					for (int k = 0; k < 4; k++) { J.p[k][0] = next.W[k].p.x; J.p[k][1] = next.W[k].p.y; J.p[k][2] = next.W[k].p.z; }
+					for (int k = 0; k < 4; k++) { J.p[k][0] = next.W[k].p().x; J.p[k][1] = next.W[k].p().y; J.p[k][2] = next.W[k].p().z; }
 					J.opos[0] = opos.x; J.opos[1] = opos.y; J.opos[2] = opos.z; J.oq[0] = oq.x; J.oq[1] = oq.y; J.oq[2] = oq.z; J.oq[3] = oq.w;
 					J.f = fsel; J.bi = bi; J.bj = bj; J.outer = JIG ? 1 : 0;
 					myjob = j; st = RS_WAIT;
@@ -1004,7 +1004,7 @@ template <bool JIG> __device__ __forceinline__ void co_pass(const co_lds &L, int
 				const co_job &J = L.jobs[myjob];
 				hit.normal = -V3(J.res[0], J.res[1], J.res[2]);                                  // gjk.h:417-423
 				hit.separation = fmin_std(0.0f, J.res[3]);
-				const v4 bw = inverse_w(next.W[0].p, next.W[1].p, next.W[2].p, next.W[3].p);
+				const v4 bw = inverse_w(next.W[0].p(), next.W[1].p(), next.W[2].p(), next.W[3].p());
 				hit.p0w = ((next.W[0].a * bw.x + next.W[1].a * bw.y) + next.W[2].a * bw.z) + next.W[3].a * bw.w;
 				hit.p1w = ((next.W[0].b * bw.x + next.W[1].b * bw.y) + next.W[2].b * bw.z) + next.W[3].b * bw.w;
 				st = RS_HIT;

@@ -49,3 +49,11 @@ def test_closest_feature_and_cnn_kernels(usage):
     for k in usage:
         if any(n in k for n in ("k_conv1", "k_conv2", "k_fcI", "k_fc144")):
             assert usage[k]["ScratchSize"] == 0, k
+
+
+def test_cooperative_contact_kernel(usage):
+    """k_contacts_coop (two waves per SIMD: 256 registers a wave): everything in registers, no private segment.  Until round 6 a run's two simplices kept p = a - b beside a
+    and b (24 registers), and the kernel spilled 32 registers to 76 bytes of scratch per lane."""
+    k = _one(usage, "k_contacts_coop")
+    assert k["ScratchSize"] == 0 and k["VGPRs Spill"] == 0 and k["VGPRs"] + k["AGPRs"] <= 256 and k["Occupancy"] >= 2
+    assert _one(usage, "k_solve_prep")["ScratchSize"] == 0

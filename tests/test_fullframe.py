@@ -220,3 +220,44 @@ def test_gpu_reset_stages_bit_exact_over_the_default_capacity(weights):
             assert d <= 2e-6      # test_reset_path (64x64 tiles, records in LDS) sees the same last-place differences against the reference
     finally:
         ctx.close(); orc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("voxel", [0, 1])
+def test_gpu_overlapped_update_on_a_full_frame_equals_the_synchronous_one(weights, voxel):
+    """The reference's job / passes structure on two contexts (handtrack.h:755-768: ht_job_start / ht_job_wait / ht_job_collect, then the caller's part
+    ht_update_passes_sync) with the job collected first IS the synchronous sequence: bit for bit, on a 320x240 frame and with subsample_voxel -- the caller's part then runs
+    its passes on the voxel cloud of the full frame (handtrack.h:751-753), which it has to build itself."""
+    from hand_tracking_samples_amd import native
+    G, (_, model, nb) = GOLD["qvga"], CASES["qvga"]
+    nf = len(G["rows"])
+    depth = np.ascontiguousarray(np.stack([G["f%d/depth" % f] for f in range(nf)])); cams = np.ascontiguousarray(np.stack([G["f%d/cam" % f] for f in range(nf)]), np.float32)
+    start = np.stack([G["f%d/startpose" % f] for f in range(nf)])
+    h, w = depth.shape[1], depth.shape[2]
+    par = dict(microforce=3.0, mainthreadpasses=3, subsample_voxel=voxel, subsample_size=0.01)
+    ref = native.Context(model, nf)
+    main = native.Context(model, nf); job = native.Context(model, nf)
+    try:
+        for c in (ref, main, job):
+            c.load_weights(weights); c.set_params(**par)
+        ref.tracker_reset(start); main.tracker_reset(start)
+        u16 = C.POINTER(C.c_uint16); fp = C.POINTER(C.c_float)
+        L = main.L
+        L.ht_job_start.argtypes = [C.c_void_p, C.c_void_p, u16, fp, C.c_int, C.c_int, C.c_float, C.c_int]
+        L.ht_job_wait.argtypes = [C.c_void_p]
+        L.ht_job_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.ht_update_passes_sync.argtypes = [C.c_void_p, u16, fp, C.c_int, C.c_int, C.c_int, fp]
+        for it in range(2):      # the second update runs on carried momenta and flags
+            want, _ = ref.update_frames_sync(depth, cams, 0.17, want_cnn=True)
+            got = np.zeros((nf, nb, 7), np.float32)
+            assert L.ht_job_start(job.h, main.h, depth.ctypes.data_as(u16), cams.ctypes.data_as(fp), w, h, 0.17, nf) == 0
+            assert L.ht_job_wait(job.h) == 0
+            assert L.ht_job_collect(job.h, main.h, nf, None) == 0
+            assert L.ht_update_passes_sync(main.h, depth.ctypes.data_as(u16), cams.ctypes.data_as(fp), w, h, nf, got.ctypes.data_as(fp)) == 0
+            assert np.isfinite(got).all()
+            assert np.array_equal(got, want), "update %d: overlapped (job collected first) differs from the synchronous update by %.3e" % (it, np.abs(got - want).max())
+            assert np.array_equal(main.get_state(0, nf), ref.get_state(0, nf))
+            assert main.tracker_flags(nf)[1].tolist() == ref.tracker_flags(nf)[1].tolist()
+    finally:
+        for c in (ref, main, job):
+            c.close()
