@@ -107,7 +107,7 @@ def same(name, new, old):
     bad += not ok
 f = htfx.load(T + "/frames256.htfx"); f256 = {k: f[k] for k in ("depth", "cam", "startpose", "gtpose", "rows")}
 same("frames256.npz", f256, dict(np.load(G + "/frames256.npz")))
-f = htfx.load(T + "/frames1024.htfx"); f1024 = {k: f[k] for k in ("depth", "cam", "startpose", "rows")}
+f = htfx.load(T + "/frames1024.htfx"); f1024 = {k: f[k] for k in ("depth", "cam", "startpose", "gtpose", "rows")}      # gtpose: the rendered row's own pose (labels of tools/train_synthetic.py)
 same("frames1024.npz", f1024, dict(np.load(G + "/frames1024.npz")))
 g = htfx.load(T + "/frames5.htfx"); f5 = {k: g[k] for k in ("depth", "cam", "startpose", "rows")}
 same("frames5_64.npz", f5, dict(np.load(G + "/frames5_64.npz")))
