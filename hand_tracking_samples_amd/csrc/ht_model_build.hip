@@ -515,6 +515,7 @@ bool ht_build_model(const char *json_path, int flags, fx_map &out, std::string &
 	for (int j = 0; j < nj; j++) if (joints[j].rb0 < 0 || joints[j].rb0 > j || joints[j].rb1 < 0 || joints[j].rb1 >= nb) { err = "model json: joint " + std::to_string(j) + " must attach to an earlier body"; return false; }
 
 	std::vector<body> bodies(nb);
+	std::vector<std::vector<v3>> sdverts(nb);      // the subdivision surfaces GetMeshes(true) hands to a renderer (physmodel.h:295-303)
 	for (int i = 0; i < nb; i++)
 	{
 		const jnode &c = cages->items[i]; const jnode *jv = c.get("verts"), *jf = c.get("faces");
@@ -525,6 +526,10 @@ bool ht_build_model(const char *json_path, int flags, fx_map &out, std::string &
 		hemesh m;
 		if (!m.create(cv, cf)) { err = "model json: cage " + std::to_string(i) + " is not a closed manifold"; return false; }
 		if (!subdivide(m) || !subdivide(m)) { err = "subdivision failed on cage " + std::to_string(i); return false; }      // physmodel.h:256
+		{      // sdmeshes (physmodel.h:258): MeshFlatShadeTex(subdiv.verts, subdiv.GenerateTris()) -- three fresh vertices per triangle, in the bone's rig frame
+			const std::vector<int> st = m.tris();
+			for (int k : st) sdverts[i].push_back(m.verts[k]);
+		}
 		std::vector<v3> verts = m.verts; std::vector<int> tris;
 		if (!greedy_hull(verts, 48, tris)) { err = "convex hull failed on cage " + std::to_string(i); return false; }      // physmodel.h:454
 		v3 position = V3(0, 0, 0);
@@ -564,6 +569,7 @@ bool ht_build_model(const char *json_path, int flags, fx_map &out, std::string &
 	{
 		const body &b = bodies[i];
 		put_body(out, i, b, bf);
+		{ std::vector<float> sv; for (auto &x : sdverts[i]) { sv.push_back(x.x); sv.push_back(x.y); sv.push_back(x.z); } out["b" + std::to_string(i) + "/sdverts"] = fx_f32(sv, { (uint32_t)sdverts[i].size(), 3 }); }
 		collide.push_back(b.collide); nverts.push_back((int)b.verts.size()); nplanes.push_back((int)b.planes.size());
 		for (int k : b.ignore) ign[(size_t)i * nb + k] = 1;
 		igncount.push_back((int)b.ignore.size());      // entries incl. duplicates: what `ignore.size()` reads in handtrack.h:408

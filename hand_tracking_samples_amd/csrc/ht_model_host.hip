@@ -16,6 +16,7 @@ struct ht_model
 	int nb = 0, nj = 0;
 	std::vector<std::vector<float>> verts, planes;      // per body: [n][3] com-centred vertices, [n][4] local half-space planes
 	std::vector<std::vector<int>> tris;                 // per body: [n][3] hull triangles over verts
+	std::vector<std::vector<float>> sdverts;            // per body: [3 t][3] the subdivision surface's triangles corner by corner, in the bone's rig frame (GetMeshes(true), physmodel.h:258)
 	std::vector<float> com, rest;                       // [nb][3], [nb][7]
 	std::string err;
 };
@@ -42,6 +43,8 @@ extern "C" int ht_model_open(const char *path, int hand_tweaks, ht_model **out)
 		m->verts.emplace_back(v->f(), v->f() + (size_t)v->dims[0] * 3);
 		m->planes.emplace_back(p->f(), p->f() + (size_t)p->dims[0] * 4);
 		m->tris.emplace_back(t->i(), t->i() + (size_t)t->dims[0] * 3);
+		const fx_arr *sv = get(k + "/sdverts");
+		if (sv) m->sdverts.emplace_back(sv->f(), sv->f() + (size_t)sv->dims[0] * 3); else m->sdverts.emplace_back();
 		const float *r = bf->f() + 26 * b;      // mass massinv radius radius_inner damping friction gravscale com3 pos_start3 quat_start4 tensorinv9
 		m->com.insert(m->com.end(), r + 7, r + 10);
 		m->rest.insert(m->rest.end(), r + 10, r + 17);
@@ -66,6 +69,15 @@ extern "C" int ht_model_body_mesh(const ht_model *m, int body, float *verts, int
 	if (!m || body < 0 || body >= m->nb) return HT_ERR_ARG;
 	if (verts) memcpy(verts, m->verts[body].data(), m->verts[body].size() * sizeof(float));
 	if (tris) memcpy(tris, m->tris[body].data(), m->tris[body].size() * sizeof(int));
+	return HT_OK;
+}
+// the subdivision surface of a body (PhysModel::sdmeshes, physmodel.h:258: MeshFlatShadeTex of the twice-subdivided control cage): *nverts corner positions, three per
+// triangle in order, in the bone's rig frame -- drawn at Pose{PositionUser, orientation} (physmodel.h:297-298).  verts may be NULL to ask for the count.
+extern "C" int ht_model_body_sdmesh(const ht_model *m, int body, int *nverts, float *verts)
+{
+	if (!m || body < 0 || body >= m->nb) return HT_ERR_ARG;
+	if (nverts) *nverts = (int)m->sdverts[body].size() / 3;
+	if (verts) memcpy(verts, m->sdverts[body].data(), m->sdverts[body].size() * sizeof(float));
 	return HT_OK;
 }
 // PhysModel::HitCheck(v0, v1): the segment is clipped against the hull of every body in turn, each body starting from the impact the previous

@@ -19,7 +19,7 @@ MAXPTS, ROW, CONTACT = 4096, 16, 12      # HT_MAX_POINTS
 SYMBOLS = (
     "ht_create", "ht_destroy", "ht_model_bake", "ht_last_error", "ht_get_params", "ht_set_params", "ht_model_info", "ht_config_read", "ht_scale",
     "ht_cnn_load_weights", "ht_cnn_eval", "ht_cnn_eval_dev", "ht_cnn_load_weights_sized", "ht_cnn_eval_sized", "ht_cnn_eval_sized_dev", "ht_cnn_train", "ht_cnn_get_weights", "ht_expected_cnn", "ht_expected_cnn_full",
-    "ht_model_open", "ht_model_close", "ht_model_error", "ht_model_counts", "ht_model_body", "ht_model_body_mesh", "ht_model_hitcheck",
+    "ht_model_open", "ht_model_close", "ht_model_error", "ht_model_counts", "ht_model_body", "ht_model_body_mesh", "ht_model_body_sdmesh", "ht_model_hitcheck",
     "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_update_frames_sync", "ht_update_frames_dev", "ht_update_direct_sync", "ht_update_direct_dev", "ht_update_cnn_model_sync", "ht_get_cnn_results", "ht_get_cnn_layers", "ht_frames_overflow", "ht_reserve_points", "ht_point_capacity", "ht_capacity_events", "ht_segment_vr", "ht_segment_vr_dev", "ht_slowfit", "ht_set_points", "ht_fit_rows", "ht_physics_update",
     "ht_stage_prepare", "ht_stage_decode", "ht_stage_fit_error", "ht_stage_cloud_rows", "ht_stage_contacts", "ht_stage_fit",
     "ht_stage_multistep", "ht_stage_multistep_range", "ht_stage_scratch_unibody", "ht_stage_chamber", "ht_profile_enable", "ht_profile_read", "ht_debug_solve_stats", "ht_debug_contact_stats", "ht_debug_solver_build", "ht_debug_reset_flags", "ht_debug_reset_organisation", "ht_update_passes_sync", "ht_job_start", "ht_job_poll", "ht_job_wait", "ht_job_collect", "ht_debug_contact_kernel", "ht_debug_solve_tables", "ht_debug_solve_tables_header",

@@ -125,6 +125,21 @@ inline DCamera camsub(const DCamera &c, int s)                                  
 	return DCamera({ c.dim().x / s, c.dim().y / s }, { c.focal().x / (float)s, c.focal().y / (float)s }, { c.principal().x / (float)s, c.principal().y / (float)s }, c.depth_scale, c.pose);
 }
 struct Mesh { std::vector<float3> verts; std::vector<int3> tris; Pose pose; float4 hack{ 1, 1, 1, 1 }; std::string material; };      // mesh.h (what GetMeshes hands to a renderer)
+namespace detail
+{
+// PhysModel::sdmeshes[body] (physmodel.h:258): the twice-subdivided control cage, flat-shaded -- three fresh vertices per triangle, as MeshFlatShadeTex lays them out
+// (mesh.h:154-177; positions only: the tangent frames and texture coordinates a renderer derives from them are not part of this surface)
+inline Mesh subdivision_mesh(const ht_model *m, int body)
+{
+	Mesh mesh; int nv = 0;
+	ht_model_body_sdmesh(m, body, &nv, nullptr);
+	std::vector<float> v((size_t)nv * 3);
+	ht_model_body_sdmesh(m, body, nullptr, v.data());
+	for (int i = 0; i < nv; i++) mesh.verts.push_back({ v[3 * i], v[3 * i + 1], v[3 * i + 2] });
+	for (int i = 0; i + 2 < nv; i += 3) mesh.tris.push_back({ i, i + 1, i + 2 });
+	return mesh;
+}
+}
 
 // ---- the host-side image helpers the applications draw with (synthetic-tracker.cpp:191,206,208-209,218,221-222): plain loops over small rasters, no device work.
 //      Same names and results as the reference's templates; written for this Image / DCamera.
@@ -303,7 +318,14 @@ struct HandTracker                                                              
 			check(ctx_, ht_set_state(ctx_, which_, 0, 1, st.data()));
 			return *this;
 		}
-		std::vector<Mesh> &GetMeshes(int = 0) { const std::vector<Pose> p = GetPose(); for (size_t b = 0; b < meshes_.size() && b < p.size(); b++) meshes_[b].pose = p[b]; return meshes_; }
+		// physmodel.h:295-303: the subdivision meshes live in rig space (pose = PositionUser, orientation), the hull meshes in the centre-of-mass frames
+		std::vector<Mesh> &GetMeshes(int show_subdiv = 0)
+		{
+			const std::vector<Pose> p = GetPose(), u = GetPoseUser();
+			for (size_t b = 0; b < sdmeshes_.size() && b < u.size(); b++) sdmeshes_[b].pose = u[b];
+			for (size_t b = 0; b < meshes_.size() && b < p.size(); b++) meshes_[b].pose = p[b];
+			return show_subdiv ? sdmeshes_ : meshes_;
+		}
 		// void FitPointCloud(const std::vector<float3> &points, std::vector<LimitLinear> linears = {}, std::vector<LimitAngular> angulars = {}, float microforce = 1.0f)
 		// (physmodel.h:345-356): one fit step of this model against a point cloud under the caller's rows, the cloud rows, the joint rows and the collision rows
 		std::vector<RigidBody> rigidbodies;                                                                          // handles for the rows (physmodel.h:253)
@@ -316,7 +338,7 @@ struct HandTracker                                                              
 		void FitPointCloud(const std::vector<float3> &points, float microforce) { FitPointCloud(points, {}, {}, microforce); }      // round-1 shorthand
 	private:
 		friend struct HandTracker;
-		ht_ctx *ctx_ = nullptr; int which_ = 0, nb_ = 0; std::vector<float3> com_; std::vector<Mesh> meshes_;
+		ht_ctx *ctx_ = nullptr; int which_ = 0, nb_ = 0; std::vector<float3> com_; std::vector<Mesh> meshes_, sdmeshes_;
 		std::vector<Pose> read(bool user) const
 		{
 			std::vector<float> st((size_t)nb_ * HT_STATE);
@@ -359,10 +381,10 @@ struct HandTracker                                                              
 					ht_model_body_mesh(m, b, v.data(), t.data());
 					for (int i = 0; i < nv; i++) mesh.verts.push_back({ v[3 * i], v[3 * i + 1], v[3 * i + 2] });
 					for (int i = 0; i < nt; i++) mesh.tris.push_back({ t[3 * i], t[3 * i + 1], t[3 * i + 2] });
-					handmodel.com_.push_back({ com[0], com[1], com[2] }); handmodel.meshes_.push_back(mesh);
+					handmodel.com_.push_back({ com[0], com[1], com[2] }); handmodel.meshes_.push_back(mesh); handmodel.sdmeshes_.push_back(detail::subdivision_mesh(m, b));
 				}
 			if (m) ht_model_close(m);
-			othermodel.com_ = handmodel.com_; othermodel.meshes_ = handmodel.meshes_;
+			othermodel.com_ = handmodel.com_; othermodel.meshes_ = handmodel.meshes_; othermodel.sdmeshes_ = handmodel.sdmeshes_;
 			handmodel.ctx_ = othermodel.ctx_ = ctx_; handmodel.nb_ = othermodel.nb_ = nb_; handmodel.which_ = 0; othermodel.which_ = 1;
 			for (int b = 0; b < nb_; b++) { handmodel.rigidbodies.push_back(RigidBody{ ctx_, 0, b }); othermodel.rigidbodies.push_back(RigidBody{ ctx_, 1, b }); }
 		}
@@ -581,7 +603,7 @@ public:
 		float3 PositionUser() const { return pose() * float3{ -com.x, -com.y, -com.z }; } };                          // physics.h:142
 	struct ModelHitInfo { bool hit = false; float3 impact{ 0, 0, 0 }, normal{ 0, 0, 0 }; int rb = -1; operator bool() const { return hit; } };      // physmodel.h:280-286
 	std::vector<Body> rigidbodies;
-	std::vector<Mesh> sdmeshes;
+	std::vector<Mesh> sdmeshes, meshes;      // physmodel.h:251-252: the subdivision surfaces (rig space) and the collision hulls (centre-of-mass frames)
 	explicit PhysModel(const char *jsonfile, bool hand_tweaks = false)
 	{
 		ht_model *m = nullptr;
@@ -599,13 +621,19 @@ public:
 			ht_model_body_mesh(m, b, v.data(), t.data());
 			for (int i = 0; i < nv; i++) mesh.verts.push_back({ v[3 * i], v[3 * i + 1], v[3 * i + 2] });
 			for (int i = 0; i < nt; i++) mesh.tris.push_back({ t[3 * i], t[3 * i + 1], t[3 * i + 2] });
-			sdmeshes.push_back(mesh);
+			meshes.push_back(mesh);
+			sdmeshes.push_back(detail::subdivision_mesh(m, b));
 		}
 	}
 	std::vector<Pose> GetPose() const { std::vector<Pose> p; for (auto &rb : rigidbodies) p.push_back(rb.pose()); return p; }                                            // physmodel.h:433
 	std::vector<Pose> GetPoseUser() const { std::vector<Pose> p; for (auto &rb : rigidbodies) { Pose q = rb.pose(); q.position = rb.PositionUser(); p.push_back(q); } return p; }      // :434
 	PhysModel &SetPose(const std::vector<Pose> &poses) { for (size_t i = 0; i < poses.size() && i < rigidbodies.size(); i++) { rigidbodies[i].position = poses[i].position; rigidbodies[i].orientation = poses[i].orientation; } return *this; }      // :435
-	std::vector<Mesh> &GetMeshes(int = 0) { for (size_t i = 0; i < rigidbodies.size(); i++) sdmeshes[i].pose = rigidbodies[i].pose(); return sdmeshes; }                 // :295-303 (hull meshes in the bodies' own frames)
+	std::vector<Mesh> &GetMeshes(int show_subdiv = 0)                                                                                                                    // :295-303
+	{
+		for (size_t i = 0; i < rigidbodies.size(); i++) { Pose u = rigidbodies[i].pose(); u.position = rigidbodies[i].PositionUser(); sdmeshes[i].pose = u; }      // the subdivision meshes are in rig space
+		for (size_t i = 0; i < rigidbodies.size(); i++) meshes[i].pose = rigidbodies[i].pose();                                                                   // the hulls in the centre-of-mass frames
+		return show_subdiv ? sdmeshes : meshes;
+	}
 	ModelHitInfo HitCheck(const float3 &v0, const float3 &v1) const                                                                                                      // :287-294
 	{
 		std::vector<float> p7(rigidbodies.size() * HT_POSE);

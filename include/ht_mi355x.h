@@ -227,6 +227,7 @@ const char *ht_model_error(const ht_model *m);
 int ht_model_counts(const ht_model *m, int *n_bodies, int *n_joints);
 int ht_model_body(const ht_model *m, int body, int *nverts, int *ntris, int *nplanes, float *com3, float *rest_pose7);
 int ht_model_body_mesh(const ht_model *m, int body, float *verts, int *tris);
+int ht_model_body_sdmesh(const ht_model *m, int body, int *nverts, float *verts);      /* PhysModel::sdmeshes (physmodel.h:258): the twice-subdivided control cage flat-shaded, three corner positions per triangle in the bone's rig frame; verts NULL: the count only */
 int ht_model_hitcheck(const ht_model *m, const float *poses, const float *v0, const float *v1, float *impact3, float *normal3, int *body);
 
 /* ---- segmentation: the step before the tracker for full-size frames --------------------------------------------------

@@ -393,6 +393,7 @@ static int dump_model(PhysModel &m, const char *outfn)
 	{
 		auto &rb = m.rigidbodies[b];
 		o.v3("b" + std::to_string(b) + "/verts", rb.shapes[0].verts);
+		{ std::vector<float3> sv; for (auto &v : m.sdmeshes[b].verts) sv.push_back(v.position); o.v3("b" + std::to_string(b) + "/sdverts", sv); }      // GetMeshes(true): the subdivision surface, rig space (physmodel.h:258,295-303)
 		std::vector<float> pl; for (auto &p : rb.shapes[0].planes) for (int i = 0; i < 4; i++) pl.push_back(p[i]);
 		o.f32("b" + std::to_string(b) + "/planes", pl, { (uint32_t)rb.shapes[0].planes.size(), 4 });
 		std::vector<int> tr; for (auto &t : rb.shapes[0].tris) for (int i = 0; i < 3; i++) tr.push_back(t[i]);

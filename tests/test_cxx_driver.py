@@ -49,7 +49,7 @@ def test_fake_hand_depth_raster_matches_the_reference(tmp_path):
     gt = np.stack([G["f%d/gtpose" % f] for f in range(n)]); start = np.stack([G["f%d/startpose" % f] for f in range(n)])
     _write_input(tmp_path / "in.bin", depth, cams, start, gt)
     out = subprocess.check_output([exe, "fakedepth", ol.MODEL, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")]).decode()
-    assert "92 mesh triangles" in out
+    assert "512 mesh triangles" in out      # GetMeshes(true): the subdivision surface of the palm (258 vertices, 256 quads)
     got = np.fromfile(tmp_path / "out.bin", np.uint16).reshape(depth.shape)
     hand = depth < 4000
     assert hand.sum() > 2000
