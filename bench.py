@@ -14,7 +14,7 @@ configs[3] (65536 frames over 8 GPUs) is `--gpus 8 --frames-per-gpu 8192`.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP-event timed on the
 stream it runs on) and `cpu_baseline` (the reference's own code from oracle/_ref when present, else the C oracle port).
-The batch is 1024 DISTINCT animation-bank frames (tests/golden/frames1024.npz, row (3 + 9 i) mod 2336: SURVEY 8d config 2;
+The batch is 1024 DISTINCT animation-bank frames (bench_data/frames1024.npz, row (3 + 9 i) mod 2336: SURVEY 8d config 2;
 larger batches repeat them, every rank starts at another offset); after the timed loop EVERY distinct frame of rank 0's
 batch is compared with what the reference itself produced for it (tests/golden/poses1024.htfx, `verified`), so a number
 from a build that computes something else is reported as such.  Tuning switches of the library (HT_DEBUG_SKIP, HT_NO_SIDE, HT_NO_OVERLAP) make the run refuse.
@@ -76,14 +76,14 @@ def _tile(a, n, first=0):
 def _load_frames(n, first=0):
     """BASELINE configs[2]: 1024 distinct 64x64 frames (animation-bank row (3 + 9 i) mod 2336, tools/regen_goldens.sh), repeated for larger batches, from frame `first` on"""
     import numpy as np
-    z = np.load(os.path.join(ROOT, "tests", "golden", "frames1024.npz"))
+    z = np.load(os.path.join(ROOT, "bench_data", "frames1024.npz"))
     return (_tile(z["depth"].reshape(-1, 4096), n, first).astype(np.uint16), _tile(z["cam"], n, first).astype(np.float32), _tile(z["startpose"], n, first).astype(np.float32))
 
 
 def _load_frames5(n, first=0):
     """BASELINE configs[4]: 256 distinct 128x128 frames of the 26-bone hand (animation-bank row 3 + 9 i, ref_harness fullframes: tools/regen_goldens.sh), repeated"""
     import numpy as np
-    z = np.load(os.path.join(ROOT, "tests", "golden", "frames5_256.npz"))
+    z = np.load(os.path.join(ROOT, "bench_data", "frames5_256.npz"))
     return (_tile(z["depth"], n, first).astype(np.uint16), _tile(z["cam"], n, first).astype(np.float32), _tile(z["startpose"], n, first).astype(np.float32))
 
 

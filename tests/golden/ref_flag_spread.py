@@ -2,7 +2,7 @@
 
 Compiles oracle/ref_harness.cpp against the reference headers four ways -- IEEE (-O2 -ffp-contract=off: the build every fixture comes from),
 FMA-contracted (-O2 -march=native, clang's default -ffp-contract=on, and =fast) and the reference Makefile's own default (-Ofast -march=native,
-Makefile:22-28) -- runs the whole unit of work on the 1024 bench frames (tests/golden/frames1024.npz) with each and prints / writes the per-frame
+Makefile:22-28) -- runs the whole unit of work on the 1024 bench frames (bench_data/frames1024.npz) with each and prints / writes the per-frame
 pose differences against the IEEE build.  This is the yardstick for the floating-point tolerance of the device path: the device solver evaluates
 the reference's row updates in Jacobian form with fused multiply-adds (csrc/ht_quad.hpp), i.e. it is one more "build" of the same algorithm.
 
@@ -10,7 +10,7 @@ the reference's row updates in Jacobian form with fused multiply-adds (csrc/ht_q
 
 With `takecnn` the unit of work runs with always_take_cnn = 1 (every CNN-driven pose accepted: the user pose then depends on the net and MultiStepSim on every frame);
 the per-frame file is committed as tests/golden/ref_spread1024_takecnn.npz and held against tests/golden/poses1024_takecnn.htfx.
-`config5` / `e2e`: BASELINE configs[4] instead -- the 256 frames of tests/golden/frames5_256.npz with the 26-bone hand as the reference runs them (posesfull) / end to end
+`config5` / `e2e`: BASELINE configs[4] instead -- the 256 frames of bench_data/frames5_256.npz with the 26-bone hand as the reference runs them (posesfull) / end to end
 with the 128x128-input net (e2e128); committed as tests/golden/ref_spread5_256.npz / ref_spread5e2e_256.npz.
 The FMA builds are compiled for -march=x86-64-v3 (a fixed target: the yardstick does not depend on the host that regenerates it).
 
@@ -58,14 +58,14 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         env = dict(os.environ)
         if five:
-            d = np.load(os.path.join(HERE, "frames5_256.npz"))
+            d = np.load(os.path.join(ROOT, "bench_data", "frames5_256.npz"))
             frames = os.path.join(td, "frames5_256.htfx")
             htfx.save(frames, {"depth": d["depth"], "cam": d["cam"], "startpose": d["startpose"], "rows": d["rows"]})
             mj = os.path.join(td, "model_hand26.json")
             subprocess.check_call([sys.executable, os.path.join(HERE, "make_model_hand26.py"), mj], stdout=subprocess.DEVNULL)
             env["HT_REF_MODEL_JSON"] = mj
         else:
-            d = np.load(os.path.join(HERE, "frames1024.npz"))
+            d = np.load(os.path.join(ROOT, "bench_data", "frames1024.npz"))
             frames = os.path.join(td, "frames1024.htfx")
             htfx.save(frames, {"depth": d["depth"].reshape(-1, 64, 64), "cam": d["cam"], "startpose": d["startpose"]})
         res = {}
@@ -101,7 +101,7 @@ def main():
         if len(sys.argv) > 2:
             np.savez_compressed(sys.argv[2], **per_frame)
     if len(sys.argv) > 1:
-        json.dump({"what": "reference built with other compiler flags vs its IEEE build (-O2 -ffp-contract=off), whole unit of work on the bench frames (%s)" % ("tests/golden/frames5_256.npz, 26 bones, " + mode if five else "tests/golden/frames1024.npz"), "builds": out}, open(sys.argv[1], "w"), indent=1)
+        json.dump({"what": "reference built with other compiler flags vs its IEEE build (-O2 -ffp-contract=off), whole unit of work on the bench frames (%s)" % ("bench_data/frames5_256.npz, 26 bones, " + mode if five else "bench_data/frames1024.npz"), "builds": out}, open(sys.argv[1], "w"), indent=1)
 
 
 if __name__ == "__main__":

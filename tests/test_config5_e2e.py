@@ -77,7 +77,7 @@ def test_oracle_reproduces_all_64_bench_frames(oracle):
 
 
 G256 = htfx.load(os.path.join(HERE, "golden", "e2e128_256.htfx"))      # the bench's configs[4] batch: 256 distinct frames, the reference's results for all of them (all/ only)
-FR256 = np.load(os.path.join(HERE, "golden", "frames5_256.npz"))
+FR256 = np.load(os.path.join(os.path.dirname(HERE), "bench_data", "frames5_256.npz"))
 
 
 def test_oracle_reproduces_all_256_bench_frames(oracle):

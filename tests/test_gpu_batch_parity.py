@@ -37,7 +37,7 @@ def _diff(got, ref):
 def _run_batch(weights, take_cnn):
     from hand_tracking_samples_amd import native
     n = 1024
-    d = np.load(os.path.join(HERE, "golden", "frames1024.npz"))
+    d = np.load(os.path.join(os.path.dirname(HERE), "bench_data", "frames1024.npz"))
     depth, cams, start = d["depth"].reshape(n, -1), d["cam"], d["startpose"]
     ctx = native.Context(ol.MODEL, n)
     ctx.load_weights(weights)
@@ -54,7 +54,7 @@ def _run_batch(weights, take_cnn):
 def _restatement_given_heat_maps(weights, cnn, take_cnn):
     """the CPU restatement (pinned on the reference bit for bit) on the 1024 frames, given the DEVICE's heat-maps: what the reference's arithmetic makes of the very CNN
     output the device's solver worked from -- the net's own rounding (MFMA accumulation, <= 2.6e-6: tests/test_gpu_cnn.py) is taken out of the comparison"""
-    d = np.load(os.path.join(HERE, "golden", "frames1024.npz"))
+    d = np.load(os.path.join(os.path.dirname(HERE), "bench_data", "frames1024.npz"))
     orc = ol.Oracle(weights)
     orc.head.par.microforce = 3.0; orc.head.par.mainthreadpasses = 3; orc.head.par.always_take_cnn = 1 if take_cnn else 0
     n = len(cnn)

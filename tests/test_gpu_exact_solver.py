@@ -19,7 +19,7 @@ from hand_tracking_samples_amd import weights as W
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-FR = np.load(os.path.join(HERE, "golden", "frames1024.npz"))      # the bench's 1024 distinct frames
+FR = np.load(os.path.join(os.path.dirname(HERE), "bench_data", "frames1024.npz"))      # the bench's 1024 distinct frames
 REF = htfx.load(os.path.join(HERE, "golden", "poses1024.htfx"))
 N = len(FR["depth"])
 

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def _update(weights, tables, n, take_cnn=0, build=0, voxel=0):
     from hand_tracking_samples_amd import native
-    d = np.load(os.path.join(HERE, "golden", "frames1024.npz"))
+    d = np.load(os.path.join(os.path.dirname(HERE), "bench_data", "frames1024.npz"))
     depth, cams, start = d["depth"].reshape(1024, -1)[:n], d["cam"][:n], d["startpose"][:n]
     ctx = native.Context(ol.MODEL, n)
     try:

@@ -46,7 +46,7 @@ def _restatement_trace(weights, d, n):
 def test_every_solve_single_step_from_the_restatements_state(weights):
     from hand_tracking_samples_amd import native
     n = 1024
-    d = np.load(os.path.join(HERE, "golden", "frames1024.npz"))
+    d = np.load(os.path.join(os.path.dirname(HERE), "bench_data", "frames1024.npz"))
     trace, analysis = _restatement_trace(weights, d, n)
     assert np.isfinite(trace).all()
     ctx = native.Context(ol.MODEL, n)

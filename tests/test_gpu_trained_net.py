@@ -47,7 +47,7 @@ def test_net_and_decode_with_trained_weights_against_the_restatement(trained):
     tests/test_gpu_cnn.py, the decode of the device's own heat-maps as tests/test_gpu_cnn.py holds it on the golden frames"""
     from hand_tracking_samples_amd import native
     w = trained["weights"]; fr = trained["test_frames"]; x = trained["inputs"][fr]
-    d = np.load(os.path.join(HERE, "golden", "frames1024.npz"))
+    d = np.load(os.path.join(os.path.dirname(HERE), "bench_data", "frames1024.npz"))
     ctx = native.Context(ol.MODEL, len(fr))
     try:
         ctx.load_weights(w)
@@ -80,7 +80,7 @@ def test_unit_of_work_with_the_trained_net_takes_the_cnn_pose_where_the_referenc
     from hand_tracking_samples_amd import native
     import parity_rule as pr
     w = trained["weights"]; fr = trained["test_frames"]
-    d = np.load(os.path.join(HERE, "golden", "frames1024.npz"))
+    d = np.load(os.path.join(os.path.dirname(HERE), "bench_data", "frames1024.npz"))
     depth, cams, start = d["depth"][fr].reshape(len(fr), -1), d["cam"][fr], d["startpose"][fr]
     n = len(fr)
     ctx = native.Context(ol.MODEL, n)

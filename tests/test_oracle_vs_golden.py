@@ -277,10 +277,10 @@ def test_unit_of_work_on_all_256_bench_frames(weights):
 
 
 def test_unit_of_work_on_all_1024_bench_frames(weights):
-    """The same on the 1024 DISTINCT frames bench.py times (tests/golden/frames1024.npz, poses1024.htfx = `ref_harness posesfull`): the checker the device is held
+    """The same on the 1024 DISTINCT frames bench.py times (bench_data/frames1024.npz, poses1024.htfx = `ref_harness posesfull`): the checker the device is held
     to on every frame of the headline number reproduces the reference on every one of them, bit for bit."""
     import os
-    d = np.load(os.path.join(ol.GOLDEN, "frames1024.npz"))
+    d = np.load(os.path.join(ol.ROOT, "bench_data", "frames1024.npz"))
     ref = htfx.load(os.path.join(ol.GOLDEN, "poses1024.htfx"))
     n = len(d["depth"])
     assert n == 1024 and ref["uw_pose_user"].shape[0] == n
@@ -303,7 +303,7 @@ def test_unit_of_work_always_take_cnn(weights):
     """The application's always_take_cnn switch (synthetic-tracker.cpp:91; handtrack.h:720-722): the restatement against `ref_harness poses ... takecnn` on every fourth of
     the 1024 bench frames (tests/golden/poses1024_takecnn.htfx): user poses, othermodel and flags bit for bit.  Every frame takes the accept branch here."""
     import os
-    d = np.load(os.path.join(ol.GOLDEN, "frames1024.npz"))
+    d = np.load(os.path.join(ol.ROOT, "bench_data", "frames1024.npz"))
     ref = htfx.load(os.path.join(ol.GOLDEN, "poses1024_takecnn.htfx"))
     plain = htfx.load(os.path.join(ol.GOLDEN, "poses1024.htfx"))
     assert not np.array_equal(ref["uw_pose_user"], plain["uw_pose_user"])      # the switch matters
@@ -326,7 +326,7 @@ def test_the_rounding_mode_of_the_exact_order_comparison_moves_frames_at_roundin
     ConstrainConeAngle) rounded once from double, as the device forms them -- NOT the pinned mode (glibc's float functions, as the reference calls them).  How many frames the
     two modes differ on, and by how much: every eighth of the 1024 bench frames."""
     import os
-    d = np.load(os.path.join(ol.GOLDEN, "frames1024.npz"))
+    d = np.load(os.path.join(ol.ROOT, "bench_data", "frames1024.npz"))
     ref = htfx.load(os.path.join(ol.GOLDEN, "poses1024.htfx"))
     orc = ol.Oracle(weights)
     orc.head.par.microforce = 3.0; orc.head.par.mainthreadpasses = 3

@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as ol, parity_rule as pr
 from hand_tracking_samples_amd import native, weights as W
 F = [int(a) for a in sys.argv[1:]] or [6, 130, 217, 939, 212]
-d = np.load(os.path.join(ROOT, "tests", "golden", "frames1024.npz"))
+d = np.load(os.path.join(ROOT, "bench_data", "frames1024.npz"))
 depth, cams, start = d["depth"][F].reshape(len(F), -1), d["cam"][F], d["startpose"][F]
 w = W.make_cnnb()
 n = len(F)

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import htfx, oracle_lib as ol
 from hand_tracking_samples_amd import native, weights as W
-FR = np.load(os.path.join(ROOT, "tests/golden/frames1024.npz")); REF = htfx.load(os.path.join(ROOT, "tests/golden/poses1024.htfx")); SP = np.load(os.path.join(ROOT, "tests/golden/ref_spread1024.npz"))
+FR = np.load(os.path.join(ROOT, "bench_data/frames1024.npz")); REF = htfx.load(os.path.join(ROOT, "tests/golden/poses1024.htfx")); SP = np.load(os.path.join(ROOT, "tests/golden/ref_spread1024.npz"))
 N = 1024
 ctx = native.Context(ol.MODEL, N); ctx.load_weights(W.make_cnnb()); ctx.set_params(microforce=3.0, mainthreadpasses=3)
 ctx.tracker_reset(FR["startpose"]); got = ctx.update_sync(FR["depth"].reshape(N, -1), FR["cam"]); other = ctx.get_state(1, N)[:, :, :7]

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from hand_tracking_samples_amd import native, weights as W
 B = int(os.environ.get("FRAMES", "1024"))
 dev = torch.device("cuda", 0)
-z = np.load(os.path.join(ROOT, "tests", "golden", "frames1024.npz"))
+z = np.load(os.path.join(ROOT, "bench_data", "frames1024.npz"))
 idx = np.arange(B) % 1024
 depth, cams, start = z["depth"].reshape(-1, 4096)[idx].astype(np.uint16), z["cam"][idx].astype(np.float32), z["startpose"][idx].astype(np.float32)
 ctx = native.Context(os.path.join(ROOT, "hand_tracking_samples_amd", "assets", "model_hand17.htfx"), B)

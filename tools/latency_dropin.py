@@ -10,7 +10,7 @@ lib = os.path.dirname(native.lib_path())
 with tempfile.TemporaryDirectory() as td:
     exe = os.path.join(td, "driver")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cxx_headless_driver.cpp"), "-o", exe, "-L" + lib, "-lht_mi355x", "-Wl,-rpath," + lib])
-    z = np.load(os.path.join(ROOT, "tests", "golden", "frames1024.npz")); n = 32
+    z = np.load(os.path.join(ROOT, "bench_data", "frames1024.npz")); n = 32
     with open(os.path.join(td, "in.bin"), "wb") as f:
         f.write(struct.pack("<4i", n, 64, 64, 17))
         for k in range(n):

@@ -99,6 +99,7 @@ import sys, numpy as np
 sys.path.insert(0, "tests")
 import htfx
 T, G, write = sys.argv[1], sys.argv[2], sys.argv[3] == "1"
+BD = "bench_data"      # the bench's input frames (bench.py, the batch tests) live beside the tests' goldens, not among them
 bad = 0
 def same(name, new, old):
     global bad
@@ -108,20 +109,20 @@ def same(name, new, old):
 f = htfx.load(T + "/frames256.htfx"); f256 = {k: f[k] for k in ("depth", "cam", "startpose", "gtpose", "rows")}
 same("frames256.npz", f256, dict(np.load(G + "/frames256.npz")))
 f = htfx.load(T + "/frames1024.htfx"); f1024 = {k: f[k] for k in ("depth", "cam", "startpose", "gtpose", "rows")}      # gtpose: the rendered row's own pose (labels of tools/train_synthetic.py)
-same("frames1024.npz", f1024, dict(np.load(G + "/frames1024.npz")))
+same("frames1024.npz", f1024, dict(np.load(BD + "/frames1024.npz")))
 g = htfx.load(T + "/frames5.htfx"); f5 = {k: g[k] for k in ("depth", "cam", "startpose", "rows")}
 same("frames5_64.npz", f5, dict(np.load(G + "/frames5_64.npz")))
 g = htfx.load(T + "/frames5_256.htfx"); f5b = {k: g[k] for k in ("depth", "cam", "startpose", "rows")}
-same("frames5_256.npz", f5b, dict(np.load(G + "/frames5_256.npz")))
+same("frames5_256.npz", f5b, dict(np.load(BD + "/frames5_256.npz")))
 s = htfx.load(T + "/seg.htfx"); seg = {k.replace("/", "__"): v for k, v in s.items()}
 same("segment6.npz", seg, dict(np.load(G + "/segment6.npz")))
 v = htfx.load(T + "/viz1.htfx"); viz = {k: (a.astype(np.uint8) if k.endswith("_labels") else a) for k, a in v.items()}      # the label images travel as 16-bit words in the container
 same("viz1.npz", viz, dict(np.load(G + "/viz1.npz")))
 if write:
     np.savez_compressed(G + "/frames256.npz", **f256)
-    np.savez_compressed(G + "/frames1024.npz", **f1024)
+    np.savez_compressed(BD + "/frames1024.npz", **f1024)
     np.savez_compressed(G + "/frames5_64.npz", **f5)
-    np.savez_compressed(G + "/frames5_256.npz", **f5b)
+    np.savez_compressed(BD + "/frames5_256.npz", **f5b)
     np.savez_compressed(G + "/segment6.npz", **seg)
     np.savez_compressed(G + "/viz1.npz", **viz)
 sys.exit(1 if bad else 0)

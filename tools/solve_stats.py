@@ -11,10 +11,10 @@ from hand_tracking_samples_amd import native, weights  # noqa: E402
 
 B = int(os.environ.get("FRAMES", "1024"))
 CFG5 = os.environ.get("CONFIG5") == "1"      # BASELINE configs[4]: 128x128 frames, 26-bone hand, full-frame update
-d = np.load(os.path.join(ROOT, "tests", "golden", "frames5_256.npz" if CFG5 else "frames1024.npz"))
+d = np.load(os.path.join(ROOT, "bench_data", "frames5_256.npz" if CFG5 else "frames1024.npz"))
 idx = np.arange(B) % len(d["depth"])
 depth, cams, start = d["depth"][idx], d["cam"][idx], d["startpose"][idx]
-ctx = native.Context(os.path.join(ROOT, "tests", "golden", "model_hand26.htfx" if CFG5 else "model_hand17.htfx"), B)
+ctx = native.Context(os.path.join(ROOT, "hand_tracking_samples_amd", "assets", "model_hand26.htfx" if CFG5 else "model_hand17.htfx"), B)
 ctx.load_weights(weights.make_cnnb())
 ctx.set_params(microforce=3.0, mainthreadpasses=int(os.environ.get('PASSES', '3')))
 ctx.debug_solve_stats(B, reset=True); ctx.debug_contact_stats(B, reset=True)

@@ -11,7 +11,7 @@ kw = {}
 for a in sys.argv[1:]:
     k, v = a.split("=")
     kw[k] = float(v) if "." in v or "e" in v else int(v)
-d = np.load(os.path.join(ROOT, "tests", "golden", "frames1024.npz"))      # the bench's 1024 distinct frames
+d = np.load(os.path.join(ROOT, "bench_data", "frames1024.npz"))      # the bench's 1024 distinct frames
 idx = np.arange(B) % len(d["depth"])
 depth, cams, start = d["depth"][idx].reshape(B, -1), d["cam"][idx], d["startpose"][idx]
 dev = torch.device("cuda:0")

@@ -1,6 +1,6 @@
 """Trains the hand-pose net with the repo's own training step (ht_cnn_train = CNN::Train, cnn.h:558-580) the way train-hand-pose-cnn does (train-cnn.cpp:156-162: one sample
 per step, lr 0.001, labels from GatherHandExpectedCNN of the frame's ground-truth pose, handtrack.h:160-173) on the bench's software-rendered 64x64 tiles
-(tests/golden/frames1024.npz: animation-bank rows 3 + 9 i with their ground-truth poses), from seeded Xavier weights with FC2 gain 1 (the reference's own init range,
+(bench_data/frames1024.npz: animation-bank rows 3 + 9 i with their ground-truth poses), from seeded Xavier weights with FC2 gain 1 (the reference's own init range,
 cnn.h:282,448).  The trained handposedd.cnnb is not shipped with the reference: this is how the repo makes a net whose heat-maps have REAL peaks.
 
     python tools/train_synthetic.py [--epochs 300] [--curve profiles/r06_train_curve.json] [--out weights.cnnb]
@@ -23,7 +23,7 @@ HOLD = 16      # every HOLD-th frame is held out
 
 
 def dataset():
-    d = np.load(os.path.join(ROOT, "tests", "golden", "frames1024.npz"))
+    d = np.load(os.path.join(ROOT, "bench_data", "frames1024.npz"))
     n = len(d["gtpose"])
     return d["depth"][:n].reshape(n, -1), d["cam"][:n], d["gtpose"]
 
@@ -83,7 +83,7 @@ if __name__ == "__main__":
     print("held-out mse %.3e -> %.3e (x %.1f); train mse first epoch %.3e, last %.3e; mean landmark peak of the held-out heat-maps %.3f (uniform: 0.004); %d steps in %.0f s"
           % (r["held_out_mse_before"], c[-1]["held_out_mse"], r["held_out_mse_before"] / c[-1]["held_out_mse"], c[0]["train_mse"], c[-1]["train_mse"], float(peak.mean()), c[-1]["steps"], r["seconds"]))
     if a.curve:
-        json.dump({"what": "tools/train_synthetic.py: batch-1 SGD (ht_cnn_train), lr 0.001, seeded Xavier init (gain 1), %d train / %d held-out tiles of tests/golden/frames1024.npz" % (r["train_frames"], len(r["test_frames"])),
+        json.dump({"what": "tools/train_synthetic.py: batch-1 SGD (ht_cnn_train), lr 0.001, seeded Xavier init (gain 1), %d train / %d held-out tiles of bench_data/frames1024.npz" % (r["train_frames"], len(r["test_frames"])),
                    "held_out_mse_before": r["held_out_mse_before"], "curve": c, "seconds": r["seconds"]}, open(a.curve, "w"), indent=1)
     if a.out:
         W.save_cnnb(a.out, r["weights"])
