@@ -50,6 +50,7 @@ def parse_args(argv=None):
     ap.add_argument("--frames-per-gpu", type=int, default=1024)
     ap.add_argument("--workload", default="cnn+solver", choices=["cnn+solver", "cnn", "config5", "config5-cnn128", "config5-e2e"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-two-in-flight", action="store_true", help="skip the extra leg that times two batches in flight on two contexts")
     ap.add_argument("--no-host-io", action="store_true", help="skip the extra leg that times the same steps with pinned host buffers in and out")
     ap.add_argument("--always-take-cnn", action="store_true", help="cnn+solver workload with the application's always_take_cnn switch (synthetic-tracker.cpp:91): every frame accepts the CNN-driven pose; verified against tests/golden/poses1024_takecnn.htfx")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the pose gather even with one rank")
@@ -588,6 +589,33 @@ def main():
                    "what": "pinned host depth + cameras in, poses out to pinned host memory; upload of step k + 1 and download of step k - 1 on a copy stream beside step k (double buffers, the host one step ahead); "
                            "resident_same_loop = the same loop and pacing without the transfers"}
 
+    # ---- the same step with TWO batches in flight: a second context on its own streams takes every other batch, so that one batch's kernels fill the gaps the other's
+    #      leave (at 1024 frames every kernel of the step is latency-bound and the dominant ones take whole CUs: DESIGN.md section 15).  What a deployment with a queue of
+    #      INDEPENDENT batches gets out of the GPU; never `value`: the headline stays one 1024-frame batch at a time ----
+    two = None
+    if rank == 0 and wl == "cnn+solver" and args.steps > 0 and not args.no_two_in_flight and not use_dist:
+        ctx2 = native.Context(os.path.join(ROOT, "hand_tracking_samples_amd", "assets", "model_hand17.htfx"), B, device=local)
+        ctx2.load_weights(W.make_cnnb(seed, gain))
+        ctx2.set_params(microforce=3.0, mainthreadpasses=3, **({"always_take_cnn": 1} if args.always_take_cnn else {}))
+        s2 = torch.cuda.Stream(device=dev)
+        out2 = [torch.empty((B, ctx.nb, 7), dtype=torch.float32, device=dev) for _ in range(2)]
+        ctx.profile_enable(0)
+
+        def pairs(n):
+            for _ in range(n):
+                ctx.update_dev(d_depth.data_ptr(), d_cams.data_ptr(), d_start.data_ptr(), B, out2[0].data_ptr(), stream.cuda_stream)
+                ctx2.update_dev(d_depth.data_ptr(), d_cams.data_ptr(), d_start.data_ptr(), B, out2[1].data_ptr(), s2.cuda_stream)
+            torch.cuda.synchronize()
+
+        pairs(max(2, args.warmup))
+        t0p = time.perf_counter()
+        pairs(args.steps)
+        ep = time.perf_counter() - t0p
+        two = {"value": round(2 * B * args.steps / ep, 2), "unit": "frames/s", "ms_per_pair_of_batches": round(ep / args.steps * 1e3, 4), "batches_in_flight": 2, "frames_per_batch": B,
+               "poses_equal_single_batch_run": bool(torch.equal(out2[0], d_poses) and torch.equal(out2[1], d_poses)),
+               "what": "two contexts, two streams, the same %d-frame batch on each, enqueued alternately: throughput of independent batches when one batch's kernels may run in the gaps of the other's" % B}
+        ctx2.close()
+
     # phase table from a second, untimed pass with every phase bracketed (this serialises the side streams)
     ctx.profile_enable(2)
     nphase = max(2, min(5, args.steps))
@@ -689,6 +717,8 @@ def main():
             out["roofline_cnn"] = cnn_roof
         if host_io:
             out["host_io"] = host_io
+        if two:
+            out["two_batches_in_flight"] = two
         if world == 1 and not args.no_cpu_baseline:
             if cnn128:
                 out["cpu_baseline"] = cpu_baseline_cnn128(x128, w128)

@@ -88,6 +88,7 @@ struct ht_prof_scope
 // to a multiple of 8 when a body beyond the 16th rides on its quad (7 per such body at most), and the tail that takes what does not fit k_solve's LDS
 static inline size_t ht_scratch_rows(size_t pts_cap, size_t nb) { return pts_cap + 5 * nb + 32 + 7 * 16 + HT_SCRATCH_TAIL; }
 int ht_alloc_buffers(ht_ctx *ctx);
+int ht_alloc_solve_tables(ht_ctx *ctx);      // d_tables, d_chplanes, d_chon (first use of the solve-tables path)
 int ht_reserve_points_locked(ht_ctx *ctx, int points);      // grows the per-point arrays (ht_api.hip); waits for the context's streams
 // *_dev entry points: a NULL stream means the context's own stream (never the legacy default stream); the choice is remembered so that the
 // host-read helpers (ht_capacity_events, ht_frames_overflow, ht_get_tracker_flags, ...) can wait for work enqueued on a caller's stream

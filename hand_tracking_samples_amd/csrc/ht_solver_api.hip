@@ -986,7 +986,9 @@ extern "C" int ht_debug_contact_kernel(ht_ctx *ctx, int which)
 }
 extern "C" int ht_debug_solve_tables(ht_ctx *ctx, int on)
 {
-	if (!ctx) return HT_ERR_ARG;
+	if (!ctx || !ctx->ready) return HT_ERR_ARG;
+	ht_device_guard dev_guard_(ctx->device);
+	if (on) { const int r = ht_alloc_solve_tables(ctx); if (r) return r; }
 	ctx->solve_tables = on ? 1 : 0;
 	return HT_OK;
 }
