@@ -548,6 +548,30 @@ extern "C" int ht_capacity_events(ht_ctx *ctx, int *epa_cut_short, int *contacts
 	if (angular_rows_over) *angular_rows_over = v[2];
 	return HT_OK;
 }
+// What the contact kernel's per-frame pool can be asked to hold AT MOST, from the model alone: FindShapeShapeContacts (physics.h:451-462) visits every pair of colliding bodies
+// that do not ignore each other, and ContactPatch (gjk.h:607-643) returns one sample for a pair -- five only when neither body is smaller than the 0.05 m of its proximity test
+// (the kernel's exact shortcut: DESIGN.md section 4).  samples_bound <= pool and patches_bound <= patch_slots is a PROOF that no touching sample can be dropped for this model
+// (the stock hand: 91 pairs, none of them between two large bodies that do not ignore each other: 91 <= 192, 0 <= 40); otherwise the pool is a counted capacity
+// (ht_capacity_events).  Follows ht_scale (the diameters grow with the model).
+extern "C" int ht_contact_capacity(ht_ctx *ctx, int *samples_bound, int *patches_bound, int *pool, int *patch_slots)
+{
+	CHECK_READY(ctx); CHECK_MODEL(ctx);
+	const int nb = ctx->model.nb;
+	int pairs = 0, big = 0;
+	for (int i = 0; i < nb; i++) for (int j = i + 1; j < nb; j++)
+	{
+		if (!(ctx->model.collide[i] & ctx->model.collide[j] & 2)) continue;
+		if (ctx->model.ignore[i] & (1u << j)) continue;
+		pairs++;
+		const float di = ctx->h_bodyc[(size_t)i * HT_BC + HT_BC_DIAM], dj = ctx->h_bodyc[(size_t)j * HT_BC + HT_BC_DIAM];
+		if (!((di < dj ? di : dj) < 0.049f)) big++;
+	}
+	if (samples_bound) *samples_bound = pairs + 4 * big;
+	if (patches_bound) *patches_bound = big;
+	if (pool) *pool = HT_MAXCONTACT;
+	if (patch_slots) *patch_slots = 40;      // GJK_JMAX (csrc/ht_gjk.hip)
+	return HT_OK;
+}
 extern "C" int ht_frames_overflow(ht_ctx *ctx, int *frames_over)
 {
 	CHECK_READY(ctx);

@@ -22,7 +22,7 @@ SYMBOLS = (
     "ht_model_open", "ht_model_close", "ht_model_error", "ht_model_counts", "ht_model_body", "ht_model_body_mesh", "ht_model_body_sdmesh", "ht_model_hitcheck",
     "ht_tracker_reset", "ht_get_state", "ht_set_state", "ht_get_tracker_flags", "ht_set_tracker_flags", "ht_update_sync", "ht_update_dev", "ht_update_frames_sync", "ht_update_frames_dev", "ht_update_direct_sync", "ht_update_direct_dev", "ht_update_cnn_model_sync", "ht_get_cnn_results", "ht_get_cnn_layers", "ht_frames_overflow", "ht_reserve_points", "ht_point_capacity", "ht_capacity_events", "ht_segment_vr", "ht_segment_vr_dev", "ht_slowfit", "ht_set_points", "ht_fit_rows", "ht_physics_update",
     "ht_stage_prepare", "ht_stage_decode", "ht_stage_fit_error", "ht_stage_cloud_rows", "ht_stage_contacts", "ht_stage_fit",
-    "ht_stage_multistep", "ht_stage_multistep_range", "ht_stage_scratch_unibody", "ht_stage_chamber", "ht_profile_enable", "ht_profile_read", "ht_debug_solve_stats", "ht_debug_contact_stats", "ht_debug_solver_build", "ht_debug_reset_flags", "ht_debug_reset_organisation", "ht_update_passes_sync", "ht_job_start", "ht_job_poll", "ht_job_wait", "ht_job_collect", "ht_debug_contact_kernel", "ht_debug_solve_tables", "ht_debug_solve_tables_header",
+    "ht_stage_multistep", "ht_stage_multistep_range", "ht_stage_scratch_unibody", "ht_stage_chamber", "ht_profile_enable", "ht_profile_read", "ht_debug_solve_stats", "ht_debug_contact_stats", "ht_debug_solver_build", "ht_debug_reset_flags", "ht_debug_reset_organisation", "ht_update_passes_sync", "ht_job_start", "ht_job_poll", "ht_job_wait", "ht_job_collect", "ht_debug_contact_kernel", "ht_contact_capacity", "ht_debug_solve_tables", "ht_debug_solve_tables_header",
     "ht_comm_available", "ht_comm_unique_id", "ht_comm_init", "ht_comm_info", "ht_gather_poses_dev", "ht_gather_wait", "ht_gather_wait_host", "ht_comm_destroy",
 )
 
@@ -116,6 +116,7 @@ def load(build_if_missing=True):
     L.ht_debug_reset_flags.argtypes = [vp, ip, C.c_int]
     L.ht_debug_contact_kernel.argtypes = [vp, C.c_int]
     L.ht_debug_solve_tables.argtypes = [vp, C.c_int]
+    L.ht_contact_capacity.argtypes = [vp, ip, ip, ip, ip]
     L.ht_debug_solve_tables_header.argtypes = [vp, C.c_int, ip]
     L.ht_comm_unique_id.argtypes = [vp]
     L.ht_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
@@ -475,6 +476,12 @@ class Context:
     def debug_contact_kernel(self, which):
         """Test aid: pin the contact kernel's organisation (0 auto, 1 cooperative, 2 lane-per-pair).  Same contacts either way."""
         self._chk(self.L.ht_debug_contact_kernel(self.h, int(which)))
+
+    def contact_capacity(self):
+        """(samples_bound, patches_bound, pool, patch_slots): the most touching samples / five-sample patches a frame of this model can produce, and what the contact kernel holds"""
+        v = [C.c_int() for _ in range(4)]
+        self._chk(self.L.ht_contact_capacity(self.h, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
 
     def debug_solve_tables(self, on):
         """Test aid: 0 = k_solve makes every solve's tables in its own prologue (as until round 5), 1 = k_solve_prep makes them beside the contact kernel.  Same results."""

@@ -197,6 +197,10 @@ int ht_get_cnn_layers(ht_ctx *ctx, int first, int n, float *act1, float *act2, f
  *                     solved -- 192 contacts per frame and launch since round 5, it was 96); solves in which a model's angular rows exceeded what the solver keeps.
  *                     All are 0 unless a scene or a model is out of the ordinary. */
 int ht_capacity_events(ht_ctx *ctx, int *epa_cut_short, int *contacts_dropped, int *angular_rows_over);
+/* The most touching samples / five-sample patches a frame of THIS model can produce (every colliding, non-ignoring pair once; five samples where neither body is smaller than
+ * ContactPatch's 0.05 m proximity test, gjk.h:637) beside what the contact kernel's per-frame pool holds: samples_bound <= pool and patches_bound <= patch_slots proves that the
+ * kernel keeps every contact the reference's unbounded list (physics.h:451-462) would hold -- true for the stock 17-bone hand (91 <= 192, 0 <= 40). */
+int ht_contact_capacity(ht_ctx *ctx, int *samples_bound, int *patches_bound, int *pool, int *patch_slots);
 
 /* ---- training ----------------------------------------------------------------------------------------------------------
  * ht_cnn_train        replaces  float CNN::Train(const std::vector<float> &x, const std::vector<float> &t, float alpha) (cnn.h:558-580) called for

@@ -462,3 +462,22 @@ def test_models_with_many_ranged_joints(weights, tmp_path):
     dp = np.abs(one[0][:, :, :3] - one[5][:, :, :3]).max(); dq = np.abs(one[0][:, :, 3:7] - one[5][:, :, 3:7]).max()
     print("27-body chain, one step over 169 angular rows: the product's sweeps against the exact-order ones |dpos| %.1e m |dquat| %.1e" % (dp, dq))
     assert dp <= TIGHT_POS_TOL and dq <= TIGHT_QUAT_TOL
+
+
+def test_contact_pool_cannot_overflow_for_the_stock_hand():
+    """physics.h:451-462 keeps every contact in a std::vector; the contact kernel keeps the touching samples of a frame in a pool of 192 (40 five-sample patches).  For the stock
+    17-bone hand that is provably enough: 91 pairs of bodies collide without ignoring each other, and none of them joins two bodies both large enough for ContactPatch's four extra
+    samples (gjk.h:625-641 against the 0.05 m proximity test) -- at most 91 samples, no patch.  configs[4]'s 26-bone hand has 244 such pairs: there the pool is a counted capacity."""
+    from hand_tracking_samples_amd import native
+    ctx = native.Context(ol.MODEL, 1)
+    try:
+        samples, patches, pool, slots = ctx.contact_capacity()
+        assert (samples, patches) == (91, 0) and samples <= pool == 192 and patches <= slots
+    finally:
+        ctx.close()
+    ctx = native.Context(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_hand26.htfx"), 1)
+    try:
+        samples, patches, pool, slots = ctx.contact_capacity()
+        assert samples == 244 and patches == 0 and samples > pool
+    finally:
+        ctx.close()
