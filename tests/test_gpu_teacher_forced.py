@@ -96,3 +96,57 @@ def test_every_solve_single_step_from_the_restatements_state(weights, traced, bu
     if out and not build:
         open(out, "w").write("\n".join(report) + "\n")
     assert not failed, failed
+
+
+def test_every_solve_single_step_on_configs4_frames():
+    """The same on BASELINE configs[4] end to end: the 256 distinct 128x128 frames of the 26-bone hand (cloned fingers in permanent contact, ~15 polytope runs per frame) -- the
+    workload whose free-running poses are held by distribution only (tests/test_config5_e2e.py), because a tenth of its frames amplify a rounding difference in every build.
+    Taken alone from the restatement's state, every solve of every frame has to land within the same single-step bound as on the 17-bone hand."""
+    from hand_tracking_samples_amd import native, weights as W
+    model = os.path.join(HERE, "golden", "model_hand26.htfx")
+    d = np.load(os.path.join(os.path.dirname(HERE), "bench_data", "frames5_256.npz"))
+    n = len(d["depth"]); nb = 26
+    w128 = W.make_cnnb128()
+    orc = ol.Oracle(None, model=model)
+    assert orc.L.ho_set_direct(orc.h, 128, ol.fptr(w128), w128.size) == 0
+    orc.head.par.microforce = 3.0; orc.head.par.mainthreadpasses = PASSES
+    trace = np.zeros((n, STEPS + 1 + PASSES + 1, nb, 13), np.float32); analysis = np.zeros((n, 84), np.float32); user = np.zeros((nb, 7), np.float32)
+    clouds = []
+    try:
+        for i in range(n):
+            orc.reset(d["startpose"][i]); orc.L.ho_set_trace(orc.h, ol.fptr(trace[i]))
+            cam = ol.camera(d["cam"][i], 128, 128)
+            dep = np.ascontiguousarray(d["depth"][i])
+            orc.L.ho_update(orc.h, ol.u16ptr(dep), C.byref(cam), ol.fptr(user))
+            orc.L.ho_get_analysis(orc.h, ol.fptr(analysis[i]))
+            pts = np.zeros((128 * 128, 3), np.float32); nfull = C.c_int(0)
+            k = orc.L.ho_pointcloud(ol.u16ptr(dep), C.byref(cam), 0.1, 0.7, 4, ol.f3ptr(pts), 128 * 128, C.byref(nfull))      # handtrack.h:703,753: every 4th in-range pixel
+            clouds.append(pts[:k].copy())
+        orc.L.ho_set_trace(orc.h, None)
+    finally:
+        orc.close()
+    assert np.isfinite(trace).all()
+    ctx = native.Context(model, n)
+    failed = []
+    try:
+        ctx.set_params(microforce=3.0, mainthreadpasses=PASSES)
+        ctx.stage_decode(np.zeros((n, 2304), np.float32), d["cam"])      # uploads the frames' cameras (the pose-driven stages read them); the analysis below is the restatement's
+        ctx.set_points(clouds)
+        solves = [("MultiStepSim step %d" % s, 1, s, s + 1) for s in range(STEPS)] + [("main-thread pass %d" % i, 0, STEPS + 1 + i, STEPS + 2 + i) for i in range(PASSES)]
+        for name, which, before, after in solves:
+            ctx.set_state(which, trace[:, before])
+            if which == 1:
+                ctx.stage_multistep_range(analysis, n, before, before + 1)
+            else:
+                ctx.stage_fit(n)
+            got = ctx.get_state(which, n)
+            assert np.isfinite(got).all(), name
+            dp, dq = pr.pose_diff(got[:, :, :7], trace[:, after, :, :7])
+            print("configs[4] %-22s |dpos| p50 %.1e max %.2e m (frame %d), |dquat| p50 %.1e max %.2e (frame %d); frames inside 1e-6 m / 2e-5: %d of %d"
+                  % (name, np.median(dp), dp.max(), int(dp.argmax()), np.median(dq), dq.max(), int(dq.argmax()), int(((dp <= SINGLE_STEP[0]) & (dq <= SINGLE_STEP[1])).sum()), n))
+            if not ((dp <= SINGLE_STEP[0]) & (dq <= SINGLE_STEP[1])).all():
+                failed.append(name)
+        assert ctx.capacity_events() == (0, 0, 0)
+    finally:
+        ctx.close()
+    assert not failed, failed
