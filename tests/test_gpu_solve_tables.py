@@ -71,3 +71,31 @@ def test_stage_calls_are_the_same_bits(golden, weights):
         finally:
             ctx.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+def test_configs4_end_to_end_is_the_same_bits():
+    """the 26-bone hand (25 joints: three linear blocks of joint rows, ~120 angular rows, more than sixteen bodies' chains) on 128x128 frames end to end, tables on == off"""
+    from hand_tracking_samples_amd import native, weights as W
+    fr = np.load(os.path.join(os.path.dirname(HERE), "bench_data", "frames5_256.npz"))
+    n = 128
+    res = []
+    for tables in (1, 0):
+        ctx = native.Context(os.path.join(HERE, "golden", "model_hand26.htfx"), n)
+        try:
+            ctx.load_weights128(W.make_cnnb128())
+            ctx.set_params(microforce=3.0, mainthreadpasses=3)
+            ctx.debug_solve_tables(tables)
+            ctx.tracker_reset(fr["startpose"][:n])
+            out = []
+            for _ in range(2):
+                poses, _ = ctx.update_direct_sync(fr["depth"][:n], fr["cam"][:n], 128, want_cnn=True)
+                out += [poses, ctx.get_state(0, n), ctx.get_state(1, n)]
+            if tables:
+                hd = ctx.debug_solve_tables_header(n)
+                print("configs[4]: tables usable on %d of %d frames in the update's last solve (angular rows %d .. %d)" % (int((hd[:, 0] != 0).sum()), n, hd[:, 1].min(), hd[:, 1].max()))
+            assert ctx.capacity_events() == (0, 0, 0)
+            res.append(out)
+        finally:
+            ctx.close()
+    for k, (x, y) in enumerate(zip(*res)):
+        assert np.array_equal(x, y), "output %d differs (largest move %.3e)" % (k, float(np.abs(x.astype(np.float64) - y).max()))
