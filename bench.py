@@ -50,6 +50,7 @@ def parse_args(argv=None):
     ap.add_argument("--frames-per-gpu", type=int, default=1024)
     ap.add_argument("--workload", default="cnn+solver", choices=["cnn+solver", "cnn", "config5", "config5-cnn128", "config5-e2e"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--solve-tables", type=int, default=-1, help="measurement aid: ht_debug_solve_tables(mode) on the timed context (0 k_solve's own prologue, 1 every table from k_solve_prep, 2 the pose-only tables); default: the library's choice")
     ap.add_argument("--no-two-in-flight", action="store_true", help="skip the extra leg that times two batches in flight on two contexts")
     ap.add_argument("--no-host-io", action="store_true", help="skip the extra leg that times the same steps with pinned host buffers in and out")
     ap.add_argument("--always-take-cnn", action="store_true", help="cnn+solver workload with the application's always_take_cnn switch (synthetic-tracker.cpp:91): every frame accepts the CNN-driven pose; verified against tests/golden/poses1024_takecnn.htfx")
@@ -432,6 +433,8 @@ def main():
     if not e2e:
         ctx.load_weights(W.make_cnnb(seed, gain))
     ctx.set_params(microforce=3.0, mainthreadpasses=3, **({"always_take_cnn": 1} if args.always_take_cnn else {}))        # synthetic-tracker.cpp:91-93
+    if args.solve_tables >= 0:
+        ctx.debug_solve_tables(args.solve_tables)
     d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
     d_cams = torch.from_numpy(cams).to(dev)
     d_start = torch.from_numpy(start).to(dev)

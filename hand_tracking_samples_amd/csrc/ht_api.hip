@@ -661,7 +661,7 @@ int ht_alloc_buffers(ht_ctx *ctx)
 	}
 	A(d_nrows, B);
 	A(d_chamber, B * 5 * nb * HT_ROW); A(d_nchamber, B); A(d_accepted, B);
-	if (ht_tuning_env("HT_TABLES")) { if ((r = ht_alloc_solve_tables(ctx))) return r; }      // measurement builds (tools/exp_tables.sh); otherwise on ht_debug_solve_tables(ctx, 1)
+	if (ht_tuning_int("HT_TABLES", 0) > 0) { if ((r = ht_alloc_solve_tables(ctx))) return r; }      // measurement builds (tools/exp_tables.sh); otherwise on ht_debug_solve_tables(ctx, 1)
 	A(d_contacts, B * HT_MAXCONTACT * HT_CONTACT); A(d_ncontacts, B); A(d_epa_ws, ht_contacts_workspace_bytes((int)B)); HIPCHK(ctx, hipMemset(ctx->d_epa_ws, 0, ht_contacts_workspace_bytes((int)B)));
 	ctx->cstride = (int)B + 8; A(d_cwork, (size_t)HT_CONTACT_SLOTS * ctx->cstride); A(d_corder, (size_t)HT_CONTACT_SLOTS * ctx->cstride); A(d_porder, B); A(d_swork, (size_t)HT_CONTACT_SLOTS * ctx->cstride); A(d_sorder, (size_t)HT_CONTACT_SLOTS * ctx->cstride);
 	if ((r = ht_reserve_points_locked(ctx, HT_MAXPTS))) return r;

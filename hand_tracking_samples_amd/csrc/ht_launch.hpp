@@ -45,6 +45,7 @@ struct prep_args
 	const float *ch_planes; const int *ch_on;                   // boundary planes [B][5][4] of the frames whose ch_on is set (k_chamber_planes); null: a solve without them
 	float *rows_pre; int *n_pre; float ch_maxforce;             // their rows in the reference's layout [B][5 * nb][HT_ROW] and count, for a frame that falls back to k_solve's own prologue
 	int apply_angles; float drive_force; int ray_rows; int arm_cone; int steps_keyangles; float min_cray_prob;
+	int parts;                                                  // which tables this launch makes: 1 the pose-only ones (joints' groups, angular records, the blocks' couplings and edges: waves 0 and 1), 2 the chain tables (waves 2 and 3: lists, dealing, four-row couplings, landmark rays, boundary-plane rows)
 	float *tables;                                              // [B][TB_WORDS]
 	int dbg;
 };

@@ -533,8 +533,10 @@ __global__ __launch_bounds__(PREP_THREADS) void k_solve_prep(ht_model_dev M, ht_
 	int npre = 0, ncl = 0, n1 = 0, nlist = 0, c4_total = 0;
 	bool idx_lds = false;
 
-	if (role == 0) prep_angular(M, ph, a, S, T, b, lane, ok, na);
-	else if (role == 1) prep_joints(M, ph, S, T, lane);
+	const bool pose = (a.parts & 1) != 0, chains = (a.parts & 2) != 0;
+	if (role == 0) { if (pose) prep_angular(M, ph, a, S, T, b, lane, ok, na); else ok = 0; }
+	else if (role == 1) { if (pose) prep_joints(M, ph, S, T, lane); }
+	else if (!chains) {}
 	else if (role == 3)
 	{
 		if (a.n_pre && lane == 0) a.n_pre[b] = chamber ? 5 * nb : 0;
@@ -647,9 +649,9 @@ __global__ __launch_bounds__(PREP_THREADS) void k_solve_prep(ht_model_dev M, ht_
 	if (role == 0)
 	{
 		int *H = reinterpret_cast<int *>(T + TB_HDR);
-		if (lane == 0) { H[TH_OK] = ok; H[TH_NA] = na; }
+		if (lane == 0) { H[TH_OK] = ok; H[TH_NA] = na; H[TH_CHAIN_OK] = chains ? 1 : 0; }
 	}
-	if (role != 2) return;
+	if (role != 2 || !chains) return;
 	// ---- wave 2, second half: the couplings of every block of four rows with the rows before them (k_solve's prologue: a quad per block, lane c takes slot c of the block's
 	//      four records; -G(j,i) = -(c_j . d_i), the three lanes' shares summed (p0 + p1) + p2 on lane 2, which writes the rows' entries) ----
 	{
@@ -688,5 +690,5 @@ __global__ __launch_bounds__(PREP_THREADS) void k_solve_prep(ht_model_dev M, ht_
 }
 void ht_launch_solve_prep(const ht_model_dev &M, const ht_physics_dev &ph, const prep_args &a, int B, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_solve_prep, dim3(B), dim3(PREP_THREADS), 0, s, M, ph, a);
+	hipLaunchKernelGGL(k_solve_prep, dim3(B), dim3((a.parts & 2) ? PREP_THREADS : 128), 0, s, M, ph, a);      // the pose-only tables take waves 0 and 1
 }

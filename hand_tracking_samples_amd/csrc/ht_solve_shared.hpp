@@ -208,7 +208,8 @@ __device__ __forceinline__ int angular_range_count(v3 lmin, v3 lmax)
 #define TB_EML (TB_GL + 2048)                // edge words of linear block Q as they are while the frame has no contact
 static_assert(TB_EML + 256 == TB_WORDS, "ht_launch.hpp states the size of a frame's tables");
 // header words
-#define TH_OK 0            // 1: the tables hold the frame (0: a frame the blocked form does not hold -- k_solve runs its own prologue)
+#define TH_OK 0            // 1: the pose-only tables (joints' groups, angular records, block couplings and edges) hold the frame (0: a frame the blocked form does not hold, or not made -- k_solve runs its own prologue)
+#define TH_CHAIN_OK 16     // 1: the chain tables (lists, dealing, four-row couplings, the landmark rays' and boundary planes' records) were made too
 #define TH_NA 1            // angular rows
 #define TH_NPRE 2          // single-body rows ahead of the cloud rows (landmark rays / boundary planes)
 #define TH_TOTAL 3         // blocks of four single-body rows over all four DPP rows

@@ -146,9 +146,9 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	const float dt = ph.deltaT;
 	// ---- round 6: the solve's tables come ready from k_solve_prep (ht_solve_shared.hpp, csrc/ht_prep.hip) -- the joints' groups, the angular records, the blocks' couplings
 	//      and edges, the chain lists and their blocks' couplings -- unless the frame is one the blocked form does not hold (then everything below runs as it always did).
-	//      `fast` is the same on every lane.  What is left of the prologue for such a frame: the bodies, the contacts' groups and their couplings.
+	//      The flags are the same on every lane.  What is left of the prologue for such a frame: the bodies, the contacts' groups and their couplings.
 	const float *const T = a.tables ? a.tables + (size_t)b * TB_WORDS : nullptr;
-	bool fast = false;
+	bool fast_pose = false, fast_chain = false;      // the pose-only tables (joints' groups, angular records, the blocks' couplings and edges) / the chain tables (lists, dealing, four-row couplings, landmark rays): k_solve_prep may have made either
 	int t_na = 0, t_npre = 0, t_total = 0, t_e0 = 0, t_nblk = 0, t_head = 0;
 	if constexpr (!EXACT)
 	{
@@ -161,8 +161,10 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 			t_e0 = R == 0 ? __builtin_amdgcn_readlane(h, TH_E0) : R == 1 ? __builtin_amdgcn_readlane(h, TH_E0 + 1) : R == 2 ? __builtin_amdgcn_readlane(h, TH_E0 + 2) : __builtin_amdgcn_readlane(h, TH_E0 + 3);
 			t_nblk = R == 0 ? __builtin_amdgcn_readlane(h, TH_NBLK) : R == 1 ? __builtin_amdgcn_readlane(h, TH_NBLK + 1) : R == 2 ? __builtin_amdgcn_readlane(h, TH_NBLK + 2) : __builtin_amdgcn_readlane(h, TH_NBLK + 3);
 			t_head = R == 0 ? __builtin_amdgcn_readlane(h, TH_HEAD) : R == 1 ? __builtin_amdgcn_readlane(h, TH_HEAD + 1) : R == 2 ? __builtin_amdgcn_readlane(h, TH_HEAD + 2) : __builtin_amdgcn_readlane(h, TH_HEAD + 3);
-			fast = __builtin_amdgcn_readlane(h, TH_OK) != 0 && 3 * nj + 3 * (nc0 > HT_MAXCONTACT ? HT_MAXCONTACT : nc0) <= 4 * BLK_LROWS && !HT_DBG(a.dbg, 65536) && !HT_DBG(a.dbg, 1 << 22);
-			fast = __builtin_amdgcn_readfirstlane((int)fast) != 0;
+			fast_pose = __builtin_amdgcn_readlane(h, TH_OK) != 0 && 3 * nj + 3 * (nc0 > HT_MAXCONTACT ? HT_MAXCONTACT : nc0) <= 4 * BLK_LROWS && !HT_DBG(a.dbg, 65536) && !HT_DBG(a.dbg, 1 << 22);
+			fast_pose = __builtin_amdgcn_readfirstlane((int)fast_pose) != 0;
+			fast_chain = fast_pose && __builtin_amdgcn_readlane(h, TH_CHAIN_OK) != 0;
+			fast_chain = __builtin_amdgcn_readfirstlane((int)fast_chain) != 0;
 		}
 	}
 
@@ -183,12 +185,12 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 		m3 I = world_inertia(V4(s[3], s[4], s[5], s[6]), LM(bc + HT_BC_TINV), bc[HT_BC_MASSINV]);
 		S.I4[lane][0] = make_float4(I.x.x, I.x.y, I.x.z, 0.0f); S.I4[lane][1] = make_float4(I.y.x, I.y.y, I.y.z, 0.0f); S.I4[lane][2] = make_float4(I.z.x, I.z.y, I.z.z, 0.0f);
 	}
-	if (lane < nj && !fast) for (int i = 0; i < 6; i++) S.jr[lane][i] = M.jointc[lane * HT_JC + HT_JC_RMIN + i];
-	if (lane == 0) S.nray = fast && a.ray_rows ? t_npre : 0;
+	if (lane < nj && !fast_pose) for (int i = 0; i < 6; i++) S.jr[lane][i] = M.jointc[lane * HT_JC + HT_JC_RMIN + i];
+	if (lane == 0) S.nray = fast_chain && a.ray_rows ? t_npre : 0;
 	__syncthreads();
 
 	// ---- HandModelEnhancements (handtrack.h:417-420, 434-440); acos()/cos() are the C double overloads there ----
-	if (nb >= 17 && !a.no_model_rows && !fast)
+	if (nb >= 17 && !a.no_model_rows && !fast_pose)
 	{
 		if (lane < 4)
 		{
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 		}
 	}
 	// ---- landmark-ray rows of MultiStepSim (handtrack.h:666-676): 2 dead-zone pairs per open finger ----
-	if (fast) {}
+	if (fast_chain) {}
 	else if (a.ray_rows && a.sf_ncray + (a.sf_select >= 0) > 0 && lane == 8)
 	{
 		// slowfit (handtrack.h:803-810): dead-zone pairs along the two axes perpendicular to each landmark ray, rays from the origin, then the nail
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	// row counts per joint (lane j = joint j), their prefixes over the joints by a scalar walk through the lanes' registers, and the owner table of the range rows
 	int na_pre, na;
 	const int na_fix = na_user + (a.apply_angles ? 12 : 0) + (a.arm_cone ? 1 : 0);      // [caller's rows | ApplyAngles, arm cone | relative rows | joint ranges]
-	if (fast) { na_pre = na_fix; na = t_na; }
+	if (fast_pose) { na_pre = na_fix; na = t_na; }
 	else
 	{
 		const int acnt = (lane < nj && !a.no_model_rows) ? angular_range_count(L3(S.jr[lane]), L3(S.jr[lane] + 3)) : 0;
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 		const int r = lane + 64 * s;
 		arow &R = AR[s];
 		R.rb0 = -1; R.rb1 = -1; R.axis = V3(0, 0, 1); R.targetspin = -FLT_MAX; R.mn = 0; R.mx = 0; R.s2t = 0; R.torque = 0; R.mintorque = 0; R.lev = 0;
-		if (r < na && !fast)
+		if (r < na && !fast_pose)
 		{
 			float row[8];
 			if (r < na_user)
@@ -405,12 +407,12 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 		__threadfence_block();
 		__syncthreads();
 	}
-	if (fast)      // the joints' groups as k_solve_prep made them (the same statements as the loop below, csrc/ht_prep.hip)
+	if (fast_pose)      // the joints' groups as k_solve_prep made them (the same statements as the loop below, csrc/ht_prep.hip)
 	{
 		const float4 *src = reinterpret_cast<const float4 *>(T + TB_POOL);
 		for (int i = lane; i < njg * (LGRP / 4); i += 64) reinterpret_cast<float4 *>(pool)[i] = src[i];
 	}
-	for (int r = (fast ? 3 * njg : 0) + lane; r < n2; r += 64)
+	for (int r = (fast_pose ? 3 * njg : 0) + lane; r < n2; r += 64)
 	{
 		int rb0, rb1, meta = 0, g, kk;
 		v3 p0, p1, n; float targetdist, tsnb, fmn, fmx;
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 		for (int s = 0; s < ASLOTS; s++) sw = sw || (lane + 64 * s < na && AR[s].targetspin == -FLT_MAX && AR[s].mintorque < 0);
 		blocked = !a.two_body_levels && ngt == 0 && n2 <= 4 * BLK_LROWS && na <= 128 && __ballot(sw) == 0ull;
 		blocked = __builtin_amdgcn_readfirstlane((int)blocked) != 0;
-		if (fast) blocked = true;      // k_solve_prep looked at the angular rows (no row RemoveBias switches on, no more than the builds keep), the row count was checked at the top
+		if (fast_pose) blocked = true;      // k_solve_prep looked at the angular rows (no row RemoveBias switches on, no more than the builds keep), the row count was checked at the top
 	}
 	int nga = 0;
 	if (!blocked)
@@ -591,10 +593,10 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	float *const gG = a.scratch + (size_t)a.batch * a.scratch_stride * (CREC + 2) + (size_t)b * a.scratch_stride * 4;      // and, behind those, the couplings of its rows' blocks of four when the build's LDS has no room for them (QUAD_G_BLOCK floats per block; the region has 16 B per chain entry)
 	if (sums_lds) { for (int i = lane; i < nlist; i += 64) S.csum[i] = 0.0f; }
 	else for (int i = lane; i < nlist && i < a.scratch_stride; i += 64) gsum[i] = 0.0f;
-	if (fast) { if (idx_lds) for (int i = lane; i < nlist; i += 64) S.cidx[i] = (unsigned short)gidx[i]; }      // the lists as k_solve_prep placed them (in HBM for the builds that walk them there)
+	if (fast_chain) { if (idx_lds) for (int i = lane; i < nlist; i += 64) S.cidx[i] = (unsigned short)gidx[i]; }      // the lists as k_solve_prep placed them (in HBM for the builds that walk them there)
 	else if (idx_lds) { for (int i = lane; i < nlist; i += 64) S.cidx[i] = (unsigned short)noop_idx; }
 	else for (int i = lane; i < nlist && i < a.scratch_stride; i += 64) gidx[i] = (unsigned)noop_idx;
-	if (lane == 0 && !fast) quad_write_noop(scr + (size_t)noop_idx * CREC);
+	if (lane == 0 && !fast_chain) quad_write_noop(scr + (size_t)noop_idx * CREC);
 	auto pre_ptr = [&](int i) -> const float * { return a.ray_rows ? S.ray[i] : a.rows_pre + ((size_t)b * a.pre_stride + i) * HT_ROW; };
 	auto body_of = [&](int i) -> int {
 		if (i < npre) return (int)pre_ptr(i)[1];
@@ -603,7 +605,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	};
 	__syncthreads();
 	int mycnt = 0;                                     // lane bb counts the rows of body bb
-	if (!fast)
+	if (!fast_chain)
 	for (int base = 0; base < n1; base += 64)          // pass A: rows per body
 	{
 		const int i = base + lane;
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	const bool chain4 = !EXACT && !HT_DBG(a.dbg, 65536);      // HT_DEBUG_SKIP += 65536 (-DHT_TUNING): the row-by-row walk, for an A/B
 	int c4_e0 = 0, c4_nblk = 0, c4_head = 0, c4_start = 0, c4_next = -1, c4_total = 0;
 	int myblk = (lane < nb && !HT_DBG(a.dbg, 1)) ? (mycnt + 3) >> 2 : 0;
-	if (fast)
+	if (fast_chain)
 	{
 		c4_e0 = t_e0; c4_nblk = t_nblk; c4_head = t_head; c4_total = t_total;
 		if (lane < HT_MAXNB) { myblk = reinterpret_cast<const int *>(T + TB_CCNT)[lane]; c4_next = reinterpret_cast<const int *>(T + TB_CNEXT)[lane]; }
@@ -664,7 +666,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	// does not host yet, its entries follow the host's in the list, and the host's entries are padded to a multiple of 8 with the record that changes nothing
 	// (zero direction, zero limits: impulse 0), so that the quad changes body at a block boundary of the chain walk (quad_chain_run).
 	int myextra = -1, myhost = -1;
-	if (!fast)
+	if (!fast_chain)
 	{
 		int avail = (lane < 16 && lane < nb) ? mycnt : 0x7fffff;
 		for (int e = 16; e < nb; e++)
@@ -691,7 +693,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	if (chain4) { mystart = c4_start; if (lane < HT_MAXNB) { S.ccnt[lane] = myblk; S.cstart[lane] = mystart; S.cextra[lane] = (signed char)c4_next; } }      // ccnt: blocks, cextra: the next body of the DPP row
 	else if (lane < HT_MAXNB) { S.ccnt[lane] = HT_DBG(a.dbg, 1) ? 0 : mycnt; S.cstart[lane] = mystart; S.cextra[lane] = (signed char)(HT_DBG(a.dbg, 1) ? -1 : myextra); }
 	int myrun = 0;
-	if (!fast)
+	if (!fast_chain)
 	for (int base = 0; base < n1; base += 64)          // pass B: placement in stable order; records of the rows that have none yet
 	{
 		const int i = base + lane;
@@ -734,14 +736,14 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	for (int s = 0; s < ASLOTS; s++)
 	{
 		const arow &R = AR[s];
-		const bool on = lane + 64 * s < na && !fast;
+		const bool on = lane + 64 * s < na && !fast_pose;
 		ABA0[s] = (on && R.rb0 >= 0) ? -mul(body_I(S, R.rb0), R.axis) : V3(0, 0, 0);
 		ABA1[s] = (on && R.rb1 >= 0) ? mul(body_I(S, R.rb1), R.axis) : V3(0, 0, 0);
 	}
 	__threadfence_block();      // the records and lists are read back by other lanes of this wave
 	__syncthreads();
 	const bool g_lds = idx_lds && S.NCG > 0 && QUAD_G_BLOCK * (c4_total + 4) <= S.NCG;      // the couplings in LDS (the walk reads four blocks ahead); only beside LDS chain lists: one instance of the walk less
-	if (fast)
+	if (fast_chain)
 	{
 		if (g_lds) { for (int i = lane; i < QUAD_G_BLOCK * c4_total; i += 64) S.cg[i] = gG[i]; __threadfence_block(); __syncthreads(); }      // k_solve_prep left them in the frame's HBM slot
 	}
@@ -902,7 +904,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	// ---- the prologue scratch is dead now: angular rows move from their builder lanes into their records ----
 	const bool arec_lds = na <= S.NANG;
 	float *const arec = arec_lds ? S.arec : garec;
-	if (fast)      // the records, the idle record and the slack as k_solve_prep wrote them (the prologue scratch they share LDS with is dead: the contacts' groups are made)
+	if (fast_pose)      // the records, the idle record and the slack as k_solve_prep wrote them (the prologue scratch they share LDS with is dead: the contacts' groups are made)
 	{
 		const float4 *src = reinterpret_cast<const float4 *>(T + TB_AREC);
 		for (int i = lane; i < (na + 4) * (AROW / 4); i += 64) reinterpret_cast<float4 *>(arec)[i] = src[i];
@@ -938,7 +940,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 			S.blk.abody[r] = (unsigned short)(r < na ? ((AR[s].rb0 >= 0 ? AR[s].rb0 : 255) | ((AR[s].rb1 >= 0 ? AR[s].rb1 : 255) << 8)) : 0xFFFF);
 		}
 	}
-	}      // !fast
+	}      // !fast_pose
 	__threadfence_block();
 	__syncthreads();
 
@@ -997,7 +999,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 				}
 			}
 		};
-		if (fast)      // the angular blocks' couplings, and the linear blocks' couplings among the joints' rows, as k_solve_prep left them (register 4k + c of lane l at (k * 64 + l) * 4 + c)
+		if (fast_pose)      // the angular blocks' couplings, and the linear blocks' couplings among the joints' rows, as k_solve_prep left them (register 4k + c of lane l at (k * 64 + l) * 4 + c)
 		{
 #pragma unroll
 			for (int k = 0; k < 8; k++)
@@ -1060,7 +1062,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 		// half-wave's block and the upper's in lockstep, so it runs when either holds a contact row; a joint row's lane then forms the values it already has once more.
 		const int njr = 3 * njg;      // the joints' rows lead the list
 		auto has_contacts = [&](int Q) -> bool { return n2 > njr && BLK_LROWS * Q < n2 && BLK_LROWS * (Q + 1) > njr; };
-		const bool fwd = !fast || has_contacts(0) || has_contacts(2), bwd = !fast || has_contacts(1) || has_contacts(3);
+		const bool fwd = !fast_pose || has_contacts(0) || has_contacts(2), bwd = !fast_pose || has_contacts(1) || has_contacts(3);
 		if (pool_lds) { if (nbl > 0 && fwd) lin_couplings(S.pool, false); if (nbl > 1 && bwd) lin_couplings(S.pool, true); }
 		else { if (nbl > 0 && fwd) lin_couplings(gpool, false); if (nbl > 1 && bwd) lin_couplings(gpool, true); }
 		if (HT_DBG(a.dbg, 2048)) t_c1 = clock64();
@@ -1121,14 +1123,14 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 		};
 		// a block without a contact row has the edges k_solve_prep sorted for it; the angular blocks all have
 		auto tab_edges = [&](int off, int Q) -> unsigned { return reinterpret_cast<const unsigned *>(T + off)[Q * 64 + lane]; };
-		if (nbl > 0) emL0 = fast && !has_contacts(0) ? tab_edges(TB_EML, 0) : lin_edges(0);
-		if (nbl > 1) emL1 = fast && !has_contacts(1) ? tab_edges(TB_EML, 1) : lin_edges(1);
-		if (nbl > 2) emL2 = fast && !has_contacts(2) ? tab_edges(TB_EML, 2) : lin_edges(2);
-		if (nbl > 3) emL3 = fast && !has_contacts(3) ? tab_edges(TB_EML, 3) : lin_edges(3);
-		if (nba > 0) emA0 = fast ? tab_edges(TB_EMA, 0) : ang_edges(0);
-		if (nba > 1) emA1 = fast ? tab_edges(TB_EMA, 1) : ang_edges(1);
-		if (nba > 2) emA2 = fast ? tab_edges(TB_EMA, 2) : ang_edges(2);
-		if (nba > 3) emA3 = fast ? tab_edges(TB_EMA, 3) : ang_edges(3);
+		if (nbl > 0) emL0 = fast_pose && !has_contacts(0) ? tab_edges(TB_EML, 0) : lin_edges(0);
+		if (nbl > 1) emL1 = fast_pose && !has_contacts(1) ? tab_edges(TB_EML, 1) : lin_edges(1);
+		if (nbl > 2) emL2 = fast_pose && !has_contacts(2) ? tab_edges(TB_EML, 2) : lin_edges(2);
+		if (nbl > 3) emL3 = fast_pose && !has_contacts(3) ? tab_edges(TB_EML, 3) : lin_edges(3);
+		if (nba > 0) emA0 = fast_pose ? tab_edges(TB_EMA, 0) : ang_edges(0);
+		if (nba > 1) emA1 = fast_pose ? tab_edges(TB_EMA, 1) : ang_edges(1);
+		if (nba > 2) emA2 = fast_pose ? tab_edges(TB_EMA, 2) : ang_edges(2);
+		if (nba > 3) emA3 = fast_pose ? tab_edges(TB_EMA, 3) : ang_edges(3);
 		__syncthreads();
 		if (HT_DBG(a.dbg, 2048)) t_c2 = clock64();
 	}

@@ -67,12 +67,15 @@ static void solve_step(ht_ctx *ctx, int which, const float *rows_pre, const int 
 // Round 6: the tables of a solve (ht_solve_shared.hpp) are made by k_solve_prep on whichever stream runs the solve's row producers, behind the cloud rows (it lists them per
 // body) and beside the contact kernel; the solve_step that follows is told to start from them.  Off for the exact-order builds (their sweeps take the rows as the reference
 // lays them out) and under ht_debug_solve_tables(0).
-static bool solve_tables_on(const ht_ctx *ctx)
+// 0: off; 1: every table (pose-only and chain tables: one launch behind the cloud rows); 2: the pose-only tables alone, on the side stream the cloud rows do not use
+static int solve_tables_mode(const ht_ctx *ctx)
 {
-	static const bool on = ht_tuning_env("HT_TABLES");      // timing experiments (-DHT_TUNING builds only): tools/exp_tables.sh
-	return (ctx->solve_tables || on) && ctx->d_tables && !exact_solver(ctx);
+	static const int env = ht_tuning_int("HT_TABLES", -1);      // timing experiments (-DHT_TUNING builds only): tools/exp_tables.sh
+	const int m = env >= 0 ? env : ctx->solve_tables;
+	return (m && ctx->d_tables && !exact_solver(ctx)) ? m : 0;
 }
-static void solve_prep(ht_ctx *ctx, int which, bool cloud, bool chamber, const int *active, int apply_angles, float drive_force, int ray_rows, int arm_cone, int B, hipStream_t s)
+static bool solve_tables_on(const ht_ctx *ctx) { return solve_tables_mode(ctx) == 1; }
+static void solve_prep(ht_ctx *ctx, int which, bool cloud, bool chamber, const int *active, int apply_angles, float drive_force, int ray_rows, int arm_cone, int B, hipStream_t s, int parts = 3)
 {
 	prep_args a;
 	memset(&a, 0, sizeof a);
@@ -82,7 +85,7 @@ static void solve_prep(ht_ctx *ctx, int which, bool cloud, bool chamber, const i
 	if (chamber) { a.ch_planes = ctx->d_chplanes; a.ch_on = ctx->d_chon; a.rows_pre = ctx->d_chamber; a.n_pre = ctx->d_nchamber; a.ch_maxforce = 10.0f; }
 	a.apply_angles = apply_angles; a.drive_force = drive_force; a.ray_rows = ray_rows; a.arm_cone = arm_cone;
 	a.steps_keyangles = ctx->par.steps_keyangles; a.min_cray_prob = ctx->par.min_cray_prob;
-	a.tables = ctx->d_tables; a.dbg = ht_tuning_flags();
+	a.tables = ctx->d_tables; a.dbg = ht_tuning_flags(); a.parts = parts;
 	ht_launch_solve_prep(ctx->model, ctx->phys, a, B, s);
 }
 // Fork/join helpers: the row-producing kernels of one fit step only read the pose, so they run side by side on two extra streams
@@ -161,17 +164,19 @@ static void multistep(ht_ctx *ctx, int B, hipStream_t s, int from_step = 0, int 
 		const bool cloud = (st >= p.steps_cloudstart) && !p.angles_only;
 		const bool coll = ctx->phys.use_collision != 0;
 		static const bool no_side = ht_tuning_env("HT_NO_SIDE");      // timing experiments (-DHT_TUNING builds only)
-		const bool tables = solve_tables_on(ctx);
+		const bool pose_only = solve_tables_mode(ctx) == 2 && side >= 0 && coll && !ctx->profile_phases && !no_side && part == 0 && !active;      // the pose-only tables: on the OTHER side stream, beside the cloud rows
+		const bool tables = solve_tables_on(ctx) || pose_only;
 		// beside the contact kernel: the step's cloud rows, and (round 6) the solve's tables behind them -- a step without cloud rows forks for the tables alone
 		const bool par = side >= 0 && (cloud || tables) && coll && !ctx->profile_phases && !no_side;
 		if (part != 2)
 		{
-			if (par) fork1(ctx, s, side);
+			if (par && pose_only) fork(ctx, s); else if (par) fork1(ctx, s, side);
 			const cloud_records cr = cloud_rec(ctx);
 			if (cloud) { ht_prof_scope ps(ctx, prof ? "cloud_rows" : nullptr, s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[1], ctx->d_pts, ctx->d_npts, ctx->d_cams, active, 4, 1, 2, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[side] : s, 0.0f, 0.0f, rec_or_rows(ctx, &cr)); }
-			if (tables) { ht_prof_scope ps(ctx, prof ? "solve_prep" : nullptr, s, true); solve_prep(ctx, 1, cloud, false, active, angles, st < p.steps_palmangle ? 10000.0f : 0.0f, rays, 1, B, par ? ctx->side[side] : s); }
+			if (pose_only) solve_prep(ctx, 1, false, false, active, angles, st < p.steps_palmangle ? 10000.0f : 0.0f, rays, 1, B, ctx->side[1 - side], 1);
+			else if (tables) { ht_prof_scope ps(ctx, prof ? "solve_prep" : nullptr, s, true); solve_prep(ctx, 1, cloud, false, active, angles, st < p.steps_palmangle ? 10000.0f : 0.0f, rays, 1, B, par ? ctx->side[side] : s); }
 			if (coll && !(first_contacts_done && st == from_step)) { ht_prof_scope ps(ctx, prof ? "contacts" : nullptr, s, true); const contact_slot ch = contact_history(ctx, st < 8 ? st : -1, active, B); ht_launch_contacts(ctx->model, ctx->d_state[1], ctx->phys.driftmax, ctx->phys.jiggle_sin, active, ctx->d_epa_ws, ctx->d_contacts, ctx->d_ncontacts, B, s, false, ctx->contact_kernel, active && active == ctx->d_flags && !ctx->many_reset, ch.order, ch.work); }
-			if (par) join1(ctx, s, side);
+			if (par && pose_only) join(ctx, s, 2); else if (par) join1(ctx, s, side);
 			if (part == 0 && !active) mark("  step: rows done", s);
 		}
 		if (part == 1) continue;
@@ -188,11 +193,13 @@ static void main_pass(ht_ctx *ctx, int B, hipStream_t s, float *poses_out = null
 	const bool coll = ctx->phys.use_collision != 0;
 	static const bool no_side = ht_tuning_env("HT_NO_SIDE");
 	const bool par = !ctx->profile_phases && !no_side;
+	const bool pose_only = solve_tables_mode(ctx) == 2 && par;
 	const bool tables = solve_tables_on(ctx);
 	// Round 6: the five boundary planes follow from the points alone, so an update makes them once (beside the net: run_update) and every pass only their rows, inside
 	// k_solve_prep.  A pass outside an update (ht_stage_fit) makes them here.
 	if (tables && !ctx->planes_valid) { ht_prof_scope ps(ctx, "chamber", s, true); ht_launch_chamber_planes(ctx->model, pts, npts, p.min_point_num, p.boundary_planes, ctx->d_chplanes, ctx->d_chon, B, s); }
 	if (par) { if (tables) fork1(ctx, s, 0); else fork(ctx, s); }
+	if (pose_only) solve_prep(ctx, 0, false, false, nullptr, 0, 0.0f, 0, 0, B, ctx->side[1], 1);      // the pose-only tables ahead of the boundary planes on their side stream: both beside the cloud rows
 	if (!tables) { ht_prof_scope ps(ctx, "chamber", s, true); ht_launch_chamber(ctx->model, ctx->d_state[0], pts, npts, p.min_point_num, p.boundary_planes, 10.0f, ctx->d_chamber, ctx->d_nchamber, B, par ? ctx->side[1] : s); }
 	const cloud_records cr = cloud_rec(ctx);
 	{ ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[0], pts, npts, ctx->d_cams, nullptr, 1, 0, 1, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[0] : s, 0.0f, 0.0f, rec_or_rows(ctx, &cr)); }
@@ -202,7 +209,7 @@ static void main_pass(ht_ctx *ctx, int B, hipStream_t s, float *poses_out = null
 	if (par) { mark("  pass: cloud rows done", ctx->side[0]); if (!tables) mark("  pass: chamber done", ctx->side[1]); }
 	if (par) join(ctx, s, tables ? 1 : 2);
 	ht_prof_scope ps(ctx, "solve", s);
-	solve_step(ctx, 0, ctx->d_chamber, ctx->d_nchamber, true, coll, nullptr, 0, 0.0f, 0, 0, 0, B, s, false, poses_out, npts, pass >= 0 && pass < 8 ? 8 + pass : -1, tables);
+	solve_step(ctx, 0, ctx->d_chamber, ctx->d_nchamber, true, coll, nullptr, 0, 0.0f, 0, 0, 0, B, s, false, poses_out, npts, pass >= 0 && pass < 8 ? 8 + pass : -1, tables || pose_only);
 }
 // Behind the join of the side stream, so nothing of the step waits for it: the running counts of reset frames go to the host (ht_host.hpp: d_nreset).  The
 // update's stream picks the copy up again at its very end (reset_tail_join: long finished by then) -- every stream of an update has to come back to the
@@ -1012,8 +1019,9 @@ extern "C" int ht_debug_solve_tables(ht_ctx *ctx, int on)
 {
 	if (!ctx || !ctx->ready) return HT_ERR_ARG;
 	ht_device_guard dev_guard_(ctx->device);
+	if (on < 0 || on > 2) return HT_ERR_ARG;
 	if (on) { const int r = ht_alloc_solve_tables(ctx); if (r) return r; }
-	ctx->solve_tables = on ? 1 : 0;
+	ctx->solve_tables = on;
 	return HT_OK;
 }
 extern "C" int ht_debug_solve_tables_header(ht_ctx *ctx, int B, int *hdr)

@@ -351,9 +351,10 @@ int ht_debug_reset_organisation(ht_ctx *ctx, int *many);
  * 2 one lane group per body pair).  Same contacts in the same order either way. */
 int ht_debug_contact_kernel(ht_ctx *ctx, int which);
 /* Test / measurement aid: 0 (default) = every solve makes its tables (joint groups, angular records, block couplings, chain lists) in k_solve's own one-wave prologue;
- * 1 = k_solve_prep makes them on a side stream beside the contact kernel (csrc/ht_prep.hip; round 6's experiment: k_solve 8 % shorter, the step longer -- profiles/r06_notes.md).
+ * 1 = k_solve_prep makes them on a side stream beside the contact kernel (csrc/ht_prep.hip; round 6's experiment: k_solve 8 % shorter, the step longer -- profiles/r06_notes.md);
+ * 2 = only the pose-only tables (joint groups, angular records, block couplings), on the side stream the cloud rows do not use: also measured slower.
  * Where the tables are made, never what they hold: results are identical bit for bit (tests/test_gpu_solve_tables.py). */
-int ht_debug_solve_tables(ht_ctx *ctx, int on);
+int ht_debug_solve_tables(ht_ctx *ctx, int mode);
 int ht_debug_solve_tables_header(ht_ctx *ctx, int B, int *hdr);      /* tuning aid: the 32 header words of every frame's tables as the latest k_solve_prep left them ([B][32]; words 20-27: cycle stamps of a -DHT_TUNING build) */
 
 #ifdef __cplusplus

@@ -37,12 +37,13 @@ def _update(weights, tables, n, take_cnn=0, build=0, voxel=0):
     return out
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("take_cnn,build", [(0, 0), (1, 0), (0, 1), (0, 3), (0, 4), (0, 6)])
-def test_update_is_the_same_bits_with_the_tables_made_beside_the_contacts(weights, take_cnn, build):
+def test_update_is_the_same_bits_with_the_tables_made_beside_the_contacts(weights, take_cnn, build, mode):
     """256 bench frames (chamber on / off at 400 points, reset frames, up to a dozen contacts), every build of k_solve: LDS builds, the build whose arrays all live in HBM (4),
     the build with four angular-row slots (6)"""
     n = 256
-    a, b = _update(weights, 1, n, take_cnn, build), _update(weights, 0, n, take_cnn, build)
+    a, b = _update(weights, mode, n, take_cnn, build), _update(weights, 0, n, take_cnn, build)      # mode 1: every table from k_solve_prep; 2: the pose-only tables alone (the chain lists stay in k_solve)
     for k, (x, y) in enumerate(zip(a, b)):
         differ = np.nonzero((x != y).reshape(n, -1).any(axis=1))[0]
         assert len(differ) == 0, "output %d differs on frames %s (largest move %.3e)" % (k, differ[:8].tolist(), float(np.abs(x.astype(np.float64) - y).max()))
@@ -55,7 +56,7 @@ def test_stage_calls_are_the_same_bits(golden, weights):
     depth = np.stack([golden["f%d/depth" % f].reshape(-1) for f in range(nf)]); cams = np.stack([golden["f%d/cam" % f] for f in range(nf)])
     start = np.stack([golden["f%d/startpose" % f] for f in range(nf)])
     res = []
-    for tables in (1, 0):
+    for tables in (1, 2, 0):
         ctx = native.Context(ol.MODEL, nf)
         try:
             ctx.load_weights(weights)
@@ -70,7 +71,8 @@ def test_stage_calls_are_the_same_bits(golden, weights):
             res.append((s1, ctx.get_state(0, nf)))
         finally:
             ctx.close()
-    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    for r in res[:2]:
+        assert np.array_equal(r[0], res[2][0]) and np.array_equal(r[1], res[2][1])
 
 
 def test_configs4_end_to_end_is_the_same_bits():
@@ -79,7 +81,7 @@ def test_configs4_end_to_end_is_the_same_bits():
     fr = np.load(os.path.join(os.path.dirname(HERE), "bench_data", "frames5_256.npz"))
     n = 128
     res = []
-    for tables in (1, 0):
+    for tables in (1, 2, 0):
         ctx = native.Context(os.path.join(HERE, "golden", "model_hand26.htfx"), n)
         try:
             ctx.load_weights128(W.make_cnnb128())
@@ -90,12 +92,13 @@ def test_configs4_end_to_end_is_the_same_bits():
             for _ in range(2):
                 poses, _ = ctx.update_direct_sync(fr["depth"][:n], fr["cam"][:n], 128, want_cnn=True)
                 out += [poses, ctx.get_state(0, n), ctx.get_state(1, n)]
-            if tables:
+            if tables == 1:
                 hd = ctx.debug_solve_tables_header(n)
                 print("configs[4]: tables usable on %d of %d frames in the update's last solve (angular rows %d .. %d)" % (int((hd[:, 0] != 0).sum()), n, hd[:, 1].min(), hd[:, 1].max()))
             assert ctx.capacity_events() == (0, 0, 0)
             res.append(out)
         finally:
             ctx.close()
-    for k, (x, y) in enumerate(zip(*res)):
-        assert np.array_equal(x, y), "output %d differs (largest move %.3e)" % (k, float(np.abs(x.astype(np.float64) - y).max()))
+    for r in res[:2]:
+        for k, (x, y) in enumerate(zip(r, res[2])):
+            assert np.array_equal(x, y), "output %d differs (largest move %.3e)" % (k, float(np.abs(x.astype(np.float64) - y).max()))
