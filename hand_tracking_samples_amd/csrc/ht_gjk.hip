@@ -9,7 +9,7 @@
 //
 // Two organisations of the same arithmetic (ht_launch_contacts):
 //   k_contacts_coop (every batch size, when a frame of the model fits its LDS): lane-per-run simplex logic in owner waves, support scans worked off cooperatively by all waves of a
-//     block, one scan pair per DPP row, polytope jobs taken by any wave -- described at the kernel below.  Owns the CU (152 KB of LDS, 255 VGPRs).
+//     block, one scan pair per DPP row, polytope jobs taken by any wave -- described at the kernel below.  Owns the CU (156 KB of LDS, 8 waves of 242 VGPRs).
 //   k_contacts (the fall-back for models whose padded vertices leave no room for a frame in the other's LDS; until round 3 also the faster one
 //     above ~1100 frames): a block serves two frames (one wave each) and stages all collision vertices (3042 x float4 = 48 KB, w = vertex
 //     index) in LDS once.  GJK runs on lane groups: a candidate pair is served by 1, 2 or 4 neighbouring lanes (4 when a frame has <= 16
@@ -1311,7 +1311,7 @@ void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftma
 		attr_set[dev] = true;
 	}
 	lk.unlock();
-	// Which organisation: the cooperative kernel (a CU per block: 152 KB of LDS, 249 VGPRs) whenever a frame of the model fits its LDS beside the padded vertex
+	// Which organisation: the cooperative kernel (a CU per block: 156 KB of LDS, 242 VGPRs) whenever a frame of the model fits its LDS beside the padded vertex
 	// copy.  Whole steps on one device, cooperative against lane-per-pair: 1536 frames 7.57 against 7.64 ms, 2048 frames 8.46 / 8.56, 4096 frames 14.74 / 14.96,
 	// 8192 frames 27.00 / 27.57 (tools/exp_coop_max.sh; until the polytope and the frame-to-block assignment were reworked in round 3 the lane-per-pair kernel won
 	// above ~1100 frames because its smaller blocks run beside the cloud-row kernel).  force_kernel (ht_debug_contact_kernel): 1 cooperative, 2 lane-per-pair.
