@@ -166,3 +166,57 @@ def test_exact_order_solver_on_config5_end_to_end_26_bones():
     bad = [i for i in range(n) if not (np.array_equal(others[i], other[0, i]) and np.array_equal(hands[i], hand[0, i]) and np.array_equal(poses[i], user[0, i]))]
     print("config 5 end to end, exact-order solver against the restatement given the device's CNN output: %d of %d frames differ" % (len(bad), n))
     assert not bad, bad
+
+
+def test_exact_order_solver_follows_a_stream_bit_for_bit(weights):
+    """Deep tracker states.  Sixty-four trackers each follow a moving hand for twelve consecutive updates -- tracker i sees bench frame (16 i + k) mod 1024 in update k, i.e.
+    every update brings a NEW frame nine animation rows on (the other tests show a tracker the same frame twice) -- so the carried pose lags the cloud, the accumulated-error
+    take (handtrack.h:712-726), the `initializing` countdown (:727) and the full-reset branch (:706-711) fire in the middle of a stream, on states no fixture starts from.
+    Free-running, no teacher forcing: with the exact-order sweeps the device equals the restatement -- given the device's heat-maps -- bit for bit after EVERY update: user
+    poses, both models' states with momenta, prev_frame_error and `initializing`."""
+    from hand_tracking_samples_amd import native
+    T, K = 64, 12
+    idx = [(16 * np.arange(T) + k) % N for k in range(K)]
+    depth = FR["depth"].reshape(N, -1); start = FR["startpose"][idx[0]]
+    ctx = native.Context(ol.MODEL, T)
+    try:
+        ctx.load_weights(weights)
+        ctx.set_params(microforce=3.0, mainthreadpasses=3)
+        ctx.debug_solver_build(5)
+        ctx.tracker_reset(start)
+        dev = []
+        for k in range(K):
+            p, c = ctx.update_sync(depth[idx[k]], FR["cam"][idx[k]], want_cnn=True)
+            dev.append((p, c, ctx.get_state(1, T), ctx.get_state(0, T), np.stack(ctx.tracker_flags(T), 1).astype(np.float32), ctx.debug_reset_flags(T)))
+        assert ctx.capacity_events() == (0, 0, 0)
+    finally:
+        ctx.debug_solver_build(0)
+        ctx.close()
+    orc = ol.Oracle(weights)
+    orc.head.par.microforce = 3.0; orc.head.par.mainthreadpasses = 3
+    orc.L.ho_set_round_once(1)
+    bad = []; takes = 0
+    try:
+        for i in range(T):
+            orc.reset(start[i])
+            for k in range(K):
+                f = idx[k][i]
+                cam = ol.camera(FR["cam"][f], 64, 64)
+                orc.L.ho_set_cnn_override(orc.h, ol.fptr(np.ascontiguousarray(dev[k][1][i])))
+                user = np.zeros((orc.nb, 7), np.float32)
+                before = orc.get_state(0)
+                orc.L.ho_update(orc.h, ol.u16ptr(np.ascontiguousarray(depth[f])), C.byref(cam), ol.fptr(user))
+                same = (np.array_equal(dev[k][0][i], user) and np.array_equal(dev[k][2][i], orc.get_state(1)) and np.array_equal(dev[k][3][i], orc.get_state(0))
+                        and np.array_equal(dev[k][4][i], np.array(orc.flags()[:2], np.float32)))
+                if not same:
+                    bad.append((i, k)); break      # a tracker that left the restatement's stream stays out: report where it left
+        orc.L.ho_set_cnn_override(orc.h, None)
+    finally:
+        orc.L.ho_set_round_once(0)
+        orc.close()
+    resets = np.stack([d[5] for d in dev])      # [K, T]
+    ini = np.stack([d[4][:, 1] for d in dev])
+    print("stream of %d updates on %d trackers, exact-order solver against the restatement: %d trackers leave it (first at %s); full resets per update %s; trackers with `initializing` > 0 after the last update: %d"
+          % (K, T, len(bad), bad[:4], resets.sum(axis=1).tolist(), int((ini[-1] > 0).sum())))
+    assert not bad, bad
+    assert resets[1:].sum() >= 8      # the full-reset branch fired in mid-stream, on several trackers

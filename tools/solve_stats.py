@@ -40,8 +40,8 @@ for k, nm in zip(range(5, 11), ["steps_lin", "steps_ang", "maxchain", "n1", "n2"
 w = st[:, 4].argmax()
 print("worst frame", w, st[w])
 
-hd = ctx.debug_solve_tables_header(B)
-print("---- k_solve_prep, the update's last launch (a main-thread pass), cycles per frame: angular wave %.0f, joints wave %.0f, chains wave (lists) %.0f, boundary-plane wave %.0f (max %d), all waves to the barrier %.0f, chain couplings %.0f; tables ok on %d of %d frames"
+hd = ctx.debug_solve_tables_header(B) if os.environ.get("HT_TABLES", "0") != "0" else None      # the tables exist only when a run asked for them
+if hd is not None: print("---- k_solve_prep, the update's last launch (a main-thread pass), cycles per frame: angular wave %.0f, joints wave %.0f, chains wave (lists) %.0f, boundary-plane wave %.0f (max %d), all waves to the barrier %.0f, chain couplings %.0f; tables ok on %d of %d frames"
       % (hd[:, 20].mean(), hd[:, 21].mean(), hd[:, 22].mean(), hd[:, 23].mean(), hd[:, 23].max(), hd[:, 24].mean(), hd[:, 25].mean(), int((hd[:, 0] != 0).sum()), B))
 print("---- k_contacts (sum over %s launches per frame)" % np.unique(cs[:, 0]))
 # the fields of k_contacts_coop (wave f of a block reports its own cycles beside frame f's counts); the lane-per-pair kernel (HT_CONTACTS_LANES) fills them differently
