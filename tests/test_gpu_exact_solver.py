@@ -220,3 +220,55 @@ def test_exact_order_solver_follows_a_stream_bit_for_bit(weights):
           % (K, T, len(bad), bad[:4], resets.sum(axis=1).tolist(), int((ini[-1] > 0).sum())))
     assert not bad, bad
     assert resets[1:].sum() >= 8      # the full-reset branch fired in mid-stream, on several trackers
+
+
+def test_exact_order_solver_follows_a_stream_on_config5():
+    """The stream test on BASELINE configs[4] end to end (128x128 frames, the 128x128-input net, 26 bones): sixteen trackers, six updates, tracker i sees frame (16 i + k) mod 256
+    of bench_data/frames5_256.npz in update k.  Exact-order sweeps, free-running: bit for bit after every update."""
+    from hand_tracking_samples_amd import native
+    fr = np.load(os.path.join(ROOT, "bench_data", "frames5_256.npz"))
+    model26 = os.path.join(HERE, "golden", "model_hand26.htfx")
+    w128 = W.make_cnnb128()
+    n5 = len(fr["depth"]); T, K = 16, 6
+    idx = [(16 * np.arange(T) + k) % n5 for k in range(K)]
+    start = fr["startpose"][idx[0]]
+    ctx = native.Context(model26, T)
+    try:
+        ctx.load_weights128(w128)
+        ctx.set_params(microforce=3.0, mainthreadpasses=3)
+        ctx.debug_solver_build(5)
+        ctx.tracker_reset(start)
+        dev = []
+        for k in range(K):
+            p, c = ctx.update_direct_sync(fr["depth"][idx[k]], fr["cam"][idx[k]], 128, want_cnn=True)
+            dev.append((p, c, ctx.get_state(1, T), ctx.get_state(0, T), np.stack(ctx.tracker_flags(T), 1).astype(np.float32), ctx.debug_reset_flags(T)))
+        assert ctx.capacity_events() == (0, 0, 0)
+    finally:
+        ctx.debug_solver_build(0)
+        ctx.close()
+    orc = ol.Oracle(None, model=model26)
+    assert orc.L.ho_set_direct(orc.h, 128, ol.fptr(w128), w128.size) == 0
+    orc.head.par.microforce = 3.0; orc.head.par.mainthreadpasses = 3
+    orc.L.ho_set_round_once(1)
+    bad = []
+    try:
+        for i in range(T):
+            orc.reset(start[i])
+            for k in range(K):
+                f = idx[k][i]
+                cam = ol.camera(fr["cam"][f], 128, 128)
+                orc.L.ho_set_cnn_override(orc.h, ol.fptr(np.ascontiguousarray(dev[k][1][i])))
+                user = np.zeros((orc.nb, 7), np.float32)
+                orc.L.ho_update(orc.h, ol.u16ptr(np.ascontiguousarray(fr["depth"][f]).reshape(-1)), C.byref(cam), ol.fptr(user))
+                same = (np.array_equal(dev[k][0][i], user) and np.array_equal(dev[k][2][i], orc.get_state(1)) and np.array_equal(dev[k][3][i], orc.get_state(0))
+                        and np.array_equal(dev[k][4][i], np.array(orc.flags()[:2], np.float32)))
+                if not same:
+                    bad.append((i, k)); break
+        orc.L.ho_set_cnn_override(orc.h, None)
+    finally:
+        orc.L.ho_set_round_once(0)
+        orc.close()
+    resets = np.stack([d[5] for d in dev])
+    print("configs[4] stream of %d updates on %d trackers, exact-order solver against the restatement: %d trackers leave it (first at %s); full resets per update %s"
+          % (K, T, len(bad), bad[:4], resets.sum(axis=1).tolist()))
+    assert not bad, bad
