@@ -272,3 +272,92 @@ def test_exact_order_solver_follows_a_stream_on_config5():
     print("configs[4] stream of %d updates on %d trackers, exact-order solver against the restatement: %d trackers leave it (first at %s); full resets per update %s"
           % (K, T, len(bad), bad[:4], resets.sum(axis=1).tolist()))
     assert not bad, bad
+
+
+# HandTracker's public knobs (handtrack.h:560-603; config file keys handtrack.h:846-880) and PhysModel's (physmodel.h:229-236), each moved off its default.
+# device name -> (oracle struct: "par" | "phys", oracle field)
+_KNOB = {"physics_iterations": ("phys", "iterations"), "physics_iterations_post": ("phys", "iterations_post"), "physics_use_collision": ("phys", "use_collision"),
+         "physics_weak_force": ("phys", "weak_force"), "bone_sum_error_scale": ("phys", "bone_sum_error_scale"), "unibody_force": ("phys", "unibody_force")}
+_VARIANTS = [
+    ("defaults of the class (microforce 1, one pass)", dict(microforce=1.0, mainthreadpasses=1)),
+    ("angles_only", dict(angles_only=1)),
+    ("no boundary planes", dict(boundary_planes=0)),
+    ("always_take_cnn", dict(always_take_cnn=1)),
+    ("four steps, cloud from step 0", dict(steps=4, steps_keypoints=2, steps_keyangles=1, steps_palmangle=1, steps_cloudstart=0)),
+    ("seven steps, cloud from step 3, one unibody step", dict(steps=7, steps_keypoints=5, steps_keyangles=3, steps_palmangle=1, steps_cloudstart=3, steps_unibody=1)),
+    ("every second point, few points needed", dict(subsample_fraction=2, min_point_num=100)),
+    ("many points needed (initializing stays armed)", dict(min_point_num=2000)),
+    ("accumulated-error threshold, ray probability floor", dict(accum_error_threshold=0.05, min_cray_prob=0.1)),
+    ("weak cloud force", dict(cloudforce_max_point=5.0, cloudforce_max_sum=500.0)),
+    ("eager full reset", dict(full_reset_on_error=0.2)),
+    ("reluctant full reset", dict(full_reset_on_error=5.0)),
+    ("short depth range", dict(drangey=0.55)),
+    ("eight iterations, two post", dict(physics_iterations=8, physics_iterations_post=2)),
+    ("no collisions", dict(physics_use_collision=0)),
+    ("joint-limit force, error scale, unibody force", dict(physics_weak_force=0.2, bone_sum_error_scale=2.0, unibody_force=0.3)),
+    ("voxel subsampling", dict(subsample_voxel=1, subsample_size=0.01, subsample_fraction=1)),
+    ("five passes, strong microforce", dict(mainthreadpasses=5, microforce=6.0)),
+]
+
+
+@pytest.mark.parametrize("name,knobs", _VARIANTS, ids=[v[0].split(",")[0].replace(" ", "_") for v in _VARIANTS])
+def test_exact_order_solver_follows_a_stream_with_every_knob_moved(weights, name, knobs):
+    """Every public parameter of the tracker moved off its default, one group at a time, through a four-update stream on 32 trackers: exact-order sweeps, free-running,
+    against the restatement with the same parameter -- bit for bit after every update.  (The sweeps are the only thing the product build does differently, and a parameter
+    reaches them as data: what this pins is every parameter's way through the host side and the row-building kernels, on states a stream produces.  The product's sweeps
+    under the same parameter are held against the exact-order ones on the stream's first update.)"""
+    from hand_tracking_samples_amd import native
+    T, K = 32, 4
+    idx = [(32 * np.arange(T) + 5 + k) % N for k in range(K)]
+    depth = FR["depth"].reshape(N, -1); start = FR["startpose"][idx[0]]
+    par = dict(microforce=3.0, mainthreadpasses=3); par.update(knobs)
+    ctx = native.Context(ol.MODEL, T)
+    try:
+        ctx.load_weights(weights)
+        ctx.set_params(**par)
+        ctx.debug_solver_build(5)
+        ctx.tracker_reset(start)
+        dev = []
+        for k in range(K):
+            p, c = ctx.update_sync(depth[idx[k]], FR["cam"][idx[k]], want_cnn=True)
+            dev.append((p, c, ctx.get_state(1, T), ctx.get_state(0, T), np.stack(ctx.tracker_flags(T), 1).astype(np.float32), ctx.debug_reset_flags(T)))
+        assert ctx.capacity_events() == (0, 0, 0)
+        # the PRODUCT sweeps under the same parameter: the stream's first update again (one update: little room for amplification).  A parameter the product's sweeps
+        # dropped or misread would move every tracker; rounding moves the median by nothing and single trackers by an amplified last bit.
+        ctx.debug_solver_build(0)
+        ctx.tracker_reset(start)
+        prod = ctx.update_sync(depth[idx[0]], FR["cam"][idx[0]])
+        import parity_rule as pr
+        dp, dq = pr.pose_diff(prod, dev[0][0])
+        tight = int(((dp <= pr.TIGHT[0]) & (dq <= pr.TIGHT[1])).sum())
+        print("%-55s: product sweeps against exact-order sweeps, first update: median %.1e m / %.1e, %d of %d trackers inside 2e-5 m / 2e-4, largest %.1e m / %.1e" % (name, np.median(dp), np.median(dq), tight, T, dp.max(), dq.max()))
+        assert np.isfinite(prod).all() and np.median(dp) <= 2e-6 and np.median(dq) <= 4e-5 and tight >= T - 4 and dp.max() <= pr.CAP_TAKE_CNN[0] and dq.max() <= pr.CAP_TAKE_CNN[1]
+    finally:
+        ctx.debug_solver_build(0)
+        ctx.close()
+    orc = ol.Oracle(weights)
+    for k_, v in par.items():
+        where, field = _KNOB.get(k_, ("par", k_))
+        setattr(orc.head.par if where == "par" else orc.head.phys, field, v)
+    orc.L.ho_set_round_once(1)
+    bad = []
+    try:
+        for i in range(T):
+            orc.reset(start[i])
+            for k in range(K):
+                f = idx[k][i]
+                cam = ol.camera(FR["cam"][f], 64, 64)
+                orc.L.ho_set_cnn_override(orc.h, ol.fptr(np.ascontiguousarray(dev[k][1][i])))
+                user = np.zeros((orc.nb, 7), np.float32)
+                orc.L.ho_update(orc.h, ol.u16ptr(np.ascontiguousarray(depth[f])), C.byref(cam), ol.fptr(user))
+                same = (np.array_equal(dev[k][0][i], user) and np.array_equal(dev[k][2][i], orc.get_state(1)) and np.array_equal(dev[k][3][i], orc.get_state(0))
+                        and np.array_equal(dev[k][4][i], np.array(orc.flags()[:2], np.float32)))
+                if not same:
+                    bad.append((i, k)); break
+        orc.L.ho_set_cnn_override(orc.h, None)
+    finally:
+        orc.L.ho_set_round_once(0)
+        orc.close()
+    resets = np.stack([d[5] for d in dev])
+    print("%-55s: %d of %d trackers leave the restatement's stream (first at %s); full resets per update %s" % (name, len(bad), T, bad[:4], resets.sum(axis=1).tolist()))
+    assert not bad, bad
