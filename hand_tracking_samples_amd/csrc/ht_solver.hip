@@ -620,6 +620,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 			todo &= ~m;
 		}
 	}
+	const long long t_l1 = HT_DBG(a.dbg, 262144) ? clock64() : 0;      // HT_DEBUG_SKIP += 262144 (with 2048): the chain lists' parts in the places of the prologue's first four
 	// CHAIN4: the bodies' chains in blocks of four rows, dealt longest first to the wave's four DPP rows (each body to the row with the fewest blocks so far); a row's
 	// segment of the lists = its bodies' blocks one after the other, a chain padded to whole blocks with the record that changes nothing
 	const bool chain4 = !EXACT && !HT_DBG(a.dbg, 65536);      // HT_DEBUG_SKIP += 65536 (-DHT_TUNING): the row-by-row walk, for an A/B
@@ -693,6 +694,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 	if (chain4) { mystart = c4_start; if (lane < HT_MAXNB) { S.ccnt[lane] = myblk; S.cstart[lane] = mystart; S.cextra[lane] = (signed char)c4_next; } }      // ccnt: blocks, cextra: the next body of the DPP row
 	else if (lane < HT_MAXNB) { S.ccnt[lane] = HT_DBG(a.dbg, 1) ? 0 : mycnt; S.cstart[lane] = mystart; S.cextra[lane] = (signed char)(HT_DBG(a.dbg, 1) ? -1 : myextra); }
 	int myrun = 0;
+	const long long t_l2 = HT_DBG(a.dbg, 262144) ? clock64() : 0;
 	if (!fast_chain)
 	for (int base = 0; base < n1; base += 64)          // pass B: placement in stable order; records of the rows that have none yet
 	{
@@ -730,6 +732,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 			}
 		}
 	}
+	const long long t_l3 = HT_DBG(a.dbg, 262144) ? clock64() : 0;
 	// the last use of the inverse inertias, which share LDS with the angular records: every row's Iinv*axis, while the table is still there
 	v3 ABA0[ASLOTS], ABA1[ASLOTS];
 #pragma unroll
@@ -785,6 +788,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 		__threadfence_block();
 		__syncthreads();
 	}
+	const long long t_l4 = HT_DBG(a.dbg, 262144) ? clock64() : 0;
 	v3 pos_next = V3(0, 0, 0); v4 q_next = V4(0, 0, 0, 1);
 	auto calc_next_pose = [&]() {
 		// rbcalcnextpose physics.h:522-531 with rkupdateq :211-218 (momentum-preserving RK4 on the quaternion)
@@ -1499,6 +1503,7 @@ __global__ __launch_bounds__(64, 2) void k_solve(ht_model_dev M, ht_physics_dev 
 		o[0] += 1.0f; o[1] += (float)cyc_chain; o[2] += (float)cyc_lin; o[3] += (float)cyc_ang; o[4] += (float)(clock64() - t_begin);
 		o[5] += blocked ? (float)(t_c1 - t_c0) : (float)nlev_lin; o[6] += blocked ? (float)(t_c2 - t_c1) : (float)nlev_ang;      /* blocked frames: cycles of the couplings / of the edge words */ o[7] += (float)mc; o[8] += (float)n1; o[9] += (float)n2; o[10] += (float)na; o[11] += (float)(t_begin - t_entry);
 		o[12] += (float)(t_m1 - t_entry); o[13] += (float)(t_m2 - t_m1); o[14] += (float)(t_m2b - t_m2); o[15] += (float)(t_m3 - t_m2b);
+		if (HT_DBG(a.dbg, 262144)) { o[12] += (float)(t_l1 - t_m3) - (float)(t_m1 - t_entry); o[13] += (float)(t_l2 - t_l1) - (float)(t_m2 - t_m1); o[14] += (float)(t_l3 - t_l2) - (float)(t_m2b - t_m2); o[15] += (float)(t_l4 - t_l3) - (float)(t_m3 - t_m2b); }      /* the chain lists' parts: set-up + counting pass | dealing | placement pass + records | Iinv*axis + four-row couplings */
 		if (HT_DBG(a.dbg, 32768)) { o[12] += (float)cyc_bh - (float)(t_m1 - t_entry); o[13] += (float)cyc_br - (float)(t_m2 - t_m1); o[14] += (float)cyc_bg - (float)(t_m2b - t_m2); }      /* HT_DEBUG_SKIP += 32768: the blocked linear phase's head / resolve / gather cycles instead of the first three prologue parts */
 	}
 	}      // !EXACT
