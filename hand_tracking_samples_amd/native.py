@@ -161,7 +161,7 @@ class Context:
     def __init__(self, model_path, max_batch, device=0):
         self.L = load()
         self.h = C.c_void_p()
-        rc = self.L.ht_create(os.fsencode(model_path), int(max_batch), int(device), C.byref(self.h))
+        rc = self.L.ht_create(None if model_path is None else os.fsencode(model_path), int(max_batch), int(device), C.byref(self.h))      # None: a context that serves the net only (ht_mi355x.h)
         if rc != HT_OK:
             msg = self.L.ht_last_error(self.h).decode() if self.h else "ht_create failed"
             if self.h:
