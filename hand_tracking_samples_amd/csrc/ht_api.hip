@@ -628,15 +628,13 @@ extern "C" int ht_point_capacity(ht_ctx *ctx, int *points)
 	*points = ctx->model.pts_cap;
 	return HT_OK;
 }
-// the buffers of the solve tables (k_solve_prep's output, ht_solve_shared.hpp) and of the update's boundary planes: only a context that switches the path on has them
+// the buffer of the solve tables (k_solve_prep's output, ht_solve_shared.hpp): only a context that switches the path on has it
 int ht_alloc_solve_tables(ht_ctx *ctx)
 {
 	if (ctx->d_tables) return HT_OK;
 	const size_t B = (size_t)ctx->B;
 	int r;
 	if ((r = dev_alloc(ctx, &ctx->d_tables, B * TB_WORDS))) return r;
-	if ((r = dev_alloc(ctx, &ctx->d_chplanes, B * 20))) return r;
-	if ((r = dev_alloc(ctx, &ctx->d_chon, B))) return r;
 	return HT_OK;
 }
 int ht_alloc_buffers(ht_ctx *ctx)
@@ -660,7 +658,7 @@ int ht_alloc_buffers(ht_ctx *ctx)
 		if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cu = prop.multiProcessorCount;
 	}
 	A(d_nrows, B);
-	A(d_chamber, B * 5 * nb * HT_ROW); A(d_nchamber, B); A(d_accepted, B);
+	A(d_chamber, B * 5 * nb * HT_ROW); A(d_nchamber, B); A(d_accepted, B); A(d_chplanes, B * 20); A(d_chon, B);
 	if (ht_tuning_int("HT_TABLES", 0) > 0) { if ((r = ht_alloc_solve_tables(ctx))) return r; }      // measurement builds (tools/exp_tables.sh); otherwise on ht_debug_solve_tables(ctx, 1)
 	A(d_contacts, B * HT_MAXCONTACT * HT_CONTACT); A(d_ncontacts, B); A(d_epa_ws, ht_contacts_workspace_bytes((int)B)); HIPCHK(ctx, hipMemset(ctx->d_epa_ws, 0, ht_contacts_workspace_bytes((int)B)));
 	ctx->cstride = (int)B + 8; A(d_cwork, (size_t)HT_CONTACT_SLOTS * ctx->cstride); A(d_corder, (size_t)HT_CONTACT_SLOTS * ctx->cstride); A(d_porder, B); A(d_swork, (size_t)HT_CONTACT_SLOTS * ctx->cstride); A(d_sorder, (size_t)HT_CONTACT_SLOTS * ctx->cstride);

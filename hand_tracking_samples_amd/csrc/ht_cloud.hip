@@ -802,48 +802,60 @@ __global__ __launch_bounds__(256) void k_fit_error(ht_model_dev M, const float *
 }
 
 // ------------------------------------------------------------------------------------------------- k_chamber
-// 5 silhouette planes through the camera origin + one ConstrainUnderPlane row per (plane, body); rows [B][5*nb][HT_ROW], nch[b] = 0 or 5*nb
-__global__ __launch_bounds__(64) void k_chamber(ht_model_dev M, const float *__restrict__ state, const float4 *__restrict__ pts, const int *__restrict__ npts,
-                                                int min_point_num, int enabled, float maxforce, float *__restrict__ rows, int *__restrict__ nch)
+// 5 silhouette planes through the camera origin + one ConstrainUnderPlane row per (plane, body); rows [B][5*nb][HT_ROW], nch[b] = 0 or 5*nb.
+// planes_in / on_in (round 6): the frame's five planes as k_chamber_planes below left them -- they follow from the points alone, so the three main-thread passes of an
+// update (handtrack.h:769-780) share one scan made beside the net; null: the scan is made here (a pass outside an update: ht_stage_chamber, ht_stage_fit).
+// Four waves per frame share the (plane, body) items: the kernel is the items' memory round trips one after the other, 85 items on one wave were 69 us per launch.
+#define CHB_THREADS 256
+__global__ __launch_bounds__(CHB_THREADS) void k_chamber(ht_model_dev M, const float *__restrict__ state, const float4 *__restrict__ pts, const int *__restrict__ npts,
+                                                        int min_point_num, int enabled, float maxforce, float *__restrict__ rows, int *__restrict__ nch,
+                                                        const float *__restrict__ planes_in, const int *__restrict__ on_in)
 {
 	__shared__ float tab[HT_MAXNB * BT];
 	__shared__ float planes[5][4];
 	__shared__ int voff[HT_MAXNB + 1];      // vertex ranges of the bodies (picked per lane below: from LDS, not from the kernel-argument segment)
-	const int b = blockIdx.x, lane = threadIdx.x;
-	const int n = npts[b];
-	const bool on = enabled && n > min_point_num;        // handtrack.h:774
-	if (lane == 0) nch[b] = on ? 5 * M.nb : 0;
-	if (!on) return;
-	body_table_build(M, state + (size_t)b * M.nb * HT_STATE_STRIDE, tab, lane);
-	if (lane <= M.nb) voff[lane] = M.vert_off[lane];
-	// containing_plane (physmodel.h:183-193): a sequential scan of the cloud per direction (the running `best` decides the next comparison).  The five
-	// directions take one lane each; the points reach them through an LDS chunk the whole wave fills with coalesced reads (a lane reading the
-	// points straight from HBM waits a memory round trip per point: 100 us for a 424-point frame).
 	__shared__ float4 chunk[256];
-	const float od[5][3] = { { -1, -0.25f, 0 }, { -1, -1, 0 }, { 0, -1, 0 }, { 1, -1, 0 }, { 1, -0.25f, 0 } };    // handtrack.h:776
-	const int dl = lane < 5 ? lane : 0;
-	const v3 outdir = V3(od[dl][0], od[dl][1], od[dl][2]), origin = V3(0, 0, 0), viewdir = V3(0, 0, 1);
-	v3 best = viewdir - outdir;
-	best = best + origin;
-	const v3 tangent = cross(best, outdir);
-	for (int base = 0; base < n; base += 256)
+	const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const int n = npts[b];
+	const bool on = planes_in ? on_in[b] != 0 : (enabled && n > min_point_num);        // handtrack.h:774
+	if (t == 0) nch[b] = on ? 5 * M.nb : 0;
+	if (!on) return;
+	if (wave == 0) body_table_build(M, state + (size_t)b * M.nb * HT_STATE_STRIDE, tab, lane);
+	if (wave == 1 && lane <= M.nb) voff[lane] = M.vert_off[lane];
+	if (planes_in)
 	{
-		const int m = min(256, n - base);
-		__syncthreads();
-		for (int i = lane; i < m; i += 64) chunk[i] = pts[(size_t)b * M.pts_cap + base + i];
-		__syncthreads();
-		if (lane < 5)
-			for (int i = 0; i < m; i++)
-			{
-				const float4 pv = chunk[i];
-				const v3 p = V3(pv.x, pv.y, pv.z);
-				if (dot(cross(best - origin, p - origin), tangent) > 0) best = p;
-			}
+		if (wave == 2 && lane < 20) planes[lane >> 2][lane & 3] = planes_in[(size_t)b * 20 + lane];
 	}
-	if (lane < 5)
+	else
 	{
-		v3 nn = normalize(cross(tangent, best));
-		planes[lane][0] = nn.x; planes[lane][1] = nn.y; planes[lane][2] = nn.z; planes[lane][3] = -dot(nn, origin);
+		// containing_plane (physmodel.h:183-193): a sequential scan of the cloud per direction (the running `best` decides the next comparison).  The five
+		// directions take one lane each; the points reach them through an LDS chunk the block fills with coalesced reads (a lane reading the
+		// points straight from HBM waits a memory round trip per point: 100 us for a 424-point frame).
+		const float od[5][3] = { { -1, -0.25f, 0 }, { -1, -1, 0 }, { 0, -1, 0 }, { 1, -1, 0 }, { 1, -0.25f, 0 } };    // handtrack.h:776
+		const int dl = t < 5 ? t : 0;
+		const v3 outdir = V3(od[dl][0], od[dl][1], od[dl][2]), origin = V3(0, 0, 0), viewdir = V3(0, 0, 1);
+		v3 best = viewdir - outdir;
+		best = best + origin;
+		const v3 tangent = cross(best, outdir);
+		for (int base = 0; base < n; base += 256)
+		{
+			const int m = min(256, n - base);
+			__syncthreads();
+			if (t < m) chunk[t] = pts[(size_t)b * M.pts_cap + base + t];
+			__syncthreads();
+			if (t < 5)
+				for (int i = 0; i < m; i++)
+				{
+					const float4 pv = chunk[i];
+					const v3 p = V3(pv.x, pv.y, pv.z);
+					if (dot(cross(best - origin, p - origin), tangent) > 0) best = p;
+				}
+		}
+		if (t < 5)
+		{
+			v3 nn = normalize(cross(tangent, best));
+			planes[t][0] = nn.x; planes[t][1] = nn.y; planes[t][2] = nn.z; planes[t][3] = -dot(nn, origin);
+		}
 	}
 	__syncthreads();
 	// one ConstrainUnderPlane row (physics.h:347-350) per (plane, body): the body's support vertex against the plane normal (maxdir geometric.h:218-224: the
@@ -851,7 +863,7 @@ __global__ __launch_bounds__(64) void k_chamber(ht_model_dev M, const float *__r
 	// body's ~180 vertices in global memory waited a memory round trip per vertex: 76 of the kernel's 140 us); the sixteen first-maxima merge under
 	// "larger value, then lower index", which is the sequential scan's winner.
 	const int g = lane & 15;
-	for (int item0 = 0; item0 < 5 * M.nb; item0 += 4)
+	for (int item0 = 4 * wave; item0 < 5 * M.nb; item0 += 4 * (CHB_THREADS / 64))
 	{
 		const int item = item0 + (lane >> 4);
 		const bool on = item < 5 * M.nb;
@@ -1002,9 +1014,10 @@ void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4
 #endif
 	hipLaunchKernelGGL(k_fit_error, dim3(B), dim3(256), ((size_t)M.plane_off[M.nb] + 16) * sizeof(float4), s, M, state, pts, npts, depth, cams, w, h, scale, err, after ? *after : none);
 }
-void ht_launch_chamber(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, int min_point_num, int enabled, float maxforce, float *rows, int *nch, int B, hipStream_t s)
+void ht_launch_chamber(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, int min_point_num, int enabled, float maxforce, float *rows, int *nch, int B, hipStream_t s,
+                       const float *planes, const int *planes_on)
 {
-	hipLaunchKernelGGL(k_chamber, dim3(B), dim3(64), 0, s, M, state, pts, npts, min_point_num, enabled, maxforce, rows, nch);
+	hipLaunchKernelGGL(k_chamber, dim3(B), dim3(CHB_THREADS), 0, s, M, state, pts, npts, min_point_num, enabled, maxforce, rows, nch, planes, planes ? planes_on : nullptr);
 }
 
 // order[.] = the frames by their point counts, most first (equal counts in whatever order the atomics fall: nothing depends on it): a counting sort in one block

@@ -64,7 +64,8 @@ struct ht_fit_after
 	float *hand; const float *other; const float *err_old; float *prev_err; int *initializing, *accepted; int nb, min_point_num, always_take_cnn; float accum_thr;
 };
 void ht_launch_fit_error(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, const uint16_t *depth, const float *cams, int w, int h, float scale, float *err, int B, hipStream_t s, const ht_fit_after *after = nullptr);
-void ht_launch_chamber(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, int min_point_num, int enabled, float maxforce, float *rows, int *nch, int B, hipStream_t s);
+void ht_launch_chamber(const ht_model_dev &M, const float *state, const float4 *pts, const int *npts, int min_point_num, int enabled, float maxforce, float *rows, int *nch, int B, hipStream_t s,
+                       const float *planes = nullptr, const int *planes_on = nullptr);      // planes [B][5][4] / planes_on [B] of ht_launch_chamber_planes: the scan is not made again
 void ht_launch_chamber_planes(const ht_model_dev &M, const float4 *pts, const int *npts, int min_point_num, int enabled, float *planes, int *on, int B, hipStream_t s);      // the five planes alone [B][5][4], on [B]: once per update (k_solve_prep makes their rows pass by pass)
 void ht_launch_contacts(const ht_model_dev &M, const float *state, float driftmax, float jiggle_sin, const int *active_flag, void *epa_ws, float *contacts, int *ncontacts, int B, hipStream_t s, bool beside_cloud_rows = false, int force_kernel = 0, int few_frames = 0,
                         const int *order = nullptr, int *work_out = nullptr);      // order / work_out (cooperative kernel only, both may be null): the frame of every (slot, block) as k_contact_order dealt them; where every live frame leaves what it cost

@@ -195,12 +195,12 @@ static void main_pass(ht_ctx *ctx, int B, hipStream_t s, float *poses_out = null
 	const bool par = !ctx->profile_phases && !no_side;
 	const bool pose_only = solve_tables_mode(ctx) == 2 && par;
 	const bool tables = solve_tables_on(ctx);
-	// Round 6: the five boundary planes follow from the points alone, so an update makes them once (beside the net: run_update) and every pass only their rows, inside
-	// k_solve_prep.  A pass outside an update (ht_stage_fit) makes them here.
-	if (tables && !ctx->planes_valid) { ht_prof_scope ps(ctx, "chamber", s, true); ht_launch_chamber_planes(ctx->model, pts, npts, p.min_point_num, p.boundary_planes, ctx->d_chplanes, ctx->d_chon, B, s); }
+	// Round 6: the five boundary planes follow from the points alone, so an update makes them once (beside the net: run_update) and every pass only their rows (k_chamber,
+	// or k_solve_prep with the solve tables).  A pass outside an update (ht_stage_fit) makes them here.
+	if (!ctx->planes_valid) { ht_prof_scope ps(ctx, "chamber", s, true); ht_launch_chamber_planes(ctx->model, pts, npts, p.min_point_num, p.boundary_planes, ctx->d_chplanes, ctx->d_chon, B, s); }
 	if (par) { if (tables) fork1(ctx, s, 0); else fork(ctx, s); }
 	if (pose_only) solve_prep(ctx, 0, false, false, nullptr, 0, 0.0f, 0, 0, B, ctx->side[1], 1);      // the pose-only tables ahead of the boundary planes on their side stream: both beside the cloud rows
-	if (!tables) { ht_prof_scope ps(ctx, "chamber", s, true); ht_launch_chamber(ctx->model, ctx->d_state[0], pts, npts, p.min_point_num, p.boundary_planes, 10.0f, ctx->d_chamber, ctx->d_nchamber, B, par ? ctx->side[1] : s); }
+	if (!tables) { ht_prof_scope ps(ctx, "chamber", s, true); ht_launch_chamber(ctx->model, ctx->d_state[0], pts, npts, p.min_point_num, p.boundary_planes, 10.0f, ctx->d_chamber, ctx->d_nchamber, B, par ? ctx->side[1] : s, ctx->d_chplanes, ctx->d_chon); }
 	const cloud_records cr = cloud_rec(ctx);
 	{ ht_prof_scope ps(ctx, "cloud_rows", s, true); ht_launch_cloud_rows(ctx->model, ctx->d_state[0], pts, npts, ctx->d_cams, nullptr, 1, 0, 1, p, ctx->d_rows, ctx->d_nrows, B, par ? ctx->side[0] : s, 0.0f, 0.0f, rec_or_rows(ctx, &cr)); }
 	if (tables) { ht_prof_scope ps(ctx, "solve_prep", s, true); solve_prep(ctx, 0, true, true, nullptr, 0, 0.0f, 0, 0, B, par ? ctx->side[0] : s); }
@@ -305,7 +305,7 @@ static int run_update_(ht_ctx *ctx, const uint16_t *d_depth, const float *d_cams
 	// batches of several rounds per CU: the block-per-frame kernels take the frames with the most points first, so that a launch ends on short blocks
 	if (ctx->d_porder && B > ctx->n_cu * 8 && !exact_solver(ctx)) { ht_launch_order_by_points(ctx->d_npts, ctx->d_porder, B, s); ctx->model.frame_order = ctx->d_porder; }
 	auto update_planes = [&](hipStream_t t) {      // the boundary planes of the main-thread cloud (handtrack.h:751, 774-778), once per update
-		if (!solve_tables_on(ctx) || mode == UPD_CNN_MODEL || mode == UPD_KICKSTART || p.angles_only || p.mainthreadpasses < 1) return;
+		if (mode == UPD_CNN_MODEL || mode == UPD_KICKSTART || p.angles_only || p.mainthreadpasses < 1) return;
 		ht_launch_chamber_planes(ctx->model, p.subsample_voxel ? ctx->d_ptsv : ctx->d_pts, p.subsample_voxel ? ctx->d_nptsv : ctx->d_npts, p.min_point_num, p.boundary_planes, ctx->d_chplanes, ctx->d_chon, B, t);
 		ctx->planes_valid = true;
 	};
