@@ -39,12 +39,13 @@ python3 bench.py --workload config5-e2e --steps 10 > $OUT/bench_config5_e2e.json
 python3 bench.py --workload config5-cnn128 > $OUT/bench_config5_cnn128.json 2> $OUT/bench_cnn128.err
 python3 tools/latency_dropin.py 300 > $OUT/latency_dropin.jsonl 2> $OUT/latency_dropin.err      # HandTracker::update one frame per call, ht_update_sync on 8 / 64 trackers: p50 / p99
 python3 bench.py --force-dist --steps 10 --no-cpu-baseline > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err      # the RCCL gather rehearsed on this box's one rank
-python3 -m pytest tests -m gpu -q -s > $OUT/gpu_tests.log 2>&1 || true
+[ -n "$SKIP_TESTS" ] || python3 -m pytest tests -m gpu -q -s > $OUT/gpu_tests.log 2>&1 || true      # SKIP_TESTS=1: the suite is run on its own (gpurun's limit per call)
 echo "benches done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprofv3.json 2> $OUT/trace.err
+# (the legs that put two batches or an upload beside the step are left out: their launches run into each other and would blur the per-kernel averages)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-two-in-flight --no-host-io > $OUT/bench_under_rocprofv3.json 2> $OUT/trace.err
 cp $(find $OUT/trace -name "t_kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 python3 tools/step_timeline.py $(find $OUT/trace -name "t_kernel_trace.csv" | head -1) > $OUT/step_timeline.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace8192 -o t -- python3 bench.py --frames-per-gpu 8192 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/trace8192.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace8192 -o t -- python3 bench.py --frames-per-gpu 8192 --steps 3 --warmup 1 --no-cpu-baseline --no-two-in-flight --no-host-io > /dev/null 2> $OUT/trace8192.err
 cp $(find $OUT/trace8192 -name "t_kernel_stats.csv" | head -1) $OUT/kernel_stats_frames8192.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cnn -o t -- python3 bench.py --workload cnn --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/trace_cnn.err
 cp $(find $OUT/trace_cnn -name "t_kernel_stats.csv" | head -1) $OUT/kernel_stats_cnn.csv
