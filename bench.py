@@ -543,33 +543,39 @@ def main():
     host_io = None
     if rank == 0 and wl == "cnn+solver" and args.steps > 0 and not args.no_host_io:
         h_depth = torch.from_numpy(depth.view(np.int16)).pin_memory(); h_cams = torch.from_numpy(cams).pin_memory()
+        h_depth2 = [h_depth, torch.from_numpy(depth.view(np.int16).copy()).pin_memory()]      # the zero-copy variant reads the frames where they lie: two pinned buffers, as a capture loop would fill them in turn
         h_poses = [torch.empty((B, ctx.nb, 7), dtype=torch.float32).pin_memory() for _ in range(2)]
         din = [torch.empty_like(d_depth) for _ in range(2)]; cin = [torch.empty_like(d_cams) for _ in range(2)]
         dout = [torch.empty((B, ctx.nb, 7), dtype=torch.float32, device=dev) for _ in range(2)]
         copy = torch.cuda.Stream(device=dev)
         e_in = [torch.cuda.Event() for _ in range(2)]; e_out = [torch.cuda.Event() for _ in range(2)]; e_used = [torch.cuda.Event() for _ in range(2)]
 
-        def upload(k):
+        def upload(k, zero):
             with torch.cuda.stream(copy):
                 e_used[k % 2].synchronize()      # the HOST waits until the step that read this buffer pair is through: a host that queues many steps ahead slows the device's own streams down (tools/exp_hostio2.py: 5.63 ms per step queued ahead, 5.10 paced)
-                din[k % 2].copy_(h_depth, non_blocking=True); cin[k % 2].copy_(h_cams, non_blocking=True)
+                if not zero:
+                    din[k % 2].copy_(h_depth, non_blocking=True)
+                cin[k % 2].copy_(h_cams, non_blocking=True)      # the cameras (48 B a frame, read by many kernels) are copied in either variant
                 e_in[k % 2].record(copy)
 
-        def run(n, transfers):
+        def run(n, transfers, zero=False):
+            # zero: no copy engine in the step's way -- a pinned allocation has one address for host and device, so k_prepare reads the frames over the host link itself
+            # (ht_update_dev with the pinned pointer) and the step's last kernel writes the poses straight to pinned host memory (tools/exp_hostio_zero_copy.py)
             for b in range(2):
                 e_used[b].record(stream)
             if transfers:
-                upload(0)
+                upload(0, zero)
             for k in range(n):
                 if transfers and k + 1 < n:
-                    upload(k + 1)
+                    upload(k + 1, zero)
                 elif not transfers:
                     e_used[(k + 1) % 2].synchronize()      # the same pacing without the transfers: the yardstick of this leg
                 if transfers:
                     stream.wait_event(e_in[k % 2])
-                ctx.update_dev(din[k % 2].data_ptr(), cin[k % 2].data_ptr(), d_start.data_ptr(), B, dout[k % 2].data_ptr(), stream.cuda_stream)
+                ctx.update_dev(h_depth2[k % 2].data_ptr() if zero else din[k % 2].data_ptr(), cin[k % 2].data_ptr(), d_start.data_ptr(), B,
+                               h_poses[k % 2].data_ptr() if zero else dout[k % 2].data_ptr(), stream.cuda_stream)
                 e_out[k % 2].record(stream); e_used[k % 2].record(stream)
-                if transfers:
+                if transfers and not zero:
                     with torch.cuda.stream(copy):
                         copy.wait_event(e_out[k % 2])
                         h_poses[k % 2].copy_(dout[k % 2], non_blocking=True)
@@ -586,11 +592,20 @@ def main():
             res[transfers] = time.perf_counter() - t0h
         eh = res[True]
         same = bool(torch.equal(h_poses[(args.steps - 1) % 2], d_poses.cpu()))
+        run(max(2, args.warmup), True, True)
+        t0h = time.perf_counter()
+        run(args.steps, True, True)
+        ez = time.perf_counter() - t0h
+        same_zero = bool(torch.equal(h_poses[(args.steps - 1) % 2], d_poses.cpu()))
         host_io = {"value": round(B * args.steps / eh, 2), "unit": "frames/s", "ms_per_step": round(eh / args.steps * 1e3, 4),
                    "resident_same_loop_ms_per_step": round(res[False] / args.steps * 1e3, 4), "fraction_of_resident_rate": round(res[False] / eh, 4),
                    "bytes_per_step": {"host_to_device": int(h_depth.numel() * 2 + h_cams.numel() * 4), "device_to_host": int(h_poses[0].numel() * 4)}, "poses_equal_resident_run": same,
                    "what": "pinned host depth + cameras in, poses out to pinned host memory; upload of step k + 1 and download of step k - 1 on a copy stream beside step k (double buffers, the host one step ahead); "
-                           "resident_same_loop = the same loop and pacing without the transfers"}
+                           "resident_same_loop = the same loop and pacing without the transfers",
+                   "zero_copy": {"value": round(B * args.steps / ez, 2), "unit": "frames/s", "ms_per_step": round(ez / args.steps * 1e3, 4), "fraction_of_resident_rate": round(res[False] / ez, 4),
+                                 "poses_equal_resident_run": same_zero,
+                                 "what": "the same loop without a copy engine: ht_update_dev is handed the PINNED host pointers of the depth frames and of the pose output (one address for host and device); "
+                                         "k_prepare reads the frames over the host link, the last solve writes the poses there; only the cameras are copied"}}
 
     # ---- the same step with TWO batches in flight: a second context on its own streams takes every other batch, so that one batch's kernels fill the gaps the other's
     #      leave (at 1024 frames every kernel of the step is latency-bound and the dominant ones take whole CUs: DESIGN.md section 15).  What a deployment with a queue of

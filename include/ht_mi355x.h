@@ -131,7 +131,10 @@ int ht_cnn_eval_sized_dev(ht_ctx *ctx, int side, const float *d_in, float *d_out
  * ht_update_dev       the same on device buffers, asynchronous on `stream`; d_start_poses (optional, [B][nb][7]) re-seeds every
  *                     tracker slot before the update (independent-frame batches, BASELINE config 3).  The call only enqueues (kernels, two
  *                     side streams forked off `stream` and joined back into it, one 8-byte copy to pinned host memory): it can be captured
- *                     into a HIP graph and replayed (tests/test_gpu_graph.py). */
+ *                     into a HIP graph and replayed (tests/test_gpu_graph.py).  d_depth and d_poses_out may be PINNED HOST memory (hipHostMalloc: one
+ *                     address for host and device): the input transform then reads the frames over the host link and the last solve writes the poses there --
+ *                     for frames that arrive in host memory this beats uploads on a copy stream beside the step (bench.py host_io: 0.94 against 0.80 of the
+ *                     device-resident rate at 1024 frames; tests/test_gpu_zero_copy.py).  d_cams is read by many kernels: keep it in device memory. */
 int ht_tracker_reset(ht_ctx *ctx, int first, int n, const float *poses);
 int ht_get_state(ht_ctx *ctx, int which, int first, int n, float *state);
 int ht_set_state(ht_ctx *ctx, int which, int first, int n, const float *state);
